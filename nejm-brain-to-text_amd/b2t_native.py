@@ -1,0 +1,107 @@
+"""ctypes binding of libb2t_hip.so (the C ABI declared in include/b2t.h).
+
+The library is the product's compute path: there is NO CPU/PyTorch fallback.  `load()` raises if
+the shared object is missing or lacks a declared symbol; every wrapper raises RuntimeError with
+b2t_last_error() when an entry point reports failure.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libb2t_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "b2t.h")
+
+_lib = None
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+VP = C.c_void_p
+LL = C.c_longlong
+
+
+class GemmDesc(C.Structure):
+    """Mirror of b2t_gemm_desc (include/b2t.h)."""
+    _fields_ = [
+        ("A", VP), ("B", VP), ("C", VP), ("bias", VP),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("Z", C.c_int),
+        ("a_kcontig", C.c_int), ("b_kcontig", C.c_int),
+        ("a_s0", LL), ("a_s1", LL), ("a_div", C.c_int), ("a_sz", LL),
+        ("b_s0", LL), ("b_s1", LL), ("b_div", C.c_int), ("b_sz", LL),
+        ("c_s0", LL), ("c_s1", LL), ("c_div", C.c_int), ("c_sz", LL),
+        ("b_zmap", VP), ("bias_sz", LL),
+        ("epilogue", C.c_int), ("accumulate", C.c_int),
+    ]
+
+
+_SIGNATURES = {
+    "b2t_version": (C.c_int, []),
+    "b2t_last_error": (C.c_char_p, []),
+    "b2t_augment_smooth_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         C.c_uint64, VP, VP, C.POINTER(C.c_float), C.c_int, C.c_int, VP]),
+    "b2t_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), VP]),
+    "b2t_softsign_bwd_f32": (C.c_int, [VP, VP, LL, VP]),
+    "b2t_colsum_ws_bytes": (C.c_size_t, [LL, C.c_int]),
+    "b2t_colsum_f32": (C.c_int, [VP, LL, C.c_int, LL, VP, C.c_int, VP, C.c_int, LL, LL, VP]),
+    "b2t_day_reduce_f32": (C.c_int, [VP, VP, C.c_int, LL, VP, LL, VP]),
+    "b2t_patch_fold_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "b2t_dropout_f32": (C.c_int, [VP, VP, LL, C.c_float, C.c_uint64, VP]),
+    "b2t_gru_sync_bytes": (C.c_size_t, [C.c_int]),
+    "b2t_gru_layer_fwd_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "b2t_gru_layer_bwd_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        VP, VP]),
+    "b2t_transpose_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
+    "b2t_ctc_loss_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, VP]),
+    "b2t_opt_prepare": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),
+    "b2t_grad_norm_clip_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_float, VP, VP, VP, C.c_int, VP]),
+    "b2t_adamw_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, VP, C.POINTER(C.c_float),
+                                C.POINTER(C.c_float), C.c_double, C.c_double, C.c_float, VP]),
+    "b2t_greedy_decode_f32": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "b2t_edit_distance_i32": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, VP, C.c_int, VP]),
+    "b2t_lm_prologue_f32": (C.c_int, [VP, VP, C.c_float, VP, C.c_int, C.c_int, VP]),
+}
+
+
+def header_symbols():
+    """Every function name declared in include/b2t.h."""
+    with open(HEADER_PATH) as f:
+        txt = f.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(b2t_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    """Load libb2t_hip.so; fail loudly if it (or any declared symbol) is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is the only compute path of this package "
+            f"(no CPU fallback). Build it with `python __graft_entry__.py`.")
+    lib = C.CDLL(LIB_PATH)
+    for name in header_symbols():
+        if not hasattr(lib, name):
+            raise RuntimeError(f"libb2t_hip.so does not export {name} declared in include/b2t.h")
+        if name not in _SIGNATURES:
+            raise RuntimeError(f"b2t_native has no ctypes signature for {name}")
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.b2t_version() != 1:
+        raise RuntimeError("libb2t_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().b2t_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

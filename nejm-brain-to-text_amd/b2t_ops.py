@@ -1,0 +1,424 @@
+"""Host-side operators over libb2t_hip.so: thin typed wrappers (torch tensors in, raw pointers out)
+and the forward/backward orchestration of the day-layer -> GRU stack -> head -> CTC path.
+
+PyTorch is used for device memory, streams and autograd plumbing only; every arithmetic step is a
+call into the C ABI (include/b2t.h).  There is no CPU fallback: tensors must live on the HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+import b2t_native as N
+
+ARENA_ALIGN = 1024  # floats; one optimizer chunk (csrc/optimizer.hip)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, dtype=torch.float32, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be on the HIP device (got {t.device}); this package has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def pad_to(n: int, a: int = ARENA_ALIGN) -> int:
+    return (n + a - 1) // a * a
+
+
+# ------------------------------------------------------------------------------------------------
+# smoothing kernel taps (model_training/data_augmentations.py:19-24), computed on the host
+# ------------------------------------------------------------------------------------------------
+_TAPS_CACHE: Dict[Tuple[float, int], np.ndarray] = {}
+
+
+def gauss_taps(std: float, size: int) -> np.ndarray:
+    """Impulse response of scipy's gaussian_filter1d (truncate 4 sigma) on a `size`-sample unit
+    impulse, entries > 0.01 kept and renormalised — same construction as the reference."""
+    key = (float(std), int(size))
+    if key not in _TAPS_CACHE:
+        r = int(4.0 * float(std) + 0.5)
+        x = np.arange(-r, r + 1, dtype=np.float64)
+        phi = np.exp(-0.5 / (float(std) ** 2) * x * x)
+        phi /= phi.sum()
+        resp = np.zeros(int(size), dtype=np.float32)
+        c = int(size) // 2
+        lo, hi = max(0, c - r), min(int(size), c + r + 1)
+        resp[lo:hi] = phi[(lo - (c - r)):(hi - (c - r))].astype(np.float32)
+        keep = resp[resp > 0.01]
+        _TAPS_CACHE[key] = (keep / np.sum(keep)).astype(np.float32)
+    return _TAPS_CACHE[key]
+
+
+def augment_smooth(x: torch.Tensor, std: float, size: int, padding: str = "same", cut: int = 0,
+                   white_std: float = 0.0, offset_std: float = 0.0, seed: int = 0,
+                   white_noise: Optional[torch.Tensor] = None, offset_noise: Optional[torch.Tensor] = None,
+                   smooth: bool = True) -> torch.Tensor:
+    """Fused noise + cut + Gaussian smoothing (rnn_trainer.py:436-484, data_augmentations.py:6-37)."""
+    _need(x, name="features")
+    B, T, F = x.shape
+    taps = gauss_taps(std, size) if smooth else np.ones(1, dtype=np.float32)
+    nt = int(taps.shape[0])
+    mode = {"same": 0, "valid": 1}[padding]
+    Tc = T - cut
+    T_out = Tc if mode == 0 else Tc - nt + 1
+    if T_out <= 0:
+        raise RuntimeError("sequence shorter than the smoothing kernel")
+    y = torch.empty((B, T_out, F), dtype=torch.float32, device=x.device)
+    tp = (C.c_float * nt)(*[float(v) for v in taps])
+    if white_noise is not None:
+        _need(white_noise, name="white_noise")
+    if offset_noise is not None:
+        _need(offset_noise, name="offset_noise")
+    N.check(N.load().b2t_augment_smooth_f32(_p(x), _p(y), B, T, F, int(cut), float(white_std), float(offset_std),
+                                            C.c_uint64(seed & (2 ** 64 - 1)), _p(white_noise), _p(offset_noise),
+                                            tp, nt, mode, _stream()), "b2t_augment_smooth_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM wrapper
+# ------------------------------------------------------------------------------------------------
+def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,
+         b_sz=0, c_s0=0, c_s1=0, c_div=0, c_sz=0, bias=None, bias_sz=0, b_zmap=None, epilogue=0, accumulate=0,
+         a_off=0, b_off=0, c_off=0):
+    d = N.GemmDesc()
+    d.A = A.data_ptr() + 4 * a_off
+    d.B = B.data_ptr() + 4 * b_off
+    d.C = Cm.data_ptr() + 4 * c_off
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.M, d.N, d.K, d.Z = M, N_, K, Z
+    d.a_kcontig, d.b_kcontig = a_kc, b_kc
+    d.a_s0, d.a_s1, d.a_div, d.a_sz = a_s0, a_s1, a_div, a_sz
+    d.b_s0, d.b_s1, d.b_div, d.b_sz = b_s0, b_s1, b_div, b_sz
+    d.c_s0, d.c_s1, d.c_div, d.c_sz = c_s0, c_s1, c_div, c_sz
+    d.b_zmap = b_zmap.data_ptr() if b_zmap is not None else None
+    d.bias_sz = bias_sz
+    d.epilogue, d.accumulate = epilogue, accumulate
+    N.check(N.load().b2t_gemm_f32(C.byref(d), _stream()), "b2t_gemm_f32")
+
+
+def colsum(x, rows, cols, ld, out, accumulate=0, Z=1, x_sz=0, out_sz=0, x_off=0, out_off=0):
+    lib = N.load()
+    nbytes = lib.b2t_colsum_ws_bytes(rows, cols) * Z
+    ws = torch.empty((nbytes // 4 + 1,), dtype=torch.float32, device=x.device)
+    N.check(lib.b2t_colsum_f32(C.c_void_p(x.data_ptr() + 4 * x_off), rows, cols, ld,
+                               C.c_void_p(out.data_ptr() + 4 * out_off), accumulate, _p(ws), Z, x_sz, out_sz,
+                               _stream()), "b2t_colsum_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter layout
+# ------------------------------------------------------------------------------------------------
+class ModelDims:
+    def __init__(self, neural_dim, n_units, n_days, n_classes, n_layers, patch_size, patch_stride):
+        self.F, self.H, self.D, self.C, self.L = neural_dim, n_units, n_days, n_classes, n_layers
+        self.patch, self.stride = patch_size, patch_stride
+        self.In0 = neural_dim * patch_size if patch_size > 0 else neural_dim
+        if self.H % 16 != 0:
+            raise RuntimeError(f"n_units={self.H} must be a multiple of 16 for the MFMA recurrent tiles")
+        if self.F % 4 != 0:
+            raise RuntimeError(f"neural_dim={self.F} must be a multiple of 4")
+
+    def out_T(self, T):
+        return (T - self.patch) // self.stride + 1 if self.patch > 0 else T
+
+
+class Params:
+    """Views of the model's parameter arena needed by the kernels."""
+    def __init__(self, day_w, day_b, day_w_stride, day_b_stride, w_ih, w_hh, b_ih, b_hh, out_w, out_b, h0):
+        self.day_w, self.day_b = day_w, day_b                  # arena views starting at day 0
+        self.day_w_stride, self.day_b_stride = day_w_stride, day_b_stride
+        self.w_ih, self.w_hh, self.b_ih, self.b_hh = w_ih, w_hh, b_ih, b_hh
+        self.out_w, self.out_b, self.h0 = out_w, out_b, h0
+
+
+GRU_MODE = {"value": 0}  # 0 = step-launch sweep, 1 = persistent sweep (csrc/gru_persistent.hip)
+
+
+class Workspace:
+    """Shape-keyed scratch buffers (allocated once per (B,T) from torch's caching allocator)."""
+    def __init__(self):
+        self.bufs: Dict[Tuple, torch.Tensor] = {}
+
+    def get(self, name, shape, device, dtype=torch.float32):
+        key = (name, tuple(shape), str(device), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.bufs[key] = t
+        return t
+
+
+class ForwardCtx:
+    pass
+
+
+def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.Tensor,
+                  states: Optional[torch.Tensor], ws: Workspace, save: bool,
+                  in_drop: float = 0.0, rnn_drop: float = 0.0, seed: int = 0, reuse_saved: bool = False):
+    """day layer -> (patch) -> L x GRU -> head.  x [B,T,F] fp32 on device, day_idx int32 [B].
+    Returns logits [B,T',C], hidden [L,B,H] and (if save) the context for model_backward.
+    Mirrors GRUDecoder.forward (model_training/rnn_model.py:88-134)."""
+    lib = N.load()
+    _need(x, name="x")
+    _need(day_idx, torch.int32, "day_idx")
+    B, T, F = x.shape
+    H, L, Cc = dims.H, dims.L, dims.C
+    if F != dims.F:
+        raise RuntimeError(f"input feature dim {F} != neural_dim {dims.F}")
+    Tp = dims.out_T(T)
+    if Tp <= 0:
+        raise RuntimeError("sequence shorter than patch_size")
+    dev = x.device
+    st = _stream()
+
+    def sbuf(name, shape):
+        # saved-for-backward buffers: workspace-owned only when the caller guarantees one
+        # forward/backward in flight (the trainer's fused step); fresh allocations otherwise.
+        if save and reuse_saved:
+            return ws.get(name, shape, dev)
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+
+    # 1. day layer: U[b] = softsign(x[b] @ W[day[b]] + c[day[b]])   (rnn_model.py:95-99)
+    U = sbuf("U", (B, T, F))
+    gemm(x, prm.day_w, U, M=T, N_=F, K=F, Z=B, a_kc=1, a_s0=F, a_sz=T * F, b_kc=0, b_s0=F, b_sz=prm.day_w_stride,
+         c_s0=F, c_sz=T * F, bias=prm.day_b, bias_sz=prm.day_b_stride, b_zmap=day_idx, epilogue=1)
+    Ud = U
+    if in_drop > 0:
+        Ud = sbuf("Ud", (B, T, F))
+        N.check(lib.b2t_dropout_f32(_p(U), _p(Ud), U.numel(), float(in_drop), C.c_uint64(seed * 1000003 + 17), st),
+                "b2t_dropout_f32")
+
+    gi = ws.get("gi", (Tp, B, 3 * H), dev)
+    outs: List[torch.Tensor] = []
+    outs_d: List[torch.Tensor] = []
+    reserves: List[Optional[torch.Tensor]] = []
+    hidden = torch.empty((L, B, H), dtype=torch.float32, device=dev)
+    sync_ws = None
+    if GRU_MODE["value"] == 1:
+        sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32)
+    for l in range(L):
+        # 2. input projection gi = in_t W_ih^T + b_ih, time-major [T'][B][3H]
+        if l == 0:
+            a_s0 = dims.stride * F if dims.patch > 0 else F
+            gemm(Ud, prm.w_ih[0], gi, M=Tp, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0, a_sz=T * F,
+                 b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H, bias=prm.b_ih[0])
+        else:
+            gemm(outs_d[l - 1][1:], prm.w_ih[l], gi, M=Tp * B, N_=3 * H, K=H, a_kc=1, a_s0=H, b_kc=1, b_s0=H,
+                 c_s0=3 * H, bias=prm.b_ih[l])
+        # 3. recurrent sweep.  outbuf[0] = initial state so that outbuf[0:T'] is the h_{t-1} matrix.
+        outbuf = sbuf(f"out{l}", (Tp + 1, B, H))
+        if states is None:
+            outbuf[0].copy_(prm.h0.view(1, H).expand(B, H))
+        else:
+            outbuf[0].copy_(states[l])
+        res = sbuf(f"res{l}", (Tp, B, 4 * H)) if save else None
+        N.check(lib.b2t_gru_layer_fwd_f32(_p(gi), _p(prm.w_hh[l]), _p(prm.b_hh[l]), _p(outbuf[0]), _p(outbuf[1:]),
+                                          _p(res), _p(hidden[l]), Tp, B, H, GRU_MODE["value"], _p(sync_ws), st),
+                "b2t_gru_layer_fwd_f32")
+        outs.append(outbuf)
+        reserves.append(res)
+        od = outbuf
+        if rnn_drop > 0 and l < L - 1:   # nn.GRU inter-layer dropout (rnn_model.py:70)
+            od = sbuf(f"outd{l}", (Tp + 1, B, H))
+            N.check(lib.b2t_dropout_f32(_p(outbuf[1:]), _p(od[1:]), Tp * B * H, float(rnn_drop),
+                                        C.c_uint64(seed * 1000003 + 101 + l), st), "b2t_dropout_f32")
+        outs_d.append(od)
+
+    # 4. head: logits[b,t,:] = out W^T + b  (rnn_model.py:129), written batch-first
+    logits = torch.empty((B, Tp, Cc), dtype=torch.float32, device=dev)
+    gemm(outs[L - 1][1:], prm.out_w, logits, M=Tp * B, N_=Cc, K=H, a_kc=1, a_s0=H, b_kc=1, b_s0=H,
+         c_div=B, c_s1=Cc, c_s0=Tp * Cc, bias=prm.out_b)
+    if not save:
+        return logits, hidden, None
+    ctx = ForwardCtx()
+    ctx.x, ctx.day_idx, ctx.U, ctx.Ud = x, day_idx, U, Ud
+    ctx.outs, ctx.outs_d, ctx.reserves = outs, outs_d, reserves
+    ctx.B, ctx.T, ctx.Tp = B, T, Tp
+    ctx.in_drop, ctx.rnn_drop, ctx.seed = in_drop, rnn_drop, seed
+    ctx.custom_states = states is not None
+    return logits, hidden, ctx
+
+
+class Grads:
+    """Destination views for parameter gradients (normally views of the model's gradient arena)."""
+    def __init__(self, day_w, day_b, day_w_stride, day_b_stride, w_ih, w_hh, b_ih, b_hh, out_w, out_b, h0):
+        self.day_w, self.day_b = day_w, day_b
+        self.day_w_stride, self.day_b_stride = day_w_stride, day_b_stride
+        self.w_ih, self.w_hh, self.b_ih, self.b_hh = w_ih, w_hh, b_ih, b_hh
+        self.out_w, self.out_b, self.h0 = out_w, out_b, h0
+
+
+def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dlogits: torch.Tensor, ldd: int,
+                   ws: Workspace, dhidden: Optional[torch.Tensor] = None, want_dstates: bool = False,
+                   bucket_cb=None):
+    """Gradients of every parameter given dlogits [B,T',ldd] (ldd multiple of 4, >= C).
+    Overwrites the destinations in `grd` (days absent from the batch are not touched).
+    Follows SURVEY Appendix A2/A3; replaces loss.backward() at rnn_trainer.py:547."""
+    lib = N.load()
+    B, T, Tp = ctx.B, ctx.T, ctx.Tp
+    F, H, L, Cc = dims.F, dims.H, dims.L, dims.C
+    dev = dlogits.device
+    st = _stream()
+    M = Tp * B
+    top = ctx.outs[L - 1]
+
+    # head: d_out[t,b,:] = dlogits[b,t,:] W_out ; dW_out = dlogits^T out ; db_out = colsum
+    dY = ws.get("dY0", (Tp, B, H), dev)
+    gemm(dlogits, prm.out_w, dY, M=M, N_=H, K=Cc, a_kc=1, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H, c_s0=H)
+    gemm(dlogits, top[1:], grd.out_w, M=Cc, N_=H, K=M, a_kc=0, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H,
+         c_s0=H)
+    colsum(dlogits, B * Tp, Cc, ldd, grd.out_b)
+    if bucket_cb:
+        bucket_cb("head")
+
+    dG = ws.get("dG", (Tp, B, 4 * H), dev)
+    dh_init = ws.get("dh_init", (L, B, H), dev)
+    carry = ws.get("carry", (B, H), dev)
+    whh_t = ws.get("whh_t", (H, 3 * H), dev)
+    s4 = ws.get("s4", (4 * H,), dev)
+    dYn = ws.get("dY1", (Tp, B, H), dev)
+    sync_ws = None
+    if GRU_MODE["value"] == 1:
+        sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32)
+    for l in reversed(range(L)):
+        if ctx.rnn_drop > 0 and l < L - 1:   # gradient through the inter-layer dropout mask
+            N.check(lib.b2t_dropout_f32(_p(dY), _p(dY), Tp * B * H, float(ctx.rnn_drop),
+                                        C.c_uint64(ctx.seed * 1000003 + 101 + l), st), "b2t_dropout_f32")
+        N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_t), 3 * H, H, st), "b2t_transpose_f32")
+        outbuf = ctx.outs[l]
+        dhl = dhidden[l].contiguous() if dhidden is not None else None
+        N.check(lib.b2t_gru_layer_bwd_f32(_p(dY), _p(dhl), _p(ctx.reserves[l]), _p(outbuf[1:]), _p(outbuf[0]),
+                                          _p(whh_t), _p(dG), _p(dh_init[l]), _p(carry), Tp, B, H, GRU_MODE["value"],
+                                          _p(sync_ws), st), "b2t_gru_layer_bwd_f32")
+        # dW_hh = dGh^T h_prev   (dGh = dG cols [0,3H); h_prev rows = outbuf[0:T'])
+        gemm(dG, outbuf, grd.w_hh[l], M=3 * H, N_=H, K=M, a_kc=0, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H)
+        # dW_ih = dGi^T in      (dGi = dG cols [0,2H) + [3H,4H))
+        if l == 0:
+            In = dims.In0
+            bs1 = dims.stride * F if dims.patch > 0 else F
+            kw = dict(b_kc=0, b_div=B, b_s1=bs1, b_s0=T * F)
+            inp = ctx.Ud
+            in_off = 0
+        else:
+            In = H
+            kw = dict(b_kc=0, b_s0=H)
+            inp = ctx.outs_d[l - 1]
+            in_off = B * H  # skip the initial-state slot
+        gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=M, a_kc=0, a_s0=4 * H, c_s0=In, b_off=in_off, **kw)
+        gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=M, a_kc=0, a_s0=4 * H, a_off=3 * H, c_s0=In, c_off=2 * H * In,
+             b_off=in_off, **kw)
+        # biases: column sums of dG -> (s_r, s_z, s_nr, s_n)
+        colsum(dG, M, 4 * H, 4 * H, s4)
+        grd.b_ih[l][:2 * H].copy_(s4[:2 * H]); grd.b_ih[l][2 * H:].copy_(s4[3 * H:])
+        grd.b_hh[l].copy_(s4[:3 * H])
+        if bucket_cb:
+            bucket_cb(f"layer{l}")
+        # gradient wrt this layer's input: dIn = dGi W_ih
+        if l > 0:
+            gemm(dG, prm.w_ih[l], dYn, M=M, N_=H, K=2 * H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H)
+            gemm(dG, prm.w_ih[l], dYn, M=M, N_=H, K=H, a_kc=1, a_s0=4 * H, a_off=3 * H, b_kc=0, b_s0=H,
+                 b_off=2 * H * H, c_s0=H, accumulate=1)
+            dY, dYn = dYn, dY
+    # h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
+    if not ctx.custom_states:
+        colsum(dh_init, L * B, H, H, grd.h0)
+    else:
+        grd.h0.zero_()
+    if bucket_cb:
+        bucket_cb("h0")
+
+    # layer-0 input gradient -> dU [B][T][F]
+    dU = ws.get("dU", (B, T, F), dev)
+    if dims.patch > 0:
+        In = dims.In0
+        dV = ws.get("dV", (B, Tp, In), dev)
+        gemm(dG, prm.w_ih[0], dV, M=M, N_=In, K=2 * H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=In, c_div=B, c_s1=In,
+             c_s0=Tp * In)
+        gemm(dG, prm.w_ih[0], dV, M=M, N_=In, K=H, a_kc=1, a_s0=4 * H, a_off=3 * H, b_kc=0, b_s0=In,
+             b_off=2 * H * In, c_div=B, c_s1=In, c_s0=Tp * In, accumulate=1)
+        N.check(lib.b2t_patch_fold_f32(_p(dV), _p(dU), B, T, F, Tp, dims.patch, dims.stride, st), "b2t_patch_fold_f32")
+    else:
+        gemm(dG, prm.w_ih[0], dU, M=M, N_=F, K=2 * H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=F, c_div=B, c_s1=F, c_s0=T * F)
+        gemm(dG, prm.w_ih[0], dU, M=M, N_=F, K=H, a_kc=1, a_s0=4 * H, a_off=3 * H, b_kc=0, b_s0=F, b_off=2 * H * F,
+             c_div=B, c_s1=F, c_s0=T * F, accumulate=1)
+    if ctx.in_drop > 0:
+        N.check(lib.b2t_dropout_f32(_p(dU), _p(dU), dU.numel(), float(ctx.in_drop),
+                                    C.c_uint64(ctx.seed * 1000003 + 17), st), "b2t_dropout_f32")
+    # softsign backward in place: dpre = dU * (1-|U|)^2
+    N.check(lib.b2t_softsign_bwd_f32(_p(ctx.U), _p(dU), dU.numel(), st), "b2t_softsign_bwd_f32")
+    # per-sample partial day gradients, then deterministic reduction by day
+    slab = ws.get("day_slab", (B, F, F), dev)
+    gemm(ctx.x, dU, slab, M=F, N_=F, K=T, Z=B, a_kc=0, a_s0=F, a_sz=T * F, b_kc=0, b_s0=F, b_sz=T * F, c_s0=F,
+         c_sz=F * F)
+    N.check(lib.b2t_day_reduce_f32(_p(slab), _p(ctx.day_idx), B, F * F, _p(grd.day_w), grd.day_w_stride, st),
+            "b2t_day_reduce_f32")
+    bslab = ws.get("day_bslab", (B, pad_to(F, 4)), dev)
+    colsum(dU, T, F, F, bslab, Z=B, x_sz=T * F, out_sz=bslab.shape[1])
+    N.check(lib.b2t_day_reduce_f32(_p(bslab), _p(ctx.day_idx), B, bslab.shape[1], _p(grd.day_b), grd.day_b_stride, st),
+            "b2t_day_reduce_f32")
+    if bucket_cb:
+        bucket_cb("day")
+    return dh_init if want_dstates else None
+
+
+def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, in_len: torch.Tensor, tgt_len: torch.Tensor,
+             want_grad: bool, grad_scale: float, ws: Workspace):
+    """loss [B] and (optionally) dlogits [B,T,ldd] — fused log-softmax + CTC (rnn_trainer.py:538-545)."""
+    _need(logits, name="logits")
+    B, T, Cc = logits.shape
+    dev = logits.device
+    targets = _need(targets.to(device=dev, dtype=torch.int32).contiguous(), torch.int32, "targets")
+    in_len = in_len.to(device=dev, dtype=torch.int32).contiguous()
+    tgt_len = tgt_len.to(device=dev, dtype=torch.int32).contiguous()
+    S_max = max(1, targets.shape[1])
+    if targets.shape[1] == 0:
+        targets = torch.zeros((B, 1), dtype=torch.int32, device=dev)
+    ldd = pad_to(Cc, 4)
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    alpha = ws.get("ctc_alpha", (B, T, 2 * S_max + 1), dev)
+    dl = ws.get("ctc_dlogits", (B, T, ldd), dev) if want_grad else None
+    N.check(N.load().b2t_ctc_loss_f32(_p(logits), _p(targets), _p(in_len), _p(tgt_len), _p(loss), _p(alpha), _p(dl),
+                                      B, T, Cc, S_max, ldd, float(grad_scale), _stream()), "b2t_ctc_loss_f32")
+    return loss, dl, ldd
+
+
+def greedy_decode(logits: torch.Tensor, lens: torch.Tensor):
+    """argmax -> collapse repeats -> drop blank (rnn_trainer.py:725-728). Returns ids [B,T], lengths [B], argmax [B,T]."""
+    _need(logits, name="logits")
+    B, T, Cc = logits.shape
+    dev = logits.device
+    lens = lens.to(device=dev, dtype=torch.int32).contiguous()
+    ids = torch.zeros((B, T), dtype=torch.int32, device=dev)
+    ln = torch.empty((B,), dtype=torch.int32, device=dev)
+    am = torch.empty((B, T), dtype=torch.int32, device=dev)
+    N.check(N.load().b2t_greedy_decode_f32(_p(logits), _p(lens), _p(ids), _p(ln), _p(am), B, T, Cc, _stream()),
+            "b2t_greedy_decode_f32")
+    return ids, ln, am
+
+
+def edit_distance(a: torch.Tensor, a_len: torch.Tensor, b: torch.Tensor, b_len: torch.Tensor) -> torch.Tensor:
+    """Levenshtein distance per row (torchaudio.functional.edit_distance at rnn_trainer.py:734)."""
+    dev = a.device
+    a = a.to(torch.int32).contiguous(); b = b.to(device=dev, dtype=torch.int32).contiguous()
+    a_len = a_len.to(device=dev, dtype=torch.int32).contiguous(); b_len = b_len.to(device=dev, dtype=torch.int32).contiguous()
+    Bn = a.shape[0]
+    out = torch.empty((Bn,), dtype=torch.int32, device=dev)
+    N.check(N.load().b2t_edit_distance_i32(_p(a), _p(a_len), a.shape[1], _p(b), _p(b_len), b.shape[1], _p(out), Bn,
+                                           _stream()), "b2t_edit_distance_i32")
+    return out

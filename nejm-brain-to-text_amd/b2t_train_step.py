@@ -1,0 +1,267 @@
+"""TrainStep — the fused GRU+CTC training step on the HIP path, and the data-parallel gradient reducer.
+
+One step = the body of the reference's loop, model_training/rnn_trainer.py:527-558:
+    logits = model(features, day_idx); loss = mean(CTC(log_softmax(logits)));
+    loss.backward(); clip_grad_norm_(10); AdamW(3 groups).step(); LambdaLR.step()
+executed without autograd: forward and backward are explicit kernel sequences (b2t_ops), parameter
+gradients land in the model's flat gradient arena, and clipping + AdamW are two launches over it.
+No host synchronisation happens inside a step.
+
+Data parallel (new functionality — the reference is single-GPU): one process per GPU,
+minibatch sharded across ranks, gradient arena all-reduced (sum) in buckets that follow backward order
+(head, GRU layer L-1 ... 0, h0, day layers) on the process group's communication stream (RCCL over xGMI
+for backend "nccl"), each bucket launched as soon as its kernels are enqueued so that it overlaps the
+lower layers' backward sweeps.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+import b2t_native as N
+import b2t_ops as ops
+
+
+def cosine_lr_factor(step: int, min_lr_ratio: float, decay_steps: int, warmup_steps: int) -> float:
+    """LambdaLR factor of the reference schedule (rnn_trainer.py:306-326): linear warm-up, cosine decay
+    to min_lr_ratio, constant afterwards.  Batch i uses factor(i) (LambdaLR(..., -1))."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    if step < decay_steps:
+        progress = float(step - warmup_steps) / float(max(1, decay_steps - warmup_steps))
+        cosine = 0.5 * (1.0 + math.cos(math.pi * progress))
+        return max(min_lr_ratio, min_lr_ratio + (1.0 - min_lr_ratio) * cosine)
+    return min_lr_ratio
+
+
+def param_group_of(name: str) -> int:
+    """0 = bias (no decay), 1 = day layers, 2 = everything else (rnn_trainer.py:267-269)."""
+    if "gru.bias" in name or "out.bias" in name:
+        return 0
+    if "day_" in name:
+        return 1
+    return 2
+
+
+def bucket_spans(layout, n_layers: int) -> List[Tuple[str, int, int]]:
+    """Contiguous arena ranges (name, start, end) in backward-completion order."""
+    names, spans = layout["names"], layout["spans"]
+
+    def rng(first, last):
+        a = spans[names.index(first)][0]
+        o, n = spans[names.index(last)]
+        return a, o + ops.pad_to(n)
+
+    out = [("head", *rng("out.weight", "out.bias"))]
+    for l in reversed(range(n_layers)):
+        out.append((f"layer{l}", *rng(f"gru.weight_ih_l{l}", f"gru.bias_hh_l{l}")))
+    out.append(("h0", *rng("h0", "h0")))
+    n_days = len([n for n in names if n.startswith("day_weights.")])
+    out.append(("day", *rng("day_weights.0", f"day_biases.{n_days - 1}")))
+    return out
+
+
+class GradReducer:
+    """Bucketed data-parallel gradient all-reduce over a flat arena (torch.distributed: RCCL on GPU,
+    gloo in the CPU tests).  `launch(name)` starts the asynchronous all-reduce of one bucket;
+    `finish()` waits for all of them.  Works on any device torch.distributed supports."""
+
+    def __init__(self, grad_arena: torch.Tensor, buckets: List[Tuple[str, int, int]], group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.arena = grad_arena
+        self.buckets = {n: (a, b) for n, a, b in buckets}
+        self.pending = []
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def launch(self, name: str):
+        if self.world == 1:
+            return
+        a, b = self.buckets[name]
+        self.pending.append(self.dist.all_reduce(self.arena[a:b], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def union_active(self, active: torch.Tensor):
+        """active[seg] = max over ranks (a day tensor is updated if ANY rank saw that day)."""
+        if self.world > 1:
+            self.dist.all_reduce(active, op=self.dist.ReduceOp.MAX, group=self.group)
+        return active
+
+
+class TrainStep:
+    def __init__(self, model, args: Dict, group=None, global_batch_scale: Optional[int] = None):
+        """model: rnn_model.GRUDecoder on the HIP device.  args: the flat keys of rnn_args.yaml used by
+        the optimizer/scheduler (lr_max, lr_min, lr_decay_steps, lr_warmup_steps, *_day, beta0, beta1, epsilon,
+        weight_decay, weight_decay_day, grad_norm_clip_value)."""
+        self.model = model
+        self.args = args
+        self.it = 0
+        arena = model.arena()
+        if not arena.is_cuda:
+            raise RuntimeError("TrainStep needs the model on the HIP device (model.to('cuda'))")
+        dev = arena.device
+        lay = model.layout()
+        self.dev = dev
+        self.grads = model.arena_grads()
+        self.grad_arena = model.grad_arena()
+        self.exp_avg = torch.zeros_like(arena)
+        self.exp_avg_sq = torch.zeros_like(arena)
+        nchunks = lay["total"] // ops.ARENA_ALIGN
+        chunk2seg = np.zeros(nchunks, dtype=np.int32)
+        seg_group = np.zeros(len(lay["names"]), dtype=np.int32)
+        seg_day = np.full(len(lay["names"]), -1, dtype=np.int32)
+        for s, (name, (o, n)) in enumerate(zip(lay["names"], lay["spans"])):
+            chunk2seg[o // ops.ARENA_ALIGN:(o + ops.pad_to(n)) // ops.ARENA_ALIGN] = s
+            seg_group[s] = param_group_of(name)
+            if name.startswith("day_"):
+                seg_day[s] = int(name.split(".")[1])
+        self.nseg, self.nchunks = len(lay["names"]), nchunks
+        self.chunk2seg = torch.from_numpy(chunk2seg).to(dev)
+        self.seg_group = torch.from_numpy(seg_group).to(dev)
+        self.seg_day = torch.from_numpy(seg_day).to(dev)
+        self.seg_step = torch.zeros(self.nseg, dtype=torch.int32, device=dev)
+        self.active = torch.ones(self.nseg, dtype=torch.int32, device=dev)
+        self.partial = torch.empty(nchunks, dtype=torch.float32, device=dev)
+        self.out3 = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.requires = [True] * self.nseg
+        self.keep_unclipped = True if args.get("_debug_keep_unclipped", False) else False
+        self._unclipped = None
+        import torch.distributed as dist
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reducer = GradReducer(self.grad_arena, bucket_spans(lay, model.n_layers), group) if self.world > 1 else None
+        self.day_range = None
+        if self.world > 1:
+            b = dict((n, (a, e)) for n, a, e in bucket_spans(lay, model.n_layers))
+            self.day_range = b["day"]
+
+    # -- learning rates of the three groups for the current batch (rnn_trainer.py:294-363) ------------
+    def current_lrs(self):
+        a = self.args
+        f_main = cosine_lr_factor(self.it, a["lr_min"] / a["lr_max"], a["lr_decay_steps"], a["lr_warmup_steps"])
+        f_day = cosine_lr_factor(self.it, a["lr_min_day"] / a["lr_max_day"], a["lr_decay_steps_day"],
+                                 a["lr_warmup_steps_day"])
+        return [a["lr_max"] * f_main, a["lr_max_day"] * f_day, a["lr_max"] * f_main]
+
+    def adjusted_lens(self, n_time_steps: torch.Tensor) -> torch.Tensor:
+        """rnn_trainer.py:532 — with the patch_size==0 case handled (the reference divides by
+        patch_stride=0 there)."""
+        ps, st = self.model.patch_size, self.model.patch_stride
+        n = n_time_steps.to(torch.int64)
+        if ps > 0:
+            return ((n - ps).to(torch.float32) / st + 1).to(torch.int32)
+        return n.to(torch.int32)
+
+    def step(self, feats: torch.Tensor, day_idx: torch.Tensor, targets: torch.Tensor, n_time_steps: torch.Tensor,
+             phone_seq_lens: torch.Tensor):
+        """feats [B,T,F] (already augmented + smoothed), day_idx [B], targets [B,S], lengths [B].
+        Returns (mean CTC loss, pre-clip gradient norm) as 0-d device tensors (no sync)."""
+        lib = N.load()
+        model = self.model
+        dev = self.dev
+        st = ops._stream()
+        B = feats.shape[0]
+        day_dev = day_idx.to(device=dev, dtype=torch.int32).contiguous()
+        adj = self.adjusted_lens(n_time_steps.to(dev))
+        logits, hidden, ctx = ops.model_forward(model._dims, model._kernel_params(), feats, day_dev, None, model._ws,
+                                                save=True, in_drop=model._p_in(), rnn_drop=model._p_rnn(),
+                                                seed=model._next_seed(), reuse_saved=True)
+        # torch.mean over the (global) batch: rnn_trainer.py:545
+        loss_b, dl, ldd = ops.ctc_loss(logits, targets, adj, phone_seq_lens, True, 1.0 / (B * self.world), model._ws)
+        N.check(lib.b2t_opt_prepare(ops._p(day_dev), B, ops._p(self.seg_day), self.nseg, ops._p(self.active), st),
+                "b2t_opt_prepare")
+        red = self.reducer
+        if red is not None:
+            # ranks see different days: zero the day-gradient region so absent days contribute 0 to the sum
+            a, e = self.day_range
+            self.grad_arena[a:e].zero_()
+            red.union_active(self.active)
+        ops.model_backward(model._dims, model._kernel_params(), self.grads, ctx, dl, ldd, model._ws,
+                           bucket_cb=(red.launch if red is not None else None))
+        if red is not None:
+            red.finish()
+        if self.keep_unclipped:
+            self._unclipped = self.grad_arena.clone()
+        clip = float(self.args.get("grad_norm_clip_value", 0) or 0)
+        N.check(lib.b2t_grad_norm_clip_f32(ops._p(self.grad_arena), ops._p(self.chunk2seg), ops._p(self.active),
+                                           self.nchunks, clip, ops._p(self.partial), ops._p(self.out3),
+                                           ops._p(self.seg_step), self.nseg, st), "b2t_grad_norm_clip_f32")
+        lrs = self.current_lrs()
+        a = self.args
+        lr3 = (C.c_float * 3)(*lrs)
+        wd3 = (C.c_float * 3)(0.0, float(a.get("weight_decay_day", 0)), float(a["weight_decay"]))
+        N.check(lib.b2t_adamw_f32(ops._p(model.arena()), ops._p(self.grad_arena), ops._p(self.exp_avg),
+                                  ops._p(self.exp_avg_sq), ops._p(self.chunk2seg), ops._p(self.active),
+                                  ops._p(self.seg_group), ops._p(self.seg_step), self.nchunks,
+                                  ops._p(self.out3) if clip > 0 else None, lr3, wd3, float(a["beta0"]),
+                                  float(a["beta1"]), float(a["epsilon"]), st), "b2t_adamw_f32")
+        self.it += 1
+        loss = loss_b.mean()
+        if self.world > 1:
+            loss = loss  # per-rank mean of its shard; callers all-reduce for logging if they want the global mean
+        self.last_logits, self.last_adjusted = logits, adj
+        return loss, self.out3[1]
+
+    # -- helpers for tests / checkpoints ---------------------------------------------------------------
+    def last_unclipped_grads(self) -> Dict[str, np.ndarray]:
+        if self._unclipped is None:
+            raise RuntimeError("construct TrainStep with args['_debug_keep_unclipped']=True")
+        lay = self.model.layout()
+        host = self._unclipped.cpu().numpy()
+        act = self.active.cpu().numpy()
+        out = {}
+        for s, (name, (o, n)) in enumerate(zip(lay["names"], lay["spans"])):
+            if act[s]:
+                p = dict(self.model._param_order())[name]
+                out[name] = host[o:o + n].reshape(tuple(p.shape))
+        return out
+
+    def optimizer_state_dict(self):
+        """torch.optim.AdamW-format state (rnn_trainer.py:392-398 checkpoint key 'optimizer_state_dict'):
+        parameter indices run over the groups bias, day, other in named_parameters order."""
+        lay = self.model.layout()
+        named = [n for n, _ in self.model.named_parameters()]
+        order = [n for g in (0, 1, 2) for n in named if param_group_of(n) == g]
+        steps = self.seg_step.cpu().numpy()
+        ea, es = self.exp_avg.cpu(), self.exp_avg_sq.cpu()
+        state = {}
+        shapes = {n: tuple(p.shape) for n, p in self.model.named_parameters()}
+        for i, n in enumerate(order):
+            s = lay["names"].index(n)
+            o, cnt = lay["spans"][s]
+            if steps[s] > 0:
+                state[i] = dict(step=torch.tensor(float(steps[s])), exp_avg=ea[o:o + cnt].view(shapes[n]).clone(),
+                                exp_avg_sq=es[o:o + cnt].view(shapes[n]).clone())
+        a = self.args
+        lrs = self.current_lrs()
+        groups, k = [], 0
+        for g, (gt, lr0, wd) in enumerate((("bias", a["lr_max"], 0), ("day_layer", a["lr_max_day"], a.get("weight_decay_day", 0)),
+                                           ("other", a["lr_max"], a["weight_decay"]))):
+            cnt = sum(1 for n in order if param_group_of(n) == g)
+            groups.append(dict(lr=lrs[g], initial_lr=lr0, betas=(a["beta0"], a["beta1"]), eps=a["epsilon"],
+                               weight_decay=wd, group_type=gt, params=list(range(k, k + cnt))))
+            k += cnt
+        return dict(state=state, param_groups=groups)
+
+    def load_optimizer_state_dict(self, sd):
+        lay = self.model.layout()
+        named = [n for n, _ in self.model.named_parameters()]
+        order = [n for g in (0, 1, 2) for n in named if param_group_of(n) == g]
+        steps = np.zeros(self.nseg, dtype=np.int32)
+        for i, stt in sd.get("state", {}).items():
+            n = order[int(i)]
+            s = lay["names"].index(n)
+            o, cnt = lay["spans"][s]
+            steps[s] = int(float(stt["step"]))
+            self.exp_avg[o:o + cnt].copy_(stt["exp_avg"].reshape(-1).to(self.dev))
+            self.exp_avg_sq[o:o + cnt].copy_(stt["exp_avg_sq"].reshape(-1).to(self.dev))
+        self.seg_step.copy_(torch.from_numpy(steps).to(self.dev))

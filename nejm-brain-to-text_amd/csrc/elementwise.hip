@@ -1,0 +1,281 @@
+// elementwise.hip — HBM-bound passes of the hot path: fused augmentation + Gaussian smoothing,
+// softsign backward, column sums, patch fold, dropout, transpose, per-day gradient reduction.
+// All kernels read/write 16 B per lane along the contiguous (feature) axis.
+#include "common.h"
+
+namespace b2t {
+
+struct Taps { float v[33]; };
+
+__device__ __forceinline__ float4 f4_fma(float s, float4 a, float4 acc) {
+  acc.x = fmaf(s, a.x, acc.x); acc.y = fmaf(s, a.y, acc.y);
+  acc.z = fmaf(s, a.z, acc.z); acc.w = fmaf(s, a.w, acc.w);
+  return acc;
+}
+
+// Noisy input sample at position `tin` of the cut sequence (zero outside [0,Tc)).
+__device__ __forceinline__ float4 noisy_fetch(const float* __restrict__ x, int b, int tin, int f, int T, int F,
+                                              int Tc, int cut, float ws, float os, uint64_t seed,
+                                              const float* __restrict__ wn, float4 offv) {
+  if (tin < 0 || tin >= Tc) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long e = ((long long)b * T + (tin + cut)) * F + f;
+  float4 v = *reinterpret_cast<const float4*>(x + e);
+  if (ws > 0.f) {
+    float4 n = wn ? *reinterpret_cast<const float4*>(wn + e) : Philox::normal4(seed, (uint64_t)(e >> 2), 0u);
+    v.x = fmaf(ws, n.x, v.x); v.y = fmaf(ws, n.y, v.y); v.z = fmaf(ws, n.z, v.z); v.w = fmaf(ws, n.w, v.w);
+  }
+  v.x += offv.x; v.y += offv.y; v.z += offv.z; v.w += offv.w;
+  return v;
+}
+
+constexpr int TCH = 32;  // outputs per thread along T
+
+// Sliding-window form: each noisy input is generated once per chunk (+ (NT-1)/TCH halo).
+template <int NT>
+__global__ __launch_bounds__(128) void augment_smooth_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int T, int F, int Tc, int T_out, int cut, int left,
+                                                             float ws, float os, uint64_t seed,
+                                                             const float* __restrict__ wn,
+                                                             const float* __restrict__ on, Taps taps) {
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TCH;
+  for (int f = threadIdx.x * 4; f < F; f += blockDim.x * 4) {
+    float4 offv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (os > 0.f) {
+      float4 n = on ? *reinterpret_cast<const float4*>(on + (long long)b * F + f)
+                    : Philox::normal4(seed, (uint64_t)(((long long)b * F + f) >> 2), 1u);
+      offv = make_float4(os * n.x, os * n.y, os * n.z, os * n.w);
+    }
+    float4 win[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) win[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < TCH + NT - 1; ++s) {
+      const int tin = t0 - left + s;
+      float4 v = noisy_fetch(x, b, tin, f, T, F, Tc, cut, ws, os, seed, wn, offv);
+#pragma unroll
+      for (int j = 0; j < NT - 1; ++j) win[j] = win[j + 1];
+      win[NT - 1] = v;
+      const int t = t0 + s - (NT - 1);
+      if (s >= NT - 1 && t < T_out) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc = f4_fma(taps.v[j], win[j], acc);
+        *reinterpret_cast<float4*>(y + ((long long)b * T_out + t) * F + f) = acc;
+      }
+    }
+  }
+}
+
+// Generic tap count: direct form (regenerates the counter-based noise per tap; rarely used).
+__global__ __launch_bounds__(128) void augment_smooth_generic_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                     int T, int F, int Tc, int T_out, int cut, int left,
+                                                                     float ws, float os, uint64_t seed,
+                                                                     const float* __restrict__ wn,
+                                                                     const float* __restrict__ on, Taps taps, int nt) {
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TCH;
+  for (int f = threadIdx.x * 4; f < F; f += blockDim.x * 4) {
+    float4 offv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (os > 0.f) {
+      float4 n = on ? *reinterpret_cast<const float4*>(on + (long long)b * F + f)
+                    : Philox::normal4(seed, (uint64_t)(((long long)b * F + f) >> 2), 1u);
+      offv = make_float4(os * n.x, os * n.y, os * n.z, os * n.w);
+    }
+    for (int t = t0; t < t0 + TCH && t < T_out; ++t) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < nt; ++j)
+        acc = f4_fma(taps.v[j], noisy_fetch(x, b, t + j - left, f, T, F, Tc, cut, ws, os, seed, wn, offv), acc);
+      *reinterpret_cast<float4*>(y + ((long long)b * T_out + t) * F + f) = acc;
+    }
+  }
+}
+
+__global__ void softsign_bwd_kernel(const float* __restrict__ u, float* __restrict__ du, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(u)[i];
+    float4 d = reinterpret_cast<float4*>(du)[i];
+    float s;
+    s = 1.f - fabsf(a.x); d.x *= s * s;
+    s = 1.f - fabsf(a.y); d.y *= s * s;
+    s = 1.f - fabsf(a.z); d.z *= s * s;
+    s = 1.f - fabsf(a.w); d.w *= s * s;
+    reinterpret_cast<float4*>(du)[i] = d;
+  }
+}
+
+// Column sums, two deterministic stages: block (cx, ry) sums rows [ry*RPB, ...) of 64 columns.
+constexpr int CS_RPB = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long rows, int cols,
+                                                             long long ld, float* __restrict__ part, long long x_sz) {
+  __shared__ float red[4][64];
+  x += (long long)blockIdx.z * x_sz;
+  part += (long long)blockIdx.z * gridDim.y * cols;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * CS_RPB;
+  float s = 0.f;
+  if (c < cols)
+    for (long long r = r0 + w; r < r0 + CS_RPB && r < rows; r += 4) s += x[r * ld + c];
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < cols)
+    part[(long long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out,
+                                    int accumulate, long long out_sz) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  part += (long long)blockIdx.y * nparts * cols;
+  out += (long long)blockIdx.y * out_sz;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long long)p * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ void patch_fold_kernel(const float* __restrict__ dv, float* __restrict__ du, int T, int F, int Tp,
+                                  int patch, int stride) {
+  // du[b,t,f] = sum_{p,k: p*stride+k=t} dv[b,p,k*F+f]
+  const int b = blockIdx.z, t = blockIdx.y;
+  const int f = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (f >= F) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p_hi = t / stride; if (p_hi > Tp - 1) p_hi = Tp - 1;
+  for (int p = p_hi; p >= 0; --p) {
+    const int k = t - p * stride;
+    if (k >= patch) break;
+    float4 v = *reinterpret_cast<const float4*>(dv + (((long long)b * Tp + p) * patch + k) * F + f);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(du + ((long long)b * T + t) * F + f) = acc;
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p, float scale,
+                               uint64_t seed) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 u = Philox::uniform4(seed, (uint64_t)i, 2u);
+    v.x = u.x >= p ? v.x * scale : 0.f; v.y = u.y >= p ? v.y * scale : 0.f;
+    v.z = u.z >= p ? v.z * scale : 0.f; v.w = u.w >= p ? v.w * scale : 0.f;
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y)
+    if (r0 + i < rows && c < cols) tile[i][threadIdx.x] = in[(long long)(r0 + i) * cols + c];
+  __syncthreads();
+  int r = r0 + threadIdx.x, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y)
+    if (c0 + i < cols && r < rows) out[(long long)(c0 + i) * rows + r] = tile[threadIdx.x][i];
+}
+
+// out[slot_of_first_sample_with_that_day] : out[d][i] = sum_{b: day[b]==d} slab[b][i], for days present.
+// One block column per i-chunk; blockIdx.y = b; only the FIRST sample of each day does the sum (deterministic order).
+__global__ void day_reduce_kernel(const float* __restrict__ slab, const int* __restrict__ day, int B, long long n,
+                                  float* __restrict__ out, long long out_stride) {
+  const int b = blockIdx.y;
+  const int d = day[b];
+  for (int j = 0; j < b; ++j) if (day[j] == d) return;  // not the first of its day
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = b; j < B; ++j) {
+    if (day[j] != d) continue;
+    float4 v = *reinterpret_cast<const float4*>(slab + (long long)j * n + i);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + (long long)d * out_stride + i) = acc;
+}
+
+}  // namespace b2t
+
+using namespace b2t;
+
+extern "C" int b2t_augment_smooth_f32(const float* x, float* y, int B, int T, int F, int cut, float white_std,
+                                      float offset_std, uint64_t seed, const float* white_noise,
+                                      const float* offset_noise, const float* taps_host, int ntaps, int padding_mode,
+                                      void* stream) {
+  B2T_REQUIRE(B > 0 && T > 0 && F > 0 && (F % 4) == 0, "augment_smooth: bad shape B=%d T=%d F=%d (F%%4 must be 0)", B, T, F);
+  B2T_REQUIRE(ntaps >= 1 && ntaps <= 33 && taps_host, "augment_smooth: ntaps=%d out of [1,33]", ntaps);
+  B2T_REQUIRE(cut >= 0 && cut < T, "augment_smooth: cut=%d out of range", cut);
+  B2T_REQUIRE(padding_mode == 0 || padding_mode == 1, "augment_smooth: padding_mode must be 0 (same) or 1 (valid)");
+  const int Tc = T - cut;
+  const int T_out = padding_mode == 0 ? Tc : Tc - ntaps + 1;
+  B2T_REQUIRE(T_out > 0, "augment_smooth: sequence (T=%d, cut=%d) shorter than kernel (%d taps)", T, cut, ntaps);
+  const int left = padding_mode == 0 ? (ntaps - 1) / 2 : 0;
+  Taps tp; memset(&tp, 0, sizeof(tp));
+  for (int i = 0; i < ntaps; ++i) tp.v[i] = taps_host[i];
+  dim3 grid((T_out + TCH - 1) / TCH, B), block(128);
+  hipStream_t s = as_stream(stream);
+  if (ntaps == 9)
+    hipLaunchKernelGGL((augment_smooth_kernel<9>), grid, block, 0, s, x, y, T, F, Tc, T_out, cut, left, white_std,
+                       offset_std, seed, white_noise, offset_noise, tp);
+  else
+    hipLaunchKernelGGL(augment_smooth_generic_kernel, grid, block, 0, s, x, y, T, F, Tc, T_out, cut, left, white_std,
+                       offset_std, seed, white_noise, offset_noise, tp, ntaps);
+  B2T_CHECK_LAUNCH("b2t_augment_smooth_f32");
+  return 0;
+}
+
+extern "C" int b2t_softsign_bwd_f32(const float* u, float* du, long long n, void* stream) {
+  B2T_REQUIRE(n > 0 && (n % 4) == 0, "softsign_bwd: n=%lld must be a positive multiple of 4", n);
+  long long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(softsign_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), u, du, n4);
+  B2T_CHECK_LAUNCH("b2t_softsign_bwd_f32");
+  return 0;
+}
+
+extern "C" size_t b2t_colsum_ws_bytes(long long rows, int cols) {
+  long long nparts = (rows + CS_RPB - 1) / CS_RPB;
+  return (size_t)(nparts * cols * sizeof(float));
+}
+
+extern "C" int b2t_colsum_f32(const float* x, long long rows, int cols, long long ld, float* out, int accumulate,
+                              float* ws, int Z, long long x_sz, long long out_sz, void* stream) {
+  B2T_REQUIRE(rows > 0 && cols > 0 && ws && Z > 0, "colsum: bad args rows=%lld cols=%d Z=%d", rows, cols, Z);
+  int nparts = (int)((rows + CS_RPB - 1) / CS_RPB);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nparts, Z), dim3(256), 0, s, x, rows, cols, ld, ws, x_sz);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256, Z), dim3(256), 0, s, ws, nparts, cols, out, accumulate,
+                     out_sz);
+  B2T_CHECK_LAUNCH("b2t_colsum_f32");
+  return 0;
+}
+
+extern "C" int b2t_patch_fold_f32(const float* dv, float* du, int B, int T, int F, int Tp, int patch, int stride,
+                                  void* stream) {
+  B2T_REQUIRE(B > 0 && T > 0 && F > 0 && (F % 4) == 0 && patch > 0 && stride > 0, "patch_fold: bad args");
+  dim3 block(128), grid((F / 4 + 127) / 128, T, B);
+  hipLaunchKernelGGL(patch_fold_kernel, grid, block, 0, as_stream(stream), dv, du, T, F, Tp, patch, stride);
+  B2T_CHECK_LAUNCH("b2t_patch_fold_f32");
+  return 0;
+}
+
+extern "C" int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t seed, void* stream) {
+  B2T_REQUIRE(n > 0 && (n % 4) == 0 && p >= 0.f && p < 1.f, "dropout: bad args n=%lld p=%f", n, (double)p);
+  long long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n4, p, 1.0f / (1.0f - p), seed);
+  B2T_CHECK_LAUNCH("b2t_dropout_f32");
+  return 0;
+}
+
+extern "C" int b2t_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
+  B2T_REQUIRE(rows > 0 && cols > 0, "transpose: bad shape");
+  dim3 block(32, 8), grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, as_stream(stream), in, out, rows, cols);
+  B2T_CHECK_LAUNCH("b2t_transpose_f32");
+  return 0;
+}
+
+extern "C" int b2t_day_reduce_f32(const float* slab, const int32_t* day_idx, int B, long long n, float* out,
+                                  long long out_stride, void* stream) {
+  B2T_REQUIRE(B > 0 && n > 0 && (n % 4) == 0, "day_reduce: bad args");
+  dim3 block(256), grid((unsigned)((n / 4 + 255) / 256), B);
+  hipLaunchKernelGGL(day_reduce_kernel, grid, block, 0, as_stream(stream), slab, day_idx, B, n, out, out_stride);
+  B2T_CHECK_LAUNCH("b2t_day_reduce_f32");
+  return 0;
+}

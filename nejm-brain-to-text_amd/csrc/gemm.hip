@@ -1,0 +1,221 @@
+// gemm.hip — exact-fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// C[z][m][n] (+)= sum_k A(z,m,k) * B(z,n,k) (+ bias[n]) -> optional softsign.
+// 128x128x16 block tile, 256 threads = 4 wave64 in a 2x2 grid, each wave owns a 64x64
+// sub-tile = 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  Operands are staged through
+// LDS k-major ([k][m], row pitch 132 floats) so an MFMA fragment read is one conflict-free
+// ds_read_b32 per operand (lanes 0-31 read 32 consecutive floats).  Global->register prefetch of
+// tile k+1 overlaps the MFMAs of tile k; LDS is double buffered (one barrier per k-tile).
+// The f32-input MFMA is bit-for-bit a k-ordered fmaf chain (no reduced-precision path exists
+// on gfx950), so results match an fp32 CPU GEMM to summation-order roundoff.
+#include "common.h"
+
+namespace b2t {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BKT = 16, PITCH = 132;
+
+struct GemmArgs {
+  const float* A; const float* B; float* C; const float* bias;
+  int M, N, K;
+  long long a_s0, a_s1; int a_div; long long a_sz;
+  long long b_s0, b_s1; int b_div; long long b_sz;
+  long long c_s0, c_s1; int c_div; long long c_sz;
+  const int* b_zmap; long long bias_sz;
+  int epilogue; int accumulate;
+};
+
+__device__ __forceinline__ long long rowoff(int i, long long s0, long long s1, int div) {
+  return div > 0 ? (long long)(i / div) * s1 + (long long)(i % div) * s0 : (long long)i * s0;
+}
+
+// Load one operand tile slice owned by this thread into 2 float4 registers.
+// KC (k contiguous): tile rows are the M/N index (128 of them), 16 k per row -> thread (row=t/4+64r, k4=t%4)
+// MC (m contiguous): tile rows are k (16 of them), 128 m per row        -> thread (krow=t/32+8r, m4=t%32)
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, const long long* roff, int ext0,
+                                          int ext_m, int base_m, int k0, int Kend,
+                                          long long s0, long long s1, int div, float4 (&v)[2], int tid) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (KC) {
+      const int row = base_m + (tid >> 2) + 64 * r;
+      const int k = k0 + (tid & 3) * 4;
+      if (row < ext_m) {
+        const float* p = P + roff[r] + k;
+        if (k + 3 < Kend) {
+          o = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k < Kend) o.x = p[0];
+          if (k + 1 < Kend) o.y = p[1];
+          if (k + 2 < Kend) o.z = p[2];
+        }
+      }
+    } else {
+      const int k = k0 + (tid >> 5) + 8 * r;
+      const int m = base_m + (tid & 31) * 4;
+      if (k < Kend) {
+        const float* p = P + rowoff(k, s0, s1, div) + m;
+        if (m + 3 < ext_m) {
+          o = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (m < ext_m) o.x = p[0];
+          if (m + 1 < ext_m) o.y = p[1];
+          if (m + 2 < ext_m) o.z = p[2];
+        }
+      }
+    }
+    v[r] = o;
+  }
+  (void)ext0;
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&v)[2], int tid) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if constexpr (KC) {
+      const int row = (tid >> 2) + 64 * r;
+      const int k = (tid & 3) * 4;
+      S[(k + 0) * PITCH + row] = v[r].x;
+      S[(k + 1) * PITCH + row] = v[r].y;
+      S[(k + 2) * PITCH + row] = v[r].z;
+      S[(k + 3) * PITCH + row] = v[r].w;
+    } else {
+      const int k = (tid >> 5) + 8 * r;
+      const int m = (tid & 31) * 4;
+      *reinterpret_cast<float4*>(&S[k * PITCH + m]) = v[r];
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKT * PITCH];
+  float* As = smem;
+  float* Bs = smem + 2 * BKT * PITCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  const float* A = g.A + (long long)z * g.a_sz;
+  const int zb = g.b_zmap ? g.b_zmap[z] : z;
+  const float* B = g.B + (long long)zb * g.b_sz;
+  const float* bias = g.bias ? g.bias + (long long)zb * g.bias_sz : nullptr;
+  float* C = g.C + (long long)z * g.c_sz;
+
+  long long roffA[2] = {0, 0}, roffB[2] = {0, 0};
+  if constexpr (AKC) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int row = m0 + (tid >> 2) + 64 * r;
+      roffA[r] = rowoff(row < g.M ? row : 0, g.a_s0, g.a_s1, g.a_div);
+    }
+  }
+  if constexpr (BKC) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int row = n0 + (tid >> 2) + 64 * r;
+      roffB[r] = rowoff(row < g.N ? row : 0, g.b_s0, g.b_s1, g.b_div);
+    }
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int K = g.K;
+  const int nk = (K + BKT - 1) / BKT;
+  float4 ra[2], rb[2];
+  load_tile<AKC>(A, roffA, 0, g.M, m0, 0, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
+  load_tile<BKC>(B, roffB, 0, g.N, n0, 0, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
+  store_tile<AKC>(As, ra, tid);
+  store_tile<BKC>(Bs, rb, tid);
+  __syncthreads();
+
+  const int lk = lane >> 5, li = lane & 31;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_tile<AKC>(A, roffA, 0, g.M, m0, (kt + 1) * BKT, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
+      load_tile<BKC>(B, roffB, 0, g.N, n0, (kt + 1) * BKT, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
+    }
+    const float* as = As + cur * BKT * PITCH + wm * 64 + li;
+    const float* bs = Bs + cur * BKT * PITCH + wn * 64 + li;
+#pragma unroll
+    for (int kk = 0; kk < BKT; kk += 2) {
+      const float a0 = as[(kk + lk) * PITCH], a1 = as[(kk + lk) * PITCH + 32];
+      const float b0 = bs[(kk + lk) * PITCH], b1 = bs[(kk + lk) * PITCH + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<AKC>(As + (cur ^ 1) * BKT * PITCH, ra, tid);
+      store_tile<BKC>(Bs + (cur ^ 1) * BKT * PITCH, rb, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (row < g.M) {
+          float v = acc[i][j][e] + bv;
+          if (g.epilogue == 1) v = v / (1.0f + fabsf(v));
+          float* p = C + rowoff(row, g.c_s0, g.c_s1, g.c_div) + col;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace b2t
+
+extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
+  using namespace b2t;
+  B2T_REQUIRE(d != nullptr, "b2t_gemm_f32: null descriptor");
+  B2T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->Z > 0, "b2t_gemm_f32: bad shape M=%d N=%d K=%d Z=%d",
+              d->M, d->N, d->K, d->Z);
+  B2T_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "b2t_gemm_f32: A/B must be 16-byte aligned");
+  B2T_REQUIRE((d->a_s0 % 4) == 0 && (d->a_s1 % 4) == 0 && (d->a_sz % 4) == 0 && (d->b_s0 % 4) == 0 &&
+                  (d->b_s1 % 4) == 0 && (d->b_sz % 4) == 0,
+              "b2t_gemm_f32: A/B strides must be multiples of 4 elements");
+  GemmArgs g;
+  g.A = d->A; g.B = d->B; g.C = d->C; g.bias = d->bias;
+  g.M = d->M; g.N = d->N; g.K = d->K;
+  g.a_s0 = d->a_s0; g.a_s1 = d->a_s1; g.a_div = d->a_div; g.a_sz = d->a_sz;
+  g.b_s0 = d->b_s0; g.b_s1 = d->b_s1; g.b_div = d->b_div; g.b_sz = d->b_sz;
+  g.c_s0 = d->c_s0; g.c_s1 = d->c_s1; g.c_div = d->c_div; g.c_sz = d->c_sz;
+  g.b_zmap = d->b_zmap; g.bias_sz = d->bias_sz; g.epilogue = d->epilogue; g.accumulate = d->accumulate;
+  dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->Z), block(256);
+  hipStream_t s = as_stream(stream);
+  if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
+  else if (d->a_kcontig && !d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
+  else if (!d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);
+  B2T_CHECK_LAUNCH("b2t_gemm_f32");
+  return 0;
+}

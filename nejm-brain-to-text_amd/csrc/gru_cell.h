@@ -1,0 +1,78 @@
+// gru_cell.h — device pieces shared by the step-launch and persistent GRU sweeps.
+#pragma once
+#include "common.h"
+
+namespace b2t {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+// Sum the 4 waves' partial 16x16 MFMA accumulators through LDS.  After the call thread (wave, lane)
+// owns output row 4*(lane>>4) + wave, column lane&15 of each of the NG tiles.
+// red must hold 4*NG*4*64 floats.  Contains one __syncthreads(); callers looping over steps must
+// place another barrier before the next call reuses `red`.
+template <int NG>
+__device__ __forceinline__ void cross_wave_reduce(float* red, const f32x4 (&acc)[NG], float (&out)[NG], int wave,
+                                                  int lane) {
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * NG + g) * 4 + r) * 64 + lane] = acc[g][r];
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const float s0 = red[((0 * NG + g) * 4 + wave) * 64 + lane];
+    const float s1 = red[((1 * NG + g) * 4 + wave) * 64 + lane];
+    const float s2 = red[((2 * NG + g) * 4 + wave) * 64 + lane];
+    const float s3 = red[((3 * NG + g) * 4 + wave) * 64 + lane];
+    out[g] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+// Gate math of one (row, unit): gi row pointer [3H], recurrent sums gh[3] (without bias).
+// r = s(gi_r+gh_r), z = s(gi_z+gh_z), n = tanh(gi_n + r*gh_n), h = (1-z) n + z h_prev.
+__device__ __forceinline__ float gru_gate_fwd(const float* __restrict__ gi_row, const float* __restrict__ b_hh,
+                                              const float (&gh)[3], float hp, int unit, int H,
+                                              float* __restrict__ out_row, float* __restrict__ res_row) {
+  const float ghr = gh[0] + b_hh[unit];
+  const float ghz = gh[1] + b_hh[H + unit];
+  const float ghn = gh[2] + b_hh[2 * H + unit];
+  const float r = sigmoidf_(gi_row[unit] + ghr);
+  const float z = sigmoidf_(gi_row[H + unit] + ghz);
+  const float n = tanhf(gi_row[2 * H + unit] + r * ghn);
+  const float h = (1.0f - z) * n + z * hp;
+  out_row[unit] = h;
+  if (res_row) {
+    res_row[unit] = r;
+    res_row[H + unit] = z;
+    res_row[2 * H + unit] = n;
+    res_row[3 * H + unit] = ghn;
+  }
+  return h;
+}
+
+// Gate gradients of one (row, unit).  rs = reserve row [4H] = (r,z,n,gh_n).
+// Writes dG row [4H] = (dr_pre, dz_pre, dn_pre*r, dn_pre); *dz_term = d*z (the direct path into dh_{t-1}).
+__device__ __forceinline__ void gru_gate_bwd(const float* __restrict__ rs, float hp, float d, int unit, int H,
+                                             float* __restrict__ dg_row, float* dz_term) {
+  const float r = rs[unit], z = rs[H + unit], n = rs[2 * H + unit], ghn = rs[3 * H + unit];
+  const float dn = d * (1.0f - z);
+  const float dz = d * (hp - n);
+  const float dn_pre = dn * (1.0f - n * n);
+  const float dz_pre = dz * z * (1.0f - z);
+  const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+  dg_row[unit] = dr_pre;
+  dg_row[H + unit] = dz_pre;
+  dg_row[2 * H + unit] = dn_pre * r;
+  dg_row[3 * H + unit] = dn_pre;
+  *dz_term = d * z;
+}
+
+// persistent sweeps (gru_persistent.hip)
+size_t gru_persistent_sync_bytes(int T);
+int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
+                       float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s);
+int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
+                       const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
+                       void* sync_ws, hipStream_t s);
+
+}  // namespace b2t
