@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — GRU+CTC training throughput (sentences/s) on BASELINE.json config 2:
+5-layer GRU-512 + CTC on synthetic [B=64, T=500, F=512] -> 41 phonemes, fp32, per GPU.
+
+One "step" = one pass of the hot path over one synthetic minibatch already resident in HBM:
+  on-GPU augmentation (white noise 1.0, offset 0.2, random cut, 9-tap smoothing) -> day layer ->
+  5 x GRU -> head -> log-softmax + CTC -> full backward -> clip_grad_norm_(10) -> AdamW (3 groups).
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI), 64 sentences per rank
+(weak scaling), bucketed gradient all-reduce overlapped with the backward sweeps.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle's numpy port of the
+same step, timed on this host's cores, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nejm-brain-to-text_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B, T, F, H, L, C, D, S = 64, 500, 512, 512, 5, 41, 45, 60
+ALG_BYTES_PER_STEP = 12.08e9      # algorithmic HBM bytes of one fp32 C2 training step
+FLOPS_PER_STEP = 1.564e12         # 521.4 GFLOP forward x3
+PEAK_F32_MFMA = 157.3e12          # MI355X_MICROARCH.md chip table (fp32-input MFMA = vector peak)
+PEAK_HBM = 8.0e12
+
+
+def make_batch(seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, F, generator=g)
+    days = torch.tensor([0, 11, 22, 33]).repeat_interleave(B // 4)
+    labels = torch.randint(1, C, (B, S), generator=g)
+    lens = torch.randint(20, S + 1, (B,), generator=g)
+    for b in range(B):
+        labels[b, lens[b]:] = 0
+    nts = torch.full((B,), T, dtype=torch.int32)
+    return x.to(dev), days, labels.to(dev), nts.to(dev), lens.to(dev)
+
+
+ARGS = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=120000, lr_warmup_steps=1000, lr_max_day=0.005,
+            lr_min_day=0.0001, lr_decay_steps_day=120000, lr_warmup_steps_day=1000, beta0=0.9, beta1=0.999,
+            epsilon=0.1, weight_decay=0.001, weight_decay_day=0, grad_norm_clip_value=10)
+
+
+def cpu_baseline():
+    """Oracle (numpy port of the reference step, rnn_trainer.py:527-558) on ONE full C2 minibatch."""
+    from oracle import b2t_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B, T, F)).astype(np.float32)
+    days = np.repeat(np.array([0, 11, 22, 33]), B // 4)
+    labels = rng.integers(1, C, (B, S)); lens = rng.integers(20, S + 1, B)
+    for b in range(B):
+        labels[b, lens[b]:] = 0
+    sd = {}
+    for i in range(D):
+        sd[f"day_weights.{i}"] = np.eye(F, dtype=np.float32); sd[f"day_biases.{i}"] = np.zeros((1, F), np.float32)
+    k = 1.0 / np.sqrt(H)
+    for l in range(L):
+        sd[f"gru.weight_ih_l{l}"] = rng.uniform(-k, k, (3 * H, F if l == 0 else H)).astype(np.float32)
+        sd[f"gru.weight_hh_l{l}"] = rng.uniform(-k, k, (3 * H, H)).astype(np.float32)
+        sd[f"gru.bias_ih_l{l}"] = rng.uniform(-k, k, 3 * H).astype(np.float32)
+        sd[f"gru.bias_hh_l{l}"] = rng.uniform(-k, k, 3 * H).astype(np.float32)
+    sd["out.weight"] = rng.uniform(-k, k, (C, H)).astype(np.float32); sd["out.bias"] = np.zeros(C, np.float32)
+    sd["h0"] = rng.uniform(-k, k, (1, 1, H)).astype(np.float32)
+    t0 = time.time()
+    wn = rng.standard_normal((B, T, F)).astype(np.float32); on = rng.standard_normal((B, 1, F)).astype(np.float32)
+    feats, n = O.transform_data(x, np.full(B, T), "train", white_noise=wn, white_noise_std=1.0, offset_noise=on,
+                                constant_offset_std=0.2, cut=1)
+    loss, _, _, g = O.model_loss_and_grads(sd, feats, days, labels, n, lens, L)
+    norm, gc = O.clip_grad_norm(g, 10.0)
+    for name in gc:
+        O.adamw_step(sd[name], gc[name], np.zeros_like(sd[name]), np.zeros_like(sd[name]), 1, 5e-6, 0.001)
+    dt = time.time() - t0
+    return dict(value=round(B / dt, 3), unit="sentences/s", cores=os.cpu_count(), kind="port",
+                sample=f"1 full step of the same workload (B={B}, T={T}; numpy/BLAS port in oracle/), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gru-mode", type=int, default=int(os.environ.get("B2T_GRU_MODE", "-1")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    if a.gru_mode >= 0:
+        ops.GRU_MODE["value"] = a.gru_mode
+
+    torch.manual_seed(10)
+    model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
+    ts = TrainStep(model, dict(ARGS))
+    x, days, labels, nts, lens = make_batch(1000 + rank, dev)
+    cut_rng = np.random.RandomState(1 + rank)
+
+    def step(i):
+        cut = int(cut_rng.randint(0, 3))          # rnn_trainer.py:468-471
+        feats = ops.augment_smooth(x, 2, 100, "same", cut=cut, white_std=1.0, offset_std=0.2, seed=i * 7919 + rank)
+        return ts.step(feats, days, labels, nts - cut, lens)
+
+    for i in range(a.warmup):
+        loss, gn = step(i)
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss, gn = step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / a.steps * 1e3
+    value = B * world * a.steps / dt
+    lossv = float(loss)
+    assert np.isfinite(lossv), "non-finite loss in the bench step"
+
+    # ---- live per-kernel timing (HIP events on the launch stream) over 2 extra instrumented steps ----
+    prof = ops.PROFILE
+    prof["on"] = True; prof["ev"] = []
+    for i in range(2):
+        step(a.warmup + a.steps + i)
+    torch.cuda.synchronize()
+    prof["on"] = False
+    agg = {}
+    for name, flops, nlaunch, e0, e1 in prof["ev"]:
+        t = e0.elapsed_time(e1) * 1e-3
+        r = agg.setdefault(name, [0.0, 0.0, 0])
+        r[0] += t; r[1] += flops; r[2] += nlaunch
+    dom = max(agg.items(), key=lambda kv: kv[1][0])
+    dname, (dtime, dflops, dlaunch) = dom
+    achieved = dflops / dtime if dtime > 0 else 0.0
+    roofline = dict(bound="mfma", kernel=dname, achieved=round(achieved / 1e12, 3), peak=round(PEAK_F32_MFMA / 1e12, 1),
+                    unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA, 4), traffic=None,
+                    avg_launch_us=round(dtime / max(1, dlaunch) * 1e6, 2), launches_per_step=dlaunch // 2,
+                    share_of_step=round(dtime / 2 / (ms * 1e-3), 3),
+                    step_flops_frac=round(FLOPS_PER_STEP / (ms * 1e-3) / PEAK_F32_MFMA, 4),
+                    step_hbm_frac=round(ALG_BYTES_PER_STEP / (ms * 1e-3) / PEAK_HBM, 4),
+                    breakdown_ms={k: round(v[0] / 2 * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])})
+
+    if rank == 0:
+        out = dict(metric="GRU+CTC train sentences/sec", value=round(value, 2), unit="sentences/s", n_gpus=world,
+                   steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="BASELINE.json configs[1]: 5-layer GRU-512 + CTC, synthetic [B=64,T=500,F=512] -> 41 "
+                                        "phonemes, fp32, full training step incl. on-GPU augmentation, clip and AdamW",
+                               global_batch=B * world, seq_len=T, parallelism=f"dp{world}",
+                               gru_mode=ops.gru_mode_for(B, H)),
+                   roofline=roofline, final_loss=round(lossv, 4))
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

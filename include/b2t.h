@@ -68,6 +68,10 @@ typedef struct b2t_gemm_desc {
   long long c_s0, c_s1; int c_div; long long c_sz;
   const int* b_zmap; long long bias_sz;   /* bias row of batch z = bias + b_zmap[z]*bias_sz (0: shared) */
   int epilogue; int accumulate;
+  /* split-K (weight gradients: few output tiles, K = T*B): splitk > 1 launches Z*splitk slices; slice ks
+   * reduces k in [ks*kc, min(K,(ks+1)*kc)) (kc = ceil(K/splitk) rounded up to 16) into the slab
+   * C + z*c_sz + ks*c_ks; the caller sums the slabs deterministically (b2t_colsum_f32). */
+  int splitk; long long c_ks;
 } b2t_gemm_desc;
 int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream);
 
@@ -101,6 +105,9 @@ int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t see
  * W_hh slices resident in registers, agent-scope flag hand-off of h_t between workgroups).
  * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode; zeroed by the call). */
 size_t b2t_gru_sync_bytes(int T);
+/* Persistent mode only: copies the sweep's error word to the host and synchronises the stream.
+ * *status_host = 0: clean; 1: a bounded hand-off spin gave up (results of that sweep are invalid). */
+int b2t_gru_sync_status(const void* sync_ws, int T, int B, int* status_host, void* stream);
 int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const float* b_hh,
                           const float* h_init, float* out, float* reserve, float* h_last,
                           int T, int B, int H, int mode, void* sync_ws, void* stream);

@@ -40,6 +40,29 @@ def pad_to(n: int, a: int = ARENA_ALIGN) -> int:
     return (n + a - 1) // a * a
 
 
+# Live kernel timing for bench.py: when PROFILE["on"], every C-ABI call below is bracketed by HIP
+# events recorded on the launch stream (torch's current stream — the stream handed to the library).
+PROFILE = {"on": False, "ev": []}
+
+
+class _Prof:
+    def __init__(self, name, flops=0.0, launches=1):
+        self.name, self.flops, self.launches = name, flops, launches
+
+    def __enter__(self):
+        if PROFILE["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE["on"]:
+            self.e1.record()
+            PROFILE["ev"].append((self.name, self.flops, self.launches, self.e0, self.e1))
+        return False
+
+
 # ------------------------------------------------------------------------------------------------
 # smoothing kernel taps (model_training/data_augmentations.py:19-24), computed on the host
 # ------------------------------------------------------------------------------------------------
@@ -84,9 +107,10 @@ def augment_smooth(x: torch.Tensor, std: float, size: int, padding: str = "same"
         _need(white_noise, name="white_noise")
     if offset_noise is not None:
         _need(offset_noise, name="offset_noise")
-    N.check(N.load().b2t_augment_smooth_f32(_p(x), _p(y), B, T, F, int(cut), float(white_std), float(offset_std),
-                                            C.c_uint64(seed & (2 ** 64 - 1)), _p(white_noise), _p(offset_noise),
-                                            tp, nt, mode, _stream()), "b2t_augment_smooth_f32")
+    with _Prof("augment_smooth"):
+        N.check(N.load().b2t_augment_smooth_f32(_p(x), _p(y), B, T, F, int(cut), float(white_std), float(offset_std),
+                                                C.c_uint64(seed & (2 ** 64 - 1)), _p(white_noise), _p(offset_noise),
+                                                tp, nt, mode, _stream()), "b2t_augment_smooth_f32")
     return y
 
 
@@ -95,7 +119,17 @@ def augment_smooth(x: torch.Tensor, std: float, size: int, padding: str = "same"
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,
          b_sz=0, c_s0=0, c_s1=0, c_div=0, c_sz=0, bias=None, bias_sz=0, b_zmap=None, epilogue=0, accumulate=0,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, splitk=1, ws=None, _splitk=1, _c_ks=0):
+    """C = A.B^T through b2t_gemm_f32.  splitk>1 (needs `ws`): partial products go to a workspace slab and
+    are summed deterministically into C by b2t_colsum_f32 (used for the weight gradients, K = T*B)."""
+    if splitk > 1:
+        if Z != 1 or epilogue != 0 or c_div != 0 or c_s0 != N_:
+            raise RuntimeError("split-K gemm supports Z=1, dense row-major C, no epilogue")
+        slab = ws.get("splitk_slab", (splitk, M * N_), Cm.device)
+        gemm(A, B, slab, M=M, N_=N_, K=K, a_kc=a_kc, b_kc=b_kc, a_s0=a_s0, a_s1=a_s1, a_div=a_div, b_s0=b_s0,
+             b_s1=b_s1, b_div=b_div, c_s0=N_, bias=bias, a_off=a_off, b_off=b_off, _splitk=splitk, _c_ks=M * N_)
+        colsum(slab, splitk, M * N_, M * N_, Cm, accumulate=accumulate, out_off=c_off)
+        return
     d = N.GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -109,7 +143,9 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
     d.b_zmap = b_zmap.data_ptr() if b_zmap is not None else None
     d.bias_sz = bias_sz
     d.epilogue, d.accumulate = epilogue, accumulate
-    N.check(N.load().b2t_gemm_f32(C.byref(d), _stream()), "b2t_gemm_f32")
+    d.splitk, d.c_ks = _splitk, _c_ks
+    with _Prof("gemm_f32_kernel", 2.0 * M * N_ * K * Z):
+        N.check(N.load().b2t_gemm_f32(C.byref(d), _stream()), "b2t_gemm_f32")
 
 
 def colsum(x, rows, cols, ld, out, accumulate=0, Z=1, x_sz=0, out_sz=0, x_off=0, out_off=0):
@@ -147,7 +183,25 @@ class Params:
         self.out_w, self.out_b, self.h0 = out_w, out_b, h0
 
 
-GRU_MODE = {"value": 0}  # 0 = step-launch sweep, 1 = persistent sweep (csrc/gru_persistent.hip)
+# GRU sweep mode: 1 = persistent single-launch sweep (csrc/gru_persistent.hip), 0 = one launch per time step.
+# -1 = choose per call: persistent whenever its (H/16) x ceil(B/16) workgroups can be co-resident.
+GRU_MODE = {"value": int(__import__("os").environ.get("B2T_GRU_MODE", "-1"))}
+MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs, one 256-thread workgroup (<=512 VGPRs/lane) per CU
+
+
+def gru_mode_for(B: int, H: int) -> int:
+    m = GRU_MODE["value"]
+    if m in (0, 1):
+        return m
+    return 1 if (H // 16) * ((B + 15) // 16) <= MAX_RESIDENT_WGS and H <= 1024 else 0
+
+
+def gru_sync_check(sync_ws, T: int, B: int):
+    """Raise if the last persistent sweep on sync_ws reported a hand-off timeout (synchronises)."""
+    st = C.c_int(0)
+    N.check(N.load().b2t_gru_sync_status(_p(sync_ws), T, B, C.byref(st), _stream()), "b2t_gru_sync_status")
+    if st.value != 0:
+        raise RuntimeError("persistent GRU sweep: inter-workgroup hand-off timed out (results invalid)")
 
 
 class Workspace:
@@ -209,9 +263,8 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     outs_d: List[torch.Tensor] = []
     reserves: List[Optional[torch.Tensor]] = []
     hidden = torch.empty((L, B, H), dtype=torch.float32, device=dev)
-    sync_ws = None
-    if GRU_MODE["value"] == 1:
-        sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32)
+    mode = gru_mode_for(B, H)
+    sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32) if mode == 1 else None
     for l in range(L):
         # 2. input projection gi = in_t W_ih^T + b_ih, time-major [T'][B][3H]
         if l == 0:
@@ -228,9 +281,10 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
         else:
             outbuf[0].copy_(states[l])
         res = sbuf(f"res{l}", (Tp, B, 4 * H)) if save else None
-        N.check(lib.b2t_gru_layer_fwd_f32(_p(gi), _p(prm.w_hh[l]), _p(prm.b_hh[l]), _p(outbuf[0]), _p(outbuf[1:]),
-                                          _p(res), _p(hidden[l]), Tp, B, H, GRU_MODE["value"], _p(sync_ws), st),
-                "b2t_gru_layer_fwd_f32")
+        with _Prof("gru_sweep_fwd", 2.0 * Tp * B * 3 * H * H, Tp if mode == 0 else 1):
+            N.check(lib.b2t_gru_layer_fwd_f32(_p(gi), _p(prm.w_hh[l]), _p(prm.b_hh[l]), _p(outbuf[0]), _p(outbuf[1:]),
+                                              _p(res), _p(hidden[l]), Tp, B, H, mode, _p(sync_ws), st),
+                    "b2t_gru_layer_fwd_f32")
         outs.append(outbuf)
         reserves.append(res)
         od = outbuf
@@ -253,6 +307,14 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ctx.in_drop, ctx.rnn_drop, ctx.seed = in_drop, rnn_drop, seed
     ctx.custom_states = states is not None
     return logits, hidden, ctx
+
+
+def splitk_for(M: int, Nn: int, K: int, target_blocks: int = 1024) -> int:
+    """Number of K slices so that a weight-gradient GEMM (few 128x128 output tiles, very long K) fills the
+    chip: ~4 workgroups per CU on 256 CUs, each slice at least 256 deep."""
+    tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
+    sk = max(1, min(target_blocks // max(1, tiles), K // 256))
+    return int(sk)
 
 
 class Grads:
@@ -293,9 +355,8 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     whh_t = ws.get("whh_t", (H, 3 * H), dev)
     s4 = ws.get("s4", (4 * H,), dev)
     dYn = ws.get("dY1", (Tp, B, H), dev)
-    sync_ws = None
-    if GRU_MODE["value"] == 1:
-        sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32)
+    mode = gru_mode_for(B, H)
+    sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32) if mode == 1 else None
     for l in reversed(range(L)):
         if ctx.rnn_drop > 0 and l < L - 1:   # gradient through the inter-layer dropout mask
             N.check(lib.b2t_dropout_f32(_p(dY), _p(dY), Tp * B * H, float(ctx.rnn_drop),
@@ -303,11 +364,13 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
         N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_t), 3 * H, H, st), "b2t_transpose_f32")
         outbuf = ctx.outs[l]
         dhl = dhidden[l].contiguous() if dhidden is not None else None
-        N.check(lib.b2t_gru_layer_bwd_f32(_p(dY), _p(dhl), _p(ctx.reserves[l]), _p(outbuf[1:]), _p(outbuf[0]),
-                                          _p(whh_t), _p(dG), _p(dh_init[l]), _p(carry), Tp, B, H, GRU_MODE["value"],
-                                          _p(sync_ws), st), "b2t_gru_layer_bwd_f32")
+        with _Prof("gru_sweep_bwd", 2.0 * Tp * B * 3 * H * H, Tp + 1 if mode == 0 else 1):
+            N.check(lib.b2t_gru_layer_bwd_f32(_p(dY), _p(dhl), _p(ctx.reserves[l]), _p(outbuf[1:]), _p(outbuf[0]),
+                                              _p(whh_t), _p(dG), _p(dh_init[l]), _p(carry), Tp, B, H, mode,
+                                              _p(sync_ws), st), "b2t_gru_layer_bwd_f32")
         # dW_hh = dGh^T h_prev   (dGh = dG cols [0,3H); h_prev rows = outbuf[0:T'])
-        gemm(dG, outbuf, grd.w_hh[l], M=3 * H, N_=H, K=M, a_kc=0, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H)
+        sk = splitk_for(3 * H, H, M)
+        gemm(dG, outbuf, grd.w_hh[l], M=3 * H, N_=H, K=M, a_kc=0, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H, splitk=sk, ws=ws)
         # dW_ih = dGi^T in      (dGi = dG cols [0,2H) + [3H,4H))
         if l == 0:
             In = dims.In0
@@ -320,9 +383,10 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
             kw = dict(b_kc=0, b_s0=H)
             inp = ctx.outs_d[l - 1]
             in_off = B * H  # skip the initial-state slot
-        gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=M, a_kc=0, a_s0=4 * H, c_s0=In, b_off=in_off, **kw)
+        gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=M, a_kc=0, a_s0=4 * H, c_s0=In, b_off=in_off,
+             splitk=splitk_for(2 * H, In, M), ws=ws, **kw)
         gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=M, a_kc=0, a_s0=4 * H, a_off=3 * H, c_s0=In, c_off=2 * H * In,
-             b_off=in_off, **kw)
+             b_off=in_off, splitk=splitk_for(H, In, M), ws=ws, **kw)
         # biases: column sums of dG -> (s_r, s_z, s_nr, s_n)
         colsum(dG, M, 4 * H, 4 * H, s4)
         grd.b_ih[l][:2 * H].copy_(s4[:2 * H]); grd.b_ih[l][2 * H:].copy_(s4[3 * H:])
@@ -393,8 +457,9 @@ def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, in_len: torch.Tensor, 
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     alpha = ws.get("ctc_alpha", (B, T, 2 * S_max + 1), dev)
     dl = ws.get("ctc_dlogits", (B, T, ldd), dev) if want_grad else None
-    N.check(N.load().b2t_ctc_loss_f32(_p(logits), _p(targets), _p(in_len), _p(tgt_len), _p(loss), _p(alpha), _p(dl),
-                                      B, T, Cc, S_max, ldd, float(grad_scale), _stream()), "b2t_ctc_loss_f32")
+    with _Prof("ctc_kernel"):
+        N.check(N.load().b2t_ctc_loss_f32(_p(logits), _p(targets), _p(in_len), _p(tgt_len), _p(loss), _p(alpha), _p(dl),
+                                          B, T, Cc, S_max, ldd, float(grad_scale), _stream()), "b2t_ctc_loss_f32")
     return loss, dl, ldd
 
 

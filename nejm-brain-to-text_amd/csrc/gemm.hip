@@ -24,6 +24,7 @@ struct GemmArgs {
   long long c_s0, c_s1; int c_div; long long c_sz;
   const int* b_zmap; long long bias_sz;
   int epilogue; int accumulate;
+  int splitk; int kchunk; long long c_ks;
 };
 
 __device__ __forceinline__ long long rowoff(int i, long long s0, long long s1, int div) {
@@ -100,14 +101,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.z;
+  const int z = blockIdx.z / g.splitk;
+  const int ks = blockIdx.z - z * g.splitk;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
   const float* A = g.A + (long long)z * g.a_sz;
   const int zb = g.b_zmap ? g.b_zmap[z] : z;
   const float* B = g.B + (long long)zb * g.b_sz;
-  const float* bias = g.bias ? g.bias + (long long)zb * g.bias_sz : nullptr;
-  float* C = g.C + (long long)z * g.c_sz;
+  const float* bias = (g.bias && ks == 0) ? g.bias + (long long)zb * g.bias_sz : nullptr;
+  float* C = g.C + (long long)z * g.c_sz + (long long)ks * g.c_ks;
 
   long long roffA[2] = {0, 0}, roffB[2] = {0, 0};
   if constexpr (AKC) {
@@ -133,11 +135,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int K = g.K;
-  const int nk = (K + BKT - 1) / BKT;
+  const int kb = ks * g.kchunk;                      // split-K: this block reduces k in [kb, K)
+  const int K = min(g.K, kb + g.kchunk);
+  const int nk = (K - kb + BKT - 1) / BKT;
   float4 ra[2], rb[2];
-  load_tile<AKC>(A, roffA, 0, g.M, m0, 0, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
-  load_tile<BKC>(B, roffB, 0, g.N, n0, 0, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
+  load_tile<AKC>(A, roffA, 0, g.M, m0, kb, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
+  load_tile<BKC>(B, roffB, 0, g.N, n0, kb, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
   store_tile<AKC>(As, ra, tid);
   store_tile<BKC>(Bs, rb, tid);
   __syncthreads();
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<AKC>(A, roffA, 0, g.M, m0, (kt + 1) * BKT, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
-      load_tile<BKC>(B, roffB, 0, g.N, n0, (kt + 1) * BKT, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
+      load_tile<AKC>(A, roffA, 0, g.M, m0, kb + (kt + 1) * BKT, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
+      load_tile<BKC>(B, roffB, 0, g.N, n0, kb + (kt + 1) * BKT, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
     }
     const float* as = As + cur * BKT * PITCH + wm * 64 + li;
     const float* bs = Bs + cur * BKT * PITCH + wn * 64 + li;
@@ -210,7 +213,12 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
   g.b_s0 = d->b_s0; g.b_s1 = d->b_s1; g.b_div = d->b_div; g.b_sz = d->b_sz;
   g.c_s0 = d->c_s0; g.c_s1 = d->c_s1; g.c_div = d->c_div; g.c_sz = d->c_sz;
   g.b_zmap = d->b_zmap; g.bias_sz = d->bias_sz; g.epilogue = d->epilogue; g.accumulate = d->accumulate;
-  dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->Z), block(256);
+  g.splitk = d->splitk > 1 ? d->splitk : 1;
+  B2T_REQUIRE(g.splitk == 1 || (d->epilogue == 0 && d->accumulate == 0),
+              "b2t_gemm_f32: split-K slabs cannot carry an epilogue/accumulate (reduce them with b2t_colsum_f32)");
+  g.kchunk = ((d->K + g.splitk - 1) / g.splitk + BKT - 1) / BKT * BKT;
+  g.c_ks = d->c_ks;
+  dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->Z * g.splitk), block(256);
   hipStream_t s = as_stream(stream);
   if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
   else if (d->a_kcontig && !d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);

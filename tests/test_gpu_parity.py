@@ -282,3 +282,73 @@ def test_edit_distance_random():
                             torch.from_numpy(bl).to(dev)).cpu().numpy()
     ref = [O.edit_distance(a[i, :al[i]], b[i, :bl[i]]) for i in range(Bn)]
     np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("tag", ["h64", "h512", "patch"])
+def test_gru_sweep_modes(golden_dir, tag, mode):
+    """Step-launch (0) and persistent (1) sweeps both reproduce the reference forward, and the persistent
+    hand-off reports no timeout."""
+    import b2t_ops as ops
+    z = load(golden_dir, f"fwd_{tag}.npz")
+    old = ops.GRU_MODE["value"]
+    ops.GRU_MODE["value"] = mode
+    try:
+        m = make_model(z["cfg"], sd_of(z)).eval()
+        dev = _dev()
+        with torch.no_grad():
+            logits, hidden = m(torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["day_idx"]).to(dev), None, True)
+        np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], atol=1e-4)
+        np.testing.assert_allclose(hidden.cpu().numpy(), z["hidden"], atol=1e-4)
+        if mode == 1:
+            B, T = z["x"].shape[0], logits.shape[1]
+            ops.gru_sync_check(m._ws.get("gru_sync", (N_sync(T),), dev, torch.int32), T, B)
+    finally:
+        ops.GRU_MODE["value"] = old
+
+
+def N_sync(T):
+    import b2t_native as Nn
+    return Nn.load().b2t_gru_sync_bytes(T) // 4 + 16
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_train_step_modes_vs_oracle(mode):
+    """C2-shaped slice (H=512, L=2, B=40 = 2.5 row groups, T=60): loss + every gradient vs the oracle, both modes,
+    run 3 times back-to-back so the persistent hand-off is exercised with warm caches."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from rnn_trainer import TrainStep
+    dev = _dev()
+    old = ops.GRU_MODE["value"]
+    ops.GRU_MODE["value"] = mode
+    try:
+        torch.manual_seed(3)
+        F, H, D, C, L, B, T, S = 64, 512, 4, 41, 2, 40, 60, 7
+        model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0)
+        sd0 = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        model = model.to(dev).train()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, T, F, generator=g) * 0.5
+        day = torch.randint(0, D, (B,), generator=g)
+        tgt = torch.randint(1, C, (B, S), generator=g)
+        tl = torch.randint(1, S + 1, (B,), generator=g); nt = torch.randint(30, T + 1, (B,), generator=g)
+        for b in range(B):
+            tgt[b, tl[b]:] = 0
+        lo, _, _, go = O.model_loss_and_grads(sd0, x.numpy(), day.numpy(), tgt.numpy(), nt.numpy(), tl.numpy(), L)
+        args = dict(lr_max=0.0, lr_min=0.0, lr_decay_steps=10, lr_warmup_steps=0, lr_max_day=0.0, lr_min_day=0.0,
+                    lr_decay_steps_day=10, lr_warmup_steps_day=0, beta0=0.9, beta1=0.999, epsilon=0.1, weight_decay=0.0,
+                    weight_decay_day=0, grad_norm_clip_value=0, _debug_keep_unclipped=True)
+        args["lr_max"] = 1e-30; args["lr_max_day"] = 1e-30; args["lr_min"] = 1e-30; args["lr_min_day"] = 1e-30
+        ts = TrainStep(model, args)
+        for rep in range(3):
+            loss, gnorm = ts.step(x.to(dev), day, tgt, nt, tl)
+            np.testing.assert_allclose(float(loss), float(lo), rtol=2e-5)
+            got = ts.last_unclipped_grads()
+            assert set(got) == set(go)
+            for k, ref in go.items():
+                np.testing.assert_allclose(got[k], ref, atol=1e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=f"{k} rep{rep}")
+        if mode == 1:
+            ops.gru_sync_check(model._ws.get("gru_sync", (N_sync(T),), dev, torch.int32), T, B)
+    finally:
+        ops.GRU_MODE["value"] = old
