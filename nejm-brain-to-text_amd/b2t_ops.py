@@ -344,7 +344,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     dY = ws.get("dY0", (Tp, B, H), dev)
     gemm(dlogits, prm.out_w, dY, M=M, N_=H, K=Cc, a_kc=1, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H, c_s0=H)
     gemm(dlogits, top[1:], grd.out_w, M=Cc, N_=H, K=M, a_kc=0, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H,
-         c_s0=H)
+         c_s0=H, splitk=splitk_for(Cc, H, M), ws=ws)
     colsum(dlogits, B * Tp, Cc, ldd, grd.out_b)
     if bucket_cb:
         bucket_cb("head")

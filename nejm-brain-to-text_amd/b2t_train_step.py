@@ -144,6 +144,14 @@ class TrainStep:
             b = dict((n, (a, e)) for n, a, e in bucket_spans(lay, model.n_layers))
             self.day_range = b["day"]
 
+    def freeze(self, names):
+        """Mark tensors as never-updated (requires_grad=False in the reference, rnn_trainer.py:249-254)."""
+        lay = self.model.layout()
+        sd = self.seg_day.cpu().numpy().copy()
+        for n in names:
+            sd[lay["names"].index(n)] = -2
+        self.seg_day.copy_(torch.from_numpy(sd).to(self.dev))
+
     # -- learning rates of the three groups for the current batch (rnn_trainer.py:294-363) ------------
     def current_lrs(self):
         a = self.args

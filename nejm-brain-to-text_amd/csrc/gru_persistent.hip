@@ -60,7 +60,7 @@ __device__ __forceinline__ void store_sc1(float* p, float v) { __hip_atomic_stor
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <int NCH>  // 16-wide K chunks per wave; covers H <= 64*NCH
+template <int NCH, int MT>  // NCH: 16-wide K chunks per wave (H <= 64*NCH); MT: row groups per workgroup
 __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
@@ -69,12 +69,11 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
                                                                  unsigned* sync) {
   __shared__ float red[4 * 3 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int j0 = blockIdx.x * 16;
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
-  const int row = m0 + 4 * q + wave, unit = j0 + j, arow = m0 + j;
-  unsigned* cnt = sync + (size_t)blockIdx.y * T;
-  unsigned* err = sync + (size_t)gridDim.y * T;
+  const int unit = j0 + j;
+  unsigned* err = sync + (size_t)gridDim.y * MT * T;
   const int nch = H / 16;
 
   float4 w[3][NCH];
@@ -87,10 +86,25 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
                          : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float bhr = b_hh[unit], bhz = b_hh[H + unit], bhn = b_hh[2 * H + unit];
-  const bool live = row < B;
-  float hp = live ? h_init[(long long)row * H + unit] : 0.f;
+  float hpv[MT];
+#pragma unroll
+  for (int rr = 0; rr < MT; ++rr) {
+    const int row = (blockIdx.y * MT + rr) * 16 + 4 * q + wave;
+    hpv[rr] = row < B ? h_init[(long long)row * H + unit] : 0.f;
+  }
 
   for (int t = 0; t < T; ++t) {
+#pragma unroll
+   for (int rr = 0; rr < MT; ++rr) {
+    // Row groups are independent recurrences: while the peers' h_{t-1} of group r is in flight,
+    // this workgroup is busy with the other groups (the hand-off latency hides behind their MFMAs).
+    const int rg = blockIdx.y * MT + rr;
+    const int m0 = rg * 16;
+    if (m0 >= B) continue;
+    const int row = m0 + 4 * q + wave, arow = m0 + j;
+    const bool live = row < B;
+    unsigned* cnt = sync + (size_t)rg * T;
+    float hp = hpv[rr];
     float gir = 0.f, giz = 0.f, gin = 0.f;
     if (live) {
       const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit;
@@ -136,7 +150,9 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
       }
       hp = h;
     }
+    hpv[rr] = hp;
     publish_count(cnt + t);  // also fences `red` for the next iteration
+   }
   }
 }
 
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
 // dGh_{t+1} row block with its register-resident W_hh[:, slice] and (B) forms the gate gradients of
 // step t for its slice, publishing them as dG[t] for the other workgroups of the row group.
 // ---------------------------------------------------------------------------------------------------
-template <int NCB>  // 16-wide chunks of the 3H contraction per wave; covers 3H <= 64*NCB
+template <int NCB, int MT>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
 __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __restrict__ dY,
                                                                  const float* __restrict__ dh_last,
                                                                  const float* __restrict__ reserve,
@@ -156,12 +172,11 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  unsigned* sync) {
   __shared__ float red[4 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int j0 = blockIdx.x * 16;
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
-  const int row = m0 + 4 * q + wave, unit = j0 + j, arow = m0 + j;
-  unsigned* cnt = sync + (size_t)blockIdx.y * T;
-  unsigned* err = sync + (size_t)gridDim.y * T;
+  const int unit = j0 + j;
+  unsigned* err = sync + (size_t)gridDim.y * MT * T;
   const int nch = 3 * H / 16;
 
   float4 w[NCB];
@@ -171,10 +186,20 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     w[ci] = c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit * 3 * H + c * 16 + 4 * q)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const bool live = row < B;
-  float dzterm = 0.f;
+  float dzv[MT];
+#pragma unroll
+  for (int rr = 0; rr < MT; ++rr) dzv[rr] = 0.f;
 
   for (int t = T - 1; t >= -1; --t) {
+#pragma unroll
+   for (int rr = 0; rr < MT; ++rr) {
+    const int rg = blockIdx.y * MT + rr;
+    const int m0 = rg * 16;
+    if (m0 >= B) continue;
+    const int row = m0 + 4 * q + wave, arow = m0 + j;
+    const bool live = row < B;
+    unsigned* cnt = sync + (size_t)rg * T;
+    float dzterm = dzv[rr];
     // operands of the elementwise part do not depend on the recurrence: fetch them first
     float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hprev = 0.f, dy = 0.f;
     if (live && t >= 0) {
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     }
     if (t < 0) {
       if (live) dh_init[(long long)row * H + unit] = carry;
-      break;
+      continue;
     }
     if (live) {
       const float d = dy + carry;
@@ -226,7 +251,9 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       store_sc1(dg + 3 * H, dn_pre);
       dzterm = d * z;
     }
+    dzv[rr] = dzterm;
     publish_count(cnt + t);
+   }
   }
 }
 
@@ -243,8 +270,13 @@ static int cu_count() {
   return n;
 }
 
+// Row groups per workgroup: 2 halves the workgroup count (weights are shared by the groups) and lets each
+// workgroup overlap one group's hand-off latency with the other group's MFMAs.
+static int pick_mt(int B) { (void)B; return 1; }  // MT=2 measured 2x slower per sweep: the exposed latencies are the workgroup's own load/drain, not the peers'
+
 static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
-  const int gx = H / 16, gy = (B + 15) / 16;
+  const int mt = pick_mt(B);
+  const int gx = H / 16, gy = ((B + 15) / 16 + mt - 1) / mt;
   if (!sync_ws) { set_error("%s: sync_ws is required in persistent mode", what); return 2; }
   if (gy > 64) { set_error("%s: B=%d exceeds 1024 rows in persistent mode", what, B); return 2; }
   const int cus = cu_count();
@@ -261,13 +293,20 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
                        float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
-  dim3 grid(H / 16, (B + 15) / 16), block(256);
+  const int mt = pick_mt(B);
+  dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * T + 16) * sizeof(unsigned), s), "gru_layer_fwd: memset");
+  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T + 16) * sizeof(unsigned), s), "gru_layer_fwd: memset");
   if (rc) return rc;
-#define B2T_LAUNCH_FWD(NCH)                                                                                         \
-  hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, H, \
-                     sync)
+#define B2T_LAUNCH_FWD(NCH)                                                                                            \
+  do {                                                                                                                 \
+    if (mt == 2)                                                                                                       \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 2>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                         B, H, sync);                                                                                  \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 1>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                         B, H, sync);                                                                                  \
+  } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
   else if (H <= 512) B2T_LAUNCH_FWD(8);
@@ -283,13 +322,20 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
                        void* sync_ws, hipStream_t s) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
-  dim3 grid(H / 16, (B + 15) / 16), block(256);
+  const int mt = pick_mt(B);
+  dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * T + 16) * sizeof(unsigned), s), "gru_layer_bwd: memset");
+  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T + 16) * sizeof(unsigned), s), "gru_layer_bwd: memset");
   if (rc) return rc;
-#define B2T_LAUNCH_BWD(NCB)                                                                                          \
-  hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG, \
-                     dh_init, T, B, H, sync)
+#define B2T_LAUNCH_BWD(NCB)                                                                                           \
+  do {                                                                                                                \
+    if (mt == 2)                                                                                                      \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 2>), grid, block, 0, s, dY, dh_last, reserve, out, h_init,      \
+                         w_hh_t, dG, dh_init, T, B, H, sync);                                                         \
+    else                                                                                                              \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 1>), grid, block, 0, s, dY, dh_last, reserve, out, h_init,      \
+                         w_hh_t, dG, dh_init, T, B, H, sync);                                                         \
+  } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);
   else if (H <= 256) B2T_LAUNCH_BWD(12);
   else if (H <= 512) B2T_LAUNCH_BWD(24);
@@ -306,7 +352,8 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
 extern "C" int b2t_gru_sync_status(const void* sync_ws, int T, int B, int* status_host, void* stream) {
   using namespace b2t;
   B2T_REQUIRE(sync_ws && status_host, "gru_sync_status: null argument");
-  const size_t off = (size_t)((B + 15) / 16) * T;
+  const int mt = b2t::pick_mt(B);
+  const size_t off = (size_t)(((B + 15) / 16 + mt - 1) / mt) * mt * T;
   int rc = check_hip(hipMemcpyAsync(status_host, reinterpret_cast<const unsigned*>(sync_ws) + off, sizeof(int),
                                     hipMemcpyDeviceToHost, as_stream(stream)), "gru_sync_status: copy");
   if (rc) return rc;

@@ -21,7 +21,9 @@ __global__ void opt_prepare_kernel(const int32_t* __restrict__ day_idx, int B, c
   if (s >= nseg) return;
   const int d = seg_day[s];
   int a = 1;
-  if (d >= 0) {
+  if (d == -2) {          // frozen tensor (requires_grad = False: rnn_trainer.py:249-254)
+    a = 0;
+  } else if (d >= 0) {
     a = 0;
     for (int b = 0; b < B; ++b) a |= (day_idx[b] == d);
   }

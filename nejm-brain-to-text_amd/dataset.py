@@ -1,0 +1,209 @@
+"""Batch sources with the reference's batch-dict contract (model_training/dataset.py:100-159):
+    input_features [B,T,F] f32 zero-padded · seq_class_ids [B,S] zero-padded · n_time_steps [B] ·
+    phone_seq_lens [B] · day_indicies [B] · transcriptions [B,*] · block_nums [B] · trial_nums [B]
+
+`BrainToTextDataset` / `train_test_split_indicies` keep the reference's constructor arguments and
+sampling semantics (day-balanced random training batches drawn with replacement; validation batches
+that visit every trial once, one day per batch) and read the same HDF5 layout
+(groups `trial_%04d` with datasets input_features / seq_class_ids / transcription and attrs
+n_time_steps / seq_len / block_num / trial_num).  h5py is imported lazily: it is only needed when real
+session files are used.  `SyntheticTrials` produces the same dict from seeded random data so the
+trainer, tests and benchmarks run without the Dryad download.
+(Row f1 of SURVEY §8 — a GPU-resident flat-binary loader — is the planned successor of the HDF5 path.)
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pad_sequence
+from torch.utils.data import Dataset
+
+
+def _collate(feats, labels, trans, n_steps, seq_lens, days, blocks, trials):
+    return {
+        'input_features': pad_sequence(feats, batch_first=True, padding_value=0),
+        'seq_class_ids': pad_sequence(labels, batch_first=True, padding_value=0),
+        'n_time_steps': torch.tensor(n_steps),
+        'phone_seq_lens': torch.tensor(seq_lens),
+        'day_indicies': torch.tensor(days),
+        'transcriptions': torch.stack(trans) if trans else torch.zeros((0, 1), dtype=torch.int64),
+        'block_nums': torch.tensor(blocks),
+        'trial_nums': torch.tensor(trials),
+    }
+
+
+class BrainToTextDataset(Dataset):
+    """Each item is a whole batch.  split='train': n_batches random batches, each made of
+    `days_per_batch` distinct days with ceil(batch_size/days_per_batch) trials per day sampled with
+    replacement, surplus trials removed from random days; split='test': consecutive slices of each day."""
+
+    def __init__(self, trial_indicies, n_batches, split='train', batch_size=64, days_per_batch=1, random_seed=-1,
+                 must_include_days=None, feature_subset=None):
+        if random_seed != -1:
+            np.random.seed(random_seed)
+            torch.manual_seed(random_seed)
+        if split not in ('train', 'test'):
+            raise ValueError(f'split must be either "train" or "test". Received {split}')
+        self.split, self.batch_size, self.days_per_batch = split, batch_size, days_per_batch
+        self.trial_indicies = trial_indicies
+        self.n_days = len(trial_indicies)
+        self.n_trials = sum(len(v['trials']) for v in trial_indicies.values())
+        self.feature_subset = feature_subset
+        if must_include_days is not None:
+            if len(must_include_days) > (days_per_batch or 0):
+                raise ValueError('must_include_days must be less than or equal to days_per_batch')
+            must_include_days = [d if d >= 0 else self.n_days + d for d in must_include_days]
+        self.must_include_days = must_include_days
+        if split == 'train':
+            if days_per_batch > self.n_days:
+                raise ValueError(f'Requested days_per_batch: {days_per_batch} is greater than available days {self.n_days}.')
+            self.n_batches = n_batches
+            self.batch_index = self._index_train()
+        else:
+            self.batch_index = self._index_test()
+            self.n_batches = len(self.batch_index)
+
+    def __len__(self):
+        return self.n_batches
+
+    def _index_train(self):
+        days_all = list(self.trial_indicies.keys())
+        fixed = list(self.must_include_days) if self.must_include_days else []
+        free = [d for d in days_all if d not in fixed]
+        per_day = math.ceil(self.batch_size / self.days_per_batch)
+        index = {}
+        for bi in range(self.n_batches):
+            if fixed:
+                extra = np.random.choice(free, size=self.days_per_batch - len(fixed), replace=False)
+                days = np.concatenate((fixed, extra))
+            else:
+                days = np.random.choice(days_all, size=self.days_per_batch, replace=False)
+            picks = {d: np.random.choice(self.trial_indicies[d]['trials'], size=per_day, replace=True) for d in days}
+            surplus = per_day * len(days) - self.batch_size
+            while surplus > 0:
+                d = np.random.choice(days)
+                picks[d] = picks[d][:-1]
+                surplus -= 1
+            index[bi] = picks
+        return index
+
+    def _index_test(self):
+        index, bi = {}, 0
+        for d, info in self.trial_indicies.items():
+            trials = info['trials']
+            for s in range(0, len(trials), self.batch_size):
+                index[bi] = {d: trials[s:s + self.batch_size]}
+                bi += 1
+        return index
+
+    def __getitem__(self, idx):
+        import h5py
+        feats, labels, trans, n_steps, seq_lens, days, blocks, trials = [], [], [], [], [], [], [], []
+        for d, tlist in self.batch_index[idx].items():
+            with h5py.File(self.trial_indicies[d]['session_path'], 'r') as f:
+                for t in tlist:
+                    try:
+                        g = f[f'trial_{t:04d}']
+                        x = torch.from_numpy(g['input_features'][:])
+                        if self.feature_subset:
+                            x = x[:, self.feature_subset]
+                        feats.append(x)
+                        labels.append(torch.from_numpy(g['seq_class_ids'][:]))
+                        trans.append(torch.from_numpy(g['transcription'][:]))
+                        n_steps.append(g.attrs['n_time_steps'])
+                        seq_lens.append(g.attrs['seq_len'])
+                        days.append(int(d))
+                        blocks.append(g.attrs['block_num'])
+                        trials.append(g.attrs['trial_num'])
+                    except Exception as e:  # the reference logs and skips unreadable trials (dataset.py:144-146)
+                        print(f'Error loading trial {t} from session {self.trial_indicies[d]["session_path"]}: {e}')
+        return _collate(feats, labels, trans, n_steps, seq_lens, days, blocks, trials)
+
+
+def train_test_split_indicies(file_paths, test_percentage=0.1, seed=-1, bad_trials_dict=None):
+    """Per-day trial lists for the train / test splits: {day: {'trials': [...], 'session_path': path}}."""
+    if seed != -1:
+        np.random.seed(seed)
+    per_day = {}
+    for i, path in enumerate(file_paths):
+        sess = [s for s in path.split('/') if s.startswith('t15.20') or s.startswith('t12.20')]
+        session = sess[0] if sess else os.path.basename(os.path.dirname(path))
+        good = []
+        if os.path.exists(path):
+            import h5py
+            with h5py.File(path, 'r') as f:
+                for t in range(len(list(f.keys()))):
+                    g = f[f'trial_{t:04d}']
+                    bn, tn = g.attrs['block_num'], g.attrs['trial_num']
+                    bad = (bad_trials_dict is not None and session in bad_trials_dict
+                           and str(bn) in bad_trials_dict[session] and tn in bad_trials_dict[session][str(bn)])
+                    if not bad:
+                        good.append(t)
+        per_day[i] = (good, path)
+    train, test = {}, {}
+    for day, (good, path) in per_day.items():
+        if test_percentage == 0:
+            tr, te = good, []
+        elif test_percentage == 1:
+            tr, te = [], good
+        else:
+            n_test = max(1, int(len(good) * test_percentage))
+            te = np.random.choice(good, size=n_test, replace=False).tolist()
+            tr = [t for t in good if t not in te]
+        train[day] = {'trials': tr, 'session_path': path}
+        test[day] = {'trials': te, 'session_path': path}
+    return train, test
+
+
+class SyntheticTrials(Dataset):
+    """Seeded synthetic stand-in with the same batch dict: class-dependent templates + noise so that a
+    short training run measurably lowers the CTC loss / PER (used by tests and examples)."""
+
+    def __init__(self, n_batches, batch_size, n_days, n_features, n_classes, days_per_batch, max_T=120, min_T=60,
+                 max_S=12, seed=0, one_day_per_batch=False):
+        self.n_batches, self.B, self.D, self.F, self.C = n_batches, batch_size, n_days, n_features, n_classes
+        self.dpb, self.max_T, self.min_T, self.max_S, self.seed = days_per_batch, max_T, min_T, max_S, seed
+        self.one_day = one_day_per_batch
+        g = np.random.default_rng(1234)
+        self.templates = g.standard_normal((n_classes, n_features)).astype(np.float32)
+        self.day_gain = (1.0 + 0.1 * g.standard_normal((n_days, n_features))).astype(np.float32)
+
+    def __len__(self):
+        return self.n_batches
+
+    def __getitem__(self, idx):
+        g = np.random.default_rng(self.seed * 1000003 + idx)
+        if self.one_day:
+            days = np.full(self.B, idx % self.D)
+        else:
+            chosen = g.choice(self.D, size=min(self.dpb, self.D), replace=False)
+            days = np.repeat(chosen, math.ceil(self.B / len(chosen)))[:self.B]
+        feats, labels, n_steps, seq_lens = [], [], [], []
+        for b in range(self.B):
+            S = int(g.integers(3, self.max_S + 1))
+            lab = g.integers(1, self.C, S)
+            T = int(g.integers(max(self.min_T, 6 * S), self.max_T + 1))
+            bounds = np.sort(g.choice(np.arange(1, T), size=S - 1, replace=False)) if S > 1 else np.array([], int)
+            seg = np.searchsorted(bounds, np.arange(T), side='right')
+            x = self.templates[lab[seg]] * self.day_gain[days[b]] + 0.5 * g.standard_normal((T, self.F)).astype(np.float32)
+            feats.append(torch.from_numpy(x.astype(np.float32)))
+            labels.append(torch.from_numpy(lab.astype(np.int64)))
+            n_steps.append(T)
+            seq_lens.append(S)
+        trans = [torch.zeros(4, dtype=torch.int64) for _ in range(self.B)]
+        return _collate(feats, labels, trans, n_steps, seq_lens, [int(d) for d in days], [0] * self.B,
+                        list(range(self.B)))
+
+
+def make_synthetic_datasets(args):
+    dsa = args['dataset']
+    syn = dsa['synthetic'] if isinstance(dsa['synthetic'], dict) else {}
+    kw = dict(batch_size=dsa['batch_size'], n_days=len(dsa['sessions']), n_features=args['model']['n_input_features'],
+              n_classes=dsa['n_classes'], days_per_batch=dsa['days_per_batch'], max_T=syn.get('max_T', 120),
+              min_T=syn.get('min_T', 60), max_S=syn.get('max_S', 12))
+    train = SyntheticTrials(args['num_training_batches'], seed=dsa.get('seed', 1), **kw)
+    val = SyntheticTrials(syn.get('val_batches', 4), seed=10_000 + dsa.get('seed', 1), one_day_per_batch=True, **kw)
+    return train, val

@@ -1,2 +1,455 @@
-"""Placeholder import surface; the full trainer is defined below in this module."""
-from b2t_train_step import TrainStep, GradReducer, cosine_lr_factor, param_group_of, bucket_spans  # noqa: F401
+"""BrainToTextDecoder_Trainer — MI355X-native drop-in for model_training/rnn_trainer.py:27-770.
+
+Same constructor argument (the rnn_args.yaml dict), same public methods and return values
+(`train()` -> {'train_losses','val_losses','val_PERs','val_metrics'}, `validation(loader, return_logits,
+return_data)`, `transform_data`, `create_optimizer`, `create_cosine_lr_scheduler`,
+`load/save_model_checkpoint`), same log lines and checkpoint dict keys — but the step body
+(rnn_trainer.py:513-558) is the fused HIP TrainStep (b2t_train_step.py): no autograd graph, no
+torch.compile, fp32 MFMA kernels, gradient arena + single-launch clip/AdamW, optional data-parallel
+all-reduce over RCCL when launched under torch.distributed (one process per GPU).
+
+Differences from the reference that are deliberate and documented:
+  * patch_size == 0 works (the reference divides by patch_stride=0 at :532/:707);
+  * `use_amp` is accepted and ignored: this path computes in fp32 (BASELINE config 2);
+  * `self.optimizer` / `self.learning_rate_scheduler` are light adapters over TrainStep exposing
+    `param_groups`, `state_dict()`, `load_state_dict()` in torch.optim.AdamW / LambdaLR format so that
+    checkpoints interoperate (keys carry the reference's `_orig_mod.` prefix).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import pathlib
+import pickle
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+import b2t_ops as ops
+from b2t_train_step import (GradReducer, TrainStep, bucket_spans, cosine_lr_factor,  # noqa: F401 (re-exported)
+                            param_group_of)
+from rnn_model import GRUDecoder
+
+CKPT_PREFIX = "_orig_mod."   # the reference wraps the model in torch.compile (rnn_trainer.py:134)
+
+
+class HipCTCLoss:
+    """Callable with torch.nn.CTCLoss(blank=0, reduction='none', zero_infinity=False)'s call surface
+    (rnn_trainer.py:242): ctc_loss(log_probs[T,B,C], targets, input_lengths, target_lengths) -> [B]."""
+
+    def __init__(self):
+        self._ws = ops.Workspace()
+
+    def __call__(self, log_probs, targets, input_lengths, target_lengths):
+        lp = log_probs.permute(1, 0, 2).contiguous().float()    # kernel normalises again: a no-op on log-probs
+        loss, _, _ = ops.ctc_loss(lp, targets, input_lengths, target_lengths, False, 1.0, self._ws)
+        return loss
+
+
+class _OptimizerAdapter:
+    def __init__(self, ts: TrainStep):
+        self._ts = ts
+
+    @property
+    def param_groups(self):
+        return self._ts.optimizer_state_dict()["param_groups"]
+
+    def state_dict(self):
+        return self._ts.optimizer_state_dict()
+
+    def load_state_dict(self, sd):
+        self._ts.load_optimizer_state_dict(sd)
+
+    def zero_grad(self, set_to_none=True):
+        pass   # gradients are overwritten every step
+
+
+class _SchedulerAdapter:
+    def __init__(self, ts: TrainStep):
+        self._ts = ts
+
+    def state_dict(self):
+        return dict(last_epoch=self._ts.it, _step_count=self._ts.it + 1, _last_lr=self._ts.current_lrs())
+
+    def load_state_dict(self, sd):
+        self._ts.it = int(sd.get("last_epoch", 0))
+
+    def get_last_lr(self):
+        return self._ts.current_lrs()
+
+
+def _strip_prefix(sd):
+    out = {}
+    for k, v in sd.items():
+        out[k.replace("module.", "").replace("_orig_mod.", "")] = v
+    return out
+
+
+class BrainToTextDecoder_Trainer:
+    def __init__(self, args):
+        self.args = args
+        self.logger = None
+        self.device = None
+        self.model = None
+        self.optimizer = None
+        self.learning_rate_scheduler = None
+        self.ctc_loss = None
+        self.best_val_PER = torch.inf
+        self.best_val_loss = torch.inf
+        self.train_dataset = self.val_dataset = self.train_loader = self.val_loader = None
+        self.transform_args = self.args['dataset']['data_transforms']
+
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.is_main = self.rank == 0
+
+        if args['mode'] == 'train' and self.is_main:
+            os.makedirs(self.args['output_dir'], exist_ok=False)
+        if (args['save_best_checkpoint'] or args['save_all_val_steps'] or args['save_final_model']) and self.is_main:
+            os.makedirs(self.args['checkpoint_dir'], exist_ok=False)
+
+        self.logger = logging.getLogger(__name__)
+        for h in self.logger.handlers[:]:
+            self.logger.removeHandler(h)
+        self.logger.setLevel(logging.INFO if self.is_main else logging.WARNING)
+        fmt = logging.Formatter(fmt='%(asctime)s: %(message)s')
+        if args['mode'] == 'train' and self.is_main:
+            fh = logging.FileHandler(str(pathlib.Path(self.args['output_dir'], 'training_log')))
+            fh.setFormatter(fmt)
+            self.logger.addHandler(fh)
+        sh = logging.StreamHandler(sys.stdout)
+        sh.setFormatter(fmt)
+        self.logger.addHandler(sh)
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("BrainToTextDecoder_Trainer needs an MI355X: this package has no CPU compute path")
+        if self.world > 1:
+            gpu_num = int(os.environ.get("LOCAL_RANK", "0"))
+        else:
+            try:
+                gpu_num = int(self.args.get('gpu_number', 0))
+            except ValueError:
+                self.logger.warning(f"Invalid gpu_number value: {self.args.get('gpu_number')}. Using 0 instead.")
+                gpu_num = 0
+            if gpu_num > torch.cuda.device_count() - 1:
+                self.logger.warning(f"Requested GPU {gpu_num} not available. Using GPU 0 instead.")
+                gpu_num = 0
+        self.device = torch.device(f"cuda:{gpu_num}")
+        torch.cuda.set_device(self.device)
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=self.device)
+        self.logger.info(f'Using device: {self.device}')
+
+        if self.args['seed'] != -1:
+            np.random.seed(self.args['seed'])
+            random.seed(self.args['seed'])
+            torch.manual_seed(self.args['seed'])
+
+        self.model = GRUDecoder(
+            neural_dim=self.args['model']['n_input_features'],
+            n_units=self.args['model']['n_units'],
+            n_days=len(self.args['dataset']['sessions']),
+            n_classes=self.args['dataset']['n_classes'],
+            rnn_dropout=self.args['model']['rnn_dropout'],
+            input_dropout=self.args['model']['input_network']['input_layer_dropout'],
+            n_layers=self.args['model']['n_layers'],
+            patch_size=self.args['model']['patch_size'],
+            patch_stride=self.args['model']['patch_stride'],
+        )
+        self.logger.info("Initialized RNN decoding model (HIP/gfx950 path)")
+        self.logger.info(self.model)
+        total_params = sum(p.numel() for p in self.model.parameters())
+        self.logger.info(f"Model has {total_params:,} parameters")
+        day_params = sum(p.numel() for n, p in self.model.named_parameters() if 'day' in n)
+        self.logger.info(f"Model has {day_params:,} day-specific parameters | {((day_params / total_params) * 100):.2f}% of total parameters")
+
+        self._build_datasets()
+
+        for name, param in self.model.named_parameters():
+            if not self.args['model']['rnn_trainable'] and 'gru' in name:
+                param.requires_grad = False
+            elif not self.args['model']['input_network']['input_trainable'] and 'day' in name:
+                param.requires_grad = False
+        self.model.to(self.device)
+
+        self.optimizer = self.create_optimizer()
+        if self.args['lr_scheduler_type'] == 'cosine':
+            self.learning_rate_scheduler = self.create_cosine_lr_scheduler(self.optimizer)
+        elif self.args['lr_scheduler_type'] == 'linear':
+            raise ValueError("lr_scheduler_type 'linear' is not built on the HIP path; use 'cosine' (rnn_args.yaml default)")
+        else:
+            raise ValueError(f"Invalid learning rate scheduler type: {self.args['lr_scheduler_type']}")
+        self.ctc_loss = HipCTCLoss()
+        if self.args['init_from_checkpoint']:
+            self.load_model_checkpoint(self.args['init_checkpoint_path'])
+
+    # ------------------------------------------------------------------ data ---------------------
+    def _build_datasets(self):
+        import dataset as ds
+        a = self.args
+        dsa = a['dataset']
+        feature_subset = dsa.get('feature_subset')
+        if dsa.get('synthetic'):
+            self.train_dataset, self.val_dataset = ds.make_synthetic_datasets(a)
+        else:
+            train_paths = [os.path.join(dsa["dataset_dir"], s, 'data_train.hdf5') for s in dsa['sessions']]
+            val_paths = [os.path.join(dsa["dataset_dir"], s, 'data_val.hdf5') for s in dsa['sessions']]
+            if len(set(train_paths)) != len(train_paths):
+                raise ValueError("There are duplicate sessions listed in the train dataset")
+            if len(set(val_paths)) != len(val_paths):
+                raise ValueError("There are duplicate sessions listed in the val dataset")
+            train_trials, _ = ds.train_test_split_indicies(train_paths, test_percentage=0, seed=dsa['seed'])
+            _, val_trials = ds.train_test_split_indicies(val_paths, test_percentage=1, seed=dsa['seed'])
+            if self.is_main and a['mode'] == 'train':
+                with open(os.path.join(a['output_dir'], 'train_val_trials.json'), 'w') as f:
+                    json.dump({'train': train_trials, 'val': val_trials}, f)
+            if feature_subset is not None:
+                self.logger.info(f'Using only a subset of features: {feature_subset}')
+            self.train_dataset = ds.BrainToTextDataset(
+                trial_indicies=train_trials, split='train', days_per_batch=dsa['days_per_batch'],
+                n_batches=a['num_training_batches'], batch_size=dsa['batch_size'], must_include_days=None,
+                random_seed=dsa['seed'], feature_subset=feature_subset)
+            self.val_dataset = ds.BrainToTextDataset(
+                trial_indicies=val_trials, split='test', days_per_batch=None, n_batches=None,
+                batch_size=dsa['batch_size'], must_include_days=None, random_seed=dsa['seed'],
+                feature_subset=feature_subset)
+        nw = dsa.get('num_dataloader_workers', 0)
+        self.train_loader = DataLoader(self.train_dataset, batch_size=None, shuffle=dsa.get('loader_shuffle', False),
+                                       num_workers=nw, pin_memory=True)
+        self.val_loader = DataLoader(self.val_dataset, batch_size=None, shuffle=False, num_workers=0, pin_memory=True)
+        if 'dataset_probability_val' not in dsa:
+            dsa['dataset_probability_val'] = [1] * len(dsa['sessions'])
+        self.logger.info("Successfully initialized datasets")
+
+    # ------------------------------------------------------------------ optimizer ----------------
+    def create_optimizer(self):
+        """AdamW with the reference's three parameter groups (rnn_trainer.py:259-292), realised as the
+        flat-arena TrainStep; returns an adapter with torch-format state_dict()."""
+        flat = {k: self.args[k] for k in ('lr_max', 'lr_min', 'lr_decay_steps', 'lr_warmup_steps', 'lr_max_day',
+                                          'lr_min_day', 'lr_decay_steps_day', 'lr_warmup_steps_day', 'beta0', 'beta1',
+                                          'epsilon', 'weight_decay', 'weight_decay_day', 'grad_norm_clip_value')}
+        self.train_step = TrainStep(self.model, flat)
+        frozen = [n for n, p in self.model.named_parameters() if not p.requires_grad]
+        if frozen:
+            self.train_step.freeze(frozen)
+        return _OptimizerAdapter(self.train_step)
+
+    def create_cosine_lr_scheduler(self, optim):
+        return _SchedulerAdapter(self.train_step)
+
+    # ------------------------------------------------------------------ checkpoints --------------
+    def load_model_checkpoint(self, load_path):
+        checkpoint = torch.load(load_path, weights_only=False, map_location="cpu")
+        self.model.load_state_dict(_strip_prefix(checkpoint['model_state_dict']))
+        self.model.to(self.device)
+        if 'optimizer_state_dict' in checkpoint:
+            self.optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        if 'scheduler_state_dict' in checkpoint:
+            self.learning_rate_scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
+        self.best_val_PER = checkpoint['val_PER']
+        self.best_val_loss = checkpoint['val_loss'] if 'val_loss' in checkpoint.keys() else torch.inf
+        self.logger.info("Loaded model from checkpoint: " + load_path)
+
+    def save_model_checkpoint(self, save_path, PER, loss=None):
+        if not self.is_main:
+            return
+        checkpoint = {
+            'model_state_dict': {CKPT_PREFIX + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+            'optimizer_state_dict': self.optimizer.state_dict(),
+            'scheduler_state_dict': self.learning_rate_scheduler.state_dict(),
+            'val_PER': PER,
+            'val_loss': loss,
+        }
+        torch.save(checkpoint, save_path)
+        self.logger.info("Saved model to checkpoint: " + save_path)
+        with open(os.path.join(self.args['checkpoint_dir'], 'args.yaml'), 'w') as f:
+            try:
+                from omegaconf import OmegaConf
+                OmegaConf.save(config=self.args, f=f)
+            except ImportError:
+                import yaml
+                yaml.safe_dump(_to_plain(self.args), f)
+
+    # ------------------------------------------------------------------ augmentation -------------
+    def transform_data(self, features, n_time_steps, mode='train'):
+        """Noise -> cut -> smoothing in ONE fused kernel pass (reference order, rnn_trainer.py:455-481).
+        Static gain / random walk (std 0 in rnn_args.yaml:64,66) are not built: non-zero values raise."""
+        ta = self.transform_args
+        if mode == 'train' and (ta.get('static_gain_std', 0) > 0 or ta.get('random_walk_std', 0) > 0):
+            raise NotImplementedError("static_gain_std / random_walk_std > 0 are not built on the HIP path")
+        cut, ws_, os_ = 0, 0.0, 0.0
+        if mode == 'train':
+            ws_, os_ = float(ta['white_noise_std']), float(ta['constant_offset_std'])
+            if ta['random_cut'] > 0:
+                cut = int(np.random.randint(0, ta['random_cut']))
+        features = features.to(self.device, torch.float32).contiguous()
+        seed = int(np.random.randint(0, 2 ** 31 - 1)) if (ws_ > 0 or os_ > 0) else 0
+        out = ops.augment_smooth(features, ta['smooth_kernel_std'], ta['smooth_kernel_size'], 'same', cut=cut,
+                                 white_std=ws_, offset_std=os_, seed=seed, smooth=bool(ta['smooth_data']))
+        return out, n_time_steps - cut
+
+    # ------------------------------------------------------------------ train --------------------
+    def train(self):
+        self.model.train()
+        train_losses, val_losses, val_PERs, val_results = [], [], [], []
+        val_steps_since_improvement = 0
+        save_best_checkpoint = self.args.get('save_best_checkpoint', True)
+        early_stopping = self.args.get('early_stopping', True)
+        early_stopping_val_steps = self.args['early_stopping_val_steps']
+        train_start_time = time.time()
+        i = -1
+        for i, batch in enumerate(self.train_loader):
+            if self.world > 1 and (i % self.world) != self.rank:
+                continue                       # shard the pre-generated batch index across ranks
+            self.model.train()
+            start_time = time.time()
+            features = batch['input_features'].to(self.device, non_blocking=True)
+            labels = batch['seq_class_ids'].to(self.device, non_blocking=True)
+            n_time_steps = batch['n_time_steps'].to(self.device, non_blocking=True)
+            phone_seq_lens = batch['phone_seq_lens'].to(self.device, non_blocking=True)
+            day_indicies = batch['day_indicies']
+            features, n_time_steps = self.transform_data(features, n_time_steps, 'train')
+            loss, grad_norm = self.train_step.step(features, day_indicies, labels, n_time_steps, phone_seq_lens)
+            lossv = loss.item()                # per-step host sync, like the reference (:562)
+            gnv = grad_norm.item()
+            if not np.isfinite(gnv):           # clip_grad_norm_(error_if_nonfinite=True), :551-555
+                raise RuntimeError(f"The total norm for gradients is non-finite ({gnv}), so it cannot be clipped")
+            train_step_duration = time.time() - start_time
+            train_losses.append(lossv)
+            if i % self.args['batches_per_train_log'] == 0:
+                self.logger.info(f'Train batch {i}: ' + f'loss: {lossv:.2f} ' + f'grad norm: {gnv:.2f} '
+                                 f'time: {train_step_duration:.3f}')
+            if i % self.args['batches_per_val_step'] == 0 or i == (self.args['num_training_batches'] - 1):
+                self.logger.info(f"Running test after training batch: {i}")
+                start_time = time.time()
+                val_metrics = self.validation(loader=self.val_loader, return_logits=self.args['save_val_logits'],
+                                              return_data=self.args['save_val_data'])
+                val_step_duration = time.time() - start_time
+                self.logger.info(f'Val batch {i}: ' + f'PER (avg): {val_metrics["avg_PER"]:.4f} ' +
+                                 f'CTC Loss (avg): {val_metrics["avg_loss"]:.4f} ' + f'time: {val_step_duration:.3f}')
+                if self.args['log_individual_day_val_PER']:
+                    for day in val_metrics['day_PERs'].keys():
+                        dp = val_metrics['day_PERs'][day]
+                        if dp['total_seq_length'] > 0:
+                            self.logger.info(f"{self.args['dataset']['sessions'][day]} val PER: "
+                                             f"{dp['total_edit_distance'] / dp['total_seq_length']:0.4f}")
+                val_PERs.append(val_metrics['avg_PER'])
+                val_losses.append(val_metrics['avg_loss'])
+                val_results.append(val_metrics)
+                new_best = False
+                if val_metrics['avg_PER'] < self.best_val_PER:
+                    self.logger.info(f"New best test PER {self.best_val_PER:.4f} --> {val_metrics['avg_PER']:.4f}")
+                    self.best_val_PER, self.best_val_loss, new_best = val_metrics['avg_PER'], val_metrics['avg_loss'], True
+                elif val_metrics['avg_PER'] == self.best_val_PER and (val_metrics['avg_loss'] < self.best_val_loss):
+                    self.logger.info(f"New best test loss {self.best_val_loss:.4f} --> {val_metrics['avg_loss']:.4f}")
+                    self.best_val_loss, new_best = val_metrics['avg_loss'], True
+                if new_best:
+                    if save_best_checkpoint:
+                        self.logger.info("Checkpointing model")
+                        self.save_model_checkpoint(f'{self.args["checkpoint_dir"]}/best_checkpoint', self.best_val_PER,
+                                                   self.best_val_loss)
+                    if self.args['save_val_metrics'] and self.is_main:
+                        with open(f'{self.args["checkpoint_dir"]}/val_metrics.pkl', 'wb') as f:
+                            pickle.dump(val_metrics, f)
+                    val_steps_since_improvement = 0
+                else:
+                    val_steps_since_improvement += 1
+                if self.args['save_all_val_steps']:
+                    self.save_model_checkpoint(f'{self.args["checkpoint_dir"]}/checkpoint_batch_{i}',
+                                               val_metrics['avg_PER'], val_metrics['avg_loss'])
+                if early_stopping and (val_steps_since_improvement >= early_stopping_val_steps):
+                    self.logger.info(f'Overall validation PER has not improved in {early_stopping_val_steps} '
+                                     f'validation steps. Stopping training early at batch: {i}')
+                    break
+        training_duration = time.time() - train_start_time
+        self.logger.info(f'Best avg val PER achieved: {self.best_val_PER:.5f}')
+        self.logger.info(f'Total training time: {(training_duration / 60):.2f} minutes')
+        if self.args['save_final_model'] and val_PERs:
+            self.save_model_checkpoint(f'{self.args["checkpoint_dir"]}/final_checkpoint_batch_{i}', val_PERs[-1],
+                                       val_losses[-1])
+        return {'train_losses': train_losses, 'val_losses': val_losses, 'val_PERs': val_PERs, 'val_metrics': val_results}
+
+    # ------------------------------------------------------------------ validation ---------------
+    def validation(self, loader, return_logits=False, return_data=False):
+        """Greedy-CTC PER on the validation set (rnn_trainer.py:653-770): forward, CTC loss, argmax /
+        collapse / blank removal and Levenshtein distance all run on the GPU; one host copy per batch."""
+        self.model.eval()
+        metrics = {}
+        if return_logits:
+            metrics['logits'] = []
+            metrics['n_time_steps'] = []
+        if return_data:
+            metrics['input_features'] = []
+        for k in ('decoded_seqs', 'true_seq', 'phone_seq_lens', 'transcription', 'losses', 'block_nums', 'trial_nums',
+                  'day_indicies'):
+            metrics[k] = []
+        total_edit_distance = 0
+        total_seq_length = 0
+        day_per = {}
+        pv = self.args['dataset']['dataset_probability_val']
+        for d in range(len(self.args['dataset']['sessions'])):
+            if pv[d] == 1:
+                day_per[d] = {'total_edit_distance': 0, 'total_seq_length': 0}
+        for i, batch in enumerate(loader):
+            day = int(batch['day_indicies'][0].item())
+            if pv[day] == 0:
+                if self.args['log_val_skip_logs']:
+                    self.logger.info(f"Skipping validation on day {day}")
+                continue
+            features = batch['input_features'].to(self.device)
+            labels = batch['seq_class_ids'].to(self.device)
+            n_time_steps = batch['n_time_steps'].to(self.device)
+            phone_seq_lens = batch['phone_seq_lens'].to(self.device)
+            with torch.no_grad():
+                features, n_time_steps = self.transform_data(features, n_time_steps, 'val')
+                adjusted_lens = self.train_step.adjusted_lens(n_time_steps)
+                logits = self.model(features, batch['day_indicies'])
+                loss_b, _, _ = ops.ctc_loss(logits, labels, adjusted_lens, phone_seq_lens, False, 1.0, self.model._ws)
+                loss = loss_b.mean()
+                ids, lens, _ = ops.greedy_decode(logits, adjusted_lens)
+                dist = ops.edit_distance(ids, lens, labels, phone_seq_lens)
+            metrics['losses'].append(loss.cpu().detach().numpy())
+            ids_h, lens_h = ids.cpu().numpy(), lens.cpu().numpy()
+            decoded_seqs = [ids_h[b, :lens_h[b]].astype(np.int64) for b in range(ids_h.shape[0])]
+            batch_edit_distance = int(dist.sum().item())
+            day_per[day]['total_edit_distance'] += batch_edit_distance
+            day_per[day]['total_seq_length'] += torch.sum(phone_seq_lens).item()
+            total_edit_distance += batch_edit_distance
+            total_seq_length += torch.sum(phone_seq_lens).item()
+            if return_logits:
+                metrics['logits'].append(logits.cpu().float().numpy())
+                metrics['n_time_steps'].append(adjusted_lens.cpu().numpy())
+            if return_data:
+                metrics['input_features'].append(batch['input_features'].cpu().numpy())
+            metrics['decoded_seqs'].append(decoded_seqs)
+            metrics['true_seq'].append(batch['seq_class_ids'].cpu().numpy())
+            metrics['phone_seq_lens'].append(batch['phone_seq_lens'].cpu().numpy())
+            metrics['transcription'].append(batch['transcriptions'].cpu().numpy())
+            metrics['losses'].append(loss.detach().item())
+            metrics['block_nums'].append(batch['block_nums'].numpy())
+            metrics['trial_nums'].append(batch['trial_nums'].numpy())
+            metrics['day_indicies'].append(batch['day_indicies'].cpu().numpy())
+        avg_PER = total_edit_distance / max(1, total_seq_length)
+        metrics['day_PERs'] = day_per
+        metrics['avg_PER'] = float(avg_PER)
+        metrics['avg_loss'] = float(np.mean(metrics['losses'])) if metrics['losses'] else float('nan')
+        return metrics
+
+
+def _to_plain(o):
+    if isinstance(o, dict) or hasattr(o, "items"):
+        return {str(k): _to_plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)) or (hasattr(o, "__iter__") and not isinstance(o, (str, bytes))):
+        return [_to_plain(v) for v in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    return o

@@ -341,7 +341,21 @@ def make_evalstep():
             f.write(c + "\t" + ref_helpers.remove_punctuation(c) + "\n")
 
 
+def make_init():
+    """Initial weights of the reference class under a fixed seed (rnn_model.py:50-86 init order)."""
+    for tag, cfg in (("a", (16, 32, 3, 41, 0.4, 0.2, 2, 14, 4)), ("b", (24, 48, 2, 41, 0.0, 0.0, 3, 0, 0))):
+        torch.manual_seed(10)
+        m = GRUDecoder(*cfg)
+        arrs = {f"sd::{k}": v for k, v in sd_np(m).items()}
+        names = np.array([n for n, _ in m.named_parameters()])
+        save(f"init_{tag}.npz", cfg=np.array(cfg, dtype=np.float64), names=names, **arrs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "init":
+        make_init()
+        sys.exit(0)
+    make_init()
     make_forward()
     make_smooth()
     make_ctc()

@@ -1,0 +1,94 @@
+"""End-to-end trainer on the GPU with the synthetic batch source: the reference's train() contract
+(return dict, log/ckpt files, checkpoint keys) and that training actually learns."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_args(tmp, n_batches=40, patch=(4, 2), dropout=(0.1, 0.1)):
+    sessions = [f"t15.2023.08.{d:02d}" for d in range(11, 17)]
+    return {
+        'model': {'n_input_features': 32, 'n_units': 64, 'rnn_dropout': dropout[0], 'rnn_trainable': True, 'n_layers': 2,
+                  'patch_size': patch[0], 'patch_stride': patch[1],
+                  'input_network': {'n_input_layers': 1, 'input_layer_sizes': [32], 'input_trainable': True,
+                                    'input_layer_dropout': dropout[1]}},
+        'gpu_number': '0', 'mode': 'train', 'use_amp': True,
+        'output_dir': os.path.join(tmp, 'out'), 'checkpoint_dir': os.path.join(tmp, 'out', 'checkpoint'),
+        'init_from_checkpoint': False, 'init_checkpoint_path': None, 'save_best_checkpoint': True,
+        'save_all_val_steps': False, 'save_final_model': False, 'save_val_metrics': True, 'early_stopping': False,
+        'early_stopping_val_steps': 20, 'num_training_batches': n_batches, 'lr_scheduler_type': 'cosine',
+        'lr_max': 0.02, 'lr_min': 0.001, 'lr_decay_steps': n_batches, 'lr_warmup_steps': 5, 'lr_max_day': 0.02,
+        'lr_min_day': 0.001, 'lr_decay_steps_day': n_batches, 'lr_warmup_steps_day': 5, 'beta0': 0.9, 'beta1': 0.999,
+        'epsilon': 0.1, 'weight_decay': 0.001, 'weight_decay_day': 0, 'seed': 10, 'grad_norm_clip_value': 10,
+        'batches_per_train_log': 10, 'batches_per_val_step': 20, 'batches_per_save': 0,
+        'log_individual_day_val_PER': True, 'log_val_skip_logs': False, 'save_val_logits': True, 'save_val_data': False,
+        'dataset': {'data_transforms': {'white_noise_std': 0.2, 'constant_offset_std': 0.05, 'random_walk_std': 0.0,
+                                        'random_walk_axis': -1, 'static_gain_std': 0.0, 'random_cut': 3,
+                                        'smooth_kernel_size': 100, 'smooth_data': True, 'smooth_kernel_std': 2},
+                    'neural_dim': 32, 'batch_size': 16, 'n_classes': 41, 'max_seq_elements': 500, 'days_per_batch': 3,
+                    'seed': 1, 'num_dataloader_workers': 0, 'loader_shuffle': False, 'must_include_days': None,
+                    'test_percentage': 0.1, 'feature_subset': None, 'dataset_dir': '/nonexistent', 'bad_trials_dict': None,
+                    'sessions': sessions, 'dataset_probability_val': [1] * len(sessions),
+                    'synthetic': {'max_T': 80, 'min_T': 50, 'max_S': 6, 'val_batches': 3}},
+    }
+
+
+def test_trainer_end_to_end(tmp_path):
+    from rnn_trainer import BrainToTextDecoder_Trainer
+    args = make_args(str(tmp_path))
+    tr = BrainToTextDecoder_Trainer(args)
+    stats = tr.train()
+    assert set(stats) == {'train_losses', 'val_losses', 'val_PERs', 'val_metrics'}
+    assert len(stats['train_losses']) == 40 and len(stats['val_PERs']) == 3       # batches 0, 20, 39
+    first, last = np.mean(stats['train_losses'][:5]), np.mean(stats['train_losses'][-5:])
+    assert np.all(np.isfinite(stats['train_losses'])) and last < 0.8 * first, (first, last)
+    vm = stats['val_metrics'][-1]
+    for k in ('decoded_seqs', 'true_seq', 'phone_seq_lens', 'transcription', 'losses', 'block_nums', 'trial_nums',
+              'day_indicies', 'day_PERs', 'avg_PER', 'avg_loss', 'logits', 'n_time_steps'):
+        assert k in vm, k
+    assert 0.0 <= vm['avg_PER'] <= 2.0
+    # files the reference writes
+    assert os.path.exists(os.path.join(args['output_dir'], 'training_log'))
+    ck = os.path.join(args['checkpoint_dir'], 'best_checkpoint')
+    assert os.path.exists(ck) and os.path.exists(os.path.join(args['checkpoint_dir'], 'args.yaml'))
+    assert os.path.exists(os.path.join(args['checkpoint_dir'], 'val_metrics.pkl'))
+    c = torch.load(ck, weights_only=False)
+    assert set(c) == {'model_state_dict', 'optimizer_state_dict', 'scheduler_state_dict', 'val_PER', 'val_loss'}
+    assert all(k.startswith('_orig_mod.') for k in c['model_state_dict'])
+    assert [g['group_type'] for g in c['optimizer_state_dict']['param_groups']] == ['bias', 'day_layer', 'other']
+    # evaluate_model.py-style load: strip prefixes, load, one decoding step on a raw trial
+    from rnn_model import GRUDecoder
+    from evaluate_model_helpers import runSingleDecodingStep
+    m = GRUDecoder(32, 64, 6, 41, 0.1, 0.1, 2, 4, 2)
+    sd = {k.replace("module.", "").replace("_orig_mod.", ""): v for k, v in c['model_state_dict'].items()}
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    x = torch.randn(1, 70, 32).to(torch.bfloat16)
+    lg = runSingleDecodingStep(x, 2, m, {'dataset': {'data_transforms': args['dataset']['data_transforms']}}, "cuda:0")
+    assert lg.shape == (1, (70 - 8 - 4) // 2 + 1, 41) and lg.dtype == np.float32
+
+
+def test_trainer_resume_and_validation_matches_oracle(tmp_path):
+    """validation(): PER and loss equal the oracle's greedy/edit-distance/CTC on the same logits."""
+    from oracle import b2t_oracle as O
+    from rnn_trainer import BrainToTextDecoder_Trainer
+    args = make_args(str(tmp_path), n_batches=3, patch=(0, 0), dropout=(0.0, 0.0))
+    args['batches_per_val_step'] = 100
+    tr = BrainToTextDecoder_Trainer(args)
+    vm = tr.validation(tr.val_loader, return_logits=True)
+    tot_e, tot_l, losses = 0, 0, []
+    for bi, batch in enumerate(tr.val_loader):
+        logits = vm['logits'][bi]; lens = vm['n_time_steps'][bi]
+        for b in range(logits.shape[0]):
+            d = O.greedy_decode_trainer(logits[b], int(lens[b]))
+            np.testing.assert_array_equal(d, vm['decoded_seqs'][bi][b])
+            S = int(batch['phone_seq_lens'][b])
+            tot_e += O.edit_distance(d, batch['seq_class_ids'][b][:S].numpy()); tot_l += S
+        lo, _ = O.ctc_loss_fwd_bwd(logits, batch['seq_class_ids'].numpy(), lens, batch['phone_seq_lens'].numpy(), want_grad=False)
+        losses.append(lo.mean())
+    assert abs(vm['avg_PER'] - tot_e / tot_l) < 1e-9
+    np.testing.assert_allclose(vm['avg_loss'], np.mean(np.repeat(losses, 2)), rtol=1e-5)
