@@ -93,8 +93,10 @@ int b2t_day_reduce_f32(const float* slab, const int32_t* day_idx, int B, long lo
 int b2t_patch_fold_f32(const float* dv, float* du, int B, int T, int F, int Tp,
                        int patch, int stride, void* stream);
 /* dropout (rnn_model.py:102-103, nn.GRU inter-layer dropout :70): y = x*mask/(1-p), Philox mask
- * keyed by (seed, index); forward and backward apply the same mask. In place allowed. */
-int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t seed, void* stream);
+ * keyed by (seed, elem0 + index) so that a tensor processed in chunks gets the mask of the whole tensor;
+ * forward and backward apply the same mask. In place allowed. */
+int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t seed, long long elem0,
+                    void* stream);
 
 /* ---- a5: GRU layer sweep (torch.nn.GRU at rnn_model.py:65-72,126) --------------------------
  * One layer, all T steps.  gi [T][B][3H] = W_ih x_t + b_ih (precomputed by b2t_gemm_f32),

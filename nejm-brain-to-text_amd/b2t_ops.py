@@ -1,13 +1,21 @@
 """Host-side operators over libb2t_hip.so: thin typed wrappers (torch tensors in, raw pointers out)
 and the forward/backward orchestration of the day-layer -> GRU stack -> head -> CTC path.
 
-PyTorch is used for device memory, streams and autograd plumbing only; every arithmetic step is a
+PyTorch is used for device memory, streams/events and autograd plumbing only; every arithmetic step is a
 call into the C ABI (include/b2t.h).  There is no CPU fallback: tensors must live on the HIP device.
+
+Execution plan (model_forward / model_backward).  A GRU layer is a strictly serial chain over time, and
+one layer's persistent sweep keeps only H/16 x ceil(B/16) = 128 workgroups busy, each mostly waiting on
+the inter-workgroup hand-off.  The time axis is therefore cut into chunks and the layers are software
+pipelined over them on per-layer HIP streams: while layer l sweeps chunk c, layer l+1 runs its input
+projection GEMM + sweep on chunk c-1, etc.; in the backward pass the weight-gradient GEMMs of layer l run on
+that layer's GEMM stream while the layers below are still sweeping.  Dependencies are HIP events; the
+caller's stream joins all of them before the function returns.
 """
 from __future__ import annotations
 
 import ctypes as C
-import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -115,20 +123,20 @@ def augment_smooth(x: torch.Tensor, std: float, size: int, padding: str = "same"
 
 
 # ------------------------------------------------------------------------------------------------
-# GEMM wrapper
+# GEMM / reductions
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,
          b_sz=0, c_s0=0, c_s1=0, c_div=0, c_sz=0, bias=None, bias_sz=0, b_zmap=None, epilogue=0, accumulate=0,
-         a_off=0, b_off=0, c_off=0, splitk=1, ws=None, _splitk=1, _c_ks=0):
+         a_off=0, b_off=0, c_off=0, splitk=1, ws=None, slab="splitk_slab", _splitk=1, _c_ks=0):
     """C = A.B^T through b2t_gemm_f32.  splitk>1 (needs `ws`): partial products go to a workspace slab and
     are summed deterministically into C by b2t_colsum_f32 (used for the weight gradients, K = T*B)."""
     if splitk > 1:
         if Z != 1 or epilogue != 0 or c_div != 0 or c_s0 != N_:
             raise RuntimeError("split-K gemm supports Z=1, dense row-major C, no epilogue")
-        slab = ws.get("splitk_slab", (splitk, M * N_), Cm.device)
-        gemm(A, B, slab, M=M, N_=N_, K=K, a_kc=a_kc, b_kc=b_kc, a_s0=a_s0, a_s1=a_s1, a_div=a_div, b_s0=b_s0,
+        sl = ws.get(slab, (splitk, M * N_), Cm.device)
+        gemm(A, B, sl, M=M, N_=N_, K=K, a_kc=a_kc, b_kc=b_kc, a_s0=a_s0, a_s1=a_s1, a_div=a_div, b_s0=b_s0,
              b_s1=b_s1, b_div=b_div, c_s0=N_, bias=bias, a_off=a_off, b_off=b_off, _splitk=splitk, _c_ks=M * N_)
-        colsum(slab, splitk, M * N_, M * N_, Cm, accumulate=accumulate, out_off=c_off)
+        colsum(sl, splitk, M * N_, M * N_, Cm, accumulate=accumulate, out_off=c_off)
         return
     d = N.GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -148,6 +156,13 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
         N.check(N.load().b2t_gemm_f32(C.byref(d), _stream()), "b2t_gemm_f32")
 
 
+def splitk_for(M: int, Nn: int, K: int, target_blocks: int = 1024) -> int:
+    """Number of K slices so that a weight-gradient GEMM (few 128x128 output tiles, very long K) fills the
+    chip: ~4 workgroups per CU on 256 CUs, each slice at least 256 deep."""
+    tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
+    return int(max(1, min(target_blocks // max(1, tiles), K // 256)))
+
+
 def colsum(x, rows, cols, ld, out, accumulate=0, Z=1, x_sz=0, out_sz=0, x_off=0, out_off=0):
     lib = N.load()
     nbytes = lib.b2t_colsum_ws_bytes(rows, cols) * Z
@@ -157,8 +172,13 @@ def colsum(x, rows, cols, ld, out, accumulate=0, Z=1, x_sz=0, out_sz=0, x_off=0,
                                _stream()), "b2t_colsum_f32")
 
 
+def dropout(x, y, n, p, seed, elem0=0, x_off=0, y_off=0):
+    N.check(N.load().b2t_dropout_f32(C.c_void_p(x.data_ptr() + 4 * x_off), C.c_void_p(y.data_ptr() + 4 * y_off), n,
+                                     float(p), C.c_uint64(seed), elem0, _stream()), "b2t_dropout_f32")
+
+
 # ------------------------------------------------------------------------------------------------
-# parameter layout
+# model description, parameter views, workspace
 # ------------------------------------------------------------------------------------------------
 class ModelDims:
     def __init__(self, neural_dim, n_units, n_days, n_classes, n_layers, patch_size, patch_stride):
@@ -183,10 +203,16 @@ class Params:
         self.out_w, self.out_b, self.h0 = out_w, out_b, h0
 
 
+class Grads(Params):
+    """Destination views for parameter gradients (normally views of the model's gradient arena)."""
+
+
 # GRU sweep mode: 1 = persistent single-launch sweep (csrc/gru_persistent.hip), 0 = one launch per time step.
 # -1 = choose per call: persistent whenever its (H/16) x ceil(B/16) workgroups can be co-resident.
-GRU_MODE = {"value": int(__import__("os").environ.get("B2T_GRU_MODE", "-1"))}
-MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs, one 256-thread workgroup (<=512 VGPRs/lane) per CU
+GRU_MODE = {"value": int(os.environ.get("B2T_GRU_MODE", "-1"))}
+MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its workgroups resident at once
+# Number of time chunks the layers are software-pipelined over (1 = layer-by-layer, no side streams).
+PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16}
 
 
 def gru_mode_for(B: int, H: int) -> int:
@@ -204,10 +230,17 @@ def gru_sync_check(sync_ws, T: int, B: int):
         raise RuntimeError("persistent GRU sweep: inter-workgroup hand-off timed out (results invalid)")
 
 
+def gru_sync_check_all(ws, L: int, Tp: int, B: int, device):
+    for l in range(L):
+        gru_sync_check(ws.sync_ws(l, Tp, device), Tp, B)
+
+
 class Workspace:
-    """Shape-keyed scratch buffers (allocated once per (B,T) from torch's caching allocator)."""
+    """Shape-keyed scratch buffers (allocated once per shape from torch's caching allocator) plus the
+    per-layer side streams of the pipelined execution plan."""
     def __init__(self):
         self.bufs: Dict[Tuple, torch.Tensor] = {}
+        self.streams: Dict[Tuple, List[torch.cuda.Stream]] = {}
 
     def get(self, name, shape, device, dtype=torch.float32):
         key = (name, tuple(shape), str(device), dtype)
@@ -217,11 +250,36 @@ class Workspace:
             self.bufs[key] = t
         return t
 
+    def layer_streams(self, L, device):
+        key = (L, str(device))
+        if key not in self.streams:
+            self.streams[key] = ([torch.cuda.Stream(device=device) for _ in range(L)],
+                                 [torch.cuda.Stream(device=device) for _ in range(L)])
+        return self.streams[key]
+
+    def sync_ws(self, l, Tp, device):
+        return self.get(f"gru_sync{l}", (N.load().b2t_gru_sync_bytes(Tp) // 4 + 16,), device, torch.int32)
+
+
+def time_chunks(Tp: int) -> List[Tuple[int, int]]:
+    n = max(1, min(PIPELINE["chunks"], Tp // max(1, PIPELINE["min_chunk"])))
+    ch = (Tp + n - 1) // n
+    return [(t0, min(Tp, t0 + ch)) for t0 in range(0, Tp, ch)]
+
 
 class ForwardCtx:
     pass
 
 
+def _ev(stream=None):
+    e = torch.cuda.Event()
+    e.record(stream if stream is not None else torch.cuda.current_stream())
+    return e
+
+
+# ------------------------------------------------------------------------------------------------
+# forward
+# ------------------------------------------------------------------------------------------------
 def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.Tensor,
                   states: Optional[torch.Tensor], ws: Workspace, save: bool,
                   in_drop: float = 0.0, rnn_drop: float = 0.0, seed: int = 0, reuse_saved: bool = False):
@@ -239,7 +297,7 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     if Tp <= 0:
         raise RuntimeError("sequence shorter than patch_size")
     dev = x.device
-    st = _stream()
+    main = torch.cuda.current_stream()
 
     def sbuf(name, shape):
         # saved-for-backward buffers: workspace-owned only when the caller guarantees one
@@ -255,48 +313,73 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     Ud = U
     if in_drop > 0:
         Ud = sbuf("Ud", (B, T, F))
-        N.check(lib.b2t_dropout_f32(_p(U), _p(Ud), U.numel(), float(in_drop), C.c_uint64(seed * 1000003 + 17), st),
-                "b2t_dropout_f32")
+        dropout(U, Ud, U.numel(), in_drop, seed * 1000003 + 17)
 
-    gi = ws.get("gi", (Tp, B, 3 * H), dev)
-    outs: List[torch.Tensor] = []
-    outs_d: List[torch.Tensor] = []
-    reserves: List[Optional[torch.Tensor]] = []
-    hidden = torch.empty((L, B, H), dtype=torch.float32, device=dev)
     mode = gru_mode_for(B, H)
-    sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32) if mode == 1 else None
-    for l in range(L):
-        # 2. input projection gi = in_t W_ih^T + b_ih, time-major [T'][B][3H]
-        if l == 0:
-            a_s0 = dims.stride * F if dims.patch > 0 else F
-            gemm(Ud, prm.w_ih[0], gi, M=Tp, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0, a_sz=T * F,
-                 b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H, bias=prm.b_ih[0])
-        else:
-            gemm(outs_d[l - 1][1:], prm.w_ih[l], gi, M=Tp * B, N_=3 * H, K=H, a_kc=1, a_s0=H, b_kc=1, b_s0=H,
-                 c_s0=3 * H, bias=prm.b_ih[l])
-        # 3. recurrent sweep.  outbuf[0] = initial state so that outbuf[0:T'] is the h_{t-1} matrix.
-        outbuf = sbuf(f"out{l}", (Tp + 1, B, H))
+    chunks = time_chunks(Tp)
+    s_sweep, s_gemm = ws.layer_streams(L, dev)
+    piped = len(chunks) > 1
+    outs = [sbuf(f"out{l}", (Tp + 1, B, H)) for l in range(L)]
+    outs_d = [sbuf(f"outd{l}", (Tp + 1, B, H)) if (rnn_drop > 0 and l < L - 1) else outs[l] for l in range(L)]
+    reserves = [sbuf(f"res{l}", (Tp, B, 4 * H)) if save else None for l in range(L)]
+    gis = [ws.get(f"gi{l if piped else 0}", (Tp, B, 3 * H), dev) for l in range(L)]
+    hidden = torch.empty((L, B, H), dtype=torch.float32, device=dev)
+    for l in range(L):   # slot 0 = initial state, so outs[l][0:T'] is the h_{t-1} matrix
         if states is None:
-            outbuf[0].copy_(prm.h0.view(1, H).expand(B, H))
+            outs[l][0].copy_(prm.h0.view(1, H).expand(B, H))
         else:
-            outbuf[0].copy_(states[l])
-        res = sbuf(f"res{l}", (Tp, B, 4 * H)) if save else None
-        with _Prof("gru_sweep_fwd", 2.0 * Tp * B * 3 * H * H, Tp if mode == 0 else 1):
-            N.check(lib.b2t_gru_layer_fwd_f32(_p(gi), _p(prm.w_hh[l]), _p(prm.b_hh[l]), _p(outbuf[0]), _p(outbuf[1:]),
-                                              _p(res), _p(hidden[l]), Tp, B, H, mode, _p(sync_ws), st),
-                    "b2t_gru_layer_fwd_f32")
-        outs.append(outbuf)
-        reserves.append(res)
-        od = outbuf
-        if rnn_drop > 0 and l < L - 1:   # nn.GRU inter-layer dropout (rnn_model.py:70)
-            od = sbuf(f"outd{l}", (Tp + 1, B, H))
-            N.check(lib.b2t_dropout_f32(_p(outbuf[1:]), _p(od[1:]), Tp * B * H, float(rnn_drop),
-                                        C.c_uint64(seed * 1000003 + 101 + l), st), "b2t_dropout_f32")
-        outs_d.append(od)
+            outs[l][0].copy_(states[l])
+    ev0 = _ev(main)
+    if piped:
+        for s in s_sweep + s_gemm:
+            s.wait_event(ev0)
+    ev_sw: List[List[Optional[torch.cuda.Event]]] = [[None] * len(chunks) for _ in range(L)]
+    a_s0_l0 = dims.stride * F if dims.patch > 0 else F
+    for c, (t0, t1) in enumerate(chunks):
+        n = t1 - t0
+        for l in range(L):
+            sg = s_gemm[l] if piped else main
+            ss = s_sweep[l] if piped else main
+            # 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
+            with torch.cuda.stream(sg):
+                if l == 0:
+                    gemm(Ud, prm.w_ih[0], gis[0], M=n, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0_l0, a_sz=T * F,
+                         a_off=t0 * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H, c_off=t0 * B * 3 * H,
+                         bias=prm.b_ih[0])
+                else:
+                    if piped:
+                        sg.wait_event(ev_sw[l - 1][c])
+                    src = outs[l - 1]
+                    if outs_d[l - 1] is not outs[l - 1]:   # nn.GRU inter-layer dropout (rnn_model.py:70)
+                        dropout(outs[l - 1], outs_d[l - 1], n * B * H, rnn_drop, seed * 1000003 + 101 + (l - 1),
+                                elem0=t0 * B * H, x_off=(1 + t0) * B * H, y_off=(1 + t0) * B * H)
+                        src = outs_d[l - 1]
+                    gemm(src, prm.w_ih[l], gis[l], M=n * B, N_=3 * H, K=H, a_kc=1, a_s0=H, a_off=(1 + t0) * B * H,
+                         b_kc=1, b_s0=H, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[l])
+                ev_gi = _ev(sg) if piped else None
+            # 3. recurrent sweep over the chunk, continuing from outs[l][t0] = h_{t0-1}
+            with torch.cuda.stream(ss):
+                if piped:
+                    ss.wait_event(ev_gi)
+                res_ptr = C.c_void_p(reserves[l].data_ptr() + 4 * t0 * B * 4 * H) if save else None
+                with _Prof("gru_sweep_fwd", 2.0 * n * B * 3 * H * H, n if mode == 0 else 1):
+                    N.check(lib.b2t_gru_layer_fwd_f32(
+                        C.c_void_p(gis[l].data_ptr() + 4 * t0 * B * 3 * H), _p(prm.w_hh[l]), _p(prm.b_hh[l]),
+                        C.c_void_p(outs[l].data_ptr() + 4 * t0 * B * H),
+                        C.c_void_p(outs[l].data_ptr() + 4 * (1 + t0) * B * H), res_ptr,
+                        _p(hidden[l]) if t1 == Tp else None, n, B, H, mode,
+                        _p(ws.sync_ws(l, Tp, dev)) if mode == 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
+                if piped:
+                    ev_sw[l][c] = _ev(ss)
+    if piped:
+        for l in range(L):
+            main.wait_event(ev_sw[l][-1])
+        for s in s_gemm:
+            main.wait_event(_ev(s))
 
     # 4. head: logits[b,t,:] = out W^T + b  (rnn_model.py:129), written batch-first
     logits = torch.empty((B, Tp, Cc), dtype=torch.float32, device=dev)
-    gemm(outs[L - 1][1:], prm.out_w, logits, M=Tp * B, N_=Cc, K=H, a_kc=1, a_s0=H, b_kc=1, b_s0=H,
+    gemm(outs[L - 1], prm.out_w, logits, M=Tp * B, N_=Cc, K=H, a_kc=1, a_s0=H, a_off=B * H, b_kc=1, b_s0=H,
          c_div=B, c_s1=Cc, c_s0=Tp * Cc, bias=prm.out_b)
     if not save:
         return logits, hidden, None
@@ -306,99 +389,151 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ctx.B, ctx.T, ctx.Tp = B, T, Tp
     ctx.in_drop, ctx.rnn_drop, ctx.seed = in_drop, rnn_drop, seed
     ctx.custom_states = states is not None
+    ctx.chunks, ctx.mode = chunks, mode
     return logits, hidden, ctx
 
 
-def splitk_for(M: int, Nn: int, K: int, target_blocks: int = 1024) -> int:
-    """Number of K slices so that a weight-gradient GEMM (few 128x128 output tiles, very long K) fills the
-    chip: ~4 workgroups per CU on 256 CUs, each slice at least 256 deep."""
-    tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
-    sk = max(1, min(target_blocks // max(1, tiles), K // 256))
-    return int(sk)
-
-
-class Grads:
-    """Destination views for parameter gradients (normally views of the model's gradient arena)."""
-    def __init__(self, day_w, day_b, day_w_stride, day_b_stride, w_ih, w_hh, b_ih, b_hh, out_w, out_b, h0):
-        self.day_w, self.day_b = day_w, day_b
-        self.day_w_stride, self.day_b_stride = day_w_stride, day_b_stride
-        self.w_ih, self.w_hh, self.b_ih, self.b_hh = w_ih, w_hh, b_ih, b_hh
-        self.out_w, self.out_b, self.h0 = out_w, out_b, h0
-
-
+# ------------------------------------------------------------------------------------------------
+# backward
+# ------------------------------------------------------------------------------------------------
 def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dlogits: torch.Tensor, ldd: int,
                    ws: Workspace, dhidden: Optional[torch.Tensor] = None, want_dstates: bool = False,
                    bucket_cb=None):
     """Gradients of every parameter given dlogits [B,T',ldd] (ldd multiple of 4, >= C).
     Overwrites the destinations in `grd` (days absent from the batch are not touched).
-    Follows SURVEY Appendix A2/A3; replaces loss.backward() at rnn_trainer.py:547."""
+    Follows SURVEY Appendix A2/A3; replaces loss.backward() at rnn_trainer.py:547.
+    bucket_cb(name) is called (on the stream that produced them) as soon as a gradient bucket is complete:
+    "head", "layer{l}", "h0", "day" — the data-parallel reducer hooks its all-reduce there."""
     lib = N.load()
     B, T, Tp = ctx.B, ctx.T, ctx.Tp
     F, H, L, Cc = dims.F, dims.H, dims.L, dims.C
     dev = dlogits.device
-    st = _stream()
     M = Tp * B
-    top = ctx.outs[L - 1]
+    main = torch.cuda.current_stream()
+    chunks, mode = ctx.chunks, ctx.mode
+    piped = len(chunks) > 1
+    s_sweep, s_gemm = ws.layer_streams(L, dev)
+    nc = len(chunks)
 
     # head: d_out[t,b,:] = dlogits[b,t,:] W_out ; dW_out = dlogits^T out ; db_out = colsum
-    dY = ws.get("dY0", (Tp, B, H), dev)
-    gemm(dlogits, prm.out_w, dY, M=M, N_=H, K=Cc, a_kc=1, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H, c_s0=H)
-    gemm(dlogits, top[1:], grd.out_w, M=Cc, N_=H, K=M, a_kc=0, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H,
-         c_s0=H, splitk=splitk_for(Cc, H, M), ws=ws)
+    dYs = [ws.get(f"dY{l}", (Tp, B, H), dev) for l in range(L)]
+    gemm(dlogits, prm.out_w, dYs[L - 1], M=M, N_=H, K=Cc, a_kc=1, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H,
+         c_s0=H)
+    ev_top = _ev(main)
+    gemm(dlogits, ctx.outs[L - 1], grd.out_w, M=Cc, N_=H, K=M, a_kc=0, a_div=B, a_s1=ldd, a_s0=Tp * ldd, b_kc=0, b_s0=H,
+         b_off=B * H, c_s0=H, splitk=splitk_for(Cc, H, M), ws=ws, slab="splitk_slab_head")
     colsum(dlogits, B * Tp, Cc, ldd, grd.out_b)
     if bucket_cb:
         bucket_cb("head")
 
-    dG = ws.get("dG", (Tp, B, 4 * H), dev)
+    dGs = [ws.get(f"dG{l if piped else 0}", (Tp, B, 4 * H), dev) for l in range(L)]
     dh_init = ws.get("dh_init", (L, B, H), dev)
-    carry = ws.get("carry", (B, H), dev)
-    whh_t = ws.get("whh_t", (H, 3 * H), dev)
-    s4 = ws.get("s4", (4 * H,), dev)
-    dYn = ws.get("dY1", (Tp, B, H), dev)
-    mode = gru_mode_for(B, H)
-    sync_ws = ws.get("gru_sync", (lib.b2t_gru_sync_bytes(Tp) // 4 + 16,), dev, torch.int32) if mode == 1 else None
-    for l in reversed(range(L)):
-        if ctx.rnn_drop > 0 and l < L - 1:   # gradient through the inter-layer dropout mask
-            N.check(lib.b2t_dropout_f32(_p(dY), _p(dY), Tp * B * H, float(ctx.rnn_drop),
-                                        C.c_uint64(ctx.seed * 1000003 + 101 + l), st), "b2t_dropout_f32")
-        N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_t), 3 * H, H, st), "b2t_transpose_f32")
-        outbuf = ctx.outs[l]
-        dhl = dhidden[l].contiguous() if dhidden is not None else None
-        with _Prof("gru_sweep_bwd", 2.0 * Tp * B * 3 * H * H, Tp + 1 if mode == 0 else 1):
-            N.check(lib.b2t_gru_layer_bwd_f32(_p(dY), _p(dhl), _p(ctx.reserves[l]), _p(outbuf[1:]), _p(outbuf[0]),
-                                              _p(whh_t), _p(dG), _p(dh_init[l]), _p(carry), Tp, B, H, mode,
-                                              _p(sync_ws), st), "b2t_gru_layer_bwd_f32")
-        # dW_hh = dGh^T h_prev   (dGh = dG cols [0,3H); h_prev rows = outbuf[0:T'])
-        sk = splitk_for(3 * H, H, M)
-        gemm(dG, outbuf, grd.w_hh[l], M=3 * H, N_=H, K=M, a_kc=0, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H, splitk=sk, ws=ws)
-        # dW_ih = dGi^T in      (dGi = dG cols [0,2H) + [3H,4H))
-        if l == 0:
-            In = dims.In0
-            bs1 = dims.stride * F if dims.patch > 0 else F
-            kw = dict(b_kc=0, b_div=B, b_s1=bs1, b_s0=T * F)
-            inp = ctx.Ud
-            in_off = 0
-        else:
-            In = H
-            kw = dict(b_kc=0, b_s0=H)
-            inp = ctx.outs_d[l - 1]
-            in_off = B * H  # skip the initial-state slot
-        gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=M, a_kc=0, a_s0=4 * H, c_s0=In, b_off=in_off,
-             splitk=splitk_for(2 * H, In, M), ws=ws, **kw)
-        gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=M, a_kc=0, a_s0=4 * H, a_off=3 * H, c_s0=In, c_off=2 * H * In,
-             b_off=in_off, splitk=splitk_for(H, In, M), ws=ws, **kw)
-        # biases: column sums of dG -> (s_r, s_z, s_nr, s_n)
-        colsum(dG, M, 4 * H, 4 * H, s4)
-        grd.b_ih[l][:2 * H].copy_(s4[:2 * H]); grd.b_ih[l][2 * H:].copy_(s4[3 * H:])
-        grd.b_hh[l].copy_(s4[:3 * H])
-        if bucket_cb:
-            bucket_cb(f"layer{l}")
-        # gradient wrt this layer's input: dIn = dGi W_ih
+    carries = [ws.get(f"carry{l}", (2, B, H), dev) for l in range(L)]
+    scratch = [ws.get(f"bwd_scratch{l}", (B, H), dev) for l in range(L)]
+    whh_ts = [ws.get(f"whh_t{l if piped else 0}", (H, 3 * H), dev) for l in range(L)]
+    dU = ws.get("dU", (B, T, F), dev)
+    dV = ws.get("dV", (B, Tp, dims.In0), dev) if dims.patch > 0 else None
+    if piped:
+        for s in s_sweep + s_gemm:
+            s.wait_event(ev_top)
+    ev_dx: List[List[Optional[torch.cuda.Event]]] = [[None] * nc for _ in range(L)]
+    ev_bs: List[List[Optional[torch.cuda.Event]]] = [[None] * nc for _ in range(L)]
+    ev_wt = [None] * L
+    if piped:
+        for l in range(L):
+            with torch.cuda.stream(s_gemm[l]):
+                N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_ts[l]), 3 * H, H, _stream()), "b2t_transpose_f32")
+                ev_wt[l] = _ev(s_gemm[l])
+
+    def dx_gemm(l, t0, n):
+        """dIn = dGi W_ih for rows of chunk [t0,t0+n): into dY[l-1] (l>0) or dU / dV (l == 0)."""
+        a_off = t0 * B * 4 * H
         if l > 0:
-            gemm(dG, prm.w_ih[l], dYn, M=M, N_=H, K=2 * H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H)
-            gemm(dG, prm.w_ih[l], dYn, M=M, N_=H, K=H, a_kc=1, a_s0=4 * H, a_off=3 * H, b_kc=0, b_s0=H,
-                 b_off=2 * H * H, c_s0=H, accumulate=1)
-            dY, dYn = dYn, dY
+            kw = dict(M=n * B, N_=H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H, c_off=t0 * B * H)
+            gemm(dGs[l], prm.w_ih[l], dYs[l - 1], K=2 * H, a_off=a_off, **kw)
+            gemm(dGs[l], prm.w_ih[l], dYs[l - 1], K=H, a_off=a_off + 3 * H, b_off=2 * H * H, accumulate=1, **kw)
+        else:
+            In = dims.In0
+            if dims.patch > 0:
+                dst, kw = dV, dict(c_div=B, c_s1=In, c_s0=Tp * In, c_off=t0 * In)
+            else:
+                dst, kw = dU, dict(c_div=B, c_s1=F, c_s0=T * F, c_off=t0 * F)
+            gemm(dGs[0], prm.w_ih[0], dst, M=n * B, N_=In, K=2 * H, a_kc=1, a_s0=4 * H, a_off=a_off, b_kc=0, b_s0=In, **kw)
+            gemm(dGs[0], prm.w_ih[0], dst, M=n * B, N_=In, K=H, a_kc=1, a_s0=4 * H, a_off=a_off + 3 * H, b_kc=0, b_s0=In,
+                 b_off=2 * H * In, accumulate=1, **kw)
+
+    for c in reversed(range(nc)):
+        t0, t1 = chunks[c]
+        n = t1 - t0
+        for l in reversed(range(L)):
+            ss = s_sweep[l] if piped else main
+            sg = s_gemm[l] if piped else main
+            with torch.cuda.stream(ss):
+                if piped:
+                    if l < L - 1:
+                        ss.wait_event(ev_dx[l + 1][c])
+                    if c == nc - 1:
+                        ss.wait_event(ev_wt[l])
+                else:
+                    if c == nc - 1:
+                        N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_ts[l]), 3 * H, H, _stream()),
+                                "b2t_transpose_f32")
+                if ctx.rnn_drop > 0 and l < L - 1:   # gradient through the inter-layer dropout mask
+                    dropout(dYs[l], dYs[l], n * B * H, ctx.rnn_drop, ctx.seed * 1000003 + 101 + l,
+                            elem0=t0 * B * H, x_off=t0 * B * H, y_off=t0 * B * H)
+                if c == nc - 1:
+                    dh_last = _p(dhidden[l].contiguous()) if dhidden is not None else None
+                else:
+                    dh_last = _p(carries[l][(c + 1) % 2])
+                dh_out = _p(dh_init[l]) if c == 0 else _p(carries[l][c % 2])
+                outb = ctx.outs[l]
+                with _Prof("gru_sweep_bwd", 2.0 * n * B * 3 * H * H, n + 1 if mode == 0 else 1):
+                    N.check(lib.b2t_gru_layer_bwd_f32(
+                        C.c_void_p(dYs[l].data_ptr() + 4 * t0 * B * H), dh_last,
+                        C.c_void_p(ctx.reserves[l].data_ptr() + 4 * t0 * B * 4 * H),
+                        C.c_void_p(outb.data_ptr() + 4 * (1 + t0) * B * H), C.c_void_p(outb.data_ptr() + 4 * t0 * B * H),
+                        _p(whh_ts[l]), C.c_void_p(dGs[l].data_ptr() + 4 * t0 * B * 4 * H), dh_out, _p(scratch[l]),
+                        n, B, H, mode, _p(ws.sync_ws(l, Tp, dev)) if mode == 1 else None, _stream()),
+                        "b2t_gru_layer_bwd_f32")
+                if piped:
+                    ev_bs[l][c] = _ev(ss)
+            with torch.cuda.stream(sg):
+                if piped:
+                    sg.wait_event(ev_bs[l][c])
+                dx_gemm(l, t0, n)
+                if piped:
+                    ev_dx[l][c] = _ev(sg)
+            if (not piped) and c == 0:
+                _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
+    if piped:
+        for l in reversed(range(L)):
+            with torch.cuda.stream(s_gemm[l]):
+                _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
+
+    # layer-0 input gradient -> day layer (on layer 0's GEMM stream: its dU/dV GEMMs are already ordered there)
+    with torch.cuda.stream(s_gemm[0] if piped else main):
+        if dims.patch > 0:
+            N.check(lib.b2t_patch_fold_f32(_p(dV), _p(dU), B, T, F, Tp, dims.patch, dims.stride, _stream()),
+                    "b2t_patch_fold_f32")
+        if ctx.in_drop > 0:
+            dropout(dU, dU, dU.numel(), ctx.in_drop, ctx.seed * 1000003 + 17)
+        # softsign backward in place: dpre = dU * (1-|U|)^2
+        N.check(lib.b2t_softsign_bwd_f32(_p(ctx.U), _p(dU), dU.numel(), _stream()), "b2t_softsign_bwd_f32")
+        # per-sample partial day gradients, then deterministic reduction by day
+        slab = ws.get("day_slab", (B, F, F), dev)
+        gemm(ctx.x, dU, slab, M=F, N_=F, K=T, Z=B, a_kc=0, a_s0=F, a_sz=T * F, b_kc=0, b_s0=F, b_sz=T * F, c_s0=F,
+             c_sz=F * F)
+        N.check(lib.b2t_day_reduce_f32(_p(slab), _p(ctx.day_idx), B, F * F, _p(grd.day_w), grd.day_w_stride, _stream()),
+                "b2t_day_reduce_f32")
+        bslab = ws.get("day_bslab", (B, pad_to(F, 4)), dev)
+        colsum(dU, T, F, F, bslab, Z=B, x_sz=T * F, out_sz=bslab.shape[1])
+        N.check(lib.b2t_day_reduce_f32(_p(bslab), _p(ctx.day_idx), B, bslab.shape[1], _p(grd.day_b), grd.day_b_stride,
+                                       _stream()), "b2t_day_reduce_f32")
+        if bucket_cb:
+            bucket_cb("day")
+    if piped:
+        for s in s_sweep + s_gemm:
+            main.wait_event(_ev(s))
     # h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
     if not ctx.custom_states:
         colsum(dh_init, L * B, H, H, grd.h0)
@@ -406,41 +541,41 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
         grd.h0.zero_()
     if bucket_cb:
         bucket_cb("h0")
-
-    # layer-0 input gradient -> dU [B][T][F]
-    dU = ws.get("dU", (B, T, F), dev)
-    if dims.patch > 0:
-        In = dims.In0
-        dV = ws.get("dV", (B, Tp, In), dev)
-        gemm(dG, prm.w_ih[0], dV, M=M, N_=In, K=2 * H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=In, c_div=B, c_s1=In,
-             c_s0=Tp * In)
-        gemm(dG, prm.w_ih[0], dV, M=M, N_=In, K=H, a_kc=1, a_s0=4 * H, a_off=3 * H, b_kc=0, b_s0=In,
-             b_off=2 * H * In, c_div=B, c_s1=In, c_s0=Tp * In, accumulate=1)
-        N.check(lib.b2t_patch_fold_f32(_p(dV), _p(dU), B, T, F, Tp, dims.patch, dims.stride, st), "b2t_patch_fold_f32")
-    else:
-        gemm(dG, prm.w_ih[0], dU, M=M, N_=F, K=2 * H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=F, c_div=B, c_s1=F, c_s0=T * F)
-        gemm(dG, prm.w_ih[0], dU, M=M, N_=F, K=H, a_kc=1, a_s0=4 * H, a_off=3 * H, b_kc=0, b_s0=F, b_off=2 * H * F,
-             c_div=B, c_s1=F, c_s0=T * F, accumulate=1)
-    if ctx.in_drop > 0:
-        N.check(lib.b2t_dropout_f32(_p(dU), _p(dU), dU.numel(), float(ctx.in_drop),
-                                    C.c_uint64(ctx.seed * 1000003 + 17), st), "b2t_dropout_f32")
-    # softsign backward in place: dpre = dU * (1-|U|)^2
-    N.check(lib.b2t_softsign_bwd_f32(_p(ctx.U), _p(dU), dU.numel(), st), "b2t_softsign_bwd_f32")
-    # per-sample partial day gradients, then deterministic reduction by day
-    slab = ws.get("day_slab", (B, F, F), dev)
-    gemm(ctx.x, dU, slab, M=F, N_=F, K=T, Z=B, a_kc=0, a_s0=F, a_sz=T * F, b_kc=0, b_s0=F, b_sz=T * F, c_s0=F,
-         c_sz=F * F)
-    N.check(lib.b2t_day_reduce_f32(_p(slab), _p(ctx.day_idx), B, F * F, _p(grd.day_w), grd.day_w_stride, st),
-            "b2t_day_reduce_f32")
-    bslab = ws.get("day_bslab", (B, pad_to(F, 4)), dev)
-    colsum(dU, T, F, F, bslab, Z=B, x_sz=T * F, out_sz=bslab.shape[1])
-    N.check(lib.b2t_day_reduce_f32(_p(bslab), _p(ctx.day_idx), B, bslab.shape[1], _p(grd.day_b), grd.day_b_stride, st),
-            "b2t_day_reduce_f32")
-    if bucket_cb:
-        bucket_cb("day")
     return dh_init if want_dstates else None
 
 
+def _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb):
+    """dW_hh = dGh^T h_prev, dW_ih = dGi^T in, bias gradients = column sums of dG (layer l)."""
+    B, T = ctx.B, ctx.T
+    F, H = dims.F, dims.H
+    dG = dGs[l]
+    dev = dG.device
+    gemm(dG, ctx.outs[l], grd.w_hh[l], M=3 * H, N_=H, K=M, a_kc=0, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H,
+         splitk=splitk_for(3 * H, H, M), ws=ws, slab=f"splitk_slab{l}")
+    if l == 0:
+        In = dims.In0
+        bs1 = dims.stride * F if dims.patch > 0 else F
+        kw = dict(b_kc=0, b_div=B, b_s1=bs1, b_s0=T * F)
+        inp, in_off = ctx.Ud, 0
+    else:
+        In = H
+        kw = dict(b_kc=0, b_s0=H)
+        inp, in_off = ctx.outs_d[l - 1], B * H   # skip the initial-state slot
+    gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=M, a_kc=0, a_s0=4 * H, c_s0=In, b_off=in_off,
+         splitk=splitk_for(2 * H, In, M), ws=ws, slab=f"splitk_slab{l}", **kw)
+    gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=M, a_kc=0, a_s0=4 * H, a_off=3 * H, c_s0=In, c_off=2 * H * In,
+         b_off=in_off, splitk=splitk_for(H, In, M), ws=ws, slab=f"splitk_slab{l}", **kw)
+    s4 = ws.get(f"s4_{l}", (4 * H,), dev)
+    colsum(dG, M, 4 * H, 4 * H, s4)     # (s_r, s_z, s_nr, s_n)
+    grd.b_ih[l][:2 * H].copy_(s4[:2 * H]); grd.b_ih[l][2 * H:].copy_(s4[3 * H:])
+    grd.b_hh[l].copy_(s4[:3 * H])
+    if bucket_cb:
+        bucket_cb(f"layer{l}")
+
+
+# ------------------------------------------------------------------------------------------------
+# CTC / decode
+# ------------------------------------------------------------------------------------------------
 def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, in_len: torch.Tensor, tgt_len: torch.Tensor,
              want_grad: bool, grad_scale: float, ws: Workspace):
     """loss [B] and (optionally) dlogits [B,T,ldd] — fused log-softmax + CTC (rnn_trainer.py:538-545)."""

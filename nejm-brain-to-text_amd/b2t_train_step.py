@@ -178,7 +178,10 @@ class TrainStep:
         dev = self.dev
         st = ops._stream()
         B = feats.shape[0]
-        day_dev = day_idx.to(device=dev, dtype=torch.int32).contiguous()
+        if day_idx.is_cuda:
+            day_dev = day_idx.to(dtype=torch.int32).contiguous()
+        else:   # pageable H2D copies block the host until the stream drains: stage through pinned memory
+            day_dev = day_idx.to(torch.int32).pin_memory().to(dev, non_blocking=True)
         adj = self.adjusted_lens(n_time_steps.to(dev))
         logits, hidden, ctx = ops.model_forward(model._dims, model._kernel_params(), feats, day_dev, None, model._ws,
                                                 save=True, in_drop=model._p_in(), rnn_drop=model._p_rnn(),

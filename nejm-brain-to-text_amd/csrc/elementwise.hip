@@ -150,10 +150,10 @@ __global__ void patch_fold_kernel(const float* __restrict__ dv, float* __restric
 }
 
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p, float scale,
-                               uint64_t seed) {
+                               uint64_t seed, long long idx0) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 v = reinterpret_cast<const float4*>(x)[i];
-    float4 u = Philox::uniform4(seed, (uint64_t)i, 2u);
+    float4 u = Philox::uniform4(seed, (uint64_t)(idx0 + i), 2u);
     v.x = u.x >= p ? v.x * scale : 0.f; v.y = u.y >= p ? v.y * scale : 0.f;
     v.z = u.z >= p ? v.z * scale : 0.f; v.w = u.w >= p ? v.w * scale : 0.f;
     reinterpret_cast<float4*>(y)[i] = v;
@@ -254,11 +254,12 @@ extern "C" int b2t_patch_fold_f32(const float* dv, float* du, int B, int T, int 
   return 0;
 }
 
-extern "C" int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t seed, void* stream) {
-  B2T_REQUIRE(n > 0 && (n % 4) == 0 && p >= 0.f && p < 1.f, "dropout: bad args n=%lld p=%f", n, (double)p);
+extern "C" int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t seed, long long elem0,
+                               void* stream) {
+  B2T_REQUIRE(n > 0 && (n % 4) == 0 && (elem0 % 4) == 0 && p >= 0.f && p < 1.f, "dropout: bad args n=%lld p=%f", n, (double)p);
   long long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n4, p, 1.0f / (1.0f - p), seed);
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n4, p, 1.0f / (1.0f - p), seed, elem0 / 4);
   B2T_CHECK_LAUNCH("b2t_dropout_f32");
   return 0;
 }

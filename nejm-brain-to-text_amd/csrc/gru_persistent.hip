@@ -21,7 +21,8 @@ using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr unsigned SPIN_LIMIT = 4u << 20;  // ~seconds; a healthy hand-off takes microseconds
+constexpr unsigned SPIN_LIMIT = 4u << 20;
+constexpr int CSTRIDE = 32;  // words between counters: one 128-byte line per (row group, step) counter  // ~seconds; a healthy hand-off takes microseconds
 
 // Thread 0 polls until *p >= target (or the error word is set / the spin limit is hit), then barrier.
 __device__ __forceinline__ void wait_count(unsigned* p, unsigned target, unsigned* err) {
@@ -57,6 +58,18 @@ __device__ __forceinline__ float4 load_sc1_f4(const float* base_uniform, unsigne
 
 __device__ __forceinline__ void store_sc1(float* p, float v) { __hip_atomic_store(p, v, RLX_AGENT); }
 
+// 16-byte sc1 (write-through) store through a buffer descriptor based at a wave-uniform pointer.
+// Scalar sc1 stores are one fabric write each (~6x the cost per byte of a 16-byte one), so the 16x16
+// tile a workgroup produces per step is staged through LDS and written as 64 x 16 B.
+__device__ __forceinline__ void store_sc1_f4(float* base_uniform, unsigned byte_off, float4 v) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7fffffff, 0x00020000);
+  u32x4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, byte_off, 0, /*aux: sc1*/ 16);
+}
+
+constexpr int TP = 20;  // LDS pitch (floats) of a staged 16x16 tile: 16-byte aligned rows, conflict-light
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
@@ -66,14 +79,22 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
                                                                  float* __restrict__ reserve, int T, int B, int H,
-                                                                 unsigned* sync) {
-  __shared__ float red[4 * 3 * 4 * 64];
+                                                                 unsigned* sync, long long zs_gi, long long zs_w,
+                                                                 long long zs_out, long long zs_sync) {
+  {   // blockIdx.z selects one of several independent sweeps packed into one launch (strides in elements)
+    const long long z = blockIdx.z;
+    gi += z * zs_gi; w_hh += z * zs_w; b_hh += z * 3 * H; h_init += z * zs_out; out += z * zs_out;
+    if (reserve) reserve += z * (zs_gi / 3 * 4);
+    sync += z * zs_sync;
+  }
+  __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TP];
+  float* hs = red + 4 * 3 * 4 * 64;   // staged h tile [16 rows][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j0 = blockIdx.x * 16;
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
   const int unit = j0 + j;
-  unsigned* err = sync + (size_t)gridDim.y * MT * T;
+  unsigned* err = sync;  // word 0: error flag; counters start at word 16
   const int nch = H / 16;
 
   float4 w[3][NCH];
@@ -93,6 +114,13 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     hpv[rr] = row < B ? h_init[(long long)row * H + unit] : 0.f;
   }
 
+#ifdef B2T_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#define TSTAMP(i) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; }
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#else
+#define TSTAMP(i)
+#endif
   for (int t = 0; t < T; ++t) {
 #pragma unroll
    for (int rr = 0; rr < MT; ++rr) {
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     if (m0 >= B) continue;
     const int row = m0 + 4 * q + wave, arow = m0 + j;
     const bool live = row < B;
-    unsigned* cnt = sync + (size_t)rg * T;
+    unsigned* cnt = sync + 32 + (size_t)rg * T * CSTRIDE;
     float hp = hpv[rr];
     float gir = 0.f, giz = 0.f, gin = 0.f;
     if (live) {
@@ -112,9 +140,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     }
     const float* hsrc = h_init;
     if (t > 0) {
-      wait_count(cnt + (t - 1), G, err);
+      wait_count(cnt + (size_t)(t - 1) * CSTRIDE, G, err);
       hsrc = out + (long long)(t - 1) * B * H;
     }
+    TSTAMP(0)   // poll + barrier
     f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -135,15 +164,18 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].w, w[g][ci].w, acc[g], 0, 0, 0);
       }
     }
+    asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
+    TSTAMP(1)   // loads + MFMA
     float gh[3];
     cross_wave_reduce<3>(red, acc, gh, wave, lane);
+    TSTAMP(2)   // reduce
     if (live) {
       const float ghn = gh[2] + bhn;
       const float r = sigmoidf_(gir + gh[0] + bhr);
       const float z = sigmoidf_(giz + gh[1] + bhz);
       const float n = tanhf(gin + r * ghn);
       const float h = (1.0f - z) * n + z * hp;
-      store_sc1(out + ((long long)t * B + row) * H + unit, h);
+      hs[(4 * q + wave) * TP + j] = h;
       if (reserve) {
         float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
         rs[0] = r; rs[H] = z; rs[2 * H] = n; rs[3 * H] = ghn;
@@ -151,9 +183,23 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
       hp = h;
     }
     hpv[rr] = hp;
-    publish_count(cnt + t);  // also fences `red` for the next iteration
+    TSTAMP(3)   // gates
+    __syncthreads();                       // tile staged; also fences `red` for the next iteration
+    if (wave == 0) {                       // one wave writes the 16x16 tile as 64 x 16 B write-through stores
+      const int r = lane >> 2, c4 = (lane & 3) * 4;
+      if (m0 + r < B)
+        store_sc1_f4(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + j0 + c4) * 4),
+                     *reinterpret_cast<const float4*>(&hs[r * TP + c4]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
+    }
+    TSTAMP(4)   // stage barrier + store + drain + publish
    }
   }
+#ifdef B2T_TIMING
+  if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 17))
+    for (int i = 0; i < 5; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -170,13 +216,14 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  const float* __restrict__ w_hh_t, float* dG,
                                                                  float* __restrict__ dh_init, int T, int B, int H,
                                                                  unsigned* sync) {
-  __shared__ float red[4 * 4 * 64];
+  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 + 4 * 16 * TP];
+  float* gs = red + 4 * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j0 = blockIdx.x * 16;
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
   const int unit = j0 + j;
-  unsigned* err = sync + (size_t)gridDim.y * MT * T;
+  unsigned* err = sync;  // word 0: error flag; counters start at word 16
   const int nch = 3 * H / 16;
 
   float4 w[NCB];
@@ -198,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     if (m0 >= B) continue;
     const int row = m0 + 4 * q + wave, arow = m0 + j;
     const bool live = row < B;
-    unsigned* cnt = sync + (size_t)rg * T;
+    unsigned* cnt = sync + 32 + (size_t)rg * T * CSTRIDE;
     float dzterm = dzv[rr];
     // operands of the elementwise part do not depend on the recurrence: fetch them first
     float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hprev = 0.f, dy = 0.f;
@@ -210,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     }
     float carry = 0.f;
     if (t < T - 1) {
-      wait_count(cnt + (t + 1), G, err);
+      wait_count(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
       const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       float4 a[NCB];
@@ -244,20 +291,28 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       const float dn_pre = dn * (1.0f - n * n);
       const float dz_pre = dz * z * (1.0f - z);
       const float dr_pre = dn_pre * ghn * r * (1.0f - r);
-      float* dg = dG + ((long long)t * B + row) * 4 * H + unit;
-      store_sc1(dg, dr_pre);
-      store_sc1(dg + H, dz_pre);
-      store_sc1(dg + 2 * H, dn_pre * r);
-      store_sc1(dg + 3 * H, dn_pre);
+      const int lr = 4 * q + wave;
+      gs[(0 * 16 + lr) * TP + j] = dr_pre;
+      gs[(1 * 16 + lr) * TP + j] = dz_pre;
+      gs[(2 * 16 + lr) * TP + j] = dn_pre * r;
+      gs[(3 * 16 + lr) * TP + j] = dn_pre;
       dzterm = d * z;
     }
     dzv[rr] = dzterm;
-    publish_count(cnt + t);
+    __syncthreads();
+    {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores
+      const int r2 = lane >> 2, c4 = (lane & 3) * 4;
+      if (m0 + r2 < B)
+        store_sc1_f4(dG + (long long)t * B * 4 * H,
+                     (unsigned)(((long long)(m0 + r2) * 4 * H + wave * H + j0 + c4) * 4),
+                     *reinterpret_cast<const float4*>(&gs[(wave * 16 + r2) * TP + c4]));
+    }
+    publish_count(cnt + (size_t)t * CSTRIDE);
    }
   }
 }
 
-size_t gru_persistent_sync_bytes(int T) { return ((size_t)T * 64 + 64) * sizeof(unsigned); }
+size_t gru_persistent_sync_bytes(int T) { return ((size_t)T * 64 * CSTRIDE + 64) * sizeof(unsigned); }
 
 static int cu_count() {
   static int n = -1;
@@ -296,16 +351,16 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   const int mt = pick_mt(B);
   dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T + 16) * sizeof(unsigned), s), "gru_layer_fwd: memset");
+  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T * CSTRIDE + 32) * sizeof(unsigned), s), "gru_layer_fwd: memset");
   if (rc) return rc;
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
     if (mt == 2)                                                                                                       \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 2>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync);                                                                                  \
+                         B, H, sync, 0LL, 0LL, 0LL, 0LL);                                                              \
     else                                                                                                               \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 1>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync);                                                                                  \
+                         B, H, sync, 0LL, 0LL, 0LL, 0LL);                                                              \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
@@ -325,7 +380,7 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   const int mt = pick_mt(B);
   dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T + 16) * sizeof(unsigned), s), "gru_layer_bwd: memset");
+  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T * CSTRIDE + 32) * sizeof(unsigned), s), "gru_layer_bwd: memset");
   if (rc) return rc;
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
   do {                                                                                                                \
@@ -348,12 +403,27 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
 
 }  // namespace b2t
 
+// EXPERIMENT: nz independent forward sweeps (H=512 only) packed into one launch via blockIdx.z.
+extern "C" int b2t_exp_gru_fwd_multi(const float* gi, const float* w_hh, const float* b_hh, float* outbuf, float* reserve,
+                                     int T, int B, int H, int nz, void* sync_ws, void* stream) {
+  using namespace b2t;
+  dim3 grid(H / 16, (B + 15) / 16, nz), block(256);
+  unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
+  const long long zs_sync = (long long)grid.y * T * CSTRIDE + 32;
+  hipMemsetAsync(sync, 0, (size_t)zs_sync * nz * sizeof(unsigned), as_stream(stream));
+  const long long zs_out = (long long)(T + 1) * B * H;
+  hipLaunchKernelGGL((gru_persist_fwd_kernel<8, 1>), grid, block, 0, as_stream(stream), gi, w_hh, b_hh, outbuf,
+                     outbuf + (long long)B * H, reserve, T, B, H, sync, (long long)T * B * 3 * H, (long long)3 * H * H, zs_out,
+                     zs_sync);
+  return check_hip(hipGetLastError(), "exp multi");
+}
+
 // Error word of the last persistent sweep that used sync_ws (0 = clean, 1 = a bounded spin gave up).
 extern "C" int b2t_gru_sync_status(const void* sync_ws, int T, int B, int* status_host, void* stream) {
   using namespace b2t;
   B2T_REQUIRE(sync_ws && status_host, "gru_sync_status: null argument");
-  const int mt = b2t::pick_mt(B);
-  const size_t off = (size_t)(((B + 15) / 16 + mt - 1) / mt) * mt * T;
+  (void)T; (void)B;
+  const size_t off = 0;  // word 0 of the sync workspace
   int rc = check_hip(hipMemcpyAsync(status_host, reinterpret_cast<const unsigned*>(sync_ws) + off, sizeof(int),
                                     hipMemcpyDeviceToHost, as_stream(stream)), "gru_sync_status: copy");
   if (rc) return rc;

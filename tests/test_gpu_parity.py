@@ -302,7 +302,7 @@ def test_gru_sweep_modes(golden_dir, tag, mode):
         np.testing.assert_allclose(hidden.cpu().numpy(), z["hidden"], atol=1e-4)
         if mode == 1:
             B, T = z["x"].shape[0], logits.shape[1]
-            ops.gru_sync_check(m._ws.get("gru_sync", (N_sync(T),), dev, torch.int32), T, B)
+            ops.gru_sync_check_all(m._ws, m.n_layers, T, B, dev)
     finally:
         ops.GRU_MODE["value"] = old
 
@@ -349,6 +349,6 @@ def test_train_step_modes_vs_oracle(mode):
             for k, ref in go.items():
                 np.testing.assert_allclose(got[k], ref, atol=1e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=f"{k} rep{rep}")
         if mode == 1:
-            ops.gru_sync_check(model._ws.get("gru_sync", (N_sync(T),), dev, torch.int32), T, B)
+            ops.gru_sync_check_all(model._ws, L, T, B, dev)
     finally:
         ops.GRU_MODE["value"] = old

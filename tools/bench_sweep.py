@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Concurrency scaling of the persistent GRU sweeps: N independent layer sweeps on N streams."""
+import os, sys, ctypes as C
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nejm-brain-to-text_amd"))
+import torch
+import b2t_native as N, b2t_ops as ops
+lib = N.load()
+dev = torch.device("cuda:0")
+B, H = 64, 512
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 125
+_p = ops._p
+def mk(n):
+    out = []
+    for i in range(n):
+        d = dict(gi=torch.randn(T, B, 3 * H, device=dev) * 0.1, w=torch.randn(3 * H, H, device=dev) * 0.04,
+                 b=torch.zeros(3 * H, device=dev), out=torch.zeros(T + 1, B, H, device=dev),
+                 res=torch.empty(T, B, 4 * H, device=dev), sync=torch.zeros(lib.b2t_gru_sync_bytes(T) // 4 + 16, dtype=torch.int32, device=dev),
+                 s=torch.cuda.Stream(), dY=torch.randn(T, B, H, device=dev) * 0.01, wt=torch.randn(H, 3 * H, device=dev) * 0.04,
+                 dG=torch.empty(T, B, 4 * H, device=dev), dh=torch.empty(B, H, device=dev), sc=torch.empty(B, H, device=dev))
+        out.append(d)
+    return out
+def fwd(d):
+    with torch.cuda.stream(d["s"]):
+        N.check(lib.b2t_gru_layer_fwd_f32(_p(d["gi"]), _p(d["w"]), _p(d["b"]), _p(d["out"][0]), _p(d["out"][1:]), _p(d["res"]), None, T, B, H, 1, _p(d["sync"]), ops._stream()), "f")
+def bwd(d):
+    with torch.cuda.stream(d["s"]):
+        N.check(lib.b2t_gru_layer_bwd_f32(_p(d["dY"]), None, _p(d["res"]), _p(d["out"][1:]), _p(d["out"][0]), _p(d["wt"]), _p(d["dG"]), _p(d["dh"]), _p(d["sc"]), T, B, H, 1, _p(d["sync"]), ops._stream()), "b")
+import time
+for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    for n in (1, 2, 3, 4, 5, 6):
+        ds = mk(n)
+        for d in ds: fwd(d)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for d in ds: fn(d)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print(f"{name} N={n}: wall {dt*1e3:7.3f} ms  -> {dt/T*1e6:6.2f} us/step wall, {dt/T/n*1e6:6.2f} us per sweep-step")
+
+lib.b2t_exp_gru_fwd_multi.restype = C.c_int
+lib.b2t_exp_gru_fwd_multi.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
+for n in (1, 2, 3, 4, 5, 6):
+    gi = torch.randn(n, T, B, 3 * H, device=dev) * 0.1; w = torch.randn(n, 3 * H, H, device=dev) * 0.04
+    b = torch.zeros(n, 3 * H, device=dev); out = torch.zeros(n, T + 1, B, H, device=dev); res = torch.empty(n, T, B, 4 * H, device=dev)
+    sync = torch.zeros(n * (4 * T * 32 + 32) + 64, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        N.check(lib.b2t_exp_gru_fwd_multi(_p(gi), _p(w), _p(b), _p(out), _p(res), T, B, H, n, _p(sync), ops._stream()), "m")
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"multi-z fwd N={n}: wall {dt*1e3:7.3f} ms -> {dt/T/n*1e6:6.2f} us per sweep-step  timing(ticks/step) wg0={sync[8:13].tolist()} wg17={sync[16:21].tolist()}")
