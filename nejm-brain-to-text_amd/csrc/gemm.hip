@@ -1,20 +1,36 @@
 // gemm.hip — exact-fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32).
 //
 // C[z][m][n] (+)= sum_k A(z,m,k) * B(z,n,k) (+ bias[n]) -> optional softsign.
-// 128x128x16 block tile, 256 threads = 4 wave64 in a 2x2 grid, each wave owns a 64x64
-// sub-tile = 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  Operands are staged through
-// LDS k-major ([k][m], row pitch 132 floats) so an MFMA fragment read is one conflict-free
-// ds_read_b32 per operand (lanes 0-31 read 32 consecutive floats).  Global->register prefetch of
-// tile k+1 overlaps the MFMAs of tile k; LDS is double buffered (one barrier per k-tile).
-// The f32-input MFMA is bit-for-bit a k-ordered fmaf chain (no reduced-precision path exists
-// on gfx950), so results match an fp32 CPU GEMM to summation-order roundoff.
+// 128x128xBK block tile, 256 threads = 4 wave64 in a 2x2 grid, each wave owns a 64x64 sub-tile =
+// 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  Operands are staged through LDS k-major
+// ([k][m]) so an MFMA fragment read is one conflict-free ds_read_b32 per operand (lanes 0-31 read 32
+// consecutive floats); fragment reads run one k-step ahead of the MFMAs that consume them.
+// Global->register prefetch of tile k+1 overlaps the MFMAs of tile k; LDS is double buffered (one barrier
+// per k-tile).  Full k-tiles take a branch-free load path (out-of-range rows/columns are clamped to valid
+// addresses: they only feed accumulator rows/columns that are never stored); only a partial last k-tile
+// takes the predicated path.  The f32-input MFMA is bit-for-bit a k-ordered fmaf chain (no reduced-
+// precision path exists on gfx950), so results match an fp32 CPU GEMM to summation-order roundoff.
 #include "common.h"
 
 namespace b2t {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BKT = 16, PITCH = 132;
+#ifndef B2T_GEMM_BK
+#define B2T_GEMM_BK 16
+#endif
+#ifndef B2T_GEMM_OCC
+#define B2T_GEMM_OCC 3
+#endif
+constexpr int BM = 128, BN = 128, BKT = B2T_GEMM_BK;
+constexpr int NLD = BKT / 8;       // float4 loads per thread per operand tile (128 x BKT floats / 256 threads)
+constexpr int TPR = BKT / 4;       // k-contiguous mode: threads per tile row
+constexpr int RPP = 256 / TPR;     // k-contiguous mode: rows covered per pass
+// LDS row pitch (floats).  k-contiguous operands are transposed on the way in (4 scalar ds_write_b32 per
+// float4): an odd pitch spreads the lanes that share a row over distinct banks.  m-contiguous operands are
+// stored as float4 rows and need a 16-byte aligned pitch.
+template <bool KC> struct Pitch { static constexpr int v = KC ? 129 : 132; };
+constexpr int PITCH_MAX = 132;
 
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias;
@@ -34,52 +50,63 @@ __device__ __forceinline__ long long rowoff(int i, long long s0, long long s1, i
 // Load one operand tile slice owned by this thread into 2 float4 registers.
 // KC (k contiguous): tile rows are the M/N index (128 of them), 16 k per row -> thread (row=t/4+64r, k4=t%4)
 // MC (m contiguous): tile rows are k (16 of them), 128 m per row        -> thread (krow=t/32+8r, m4=t%32)
+// ---- fast path: a full k-tile, no predicates --------------------------------------------------------
+// KC (k contiguous): thread (row = tid/TPR + RPP*r, k4 = tid%TPR); roff[r] = offset of its (clamped) row.
+// MC (m contiguous): thread (krow = tid/32 + 8*r, m4 = tid%32);    mcl = clamped, 4-aligned column offset.
 template <bool KC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, const long long* roff, int ext0,
-                                          int ext_m, int base_m, int k0, int Kend,
-                                          long long s0, long long s1, int div, float4 (&v)[2], int tid) {
+__device__ __forceinline__ void load_full(const float* __restrict__ P, const long long (&roff)[NLD], int mcl, int k0,
+                                          long long s0, long long s1, int div, float4 (&v)[NLD], int tid) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < NLD; ++r) {
+    if constexpr (KC) {
+      v[r] = *reinterpret_cast<const float4*>(P + roff[r] + k0 + (tid % TPR) * 4);
+    } else {
+      v[r] = *reinterpret_cast<const float4*>(P + rowoff(k0 + (tid >> 5) + 8 * r, s0, s1, div) + mcl);
+    }
+  }
+}
+
+// ---- slow path: partial last k-tile (zero-filled beyond K, rows/columns beyond the extent zero) ------
+template <bool KC>
+__device__ __forceinline__ void load_tail(const float* __restrict__ P, const long long (&roff)[NLD], int ext_m,
+                                          int base_m, int k0, int Kend, long long s0, long long s1, int div,
+                                          float4 (&v)[NLD], int tid) {
+#pragma unroll
+  for (int r = 0; r < NLD; ++r) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (KC) {
-      const int row = base_m + (tid >> 2) + 64 * r;
-      const int k = k0 + (tid & 3) * 4;
+      const int row = base_m + tid / TPR + RPP * r;
+      const int k = k0 + (tid % TPR) * 4;
       if (row < ext_m) {
         const float* p = P + roff[r] + k;
-        if (k + 3 < Kend) {
-          o = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (k < Kend) o.x = p[0];
-          if (k + 1 < Kend) o.y = p[1];
-          if (k + 2 < Kend) o.z = p[2];
-        }
+        if (k < Kend) o.x = p[0];
+        if (k + 1 < Kend) o.y = p[1];
+        if (k + 2 < Kend) o.z = p[2];
+        if (k + 3 < Kend) o.w = p[3];
       }
     } else {
       const int k = k0 + (tid >> 5) + 8 * r;
       const int m = base_m + (tid & 31) * 4;
       if (k < Kend) {
         const float* p = P + rowoff(k, s0, s1, div) + m;
-        if (m + 3 < ext_m) {
-          o = *reinterpret_cast<const float4*>(p);
-        } else {
-          if (m < ext_m) o.x = p[0];
-          if (m + 1 < ext_m) o.y = p[1];
-          if (m + 2 < ext_m) o.z = p[2];
-        }
+        if (m < ext_m) o.x = p[0];
+        if (m + 1 < ext_m) o.y = p[1];
+        if (m + 2 < ext_m) o.z = p[2];
+        if (m + 3 < ext_m) o.w = p[3];
       }
     }
     v[r] = o;
   }
-  (void)ext0;
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&v)[2], int tid) {
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&v)[NLD], int tid) {
+  constexpr int PITCH = Pitch<KC>::v;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < NLD; ++r) {
     if constexpr (KC) {
-      const int row = (tid >> 2) + 64 * r;
-      const int k = (tid & 3) * 4;
+      const int row = tid / TPR + RPP * r;
+      const int k = (tid % TPR) * 4;
       S[(k + 0) * PITCH + row] = v[r].x;
       S[(k + 1) * PITCH + row] = v[r].y;
       S[(k + 2) * PITCH + row] = v[r].z;
@@ -93,10 +120,11 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (
 }
 
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKT * PITCH];
+__global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKT * PITCH_MAX];
+  constexpr int PA = Pitch<AKC>::v, PB = Pitch<BKC>::v;
   float* As = smem;
-  float* Bs = smem + 2 * BKT * PITCH;
+  float* Bs = smem + 2 * BKT * PITCH_MAX;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -111,21 +139,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const float* bias = (g.bias && ks == 0) ? g.bias + (long long)zb * g.bias_sz : nullptr;
   float* C = g.C + (long long)z * g.c_sz + (long long)ks * g.c_ks;
 
-  long long roffA[2] = {0, 0}, roffB[2] = {0, 0};
-  if constexpr (AKC) {
+  // per-thread row offsets (k-contiguous operands) / clamped column offsets (m-contiguous operands)
+  long long roffA[NLD], roffB[NLD];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int row = m0 + (tid >> 2) + 64 * r;
-      roffA[r] = rowoff(row < g.M ? row : 0, g.a_s0, g.a_s1, g.a_div);
-    }
+  for (int r = 0; r < NLD; ++r) {
+    const int ra_ = m0 + tid / TPR + RPP * r, rb_ = n0 + tid / TPR + RPP * r;
+    roffA[r] = AKC ? rowoff(ra_ < g.M ? ra_ : g.M - 1, g.a_s0, g.a_s1, g.a_div) : 0;
+    roffB[r] = BKC ? rowoff(rb_ < g.N ? rb_ : g.N - 1, g.b_s0, g.b_s1, g.b_div) : 0;
   }
-  if constexpr (BKC) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int row = n0 + (tid >> 2) + 64 * r;
-      roffB[r] = rowoff(row < g.N ? row : 0, g.b_s0, g.b_s1, g.b_div);
-    }
-  }
+  // m-contiguous: a float4 that starts inside the (4-padded) row stays inside the row pitch; one that starts
+  // beyond it is redirected to the last in-range float4.
+  const int mclA = min(m0 + (tid & 31) * 4, ((g.M + 3) & ~3) - 4);
+  const int mclB = min(n0 + (tid & 31) * 4, ((g.N + 3) & ~3) - 4);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -138,9 +163,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int kb = ks * g.kchunk;                      // split-K: this block reduces k in [kb, K)
   const int K = min(g.K, kb + g.kchunk);
   const int nk = (K - kb + BKT - 1) / BKT;
-  float4 ra[2], rb[2];
-  load_tile<AKC>(A, roffA, 0, g.M, m0, kb, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
-  load_tile<BKC>(B, roffB, 0, g.N, n0, kb, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
+  const int nfull = (K - kb) / BKT;                  // tiles that need no k predicate
+  float4 ra[NLD], rb[NLD];
+
+  auto fetch = [&](int kt) {
+    const int k0 = kb + kt * BKT;
+    if (kt < nfull) {
+      load_full<AKC>(A, roffA, mclA, k0, g.a_s0, g.a_s1, g.a_div, ra, tid);
+      load_full<BKC>(B, roffB, mclB, k0, g.b_s0, g.b_s1, g.b_div, rb, tid);
+    } else {
+      load_tail<AKC>(A, roffA, g.M, m0, k0, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
+      load_tail<BKC>(B, roffB, g.N, n0, k0, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
+    }
+  };
+  fetch(0);
   store_tile<AKC>(As, ra, tid);
   store_tile<BKC>(Bs, rb, tid);
   __syncthreads();
@@ -149,24 +185,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) {
-      load_tile<AKC>(A, roffA, 0, g.M, m0, kb + (kt + 1) * BKT, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
-      load_tile<BKC>(B, roffB, 0, g.N, n0, kb + (kt + 1) * BKT, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
-    }
-    const float* as = As + cur * BKT * PITCH + wm * 64 + li;
-    const float* bs = Bs + cur * BKT * PITCH + wn * 64 + li;
+    if (more) fetch(kt + 1);
+    const float* as = As + cur * BKT * PA + wm * 64 + li + lk * PA;
+    const float* bs = Bs + cur * BKT * PB + wn * 64 + li + lk * PB;
+    // fragment reads run one k-step ahead of the MFMAs
+    float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
 #pragma unroll
     for (int kk = 0; kk < BKT; kk += 2) {
-      const float a0 = as[(kk + lk) * PITCH], a1 = as[(kk + lk) * PITCH + 32];
-      const float b0 = bs[(kk + lk) * PITCH], b1 = bs[(kk + lk) * PITCH + 32];
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (kk + 2 < BKT) {
+        na0 = as[(kk + 2) * PA]; na1 = as[(kk + 2) * PA + 32];
+        nb0 = bs[(kk + 2) * PB]; nb1 = bs[(kk + 2) * PB + 32];
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     if (more) {
-      store_tile<AKC>(As + (cur ^ 1) * BKT * PITCH, ra, tid);
-      store_tile<BKC>(Bs + (cur ^ 1) * BKT * PITCH, rb, tid);
+      store_tile<AKC>(As + (cur ^ 1) * BKT * PA, ra, tid);
+      store_tile<BKC>(Bs + (cur ^ 1) * BKT * PB, rb, tid);
     }
     __syncthreads();
     cur ^= 1;
