@@ -107,6 +107,9 @@ int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t see
  * W_hh slices resident in registers, agent-scope flag hand-off of h_t between workgroups).
  * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode; zeroed by the call). */
 size_t b2t_gru_sync_bytes(int T);
+/* Workspace size valid for every mode (mode 2 = persistent sweep with data-tagged 8-byte {value,tag}
+ * granule hand-off, csrc/gru_granule.hip: needs T*B*H*8 bytes of granules behind the control words). */
+size_t b2t_gru_ws_bytes(int T, int B, int H);
 /* Persistent mode only: copies the sweep's error word to the host and synchronises the stream.
  * *status_host = 0: clean; 1: a bounded hand-off spin gave up (results of that sweep are invalid). */
 int b2t_gru_sync_status(const void* sync_ws, int T, int B, int* status_host, void* stream);

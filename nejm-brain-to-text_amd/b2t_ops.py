@@ -207,8 +207,11 @@ class Grads(Params):
     """Destination views for parameter gradients (normally views of the model's gradient arena)."""
 
 
-# GRU sweep mode: 1 = persistent single-launch sweep (csrc/gru_persistent.hip), 0 = one launch per time step.
-# -1 = choose per call: persistent whenever its (H/16) x ceil(B/16) workgroups can be co-resident.
+# GRU sweep mode: 0 = one launch per time step; 1 = persistent single-launch sweep with counter hand-off
+# (csrc/gru_persistent.hip); 2 = persistent sweep with data-tagged granule hand-off (csrc/gru_granule.hip).
+# -1 = choose per call: mode 1 whenever its (H/16) x ceil(B/16) workgroups can be co-resident, else 0.
+# (Mode 2 is parity-clean but measured SLOWER than mode 1 on MI355X — 5.6 vs 4.6 us/step at H=512, B=64: with a
+# 32 KB payload per workgroup-step every retry of the tagged read is a full fabric round trip; it stays opt-in.)
 GRU_MODE = {"value": int(os.environ.get("B2T_GRU_MODE", "-1"))}
 MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its workgroups resident at once
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer, no side streams).
@@ -217,7 +220,7 @@ PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16}
 
 def gru_mode_for(B: int, H: int) -> int:
     m = GRU_MODE["value"]
-    if m in (0, 1):
+    if m in (0, 1, 2):
         return m
     return 1 if (H // 16) * ((B + 15) // 16) <= MAX_RESIDENT_WGS and H <= 1024 else 0
 
@@ -230,9 +233,10 @@ def gru_sync_check(sync_ws, T: int, B: int):
         raise RuntimeError("persistent GRU sweep: inter-workgroup hand-off timed out (results invalid)")
 
 
-def gru_sync_check_all(ws, L: int, Tp: int, B: int, device):
+def gru_sync_check_all(ws, L: int, Tp: int, B: int, device, H: int = 512):
     for l in range(L):
-        gru_sync_check(ws.sync_ws(l, Tp, device), Tp, B)
+        gru_sync_check(ws.sync_ws(l, Tp, device, B, H), Tp, B)
+        gru_sync_check(ws.sync_ws(l, Tp, device, B, H, "b"), Tp, B)
 
 
 class Workspace:
@@ -246,7 +250,7 @@ class Workspace:
         key = (name, tuple(shape), str(device), dtype)
         t = self.bufs.get(key)
         if t is None:
-            t = torch.empty(shape, dtype=dtype, device=device)
+            t = (torch.zeros if dtype == torch.int32 else torch.empty)(shape, dtype=dtype, device=device)
             self.bufs[key] = t
         return t
 
@@ -257,8 +261,8 @@ class Workspace:
                                  [torch.cuda.Stream(device=device) for _ in range(L)])
         return self.streams[key]
 
-    def sync_ws(self, l, Tp, device):
-        return self.get(f"gru_sync{l}", (N.load().b2t_gru_sync_bytes(Tp) // 4 + 16,), device, torch.int32)
+    def sync_ws(self, l, Tp, device, B=64, H=512, tag=""):
+        return self.get(f"gru_sync{tag}{l}", (N.load().b2t_gru_ws_bytes(Tp, B, H) // 4 + 16,), device, torch.int32)
 
 
 def time_chunks(Tp: int) -> List[Tuple[int, int]]:
@@ -368,7 +372,7 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
                         C.c_void_p(outs[l].data_ptr() + 4 * t0 * B * H),
                         C.c_void_p(outs[l].data_ptr() + 4 * (1 + t0) * B * H), res_ptr,
                         _p(hidden[l]) if t1 == Tp else None, n, B, H, mode,
-                        _p(ws.sync_ws(l, Tp, dev)) if mode == 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
+                        _p(ws.sync_ws(l, Tp, dev, B, H)) if mode >= 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
                 if piped:
                     ev_sw[l][c] = _ev(ss)
     if piped:
@@ -493,7 +497,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                         C.c_void_p(ctx.reserves[l].data_ptr() + 4 * t0 * B * 4 * H),
                         C.c_void_p(outb.data_ptr() + 4 * (1 + t0) * B * H), C.c_void_p(outb.data_ptr() + 4 * t0 * B * H),
                         _p(whh_ts[l]), C.c_void_p(dGs[l].data_ptr() + 4 * t0 * B * 4 * H), dh_out, _p(scratch[l]),
-                        n, B, H, mode, _p(ws.sync_ws(l, Tp, dev)) if mode == 1 else None, _stream()),
+                        n, B, H, min(mode, 1), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
                         "b2t_gru_layer_bwd_f32")
                 if piped:
                     ev_bs[l][c] = _ev(ss)

@@ -113,13 +113,20 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
 using namespace b2t;
 
 extern "C" size_t b2t_gru_sync_bytes(int T) { return b2t::gru_persistent_sync_bytes(T); }
+extern "C" size_t b2t_gru_ws_bytes(int T, int B, int H) {
+  const size_t a = b2t::gru_persistent_sync_bytes(T), g = b2t::gru_granule_bytes(T, B, H);
+  return a > g ? a : g;
+}
 
 extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init,
                                      float* out, float* reserve, float* h_last, int T, int B, int H, int mode,
                                      void* sync_ws, void* stream) {
   B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_fwd: bad shape T=%d B=%d H=%d (H%%16 must be 0)", T, B, H);
   hipStream_t s = as_stream(stream);
-  if (mode == 1) {
+  if (mode == 2) {
+    int rc = gru_granule_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
+    if (rc) return rc;
+  } else if (mode == 1) {
     int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
     if (rc) return rc;
   } else {
@@ -145,7 +152,7 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
   B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_bwd: bad shape T=%d B=%d H=%d", T, B, H);
   B2T_REQUIRE(carry_ws != nullptr, "gru_layer_bwd: carry_ws is required ([B][H] floats)");
   hipStream_t s = as_stream(stream);
-  if (mode == 1) {
+  if (mode >= 1) {
     return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s);
   }
   dim3 grid(H / 16, (B + 15) / 16), block(256);

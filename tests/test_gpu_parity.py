@@ -284,7 +284,7 @@ def test_edit_distance_random():
     np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("tag", ["h64", "h512", "patch"])
 def test_gru_sweep_modes(golden_dir, tag, mode):
     """Step-launch (0) and persistent (1) sweeps both reproduce the reference forward, and the persistent
@@ -300,9 +300,9 @@ def test_gru_sweep_modes(golden_dir, tag, mode):
             logits, hidden = m(torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["day_idx"]).to(dev), None, True)
         np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], atol=1e-4)
         np.testing.assert_allclose(hidden.cpu().numpy(), z["hidden"], atol=1e-4)
-        if mode == 1:
+        if mode >= 1:
             B, T = z["x"].shape[0], logits.shape[1]
-            ops.gru_sync_check_all(m._ws, m.n_layers, T, B, dev)
+            ops.gru_sync_check_all(m._ws, m.n_layers, T, B, dev, m.n_units)
     finally:
         ops.GRU_MODE["value"] = old
 
@@ -312,7 +312,7 @@ def N_sync(T):
     return Nn.load().b2t_gru_sync_bytes(T) // 4 + 16
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_train_step_modes_vs_oracle(mode):
     """C2-shaped slice (H=512, L=2, B=40 = 2.5 row groups, T=60): loss + every gradient vs the oracle, both modes,
     run 3 times back-to-back so the persistent hand-off is exercised with warm caches."""
@@ -348,7 +348,7 @@ def test_train_step_modes_vs_oracle(mode):
             assert set(got) == set(go)
             for k, ref in go.items():
                 np.testing.assert_allclose(got[k], ref, atol=1e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=f"{k} rep{rep}")
-        if mode == 1:
-            ops.gru_sync_check_all(model._ws, L, T, B, dev)
+        if mode >= 1:
+            ops.gru_sync_check_all(model._ws, L, T, B, dev, H)
     finally:
         ops.GRU_MODE["value"] = old

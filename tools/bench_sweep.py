@@ -10,20 +10,21 @@ lib = N.load()
 dev = torch.device("cuda:0")
 B, H = 64, 512
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 125
+FMODE = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 _p = ops._p
 def mk(n):
     out = []
     for i in range(n):
         d = dict(gi=torch.randn(T, B, 3 * H, device=dev) * 0.1, w=torch.randn(3 * H, H, device=dev) * 0.04,
                  b=torch.zeros(3 * H, device=dev), out=torch.zeros(T + 1, B, H, device=dev),
-                 res=torch.empty(T, B, 4 * H, device=dev), sync=torch.zeros(lib.b2t_gru_sync_bytes(T) // 4 + 16, dtype=torch.int32, device=dev),
+                 res=torch.empty(T, B, 4 * H, device=dev), sync=torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev),
                  s=torch.cuda.Stream(), dY=torch.randn(T, B, H, device=dev) * 0.01, wt=torch.randn(H, 3 * H, device=dev) * 0.04,
                  dG=torch.empty(T, B, 4 * H, device=dev), dh=torch.empty(B, H, device=dev), sc=torch.empty(B, H, device=dev))
         out.append(d)
     return out
 def fwd(d):
     with torch.cuda.stream(d["s"]):
-        N.check(lib.b2t_gru_layer_fwd_f32(_p(d["gi"]), _p(d["w"]), _p(d["b"]), _p(d["out"][0]), _p(d["out"][1:]), _p(d["res"]), None, T, B, H, 1, _p(d["sync"]), ops._stream()), "f")
+        N.check(lib.b2t_gru_layer_fwd_f32(_p(d["gi"]), _p(d["w"]), _p(d["b"]), _p(d["out"][0]), _p(d["out"][1:]), _p(d["res"]), None, T, B, H, FMODE, _p(d["sync"]), ops._stream()), "f")
 def bwd(d):
     with torch.cuda.stream(d["s"]):
         N.check(lib.b2t_gru_layer_bwd_f32(_p(d["dY"]), None, _p(d["res"]), _p(d["out"][1:]), _p(d["out"][0]), _p(d["wt"]), _p(d["dG"]), _p(d["dh"]), _p(d["sc"]), T, B, H, 1, _p(d["sync"]), ops._stream()), "b")
@@ -40,14 +41,3 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
             dt = time.perf_counter() - t0
         print(f"{name} N={n}: wall {dt*1e3:7.3f} ms  -> {dt/T*1e6:6.2f} us/step wall, {dt/T/n*1e6:6.2f} us per sweep-step")
 
-lib.b2t_exp_gru_fwd_multi.restype = C.c_int
-lib.b2t_exp_gru_fwd_multi.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
-for n in (1, 2, 3, 4, 5, 6):
-    gi = torch.randn(n, T, B, 3 * H, device=dev) * 0.1; w = torch.randn(n, 3 * H, H, device=dev) * 0.04
-    b = torch.zeros(n, 3 * H, device=dev); out = torch.zeros(n, T + 1, B, H, device=dev); res = torch.empty(n, T, B, 4 * H, device=dev)
-    sync = torch.zeros(n * (4 * T * 32 + 32) + 64, dtype=torch.int32, device=dev)
-    for rep in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        N.check(lib.b2t_exp_gru_fwd_multi(_p(gi), _p(w), _p(b), _p(out), _p(res), T, B, H, n, _p(sync), ops._stream()), "m")
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"multi-z fwd N={n}: wall {dt*1e3:7.3f} ms -> {dt/T/n*1e6:6.2f} us per sweep-step  timing(ticks/step) wg0={sync[8:13].tolist()} wg17={sync[16:21].tolist()}")
