@@ -172,9 +172,26 @@ int b2t_edit_distance_i32(const int32_t* a, const int32_t* a_len, int La_max, co
 
 /* ---- a14/a17: LM-decoder prologue + CTC prefix beam search ---------------------------------
  * lm_decoder.cc:14-37 DecodeNumpy: logp = log_softmax(logits) - log_priors; logp[:,0] -= blank_penalty.
- * (The batched prefix-beam kernel of ctc_prefix_beam_search.cc:44-136 is declared here once built.) */
+ * logits/logp [rows][C]; log_priors may be NULL (zeros). */
 int b2t_lm_prologue_f32(const float* logits, const float* log_priors, float blank_penalty,
                         float* logp, int rows, int C, void* stream);
+/* Batched CTC prefix beam search — the LM-free searcher BrainSpeechDecoder uses when no TLG graph is loaded
+ * (language_model/runtime/core/decoder/ctc_prefix_beam_search.cc:44-136; PrefixScore ctc_prefix_beam_search.h:27-42;
+ * LogAdd language_model/runtime/core/utils/utils.cc:24-30).  One workgroup per utterance, beam in LDS,
+ * prefix trie + search state in the caller-provided `state` block (U * b2t_beam_state_bytes bytes), which
+ * persists between calls so logp can be fed chunk by chunk (streaming).  b2t_beam_reset = Reset().
+ *   logp [U][T][C] (C <= 64), lens [U] (NULL: T), first_beam <= 16 classes per frame, second_beam <= 32 prefixes.
+ * Outputs, sorted best first (slots beyond the live beam: hyp_len = -1):
+ *   hyps [U][second_beam][max_len] token ids, hyp_len [U][second_beam], score = LogAdd(s, ns), vscore = Viterbi
+ *   score, times [U][second_beam][max_len] (frame of each token on the Viterbi path; may be NULL).
+ * max_nodes bounds the trie (<= second_beam new nodes per frame); b2t_beam_overflowed reports exhaustion. */
+size_t b2t_beam_state_bytes(int max_len, int max_nodes);
+int b2t_beam_reset(void* state, int U, int max_len, int max_nodes, void* stream);
+int b2t_prefix_beam_search_f32(const float* logp, const int32_t* lens, int U, int T, int C, int first_beam,
+                               int second_beam, int blank, void* state, int max_len, int max_nodes,
+                               int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
+                               void* stream);
+int b2t_beam_overflowed(const void* state, int U, int max_len, int max_nodes, int* flag_host, void* stream);
 
 #ifdef __cplusplus
 }

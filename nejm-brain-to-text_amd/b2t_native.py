@@ -65,6 +65,11 @@ _SIGNATURES = {
     "b2t_greedy_decode_f32": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_edit_distance_i32": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, VP, C.c_int, VP]),
     "b2t_lm_prologue_f32": (C.c_int, [VP, VP, C.c_float, VP, C.c_int, C.c_int, VP]),
+    "b2t_beam_state_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "b2t_beam_reset": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
+    "b2t_prefix_beam_search_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int,
+                                             C.c_int, VP, VP, VP, VP, VP, VP]),
+    "b2t_beam_overflowed": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), VP]),
 }
 
 

@@ -1,0 +1,381 @@
+// beam.hip — batched CTC prefix beam search (LM-free searcher of the reference's decoder:
+// language_model/runtime/core/decoder/ctc_prefix_beam_search.cc:44-136, PrefixScore at
+// ctc_prefix_beam_search.h:27-42, LogAdd at language_model/runtime/core/utils/utils.cc:24-30).
+//
+// One workgroup per utterance; the live beam (<= 32 prefixes: scores, Viterbi scores, trie node ids) lives
+// in LDS for the whole call, frames are consumed sequentially.  Prefixes are nodes of a per-utterance trie in
+// HBM (parent/token/depth arrays + an open-addressing hash on (parent, token)), so prefix identity — the
+// std::unordered_map<vector<int>> key of the reference — is a node id and merging two ways of reaching the
+// same prefix is an integer compare.  Every frame is evaluated in GATHER form: one thread per output
+// candidate ("prefix h stays" / "prefix h extended by top-k class c") collects the <= 3 contributions the
+// reference's scatter loops would add to it (blank, repeated last token, extension of the parent prefix), so
+// the log-sum order is fixed and the result is deterministic.  Survivors are ranked by counting and written
+// in sorted order.  Viterbi token times are kept per prefix like the reference (times_s / times_ns).
+// State persists in HBM between calls: Search() can be fed frame by frame (streaming decode).
+#include "common.h"
+
+namespace b2t {
+
+constexpr int BMAX = 32;           // max second_beam_size
+constexpr int KMAX = 16;           // max first_beam_size
+constexpr int NCAND = BMAX * (KMAX + 1);
+constexpr float NEGMAX = -3.402823466e38f;   // -FLT_MAX: the reference's log-zero sentinel
+
+__device__ __forceinline__ float log_add(float x, float y) {
+  if (x <= NEGMAX) return y;
+  if (y <= NEGMAX) return x;
+  const float m = fmaxf(x, y);
+  return logf(expf(x - m) + expf(y - m)) + m;
+}
+
+// ---- state layout (ints unless noted), per utterance ------------------------------------------------
+//   hdr[8]: nb, abs_t, node_count, cur, overflow
+//   parent[NN] token[NN] depth[NN]  hkey[HT] (u64)  hval[HT]
+//   hyp buffers x2: node[BMAX], fl[5][BMAX] (s, ns, v_s, v_ns, ctp), times_s[BMAX][L], times_ns[BMAX][L]
+struct BeamLayout {
+  int NN, HT, L;
+  size_t o_parent, o_token, o_depth, o_hkey, o_hval, o_hyp, hyp_stride, total;
+  __host__ __device__ BeamLayout(int nn, int l) {
+    NN = nn; L = l;
+    HT = 1; while (HT < 2 * nn) HT <<= 1;
+    size_t o = 8 * 4;
+    o_parent = o; o += (size_t)NN * 4;
+    o_token = o; o += (size_t)NN * 4;
+    o_depth = o; o += (size_t)NN * 4;
+    o = (o + 7) & ~(size_t)7;
+    o_hkey = o; o += (size_t)HT * 8;
+    o_hval = o; o += (size_t)HT * 4;
+    o_hyp = o;
+    hyp_stride = ((size_t)BMAX * 4 + (size_t)5 * BMAX * 4 + (size_t)2 * BMAX * L * 4);
+    o += 2 * hyp_stride;
+    total = (o + 255) & ~(size_t)255;
+  }
+};
+
+struct HypBuf {
+  int* node; float* fl; int* ts; int* tns;
+  __device__ HypBuf(unsigned char* base, const BeamLayout& lay, int which) {
+    unsigned char* p = base + lay.o_hyp + (size_t)which * lay.hyp_stride;
+    node = reinterpret_cast<int*>(p); p += BMAX * 4;
+    fl = reinterpret_cast<float*>(p); p += 5 * BMAX * 4;
+    ts = reinterpret_cast<int*>(p); p += (size_t)BMAX * lay.L * 4;
+    tns = reinterpret_cast<int*>(p);
+  }
+};
+
+__global__ void beam_reset_kernel(unsigned char* state, size_t per_utt, int NN, int L) {
+  BeamLayout lay(NN, L);
+  unsigned char* st = state + (size_t)blockIdx.x * per_utt;
+  int* hdr = reinterpret_cast<int*>(st);
+  unsigned long long* hkey = reinterpret_cast<unsigned long long*>(st + lay.o_hkey);
+  int* hval0 = reinterpret_cast<int*>(st + lay.o_hval);
+  for (int i = threadIdx.x; i < lay.HT; i += blockDim.x) { hkey[i] = ~0ull; hval0[i] = -1; }
+  if (threadIdx.x == 0) {
+    hdr[0] = 1; hdr[1] = 0; hdr[2] = 1; hdr[3] = 0; hdr[4] = 0;
+    reinterpret_cast<int*>(st + lay.o_parent)[0] = -1;   // node 0 = empty prefix
+    reinterpret_cast<int*>(st + lay.o_token)[0] = -1;
+    reinterpret_cast<int*>(st + lay.o_depth)[0] = 0;
+    HypBuf hb(st, lay, 0);
+    hb.node[0] = 0;
+    hb.fl[0 * BMAX] = 0.f;      // s
+    hb.fl[1 * BMAX] = NEGMAX;   // ns
+    hb.fl[2 * BMAX] = 0.f;      // v_s
+    hb.fl[3 * BMAX] = 0.f;      // v_ns   (ctc_prefix_beam_search.cc:27-31)
+    hb.fl[4 * BMAX] = NEGMAX;   // cur_token_prob
+  }
+}
+
+__device__ int trie_find_or_add(int parent, int token, int* par, int* tok, int* dep, unsigned long long* hkey,
+                                int* hval, int HT, int NN, int* hdr) {
+  const unsigned long long key = ((unsigned long long)(unsigned)parent << 32) | (unsigned)token;
+  unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & (unsigned)(HT - 1);
+  for (int probe = 0; probe < HT; ++probe) {
+    unsigned long long k = hkey[h];
+    if (k == key) {
+      int v;
+      while ((v = __hip_atomic_load(&hval[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {}
+      return v;
+    }
+    if (k == ~0ull) {
+      const unsigned long long prev = atomicCAS(&hkey[h], ~0ull, key);
+      if (prev == ~0ull) {
+        const int id = atomicAdd(&hdr[2], 1);
+        if (id >= NN) { hdr[4] = 1; hval[h] = 0; return 0; }   // overflow flag; results invalid
+        par[id] = parent; tok[id] = token; dep[id] = dep[parent] + 1;
+        __hip_atomic_store(&hval[h], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return id;
+      }
+      if (prev == key) continue;   // someone else inserted the same key: re-read this slot
+    }
+    h = (h + 1) & (unsigned)(HT - 1);
+  }
+  hdr[4] = 1;
+  return 0;
+}
+
+// times-vector source of a candidate: hyp index, which vector (0 = times_s, 1 = times_ns), op
+// (0 copy, 1 copy + append t, 2 copy + overwrite last with t, 3 empty)
+struct TSrc { short h; char vec; char op; };
+
+__global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restrict__ logp, const int32_t* __restrict__ lens,
+                                                          int T, int C, int K, int beam, int blank,
+                                                          unsigned char* state, size_t per_utt, int NN, int L,
+                                                          int32_t* __restrict__ hyps, int32_t* __restrict__ hyp_len,
+                                                          float* __restrict__ score, float* __restrict__ vscore,
+                                                          int32_t* __restrict__ times) {
+  const int u = blockIdx.x, tid = threadIdx.x;
+  BeamLayout lay(NN, L);
+  unsigned char* st = state + (size_t)u * per_utt;
+  int* hdr = reinterpret_cast<int*>(st);
+  int* par = reinterpret_cast<int*>(st + lay.o_parent);
+  int* tok = reinterpret_cast<int*>(st + lay.o_token);
+  int* dep = reinterpret_cast<int*>(st + lay.o_depth);
+  unsigned long long* hkey = reinterpret_cast<unsigned long long*>(st + lay.o_hkey);
+  int* hval = reinterpret_cast<int*>(st + lay.o_hval);
+
+  __shared__ int h_node[BMAX], h_par[BMAX], h_tok[BMAX], h_dep[BMAX];
+  __shared__ float h_s[BMAX], h_ns[BMAX], h_vs[BMAX], h_vns[BMAX], h_ctp[BMAX], h_score[BMAX], h_vit[BMAX];
+  __shared__ int tk_id[KMAX]; __shared__ float tk_p[KMAX];
+  __shared__ float cp[64];        // class log-probs of the frame; selection marks
+  __shared__ int c_valid[NCAND], c_node[NCAND], c_tok[NCAND], c_rank[NCAND];
+  __shared__ float c_s[NCAND], c_ns[NCAND], c_vs[NCAND], c_vns[NCAND], c_ctp[NCAND], c_sc[NCAND];
+  __shared__ TSrc c_ts[NCAND], c_tn[NCAND];
+  __shared__ int s_nb, s_cur, s_abs;
+
+  if (tid == 0) { s_nb = hdr[0]; s_abs = hdr[1]; s_cur = hdr[3]; }
+  __syncthreads();
+  {
+    HypBuf hb(st, lay, s_cur);
+    if (tid < s_nb) {
+      const int n = hb.node[tid];
+      h_node[tid] = n; h_par[tid] = par[n]; h_tok[tid] = tok[n]; h_dep[tid] = dep[n];
+      h_s[tid] = hb.fl[0 * BMAX + tid]; h_ns[tid] = hb.fl[1 * BMAX + tid]; h_vs[tid] = hb.fl[2 * BMAX + tid];
+      h_vns[tid] = hb.fl[3 * BMAX + tid]; h_ctp[tid] = hb.fl[4 * BMAX + tid];
+    }
+  }
+  __syncthreads();
+
+  int Tu = lens ? lens[u] : T;
+  if (Tu > T) Tu = T;
+  const float* lp_u = logp + (long long)u * T * C;
+
+  for (int f = 0; f < Tu; ++f) {
+    const int nb = s_nb, cur = s_cur, at = s_abs;
+    // ---- 1. first beam: top-K classes of the frame (one wave; ties -> lowest class id) --------------
+    if (tid < 64) {
+      float v = tid < C ? lp_u[(long long)f * C + tid] : -INFINITY;
+      cp[tid] = v;
+      for (int k = 0; k < K; ++k) {
+        float best = v; int bi = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (tid == 0) { tk_id[k] = bi; tk_p[k] = best; }
+        if (tid == bi) v = -INFINITY;
+      }
+    }
+    if (tid < nb) {
+      h_score[tid] = log_add(h_s[tid], h_ns[tid]);
+      h_vit[tid] = h_vs[tid] > h_vns[tid] ? h_vs[tid] : h_vns[tid];
+    }
+    __syncthreads();
+
+    // ---- 2. candidates (gather form) --------------------------------------------------------------------
+    const int ncand = nb * (K + 1);
+    for (int ci = tid; ci < ncand; ci += blockDim.x) {
+      const int h = ci / (K + 1), slot = ci - h * (K + 1);
+      float ns_ = NEGMAX, s_ = NEGMAX, vs_ = NEGMAX, vns_ = NEGMAX, ctp_ = NEGMAX;
+      TSrc ts{0, 0, 3}, tn{0, 0, 3};
+      int valid = 0, node = -1, token = -1, pnode = -1;
+      const int hvec = h_vs[h] > h_vns[h] ? 0 : 1;     // which vector PrefixScore::times() returns
+      if (slot == 0) {                                   // prefix h stays
+        node = h_node[h];
+        const int last = h_tok[h];
+        for (int k = 0; k < K; ++k) {
+          const int c = tk_id[k]; const float p = tk_p[k];
+          if (c == blank) {                              // case 0: *a + blank => *a
+            s_ = log_add(s_, h_score[h] + p);
+            vs_ = h_vit[h] + p;
+            ts = TSrc{(short)h, (char)hvec, 0};
+            valid = 1;
+          } else if (h_dep[h] > 0 && c == last) {        // case 1: *a + a => *a
+            ns_ = log_add(ns_, h_ns[h] + p);
+            if (vns_ < h_vns[h] + p) {
+              vns_ = h_vns[h] + p;
+              if (ctp_ < p) { ctp_ = p; tn = TSrc{(short)h, 1, 2}; }
+            }
+            valid = 1;
+          }
+        }
+        if (h_dep[h] > 0) {                              // extension of the parent prefix that lands on h
+          int hp = -1;
+          for (int x = 0; x < nb; ++x) if (h_node[x] == h_par[h]) hp = x;
+          if (hp >= 0) {
+            for (int k = 0; k < K; ++k) {
+              if (tk_id[k] != last || last == blank) continue;
+              const float p = tk_p[k];
+              float add, vc; TSrc src;
+              if (h_dep[hp] > 0 && last == h_tok[hp]) {  // case 2: *a(blank) + a => *aa
+                add = h_s[hp] + p; vc = h_vs[hp] + p; src = TSrc{(short)hp, 0, 1};
+              } else {                                   // case 3: *a + b => *ab
+                add = h_score[hp] + p; vc = h_vit[hp] + p;
+                src = TSrc{(short)hp, (char)(h_vs[hp] > h_vns[hp] ? 0 : 1), 1};
+              }
+              ns_ = log_add(ns_, add);
+              if (vns_ < vc) { vns_ = vc; ctp_ = p; tn = src; }
+              valid = 1;
+            }
+          }
+        }
+      } else {                                           // prefix h extended by class c (new prefix)
+        const int c = tk_id[slot - 1]; const float p = tk_p[slot - 1];
+        if (c != blank) {
+          bool merged = false;                           // already a live prefix: gathered by its "stay" slot
+          for (int x = 0; x < nb; ++x) merged |= (h_par[x] == h_node[h] && h_tok[x] == c && h_dep[x] > 0);
+          if (!merged) {
+            float add, vc; TSrc src;
+            if (h_dep[h] > 0 && c == h_tok[h]) { add = h_s[h] + p; vc = h_vs[h] + p; src = TSrc{(short)h, 0, 1}; }
+            else { add = h_score[h] + p; vc = h_vit[h] + p; src = TSrc{(short)h, (char)hvec, 1}; }
+            ns_ = log_add(ns_, add);
+            if (vns_ < vc) { vns_ = vc; ctp_ = p; tn = src; }
+            valid = 1; pnode = h_node[h]; token = c;
+          }
+        }
+      }
+      c_valid[ci] = valid; c_node[ci] = slot == 0 ? node : -1 - pnode; c_tok[ci] = token;
+      c_s[ci] = s_; c_ns[ci] = ns_; c_vs[ci] = vs_; c_vns[ci] = vns_; c_ctp[ci] = ctp_;
+      c_sc[ci] = valid ? log_add(s_, ns_) : -INFINITY;
+      c_ts[ci] = ts; c_tn[ci] = tn;
+    }
+    __syncthreads();
+
+    // ---- 3. second beam: rank by counting (ties -> lower candidate index), keep the best `beam` ---------
+    for (int ci = tid; ci < ncand; ci += blockDim.x) {
+      int r = 0;
+      if (c_valid[ci]) {
+        const float sc = c_sc[ci];
+        for (int x = 0; x < ncand; ++x) r += (c_valid[x] && (c_sc[x] > sc || (c_sc[x] == sc && x < ci)));
+      } else {
+        r = 1 << 20;
+      }
+      c_rank[ci] = r;
+    }
+    __syncthreads();
+
+    // ---- 4. write survivors (sorted) into the other hypothesis buffer ------------------------------------
+    HypBuf hc(st, lay, cur), hn(st, lay, cur ^ 1);
+    for (int ci = tid; ci < ncand; ci += blockDim.x) {
+      const int r = c_rank[ci];
+      if (r >= beam) continue;
+      int node = c_node[ci];
+      if (node < 0) node = trie_find_or_add(-1 - node, c_tok[ci], par, tok, dep, hkey, hval, lay.HT, lay.NN, hdr);
+      hn.node[r] = node;
+      hn.fl[0 * BMAX + r] = c_s[ci]; hn.fl[1 * BMAX + r] = c_ns[ci]; hn.fl[2 * BMAX + r] = c_vs[ci];
+      hn.fl[3 * BMAX + r] = c_vns[ci]; hn.fl[4 * BMAX + r] = c_ctp[ci];
+      // token-time vectors
+      for (int which = 0; which < 2; ++which) {
+        const TSrc src = which == 0 ? c_ts[ci] : c_tn[ci];
+        int* dst = (which == 0 ? hn.ts : hn.tns) + (size_t)r * lay.L;
+        if (src.op == 3) continue;
+        const int* sv = (src.vec == 0 ? hc.ts : hc.tns) + (size_t)src.h * lay.L;
+        const int n = h_dep[src.h];
+        for (int i = 0; i < n && i < lay.L; ++i) dst[i] = sv[i];
+        if (src.op == 1 && n < lay.L) dst[n] = at;
+        if (src.op == 2 && n > 0) dst[n - 1] = at;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cnt = 0;
+      for (int x = 0; x < ncand; ++x) cnt += c_valid[x];
+      s_nb = cnt < beam ? cnt : beam; s_cur = cur ^ 1; s_abs = at + 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // reload the new beam into LDS (node ids were assigned by other threads: read them back from the buffer)
+    {
+      HypBuf hb(st, lay, s_cur);
+      if (tid < s_nb) {
+        const int n = hb.node[tid];
+        h_node[tid] = n; h_par[tid] = par[n]; h_tok[tid] = tok[n]; h_dep[tid] = dep[n];
+        h_s[tid] = hb.fl[0 * BMAX + tid]; h_ns[tid] = hb.fl[1 * BMAX + tid]; h_vs[tid] = hb.fl[2 * BMAX + tid];
+        h_vns[tid] = hb.fl[3 * BMAX + tid]; h_ctp[tid] = hb.fl[4 * BMAX + tid];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- results: hypotheses (token sequences by walking the trie), scores, Viterbi times ------------------
+  if (tid == 0) { hdr[0] = s_nb; hdr[1] = s_abs; hdr[3] = s_cur; }
+  {
+    HypBuf hb(st, lay, s_cur);
+    if (tid < beam) {
+      const long long o = (long long)u * beam + tid;
+      if (tid < s_nb) {
+        const int n = h_dep[tid];
+        hyp_len[o] = n;
+        score[o] = log_add(h_s[tid], h_ns[tid]);
+        vscore[o] = h_vs[tid] > h_vns[tid] ? h_vs[tid] : h_vns[tid];
+        int node = h_node[tid];
+        for (int i = n - 1; i >= 0; --i) { if (i < L) hyps[o * L + i] = tok[node]; node = par[node]; }
+        const int* tv = (h_vs[tid] > h_vns[tid] ? hb.ts : hb.tns) + (size_t)tid * lay.L;
+        if (times) for (int i = 0; i < n && i < L; ++i) times[o * L + i] = tv[i];
+      } else {
+        hyp_len[o] = -1; score[o] = NEGMAX; vscore[o] = NEGMAX;
+      }
+    }
+  }
+}
+
+}  // namespace b2t
+
+using namespace b2t;
+
+extern "C" size_t b2t_beam_state_bytes(int max_len, int max_nodes) {
+  BeamLayout lay(max_nodes, max_len);
+  return lay.total;
+}
+
+extern "C" int b2t_beam_reset(void* state, int U, int max_len, int max_nodes, void* stream) {
+  B2T_REQUIRE(state && U > 0 && max_len > 0 && max_nodes > 1, "beam_reset: bad args");
+  BeamLayout lay(max_nodes, max_len);
+  hipLaunchKernelGGL(beam_reset_kernel, dim3(U), dim3(256), 0, as_stream(stream), reinterpret_cast<unsigned char*>(state),
+                     lay.total, max_nodes, max_len);
+  B2T_CHECK_LAUNCH("b2t_beam_reset");
+  return 0;
+}
+
+extern "C" int b2t_prefix_beam_search_f32(const float* logp, const int32_t* lens, int U, int T, int C, int first_beam,
+                                          int second_beam, int blank, void* state, int max_len, int max_nodes,
+                                          int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
+                                          void* stream) {
+  B2T_REQUIRE(logp && state && U > 0 && T > 0 && C > 1 && C <= 64, "prefix_beam_search: bad shape U=%d T=%d C=%d", U, T, C);
+  B2T_REQUIRE(first_beam >= 1 && second_beam >= 1 && second_beam <= BMAX, "prefix_beam_search: beams out of range (<=%d)", BMAX);
+  if (first_beam > C) first_beam = C;
+  B2T_REQUIRE(first_beam <= KMAX, "prefix_beam_search: first_beam_size <= %d", KMAX);
+  BeamLayout lay(max_nodes, max_len);
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+                     blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
+                     vscore, times);
+  B2T_CHECK_LAUNCH("b2t_prefix_beam_search_f32");
+  return 0;
+}
+
+// 1 if any utterance's trie overflowed max_nodes / max_len (results invalid); synchronises the stream.
+extern "C" int b2t_beam_overflowed(const void* state, int U, int max_len, int max_nodes, int* flag_host, void* stream) {
+  B2T_REQUIRE(state && flag_host, "beam_overflowed: null");
+  BeamLayout lay(max_nodes, max_len);
+  *flag_host = 0;
+  for (int u = 0; u < U; ++u) {
+    int hdr[8];
+    int rc = check_hip(hipMemcpyAsync(hdr, reinterpret_cast<const unsigned char*>(state) + (size_t)u * lay.total, sizeof(hdr),
+                                      hipMemcpyDeviceToHost, as_stream(stream)), "beam_overflowed: copy");
+    if (rc) return rc;
+    rc = check_hip(hipStreamSynchronize(as_stream(stream)), "beam_overflowed: sync");
+    if (rc) return rc;
+    if (hdr[4]) *flag_host = 1;
+  }
+  return 0;
+}

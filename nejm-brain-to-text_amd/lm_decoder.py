@@ -1,0 +1,162 @@
+"""lm_decoder — Python surface of the reference's pybind11 module
+(language_model/runtime/server/x86/python/lm_decoder.cc:51-75) over the HIP decoder kernels.
+
+Built so far: the DecodeNumpy prologue (log_softmax - priors, blank penalty) and the LM-free searcher the
+reference's BrainSpeechDecoder falls back to when no TLG graph is loaded (CtcPrefixBeamSearch,
+brain_speech_decoder.cc:23-28) — as a batched, streaming-capable GPU kernel (csrc/beam.hip).
+NOT built: WFST (TLG.fst) token passing, lattice n-best and LM rescoring: constructing a
+DecodeResource with an FST path raises NotImplementedError instead of silently decoding without a language model.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+import b2t_native as N
+import b2t_ops as ops
+
+K_SPACE = "▁"   # WeNet's kSpaceSymbol
+
+
+class DecodeOptions:
+    """DecodeOptions(max_active, min_active, beam, lattice_beam, acoustic_scale, ctc_blank_skip_threshold,
+    length_penalty, nbest) — same 8 positional arguments as the reference (language-model-standalone.py:486-496).
+    The WFST fields are stored; the prefix-beam searcher uses first_beam_size / second_beam_size (defaults 10/10)."""
+
+    def __init__(self, max_active, min_active, beam, lattice_beam, acoustic_scale, ctc_blank_skip_threshold,
+                 length_penalty, nbest):
+        self.max_active, self.min_active, self.beam, self.lattice_beam = max_active, min_active, beam, lattice_beam
+        self.acoustic_scale, self.ctc_blank_skip_threshold = acoustic_scale, ctc_blank_skip_threshold
+        self.length_penalty, self.nbest = length_penalty, nbest
+        self.first_beam_size, self.second_beam_size, self.blank = 10, 10, 0
+
+
+class DecodeResource:
+    """DecodeResource(fst_path, lm_fst_path, rescore_lm_fst_path, dict_path, unit_path)."""
+
+    def __init__(self, fst_path, lm_fst_path, rescore_lm_fst_path, dict_path, unit_path):
+        if fst_path or lm_fst_path or rescore_lm_fst_path:
+            raise NotImplementedError("WFST (TLG.fst / G.fst) decoding is not built on the HIP path yet; "
+                                      "pass empty FST paths to use the CTC prefix beam searcher")
+        self.symbols = self._read_table(dict_path) if dict_path else None
+        self.units = self._read_table(unit_path) if unit_path else None
+
+    @staticmethod
+    def _read_table(path):
+        table = {}
+        with open(path) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 2:
+                    table[int(parts[-1])] = parts[0]
+        return table
+
+
+class DecodeResult:
+    def __init__(self, sentence="", ac_score=0.0, lm_score=0.0):
+        self.sentence, self.ac_score, self.lm_score = sentence, ac_score, lm_score
+
+
+def process_blank(s: str) -> str:
+    """language_model/runtime/core/utils/string.cc:121-146: drop leading/duplicate/trailing space symbols, lower-case."""
+    out = []
+    for ch in s:
+        if ch != K_SPACE and ch != " ":
+            out.append(ch)
+        elif out and out[-1] != " ":
+            out.append(" ")
+    return "".join(out).rstrip(" ").lower()
+
+
+class BrainSpeechDecoder:
+    """Decode()/Reset()/FinishDecoding()/DecodedSomething()/result() as in brain_speech_decoder.h:112-124.
+    Decode() may be called repeatedly with consecutive chunks of log-probabilities (streaming)."""
+
+    def __init__(self, resource: DecodeResource, opts: DecodeOptions, device="cuda:0", max_len=1024):
+        self.res, self.opts = resource, opts
+        self.device = torch.device(device)
+        self.max_len = max_len
+        self.max_nodes = max_len * max(1, opts.second_beam_size) + 2
+        lib = N.load()
+        nbytes = lib.b2t_beam_state_bytes(self.max_len, self.max_nodes)
+        self.state = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+        self.acoustic_scale = 1.0
+        self._result: List[DecodeResult] = []
+        self._out = None
+        self.Reset()
+
+    def SetOpt(self, opts: DecodeOptions):
+        self.opts = opts
+
+    def Reset(self):
+        self._result = []
+        with torch.cuda.device(self.device):
+            N.check(N.load().b2t_beam_reset(ops._p(self.state), 1, self.max_len, self.max_nodes, ops._stream()),
+                    "b2t_beam_reset")
+
+    def Decode(self, logp):
+        lp = torch.as_tensor(logp, dtype=torch.float32).to(self.device).contiguous()
+        if lp.dim() != 2:
+            raise ValueError("logp must be [T, C]")
+        T, Cc = lp.shape
+        bm = self.opts.second_beam_size
+        hyps = torch.zeros((1, bm, self.max_len), dtype=torch.int32, device=self.device)
+        hl = torch.empty((1, bm), dtype=torch.int32, device=self.device)
+        sc = torch.empty((1, bm), dtype=torch.float32, device=self.device)
+        vs = torch.empty((1, bm), dtype=torch.float32, device=self.device)
+        tm = torch.zeros((1, bm, self.max_len), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.load().b2t_prefix_beam_search_f32(ops._p(lp), None, 1, T, Cc, self.opts.first_beam_size, bm,
+                                                        self.opts.blank, ops._p(self.state), self.max_len,
+                                                        self.max_nodes, ops._p(hyps), ops._p(hl), ops._p(sc), ops._p(vs),
+                                                        ops._p(tm), ops._stream()), "b2t_prefix_beam_search_f32")
+        self._out = (hyps.cpu().numpy()[0], hl.cpu().numpy()[0], sc.cpu().numpy()[0], vs.cpu().numpy()[0],
+                     tm.cpu().numpy()[0])
+        self._update_result()
+
+    def _update_result(self):
+        hyps, hl, sc, vs, tm = self._out
+        table = self.res.symbols or self.res.units
+        self._result = []
+        for i in range(len(hl)):
+            if hl[i] < 0:
+                continue
+            ids = hyps[i, :hl[i]]
+            words = [table.get(int(t), str(int(t))) if table else str(int(t)) for t in ids]
+            r = DecodeResult(process_blank("".join(" " + w for w in words)), float(sc[i]) / self.acoustic_scale,
+                             float(sc[i]))
+            r.tokens, r.times, r.viterbi_score = ids.copy(), tm[i, :hl[i]].copy(), float(vs[i])
+            self._result.append(r)
+
+    def FinishDecoding(self):
+        pass   # CtcPrefixBeamSearch::FinalizeSearch is a no-op (ctc_prefix_beam_search.h)
+
+    def Rescore(self):
+        raise NotImplementedError("lattice LM rescoring needs the WFST decoder (not built)")
+
+    def DecodedSomething(self):
+        return bool(self._result) and bool(self._result[0].sentence)
+
+    def result(self):
+        return self._result
+
+
+def DecodeNumpy(decoder: BrainSpeechDecoder, logits, log_priors, blank_penalty: float):
+    """logp = log_softmax(logits) - log_priors; logp[:,0] -= blank_penalty; decoder.Decode(logp)  (lm_decoder.cc:14-37)."""
+    lg = torch.as_tensor(np.ascontiguousarray(logits), dtype=torch.float32).to(decoder.device)
+    pr = torch.as_tensor(np.ascontiguousarray(log_priors), dtype=torch.float32).to(decoder.device)
+    if lg.dim() != 2 or pr.shape != lg.shape:
+        raise ValueError("logits and log_priors must be [T, C] arrays of the same shape")
+    out = torch.empty_like(lg)
+    with torch.cuda.device(decoder.device):
+        N.check(N.load().b2t_lm_prologue_f32(ops._p(lg), ops._p(pr), float(blank_penalty), ops._p(out), lg.shape[0],
+                                             lg.shape[1], ops._stream()), "b2t_lm_prologue_f32")
+    decoder.Decode(out)
+
+
+def DecodeNumpyLogProbs(decoder: BrainSpeechDecoder, log_probs):
+    decoder.Decode(log_probs)
