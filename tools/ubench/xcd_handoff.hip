@@ -19,14 +19,18 @@ __global__ void pingpong(u64* ga, u64* gb, int blkA, int blkB, int iters, int mo
   for (int i = 1; i <= iters; ++i) {
     if (me == 0) {
       u64 g = ((u64)i << 32) | (unsigned)i;
-      if (mode == 0) __hip_atomic_store(mine, g, RLX_AGENT); else *(volatile u64*)mine = g;
+      if (mode == 0) __hip_atomic_store(mine, g, RLX_AGENT);
+      else if (mode == 1) *(volatile u64*)mine = g;
+      else asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(mine), "v"(g) : "memory");   // truly plain store
       unsigned spins = 0;
-      while ((__hip_atomic_load(theirs, RLX_AGENT) >> 32) != (u64)i) { if (++spins > (1u << 22)) { cycles[2] = 1; return; } }
+      while ((__hip_atomic_load(theirs, RLX_AGENT) >> 32) != (u64)i) { if (++spins > (1u << 18)) { cycles[2] = 1; return; } }
     } else {
       unsigned spins = 0;
-      while ((__hip_atomic_load(theirs, RLX_AGENT) >> 32) != (u64)i) { if (++spins > (1u << 22)) { cycles[2] = 1; return; } }
+      while ((__hip_atomic_load(theirs, RLX_AGENT) >> 32) != (u64)i) { if (++spins > (1u << 18)) { cycles[2] = 1; return; } }
       u64 g = ((u64)i << 32) | (unsigned)i;
-      if (mode == 0) __hip_atomic_store(mine, g, RLX_AGENT); else *(volatile u64*)mine = g;
+      if (mode == 0) __hip_atomic_store(mine, g, RLX_AGENT);
+      else if (mode == 1) *(volatile u64*)mine = g;
+      else asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(mine), "v"(g) : "memory");
     }
   }
   if (me == 0) cycles[0] = __builtin_amdgcn_s_memtime() - t0;
@@ -41,12 +45,12 @@ int main() {
   const int iters = 2000;
   int pairs[3][2] = {{0, 8}, {0, 1}, {0, 4}};
   const char* names[3] = {"same XCD (b0,b8)", "cross XCD (b0,b1)", "cross XCD (b0,b4)"};
-  for (int p = 0; p < 3; ++p) for (int mode = 0; mode < 2; ++mode) {
+  for (int p = 0; p < 3; ++p) for (int mode = 0; mode < 3; ++mode) {
     hipMemset(g, 0, 1 << 20); hipMemset(cyc, 0, 64);
     hipLaunchKernelGGL(pingpong, dim3(256), dim3(64), 0, 0, g, g + 4096, pairs[p][0], pairs[p][1], iters, mode, cyc);
     hipDeviceSynchronize();
     u64 h[3]; hipMemcpy(h, cyc, 24, hipMemcpyDeviceToHost);
-    printf("%-20s %-6s stores: %s  round trip %.0f cycles (one-way hand-off ~%.0f)\n", names[p], mode ? "plain" : "sc1",
+    printf("%-20s %-6s stores: %s  round trip %.0f cycles (one-way hand-off ~%.0f)\n", names[p], mode == 0 ? "sc1" : (mode == 1 ? "volat." : "plain"),
            h[2] ? "TIMEOUT" : "ok", (double)h[0] / iters, (double)h[0] / iters / 2);
   }
   return 0;
