@@ -83,6 +83,8 @@ int b2t_softsign_bwd_f32(const float* u, float* du, long long n, void* stream);
 size_t b2t_colsum_ws_bytes(long long rows, int cols);   /* per batch entry z */
 int b2t_colsum_f32(const float* x, long long rows, int cols, long long ld, float* out,
                    int accumulate, float* ws, int Z, long long x_sz, long long out_sz, void* stream);
+/* split-K slab reduction: out[i] (+)= sum_{s<nslab} slab[s*n + i], slabs added in index order (deterministic). */
+int b2t_slab_reduce_f32(const float* slab, int nslab, long long n, float* out, int accumulate, void* stream);
 /* per-day reduction of per-sample partial gradients (day layer, rnn_model.py:95-98 autograd):
  * out[d*out_stride + i] = sum_{b: day_idx[b]==d} slab[b*n + i] for every day present in day_idx
  * (summed in batch order: deterministic); days absent from the batch are not touched. */

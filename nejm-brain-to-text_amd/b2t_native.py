@@ -46,6 +46,7 @@ _SIGNATURES = {
     "b2t_softsign_bwd_f32": (C.c_int, [VP, VP, LL, VP]),
     "b2t_colsum_ws_bytes": (C.c_size_t, [LL, C.c_int]),
     "b2t_colsum_f32": (C.c_int, [VP, LL, C.c_int, LL, VP, C.c_int, VP, C.c_int, LL, LL, VP]),
+    "b2t_slab_reduce_f32": (C.c_int, [VP, C.c_int, LL, VP, C.c_int, VP]),
     "b2t_day_reduce_f32": (C.c_int, [VP, VP, C.c_int, LL, VP, LL, VP]),
     "b2t_patch_fold_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_dropout_f32": (C.c_int, [VP, VP, LL, C.c_float, C.c_uint64, LL, VP]),

@@ -136,7 +136,8 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
         sl = ws.get(slab, (splitk, M * N_), Cm.device)
         gemm(A, B, sl, M=M, N_=N_, K=K, a_kc=a_kc, b_kc=b_kc, a_s0=a_s0, a_s1=a_s1, a_div=a_div, b_s0=b_s0,
              b_s1=b_s1, b_div=b_div, c_s0=N_, bias=bias, a_off=a_off, b_off=b_off, _splitk=splitk, _c_ks=M * N_)
-        colsum(sl, splitk, M * N_, M * N_, Cm, accumulate=accumulate, out_off=c_off)
+        N.check(N.load().b2t_slab_reduce_f32(_p(sl), splitk, M * N_, C.c_void_p(Cm.data_ptr() + 4 * c_off), accumulate,
+                                             _stream()), "b2t_slab_reduce_f32")
         return
     d = N.GemmDesc()
     d.A = A.data_ptr() + 4 * a_off

@@ -132,6 +132,19 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
   out[c] = accumulate ? out[c] + s : s;
 }
 
+// out[i] (+)= sum_s slab[s][i]  — deterministic split-K reduction, float4 per lane, slabs summed in order
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslab, long long n4, float* __restrict__ out,
+                                   int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 acc = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nslab; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(slab + (long long)s * n4 * 4)[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
 __global__ void patch_fold_kernel(const float* __restrict__ dv, float* __restrict__ du, int T, int F, int Tp,
                                   int patch, int stride) {
   // du[b,t,f] = sum_{p,k: p*stride+k=t} dv[b,p,k*F+f]
@@ -242,6 +255,16 @@ extern "C" int b2t_colsum_f32(const float* x, long long rows, int cols, long lon
   hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256, Z), dim3(256), 0, s, ws, nparts, cols, out, accumulate,
                      out_sz);
   B2T_CHECK_LAUNCH("b2t_colsum_f32");
+  return 0;
+}
+
+extern "C" int b2t_slab_reduce_f32(const float* slab, int nslab, long long n, float* out, int accumulate, void* stream) {
+  B2T_REQUIRE(slab && out && nslab > 0 && n > 0 && (n % 4) == 0 && ((uintptr_t)out & 15) == 0,
+              "slab_reduce: n=%lld must be a positive multiple of 4 and out 16-byte aligned", n);
+  const long long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), slab, nslab, n4, out, accumulate);
+  B2T_CHECK_LAUNCH("b2t_slab_reduce_f32");
   return 0;
 }
 

@@ -22,7 +22,8 @@ using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr unsigned SPIN_LIMIT = 4u << 20;
-constexpr int CSTRIDE = 32;  // words between counters: one 128-byte line per (row group, step) counter  // ~seconds; a healthy hand-off takes microseconds
+constexpr int CSTRIDE = 1;   // words between counters (one line per counter was measured: no effect)
+constexpr int SETW = 64 * 1024;  // counters per set; two sets alternate between calls (self-cleaning, no memset)  // ~seconds; a healthy hand-off takes microseconds
 
 // Thread 0 polls until *p >= target (or the error word is set / the spin limit is hit), then barrier.
 __device__ __forceinline__ void wait_count(unsigned* p, unsigned target, unsigned* err) {
@@ -79,14 +80,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
                                                                  float* __restrict__ reserve, int T, int B, int H,
-                                                                 unsigned* sync, long long zs_gi, long long zs_w,
-                                                                 long long zs_out, long long zs_sync) {
-  {   // blockIdx.z selects one of several independent sweeps packed into one launch (strides in elements)
-    const long long z = blockIdx.z;
-    gi += z * zs_gi; w_hh += z * zs_w; b_hh += z * 3 * H; h_init += z * zs_out; out += z * zs_out;
-    if (reserve) reserve += z * (zs_gi / 3 * 4);
-    sync += z * zs_sync;
-  }
+                                                                 unsigned* sync) {
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TP];
   float* hs = red + 4 * 3 * 4 * 64;   // staged h tile [16 rows][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -94,7 +88,15 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
   const int unit = j0 + j;
-  unsigned* err = sync;  // word 0: error flag; counters start at word 16
+  unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
+  // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
+  // on this workspace (stream order makes that safe), so no memset node is needed in front of the launch.
+  const unsigned pset = sync[1] & 1u;
+  {
+    unsigned* other = sync + 32 + (size_t)(1u - pset) * SETW;
+    const int nthr = gridDim.x * gridDim.y * 256;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
+  }
   const int nch = H / 16;
 
   float4 w[3][NCH];
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     if (m0 >= B) continue;
     const int row = m0 + 4 * q + wave, arow = m0 + j;
     const bool live = row < B;
-    unsigned* cnt = sync + 32 + (size_t)rg * T * CSTRIDE;
+    unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
     float hp = hpv[rr];
     float gir = 0.f, giz = 0.f, gin = 0.f;
     if (live) {
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     TSTAMP(4)   // stage barrier + store + drain + publish
    }
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync[1] = 1u - pset;   // next call uses the cleared set
 #ifdef B2T_TIMING
   if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 17))
     for (int i = 0; i < 5; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)T);
@@ -223,7 +226,15 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
   const int unit = j0 + j;
-  unsigned* err = sync;  // word 0: error flag; counters start at word 16
+  unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
+  // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
+  // on this workspace (stream order makes that safe), so no memset node is needed in front of the launch.
+  const unsigned pset = sync[1] & 1u;
+  {
+    unsigned* other = sync + 32 + (size_t)(1u - pset) * SETW;
+    const int nthr = gridDim.x * gridDim.y * 256;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
+  }
   const int nch = 3 * H / 16;
 
   float4 w[NCB];
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     if (m0 >= B) continue;
     const int row = m0 + 4 * q + wave, arow = m0 + j;
     const bool live = row < B;
-    unsigned* cnt = sync + 32 + (size_t)rg * T * CSTRIDE;
+    unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
     float dzterm = dzv[rr];
     // operands of the elementwise part do not depend on the recurrence: fetch them first
     float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hprev = 0.f, dy = 0.f;
@@ -310,9 +321,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     publish_count(cnt + (size_t)t * CSTRIDE);
    }
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync[1] = 1u - pset;
 }
 
-size_t gru_persistent_sync_bytes(int T) { return ((size_t)T * 64 * CSTRIDE + 64) * sizeof(unsigned); }
+size_t gru_persistent_sync_bytes(int T) { (void)T; return ((size_t)2 * SETW + 64) * sizeof(unsigned); }
 
 static int cu_count() {
   static int n = -1;
@@ -333,7 +345,10 @@ static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
   const int mt = pick_mt(B);
   const int gx = H / 16, gy = ((B + 15) / 16 + mt - 1) / mt;
   if (!sync_ws) { set_error("%s: sync_ws is required in persistent mode", what); return 2; }
-  if (gy > 64) { set_error("%s: B=%d exceeds 1024 rows in persistent mode", what, B); return 2; }
+  if ((long long)gy * mt * T * CSTRIDE > SETW) {
+    set_error("%s: %d row groups x %d steps exceed the %d hand-off counters of one call", what, gy * mt, T, SETW);
+    return 2;
+  }
   const int cus = cu_count();
   if (gx * gy > cus) {
     set_error("%s: persistent sweep needs %d co-resident workgroups but the device has %d CUs (use mode 0)", what,
@@ -350,17 +365,15 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   if (rc) return rc;
   const int mt = pick_mt(B);
   dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
-  unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T * CSTRIDE + 32) * sizeof(unsigned), s), "gru_layer_fwd: memset");
-  if (rc) return rc;
+  unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
     if (mt == 2)                                                                                                       \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 2>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, 0LL, 0LL, 0LL, 0LL);                                                              \
+                         B, H, sync);                                                                                  \
     else                                                                                                               \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 1>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, 0LL, 0LL, 0LL, 0LL);                                                              \
+                         B, H, sync);                                                                                  \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
@@ -380,8 +393,6 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   const int mt = pick_mt(B);
   dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-  rc = check_hip(hipMemsetAsync(sync, 0, ((size_t)grid.y * mt * T * CSTRIDE + 32) * sizeof(unsigned), s), "gru_layer_bwd: memset");
-  if (rc) return rc;
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
   do {                                                                                                                \
     if (mt == 2)                                                                                                      \
@@ -402,21 +413,6 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
 }
 
 }  // namespace b2t
-
-// EXPERIMENT: nz independent forward sweeps (H=512 only) packed into one launch via blockIdx.z.
-extern "C" int b2t_exp_gru_fwd_multi(const float* gi, const float* w_hh, const float* b_hh, float* outbuf, float* reserve,
-                                     int T, int B, int H, int nz, void* sync_ws, void* stream) {
-  using namespace b2t;
-  dim3 grid(H / 16, (B + 15) / 16, nz), block(256);
-  unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-  const long long zs_sync = (long long)grid.y * T * CSTRIDE + 32;
-  hipMemsetAsync(sync, 0, (size_t)zs_sync * nz * sizeof(unsigned), as_stream(stream));
-  const long long zs_out = (long long)(T + 1) * B * H;
-  hipLaunchKernelGGL((gru_persist_fwd_kernel<8, 1>), grid, block, 0, as_stream(stream), gi, w_hh, b_hh, outbuf,
-                     outbuf + (long long)B * H, reserve, T, B, H, sync, (long long)T * B * 3 * H, (long long)3 * H * H, zs_out,
-                     zs_sync);
-  return check_hip(hipGetLastError(), "exp multi");
-}
 
 // Error word of the last persistent sweep that used sync_ws (0 = clean, 1 = a bounded spin gave up).
 extern "C" int b2t_gru_sync_status(const void* sync_ws, int T, int B, int* status_host, void* stream) {
