@@ -216,7 +216,8 @@ class Grads(Params):
 GRU_MODE = {"value": int(os.environ.get("B2T_GRU_MODE", "-1"))}
 MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its workgroups resident at once
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer, no side streams).
-PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16}
+PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16,
+            "sweep_streams": int(os.environ.get("B2T_SWEEP_STREAMS", "64"))}
 
 
 def gru_mode_for(B: int, H: int) -> int:
@@ -258,7 +259,11 @@ class Workspace:
     def layer_streams(self, L, device):
         key = (L, str(device))
         if key not in self.streams:
-            self.streams[key] = ([torch.cuda.Stream(device=device) for _ in range(L)],
+            # One sweep stream per layer by default.  B2T_SWEEP_STREAMS=2 (with B2T_SWEEP_EXCLUSIVE=1: one persistent
+            # workgroup per CU) bounds the sweeps in flight to two — measured slower inside the full step, see DESIGN.md.
+            nsw = max(1, min(L, PIPELINE["sweep_streams"]))
+            base = [torch.cuda.Stream(device=device) for _ in range(nsw)]
+            self.streams[key] = ([base[l % nsw] for l in range(L)],
                                  [torch.cuda.Stream(device=device) for _ in range(L)])
         return self.streams[key]
 
@@ -340,9 +345,12 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
             s.wait_event(ev0)
     ev_sw: List[List[Optional[torch.cuda.Event]]] = [[None] * len(chunks) for _ in range(L)]
     a_s0_l0 = dims.stride * F if dims.patch > 0 else F
-    for c, (t0, t1) in enumerate(chunks):
+    # cells (chunk c, layer l) are enqueued diagonal by diagonal (c + l), a topological order in which the two
+    # sweep streams never wait on work that is queued behind them
+    for c, l in sorted(((c, l) for c in range(len(chunks)) for l in range(L)), key=lambda cl: (cl[0] + cl[1], cl[1])):
+        t0, t1 = chunks[c]
         n = t1 - t0
-        for l in range(L):
+        if True:
             sg = s_gemm[l] if piped else main
             ss = s_sweep[l] if piped else main
             # 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
@@ -467,10 +475,11 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
             gemm(dGs[0], prm.w_ih[0], dst, M=n * B, N_=In, K=H, a_kc=1, a_s0=4 * H, a_off=a_off + 3 * H, b_kc=0, b_s0=In,
                  b_off=2 * H * In, accumulate=1, **kw)
 
-    for c in reversed(range(nc)):
+    for c, l in sorted(((c, l) for c in range(nc) for l in range(L)),
+                       key=lambda cl: ((nc - 1 - cl[0]) + (L - 1 - cl[1]), -cl[1])):
         t0, t1 = chunks[c]
         n = t1 - t0
-        for l in reversed(range(L)):
+        if True:
             ss = s_sweep[l] if piped else main
             sg = s_gemm[l] if piped else main
             with torch.cuda.stream(ss):

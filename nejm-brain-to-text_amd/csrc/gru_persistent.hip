@@ -13,6 +13,7 @@
 //     memset node ahead of every launch; every spin is bounded and reports through an error word.
 //   * row groups are independent recurrences, so the 4 groups of a B=64 batch progress independently.
 // All workgroups must be co-resident (grid <= CU count); the entry point checks that.
+#include <stdlib.h>
 #include "gru_cell.h"
 
 namespace b2t {
@@ -339,6 +340,27 @@ static int cu_count() {
 
 // Row groups per workgroup: 2 halves the workgroup count (weights are shared by the groups) and lets each
 // workgroup overlap one group's hand-off latency with the other group's MFMAs.
+// One persistent workgroup per CU: co-resident workgroups of concurrent sweeps on one CU gain almost nothing
+// (measured: 2/CU -> 1.27x, 3/CU -> 1.1x CU throughput) while every lock-step peer group then runs at the pace
+// of its slowest member.  Requesting more than half of the 160 KiB LDS makes the dispatcher place concurrent
+// sweeps (other layers of the pipelined plan) on different CUs instead of stacking them.
+constexpr unsigned EXCLUSIVE_LDS = 84 * 1024;
+template <typename K> static void want_exclusive(K kernel) {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCLUSIVE_LDS);
+    done = true;
+  }
+}
+static unsigned exclusive_lds() {
+  static int v = -1;
+  // opt-in: exclusive CUs make two concurrent sweeps scale perfectly in isolation (tools/bench_sweep.py) but starve
+  // next to the 3-blocks-per-CU GEMMs of the pipelined step (a sweep workgroup then waits for 84 KB of LDS while the
+  // GEMM keeps refilling 34 KB slots), which stalls its lock-step peers for milliseconds.
+  if (v < 0) { const char* e = getenv("B2T_SWEEP_EXCLUSIVE"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v ? EXCLUSIVE_LDS : 0u;
+}
+
 static int pick_mt(int B) { (void)B; return 1; }  // MT=2 measured 2x slower per sweep: the exposed latencies are the workgroup's own load/drain, not the peers'
 
 static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
@@ -368,11 +390,12 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
+    want_exclusive(gru_persist_fwd_kernel<NCH, 1>); want_exclusive(gru_persist_fwd_kernel<NCH, 2>);                    \
     if (mt == 2)                                                                                                       \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 2>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
                          B, H, sync);                                                                                  \
     else                                                                                                               \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 1>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 1>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
                          B, H, sync);                                                                                  \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
@@ -395,11 +418,12 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
   do {                                                                                                                \
+    want_exclusive(gru_persist_bwd_kernel<NCB, 1>); want_exclusive(gru_persist_bwd_kernel<NCB, 2>);                   \
     if (mt == 2)                                                                                                      \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 2>), grid, block, 0, s, dY, dh_last, reserve, out, h_init,      \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init,      \
                          w_hh_t, dG, dh_init, T, B, H, sync);                                                         \
     else                                                                                                              \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 1>), grid, block, 0, s, dY, dh_last, reserve, out, h_init,      \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 1>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init,      \
                          w_hh_t, dG, dh_init, T, B, H, sync);                                                         \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);
