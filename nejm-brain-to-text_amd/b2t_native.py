@@ -10,6 +10,11 @@ import ctypes as C
 import os
 import re
 
+# The pipelined execution plan (b2t_ops) runs the GRU layers on 2L+1 HIP streams.  ROCm maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue serialise, which stalls the persistent
+# sweeps behind the kernels they wait for.  Must be set before the HIP runtime initialises (first torch.cuda use).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libb2t_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "b2t.h")

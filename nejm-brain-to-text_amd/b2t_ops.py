@@ -267,6 +267,13 @@ class Workspace:
                                  [torch.cuda.Stream(device=device) for _ in range(L)])
         return self.streams[key]
 
+    def wgrad_streams(self, L, device):
+        # The weight-gradient GEMMs share the per-layer GEMM streams: the plan must not use more HIP streams than the
+        # runtime has hardware queues (GPU_MAX_HW_QUEUES=16 is set by bench.py / the trainer).  Streams that share a
+        # hardware queue serialise, and a persistent sweep stuck behind the kernel it waits for costs milliseconds
+        # (measured: 16 streams -> 86 ms/step instead of 31).  2L+1 = 11 streams at L=5.
+        return self.layer_streams(L, device)[1]
+
     def sync_ws(self, l, Tp, device, B=64, H=512, tag=""):
         return self.get(f"gru_sync{tag}{l}", (N.load().b2t_gru_ws_bytes(Tp, B, H) // 4 + 16,), device, torch.int32)
 
@@ -426,6 +433,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     chunks, mode = ctx.chunks, ctx.mode
     piped = len(chunks) > 1
     s_sweep, s_gemm = ws.layer_streams(L, dev)
+    s_wg = ws.wgrad_streams(L, dev)
     nc = len(chunks)
 
     # head: d_out[t,b,:] = dlogits[b,t,:] W_out ; dW_out = dlogits^T out ; db_out = colsum
@@ -447,7 +455,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     dU = ws.get("dU", (B, T, F), dev)
     dV = ws.get("dV", (B, Tp, dims.In0), dev) if dims.patch > 0 else None
     if piped:
-        for s in s_sweep + s_gemm:
+        for s in s_sweep + s_gemm + s_wg:
             s.wait_event(ev_top)
     ev_dx: List[List[Optional[torch.cuda.Event]]] = [[None] * nc for _ in range(L)]
     ev_bs: List[List[Optional[torch.cuda.Event]]] = [[None] * nc for _ in range(L)]
@@ -517,11 +525,14 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                 dx_gemm(l, t0, n)
                 if piped:
                     ev_dx[l][c] = _ev(sg)
+            if piped and c == 0:
+                # weight gradients of the whole layer once its last chunk is swept, on their own stream (they overlap
+                # the sweeps of the layers below).  Per-chunk accumulation (t0/t1/accumulate) is supported by the helper
+                # but measured slower inside the full step: 8x more launches competing with the sweeps' CUs.
+                with torch.cuda.stream(s_wg[l]):
+                    s_wg[l].wait_event(ev_bs[l][c])
+                    _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
             if (not piped) and c == 0:
-                _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
-    if piped:
-        for l in reversed(range(L)):
-            with torch.cuda.stream(s_gemm[l]):
                 _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
 
     # layer-0 input gradient -> day layer (on layer 0's GEMM stream: its dU/dV GEMMs are already ordered there)
@@ -546,7 +557,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
         if bucket_cb:
             bucket_cb("day")
     if piped:
-        for s in s_sweep + s_gemm:
+        for s in s_sweep + s_gemm + s_wg:
             main.wait_event(_ev(s))
     # h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
     if not ctx.custom_states:
@@ -558,33 +569,40 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     return dh_init if want_dstates else None
 
 
-def _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb):
-    """dW_hh = dGh^T h_prev, dW_ih = dGi^T in, bias gradients = column sums of dG (layer l)."""
+def _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb, t0=0, t1=None, accumulate=0, final=True):
+    """dW_hh = dGh^T h_prev, dW_ih = dGi^T in, bias gradients = column sums of dG (layer l), over the time
+    rows [t0, t1) (default: all).  In the pipelined plan this is called once per chunk as soon as that chunk's
+    sweep has finished (first chunk overwrites, later chunks accumulate — fixed order, deterministic), so the
+    weight-gradient GEMMs fill the CUs the sweeps leave idle instead of forming a tail after the last sweep."""
     B, T = ctx.B, ctx.T
     F, H = dims.F, dims.H
     dG = dGs[l]
     dev = dG.device
-    gemm(dG, ctx.outs[l], grd.w_hh[l], M=3 * H, N_=H, K=M, a_kc=0, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H,
-         splitk=splitk_for(3 * H, H, M), ws=ws, slab=f"splitk_slab{l}")
+    t1 = ctx.Tp if t1 is None else t1
+    K = (t1 - t0) * B
+    a0 = t0 * B * 4 * H
+    gemm(dG, ctx.outs[l], grd.w_hh[l], M=3 * H, N_=H, K=K, a_kc=0, a_s0=4 * H, a_off=a0, b_kc=0, b_s0=H,
+         b_off=t0 * B * H, c_s0=H, splitk=splitk_for(3 * H, H, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate)
     if l == 0:
         In = dims.In0
         bs1 = dims.stride * F if dims.patch > 0 else F
         kw = dict(b_kc=0, b_div=B, b_s1=bs1, b_s0=T * F)
-        inp, in_off = ctx.Ud, 0
+        inp, in_off = ctx.Ud, t0 * bs1
     else:
         In = H
         kw = dict(b_kc=0, b_s0=H)
-        inp, in_off = ctx.outs_d[l - 1], B * H   # skip the initial-state slot
-    gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=M, a_kc=0, a_s0=4 * H, c_s0=In, b_off=in_off,
-         splitk=splitk_for(2 * H, In, M), ws=ws, slab=f"splitk_slab{l}", **kw)
-    gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=M, a_kc=0, a_s0=4 * H, a_off=3 * H, c_s0=In, c_off=2 * H * In,
-         b_off=in_off, splitk=splitk_for(H, In, M), ws=ws, slab=f"splitk_slab{l}", **kw)
+        inp, in_off = ctx.outs_d[l - 1], (1 + t0) * B * H   # skip the initial-state slot
+    gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=K, a_kc=0, a_s0=4 * H, a_off=a0, c_s0=In, b_off=in_off,
+         splitk=splitk_for(2 * H, In, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate, **kw)
+    gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=K, a_kc=0, a_s0=4 * H, a_off=a0 + 3 * H, c_s0=In, c_off=2 * H * In,
+         b_off=in_off, splitk=splitk_for(H, In, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate, **kw)
     s4 = ws.get(f"s4_{l}", (4 * H,), dev)
-    colsum(dG, M, 4 * H, 4 * H, s4)     # (s_r, s_z, s_nr, s_n)
-    grd.b_ih[l][:2 * H].copy_(s4[:2 * H]); grd.b_ih[l][2 * H:].copy_(s4[3 * H:])
-    grd.b_hh[l].copy_(s4[:3 * H])
-    if bucket_cb:
-        bucket_cb(f"layer{l}")
+    colsum(dG, K, 4 * H, 4 * H, s4, accumulate=accumulate, x_off=a0)     # (s_r, s_z, s_nr, s_n)
+    if final:
+        grd.b_ih[l][:2 * H].copy_(s4[:2 * H]); grd.b_ih[l][2 * H:].copy_(s4[3 * H:])
+        grd.b_hh[l].copy_(s4[:3 * H])
+        if bucket_cb:
+            bucket_cb(f"layer{l}")
 
 
 # ------------------------------------------------------------------------------------------------

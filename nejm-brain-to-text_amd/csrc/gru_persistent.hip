@@ -58,6 +58,14 @@ __device__ __forceinline__ float4 load_sc1_f4(const float* base_uniform, unsigne
   return f;
 }
 
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __frcp_rn(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  // 1 - 2/(1+e^{2x}); saturates correctly: e^{2x} -> inf gives 1, -> 0 gives -1
+  return 1.0f - 2.0f * __frcp_rn(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 __device__ __forceinline__ void store_sc1(float* p, float v) { __hip_atomic_store(p, v, RLX_AGENT); }
 
 // 16-byte sc1 (write-through) store through a buffer descriptor based at a wave-uniform pointer.
@@ -173,10 +181,12 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     cross_wave_reduce<3>(red, acc, gh, wave, lane);
     TSTAMP(2)   // reduce
     if (live) {
+      // gate non-linearities on the hardware exp unit (v_exp_f32, ~1 ulp): sigmoid(x) = 1/(1+2^(-x log2 e)),
+      // tanh(x) = 1 - 2/(1+2^(2x log2 e)); the precise libm forms cost ~800 cycles per step on the serial chain.
       const float ghn = gh[2] + bhn;
-      const float r = sigmoidf_(gir + gh[0] + bhr);
-      const float z = sigmoidf_(giz + gh[1] + bhz);
-      const float n = tanhf(gin + r * ghn);
+      const float r = fast_sigmoid(gir + gh[0] + bhr);
+      const float z = fast_sigmoid(giz + gh[1] + bhz);
+      const float n = fast_tanh(gin + r * ghn);
       const float h = (1.0f - z) * n + z * hp;
       hs[(4 * q + wave) * TP + j] = h;
       if (reserve) {
