@@ -131,7 +131,16 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
   const int wm = wave >> 1, wn = wave & 1;
   const int z = blockIdx.z / g.splitk;
   const int ks = blockIdx.z - z * g.splitk;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: the dispatcher sends workgroup b to XCD b % 8 (private L2 each).  Remap so that every XCD
+  // walks a CONTIGUOUS range of tiles in row-major order: the n-tiles that share an A row-panel then hit the same
+  // L2 instead of fetching the panel once per XCD.  Bijective for any tile count (cdna_hip_programming.md T1).
+  int m0, n0;
+  {
+    const int gx = (g.N + BN - 1) / BN, nwg = gridDim.x;
+    const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    m0 = (tile / gx) * BM; n0 = (tile % gx) * BN;
+  }
 
   const float* A = g.A + (long long)z * g.a_sz;
   const int zb = g.b_zmap ? g.b_zmap[z] : z;
@@ -257,7 +266,7 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
               "b2t_gemm_f32: split-K slabs cannot carry an epilogue/accumulate (reduce them with b2t_colsum_f32)");
   g.kchunk = ((d->K + g.splitk - 1) / g.splitk + BKT - 1) / BKT * BKT;
   g.c_ks = d->c_ks;
-  dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, d->Z * g.splitk), block(256);
+  dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);
   hipStream_t s = as_stream(stream);
   if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
   else if (d->a_kcontig && !d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);

@@ -43,3 +43,14 @@ for name, (fn, flops) in cases.items():
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print(f"{name:40s} {ms*1e3:9.1f} us  {flops/ms/1e9:7.1f} TFLOP/s")
+
+# calibration: large square problems (the guide's untuned 128x128 f32-MFMA kernel reaches 122 TF at 4096^3)
+for n in (2048, 4096):
+    A = torch.randn(n, n, device=dev); Bm = torch.randn(n, n, device=dev); Cm = torch.empty(n, n, device=dev)
+    for kc in ((1, 1), (1, 0), (0, 0)):
+        fn = lambda: ops.gemm(A, Bm, Cm, M=n, N_=n, K=n, a_kc=kc[0], b_kc=kc[1], a_s0=n, b_s0=n, c_s0=n)
+        fn(); fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); [fn() for _ in range(5)]; e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print(f"square {n}^3 akc={kc[0]} bkc={kc[1]}: {ms*1e3:9.1f} us  {2.0*n**3/ms/1e9:7.1f} TFLOP/s")
