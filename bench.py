@@ -125,20 +125,36 @@ def main():
         feats = ops.augment_smooth(x, 2, 100, "same", cut=cut, white_std=1.0, offset_std=0.2, seed=i * 7919 + rank)
         return ts.step(feats, days, labels, nts - cut, lens)
 
-    for i in range(a.warmup):
-        loss, gn = step(i)
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss, gn = step(a.warmup + i)
-    t_enq = time.perf_counter() - t0           # host time to enqueue K steps (no sync inside a step)
-    fence()
-    dt = time.perf_counter() - t0
+
+    def timed_run():
+        for i in range(a.warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            loss, gn = step(a.warmup + i)
+        t_enq = time.perf_counter() - t0           # host time to enqueue K steps (no sync inside a step)
+        fence()
+        dt = time.perf_counter() - t0
+        model._ws.check_sync()     # a hand-off timeout inside a persistent sweep would invalidate the run
+        return loss, dt, t_enq
+
+    try:
+        loss, dt, t_enq = timed_run()
+    except RuntimeError as e:
+        # The pipelined plan keeps several persistent sweeps in flight; if one of them ever reports a hand-off
+        # timeout the measurement is discarded and repeated with the layers strictly in sequence (no side streams).
+        sys.stderr.write(f"[bench] {e}; re-running with the serial execution plan\n")
+        ops.PIPELINE["chunks"] = 1
+        for buf in model._ws.bufs.values():
+            if buf.dtype == torch.int32:
+                buf.zero_()
+        loss, dt, t_enq = timed_run()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -166,7 +182,7 @@ def main():
     roofline = dict(bound="mfma", kernel=dname, achieved=round(achieved / 1e12, 3), peak=round(PEAK_F32_MFMA / 1e12, 1),
                     unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA, 4), traffic=None,
                     avg_launch_us=round(dtime / max(1, dlaunch) * 1e6, 2), launches_per_step=dlaunch // 2,
-                    share_of_step=round(dtime / 2 / (ms * 1e-3), 3),
+                    summed_stream_time_over_step=round(dtime / 2 / (ms * 1e-3), 3),   # >1: launches overlap on side streams
                     step_flops_frac=round(FLOPS_PER_STEP / (ms * 1e-3) / PEAK_F32_MFMA, 4),
                     step_hbm_frac=round(ALG_BYTES_PER_STEP / (ms * 1e-3) / PEAK_HBM, 4),
                     breakdown_ms={k: round(v[0] / 2 * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])})
@@ -178,7 +194,8 @@ def main():
                    config=dict(workload="BASELINE.json configs[1]: 5-layer GRU-512 + CTC, synthetic [B=64,T=500,F=512] -> 41 "
                                         "phonemes, fp32, full training step incl. on-GPU augmentation, clip and AdamW",
                                global_batch=B * world, seq_len=T, parallelism=f"dp{world}",
-                               gru_mode=ops.gru_mode_for(B, H)),
+                               gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
+                               bwd_sweeps_in_flight=ops.PIPELINE["bwd_sweeps"]),
                    roofline=roofline, final_loss=round(lossv, 4),
                    host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
         if world == 1 and not a.no_cpu_baseline:

@@ -217,7 +217,8 @@ GRU_MODE = {"value": int(os.environ.get("B2T_GRU_MODE", "-1"))}
 MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its workgroups resident at once
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer, no side streams).
 PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16,
-            "sweep_streams": int(os.environ.get("B2T_SWEEP_STREAMS", "64"))}
+            "sweep_streams": int(os.environ.get("B2T_SWEEP_STREAMS", "64")),
+            "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "3"))}
 
 
 def gru_mode_for(B: int, H: int) -> int:
@@ -266,6 +267,12 @@ class Workspace:
             self.streams[key] = ([base[l % nsw] for l in range(L)],
                                  [torch.cuda.Stream(device=device) for _ in range(L)])
         return self.streams[key]
+
+    def check_sync(self):
+        """Raise if any persistent sweep that used this workspace reported a hand-off timeout (synchronises)."""
+        for key, buf in self.bufs.items():
+            if str(key[0]).startswith("gru_sync") and int(buf[0].item()) != 0:
+                raise RuntimeError(f"persistent GRU sweep ({key[0]}): inter-workgroup hand-off timed out — results invalid")
 
     def wgrad_streams(self, L, device):
         # The weight-gradient GEMMs share the per-layer GEMM streams: the plan must not use more HIP streams than the
@@ -433,6 +440,12 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     chunks, mode = ctx.chunks, ctx.mode
     piped = len(chunks) > 1
     s_sweep, s_gemm = ws.layer_streams(L, dev)
+    # Residency bound: a backward sweep workgroup needs ~250 VGPRs/lane -> at most 2 per CU -> 512 slots on the chip.
+    # Five concurrent backward sweeps (5 x 128 workgroups) would not all fit: two partially resident sweeps can then
+    # hold the CUs each other's missing workgroups need and spin until the hand-off timeout.  Bound the backward
+    # sweeps in flight to PIPELINE["bwd_sweeps"] (3 x 128 = 384 <= 512) by sharing that many sweep streams.
+    nbs = max(1, min(L, PIPELINE["bwd_sweeps"]))
+    s_sweep = [s_sweep[l % nbs] for l in range(L)]
     s_wg = ws.wgrad_streams(L, dev)
     nc = len(chunks)
 

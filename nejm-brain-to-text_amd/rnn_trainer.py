@@ -324,6 +324,7 @@ class BrainToTextDecoder_Trainer:
             train_step_duration = time.time() - start_time
             train_losses.append(lossv)
             if i % self.args['batches_per_train_log'] == 0:
+                self.model._ws.check_sync()    # bounded hand-off spins report through an error word: fail loudly
                 self.logger.info(f'Train batch {i}: ' + f'loss: {lossv:.2f} ' + f'grad norm: {gnv:.2f} '
                                  f'time: {train_step_duration:.3f}')
             if i % self.args['batches_per_val_step'] == 0 or i == (self.args['num_training_batches'] - 1):
