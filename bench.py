@@ -195,7 +195,7 @@ def main():
                                         "phonemes, fp32, full training step incl. on-GPU augmentation, clip and AdamW",
                                global_batch=B * world, seq_len=T, parallelism=f"dp{world}",
                                gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
-                               bwd_sweeps_in_flight=ops.PIPELINE["bwd_sweeps"]),
+                               bwd_sweeps_in_flight=min(L, ops.PIPELINE["bwd_sweeps"])),
                    roofline=roofline, final_loss=round(lossv, 4),
                    host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
         if world == 1 and not a.no_cpu_baseline:

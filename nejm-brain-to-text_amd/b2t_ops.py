@@ -218,7 +218,7 @@ MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its wor
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer, no side streams).
 PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16,
             "sweep_streams": int(os.environ.get("B2T_SWEEP_STREAMS", "64")),
-            "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "3"))}
+            "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "64"))}
 
 
 def gru_mode_for(B: int, H: int) -> int:
@@ -440,10 +440,13 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     chunks, mode = ctx.chunks, ctx.mode
     piped = len(chunks) > 1
     s_sweep, s_gemm = ws.layer_streams(L, dev)
-    # Residency bound: a backward sweep workgroup needs ~250 VGPRs/lane -> at most 2 per CU -> 512 slots on the chip.
-    # Five concurrent backward sweeps (5 x 128 workgroups) would not all fit: two partially resident sweeps can then
-    # hold the CUs each other's missing workgroups need and spin until the hand-off timeout.  Bound the backward
-    # sweeps in flight to PIPELINE["bwd_sweeps"] (3 x 128 = 384 <= 512) by sharing that many sweep streams.
+    # Residency: a backward sweep workgroup needs ~250 VGPRs/lane -> 2 per CU -> 512 slots on the chip, and L concurrent
+    # sweeps (5 x 128 workgroups) do not all fit.  That is safe: the 16-row groups of a sweep are independent
+    # recurrences and workgroups are dispatched in grid order, so a partially resident sweep still has every row group
+    # but its last one complete; complete groups finish and free their slots, and the at most one incomplete group per
+    # sweep holds < H/16 slots (4 per XCD at H=512, of 64).  PIPELINE["bwd_sweeps"] (default: one per layer) can bound
+    # the sweeps in flight by sharing streams.  (The hand-off timeouts once seen with 5 in flight were a parity-flip
+    # race in the kernel epilogue, fixed in gru_persistent.hip:finish_call, not a residency deadlock.)
     nbs = max(1, min(L, PIPELINE["bwd_sweeps"]))
     s_sweep = [s_sweep[l % nbs] for l in range(L)]
     s_wg = ws.wgrad_streams(L, dev)

@@ -78,6 +78,22 @@ __device__ __forceinline__ void store_sc1_f4(float* base_uniform, unsigned byte_
   __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, byte_off, 0, /*aux: sc1*/ 16);
 }
 
+// End of a call: the LAST workgroup to finish flips the counter-set parity (word 1) and re-arms the
+// finish counter (word 2).  It must be the last one: row groups are independent recurrences, so any fixed
+// workgroup (say block 0) can finish all T steps before a late-dispatched workgroup of another row group has
+// read word 1 -- that workgroup would then count in (and clear) the wrong set and the call would never finish.
+// (Seen as rare hand-off timeouts when several sweeps and GEMMs shared the chip.)
+__device__ __forceinline__ void finish_call(unsigned* sync, unsigned pset) {
+  if (threadIdx.x == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned done = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == total - 1u) {
+      __hip_atomic_store(sync + 2, 0u, RLX_AGENT);
+      __hip_atomic_store(sync + 1, 1u - pset, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 constexpr int TP = 20;  // LDS pitch (floats) of a staged 16x16 tile: 16-byte aligned rows, conflict-light
 
 // ---------------------------------------------------------------------------------------------------
@@ -100,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
   // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
   // on this workspace (stream order makes that safe), so no memset node is needed in front of the launch.
-  const unsigned pset = sync[1] & 1u;
+  const unsigned pset = __hip_atomic_load(sync + 1, RLX_AGENT) & 1u;
   {
     unsigned* other = sync + 32 + (size_t)(1u - pset) * SETW;
     const int nthr = gridDim.x * gridDim.y * 256;
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     TSTAMP(4)   // stage barrier + store + drain + publish
    }
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync[1] = 1u - pset;   // next call uses the cleared set
+  finish_call(sync, pset);   // next call uses the cleared set
 #ifdef B2T_TIMING
   if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 17))
     for (int i = 0; i < 5; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)T);
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
   // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
   // on this workspace (stream order makes that safe), so no memset node is needed in front of the launch.
-  const unsigned pset = sync[1] & 1u;
+  const unsigned pset = __hip_atomic_load(sync + 1, RLX_AGENT) & 1u;
   {
     unsigned* other = sync + 32 + (size_t)(1u - pset) * SETW;
     const int nthr = gridDim.x * gridDim.y * 256;
@@ -332,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     publish_count(cnt + (size_t)t * CSTRIDE);
    }
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sync[1] = 1u - pset;
+  finish_call(sync, pset);
 }
 
 size_t gru_persistent_sync_bytes(int T) { (void)T; return ((size_t)2 * SETW + 64) * sizeof(unsigned); }
