@@ -179,8 +179,20 @@ def main():
     dom = max(agg.items(), key=lambda kv: kv[1][0])
     dname, (dtime, dflops, dlaunch) = dom
     achieved = dflops / dtime if dtime > 0 else 0.0
+    # `traffic`: memory-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    # (profiles/pmc_latest.json; PMC cannot be collected from inside this process).  Only valid for the plan it was
+    # measured on (same number of time chunks), else null.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            pmc = json.load(f)
+        if dname in pmc and pmc.get("time_chunks") == ops.PIPELINE["chunks"]:
+            traffic, traffic_src = round(pmc[dname]["bytes_per_launch"] / 1e9, 4), pmc["source"]
+    except OSError:
+        pass
     roofline = dict(bound="mfma", kernel=dname, achieved=round(achieved / 1e12, 3), peak=round(PEAK_F32_MFMA / 1e12, 1),
-                    unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA, 4), traffic=None,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA, 4), traffic=traffic, traffic_unit="GB/launch",
+                    traffic_source=traffic_src,
                     avg_launch_us=round(dtime / max(1, dlaunch) * 1e6, 2), launches_per_step=dlaunch // 2,
                     summed_stream_time_over_step=round(dtime / 2 / (ms * 1e-3), 3),   # >1: launches overlap on side streams
                     step_flops_frac=round(FLOPS_PER_STEP / (ms * 1e-3) / PEAK_F32_MFMA, 4),

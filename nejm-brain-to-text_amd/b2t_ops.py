@@ -153,7 +153,7 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
     d.bias_sz = bias_sz
     d.epilogue, d.accumulate = epilogue, accumulate
     d.splitk, d.c_ks = _splitk, _c_ks
-    with _Prof("gemm_f32_kernel", 2.0 * M * N_ * K * Z):
+    with _Prof(f"gemm_f32_kernel<{int(bool(a_kc))},{int(bool(b_kc))}>", 2.0 * M * N_ * K * Z):   # one name per rocprof symbol
         N.check(N.load().b2t_gemm_f32(C.byref(d), _stream()), "b2t_gemm_f32")
 
 
