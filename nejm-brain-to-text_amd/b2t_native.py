@@ -16,7 +16,7 @@ import re
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libb2t_hip.so")
+LIB_PATH = os.environ.get("B2T_LIB") or os.path.join(_HERE, "csrc", "libb2t_hip.so")   # B2T_LIB: A/B builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "b2t.h")
 
 _lib = None

@@ -9,10 +9,13 @@
 //     through HBM/L2 with the write-through hand-off of cdna_hip_programming.md §6 Guideline 16 (R1):
 //     producers store the payload with sc1 (write-through) stores, every storing wave drains vmcnt(0),
 //     barrier, one lane bumps an agent-scope counter; consumers poll that ONE word relaxed and then read
-//     the payload with sc1 loads (no L1 hit possible, no fence needed).  Counters are zeroed by a
-//     memset node ahead of every launch; every spin is bounded and reports through an error word.
+//     the payload with sc1 loads (no L1 hit possible, no fence needed).  Counters are self-cleaning (two sets
+//     alternate between calls, finish_call); every spin is bounded and reports through an error word.
 //   * row groups are independent recurrences, so the 4 groups of a B=64 batch progress independently.
-// All workgroups must be co-resident (grid <= CU count); the entry point checks that.
+//   * per step the operand loads (8 x 16 B per lane, ~2700 cycles until the last one lands) are all issued before
+//     the first MFMA and consumed chunk by chunk (vmcnt(7), vmcnt(6), ...): loads must be branch-free (clamped)
+//     and fenced with sched_barrier, otherwise the compiler either waits for all of them or sinks them.
+// The entry point requires grid <= CU count (one row group resident is what correctness needs).
 #include <stdlib.h>
 #include "gru_cell.h"
 
@@ -50,9 +53,10 @@ __device__ __forceinline__ void publish_count(unsigned* p) {
 }
 
 // 16-byte sc1 (L1-bypassing) load through a buffer descriptor based at a wave-uniform pointer.
-__device__ __forceinline__ float4 load_sc1_f4(const float* base_uniform, unsigned byte_off) {
+template <int AUX>   // AUX 16 = sc1 (device scope: never served from a stale per-XCD L2 line), 0 = ordinary cached load
+__device__ __forceinline__ float4 load_f4(const float* base_uniform, unsigned byte_off) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base_uniform), 0, 0x7fffffff, 0x00020000);
-  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, /*aux: sc1*/ 16);
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, AUX);
   float4 f;
   f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
   return f;
@@ -71,11 +75,12 @@ __device__ __forceinline__ void store_sc1(float* p, float v) { __hip_atomic_stor
 // 16-byte sc1 (write-through) store through a buffer descriptor based at a wave-uniform pointer.
 // Scalar sc1 stores are one fabric write each (~6x the cost per byte of a 16-byte one), so the 16x16
 // tile a workgroup produces per step is staged through LDS and written as 64 x 16 B.
-__device__ __forceinline__ void store_sc1_f4(float* base_uniform, unsigned byte_off, float4 v) {
+template <int AUX>   // AUX 16 = sc1 write-through to memory, 0 = ordinary store (lands in this XCD's L2)
+__device__ __forceinline__ void store_f4(float* base_uniform, unsigned byte_off, float4 v) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7fffffff, 0x00020000);
   u32x4 u;
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, byte_off, 0, /*aux: sc1*/ 16);
+  __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, byte_off, 0, AUX);
 }
 
 // End of a call: the LAST workgroup to finish flips the counter-set parity (word 1) and re-arms the
@@ -94,12 +99,20 @@ __device__ __forceinline__ void finish_call(unsigned* sync, unsigned pset) {
   }
 }
 
+// Which 16-wide K chunk wave `w` contracts in its ci-th slot.  Contiguous per wave (default): the wave's consecutive
+// 64-byte operand reads of a row fall into the same 128-byte lines.  B2T_KCHUNK_STRIDED: chunks dealt round-robin.
+#ifdef B2T_KCHUNK_STRIDED
+#define KCHUNK(w, ci, n) ((w) + 4 * (ci))
+#else
+#define KCHUNK(w, ci, n) ((w) * (n) + (ci))
+#endif
+
 constexpr int TP = 20;  // LDS pitch (floats) of a staged 16x16 tile: 16-byte aligned rows, conflict-light
 
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <int NCH, int MT>  // NCH: 16-wide K chunks per wave (H <= 64*NCH); MT: row groups per workgroup
+template <int NCH>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
 __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
@@ -108,11 +121,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
                                                                  unsigned* sync) {
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TP];
   float* hs = red + 4 * 3 * 4 * 64;   // staged h tile [16 rows][TP]
+  constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = blockIdx.x * 16;
-  const unsigned G = gridDim.x;
+  const unsigned G = (unsigned)H / 16u;
   const int j = lane & 15, q = lane >> 4;
-  const int unit = j0 + j;
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
   // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
   // on this workspace (stream order makes that safe), so no memset node is needed in front of the launch.
@@ -122,44 +134,36 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     const int nthr = gridDim.x * gridDim.y * 256;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
   }
+  const int rg = blockIdx.y, m0 = rg * 16;   // row groups are independent recurrences
+  const int j0 = blockIdx.x * 16;
+  const int unit = j0 + j;
   const int nch = H / 16;
 
   float4 w[3][NCH];
 #pragma unroll
   for (int ci = 0; ci < NCH; ++ci) {
-    const int c = wave + 4 * ci;
+    const int c = KCHUNK(wave, ci, NCH);
 #pragma unroll
     for (int g = 0; g < 3; ++g)
       w[g][ci] = c < nch ? *reinterpret_cast<const float4*>(w_hh + ((long long)g * H + unit) * H + c * 16 + 4 * q)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float bhr = b_hh[unit], bhz = b_hh[H + unit], bhn = b_hh[2 * H + unit];
-  float hpv[MT];
-#pragma unroll
-  for (int rr = 0; rr < MT; ++rr) {
-    const int row = (blockIdx.y * MT + rr) * 16 + 4 * q + wave;
-    hpv[rr] = row < B ? h_init[(long long)row * H + unit] : 0.f;
-  }
+  const int row = m0 + 4 * q + wave, arow = m0 + j;
+  const int arow_c = arow < B ? arow : B - 1;
+  const bool live = row < B;
+  unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
+  float hp = live ? h_init[(long long)row * H + unit] : 0.f;
 
 #ifdef B2T_TIMING
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define TSTAMP(i) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; }
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #else
 #define TSTAMP(i)
 #endif
   for (int t = 0; t < T; ++t) {
-#pragma unroll
-   for (int rr = 0; rr < MT; ++rr) {
-    // Row groups are independent recurrences: while the peers' h_{t-1} of group r is in flight,
-    // this workgroup is busy with the other groups (the hand-off latency hides behind their MFMAs).
-    const int rg = blockIdx.y * MT + rr;
-    const int m0 = rg * 16;
-    if (m0 >= B) continue;
-    const int row = m0 + 4 * q + wave, arow = m0 + j;
-    const bool live = row < B;
-    unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
-    float hp = hpv[rr];
+   {
     float gir = 0.f, giz = 0.f, gin = 0.f;
     if (live) {
       const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit;
@@ -177,10 +181,17 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     float4 a[NCH];
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci) {
-      const int c = wave + 4 * ci;
-      a[ci] = (c < nch && arow < B) ? load_sc1_f4(hsrc, (unsigned)(((long long)arow * H + c * 16 + 4 * q) * 4))
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = KCHUNK(wave, ci, NCH);
+      // branch-free (clamped) so the compiler can wait per chunk (vmcnt(7), vmcnt(6), ...) and start the MFMAs of
+      // chunk 0 while chunks 1.. are still in flight; a conditional load makes it wait for everything (vmcnt(0)).
+      // Out-of-range chunks multiply a zero weight, out-of-range rows are never stored.
+      a[ci] = load_f4<AUX>(hsrc, (unsigned)(((long long)arow_c * H + (c < nch ? c : nch - 1) * 16 + 4 * q) * 4));
     }
+    __builtin_amdgcn_sched_barrier(0);   // all loads are in flight before the first MFMA (the scheduler would sink them)
+#ifdef B2T_TIMING_SPLIT_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP(6)   // operand loads complete (timing build only: serialises loads and MFMAs)
+#endif
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci) {
 #pragma unroll
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     float gh[3];
     cross_wave_reduce<3>(red, acc, gh, wave, lane);
     TSTAMP(2)   // reduce
+    float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_ghn = 0.f;
     if (live) {
       // gate non-linearities on the hardware exp unit (v_exp_f32, ~1 ulp): sigmoid(x) = 1/(1+2^(-x log2 e)),
       // tanh(x) = 1 - 2/(1+2^(2x log2 e)); the precise libm forms cost ~800 cycles per step on the serial chain.
@@ -205,30 +217,33 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
       const float n = fast_tanh(gin + r * ghn);
       const float h = (1.0f - z) * n + z * hp;
       hs[(4 * q + wave) * TP + j] = h;
-      if (reserve) {
-        float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
-        rs[0] = r; rs[H] = z; rs[2 * H] = n; rs[3 * H] = ghn;
-      }
+      sv_r = r; sv_z = z; sv_n = n; sv_ghn = ghn;
       hp = h;
     }
-    hpv[rr] = hp;
     TSTAMP(3)   // gates
     __syncthreads();                       // tile staged; also fences `red` for the next iteration
+    TSTAMP(4)   // stage barrier (waits for the slowest wave's gates)
     if (wave == 0) {                       // one wave writes the 16x16 tile as 64 x 16 B write-through stores
       const int r = lane >> 2, c4 = (lane & 3) * 4;
       if (m0 + r < B)
-        store_sc1_f4(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + j0 + c4) * 4),
+        store_f4<AUX>(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + j0 + c4) * 4),
                      *reinterpret_cast<const float4*>(&hs[r * TP + c4]));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
     }
-    TSTAMP(4)   // stage barrier + store + drain + publish
+    // The gate values saved for the backward sweep are nobody's dependency inside this sweep: store them AFTER the
+    // publish so their write acknowledgements are not part of the drain in front of the counter increment.
+    if (live && reserve) {
+      float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
+      rs[0] = sv_r; rs[H] = sv_z; rs[2 * H] = sv_n; rs[3 * H] = sv_ghn;
+    }
+    TSTAMP(5)   // tile store + drain + publish
    }
   }
   finish_call(sync, pset);   // next call uses the cleared set
 #ifdef B2T_TIMING
   if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 17))
-    for (int i = 0; i < 5; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+    for (int i = 0; i < 7; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)T);
 #endif
 }
 
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
 // dGh_{t+1} row block with its register-resident W_hh[:, slice] and (B) forms the gate gradients of
 // step t for its slice, publishing them as dG[t] for the other workgroups of the row group.
 // ---------------------------------------------------------------------------------------------------
-template <int NCB, int MT>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
+template <int NCB>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
 __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __restrict__ dY,
                                                                  const float* __restrict__ dh_last,
                                                                  const float* __restrict__ reserve,
@@ -248,11 +263,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  unsigned* sync) {
   __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 + 4 * 16 * TP];
   float* gs = red + 4 * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TP]
+  constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = blockIdx.x * 16;
-  const unsigned G = gridDim.x;
+  const unsigned G = (unsigned)H / 16u;
   const int j = lane & 15, q = lane >> 4;
-  const int unit = j0 + j;
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
   // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
   // on this workspace (stream order makes that safe), so no memset node is needed in front of the launch.
@@ -262,29 +276,26 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     const int nthr = gridDim.x * gridDim.y * 256;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
   }
+  const int rg = blockIdx.y, m0 = rg * 16;   // row groups are independent recurrences
+  const int j0 = blockIdx.x * 16;
+  const int unit = j0 + j;
   const int nch = 3 * H / 16;
 
   float4 w[NCB];
 #pragma unroll
   for (int ci = 0; ci < NCB; ++ci) {
-    const int c = wave + 4 * ci;
+    const int c = KCHUNK(wave, ci, NCB);
     w[ci] = c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit * 3 * H + c * 16 + 4 * q)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  float dzv[MT];
-#pragma unroll
-  for (int rr = 0; rr < MT; ++rr) dzv[rr] = 0.f;
+  const int row = m0 + 4 * q + wave, arow = m0 + j;
+  const int arow_c = arow < B ? arow : B - 1;
+  const bool live = row < B;
+  unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
+  float dzterm = 0.f;
 
   for (int t = T - 1; t >= -1; --t) {
-#pragma unroll
-   for (int rr = 0; rr < MT; ++rr) {
-    const int rg = blockIdx.y * MT + rr;
-    const int m0 = rg * 16;
-    if (m0 >= B) continue;
-    const int row = m0 + 4 * q + wave, arow = m0 + j;
-    const bool live = row < B;
-    unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
-    float dzterm = dzv[rr];
+   {
     // operands of the elementwise part do not depend on the recurrence: fetch them first
     float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hprev = 0.f, dy = 0.f;
     if (live && t >= 0) {
@@ -301,10 +312,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       float4 a[NCB];
 #pragma unroll
       for (int ci = 0; ci < NCB; ++ci) {
-        const int c = wave + 4 * ci;
-        a[ci] = (c < nch && arow < B) ? load_sc1_f4(dgh, (unsigned)(((long long)arow * 4 * H + c * 16 + 4 * q) * 4))
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = KCHUNK(wave, ci, NCB);
+        a[ci] = load_f4<AUX>(dgh, (unsigned)(((long long)arow_c * 4 * H + (c < nch ? c : nch - 1) * 16 + 4 * q) * 4));   // branch-free, see forward
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ci = 0; ci < NCB; ++ci) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].x, w[ci].x, acc[0], 0, 0, 0);
@@ -336,12 +347,11 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       gs[(3 * 16 + lr) * TP + j] = dn_pre;
       dzterm = d * z;
     }
-    dzv[rr] = dzterm;
     __syncthreads();
     {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores
       const int r2 = lane >> 2, c4 = (lane & 3) * 4;
       if (m0 + r2 < B)
-        store_sc1_f4(dG + (long long)t * B * 4 * H,
+        store_f4<AUX>(dG + (long long)t * B * 4 * H,
                      (unsigned)(((long long)(m0 + r2) * 4 * H + wave * H + j0 + c4) * 4),
                      *reinterpret_cast<const float4*>(&gs[(wave * 16 + r2) * TP + c4]));
     }
@@ -364,10 +374,8 @@ static int cu_count() {
   return n;
 }
 
-// Row groups per workgroup: 2 halves the workgroup count (weights are shared by the groups) and lets each
-// workgroup overlap one group's hand-off latency with the other group's MFMAs.
-// One persistent workgroup per CU: co-resident workgroups of concurrent sweeps on one CU gain almost nothing
-// (measured: 2/CU -> 1.27x, 3/CU -> 1.1x CU throughput) while every lock-step peer group then runs at the pace
+// One persistent workgroup per CU: co-resident workgroups of concurrent sweeps on one CU gain little
+// (measured: 2/CU -> 1.3x CU throughput) while every lock-step peer group then runs at the pace
 // of its slowest member.  Requesting more than half of the 160 KiB LDS makes the dispatcher place concurrent
 // sweeps (other layers of the pipelined plan) on different CUs instead of stacking them.
 constexpr unsigned EXCLUSIVE_LDS = 84 * 1024;
@@ -387,14 +395,13 @@ static unsigned exclusive_lds() {
   return v ? EXCLUSIVE_LDS : 0u;
 }
 
-static int pick_mt(int B) { (void)B; return 1; }  // MT=2 measured 2x slower per sweep: the exposed latencies are the workgroup's own load/drain, not the peers'
-
+// (Two row groups per workgroup -- half the workgroups, shared weights -- was measured 2x slower per sweep: the
+// exposed latencies are the workgroup's own load/drain, not the peers'.  Removed.)
 static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
-  const int mt = pick_mt(B);
-  const int gx = H / 16, gy = ((B + 15) / 16 + mt - 1) / mt;
+  const int gx = H / 16, gy = (B + 15) / 16;
   if (!sync_ws) { set_error("%s: sync_ws is required in persistent mode", what); return 2; }
-  if ((long long)gy * mt * T * CSTRIDE > SETW) {
-    set_error("%s: %d row groups x %d steps exceed the %d hand-off counters of one call", what, gy * mt, T, SETW);
+  if ((long long)gy * T * CSTRIDE > SETW) {
+    set_error("%s: %d row groups x %d steps exceed the %d hand-off counters of one call", what, gy, T, SETW);
     return 2;
   }
   const int cus = cu_count();
@@ -403,7 +410,6 @@ static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
               gx * gy, cus);
     return 4;
   }
-  (void)T;
   return 0;
 }
 
@@ -411,18 +417,13 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
                        float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
-  const int mt = pick_mt(B);
-  dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
+  const dim3 grid(H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
-    want_exclusive(gru_persist_fwd_kernel<NCH, 1>); want_exclusive(gru_persist_fwd_kernel<NCH, 2>);                    \
-    if (mt == 2)                                                                                                       \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync);                                                                                  \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, 1>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync);                                                                                  \
+    want_exclusive(gru_persist_fwd_kernel<NCH>);                                                                       \
+    hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                       B, H, sync);                                                                                    \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
@@ -439,18 +440,13 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
                        void* sync_ws, hipStream_t s) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
-  const int mt = pick_mt(B);
-  dim3 grid(H / 16, ((B + 15) / 16 + mt - 1) / mt), block(256);
+  const dim3 grid(H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
   do {                                                                                                                \
-    want_exclusive(gru_persist_bwd_kernel<NCB, 1>); want_exclusive(gru_persist_bwd_kernel<NCB, 2>);                   \
-    if (mt == 2)                                                                                                      \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init,      \
-                         w_hh_t, dG, dh_init, T, B, H, sync);                                                         \
-    else                                                                                                              \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, 1>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init,      \
-                         w_hh_t, dG, dh_init, T, B, H, sync);                                                         \
+    want_exclusive(gru_persist_bwd_kernel<NCB>);                                                                      \
+    hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init,      \
+                       w_hh_t, dG, dh_init, T, B, H, sync);                                                           \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);
   else if (H <= 256) B2T_LAUNCH_BWD(12);
