@@ -123,7 +123,14 @@ extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const f
                                      void* sync_ws, void* stream) {
   B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_fwd: bad shape T=%d B=%d H=%d (H%%16 must be 0)", T, B, H);
   hipStream_t s = as_stream(stream);
-  if (mode == 2) {
+  B2T_REQUIRE(mode >= 0 && mode <= 3, "gru_layer_fwd: unknown mode %d", mode);
+  if (mode == 3) {   // pipelined sweep; shapes it does not cover run as mode 1 (same protocol and workspace)
+    int rc = gru_pipeline_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
+    if (rc == 4) mode = 1;
+    else if (rc) return rc;
+  }
+  if (mode == 3) {
+  } else if (mode == 2) {
     int rc = gru_granule_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
     if (rc) return rc;
   } else if (mode == 1) {
@@ -152,7 +159,12 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
   B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_bwd: bad shape T=%d B=%d H=%d", T, B, H);
   B2T_REQUIRE(carry_ws != nullptr, "gru_layer_bwd: carry_ws is required ([B][H] floats)");
   hipStream_t s = as_stream(stream);
-  if (mode >= 1) {
+  B2T_REQUIRE(mode >= 0 && mode <= 3, "gru_layer_bwd: unknown mode %d", mode);
+  if (mode == 3) {
+    int rc = gru_pipeline_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s);
+    if (rc != 4) return rc;   // 4: shape not covered -> mode 1
+  }
+  if (mode >= 1) {   // mode 2 (granule forward) pairs with the counter backward
     return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s);
   }
   dim3 grid(H / 16, (B + 15) / 16), block(256);

@@ -75,6 +75,13 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
                        void* sync_ws, hipStream_t s);
 
+// software-pipelined persistent sweeps, R row groups per workgroup (gru_pipeline.hip); return 4 = shape not covered
+int gru_pipeline_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
+                     float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s);
+int gru_pipeline_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
+                     const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
+                     void* sync_ws, hipStream_t s);
+
 // granule (data-tagged hand-off) sweeps (gru_granule.hip)
 size_t gru_granule_bytes(int T, int B, int H);
 int gru_granule_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,

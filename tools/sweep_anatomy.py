@@ -27,8 +27,10 @@ def mk(stream):
                 sync=torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev), s=stream)
 def fwd(d):
     with torch.cuda.stream(d["s"]):
-        N.check(lib.b2t_gru_layer_fwd_f32(_p(d["gi"]), _p(d["w"]), _p(d["b"]), _p(d["out"][0]), _p(d["out"][1:]), _p(d["res"]), None, T, B, H, 1, _p(d["sync"]), ops._stream()), "f")
-names = ["poll", "mfma(+loads)", "reduce", "gates", "stagebar", "store+pub", "loads"]
+        N.check(lib.b2t_gru_layer_fwd_f32(_p(d["gi"]), _p(d["w"]), _p(d["b"]), _p(d["out"][0]), _p(d["out"][1:]), _p(d["res"]), None, T, B, H, MODE, _p(d["sync"]), ops._stream()), "f")
+MODE = int(os.environ.get("B2T_GRU_MODE", "1"))
+names = ["poll", "loads+mfma", "reduce", "gates", "stagebar", "store+pub", "(split:loads)"] if MODE == 1 else \
+        ["drain", "repoll", "issue", "mfma", "reduce", "gates", "stagebar", "store+pub"]
 for tag, plans in (("1 WG/CU", [[0, 1, 2, 3]]), ("2 WG/CU", [[0, 1]]), ("4 WG/CU", [[0]]), ("2 sweeps on 4 slices", [[0, 1, 2, 3]] * 2)):
     ds = [mk(masked_stream(p)) for p in plans]
     for rep in range(3):
