@@ -221,9 +221,18 @@ PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16,
             "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "64"))}
 
 
+def bwd_mode_for(fwd_mode: int) -> int:
+    """Backward sweep mode that goes with a forward mode (B2T_GRU_BWD_MODE overrides): the granule forward (2) pairs
+    with the counter backward (1); the pipelined forward (3) with the pipelined backward (3)."""
+    e = os.environ.get("B2T_GRU_BWD_MODE")
+    if e is not None and fwd_mode >= 1:
+        return int(e)
+    return {0: 0, 1: 1, 2: 1, 3: 3}[fwd_mode]
+
+
 def gru_mode_for(B: int, H: int) -> int:
     m = GRU_MODE["value"]
-    if m in (0, 1, 2):
+    if m in (0, 1, 2, 3):
         return m
     return 1 if (H // 16) * ((B + 15) // 16) <= MAX_RESIDENT_WGS and H <= 1024 else 0
 
@@ -531,7 +540,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                         C.c_void_p(ctx.reserves[l].data_ptr() + 4 * t0 * B * 4 * H),
                         C.c_void_p(outb.data_ptr() + 4 * (1 + t0) * B * H), C.c_void_p(outb.data_ptr() + 4 * t0 * B * H),
                         _p(whh_ts[l]), C.c_void_p(dGs[l].data_ptr() + 4 * t0 * B * 4 * H), dh_out, _p(scratch[l]),
-                        n, B, H, min(mode, 1), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
+                        n, B, H, bwd_mode_for(mode), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
                         "b2t_gru_layer_bwd_f32")
                 if piped:
                     ev_bs[l][c] = _ev(ss)

@@ -33,9 +33,13 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
                                                                  float* __restrict__ reserve, int T, int B, int H,
                                                                  unsigned* sync) {
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TP];
+  __shared__ __attribute__((aligned(16))) float stage[4][NCH * SLOT_F];   // per-wave operand staging (gru_sync.h)
   float* hs = red + 4 * 3 * 4 * 64;   // staged h tile [16 rows][TP]
   constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef B2T_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
+#endif
   const unsigned G = (unsigned)H / 16u;
   const int j = lane & 15, q = lane >> 4;
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
@@ -91,28 +95,29 @@ __global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __
     f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 a[NCH];
-#pragma unroll
-    for (int ci = 0; ci < NCH; ++ci) {
-      const int c = KCHUNK(wave, ci, NCH);
-      // branch-free (clamped) so the compiler can wait per chunk (vmcnt(7), vmcnt(6), ...) and start the MFMAs of
-      // chunk 0 while chunks 1.. are still in flight; a conditional load makes it wait for everything (vmcnt(0)).
-      // Out-of-range chunks multiply a zero weight, out-of-range rows are never stored.
-      a[ci] = load_f4<AUX>(hsrc, (unsigned)(((long long)arow_c * H + (c < nch ? c : nch - 1) * 16 + 4 * q) * 4));
-    }
+    // All loads go out first (branch-free, clamped: a conditional load makes the compiler wait for everything), then
+    // each pair is transposed and consumed as it lands (vmcnt(6), vmcnt(4), ...).
+    float4 v[NCH];
+    issue_block_loads<NCH, AUX>(v, hsrc, m0, B, H, wave * NCH * 16, H, lane);
     __builtin_amdgcn_sched_barrier(0);   // all loads are in flight before the first MFMA (the scheduler would sink them)
 #ifdef B2T_TIMING_SPLIT_LOADS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TSTAMP(6)   // operand loads complete (timing build only: serialises loads and MFMAs)
 #endif
 #pragma unroll
-    for (int ci = 0; ci < NCH; ++ci) {
+    for (int p = 0; p < NCH / 2; ++p) {
+      float4 a[2];
+      transpose_pair(&stage[wave][2 * p * SLOT_F], v[2 * p], v[2 * p + 1], a[0], a[1], lane);
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].x, w[g][ci].x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].y, w[g][ci].y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].z, w[g][ci].z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].w, w[g][ci].w, acc[g], 0, 0, 0);
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int ci = 2 * p + h2;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].x, w[g][ci].x, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].y, w[g][ci].y, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].z, w[g][ci].z, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].w, w[g][ci].w, acc[g], 0, 0, 0);
+        }
       }
     }
     asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
@@ -175,9 +180,14 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  float* __restrict__ dh_init, int T, int B, int H,
                                                                  unsigned* sync) {
   __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 + 4 * 16 * TP];
+  constexpr int NSLOT = NCB < 8 ? NCB : 8;   // staging slots per wave, recycled every NSLOT instructions
+  __shared__ __attribute__((aligned(16))) float stage[4][NSLOT * SLOT_F];
   float* gs = red + 4 * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TP]
   constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef B2T_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
+#endif
   const unsigned G = (unsigned)H / 16u;
   const int j = lane & 15, q = lane >> 4;
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
@@ -222,19 +232,21 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       wait_count(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
       const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-      float4 a[NCB];
-#pragma unroll
-      for (int ci = 0; ci < NCB; ++ci) {
-        const int c = KCHUNK(wave, ci, NCB);
-        a[ci] = load_f4<AUX>(dgh, (unsigned)(((long long)arow_c * 4 * H + (c < nch ? c : nch - 1) * 16 + 4 * q) * 4));   // branch-free, see forward
-      }
+      float4 v[NCB];
+      issue_block_loads<NCB, AUX>(v, dgh, m0, B, 4 * H, wave * NCB * 16, 3 * H, lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ci = 0; ci < NCB; ++ci) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].x, w[ci].x, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].y, w[ci].y, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].z, w[ci].z, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ci].w, w[ci].w, acc[0], 0, 0, 0);
+      for (int p = 0; p < NCB / 2; ++p) {
+        float4 a[2];
+        transpose_pair(&stage[wave][((2 * p) % NSLOT) * SLOT_F], v[2 * p], v[2 * p + 1], a[0], a[1], lane);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int ci = 2 * p + h2;
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].x, w[ci].x, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].y, w[ci].y, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].z, w[ci].z, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].w, w[ci].w, acc[0], 0, 0, 0);
+        }
       }
       float s[1];
       cross_wave_reduce<1>(red, acc, s, wave, lane);

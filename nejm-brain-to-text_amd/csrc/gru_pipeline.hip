@@ -56,6 +56,15 @@ __device__ __forceinline__ void issue_poll(unsigned& dst, const unsigned* p) {
 __device__ __forceinline__ void issue_store_f32(float* p, float v) {
   asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void issue_store_sc1_x4(u32x4s rsrc, unsigned byte_off, f32x4 v) {
+#ifdef B2T_EXPERIMENT_PLAIN_TILE_STORE   // timing experiment only: NOT visible across XCDs
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(byte_off), "s"(rsrc) : "memory");
+#elif defined(B2T_EXPERIMENT_NO_TILE_STORE)
+  asm volatile("" ::"v"(v), "v"(byte_off), "s"(rsrc) : "memory");
+#else
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" ::"v"(v), "v"(byte_off), "s"(rsrc) : "memory");
+#endif
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // Full drain that the compiler's wait-insertion pass can also see (a real S_WAITCNT vmcnt(0), expcnt/lgkmcnt
 // untouched): after it the pass knows none of ITS loads is pending and adds no waits of its own downstream.
@@ -89,17 +98,22 @@ __device__ __forceinline__ void poll_until(const unsigned* p, unsigned target, u
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+// (at most 256 registers, i.e. two waves per SIMD: a workgroup that needs a whole SIMD to itself can only start on a CU
+// the GEMMs have completely left, and the sweep cannot take its first step before all of its workgroups run)
 template <int NCH, int R>   // NCH: 16-wide K chunks per wave (H <= 64*NCH); R: row groups per workgroup (even)
-__global__ __launch_bounds__(256, 1) void gru_pipe_fwd_kernel(const float* __restrict__ gi,
+__global__ __launch_bounds__(256, (NCH <= 8 ? 2 : 1)) void gru_pipe_fwd_kernel(const float* __restrict__ gi,
                                                               const float* __restrict__ w_hh,
                                                               const float* __restrict__ b_hh,
                                                               const float* __restrict__ h_init, float* out,
                                                               float* __restrict__ reserve, int T, int B, int H,
                                                               unsigned* sync) {
-  static_assert(R == 2 || R == 4, "the buffer parity of an item is r & 1");
+  static_assert(R == 4, "buffer parity of an item is r & 1; the deferred publish needs R >= 3");
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TP];
   float* hs = red + 4 * 3 * 4 * 64;   // staged h tile [16 rows][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef B2T_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
+#endif
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
   const int j0 = blockIdx.x * 16, unit = j0 + j;
@@ -170,6 +184,10 @@ __global__ __launch_bounds__(256, 1) void gru_pipe_fwd_kernel(const float* __res
 #define PSTAMP(i)
 #endif
 
+  unsigned* pub_ptr = nullptr;   // counter of the previous item (its tile is still in LDS, unpublished); wave-uniform
+  int pub_m0 = 0, pub_t = 0;
+  bool published = false;
+
   for (int t = 0; t < T; ++t) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -177,54 +195,56 @@ __global__ __launch_bounds__(256, 1) void gru_pipe_fwd_kernel(const float* __res
       // ---- next item (rn, tn) and the one after (r2, t2) --------------------------------------------------------
       const int rn = (r + 1) % R, tn = (r + 1 < R) ? t : t + 1;
       const int r2 = (r + 2) % R, t2 = (r + 2 < R) ? t : t + 1;
-      // (a) the next item's operands must be published.  Its poll went out one iteration ago, and so did everything
-      // else still outstanding (the loads of THIS item, the late reserve stores): this drain is free.
-      // (wave 0 already drained in its publish; only its counter increment, which returns nothing, may be in flight,
-      // and waiting for that acknowledgement here would put a fabric round trip on every item)
-      if (wave != 0) drain_vm();
+      // (a) this item's fragments, its gi values and the poll of the next item must have landed.  They were issued
+      // most of an item ago.  The only younger operation of a wave is wave 0's counter increment (it returns nothing
+      // and waiting for its acknowledgement would put a fabric round trip on every item): vmcnt(1) there.
+      if (wave == 0 && published) wait_vm<1>(); else drain_vm();
       after_wait(pvv);
 #pragma unroll
       for (int ci = 0; ci < NCH; ++ci) after_wait(abuf[P][ci]);
       after_wait(gbuf[P][0]); after_wait(gbuf[P][1]); after_wait(gbuf[P][2]);
-      PSTAMP(0)   // drain
+      PSTAMP(0)   // wait for the prefetch
       {
         const unsigned pv = __builtin_amdgcn_readfirstlane(pvv);
         if (pv_need && pv < G) poll_until(pv_ptr, G, pv, err);
       }
       PSTAMP(1)   // blocking re-poll (normally nothing)
-      // (b) issue the next item's loads (clamped: past the end they re-read the last step, results unused), then the
-      // poll of the item after next: counter (rg0 + r2, t2 - 1); not needed for t2 == 0, past the end, or row groups
-      // beyond the batch (the load is still issued, branch-free, on a valid word).
-      {
-        const int tl = tn < T ? tn : T - 1;
-        const u32x4s rs = make_rsrc(tl > 0 ? out + (long long)(tl - 1) * B * H : h_init);
-#pragma unroll
-        for (int ci = 0; ci < NCH; ++ci)
-          issue_load_sc1_x4(abuf[P ^ 1][ci], rs, (unsigned)arow[rn] * (unsigned)H * 4u + coff[ci]);
-        const float* g3 = gi + ((long long)tl * B + orow[rn]) * 3 * H + unit;
-        issue_load_f32(gbuf[P ^ 1][0], g3); issue_load_f32(gbuf[P ^ 1][1], g3 + H); issue_load_f32(gbuf[P ^ 1][2], g3 + 2 * H);
-        pv_need = (t2 > 0) && (t2 < T) && (rg0 + r2 < nrg);
-        const int tc = t2 > 0 ? (t2 < T ? t2 - 1 : T - 1) : 0;
-        const int rc = (rg0 + r2 < nrg) ? rg0 + r2 : nrg - 1;
-        pv_ptr = cset + (size_t)rc * T + tc;
-        issue_poll(pvv, pv_ptr);
+      // (b) the previous item's h tile goes out first (wave 0), then this item's MFMAs run with the NEXT item's loads
+      // sprinkled between them.  The CU's texture path accepts the 64-byte pieces of these loads at ~16 B/clock
+      // (measured: 32 KB of fragments = ~2000 cycles, whatever the cache policy or locality), and a wave that issues
+      // them back to back just stalls at issue for that long; fed a couple at a time between groups of MFMAs they
+      // cost nothing.  Clamped addresses: past the end they re-read the last step, results unused.
+      if (wave == 0 && pub_ptr != nullptr) {
+        const int r4 = lane >> 2, c4 = (lane & 3) * 4;
+        f32x4 tv;
+        tv[0] = hs[r4 * TP + c4]; tv[1] = hs[r4 * TP + c4 + 1]; tv[2] = hs[r4 * TP + c4 + 2]; tv[3] = hs[r4 * TP + c4 + 3];
+        if (pub_m0 + r4 < B) issue_store_sc1_x4(make_rsrc(out + (long long)pub_t * B * H),
+                                                (unsigned)(((long long)(pub_m0 + r4) * H + j0 + c4) * 4), tv);
       }
-      // The previous item's gate values (saved for the backward sweep) go out here, behind the prefetch: nothing
-      // waits on them before this item's publish, a few thousand cycles away.
-      if (sv_off >= 0 && reserve) {
-        float* rs = reserve + sv_off;
-        issue_store_f32(rs, sv[0]); issue_store_f32(rs + H, sv[1]); issue_store_f32(rs + 2 * H, sv[2]);
-        issue_store_f32(rs + 3 * H, sv[3]);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before the MFMAs of item (t, r) start
-      PSTAMP(2)   // issue block
+      const int tl = tn < T ? tn : T - 1;
+      const u32x4s rsn = make_rsrc(tl > 0 ? out + (long long)(tl - 1) * B * H : h_init);
+      const unsigned rown = (unsigned)arow[rn] * (unsigned)H * 4u;
+      const float* g3 = gi + ((long long)tl * B + orow[rn]) * 3 * H + unit;
+      float* rsv = reserve + (sv_off >= 0 ? sv_off : 0);
+      const bool do_rsv = sv_off >= 0 && reserve;
+      __builtin_amdgcn_sched_barrier(0);
+      PSTAMP(2)   // tile store issue + address set-up
 
       // (c) item (t, r): recurrent product from the fragments loaded one iteration ago
       f32x4 acc[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int LPG = NCH >= 8 ? 2 : 1;   // fragment loads per MFMA group: all of them go out in the first half
 #pragma unroll
       for (int ci = 0; ci < NCH; ++ci) {
+#pragma unroll
+        for (int k = 0; k < LPG; ++k) {
+          const int li = ci * LPG + k;
+          if (li < NCH) issue_load_sc1_x4(abuf[P ^ 1][li], rsn, rown + coff[li]);
+        }
+        if (ci * LPG >= NCH && ci * LPG < NCH + 3) issue_load_f32(gbuf[P ^ 1][ci * LPG - NCH], g3 + (long long)(ci * LPG - NCH) * H);
+        if (LPG == 2 && ci * LPG + 1 >= NCH && ci * LPG + 1 < NCH + 3)
+          issue_load_f32(gbuf[P ^ 1][ci * LPG + 1 - NCH], g3 + (long long)(ci * LPG + 1 - NCH) * H);
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[P][ci][0], w[g][ci].x, acc[g], 0, 0, 0);
@@ -232,13 +252,41 @@ __global__ __launch_bounds__(256, 1) void gru_pipe_fwd_kernel(const float* __res
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[P][ci][2], w[g][ci].z, acc[g], 0, 0, 0);
           acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[P][ci][3], w[g][ci].w, acc[g], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (LPG == 1) {   // small H: the gi loads did not fit in the loop above
+        issue_load_f32(gbuf[P ^ 1][0], g3); issue_load_f32(gbuf[P ^ 1][1], g3 + H); issue_load_f32(gbuf[P ^ 1][2], g3 + 2 * H);
+      }
+      // the previous item's gate values (saved for the backward sweep; nothing in this sweep waits for them)
+      if (do_rsv) {
+        issue_store_f32(rsv, sv[0]); issue_store_f32(rsv + H, sv[1]); issue_store_f32(rsv + 2 * H, sv[2]);
+        issue_store_f32(rsv + 3 * H, sv[3]);
       }
       asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
+      __builtin_amdgcn_sched_barrier(0);
       PSTAMP(3)   // MFMA
+      // (c2) late publish of the PREVIOUS item: its tile store went out a whole MFMA phase ago, in front of at least
+      // NCH + 3 younger operations of wave 0, so vmcnt(NCH + 3) proves the write-through acknowledged without waiting
+      // for the loads that were just issued.  Then the poll of the item
+      // after next: counter (rg0 + r2, t2 - 1); not needed for t2 == 0, past the end, or row groups beyond the batch
+      // (the load is still issued, branch-free, on a valid word).  The counter increment goes out behind the poll.
+      published = false;
+      if (wave == 0 && pub_ptr != nullptr) wait_vm<NCH + 3>();   // the tile store is older than the NCH + 3 loads above
+      {
+        pv_need = (t2 > 0) && (t2 < T) && (rg0 + r2 < nrg);
+        const int tc = t2 > 0 ? (t2 < T ? t2 - 1 : T - 1) : 0;
+        const int rc = (rg0 + r2 < nrg) ? rg0 + r2 : nrg - 1;
+        pv_ptr = cset + (size_t)rc * T + tc;
+        issue_poll(pvv, pv_ptr);
+      }
+      if (wave == 0 && pub_ptr != nullptr) {
+        if (lane == 0) __hip_atomic_fetch_add(pub_ptr, 1u, RLX_AGENT);
+        published = true;
+      }
       float gh[3];
       cross_wave_reduce<3>(red, acc, gh, wave, lane);
-      PSTAMP(4)   // reduce
-      // (d) gates, stage, publish
+      PSTAMP(4)   // late publish + poll issue + reduce
+      // (d) gates, stage, store the tile (published after the next item's MFMAs)
       const int m0 = (rg0 + r) * 16;
       const bool live = (m0 + 4 * q + wave) < B;
       const float ghn = gh[2] + bhn;
@@ -253,22 +301,25 @@ __global__ __launch_bounds__(256, 1) void gru_pipe_fwd_kernel(const float* __res
       PSTAMP(5)   // gates
       __syncthreads();   // tile staged; also fences `red` for the next item
       PSTAMP(6)   // stage barrier
-      if (wave == 0) {
-        const int r4 = lane >> 2, c4 = (lane & 3) * 4;
-        if (m0 + r4 < B)
-          store_f4<PAUX>(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r4) * H + j0 + c4) * 4),
-                         *reinterpret_cast<const float4*>(&hs[r4 * TP + c4]));
-        drain_vm();   // the prefetch went out a whole MFMA phase ago: this waits for the tile's write-through only
-        if (lane == 0 && m0 < B) __hip_atomic_fetch_add(cset + (size_t)(rg0 + r) * T + t, 1u, RLX_AGENT);
-      }
-      PSTAMP(7)   // store + drain + publish (wave 0)
+      pub_ptr = (m0 < B) ? cset + (size_t)(rg0 + r) * T + t : nullptr;   // stored and published during the next item
+      pub_m0 = m0; pub_t = t;
+      PSTAMP(7)
     }
+  }
+  // the last item's tile and publish, then the last reserve values
+  drain_vm();
+  if (wave == 0 && pub_ptr != nullptr) {
+    const int r4 = lane >> 2, c4 = (lane & 3) * 4;
+    if (pub_m0 + r4 < B)
+      store_f4<PAUX>(out + (long long)pub_t * B * H, (unsigned)(((long long)(pub_m0 + r4) * H + j0 + c4) * 4),
+                     *reinterpret_cast<const float4*>(&hs[r4 * TP + c4]));
+    drain_vm();
+    if (lane == 0) __hip_atomic_fetch_add(pub_ptr, 1u, RLX_AGENT);
   }
 #ifdef B2T_TIMING
   if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 17))
     for (int i = 0; i < 8; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)(T * R));
 #endif
-  wait_vm<0>();
   if (sv_off >= 0 && reserve) {
     float* rs = reserve + sv_off;
     rs[0] = sv[0]; rs[H] = sv[1]; rs[2 * H] = sv[2]; rs[3 * H] = sv[3];
@@ -290,10 +341,13 @@ __global__ __launch_bounds__(256, 1) void gru_pipe_bwd_kernel(const float* __res
                                                               const float* __restrict__ w_hh_t, float* dG,
                                                               float* __restrict__ dh_init, int T, int B, int H,
                                                               unsigned* sync) {
-  static_assert(R == 2 || R == 4, "the buffer parity of an item is r & 1");
+  static_assert(R == 4, "buffer parity of an item is r & 1; the deferred publish needs R >= 3");
   __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 + 4 * 16 * TP];
   float* gs = red + 4 * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef B2T_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
+#endif
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
   const int j0 = blockIdx.x * 16, unit = j0 + j;
@@ -452,7 +506,10 @@ __global__ __launch_bounds__(256, 1) void gru_pipe_bwd_kernel(const float* __res
   finish_call(sync, pset);
 }
 
-static int pipe_rows(int B) { const int nrg = (B + 15) / 16; return nrg >= 4 ? 4 : 2; }
+// Row groups per workgroup: always 4.  The publish of an item is deferred by one item, so the item that consumes
+// it must be at least two items later: R >= 3 (with R = 2 a workgroup would wait for its own, not yet issued, counter
+// increment).  Row groups beyond the batch are processed as dead items (no polls, no stores).
+static int pipe_rows(int B) { (void)B; return 4; }
 
 static int pipe_check(int B, int H, int T, void* sync_ws, const char* what) {
   const int nrg = (B + 15) / 16;
@@ -461,7 +518,7 @@ static int pipe_check(int B, int H, int T, void* sync_ws, const char* what) {
     set_error("%s: %d row groups x %d steps exceed the %d hand-off counters of one call", what, nrg, T, SETW);
     return 2;
   }
-  if (nrg < 2) { set_error("%s: the pipelined sweep needs at least 2 row groups (B > 16); use mode 1", what); return 4; }
+  if (nrg < 3) { set_error("%s: the pipelined sweep pays off from 3 row groups (B > 32); use mode 1", what); return 4; }
   return 0;
 }
 
@@ -474,10 +531,7 @@ int gru_pipeline_fwd(const float* gi, const float* w_hh, const float* b_hh, cons
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH(NCH)                                                                                                \
   do {                                                                                                                 \
-    if (R == 4)                                                                                                        \
-      hipLaunchKernelGGL((gru_pipe_fwd_kernel<NCH, 4>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync); \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gru_pipe_fwd_kernel<NCH, 2>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync); \
+    hipLaunchKernelGGL((gru_pipe_fwd_kernel<NCH, 4>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync); \
   } while (0)
   if (H <= 128) B2T_LAUNCH(2);
   else if (H <= 256) B2T_LAUNCH(4);
@@ -498,12 +552,8 @@ int gru_pipeline_bwd(const float* dY, const float* dh_last, const float* reserve
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH(NCB)                                                                                                \
   do {                                                                                                                 \
-    if (R == 4)                                                                                                        \
-      hipLaunchKernelGGL((gru_pipe_bwd_kernel<NCB, 4>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG,    \
-                         dh_init, T, B, H, sync);                                                                      \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gru_pipe_bwd_kernel<NCB, 2>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG,    \
-                         dh_init, T, B, H, sync);                                                                      \
+    hipLaunchKernelGGL((gru_pipe_bwd_kernel<NCB, 4>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG,      \
+                       dh_init, T, B, H, sync);                                                                        \
   } while (0)
   if (H <= 128) B2T_LAUNCH(6);
   else if (H <= 256) B2T_LAUNCH(12);

@@ -83,13 +83,46 @@ __device__ __forceinline__ void finish_call(unsigned* sync, unsigned pset) {
   }
 }
 
-// Which 16-wide K chunk wave `w` contracts in its ci-th slot.  Contiguous per wave (default): the wave's consecutive
-// 64-byte operand reads of a row fall into the same 128-byte lines.  B2T_KCHUNK_STRIDED: chunks dealt round-robin.
-#ifdef B2T_KCHUNK_STRIDED
-#define KCHUNK(w, ci, n) ((w) + 4 * (ci))
-#else
+// Which 16-wide K chunk wave `w` contracts in its ci-th slot: contiguous per wave (the operand staging below relies
+// on it: a wave reads 32 consecutive floats of a row per load).
 #define KCHUNK(w, ci, n) ((w) * (n) + (ci))
-#endif
+
+// ---- operand block -> MFMA A fragments --------------------------------------------------------------------------
+// The A fragment of v_mfma_f32_16x16x4_f32 wants lane (j = lane & 15, q = lane >> 4) to hold row j, 4 consecutive k.
+// Loading it directly (one 16-byte load per lane) makes every 4 CONSECUTIVE lanes touch 4 different rows, i.e. 4
+// different cache lines, and the texture addresser then accepts only 16 B/clock per CU (tools/ubench/tcp_pattern.hip:
+// 2048 cycles per 32 KB block, whatever the cache policy; 515 cycles when 4 consecutive lanes read 64 consecutive
+// bytes; 571 under full-chip load when 8 consecutive lanes read one whole 128-byte line).  So a wave loads the block
+// line by line -- instruction (p, rh): rows 8 rh .. 8 rh + 7 of the row group, 32 floats (one line) each, starting at
+// the wave's column col0 + 32 p -- and transposes each pair of instructions into two fragments through a private LDS
+// slot pair (the same wave writes and reads: LDS operations of a wave execute in order, no barrier).
+// Slot: 8 rows x 36 floats (144-byte pitch: the fragment reads of 16 lanes then hit 16 distinct 4-bank groups, and
+// the second slot of a pair starts 1152 B = 32 banks later, interleaving with the first).
+constexpr int SLOT_F = 8 * 36;
+
+template <int N, int AUX>
+__device__ __forceinline__ void issue_block_loads(float4 (&v)[N], const float* slab_uniform, int m0, int B, int ld,
+                                                  int col0, int ncol, int lane) {
+  const int r8 = lane >> 3, p8 = lane & 7;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int row = m0 + (i & 1) * 8 + r8, col = col0 + (i >> 1) * 32 + p8 * 4;
+    // clamped, branch-free: rows beyond the batch are never stored, columns beyond the operand meet zero weights
+    const long long off = (long long)(row < B ? row : B - 1) * ld + (col < ncol ? col : ncol - 4);
+    v[i] = load_f4<AUX>(slab_uniform, (unsigned)(off * 4));
+  }
+}
+
+// v0 = instruction (p, 0), v1 = instruction (p, 1)  ->  a0 = fragment of chunk 2p, a1 = fragment of chunk 2p + 1
+__device__ __forceinline__ void transpose_pair(float* slot_pair, float4 v0, float4 v1, float4& a0, float4& a1, int lane) {
+  const int r8 = lane >> 3, p8 = lane & 7;
+  *reinterpret_cast<float4*>(&slot_pair[r8 * 36 + p8 * 4]) = v0;
+  *reinterpret_cast<float4*>(&slot_pair[SLOT_F + r8 * 36 + p8 * 4]) = v1;
+  const int j = lane & 15, q = lane >> 4;
+  const float* s = slot_pair + (j >> 3) * SLOT_F + (j & 7) * 36 + 4 * q;
+  a0 = *reinterpret_cast<const float4*>(s);
+  a1 = *reinterpret_cast<const float4*>(s + 16);
+}
 
 constexpr int TP = 20;  // LDS pitch (floats) of a staged 16x16 tile: 16-byte aligned rows, conflict-light
 
