@@ -216,7 +216,7 @@ class Grads(Params):
 GRU_MODE = {"value": int(os.environ.get("B2T_GRU_MODE", "-1"))}
 MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its workgroups resident at once
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer, no side streams).
-PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "8")), "min_chunk": 16,
+PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "6")), "min_chunk": 16,
             "sweep_streams": int(os.environ.get("B2T_SWEEP_STREAMS", "64")),
             "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "64"))}
 
@@ -552,10 +552,13 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                     ev_dx[l][c] = _ev(sg)
             if piped and c == 0:
                 # weight gradients of the whole layer once its last chunk is swept, on their own stream (they overlap
-                # the sweeps of the layers below).  Per-chunk accumulation (t0/t1/accumulate) is supported by the helper
-                # but measured slower inside the full step: 8x more launches competing with the sweeps' CUs.
-                with torch.cuda.stream(s_wg[l]):
-                    s_wg[l].wait_event(ev_bs[l][c])
+                # the sweeps of the layers below).  Per-chunk accumulation is supported by the helper but measured
+                # slower inside the full step, for every layer and also for layer 0 alone (28.2 vs 27.1 ms): more
+                # launches competing with the sweeps' CUs.  Layer 0's go to the top layer's GEMM stream (idle by then)
+                # so that they overlap the day-layer backward instead of queueing in front of it.
+                swg = s_gemm[L - 1] if (l == 0 and L > 1) else s_wg[l]
+                with torch.cuda.stream(swg):
+                    swg.wait_event(ev_bs[l][c])
                     _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
             if (not piped) and c == 0:
                 _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
