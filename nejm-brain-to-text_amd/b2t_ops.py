@@ -408,10 +408,10 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
                 if piped:
                     ev_sw[l][c] = _ev(ss)
     if piped:
-        for l in range(L):
-            main.wait_event(ev_sw[l][-1])
-        for s in s_gemm:
-            main.wait_event(_ev(s))
+        # One join is enough: the last chunk of the top layer's sweep transitively depends on every GEMM and sweep
+        # enqueued above.  (Each wait is a barrier packet the command processor works through one by one: the 10-15
+        # joins that used to sit here and at the end of the backward pass cost ~0.3 ms of idle chip each.)
+        main.wait_event(ev_sw[L - 1][-1])
 
     # 4. head: logits[b,t,:] = out W^T + b  (rnn_model.py:129), written batch-first
     logits = torch.empty((B, Tp, Cc), dtype=torch.float32, device=dev)
@@ -585,7 +585,9 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
         if bucket_cb:
             bucket_cb("day")
     if piped:
-        for s in s_sweep + s_gemm + s_wg:
+        # every sweep stream's last launch is followed by a GEMM on that layer's GEMM stream (which waits for it), and
+        # the weight-gradient streams are GEMM streams: joining the L GEMM streams joins everything
+        for s in s_gemm:
             main.wait_event(_ev(s))
     # h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
     if not ctx.custom_states:
