@@ -357,15 +357,17 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     reserves = [sbuf(f"res{l}", (Tp, B, 4 * H)) if save else None for l in range(L)]
     gis = [ws.get(f"gi{l if piped else 0}", (Tp, B, 3 * H), dev) for l in range(L)]
     hidden = torch.empty((L, B, H), dtype=torch.float32, device=dev)
-    for l in range(L):   # slot 0 = initial state, so outs[l][0:T'] is the h_{t-1} matrix
-        if states is None:
-            outs[l][0].copy_(prm.h0.view(1, H).expand(B, H))
-        else:
-            outs[l][0].copy_(states[l])
     ev0 = _ev(main)
     if piped:
         for s in s_sweep + s_gemm:
             s.wait_event(ev0)
+    for l in range(L):   # slot 0 = initial state, so outs[l][0:T'] is the h_{t-1} matrix
+        # (on the layer's sweep stream: five small broadcast copies in front of the first GEMM were ~0.25 ms of step)
+        with torch.cuda.stream(s_sweep[l] if piped else main):
+            if states is None:
+                outs[l][0].copy_(prm.h0.view(1, H).expand(B, H))
+            else:
+                outs[l][0].copy_(states[l])
     ev_sw: List[List[Optional[torch.cuda.Event]]] = [[None] * len(chunks) for _ in range(L)]
     a_s0_l0 = dims.stride * F if dims.patch > 0 else F
     # cells (chunk c, layer l) are enqueued diagonal by diagonal (c + l), a topological order in which the two
@@ -479,17 +481,18 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     whh_ts = [ws.get(f"whh_t{l if piped else 0}", (H, 3 * H), dev) for l in range(L)]
     dU = ws.get("dU", (B, T, F), dev)
     dV = ws.get("dV", (B, Tp, dims.In0), dev) if dims.patch > 0 else None
-    if piped:
-        for s in s_sweep + s_gemm + s_wg:
-            s.wait_event(ev_top)
     ev_dx: List[List[Optional[torch.cuda.Event]]] = [[None] * nc for _ in range(L)]
     ev_bs: List[List[Optional[torch.cuda.Event]]] = [[None] * nc for _ in range(L)]
     ev_wt = [None] * L
     if piped:
+        # W_hh^T for the backward sweeps depends on the parameters only: enqueued BEFORE the streams wait for the head
+        # (they run while the CTC kernel has the chip to itself instead of in front of the first backward sweep)
         for l in range(L):
             with torch.cuda.stream(s_gemm[l]):
                 N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_ts[l]), 3 * H, H, _stream()), "b2t_transpose_f32")
                 ev_wt[l] = _ev(s_gemm[l])
+        for s in s_sweep + s_gemm:
+            s.wait_event(ev_top)
 
     def dx_gemm(l, t0, n):
         """dIn = dGi W_ih for rows of chunk [t0,t0+n): into dY[l-1] (l>0) or dU / dV (l == 0)."""
