@@ -218,7 +218,8 @@ MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its wor
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer, no side streams).
 PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "6")), "min_chunk": 16,
             "sweep_streams": int(os.environ.get("B2T_SWEEP_STREAMS", "64")),
-            "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "64"))}
+            "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "64")),
+            "sweep_priority": int(os.environ.get("B2T_SWEEP_PRIORITY", "0"))}
 
 
 def bwd_mode_for(fwd_mode: int) -> int:
@@ -272,7 +273,7 @@ class Workspace:
             # One sweep stream per layer by default.  B2T_SWEEP_STREAMS=2 (with B2T_SWEEP_EXCLUSIVE=1: one persistent
             # workgroup per CU) bounds the sweeps in flight to two — measured slower inside the full step, see DESIGN.md.
             nsw = max(1, min(L, PIPELINE["sweep_streams"]))
-            base = [torch.cuda.Stream(device=device) for _ in range(nsw)]
+            base = [torch.cuda.Stream(device=device, priority=(-1 if PIPELINE["sweep_priority"] else 0)) for _ in range(nsw)]
             self.streams[key] = ([base[l % nsw] for l in range(L)],
                                  [torch.cuda.Stream(device=device) for _ in range(L)])
         return self.streams[key]

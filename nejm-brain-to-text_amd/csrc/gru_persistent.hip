@@ -26,7 +26,7 @@ namespace b2t {
 // forward
 // ---------------------------------------------------------------------------------------------------
 template <int NCH>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
-__global__ __launch_bounds__(256, 1) void gru_persist_fwd_kernel(const float* __restrict__ gi,
+__global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,

@@ -511,6 +511,21 @@ __global__ __launch_bounds__(256, 1) void gru_pipe_bwd_kernel(const float* __res
 // increment).  Row groups beyond the batch are processed as dead items (no polls, no stores).
 static int pipe_rows(int B) { (void)B; return 4; }
 
+// B2T_PIPE_EXCLUSIVE_KB=n: request n KB of (unused) dynamic LDS per workgroup so that no second sweep workgroup fits on
+// the CU (GEMM workgroups, 34 KB each, still do when n <= 92).
+static unsigned pipe_extra_lds() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("B2T_PIPE_EXCLUSIVE_KB"); v = e ? atoi(e) * 1024 : 0; }
+  return (unsigned)v;
+}
+template <typename K> static void pipe_allow_lds(K kernel) {
+  static bool done = false;
+  if (!done && pipe_extra_lds() > 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_extra_lds());
+    done = true;
+  }
+}
+
 static int pipe_check(int B, int H, int T, void* sync_ws, const char* what) {
   const int nrg = (B + 15) / 16;
   if (!sync_ws) { set_error("%s: sync_ws is required in persistent mode", what); return 2; }
@@ -531,7 +546,8 @@ int gru_pipeline_fwd(const float* gi, const float* w_hh, const float* b_hh, cons
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH(NCH)                                                                                                \
   do {                                                                                                                 \
-    hipLaunchKernelGGL((gru_pipe_fwd_kernel<NCH, 4>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync); \
+    pipe_allow_lds(gru_pipe_fwd_kernel<NCH, 4>);                                                                       \
+    hipLaunchKernelGGL((gru_pipe_fwd_kernel<NCH, 4>), grid, block, pipe_extra_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync); \
   } while (0)
   if (H <= 128) B2T_LAUNCH(2);
   else if (H <= 256) B2T_LAUNCH(4);
