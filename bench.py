@@ -164,10 +164,11 @@ def main():
     lossv = float(loss)
     assert np.isfinite(lossv), "non-finite loss in the bench step"
 
-    # ---- live per-kernel timing (HIP events on the launch stream) over 2 extra instrumented steps ----
+    # ---- live per-kernel timing (HIP events on the launch stream) over 4 extra instrumented steps ----
     prof = ops.PROFILE
     prof["on"] = True; prof["ev"] = []
-    for i in range(2):
+    NPROF = 4
+    for i in range(NPROF):
         step(a.warmup + a.steps + i)
     torch.cuda.synchronize()
     prof["on"] = False
@@ -193,11 +194,11 @@ def main():
     roofline = dict(bound="mfma", kernel=dname, achieved=round(achieved / 1e12, 3), peak=round(PEAK_F32_MFMA / 1e12, 1),
                     unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA, 4), traffic=traffic, traffic_unit="GB/launch",
                     traffic_source=traffic_src,
-                    avg_launch_us=round(dtime / max(1, dlaunch) * 1e6, 2), launches_per_step=dlaunch // 2,
-                    summed_stream_time_over_step=round(dtime / 2 / (ms * 1e-3), 3),   # >1: launches overlap on side streams
+                    avg_launch_us=round(dtime / max(1, dlaunch) * 1e6, 2), launches_per_step=dlaunch // NPROF,
+                    summed_stream_time_over_step=round(dtime / NPROF / (ms * 1e-3), 3),   # >1: launches overlap on side streams
                     step_flops_frac=round(FLOPS_PER_STEP / (ms * 1e-3) / PEAK_F32_MFMA, 4),
                     step_hbm_frac=round(ALG_BYTES_PER_STEP / (ms * 1e-3) / PEAK_HBM, 4),
-                    breakdown_ms={k: round(v[0] / 2 * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])})
+                    breakdown_ms={k: round(v[0] / NPROF * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])})
 
     if rank == 0:
         out = dict(metric="GRU+CTC train sentences/sec", value=round(value, 2), unit="sentences/s", n_gpus=world,
