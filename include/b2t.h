@@ -106,7 +106,11 @@ int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t see
  * out [T][B][H]; reserve [T][B][4H] = (r,z,n,gh_n) saved for the backward sweep (may be NULL
  * for inference).  h_last [B][H] (optional) = out[T-1].
  * mode: 0 = step-launch kernels (one launch per time step), 1 = persistent sweep (one launch,
- * W_hh slices resident in registers, agent-scope flag hand-off of h_t between workgroups).
+ * W_hh slices resident in registers, agent-scope flag hand-off of h_t between workgroups),
+ * 2 = persistent forward with data-tagged granules (backward: as mode 1), 3 = software-pipelined
+ * persistent sweep, 4 row groups per workgroup (csrc/gru_pipeline.hip; shapes it does not cover --
+ * fewer than 3 row groups, H > 512 backward / > 768 forward -- run as mode 1).  All modes produce the
+ * same out / reserve / dG layouts and can be mixed between calls on one workspace.
  * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode; zeroed by the call). */
 size_t b2t_gru_sync_bytes(int T);
 /* Workspace size valid for every mode (mode 2 = persistent sweep with data-tagged 8-byte {value,tag}

@@ -65,6 +65,11 @@ __device__ __forceinline__ void issue_store_sc1_x4(u32x4s rsrc, unsigned byte_of
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1" ::"v"(v), "v"(byte_off), "s"(rsrc) : "memory");
 #endif
 }
+// The source registers of an assembly-issued store must stay untouched until the store has completed (this target has
+// no interlock: the compiler protects its OWN stores with vmcnt waits, it cannot see ours).  keep_until_here() is a
+// fake use: placed behind the drain that covers the store, it keeps the register allocator from reusing them earlier.
+__device__ __forceinline__ void keep_until_here(const f32x4& v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void keep_until_here(float v) { asm volatile("" ::"v"(v)); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // Full drain that the compiler's wait-insertion pass can also see (a real S_WAITCNT vmcnt(0), expcnt/lgkmcnt
 // untouched): after it the pass knows none of ITS loads is pending and adds no waits of its own downstream.
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 2 : 1)) void gru_pipe_fwd_kernel(c
   float gbuf[2][3];      // its gi_r, gi_z, gi_n
   unsigned pvv = 0;      // raw poll word of the item after next (in flight)
   float sv[4] = {0.f, 0.f, 0.f, 0.f};   // (r, z, n, gh_n) of the previous item, stored one item late (see below)
+  float hold[4] = {0.f, 0.f, 0.f, 0.f}; // the registers those stores read from
   long long sv_off = -1;
 
   // prologue: item (t=0, r=0) reads h_init, no counter involved; the "poll" of item (0,1) is a dummy
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 2 : 1)) void gru_pipe_fwd_kernel(c
 
   unsigned* pub_ptr = nullptr;   // counter of the previous item (its tile is still in LDS, unpublished); wave-uniform
   int pub_m0 = 0, pub_t = 0;
-  bool published = false;
+
 
   for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -196,9 +202,12 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 2 : 1)) void gru_pipe_fwd_kernel(c
       const int rn = (r + 1) % R, tn = (r + 1 < R) ? t : t + 1;
       const int r2 = (r + 2) % R, t2 = (r + 2 < R) ? t : t + 1;
       // (a) this item's fragments, its gi values and the poll of the next item must have landed.  They were issued
-      // most of an item ago.  The only younger operation of a wave is wave 0's counter increment (it returns nothing
-      // and waiting for its acknowledgement would put a fabric round trip on every item): vmcnt(1) there.
-      if (wave == 0 && published) wait_vm<1>(); else drain_vm();
+      // most of an item ago, and so was wave 0's counter increment: a full drain.  (vmcnt(n > 0) is NOT usable to
+      // wait for a load that has a store or a no-return atomic behind or in front of it: those retire out of order
+      // with respect to loads, so "at most n outstanding" does not say which ones.  An earlier version did, and read
+      // tiles that were not published yet -- a few elements per thousand steps off by 1e-3.)
+      drain_vm();
+      keep_until_here(hold[0]); keep_until_here(hold[1]); keep_until_here(hold[2]); keep_until_here(hold[3]);
       after_wait(pvv);
 #pragma unroll
       for (int ci = 0; ci < NCH; ++ci) after_wait(abuf[P][ci]);
@@ -214,9 +223,9 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 2 : 1)) void gru_pipe_fwd_kernel(c
       // (measured: 32 KB of fragments = ~2000 cycles, whatever the cache policy or locality), and a wave that issues
       // them back to back just stalls at issue for that long; fed a couple at a time between groups of MFMAs they
       // cost nothing.  Clamped addresses: past the end they re-read the last step, results unused.
+      f32x4 tv = f32x4{0.f, 0.f, 0.f, 0.f};
       if (wave == 0 && pub_ptr != nullptr) {
         const int r4 = lane >> 2, c4 = (lane & 3) * 4;
-        f32x4 tv;
         tv[0] = hs[r4 * TP + c4]; tv[1] = hs[r4 * TP + c4 + 1]; tv[2] = hs[r4 * TP + c4 + 2]; tv[3] = hs[r4 * TP + c4 + 3];
         if (pub_m0 + r4 < B) issue_store_sc1_x4(make_rsrc(out + (long long)pub_t * B * H),
                                                 (unsigned)(((long long)(pub_m0 + r4) * H + j0 + c4) * 4), tv);
@@ -258,20 +267,20 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 2 : 1)) void gru_pipe_fwd_kernel(c
         issue_load_f32(gbuf[P ^ 1][0], g3); issue_load_f32(gbuf[P ^ 1][1], g3 + H); issue_load_f32(gbuf[P ^ 1][2], g3 + 2 * H);
       }
       // the previous item's gate values (saved for the backward sweep; nothing in this sweep waits for them)
+      hold[0] = sv[0]; hold[1] = sv[1]; hold[2] = sv[2]; hold[3] = sv[3];   // untouched until the next drain, see (a)
       if (do_rsv) {
-        issue_store_f32(rsv, sv[0]); issue_store_f32(rsv + H, sv[1]); issue_store_f32(rsv + 2 * H, sv[2]);
-        issue_store_f32(rsv + 3 * H, sv[3]);
+        issue_store_f32(rsv, hold[0]); issue_store_f32(rsv + H, hold[1]); issue_store_f32(rsv + 2 * H, hold[2]);
+        issue_store_f32(rsv + 3 * H, hold[3]);
       }
       asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
       __builtin_amdgcn_sched_barrier(0);
       PSTAMP(3)   // MFMA
-      // (c2) late publish of the PREVIOUS item: its tile store went out a whole MFMA phase ago, in front of at least
-      // NCH + 3 younger operations of wave 0, so vmcnt(NCH + 3) proves the write-through acknowledged without waiting
-      // for the loads that were just issued.  Then the poll of the item
+      // (c2) late publish of the PREVIOUS item: its tile store went out a whole MFMA phase ago; a full drain proves the
+      // write-through acknowledged (the loads issued under the MFMAs are at least half a phase old).  Then the poll of the item
       // after next: counter (rg0 + r2, t2 - 1); not needed for t2 == 0, past the end, or row groups beyond the batch
       // (the load is still issued, branch-free, on a valid word).  The counter increment goes out behind the poll.
-      published = false;
-      if (wave == 0 && pub_ptr != nullptr) wait_vm<NCH + 3>();   // the tile store is older than the NCH + 3 loads above
+      if (wave == 0 && pub_ptr != nullptr) drain_vm();   // the tile store AND the loads issued under the MFMAs (see (a))
+      keep_until_here(tv);
       {
         pv_need = (t2 > 0) && (t2 < T) && (rg0 + r2 < nrg);
         const int tc = t2 > 0 ? (t2 < T ? t2 - 1 : T - 1) : 0;
@@ -281,7 +290,6 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 2 : 1)) void gru_pipe_fwd_kernel(c
       }
       if (wave == 0 && pub_ptr != nullptr) {
         if (lane == 0) __hip_atomic_fetch_add(pub_ptr, 1u, RLX_AGENT);
-        published = true;
       }
       float gh[3];
       cross_wave_reduce<3>(red, acc, gh, wave, lane);

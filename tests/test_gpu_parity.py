@@ -284,7 +284,7 @@ def test_edit_distance_random():
     np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("tag", ["h64", "h512", "patch"])
 def test_gru_sweep_modes(golden_dir, tag, mode):
     """Step-launch (0) and persistent (1) sweeps both reproduce the reference forward, and the persistent
@@ -312,7 +312,7 @@ def N_sync(T):
     return Nn.load().b2t_gru_sync_bytes(T) // 4 + 16
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_train_step_modes_vs_oracle(mode):
     """C2-shaped slice (H=512, L=2, B=40 = 2.5 row groups, T=60): loss + every gradient vs the oracle, both modes,
     run 3 times back-to-back so the persistent hand-off is exercised with warm caches."""
