@@ -132,6 +132,23 @@ int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, const float* re
                           int T, int B, int H, int mode, void* sync_ws, void* stream);
 int b2t_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 
+/* Persistent sweeps (mode 1) released sub-chunk by sub-chunk.  A launch of T steps is cut into sub-chunks of `sub`
+ * steps (forward: in time order; backward: counted from the END of the launch, the order the sweep visits them).
+ * The kernel enters sub-chunk k only once ready[k] >= epoch (the caller writes it with b2t_stream_write_value32 behind
+ * the GEMM that produced gi / dY of that sub-chunk) and stores done[k] = epoch once every workgroup has finished it
+ * (out / dG of the sub-chunk are then in memory; wait for it with b2t_stream_wait_value32_gte in front of the consuming
+ * GEMM).  ready / done: plain device words (NULL = no waiting / no signalling); epoch must grow from pass to pass. */
+int b2t_gru_layer_fwd_flagged_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init,
+                                  float* out, float* reserve, float* h_last, int T, int B, int H, void* sync_ws,
+                                  const uint32_t* ready, uint32_t* done, int sub, uint32_t epoch, void* stream);
+int b2t_gru_layer_bwd_flagged_f32(const float* dY, const float* dh_last, const float* reserve, const float* out,
+                                  const float* h_init, const float* w_hh_t, float* dG, float* dh_init,
+                                  int T, int B, int H, void* sync_ws,
+                                  const uint32_t* ready, uint32_t* done, int sub, uint32_t epoch, void* stream);
+/* Stream-ordered 32-bit word write / wait-until->= executed by the command processor (no kernel launch). */
+int b2t_stream_write_value32(void* ptr, uint32_t value, void* stream);
+int b2t_stream_wait_value32_gte(void* ptr, uint32_t value, void* stream);
+
 /* ---- a7: log-softmax + CTC loss (torch.nn.CTCLoss(blank=0,'none') at rnn_trainer.py:242,538-545)
  * logits [B][T][C] batch-first.  targets [B][S_max] int32 (0-padded), in_len/tgt_len [B] int32.
  * loss [B] = -log p(target | logits[:in_len]) (inf when infeasible; zero_infinity=False).

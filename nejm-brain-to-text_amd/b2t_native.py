@@ -62,6 +62,12 @@ _SIGNATURES = {
     "b2t_gru_layer_bwd_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int,
                                         VP, VP]),
     "b2t_transpose_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
+    "b2t_gru_layer_fwd_flagged_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP,
+                                                C.c_int, C.c_uint32, VP]),
+    "b2t_gru_layer_bwd_flagged_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP,
+                                                C.c_int, C.c_uint32, VP]),
+    "b2t_stream_write_value32": (C.c_int, [VP, C.c_uint32, VP]),
+    "b2t_stream_wait_value32_gte": (C.c_int, [VP, C.c_uint32, VP]),
     "b2t_ctc_loss_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, VP]),
     "b2t_opt_prepare": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),

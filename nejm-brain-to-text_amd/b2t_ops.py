@@ -219,7 +219,9 @@ MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its wor
 PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "6")), "min_chunk": 16,
             "sweep_streams": int(os.environ.get("B2T_SWEEP_STREAMS", "64")),
             "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "64")),
-            "sweep_priority": int(os.environ.get("B2T_SWEEP_PRIORITY", "0"))}
+            "sweep_priority": int(os.environ.get("B2T_SWEEP_PRIORITY", "0")),
+            # sub-chunk flags (SweepFlags, csrc/gru_sync.h): steps per sub-chunk, 0 = event-per-chunk hand-over
+            "sub": int(os.environ.get("B2T_SUB", "0"))}
 
 
 def bwd_mode_for(fwd_mode: int) -> int:
@@ -293,6 +295,23 @@ class Workspace:
 
     def sync_ws(self, l, Tp, device, B=64, H=512, tag=""):
         return self.get(f"gru_sync{tag}{l}", (N.load().b2t_gru_ws_bytes(Tp, B, H) // 4 + 16,), device, torch.int32)
+
+
+def sub_ranges(n: int, sub: int, from_end: bool = False) -> List[Tuple[int, int]]:
+    """Sub-chunks of a launch of n steps, in the order the sweep visits them: forward from step 0, backward from step
+    n-1 (the k-th range then is [n-(k+1)*sub, n-k*sub))."""
+    if from_end:
+        return [(max(0, n - (k + 1) * sub), n - k * sub) for k in range((n + sub - 1) // sub)]
+    return [(k * sub, min(n, (k + 1) * sub)) for k in range((n + sub - 1) // sub)]
+
+
+def stream_write_value(t: torch.Tensor, index: int, value: int):
+    N.check(N.load().b2t_stream_write_value32(C.c_void_p(t.data_ptr() + 4 * index), value, _stream()), "b2t_stream_write_value32")
+
+
+def stream_wait_value(t: torch.Tensor, index: int, value: int):
+    N.check(N.load().b2t_stream_wait_value32_gte(C.c_void_p(t.data_ptr() + 4 * index), value, _stream()),
+            "b2t_stream_wait_value32_gte")
 
 
 def time_chunks(Tp: int) -> List[Tuple[int, int]]:
@@ -373,9 +392,48 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     a_s0_l0 = dims.stride * F if dims.patch > 0 else F
     # cells (chunk c, layer l) are enqueued diagonal by diagonal (c + l), a topological order in which the two
     # sweep streams never wait on work that is queued behind them
+    # Sub-chunk flags: the consumer layer trails its producer by SUB steps instead of a whole chunk launch (the
+    # projection GEMM of a chunk no longer sits between two dependent sweeps).  Flag words only ever grow (epoch).
+    SUB = PIPELINE["sub"]
+    flagged = piped and SUB > 0 and mode == 1 and rnn_drop == 0
+    if flagged:
+        nsub_max = max((t1 - t0 + SUB - 1) // SUB for t0, t1 in chunks)
+        fflags = ws.get("fwd_flags", (2, L, len(chunks), nsub_max), dev, torch.int32)   # [ready|done][l][c][k]
+        ws.epoch = getattr(ws, "epoch", 0) + 1
+        epoch = ws.epoch
+        fidx = lambda kind, l, c, k: ((kind * L + l) * len(chunks) + c) * nsub_max + k
     for c, l in sorted(((c, l) for c in range(len(chunks)) for l in range(L)), key=lambda cl: (cl[0] + cl[1], cl[1])):
         t0, t1 = chunks[c]
         n = t1 - t0
+        if flagged:
+            sg, ss = s_gemm[l], s_sweep[l]
+            with torch.cuda.stream(sg):
+                for k, (s0, s1) in enumerate(sub_ranges(n, SUB)):
+                    if l == 0:
+                        gemm(Ud, prm.w_ih[0], gis[0], M=s1 - s0, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0_l0, a_sz=T * F,
+                             a_off=(t0 + s0) * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H,
+                             c_off=(t0 + s0) * B * 3 * H, bias=prm.b_ih[0])
+                    else:
+                        stream_wait_value(fflags, fidx(1, l - 1, c, k), epoch)
+                        gemm(outs[l - 1], prm.w_ih[l], gis[l], M=(s1 - s0) * B, N_=3 * H, K=H, a_kc=1, a_s0=H,
+                             a_off=(1 + t0 + s0) * B * H, b_kc=1, b_s0=H, c_s0=3 * H, c_off=(t0 + s0) * B * 3 * H,
+                             bias=prm.b_ih[l])
+                    stream_write_value(fflags, fidx(0, l, c, k), epoch)
+            with torch.cuda.stream(ss):
+                if l > 0:   # launch only once the producer sweep is up and running (residency: DESIGN.md 4b)
+                    stream_wait_value(fflags, fidx(1, l - 1, c, 0), epoch)
+                res_ptr = C.c_void_p(reserves[l].data_ptr() + 4 * t0 * B * 4 * H) if save else None
+                with _Prof("gru_sweep_fwd", 2.0 * n * B * 3 * H * H, 1):
+                    N.check(lib.b2t_gru_layer_fwd_flagged_f32(
+                        C.c_void_p(gis[l].data_ptr() + 4 * t0 * B * 3 * H), _p(prm.w_hh[l]), _p(prm.b_hh[l]),
+                        C.c_void_p(outs[l].data_ptr() + 4 * t0 * B * H),
+                        C.c_void_p(outs[l].data_ptr() + 4 * (1 + t0) * B * H), res_ptr,
+                        _p(hidden[l]) if t1 == Tp else None, n, B, H, _p(ws.sync_ws(l, Tp, dev, B, H)),
+                        C.c_void_p(fflags.data_ptr() + 4 * fidx(0, l, c, 0)),
+                        C.c_void_p(fflags.data_ptr() + 4 * fidx(1, l, c, 0)) if l < L - 1 else None,
+                        SUB, epoch, _stream()), "b2t_gru_layer_fwd_flagged_f32")
+                ev_sw[l][c] = _ev(ss)
+            continue
         if True:
             sg = s_gemm[l] if piped else main
             ss = s_sweep[l] if piped else main

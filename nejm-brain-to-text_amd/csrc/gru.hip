@@ -12,6 +12,7 @@
 //                         h_t is handed between workgroups with agent-scope flags.
 #include "common.h"
 #include "gru_cell.h"
+#include "gru_sync.h"
 
 namespace b2t {
 
@@ -134,7 +135,7 @@ extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const f
     int rc = gru_granule_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
     if (rc) return rc;
   } else if (mode == 1) {
-    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
+    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s);
     if (rc) return rc;
   } else {
     dim3 grid(H / 16, (B + 15) / 16), block(256);
@@ -165,7 +166,7 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
     if (rc != 4) return rc;   // 4: shape not covered -> mode 1
   }
   if (mode >= 1) {   // mode 2 (granule forward) pairs with the counter backward
-    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s);
+    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s);
   }
   dim3 grid(H / 16, (B + 15) / 16), block(256);
   for (int t = T - 1; t >= -1; --t)
@@ -173,4 +174,41 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
                        carry_ws, t, T, B, H);
   B2T_CHECK_LAUNCH("b2t_gru_layer_bwd_f32");
   return 0;
+}
+
+// ---- persistent sweeps released sub-chunk by sub-chunk (SweepFlags, gru_sync.h) ----------------------------------
+extern "C" int b2t_gru_layer_fwd_flagged_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init,
+                                             float* out, float* reserve, float* h_last, int T, int B, int H,
+                                             void* sync_ws, const uint32_t* ready, uint32_t* done, int sub, uint32_t epoch,
+                                             void* stream) {
+  B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_fwd_flagged: bad shape T=%d B=%d H=%d", T, B, H);
+  B2T_REQUIRE((!ready && !done) || sub > 0, "gru_layer_fwd_flagged: sub must be > 0 when flags are given");
+  hipStream_t s = as_stream(stream);
+  int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, SweepFlags{ready, done, sub, epoch}, s);
+  if (rc) return rc;
+  if (h_last)
+    return check_hip(hipMemcpyAsync(h_last, out + (long long)(T - 1) * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s),
+                     "gru_layer_fwd_flagged: h_last copy");
+  return 0;
+}
+
+extern "C" int b2t_gru_layer_bwd_flagged_f32(const float* dY, const float* dh_last, const float* reserve, const float* out,
+                                             const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T,
+                                             int B, int H, void* sync_ws, const uint32_t* ready, uint32_t* done, int sub,
+                                             uint32_t epoch, void* stream) {
+  B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_bwd_flagged: bad shape T=%d B=%d H=%d", T, B, H);
+  B2T_REQUIRE((!ready && !done) || sub > 0, "gru_layer_bwd_flagged: sub must be > 0 when flags are given");
+  return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws,
+                            SweepFlags{ready, done, sub, epoch}, as_stream(stream));
+}
+
+// Stream-ordered word operations executed by the command processor (no kernel): hipStreamWriteValue32 /
+// hipStreamWaitValue32 on ordinary device memory (measured: ~2 us from a kernel's store to the dependent launch).
+extern "C" int b2t_stream_write_value32(void* ptr, uint32_t value, void* stream) {
+  B2T_REQUIRE(ptr != nullptr, "stream_write_value32: null pointer");
+  return check_hip(hipStreamWriteValue32(as_stream(stream), ptr, value, 0), "hipStreamWriteValue32");
+}
+extern "C" int b2t_stream_wait_value32_gte(void* ptr, uint32_t value, void* stream) {
+  B2T_REQUIRE(ptr != nullptr, "stream_wait_value32_gte: null pointer");
+  return check_hip(hipStreamWaitValue32(as_stream(stream), ptr, value, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32");
 }

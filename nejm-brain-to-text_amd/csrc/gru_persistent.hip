@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
                                                                  float* __restrict__ reserve, int T, int B, int H,
-                                                                 unsigned* sync) {
+                                                                 unsigned* sync, SweepFlags fl) {
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TP];
   __shared__ __attribute__((aligned(16))) float stage[4][NCH * SLOT_F];   // per-wave operand staging (gru_sync.h)
   float* hs = red + 4 * 3 * 4 * 64;   // staged h tile [16 rows][TP]
@@ -79,12 +79,21 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
 #else
 #define TSTAMP(i)
 #endif
+  unsigned* tickets = sync + 32 + (size_t)pset * SETW + (size_t)gridDim.y * T * CSTRIDE;   // behind the step counters
   for (int t = 0; t < T; ++t) {
    {
+    // gi of sub-chunk k is written by a GEMM that may still be running when this kernel starts
+    if (fl.ready && t % fl.sub == 0) wait_flag(fl.ready + t / fl.sub, fl.epoch, err);
     float gir = 0.f, giz = 0.f, gin = 0.f;
     if (live) {
       const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit;
-      gir = g3[0]; giz = g3[H]; gin = g3[2 * H];
+      if (fl.ready) {   // produced while this kernel runs: read it coherently
+        gir = __hip_atomic_load(const_cast<float*>(g3), RLX_AGENT);
+        giz = __hip_atomic_load(const_cast<float*>(g3 + H), RLX_AGENT);
+        gin = __hip_atomic_load(const_cast<float*>(g3 + 2 * H), RLX_AGENT);
+      } else {
+        gir = g3[0]; giz = g3[H]; gin = g3[2 * H];
+      }
     }
     const float* hsrc = h_init;
     if (t > 0) {
@@ -147,7 +156,11 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
         store_f4<AUX>(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + j0 + c4) * 4),
                      *reinterpret_cast<const float4*>(&hs[r * TP + c4]));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
+      if (lane == 0) {
+        __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
+        if (fl.done && ((t + 1) % fl.sub == 0 || t == T - 1))
+          signal_done(tickets + t / fl.sub, fl.done + t / fl.sub, gridDim.x * gridDim.y, fl.epoch);
+      }
     }
     // The gate values saved for the backward sweep are nobody's dependency inside this sweep: store them AFTER the
     // publish so their write acknowledgements are not part of the drain in front of the counter increment.
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  const float* __restrict__ h_init,
                                                                  const float* __restrict__ w_hh_t, float* dG,
                                                                  float* __restrict__ dh_init, int T, int B, int H,
-                                                                 unsigned* sync) {
+                                                                 unsigned* sync, SweepFlags fl) {
   __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 + 4 * 16 * TP];
   constexpr int NSLOT = NCB < 8 ? NCB : 8;   // staging slots per wave, recycled every NSLOT instructions
   __shared__ __attribute__((aligned(16))) float stage[4][NSLOT * SLOT_F];
@@ -217,15 +230,20 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
   float dzterm = 0.f;
 
+  unsigned* tickets = sync + 32 + (size_t)pset * SETW + (size_t)gridDim.y * T * CSTRIDE;   // behind the step counters
   for (int t = T - 1; t >= -1; --t) {
    {
+    // sub-chunk k (counted from the END of the launch: the sweep runs backwards) of dY comes from a GEMM that may
+    // still be running when this kernel starts
+    if (fl.ready && t >= 0 && (T - 1 - t) % fl.sub == 0) wait_flag(fl.ready + (T - 1 - t) / fl.sub, fl.epoch, err);
     // operands of the elementwise part do not depend on the recurrence: fetch them first
     float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hprev = 0.f, dy = 0.f;
     if (live && t >= 0) {
       const float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
       r = rs[0]; z = rs[H]; n = rs[2 * H]; ghn = rs[3 * H];
       hprev = t > 0 ? out[((long long)(t - 1) * B + row) * H + unit] : h_init[(long long)row * H + unit];
-      dy = dY[((long long)t * B + row) * H + unit];
+      const float* dyp = dY + ((long long)t * B + row) * H + unit;
+      dy = fl.ready ? __hip_atomic_load(const_cast<float*>(dyp), RLX_AGENT) : dyp[0];
     }
     float carry = 0.f;
     if (t < T - 1) {
@@ -281,6 +299,8 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                      *reinterpret_cast<const float4*>(&gs[(wave * 16 + r2) * TP + c4]));
     }
     publish_count(cnt + (size_t)t * CSTRIDE);
+    if (fl.done && threadIdx.x == 0 && ((T - t) % fl.sub == 0 || t == 0))
+      signal_done(tickets + (T - 1 - t) / fl.sub, fl.done + (T - 1 - t) / fl.sub, gridDim.x * gridDim.y, fl.epoch);
    }
   }
   finish_call(sync, pset);
@@ -325,7 +345,7 @@ static unsigned exclusive_lds() {
 static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
   const int gx = H / 16, gy = (B + 15) / 16;
   if (!sync_ws) { set_error("%s: sync_ws is required in persistent mode", what); return 2; }
-  if ((long long)gy * T * CSTRIDE > SETW) {
+  if ((long long)gy * T * CSTRIDE + T > SETW) {   // step counters + (at most T) sub-chunk tickets
     set_error("%s: %d row groups x %d steps exceed the %d hand-off counters of one call", what, gy, T, SETW);
     return 2;
   }
@@ -339,7 +359,7 @@ static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
 }
 
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
-                       float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s) {
+                       float* reserve, int T, int B, int H, void* sync_ws, const SweepFlags& fl, hipStream_t s) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
   const dim3 grid(H / 16, (B + 15) / 16), block(256);
@@ -348,7 +368,7 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   do {                                                                                                                 \
     want_exclusive(gru_persist_fwd_kernel<NCH>);                                                                       \
     hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                       B, H, sync);                                                                                    \
+                       B, H, sync, fl);                                                                                \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
@@ -362,7 +382,7 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
 
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
-                       void* sync_ws, hipStream_t s) {
+                       void* sync_ws, const SweepFlags& fl, hipStream_t s) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
   const dim3 grid(H / 16, (B + 15) / 16), block(256);
@@ -371,7 +391,7 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   do {                                                                                                                \
     want_exclusive(gru_persist_bwd_kernel<NCB>);                                                                      \
     hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init,      \
-                       w_hh_t, dG, dh_init, T, B, H, sync);                                                           \
+                       w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                       \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);
   else if (H <= 256) B2T_LAUNCH_BWD(12);

@@ -352,3 +352,40 @@ def test_train_step_modes_vs_oracle(mode):
             ops.gru_sync_check_all(model._ws, L, T, B, dev, H)
     finally:
         ops.GRU_MODE["value"] = old
+
+
+def test_train_step_sub_chunk_flags():
+    """Opt-in hand-over of sub-chunks between running sweeps and the GEMM streams (PIPELINE['sub'] > 0: SweepFlags +
+    b2t_stream_write_value32 / b2t_stream_wait_value32_gte): same gradients as the event-per-chunk plan."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    F, H, D, C, L, B, T = 512, 512, 3, 41, 3, 48, 64
+    args = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=1000, lr_warmup_steps=10, lr_scheduler_type="cosine",
+                lr_max_day=0.005, lr_min_day=0.0001, lr_decay_steps_day=1000, lr_warmup_steps_day=10, beta0=0.9,
+                beta1=0.999, epsilon=0.1, weight_decay=0.001, weight_decay_day=0, grad_norm_clip_value=10,
+                _debug_keep_unclipped=True)
+    torch.manual_seed(11)
+    x = torch.randn(B, T, F, device=dev); day = torch.randint(0, D, (B,), device=dev, dtype=torch.int32)
+    tgt = torch.randint(1, C, (B, 9), device=dev, dtype=torch.int32)
+    nt = torch.full((B,), T, device=dev, dtype=torch.int32); tl = torch.full((B,), 9, device=dev, dtype=torch.int32)
+    old_sub, old_mode = ops.PIPELINE["sub"], ops.GRU_MODE["value"]
+    got = {}
+    try:
+        ops.GRU_MODE["value"] = 1
+        for sub in (0, 7):
+            ops.PIPELINE["sub"] = sub
+            torch.manual_seed(12)
+            model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
+            ts = TrainStep(model, dict(args))
+            for _ in range(3):
+                loss, _ = ts.step(x, day, tgt, nt, tl)
+            torch.cuda.synchronize()
+            model._ws.check_sync()
+            got[sub] = (float(loss), {k: v.copy() for k, v in ts.last_unclipped_grads().items()})
+    finally:
+        ops.PIPELINE["sub"], ops.GRU_MODE["value"] = old_sub, old_mode
+    np.testing.assert_allclose(got[7][0], got[0][0], rtol=1e-6)
+    for k, ref in got[0][1].items():
+        np.testing.assert_allclose(got[7][1][k], ref, atol=2e-5 * max(1e-6, float(np.abs(ref).max())), err_msg=k)

@@ -22,9 +22,13 @@ int main() {
   int can = 0; CK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
   printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
   unsigned *go, *prog;
-  CK(hipExtMallocWithFlags((void**)&go, 8, hipMallocSignalMemory));
-  CK(hipExtMallocWithFlags((void**)&prog, 8, hipMallocSignalMemory));
-  CK(hipMemset(go, 0, 8)); CK(hipMemset(prog, 0, 8));
+  // can signal memory be an array?  (one allocation, words 8 bytes apart)
+  unsigned long long* arr = nullptr;
+  hipError_t ea = hipExtMallocWithFlags((void**)&arr, 8 * 64, hipMallocSignalMemory);
+  printf("hipExtMallocWithFlags(512 B, hipMallocSignalMemory): %s\n", hipGetErrorString(ea));
+  if (ea != hipSuccess) { (void)hipGetLastError(); CK(hipMalloc((void**)&arr, 8 * 64)); printf("falling back to plain hipMalloc for the flag array\n"); }
+  CK(hipMemset(arr, 0, 8 * 64));
+  go = (unsigned*)(arr + 5); prog = (unsigned*)(arr + 9);
   const int n = 50;
   unsigned long long *ts, *tk; CK(hipMalloc(&ts, (n + 1) * 8)); CK(hipMalloc(&tk, (n + 1) * 8));
   hipStream_t s1, s2, s3; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s3, hipStreamNonBlocking));
