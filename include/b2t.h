@@ -215,6 +215,22 @@ int b2t_prefix_beam_search_f32(const float* logp, const int32_t* lens, int U, in
                                int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
                                void* stream);
 int b2t_beam_overflowed(const void* state, int U, int max_len, int max_nodes, int* flag_host, void* stream);
+/* The same search with a token-level back-off n-gram LM fused in (the "CTC prefix beam + n-gram" decode of
+ * BASELINE.json configs 4-5; the reference reaches its ARPA LMs through a word-level WFST,
+ * language_model/runtime/core/decoder/ctc_wfst_beam_search.cc, whose graphs are not in the checkout: pinned by
+ * oracle/b2t_oracle.py:prefix_beam_search_lm only).  The LM is an automaton in device memory built by
+ * nejm-brain-to-text_amd/ngram_lm.py from ARPA text: lm_child [n_nodes][lm_vocab] (-1 = absent), lm_logp / lm_bow
+ * [n_nodes] natural logs, lm_suffix / lm_nstate [n_nodes]; vocabulary = class ids 0..C-1, then <s>, </s>, <unk>.
+ * Every emitted token adds alpha * ln p(token | history) + beta; pruning and ranking use CTC score + LM score.
+ * lm_score [U][second_beam] receives the LM part (plus alpha * ln p(</s> | history) when lm_eos >= 0); `score`
+ * stays the CTC part.  Same state block, streaming and reset rules as b2t_prefix_beam_search_f32. */
+int b2t_prefix_beam_search_lm_f32(const float* logp, const int32_t* lens, int U, int T, int C, int first_beam,
+                                  int second_beam, int blank, void* state, int max_len, int max_nodes,
+                                  int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
+                                  const int32_t* lm_child, const float* lm_logp, const float* lm_bow,
+                                  const int32_t* lm_suffix, const int32_t* lm_nstate, int lm_vocab,
+                                  int lm_start_state, int lm_eos, float alpha, float beta, float unk_logp,
+                                  float* lm_score, void* stream);
 
 #ifdef __cplusplus
 }

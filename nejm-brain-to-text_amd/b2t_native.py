@@ -82,6 +82,9 @@ _SIGNATURES = {
     "b2t_prefix_beam_search_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int,
                                              C.c_int, VP, VP, VP, VP, VP, VP]),
     "b2t_beam_overflowed": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), VP]),
+    "b2t_prefix_beam_search_lm_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int,
+                                                C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int,
+                                                C.c_float, C.c_float, C.c_float, VP, VP]),
 }
 
 

@@ -12,6 +12,13 @@
 // the log-sum order is fixed and the result is deterministic.  Survivors are ranked by counting and written
 // in sorted order.  Viterbi token times are kept per prefix like the reference (times_s / times_ns).
 // State persists in HBM between calls: Search() can be fed frame by frame (streaming decode).
+//
+// Optional n-gram fusion (b2t_prefix_beam_search_lm_f32): a token-level back-off LM, resident in HBM as an automaton
+// (ngram_lm.py: dense child table per n-gram node, ln p, ln back-off, suffix link, next state), adds
+// alpha * ln p(token | history) + beta per emitted token.  The LM score and LM state depend on the prefix only, so they
+// are stored once per trie node; the second beam is pruned, and hypotheses are ranked, by CTC score + LM score.  The
+// reference reaches its LMs through a word-level WFST that cannot be built or pinned here: this part is
+// pinned by the oracle's restatement only.
 #include "common.h"
 
 namespace b2t {
@@ -28,13 +35,35 @@ __device__ __forceinline__ float log_add(float x, float y) {
   return logf(expf(x - m) + expf(y - m)) + m;
 }
 
+// Back-off automaton of the fused n-gram LM (all tables in HBM; child == nullptr: no LM).
+struct LmArgs {
+  const int* child; const float* logp; const float* bow; const int* suffix; const int* nstate;
+  int V, start, eos;
+  float alpha, beta, unk;
+};
+
+// ln p(w | state) and the state after emitting w: at most `order` dependent steps.
+__device__ __forceinline__ float lm_step(const LmArgs& lm, int state, int w, int* next) {
+  float acc = 0.f;
+  int s = state;
+  for (int it = 0; it < 16; ++it) {
+    const int c = lm.child[(long long)s * lm.V + w];
+    if (c >= 0) { *next = lm.nstate[c]; return acc + lm.logp[c]; }
+    if (s == 0) break;
+    acc += lm.bow[s];
+    s = lm.suffix[s];
+  }
+  *next = 0;
+  return acc + lm.unk;
+}
+
 // ---- state layout (ints unless noted), per utterance ------------------------------------------------
 //   hdr[8]: nb, abs_t, node_count, cur, overflow
-//   parent[NN] token[NN] depth[NN]  hkey[HT] (u64)  hval[HT]
+//   parent[NN] token[NN] depth[NN] lm[NN] (float) lmstate[NN]  hkey[HT] (u64)  hval[HT]
 //   hyp buffers x2: node[BMAX], fl[5][BMAX] (s, ns, v_s, v_ns, ctp), times_s[BMAX][L], times_ns[BMAX][L]
 struct BeamLayout {
   int NN, HT, L;
-  size_t o_parent, o_token, o_depth, o_hkey, o_hval, o_hyp, hyp_stride, total;
+  size_t o_parent, o_token, o_depth, o_nlm, o_nlst, o_hkey, o_hval, o_hyp, hyp_stride, total;
   __host__ __device__ BeamLayout(int nn, int l) {
     NN = nn; L = l;
     HT = 1; while (HT < 2 * nn) HT <<= 1;
@@ -42,6 +71,8 @@ struct BeamLayout {
     o_parent = o; o += (size_t)NN * 4;
     o_token = o; o += (size_t)NN * 4;
     o_depth = o; o += (size_t)NN * 4;
+    o_nlm = o; o += (size_t)NN * 4;     // LM score of the prefix (float)
+    o_nlst = o; o += (size_t)NN * 4;    // LM state of the prefix
     o = (o + 7) & ~(size_t)7;
     o_hkey = o; o += (size_t)HT * 8;
     o_hval = o; o += (size_t)HT * 4;
@@ -75,6 +106,8 @@ __global__ void beam_reset_kernel(unsigned char* state, size_t per_utt, int NN, 
     reinterpret_cast<int*>(st + lay.o_parent)[0] = -1;   // node 0 = empty prefix
     reinterpret_cast<int*>(st + lay.o_token)[0] = -1;
     reinterpret_cast<int*>(st + lay.o_depth)[0] = 0;
+    reinterpret_cast<float*>(st + lay.o_nlm)[0] = 0.f;
+    reinterpret_cast<int*>(st + lay.o_nlst)[0] = -1;   // LM state of the empty prefix: set by the first fused search
     HypBuf hb(st, lay, 0);
     hb.node[0] = 0;
     hb.fl[0 * BMAX] = 0.f;      // s
@@ -122,17 +155,23 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
                                                           unsigned char* state, size_t per_utt, int NN, int L,
                                                           int32_t* __restrict__ hyps, int32_t* __restrict__ hyp_len,
                                                           float* __restrict__ score, float* __restrict__ vscore,
-                                                          int32_t* __restrict__ times) {
+                                                          int32_t* __restrict__ times, LmArgs lm,
+                                                          float* __restrict__ lm_score) {
   const int u = blockIdx.x, tid = threadIdx.x;
+  const bool fused = lm.child != nullptr;
   BeamLayout lay(NN, L);
   unsigned char* st = state + (size_t)u * per_utt;
   int* hdr = reinterpret_cast<int*>(st);
   int* par = reinterpret_cast<int*>(st + lay.o_parent);
   int* tok = reinterpret_cast<int*>(st + lay.o_token);
   int* dep = reinterpret_cast<int*>(st + lay.o_depth);
+  float* nlm = reinterpret_cast<float*>(st + lay.o_nlm);
+  int* nlst = reinterpret_cast<int*>(st + lay.o_nlst);
   unsigned long long* hkey = reinterpret_cast<unsigned long long*>(st + lay.o_hkey);
   int* hval = reinterpret_cast<int*>(st + lay.o_hval);
 
+  __shared__ float h_lm[BMAX], c_lm[NCAND];
+  __shared__ int h_lst[BMAX], c_lst[NCAND];
   __shared__ int h_node[BMAX], h_par[BMAX], h_tok[BMAX], h_dep[BMAX];
   __shared__ float h_s[BMAX], h_ns[BMAX], h_vs[BMAX], h_vns[BMAX], h_ctp[BMAX], h_score[BMAX], h_vit[BMAX];
   __shared__ int tk_id[KMAX]; __shared__ float tk_p[KMAX];
@@ -142,12 +181,16 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   __shared__ TSrc c_ts[NCAND], c_tn[NCAND];
   __shared__ int s_nb, s_cur, s_abs;
 
-  if (tid == 0) { s_nb = hdr[0]; s_abs = hdr[1]; s_cur = hdr[3]; }
+  if (tid == 0) {
+    s_nb = hdr[0]; s_abs = hdr[1]; s_cur = hdr[3];
+    if (fused && nlst[0] < 0) nlst[0] = lm.start;   // first fused search after a reset
+  }
   __syncthreads();
   {
     HypBuf hb(st, lay, s_cur);
     if (tid < s_nb) {
       const int n = hb.node[tid];
+      h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0;
       h_node[tid] = n; h_par[tid] = par[n]; h_tok[tid] = tok[n]; h_dep[tid] = dep[n];
       h_s[tid] = hb.fl[0 * BMAX + tid]; h_ns[tid] = hb.fl[1 * BMAX + tid]; h_vs[tid] = hb.fl[2 * BMAX + tid];
       h_vns[tid] = hb.fl[3 * BMAX + tid]; h_ctp[tid] = hb.fl[4 * BMAX + tid];
@@ -189,6 +232,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       float ns_ = NEGMAX, s_ = NEGMAX, vs_ = NEGMAX, vns_ = NEGMAX, ctp_ = NEGMAX;
       TSrc ts{0, 0, 3}, tn{0, 0, 3};
       int valid = 0, node = -1, token = -1, pnode = -1;
+      float lmv = h_lm[h]; int lst = h_lst[h];     // a prefix that stays keeps its LM score and state
       const int hvec = h_vs[h] > h_vns[h] ? 0 : 1;     // which vector PrefixScore::times() returns
       if (slot == 0) {                                   // prefix h stays
         node = h_node[h];
@@ -241,12 +285,18 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
             ns_ = log_add(ns_, add);
             if (vns_ < vc) { vns_ = vc; ctp_ = p; tn = src; }
             valid = 1; pnode = h_node[h]; token = c;
+            if (fused) {   // LM score / state of the NEW prefix (a function of the prefix only)
+              int ns2;
+              lmv = h_lm[h] + lm.alpha * lm_step(lm, h_lst[h], c, &ns2) + lm.beta;
+              lst = ns2;
+            }
           }
         }
       }
       c_valid[ci] = valid; c_node[ci] = slot == 0 ? node : -1 - pnode; c_tok[ci] = token;
       c_s[ci] = s_; c_ns[ci] = ns_; c_vs[ci] = vs_; c_vns[ci] = vns_; c_ctp[ci] = ctp_;
-      c_sc[ci] = valid ? log_add(s_, ns_) : -INFINITY;
+      c_lm[ci] = lmv; c_lst[ci] = lst;
+      c_sc[ci] = valid ? log_add(s_, ns_) + (fused ? lmv : 0.f) : -INFINITY;
       c_ts[ci] = ts; c_tn[ci] = tn;
     }
     __syncthreads();
@@ -270,7 +320,10 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       const int r = c_rank[ci];
       if (r >= beam) continue;
       int node = c_node[ci];
-      if (node < 0) node = trie_find_or_add(-1 - node, c_tok[ci], par, tok, dep, hkey, hval, lay.HT, lay.NN, hdr);
+      if (node < 0) {
+        node = trie_find_or_add(-1 - node, c_tok[ci], par, tok, dep, hkey, hval, lay.HT, lay.NN, hdr);
+        if (fused) { nlm[node] = c_lm[ci]; nlst[node] = c_lst[ci]; }   // (re)written with the same values if it existed
+      }
       hn.node[r] = node;
       hn.fl[0 * BMAX + r] = c_s[ci]; hn.fl[1 * BMAX + r] = c_ns[ci]; hn.fl[2 * BMAX + r] = c_vs[ci];
       hn.fl[3 * BMAX + r] = c_vns[ci]; hn.fl[4 * BMAX + r] = c_ctp[ci];
@@ -299,6 +352,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       HypBuf hb(st, lay, s_cur);
       if (tid < s_nb) {
         const int n = hb.node[tid];
+        h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0;
         h_node[tid] = n; h_par[tid] = par[n]; h_tok[tid] = tok[n]; h_dep[tid] = dep[n];
         h_s[tid] = hb.fl[0 * BMAX + tid]; h_ns[tid] = hb.fl[1 * BMAX + tid]; h_vs[tid] = hb.fl[2 * BMAX + tid];
         h_vns[tid] = hb.fl[3 * BMAX + tid]; h_ctp[tid] = hb.fl[4 * BMAX + tid];
@@ -318,12 +372,18 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
         hyp_len[o] = n;
         score[o] = log_add(h_s[tid], h_ns[tid]);
         vscore[o] = h_vs[tid] > h_vns[tid] ? h_vs[tid] : h_vns[tid];
+        if (lm_score) {
+          float l = h_lm[tid];
+          if (fused && lm.eos >= 0) { int dummy; l += lm.alpha * lm_step(lm, h_lst[tid], lm.eos, &dummy); }
+          lm_score[o] = l;
+        }
         int node = h_node[tid];
         for (int i = n - 1; i >= 0; --i) { if (i < L) hyps[o * L + i] = tok[node]; node = par[node]; }
         const int* tv = (h_vs[tid] > h_vns[tid] ? hb.ts : hb.tns) + (size_t)tid * lay.L;
         if (times) for (int i = 0; i < n && i < L; ++i) times[o * L + i] = tv[i];
       } else {
         hyp_len[o] = -1; score[o] = NEGMAX; vscore[o] = NEGMAX;
+        if (lm_score) lm_score[o] = 0.f;
       }
     }
   }
@@ -358,8 +418,32 @@ extern "C" int b2t_prefix_beam_search_f32(const float* logp, const int32_t* lens
   BeamLayout lay(max_nodes, max_len);
   hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
-                     vscore, times);
+                     vscore, times, LmArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, 0.f, 0.f, 0.f},
+                     static_cast<float*>(nullptr));
   B2T_CHECK_LAUNCH("b2t_prefix_beam_search_f32");
+  return 0;
+}
+
+extern "C" int b2t_prefix_beam_search_lm_f32(const float* logp, const int32_t* lens, int U, int T, int C, int first_beam,
+                                             int second_beam, int blank, void* state, int max_len, int max_nodes,
+                                             int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
+                                             const int32_t* lm_child, const float* lm_logp, const float* lm_bow,
+                                             const int32_t* lm_suffix, const int32_t* lm_nstate, int lm_vocab,
+                                             int lm_start_state, int lm_eos, float alpha, float beta, float unk_logp,
+                                             float* lm_score, void* stream) {
+  B2T_REQUIRE(logp && state && U > 0 && T > 0 && C > 1 && C <= 64, "prefix_beam_search_lm: bad shape U=%d T=%d C=%d", U, T, C);
+  B2T_REQUIRE(first_beam >= 1 && second_beam >= 1 && second_beam <= BMAX, "prefix_beam_search_lm: beams out of range (<=%d)", BMAX);
+  B2T_REQUIRE(lm_child && lm_logp && lm_bow && lm_suffix && lm_nstate && lm_vocab >= C, "prefix_beam_search_lm: LM tables missing");
+  B2T_REQUIRE(lm_eos < lm_vocab && lm_start_state >= 0, "prefix_beam_search_lm: bad LM vocabulary / start state");
+  if (first_beam > C) first_beam = C;
+  B2T_REQUIRE(first_beam <= KMAX, "prefix_beam_search_lm: first_beam_size <= %d", KMAX);
+  BeamLayout lay(max_nodes, max_len);
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+                     blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
+                     vscore, times,
+                     LmArgs{lm_child, lm_logp, lm_bow, lm_suffix, lm_nstate, lm_vocab, lm_start_state, lm_eos, alpha, beta, unk_logp},
+                     lm_score);
+  B2T_CHECK_LAUNCH("b2t_prefix_beam_search_lm_f32");
   return 0;
 }
 

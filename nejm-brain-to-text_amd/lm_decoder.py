@@ -3,9 +3,12 @@
 
 Built so far: the DecodeNumpy prologue (log_softmax - priors, blank penalty) and the LM-free searcher the
 reference's BrainSpeechDecoder falls back to when no TLG graph is loaded (CtcPrefixBeamSearch,
-brain_speech_decoder.cc:23-28) — as a batched, streaming-capable GPU kernel (csrc/beam.hip).
-NOT built: WFST (TLG.fst) token passing, lattice n-best and LM rescoring: constructing a
-DecodeResource with an FST path raises NotImplementedError instead of silently decoding without a language model.
+brain_speech_decoder.cc:23-28) — as a batched, streaming-capable GPU kernel (csrc/beam.hip) — optionally fused with a
+token-level ARPA n-gram LM resident in HBM (ngram_lm.NGramLM; DecodeResource.set_token_lm, DecodeOptions.lm_alpha /
+lm_beta): every emitted token adds lm_alpha * ln p(token | history) + lm_beta, pruning and ranking use the sum.
+NOT built: WFST (TLG.fst) token passing over a word-level lexicon/LM graph, lattice n-best and LM rescoring
+(SURVEY §8 a15/a16): constructing a DecodeResource with an FST path raises NotImplementedError instead of silently
+decoding without that graph.
 """
 from __future__ import annotations
 
@@ -33,6 +36,7 @@ class DecodeOptions:
         self.acoustic_scale, self.ctc_blank_skip_threshold = acoustic_scale, ctc_blank_skip_threshold
         self.length_penalty, self.nbest = length_penalty, nbest
         self.first_beam_size, self.second_beam_size, self.blank = 10, 10, 0
+        self.lm_alpha, self.lm_beta, self.lm_eos = 0.0, 0.0, False   # token-level n-gram fusion (set_token_lm)
 
 
 class DecodeResource:
@@ -44,6 +48,11 @@ class DecodeResource:
                                       "pass empty FST paths to use the CTC prefix beam searcher")
         self.symbols = self._read_table(dict_path) if dict_path else None
         self.units = self._read_table(unit_path) if unit_path else None
+        self.token_lm = None
+
+    def set_token_lm(self, lm):
+        """Attach an ngram_lm.NGramLM over the decoder's output tokens (fused into the prefix beam search)."""
+        self.token_lm = lm
 
     @staticmethod
     def _read_table(path):
@@ -109,18 +118,32 @@ class BrainSpeechDecoder:
         sc = torch.empty((1, bm), dtype=torch.float32, device=self.device)
         vs = torch.empty((1, bm), dtype=torch.float32, device=self.device)
         tm = torch.zeros((1, bm, self.max_len), dtype=torch.int32, device=self.device)
+        lm = self.res.token_lm
+        lms = torch.zeros((1, bm), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            N.check(N.load().b2t_prefix_beam_search_f32(ops._p(lp), None, 1, T, Cc, self.opts.first_beam_size, bm,
-                                                        self.opts.blank, ops._p(self.state), self.max_len,
-                                                        self.max_nodes, ops._p(hyps), ops._p(hl), ops._p(sc), ops._p(vs),
-                                                        ops._p(tm), ops._stream()), "b2t_prefix_beam_search_f32")
+            if lm is None:
+                N.check(N.load().b2t_prefix_beam_search_f32(ops._p(lp), None, 1, T, Cc, self.opts.first_beam_size, bm,
+                                                            self.opts.blank, ops._p(self.state), self.max_len,
+                                                            self.max_nodes, ops._p(hyps), ops._p(hl), ops._p(sc), ops._p(vs),
+                                                            ops._p(tm), ops._stream()), "b2t_prefix_beam_search_f32")
+            else:
+                if lm.C != Cc:
+                    raise ValueError(f"the token LM was built for {lm.C} classes, the log-probabilities have {Cc}")
+                d = lm.to_device(self.device)
+                N.check(N.load().b2t_prefix_beam_search_lm_f32(
+                    ops._p(lp), None, 1, T, Cc, self.opts.first_beam_size, bm, self.opts.blank, ops._p(self.state),
+                    self.max_len, self.max_nodes, ops._p(hyps), ops._p(hl), ops._p(sc), ops._p(vs), ops._p(tm),
+                    ops._p(d["child"]), ops._p(d["logp"]), ops._p(d["bow"]), ops._p(d["suffix"]), ops._p(d["nstate"]), lm.V,
+                    lm.start_state, lm.eos if self.opts.lm_eos else -1, float(self.opts.lm_alpha), float(self.opts.lm_beta),
+                    float(lm.unk_logp), ops._p(lms), ops._stream()), "b2t_prefix_beam_search_lm_f32")
         self._out = (hyps.cpu().numpy()[0], hl.cpu().numpy()[0], sc.cpu().numpy()[0], vs.cpu().numpy()[0],
-                     tm.cpu().numpy()[0])
+                     tm.cpu().numpy()[0], lms.cpu().numpy()[0])
         self._update_result()
 
     def _update_result(self):
-        hyps, hl, sc, vs, tm = self._out
+        hyps, hl, sc, vs, tm, lms = self._out
         table = self.res.symbols or self.res.units
+        fused = self.res.token_lm is not None
         self._result = []
         for i in range(len(hl)):
             if hl[i] < 0:
@@ -128,9 +151,12 @@ class BrainSpeechDecoder:
             ids = hyps[i, :hl[i]]
             words = [table.get(int(t), str(int(t))) if table else str(int(t)) for t in ids]
             r = DecodeResult(process_blank("".join(" " + w for w in words)), float(sc[i]) / self.acoustic_scale,
-                             float(sc[i]))
+                             float(lms[i]) if fused else float(sc[i]))
             r.tokens, r.times, r.viterbi_score = ids.copy(), tm[i, :hl[i]].copy(), float(vs[i])
+            r.total_score = float(sc[i]) + (float(lms[i]) if fused else 0.0)
             self._result.append(r)
+        if fused:   # the end-of-sentence term (lm_eos) can reorder the final list
+            self._result.sort(key=lambda r: -r.total_score)
 
     def FinishDecoding(self):
         pass   # CtcPrefixBeamSearch::FinalizeSearch is a no-op (ctc_prefix_beam_search.h)

@@ -111,3 +111,104 @@ def test_lm_decoder_surface_and_prologue():
         lm_decoder.DecodeResource("TLG.fst", "", "", "words.txt", "")
     with pytest.raises(NotImplementedError):
         dec.Rescore()
+
+
+# ---- n-gram fusion (b2t_prefix_beam_search_lm_f32) ---------------------------------------------------------------
+WORDS41 = [None] + [f"p{i}" for i in range(1, 41)]
+
+
+def _search_lm(logp, lm, alpha, beta, first, second, chunks=None, eos=False):
+    import ctypes as C
+    import b2t_native as N
+    import b2t_ops as ops
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    U, T, Cc = logp.shape
+    L, NN = T + 1, T * second + 2
+    state = torch.empty((lib.b2t_beam_state_bytes(L, NN) * U,), dtype=torch.uint8, device=dev)
+    N.check(lib.b2t_beam_reset(ops._p(state), U, L, NN, ops._stream()), "reset")
+    hyps = torch.zeros((U, second, L), dtype=torch.int32, device=dev)
+    hl = torch.empty((U, second), dtype=torch.int32, device=dev)
+    sc = torch.empty((U, second), device=dev); vs = torch.empty((U, second), device=dev); lms = torch.empty((U, second), device=dev)
+    tm = torch.zeros((U, second, L), dtype=torch.int32, device=dev)
+    d = lm.to_device(dev)
+    for a, b in (chunks or [(0, T)]):
+        lp = torch.from_numpy(np.ascontiguousarray(logp[:, a:b])).to(dev)
+        N.check(lib.b2t_prefix_beam_search_lm_f32(
+            ops._p(lp), None, U, b - a, Cc, first, second, 0, ops._p(state), L, NN, ops._p(hyps), ops._p(hl), ops._p(sc),
+            ops._p(vs), ops._p(tm), ops._p(d["child"]), ops._p(d["logp"]), ops._p(d["bow"]), ops._p(d["suffix"]),
+            ops._p(d["nstate"]), lm.V, lm.start_state, lm.eos if eos else -1, float(alpha), float(beta), float(lm.unk_logp),
+            ops._p(lms), ops._stream()), "search_lm")
+    flag = C.c_int(0)
+    N.check(lib.b2t_beam_overflowed(ops._p(state), U, L, NN, C.byref(flag), ops._stream()), "ovf")
+    assert flag.value == 0
+    return hyps.cpu().numpy(), hl.cpu().numpy(), sc.cpu().numpy(), lms.cpu().numpy()
+
+
+@pytest.mark.parametrize("order,first,second", [(2, 10, 10), (3, 10, 10), (5, 8, 16)])
+def test_prefix_beam_lm_vs_oracle(order, first, second):
+    import ngram_lm
+    text = ngram_lm.synthetic_arpa(WORDS41, order, 400, seed=order)
+    lm = ngram_lm.NGramLM.from_arpa(text, WORDS41)
+    o, tab = O.parse_arpa(text)
+    rng = np.random.default_rng(order)
+    U, T, C = 5, 50, 41
+    logits = rng.standard_normal((U, T, C)).astype(np.float32) * 2.5
+    logits[..., 0] += 1.0
+    logp = O.log_softmax(logits)
+    alpha, beta = 0.7, 0.3
+    hyps, hl, sc, lms = _search_lm(logp, lm, alpha, beta, first, second)
+    for u in range(U):
+        ref = O.prefix_beam_search_lm(logp[u], o, tab, WORDS41, alpha, beta, first, second)
+        got = [(tuple(hyps[u, i, :hl[u, i]]), sc[u, i], lms[u, i]) for i in range(second) if hl[u, i] >= 0]
+        # compare as sets over the hypotheses whose total score is clear of the pruning boundary (fp32 vs fp64 ties)
+        assert got[0][0] == ref[0][0]
+        refd = {p: (a, l) for p, a, l, _ in ref}
+        hits = 0
+        for p, a, l in got:
+            if p in refd:
+                hits += 1
+                np.testing.assert_allclose(a, refd[p][0], rtol=2e-4, atol=2e-4)
+                np.testing.assert_allclose(l, refd[p][1], rtol=2e-4, atol=2e-4)
+        assert hits >= len(ref) - 2
+
+
+def test_prefix_beam_lm_streaming_equals_offline_and_eos():
+    import ngram_lm
+    text = ngram_lm.synthetic_arpa(WORDS41, 3, 300, seed=9)
+    lm = ngram_lm.NGramLM.from_arpa(text, WORDS41)
+    rng = np.random.default_rng(4)
+    logp = O.log_softmax((rng.standard_normal((3, 48, 41)) * 2.0).astype(np.float32))
+    a = _search_lm(logp, lm, 0.5, 0.1, 10, 10)
+    b = _search_lm(logp, lm, 0.5, 0.1, 10, 10, chunks=[(0, 7), (7, 8), (8, 30), (30, 48)])
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    c = _search_lm(logp, lm, 0.5, 0.1, 10, 10, eos=True)
+    for u in range(3):
+        for i in range(10):
+            if c[1][u, i] < 0:
+                continue
+            ids = c[0][u, i, :c[1][u, i]]
+            np.testing.assert_allclose(c[3][u, i], 0.5 * lm.sentence_logp(ids, bos=True, eos=True) + 0.1 * len(ids), rtol=1e-4, atol=1e-4)
+
+
+def test_lm_decoder_with_token_lm():
+    import lm_decoder
+    import ngram_lm
+    text = ngram_lm.synthetic_arpa(WORDS41, 3, 300, seed=2)
+    lm = ngram_lm.NGramLM.from_arpa(text, WORDS41)
+    o, tab = O.parse_arpa(text)
+    res = lm_decoder.DecodeResource("", "", "", "", "")
+    res.set_token_lm(lm)
+    opts = lm_decoder.DecodeOptions(7000, 200, 17.0, 8.0, 0.5, 1.0, 0.0, 10)
+    opts.lm_alpha, opts.lm_beta = 0.8, 0.2
+    dec = lm_decoder.BrainSpeechDecoder(res, opts)
+    rng = np.random.default_rng(8)
+    logp = O.log_softmax((rng.standard_normal((40, 41)) * 2.0).astype(np.float32))
+    lm_decoder.DecodeNumpyLogProbs(dec, logp)
+    dec.FinishDecoding()
+    ref = O.prefix_beam_search_lm(logp, o, tab, WORDS41, 0.8, 0.2, 10, 10)
+    best = dec.result()[0]
+    assert tuple(best.tokens) == ref[0][0]
+    assert best.lm_score == pytest.approx(ref[0][2], rel=2e-4, abs=2e-4)
+    assert best.ac_score == pytest.approx(ref[0][1] / dec.acoustic_scale, rel=2e-4, abs=2e-4)
