@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   __shared__ float c_s[NCAND], c_ns[NCAND], c_vs[NCAND], c_vns[NCAND], c_ctp[NCAND], c_sc[NCAND];
   __shared__ TSrc c_ts[NCAND], c_tn[NCAND];
   __shared__ int s_nb, s_cur, s_abs;
+  __shared__ int s_rk2ci[BMAX];
 
   if (tid == 0) {
     s_nb = hdr[0]; s_abs = hdr[1]; s_cur = hdr[3];
@@ -316,6 +317,8 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
 
     // ---- 4. write survivors (sorted) into the other hypothesis buffer ------------------------------------
     HypBuf hc(st, lay, cur), hn(st, lay, cur ^ 1);
+    if (tid < BMAX) s_rk2ci[tid] = -1;
+    __syncthreads();
     for (int ci = tid; ci < ncand; ci += blockDim.x) {
       const int r = c_rank[ci];
       if (r >= beam) continue;
@@ -327,16 +330,26 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       hn.node[r] = node;
       hn.fl[0 * BMAX + r] = c_s[ci]; hn.fl[1 * BMAX + r] = c_ns[ci]; hn.fl[2 * BMAX + r] = c_vs[ci];
       hn.fl[3 * BMAX + r] = c_vns[ci]; hn.fl[4 * BMAX + r] = c_ctp[ci];
-      // token-time vectors
-      for (int which = 0; which < 2; ++which) {
+      s_rk2ci[r] = ci;
+    }
+    __syncthreads();
+    // token-time vectors of the survivors: all threads share the copies (one element each) -- a survivor copying its
+    // own two vectors serially was ~80 % of a frame's time (2 x depth dependent HBM round trips)
+    {
+      const int nsurv = min(beam, ncand);
+      const int Lc = min(lay.L, at + 2);   // a prefix is never longer than the number of frames seen
+      for (int idx = tid; idx < nsurv * 2 * Lc; idx += blockDim.x) {
+        const int i = idx % Lc, which = (idx / Lc) & 1, r = idx / (2 * Lc);
+        const int ci = s_rk2ci[r];
+        if (ci < 0) continue;
         const TSrc src = which == 0 ? c_ts[ci] : c_tn[ci];
-        int* dst = (which == 0 ? hn.ts : hn.tns) + (size_t)r * lay.L;
         if (src.op == 3) continue;
-        const int* sv = (src.vec == 0 ? hc.ts : hc.tns) + (size_t)src.h * lay.L;
         const int n = h_dep[src.h];
-        for (int i = 0; i < n && i < lay.L; ++i) dst[i] = sv[i];
-        if (src.op == 1 && n < lay.L) dst[n] = at;
-        if (src.op == 2 && n > 0) dst[n - 1] = at;
+        int* dst = (which == 0 ? hn.ts : hn.tns) + (size_t)r * lay.L;
+        const int* sv = (src.vec == 0 ? hc.ts : hc.tns) + (size_t)src.h * lay.L;
+        if (src.op == 1 && i == n) dst[i] = at;
+        else if (src.op == 2 && i == n - 1) dst[i] = at;
+        else if (i < n) dst[i] = sv[i];
       }
     }
     __syncthreads();
