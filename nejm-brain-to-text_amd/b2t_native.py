@@ -105,6 +105,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is the only compute path of this package "
             f"(no CPU fallback). Build it with `python __graft_entry__.py`.")
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE this library is
+    # loaded, so that both bind to the same runtime instance: loading ours first pulls in /opt/rocm's copy, and the
+    # device pointers torch hands us then belong to a different runtime ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name in header_symbols():
         if not hasattr(lib, name):
