@@ -389,3 +389,36 @@ def test_train_step_sub_chunk_flags():
     np.testing.assert_allclose(got[7][0], got[0][0], rtol=1e-6)
     for k, ref in got[0][1].items():
         np.testing.assert_allclose(got[7][1][k], ref, atol=2e-5 * max(1e-6, float(np.abs(ref).max())), err_msg=k)
+
+
+@pytest.mark.parametrize("B,H,T", [(5, 48, 9), (17, 80, 13), (33, 272, 11), (64, 512, 24), (70, 768, 7)])
+def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T):
+    """Persistent sweeps (line-wise operand loads + LDS transpose, clamped rows / columns) against the step-launch
+    kernels on shapes that are not multiples of the tile sizes: forward out / reserve, backward dG / dh0."""
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev(); p = ops._p
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    rnd = lambda *s: (torch.randn(*s, generator=g)).to(dev)
+    gi, w, b_, h0 = rnd(T, B, 3 * H) * 0.5, rnd(3 * H, H) * (1.0 / H ** 0.5), rnd(3 * H) * 0.1, rnd(B, H) * 0.3
+    dY, dhl = rnd(T, B, H) * 0.05, rnd(B, H) * 0.05
+    wt = w.t().contiguous()
+
+    def run(mode):
+        out = torch.zeros(T + 1, B, H, device=dev); out[0] = h0
+        res = torch.zeros(T, B, 4 * H, device=dev)
+        sync = torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev)
+        Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out[0]), p(out[1:]), p(res), None, T, B, H, mode, p(sync),
+                                           ops._stream()), "fwd")
+        dG = torch.zeros(T, B, 4 * H, device=dev); dh = torch.zeros(B, H, device=dev); sc = torch.empty(B, H, device=dev)
+        Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(res), p(out[1:]), p(out[0]), p(wt), p(dG), p(dh), p(sc), T, B, H,
+                                           mode, p(sync), ops._stream()), "bwd")
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0
+        return out, res, dG, dh
+
+    ref = run(0)
+    for rep in range(3):
+        got = run(1)
+        for a, r, name in zip(got, ref, ("out", "reserve", "dG", "dh0")):
+            np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=3e-6 * max(1.0, float(r.abs().max())), err_msg=name)
