@@ -232,6 +232,34 @@ int b2t_prefix_beam_search_lm_f32(const float* logp, const int32_t* lens, int U,
                                   int lm_start_state, int lm_eos, float alpha, float beta, float unk_logp,
                                   float* lm_score, void* stream);
 
+/* Word-level variant: the search is constrained by a pronunciation lexicon (trie over the classes; words are
+ * delimited by the SIL class, evaluate_model_helpers.py:79-83 class 1) and a WORD n-gram is fused in: closing a word
+ * with SIL (or the end of the utterance) adds alpha * ln p(word | word history) + beta, homophones resolve to the
+ * word the LM prefers.  Stands in for the TLG graph search of the reference (ctc_wfst_beam_search.cc:70-160 over
+ * T o L o G built by tools/fst/make_tlg.sh:29-46) -- without its graph optimisations and optional-silence arcs, and
+ * pinned by the oracle only (oracle/b2t_oracle.py:prefix_beam_search_lexicon).  Tables: ngram_lm.Lexicon /
+ * ngram_lm.SparseNGramLM (sorted child arrays, bisection).  lm_score is -inf for hypotheses ending inside a word. */
+typedef struct {
+  const int32_t* lex_child;   /* [n_lex_nodes][C], -1 = no edge */
+  const int32_t* lex_wbeg;    /* [n_lex_nodes] */
+  const int32_t* lex_wend;    /* [n_lex_nodes]: words ending at the node = wlist[wbeg..wend) */
+  const int32_t* wlist;
+  const int32_t* lm_cb;       /* [n_lm_nodes] children of LM node n: (lm_ctok, lm_cnode)[cb..ce), sorted by word id */
+  const int32_t* lm_ce;
+  const int32_t* lm_ctok;
+  const int32_t* lm_cnode;
+  const float* lm_logp;       /* [n_lm_nodes] natural logs */
+  const float* lm_bow;
+  const int32_t* lm_suffix;
+  const int32_t* lm_nstate;
+  int32_t lm_start_state, lm_eos /* word id of </s>, or -1 */, sil;
+  float alpha, beta, unk_logp;
+} b2t_lexlm_t;
+int b2t_prefix_beam_search_lex_f32(const float* logp, const int32_t* lens, int U, int T, int C, int first_beam,
+                                   int second_beam, int blank, void* state, int max_len, int max_nodes,
+                                   int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
+                                   const b2t_lexlm_t* d, float* lm_score, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

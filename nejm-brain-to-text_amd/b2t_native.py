@@ -42,6 +42,14 @@ class GemmDesc(C.Structure):
     ]
 
 
+class LexLmDesc(C.Structure):
+    """Mirror of b2t_lexlm_t (include/b2t.h)."""
+    _fields_ = [(n, VP) for n in ("lex_child", "lex_wbeg", "lex_wend", "wlist", "lm_cb", "lm_ce", "lm_ctok", "lm_cnode",
+                                  "lm_logp", "lm_bow", "lm_suffix", "lm_nstate")] + \
+               [("lm_start_state", C.c_int32), ("lm_eos", C.c_int32), ("sil", C.c_int32),
+                ("alpha", C.c_float), ("beta", C.c_float), ("unk_logp", C.c_float)]
+
+
 _SIGNATURES = {
     "b2t_version": (C.c_int, []),
     "b2t_last_error": (C.c_char_p, []),
@@ -82,6 +90,8 @@ _SIGNATURES = {
     "b2t_prefix_beam_search_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int,
                                              C.c_int, VP, VP, VP, VP, VP, VP]),
     "b2t_beam_overflowed": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), VP]),
+    "b2t_prefix_beam_search_lex_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int,
+                                                 C.c_int, VP, VP, VP, VP, VP, VP, VP, VP]),
     "b2t_prefix_beam_search_lm_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_int,
                                                 C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int,
                                                 C.c_float, C.c_float, C.c_float, VP, VP]),

@@ -40,7 +40,43 @@ struct LmArgs {
   const int* child; const float* logp; const float* bow; const int* suffix; const int* nstate;
   int V, start, eos;
   float alpha, beta, unk;
+  // word-level mode (lex_child != nullptr): pronunciation trie + sparse children of the word LM; `child` is unused
+  const int* lex_child; const int* lex_wbeg; const int* lex_wend; const int* wlist;
+  const int* cb; const int* ce; const int* ctok; const int* cnode;
+  int sil;
 };
+
+// the same with sorted child arrays (large vocabularies): bisection in ctok[cb[s] .. ce[s])
+__device__ __forceinline__ float lm_step_sparse(const LmArgs& lm, int state, int w, int* next) {
+  float acc = 0.f;
+  int s = state;
+  for (int it = 0; it < 16; ++it) {
+    int lo = lm.cb[s], hi = lm.ce[s];
+    const int end = hi;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (lm.ctok[mid] < w) lo = mid + 1; else hi = mid;
+    }
+    if (lo < end && lm.ctok[lo] == w) { const int c = lm.cnode[lo]; *next = lm.nstate[c]; return acc + lm.logp[c]; }
+    if (s == 0) break;
+    acc += lm.bow[s];
+    s = lm.suffix[s];
+  }
+  *next = 0;
+  return acc + lm.unk;
+}
+
+// Word emission at lexicon node lx (a word end): the homophone the LM likes best (ties -> lowest word id).
+__device__ __forceinline__ float emit_word(const LmArgs& lm, int lx, int state, int* next) {
+  float best = -INFINITY; int bn = 0;
+  for (int k = lm.lex_wbeg[lx]; k < lm.lex_wend[lx]; ++k) {
+    int ns;
+    const float lp = lm_step_sparse(lm, state, lm.wlist[k], &ns);
+    if (lp > best) { best = lp; bn = ns; }
+  }
+  *next = bn;
+  return best;
+}
 
 // ln p(w | state) and the state after emitting w: at most `order` dependent steps.
 __device__ __forceinline__ float lm_step(const LmArgs& lm, int state, int w, int* next) {
@@ -63,7 +99,7 @@ __device__ __forceinline__ float lm_step(const LmArgs& lm, int state, int w, int
 //   hyp buffers x2: node[BMAX], fl[5][BMAX] (s, ns, v_s, v_ns, ctp), times_s[BMAX][L], times_ns[BMAX][L]
 struct BeamLayout {
   int NN, HT, L;
-  size_t o_parent, o_token, o_depth, o_nlm, o_nlst, o_hkey, o_hval, o_hyp, hyp_stride, total;
+  size_t o_parent, o_token, o_depth, o_nlm, o_nlst, o_nlx, o_hkey, o_hval, o_hyp, hyp_stride, total;
   __host__ __device__ BeamLayout(int nn, int l) {
     NN = nn; L = l;
     HT = 1; while (HT < 2 * nn) HT <<= 1;
@@ -73,6 +109,7 @@ struct BeamLayout {
     o_depth = o; o += (size_t)NN * 4;
     o_nlm = o; o += (size_t)NN * 4;     // LM score of the prefix (float)
     o_nlst = o; o += (size_t)NN * 4;    // LM state of the prefix
+    o_nlx = o; o += (size_t)NN * 4;     // lexicon-trie node of the prefix (word-level mode)
     o = (o + 7) & ~(size_t)7;
     o_hkey = o; o += (size_t)HT * 8;
     o_hval = o; o += (size_t)HT * 4;
@@ -108,6 +145,7 @@ __global__ void beam_reset_kernel(unsigned char* state, size_t per_utt, int NN, 
     reinterpret_cast<int*>(st + lay.o_depth)[0] = 0;
     reinterpret_cast<float*>(st + lay.o_nlm)[0] = 0.f;
     reinterpret_cast<int*>(st + lay.o_nlst)[0] = -1;   // LM state of the empty prefix: set by the first fused search
+    reinterpret_cast<int*>(st + lay.o_nlx)[0] = 0;
     HypBuf hb(st, lay, 0);
     hb.node[0] = 0;
     hb.fl[0 * BMAX] = 0.f;      // s
@@ -158,7 +196,8 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
                                                           int32_t* __restrict__ times, LmArgs lm,
                                                           float* __restrict__ lm_score) {
   const int u = blockIdx.x, tid = threadIdx.x;
-  const bool fused = lm.child != nullptr;
+  const bool lexm = lm.lex_child != nullptr;
+  const bool fused = lm.child != nullptr || lexm;
   BeamLayout lay(NN, L);
   unsigned char* st = state + (size_t)u * per_utt;
   int* hdr = reinterpret_cast<int*>(st);
@@ -167,11 +206,12 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   int* dep = reinterpret_cast<int*>(st + lay.o_depth);
   float* nlm = reinterpret_cast<float*>(st + lay.o_nlm);
   int* nlst = reinterpret_cast<int*>(st + lay.o_nlst);
+  int* nlx = reinterpret_cast<int*>(st + lay.o_nlx);
   unsigned long long* hkey = reinterpret_cast<unsigned long long*>(st + lay.o_hkey);
   int* hval = reinterpret_cast<int*>(st + lay.o_hval);
 
   __shared__ float h_lm[BMAX], c_lm[NCAND];
-  __shared__ int h_lst[BMAX], c_lst[NCAND];
+  __shared__ int h_lst[BMAX], c_lst[NCAND], h_lx[BMAX], c_lx[NCAND];
   __shared__ int h_node[BMAX], h_par[BMAX], h_tok[BMAX], h_dep[BMAX];
   __shared__ float h_s[BMAX], h_ns[BMAX], h_vs[BMAX], h_vns[BMAX], h_ctp[BMAX], h_score[BMAX], h_vit[BMAX];
   __shared__ int tk_id[KMAX]; __shared__ float tk_p[KMAX];
@@ -191,7 +231,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
     HypBuf hb(st, lay, s_cur);
     if (tid < s_nb) {
       const int n = hb.node[tid];
-      h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0;
+      h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0; h_lx[tid] = lexm ? nlx[n] : 0;
       h_node[tid] = n; h_par[tid] = par[n]; h_tok[tid] = tok[n]; h_dep[tid] = dep[n];
       h_s[tid] = hb.fl[0 * BMAX + tid]; h_ns[tid] = hb.fl[1 * BMAX + tid]; h_vs[tid] = hb.fl[2 * BMAX + tid];
       h_vns[tid] = hb.fl[3 * BMAX + tid]; h_ctp[tid] = hb.fl[4 * BMAX + tid];
@@ -233,7 +273,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       float ns_ = NEGMAX, s_ = NEGMAX, vs_ = NEGMAX, vns_ = NEGMAX, ctp_ = NEGMAX;
       TSrc ts{0, 0, 3}, tn{0, 0, 3};
       int valid = 0, node = -1, token = -1, pnode = -1;
-      float lmv = h_lm[h]; int lst = h_lst[h];     // a prefix that stays keeps its LM score and state
+      float lmv = h_lm[h]; int lst = h_lst[h], lxv = h_lx[h];   // a prefix that stays keeps its LM score and states
       const int hvec = h_vs[h] > h_vns[h] ? 0 : 1;     // which vector PrefixScore::times() returns
       if (slot == 0) {                                   // prefix h stays
         node = h_node[h];
@@ -279,14 +319,34 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
         if (c != blank) {
           bool merged = false;                           // already a live prefix: gathered by its "stay" slot
           for (int x = 0; x < nb; ++x) merged |= (h_par[x] == h_node[h] && h_tok[x] == c && h_dep[x] > 0);
-          if (!merged) {
+          // word-level mode: the extension must follow the pronunciation trie; SIL closes a word (or is free at the root)
+          bool ok = true;
+          if (lexm && !merged) {
+            const int lx = h_lx[h];
+            if (c == lm.sil) {
+              if (lx != 0) {
+                if (lm.lex_wend[lx] > lm.lex_wbeg[lx]) {
+                  int ns2;
+                  lmv = h_lm[h] + lm.alpha * emit_word(lm, lx, h_lst[h], &ns2) + lm.beta;
+                  lst = ns2;
+                } else {
+                  ok = false;
+                }
+              }
+              lxv = 0;
+            } else {
+              lxv = lm.lex_child[(long long)lx * C + c];
+              ok = lxv >= 0;
+            }
+          }
+          if (!merged && ok) {
             float add, vc; TSrc src;
             if (h_dep[h] > 0 && c == h_tok[h]) { add = h_s[h] + p; vc = h_vs[h] + p; src = TSrc{(short)h, 0, 1}; }
             else { add = h_score[h] + p; vc = h_vit[h] + p; src = TSrc{(short)h, (char)hvec, 1}; }
             ns_ = log_add(ns_, add);
             if (vns_ < vc) { vns_ = vc; ctp_ = p; tn = src; }
             valid = 1; pnode = h_node[h]; token = c;
-            if (fused) {   // LM score / state of the NEW prefix (a function of the prefix only)
+            if (fused && !lexm) {   // LM score / state of the NEW prefix (a function of the prefix only)
               int ns2;
               lmv = h_lm[h] + lm.alpha * lm_step(lm, h_lst[h], c, &ns2) + lm.beta;
               lst = ns2;
@@ -296,7 +356,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       }
       c_valid[ci] = valid; c_node[ci] = slot == 0 ? node : -1 - pnode; c_tok[ci] = token;
       c_s[ci] = s_; c_ns[ci] = ns_; c_vs[ci] = vs_; c_vns[ci] = vns_; c_ctp[ci] = ctp_;
-      c_lm[ci] = lmv; c_lst[ci] = lst;
+      c_lm[ci] = lmv; c_lst[ci] = lst; c_lx[ci] = lxv;
       c_sc[ci] = valid ? log_add(s_, ns_) + (fused ? lmv : 0.f) : -INFINITY;
       c_ts[ci] = ts; c_tn[ci] = tn;
     }
@@ -325,7 +385,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       int node = c_node[ci];
       if (node < 0) {
         node = trie_find_or_add(-1 - node, c_tok[ci], par, tok, dep, hkey, hval, lay.HT, lay.NN, hdr);
-        if (fused) { nlm[node] = c_lm[ci]; nlst[node] = c_lst[ci]; }   // (re)written with the same values if it existed
+        if (fused) { nlm[node] = c_lm[ci]; nlst[node] = c_lst[ci]; if (lexm) nlx[node] = c_lx[ci]; }   // same values if it existed
       }
       hn.node[r] = node;
       hn.fl[0 * BMAX + r] = c_s[ci]; hn.fl[1 * BMAX + r] = c_ns[ci]; hn.fl[2 * BMAX + r] = c_vs[ci];
@@ -365,7 +425,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       HypBuf hb(st, lay, s_cur);
       if (tid < s_nb) {
         const int n = hb.node[tid];
-        h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0;
+        h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0; h_lx[tid] = lexm ? nlx[n] : 0; h_lx[tid] = lexm ? nlx[n] : 0;
         h_node[tid] = n; h_par[tid] = par[n]; h_tok[tid] = tok[n]; h_dep[tid] = dep[n];
         h_s[tid] = hb.fl[0 * BMAX + tid]; h_ns[tid] = hb.fl[1 * BMAX + tid]; h_vs[tid] = hb.fl[2 * BMAX + tid];
         h_vns[tid] = hb.fl[3 * BMAX + tid]; h_ctp[tid] = hb.fl[4 * BMAX + tid];
@@ -387,7 +447,14 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
         vscore[o] = h_vs[tid] > h_vns[tid] ? h_vs[tid] : h_vns[tid];
         if (lm_score) {
           float l = h_lm[tid];
-          if (fused && lm.eos >= 0) { int dummy; l += lm.alpha * lm_step(lm, h_lst[tid], lm.eos, &dummy); }
+          int stt = h_lst[tid], dummy;
+          if (lexm && h_lx[tid] != 0) {   // the last word has no closing SIL yet: emit it, or disqualify an unfinished word
+            const int lx = h_lx[tid];
+            if (lm.lex_wend[lx] > lm.lex_wbeg[lx]) l += lm.alpha * emit_word(lm, lx, stt, &stt) + lm.beta;
+            else l = -INFINITY;
+          }
+          if (fused && lm.eos >= 0)
+            l += lm.alpha * (lexm ? lm_step_sparse(lm, stt, lm.eos, &dummy) : lm_step(lm, stt, lm.eos, &dummy));
           lm_score[o] = l;
         }
         int node = h_node[tid];
@@ -431,7 +498,7 @@ extern "C" int b2t_prefix_beam_search_f32(const float* logp, const int32_t* lens
   BeamLayout lay(max_nodes, max_len);
   hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
-                     vscore, times, LmArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, 0.f, 0.f, 0.f},
+                     vscore, times, LmArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
                      static_cast<float*>(nullptr));
   B2T_CHECK_LAUNCH("b2t_prefix_beam_search_f32");
   return 0;
@@ -454,9 +521,30 @@ extern "C" int b2t_prefix_beam_search_lm_f32(const float* logp, const int32_t* l
   hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
                      vscore, times,
-                     LmArgs{lm_child, lm_logp, lm_bow, lm_suffix, lm_nstate, lm_vocab, lm_start_state, lm_eos, alpha, beta, unk_logp},
+                     LmArgs{lm_child, lm_logp, lm_bow, lm_suffix, lm_nstate, lm_vocab, lm_start_state, lm_eos, alpha, beta, unk_logp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
                      lm_score);
   B2T_CHECK_LAUNCH("b2t_prefix_beam_search_lm_f32");
+  return 0;
+}
+
+extern "C" int b2t_prefix_beam_search_lex_f32(const float* logp, const int32_t* lens, int U, int T, int C, int first_beam,
+                                              int second_beam, int blank, void* state, int max_len, int max_nodes,
+                                              int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
+                                              const b2t_lexlm_t* d, float* lm_score, void* stream) {
+  B2T_REQUIRE(logp && state && d && U > 0 && T > 0 && C > 1 && C <= 64, "prefix_beam_search_lex: bad shape U=%d T=%d C=%d", U, T, C);
+  B2T_REQUIRE(first_beam >= 1 && second_beam >= 1 && second_beam <= BMAX, "prefix_beam_search_lex: beams out of range (<=%d)", BMAX);
+  B2T_REQUIRE(d->lex_child && d->lex_wbeg && d->lex_wend && d->wlist && d->lm_cb && d->lm_ce && d->lm_ctok && d->lm_cnode &&
+                  d->lm_logp && d->lm_bow && d->lm_suffix && d->lm_nstate, "prefix_beam_search_lex: lexicon / LM tables missing");
+  B2T_REQUIRE(d->sil > 0 && d->sil < C && d->sil != blank, "prefix_beam_search_lex: sil class %d out of range", d->sil);
+  if (first_beam > C) first_beam = C;
+  B2T_REQUIRE(first_beam <= KMAX, "prefix_beam_search_lex: first_beam_size <= %d", KMAX);
+  BeamLayout lay(max_nodes, max_len);
+  LmArgs lm{nullptr, d->lm_logp, d->lm_bow, d->lm_suffix, d->lm_nstate, 0, d->lm_start_state, d->lm_eos, d->alpha, d->beta,
+            d->unk_logp, d->lex_child, d->lex_wbeg, d->lex_wend, d->wlist, d->lm_cb, d->lm_ce, d->lm_ctok, d->lm_cnode, d->sil};
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+                     blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
+                     vscore, times, lm, lm_score);
+  B2T_CHECK_LAUNCH("b2t_prefix_beam_search_lex_f32");
   return 0;
 }
 

@@ -170,3 +170,195 @@ def synthetic_arpa(id_to_word: Sequence[str], order: int, n_per_order: int, seed
         out.append("")
     out.append("\\end\\")
     return "\n".join(out)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Word-level decoding: pronunciation lexicon trie + sparse word n-gram automaton (b2t_prefix_beam_search_lex_f32)
+# ----------------------------------------------------------------------------------------------------------------
+class Lexicon:
+    """Pronunciation trie over the decoder's classes.  Words are delimited by the SIL class in the token stream (the
+    reference's phoneme transcriptions put SIL between words; its lexicon FST is built with "SIL" as the optional
+    silence, tools/fst/ctc_compile_dict_token.sh:94-98).  Arrays for the GPU:
+      child [n_nodes][C] int32 (-1 = no edge), wbeg/wend [n_nodes] -> ranges of `wlist` (word ids ending at the node).
+    Word ids are the ranks of the words in sorted order (homophone ties are broken by that order)."""
+
+    def __init__(self, prons: Dict[str, Sequence[Sequence[int]]], n_classes: int):
+        self.C = n_classes
+        self.words = sorted(prons)
+        wid = {w: i for i, w in enumerate(self.words)}
+        ids: Dict[Tuple[int, ...], int] = {(): 0}
+        ends: Dict[int, List[int]] = {}
+        for w in self.words:
+            for pron in prons[w]:
+                pron = tuple(int(x) for x in pron)
+                if not pron or any(c <= 0 or c >= n_classes for c in pron):
+                    raise ValueError(f"bad pronunciation for {w!r}: {pron}")
+                for k in range(1, len(pron) + 1):
+                    if pron[:k] not in ids:
+                        ids[pron[:k]] = len(ids)
+                ends.setdefault(ids[pron], []).append(wid[w])
+        n = len(ids)
+        self.child = np.full((n, n_classes), -1, dtype=np.int32)
+        for p, i in ids.items():
+            if p:
+                self.child[ids[p[:-1]], p[-1]] = i
+        self.wbeg = np.zeros(n, dtype=np.int32); self.wend = np.zeros(n, dtype=np.int32)
+        wl: List[int] = []
+        for i in range(n):
+            self.wbeg[i] = len(wl)
+            wl.extend(sorted(set(ends.get(i, []))))
+            self.wend[i] = len(wl)
+        self.wlist = np.array(wl if wl else [0], dtype=np.int32)
+        self.n_nodes = n
+        self._dev = None
+
+    def to_device(self, device):
+        import torch
+        if self._dev is None or self._dev["device"] != str(device):
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            self._dev = dict(device=str(device), child=t(self.child.reshape(-1)), wbeg=t(self.wbeg), wend=t(self.wend),
+                             wlist=t(self.wlist))
+        return self._dev
+
+
+class SparseNGramLM:
+    """Back-off automaton over a large (word) vocabulary: like NGramLM, but the children of a node are a sorted array
+    (ctok / cnode in [cb[n], ce[n])) searched by bisection instead of a dense table.  Vocabulary: the lexicon's word
+    ids 0..W-1, then <s> = W, </s> = W+1, <unk> = W+2."""
+
+    def __init__(self, order: int, table: Dict[Tuple[str, ...], Tuple[float, float]], words: Sequence[str],
+                 unk_logp: float = -99.0 * LN10):
+        W = len(words)
+        self.W, self.order = W, order
+        self.bos, self.eos, self.unk = W, W + 1, W + 2
+        wid = {w: i for i, w in enumerate(words)}
+        wid.update({"<s>": self.bos, "</s>": self.eos, "<unk>": self.unk})
+        grams = {tuple(wid[w] for w in g): v for g, v in table.items() if all(w in wid for w in g)}
+        ids: Dict[Tuple[int, ...], int] = {(): 0}
+        for g in sorted(grams, key=lambda g: (len(g), g)):
+            for k in range(1, len(g) + 1):
+                if g[:k] not in ids:
+                    ids[g[:k]] = len(ids)
+        n = len(ids)
+        logp = np.full(n, unk_logp, dtype=np.float32); bow = np.zeros(n, dtype=np.float32)
+        suffix = np.zeros(n, dtype=np.int32); nstate = np.zeros(n, dtype=np.int32)
+        kids: List[List[Tuple[int, int]]] = [[] for _ in range(n)]
+        for g, i in ids.items():
+            if not g:
+                continue
+            if g in grams:
+                logp[i] = grams[g][0] * LN10; bow[i] = grams[g][1] * LN10
+                kids[ids[g[:-1]]].append((g[-1], i))      # only n-grams with an entry of their own can be "found"
+            s = g[1:]
+            while s not in ids:
+                s = s[1:]
+            suffix[i] = ids[s]
+            st = g if len(g) <= order - 1 else g[1:]
+            while st not in ids:
+                st = st[1:]
+            nstate[i] = ids[st]
+        cb = np.zeros(n, dtype=np.int32); ce = np.zeros(n, dtype=np.int32)
+        ctok: List[int] = []; cnode: List[int] = []
+        for i in range(n):
+            cb[i] = len(ctok)
+            for tkn, node in sorted(kids[i]):
+                ctok.append(tkn); cnode.append(node)
+            ce[i] = len(ctok)
+        self.cb, self.ce = cb, ce
+        self.ctok = np.array(ctok if ctok else [0], dtype=np.int32); self.cnode = np.array(cnode if cnode else [0], dtype=np.int32)
+        self.logp, self.bow, self.suffix, self.nstate = logp, bow, suffix, nstate
+        self.n_nodes = n
+        c = self._find(0, self.bos)
+        self.start_state = int(self.nstate[c]) if c >= 0 and order > 1 else 0
+        u = self._find(0, self.unk)
+        self.unk_logp = float(logp[u]) if u >= 0 else float(unk_logp)
+        self._dev = None
+
+    @classmethod
+    def from_arpa(cls, text: str, words: Sequence[str], **kw) -> "SparseNGramLM":
+        order, table = parse_arpa(text)
+        return cls(order, table, words, **kw)
+
+    def _find(self, s: int, w: int) -> int:
+        lo, hi = int(self.cb[s]), int(self.ce[s])
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if self.ctok[mid] < w:
+                lo = mid + 1
+            else:
+                hi = mid
+        return int(self.cnode[lo]) if lo < int(self.ce[s]) and self.ctok[lo] == w else -1
+
+    def step(self, state: int, w: int) -> Tuple[float, int]:
+        acc, s = 0.0, state
+        while True:
+            c = self._find(s, w)
+            if c >= 0:
+                return acc + float(self.logp[c]), int(self.nstate[c])
+            if s == 0:
+                return acc + self.unk_logp, 0
+            acc += float(self.bow[s]); s = int(self.suffix[s])
+
+    def to_device(self, device):
+        import torch
+        if self._dev is None or self._dev["device"] != str(device):
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            self._dev = dict(device=str(device), cb=t(self.cb), ce=t(self.ce), ctok=t(self.ctok), cnode=t(self.cnode),
+                             logp=t(self.logp), bow=t(self.bow), suffix=t(self.suffix), nstate=t(self.nstate))
+        return self._dev
+
+
+def replay_words(lex: Lexicon, lm: SparseNGramLM, tokens: Sequence[int], alpha: float, beta: float, sil: int = 1,
+                 add_eos: bool = True):
+    """Host replay of the kernel's word emissions for ONE phoneme hypothesis: -> (words, lm score) or (None, -inf) if
+    the hypothesis ends inside a word.  Same rules, same tie-breaks (best LM probability, then lowest word id)."""
+    state, node, words, score = lm.start_state, 0, [], 0.0
+
+    def emit():
+        nonlocal state, node, score
+        best = None
+        for k in range(int(lex.wbeg[node]), int(lex.wend[node])):
+            w = int(lex.wlist[k])
+            lp, ns = lm.step(state, w)
+            if best is None or lp > best[0]:
+                best = (lp, ns, w)
+        score += alpha * best[0] + beta
+        state = best[1]; words.append(lex.words[best[2]]); node = 0
+    for c in tokens:
+        c = int(c)
+        if c == sil:
+            if node != 0:
+                if lex.wend[node] == lex.wbeg[node]:
+                    return None, -math.inf
+                emit()
+        else:
+            node = int(lex.child[node, c])
+            if node < 0:
+                return None, -math.inf
+    if node != 0:
+        if lex.wend[node] == lex.wbeg[node]:
+            return None, -math.inf
+        emit()
+    if add_eos:
+        score += alpha * lm.step(state, lm.eos)[0]
+    return words, score
+
+
+def synthetic_lexicon(n_words: int, n_classes: int, seed: int = 0, sil: int = 1, blank: int = 0):
+    """Random pronunciation dictionary (bench / tests): words w00000.. with 2-8 phonemes, a few homophones."""
+    rng = np.random.RandomState(seed)
+    phones = [c for c in range(n_classes) if c not in (sil, blank)]
+    prons: Dict[str, List[Tuple[int, ...]]] = {}
+    seen: List[Tuple[int, ...]] = []
+    for i in range(n_words):
+        if seen and rng.rand() < 0.03:
+            p = seen[rng.randint(len(seen))]          # homophone
+        else:
+            p = tuple(int(phones[j]) for j in rng.randint(len(phones), size=rng.randint(2, 9)))
+            seen.append(p)
+        prons[f"w{i:05d}"] = [p]
+    return prons
+
+
+def synthetic_word_arpa(words: Sequence[str], order: int, n_per_order: int, seed: int = 0) -> str:
+    return synthetic_arpa([None] + list(words), order, n_per_order, seed=seed, skip=(0,))

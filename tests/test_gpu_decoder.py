@@ -212,3 +212,85 @@ def test_lm_decoder_with_token_lm():
     assert tuple(best.tokens) == ref[0][0]
     assert best.lm_score == pytest.approx(ref[0][2], rel=2e-4, abs=2e-4)
     assert best.ac_score == pytest.approx(ref[0][1] / dec.acoustic_scale, rel=2e-4, abs=2e-4)
+
+
+# ---- word level: pronunciation lexicon + word n-gram (b2t_prefix_beam_search_lex_f32) ------------------------------
+def _search_lex(logp, lex, lm, alpha, beta, first, second, chunks=None, eos=True):
+    import ctypes as C
+    import b2t_native as N
+    import b2t_ops as ops
+    dev = torch.device("cuda:0")
+    lib = N.load()
+    U, T, Cc = logp.shape
+    L, NN = T + 1, T * second + 2
+    state = torch.empty((lib.b2t_beam_state_bytes(L, NN) * U,), dtype=torch.uint8, device=dev)
+    N.check(lib.b2t_beam_reset(ops._p(state), U, L, NN, ops._stream()), "reset")
+    hyps = torch.zeros((U, second, L), dtype=torch.int32, device=dev)
+    hl = torch.empty((U, second), dtype=torch.int32, device=dev)
+    sc = torch.empty((U, second), device=dev); vs = torch.empty((U, second), device=dev); lms = torch.empty((U, second), device=dev)
+    tm = torch.zeros((U, second, L), dtype=torch.int32, device=dev)
+    dl, dm = lex.to_device(dev), lm.to_device(dev)
+    d = N.LexLmDesc(dl["child"].data_ptr(), dl["wbeg"].data_ptr(), dl["wend"].data_ptr(), dl["wlist"].data_ptr(),
+                    dm["cb"].data_ptr(), dm["ce"].data_ptr(), dm["ctok"].data_ptr(), dm["cnode"].data_ptr(),
+                    dm["logp"].data_ptr(), dm["bow"].data_ptr(), dm["suffix"].data_ptr(), dm["nstate"].data_ptr(),
+                    lm.start_state, lm.eos if eos else -1, 1, float(alpha), float(beta), float(lm.unk_logp))
+    for a, b in (chunks or [(0, T)]):
+        lp = torch.from_numpy(np.ascontiguousarray(logp[:, a:b])).to(dev)
+        N.check(lib.b2t_prefix_beam_search_lex_f32(ops._p(lp), None, U, b - a, Cc, first, second, 0, ops._p(state), L, NN,
+                                                   ops._p(hyps), ops._p(hl), ops._p(sc), ops._p(vs), ops._p(tm), C.byref(d),
+                                                   ops._p(lms), ops._stream()), "search_lex")
+    flag = C.c_int(0)
+    N.check(lib.b2t_beam_overflowed(ops._p(state), U, L, NN, C.byref(flag), ops._stream()), "ovf")
+    assert flag.value == 0
+    return hyps.cpu().numpy(), hl.cpu().numpy(), sc.cpu().numpy(), lms.cpu().numpy()
+
+
+@pytest.mark.parametrize("nwords,order", [(60, 2), (400, 3)])
+def test_prefix_beam_lexicon_vs_oracle(nwords, order):
+    import ngram_lm
+    Cc = 14
+    prons = ngram_lm.synthetic_lexicon(nwords, Cc, seed=nwords)
+    lex = ngram_lm.Lexicon(prons, Cc)
+    text = ngram_lm.synthetic_word_arpa(lex.words, order, 3 * nwords, seed=order)
+    o, tab = O.parse_arpa(text)
+    lm = ngram_lm.SparseNGramLM.from_arpa(text, lex.words)
+    rng = np.random.default_rng(nwords + order)
+    U, T = 4, 45
+    logits = (rng.standard_normal((U, T, Cc)) * 1.5).astype(np.float32)
+    logits[..., 1] += 0.7                                    # SIL a bit more likely: more complete words
+    logp = O.log_softmax(logits)
+    alpha, beta, first, second = 0.6, 0.5, 8, 16
+    hyps, hl, sc, lms = _search_lex(logp, lex, lm, alpha, beta, first, second)
+    for u in range(U):
+        ref = O.prefix_beam_search_lexicon(logp[u], prons, o, tab, alpha, beta, first, second)
+        got = {}
+        for i in range(second):
+            if hl[u, i] >= 0 and np.isfinite(lms[u, i]):
+                got[tuple(hyps[u, i, :hl[u, i]])] = (sc[u, i], lms[u, i])
+        assert ref, "no complete hypothesis in the oracle"
+        best = max(got.items(), key=lambda kv: kv[1][0] + kv[1][1])
+        assert best[0] == ref[0][0]
+        hits = 0
+        for p, words, ctc, lmscore, total in ref:
+            if p in got:
+                hits += 1
+                np.testing.assert_allclose(got[p][0], ctc, rtol=2e-4, atol=2e-4)
+                np.testing.assert_allclose(got[p][1], lmscore, rtol=2e-4, atol=3e-4)
+                w2, l2 = ngram_lm.replay_words(lex, lm, p, alpha, beta)
+                assert tuple(w2) == words
+        assert hits >= len(ref) - 2
+
+
+def test_prefix_beam_lexicon_streaming_equals_offline():
+    import ngram_lm
+    Cc = 14
+    prons = ngram_lm.synthetic_lexicon(200, Cc, seed=5)
+    lex = ngram_lm.Lexicon(prons, Cc)
+    text = ngram_lm.synthetic_word_arpa(lex.words, 3, 500, seed=6)
+    lm = ngram_lm.SparseNGramLM.from_arpa(text, lex.words)
+    rng = np.random.default_rng(7)
+    logp = O.log_softmax((rng.standard_normal((3, 40, Cc)) * 1.5).astype(np.float32))
+    a = _search_lex(logp, lex, lm, 0.5, 0.3, 8, 12)
+    b = _search_lex(logp, lex, lm, 0.5, 0.3, 8, 12, chunks=[(0, 1), (1, 9), (9, 10), (10, 40)])
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)

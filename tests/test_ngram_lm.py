@@ -86,3 +86,22 @@ def test_oracle_fused_beam_prefers_lm_consistent_hypothesis():
     fused = O.prefix_beam_search_lm(logp, order, tab, WORDS, alpha=2.0, beta=0.0, first_beam=4, second_beam=4)
     assert plain[0][0] == (1, 3)
     assert fused[0][0] == (1, 2)
+
+
+def test_word_level_oracle_and_host_replay_agree():
+    """Lexicon-constrained oracle search vs the host replay of word emissions (ngram_lm.replay_words) on the oracle's
+    own hypotheses: same words, same LM score."""
+    import ngram_lm
+    prons = ngram_lm.synthetic_lexicon(120, 12, seed=3)
+    lex = ngram_lm.Lexicon(prons, 12)
+    text = ngram_lm.synthetic_word_arpa(lex.words, 3, 300, seed=4)
+    order, tab = O.parse_arpa(text)
+    lm = ngram_lm.SparseNGramLM.from_arpa(text, lex.words)
+    rng = np.random.default_rng(0)
+    logp = O.log_softmax((rng.standard_normal((40, 12)) * 1.5).astype(np.float32))
+    res = O.prefix_beam_search_lexicon(logp, prons, order, tab, 0.7, 0.4, 8, 12)
+    assert res, "the oracle found no complete hypothesis"
+    for p, words, ctc, lmscore, total in res:
+        w2, l2 = ngram_lm.replay_words(lex, lm, p, 0.7, 0.4)
+        assert tuple(w2) == words
+        assert l2 == pytest.approx(lmscore, rel=1e-5, abs=1e-4)
