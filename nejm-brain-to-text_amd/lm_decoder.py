@@ -49,10 +49,19 @@ class DecodeResource:
         self.symbols = self._read_table(dict_path) if dict_path else None
         self.units = self._read_table(unit_path) if unit_path else None
         self.token_lm = None
+        self.lexicon = self.word_lm = None
+        self.sil = 1
 
     def set_token_lm(self, lm):
         """Attach an ngram_lm.NGramLM over the decoder's output tokens (fused into the prefix beam search)."""
         self.token_lm = lm
+
+    def set_lexicon_lm(self, lexicon, word_lm, sil: int = 1):
+        """Attach an ngram_lm.Lexicon and an ngram_lm.SparseNGramLM over its words: the search is then constrained to
+        SIL-delimited dictionary words and scored by the word n-gram (b2t_prefix_beam_search_lex_f32)."""
+        if word_lm.W != len(lexicon.words):
+            raise ValueError("the word LM was built for a different vocabulary than the lexicon")
+        self.lexicon, self.word_lm, self.sil = lexicon, word_lm, sil
 
     @staticmethod
     def _read_table(path):
@@ -121,7 +130,21 @@ class BrainSpeechDecoder:
         lm = self.res.token_lm
         lms = torch.zeros((1, bm), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            if lm is None:
+            if self.res.lexicon is not None:
+                lex, wlm = self.res.lexicon, self.res.word_lm
+                if lex.C != Cc:
+                    raise ValueError(f"the lexicon was built for {lex.C} classes, the log-probabilities have {Cc}")
+                dl, dm = lex.to_device(self.device), wlm.to_device(self.device)
+                d = N.LexLmDesc(dl["child"].data_ptr(), dl["wbeg"].data_ptr(), dl["wend"].data_ptr(), dl["wlist"].data_ptr(),
+                                dm["cb"].data_ptr(), dm["ce"].data_ptr(), dm["ctok"].data_ptr(), dm["cnode"].data_ptr(),
+                                dm["logp"].data_ptr(), dm["bow"].data_ptr(), dm["suffix"].data_ptr(), dm["nstate"].data_ptr(),
+                                wlm.start_state, wlm.eos if self.opts.lm_eos else -1, self.res.sil, float(self.opts.lm_alpha),
+                                float(self.opts.lm_beta), float(wlm.unk_logp))
+                N.check(N.load().b2t_prefix_beam_search_lex_f32(
+                    ops._p(lp), None, 1, T, Cc, self.opts.first_beam_size, bm, self.opts.blank, ops._p(self.state),
+                    self.max_len, self.max_nodes, ops._p(hyps), ops._p(hl), ops._p(sc), ops._p(vs), ops._p(tm), C.byref(d),
+                    ops._p(lms), ops._stream()), "b2t_prefix_beam_search_lex_f32")
+            elif lm is None:
                 N.check(N.load().b2t_prefix_beam_search_f32(ops._p(lp), None, 1, T, Cc, self.opts.first_beam_size, bm,
                                                             self.opts.blank, ops._p(self.state), self.max_len,
                                                             self.max_nodes, ops._p(hyps), ops._p(hl), ops._p(sc), ops._p(vs),
@@ -143,13 +166,22 @@ class BrainSpeechDecoder:
     def _update_result(self):
         hyps, hl, sc, vs, tm, lms = self._out
         table = self.res.symbols or self.res.units
-        fused = self.res.token_lm is not None
+        fused = self.res.token_lm is not None or self.res.lexicon is not None
         self._result = []
         for i in range(len(hl)):
             if hl[i] < 0:
                 continue
             ids = hyps[i, :hl[i]]
-            words = [table.get(int(t), str(int(t))) if table else str(int(t)) for t in ids]
+            if self.res.lexicon is not None:
+                if not np.isfinite(lms[i]):
+                    continue                     # ends inside a word
+                import ngram_lm
+                words, _ = ngram_lm.replay_words(self.res.lexicon, self.res.word_lm, ids, self.opts.lm_alpha,
+                                                 self.opts.lm_beta, self.res.sil, self.opts.lm_eos)
+                if words is None:
+                    continue
+            else:
+                words = [table.get(int(t), str(int(t))) if table else str(int(t)) for t in ids]
             r = DecodeResult(process_blank("".join(" " + w for w in words)), float(sc[i]) / self.acoustic_scale,
                              float(lms[i]) if fused else float(sc[i]))
             r.tokens, r.times, r.viterbi_score = ids.copy(), tm[i, :hl[i]].copy(), float(vs[i])

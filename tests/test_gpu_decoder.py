@@ -294,3 +294,28 @@ def test_prefix_beam_lexicon_streaming_equals_offline():
     b = _search_lex(logp, lex, lm, 0.5, 0.3, 8, 12, chunks=[(0, 1), (1, 9), (9, 10), (10, 40)])
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_lm_decoder_with_lexicon():
+    import lm_decoder
+    import ngram_lm
+    Cc = 14
+    prons = ngram_lm.synthetic_lexicon(150, Cc, seed=21)
+    lex = ngram_lm.Lexicon(prons, Cc)
+    text = ngram_lm.synthetic_word_arpa(lex.words, 3, 400, seed=22)
+    o, tab = O.parse_arpa(text)
+    lm = ngram_lm.SparseNGramLM.from_arpa(text, lex.words)
+    res = lm_decoder.DecodeResource("", "", "", "", "")
+    res.set_lexicon_lm(lex, lm, sil=1)
+    opts = lm_decoder.DecodeOptions(7000, 200, 17.0, 8.0, 0.5, 1.0, 0.0, 10)
+    opts.lm_alpha, opts.lm_beta, opts.lm_eos, opts.first_beam_size, opts.second_beam_size = 0.6, 0.5, True, 8, 16
+    dec = lm_decoder.BrainSpeechDecoder(res, opts)
+    rng = np.random.default_rng(23)
+    logits = (rng.standard_normal((45, Cc)) * 1.5).astype(np.float32); logits[:, 1] += 0.7
+    logp = O.log_softmax(logits)
+    lm_decoder.DecodeNumpyLogProbs(dec, logp)
+    ref = O.prefix_beam_search_lexicon(logp, prons, o, tab, 0.6, 0.5, 8, 16)
+    best = dec.result()[0]
+    assert tuple(best.tokens) == ref[0][0]
+    assert best.sentence == " ".join(ref[0][1]).lower()
+    assert best.total_score == pytest.approx(ref[0][4], rel=2e-4, abs=3e-4)
