@@ -72,6 +72,10 @@ typedef struct b2t_gemm_desc {
    * reduces k in [ks*kc, min(K,(ks+1)*kc)) (kc = ceil(K/splitk) rounded up to 16) into the slab
    * C + z*c_sz + ks*c_ks; the caller sums the slabs deterministically (b2t_colsum_f32). */
   int splitk; long long c_ks;
+  /* gap in A's contiguous index i (k if a_kcontig, else m): for i >= a_brk the element is read at i + a_gap.
+   * Lets dGi = dG[:, 0:2H] ++ dG[:, 3H:4H] be ONE operand (a_brk = 2H, a_gap = H).  a_brk = 0: off; must be a
+   * multiple of 16 (k) / 128 (m, with M % 128 == 0). */
+  int a_brk; int a_gap;
 } b2t_gemm_desc;
 int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream);
 

@@ -127,7 +127,7 @@ def augment_smooth(x: torch.Tensor, std: float, size: int, padding: str = "same"
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,
          b_sz=0, c_s0=0, c_s1=0, c_div=0, c_sz=0, bias=None, bias_sz=0, b_zmap=None, epilogue=0, accumulate=0,
-         a_off=0, b_off=0, c_off=0, splitk=1, ws=None, slab="splitk_slab", _splitk=1, _c_ks=0):
+         a_off=0, b_off=0, c_off=0, splitk=1, ws=None, slab="splitk_slab", _splitk=1, _c_ks=0, a_brk=0, a_gap=0):
     """C = A.B^T through b2t_gemm_f32.  splitk>1 (needs `ws`): partial products go to a workspace slab and
     are summed deterministically into C by b2t_colsum_f32 (used for the weight gradients, K = T*B)."""
     if splitk > 1:
@@ -135,7 +135,8 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
             raise RuntimeError("split-K gemm supports Z=1, dense row-major C, no epilogue")
         sl = ws.get(slab, (splitk, M * N_), Cm.device)
         gemm(A, B, sl, M=M, N_=N_, K=K, a_kc=a_kc, b_kc=b_kc, a_s0=a_s0, a_s1=a_s1, a_div=a_div, b_s0=b_s0,
-             b_s1=b_s1, b_div=b_div, c_s0=N_, bias=bias, a_off=a_off, b_off=b_off, _splitk=splitk, _c_ks=M * N_)
+             b_s1=b_s1, b_div=b_div, c_s0=N_, bias=bias, a_off=a_off, b_off=b_off, _splitk=splitk, _c_ks=M * N_,
+             a_brk=a_brk, a_gap=a_gap)
         N.check(N.load().b2t_slab_reduce_f32(_p(sl), splitk, M * N_, C.c_void_p(Cm.data_ptr() + 4 * c_off), accumulate,
                                              _stream()), "b2t_slab_reduce_f32")
         return
@@ -153,6 +154,7 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
     d.bias_sz = bias_sz
     d.epilogue, d.accumulate = epilogue, accumulate
     d.splitk, d.c_ks = _splitk, _c_ks
+    d.a_brk, d.a_gap = a_brk, a_gap
     with _Prof(f"gemm_f32_kernel<{int(bool(a_kc))},{int(bool(b_kc))}>", 2.0 * M * N_ * K * Z):   # one name per rocprof symbol
         N.check(N.load().b2t_gemm_f32(C.byref(d), _stream()), "b2t_gemm_f32")
 
@@ -556,10 +558,22 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
     def dx_gemm(l, t0, n):
         """dIn = dGi W_ih for rows of chunk [t0,t0+n): into dY[l-1] (l>0) or dU / dV (l == 0)."""
         a_off = t0 * B * 4 * H
-        if l > 0:
+        # dGi = dG[:, 0:2H] ++ dG[:, 3H:4H] is one A operand with a gap (a_brk / a_gap), K = 3H
+        gap = dict(a_brk=2 * H, a_gap=H) if (2 * H) % 16 == 0 else None
+        if l > 0 and gap:
+            gemm(dGs[l], prm.w_ih[l], dYs[l - 1], M=n * B, N_=H, K=3 * H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H,
+                 c_off=t0 * B * H, a_off=a_off, **gap)
+        elif l > 0:
             kw = dict(M=n * B, N_=H, a_kc=1, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H, c_off=t0 * B * H)
             gemm(dGs[l], prm.w_ih[l], dYs[l - 1], K=2 * H, a_off=a_off, **kw)
             gemm(dGs[l], prm.w_ih[l], dYs[l - 1], K=H, a_off=a_off + 3 * H, b_off=2 * H * H, accumulate=1, **kw)
+        elif gap:
+            In = dims.In0
+            if dims.patch > 0:
+                dst, kw = dV, dict(c_div=B, c_s1=In, c_s0=Tp * In, c_off=t0 * In)
+            else:
+                dst, kw = dU, dict(c_div=B, c_s1=F, c_s0=T * F, c_off=t0 * F)
+            gemm(dGs[0], prm.w_ih[0], dst, M=n * B, N_=In, K=3 * H, a_kc=1, a_s0=4 * H, a_off=a_off, b_kc=0, b_s0=In, **gap, **kw)
         else:
             In = dims.In0
             if dims.patch > 0:
@@ -684,10 +698,14 @@ def _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb, t0=0, t1=None,
         In = H
         kw = dict(b_kc=0, b_s0=H)
         inp, in_off = ctx.outs_d[l - 1], (1 + t0) * B * H   # skip the initial-state slot
-    gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=K, a_kc=0, a_s0=4 * H, a_off=a0, c_s0=In, b_off=in_off,
-         splitk=splitk_for(2 * H, In, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate, **kw)
-    gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=K, a_kc=0, a_s0=4 * H, a_off=a0 + 3 * H, c_s0=In, c_off=2 * H * In,
-         b_off=in_off, splitk=splitk_for(H, In, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate, **kw)
+    if (2 * H) % 128 == 0 and (3 * H) % 128 == 0:   # dGi^T as ONE operand with a gap along m
+        gemm(dG, inp, grd.w_ih[l], M=3 * H, N_=In, K=K, a_kc=0, a_s0=4 * H, a_off=a0, c_s0=In, b_off=in_off,
+             splitk=splitk_for(3 * H, In, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate, a_brk=2 * H, a_gap=H, **kw)
+    else:
+        gemm(dG, inp, grd.w_ih[l], M=2 * H, N_=In, K=K, a_kc=0, a_s0=4 * H, a_off=a0, c_s0=In, b_off=in_off,
+             splitk=splitk_for(2 * H, In, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate, **kw)
+        gemm(dG, inp, grd.w_ih[l], M=H, N_=In, K=K, a_kc=0, a_s0=4 * H, a_off=a0 + 3 * H, c_s0=In, c_off=2 * H * In,
+             b_off=in_off, splitk=splitk_for(H, In, K), ws=ws, slab=f"splitk_slab{l}", accumulate=accumulate, **kw)
     s4 = ws.get(f"s4_{l}", (4 * H,), dev)
     colsum(dG, K, 4 * H, 4 * H, s4, accumulate=accumulate, x_off=a0)     # (s_r, s_z, s_nr, s_n)
     if final:

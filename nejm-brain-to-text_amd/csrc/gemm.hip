@@ -41,6 +41,7 @@ struct GemmArgs {
   const int* b_zmap; long long bias_sz;
   int epilogue; int accumulate;
   int splitk; int kchunk; long long c_ks;
+  int a_brk; int a_gap;   // contiguous index i of A (k if a_kcontig, else m): i >= a_brk reads from i + a_gap
 };
 
 __device__ __forceinline__ long long rowoff(int i, long long s0, long long s1, int div) {
@@ -177,11 +178,13 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
 
   auto fetch = [&](int kt) {
     const int k0 = kb + kt * BKT;
+    // gap in A's contiguous index (tile-uniform: a_brk is a multiple of the tile extent): shift the base pointer
+    const float* Ag = A + ((g.a_brk > 0 && (AKC ? k0 : m0) >= g.a_brk) ? g.a_gap : 0);
     if (kt < nfull) {
-      load_full<AKC>(A, roffA, mclA, k0, g.a_s0, g.a_s1, g.a_div, ra, tid);
+      load_full<AKC>(Ag, roffA, mclA, k0, g.a_s0, g.a_s1, g.a_div, ra, tid);
       load_full<BKC>(B, roffB, mclB, k0, g.b_s0, g.b_s1, g.b_div, rb, tid);
     } else {
-      load_tail<AKC>(A, roffA, g.M, m0, k0, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
+      load_tail<AKC>(Ag, roffA, g.M, m0, k0, K, g.a_s0, g.a_s1, g.a_div, ra, tid);
       load_tail<BKC>(B, roffB, g.N, n0, k0, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
     }
   };
@@ -266,6 +269,10 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
               "b2t_gemm_f32: split-K slabs cannot carry an epilogue/accumulate (reduce them with b2t_colsum_f32)");
   g.kchunk = ((d->K + g.splitk - 1) / g.splitk + BKT - 1) / BKT * BKT;
   g.c_ks = d->c_ks;
+  g.a_brk = d->a_brk; g.a_gap = d->a_gap;
+  B2T_REQUIRE(d->a_brk == 0 || (d->a_brk > 0 && d->a_gap % 4 == 0 &&
+                                (d->a_kcontig ? d->a_brk % BKT == 0 : (d->a_brk % BM == 0 && d->M % BM == 0))),
+              "b2t_gemm_f32: a_brk must be a multiple of the tile extent (16 along k, 128 along m with M %% 128 == 0), a_gap of 4");
   dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);
   hipStream_t s = as_stream(stream);
   if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
