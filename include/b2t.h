@@ -156,7 +156,8 @@ int b2t_stream_wait_value32_gte(void* ptr, uint32_t value, void* stream);
 /* ---- a7: log-softmax + CTC loss (torch.nn.CTCLoss(blank=0,'none') at rnn_trainer.py:242,538-545)
  * logits [B][T][C] batch-first.  targets [B][S_max] int32 (0-padded), in_len/tgt_len [B] int32.
  * loss [B] = -log p(target | logits[:in_len]) (inf when infeasible; zero_infinity=False).
- * alpha_ws: [B][T][2*S_max+1] floats scratch (alpha, consumed by the backward).
+ * alpha_ws: scratch of B*T*(2*S_max+1) floats for the loss alone, TWICE that when dlogits is requested
+ * (alpha rows, then beta rows: the two recursions run concurrently and a third pass forms the gradient).
  * dlogits [B][T][ldd] (ldd >= C) = grad_scale * d loss_b / d logits (grad_scale = 1/B for the
  * reference's torch.mean, rnn_trainer.py:545); exactly 0 for t >= in_len[b]. dlogits may be NULL. */
 int b2t_ctc_loss_f32(const float* logits, const int32_t* targets, const int32_t* in_len,

@@ -732,7 +732,7 @@ def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, in_len: torch.Tensor, 
         targets = torch.zeros((B, 1), dtype=torch.int32, device=dev)
     ldd = pad_to(Cc, 4)
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
-    alpha = ws.get("ctc_alpha", (B, T, 2 * S_max + 1), dev)
+    alpha = ws.get("ctc_alpha", (2, B, T, 2 * S_max + 1), dev)   # alpha rows, beta rows
     dl = ws.get("ctc_dlogits", (B, T, ldd), dev) if want_grad else None
     with _Prof("ctc_kernel"):
         N.check(N.load().b2t_ctc_loss_f32(_p(logits), _p(targets), _p(in_len), _p(tgt_len), _p(loss), _p(alpha), _p(dl),
