@@ -149,6 +149,31 @@ int b2t_gru_layer_bwd_flagged_f32(const float* dY, const float* dh_last, const f
                                   const float* h_init, const float* w_hh_t, float* dG, float* dh_init,
                                   int T, int B, int H, void* sync_ws,
                                   const uint32_t* ready, uint32_t* done, int sub, uint32_t epoch, void* stream);
+/* ---- a5 (mode 4): the whole GRU stack as ONE persistent launch (nn.GRU forward, rnn_model.py:126, all layers).
+ * Layer 0 reads its input projection gi0 [T][B][3H] (b_ih folded in) from a GEMM that ran before; layers l >= 1 form
+ * x_t W_ih^T inside the sweep from the tile layer l-1 has just published.  out[l] is [T+1][B][H]: slab 0 holds the
+ * initial state on entry, slab t+1 receives h_t.  When drop_p > 0 and out_drop[l] is given, layer l also writes the
+ * kept/scaled copy (nn.GRU inter-layer dropout; same mask as b2t_dropout_f32(seed = drop_seed[l], elem0 = 0) over
+ * slabs 1..T) to out_drop[l] (same layout), and layer l+1 consumes that copy.  reserve[l]: [T][B][4H] or NULL.
+ * sync_ws: b2t_gru_sync_bytes() bytes, zeroed once, one per concurrent call.  Returns 4 (and launches nothing) when the
+ * shape is not covered -- (H/16) * L * ceil(B/64) workgroups must be resident at once, H <= 512 -- the caller then runs
+ * the per-layer sweeps. */
+#define B2T_STACK_MAX_LAYERS 8
+typedef struct {
+  int T, B, H, L;
+  const float* gi0;
+  const float* w_hh[B2T_STACK_MAX_LAYERS];
+  const float* w_ih[B2T_STACK_MAX_LAYERS];   /* [0] unused */
+  const float* b_hh[B2T_STACK_MAX_LAYERS];
+  const float* b_ih[B2T_STACK_MAX_LAYERS];   /* [0] unused */
+  float* out[B2T_STACK_MAX_LAYERS];
+  float* out_drop[B2T_STACK_MAX_LAYERS];     /* NULL: no dropped copy for that layer */
+  float* reserve[B2T_STACK_MAX_LAYERS];
+  float drop_p;
+  uint64_t drop_seed[B2T_STACK_MAX_LAYERS];
+} b2t_gru_stack_t;
+int b2t_gru_stack_fwd_f32(const b2t_gru_stack_t* d, void* sync_ws, void* stream);
+
 /* Stream-ordered 32-bit word write / wait-until->= executed by the command processor (no kernel launch). */
 int b2t_stream_write_value32(void* ptr, uint32_t value, void* stream);
 int b2t_stream_wait_value32_gte(void* ptr, uint32_t value, void* stream);

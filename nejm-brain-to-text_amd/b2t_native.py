@@ -43,6 +43,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+STACK_MAX_LAYERS = 8
+
+
+class GruStackDesc(C.Structure):
+    """Mirror of b2t_gru_stack_t (include/b2t.h)."""
+    _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int), ("gi0", VP),
+                ("w_hh", VP * STACK_MAX_LAYERS), ("w_ih", VP * STACK_MAX_LAYERS), ("b_hh", VP * STACK_MAX_LAYERS),
+                ("b_ih", VP * STACK_MAX_LAYERS), ("out", VP * STACK_MAX_LAYERS), ("out_drop", VP * STACK_MAX_LAYERS),
+                ("reserve", VP * STACK_MAX_LAYERS), ("drop_p", C.c_float), ("drop_seed", C.c_uint64 * STACK_MAX_LAYERS)]
+
+
 class LexLmDesc(C.Structure):
     """Mirror of b2t_lexlm_t (include/b2t.h)."""
     _fields_ = [(n, VP) for n in ("lex_child", "lex_wbeg", "lex_wend", "wlist", "lm_cb", "lm_ce", "lm_ctok", "lm_cnode",
@@ -75,6 +86,7 @@ _SIGNATURES = {
                                                 C.c_int, C.c_uint32, VP]),
     "b2t_gru_layer_bwd_flagged_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP,
                                                 C.c_int, C.c_uint32, VP]),
+    "b2t_gru_stack_fwd_f32": (C.c_int, [C.POINTER(GruStackDesc), VP, VP]),
     "b2t_stream_write_value32": (C.c_int, [VP, C.c_uint32, VP]),
     "b2t_stream_wait_value32_gte": (C.c_int, [VP, C.c_uint32, VP]),
     "b2t_ctc_loss_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

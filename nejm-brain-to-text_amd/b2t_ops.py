@@ -239,7 +239,37 @@ def gru_mode_for(B: int, H: int) -> int:
     m = GRU_MODE["value"]
     if m in (0, 1, 2, 3):
         return m
+    if m == 4:   # fused stack where the shape is covered (b2t_gru_stack_*), per-layer persistent sweeps otherwise
+        return 1
     return 1 if (H // 16) * ((B + 15) // 16) <= MAX_RESIDENT_WGS and H <= 1024 else 0
+
+
+def stack_wanted() -> bool:
+    """B2T_GRU_MODE=4: run the GRU stack as one persistent launch per direction (csrc/gru_stack.hip)."""
+    return GRU_MODE["value"] == 4
+
+
+def gru_stack_forward(dims, prm, gi0, outs, outs_d, reserves, Tp, B, rnn_drop, seed, ws, dev) -> bool:
+    """All layers' recurrences (and the input projections of layers >= 1) in one launch on the current stream.
+    outs[l][0] must hold the initial state.  Returns False (nothing launched) when the shape is not covered."""
+    H, L = dims.H, dims.L
+    d = N.GruStackDesc()
+    d.T, d.B, d.H, d.L = Tp, B, H, L
+    d.gi0 = gi0.data_ptr()
+    d.drop_p = float(rnn_drop)
+    for l in range(L):
+        d.w_hh[l] = prm.w_hh[l].data_ptr(); d.b_hh[l] = prm.b_hh[l].data_ptr()
+        d.w_ih[l] = prm.w_ih[l].data_ptr(); d.b_ih[l] = prm.b_ih[l].data_ptr()
+        d.out[l] = outs[l].data_ptr()
+        d.out_drop[l] = outs_d[l].data_ptr() if outs_d[l] is not outs[l] else None
+        d.reserve[l] = reserves[l].data_ptr() if reserves[l] is not None else None
+        d.drop_seed[l] = (seed * 1000003 + 101 + l) & 0xFFFFFFFFFFFFFFFF
+    with _Prof("gru_stack_fwd", 2.0 * Tp * B * 3 * H * H * (2 * L - 1), 1):
+        rc = N.load().b2t_gru_stack_fwd_f32(C.byref(d), _p(ws.sync_ws(0, Tp, dev, B, H, "stk")), _stream())
+    if rc == 4:
+        return False
+    N.check(rc, "b2t_gru_stack_fwd_f32")
+    return True
 
 
 def gru_sync_check(sync_ws, T: int, B: int):
@@ -254,6 +284,7 @@ def gru_sync_check_all(ws, L: int, Tp: int, B: int, device, H: int = 512):
     for l in range(L):
         gru_sync_check(ws.sync_ws(l, Tp, device, B, H), Tp, B)
         gru_sync_check(ws.sync_ws(l, Tp, device, B, H, "b"), Tp, B)
+    gru_sync_check(ws.sync_ws(0, Tp, device, B, H, "stk"), Tp, B)
 
 
 class Workspace:
@@ -379,11 +410,24 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     reserves = [sbuf(f"res{l}", (Tp, B, 4 * H)) if save else None for l in range(L)]
     gis = [ws.get(f"gi{l if piped else 0}", (Tp, B, 3 * H), dev) for l in range(L)]
     hidden = torch.empty((L, B, H), dtype=torch.float32, device=dev)
+    a_s0_l0 = dims.stride * F if dims.patch > 0 else F
+    stacked = False
+    if stack_wanted() and mode == 1:
+        # mode 4: layer 0's projection for the whole sequence, then ONE launch for the L recurrences (layers >= 1
+        # project inside the sweep, dropout is applied by the producing layer)
+        for l in range(L):
+            outs[l][0].copy_(prm.h0.view(1, H).expand(B, H) if states is None else states[l])
+        gemm(Ud, prm.w_ih[0], gis[0], M=Tp, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0_l0, a_sz=T * F,
+             b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H, bias=prm.b_ih[0])
+        stacked = gru_stack_forward(dims, prm, gis[0], outs, outs_d, reserves, Tp, B, rnn_drop, seed, ws, dev)
+        if stacked:
+            for l in range(L):
+                hidden[l].copy_(outs[l][Tp])
     ev0 = _ev(main)
     if piped:
         for s in s_sweep + s_gemm:
             s.wait_event(ev0)
-    for l in range(L):   # slot 0 = initial state, so outs[l][0:T'] is the h_{t-1} matrix
+    for l in range(L if not stacked else 0):   # slot 0 = initial state, so outs[l][0:T'] is the h_{t-1} matrix
         # (on the layer's sweep stream: five small broadcast copies in front of the first GEMM were ~0.25 ms of step)
         with torch.cuda.stream(s_sweep[l] if piped else main):
             if states is None:
@@ -391,7 +435,6 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
             else:
                 outs[l][0].copy_(states[l])
     ev_sw: List[List[Optional[torch.cuda.Event]]] = [[None] * len(chunks) for _ in range(L)]
-    a_s0_l0 = dims.stride * F if dims.patch > 0 else F
     # cells (chunk c, layer l) are enqueued diagonal by diagonal (c + l), a topological order in which the two
     # sweep streams never wait on work that is queued behind them
     # Sub-chunk flags: the consumer layer trails its producer by SUB steps instead of a whole chunk launch (the
@@ -404,7 +447,8 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
         ws.epoch = getattr(ws, "epoch", 0) + 1
         epoch = ws.epoch
         fidx = lambda kind, l, c, k: ((kind * L + l) * len(chunks) + c) * nsub_max + k
-    for c, l in sorted(((c, l) for c in range(len(chunks)) for l in range(L)), key=lambda cl: (cl[0] + cl[1], cl[1])):
+    for c, l in sorted(((c, l) for c in range(len(chunks)) for l in range(L if not stacked else 0)),
+                       key=lambda cl: (cl[0] + cl[1], cl[1])):
         t0, t1 = chunks[c]
         n = t1 - t0
         if flagged:
@@ -470,7 +514,7 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
                         _p(ws.sync_ws(l, Tp, dev, B, H)) if mode >= 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
                 if piped:
                     ev_sw[l][c] = _ev(ss)
-    if piped:
+    if piped and not stacked:
         # One join is enough: the last chunk of the top layer's sweep transitively depends on every GEMM and sweep
         # enqueued above.  (Each wait is a barrier packet the command processor works through one by one: the 10-15
         # joins that used to sit here and at the end of the backward pass cost ~0.3 ms of idle chip each.)

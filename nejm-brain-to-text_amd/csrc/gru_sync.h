@@ -74,7 +74,7 @@ __device__ __forceinline__ void store_f4(float* base_uniform, unsigned byte_off,
 // (Seen as rare hand-off timeouts when several sweeps and GEMMs shared the chip.)
 __device__ __forceinline__ void finish_call(unsigned* sync, unsigned pset) {
   if (threadIdx.x == 0) {
-    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
     const unsigned done = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (done == total - 1u) {
       __hip_atomic_store(sync + 2, 0u, RLX_AGENT);

@@ -284,7 +284,7 @@ def test_edit_distance_random():
     np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("tag", ["h64", "h512", "patch"])
 def test_gru_sweep_modes(golden_dir, tag, mode):
     """Step-launch (0) and persistent (1) sweeps both reproduce the reference forward, and the persistent
@@ -312,7 +312,7 @@ def N_sync(T):
     return Nn.load().b2t_gru_sync_bytes(T) // 4 + 16
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_train_step_modes_vs_oracle(mode):
     """C2-shaped slice (H=512, L=2, B=40 = 2.5 row groups, T=60): loss + every gradient vs the oracle, both modes,
     run 3 times back-to-back so the persistent hand-off is exercised with warm caches."""
@@ -350,6 +350,45 @@ def test_train_step_modes_vs_oracle(mode):
                 np.testing.assert_allclose(got[k], ref, atol=1e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=f"{k} rep{rep}")
         if mode >= 1:
             ops.gru_sync_check_all(model._ws, L, T, B, dev, H)
+    finally:
+        ops.GRU_MODE["value"] = old
+
+
+@pytest.mark.parametrize("B,H,L,T,drop", [(64, 512, 5, 40, 0.4), (40, 512, 3, 33, 0.0), (23, 96, 4, 21, 0.3), (70, 256, 2, 17, 0.2)])
+def test_gru_stack_matches_layer_sweeps(B, H, L, T, drop):
+    """Mode 4 (all layers in one persistent launch, projections and inter-layer dropout inside) against the per-layer
+    plan (mode 1: GEMM + dropout kernel + sweep per layer) on the same inputs and seeds: logits, final states, every
+    saved tensor the backward reads (layer outputs, their dropped copies, gate reserves); repeated to exercise the
+    self-cleaning counters."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    dev = _dev()
+    F, D, C = 64, 3, 41
+    torch.manual_seed(B + H)
+    model = GRUDecoder(F, H, D, C, drop, 0.0, L, 0, 0).to(dev).train()
+    x = torch.randn(B, T, F, device=dev) * 0.5
+    day = torch.randint(0, D, (B,), device=dev, dtype=torch.int32)
+    prm, dims = model._kernel_params(), model._dims
+    old = ops.GRU_MODE["value"]
+    res = {}
+    try:
+        for mode in (1, 4, 4, 4):
+            ops.GRU_MODE["value"] = mode
+            logits, hidden, ctx = ops.model_forward(dims, prm, x, day, None, model._ws, True, 0.0, drop, seed=77)
+            torch.cuda.synchronize()
+            model._ws.check_sync()
+            got = dict(logits=logits, hidden=hidden, **{f"out{l}": ctx.outs[l] for l in range(L)},
+                       **{f"outd{l}": ctx.outs_d[l] for l in range(L)}, **{f"res{l}": ctx.reserves[l] for l in range(L)})
+            got = {k: v.cpu().numpy().copy() for k, v in got.items()}
+            if mode == 1:
+                res = got
+                continue
+            for k, ref in res.items():
+                a, r = (got[k][1:], ref[1:]) if k.startswith("outd") else (got[k], ref)   # slab 0 of a dropped copy is unused
+                np.testing.assert_allclose(a, r, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=k)
+            if drop > 0:   # identical masks: the zeros of the dropped copies coincide exactly
+                for l in range(L - 1):
+                    np.testing.assert_array_equal(got[f"outd{l}"][1:] == 0, res[f"outd{l}"][1:] == 0)
     finally:
         ops.GRU_MODE["value"] = old
 
