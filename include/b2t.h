@@ -103,6 +103,8 @@ int b2t_patch_fold_f32(const float* dv, float* du, int B, int T, int F, int Tp,
  * forward and backward apply the same mask. In place allowed. */
 int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t seed, long long elem0,
                     void* stream);
+/* the factors themselves: y[i] = 0 or 1/(1-p), the mask b2t_dropout_f32 applies for the same (seed, elem0) */
+int b2t_dropout_mask_f32(float* y, long long n, float p, uint64_t seed, long long elem0, void* stream);
 
 /* ---- a5: GRU layer sweep (torch.nn.GRU at rnn_model.py:65-72,126) --------------------------
  * One layer, all T steps.  gi [T][B][3H] = W_ih x_t + b_ih (precomputed by b2t_gemm_f32),
@@ -152,9 +154,9 @@ int b2t_gru_layer_bwd_flagged_f32(const float* dY, const float* dh_last, const f
 /* ---- a5 (mode 4): the whole GRU stack as ONE persistent launch (nn.GRU forward, rnn_model.py:126, all layers).
  * Layer 0 reads its input projection gi0 [T][B][3H] (b_ih folded in) from a GEMM that ran before; layers l >= 1 form
  * x_t W_ih^T inside the sweep from the tile layer l-1 has just published.  out[l] is [T+1][B][H]: slab 0 holds the
- * initial state on entry, slab t+1 receives h_t.  When drop_p > 0 and out_drop[l] is given, layer l also writes the
- * kept/scaled copy (nn.GRU inter-layer dropout; same mask as b2t_dropout_f32(seed = drop_seed[l], elem0 = 0) over
- * slabs 1..T) to out_drop[l] (same layout), and layer l+1 consumes that copy.  reserve[l]: [T][B][4H] or NULL.
+ * initial state on entry, slab t+1 receives h_t.  nn.GRU inter-layer dropout: when drop_mask[l] ([T][B][H] factors, 0 or
+ * 1/(1-p), e.g. from b2t_dropout_mask_f32) and out_drop[l] are given, layer l also writes h_t * mask to out_drop[l] (same
+ * layout as out[l]) and layer l+1 consumes that copy.  reserve[l]: [T][B][4H] or NULL.
  * sync_ws: b2t_gru_sync_bytes() bytes, zeroed once, one per concurrent call.  Returns 4 (and launches nothing) when the
  * shape is not covered -- (H/16) * L * ceil(B/64) workgroups must be resident at once, H <= 512 -- the caller then runs
  * the per-layer sweeps. */
@@ -168,9 +170,8 @@ typedef struct {
   const float* b_ih[B2T_STACK_MAX_LAYERS];   /* [0] unused */
   float* out[B2T_STACK_MAX_LAYERS];
   float* out_drop[B2T_STACK_MAX_LAYERS];     /* NULL: no dropped copy for that layer */
+  const float* drop_mask[B2T_STACK_MAX_LAYERS];   /* NULL together with out_drop */
   float* reserve[B2T_STACK_MAX_LAYERS];
-  float drop_p;
-  uint64_t drop_seed[B2T_STACK_MAX_LAYERS];
 } b2t_gru_stack_t;
 int b2t_gru_stack_fwd_f32(const b2t_gru_stack_t* d, void* sync_ws, void* stream);
 

@@ -51,7 +51,7 @@ class GruStackDesc(C.Structure):
     _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int), ("gi0", VP),
                 ("w_hh", VP * STACK_MAX_LAYERS), ("w_ih", VP * STACK_MAX_LAYERS), ("b_hh", VP * STACK_MAX_LAYERS),
                 ("b_ih", VP * STACK_MAX_LAYERS), ("out", VP * STACK_MAX_LAYERS), ("out_drop", VP * STACK_MAX_LAYERS),
-                ("reserve", VP * STACK_MAX_LAYERS), ("drop_p", C.c_float), ("drop_seed", C.c_uint64 * STACK_MAX_LAYERS)]
+                ("drop_mask", VP * STACK_MAX_LAYERS), ("reserve", VP * STACK_MAX_LAYERS)]
 
 
 class LexLmDesc(C.Structure):
@@ -75,6 +75,7 @@ _SIGNATURES = {
     "b2t_day_reduce_f32": (C.c_int, [VP, VP, C.c_int, LL, VP, LL, VP]),
     "b2t_patch_fold_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_dropout_f32": (C.c_int, [VP, VP, LL, C.c_float, C.c_uint64, LL, VP]),
+    "b2t_dropout_mask_f32": (C.c_int, [VP, LL, C.c_float, C.c_uint64, LL, VP]),
     "b2t_gru_sync_bytes": (C.c_size_t, [C.c_int]),
     "b2t_gru_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "b2t_gru_sync_status": (C.c_int, [VP, C.c_int, C.c_int, C.POINTER(C.c_int), VP]),

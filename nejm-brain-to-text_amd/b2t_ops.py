@@ -256,14 +256,20 @@ def gru_stack_forward(dims, prm, gi0, outs, outs_d, reserves, Tp, B, rnn_drop, s
     d = N.GruStackDesc()
     d.T, d.B, d.H, d.L = Tp, B, H, L
     d.gi0 = gi0.data_ptr()
-    d.drop_p = float(rnn_drop)
     for l in range(L):
         d.w_hh[l] = prm.w_hh[l].data_ptr(); d.b_hh[l] = prm.b_hh[l].data_ptr()
         d.w_ih[l] = prm.w_ih[l].data_ptr(); d.b_ih[l] = prm.b_ih[l].data_ptr()
         d.out[l] = outs[l].data_ptr()
-        d.out_drop[l] = outs_d[l].data_ptr() if outs_d[l] is not outs[l] else None
         d.reserve[l] = reserves[l].data_ptr() if reserves[l] is not None else None
-        d.drop_seed[l] = (seed * 1000003 + 101 + l) & 0xFFFFFFFFFFFFFFFF
+        if outs_d[l] is not outs[l]:
+            # nn.GRU inter-layer dropout (rnn_model.py:70): the factors are made here (whole chip, one write pass), the
+            # producing layer multiplies its tile by them -- Philox inside the sweep was its longest VALU chain
+            mask = ws.get(f"stack_mask{l}", (Tp, B, H), dev)
+            N.check(N.load().b2t_dropout_mask_f32(_p(mask), Tp * B * H, float(rnn_drop),
+                                                  C.c_uint64((seed * 1000003 + 101 + l) & 0xFFFFFFFFFFFFFFFF), 0, _stream()),
+                    "b2t_dropout_mask_f32")
+            d.out_drop[l] = outs_d[l].data_ptr()
+            d.drop_mask[l] = mask.data_ptr()
     with _Prof("gru_stack_fwd", 2.0 * Tp * B * 3 * H * H * (2 * L - 1), 1):
         rc = N.load().b2t_gru_stack_fwd_f32(C.byref(d), _p(ws.sync_ws(0, Tp, dev, B, H, "stk")), _stream())
     if rc == 4:

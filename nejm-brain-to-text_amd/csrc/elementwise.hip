@@ -173,6 +173,14 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
   }
 }
 
+__global__ void dropout_mask_kernel(float* __restrict__ y, long long n4, float p, float scale, uint64_t seed, long long idx0) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 u = Philox::uniform4(seed, (uint64_t)(idx0 + i), 2u);
+    reinterpret_cast<float4*>(y)[i] = make_float4(u.x >= p ? scale : 0.f, u.y >= p ? scale : 0.f, u.z >= p ? scale : 0.f,
+                                                  u.w >= p ? scale : 0.f);
+  }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   __shared__ float tile[32][33];
   int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
@@ -284,6 +292,15 @@ extern "C" int b2t_dropout_f32(const float* x, float* y, long long n, float p, u
   int blocks = (int)((n4 + 255) / 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n4, p, 1.0f / (1.0f - p), seed, elem0 / 4);
   B2T_CHECK_LAUNCH("b2t_dropout_f32");
+  return 0;
+}
+
+extern "C" int b2t_dropout_mask_f32(float* y, long long n, float p, uint64_t seed, long long elem0, void* stream) {
+  B2T_REQUIRE(y && n > 0 && (n % 4) == 0 && (elem0 % 4) == 0 && p >= 0.f && p < 1.f, "dropout_mask: bad args n=%lld p=%f", n, (double)p);
+  long long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, n4, p, 1.0f / (1.0f - p), seed, elem0 / 4);
+  B2T_CHECK_LAUNCH("b2t_dropout_mask_f32");
   return 0;
 }
 

@@ -35,6 +35,16 @@ __device__ __forceinline__ void issue_load_sc1_x4_imm(f32x4& dst, u32x4s rsrc, u
 __device__ __forceinline__ void issue_store_x4(u32x4s rsrc, unsigned byte_off, f32x4 v) {   // ordinary 16-byte store
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(byte_off), "s"(rsrc) : "memory");
 }
+// 16-byte stores through per-lane pointers (lanes of one instruction may address different buffers)
+__device__ __forceinline__ void issue_store_sc1_x4_ptr(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void issue_store_x4_ptr(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void issue_load_x4_ptr(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
 __device__ __forceinline__ void issue_load_buf_f32(float& dst, u32x4s rsrc, unsigned byte_off) {
   asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rsrc) : "memory");
 }

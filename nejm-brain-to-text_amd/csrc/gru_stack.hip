@@ -30,7 +30,8 @@
 namespace b2t {
 
 constexpr int STACK_MAXL = B2T_STACK_MAX_LAYERS;
-constexpr int STACK_LDS_FLOATS = 3 * (4 * 3 * 4 * 64) + 5 * 16 * TP + 8 * 4 * SLOT_F;
+constexpr int STG_F = 6 * 4 * TP;   // a gate wave's staged rows: [h, dropped h, r, z, n, gh_n][4 rows][TP]
+constexpr int STACK_LDS_FLOATS = 2 * 8 * (4 * 4 * 64) + 8 * 4 * SLOT_F + 4 * STG_F;
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
 template <int N, typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -49,39 +50,38 @@ struct StackFwd {
   float* out[STACK_MAXL];
   float* outd[STACK_MAXL];
   float* reserve[STACK_MAXL];
-  unsigned long long seed[STACK_MAXL];
-  float drop_p, drop_scale;
+  const float* mask[STACK_MAXL];   // [T][B][H] keep/scale factors of layer l's output, or null
   int T, B, H;
 };
 
 // LDS-only barrier (no vmcnt drain: the prefetched loads stay in flight across it)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// NCH: 16-wide K chunks per wave (H <= 64*NCH); EXACT: H == 64*NCH, the chunk offsets are instruction immediates
+// NC: 16-wide K chunks per wave and operand (H <= 128*NC, NC even); EXACT: H == 128*NC (chunk offsets are immediates)
 //
-// Schedule of one iteration k (item k = (t, r) for the recurrent waves; the projection waves work ONE ITEM AHEAD):
-//   recurrent waves 0-3:  MFMAs of item k ...................... | partials -> LDS | B1 | reduce + gates(k) -> tiles | B2
-//   projection waves 4-7: first 3/8 of the MFMAs of item k+1 ... |                  B1 | rest of the MFMAs, partials  | B2
-// so the two waves of a SIMD share the MFMA pipe before B1 and the gate phase (LDS reads, exp, rcp: ~2000 cycles with
-// no MFMA in it) runs under the projection's remaining MFMAs.  gi partials are double buffered (written in iteration
-// k-1 for item k).  Both groups prefetch the operands of their next item under their MFMAs and poll two items ahead.
-template <int NCH, bool EXACT>
+// All 8 waves are alike: wave w contracts K slice w (16*NC columns) of BOTH operands -- h_{t-1} with its W_hh piece,
+// x_t (the lower layer's output) with its W_ih piece -- so the two waves of a SIMD keep the MFMA pipe busy for each
+// other's LDS transposes and waits.  Iteration k:
+//   (a)  drain: operands of item k, polls of item k+1 have landed (prefetched an iteration ago)
+//   waves 0-3: publish item k-2 | reduce the 8 partial sets of item k-1, gates, stores of their own rows | MFMAs of item k |
+//   waves 4-7: MFMAs of item k (alone on the pipe while waves 0-3 form the gates) ..........................................|
+//   all:  the loads of item k+1 between the MFMAs, polls of item k+2, partials of item k -> LDS (double buffered)      |B1|
+// ONE barrier per item.  The gate phase of an item runs under the other wave's MFMAs of the next item; a gate wave
+// stages and stores the four rows it owns itself (no cross-wave tile, no second barrier).
+template <int NC, bool EXACT>
 __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A, unsigned* sync) {
   constexpr int R = 4;
-  constexpr int NAP = NCH >= 8 ? 1 : 0;   // projection chunk PAIRS contracted before B1 (what fits the recurrent waves' gaps)
-  constexpr int PART = 4 * 3 * 4 * 64;
+  constexpr int NL = 2 * NC;            // operand load instructions per item: [0, NC) h, [NC, 2 NC) x
+  constexpr int NP = NC;                // chunk pairs per item: [0, NC/2) h, [NC/2, NC) x
+  constexpr int PART = 4 * 4 * 64;      // one wave's partials: [r, z (h and x parts summed), n from h, n from x][4][64]
   extern __shared__ __attribute__((aligned(16))) float red[];   // STACK_LDS_FLOATS in use + padding (see the launcher)
-  float* redr = red;               // recurrent partials [4 waves][3 gates][4][64]
-  float* redp = red + PART;        // projection partials, [2] of the same
-  float* hs = red + 3 * PART;      // staged tiles [h, r, z, n, gh_n][16 rows][TP]
-  float* tslot = hs + 5 * 16 * TP + (threadIdx.x >> 6) * 4 * SLOT_F;   // this wave's two transpose slot pairs
+  float* tslot = red + 2 * 8 * PART + (threadIdx.x >> 6) * 4 * SLOT_F;   // this wave's two transpose slot pairs
+  float* stg = red + 2 * 8 * PART + 8 * 4 * SLOT_F + (threadIdx.x >> 6) * STG_F;   // gate waves: own rows [6 arrays][4 rows][TP]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: everything selected by it stays scalar
-  const int half = wave >> 2, kw = wave & 3;
-  const bool proj = half == 1;
+  const bool gatew = wave < 4;          // waves 0-3 also form the gates (thread = row 4 q + wave, unit j)
   const int l = blockIdx.y;
   const int T = A.T, B = A.B, H = A.H;
-  if (proj) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);   // the recurrent waves are the critical path
   const unsigned G = gridDim.x;
   const int j = lane & 15, q = lane >> 4;
   const int j0 = blockIdx.x * 16, unit = j0 + j;
@@ -95,72 +95,67 @@ __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A,
       other[i] = 0u;
   }
   unsigned* cset = counter_set(sync, pset);
-  const int nch = H / 16;
-  const bool feeds = proj && l > 0;        // this wave contracts the lower layer's output
-  const bool works = !proj || l > 0;       // layer 0's projection was done by a GEMM: its waves 4-7 only store the reserve
-  const int ldep = feeds ? l - 1 : l;      // layer whose counters this wave polls
-  const int ioff = proj ? 1 : 0;           // the projection waves run one item ahead
+  const bool first = l == 0;            // layer 0: gi comes from the GEMM, nothing to project
 
-  const float* wsrc = feeds ? A.w_ih[l] : A.w_hh[l];
-  float4 w[3][NCH];
+  // weights: chunk ci of this wave = columns [wave*16*NC + 16 ci, +16) of W_hh (wh) and W_ih (wx)
+  float4 wh[3][NC], wx[3][NC];
 #pragma unroll
-  for (int ci = 0; ci < NCH; ++ci) {
-    const int c = KCHUNK(kw, ci, NCH);
+  for (int ci = 0; ci < NC; ++ci) {
+    const int col = (wave * NC + ci) * 16 + 4 * q;
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
-      w[g][ci] = (works && c < nch) ? *reinterpret_cast<const float4*>(wsrc + ((long long)g * H + unit) * H + c * 16 + 4 * q)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 3; ++g) {
+      wh[g][ci] = col < H ? *reinterpret_cast<const float4*>(A.w_hh[l] + ((long long)g * H + unit) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wx[g][ci] = (!first && col < H) ? *reinterpret_cast<const float4*>(A.w_ih[l] + ((long long)g * H + unit) * H + col)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   const float* bh = A.b_hh[l];
   float br = bh[unit], bz = bh[H + unit], bin = 0.f;   // r, z: b_hh + b_ih (layer 0: b_ih is inside gi0)
   const float bhn = bh[2 * H + unit];
-  if (l > 0) { const float* bi = A.b_ih[l]; br += bi[unit]; bz += bi[H + unit]; bin = bi[2 * H + unit]; }
-  const bool first = l == 0;
-  const unsigned long long seed_l = A.seed[l];
-  const float drop_p = A.drop_p, drop_scale = A.drop_scale;
+  if (!first) { const float* bi = A.b_ih[l]; br += bi[unit]; bz += bi[H + unit]; bin = bi[2 * H + unit]; }
+  const float* maskp = A.mask[l];
 
   float* outp = A.out[l];                   // [T+1][B][H]: slab 0 = initial state, slab t+1 = h_t
   float* outdp = A.outd[l];
-  const bool has_d = outdp != outp;
-  const float* opbase = feeds ? A.outd[l - 1] : outp;   // operand of item (t, r): slab t + half
+  const bool has_d = maskp != nullptr;
+  const float* xbase = first ? outp : A.outd[l - 1];   // x_t = slab t+1 of the lower layer's (dropped) output
   float* resv = A.reserve[l];
-  const unsigned* cdep = cset + (size_t)ldep * nrg * T;
   unsigned* cown = cset + (size_t)l * nrg * T;
+  const unsigned* clow = cset + (size_t)(first ? 0 : l - 1) * nrg * T;
 
-  // my output row (gates) and my operand row (MFMA A fragment) in row group r, clamped into the batch; recomputed
-  // where needed (registers are the scarce resource of this kernel)
-  auto orow_of = [&](int r, int q_) { const int ro = (rg0 + r) * 16 + 4 * q_ + kw; return ro < B ? ro : B - 1; };
-  auto arow_of = [&](int r, int j_) { const int ra = (rg0 + r) * 16 + j_; return ra < B ? ra : B - 1; };
-  auto orow = [&](int r) { const int ro = (rg0 + r) * 16 + 4 * q + kw; return ro < B ? ro : B - 1; };
-  auto arow = [&](int r) { const int ra = (rg0 + r) * 16 + j; return ra < B ? ra : B - 1; };
+  // h_{t-1} of my gate element, per row group (gate waves)
   float hp[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) hp[r] = outp[(long long)orow(r) * H + unit];
-  // Operand loads are issued LINE BY LINE (instruction i: rows 8 (i & 1) + lane / 8 of the row group, the 32 floats
-  // from column kw * 16 NCH + 32 (i >> 1), 8 consecutive lanes per 128-byte line) and transposed into MFMA fragments
-  // through a per-wave LDS slot pair when they are consumed (gru_sync.h: the fragment-shaped load runs the texture
-  // addresser at 16 B/clock/CU, 64 KB per item here = 4096 cycles during which every store and poll of the workgroup
-  // queues behind it; measured: the reserve store stalled 2700 cycles at issue).
-  static_assert(NCH % 2 == 0, "chunks are loaded in pairs");
-  unsigned coff[EXACT ? 1 : NCH / 2];   // byte offset of my 16-byte piece of column block i >> 1 inside a row
+  for (int r = 0; r < R; ++r) {
+    const int ro = (rg0 + r) * 16 + 4 * q + (wave & 3);
+    hp[r] = outp[(long long)(ro < B ? ro : B - 1) * H + unit];
+  }
+
+  // Operand loads are issued LINE BY LINE (instruction i of an operand: rows 8 (i & 1) + lane / 8 of the row group, the
+  // 32 floats from column wave*16*NC + 32 (i >> 1), 8 consecutive lanes per 128-byte line) and transposed into MFMA
+  // fragments through a per-wave LDS slot pair when they are consumed (gru_sync.h: the fragment-shaped load runs the
+  // texture addresser at 16 B/clock/CU -- 64 KB per item here = 4096 cycles during which every store and poll of the
+  // workgroup queues behind it; measured: the reserve store stalled 2700 cycles at issue).
+  static_assert(NC % 2 == 0, "chunks are loaded in pairs");
+  unsigned coff[EXACT ? 1 : NC / 2];   // byte offset of my 16-byte piece of column block pb inside a row
   if constexpr (EXACT) {
-    coff[0] = (unsigned)((kw * NCH * 16 + 4 * (lane & 7)) * 4);
+    coff[0] = (unsigned)((wave * NC * 16 + 4 * (lane & 7)) * 4);
   } else {
 #pragma unroll
-    for (int pb = 0; pb < NCH / 2; ++pb) {
-      const int col = kw * NCH * 16 + pb * 32 + 4 * (lane & 7);
+    for (int pb = 0; pb < NC / 2; ++pb) {
+      const int col = wave * NC * 16 + pb * 32 + 4 * (lane & 7);
       coff[pb] = (unsigned)((col < H ? col : H - 4) * 4);   // beyond the operand: any valid column (zero weights)
     }
   }
   // byte offset of (row 8 hi + lane / 8 of row group r, clamped into the batch) in a [B][H] slab
   auto lrow_of = [&](int r, int hi, int ln_) { const int ra = (rg0 + r) * 16 + 8 * hi + (ln_ >> 3); return (unsigned)(ra < B ? ra : B - 1) * (unsigned)H * 4u; };
   auto issue_frag = [&](f32x4& dst, const u32x4s& rs, unsigned rowoff_lo, unsigned rowoff_hi, auto i_c) {
-    constexpr int i = decltype(i_c)::value;
+    constexpr int i = decltype(i_c)::value;   // index within the operand
     const unsigned ro = (i & 1) ? rowoff_hi : rowoff_lo;
     if constexpr (EXACT) issue_load_sc1_x4_imm<(i >> 1) * 128>(dst, rs, ro + coff[0]);
     else issue_load_sc1_x4(dst, rs, ro + coff[i >> 1]);
   };
-  // instructions (2p, 2p+1) of an item -> the A fragments of chunks 2p and 2p+1 (slot pair sp of this wave)
+  // instructions (2p, 2p+1) of an operand -> the A fragments of its chunks 2p and 2p+1 (slot pair sp of this wave)
   auto transpose_pair_x = [&](int sp, const f32x4& v0, const f32x4& v1, f32x4& a0, f32x4& a1, int ln_) {
     float* slot = tslot + sp * 2 * SLOT_F;
     const int r8 = ln_ >> 3, p8 = ln_ & 7;
@@ -172,85 +167,60 @@ __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A,
     a1 = *reinterpret_cast<const f32x4*>(sr + 16);
   };
 
-  // counter this wave needs before it may load the operands of item (t, r): its own layer's (r, t-1) for the
-  // recurrent waves, the lower layer's (r, t) for the projection waves
-  auto poll_for = [&](int t, int r, bool& need) -> const unsigned* {
+  // counters an item (t, r) waits for: own layer (r, t-1) [t > 0], lower layer (r, t) [l > 0]
+  auto poll_own = [&](int t, int r, bool& need) -> const unsigned* {
     const int rg = rg0 + r;
-    need = (t < T) && (rg < nrg) && (proj ? l > 0 : t > 0);
-    int tc = t - 1 + half;
-    tc = tc < 0 ? 0 : (tc > T - 1 ? T - 1 : tc);
-    return cdep + (size_t)(rg < nrg ? rg : nrg - 1) * T + tc;
+    need = (t < T) && (rg < nrg) && (t > 0);
+    const int tc = t - 1 < 0 ? 0 : (t - 1 > T - 1 ? T - 1 : t - 1);
+    return cown + (size_t)(rg < nrg ? rg : nrg - 1) * T + tc;
   };
-  // operand slab of item (t, .): clamped past the end (the loads are issued, the results unused)
-  auto slab_of = [&](int t) { const int tl = t < T ? t : T - 1; return opbase + (long long)(tl + half) * B * H; };
+  auto poll_low = [&](int t, int r, bool& need) -> const unsigned* {
+    const int rg = rg0 + r;
+    need = (t < T) && (rg < nrg) && !first;
+    return clow + (size_t)(rg < nrg ? rg : nrg - 1) * T + (t < T ? t : T - 1);
+  };
+  // operand slabs of item (t, .), clamped past the end (the loads are issued, the results unused)
+  auto hslab = [&](int t) { return outp + (long long)(t < T ? t : T - 1) * B * H; };
+  auto xslab = [&](int t) { return xbase + (long long)((t < T ? t : T - 1) + 1) * B * H; };
 
-  f32x4 abuf[2][NCH];
-  float gbuf[2][3];
-  unsigned pvv = 0;
-  bool pv_need = false;
-  const unsigned* pv_ptr = cset;
+  f32x4 abuf[2][NL];
+  float gbuf[3];
+  f32x4 mk = f32x4{1.f, 1.f, 1.f, 1.f};   // dropout factors of my piece of the previous item's tile (prefetched)
+  unsigned pvh = 0, pvx = 0;
+  bool need_h = false, need_x = false;
+  const unsigned *ptr_h = cset, *ptr_x = cset;
 
-  auto mfma_chunk = [&](f32x4 (&acc)[3], const f32x4& a, auto ci_c) {
+  // acc: [0] r, [1] z (the h and the x products share an accumulator), [2] n from h, [3] n from x.  k outer, gate
+  // inner: three independent accumulators between two MFMAs on the same one.
+  auto mfma_chunk = [&](f32x4 (&acc)[4], const f32x4& a, const float4 (&w)[3][NC], auto ci_c, auto nidx_c) {
     constexpr int ci = decltype(ci_c)::value;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[g][ci].x, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[g][ci].y, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[g][ci].z, acc[g], 0, 0, 0);
-      acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[g][ci].w, acc[g], 0, 0, 0);
-    }
-  };
-  auto put_partials = [&](float* dst, const f32x4 (&acc)[3]) {
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) dst[((kw * 3 + g) * 4 + rr) * 64 + lane] = acc[g][rr];
+    constexpr int ni = decltype(nidx_c)::value;   // 2: h operand, 3: x operand
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[0][ci].x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[1][ci].x, acc[1], 0, 0, 0);
+    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[2][ci].x, acc[ni], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[0][ci].y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[1][ci].y, acc[1], 0, 0, 0);
+    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[2][ci].y, acc[ni], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[0][ci].z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[1][ci].z, acc[1], 0, 0, 0);
+    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[2][ci].z, acc[ni], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[0][ci].w, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[1][ci].w, acc[1], 0, 0, 0);
+    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[2][ci].w, acc[ni], 0, 0, 0);
   };
 
-  // ---- prologue -------------------------------------------------------------------------------------------------
-  if (proj && first) {   // layer 0: the projection "partials" are the GEMM's gi (slot kw of partial wave 0), zeros elsewhere
-    const f32x4 zero[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    put_partials(redp, zero);
-    put_partials(redp + PART, zero);
-  }
-  __syncthreads();
-  if (proj && first) {
-    const float* g3 = A.gi0 + (long long)orow(0) * 3 * H + unit;   // item (0, 0)
-#pragma unroll
-    for (int g = 0; g < 3; ++g) redp[((0 * 3 + g) * 4 + kw) * 64 + lane] = g3[(long long)g * H];
-  }
-  if (feeds) {   // gi of item (0, 0), blocking
-    bool need0;
-    const unsigned* p0 = poll_for(0, 0, need0);
-    if (need0) poll_until(p0, G, poll_once(p0), err);
-    const u32x4s rs0 = make_rsrc(slab_of(0));
-    static_for<NCH>([&](auto ci) { issue_frag(abuf[1][ci], rs0, lrow_of(0, 0, lane), lrow_of(0, 1, lane), ci); });
-    drain_vm();
-    static_for<NCH>([&](auto ci) { after_wait(abuf[1][ci]); });
-    f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    static_for<NCH / 2>([&](auto p_c) {
-      constexpr int pp = decltype(p_c)::value;
-      f32x4 a0, a1;
-      transpose_pair_x(pp & 1, abuf[1][2 * pp], abuf[1][2 * pp + 1], a0, a1, lane);
-      mfma_chunk(acc, a0, std::integral_constant<int, 2 * pp>{});
-      mfma_chunk(acc, a1, std::integral_constant<int, 2 * pp + 1>{});
-    });
-    put_partials(redp, acc);
-  }
-  {   // operands of this wave's first loop item, (0, ioff), and the poll of the one after
-    bool need0;
-    const unsigned* p0 = poll_for(0, ioff, need0);
-    if (need0) poll_until(p0, G, poll_once(p0), err);
-    const u32x4s rs0 = make_rsrc(slab_of(0));
-    static_for<NCH>([&](auto ci) { issue_frag(abuf[0][ci], rs0, lrow_of(ioff, 0, lane), lrow_of(ioff, 1, lane), ci); });
-    {   // (layer 0, projection waves: gi of item (0, 1); everyone else: a valid address, unused)
-      const u32x4s rg = make_rsrc(A.gi0);
-      const unsigned go = (unsigned)(((long long)orow(ioff) * 3 * H + unit) * 4);
-      issue_load_buf_f32(gbuf[0][0], rg, go); issue_load_buf_f32(gbuf[0][1], rg, go + (unsigned)H * 4u);
-      issue_load_buf_f32(gbuf[0][2], rg, go + (unsigned)H * 8u);
-    }
-    pv_ptr = poll_for(0, 1 + ioff, pv_need);
-    issue_poll(pvv, pv_ptr);
+  // ---- prologue: operands of item (0, 0), polls of item (0, 1) ----------------------------------------------------
+  {
+    bool n0;
+    const unsigned* p0 = poll_low(0, 0, n0);
+    if (n0) poll_until(p0, G, poll_once(p0), err);
+    const u32x4s rh = make_rsrc(hslab(0)), rx = make_rsrc(xslab(0));
+    static_for<NC>([&](auto i) { issue_frag(abuf[0][i], rh, lrow_of(0, 0, lane), lrow_of(0, 1, lane), i); });
+    static_for<NC>([&](auto i) { issue_frag(abuf[0][NC + i], rx, lrow_of(0, 0, lane), lrow_of(0, 1, lane), i); });
+    ptr_h = poll_own(0, 1, need_h); issue_poll(pvh, ptr_h);
+    ptr_x = poll_low(0, 1, need_x); issue_poll(pvx, ptr_x);
+    const u32x4s rg = make_rsrc(A.gi0);
+    issue_load_buf_f32(gbuf[0], rg, 0u); issue_load_buf_f32(gbuf[1], rg, 0u); issue_load_buf_f32(gbuf[2], rg, 0u);
   }
   drain_vm();
   __syncthreads();
@@ -265,11 +235,12 @@ __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A,
 #else
 #define SSTAMP(i)
 #endif
-  unsigned* pub_ptr = nullptr;
-  int pub_m0 = 0, pub_t = 0;
-  f32x4 tv = f32x4{0.f, 0.f, 0.f, 0.f};   // data of the assembly-issued tile store: untouched until the drain behind it
+  unsigned* pub_ptr = nullptr;     // counter of the item whose tiles have been stored but not published yet
+  f32x4 tv = f32x4{0.f, 0.f, 0.f, 0.f}, tv2 = f32x4{0.f, 0.f, 0.f, 0.f};   // data of the assembly-issued stores: untouched until the drain behind them
 
-  for (int t = 0; t < T; ++t) {
+  // t runs to T inclusive: the extra round only finishes the last items (gates, stores, publish); its MFMAs run on
+  // clamped operands and are never used
+  for (int t = 0; t <= T; ++t) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int P = r & 1;
@@ -278,158 +249,155 @@ __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A,
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const int jj = ln & 15, qq = ln >> 4;
-      // (a) everything issued an item ago has landed (full drain: see gru_pipeline.hip on vmcnt(n > 0))
+      const int rn = (r + 1) & 3, tn = t + ((r + 1) >> 2);      // next item (operands prefetched now)
+      const int r2 = (r + 2) & 3, t2 = t + ((r + 2) >> 2);      // the one after (polled now)
+      const int rp = (r + 3) & 3, tp = t - 1 + ((r + 3) >> 2);  // previous item (gates now)
+      const bool gvalid = tp >= 0 && tp < T && (rg0 + rp) < nrg;
+      // (a) everything issued an iteration ago has landed (full drain: see gru_pipeline.hip on vmcnt(n > 0))
       drain_vm();
-      keep_until_here(tv);
-      after_wait(pvv);
+      keep_until_here(tv); keep_until_here(tv2);
+      after_wait(pvh); after_wait(pvx);
 #pragma unroll
-      for (int ci = 0; ci < NCH; ++ci) after_wait(abuf[P][ci]);
-      after_wait(gbuf[P][0]); after_wait(gbuf[P][1]); after_wait(gbuf[P][2]);
+      for (int i = 0; i < NL; ++i) after_wait(abuf[P][i]);
+      after_wait(gbuf[0]); after_wait(gbuf[1]); after_wait(gbuf[2]); after_wait(mk);
       SSTAMP(0)
       {
-        const unsigned pv = __builtin_amdgcn_readfirstlane(pvv);
-        if (pv_need && pv < G) poll_until(pv_ptr, G, pv, err);
+        const unsigned vh = __builtin_amdgcn_readfirstlane(pvh), vx = __builtin_amdgcn_readfirstlane(pvx);
+        if (need_h && vh < G) poll_until(ptr_h, G, vh, err);
+        if (need_x && vx < G) poll_until(ptr_x, G, vx, err);
       }
       SSTAMP(1)
-      // (b) the previous item's tiles go out as 64 x 16 B per array: wave 0 the h tile, wave 1 its dropped copy, waves
-      // 4-7 the four saved arrays (r, z, n, gh_n) of the reserve
-      const bool publisher = pub_ptr != nullptr && (wave == 0 || (wave == 1 && has_d));
-      if (pub_ptr != nullptr && (wave == 0 || (wave == 1 && has_d) || (proj && resv != nullptr))) {
-        const int r4 = ln >> 2, c4 = (ln & 3) * 4;
-        const float* tile = hs + (proj ? (1 + kw) * 16 * TP : 0);
-        tv[0] = tile[r4 * TP + c4]; tv[1] = tile[r4 * TP + c4 + 1]; tv[2] = tile[r4 * TP + c4 + 2]; tv[3] = tile[r4 * TP + c4 + 3];
-        if (wave == 1) {
-          const long long e = ((long long)pub_t * B + (pub_m0 + r4)) * H + j0 + c4;   // element index from slab 1
-          const float4 u = Philox::uniform4(seed_l, (uint64_t)(e >> 2), 2u);
-          tv[0] = u.x >= drop_p ? tv[0] * drop_scale : 0.f;
-          tv[1] = u.y >= drop_p ? tv[1] * drop_scale : 0.f;
-          tv[2] = u.z >= drop_p ? tv[2] * drop_scale : 0.f;
-          tv[3] = u.w >= drop_p ? tv[3] * drop_scale : 0.f;
-        }
-        if (pub_m0 + r4 < B) {
-          if (proj) issue_store_x4(make_rsrc(resv + (long long)pub_t * B * 4 * H),
-                                   (unsigned)(((long long)(pub_m0 + r4) * 4 * H + kw * H + j0 + c4) * 4), tv);
-          else issue_store_sc1_x4(make_rsrc((wave == 1 ? outdp : outp) + (long long)(pub_t + 1) * B * H),
-                                  (unsigned)(((long long)(pub_m0 + r4) * H + j0 + c4) * 4), tv);
-        }
-      }
-
-      f32x4 acc[3];
-#pragma unroll
-      for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      constexpr int LPG = NCH >= 8 ? 2 : 1;   // next-item fragment loads per MFMA group: all go out in the first half
-      const int m0 = (rg0 + r) * 16;
-      // This wave's next item (operands prefetched now) and the one after (polled now); the projection waves are one
-      // item ahead.  NOTE: every assembly statement with an OUTPUT register (loads, polls) sits in code common to both
-      // wave groups: defined inside `if (proj) .. else ..` the two definitions meet in a phi, and a copy the register
-      // allocator places there would read the register while the load is still in flight.
-      const int rn = proj ? ((r + 2) & 3) : ((r + 1) & 3), tn = t + (proj ? ((r + 2) >> 2) : ((r + 1) >> 2));
-      const int r2 = proj ? ((r + 3) & 3) : ((r + 2) & 3), t2 = t + (proj ? ((r + 3) >> 2) : ((r + 2) >> 2));
-      const u32x4s rsn = make_rsrc(slab_of(tn));
+      const u32x4s rsh = make_rsrc(hslab(tn)), rsx = make_rsrc(xslab(tn));
       const unsigned rown_lo = lrow_of(rn, 0, ln), rown_hi = lrow_of(rn, 1, ln);
-      const u32x4s rgi = make_rsrc(A.gi0 + (long long)(tn < T ? tn : T - 1) * B * 3 * H);
-      const unsigned goff = (unsigned)(((long long)orow_of(rn, qq) * 3 * H + (j0 + jj)) * 4);
-      if (proj && first) {
-        // layer 0: the GEMM's gi of item k+1 (loaded an item ago) goes where the gate threads expect projection partials
-        float* dst = redp + (P ^ 1) * PART;
+      const int m0p = (rg0 + rp) * 16;
+      f32x4 acc[4];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) dst[((0 * 3 + g) * 4 + kw) * 64 + ln] = gbuf[P][g];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSTAMP(2)
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 fr[2][2];   // fragments of the pair being contracted and of the next one (transposed one pair ahead)
-      if (works) transpose_pair_x(0, abuf[P][0], abuf[P][1], fr[0][0], fr[0][1], ln);
-      static_for<NCH / 2>([&](auto p_c) {
+      transpose_pair_x(0, abuf[P][0], abuf[P][1], fr[0][0], fr[0][1], ln);
+      __builtin_amdgcn_sched_barrier(0);
+
+      if (gatew) {
+        // ---- gates of the previous item: 8 partial sets -> r, z, n, h -> this wave's 4 rows ------------------------
+#ifndef B2T_STACK_NO_PRIO
+        __builtin_amdgcn_s_setprio(3);   // non-MFMA work next to the other wave's MFMA stream gets ~1 issue slot in 16 cycles
+#endif
+        if (wave == 0 && pub_ptr != nullptr && ln == 0) __hip_atomic_fetch_add(pub_ptr, 1u, RLX_AGENT);   // item k-2
+        const float* rd = red + (P ^ 1) * 8 * PART;   // partials of item k-1
+        float sm[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+          for (int w8 = 0; w8 < 8; w8 += 2) {
+            a0 += rd[w8 * PART + (g * 4 + wave) * 64 + ln];
+            a1 += rd[(w8 + 1) * PART + (g * 4 + wave) * 64 + ln];
+          }
+          sm[g] = a0 + a1;
+        }
+        // layer 0: x parts are zero (no W_ih here), the GEMM's gi (b_ih folded in) takes their place
+        const float xr = first ? gbuf[0] : 0.f, xz = first ? gbuf[1] : 0.f, xn = first ? gbuf[2] : sm[3] + bin;
+        const float ghn = sm[2] + bhn;
+        const float rr = fast_sigmoid(sm[0] + xr + br);
+        const float zz = fast_sigmoid(sm[1] + xz + bz);
+        const float nn = fast_tanh(xn + rr * ghn);
+        const float h = (1.0f - zz) * nn + zz * hp[rp];
+        if (gvalid) hp[rp] = h;
+        // my element is (row 4 qq + wave, unit jj): stage the wave's 4 rows x 16 units of each array and write them as
+        // 16-byte pieces -- lanes 16 a .. 16 a + 15 take array a: first (write-through, the hand-off payload) h and its
+        // dropped copy, then (ordinary stores) r, z, n, gh_n of the reserve
+        const int ti = qq * TP + jj;
+        stg[ti] = h; stg[2 * 4 * TP + ti] = rr; stg[3 * 4 * TP + ti] = zz; stg[4 * 4 * TP + ti] = nn; stg[5 * 4 * TP + ti] = ghn;
+        {
+          const int arr = ln >> 4, lr = (ln >> 2) & 3, c4 = (ln & 3) * 4;
+          const int row = m0p + 4 * lr + wave;
+          const bool rowok = gvalid && row < B;
+          const float* sp = stg + lr * TP + c4;
+          tv = *reinterpret_cast<const f32x4*>(sp);   // h (all lanes; lanes >= 32 do not store it)
+          tv2 = *reinterpret_cast<const f32x4*>(sp + (2 + arr) * 4 * TP);
+          if (has_d && arr == 1) tv = tv * mk;   // nn.GRU inter-layer dropout: factors 0 or 1/(1-p), made before the launch
+          const long long eo = (long long)(rowok ? row : 0) * H + j0 + c4;
+          float* p1 = (arr == 1 ? outdp : outp) + (long long)(tp + 1) * B * H + eo;
+          if (rowok && (arr == 0 || (arr == 1 && has_d))) issue_store_sc1_x4_ptr(p1, tv);
+          if (rowok && resv != nullptr)
+            issue_store_x4_ptr(resv + ((long long)tp * B + row) * 4 * H + arr * H + j0 + c4, tv2);
+        }
+#ifndef B2T_STACK_NO_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        SSTAMP(2)
+      }
+      SSTAMP(3)
+      static_for<NP>([&](auto p_c) {
         constexpr int pp = decltype(p_c)::value;
-        if constexpr (pp == NAP) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (proj) lds_barrier();   // B1 of the projection waves
-          __builtin_amdgcn_sched_barrier(0);
+        constexpr bool isx = pp >= NC / 2;
+        constexpr int po = isx ? pp - NC / 2 : pp;            // pair index within the operand
+        if constexpr (pp + 1 < NP) {
+          constexpr int pn = pp + 1;
+          constexpr int base = (pn >= NC / 2) ? NC + 2 * (pn - NC / 2) : 2 * pn;
+          transpose_pair_x(pn & 1, abuf[P][base], abuf[P][base + 1], fr[pn & 1][0], fr[pn & 1][1], ln);
         }
-        if constexpr (pp + 1 < NCH / 2)
-          if (works) transpose_pair_x((pp + 1) & 1, abuf[P][2 * pp + 2], abuf[P][2 * pp + 3], fr[(pp + 1) & 1][0], fr[(pp + 1) & 1][1], ln);
-        static_for<2 * LPG>([&](auto k_c) {
-          constexpr int li = pp * 2 * LPG + decltype(k_c)::value;
-          if constexpr (li < NCH) issue_frag(abuf[P ^ 1][li], rsn, rown_lo, rown_hi, std::integral_constant<int, li>{});
-        });
-        if constexpr (pp == NCH / 2 - 1) {   // (only layer 0's projection waves use these)
-          issue_load_buf_f32(gbuf[P ^ 1][0], rgi, goff); issue_load_buf_f32(gbuf[P ^ 1][1], rgi, goff + (unsigned)H * 4u);
-          issue_load_buf_f32(gbuf[P ^ 1][2], rgi, goff + (unsigned)H * 8u);
+        // the next item's loads all go out in the first half of the MFMA stream (4 per pair), so that the drain in front
+        // of the publish does not wait for fresh loads
+        if constexpr (pp < NP / 2) {
+          static_for<4>([&](auto k_c) {
+            constexpr int li = 4 * pp + decltype(k_c)::value;      // 0 .. 2 NC - 1: [0, NC) h, [NC, 2 NC) x
+            if constexpr (li < NC) issue_frag(abuf[P ^ 1][li], rsh, rown_lo, rown_hi, std::integral_constant<int, li>{});
+            else if constexpr (li < NL) issue_frag(abuf[P ^ 1][li], rsx, rown_lo, rown_hi, std::integral_constant<int, li - NC>{});
+          });
         }
-        if (works) {
-          mfma_chunk(acc, fr[pp & 1][0], std::integral_constant<int, 2 * pp>{});
-          mfma_chunk(acc, fr[pp & 1][1], std::integral_constant<int, 2 * pp + 1>{});
+#ifdef B2T_EXPERIMENT_B_IDLE   // timing experiment only (wrong results): waves 4-7 issue no MFMAs
+        if (gatew)
+#endif
+        if constexpr (!isx) {
+          mfma_chunk(acc, fr[pp & 1][0], wh, std::integral_constant<int, 2 * po>{}, std::integral_constant<int, 2>{});
+          mfma_chunk(acc, fr[pp & 1][1], wh, std::integral_constant<int, 2 * po + 1>{}, std::integral_constant<int, 2>{});
+        } else {
+          mfma_chunk(acc, fr[pp & 1][0], wx, std::integral_constant<int, 2 * po>{}, std::integral_constant<int, 3>{});
+          mfma_chunk(acc, fr[pp & 1][1], wx, std::integral_constant<int, 2 * po + 1>{}, std::integral_constant<int, 3>{});
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
+      asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
       __builtin_amdgcn_sched_barrier(0);
-      SSTAMP(3)
-      // the tile stores are a whole MFMA phase old: drain them (the publish follows B1, which joins the two storing
-      // waves); then the poll of the item after next
-      if (publisher) drain_vm();
-      keep_until_here(tv);
-      pv_ptr = poll_for(t2, r2, pv_need);
-      issue_poll(pvv, pv_ptr);
       SSTAMP(4)
-      if (proj) {
-        if (works) put_partials(redp + (P ^ 1) * PART, acc);
-        SSTAMP(5)
-        lds_barrier();   // B2
-      } else {
-        put_partials(redr, acc);
-        lds_barrier();   // B1
-        SSTAMP(5)
-        if (wave == 0 && pub_ptr != nullptr && ln == 0) __hip_atomic_fetch_add(pub_ptr, 1u, RLX_AGENT);
-        float gh[3], gx[3];
-        const float* rp = redp + P * PART;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const float s0 = redr[((0 * 3 + g) * 4 + kw) * 64 + ln], s1 = redr[((1 * 3 + g) * 4 + kw) * 64 + ln];
-          const float s2 = redr[((2 * 3 + g) * 4 + kw) * 64 + ln], s3 = redr[((3 * 3 + g) * 4 + kw) * 64 + ln];
-          gh[g] = (s0 + s1) + (s2 + s3);
-          const float x0 = rp[((0 * 3 + g) * 4 + kw) * 64 + ln], x1 = rp[((1 * 3 + g) * 4 + kw) * 64 + ln];
-          const float x2 = rp[((2 * 3 + g) * 4 + kw) * 64 + ln], x3 = rp[((3 * 3 + g) * 4 + kw) * 64 + ln];
-          gx[g] = (x0 + x1) + (x2 + x3);
+      // the gate waves' stores are a whole MFMA phase old: drain them (the publish follows B1, which joins the four)
+      if (gatew && gvalid) drain_vm();
+      keep_until_here(tv); keep_until_here(tv2);
+      pub_ptr = gvalid ? cown + (size_t)(rg0 + rp) * T + tp : nullptr;
+      {   // layer 0: the GEMM's gi of THIS item, for the gates an iteration from now; polls of the item after next
+        const int tq = t < T ? t : T - 1;
+        const int ro = (rg0 + r) * 16 + 4 * qq + (wave & 3);
+        const u32x4s rg = make_rsrc(A.gi0 + (long long)tq * B * 3 * H);
+        const unsigned go = (unsigned)(((long long)(ro < B ? ro : B - 1) * 3 * H + (j0 + jj)) * 4);
+        issue_load_buf_f32(gbuf[0], rg, go); issue_load_buf_f32(gbuf[1], rg, go + (unsigned)H * 4u);
+        issue_load_buf_f32(gbuf[2], rg, go + (unsigned)H * 8u);
+        {   // dropout factors of my 16-byte piece of THIS item's tile (lanes 16-31 of the gate waves use them)
+          const int rw = (rg0 + r) * 16 + 4 * ((ln >> 2) & 3) + (wave & 3);
+          const float* mp = (has_d ? maskp : A.gi0) + (has_d ? ((long long)tq * B + (rw < B ? rw : B - 1)) * H + j0 + (ln & 3) * 4 : 0);
+          issue_load_x4_ptr(mk, mp);
         }
-        const float ghn = gh[2] + bhn;
-        const float rr = fast_sigmoid(gx[0] + gh[0] + br);
-        const float zz = fast_sigmoid(gx[1] + gh[1] + bz);
-        const float nn = fast_tanh(gx[2] + bin + rr * ghn);
-        const float h = (1.0f - zz) * nn + zz * hp[r];
-        const int ti = (4 * qq + kw) * TP + jj;
-        hs[ti] = h; hs[16 * TP + ti] = rr; hs[2 * 16 * TP + ti] = zz; hs[3 * 16 * TP + ti] = nn; hs[4 * 16 * TP + ti] = ghn;
-        hp[r] = h;
-        SSTAMP(6)
-        lds_barrier();   // B2: tiles staged; also fences the partial buffers for the next item
+        ptr_h = poll_own(t2, r2, need_h); issue_poll(pvh, ptr_h);
+        ptr_x = poll_low(t2, r2, need_x); issue_poll(pvx, ptr_x);
       }
+      SSTAMP(5)
+      {
+        float* dst = red + P * 8 * PART + wave * PART;   // partials of item k: buffer k & 1
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) dst[(g * 4 + rr) * 64 + ln] = acc[g][rr];
+      }
+      SSTAMP(6)
+      lds_barrier();   // B1: the partials of item k are complete
       SSTAMP(7)
-      pub_ptr = (m0 < B) ? cown + (size_t)(rg0 + r) * T + t : nullptr;
-      pub_m0 = m0; pub_t = t;
     }
   }
-  // the last item's tiles and publish
   drain_vm();
-  if (pub_ptr != nullptr && (wave == 0 || (wave == 1 && has_d) || (proj && resv != nullptr))) {
-    const int r4 = lane >> 2, c4 = (lane & 3) * 4;
-    if (pub_m0 + r4 < B) {
-      float4 v = *reinterpret_cast<const float4*>(&hs[(proj ? (1 + kw) * 16 * TP : 0) + r4 * TP + c4]);
-      if (wave == 1) {
-        const long long e = ((long long)pub_t * B + (pub_m0 + r4)) * H + j0 + c4;
-        const float4 u = Philox::uniform4(seed_l, (uint64_t)(e >> 2), 2u);
-        v.x = u.x >= drop_p ? v.x * drop_scale : 0.f; v.y = u.y >= drop_p ? v.y * drop_scale : 0.f;
-        v.z = u.z >= drop_p ? v.z * drop_scale : 0.f; v.w = u.w >= drop_p ? v.w * drop_scale : 0.f;
-      }
-      if (proj) store_f4<0>(resv + (long long)pub_t * B * 4 * H, (unsigned)(((long long)(pub_m0 + r4) * 4 * H + kw * H + j0 + c4) * 4), v);
-      else store_f4<PAUX>((wave == 1 ? outdp : outp) + (long long)(pub_t + 1) * B * H, (unsigned)(((long long)(pub_m0 + r4) * H + j0 + c4) * 4), v);
-    }
-    drain_vm();
-  }
-  __syncthreads();
   if (wave == 0 && pub_ptr != nullptr && lane == 0) __hip_atomic_fetch_add(pub_ptr, 1u, RLX_AGENT);
 #ifdef B2T_TIMING
-  if (lane == 0 && kw == 0 && blockIdx.x == 0 && blockIdx.z == 0 && (int)blockIdx.y == B2T_TIMING_LAYER)
-    for (int i = 0; i < 8; ++i) sync[8 + half * 8 + i] = (unsigned)(tacc[i] / (unsigned long long)(T * R));
+  if (lane == 0 && (wave & 3) == 0 && blockIdx.x == 0 && blockIdx.z == 0 && (int)blockIdx.y == B2T_TIMING_LAYER)
+    for (int i = 0; i < 8; ++i) sync[8 + (wave >> 2) * 8 + i] = (unsigned)(tacc[i] / (unsigned long long)((T + 1) * R));
 #endif
   finish_call(sync, pset);
 }
@@ -458,16 +426,15 @@ extern "C" int b2t_gru_stack_fwd_f32(const b2t_gru_stack_t* d, void* sync_ws, vo
     return 4;
   }
   B2T_REQUIRE(d->gi0 != nullptr, "gru_stack_fwd: gi0 missing");
-  B2T_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gru_stack_fwd: dropout p=%f out of range", (double)d->drop_p);
   StackFwd A;
   memset(&A, 0, sizeof(A));
   A.gi0 = d->gi0; A.T = T; A.B = B; A.H = H;
-  A.drop_p = d->drop_p; A.drop_scale = 1.0f / (1.0f - d->drop_p);
   for (int l = 0; l < L; ++l) {
     B2T_REQUIRE(d->w_hh[l] && d->b_hh[l] && d->out[l] && (l == 0 || (d->w_ih[l] && d->b_ih[l])), "gru_stack_fwd: layer %d pointers missing", l);
     A.w_hh[l] = d->w_hh[l]; A.w_ih[l] = d->w_ih[l]; A.b_hh[l] = d->b_hh[l]; A.b_ih[l] = d->b_ih[l];
-    A.out[l] = d->out[l]; A.outd[l] = (d->out_drop[l] && d->drop_p > 0.f) ? d->out_drop[l] : d->out[l];
-    A.reserve[l] = d->reserve[l]; A.seed[l] = d->drop_seed[l];
+    B2T_REQUIRE((d->drop_mask[l] == nullptr) == (d->out_drop[l] == nullptr), "gru_stack_fwd: layer %d: drop_mask and out_drop go together", l);
+    A.out[l] = d->out[l]; A.outd[l] = d->out_drop[l] ? d->out_drop[l] : d->out[l];
+    A.reserve[l] = d->reserve[l]; A.mask[l] = d->drop_mask[l];
   }
   const dim3 grid(H / 16, L, nz), block(512);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
@@ -484,9 +451,8 @@ extern "C" int b2t_gru_stack_fwd_f32(const b2t_gru_stack_t* d, void* sync_ws, vo
     }                                                                                                                  \
     hipLaunchKernelGGL((gru_stack_fwd_kernel<NCH, EX>), grid, block, dyn, s, A, sync);                                     \
   } while (0)
-  if (H <= 128) B2T_LAUNCH(2, false);
-  else if (H <= 256) B2T_LAUNCH(4, false);
-  else B2T_LAUNCH(8, true);
+  if (H <= 256) B2T_LAUNCH(2, false);
+  else B2T_LAUNCH(4, true);
 #undef B2T_LAUNCH
   return check_hip(hipGetLastError(), "gru_stack_fwd");
 }
