@@ -234,7 +234,7 @@ int b2t_lm_prologue_f32(const float* logits, const float* log_priors, float blan
  * LogAdd language_model/runtime/core/utils/utils.cc:24-30).  One workgroup per utterance, beam in LDS,
  * prefix trie + search state in the caller-provided `state` block (U * b2t_beam_state_bytes bytes), which
  * persists between calls so logp can be fed chunk by chunk (streaming).  b2t_beam_reset = Reset().
- *   logp [U][T][C] (C <= 64), lens [U] (NULL: T), first_beam <= 16 classes per frame, second_beam <= 32 prefixes.
+ *   logp [U][T][C] (C <= 64), lens [U] (NULL: T), first_beam <= 16 classes per frame, second_beam <= 128 prefixes.
  * Outputs, sorted best first (slots beyond the live beam: hyp_len = -1):
  *   hyps [U][second_beam][max_len] token ids, hyp_len [U][second_beam], score = LogAdd(s, ns), vscore = Viterbi
  *   score, times [U][second_beam][max_len] (frame of each token on the Viterbi path; may be NULL).

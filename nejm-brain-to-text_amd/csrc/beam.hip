@@ -2,7 +2,7 @@
 // language_model/runtime/core/decoder/ctc_prefix_beam_search.cc:44-136, PrefixScore at
 // ctc_prefix_beam_search.h:27-42, LogAdd at language_model/runtime/core/utils/utils.cc:24-30).
 //
-// One workgroup per utterance; the live beam (<= 32 prefixes: scores, Viterbi scores, trie node ids) lives
+// One workgroup per utterance; the live beam (<= 128 prefixes: scores, Viterbi scores, trie node ids) lives
 // in LDS for the whole call, frames are consumed sequentially.  Prefixes are nodes of a per-utterance trie in
 // HBM (parent/token/depth arrays + an open-addressing hash on (parent, token)), so prefix identity — the
 // std::unordered_map<vector<int>> key of the reference — is a node id and merging two ways of reaching the
@@ -23,9 +23,8 @@
 
 namespace b2t {
 
-constexpr int BMAX = 32;           // max second_beam_size
+constexpr int BMAX = 128;          // max second_beam_size (the candidate arrays are dynamic LDS: 60 B x beam x (first_beam + 1))
 constexpr int KMAX = 16;           // max first_beam_size
-constexpr int NCAND = BMAX * (KMAX + 1);
 constexpr float NEGMAX = -3.402823466e38f;   // -FLT_MAX: the reference's log-zero sentinel
 
 __device__ __forceinline__ float log_add(float x, float y) {
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
                                                           int32_t* __restrict__ hyps, int32_t* __restrict__ hyp_len,
                                                           float* __restrict__ score, float* __restrict__ vscore,
                                                           int32_t* __restrict__ times, LmArgs lm,
-                                                          float* __restrict__ lm_score) {
+                                                          float* __restrict__ lm_score, int ncmax) {
   const int u = blockIdx.x, tid = threadIdx.x;
   const bool lexm = lm.lex_child != nullptr;
   const bool fused = lm.child != nullptr || lexm;
@@ -210,15 +209,29 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   unsigned long long* hkey = reinterpret_cast<unsigned long long*>(st + lay.o_hkey);
   int* hval = reinterpret_cast<int*>(st + lay.o_hval);
 
-  __shared__ float h_lm[BMAX], c_lm[NCAND];
-  __shared__ int h_lst[BMAX], c_lst[NCAND], h_lx[BMAX], c_lx[NCAND];
+  // candidate arrays: ncmax = beam * (K + 1) entries each, dynamic LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char cand_raw[];
+  float* c_lm = reinterpret_cast<float*>(cand_raw);
+  int* c_lst = reinterpret_cast<int*>(c_lm + ncmax);
+  int* c_lx = c_lst + ncmax;
+  int* c_valid = c_lx + ncmax;
+  int* c_node = c_valid + ncmax;
+  int* c_tok = c_node + ncmax;
+  int* c_rank = c_tok + ncmax;
+  float* c_s = reinterpret_cast<float*>(c_rank + ncmax);
+  float* c_ns = c_s + ncmax;
+  float* c_vs = c_ns + ncmax;
+  float* c_vns = c_vs + ncmax;
+  float* c_ctp = c_vns + ncmax;
+  float* c_sc = c_ctp + ncmax;
+  TSrc* c_ts = reinterpret_cast<TSrc*>(c_sc + ncmax);
+  TSrc* c_tn = c_ts + ncmax;
+  __shared__ float h_lm[BMAX];
+  __shared__ int h_lst[BMAX], h_lx[BMAX];
   __shared__ int h_node[BMAX], h_par[BMAX], h_tok[BMAX], h_dep[BMAX];
   __shared__ float h_s[BMAX], h_ns[BMAX], h_vs[BMAX], h_vns[BMAX], h_ctp[BMAX], h_score[BMAX], h_vit[BMAX];
   __shared__ int tk_id[KMAX]; __shared__ float tk_p[KMAX];
   __shared__ float cp[64];        // class log-probs of the frame; selection marks
-  __shared__ int c_valid[NCAND], c_node[NCAND], c_tok[NCAND], c_rank[NCAND];
-  __shared__ float c_s[NCAND], c_ns[NCAND], c_vs[NCAND], c_vns[NCAND], c_ctp[NCAND], c_sc[NCAND];
-  __shared__ TSrc c_ts[NCAND], c_tn[NCAND];
   __shared__ int s_nb, s_cur, s_abs;
   __shared__ int s_rk2ci[BMAX];
 
@@ -473,6 +486,18 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
 
 using namespace b2t;
 
+// candidate slots of a frame and the dynamic LDS they take (15 arrays of 4 bytes)
+static int first_beam_ncmax(int first_beam, int second_beam) { return second_beam * (first_beam + 1); }
+static size_t beam_cand_bytes(int first_beam, int second_beam) {   // <= 128 * 17 * 60 B = 130 KB of the CU's 160 KB
+  const size_t b = (size_t)first_beam_ncmax(first_beam, second_beam) * 15 * 4;
+  static size_t raised = 0;
+  if (b > 48 * 1024 && b > raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prefix_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
+    raised = b;
+  }
+  return b;
+}
+
 extern "C" size_t b2t_beam_state_bytes(int max_len, int max_nodes) {
   BeamLayout lay(max_nodes, max_len);
   return lay.total;
@@ -496,10 +521,10 @@ extern "C" int b2t_prefix_beam_search_f32(const float* logp, const int32_t* lens
   if (first_beam > C) first_beam = C;
   B2T_REQUIRE(first_beam <= KMAX, "prefix_beam_search: first_beam_size <= %d", KMAX);
   BeamLayout lay(max_nodes, max_len);
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
                      vscore, times, LmArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-                     static_cast<float*>(nullptr));
+                     static_cast<float*>(nullptr), first_beam_ncmax(first_beam, second_beam));
   B2T_CHECK_LAUNCH("b2t_prefix_beam_search_f32");
   return 0;
 }
@@ -518,11 +543,11 @@ extern "C" int b2t_prefix_beam_search_lm_f32(const float* logp, const int32_t* l
   if (first_beam > C) first_beam = C;
   B2T_REQUIRE(first_beam <= KMAX, "prefix_beam_search_lm: first_beam_size <= %d", KMAX);
   BeamLayout lay(max_nodes, max_len);
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
                      vscore, times,
                      LmArgs{lm_child, lm_logp, lm_bow, lm_suffix, lm_nstate, lm_vocab, lm_start_state, lm_eos, alpha, beta, unk_logp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
-                     lm_score);
+                     lm_score, first_beam_ncmax(first_beam, second_beam));
   B2T_CHECK_LAUNCH("b2t_prefix_beam_search_lm_f32");
   return 0;
 }
@@ -541,9 +566,9 @@ extern "C" int b2t_prefix_beam_search_lex_f32(const float* logp, const int32_t* 
   BeamLayout lay(max_nodes, max_len);
   LmArgs lm{nullptr, d->lm_logp, d->lm_bow, d->lm_suffix, d->lm_nstate, 0, d->lm_start_state, d->lm_eos, d->alpha, d->beta,
             d->unk_logp, d->lex_child, d->lex_wbeg, d->lex_wend, d->wlist, d->lm_cb, d->lm_ce, d->lm_ctok, d->lm_cnode, d->sil};
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), 0, as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
-                     vscore, times, lm, lm_score);
+                     vscore, times, lm, lm_score, first_beam_ncmax(first_beam, second_beam));
   B2T_CHECK_LAUNCH("b2t_prefix_beam_search_lex_f32");
   return 0;
 }

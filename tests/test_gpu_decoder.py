@@ -75,6 +75,32 @@ def test_prefix_beam_vs_oracle_random(first, second):
         assert list(tm[u, 0, :hl[u, 0]]) == ref[0][3]
 
 
+@pytest.mark.parametrize("first,second", [(10, 100), (16, 128)])
+def test_prefix_beam_wide_vs_oracle(first, second):
+    """BASELINE configs[3] quotes beam = 100: wide second beams (candidate arrays in dynamic LDS).  Far down the beam
+    the scores are dense, so fp32-vs-oracle ties at the pruning boundary may swap a few prefixes: the upper half must
+    agree exactly (prefix, score, order), the whole beam to >= 95 %."""
+    rng = np.random.default_rng(first + second)
+    U, T, C = 3, 40, 41
+    logits = rng.standard_normal((U, T, C)).astype(np.float32) * 1.5
+    logits[..., 0] += 1.0
+    logp = O.log_softmax(logits)
+    hyps, hl, sc, vs, tm = _search(logp, first, second)
+    for u in range(U):
+        ref = O.prefix_beam_search(logp[u], first, second)
+        n = int((hl[u] >= 0).sum())
+        assert n == len(ref) == second
+        got = [tuple(int(v) for v in hyps[u, i, :hl[u, i]]) for i in range(n)]
+        ref_map = {tuple(r[0]): r for r in ref}
+        for i in range(second // 2):
+            assert got[i] == tuple(ref[i][0]), (u, i)
+            assert abs(sc[u, i] - ref[i][1]) < 2e-4 * max(1.0, abs(ref[i][1]))
+            assert abs(vs[u, i] - ref[i][2]) < 2e-4 * max(1.0, abs(ref[i][2]))
+        assert sum(g in ref_map for g in got) >= int(0.95 * second)
+        assert all(sc[u, i] >= sc[u, i + 1] - 1e-6 for i in range(n - 1))
+        assert list(tm[u, 0, :hl[u, 0]]) == ref[0][3]
+
+
 def test_prefix_beam_streaming_equals_offline():
     rng = np.random.default_rng(9)
     logp = O.log_softmax(rng.standard_normal((3, 48, 41)).astype(np.float32) * 2)
@@ -145,7 +171,7 @@ def _search_lm(logp, lm, alpha, beta, first, second, chunks=None, eos=False):
     return hyps.cpu().numpy(), hl.cpu().numpy(), sc.cpu().numpy(), lms.cpu().numpy()
 
 
-@pytest.mark.parametrize("order,first,second", [(2, 10, 10), (3, 10, 10), (5, 8, 16)])
+@pytest.mark.parametrize("order,first,second", [(2, 10, 10), (3, 10, 10), (5, 8, 16), (3, 10, 100)])
 def test_prefix_beam_lm_vs_oracle(order, first, second):
     import ngram_lm
     text = ngram_lm.synthetic_arpa(WORDS41, order, 400, seed=order)
@@ -170,7 +196,7 @@ def test_prefix_beam_lm_vs_oracle(order, first, second):
                 hits += 1
                 np.testing.assert_allclose(a, refd[p][0], rtol=2e-4, atol=2e-4)
                 np.testing.assert_allclose(l, refd[p][1], rtol=2e-4, atol=2e-4)
-        assert hits >= len(ref) - 2
+        assert hits >= len(ref) - max(2, len(ref) // 20)
 
 
 def test_prefix_beam_lm_streaming_equals_offline_and_eos():

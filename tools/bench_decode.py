@@ -61,7 +61,7 @@ def run(order, first, second, n_per_order=20000):
     print(f"{name:24s} beams {first}/{second}: offline {off:7.3f} ms for {U} x {T} frames ({off / U:6.3f} ms/utterance, "
           f"{off / T * 1e3:6.1f} us/frame) | streaming {U} utterances: p50 {np.percentile(lat, 50):6.3f} ms/frame, p95 {np.percentile(lat, 95):6.3f}")
 
-for order, first, second in ((0, 10, 10), (3, 10, 10), (5, 10, 10), (5, 16, 32)):
+for order, first, second in ((0, 10, 10), (3, 10, 10), (5, 10, 10), (5, 16, 32), (3, 10, 100)):   # last: BASELINE configs[3]
     run(order, first, second)
 
 
