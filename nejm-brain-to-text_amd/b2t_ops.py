@@ -710,18 +710,34 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                                        _stream()), "b2t_day_reduce_f32")
         if bucket_cb:
             bucket_cb("day")
-    if piped:
-        # every sweep stream's last launch is followed by a GEMM on that layer's GEMM stream (which waits for it), and
-        # the weight-gradient streams are GEMM streams: joining the L GEMM streams joins everything
-        for s in s_gemm:
+    def h0_grad():
+        # h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
+        if not ctx.custom_states:
+            colsum(dh_init, L * B, H, H, grd.h0)
+        else:
+            grd.h0.zero_()
+        if bucket_cb:
+            bucket_cb("h0")
+
+    if piped and L > 2:
+        # Every sweep stream's last launch is followed by a GEMM on that layer's GEMM stream (which waits for it), and
+        # the weight-gradient streams are GEMM streams: joining the L GEMM streams joins everything.  The command
+        # processor takes ~50 us per barrier packet even when its event has long fired, so the streams that finish
+        # early (layers 1 .. L-2) are joined into one of them while the last two are still busy; the main stream then
+        # waits for three events instead of L.  The h0 reduction rides on that idle stream (layer 0's sweep is the last
+        # one to finish: after it every layer's dh_init is final).
+        with torch.cuda.stream(s_gemm[1]):
+            for l in range(2, L - 1):
+                s_gemm[1].wait_event(_ev(s_gemm[l]))
+            s_gemm[1].wait_event(ev_bs[0][0])
+            h0_grad()
+        for s in (s_gemm[1], s_gemm[L - 1], s_gemm[0]):
             main.wait_event(_ev(s))
-    # h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
-    if not ctx.custom_states:
-        colsum(dh_init, L * B, H, H, grd.h0)
     else:
-        grd.h0.zero_()
-    if bucket_cb:
-        bucket_cb("h0")
+        if piped:
+            for s in s_gemm:
+                main.wait_event(_ev(s))
+        h0_grad()
     return dh_init if want_dstates else None
 
 
