@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
 
   // candidate arrays: ncmax = beam * (K + 1) entries each, dynamic LDS
   extern __shared__ __attribute__((aligned(16))) unsigned char cand_raw[];
-  float* c_lm = reinterpret_cast<float*>(cand_raw);
+  // ranking key of a candidate: (order-preserving bits of its score) << 32 | ~index; 0 = invalid.  "How many keys
+  // are larger than mine" is then one 64-bit LDS read and one compare per candidate (score descending, index ascending)
+  unsigned long long* c_key = reinterpret_cast<unsigned long long*>(cand_raw);
+  float* c_lm = reinterpret_cast<float*>(c_key + ncmax);
   int* c_lst = reinterpret_cast<int*>(c_lm + ncmax);
   int* c_lx = c_lst + ncmax;
   int* c_valid = c_lx + ncmax;
@@ -223,8 +226,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   float* c_vs = c_ns + ncmax;
   float* c_vns = c_vs + ncmax;
   float* c_ctp = c_vns + ncmax;
-  float* c_sc = c_ctp + ncmax;
-  TSrc* c_ts = reinterpret_cast<TSrc*>(c_sc + ncmax);
+  TSrc* c_ts = reinterpret_cast<TSrc*>(c_ctp + ncmax);
   TSrc* c_tn = c_ts + ncmax;
   __shared__ float h_lm[BMAX];
   __shared__ int h_lst[BMAX], h_lx[BMAX];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   __shared__ float h_s[BMAX], h_ns[BMAX], h_vs[BMAX], h_vns[BMAX], h_ctp[BMAX], h_score[BMAX], h_vit[BMAX];
   __shared__ int tk_id[KMAX]; __shared__ float tk_p[KMAX];
   __shared__ float cp[64];        // class log-probs of the frame; selection marks
-  __shared__ int s_nb, s_cur, s_abs;
+  __shared__ int s_nb, s_cur, s_abs, s_nvalid;
   __shared__ int s_rk2ci[BMAX];
 
   if (tid == 0) {
@@ -370,28 +372,40 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       c_valid[ci] = valid; c_node[ci] = slot == 0 ? node : -1 - pnode; c_tok[ci] = token;
       c_s[ci] = s_; c_ns[ci] = ns_; c_vs[ci] = vs_; c_vns[ci] = vns_; c_ctp[ci] = ctp_;
       c_lm[ci] = lmv; c_lst[ci] = lst; c_lx[ci] = lxv;
-      c_sc[ci] = valid ? log_add(s_, ns_) + (fused ? lmv : 0.f) : -INFINITY;
+      {
+        const float scv = log_add(s_, ns_) + (fused ? lmv : 0.f);
+        unsigned bits = __float_as_uint(scv);
+        bits = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);   // monotone float -> unsigned
+        c_key[ci] = valid ? (((unsigned long long)bits << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)ci)) : 0ull;
+      }
       c_ts[ci] = ts; c_tn[ci] = tn;
     }
     __syncthreads();
 
     // ---- 3. second beam: rank by counting (ties -> lower candidate index), keep the best `beam` ---------
     for (int ci = tid; ci < ncand; ci += blockDim.x) {
+      const unsigned long long mine = c_key[ci];
       int r = 0;
-      if (c_valid[ci]) {
-        const float sc = c_sc[ci];
-        for (int x = 0; x < ncand; ++x) r += (c_valid[x] && (c_sc[x] > sc || (c_sc[x] == sc && x < ci)));
-      } else {
-        r = 1 << 20;
-      }
-      c_rank[ci] = r;
+      int x = 0;
+      for (; x + 4 <= ncand; x += 4)
+        r += (c_key[x] > mine) + (c_key[x + 1] > mine) + (c_key[x + 2] > mine) + (c_key[x + 3] > mine);
+      for (; x < ncand; ++x) r += (c_key[x] > mine);
+      c_rank[ci] = mine != 0ull ? r : (1 << 20);
     }
     __syncthreads();
 
     // ---- 4. write survivors (sorted) into the other hypothesis buffer ------------------------------------
     HypBuf hc(st, lay, cur), hn(st, lay, cur ^ 1);
     if (tid < BMAX) s_rk2ci[tid] = -1;
+    if (tid == 0) s_nvalid = 0;
     __syncthreads();
+    {   // number of valid candidates (one LDS atomic per wave)
+      int mine = 0;
+      for (int ci = tid; ci < ncand; ci += blockDim.x) mine += c_valid[ci];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+      if ((tid & 63) == 0 && mine) atomicAdd(&s_nvalid, mine);
+    }
     for (int ci = tid; ci < ncand; ci += blockDim.x) {
       const int r = c_rank[ci];
       if (r >= beam) continue;
@@ -427,8 +441,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
     }
     __syncthreads();
     if (tid == 0) {
-      int cnt = 0;
-      for (int x = 0; x < ncand; ++x) cnt += c_valid[x];
+      const int cnt = s_nvalid;
       s_nb = cnt < beam ? cnt : beam; s_cur = cur ^ 1; s_abs = at + 1;
     }
     __threadfence_block();
@@ -486,10 +499,10 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
 
 using namespace b2t;
 
-// candidate slots of a frame and the dynamic LDS they take (15 arrays of 4 bytes)
+// candidate slots of a frame and the dynamic LDS they take (one 8-byte and 14 4-byte arrays)
 static int first_beam_ncmax(int first_beam, int second_beam) { return second_beam * (first_beam + 1); }
-static size_t beam_cand_bytes(int first_beam, int second_beam) {   // <= 128 * 17 * 60 B = 130 KB of the CU's 160 KB
-  const size_t b = (size_t)first_beam_ncmax(first_beam, second_beam) * 15 * 4;
+static size_t beam_cand_bytes(int first_beam, int second_beam) {   // <= 128 * 17 * 64 B = 139 KB of the CU's 160 KB
+  const size_t b = (size_t)first_beam_ncmax(first_beam, second_beam) * 16 * 4;
   static size_t raised = 0;
   if (b > 48 * 1024 && b > raised) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prefix_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b);
