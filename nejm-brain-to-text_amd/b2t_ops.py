@@ -353,7 +353,16 @@ def stream_wait_value(t: torch.Tensor, index: int, value: int):
             "b2t_stream_wait_value32_gte")
 
 
-def time_chunks(Tp: int) -> List[Tuple[int, int]]:
+def time_chunks(Tp: int, B: int = 64, H: int = 512) -> List[Tuple[int, int]]:
+    """Time chunks of the layer pipeline.  Pipelining pays only when the sweeps of two layers can be resident together:
+    a sweep is (H/16) * ceil(B/16) workgroups that must all run at once, and the chip holds 2 backward-sweep workgroups
+    per CU up to H = 512 but only 1 beyond (the W_hh slice takes the whole register file).  At H = 768, B = 64 (192
+    workgroups of 256 slots) concurrent sweeps just block each other: 37-93 ms per step with 6 chunks against 19.8 ms
+    with the layers in sequence (tools/bench_c3.py)."""
+    wgs = (H // 16) * ((B + 15) // 16)
+    slots = MAX_RESIDENT_WGS * (2 if H <= 512 else 1)
+    if 2 * wgs > slots and "B2T_CHUNKS" not in os.environ:
+        return [(0, Tp)]
     n = max(1, min(PIPELINE["chunks"], Tp // max(1, PIPELINE["min_chunk"])))
     ch = (Tp + n - 1) // n
     return [(t0, min(Tp, t0 + ch)) for t0 in range(0, Tp, ch)]
@@ -408,7 +417,7 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
         dropout(U, Ud, U.numel(), in_drop, seed * 1000003 + 17)
 
     mode = gru_mode_for(B, H)
-    chunks = time_chunks(Tp)
+    chunks = time_chunks(Tp, B, H)
     s_sweep, s_gemm = ws.layer_streams(L, dev)
     piped = len(chunks) > 1
     outs = [sbuf(f"out{l}", (Tp + 1, B, H)) for l in range(L)]
