@@ -2,10 +2,13 @@
 name (model_training/evaluate_model_helpers.py): the per-trial decoding step runs on the HIP path;
 the phoneme table / logit re-ordering / text clean-up are format facts the decoder stage needs.
 
-Not provided (I/O glue, SURVEY §2 row 5 "out of scope"): the Redis stream client functions
-(reset/send/finalize_remote_language_model, update_remote_lm_params, get_current_redis_time_ms).
+The Redis stream client functions of the reference (reset/send/finalize_remote_language_model,
+update_remote_lm_params, get_current_redis_time_ms: evaluate_model_helpers.py:129-296) speak the same streams and
+field names here; `r` is a redis-py connection to a running LM server or a `remote_lm.LocalLMService` (the HIP beam
+search in-process).
 """
 import re
+import time
 
 import numpy as np
 import torch
@@ -79,3 +82,67 @@ def load_h5py_file(file_path, b2txt_csv_df):
             data['trial_num'].append(g.attrs['trial_num'])
             data['corpus'].append(row['Corpus'].values[0])
     return data
+
+
+# ---- language model over Redis streams (client side) -----------------------------------------------------------
+def get_current_redis_time_ms(redis_conn):
+    sec, usec = redis_conn.time()
+    return int(sec * 1000 + usec / 1000)
+
+
+def _post_and_await(r, post_stream, fields, reply_stream, last_seen, what, pause=0.001):
+    """xadd the request, then block on the reply stream until an entry newer than `last_seen` arrives.
+    Returns (id of that entry, its fields)."""
+    r.xadd(post_stream, fields)
+    if pause:
+        time.sleep(pause)
+    while True:
+        got = r.xread({reply_stream: last_seen}, count=1, block=10000)
+        if got:
+            entry_id, data = got[0][1][-1]
+            return entry_id, data
+        print(f'Still waiting for remote lm {what} from ts {last_seen}...')
+
+
+def reset_remote_language_model(r, remote_lm_done_resetting_lastEntrySeen):
+    seen, _ = _post_and_await(r, 'remote_lm_reset', {'done': 0}, 'remote_lm_done_resetting',
+                              remote_lm_done_resetting_lastEntrySeen, 'reset')
+    return seen
+
+
+def update_remote_lm_params(r, remote_lm_done_updating_lastEntrySeen, acoustic_scale=0.35, blank_penalty=90.0,
+                            alpha=0.55):
+    seen, _ = _post_and_await(r, 'remote_lm_update_params',
+                              {'acoustic_scale': acoustic_scale, 'blank_penalty': blank_penalty, 'alpha': alpha},
+                              'remote_lm_done_updating_params', remote_lm_done_updating_lastEntrySeen,
+                              'to update parameters')
+    return seen
+
+
+def send_logits_to_remote_lm(r, remote_lm_input_stream, remote_lm_output_partial_stream,
+                             remote_lm_output_partial_lastEntrySeen, logits):
+    seen, data = _post_and_await(r, remote_lm_input_stream, {'logits': np.float32(logits).tobytes()},
+                                 remote_lm_output_partial_stream, remote_lm_output_partial_lastEntrySeen,
+                                 'partial output', pause=0)
+    return seen, data[b'lm_response_partial'].decode()
+
+
+def finalize_remote_lm(r, remote_lm_output_final_stream, remote_lm_output_final_lastEntrySeen):
+    """Returns (last entry id, dict of candidate lists sorted by total score, duplicates removed)."""
+    seen, data = _post_and_await(r, 'remote_lm_finalize', {'done': 0}, remote_lm_output_final_stream,
+                                 remote_lm_output_final_lastEntrySeen, 'final output', pause=0.005)
+    parts = data[b'scoring'].decode().split(';') if data.get(b'scoring') else []
+    cands = [(parts[i], float(parts[i + 1]), float(parts[i + 2]), float(parts[i + 3]), float(parts[i + 4]))
+             for i in range(0, len(parts) - 4, 5)]
+    if not cands:
+        print('No candidate sentences were received from the language model.')
+        cands = [('', 0, 0, 0, 0)]
+    else:
+        cands.sort(key=lambda c: c[4], reverse=True)       # total score, best first
+        first = {}
+        for c in cands:                                     # keep the best-scoring copy of a repeated sentence
+            first.setdefault(c[0], c)
+        cands = list(first.values())
+    keys = ('candidate_sentences', 'candidate_acoustic_scores', 'candidate_ngram_scores', 'candidate_llm_scores',
+            'candidate_total_scores')
+    return seen, {k: [c[i] for c in cands] for i, k in enumerate(keys)}
