@@ -223,7 +223,9 @@ PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "6")), "min_chunk": 16,
             "bwd_sweeps": int(os.environ.get("B2T_BWD_SWEEPS", "64")),
             "sweep_priority": int(os.environ.get("B2T_SWEEP_PRIORITY", "0")),
             # sub-chunk flags (SweepFlags, csrc/gru_sync.h): steps per sub-chunk, 0 = event-per-chunk hand-over
-            "sub": int(os.environ.get("B2T_SUB", "0"))}
+            "sub": int(os.environ.get("B2T_SUB", "0")),
+            # experiment: run the weight-gradient GEMMs of layers >= 1 after the last backward sweep instead of under the sweeps
+            "defer_wgrad": int(os.environ.get("B2T_DEFER_WGRAD", "0"))}
 
 
 def bwd_mode_for(fwd_mode: int) -> int:
@@ -643,6 +645,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
             gemm(dGs[0], prm.w_ih[0], dst, M=n * B, N_=In, K=H, a_kc=1, a_s0=4 * H, a_off=a_off + 3 * H, b_kc=0, b_s0=In,
                  b_off=2 * H * In, accumulate=1, **kw)
 
+    deferred = []
     for c, l in sorted(((c, l) for c in range(nc) for l in range(L)),
                        key=lambda cl: ((nc - 1 - cl[0]) + (L - 1 - cl[1]), -cl[1])):
         t0, t1 = chunks[c]
@@ -692,12 +695,19 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                 # launches competing with the sweeps' CUs.  Layer 0's go to the top layer's GEMM stream (idle by then)
                 # so that they overlap the day-layer backward instead of queueing in front of it.
                 swg = s_gemm[L - 1] if (l == 0 and L > 1) else s_wg[l]
-                with torch.cuda.stream(swg):
-                    swg.wait_event(ev_bs[l][c])
-                    _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
+                if PIPELINE["defer_wgrad"] and l > 0:
+                    deferred.append((swg, l))     # experiment: weight gradients only once every sweep has finished
+                else:
+                    with torch.cuda.stream(swg):
+                        swg.wait_event(ev_bs[l][c])
+                        _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
             if (not piped) and c == 0:
                 _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
 
+    for swg, l in deferred:
+        with torch.cuda.stream(swg):
+            swg.wait_event(ev_bs[0][0])
+            _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
     # layer-0 input gradient -> day layer (on layer 0's GEMM stream: its dU/dV GEMMs are already ordered there)
     with torch.cuda.stream(s_gemm[0] if piped else main):
         if dims.patch > 0:
