@@ -451,11 +451,9 @@ static unsigned pipe_extra_lds() {
   return (unsigned)v;
 }
 template <typename K> static void pipe_allow_lds(K kernel) {
-  static bool done = false;
-  if (!done && pipe_extra_lds() > 0) {
+  // (every call: instances with the same signature share this function, a flag here would cover only the first one)
+  if (pipe_extra_lds() > 0)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_extra_lds());
-    done = true;
-  }
 }
 
 static int pipe_check(int B, int H, int T, void* sync_ws, const char* what) {
@@ -500,7 +498,8 @@ int gru_pipeline_bwd(const float* dY, const float* dh_last, const float* reserve
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH(NCB)                                                                                                \
   do {                                                                                                                 \
-    hipLaunchKernelGGL((gru_pipe_bwd_kernel<NCB, 4>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG,      \
+    pipe_allow_lds(gru_pipe_bwd_kernel<NCB, 4>);                                                                       \
+    hipLaunchKernelGGL((gru_pipe_bwd_kernel<NCB, 4>), grid, block, pipe_extra_lds(), s, dY, dh_last, reserve, out, h_init, w_hh_t, dG, \
                        dh_init, T, B, H, sync);                                                                        \
   } while (0)
   if (H <= 128) B2T_LAUNCH(6);
