@@ -78,6 +78,10 @@ typedef struct b2t_gemm_desc {
   int a_brk; int a_gap;
 } b2t_gemm_desc;
 int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream);
+/* The same GEMM with the operands rounded to bf16 (nearest-even) on their way to the matrix cores, fp32 accumulation and
+ * fp32 output: the matmul regime of the reference's `use_amp` / autocast(bfloat16) training (rnn_trainer.py:535).  Tensors
+ * stay fp32 in memory.  Split-K chunks and a_brk along k are multiples of 32 here. */
+int b2t_gemm_bf16_f32(const b2t_gemm_desc* d, void* stream);
 
 /* ---- elementwise helpers ------------------------------------------------------------------
  * softsign backward (rnn_model.py:99 autograd): du[i] *= (1-|u[i]|)^2, in place. */

@@ -125,6 +125,16 @@ def augment_smooth(x: torch.Tensor, std: float, size: int, padding: str = "same"
 # ------------------------------------------------------------------------------------------------
 # GEMM / reductions
 # ------------------------------------------------------------------------------------------------
+# Matmul precision: "f32" = exact fp32 MFMA (default; BASELINE config 2), "bf16" = operands rounded to bf16 on the way to
+# the matrix cores, fp32 accumulate / output (the reference's `use_amp: true` regime, rnn_args.yaml; B2T_AMP=1 or
+# set_amp(True)).  The recurrent sweeps, CTC and the optimizer stay fp32 either way.
+AMP = {"on": os.environ.get("B2T_AMP", "0") not in ("0", "", "false", "False")}
+
+
+def set_amp(on: bool):
+    AMP["on"] = bool(on)
+
+
 def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,
          b_sz=0, c_s0=0, c_s1=0, c_div=0, c_sz=0, bias=None, bias_sz=0, b_zmap=None, epilogue=0, accumulate=0,
          a_off=0, b_off=0, c_off=0, splitk=1, ws=None, slab="splitk_slab", _splitk=1, _c_ks=0, a_brk=0, a_gap=0):
@@ -155,6 +165,10 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
     d.epilogue, d.accumulate = epilogue, accumulate
     d.splitk, d.c_ks = _splitk, _c_ks
     d.a_brk, d.a_gap = a_brk, a_gap
+    if AMP["on"]:
+        with _Prof(f"gemm_bf16_kernel<{int(bool(a_kc))},{int(bool(b_kc))}>", 2.0 * M * N_ * K * Z):
+            N.check(N.load().b2t_gemm_bf16_f32(C.byref(d), _stream()), "b2t_gemm_bf16_f32")
+        return
     with _Prof(f"gemm_f32_kernel<{int(bool(a_kc))},{int(bool(b_kc))}>", 2.0 * M * N_ * K * Z):   # one name per rocprof symbol
         N.check(N.load().b2t_gemm_f32(C.byref(d), _stream()), "b2t_gemm_f32")
 

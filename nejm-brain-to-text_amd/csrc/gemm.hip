@@ -11,6 +11,7 @@
 // takes the predicated path.  The f32-input MFMA is bit-for-bit a k-ordered fmaf chain (no reduced-
 // precision path exists on gfx950), so results match an fp32 CPU GEMM to summation-order roundoff.
 #include "common.h"
+#include "gemm_args.h"
 
 namespace b2t {
 
@@ -31,22 +32,6 @@ constexpr int RPP = 256 / TPR;     // k-contiguous mode: rows covered per pass
 // stored as float4 rows and need a 16-byte aligned pitch.
 template <bool KC> struct Pitch { static constexpr int v = KC ? 129 : 132; };
 constexpr int PITCH_MAX = 132;
-
-struct GemmArgs {
-  const float* A; const float* B; float* C; const float* bias;
-  int M, N, K;
-  long long a_s0, a_s1; int a_div; long long a_sz;
-  long long b_s0, b_s1; int b_div; long long b_sz;
-  long long c_s0, c_s1; int c_div; long long c_sz;
-  const int* b_zmap; long long bias_sz;
-  int epilogue; int accumulate;
-  int splitk; int kchunk; long long c_ks;
-  int a_brk; int a_gap;   // contiguous index i of A (k if a_kcontig, else m): i >= a_brk reads from i + a_gap
-};
-
-__device__ __forceinline__ long long rowoff(int i, long long s0, long long s1, int div) {
-  return div > 0 ? (long long)(i / div) * s1 + (long long)(i % div) * s0 : (long long)i * s0;
-}
 
 // Load one operand tile slice owned by this thread into 2 float4 registers.
 // KC (k contiguous): tile rows are the M/N index (128 of them), 16 k per row -> thread (row=t/4+64r, k4=t%4)
@@ -258,21 +243,7 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
                   (d->b_s1 % 4) == 0 && (d->b_sz % 4) == 0,
               "b2t_gemm_f32: A/B strides must be multiples of 4 elements");
   GemmArgs g;
-  g.A = d->A; g.B = d->B; g.C = d->C; g.bias = d->bias;
-  g.M = d->M; g.N = d->N; g.K = d->K;
-  g.a_s0 = d->a_s0; g.a_s1 = d->a_s1; g.a_div = d->a_div; g.a_sz = d->a_sz;
-  g.b_s0 = d->b_s0; g.b_s1 = d->b_s1; g.b_div = d->b_div; g.b_sz = d->b_sz;
-  g.c_s0 = d->c_s0; g.c_s1 = d->c_s1; g.c_div = d->c_div; g.c_sz = d->c_sz;
-  g.b_zmap = d->b_zmap; g.bias_sz = d->bias_sz; g.epilogue = d->epilogue; g.accumulate = d->accumulate;
-  g.splitk = d->splitk > 1 ? d->splitk : 1;
-  B2T_REQUIRE(g.splitk == 1 || (d->epilogue == 0 && d->accumulate == 0),
-              "b2t_gemm_f32: split-K slabs cannot carry an epilogue/accumulate (reduce them with b2t_colsum_f32)");
-  g.kchunk = ((d->K + g.splitk - 1) / g.splitk + BKT - 1) / BKT * BKT;
-  g.c_ks = d->c_ks;
-  g.a_brk = d->a_brk; g.a_gap = d->a_gap;
-  B2T_REQUIRE(d->a_brk == 0 || (d->a_brk > 0 && d->a_gap % 4 == 0 &&
-                                (d->a_kcontig ? d->a_brk % BKT == 0 : (d->a_brk % BM == 0 && d->M % BM == 0))),
-              "b2t_gemm_f32: a_brk must be a multiple of the tile extent (16 along k, 128 along m with M %% 128 == 0), a_gap of 4");
+  { int rc = fill_gemm_args(d, g, BKT, BM, "b2t_gemm_f32"); if (rc) return rc; }
   dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);
   hipStream_t s = as_stream(stream);
   if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);

@@ -10,7 +10,9 @@ all-reduce over RCCL when launched under torch.distributed (one process per GPU)
 
 Differences from the reference that are deliberate and documented:
   * patch_size == 0 works (the reference divides by patch_stride=0 at :532/:707; SURVEY §0 fact 5);
-  * `use_amp` is accepted and ignored: this path computes in fp32 (BASELINE config 2);
+  * `use_amp` alone does not lower the precision: this path computes in fp32 (BASELINE config 2) unless
+    `args['amd_bf16_matmul']` (or B2T_AMP=1) asks for bf16 matmul operands (b2t_gemm_bf16_f32: the autocast regime
+    for the matmuls; sweeps, CTC and optimizer stay fp32);
   * `self.optimizer` / `self.learning_rate_scheduler` are light adapters over TrainStep exposing
     `param_groups`, `state_dict()`, `load_state_dict()` in torch.optim.AdamW / LambdaLR format so that
     checkpoints interoperate (keys carry the reference's `_orig_mod.` prefix).
@@ -93,6 +95,8 @@ def _strip_prefix(sd):
 class BrainToTextDecoder_Trainer:
     def __init__(self, args):
         self.args = args
+        if args.get('amd_bf16_matmul'):      # bf16 matmul operands (the `use_amp` regime of the reference), opt-in
+            ops.set_amp(True)
         self.logger = None
         self.device = None
         self.model = None

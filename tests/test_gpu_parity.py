@@ -69,6 +69,98 @@ def test_gemm(akc, bkc, M, N, K):
     np.testing.assert_allclose(tC3.cpu().numpy(), r3 / (1 + np.abs(r3)), atol=2e-5 * np.sqrt(K) * 4)  # d softsign <= 1
 
 
+def _bf16_round(x):
+    """fp32 -> nearest-even bf16 -> fp32 (what v_cvt_pk_bf16_f32 does to the operands)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 41, 37), (33, 300, 129), (512, 1536, 512), (64, 64, 41)])
+def test_gemm_bf16(akc, bkc, M, N, K):
+    """b2t_gemm_bf16_f32 (the `use_amp` matmul regime): operands rounded to bf16 (RNE), fp32 accumulate and output --
+    equal to an fp64 product of the rounded operands up to fp32 summation roundoff, for all four operand layouts."""
+    import b2t_native as Nn
+    import b2t_ops as ops
+    dev = _dev()
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = _bf16_round(A).astype(np.float64) @ _bf16_round(Bm).astype(np.float64).T + bias
+    Mp, Np, Kp = (M + 3) // 4 * 4, (N + 3) // 4 * 4, (K + 3) // 4 * 4
+    if akc:
+        Ad = torch.zeros(M, Kp); Ad[:, :K] = torch.from_numpy(A); a_s0 = Kp
+    else:
+        Ad = torch.zeros(K, Mp); Ad[:, :M] = torch.from_numpy(A.T); a_s0 = Mp
+    if bkc:
+        Bd = torch.zeros(N, Kp); Bd[:, :K] = torch.from_numpy(Bm); b_s0 = Kp
+    else:
+        Bd = torch.zeros(K, Np); Bd[:, :N] = torch.from_numpy(Bm.T); b_s0 = Np
+    Ad, Bd = Ad.to(dev), Bd.to(dev)
+    Cd = torch.full((M, N), float("nan"), device=dev)
+    old = ops.AMP["on"]
+    ops.set_amp(True)
+    try:
+        ops.gemm(Ad, Bd, Cd, M=M, N_=N, K=K, a_kc=akc, a_s0=a_s0, b_kc=bkc, b_s0=b_s0, c_s0=N, bias=torch.from_numpy(bias).to(dev))
+        got = Cd.cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+        # and it really is the bf16 product, not the fp32 one
+        if K >= 32:
+            exact = A.astype(np.float64) @ Bm.astype(np.float64).T + bias
+            assert np.abs(got - exact).max() > 10 * np.abs(got - ref).max()
+        # split-K slabs (weight-gradient shape: long K) agree with the single pass
+        if M == 512:
+            ws = ops.Workspace()
+            C2 = torch.empty((M, N), device=dev)
+            ops.gemm(Ad, Bd, C2, M=M, N_=N, K=K, a_kc=akc, a_s0=a_s0, b_kc=bkc, b_s0=b_s0, c_s0=N, splitk=4, ws=ws)
+            np.testing.assert_allclose(C2.cpu().numpy() + bias, ref, atol=2e-5 * float(np.abs(ref).max()))
+    finally:
+        ops.set_amp(old)
+
+
+def test_train_step_bf16_matmuls_track_fp32():
+    """B2T_AMP regime end to end (bf16 matmul operands everywhere, fp32 sweeps / CTC / optimizer): loss and gradients
+    stay within bf16 distance of the fp32 step on the same batch, and a few steps of training reduce the loss."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    F, H, D, C, L, B, T = 128, 256, 3, 41, 3, 32, 48
+    args = dict(lr_max=0.01, lr_min=0.001, lr_decay_steps=100, lr_warmup_steps=0, lr_scheduler_type="cosine",
+                lr_max_day=0.01, lr_min_day=0.001, lr_decay_steps_day=100, lr_warmup_steps_day=0, beta0=0.9,
+                beta1=0.999, epsilon=0.1, weight_decay=0.0, weight_decay_day=0, grad_norm_clip_value=10,
+                _debug_keep_unclipped=True)
+    torch.manual_seed(5)
+    x = torch.randn(B, T, F, device=dev) * 0.5; day = torch.randint(0, D, (B,), device=dev, dtype=torch.int32)
+    tgt = torch.randint(1, C, (B, 6), device=dev, dtype=torch.int32)
+    nt = torch.full((B,), T, device=dev, dtype=torch.int32); tl = torch.full((B,), 6, device=dev, dtype=torch.int32)
+    old = ops.AMP["on"]
+    out = {}
+    try:
+        for amp in (False, True):
+            ops.set_amp(amp)
+            torch.manual_seed(6)
+            model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
+            ts = TrainStep(model, dict(args))
+            losses = []
+            for it in range(6):
+                loss, _ = ts.step(x, day, tgt, nt, tl)
+                losses.append(float(loss))
+                if it == 0:
+                    g0 = {k: v.copy() for k, v in ts.last_unclipped_grads().items()}
+            out[amp] = (losses, g0)
+    finally:
+        ops.set_amp(old)
+    (l32, g32), (l16, g16) = out[False], out[True]
+    assert abs(l16[0] - l32[0]) < 2e-2 * abs(l32[0]) and l16[0] != l32[0]
+    assert l16[-1] < 0.9 * l16[0]
+    for k, ref in g32.items():
+        scale = max(1e-6, float(np.abs(ref).max()))
+        assert float(np.abs(g16[k] - ref).max()) < 0.08 * scale, k
+
+
 def test_smooth_golden(golden_dir):
     from data_augmentations import gauss_smooth
     z = load(golden_dir, "smooth.npz")
