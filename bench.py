@@ -203,7 +203,7 @@ def main():
     if rank == 0:
         out = dict(metric="GRU+CTC train sentences/sec", value=round(value, 2), unit="sentences/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32", data="synthetic",
+                   vs_baseline=None, dtype=("f32" if not ops.AMP["on"] else "bf16 matmul operands, f32 accumulate/sweeps (B2T_AMP)"), data="synthetic",
                    config=dict(workload="BASELINE.json configs[1]: 5-layer GRU-512 + CTC, synthetic [B=64,T=500,F=512] -> 41 "
                                         "phonemes, fp32, full training step incl. on-GPU augmentation, clip and AdamW",
                                global_batch=B * world, seq_len=T, parallelism=f"dp{world}",
