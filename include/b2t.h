@@ -121,7 +121,11 @@ int b2t_dropout_mask_f32(float* y, long long n, float p, uint64_t seed, long lon
  * persistent sweep, 4 row groups per workgroup (csrc/gru_pipeline.hip; shapes it does not cover --
  * fewer than 3 row groups, H > 512 backward / > 768 forward -- run as mode 1).  All modes produce the
  * same out / reserve / dG layouts and can be mixed between calls on one workspace.
+ * mode 1 | B2T_GRU_BF16: the recurrent product takes bf16 operands (h_{t-1} / dG_{t+1} and the W_hh slice rounded to
+ * nearest-even bf16, v_mfma_f32_16x16x16_bf16, fp32 accumulate; gates and everything stored stay fp32): the reference's
+ * autocast(bfloat16) regime for the GRU, opt-in.
  * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode; zeroed by the call). */
+#define B2T_GRU_BF16 0x100
 size_t b2t_gru_sync_bytes(int T);
 /* Workspace size valid for every mode (mode 2 = persistent sweep with data-tagged 8-byte {value,tag}
  * granule hand-off, csrc/gru_granule.hip: needs T*B*H*8 bytes of granules behind the control words). */

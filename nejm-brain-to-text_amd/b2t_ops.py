@@ -127,8 +127,10 @@ def augment_smooth(x: torch.Tensor, std: float, size: int, padding: str = "same"
 # ------------------------------------------------------------------------------------------------
 # Matmul precision: "f32" = exact fp32 MFMA (default; BASELINE config 2), "bf16" = operands rounded to bf16 on the way to
 # the matrix cores, fp32 accumulate / output (the reference's `use_amp: true` regime, rnn_args.yaml; B2T_AMP=1 or
-# set_amp(True)).  The recurrent sweeps, CTC and the optimizer stay fp32 either way.
-AMP = {"on": os.environ.get("B2T_AMP", "0") not in ("0", "", "false", "False")}
+# set_amp(True)): all GEMMs and the recurrent products of the persistent sweeps.  Gate math, accumulation, CTC and the
+# optimizer stay fp32 either way.
+AMP = {"on": os.environ.get("B2T_AMP", "0") not in ("0", "", "false", "False"),
+       "sweeps": os.environ.get("B2T_AMP_SWEEPS", "1") != "0"}   # B2T_AMP_SWEEPS=0: bf16 GEMMs only, fp32 recurrent products
 
 
 def set_amp(on: bool):
@@ -292,6 +294,14 @@ def gru_stack_forward(dims, prm, gi0, outs, outs_d, reserves, Tp, B, rnn_drop, s
         return False
     N.check(rc, "b2t_gru_stack_fwd_f32")
     return True
+
+
+GRU_BF16 = 0x100   # B2T_GRU_BF16 (include/b2t.h): bf16 operands of the recurrent product, persistent mode 1
+
+
+def sweep_mode_arg(mode: int) -> int:
+    """`mode` argument of b2t_gru_layer_fwd/bwd_f32: under set_amp(True) the persistent sweeps take bf16 operands."""
+    return mode | GRU_BF16 if (AMP["on"] and AMP.get("sweeps", True) and mode == 1) else mode
 
 
 def gru_sync_check(sync_ws, T: int, B: int):
@@ -541,7 +551,7 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
                         C.c_void_p(gis[l].data_ptr() + 4 * t0 * B * 3 * H), _p(prm.w_hh[l]), _p(prm.b_hh[l]),
                         C.c_void_p(outs[l].data_ptr() + 4 * t0 * B * H),
                         C.c_void_p(outs[l].data_ptr() + 4 * (1 + t0) * B * H), res_ptr,
-                        _p(hidden[l]) if t1 == Tp else None, n, B, H, mode,
+                        _p(hidden[l]) if t1 == Tp else None, n, B, H, sweep_mode_arg(mode),
                         _p(ws.sync_ws(l, Tp, dev, B, H)) if mode >= 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
                 if piped:
                     ev_sw[l][c] = _ev(ss)
@@ -692,7 +702,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                         C.c_void_p(ctx.reserves[l].data_ptr() + 4 * t0 * B * 4 * H),
                         C.c_void_p(outb.data_ptr() + 4 * (1 + t0) * B * H), C.c_void_p(outb.data_ptr() + 4 * t0 * B * H),
                         _p(whh_ts[l]), C.c_void_p(dGs[l].data_ptr() + 4 * t0 * B * 4 * H), dh_out, _p(scratch[l]),
-                        n, B, H, bwd_mode_for(mode), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
+                        n, B, H, sweep_mode_arg(bwd_mode_for(mode)), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
                         "b2t_gru_layer_bwd_f32")
                 if piped:
                     ev_bs[l][c] = _ev(ss)

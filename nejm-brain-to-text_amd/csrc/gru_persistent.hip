@@ -22,10 +22,37 @@
 
 namespace b2t {
 
+// BF16 = true: the recurrent products take bf16 operands (the reference's autocast regime, opt-in).  v_mfma_f32_16x16x16_bf16
+// wants exactly the fragment the fp32 path builds -- lane (j, q) holds 4 consecutive k of row j -- so the 4 floats are
+// rounded to bf16 (nearest-even) and ONE MFMA replaces the four 16x16x4 fp32 ones; the weight slice is kept as bf16
+// (half the registers).  Accumulation, gates and everything stored stay fp32.
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
+  bf16x4 r;
+  r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+  return r;
+}
+template <bool BF16> struct WFrag { using type = float4; };
+template <> struct WFrag<true> { using type = bf16x4; };
+template <bool BF16> __device__ __forceinline__ typename WFrag<BF16>::type make_wfrag(float4 v) {
+  if constexpr (BF16) return to_bf16x4(v); else return v;
+}
+template <bool BF16>
+__device__ __forceinline__ f32x4 mfma_chunk16(float4 a, typename WFrag<BF16>::type w, f32x4 acc) {
+  if constexpr (BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(a), w, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <int NCH>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
+template <int NCH, bool BF16>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
 __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
@@ -56,14 +83,14 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
   const int unit = j0 + j;
   const int nch = H / 16;
 
-  float4 w[3][NCH];
+  typename WFrag<BF16>::type w[3][NCH];
 #pragma unroll
   for (int ci = 0; ci < NCH; ++ci) {
     const int c = KCHUNK(wave, ci, NCH);
 #pragma unroll
     for (int g = 0; g < 3; ++g)
-      w[g][ci] = c < nch ? *reinterpret_cast<const float4*>(w_hh + ((long long)g * H + unit) * H + c * 16 + 4 * q)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      w[g][ci] = make_wfrag<BF16>(c < nch ? *reinterpret_cast<const float4*>(w_hh + ((long long)g * H + unit) * H + c * 16 + 4 * q)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f));
   }
   const float bhr = b_hh[unit], bhz = b_hh[H + unit], bhn = b_hh[2 * H + unit];
   const int row = m0 + 4 * q + wave, arow = m0 + j;
@@ -121,12 +148,7 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
       for (int h2 = 0; h2 < 2; ++h2) {
         const int ci = 2 * p + h2;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].x, w[g][ci].x, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].y, w[g][ci].y, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].z, w[g][ci].z, acc[g], 0, 0, 0);
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].w, w[g][ci].w, acc[g], 0, 0, 0);
-        }
+        for (int g = 0; g < 3; ++g) acc[g] = mfma_chunk16<BF16>(a[h2], w[g][ci], acc[g]);
       }
     }
     asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
 // dGh_{t+1} row block with its register-resident W_hh[:, slice] and (B) forms the gate gradients of
 // step t for its slice, publishing them as dG[t] for the other workgroups of the row group.
 // ---------------------------------------------------------------------------------------------------
-template <int NCB>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
+template <int NCB, bool BF16>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
 __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __restrict__ dY,
                                                                  const float* __restrict__ dh_last,
                                                                  const float* __restrict__ reserve,
@@ -217,12 +239,12 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   const int unit = j0 + j;
   const int nch = 3 * H / 16;
 
-  float4 w[NCB];
+  typename WFrag<BF16>::type w[NCB];
 #pragma unroll
   for (int ci = 0; ci < NCB; ++ci) {
     const int c = KCHUNK(wave, ci, NCB);
-    w[ci] = c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit * 3 * H + c * 16 + 4 * q)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    w[ci] = make_wfrag<BF16>(c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit * 3 * H + c * 16 + 4 * q)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f));
   }
   const int row = m0 + 4 * q + wave, arow = m0 + j;
   const int arow_c = arow < B ? arow : B - 1;
@@ -260,10 +282,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const int ci = 2 * p + h2;
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].x, w[ci].x, acc[0], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].y, w[ci].y, acc[0], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].z, w[ci].z, acc[0], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h2].w, w[ci].w, acc[0], 0, 0, 0);
+          acc[0] = mfma_chunk16<BF16>(a[h2], w[ci], acc[0]);
         }
       }
       float s[1];
@@ -359,16 +378,22 @@ static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
 }
 
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
-                       float* reserve, int T, int B, int H, void* sync_ws, const SweepFlags& fl, hipStream_t s) {
+                       float* reserve, int T, int B, int H, void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
   const dim3 grid(H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
-    want_exclusive(gru_persist_fwd_kernel<NCH>);                                                                       \
-    hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                       B, H, sync, fl);                                                                                \
+    if (bf16) {                                                                                                        \
+      want_exclusive(gru_persist_fwd_kernel<NCH, true>);                                                               \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                         B, H, sync, fl);                                                                              \
+    } else {                                                                                                           \
+      want_exclusive(gru_persist_fwd_kernel<NCH, false>);                                                              \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                         B, H, sync, fl);                                                                              \
+    }                                                                                                                  \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
@@ -382,16 +407,22 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
 
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
-                       void* sync_ws, const SweepFlags& fl, hipStream_t s) {
+                       void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
   const dim3 grid(H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
   do {                                                                                                                \
-    want_exclusive(gru_persist_bwd_kernel<NCB>);                                                                      \
-    hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init,      \
-                       w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                       \
+    if (bf16) {                                                                                                       \
+      want_exclusive(gru_persist_bwd_kernel<NCB, true>);                                                              \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
+                         w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                     \
+    } else {                                                                                                          \
+      want_exclusive(gru_persist_bwd_kernel<NCB, false>);                                                             \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
+                         w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                     \
+    }                                                                                                                 \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);
   else if (H <= 256) B2T_LAUNCH_BWD(12);

@@ -120,6 +120,62 @@ def test_gemm_bf16(akc, bkc, M, N, K):
         ops.set_amp(old)
 
 
+@pytest.mark.parametrize("B,H,T", [(17, 80, 9), (64, 512, 12), (40, 768, 6)])
+def test_persistent_sweep_bf16_operands(B, H, T):
+    """mode 1 | B2T_GRU_BF16: the recurrent products round their operands (h_{t-1} / dG_{t+1} and the W_hh slice) to bf16
+    and accumulate in fp32.  Reference: the same recurrences in numpy with the operands rounded explicitly."""
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev(); p = ops._p
+    g = torch.Generator().manual_seed(B + H)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    gi, w, b_, h0 = rnd(T, B, 3 * H) * 0.5, rnd(3 * H, H) * (1.0 / H ** 0.5), rnd(3 * H) * 0.1, rnd(B, H) * 0.3
+    dY, dhl = rnd(T, B, H) * 0.05, rnd(B, H) * 0.05
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    wq = _bf16_round(w.numpy()).astype(np.float64)
+    # forward
+    h = h0.numpy().astype(np.float64)
+    outs, res = [], []
+    for t in range(T):
+        gh = _bf16_round(h.astype(np.float32)).astype(np.float64) @ wq.T + b_.numpy()
+        git = gi[t].numpy().astype(np.float64)
+        r = sig(git[:, :H] + gh[:, :H]); z = sig(git[:, H:2 * H] + gh[:, H:2 * H])
+        n = np.tanh(git[:, 2 * H:] + r * gh[:, 2 * H:])
+        hprev = h
+        h = (1 - z) * n + z * hprev
+        outs.append(h); res.append((r, z, n, gh[:, 2 * H:], hprev))
+    # backward (SURVEY A3), dGh rounded for the carry product
+    carry = dhl.numpy().astype(np.float64)
+    dG_ref = np.zeros((T, B, 4 * H))
+    for t in range(T - 1, -1, -1):
+        r, z, n, ghn, hprev = res[t]
+        d = dY[t].numpy() + carry
+        dn = d * (1 - z); dz = d * (hprev - n)
+        dn_pre = dn * (1 - n * n); dz_pre = dz * z * (1 - z); dr_pre = dn_pre * ghn * r * (1 - r)
+        dG_ref[t] = np.concatenate([dr_pre, dz_pre, dn_pre * r, dn_pre], axis=1)
+        carry = d * z + _bf16_round(dG_ref[t][:, :3 * H].astype(np.float32)).astype(np.float64) @ wq
+    gi, w, b_, h0, dY, dhl = (x.to(dev) for x in (gi, w, b_, h0, dY, dhl))
+    wt = w.t().contiguous()
+    out = torch.zeros(T + 1, B, H, device=dev); out[0] = h0
+    resv = torch.zeros(T, B, 4 * H, device=dev)
+    sync = torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev)
+    Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out[0]), p(out[1:]), p(resv), None, T, B, H, 1 | ops.GRU_BF16,
+                                       p(sync), ops._stream()), "fwd")
+    dG = torch.zeros(T, B, 4 * H, device=dev); dh = torch.zeros(B, H, device=dev); sc = torch.empty(B, H, device=dev)
+    Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(resv), p(out[1:]), p(out[0]), p(wt), p(dG), p(dh), p(sc), T, B, H,
+                                       1 | ops.GRU_BF16, p(sync), ops._stream()), "bwd")
+    torch.cuda.synchronize()
+    assert int(sync[0]) == 0
+    # rounding decisions can flip where fp32 and fp64 intermediates straddle a bf16 boundary: compare at bf16-ulp scale
+    np.testing.assert_allclose(out[1:].cpu().numpy(), np.stack(outs), atol=2e-3)
+    np.testing.assert_allclose(dG.cpu().numpy(), dG_ref, atol=2e-3 * max(1.0, float(np.abs(dG_ref).max())))
+    np.testing.assert_allclose(dh.cpu().numpy(), carry, atol=2e-3 * max(1.0, float(np.abs(carry).max())))
+    # and it is not the fp32 path
+    out32 = torch.zeros(T + 1, B, H, device=dev); out32[0] = h0
+    Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out32[0]), p(out32[1:]), None, None, T, B, H, 1, p(sync), ops._stream()), "fwd32")
+    assert float((out32 - out).abs().max()) > 1e-5
+
+
 def test_train_step_bf16_matmuls_track_fp32():
     """B2T_AMP regime end to end (bf16 matmul operands everywhere, fp32 sweeps / CTC / optimizer): loss and gradients
     stay within bf16 distance of the fp32 step on the same batch, and a few steps of training reduce the loss."""
