@@ -180,6 +180,7 @@ typedef struct {
   float* out_drop[B2T_STACK_MAX_LAYERS];     /* NULL: no dropped copy for that layer */
   const float* drop_mask[B2T_STACK_MAX_LAYERS];   /* NULL together with out_drop */
   float* reserve[B2T_STACK_MAX_LAYERS];
+  int bf16;   /* != 0: bf16 operands for both products (as B2T_GRU_BF16 for the per-layer sweeps) */
 } b2t_gru_stack_t;
 int b2t_gru_stack_fwd_f32(const b2t_gru_stack_t* d, void* sync_ws, void* stream);
 

@@ -51,7 +51,7 @@ class GruStackDesc(C.Structure):
     _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int), ("gi0", VP),
                 ("w_hh", VP * STACK_MAX_LAYERS), ("w_ih", VP * STACK_MAX_LAYERS), ("b_hh", VP * STACK_MAX_LAYERS),
                 ("b_ih", VP * STACK_MAX_LAYERS), ("out", VP * STACK_MAX_LAYERS), ("out_drop", VP * STACK_MAX_LAYERS),
-                ("drop_mask", VP * STACK_MAX_LAYERS), ("reserve", VP * STACK_MAX_LAYERS)]
+                ("drop_mask", VP * STACK_MAX_LAYERS), ("reserve", VP * STACK_MAX_LAYERS), ("bf16", C.c_int)]
 
 
 class LexLmDesc(C.Structure):

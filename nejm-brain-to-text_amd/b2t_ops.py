@@ -274,6 +274,7 @@ def gru_stack_forward(dims, prm, gi0, outs, outs_d, reserves, Tp, B, rnn_drop, s
     d = N.GruStackDesc()
     d.T, d.B, d.H, d.L = Tp, B, H, L
     d.gi0 = gi0.data_ptr()
+    d.bf16 = 1 if (AMP["on"] and AMP.get("sweeps", True)) else 0
     for l in range(L):
         d.w_hh[l] = prm.w_hh[l].data_ptr(); d.b_hh[l] = prm.b_hh[l].data_ptr()
         d.w_ih[l] = prm.w_ih[l].data_ptr(); d.b_ih[l] = prm.b_ih[l].data_ptr()

@@ -22,33 +22,6 @@
 
 namespace b2t {
 
-// BF16 = true: the recurrent products take bf16 operands (the reference's autocast regime, opt-in).  v_mfma_f32_16x16x16_bf16
-// wants exactly the fragment the fp32 path builds -- lane (j, q) holds 4 consecutive k of row j -- so the 4 floats are
-// rounded to bf16 (nearest-even) and ONE MFMA replaces the four 16x16x4 fp32 ones; the weight slice is kept as bf16
-// (half the registers).  Accumulation, gates and everything stored stay fp32.
-using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
-  bf16x4 r;
-  r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
-  return r;
-}
-template <bool BF16> struct WFrag { using type = float4; };
-template <> struct WFrag<true> { using type = bf16x4; };
-template <bool BF16> __device__ __forceinline__ typename WFrag<BF16>::type make_wfrag(float4 v) {
-  if constexpr (BF16) return to_bf16x4(v); else return v;
-}
-template <bool BF16>
-__device__ __forceinline__ f32x4 mfma_chunk16(float4 a, typename WFrag<BF16>::type w, f32x4 acc) {
-  if constexpr (BF16) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(a), w, acc, 0, 0, 0);
-  } else {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------

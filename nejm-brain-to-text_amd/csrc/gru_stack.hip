@@ -68,7 +68,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   all:  the loads of item k+1 between the MFMAs, polls of item k+2, partials of item k -> LDS (double buffered)      |B1|
 // ONE barrier per item.  The gate phase of an item runs under the other wave's MFMAs of the next item; a gate wave
 // stages and stores the four rows it owns itself (no cross-wave tile, no second barrier).
-template <int NC, bool EXACT>
+template <int NC, bool EXACT, bool BF16>
 __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A, unsigned* sync) {
   constexpr int R = 4;
   constexpr int NL = 2 * NC;            // operand load instructions per item: [0, NC) h, [NC, 2 NC) x
@@ -98,15 +98,15 @@ __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A,
   const bool first = l == 0;            // layer 0: gi comes from the GEMM, nothing to project
 
   // weights: chunk ci of this wave = columns [wave*16*NC + 16 ci, +16) of W_hh (wh) and W_ih (wx)
-  float4 wh[3][NC], wx[3][NC];
+  typename WFrag<BF16>::type wh[3][NC], wx[3][NC];
 #pragma unroll
   for (int ci = 0; ci < NC; ++ci) {
     const int col = (wave * NC + ci) * 16 + 4 * q;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-      wh[g][ci] = col < H ? *reinterpret_cast<const float4*>(A.w_hh[l] + ((long long)g * H + unit) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-      wx[g][ci] = (!first && col < H) ? *reinterpret_cast<const float4*>(A.w_ih[l] + ((long long)g * H + unit) * H + col)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      wh[g][ci] = make_wfrag<BF16>(col < H ? *reinterpret_cast<const float4*>(A.w_hh[l] + ((long long)g * H + unit) * H + col) : make_float4(0.f, 0.f, 0.f, 0.f));
+      wx[g][ci] = make_wfrag<BF16>((!first && col < H) ? *reinterpret_cast<const float4*>(A.w_ih[l] + ((long long)g * H + unit) * H + col)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
   const float* bh = A.b_hh[l];
@@ -192,21 +192,28 @@ __global__ __launch_bounds__(512, 1) void gru_stack_fwd_kernel(const StackFwd A,
 
   // acc: [0] r, [1] z (the h and the x products share an accumulator), [2] n from h, [3] n from x.  k outer, gate
   // inner: three independent accumulators between two MFMAs on the same one.
-  auto mfma_chunk = [&](f32x4 (&acc)[4], const f32x4& a, const float4 (&w)[3][NC], auto ci_c, auto nidx_c) {
+  auto mfma_chunk = [&](f32x4 (&acc)[4], const f32x4& a, const typename WFrag<BF16>::type (&w)[3][NC], auto ci_c, auto nidx_c) {
     constexpr int ci = decltype(ci_c)::value;
     constexpr int ni = decltype(nidx_c)::value;   // 2: h operand, 3: x operand
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[0][ci].x, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[1][ci].x, acc[1], 0, 0, 0);
-    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[2][ci].x, acc[ni], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[0][ci].y, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[1][ci].y, acc[1], 0, 0, 0);
-    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[2][ci].y, acc[ni], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[0][ci].z, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[1][ci].z, acc[1], 0, 0, 0);
-    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[2][ci].z, acc[ni], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[0][ci].w, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[1][ci].w, acc[1], 0, 0, 0);
-    acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[2][ci].w, acc[ni], 0, 0, 0);
+    if constexpr (BF16) {   // one 16x16x16 bf16 MFMA per gate: the fragment layout is the fp32 path's
+      const bf16x4 ab = to_bf16x4(make_float4(a[0], a[1], a[2], a[3]));
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, w[0][ci], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, w[1][ci], acc[1], 0, 0, 0);
+      acc[ni] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, w[2][ci], acc[ni], 0, 0, 0);
+    } else {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[0][ci].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[1][ci].x, acc[1], 0, 0, 0);
+      acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[2][ci].x, acc[ni], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[0][ci].y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[1][ci].y, acc[1], 0, 0, 0);
+      acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[2][ci].y, acc[ni], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[0][ci].z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[1][ci].z, acc[1], 0, 0, 0);
+      acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[2][ci].z, acc[ni], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[0][ci].w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[1][ci].w, acc[1], 0, 0, 0);
+      acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[2][ci].w, acc[ni], 0, 0, 0);
+    }
   };
 
   // ---- prologue: operands of item (0, 0), polls of item (0, 1) ----------------------------------------------------
@@ -440,19 +447,21 @@ extern "C" int b2t_gru_stack_fwd_f32(const b2t_gru_stack_t* d, void* sync_ws, vo
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
   hipStream_t s = as_stream(stream);
   const unsigned dyn = stack_extra_lds();
-#define B2T_LAUNCH(NCH, EX)                                                                                                \
+#define B2T_LAUNCH2(NCH, EX, BF)                                                                                                \
   do {                                                                                                                 \
     static bool raised = false;                                                                                        \
     if (!raised) {                                                                                          \
-      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_stack_fwd_kernel<NCH, EX>),                  \
+      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_stack_fwd_kernel<NCH, EX, BF>),                  \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn), "gru_stack_fwd: LDS limit"); \
       if (rc) return rc;                                                                                               \
       raised = true;                                                                                                   \
     }                                                                                                                  \
-    hipLaunchKernelGGL((gru_stack_fwd_kernel<NCH, EX>), grid, block, dyn, s, A, sync);                                     \
+    hipLaunchKernelGGL((gru_stack_fwd_kernel<NCH, EX, BF>), grid, block, dyn, s, A, sync);                                     \
   } while (0)
+#define B2T_LAUNCH(NCH, EX) do { if (d->bf16) B2T_LAUNCH2(NCH, EX, true); else B2T_LAUNCH2(NCH, EX, false); } while (0)
   if (H <= 256) B2T_LAUNCH(2, false);
   else B2T_LAUNCH(4, true);
 #undef B2T_LAUNCH
+#undef B2T_LAUNCH2
   return check_hip(hipGetLastError(), "gru_stack_fwd");
 }
