@@ -218,6 +218,30 @@ def test_prefix_beam_lm_streaming_equals_offline_and_eos():
             np.testing.assert_allclose(c[3][u, i], 0.5 * lm.sentence_logp(ids, bos=True, eos=True) + 0.1 * len(ids), rtol=1e-4, atol=1e-4)
 
 
+def test_streaming_full_size_equals_offline():
+    """BASELINE configs[4] at size: 32 concurrent utterances, 5-gram LM, fed one frame per call (T = 200 calls) == one
+    offline call, exactly (hypotheses, lengths, CTC and LM scores); the best hypothesis of two utterances matches the oracle."""
+    import ngram_lm
+    text = ngram_lm.synthetic_arpa(WORDS41, 5, 2000, seed=5)
+    lm = ngram_lm.NGramLM.from_arpa(text, WORDS41)
+    o, tab = O.parse_arpa(text)
+    rng = np.random.default_rng(44)
+    U, T = 32, 200
+    logits = (rng.standard_normal((U, T, 41)) * 2.5).astype(np.float32)
+    logits[..., 0] += 1.5
+    logp = O.log_softmax(logits)
+    a = _search_lm(logp, lm, 0.6, 0.2, 10, 10)
+    b = _search_lm(logp, lm, 0.6, 0.2, 10, 10, chunks=[(t, t + 1) for t in range(T)])
+    for x, y in zip(a[1:], b[1:]):                       # lengths, CTC scores, LM scores
+        np.testing.assert_array_equal(x, y)
+    valid = np.arange(a[0].shape[2])[None, None, :] < a[1][:, :, None]   # entries beyond a hypothesis' length are scratch
+    np.testing.assert_array_equal(np.where(valid, a[0], 0), np.where(valid, b[0], 0))
+    for u in (0, 17):
+        ref = O.prefix_beam_search_lm(logp[u], o, tab, WORDS41, 0.6, 0.2, 10, 10)
+        assert tuple(a[0][u, 0, :a[1][u, 0]]) == ref[0][0]
+        np.testing.assert_allclose(a[2][u, 0], ref[0][1], rtol=2e-4, atol=2e-4)
+
+
 def test_lm_decoder_with_token_lm():
     import lm_decoder
     import ngram_lm
