@@ -246,7 +246,8 @@ int b2t_lm_prologue_f32(const float* logits, const float* log_priors, float blan
  *   logp [U][T][C] (C <= 64), lens [U] (NULL: T), first_beam <= 16 classes per frame, second_beam <= 128 prefixes.
  * Outputs, sorted best first (slots beyond the live beam: hyp_len = -1):
  *   hyps [U][second_beam][max_len] token ids, hyp_len [U][second_beam], score = LogAdd(s, ns), vscore = Viterbi
- *   score, times [U][second_beam][max_len] (frame of each token on the Viterbi path; may be NULL).
+ *   score, times [U][second_beam][max_len] (frame of each token on the Viterbi path; may be NULL).  Only the first
+ *   hyp_len entries of a hyps / times row are written; the rest keeps whatever the buffer held.
  * max_nodes bounds the trie (<= second_beam new nodes per frame); b2t_beam_overflowed reports exhaustion. */
 size_t b2t_beam_state_bytes(int max_len, int max_nodes);
 int b2t_beam_reset(void* state, int U, int max_len, int max_nodes, void* stream);
