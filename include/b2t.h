@@ -110,6 +110,13 @@ int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t see
 /* the factors themselves: y[i] = 0 or 1/(1-p), the mask b2t_dropout_f32 applies for the same (seed, elem0) */
 int b2t_dropout_mask_f32(float* y, long long n, float p, uint64_t seed, long long elem0, void* stream);
 
+/* ---- f1: batch assembly from a device-resident flat dataset (replaces the per-trial HDF5 reads + pad_sequence of
+ * model_training/dataset.py:100-159).  flat: rows of W 4-byte elements (all trials' frames / labels back to back);
+ * out[b][t][0:W] = flat[row_off[b] + t][0:W] for t < lens[b], zeros up to T_out.  16-byte accesses when W % 4 == 0
+ * (flat and out then 16-byte aligned). */
+int b2t_batch_gather_b32(const void* flat, const int64_t* row_off, const int32_t* lens, void* out, int B, int T_out,
+                         int W, void* stream);
+
 /* ---- a5: GRU layer sweep (torch.nn.GRU at rnn_model.py:65-72,126) --------------------------
  * One layer, all T steps.  gi [T][B][3H] = W_ih x_t + b_ih (precomputed by b2t_gemm_f32),
  * gate order r,z,n.  h_init [B][H].  w_hh [3H][H], b_hh [3H].

@@ -77,6 +77,7 @@ _SIGNATURES = {
     "b2t_patch_fold_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_dropout_f32": (C.c_int, [VP, VP, LL, C.c_float, C.c_uint64, LL, VP]),
     "b2t_dropout_mask_f32": (C.c_int, [VP, LL, C.c_float, C.c_uint64, LL, VP]),
+    "b2t_batch_gather_b32": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_gru_sync_bytes": (C.c_size_t, [C.c_int]),
     "b2t_gru_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "b2t_gru_sync_status": (C.c_int, [VP, C.c_int, C.c_int, C.POINTER(C.c_int), VP]),

@@ -295,6 +295,39 @@ extern "C" int b2t_dropout_f32(const float* x, float* y, long long n, float p, u
   return 0;
 }
 
+// out[b][t][0:W] = t < lens[b] ? flat[row_off[b] + t][0:W] : 0   (4-byte elements; W % 4 == 0 takes 16-byte accesses)
+__global__ void batch_gather_kernel(const uint32_t* __restrict__ flat, const long long* __restrict__ row_off,
+                                    const int32_t* __restrict__ lens, uint32_t* __restrict__ out, int T_out, int W) {
+  const int b = blockIdx.y;
+  const long long src = row_off[b] * (long long)W;
+  int n = lens[b];
+  if (n > T_out) n = T_out;
+  const long long live = (long long)n * W, total = (long long)T_out * W;
+  uint32_t* o = out + (long long)b * total;
+  if ((W & 3) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(flat + src);
+    uint4* o4 = reinterpret_cast<uint4*>(o);
+    const long long live4 = live >> 2, total4 = total >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x)
+      o4[i] = i < live4 ? s4[i] : make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+      o[i] = i < live ? flat[src + i] : 0u;
+  }
+}
+
+extern "C" int b2t_batch_gather_b32(const void* flat, const int64_t* row_off, const int32_t* lens, void* out, int B, int T_out,
+                                    int W, void* stream) {
+  B2T_REQUIRE(flat && row_off && lens && out && B > 0 && T_out > 0 && W > 0, "batch_gather: bad args B=%d T=%d W=%d", B, T_out, W);
+  B2T_REQUIRE((W & 3) != 0 || ((((uintptr_t)flat) | ((uintptr_t)out)) & 15) == 0, "batch_gather: 16-byte alignment needed when W %% 4 == 0");
+  const long long work = ((long long)T_out * W + 3) / 4;
+  int bx = (int)((work + 255) / 256); if (bx > 64) bx = 64; if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(batch_gather_kernel, dim3(bx, B), dim3(256), 0, as_stream(stream), static_cast<const uint32_t*>(flat),
+                     reinterpret_cast<const long long*>(row_off), lens, static_cast<uint32_t*>(out), T_out, W);
+  B2T_CHECK_LAUNCH("b2t_batch_gather_b32");
+  return 0;
+}
+
 extern "C" int b2t_dropout_mask_f32(float* y, long long n, float p, uint64_t seed, long long elem0, void* stream) {
   B2T_REQUIRE(y && n > 0 && (n % 4) == 0 && (elem0 % 4) == 0 && p >= 0.f && p < 1.f, "dropout_mask: bad args n=%lld p=%f", n, (double)p);
   long long n4 = n / 4;

@@ -9,7 +9,9 @@ that visit every trial once, one day per batch) and read the same HDF5 layout
 n_time_steps / seq_len / block_num / trial_num).  h5py is imported lazily: it is only needed when real
 session files are used.  `SyntheticTrials` produces the same dict from seeded random data so the
 trainer, tests and benchmarks run without the Dryad download.
-(Row f1 of SURVEY §8 — a GPU-resident flat-binary loader — is the planned successor of the HDF5 path.)
+`ResidentDataset` keeps every trial of a split in HBM as flat arrays (one-time conversion, optional
+flat-binary file) and assembles a batch on the device (b2t_batch_gather_b32): no per-batch file reads, no host padding,
+no PCIe copy of the features.
 """
 from __future__ import annotations
 
@@ -196,6 +198,101 @@ class SyntheticTrials(Dataset):
         trans = [torch.zeros(4, dtype=torch.int64) for _ in range(self.B)]
         return _collate(feats, labels, trans, n_steps, seq_lens, [int(d) for d in days], [0] * self.B,
                         list(range(self.B)))
+
+
+class ResidentDataset:
+    """All trials of a split resident on the device: features [sum_T, F] f32 and labels [sum_S] i32 back to back with
+    row offsets, plus the per-trial scalars.  `batch(rows)` returns the reference's batch dict (dataset.py:100-159) for
+    the given trial rows, assembled by one gather kernel per array; `from_batches(dataset)` flattens any source that
+    yields batch dicts (BrainToTextDataset over HDF5, SyntheticTrials) once; `batch_of(dataset_index)` replays the
+    source's own batch composition (the i-th batch of the source == rows i*B .. of this table).
+    `save(path)` / `load(path, device)`: a flat binary (.npz, uncompressed) so that later runs skip the conversion."""
+
+    KEYS = ('feat', 'feat_off', 'lab', 'lab_off', 'trans', 'n_time_steps', 'seq_len', 'day', 'block', 'trial', 'batch_rows')
+
+    def __init__(self, arrays: dict, device='cuda:0'):
+        self.device = torch.device(device)
+        self.host = {k: np.ascontiguousarray(arrays[k]) for k in self.KEYS}
+        h = self.host
+        self.n_trials = int(h['n_time_steps'].shape[0])
+        self.F = int(h['feat'].shape[1])
+        to = lambda a, dt: torch.from_numpy(a).to(self.device, dtype=dt).contiguous()
+        self.feat = to(h['feat'], torch.float32)
+        self.lab = to(h['lab'], torch.int32)
+        self.feat_off = to(h['feat_off'], torch.int64)
+        self.lab_off = to(h['lab_off'], torch.int64)
+        self.n_time_steps = to(h['n_time_steps'], torch.int32)
+        self.seq_len = to(h['seq_len'], torch.int32)
+        self.day = to(h['day'], torch.int64)
+        self.block = to(h['block'], torch.int64)
+        self.trial = to(h['trial'], torch.int64)
+        self.trans = to(h['trans'], torch.int64)
+
+    # ---- construction -------------------------------------------------------------------------------------------
+    @classmethod
+    def from_batches(cls, dataset, device='cuda:0'):
+        feats, labs, foff, loff = [], [], [0], [0]
+        nts, sls, days, blocks, trials, trans, rows = [], [], [], [], [], [], []
+        for bi in range(len(dataset)):
+            b = dataset[bi]
+            first = len(nts)
+            B = int(b['n_time_steps'].shape[0])
+            for i in range(B):
+                T, S = int(b['n_time_steps'][i]), int(b['phone_seq_lens'][i])
+                feats.append(b['input_features'][i, :T].numpy().astype(np.float32))
+                labs.append(b['seq_class_ids'][i, :S].numpy().astype(np.int32))
+                foff.append(foff[-1] + T); loff.append(loff[-1] + S)
+                nts.append(T); sls.append(S); days.append(int(b['day_indicies'][i]))
+                blocks.append(int(b['block_nums'][i])); trials.append(int(b['trial_nums'][i]))
+                trans.append(b['transcriptions'][i].numpy().astype(np.int64))
+            rows.append((first, B))
+        wt = max(len(t) for t in trans)
+        tr = np.zeros((len(trans), wt), dtype=np.int64)
+        for i, t in enumerate(trans):
+            tr[i, :len(t)] = t
+        arrays = dict(feat=np.concatenate(feats, 0), feat_off=np.asarray(foff, np.int64), lab=np.concatenate(labs, 0),
+                      lab_off=np.asarray(loff, np.int64), trans=tr, n_time_steps=np.asarray(nts, np.int32),
+                      seq_len=np.asarray(sls, np.int32), day=np.asarray(days, np.int64), block=np.asarray(blocks, np.int64),
+                      trial=np.asarray(trials, np.int64), batch_rows=np.asarray(rows, np.int64))
+        return cls(arrays, device)
+
+    def save(self, path):
+        np.savez(path, **self.host)
+
+    @classmethod
+    def load(cls, path, device='cuda:0'):
+        with np.load(path) as z:
+            return cls({k: z[k] for k in cls.KEYS}, device)
+
+    # ---- batches ---------------------------------------------------------------------------------------------------
+    def __len__(self):
+        return int(self.host['batch_rows'].shape[0])
+
+    def batch_of(self, i):
+        first, B = (int(v) for v in self.host['batch_rows'][i])
+        return self.batch(torch.arange(first, first + B))
+
+    def batch(self, rows):
+        import ctypes as C
+        import b2t_native as N
+        import b2t_ops as ops
+        rows_h = torch.as_tensor(rows, dtype=torch.int64).cpu()
+        B = int(rows_h.shape[0])
+        T = int(self.host['n_time_steps'][rows_h.numpy()].max())       # pad_sequence pads to the longest trial of the batch
+        S = int(self.host['seq_len'][rows_h.numpy()].max())
+        r = rows_h.to(self.device)
+        nts, sls = self.n_time_steps[r].contiguous(), self.seq_len[r].contiguous()
+        x = torch.empty((B, T, self.F), dtype=torch.float32, device=self.device)
+        y = torch.empty((B, max(S, 1)), dtype=torch.int32, device=self.device)
+        lib = N.load()
+        with torch.cuda.device(self.device):
+            N.check(lib.b2t_batch_gather_b32(ops._p(self.feat), ops._p(self.feat_off[r].contiguous()), ops._p(nts), ops._p(x),
+                                             B, T, self.F, ops._stream()), "b2t_batch_gather_b32")
+            N.check(lib.b2t_batch_gather_b32(ops._p(self.lab), ops._p(self.lab_off[r].contiguous()), ops._p(sls), ops._p(y),
+                                             B, max(S, 1), 1, ops._stream()), "b2t_batch_gather_b32")
+        return {'input_features': x, 'seq_class_ids': y.to(torch.int64), 'n_time_steps': nts.to(torch.int64),
+                'phone_seq_lens': sls.to(torch.int64), 'day_indicies': self.day[r], 'transcriptions': self.trans[r],
+                'block_nums': self.block[r], 'trial_nums': self.trial[r]}
 
 
 def make_synthetic_datasets(args):

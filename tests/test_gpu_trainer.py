@@ -92,3 +92,36 @@ def test_trainer_resume_and_validation_matches_oracle(tmp_path):
         losses.append(lo.mean())
     assert abs(vm['avg_PER'] - tot_e / tot_l) < 1e-9
     np.testing.assert_allclose(vm['avg_loss'], np.mean(np.repeat(losses, 2)), rtol=1e-5)
+
+
+def test_resident_dataset_matches_source_batches(tmp_path):
+    """the device-resident flat dataset reproduces the source's batch dicts exactly (features, labels,
+    lengths, days), batch by batch and for arbitrary row selections; the flat-binary round trip is lossless."""
+    from dataset import SyntheticTrials, ResidentDataset
+    src = SyntheticTrials(n_batches=5, batch_size=12, n_days=4, n_features=36, n_classes=41, days_per_batch=2, max_T=90,
+                          min_T=40, max_S=9, seed=3)
+    rd = ResidentDataset.from_batches(src, device='cuda:0')
+    assert len(rd) == 5 and rd.n_trials == 60
+    for i in range(len(src)):
+        a, b = src[i], rd.batch_of(i)
+        for k in ('input_features', 'seq_class_ids', 'n_time_steps', 'phone_seq_lens', 'day_indicies', 'block_nums', 'trial_nums'):
+            np.testing.assert_array_equal(b[k].cpu().numpy(), a[k].numpy(), err_msg=f"{k} batch {i}")
+        assert b['input_features'].dtype == torch.float32 and b['seq_class_ids'].dtype == torch.int64
+    # arbitrary rows (with repeats), an odd feature width (scalar copy path) and the file round trip
+    rows = torch.tensor([59, 0, 17, 17, 33])
+    got = rd.batch(rows)
+    T = int(got['n_time_steps'].max())
+    for j, r in enumerate(rows.tolist()):
+        n = int(rd.host['n_time_steps'][r]); o = int(rd.host['feat_off'][r])
+        np.testing.assert_array_equal(got['input_features'][j, :n].cpu().numpy(), rd.host['feat'][o:o + n])
+        assert float(got['input_features'][j, n:].abs().sum()) == 0.0
+    assert got['input_features'].shape == (5, T, 36)
+    p = str(tmp_path / "flat.npz")
+    rd.save(p)
+    rd2 = ResidentDataset.load(p, device='cuda:0')
+    b1, b2 = rd.batch_of(2), rd2.batch_of(2)
+    assert torch.equal(b1['input_features'], b2['input_features']) and torch.equal(b1['seq_class_ids'], b2['seq_class_ids'])
+    src7 = SyntheticTrials(n_batches=1, batch_size=5, n_days=2, n_features=7, n_classes=41, days_per_batch=1, max_T=30, min_T=20,
+                           max_S=4, seed=1)
+    rd7 = ResidentDataset.from_batches(src7, device='cuda:0')
+    np.testing.assert_array_equal(rd7.batch_of(0)['input_features'].cpu().numpy(), src7[0]['input_features'].numpy())
