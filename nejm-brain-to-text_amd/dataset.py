@@ -290,9 +290,12 @@ class ResidentDataset:
                                              B, T, self.F, ops._stream()), "b2t_batch_gather_b32")
             N.check(lib.b2t_batch_gather_b32(ops._p(self.lab), ops._p(self.lab_off[r].contiguous()), ops._p(sls), ops._p(y),
                                              B, max(S, 1), 1, ops._stream()), "b2t_batch_gather_b32")
+        # tensors the step consumes stay on the device; the bookkeeping fields are host tensors, as a DataLoader yields them
+        hn = rows_h.numpy()
+        host = lambda k: torch.from_numpy(self.host[k][hn])
         return {'input_features': x, 'seq_class_ids': y.to(torch.int64), 'n_time_steps': nts.to(torch.int64),
-                'phone_seq_lens': sls.to(torch.int64), 'day_indicies': self.day[r], 'transcriptions': self.trans[r],
-                'block_nums': self.block[r], 'trial_nums': self.trial[r]}
+                'phone_seq_lens': sls.to(torch.int64), 'day_indicies': host('day'), 'transcriptions': host('trans'),
+                'block_nums': host('block'), 'trial_nums': host('trial')}
 
 
 def make_synthetic_datasets(args):

@@ -92,6 +92,20 @@ def _strip_prefix(sd):
     return out
 
 
+class _ResidentLoader:
+    """Iterates a dataset.ResidentDataset like the DataLoader(batch_size=None) it replaces."""
+
+    def __init__(self, rd):
+        self.rd = rd
+
+    def __len__(self):
+        return len(self.rd)
+
+    def __iter__(self):
+        for i in range(len(self.rd)):
+            yield self.rd.batch_of(i)
+
+
 class BrainToTextDecoder_Trainer:
     def __init__(self, args):
         self.args = args
@@ -228,6 +242,11 @@ class BrainToTextDecoder_Trainer:
         self.train_loader = DataLoader(self.train_dataset, batch_size=None, shuffle=dsa.get('loader_shuffle', False),
                                        num_workers=nw, pin_memory=True)
         self.val_loader = DataLoader(self.val_dataset, batch_size=None, shuffle=False, num_workers=0, pin_memory=True)
+        if dsa.get('device_resident'):
+            # flatten both splits into HBM once; batches are then assembled on the device (no per-batch
+            # file reads, padding or PCIe copy).  Same batch composition and order as the loaders above.
+            self.train_loader = _ResidentLoader(ds.ResidentDataset.from_batches(self.train_dataset, self.device))
+            self.val_loader = _ResidentLoader(ds.ResidentDataset.from_batches(self.val_dataset, self.device))
         if 'dataset_probability_val' not in dsa:
             dsa['dataset_probability_val'] = [1] * len(dsa['sessions'])
         self.logger.info("Successfully initialized datasets")

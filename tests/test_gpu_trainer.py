@@ -125,3 +125,18 @@ def test_resident_dataset_matches_source_batches(tmp_path):
                            max_S=4, seed=1)
     rd7 = ResidentDataset.from_batches(src7, device='cuda:0')
     np.testing.assert_array_equal(rd7.batch_of(0)['input_features'].cpu().numpy(), src7[0]['input_features'].numpy())
+
+
+def test_trainer_with_device_resident_dataset(tmp_path):
+    """The trainer fed from the device-resident dataset produces the same losses and validation metrics as with the
+    DataLoader path (same batch composition and order, same augmentation draws)."""
+    from rnn_trainer import BrainToTextDecoder_Trainer
+    out = {}
+    for resident in (False, True):
+        args = make_args(str(tmp_path / ("r" if resident else "l")), n_batches=21)
+        args['dataset']['device_resident'] = resident
+        tr = BrainToTextDecoder_Trainer(args)
+        st = tr.train()
+        out[resident] = (st['train_losses'], st['val_PERs'])
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-6)
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=1e-9)
