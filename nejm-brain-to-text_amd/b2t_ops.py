@@ -527,7 +527,14 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
             ss = s_sweep[l] if piped else main
             # 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
             with torch.cuda.stream(sg):
-                if l == 0:
+                if l == 0 and n * B <= 512 and dims.In0 >= 2048:
+                    # streaming-sized calls (a few frames, patch input K = 7168): one GEMM over all (t, b) rows through
+                    # the two-level row map, K split over the chip -- as B per-sentence GEMMs of M = n rows the K loop
+                    # runs serially in 18 workgroups per sentence (0.4 ms of a 2 ms step)
+                    gemm(Ud, prm.w_ih[0], gis[0], M=n * B, N_=3 * H, K=dims.In0, a_kc=1, a_div=B, a_s1=a_s0_l0, a_s0=T * F,
+                         a_off=t0 * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[0],
+                         splitk=max(1, min(16, dims.In0 // 448)), ws=ws, slab="splitk_slab_gi0")
+                elif l == 0:
                     gemm(Ud, prm.w_ih[0], gis[0], M=n, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0_l0, a_sz=T * F,
                          a_off=t0 * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H, c_off=t0 * B * 3 * H,
                          bias=prm.b_ih[0])
@@ -539,8 +546,10 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
                         dropout(outs[l - 1], outs_d[l - 1], n * B * H, rnn_drop, seed * 1000003 + 101 + (l - 1),
                                 elem0=t0 * B * H, x_off=(1 + t0) * B * H, y_off=(1 + t0) * B * H)
                         src = outs_d[l - 1]
+                    small = n * B <= 512 and H >= 384      # streaming-sized call: split K (one 128-row tile otherwise)
                     gemm(src, prm.w_ih[l], gis[l], M=n * B, N_=3 * H, K=H, a_kc=1, a_s0=H, a_off=(1 + t0) * B * H,
-                         b_kc=1, b_s0=H, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[l])
+                         b_kc=1, b_s0=H, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[l],
+                         **(dict(splitk=max(1, H // 192), ws=ws, slab="splitk_slab_gi") if small else {}))
                 ev_gi = _ev(sg) if piped else None
             # 3. recurrent sweep over the chunk, continuing from outs[l][t0] = h_{t0-1}
             with torch.cuda.stream(ss):
