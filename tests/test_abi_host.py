@@ -163,3 +163,16 @@ def test_dataset_sampler_semantics():
         assert torch.all(b["input_features"][i, int(b["n_time_steps"][i]):] == 0)
         assert torch.all(b["seq_class_ids"][i, int(b["phone_seq_lens"][i]):] == 0)
     assert torch.equal(syn[1]["input_features"], b["input_features"])
+
+
+def test_time_chunk_plan_rule():
+    """Layer pipelining only when two sweeps can be resident together (b2t_ops.time_chunks): C2 pipelines over 6 chunks,
+    the H = 768 shape runs the layers in sequence, short sequences are not cut below 16 steps per chunk."""
+    import b2t_ops as ops
+    assert "B2T_CHUNKS" not in os.environ
+    c2 = ops.time_chunks(500, 64, 512)
+    assert len(c2) == 6 and c2[0][0] == 0 and c2[-1][1] == 500 and all(a[1] == b[0] for a, b in zip(c2, c2[1:]))
+    assert ops.time_chunks(122, 64, 768) == [(0, 122)]
+    assert ops.time_chunks(500, 128, 512)[-1][1] == 500 and len(ops.time_chunks(500, 128, 512)) == 6
+    assert len(ops.time_chunks(500, 192, 512)) == 1          # 2 x 384 workgroups > 512 slots
+    assert len(ops.time_chunks(40, 64, 512)) == 2 and ops.time_chunks(1, 32, 512) == [(0, 1)]
