@@ -522,49 +522,48 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
                         SUB, epoch, _stream()), "b2t_gru_layer_fwd_flagged_f32")
                 ev_sw[l][c] = _ev(ss)
             continue
-        if True:
-            sg = s_gemm[l] if piped else main
-            ss = s_sweep[l] if piped else main
-            # 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
-            with torch.cuda.stream(sg):
-                if l == 0 and n * B <= 512 and dims.In0 >= 2048:
-                    # streaming-sized calls (a few frames, patch input K = 7168): one GEMM over all (t, b) rows through
-                    # the two-level row map, K split over the chip -- as B per-sentence GEMMs of M = n rows the K loop
-                    # runs serially in 18 workgroups per sentence (0.4 ms of a 2 ms step)
-                    gemm(Ud, prm.w_ih[0], gis[0], M=n * B, N_=3 * H, K=dims.In0, a_kc=1, a_div=B, a_s1=a_s0_l0, a_s0=T * F,
-                         a_off=t0 * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[0],
-                         splitk=max(1, min(16, dims.In0 // 448)), ws=ws, slab="splitk_slab_gi0")
-                elif l == 0:
-                    gemm(Ud, prm.w_ih[0], gis[0], M=n, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0_l0, a_sz=T * F,
-                         a_off=t0 * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H, c_off=t0 * B * 3 * H,
-                         bias=prm.b_ih[0])
-                else:
-                    if piped:
-                        sg.wait_event(ev_sw[l - 1][c])
-                    src = outs[l - 1]
-                    if outs_d[l - 1] is not outs[l - 1]:   # nn.GRU inter-layer dropout (rnn_model.py:70)
-                        dropout(outs[l - 1], outs_d[l - 1], n * B * H, rnn_drop, seed * 1000003 + 101 + (l - 1),
-                                elem0=t0 * B * H, x_off=(1 + t0) * B * H, y_off=(1 + t0) * B * H)
-                        src = outs_d[l - 1]
-                    small = n * B <= 512 and H >= 384      # streaming-sized call: split K (one 128-row tile otherwise)
-                    gemm(src, prm.w_ih[l], gis[l], M=n * B, N_=3 * H, K=H, a_kc=1, a_s0=H, a_off=(1 + t0) * B * H,
-                         b_kc=1, b_s0=H, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[l],
-                         **(dict(splitk=max(1, H // 192), ws=ws, slab="splitk_slab_gi") if small else {}))
-                ev_gi = _ev(sg) if piped else None
-            # 3. recurrent sweep over the chunk, continuing from outs[l][t0] = h_{t0-1}
-            with torch.cuda.stream(ss):
+        sg = s_gemm[l] if piped else main
+        ss = s_sweep[l] if piped else main
+        # 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
+        with torch.cuda.stream(sg):
+            if l == 0 and n * B <= 512 and dims.In0 >= 2048:
+                # streaming-sized calls (a few frames, patch input K = 7168): one GEMM over all (t, b) rows through
+                # the two-level row map, K split over the chip -- as B per-sentence GEMMs of M = n rows the K loop
+                # runs serially in 18 workgroups per sentence (0.4 ms of a 2 ms step)
+                gemm(Ud, prm.w_ih[0], gis[0], M=n * B, N_=3 * H, K=dims.In0, a_kc=1, a_div=B, a_s1=a_s0_l0, a_s0=T * F,
+                     a_off=t0 * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[0],
+                     splitk=max(1, min(16, dims.In0 // 448)), ws=ws, slab="splitk_slab_gi0")
+            elif l == 0:
+                gemm(Ud, prm.w_ih[0], gis[0], M=n, N_=3 * H, K=dims.In0, Z=B, a_kc=1, a_s0=a_s0_l0, a_sz=T * F,
+                     a_off=t0 * a_s0_l0, b_kc=1, b_s0=dims.In0, c_s0=B * 3 * H, c_sz=3 * H, c_off=t0 * B * 3 * H,
+                     bias=prm.b_ih[0])
+            else:
                 if piped:
-                    ss.wait_event(ev_gi)
-                res_ptr = C.c_void_p(reserves[l].data_ptr() + 4 * t0 * B * 4 * H) if save else None
-                with _Prof("gru_sweep_fwd", 2.0 * n * B * 3 * H * H, n if mode == 0 else 1):
-                    N.check(lib.b2t_gru_layer_fwd_f32(
-                        C.c_void_p(gis[l].data_ptr() + 4 * t0 * B * 3 * H), _p(prm.w_hh[l]), _p(prm.b_hh[l]),
-                        C.c_void_p(outs[l].data_ptr() + 4 * t0 * B * H),
-                        C.c_void_p(outs[l].data_ptr() + 4 * (1 + t0) * B * H), res_ptr,
-                        _p(hidden[l]) if t1 == Tp else None, n, B, H, sweep_mode_arg(mode),
-                        _p(ws.sync_ws(l, Tp, dev, B, H)) if mode >= 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
-                if piped:
-                    ev_sw[l][c] = _ev(ss)
+                    sg.wait_event(ev_sw[l - 1][c])
+                src = outs[l - 1]
+                if outs_d[l - 1] is not outs[l - 1]:   # nn.GRU inter-layer dropout (rnn_model.py:70)
+                    dropout(outs[l - 1], outs_d[l - 1], n * B * H, rnn_drop, seed * 1000003 + 101 + (l - 1),
+                            elem0=t0 * B * H, x_off=(1 + t0) * B * H, y_off=(1 + t0) * B * H)
+                    src = outs_d[l - 1]
+                small = n * B <= 512 and H >= 384      # streaming-sized call: split K (one 128-row tile otherwise)
+                gemm(src, prm.w_ih[l], gis[l], M=n * B, N_=3 * H, K=H, a_kc=1, a_s0=H, a_off=(1 + t0) * B * H,
+                     b_kc=1, b_s0=H, c_s0=3 * H, c_off=t0 * B * 3 * H, bias=prm.b_ih[l],
+                     **(dict(splitk=max(1, H // 192), ws=ws, slab="splitk_slab_gi") if small else {}))
+            ev_gi = _ev(sg) if piped else None
+        # 3. recurrent sweep over the chunk, continuing from outs[l][t0] = h_{t0-1}
+        with torch.cuda.stream(ss):
+            if piped:
+                ss.wait_event(ev_gi)
+            res_ptr = C.c_void_p(reserves[l].data_ptr() + 4 * t0 * B * 4 * H) if save else None
+            with _Prof("gru_sweep_fwd", 2.0 * n * B * 3 * H * H, n if mode == 0 else 1):
+                N.check(lib.b2t_gru_layer_fwd_f32(
+                    C.c_void_p(gis[l].data_ptr() + 4 * t0 * B * 3 * H), _p(prm.w_hh[l]), _p(prm.b_hh[l]),
+                    C.c_void_p(outs[l].data_ptr() + 4 * t0 * B * H),
+                    C.c_void_p(outs[l].data_ptr() + 4 * (1 + t0) * B * H), res_ptr,
+                    _p(hidden[l]) if t1 == Tp else None, n, B, H, sweep_mode_arg(mode),
+                    _p(ws.sync_ws(l, Tp, dev, B, H)) if mode >= 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
+            if piped:
+                ev_sw[l][c] = _ev(ss)
     if piped and not stacked:
         # One join is enough: the last chunk of the top layer's sweep transitively depends on every GEMM and sweep
         # enqueued above.  (Each wait is a barrier packet the command processor works through one by one: the 10-15
@@ -684,59 +683,58 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                        key=lambda cl: ((nc - 1 - cl[0]) + (L - 1 - cl[1]), -cl[1])):
         t0, t1 = chunks[c]
         n = t1 - t0
-        if True:
-            ss = s_sweep[l] if piped else main
-            sg = s_gemm[l] if piped else main
-            with torch.cuda.stream(ss):
-                if piped:
-                    if l < L - 1:
-                        ss.wait_event(ev_dx[l + 1][c])
-                    if c == nc - 1:
-                        ss.wait_event(ev_wt[l])
-                else:
-                    if c == nc - 1:
-                        N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_ts[l]), 3 * H, H, _stream()),
-                                "b2t_transpose_f32")
-                if ctx.rnn_drop > 0 and l < L - 1:   # gradient through the inter-layer dropout mask
-                    dropout(dYs[l], dYs[l], n * B * H, ctx.rnn_drop, ctx.seed * 1000003 + 101 + l,
-                            elem0=t0 * B * H, x_off=t0 * B * H, y_off=t0 * B * H)
+        ss = s_sweep[l] if piped else main
+        sg = s_gemm[l] if piped else main
+        with torch.cuda.stream(ss):
+            if piped:
+                if l < L - 1:
+                    ss.wait_event(ev_dx[l + 1][c])
                 if c == nc - 1:
-                    dh_last = _p(dhidden[l].contiguous()) if dhidden is not None else None
-                else:
-                    dh_last = _p(carries[l][(c + 1) % 2])
-                dh_out = _p(dh_init[l]) if c == 0 else _p(carries[l][c % 2])
-                outb = ctx.outs[l]
-                with _Prof("gru_sweep_bwd", 2.0 * n * B * 3 * H * H, n + 1 if mode == 0 else 1):
-                    N.check(lib.b2t_gru_layer_bwd_f32(
-                        C.c_void_p(dYs[l].data_ptr() + 4 * t0 * B * H), dh_last,
-                        C.c_void_p(ctx.reserves[l].data_ptr() + 4 * t0 * B * 4 * H),
-                        C.c_void_p(outb.data_ptr() + 4 * (1 + t0) * B * H), C.c_void_p(outb.data_ptr() + 4 * t0 * B * H),
-                        _p(whh_ts[l]), C.c_void_p(dGs[l].data_ptr() + 4 * t0 * B * 4 * H), dh_out, _p(scratch[l]),
-                        n, B, H, sweep_mode_arg(bwd_mode_for(mode)), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
-                        "b2t_gru_layer_bwd_f32")
-                if piped:
-                    ev_bs[l][c] = _ev(ss)
-            with torch.cuda.stream(sg):
-                if piped:
-                    sg.wait_event(ev_bs[l][c])
-                dx_gemm(l, t0, n)
-                if piped:
-                    ev_dx[l][c] = _ev(sg)
-            if piped and c == 0:
-                # weight gradients of the whole layer once its last chunk is swept, on their own stream (they overlap
-                # the sweeps of the layers below).  Per-chunk accumulation is supported by the helper but measured
-                # slower inside the full step, for every layer and also for layer 0 alone (28.2 vs 27.1 ms): more
-                # launches competing with the sweeps' CUs.  Layer 0's go to the top layer's GEMM stream (idle by then)
-                # so that they overlap the day-layer backward instead of queueing in front of it.
-                swg = s_gemm[L - 1] if (l == 0 and L > 1) else s_wg[l]
-                if PIPELINE["defer_wgrad"] and l > 0:
-                    deferred.append((swg, l))     # experiment: weight gradients only once every sweep has finished
-                else:
-                    with torch.cuda.stream(swg):
-                        swg.wait_event(ev_bs[l][c])
-                        _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
-            if (not piped) and c == 0:
-                _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
+                    ss.wait_event(ev_wt[l])
+            else:
+                if c == nc - 1:
+                    N.check(lib.b2t_transpose_f32(_p(prm.w_hh[l]), _p(whh_ts[l]), 3 * H, H, _stream()),
+                            "b2t_transpose_f32")
+            if ctx.rnn_drop > 0 and l < L - 1:   # gradient through the inter-layer dropout mask
+                dropout(dYs[l], dYs[l], n * B * H, ctx.rnn_drop, ctx.seed * 1000003 + 101 + l,
+                        elem0=t0 * B * H, x_off=t0 * B * H, y_off=t0 * B * H)
+            if c == nc - 1:
+                dh_last = _p(dhidden[l].contiguous()) if dhidden is not None else None
+            else:
+                dh_last = _p(carries[l][(c + 1) % 2])
+            dh_out = _p(dh_init[l]) if c == 0 else _p(carries[l][c % 2])
+            outb = ctx.outs[l]
+            with _Prof("gru_sweep_bwd", 2.0 * n * B * 3 * H * H, n + 1 if mode == 0 else 1):
+                N.check(lib.b2t_gru_layer_bwd_f32(
+                    C.c_void_p(dYs[l].data_ptr() + 4 * t0 * B * H), dh_last,
+                    C.c_void_p(ctx.reserves[l].data_ptr() + 4 * t0 * B * 4 * H),
+                    C.c_void_p(outb.data_ptr() + 4 * (1 + t0) * B * H), C.c_void_p(outb.data_ptr() + 4 * t0 * B * H),
+                    _p(whh_ts[l]), C.c_void_p(dGs[l].data_ptr() + 4 * t0 * B * 4 * H), dh_out, _p(scratch[l]),
+                    n, B, H, sweep_mode_arg(bwd_mode_for(mode)), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
+                    "b2t_gru_layer_bwd_f32")
+            if piped:
+                ev_bs[l][c] = _ev(ss)
+        with torch.cuda.stream(sg):
+            if piped:
+                sg.wait_event(ev_bs[l][c])
+            dx_gemm(l, t0, n)
+            if piped:
+                ev_dx[l][c] = _ev(sg)
+        if piped and c == 0:
+            # weight gradients of the whole layer once its last chunk is swept, on their own stream (they overlap
+            # the sweeps of the layers below).  Per-chunk accumulation is supported by the helper but measured
+            # slower inside the full step, for every layer and also for layer 0 alone (28.2 vs 27.1 ms): more
+            # launches competing with the sweeps' CUs.  Layer 0's go to the top layer's GEMM stream (idle by then)
+            # so that they overlap the day-layer backward instead of queueing in front of it.
+            swg = s_gemm[L - 1] if (l == 0 and L > 1) else s_wg[l]
+            if PIPELINE["defer_wgrad"] and l > 0:
+                deferred.append((swg, l))     # experiment: weight gradients only once every sweep has finished
+            else:
+                with torch.cuda.stream(swg):
+                    swg.wait_event(ev_bs[l][c])
+                    _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
+        if (not piped) and c == 0:
+            _layer_weight_grads(dims, grd, ctx, ws, dGs, l, M, bucket_cb)
 
     for swg, l in deferred:
         with torch.cuda.stream(swg):

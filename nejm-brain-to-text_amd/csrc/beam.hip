@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       HypBuf hb(st, lay, s_cur);
       if (tid < s_nb) {
         const int n = hb.node[tid];
-        h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0; h_lx[tid] = lexm ? nlx[n] : 0; h_lx[tid] = lexm ? nlx[n] : 0;
+        h_lm[tid] = fused ? nlm[n] : 0.f; h_lst[tid] = fused ? nlst[n] : 0; h_lx[tid] = lexm ? nlx[n] : 0;
         h_node[tid] = n; h_par[tid] = par[n]; h_tok[tid] = tok[n]; h_dep[tid] = dep[n];
         h_s[tid] = hb.fl[0 * BMAX + tid]; h_ns[tid] = hb.fl[1 * BMAX + tid]; h_vs[tid] = hb.fl[2 * BMAX + tid];
         h_vns[tid] = hb.fl[3 * BMAX + tid]; h_ctp[tid] = hb.fl[4 * BMAX + tid];
