@@ -20,6 +20,10 @@
 #include "gru_cell.h"
 #include "gru_sync.h"
 
+#ifndef B2T_LOAD_AUX
+#define B2T_LOAD_AUX 16   // cache policy of the operand loads: 16 = sc1 (never served from this XCD's L2), 0 = ordinary
+#endif
+
 namespace b2t {
 
 // ---------------------------------------------------------------------------------------------------
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
     // All loads go out first (branch-free, clamped: a conditional load makes the compiler wait for everything), then
     // each pair is transposed and consumed as it lands (vmcnt(6), vmcnt(4), ...).
     float4 v[NCH];
-    issue_block_loads<NCH, AUX>(v, hsrc, m0, B, H, wave * NCH * 16, H, lane);
+    issue_block_loads<NCH, B2T_LOAD_AUX>(v, hsrc, m0, B, H, wave * NCH * 16, H, lane);
     __builtin_amdgcn_sched_barrier(0);   // all loads are in flight before the first MFMA (the scheduler would sink them)
 #ifdef B2T_TIMING_SPLIT_LOADS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
       f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
       float4 v[NCB];
-      issue_block_loads<NCB, AUX>(v, dgh, m0, B, 4 * H, wave * NCB * 16, 3 * H, lane);
+      issue_block_loads<NCB, B2T_LOAD_AUX>(v, dgh, m0, B, 4 * H, wave * NCB * 16, 3 * H, lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < NCB / 2; ++p) {
