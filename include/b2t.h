@@ -133,6 +133,7 @@ int b2t_batch_gather_b32(const void* flat, const int64_t* row_off, const int32_t
  * autocast(bfloat16) regime for the GRU, opt-in.
  * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode; zeroed by the call). */
 #define B2T_GRU_BF16 0x100
+#define B2T_GRU_WIDE 0x200   /* with B2T_GRU_BF16: 32 hidden units per workgroup (half the workgroups per sweep), H % 32 == 0, H <= 512 */
 size_t b2t_gru_sync_bytes(int T);
 /* Workspace size valid for every mode (mode 2 = persistent sweep with data-tagged 8-byte {value,tag}
  * granule hand-off, csrc/gru_granule.hip: needs T*B*H*8 bytes of granules behind the control words). */

@@ -300,9 +300,18 @@ def gru_stack_forward(dims, prm, gi0, outs, outs_d, reserves, Tp, B, rnn_drop, s
 GRU_BF16 = 0x100   # B2T_GRU_BF16 (include/b2t.h): bf16 operands of the recurrent product, persistent mode 1
 
 
-def sweep_mode_arg(mode: int) -> int:
+GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup (bf16 operands only)
+# which sweeps run with 32-unit workgroups under AMP: "" none, "f" forward, "b" backward, "fb" both (B2T_AMP_WIDE;
+# measured at C2: 18.4 / 17.5 / 17.1 / 16.1 ms per step)
+AMP["wide"] = os.environ.get("B2T_AMP_WIDE", "fb")
+
+
+def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
     """`mode` argument of b2t_gru_layer_fwd/bwd_f32: under set_amp(True) the persistent sweeps take bf16 operands."""
-    return mode | GRU_BF16 if (AMP["on"] and AMP.get("sweeps", True) and mode == 1) else mode
+    if not (AMP["on"] and AMP.get("sweeps", True) and mode == 1):
+        return mode
+    wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= 512) else 0   # (LDS staging of H > 512 exceeds 64 KB)
+    return mode | GRU_BF16 | wide
 
 
 def gru_sync_check(sync_ws, T: int, B: int):
@@ -560,7 +569,7 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
                     C.c_void_p(gis[l].data_ptr() + 4 * t0 * B * 3 * H), _p(prm.w_hh[l]), _p(prm.b_hh[l]),
                     C.c_void_p(outs[l].data_ptr() + 4 * t0 * B * H),
                     C.c_void_p(outs[l].data_ptr() + 4 * (1 + t0) * B * H), res_ptr,
-                    _p(hidden[l]) if t1 == Tp else None, n, B, H, sweep_mode_arg(mode),
+                    _p(hidden[l]) if t1 == Tp else None, n, B, H, sweep_mode_arg(mode, H, "f"),
                     _p(ws.sync_ws(l, Tp, dev, B, H)) if mode >= 1 else None, _stream()), "b2t_gru_layer_fwd_f32")
             if piped:
                 ev_sw[l][c] = _ev(ss)
@@ -710,7 +719,7 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
                     C.c_void_p(ctx.reserves[l].data_ptr() + 4 * t0 * B * 4 * H),
                     C.c_void_p(outb.data_ptr() + 4 * (1 + t0) * B * H), C.c_void_p(outb.data_ptr() + 4 * t0 * B * H),
                     _p(whh_ts[l]), C.c_void_p(dGs[l].data_ptr() + 4 * t0 * B * 4 * H), dh_out, _p(scratch[l]),
-                    n, B, H, sweep_mode_arg(bwd_mode_for(mode)), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
+                    n, B, H, sweep_mode_arg(bwd_mode_for(mode), H, "b"), _p(ws.sync_ws(l, Tp, dev, B, H, "b")) if mode >= 1 else None, _stream()),
                     "b2t_gru_layer_bwd_f32")
             if piped:
                 ev_bs[l][c] = _ev(ss)

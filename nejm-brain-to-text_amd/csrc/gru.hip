@@ -125,7 +125,8 @@ extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const f
   B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_fwd: bad shape T=%d B=%d H=%d (H%%16 must be 0)", T, B, H);
   hipStream_t s = as_stream(stream);
   const bool bf16 = (mode & B2T_GRU_BF16) != 0;   // bf16 operands of the recurrent product (persistent mode 1 only)
-  mode &= ~B2T_GRU_BF16;
+  const bool wide = (mode & B2T_GRU_WIDE) != 0;   // 32 hidden units per workgroup (with bf16 operands)
+  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE);
   B2T_REQUIRE(mode >= 0 && mode <= 3, "gru_layer_fwd: unknown mode %d", mode);
   B2T_REQUIRE(!bf16 || mode == 1, "gru_layer_fwd: B2T_GRU_BF16 goes with mode 1");
   if (mode == 3) {   // pipelined sweep; shapes it does not cover run as mode 1 (same protocol and workspace)
@@ -138,7 +139,7 @@ extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const f
     int rc = gru_granule_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
     if (rc) return rc;
   } else if (mode == 1) {
-    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s, bf16);
+    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s, bf16, wide);
     if (rc) return rc;
   } else {
     dim3 grid(H / 16, (B + 15) / 16), block(256);
@@ -164,7 +165,8 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
   B2T_REQUIRE(carry_ws != nullptr, "gru_layer_bwd: carry_ws is required ([B][H] floats)");
   hipStream_t s = as_stream(stream);
   const bool bf16 = (mode & B2T_GRU_BF16) != 0;
-  mode &= ~B2T_GRU_BF16;
+  const bool wide = (mode & B2T_GRU_WIDE) != 0;
+  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE);
   B2T_REQUIRE(mode >= 0 && mode <= 3, "gru_layer_bwd: unknown mode %d", mode);
   B2T_REQUIRE(!bf16 || mode == 1, "gru_layer_bwd: B2T_GRU_BF16 goes with mode 1");
   if (mode == 3) {
@@ -172,7 +174,7 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
     if (rc != 4) return rc;   // 4: shape not covered -> mode 1
   }
   if (mode >= 1) {   // mode 2 (granule forward) pairs with the counter backward
-    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s, bf16);
+    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s, bf16, wide);
   }
   dim3 grid(H / 16, (B + 15) / 16), block(256);
   for (int t = T - 1; t >= -1; --t)

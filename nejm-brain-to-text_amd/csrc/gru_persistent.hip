@@ -29,22 +29,26 @@ namespace b2t {
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <int NCH, bool BF16>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
-__global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kernel(const float* __restrict__ gi,
+// NT: 16-unit tiles per workgroup (1, or 2 with bf16 operands, whose weight slice is half the registers): 32 units per
+// workgroup halve the workgroups of a sweep -- five concurrent sweeps then crowd the CUs half as much.
+template <int NCH, bool BF16, int NT = 1>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
+__global__ __launch_bounds__(256, (NT == 2 ? 2 : (NCH <= 8 ? 3 : 1))) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
                                                                  float* __restrict__ reserve, int T, int B, int H,
                                                                  unsigned* sync, SweepFlags fl) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TP];
+  static_assert(NT == 1 || BF16, "two tiles per workgroup need the bf16 weight slice");
+  constexpr int TPN = 16 * NT + 4;    // LDS pitch of the staged tile (= TP for one tile)
+  __shared__ __attribute__((aligned(16))) float red[4 * 3 * NT * 4 * 64 + 16 * TPN];
   __shared__ __attribute__((aligned(16))) float stage[4][NCH * SLOT_F];   // per-wave operand staging (gru_sync.h)
-  float* hs = red + 4 * 3 * 4 * 64;   // staged h tile [16 rows][TP]
+  float* hs = red + 4 * 3 * NT * 4 * 64;   // staged h tile [16 rows][TPN]
   constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef B2T_NO_SETPRIO
   __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
 #endif
-  const unsigned G = (unsigned)H / 16u;
+  const unsigned G = (unsigned)H / (16u * NT);
   const int j = lane & 15, q = lane >> 4;
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
   // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
@@ -56,25 +60,33 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
   }
   const int rg = blockIdx.y, m0 = rg * 16;   // row groups are independent recurrences
-  const int j0 = blockIdx.x * 16;
-  const int unit = j0 + j;
+  const int j0 = blockIdx.x * 16 * NT;
+  int unit[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) unit[n] = j0 + 16 * n + j;
   const int nch = H / 16;
 
-  typename WFrag<BF16>::type w[3][NCH];
+  typename WFrag<BF16>::type w[3][NT][NCH];
 #pragma unroll
   for (int ci = 0; ci < NCH; ++ci) {
     const int c = KCHUNK(wave, ci, NCH);
 #pragma unroll
     for (int g = 0; g < 3; ++g)
-      w[g][ci] = make_wfrag<BF16>(c < nch ? *reinterpret_cast<const float4*>(w_hh + ((long long)g * H + unit) * H + c * 16 + 4 * q)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        w[g][n][ci] = make_wfrag<BF16>(c < nch ? *reinterpret_cast<const float4*>(w_hh + ((long long)g * H + unit[n]) * H + c * 16 + 4 * q)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f));
   }
-  const float bhr = b_hh[unit], bhz = b_hh[H + unit], bhn = b_hh[2 * H + unit];
+  float bhr[NT], bhz[NT], bhn[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { bhr[n] = b_hh[unit[n]]; bhz[n] = b_hh[H + unit[n]]; bhn[n] = b_hh[2 * H + unit[n]]; }
   const int row = m0 + 4 * q + wave, arow = m0 + j;
   const int arow_c = arow < B ? arow : B - 1;
   const bool live = row < B;
   unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
-  float hp = live ? h_init[(long long)row * H + unit] : 0.f;
+  float hp[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) hp[n] = live ? h_init[(long long)row * H + unit[n]] : 0.f;
 
 #ifdef B2T_TIMING
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -88,15 +100,19 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
    {
     // gi of sub-chunk k is written by a GEMM that may still be running when this kernel starts
     if (fl.ready && t % fl.sub == 0) wait_flag(fl.ready + t / fl.sub, fl.epoch, err);
-    float gir = 0.f, giz = 0.f, gin = 0.f;
-    if (live) {
-      const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit;
-      if (fl.ready) {   // produced while this kernel runs: read it coherently
-        gir = __hip_atomic_load(const_cast<float*>(g3), RLX_AGENT);
-        giz = __hip_atomic_load(const_cast<float*>(g3 + H), RLX_AGENT);
-        gin = __hip_atomic_load(const_cast<float*>(g3 + 2 * H), RLX_AGENT);
-      } else {
-        gir = g3[0]; giz = g3[H]; gin = g3[2 * H];
+    float gir[NT], giz[NT], gin[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      gir[n] = giz[n] = gin[n] = 0.f;
+      if (live) {
+        const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit[n];
+        if (fl.ready) {   // produced while this kernel runs: read it coherently
+          gir[n] = __hip_atomic_load(const_cast<float*>(g3), RLX_AGENT);
+          giz[n] = __hip_atomic_load(const_cast<float*>(g3 + H), RLX_AGENT);
+          gin[n] = __hip_atomic_load(const_cast<float*>(g3 + 2 * H), RLX_AGENT);
+        } else {
+          gir[n] = g3[0]; giz[n] = g3[H]; gin[n] = g3[2 * H];
+        }
       }
     }
     const float* hsrc = h_init;
@@ -105,9 +121,9 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
       hsrc = out + (long long)(t - 1) * B * H;
     }
     TSTAMP(0)   // poll + barrier
-    f32x4 acc[3];
+    f32x4 acc[3 * NT];   // [gate][tile]
 #pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 3 * NT; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     // All loads go out first (branch-free, clamped: a conditional load makes the compiler wait for everything), then
     // each pair is transposed and consumed as it lands (vmcnt(6), vmcnt(4), ...).
     float4 v[NCH];
@@ -125,35 +141,45 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
       for (int h2 = 0; h2 < 2; ++h2) {
         const int ci = 2 * p + h2;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = mfma_chunk16<BF16>(a[h2], w[g][ci], acc[g]);
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[g * NT + n] = mfma_chunk16<BF16>(a[h2], w[g][n][ci], acc[g * NT + n]);
       }
     }
     asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
     TSTAMP(1)   // loads + MFMA
-    float gh[3];
-    cross_wave_reduce<3>(red, acc, gh, wave, lane);
+    float gh[3 * NT];
+    cross_wave_reduce<3 * NT>(red, acc, gh, wave, lane);
     TSTAMP(2)   // reduce
-    float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_ghn = 0.f;
-    if (live) {
+    float sv_r[NT], sv_z[NT], sv_n[NT], sv_ghn[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      sv_r[n] = sv_z[n] = sv_n[n] = sv_ghn[n] = 0.f;
+      if (live) {
       // gate non-linearities on the hardware exp unit (v_exp_f32, ~1 ulp): sigmoid(x) = 1/(1+2^(-x log2 e)),
       // tanh(x) = 1 - 2/(1+2^(2x log2 e)); the precise libm forms cost ~800 cycles per step on the serial chain.
-      const float ghn = gh[2] + bhn;
-      const float r = fast_sigmoid(gir + gh[0] + bhr);
-      const float z = fast_sigmoid(giz + gh[1] + bhz);
-      const float n = fast_tanh(gin + r * ghn);
-      const float h = (1.0f - z) * n + z * hp;
-      hs[(4 * q + wave) * TP + j] = h;
-      sv_r = r; sv_z = z; sv_n = n; sv_ghn = ghn;
-      hp = h;
+        const float ghn = gh[2 * NT + n] + bhn[n];
+        const float r = fast_sigmoid(gir[n] + gh[0 * NT + n] + bhr[n]);
+        const float z = fast_sigmoid(giz[n] + gh[1 * NT + n] + bhz[n]);
+        const float nn = fast_tanh(gin[n] + r * ghn);
+        const float h = (1.0f - z) * nn + z * hp[n];
+        hs[(4 * q + wave) * TPN + 16 * n + j] = h;
+        sv_r[n] = r; sv_z[n] = z; sv_n[n] = nn; sv_ghn[n] = ghn;
+        hp[n] = h;
+      }
     }
     TSTAMP(3)   // gates
     __syncthreads();                       // tile staged; also fences `red` for the next iteration
     TSTAMP(4)   // stage barrier (waits for the slowest wave's gates)
     if (wave == 0) {                       // one wave writes the 16x16 tile as 64 x 16 B write-through stores
-      const int r = lane >> 2, c4 = (lane & 3) * 4;
-      if (m0 + r < B)
-        store_f4<AUX>(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + j0 + c4) * 4),
-                     *reinterpret_cast<const float4*>(&hs[r * TP + c4]));
+      const int r = lane >> 2;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int c4 = 16 * n + (lane & 3) * 4;
+        if (m0 + r < B)
+          store_f4<AUX>(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + j0 + c4) * 4),
+                       *reinterpret_cast<const float4*>(&hs[r * TPN + c4]));
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) {
         __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
@@ -164,8 +190,11 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
     // The gate values saved for the backward sweep are nobody's dependency inside this sweep: store them AFTER the
     // publish so their write acknowledgements are not part of the drain in front of the counter increment.
     if (live && reserve) {
-      float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
-      rs[0] = sv_r; rs[H] = sv_z; rs[2 * H] = sv_n; rs[3 * H] = sv_ghn;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float* rs = reserve + ((long long)t * B + row) * 4 * H + unit[n];
+        rs[0] = sv_r[n]; rs[H] = sv_z[n]; rs[2 * H] = sv_n[n]; rs[3 * H] = sv_ghn[n];
+      }
     }
     TSTAMP(5)   // tile store + drain + publish
    }
@@ -182,7 +211,7 @@ __global__ __launch_bounds__(256, (NCH <= 8 ? 3 : 1)) void gru_persist_fwd_kerne
 // dGh_{t+1} row block with its register-resident W_hh[:, slice] and (B) forms the gate gradients of
 // step t for its slice, publishing them as dG[t] for the other workgroups of the row group.
 // ---------------------------------------------------------------------------------------------------
-template <int NCB, bool BF16>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
+template <int NCB, bool BF16, int NT = 1>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
 __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __restrict__ dY,
                                                                  const float* __restrict__ dh_last,
                                                                  const float* __restrict__ reserve,
@@ -191,16 +220,18 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  const float* __restrict__ w_hh_t, float* dG,
                                                                  float* __restrict__ dh_init, int T, int B, int H,
                                                                  unsigned* sync, SweepFlags fl) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 + 4 * 16 * TP];
+  static_assert(NT == 1 || BF16, "two tiles per workgroup need the bf16 weight slice");
+  constexpr int TPN = 16 * NT + 4;
+  __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64 + 4 * 16 * TPN];
   constexpr int NSLOT = NCB < 8 ? NCB : 8;   // staging slots per wave, recycled every NSLOT instructions
   __shared__ __attribute__((aligned(16))) float stage[4][NSLOT * SLOT_F];
-  float* gs = red + 4 * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TP]
+  float* gs = red + 4 * NT * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TPN]
   constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef B2T_NO_SETPRIO
   __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
 #endif
-  const unsigned G = (unsigned)H / 16u;
+  const unsigned G = (unsigned)H / (16u * NT);
   const int j = lane & 15, q = lane >> 4;
   unsigned* err = sync;  // word 0: error flag (sticky), word 1: which counter set this call uses
   // Two counter sets alternate between calls: this call counts in set p and clears set 1-p for the next call
@@ -212,22 +243,28 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
   }
   const int rg = blockIdx.y, m0 = rg * 16;   // row groups are independent recurrences
-  const int j0 = blockIdx.x * 16;
-  const int unit = j0 + j;
+  const int j0 = blockIdx.x * 16 * NT;
+  int unit[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) unit[n] = j0 + 16 * n + j;
   const int nch = 3 * H / 16;
 
-  typename WFrag<BF16>::type w[NCB];
+  typename WFrag<BF16>::type w[NT][NCB];
 #pragma unroll
   for (int ci = 0; ci < NCB; ++ci) {
     const int c = KCHUNK(wave, ci, NCB);
-    w[ci] = make_wfrag<BF16>(c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit * 3 * H + c * 16 + 4 * q)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      w[n][ci] = make_wfrag<BF16>(c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit[n] * 3 * H + c * 16 + 4 * q)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f));
   }
   const int row = m0 + 4 * q + wave, arow = m0 + j;
   const int arow_c = arow < B ? arow : B - 1;
   const bool live = row < B;
   unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
-  float dzterm = 0.f;
+  float dzterm[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) dzterm[n] = 0.f;
 
   unsigned* tickets = sync + 32 + (size_t)pset * SETW + (size_t)gridDim.y * T * CSTRIDE;   // behind the step counters
   for (int t = T - 1; t >= -1; --t) {
@@ -236,19 +273,24 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     // still be running when this kernel starts
     if (fl.ready && t >= 0 && (T - 1 - t) % fl.sub == 0) wait_flag(fl.ready + (T - 1 - t) / fl.sub, fl.epoch, err);
     // operands of the elementwise part do not depend on the recurrence: fetch them first
-    float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hprev = 0.f, dy = 0.f;
-    if (live && t >= 0) {
-      const float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
-      r = rs[0]; z = rs[H]; n = rs[2 * H]; ghn = rs[3 * H];
-      hprev = t > 0 ? out[((long long)(t - 1) * B + row) * H + unit] : h_init[(long long)row * H + unit];
-      const float* dyp = dY + ((long long)t * B + row) * H + unit;
-      dy = fl.ready ? __hip_atomic_load(const_cast<float*>(dyp), RLX_AGENT) : dyp[0];
+    float r[NT], z[NT], nv[NT], ghn[NT], hprev[NT], dy[NT], carry[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      r[n] = z[n] = nv[n] = ghn[n] = hprev[n] = dy[n] = carry[n] = 0.f;
+      if (live && t >= 0) {
+        const float* rs = reserve + ((long long)t * B + row) * 4 * H + unit[n];
+        r[n] = rs[0]; z[n] = rs[H]; nv[n] = rs[2 * H]; ghn[n] = rs[3 * H];
+        hprev[n] = t > 0 ? out[((long long)(t - 1) * B + row) * H + unit[n]] : h_init[(long long)row * H + unit[n]];
+        const float* dyp = dY + ((long long)t * B + row) * H + unit[n];
+        dy[n] = fl.ready ? __hip_atomic_load(const_cast<float*>(dyp), RLX_AGENT) : dyp[0];
+      }
     }
-    float carry = 0.f;
     if (t < T - 1) {
       wait_count(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
       const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
-      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
       float4 v[NCB];
       issue_block_loads<NCB, B2T_LOAD_AUX>(v, dgh, m0, B, 4 * H, wave * NCB * 16, 3 * H, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -259,40 +301,53 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const int ci = 2 * p + h2;
-          acc[0] = mfma_chunk16<BF16>(a[h2], w[ci], acc[0]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = mfma_chunk16<BF16>(a[h2], w[n][ci], acc[n]);
         }
       }
-      float s[1];
-      cross_wave_reduce<1>(red, acc, s, wave, lane);
-      carry = s[0] + dzterm;
+      float s[NT];
+      cross_wave_reduce<NT>(red, acc, s, wave, lane);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) carry[n] = s[n] + dzterm[n];
     } else if (dh_last && live) {
-      carry = dh_last[(long long)row * H + unit];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) carry[n] = dh_last[(long long)row * H + unit[n]];
     }
     if (t < 0) {
-      if (live) dh_init[(long long)row * H + unit] = carry;
+      if (live) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dh_init[(long long)row * H + unit[n]] = carry[n];
+      }
       continue;
     }
     if (live) {
-      const float d = dy + carry;
-      const float dn = d * (1.0f - z);
-      const float dz = d * (hprev - n);
-      const float dn_pre = dn * (1.0f - n * n);
-      const float dz_pre = dz * z * (1.0f - z);
-      const float dr_pre = dn_pre * ghn * r * (1.0f - r);
-      const int lr = 4 * q + wave;
-      gs[(0 * 16 + lr) * TP + j] = dr_pre;
-      gs[(1 * 16 + lr) * TP + j] = dz_pre;
-      gs[(2 * 16 + lr) * TP + j] = dn_pre * r;
-      gs[(3 * 16 + lr) * TP + j] = dn_pre;
-      dzterm = d * z;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float d = dy[n] + carry[n];
+        const float dn = d * (1.0f - z[n]);
+        const float dz = d * (hprev[n] - nv[n]);
+        const float dn_pre = dn * (1.0f - nv[n] * nv[n]);
+        const float dz_pre = dz * z[n] * (1.0f - z[n]);
+        const float dr_pre = dn_pre * ghn[n] * r[n] * (1.0f - r[n]);
+        const int lr = 4 * q + wave, cj = 16 * n + j;
+        gs[(0 * 16 + lr) * TPN + cj] = dr_pre;
+        gs[(1 * 16 + lr) * TPN + cj] = dz_pre;
+        gs[(2 * 16 + lr) * TPN + cj] = dn_pre * r[n];
+        gs[(3 * 16 + lr) * TPN + cj] = dn_pre;
+        dzterm[n] = d * z[n];
+      }
     }
     __syncthreads();
-    {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores
-      const int r2 = lane >> 2, c4 = (lane & 3) * 4;
-      if (m0 + r2 < B)
-        store_f4<AUX>(dG + (long long)t * B * 4 * H,
-                     (unsigned)(((long long)(m0 + r2) * 4 * H + wave * H + j0 + c4) * 4),
-                     *reinterpret_cast<const float4*>(&gs[(wave * 16 + r2) * TP + c4]));
+    {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores per 16-unit tile
+      const int r2 = lane >> 2;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int c4 = 16 * n + (lane & 3) * 4;
+        if (m0 + r2 < B)
+          store_f4<AUX>(dG + (long long)t * B * 4 * H,
+                       (unsigned)(((long long)(m0 + r2) * 4 * H + wave * H + j0 + c4) * 4),
+                       *reinterpret_cast<const float4*>(&gs[(wave * 16 + r2) * TPN + c4]));
+      }
     }
     publish_count(cnt + (size_t)t * CSTRIDE);
     if (fl.done && threadIdx.x == 0 && ((T - t) % fl.sub == 0 || t == 0))
@@ -355,14 +410,20 @@ static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
 }
 
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
-                       float* reserve, int T, int B, int H, void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16) {
+                       float* reserve, int T, int B, int H, void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16,
+                       bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
-  const dim3 grid(H / 16, (B + 15) / 16), block(256);
+  if (wide && (!bf16 || (H % 32) != 0 || H > 512)) { set_error("gru_layer_fwd: 32-unit workgroups need bf16 operands, H %% 32 == 0 and H <= 512"); return 2; }
+  const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
-    if (bf16) {                                                                                                        \
+    if (bf16 && wide) {                                                                                                \
+      want_exclusive(gru_persist_fwd_kernel<NCH, true, 2>);                                                            \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                         B, H, sync, fl);                                                                              \
+    } else if (bf16) {                                                                                                 \
       want_exclusive(gru_persist_fwd_kernel<NCH, true>);                                                               \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
                          B, H, sync, fl);                                                                              \
@@ -384,14 +445,19 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
 
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
-                       void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16) {
+                       void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16, bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
-  const dim3 grid(H / 16, (B + 15) / 16), block(256);
+  if (wide && (!bf16 || (H % 32) != 0 || H > 512)) { set_error("gru_layer_bwd: 32-unit workgroups need bf16 operands, H %% 32 == 0 and H <= 512"); return 2; }
+  const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
   do {                                                                                                                \
-    if (bf16) {                                                                                                       \
+    if (bf16 && wide) {                                                                                               \
+      want_exclusive(gru_persist_bwd_kernel<NCB, true, 2>);                                                           \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
+                         w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                     \
+    } else if (bf16) {                                                                                                \
       want_exclusive(gru_persist_bwd_kernel<NCB, true>);                                                              \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
                          w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                     \

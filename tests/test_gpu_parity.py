@@ -120,8 +120,8 @@ def test_gemm_bf16(akc, bkc, M, N, K):
         ops.set_amp(old)
 
 
-@pytest.mark.parametrize("B,H,T", [(17, 80, 9), (64, 512, 12), (40, 768, 6)])
-def test_persistent_sweep_bf16_operands(B, H, T):
+@pytest.mark.parametrize("B,H,T,wide", [(17, 80, 9, 0), (64, 512, 12, 0), (40, 768, 6, 0), (64, 512, 12, 1), (23, 96, 7, 1)])
+def test_persistent_sweep_bf16_operands(B, H, T, wide):
     """mode 1 | B2T_GRU_BF16: the recurrent products round their operands (h_{t-1} / dG_{t+1} and the W_hh slice) to bf16
     and accumulate in fp32.  Reference: the same recurrences in numpy with the operands rounded explicitly."""
     import b2t_native as Nn
@@ -159,11 +159,11 @@ def test_persistent_sweep_bf16_operands(B, H, T):
     out = torch.zeros(T + 1, B, H, device=dev); out[0] = h0
     resv = torch.zeros(T, B, 4 * H, device=dev)
     sync = torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev)
-    Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out[0]), p(out[1:]), p(resv), None, T, B, H, 1 | ops.GRU_BF16,
+    Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out[0]), p(out[1:]), p(resv), None, T, B, H, 1 | ops.GRU_BF16 | (ops.GRU_WIDE if wide else 0),
                                        p(sync), ops._stream()), "fwd")
     dG = torch.zeros(T, B, 4 * H, device=dev); dh = torch.zeros(B, H, device=dev); sc = torch.empty(B, H, device=dev)
     Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(resv), p(out[1:]), p(out[0]), p(wt), p(dG), p(dh), p(sc), T, B, H,
-                                       1 | ops.GRU_BF16, p(sync), ops._stream()), "bwd")
+                                       1 | ops.GRU_BF16 | (ops.GRU_WIDE if wide else 0), p(sync), ops._stream()), "bwd")
     torch.cuda.synchronize()
     assert int(sync[0]) == 0
     # rounding decisions can flip where fp32 and fp64 intermediates straddle a bf16 boundary: compare at bf16-ulp scale
