@@ -8,7 +8,7 @@ import torch
 import b2t_native as N, b2t_ops as ops
 lib = N.load()
 dev = torch.device("cuda:0")
-B, H = 64, 512
+B, H = int(os.environ.get("B2T_B", "64")), 512
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 125
 FMODE = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 _p = ops._p
