@@ -23,12 +23,14 @@ namespace b2t {
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   float m = fmaxf(fmaxf(a, b), c);
   if (m == -INFINITY) m = 0.f;
-  return logf(expf(a - m) + expf(b - m) + expf(c - m)) + m;
+  // hardware exp2 / log2 (v_exp_f32, v_log_f32: ~1 ulp): the sum is in [1, 3], the arguments are <= 0 -- the libm forms
+  // are ~80 instructions each on the chain of T dependent steps
+  return __logf(__expf(a - m) + __expf(b - m) + __expf(c - m)) + m;
 }
 __device__ __forceinline__ float lse2(float a, float b) {
   float m = fmaxf(a, b);
   if (m == -INFINITY) m = 0.f;
-  return logf(expf(a - m) + expf(b - m)) + m;
+  return __logf(__expf(a - m) + __expf(b - m)) + m;
 }
 
 // Barrier for LDS traffic only.  __syncthreads() also drains the wave's outstanding GLOBAL operations (vmcnt(0)); inside
