@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define B2T_VERSION 1
+#define B2T_VERSION 2
 
 int b2t_version(void);
 const char* b2t_last_error(void);
@@ -107,6 +107,9 @@ int b2t_patch_fold_f32(const float* dv, float* du, int B, int T, int F, int Tp,
  * forward and backward apply the same mask. In place allowed. */
 int b2t_dropout_f32(const float* x, float* y, long long n, float p, uint64_t seed, long long elem0,
                     void* stream);
+/* random-walk augmentation (rnn_trainer.py:464-465): y += cumsum(w, axis) over tensors viewed as [outer][n][inner], summed
+ * in index order along n (torch.cumsum's CPU order). */
+int b2t_cumsum_add_f32(const float* w, float* y, long long outer, int n, long long inner, void* stream);
 /* the factors themselves: y[i] = 0 or 1/(1-p), the mask b2t_dropout_f32 applies for the same (seed, elem0) */
 int b2t_dropout_mask_f32(float* y, long long n, float p, uint64_t seed, long long elem0, void* stream);
 
@@ -123,21 +126,16 @@ int b2t_batch_gather_b32(const void* flat, const int64_t* row_off, const int32_t
  * out [T][B][H]; reserve [T][B][4H] = (r,z,n,gh_n) saved for the backward sweep (may be NULL
  * for inference).  h_last [B][H] (optional) = out[T-1].
  * mode: 0 = step-launch kernels (one launch per time step), 1 = persistent sweep (one launch,
- * W_hh slices resident in registers, agent-scope flag hand-off of h_t between workgroups),
- * 2 = persistent forward with data-tagged granules (backward: as mode 1), 3 = software-pipelined
- * persistent sweep, 4 row groups per workgroup (csrc/gru_pipeline.hip; shapes it does not cover --
- * fewer than 3 row groups, H > 512 backward / > 768 forward -- run as mode 1).  All modes produce the
- * same out / reserve / dG layouts and can be mixed between calls on one workspace.
+ * W_hh slices resident in registers, agent-scope counter hand-off of h_t between workgroups).
  * mode 1 | B2T_GRU_BF16: the recurrent product takes bf16 operands (h_{t-1} / dG_{t+1} and the W_hh slice rounded to
  * nearest-even bf16, v_mfma_f32_16x16x16_bf16, fp32 accumulate; gates and everything stored stay fp32): the reference's
  * autocast(bfloat16) regime for the GRU, opt-in.
- * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode; zeroed by the call). */
+ * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode), zeroed ONCE by the owner (self-cleaning
+ * afterwards); word 0 is a sticky error word (1 = a bounded hand-off spin gave up: results invalid). */
 #define B2T_GRU_BF16 0x100
 #define B2T_GRU_WIDE 0x200   /* with B2T_GRU_BF16: 32 hidden units per workgroup (half the workgroups per sweep), H % 32 == 0, H <= 512 */
 size_t b2t_gru_sync_bytes(int T);
-/* Workspace size valid for every mode (mode 2 = persistent sweep with data-tagged 8-byte {value,tag}
- * granule hand-off, csrc/gru_granule.hip: needs T*B*H*8 bytes of granules behind the control words). */
-size_t b2t_gru_ws_bytes(int T, int B, int H);
+size_t b2t_gru_ws_bytes(int T, int B, int H);   /* = b2t_gru_sync_bytes (kept for callers that size by shape) */
 /* Persistent mode only: copies the sweep's error word to the host and synchronises the stream.
  * *status_host = 0: clean; 1: a bounded hand-off spin gave up (results of that sweep are invalid). */
 int b2t_gru_sync_status(const void* sync_ws, int T, int B, int* status_host, void* stream);
@@ -147,54 +145,66 @@ int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const float* b_hh,
 /* Backward sweep.  dY [T][B][H] grad wrt this layer's outputs (plus dh_last
  * [B][H] optional grad wrt the final state).  w_hh_t [H][3H] is W_hh transposed (b2t_transpose).
  * dG [T][B][4H] = (dr_pre, dz_pre, dn_pre*r, dn_pre): dGh = cols [0,3H), dGi = cols [0,2H)+[3H,4H).
- * dh_init [B][H] = carry after t=0.  carry_ws: [B][H] floats scratch. */
+ * dh_init [B][H] = carry after t=0.  carry_ws: [B][H] floats scratch (mode 0 only). */
 int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, const float* reserve,
                           const float* out, const float* h_init, const float* w_hh_t,
                           float* dG, float* dh_init, float* carry_ws,
                           int T, int B, int H, int mode, void* sync_ws, void* stream);
 int b2t_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+/* dst[b][0:n] = src[0:n] for b < rows (the learnt initial state h0 broadcast over the batch, rnn_model.py:122-123) */
+int b2t_broadcast_rows_f32(const float* src, float* dst, int rows, int n, void* stream);
 
-/* Persistent sweeps (mode 1) released sub-chunk by sub-chunk.  A launch of T steps is cut into sub-chunks of `sub`
- * steps (forward: in time order; backward: counted from the END of the launch, the order the sweep visits them).
- * The kernel enters sub-chunk k only once ready[k] >= epoch (the caller writes it with b2t_stream_write_value32 behind
- * the GEMM that produced gi / dY of that sub-chunk) and stores done[k] = epoch once every workgroup has finished it
- * (out / dG of the sub-chunk are then in memory; wait for it with b2t_stream_wait_value32_gte in front of the consuming
- * GEMM).  ready / done: plain device words (NULL = no waiting / no signalling); epoch must grow from pass to pass. */
-int b2t_gru_layer_fwd_flagged_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init,
-                                  float* out, float* reserve, float* h_last, int T, int B, int H, void* sync_ws,
-                                  const uint32_t* ready, uint32_t* done, int sub, uint32_t epoch, void* stream);
-int b2t_gru_layer_bwd_flagged_f32(const float* dY, const float* dh_last, const float* reserve, const float* out,
-                                  const float* h_init, const float* w_hh_t, float* dG, float* dh_init,
-                                  int T, int B, int H, void* sync_ws,
-                                  const uint32_t* ready, uint32_t* done, int sub, uint32_t epoch, void* stream);
-/* ---- a5 (mode 4): the whole GRU stack as ONE persistent launch (nn.GRU forward, rnn_model.py:126, all layers).
- * Layer 0 reads its input projection gi0 [T][B][3H] (b_ih folded in) from a GEMM that ran before; layers l >= 1 form
- * x_t W_ih^T inside the sweep from the tile layer l-1 has just published.  out[l] is [T+1][B][H]: slab 0 holds the
- * initial state on entry, slab t+1 receives h_t.  nn.GRU inter-layer dropout: when drop_mask[l] ([T][B][H] factors, 0 or
- * 1/(1-p), e.g. from b2t_dropout_mask_f32) and out_drop[l] are given, layer l also writes h_t * mask to out_drop[l] (same
- * layout as out[l]) and layer l+1 consumes that copy.  reserve[l]: [T][B][4H] or NULL.
- * sync_ws: b2t_gru_sync_bytes() bytes, zeroed once, one per concurrent call.  Returns 4 (and launches nothing) when the
- * shape is not covered -- (H/16) * L * ceil(B/64) workgroups must be resident at once, H <= 512 -- the caller then runs
- * the per-layer sweeps. */
-#define B2T_STACK_MAX_LAYERS 8
-typedef struct {
-  int T, B, H, L;
-  const float* gi0;
-  const float* w_hh[B2T_STACK_MAX_LAYERS];
-  const float* w_ih[B2T_STACK_MAX_LAYERS];   /* [0] unused */
-  const float* b_hh[B2T_STACK_MAX_LAYERS];
-  const float* b_ih[B2T_STACK_MAX_LAYERS];   /* [0] unused */
-  float* out[B2T_STACK_MAX_LAYERS];
-  float* out_drop[B2T_STACK_MAX_LAYERS];     /* NULL: no dropped copy for that layer */
-  const float* drop_mask[B2T_STACK_MAX_LAYERS];   /* NULL together with out_drop */
-  float* reserve[B2T_STACK_MAX_LAYERS];
-  int bf16;   /* != 0: bf16 operands for both products (as B2T_GRU_BF16 for the per-layer sweeps) */
-} b2t_gru_stack_t;
-int b2t_gru_stack_fwd_f32(const b2t_gru_stack_t* d, void* sync_ws, void* stream);
-
-/* Stream-ordered 32-bit word write / wait-until->= executed by the command processor (no kernel launch). */
-int b2t_stream_write_value32(void* ptr, uint32_t value, void* stream);
-int b2t_stream_wait_value32_gte(void* ptr, uint32_t value, void* stream);
+/* ---- a3-a6 + a8: the model pass as ONE host call (GRUDecoder.forward, rnn_model.py:88-134, and its autograd
+ * backward, rnn_trainer.py:547).  The executor owns the HIP streams and events of the execution plan (one sweep stream +
+ * one GEMM stream per layer; the L layers are software-pipelined over `chunks` time chunks) and issues every launch of a
+ * pass from C++ -- ~250 launches and ~100 event operations per training step that cost 14 ms of Python/ctypes time per
+ * 25 ms step when they were issued one by one from the host language.  All device memory still comes from the caller:
+ * `ws` (b2t_pass_ws_bytes bytes, any contents; holds the activations forward saves for backward, so one forward/backward
+ * pair per ws at a time) and `sync_ws` (b2t_exec_sync_bytes bytes, zeroed once, persistent: the sweeps' counters and
+ * error words).  Asynchronous: on return everything is enqueued and the caller's stream has joined the side streams. */
+#define B2T_MAX_LAYERS 8
+typedef struct b2t_model_t {   /* parameter (or gradient) tensors under the reference's names (rnn_model.py:50-86) */
+  int F, H, D, C, L, patch, stride;
+  float* day_w; float* day_b;              /* day d at day_w + d*day_w_stride ([F][F]) / day_b + d*day_b_stride ([F]) */
+  long long day_w_stride, day_b_stride;
+  float* w_ih[B2T_MAX_LAYERS]; float* w_hh[B2T_MAX_LAYERS]; float* b_ih[B2T_MAX_LAYERS]; float* b_hh[B2T_MAX_LAYERS];
+  float* out_w; float* out_b; float* h0;
+} b2t_model_t;
+typedef struct b2t_pass_t {
+  int B, T;                  /* batch rows, input frames (T' = (T - patch) / stride + 1 when patch > 0) */
+  int chunks;                /* time chunks of the layer pipeline; 1 = layers in sequence on the caller's stream */
+  int fwd_mode, bwd_mode;    /* sweep modes (0 / 1, | B2T_GRU_BF16 | B2T_GRU_WIDE) */
+  int bf16_gemm;             /* != 0: b2t_gemm_bf16_f32 for every GEMM (the use_amp regime) */
+  int save;                  /* != 0: keep what backward needs (gate reserves, layer outputs, U) */
+  float in_drop, rnn_drop;   /* dropout probabilities (rnn_model.py:102-103, nn.GRU dropout); 0 in eval */
+  uint64_t seed;             /* Philox key of this pass's dropout masks (backward must get the same) */
+} b2t_pass_t;
+typedef struct b2t_exec b2t_exec;
+int b2t_exec_create(int n_layers, b2t_exec** out);
+int b2t_exec_destroy(b2t_exec* ex);
+size_t b2t_exec_sync_bytes(int n_layers);          /* 2 * n_layers blocks of b2t_gru_sync_bytes(0): fwd l, then bwd l */
+size_t b2t_pass_ws_bytes(const b2t_model_t* m, const b2t_pass_t* p);
+/* x [B][T][F], day_idx [B], states [L][B][H] or NULL (h0)  ->  logits [B][T'][C], hidden [L][B][H] */
+int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t_pass_t* p, const float* x,
+                      const int32_t* day_idx, const float* states, float* logits, float* hidden,
+                      void* ws, void* sync_ws, void* stream);
+/* Gradients of every parameter given dlogits [B][T'][ldd] (ldd % 4 == 0, >= C), written (not accumulated) into `grd`;
+ * days absent from day_idx are not touched.  dhidden [L][B][H] optional gradient wrt the final states; dstates
+ * [L][B][H] optional output = gradient wrt the initial states (when the forward got `states`, h0 receives no gradient).
+ * bucket_cb(user, id, stream) is called right after the last launch of a gradient bucket was enqueued on `stream`
+ * (ids: 0 = head, 1 + l = GRU layer l, L + 1 = h0, L + 2 = day layers) -- the data-parallel reducer hooks its
+ * all-reduce there, in backward-completion order.  `p`, x, day_idx, ws: as given to the forward. */
+typedef void (*b2t_bucket_cb)(void* user, int bucket, void* stream);
+int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2t_model_t* grd, const b2t_pass_t* p,
+                       const float* x, const int32_t* day_idx, const float* dlogits, int ldd,
+                       const float* dhidden, float* dstates, int custom_states, void* ws, void* sync_ws,
+                       b2t_bucket_cb bucket_cb, void* user, void* stream);
+/* Live per-launch timing (HIP events on the stream each kernel is launched on) for bench.py's roofline: while on, every
+ * GEMM / sweep launch of the two calls above is bracketed; b2t_exec_profile_read synchronises the device and returns up
+ * to `cap` records {kind, flops, milliseconds} (kind: 0-3 gemm_f32<a_kcontig,b_kcontig>, 4-7 gemm_bf16<..>, 8 forward
+ * sweep, 9 backward sweep) and clears them.  Returns the number of records, < 0 on error. */
+int b2t_exec_profile(b2t_exec* ex, int on);
+int b2t_exec_profile_read(b2t_exec* ex, int* kind_host, double* flops_host, float* ms_host, int cap);
 
 /* ---- a7: log-softmax + CTC loss (torch.nn.CTCLoss(blank=0,'none') at rnn_trainer.py:242,538-545)
  * logits [B][T][C] batch-first.  targets [B][S_max] int32 (0-padded), in_len/tgt_len [B] int32.
@@ -214,22 +224,30 @@ int b2t_ctc_loss_f32(const float* logits, const int32_t* targets, const int32_t*
  * seg_step (the tensor's own AdamW step count), active (has a gradient this step).
  * b2t_opt_prepare: active[s] = seg_day[s] < 0 || seg_day[s] in day_idx[0..B)   — days absent from the
  *   batch have grad None in the reference (rnn_trainer.py:514) and are skipped by clip and AdamW.
- * b2t_grad_norm_clip_f32 (clip_grad_norm_, rnn_trainer.py:551-555): out3 = {sum g^2, norm,
- *   clip_coef = min(1, max_norm/(norm+1e-6))} over active tensors (max_norm <= 0: coef 1); also advances
- *   seg_step of active tensors (seg_step may be NULL).  partial_ws: nchunks floats. */
+ * b2t_grad_norm_clip_f32 (clip_grad_norm_, rnn_trainer.py:551-555): out4 = {sum g^2, norm,
+ *   clip_coef = min(1, max_norm/(norm+1e-6)), status} over active tensors (max_norm <= 0: coef 1); also advances
+ *   seg_step of active tensors (seg_step may be NULL).  partial_ws: nchunks floats.
+ *   status (sticky: once non-zero it stays): 0 = OK; 1 = a persistent sweep reported a hand-off timeout (any of the
+ *   n_err error words err_words[i * err_stride] is set: the gradients are invalid); 2 = non-finite gradient norm (the
+ *   reference raises there: error_if_nonfinite=True, rnn_trainer.py:553).  With status != 0 the step counters do not
+ *   advance and b2t_adamw_f32 (given out4 as `clip4`) leaves parameters and moments untouched: a bad step is never
+ *   applied; the host raises when it next reads out4.  err_words may be NULL. */
 int b2t_opt_prepare(const int32_t* day_idx, int B, const int32_t* seg_day, int nseg, int32_t* active,
                     void* stream);
 int b2t_grad_norm_clip_f32(const float* grads, const int32_t* chunk2seg, const int32_t* active,
-                           int nchunks, float max_norm, float* partial_ws, float* out3,
-                           int32_t* seg_step, int nseg, void* stream);
+                           int nchunks, float max_norm, float* partial_ws, float* out4,
+                           int32_t* seg_step, int nseg, const uint32_t* err_words, int n_err,
+                           long long err_stride, void* stream);
 /* AdamW (torch.optim.AdamW, rnn_trainer.py:283-290), active tensors only, k = seg_step (1-based):
- *   g *= clip3[2]; p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   g *= clip4[2] (if apply_clip); p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^k) * m / (sqrt(v)/sqrt(1-b2^k) + eps)      (bias corrections evaluated in fp64)
- * lr3_host / wd3_host: HOST arrays of 3 floats (per group: bias, day, other).  clip3 may be NULL. */
+ * lr3_host / wd3_host: HOST arrays of 3 floats (per group: bias, day, other).  clip4 = the out4 of
+ * b2t_grad_norm_clip_f32 (may be NULL): nothing is updated when clip4[3] != 0. */
 int b2t_adamw_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                   const int32_t* chunk2seg, const int32_t* active, const int32_t* seg_group,
-                  const int32_t* seg_step, int nchunks, const float* clip3, const float* lr3_host,
-                  const float* wd3_host, double beta1, double beta2, float eps, void* stream);
+                  const int32_t* seg_step, int nchunks, const float* clip4, int apply_clip,
+                  const float* lr3_host, const float* wd3_host, double beta1, double beta2, float eps,
+                  void* stream);
 
 /* ---- a12: greedy CTC decode (rnn_trainer.py:724-728) --------------------------------------
  * argmax over classes (first max wins, like torch.argmax), collapse repeats, drop blank.

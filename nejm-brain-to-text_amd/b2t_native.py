@@ -43,15 +43,26 @@ class GemmDesc(C.Structure):
     ]
 
 
-STACK_MAX_LAYERS = 8
+MAX_LAYERS = 8
+FP = C.c_void_p   # float* fields of the structs below are filled from tensor.data_ptr()
 
 
-class GruStackDesc(C.Structure):
-    """Mirror of b2t_gru_stack_t (include/b2t.h)."""
-    _fields_ = [("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("L", C.c_int), ("gi0", VP),
-                ("w_hh", VP * STACK_MAX_LAYERS), ("w_ih", VP * STACK_MAX_LAYERS), ("b_hh", VP * STACK_MAX_LAYERS),
-                ("b_ih", VP * STACK_MAX_LAYERS), ("out", VP * STACK_MAX_LAYERS), ("out_drop", VP * STACK_MAX_LAYERS),
-                ("drop_mask", VP * STACK_MAX_LAYERS), ("reserve", VP * STACK_MAX_LAYERS), ("bf16", C.c_int)]
+class ModelDesc(C.Structure):
+    """Mirror of b2t_model_t (include/b2t.h): parameter or gradient tensors under the reference's names."""
+    _fields_ = [("F", C.c_int), ("H", C.c_int), ("D", C.c_int), ("C", C.c_int), ("L", C.c_int), ("patch", C.c_int),
+                ("stride", C.c_int), ("day_w", FP), ("day_b", FP), ("day_w_stride", LL), ("day_b_stride", LL),
+                ("w_ih", FP * MAX_LAYERS), ("w_hh", FP * MAX_LAYERS), ("b_ih", FP * MAX_LAYERS), ("b_hh", FP * MAX_LAYERS),
+                ("out_w", FP), ("out_b", FP), ("h0", FP)]
+
+
+class PassDesc(C.Structure):
+    """Mirror of b2t_pass_t (include/b2t.h)."""
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("chunks", C.c_int), ("fwd_mode", C.c_int), ("bwd_mode", C.c_int),
+                ("bf16_gemm", C.c_int), ("save", C.c_int), ("in_drop", C.c_float), ("rnn_drop", C.c_float),
+                ("seed", C.c_uint64)]
+
+
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 
 class LexLmDesc(C.Structure):
@@ -85,18 +96,22 @@ _SIGNATURES = {
     "b2t_gru_layer_bwd_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int,
                                         VP, VP]),
     "b2t_transpose_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
-    "b2t_gru_layer_fwd_flagged_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP,
-                                                C.c_int, C.c_uint32, VP]),
-    "b2t_gru_layer_bwd_flagged_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP,
-                                                C.c_int, C.c_uint32, VP]),
-    "b2t_gru_stack_fwd_f32": (C.c_int, [C.POINTER(GruStackDesc), VP, VP]),
-    "b2t_stream_write_value32": (C.c_int, [VP, C.c_uint32, VP]),
-    "b2t_stream_wait_value32_gte": (C.c_int, [VP, C.c_uint32, VP]),
+    "b2t_cumsum_add_f32": (C.c_int, [VP, VP, LL, C.c_int, LL, VP]),
+    "b2t_broadcast_rows_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),
+    "b2t_exec_create": (C.c_int, [C.c_int, C.POINTER(VP)]),
+    "b2t_exec_destroy": (C.c_int, [VP]),
+    "b2t_exec_sync_bytes": (C.c_size_t, [C.c_int]),
+    "b2t_pass_ws_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.POINTER(PassDesc)]),
+    "b2t_model_forward": (C.c_int, [VP, C.POINTER(ModelDesc), C.POINTER(PassDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
+    "b2t_model_backward": (C.c_int, [VP, C.POINTER(ModelDesc), C.POINTER(ModelDesc), C.POINTER(PassDesc), VP, VP, VP,
+                                     C.c_int, VP, VP, C.c_int, VP, VP, BUCKET_CB, VP, VP]),
+    "b2t_exec_profile": (C.c_int, [VP, C.c_int]),
+    "b2t_exec_profile_read": (C.c_int, [VP, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int]),
     "b2t_ctc_loss_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, VP]),
     "b2t_opt_prepare": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),
-    "b2t_grad_norm_clip_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_float, VP, VP, VP, C.c_int, VP]),
-    "b2t_adamw_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, VP, C.POINTER(C.c_float),
+    "b2t_grad_norm_clip_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_float, VP, VP, VP, C.c_int, VP, C.c_int, LL, VP]),
+    "b2t_adamw_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, VP, C.c_int, C.POINTER(C.c_float),
                                 C.POINTER(C.c_float), C.c_double, C.c_double, C.c_float, VP]),
     "b2t_greedy_decode_f32": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_edit_distance_i32": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, VP, C.c_int, VP]),
@@ -145,7 +160,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.b2t_version() != 1:
+    if lib.b2t_version() != 2:
         raise RuntimeError("libb2t_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -38,6 +38,12 @@ def cosine_lr_factor(step: int, min_lr_ratio: float, decay_steps: int, warmup_st
     return min_lr_ratio
 
 
+def linear_lr_factor(step: int, end_factor: float, total_iters: int, start_factor: float = 1.0) -> float:
+    """torch.optim.lr_scheduler.LinearLR in closed form (the reference's lr_scheduler_type 'linear',
+    rnn_trainer.py:228-234: start_factor 1.0, end_factor lr_min / lr_max, total_iters lr_decay_steps)."""
+    return start_factor + (end_factor - start_factor) * min(int(total_iters), int(step)) / float(total_iters)
+
+
 def param_group_of(name: str) -> int:
     """0 = bias (no decay), 1 = day layers, 2 = everything else (rnn_trainer.py:267-269)."""
     if "gru.bias" in name or "out.bias" in name:
@@ -99,7 +105,7 @@ class GradReducer:
 
 
 class TrainStep:
-    def __init__(self, model, args: Dict, group=None, global_batch_scale: Optional[int] = None):
+    def __init__(self, model, args: Dict, group=None, world: Optional[int] = None):
         """model: rnn_model.GRUDecoder on the HIP device.  args: the flat keys of rnn_args.yaml used by
         the optimizer/scheduler (lr_max, lr_min, lr_decay_steps, lr_warmup_steps, *_day, beta0, beta1, epsilon,
         weight_decay, weight_decay_day, grad_norm_clip_value)."""
@@ -132,13 +138,17 @@ class TrainStep:
         self.seg_step = torch.zeros(self.nseg, dtype=torch.int32, device=dev)
         self.active = torch.ones(self.nseg, dtype=torch.int32, device=dev)
         self.partial = torch.empty(nchunks, dtype=torch.float32, device=dev)
-        self.out3 = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.stat = torch.zeros(5, dtype=torch.float32, device=dev)   # {sum g^2, norm, clip coefficient, status, mean loss}
+        self.out3 = self.stat[:4]
         self.requires = [True] * self.nseg
         self.keep_unclipped = True if args.get("_debug_keep_unclipped", False) else False
         self._unclipped = None
         import torch.distributed as dist
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.reducer = GradReducer(self.grad_arena, bucket_spans(lay, model.n_layers), group) if self.world > 1 else None
+        # `world` overrides the process group's size: the single-process parity test of the data-parallel arithmetic
+        # (tests/test_gpu_trainer.py) runs the shards of several "ranks" one after the other and sums their arenas itself
+        self.world = int(world) if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.reducer = (GradReducer(self.grad_arena, bucket_spans(lay, model.n_layers), group)
+                        if (self.world > 1 and dist.is_initialized()) else None)
         self.day_range = None
         if self.world > 1:
             b = dict((n, (a, e)) for n, a, e in bucket_spans(lay, model.n_layers))
@@ -155,6 +165,10 @@ class TrainStep:
     # -- learning rates of the three groups for the current batch (rnn_trainer.py:294-363) ------------
     def current_lrs(self):
         a = self.args
+        if a.get("lr_scheduler_type", "cosine") == "linear":
+            # LinearLR scales EVERY group by the same factor (rnn_trainer.py:228-234)
+            f = linear_lr_factor(self.it, a["lr_min"] / a["lr_max"], a["lr_decay_steps"])
+            return [a["lr_max"] * f, a["lr_max_day"] * f, a["lr_max"] * f]
         f_main = cosine_lr_factor(self.it, a["lr_min"] / a["lr_max"], a["lr_decay_steps"], a["lr_warmup_steps"])
         f_day = cosine_lr_factor(self.it, a["lr_min_day"] / a["lr_max_day"], a["lr_decay_steps_day"],
                                  a["lr_warmup_steps_day"])
@@ -169,10 +183,11 @@ class TrainStep:
             return ((n - ps).to(torch.float32) / st + 1).to(torch.int32)
         return n.to(torch.int32)
 
-    def step(self, feats: torch.Tensor, day_idx: torch.Tensor, targets: torch.Tensor, n_time_steps: torch.Tensor,
-             phone_seq_lens: torch.Tensor):
-        """feats [B,T,F] (already augmented + smoothed), day_idx [B], targets [B,S], lengths [B].
-        Returns (mean CTC loss, pre-clip gradient norm) as 0-d device tensors (no sync)."""
+    def compute_grads(self, feats: torch.Tensor, day_idx: torch.Tensor, targets: torch.Tensor,
+                      n_time_steps: torch.Tensor, phone_seq_lens: torch.Tensor, reduce: bool = True):
+        """Forward + CTC + backward into the gradient arena (scaled 1 / (B * world): rnn_trainer.py:545's torch.mean over
+        the GLOBAL batch), with the bucketed all-reduce hooked into the backward when running data-parallel.
+        Returns the per-sentence losses [B]."""
         lib = N.load()
         model = self.model
         dev = self.dev
@@ -186,26 +201,40 @@ class TrainStep:
         logits, hidden, ctx = ops.model_forward(model._dims, model._kernel_params(), feats, day_dev, None, model._ws,
                                                 save=True, in_drop=model._p_in(), rnn_drop=model._p_rnn(),
                                                 seed=model._next_seed(), reuse_saved=True)
-        # torch.mean over the (global) batch: rnn_trainer.py:545
         loss_b, dl, ldd = ops.ctc_loss(logits, targets, adj, phone_seq_lens, True, 1.0 / (B * self.world), model._ws)
         N.check(lib.b2t_opt_prepare(ops._p(day_dev), B, ops._p(self.seg_day), self.nseg, ops._p(self.active), st),
                 "b2t_opt_prepare")
-        red = self.reducer
-        if red is not None:
+        red = self.reducer if reduce else None
+        if self.world > 1:
             # ranks see different days: zero the day-gradient region so absent days contribute 0 to the sum
             a, e = self.day_range
             self.grad_arena[a:e].zero_()
+        if red is not None:
             red.union_active(self.active)
         ops.model_backward(model._dims, model._kernel_params(), self.grads, ctx, dl, ldd, model._ws,
                            bucket_cb=(red.launch if red is not None else None))
         if red is not None:
             red.finish()
+        self.last_logits, self.last_adjusted = logits, adj
+        return loss_b
+
+    def apply_update(self):
+        """clip_grad_norm_ + AdamW over the (reduced) gradient arena (rnn_trainer.py:551-557); advances the schedule."""
+        lib = N.load()
+        model = self.model
+        dev = self.dev
+        st = ops._stream()
         if self.keep_unclipped:
             self._unclipped = self.grad_arena.clone()
         clip = float(self.args.get("grad_norm_clip_value", 0) or 0)
+        # The sweeps' sticky error words ride along: a hand-off timeout (or a non-finite norm, the reference's
+        # error_if_nonfinite=True at rnn_trainer.py:553) sets stat[3], and AdamW then leaves parameters, moments and step
+        # counters untouched -- a bad step is never applied; check_status() raises at the next host read.
+        ew, n_err, ew_stride = model._ws.error_words(model.n_layers, dev)
         N.check(lib.b2t_grad_norm_clip_f32(ops._p(self.grad_arena), ops._p(self.chunk2seg), ops._p(self.active),
                                            self.nchunks, clip, ops._p(self.partial), ops._p(self.out3),
-                                           ops._p(self.seg_step), self.nseg, st), "b2t_grad_norm_clip_f32")
+                                           ops._p(self.seg_step), self.nseg, ops._p(ew), n_err, ew_stride, st),
+                "b2t_grad_norm_clip_f32")
         lrs = self.current_lrs()
         a = self.args
         lr3 = (C.c_float * 3)(*lrs)
@@ -213,14 +242,30 @@ class TrainStep:
         N.check(lib.b2t_adamw_f32(ops._p(model.arena()), ops._p(self.grad_arena), ops._p(self.exp_avg),
                                   ops._p(self.exp_avg_sq), ops._p(self.chunk2seg), ops._p(self.active),
                                   ops._p(self.seg_group), ops._p(self.seg_step), self.nchunks,
-                                  ops._p(self.out3) if clip > 0 else None, lr3, wd3, float(a["beta0"]),
+                                  ops._p(self.out3), int(clip > 0), lr3, wd3, float(a["beta0"]),
                                   float(a["beta1"]), float(a["epsilon"]), st), "b2t_adamw_f32")
         self.it += 1
-        loss = loss_b.mean()
-        if self.world > 1:
-            loss = loss  # per-rank mean of its shard; callers all-reduce for logging if they want the global mean
-        self.last_logits, self.last_adjusted = logits, adj
-        return loss, self.out3[1]
+
+    def step(self, feats: torch.Tensor, day_idx: torch.Tensor, targets: torch.Tensor, n_time_steps: torch.Tensor,
+             phone_seq_lens: torch.Tensor):
+        """feats [B,T,F] (already augmented + smoothed), day_idx [B], targets [B,S], lengths [B].
+        Returns (mean CTC loss of this rank's shard, pre-clip gradient norm) as 0-d device tensors (no sync).
+        self.stat = {sum g^2, norm, clip coefficient, status, mean loss} holds the same on the device."""
+        loss_b = self.compute_grads(feats, day_idx, targets, n_time_steps, phone_seq_lens)
+        self.apply_update()
+        torch.mean(loss_b, dim=0, keepdim=True, out=self.stat[4:5])
+        return self.stat[4], self.stat[1]
+
+    def check_status(self, out3_host=None):
+        """Raise if a step was refused (synchronises unless given a host copy of out3): 1 = hand-off timeout inside a
+        persistent sweep, 2 = non-finite gradient norm (clip_grad_norm_(error_if_nonfinite=True), rnn_trainer.py:551-555)."""
+        v = out3_host if out3_host is not None else self.out3.cpu()
+        st = int(v[3])
+        if st == 1:
+            raise RuntimeError("persistent GRU sweep: inter-workgroup hand-off timed out; the step was NOT applied")
+        if st == 2:
+            raise RuntimeError(f"The total norm of order 2.0 for gradients is non-finite ({float(v[1])}), so it cannot be "
+                               "clipped; the step was NOT applied")
 
     # -- helpers for tests / checkpoints ---------------------------------------------------------------
     def last_unclipped_grads(self) -> Dict[str, np.ndarray]:
@@ -258,8 +303,12 @@ class TrainStep:
         for g, (gt, lr0, wd) in enumerate((("bias", a["lr_max"], 0), ("day_layer", a["lr_max_day"], a.get("weight_decay_day", 0)),
                                            ("other", a["lr_max"], a["weight_decay"]))):
             cnt = sum(1 for n in order if param_group_of(n) == g)
-            groups.append(dict(lr=lrs[g], initial_lr=lr0, betas=(a["beta0"], a["beta1"]), eps=a["epsilon"],
-                               weight_decay=wd, group_type=gt, params=list(range(k, k + cnt))))
+            # the full key set of torch.optim.AdamW's param_groups: Optimizer.load_state_dict adopts the saved groups
+            # wholesale, so a missing key (amsgrad, maximize, ...) makes the reference's optimizer.step() raise KeyError
+            groups.append(dict(params=list(range(k, k + cnt)), group_type=gt, lr=lrs[g], betas=(a["beta0"], a["beta1"]),
+                               eps=a["epsilon"], weight_decay=wd, amsgrad=False, maximize=False, foreach=None,
+                               capturable=False, differentiable=False, fused=True, decoupled_weight_decay=True,
+                               initial_lr=lr0))
             k += cnt
         return dict(state=state, param_groups=groups)
 

@@ -115,10 +115,10 @@ extern "C" int b2t_greedy_decode_f32(const float* logits, const int32_t* lens, i
 extern "C" int b2t_edit_distance_i32(const int32_t* a, const int32_t* a_len, int La_max, const int32_t* b,
                                      const int32_t* b_len, int Lb_max, int32_t* dist, int B, void* stream) {
   B2T_REQUIRE(B > 0 && La_max >= 0 && Lb_max >= 0, "edit_distance: bad shape");
-  size_t smem = sizeof(int) * 2 * ((size_t)Lb_max + 1);
+  const int la = La_max > 0 ? La_max : 1, lb = Lb_max > 0 ? Lb_max : 1;   // the kernel's row pitch: size the LDS from the clamped value
+  size_t smem = sizeof(int) * 2 * ((size_t)lb + 1);
   B2T_REQUIRE(smem <= 64 * 1024, "edit_distance: Lb_max=%d too long", Lb_max);
-  hipLaunchKernelGGL(edit_distance_kernel, dim3(B), dim3(64), smem, as_stream(stream), a, a_len, La_max > 0 ? La_max : 1,
-                     b, b_len, Lb_max > 0 ? Lb_max : 1, dist);
+  hipLaunchKernelGGL(edit_distance_kernel, dim3(B), dim3(64), smem, as_stream(stream), a, a_len, la, b, b_len, lb, dist);
   B2T_CHECK_LAUNCH("b2t_edit_distance_i32");
   return 0;
 }

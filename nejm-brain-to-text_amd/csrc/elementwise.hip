@@ -337,6 +337,39 @@ extern "C" int b2t_dropout_mask_f32(float* y, long long n, float p, uint64_t see
   return 0;
 }
 
+// y[o][i][k] += sum_{j <= i} w[o][j][k]: the reference's random-walk augmentation, features += cumsum(noise, dim=axis)
+// (rnn_trainer.py:464-465).  One thread per (o, k) line, summed in index order like torch.cumsum on the CPU.
+__global__ void cumsum_add_kernel(const float* __restrict__ w, float* __restrict__ y, long long outer, int n, long long inner) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= outer * inner) return;
+  const long long o = id / inner, k = id % inner;
+  const long long base = o * n * inner + k;
+  float acc = 0.f;
+  for (int i = 0; i < n; ++i) {
+    acc += w[base + (long long)i * inner];
+    y[base + (long long)i * inner] += acc;
+  }
+}
+extern "C" int b2t_cumsum_add_f32(const float* w, float* y, long long outer, int n, long long inner, void* stream) {
+  B2T_REQUIRE(w && y && outer > 0 && n > 0 && inner > 0, "cumsum_add: bad args");
+  const long long tot = outer * inner;
+  hipLaunchKernelGGL(cumsum_add_kernel, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, as_stream(stream), w, y, outer, n, inner);
+  B2T_CHECK_LAUNCH("b2t_cumsum_add_f32");
+  return 0;
+}
+
+__global__ void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long long)rows * n) dst[i] = src[i % n];
+}
+extern "C" int b2t_broadcast_rows_f32(const float* src, float* dst, int rows, int n, void* stream) {
+  B2T_REQUIRE(src && dst && rows > 0 && n > 0, "broadcast_rows: bad args");
+  const long long tot = (long long)rows * n;
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst, rows, n);
+  B2T_CHECK_LAUNCH("b2t_broadcast_rows_f32");
+  return 0;
+}
+
 extern "C" int b2t_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
   B2T_REQUIRE(rows > 0 && cols > 0, "transpose: bad shape");
   dim3 block(32, 8), grid((cols + 31) / 32, (rows + 31) / 32);

@@ -114,10 +114,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
 using namespace b2t;
 
 extern "C" size_t b2t_gru_sync_bytes(int T) { return b2t::gru_persistent_sync_bytes(T); }
-extern "C" size_t b2t_gru_ws_bytes(int T, int B, int H) {
-  const size_t a = b2t::gru_persistent_sync_bytes(T), g = b2t::gru_granule_bytes(T, B, H);
-  return a > g ? a : g;
-}
+extern "C" size_t b2t_gru_ws_bytes(int T, int B, int H) { (void)B; (void)H; return b2t::gru_persistent_sync_bytes(T); }
 
 extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init,
                                      float* out, float* reserve, float* h_last, int T, int B, int H, int mode,
@@ -127,19 +124,10 @@ extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const f
   const bool bf16 = (mode & B2T_GRU_BF16) != 0;   // bf16 operands of the recurrent product (persistent mode 1 only)
   const bool wide = (mode & B2T_GRU_WIDE) != 0;   // 32 hidden units per workgroup (with bf16 operands)
   mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE);
-  B2T_REQUIRE(mode >= 0 && mode <= 3, "gru_layer_fwd: unknown mode %d", mode);
+  B2T_REQUIRE(mode == 0 || mode == 1, "gru_layer_fwd: unknown mode %d", mode);
   B2T_REQUIRE(!bf16 || mode == 1, "gru_layer_fwd: B2T_GRU_BF16 goes with mode 1");
-  if (mode == 3) {   // pipelined sweep; shapes it does not cover run as mode 1 (same protocol and workspace)
-    int rc = gru_pipeline_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
-    if (rc == 4) mode = 1;
-    else if (rc) return rc;
-  }
-  if (mode == 3) {
-  } else if (mode == 2) {
-    int rc = gru_granule_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s);
-    if (rc) return rc;
-  } else if (mode == 1) {
-    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s, bf16, wide);
+  if (mode == 1) {
+    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s, bf16, wide);
     if (rc) return rc;
   } else {
     dim3 grid(H / 16, (B + 15) / 16), block(256);
@@ -162,61 +150,19 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
                                      const float* h_init, const float* w_hh_t, float* dG, float* dh_init,
                                      float* carry_ws, int T, int B, int H, int mode, void* sync_ws, void* stream) {
   B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_bwd: bad shape T=%d B=%d H=%d", T, B, H);
-  B2T_REQUIRE(carry_ws != nullptr, "gru_layer_bwd: carry_ws is required ([B][H] floats)");
   hipStream_t s = as_stream(stream);
   const bool bf16 = (mode & B2T_GRU_BF16) != 0;
   const bool wide = (mode & B2T_GRU_WIDE) != 0;
   mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE);
-  B2T_REQUIRE(mode >= 0 && mode <= 3, "gru_layer_bwd: unknown mode %d", mode);
+  B2T_REQUIRE(mode == 0 || mode == 1, "gru_layer_bwd: unknown mode %d", mode);
   B2T_REQUIRE(!bf16 || mode == 1, "gru_layer_bwd: B2T_GRU_BF16 goes with mode 1");
-  if (mode == 3) {
-    int rc = gru_pipeline_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s);
-    if (rc != 4) return rc;   // 4: shape not covered -> mode 1
-  }
-  if (mode >= 1) {   // mode 2 (granule forward) pairs with the counter backward
-    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, SweepFlags{nullptr, nullptr, 0, 0u}, s, bf16, wide);
-  }
+  if (mode == 1)
+    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s, bf16, wide);
+  B2T_REQUIRE(carry_ws != nullptr, "gru_layer_bwd: carry_ws is required in mode 0 ([B][H] floats)");
   dim3 grid(H / 16, (B + 15) / 16), block(256);
   for (int t = T - 1; t >= -1; --t)
     hipLaunchKernelGGL(gru_step_bwd_kernel, grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init,
                        carry_ws, t, T, B, H);
   B2T_CHECK_LAUNCH("b2t_gru_layer_bwd_f32");
   return 0;
-}
-
-// ---- persistent sweeps released sub-chunk by sub-chunk (SweepFlags, gru_sync.h) ----------------------------------
-extern "C" int b2t_gru_layer_fwd_flagged_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init,
-                                             float* out, float* reserve, float* h_last, int T, int B, int H,
-                                             void* sync_ws, const uint32_t* ready, uint32_t* done, int sub, uint32_t epoch,
-                                             void* stream) {
-  B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_fwd_flagged: bad shape T=%d B=%d H=%d", T, B, H);
-  B2T_REQUIRE((!ready && !done) || sub > 0, "gru_layer_fwd_flagged: sub must be > 0 when flags are given");
-  hipStream_t s = as_stream(stream);
-  int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, SweepFlags{ready, done, sub, epoch}, s);
-  if (rc) return rc;
-  if (h_last)
-    return check_hip(hipMemcpyAsync(h_last, out + (long long)(T - 1) * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s),
-                     "gru_layer_fwd_flagged: h_last copy");
-  return 0;
-}
-
-extern "C" int b2t_gru_layer_bwd_flagged_f32(const float* dY, const float* dh_last, const float* reserve, const float* out,
-                                             const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T,
-                                             int B, int H, void* sync_ws, const uint32_t* ready, uint32_t* done, int sub,
-                                             uint32_t epoch, void* stream) {
-  B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0, "gru_layer_bwd_flagged: bad shape T=%d B=%d H=%d", T, B, H);
-  B2T_REQUIRE((!ready && !done) || sub > 0, "gru_layer_bwd_flagged: sub must be > 0 when flags are given");
-  return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws,
-                            SweepFlags{ready, done, sub, epoch}, as_stream(stream));
-}
-
-// Stream-ordered word operations executed by the command processor (no kernel): hipStreamWriteValue32 /
-// hipStreamWaitValue32 on ordinary device memory (measured: ~2 us from a kernel's store to the dependent launch).
-extern "C" int b2t_stream_write_value32(void* ptr, uint32_t value, void* stream) {
-  B2T_REQUIRE(ptr != nullptr, "stream_write_value32: null pointer");
-  return check_hip(hipStreamWriteValue32(as_stream(stream), ptr, value, 0), "hipStreamWriteValue32");
-}
-extern "C" int b2t_stream_wait_value32_gte(void* ptr, uint32_t value, void* stream) {
-  B2T_REQUIRE(ptr != nullptr, "stream_wait_value32_gte: null pointer");
-  return check_hip(hipStreamWaitValue32(as_stream(stream), ptr, value, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32");
 }

@@ -69,24 +69,11 @@ __device__ __forceinline__ void gru_gate_bwd(const float* __restrict__ rs, float
 
 // persistent sweeps (gru_persistent.hip)
 size_t gru_persistent_sync_bytes(int T);
-struct SweepFlags;   // gru_sync.h
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
-                       float* reserve, int T, int B, int H, void* sync_ws, const SweepFlags& fl, hipStream_t s,
-                       bool bf16 = false, bool wide = false);
+                       float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s, bool bf16 = false,
+                       bool wide = false);
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
-                       void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16 = false, bool wide = false);
-
-// software-pipelined persistent sweeps, R row groups per workgroup (gru_pipeline.hip); return 4 = shape not covered
-int gru_pipeline_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
-                     float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s);
-int gru_pipeline_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
-                     const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
-                     void* sync_ws, hipStream_t s);
-
-// granule (data-tagged hand-off) sweeps (gru_granule.hip)
-size_t gru_granule_bytes(int T, int B, int H);
-int gru_granule_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
-                    float* reserve, int T, int B, int H, void* ws, hipStream_t s);
+                       void* sync_ws, hipStream_t s, bool bf16 = false, bool wide = false);
 
 }  // namespace b2t

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? 2 : (NCH <= 8 ? 3 : 1))) void gru_p
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
                                                                  float* __restrict__ reserve, int T, int B, int H,
-                                                                 unsigned* sync, SweepFlags fl) {
+                                                                 unsigned* sync) {
   static_assert(NT == 1 || BF16, "two tiles per workgroup need the bf16 weight slice");
   constexpr int TPN = 16 * NT + 4;    // LDS pitch of the staged tile (= TP for one tile)
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * NT * 4 * 64 + 16 * TPN];
@@ -95,24 +95,15 @@ __global__ __launch_bounds__(256, (NT == 2 ? 2 : (NCH <= 8 ? 3 : 1))) void gru_p
 #else
 #define TSTAMP(i)
 #endif
-  unsigned* tickets = sync + 32 + (size_t)pset * SETW + (size_t)gridDim.y * T * CSTRIDE;   // behind the step counters
   for (int t = 0; t < T; ++t) {
    {
-    // gi of sub-chunk k is written by a GEMM that may still be running when this kernel starts
-    if (fl.ready && t % fl.sub == 0) wait_flag(fl.ready + t / fl.sub, fl.epoch, err);
     float gir[NT], giz[NT], gin[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       gir[n] = giz[n] = gin[n] = 0.f;
       if (live) {
         const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit[n];
-        if (fl.ready) {   // produced while this kernel runs: read it coherently
-          gir[n] = __hip_atomic_load(const_cast<float*>(g3), RLX_AGENT);
-          giz[n] = __hip_atomic_load(const_cast<float*>(g3 + H), RLX_AGENT);
-          gin[n] = __hip_atomic_load(const_cast<float*>(g3 + 2 * H), RLX_AGENT);
-        } else {
-          gir[n] = g3[0]; giz[n] = g3[H]; gin[n] = g3[2 * H];
-        }
+        gir[n] = g3[0]; giz[n] = g3[H]; gin[n] = g3[2 * H];
       }
     }
     const float* hsrc = h_init;
@@ -181,11 +172,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? 2 : (NCH <= 8 ? 3 : 1))) void gru_p
                        *reinterpret_cast<const float4*>(&hs[r * TPN + c4]));
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
-        if (fl.done && ((t + 1) % fl.sub == 0 || t == T - 1))
-          signal_done(tickets + t / fl.sub, fl.done + t / fl.sub, gridDim.x * gridDim.y, fl.epoch);
-      }
+      if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
     }
     // The gate values saved for the backward sweep are nobody's dependency inside this sweep: store them AFTER the
     // publish so their write acknowledgements are not part of the drain in front of the counter increment.
@@ -219,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  const float* __restrict__ h_init,
                                                                  const float* __restrict__ w_hh_t, float* dG,
                                                                  float* __restrict__ dh_init, int T, int B, int H,
-                                                                 unsigned* sync, SweepFlags fl) {
+                                                                 unsigned* sync) {
   static_assert(NT == 1 || BF16, "two tiles per workgroup need the bf16 weight slice");
   constexpr int TPN = 16 * NT + 4;
   __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64 + 4 * 16 * TPN];
@@ -266,12 +253,8 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
 #pragma unroll
   for (int n = 0; n < NT; ++n) dzterm[n] = 0.f;
 
-  unsigned* tickets = sync + 32 + (size_t)pset * SETW + (size_t)gridDim.y * T * CSTRIDE;   // behind the step counters
   for (int t = T - 1; t >= -1; --t) {
    {
-    // sub-chunk k (counted from the END of the launch: the sweep runs backwards) of dY comes from a GEMM that may
-    // still be running when this kernel starts
-    if (fl.ready && t >= 0 && (T - 1 - t) % fl.sub == 0) wait_flag(fl.ready + (T - 1 - t) / fl.sub, fl.epoch, err);
     // operands of the elementwise part do not depend on the recurrence: fetch them first
     float r[NT], z[NT], nv[NT], ghn[NT], hprev[NT], dy[NT], carry[NT];
 #pragma unroll
@@ -282,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
         r[n] = rs[0]; z[n] = rs[H]; nv[n] = rs[2 * H]; ghn[n] = rs[3 * H];
         hprev[n] = t > 0 ? out[((long long)(t - 1) * B + row) * H + unit[n]] : h_init[(long long)row * H + unit[n]];
         const float* dyp = dY + ((long long)t * B + row) * H + unit[n];
-        dy[n] = fl.ready ? __hip_atomic_load(const_cast<float*>(dyp), RLX_AGENT) : dyp[0];
+        dy[n] = dyp[0];
       }
     }
     if (t < T - 1) {
@@ -350,8 +333,6 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       }
     }
     publish_count(cnt + (size_t)t * CSTRIDE);
-    if (fl.done && threadIdx.x == 0 && ((T - t) % fl.sub == 0 || t == 0))
-      signal_done(tickets + (T - 1 - t) / fl.sub, fl.done + (T - 1 - t) / fl.sub, gridDim.x * gridDim.y, fl.epoch);
    }
   }
   finish_call(sync, pset);
@@ -396,7 +377,7 @@ static unsigned exclusive_lds() {
 static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
   const int gx = H / 16, gy = (B + 15) / 16;
   if (!sync_ws) { set_error("%s: sync_ws is required in persistent mode", what); return 2; }
-  if ((long long)gy * T * CSTRIDE + T > SETW) {   // step counters + (at most T) sub-chunk tickets
+  if ((long long)gy * T * CSTRIDE > SETW) {
     set_error("%s: %d row groups x %d steps exceed the %d hand-off counters of one call", what, gy, T, SETW);
     return 2;
   }
@@ -410,7 +391,7 @@ static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
 }
 
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
-                       float* reserve, int T, int B, int H, void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16,
+                       float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s, bool bf16,
                        bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
@@ -422,15 +403,15 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
     if (bf16 && wide) {                                                                                                \
       want_exclusive(gru_persist_fwd_kernel<NCH, true, 2>);                                                            \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, fl);                                                                              \
+                         B, H, sync);                                                                              \
     } else if (bf16) {                                                                                                 \
       want_exclusive(gru_persist_fwd_kernel<NCH, true>);                                                               \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, fl);                                                                              \
+                         B, H, sync);                                                                              \
     } else {                                                                                                           \
       want_exclusive(gru_persist_fwd_kernel<NCH, false>);                                                              \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, fl);                                                                              \
+                         B, H, sync);                                                                              \
     }                                                                                                                  \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
@@ -445,7 +426,7 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
 
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
-                       void* sync_ws, const SweepFlags& fl, hipStream_t s, bool bf16, bool wide) {
+                       void* sync_ws, hipStream_t s, bool bf16, bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
   if (wide && (!bf16 || (H % 32) != 0 || H > 512)) { set_error("gru_layer_bwd: 32-unit workgroups need bf16 operands, H %% 32 == 0 and H <= 512"); return 2; }
@@ -456,15 +437,15 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
     if (bf16 && wide) {                                                                                               \
       want_exclusive(gru_persist_bwd_kernel<NCB, true, 2>);                                                           \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                     \
+                         w_hh_t, dG, dh_init, T, B, H, sync);                                                     \
     } else if (bf16) {                                                                                                \
       want_exclusive(gru_persist_bwd_kernel<NCB, true>);                                                              \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                     \
+                         w_hh_t, dG, dh_init, T, B, H, sync);                                                     \
     } else {                                                                                                          \
       want_exclusive(gru_persist_bwd_kernel<NCB, false>);                                                             \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync, fl);                                                     \
+                         w_hh_t, dG, dh_init, T, B, H, sync);                                                     \
     }                                                                                                                 \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);

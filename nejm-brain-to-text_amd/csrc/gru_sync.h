@@ -1,5 +1,4 @@
-// gru_sync.h — inter-workgroup hand-off pieces shared by the persistent GRU sweeps (gru_persistent.hip,
-// gru_pipeline.hip): agent-scope counters with bounded spins, sc1 payload accesses, the self-cleaning counter sets.
+// gru_sync.h — inter-workgroup hand-off pieces shared by the persistent GRU sweeps (gru_persistent.hip): agent-scope counters with bounded spins, sc1 payload accesses, the self-cleaning counter sets.
 #pragma once
 #include "gru_cell.h"
 
@@ -154,47 +153,8 @@ __device__ __forceinline__ f32x4 mfma_chunk16(float4 a, typename WFrag<BF16>::ty
 constexpr int TP = 20;  // LDS pitch (floats) of a staged 16x16 tile: 16-byte aligned rows, conflict-light
 
 
-// ---- sub-chunk flags between a RUNNING sweep and the GEMM streams ------------------------------------------------
-// A launch of n steps is cut into sub-chunks of `sub` steps.  ready[k] >= epoch (written by the command processor,
-// hipStreamWriteValue32, behind the GEMM that produced sub-chunk k's inputs) releases the sweep into sub-chunk k;
-// done[k] = epoch is stored by the LAST workgroup that finishes sub-chunk k (its payload stores are drained and its
-// step counter bumped before it takes its ticket), and a GEMM stream waits for it with hipStreamWaitValue32 -- the
-// consumer layer then trails the producer by one sub-chunk instead of one launch.  Flags are plain device words,
-// values only grow (epoch = pass number), nothing is ever reset.
-struct SweepFlags {
-  const unsigned* ready;   // [ceil(n / sub)] or null
-  unsigned* done;          // [ceil(n / sub)] or null
-  int sub;                 // steps per sub-chunk (> 0 when either pointer is set)
-  unsigned epoch;
-};
-
-#define RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
-
-// Thread 0 spins until *flag >= epoch (bounded, reports through the error word), then barrier.
-__device__ __forceinline__ void wait_flag(const unsigned* flag, unsigned epoch, unsigned* err) {
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(const_cast<unsigned*>(flag), RLX_SYS) - epoch) < 0) {
-      ++spins;
-      if ((spins & 255u) == 0u) {
-        if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
-        if (spins > 8u * SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }   // flags wait for whole GEMMs
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-}
-
-// Called by ONE lane of a workgroup after it has published the last step of sub-chunk k.
-__device__ __forceinline__ void signal_done(unsigned* ticket, unsigned* flag, unsigned nwg, unsigned epoch) {
-  const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  if (old == nwg - 1u) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // Layout of the sync workspace (unsigned words): [0] sticky error flag, [1] counter-set parity, [2] finish counter,
-// [8..31] timing scratch, then two counter sets of SETW words each.  Counter of (row group rg, step t): rg*T + t;
-// sub-chunk tickets (signal_done) follow at nrg*T + k.
+// [8..31] timing scratch, then two counter sets of SETW words each.  Counter of (row group rg, step t): rg*T + t.
 __device__ __forceinline__ unsigned* counter_set(unsigned* sync, unsigned pset) { return sync + 32 + (size_t)pset * SETW; }
 
 }  // namespace b2t

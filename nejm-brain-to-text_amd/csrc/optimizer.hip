@@ -46,11 +46,16 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   if (threadIdx.x == 0) part[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out3 = {sum g^2, norm, clip_coef}; also advances the per-tensor step counters of active tensors.
+// out4 = {sum g^2, norm, clip_coef, status}; also advances the per-tensor step counters of active tensors.
+// status: 0 OK, 1 a persistent sweep's error word is set (hand-off timeout: gradients invalid), 2 non-finite norm
+// (clip_grad_norm_(error_if_nonfinite=True), rnn_trainer.py:551-555).  Sticky; a bad step advances nothing.
 __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ part, int n, float max_norm,
                                                            float* __restrict__ out3, const int* __restrict__ active,
-                                                           int* __restrict__ seg_step, int nseg) {
+                                                           int* __restrict__ seg_step, int nseg,
+                                                           const unsigned* __restrict__ err_words, int n_err,
+                                                           long long err_stride) {
   __shared__ double red[16];
+  __shared__ int bad_s;
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)part[i];
 #pragma unroll
@@ -64,9 +69,18 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
     const float norm = sqrtf(sumsq);
     float coef = 1.0f;
     if (max_norm > 0.f) coef = fminf(1.0f, max_norm / (norm + 1e-6f));
-    out3[0] = sumsq; out3[1] = norm; out3[2] = coef;
+    float status = out3[3];
+    if (!(status > 0.f)) {
+      status = 0.f;
+      for (int i = 0; i < n_err; ++i)
+        if (__hip_atomic_load(const_cast<unsigned*>(err_words) + (long long)i * err_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) status = 1.f;
+      if (status == 0.f && !(fabsf(norm) <= 3.0e38f)) status = 2.f;   // inf or nan
+    }
+    out3[0] = sumsq; out3[1] = norm; out3[2] = coef; out3[3] = status;
+    bad_s = status != 0.f;
   }
-  if (seg_step)
+  __syncthreads();
+  if (seg_step && !bad_s)
     for (int i = threadIdx.x; i < nseg; i += blockDim.x) seg_step[i] += (active[i] != 0);
 }
 
@@ -76,16 +90,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float* __restrict__ v, const int* __restrict__ chunk2seg,
                                                     const int* __restrict__ active, const int* __restrict__ seg_group,
                                                     const int* __restrict__ seg_step, const float* __restrict__ clip3,
-                                                    GroupHyp hyp, double beta1, double beta2, float eps) {
+                                                    int apply_clip, GroupHyp hyp, double beta1, double beta2, float eps) {
   const int c = blockIdx.x;
   const int seg = chunk2seg[c];
   if (!active[seg]) return;
+  if (clip3 && clip3[3] != 0.f) return;   // invalid gradients (hand-off timeout / non-finite norm): never applied
   const int grp = seg_group[seg];
   const float lr = hyp.lr[grp], wd = hyp.wd[grp];
   const int k = seg_step[seg];  // already advanced for this step (1-based)
   const float bc1 = (float)(1.0 - pow(beta1, (double)k));
   const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)k));
-  const float coef = clip3 ? clip3[2] : 1.0f;
+  const float coef = (clip3 && apply_clip) ? clip3[2] : 1.0f;
   const float b1 = (float)beta1, b2 = (float)beta2;
   const long long i = (long long)c * (CHUNK / 4) + threadIdx.x;
   float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
@@ -126,25 +141,25 @@ extern "C" int b2t_opt_prepare(const int32_t* day_idx, int B, const int32_t* seg
 
 extern "C" int b2t_grad_norm_clip_f32(const float* grads, const int32_t* chunk2seg, const int32_t* active, int nchunks,
                                       float max_norm, float* partial_ws, float* out3, int32_t* seg_step, int nseg,
-                                      void* stream) {
+                                      const uint32_t* err_words, int n_err, long long err_stride, void* stream) {
   B2T_REQUIRE(nchunks > 0 && partial_ws && out3, "grad_norm_clip: bad args");
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nchunks), dim3(256), 0, s, grads, chunk2seg, active, partial_ws);
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, s, partial_ws, nchunks, max_norm, out3, active,
-                     seg_step, nseg);
+                     seg_step, nseg, err_words, err_words ? n_err : 0, err_stride);
   B2T_CHECK_LAUNCH("b2t_grad_norm_clip_f32");
   return 0;
 }
 
 extern "C" int b2t_adamw_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const int32_t* chunk2seg,
                              const int32_t* active, const int32_t* seg_group, const int32_t* seg_step, int nchunks,
-                             const float* clip3, const float* lr3_host, const float* wd3_host, double beta1,
-                             double beta2, float eps, void* stream) {
+                             const float* clip3, int apply_clip, const float* lr3_host, const float* wd3_host,
+                             double beta1, double beta2, float eps, void* stream) {
   B2T_REQUIRE(nchunks > 0 && lr3_host && wd3_host, "adamw: bad args");
   GroupHyp h;
   for (int i = 0; i < 3; ++i) { h.lr[i] = lr3_host[i]; h.wd[i] = wd3_host[i]; }
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq,
-                     chunk2seg, active, seg_group, seg_step, clip3, h, beta1, beta2, eps);
+                     chunk2seg, active, seg_group, seg_step, clip3, apply_clip, h, beta1, beta2, eps);
   B2T_CHECK_LAUNCH("b2t_adamw_f32");
   return 0;
 }

@@ -101,27 +101,31 @@ class BrainToTextDataset(Dataset):
                 bi += 1
         return index
 
-    def __getitem__(self, idx):
+    def read_trials(self, d, tlist):
+        """The trials `tlist` of day `d` from that day's session file, in order: a list of
+        (trial id, features [T,F], labels, transcription, n_time_steps, seq_len, block_num, trial_num); unreadable trials
+        are logged and skipped like the reference does (dataset.py:144-146)."""
         import h5py
+        out = []
+        with h5py.File(self.trial_indicies[d]['session_path'], 'r') as f:
+            for t in tlist:
+                try:
+                    g = f[f'trial_{t:04d}']
+                    x = torch.from_numpy(g['input_features'][:])
+                    if self.feature_subset:
+                        x = x[:, self.feature_subset]
+                    out.append((int(t), x, torch.from_numpy(g['seq_class_ids'][:]), torch.from_numpy(g['transcription'][:]),
+                                g.attrs['n_time_steps'], g.attrs['seq_len'], g.attrs['block_num'], g.attrs['trial_num']))
+                except Exception as e:
+                    print(f'Error loading trial {t} from session {self.trial_indicies[d]["session_path"]}: {e}')
+        return out
+
+    def __getitem__(self, idx):
         feats, labels, trans, n_steps, seq_lens, days, blocks, trials = [], [], [], [], [], [], [], []
         for d, tlist in self.batch_index[idx].items():
-            with h5py.File(self.trial_indicies[d]['session_path'], 'r') as f:
-                for t in tlist:
-                    try:
-                        g = f[f'trial_{t:04d}']
-                        x = torch.from_numpy(g['input_features'][:])
-                        if self.feature_subset:
-                            x = x[:, self.feature_subset]
-                        feats.append(x)
-                        labels.append(torch.from_numpy(g['seq_class_ids'][:]))
-                        trans.append(torch.from_numpy(g['transcription'][:]))
-                        n_steps.append(g.attrs['n_time_steps'])
-                        seq_lens.append(g.attrs['seq_len'])
-                        days.append(int(d))
-                        blocks.append(g.attrs['block_num'])
-                        trials.append(g.attrs['trial_num'])
-                    except Exception as e:  # the reference logs and skips unreadable trials (dataset.py:144-146)
-                        print(f'Error loading trial {t} from session {self.trial_indicies[d]["session_path"]}: {e}')
+            for (_, x, lab, tr, nt, sl, bn, tn) in self.read_trials(d, tlist):
+                feats.append(x); labels.append(lab); trans.append(tr); n_steps.append(nt); seq_lens.append(sl)
+                days.append(int(d)); blocks.append(bn); trials.append(tn)
         return _collate(feats, labels, trans, n_steps, seq_lens, days, blocks, trials)
 
 
@@ -203,12 +207,14 @@ class SyntheticTrials(Dataset):
 class ResidentDataset:
     """All trials of a split resident on the device: features [sum_T, F] f32 and labels [sum_S] i32 back to back with
     row offsets, plus the per-trial scalars.  `batch(rows)` returns the reference's batch dict (dataset.py:100-159) for
-    the given trial rows, assembled by one gather kernel per array; `from_batches(dataset)` flattens any source that
-    yields batch dicts (BrainToTextDataset over HDF5, SyntheticTrials) once; `batch_of(dataset_index)` replays the
-    source's own batch composition (the i-th batch of the source == rows i*B .. of this table).
+    the given trial rows, assembled by one gather kernel per array; `from_dataset(dataset)` flattens a source once
+    (unique trials only when the source has a trial index); `batch_of(i)` replays the source's i-th batch (its rows are
+    indices into the trial table: batch_rows[batch_off[i]:batch_off[i+1]]).
     `save(path)` / `load(path, device)`: a flat binary (.npz, uncompressed) so that later runs skip the conversion."""
 
-    KEYS = ('feat', 'feat_off', 'lab', 'lab_off', 'trans', 'n_time_steps', 'seq_len', 'day', 'block', 'trial', 'batch_rows')
+    KEYS = ('feat', 'feat_off', 'lab', 'lab_off', 'trans', 'n_time_steps', 'seq_len', 'day', 'block', 'trial', 'batch_rows',
+            'batch_off')
+    MAX_BYTES = int(float(os.environ.get("B2T_RESIDENT_MAX_GB", "200")) * 1e9)   # refuse conversions that cannot fit in HBM
 
     def __init__(self, arrays: dict, device='cuda:0'):
         self.device = torch.device(device)
@@ -230,9 +236,59 @@ class ResidentDataset:
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
-    def from_batches(cls, dataset, device='cuda:0'):
+    def from_dataset(cls, dataset, device='cuda:0'):
+        """Flatten a batch source.  A BrainToTextDataset (it has `trial_indicies` + `batch_index`) stores every UNIQUE
+        (day, trial) once -- the training split draws its 120,000 x 64 batch rows with replacement from ~8 k trials, so
+        replaying the batches would copy each trial ~1000 times -- and keeps the source's batch composition as row
+        indices into that table.  Other sources (SyntheticTrials: every batch is new data) go through from_batches."""
+        if not (hasattr(dataset, 'trial_indicies') and hasattr(dataset, 'batch_index')):
+            return cls.from_batches(dataset, device)
         feats, labs, foff, loff = [], [], [0], [0]
-        nts, sls, days, blocks, trials, trans, rows = [], [], [], [], [], [], []
+        nts, sls, days, blocks, trials, trans = [], [], [], [], [], []
+        row_of = {}
+        for d, info in dataset.trial_indicies.items():
+            wanted = sorted(set(int(t) for t in info['trials']))
+            for (t, x, lab, tr, nt, sl, bn, tn) in dataset.read_trials(d, wanted):
+                row_of[(d, t)] = len(nts)
+                T, S = int(nt), int(sl)
+                feats.append(x[:T].numpy().astype(np.float32)); labs.append(lab[:S].numpy().astype(np.int32))
+                foff.append(foff[-1] + T); loff.append(loff[-1] + S)
+                nts.append(T); sls.append(S); days.append(int(d)); blocks.append(int(bn)); trials.append(int(tn))
+                trans.append(tr.numpy().astype(np.int64))
+            if foff[-1] * feats[0].shape[1] * 4 > cls.MAX_BYTES:
+                raise RuntimeError(f"ResidentDataset: split exceeds {cls.MAX_BYTES / 1e9:.0f} GB (B2T_RESIDENT_MAX_GB)")
+        rows, off = [], [0]
+        for bi in range(len(dataset)):
+            for d, tlist in dataset.batch_index[bi].items():
+                rows.extend(row_of[(d, int(t))] for t in tlist if (d, int(t)) in row_of)   # unreadable trials were skipped
+            off.append(len(rows))
+        return cls(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), device)
+
+    @staticmethod
+    def _arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off):
+        wt = max(len(t) for t in trans)
+        tr = np.zeros((len(trans), wt), dtype=np.int64)
+        for i, t in enumerate(trans):
+            tr[i, :len(t)] = t
+        return dict(feat=np.concatenate(feats, 0), feat_off=np.asarray(foff, np.int64), lab=np.concatenate(labs, 0),
+                    lab_off=np.asarray(loff, np.int64), trans=tr, n_time_steps=np.asarray(nts, np.int32),
+                    seq_len=np.asarray(sls, np.int32), day=np.asarray(days, np.int64), block=np.asarray(blocks, np.int64),
+                    trial=np.asarray(trials, np.int64), batch_rows=np.asarray(rows, np.int64),
+                    batch_off=np.asarray(off, np.int64))
+
+    @classmethod
+    def from_batches(cls, dataset, device='cuda:0'):
+        """Replay a source batch by batch (each sampled row stored as its own trial): for sources whose batches are all
+        new data.  The estimated size is checked against MAX_BYTES before anything is copied."""
+        if len(dataset) > 0:
+            b0 = dataset[0]
+            est = len(dataset) * int(b0['input_features'].numel()) * 4
+            if est > cls.MAX_BYTES:
+                raise RuntimeError(f"ResidentDataset.from_batches: ~{est / 1e9:.0f} GB of replayed batches exceed "
+                                   f"{cls.MAX_BYTES / 1e9:.0f} GB (B2T_RESIDENT_MAX_GB); use from_dataset on a source with a "
+                                   "trial index, or keep the DataLoader path")
+        feats, labs, foff, loff = [], [], [0], [0]
+        nts, sls, days, blocks, trials, trans, rows, off = [], [], [], [], [], [], [], [0]
         for bi in range(len(dataset)):
             b = dataset[bi]
             first = len(nts)
@@ -245,16 +301,8 @@ class ResidentDataset:
                 nts.append(T); sls.append(S); days.append(int(b['day_indicies'][i]))
                 blocks.append(int(b['block_nums'][i])); trials.append(int(b['trial_nums'][i]))
                 trans.append(b['transcriptions'][i].numpy().astype(np.int64))
-            rows.append((first, B))
-        wt = max(len(t) for t in trans)
-        tr = np.zeros((len(trans), wt), dtype=np.int64)
-        for i, t in enumerate(trans):
-            tr[i, :len(t)] = t
-        arrays = dict(feat=np.concatenate(feats, 0), feat_off=np.asarray(foff, np.int64), lab=np.concatenate(labs, 0),
-                      lab_off=np.asarray(loff, np.int64), trans=tr, n_time_steps=np.asarray(nts, np.int32),
-                      seq_len=np.asarray(sls, np.int32), day=np.asarray(days, np.int64), block=np.asarray(blocks, np.int64),
-                      trial=np.asarray(trials, np.int64), batch_rows=np.asarray(rows, np.int64))
-        return cls(arrays, device)
+            rows.extend(range(first, first + B)); off.append(len(rows))
+        return cls(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), device)
 
     def save(self, path):
         np.savez(path, **self.host)
@@ -266,11 +314,11 @@ class ResidentDataset:
 
     # ---- batches ---------------------------------------------------------------------------------------------------
     def __len__(self):
-        return int(self.host['batch_rows'].shape[0])
+        return int(self.host['batch_off'].shape[0]) - 1
 
     def batch_of(self, i):
-        first, B = (int(v) for v in self.host['batch_rows'][i])
-        return self.batch(torch.arange(first, first + B))
+        a, e = int(self.host['batch_off'][i]), int(self.host['batch_off'][i + 1])
+        return self.batch(torch.from_numpy(self.host['batch_rows'][a:e]))
 
     def batch(self, rows):
         import ctypes as C

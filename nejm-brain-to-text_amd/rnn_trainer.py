@@ -76,7 +76,18 @@ class _SchedulerAdapter:
         self._ts = ts
 
     def state_dict(self):
-        return dict(last_epoch=self._ts.it, _step_count=self._ts.it + 1, _last_lr=self._ts.current_lrs())
+        """torch LambdaLR / LinearLR state (rnn_trainer.py:228-237,397): every key torch's load_state_dict reads, so that
+        the reference trainer can resume from a checkpoint written here (LambdaLR.load_state_dict pops 'lr_lambdas';
+        functions are not picklable and are saved as None, exactly like torch does)."""
+        a = self._ts.args
+        sd = dict(base_lrs=[a["lr_max"], a["lr_max_day"], a["lr_max"]], last_epoch=self._ts.it, verbose=False,
+                  _step_count=self._ts.it + 1, _get_lr_called_within_step=False, _last_lr=self._ts.current_lrs(),
+                  _is_initial=False)
+        if a.get("lr_scheduler_type", "cosine") == "linear":
+            sd.update(start_factor=1.0, end_factor=a["lr_min"] / a["lr_max"], total_iters=a["lr_decay_steps"])
+        else:
+            sd["lr_lambdas"] = [None, None, None]
+        return sd
 
     def load_state_dict(self, sd):
         self._ts.it = int(sd.get("last_epoch", 0))
@@ -93,17 +104,27 @@ def _strip_prefix(sd):
 
 
 class _ResidentLoader:
-    """Iterates a dataset.ResidentDataset like the DataLoader(batch_size=None) it replaces."""
+    """Iterates a dataset.ResidentDataset like the DataLoader(batch_size=None) it replaces (optionally only the batches
+    `indices` names: the data-parallel shard of this rank)."""
 
-    def __init__(self, rd):
+    def __init__(self, rd, indices=None):
         self.rd = rd
+        self.indices = indices
 
     def __len__(self):
-        return len(self.rd)
+        return len(self.indices) if self.indices is not None else len(self.rd)
 
     def __iter__(self):
-        for i in range(len(self.rd)):
+        for i in (self.indices if self.indices is not None else range(len(self.rd))):
             yield self.rd.batch_of(i)
+
+
+def rank_batches(n_batches: int, world: int, rank: int):
+    """Data-parallel shard of the pre-generated batch index (model_training/dataset.py:162-211): global step g consumes
+    the `world` consecutive batches g*world .. g*world + world-1, one per rank; the tail that does not fill a global step
+    is dropped so that every rank takes the same number of steps (a rank left alone in an all-reduce would hang)."""
+    steps = n_batches // world
+    return range(rank, steps * world, world)
 
 
 class BrainToTextDecoder_Trainer:
@@ -198,10 +219,8 @@ class BrainToTextDecoder_Trainer:
         self.model.to(self.device)
 
         self.optimizer = self.create_optimizer()
-        if self.args['lr_scheduler_type'] == 'cosine':
+        if self.args['lr_scheduler_type'] in ('cosine', 'linear'):   # 'linear' = LinearLR (rnn_trainer.py:228-234)
             self.learning_rate_scheduler = self.create_cosine_lr_scheduler(self.optimizer)
-        elif self.args['lr_scheduler_type'] == 'linear':
-            raise ValueError("lr_scheduler_type 'linear' is not built on the HIP path; use 'cosine' (rnn_args.yaml default)")
         else:
             raise ValueError(f"Invalid learning rate scheduler type: {self.args['lr_scheduler_type']}")
         self.ctc_loss = HipCTCLoss()
@@ -239,14 +258,19 @@ class BrainToTextDecoder_Trainer:
                 batch_size=dsa['batch_size'], must_include_days=None, random_seed=dsa['seed'],
                 feature_subset=feature_subset)
         nw = dsa.get('num_dataloader_workers', 0)
-        self.train_loader = DataLoader(self.train_dataset, batch_size=None, shuffle=dsa.get('loader_shuffle', False),
-                                       num_workers=nw, pin_memory=True)
+        # data parallel: a rank loads only the batches it owns (sampler-level sharding of the pre-generated batch index)
+        mine = list(rank_batches(len(self.train_dataset), self.world, self.rank)) if self.world > 1 else None
+        if mine is not None:
+            self.train_loader = DataLoader(self.train_dataset, batch_size=None, sampler=mine, num_workers=nw, pin_memory=True)
+        else:
+            self.train_loader = DataLoader(self.train_dataset, batch_size=None, shuffle=dsa.get('loader_shuffle', False),
+                                           num_workers=nw, pin_memory=True)
         self.val_loader = DataLoader(self.val_dataset, batch_size=None, shuffle=False, num_workers=0, pin_memory=True)
         if dsa.get('device_resident'):
-            # flatten both splits into HBM once; batches are then assembled on the device (no per-batch
-            # file reads, padding or PCIe copy).  Same batch composition and order as the loaders above.
-            self.train_loader = _ResidentLoader(ds.ResidentDataset.from_batches(self.train_dataset, self.device))
-            self.val_loader = _ResidentLoader(ds.ResidentDataset.from_batches(self.val_dataset, self.device))
+            # flatten both splits into HBM once (each unique trial once); batches are then assembled on the
+            # device (no per-batch file reads, padding or PCIe copy).  Same batch composition and order as the loaders above.
+            self.train_loader = _ResidentLoader(ds.ResidentDataset.from_dataset(self.train_dataset, self.device), mine)
+            self.val_loader = _ResidentLoader(ds.ResidentDataset.from_dataset(self.val_dataset, self.device))
         if 'dataset_probability_val' not in dsa:
             dsa['dataset_probability_val'] = [1] * len(dsa['sessions'])
         self.logger.info("Successfully initialized datasets")
@@ -257,7 +281,8 @@ class BrainToTextDecoder_Trainer:
         flat-arena TrainStep; returns an adapter with torch-format state_dict()."""
         flat = {k: self.args[k] for k in ('lr_max', 'lr_min', 'lr_decay_steps', 'lr_warmup_steps', 'lr_max_day',
                                           'lr_min_day', 'lr_decay_steps_day', 'lr_warmup_steps_day', 'beta0', 'beta1',
-                                          'epsilon', 'weight_decay', 'weight_decay_day', 'grad_norm_clip_value')}
+                                          'epsilon', 'weight_decay', 'weight_decay_day', 'grad_norm_clip_value',
+                                          'lr_scheduler_type')}
         self.train_step = TrainStep(self.model, flat)
         frozen = [n for n, p in self.model.named_parameters() if not p.requires_grad]
         if frozen:
@@ -283,6 +308,7 @@ class BrainToTextDecoder_Trainer:
     def save_model_checkpoint(self, save_path, PER, loss=None):
         if not self.is_main:
             return
+        self.train_step.check_status()
         checkpoint = {
             'model_state_dict': {CKPT_PREFIX + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
             'optimizer_state_dict': self.optimizer.state_dict(),
@@ -301,25 +327,66 @@ class BrainToTextDecoder_Trainer:
                 yaml.safe_dump(_to_plain(self.args), f)
 
     # ------------------------------------------------------------------ augmentation -------------
-    def transform_data(self, features, n_time_steps, mode='train'):
-        """Noise -> cut -> smoothing in ONE fused kernel pass (reference order, rnn_trainer.py:455-481).
-        Static gain / random walk (std 0 in rnn_args.yaml:64,66) are not built: non-zero values raise."""
+    def transform_data(self, features, n_time_steps, mode='train', _draws=None):
+        """Augmentation + smoothing in the reference's order (rnn_trainer.py:436-484): static gain -> white noise ->
+        constant offset -> random walk -> random cut -> Gaussian smoothing.  With the shipped settings (static gain and
+        random walk std 0, rnn_args.yaml:64,66) everything is ONE fused kernel pass; a non-zero static gain adds a batched
+        GEMM in front (features @ (I + N std), :449-453) and a non-zero random walk splits the pass around a cumulative
+        sum kernel (:464-465).  _draws: optional dict of pre-drawn N(0,1) tensors (static_gain [B,F,F], white [B,T,F],
+        offset [B,F], random_walk [B,T,F]) used by the parity tests to inject the reference's draws."""
         ta = self.transform_args
-        if mode == 'train' and (ta.get('static_gain_std', 0) > 0 or ta.get('random_walk_std', 0) > 0):
-            raise NotImplementedError("static_gain_std / random_walk_std > 0 are not built on the HIP path")
-        cut, ws_, os_ = 0, 0.0, 0.0
+        d = _draws or {}
+        features = features.to(self.device, torch.float32).contiguous()
+        cut, ws_, os_, sg_, rw_ = 0, 0.0, 0.0, 0.0, 0.0
         if mode == 'train':
             ws_, os_ = float(ta['white_noise_std']), float(ta['constant_offset_std'])
-            if ta['random_cut'] > 0:
-                cut = int(np.random.randint(0, ta['random_cut']))
-        features = features.to(self.device, torch.float32).contiguous()
-        seed = int(np.random.randint(0, 2 ** 31 - 1)) if (ws_ > 0 or os_ > 0) else 0
-        out = ops.augment_smooth(features, ta['smooth_kernel_std'], ta['smooth_kernel_size'], 'same', cut=cut,
-                                 white_std=ws_, offset_std=os_, seed=seed, smooth=bool(ta['smooth_data']))
+            sg_, rw_ = float(ta.get('static_gain_std', 0) or 0), float(ta.get('random_walk_std', 0) or 0)
+        seeds = [int(v) for v in np.random.randint(0, 2 ** 31 - 1, size=3)] if (ws_ > 0 or os_ > 0 or sg_ > 0 or rw_ > 0) else [0, 0, 0]
+        if mode == 'train' and ta['random_cut'] > 0:
+            cut = int(np.random.randint(0, ta['random_cut']))
+        B, T, F = features.shape
+        if sg_ > 0:
+            eye = torch.eye(F, device=self.device).expand(B, F, F).contiguous()
+            warp = ops.augment_smooth(eye, 1, 1, 'same', white_std=sg_, seed=seeds[1], white_noise=d.get('static_gain'),
+                                      smooth=False)                      # I + N(0,1) * std
+            warped = torch.empty_like(features)
+            ops.gemm(features, warp, warped, M=T, N_=F, K=F, Z=B, a_kc=1, a_s0=F, a_sz=T * F, b_kc=0, b_s0=F, b_sz=F * F,
+                     c_s0=F, c_sz=T * F)
+            features = warped
+        smooth = bool(ta['smooth_data'])
+        kw = dict(white_std=ws_, offset_std=os_, seed=seeds[0], white_noise=d.get('white'), offset_noise=d.get('offset'))
+        if rw_ > 0:
+            noisy = ops.augment_smooth(features, 1, 1, 'same', smooth=False, **kw)
+            walk = ops.augment_smooth(torch.zeros_like(features), 1, 1, 'same', white_std=rw_, seed=seeds[2],
+                                      white_noise=d.get('random_walk'), smooth=False)
+            ops.cumsum_add(walk, noisy, int(ta.get('random_walk_axis', -1)))
+            out = ops.augment_smooth(noisy, ta['smooth_kernel_std'], ta['smooth_kernel_size'], 'same', cut=cut, smooth=smooth)
+        else:
+            out = ops.augment_smooth(features, ta['smooth_kernel_std'], ta['smooth_kernel_size'], 'same', cut=cut,
+                                     smooth=smooth, **kw)
         return out, n_time_steps - cut
 
     # ------------------------------------------------------------------ train --------------------
+    def _sync_val(self, val_metrics):
+        """Data parallel: validation runs on rank 0 only; every rank gets (avg_PER, avg_loss) so that best-checkpoint
+        tracking, early stopping and the break out of the loop are the same decision on all ranks."""
+        if self.world == 1:
+            return val_metrics
+        import torch.distributed as dist
+        t = torch.zeros(2, dtype=torch.float64, device=self.device)
+        if self.is_main:
+            t[0], t[1] = val_metrics['avg_PER'], val_metrics['avg_loss']
+        dist.broadcast(t, src=0)
+        if not self.is_main:
+            val_metrics = {'avg_PER': float(t[0]), 'avg_loss': float(t[1]), 'day_PERs': {}}
+        return val_metrics
+
     def train(self):
+        """The reference's loop (rnn_trainer.py:486-651).  `i` is the GLOBAL step (= optimizer step = LR-schedule step);
+        data parallel, global step i consumes batches i*world .. i*world + world-1 of the pre-generated index, one per
+        rank (rank_batches), so a run over N ranks takes num_training_batches // N optimizer steps of N*64 sentences.
+        The host never waits for the step it has just enqueued: loss / grad norm / status of step i are copied to pinned
+        memory asynchronously and read while step i+1 runs (the reference's loss.item() at :562 drains the GPU every step)."""
         self.model.train()
         train_losses, val_losses, val_PERs, val_results = [], [], [], []
         val_steps_since_improvement = 0
@@ -327,10 +394,29 @@ class BrainToTextDecoder_Trainer:
         early_stopping = self.args.get('early_stopping', True)
         early_stopping_val_steps = self.args['early_stopping_val_steps']
         train_start_time = time.time()
+        last_step = self.args['num_training_batches'] // self.world - 1
+        pending = None      # (step, pinned stat copy, event, enqueue time)
+
+        def drain():
+            """Read the previous step's numbers (it has normally finished long ago)."""
+            nonlocal pending
+            if pending is None:
+                return None
+            step, host, ev, t0 = pending
+            pending = None
+            ev.synchronize()
+            self.train_step.check_status(host)            # refused step (hand-off timeout / non-finite norm): raise
+            lossv, gnv = float(host[4]), float(host[1])
+            train_losses.append(lossv)
+            return step, lossv, gnv, time.time() - t0
+
+        def log(rec):
+            if rec is not None and rec[0] % self.args['batches_per_train_log'] == 0:
+                self.logger.info(f'Train batch {rec[0]}: ' + f'loss: {rec[1]:.2f} ' + f'grad norm: {rec[2]:.2f} '
+                                 f'time: {rec[3]:.3f}')
+
         i = -1
         for i, batch in enumerate(self.train_loader):
-            if self.world > 1 and (i % self.world) != self.rank:
-                continue                       # shard the pre-generated batch index across ranks
             self.model.train()
             start_time = time.time()
             features = batch['input_features'].to(self.device, non_blocking=True)
@@ -339,22 +425,23 @@ class BrainToTextDecoder_Trainer:
             phone_seq_lens = batch['phone_seq_lens'].to(self.device, non_blocking=True)
             day_indicies = batch['day_indicies']
             features, n_time_steps = self.transform_data(features, n_time_steps, 'train')
-            loss, grad_norm = self.train_step.step(features, day_indicies, labels, n_time_steps, phone_seq_lens)
-            lossv = loss.item()                # per-step host sync, like the reference (:562)
-            gnv = grad_norm.item()
-            if not np.isfinite(gnv):           # clip_grad_norm_(error_if_nonfinite=True), :551-555
-                raise RuntimeError(f"The total norm for gradients is non-finite ({gnv}), so it cannot be clipped")
-            train_step_duration = time.time() - start_time
-            train_losses.append(lossv)
-            if i % self.args['batches_per_train_log'] == 0:
-                self.model._ws.check_sync()    # bounded hand-off spins report through an error word: fail loudly
-                self.logger.info(f'Train batch {i}: ' + f'loss: {lossv:.2f} ' + f'grad norm: {gnv:.2f} '
-                                 f'time: {train_step_duration:.3f}')
-            if i % self.args['batches_per_val_step'] == 0 or i == (self.args['num_training_batches'] - 1):
+            self.train_step.step(features, day_indicies, labels, n_time_steps, phone_seq_lens)
+            host = torch.empty(5, dtype=torch.float32).pin_memory()
+            host.copy_(self.train_step.stat, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            prev = drain()
+            pending = (i, host, ev, start_time)
+            log(prev)
+            if i % self.args['batches_per_val_step'] == 0 or i == last_step:
+                log(drain())                   # the weights validated / checkpointed are those of an ACCEPTED step i
                 self.logger.info(f"Running test after training batch: {i}")
                 start_time = time.time()
-                val_metrics = self.validation(loader=self.val_loader, return_logits=self.args['save_val_logits'],
-                                              return_data=self.args['save_val_data'])
+                val_metrics = None
+                if self.is_main:
+                    val_metrics = self.validation(loader=self.val_loader, return_logits=self.args['save_val_logits'],
+                                                  return_data=self.args['save_val_data'])
+                val_metrics = self._sync_val(val_metrics)
                 val_step_duration = time.time() - start_time
                 self.logger.info(f'Val batch {i}: ' + f'PER (avg): {val_metrics["avg_PER"]:.4f} ' +
                                  f'CTC Loss (avg): {val_metrics["avg_loss"]:.4f} ' + f'time: {val_step_duration:.3f}')
@@ -391,7 +478,10 @@ class BrainToTextDecoder_Trainer:
                 if early_stopping and (val_steps_since_improvement >= early_stopping_val_steps):
                     self.logger.info(f'Overall validation PER has not improved in {early_stopping_val_steps} '
                                      f'validation steps. Stopping training early at batch: {i}')
-                    break
+                    break                      # taken by every rank: the decision comes from the broadcast metrics
+            if i >= last_step:
+                break
+        log(drain())
         training_duration = time.time() - train_start_time
         self.logger.info(f'Best avg val PER achieved: {self.best_val_PER:.5f}')
         self.logger.info(f'Total training time: {(training_duration / 60):.2f} minutes')
@@ -404,6 +494,8 @@ class BrainToTextDecoder_Trainer:
     def validation(self, loader, return_logits=False, return_data=False):
         """Greedy-CTC PER on the validation set (rnn_trainer.py:653-770): forward, CTC loss, argmax /
         collapse / blank removal and Levenshtein distance all run on the GPU; one host copy per batch."""
+        if getattr(self, 'train_step', None) is not None:
+            self.train_step.check_status()     # never validate (or go on to checkpoint) weights behind a refused step
         self.model.eval()
         metrics = {}
         if return_logits:
