@@ -141,7 +141,8 @@ def main():
         t_enq = time.perf_counter() - t0           # host time to enqueue K steps (no sync inside a step)
         fence()
         dt = time.perf_counter() - t0
-        model._ws.check_sync()     # a hand-off timeout inside a persistent sweep would invalidate the run
+        ts.check_status()          # a hand-off timeout inside a persistent sweep would invalidate the run (raises)
+        model._ws.check_sync()
         return loss, dt, t_enq
 
     try:
@@ -154,6 +155,7 @@ def main():
         for buf in model._ws.bufs.values():
             if buf.dtype == torch.int32:
                 buf.zero_()
+        ts.stat.zero_()
         loss, dt, t_enq = timed_run()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -165,16 +167,21 @@ def main():
     assert np.isfinite(lossv), "non-finite loss in the bench step"
 
     # ---- live per-kernel timing (HIP events on the launch stream) over 4 extra instrumented steps ----
+    # (GEMMs and sweeps are bracketed by the C++ executor on the streams it launches them on, b2t_exec_profile; the
+    # augmentation and CTC kernels by ops._Prof on torch's current stream, which is the stream they are launched on)
     prof = ops.PROFILE
     prof["on"] = True; prof["ev"] = []
+    model._ws.profile(True)
     NPROF = 4
     for i in range(NPROF):
         step(a.warmup + a.steps + i)
     torch.cuda.synchronize()
     prof["on"] = False
+    recs = model._ws.profile_read()
+    model._ws.profile(False)
+    recs += [(name, flops, nlaunch, e0.elapsed_time(e1) * 1e-3) for name, flops, nlaunch, e0, e1 in prof["ev"]]
     agg = {}
-    for name, flops, nlaunch, e0, e1 in prof["ev"]:
-        t = e0.elapsed_time(e1) * 1e-3
+    for name, flops, nlaunch, t in recs:
         r = agg.setdefault(name, [0.0, 0.0, 0])
         r[0] += t; r[1] += flops; r[2] += nlaunch
     dom = max(agg.items(), key=lambda kv: kv[1][0])
@@ -207,8 +214,7 @@ def main():
                    config=dict(workload="BASELINE.json configs[1]: 5-layer GRU-512 + CTC, synthetic [B=64,T=500,F=512] -> 41 "
                                         "phonemes, fp32, full training step incl. on-GPU augmentation, clip and AdamW",
                                global_batch=B * world, seq_len=T, parallelism=f"dp{world}",
-                               gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
-                               bwd_sweeps_in_flight=min(L, ops.PIPELINE["bwd_sweeps"])),
+                               gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),
                    host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
         if world == 1 and not a.no_cpu_baseline:
