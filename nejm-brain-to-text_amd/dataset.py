@@ -255,7 +255,7 @@ class ResidentDataset:
                 foff.append(foff[-1] + T); loff.append(loff[-1] + S)
                 nts.append(T); sls.append(S); days.append(int(d)); blocks.append(int(bn)); trials.append(int(tn))
                 trans.append(tr.numpy().astype(np.int64))
-            if foff[-1] * feats[0].shape[1] * 4 > cls.MAX_BYTES:
+            if feats and foff[-1] * feats[0].shape[1] * 4 > cls.MAX_BYTES:
                 raise RuntimeError(f"ResidentDataset: split exceeds {cls.MAX_BYTES / 1e9:.0f} GB (B2T_RESIDENT_MAX_GB)")
         rows, off = [], [0]
         for bi in range(len(dataset)):

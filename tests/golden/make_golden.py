@@ -15,6 +15,11 @@ Reference entry points exercised:
   rnn_trainer.py:436-484 transform_data (torch.randn monkey-patched)    (transform.npz)
   rnn_trainer.py:724-736 / evaluate_model.py:129-141 greedy decode      (greedy.npz)
   evaluate_model_helpers.py:79-83,87-115 rearrange / runSingleDecodingStep (evalstep.npz)
+  rnn_trainer.py:527-558 with patch_size 14 / stride 4                   (train_step_patch.npz)
+  rnn_trainer.py:365-406 save_model_checkpoint after 3 steps + the 4th step (ckpt_ref.pt, ckpt_ref_step4.npz)
+  dataset.py:162-242 create_batch_index_train / _test                    (sampler_index.npz)
+  rnn_trainer.py:228-234 LinearLR                                        (lr_table.npz: linear_*)
+  rnn_trainer.py:449-465 static gain + random walk with injected draws   (transform.npz: full_*)
 """
 import os
 import sys
@@ -181,12 +186,14 @@ BASE_ARGS = dict(
 )
 
 
-def make_train_step():
-    """Three optimizer steps of the reference step body (rnn_trainer.py:513-558), dropout 0,
-    noise off (val-mode transform), fused=False AdamW on CPU (same math as fused)."""
-    F_, H, D, L, B, T, S = 32, 48, 6, 3, 8, 40, 6
+def make_train_step(name="train_step.npz", ps=0, st=0, dims=(32, 48, 6, 3, 8, 40, 6), ckpt=False):
+    """Four optimizer steps of the reference step body (rnn_trainer.py:513-558), dropout 0,
+    noise off (val-mode transform), fused=False AdamW on CPU (same math as fused).
+    ckpt: after step 3 the reference's save_model_checkpoint (rnn_trainer.py:387-406) writes ckpt_ref.pt; the state
+    after the 4th step goes to ckpt_ref_step4.npz (a trainer resumed from the checkpoint must reproduce it)."""
+    F_, H, D, L, B, T, S = dims
     torch.manual_seed(10)
-    model = GRUDecoder(F_, H, D, 41, 0.0, 0.0, L, 0, 0)
+    model = GRUDecoder(F_, H, D, 41, 0.0, 0.0, L, ps, st)
     gen = torch.Generator().manual_seed(99)
     perturb_days(model, gen)
     args = dict(BASE_ARGS)
@@ -204,20 +211,23 @@ def make_train_step():
     crit = torch.nn.CTCLoss(blank=0, reduction="none", zero_infinity=False)
 
     x = torch.randn(B, T, F_, generator=gen)
-    day = torch.tensor([0, 0, 2, 2, 2, 5, 5, 0])
+    day = torch.tensor([0, 0, 2, 2, 2, 5, 5, 0]) if (B, D) == (8, 6) else (torch.arange(B) // 2 * 3) % D
     targets = torch.randint(1, 41, (B, S), generator=gen)
     tgt_len = torch.randint(2, S + 1, (B,), generator=gen)
     for b in range(B):
         targets[b, tgt_len[b]:] = 0
-    n_steps_t = torch.randint(25, T + 1, (B,), generator=gen)
+    n_steps_t = torch.randint(T - 15, T + 1, (B,), generator=gen)
     out = {f"sd0::{k}": v for k, v in sd_np(model).items()}
     out.update(x=x.numpy(), day_idx=day.numpy(), targets=targets.numpy(), tgt_len=tgt_len.numpy(),
-               n_time_steps=n_steps_t.numpy(), cfg=np.array([F_, H, D, 41, L, 0, 0]),
+               n_time_steps=n_steps_t.numpy(), cfg=np.array([F_, H, D, 41, L, ps, st]),
                clip=np.float32(args["grad_norm_clip_value"]), warmup=np.int64(4))
     for step in range(4):
         opt.zero_grad()
         feats, nts = tr.transform_data(x.clone(), n_steps_t, "val")
-        adjusted = nts.to(torch.int32)     # patch_size 0 => adjusted_lens = n_time_steps
+        if ps > 0:                         # rnn_trainer.py:532
+            adjusted = ((nts - ps) / st + 1).to(torch.int32)
+        else:
+            adjusted = nts.to(torch.int32)     # patch_size 0 => adjusted_lens = n_time_steps
         logits = model(feats, day)
         loss = crit(torch.permute(logits.log_softmax(2), [1, 0, 2]), targets, adjusted, tgt_len)
         loss = torch.mean(loss)
@@ -237,7 +247,18 @@ def make_train_step():
         sched.step()
         for k, v in sd_np(model).items():
             out[f"sd{step+1}::{k}"] = v
-    save("train_step.npz", **out)
+        if ckpt and step == 2:
+            import logging
+            tr.optimizer, tr.learning_rate_scheduler = opt, sched
+            tr.logger = logging.getLogger("golden")
+            tr.args = dict(args); tr.args["checkpoint_dir"] = "/tmp"
+            tr.save_model_checkpoint(os.path.join(HERE, "ckpt_ref.pt"), 0.25, 1.5)
+            print(f"wrote ckpt_ref.pt: {os.path.getsize(os.path.join(HERE, 'ckpt_ref.pt'))/1e6:.2f} MB")
+    if ckpt:
+        save("ckpt_ref_step4.npz", **{k: v for k, v in out.items() if k.startswith("sd4::") or k in
+                                      ("x", "day_idx", "targets", "tgt_len", "n_time_steps", "cfg", "clip", "warmup", "loss3", "gnorm3", "lr3")})
+        return
+    save(name, **out)
 
 
 def make_lr_table():
@@ -258,7 +279,24 @@ def make_lr_table():
     for i in range(3):
         lrs.append([g["lr"] for g in opt.param_groups])
         opt.step(); sched.step()
-    save("lr_table.npz", steps=np.array(steps), factors=fac, groups=groups, first_lrs=np.array(lrs))
+    # lr_scheduler_type 'linear' (rnn_trainer.py:228-234): torch LinearLR over the same three groups
+    targs = dict(BASE_ARGS); targs["lr_decay_steps"] = 50
+    tr2 = _trainer_shell(GRUDecoder(8, 8, 2, 41, 0, 0, 1, 0, 0), targs)
+    torch.optim.AdamW = lambda groups, **kw: real_adamw(groups, **{k: v for k, v in kw.items() if k != "fused"})
+    try:
+        opt2 = tr2.create_optimizer()
+    finally:
+        torch.optim.AdamW = real_adamw
+    lin = torch.optim.lr_scheduler.LinearLR(optimizer=opt2, start_factor=1.0, end_factor=targs["lr_min"] / targs["lr_max"],
+                                            total_iters=targs["lr_decay_steps"])
+    lin_lrs = []
+    for i in range(60):
+        lin_lrs.append([g["lr"] for g in opt2.param_groups])
+        opt2.step(); lin.step()
+    save("lr_table.npz", steps=np.array(steps), factors=fac, groups=groups, first_lrs=np.array(lrs),
+         linear_lrs=np.array(lin_lrs, dtype=np.float64), linear_total=np.int64(50),
+         linear_sd_keys=np.array(sorted(lin.state_dict().keys())), lambda_sd_keys=np.array(sorted(sched.state_dict().keys())),
+         optim_group_keys=np.array(sorted(opt.state_dict()["param_groups"][0].keys())))
 
 
 def make_transform():
@@ -291,6 +329,25 @@ def make_transform():
         out[f"train_cut{cut}_n"] = nn_.numpy()
     yv, nv = tr.transform_data(x.clone(), n.clone(), "val")
     out["val"] = yv.numpy(); out["val_n"] = nv.numpy()
+    # every augmentation on (static gain rnn_trainer.py:449-453, random walk :464-465), draws injected in call order
+    for axis in (-1, 1):
+        a2 = dict(BASE_ARGS)
+        a2["dataset"] = dict(data_transforms=dict(BASE_ARGS["dataset"]["data_transforms"], static_gain_std=0.1,
+                                                  random_walk_std=0.05, random_walk_axis=axis))
+        tr2 = _trainer_shell(model, a2)
+        sg = torch.randn(B, C, C, generator=gen)
+        rw = torch.randn(B, T, C, generator=gen)
+        draws = [wn, on, rw]
+        real_like = torch.randn_like
+        torch.randn = lambda *shape, **kw: draws.pop(0).clone()
+        torch.randn_like = lambda t, **kw: sg.clone()
+        np.random.randint = lambda lo, hi=None, **kw: 1
+        try:
+            y, nn_ = tr2.transform_data(x.clone(), n.clone(), "train")
+        finally:
+            torch.randn = real_randn; torch.randn_like = real_like; np.random.randint = real_randint
+        tag = "last" if axis == -1 else "time"
+        out[f"full_{tag}"] = y.numpy(); out[f"full_{tag}_sg"] = sg.numpy(); out[f"full_{tag}_rw"] = rw.numpy()
     save("transform.npz", **out)
 
 
@@ -351,6 +408,31 @@ def make_init():
         save(f"init_{tag}.npz", cfg=np.array(cfg, dtype=np.float64), names=names, **arrs)
 
 
+def make_sampler_index():
+    """Batch index of the reference sampler under a seed (dataset.py:162-242): day-balanced random training batches and
+    the sequential test batches.  h5py is stubbed: the index is built in __init__ without touching files."""
+    import dataset as ref_ds
+    rng = np.random.RandomState(5)
+    trial_idx = {d: {"trials": sorted(rng.choice(200, size=int(rng.randint(5, 40)), replace=False).tolist()),
+                     "session_path": f"/nonexistent/day{d}.hdf5"} for d in range(7)}
+    out = dict(days=np.array(list(trial_idx.keys())))
+    for d, v in trial_idx.items():
+        out[f"trials_{d}"] = np.array(v["trials"])
+    for tag, kw in (("a", dict(batch_size=10, days_per_batch=3, must_include_days=None)),
+                    ("b", dict(batch_size=16, days_per_batch=4, must_include_days=[1, -1]))):
+        tr = ref_ds.BrainToTextDataset(trial_idx, n_batches=12, split="train", random_seed=7, **kw)
+        for bi, batch in tr.batch_index.items():
+            out[f"train_{tag}_{bi}_days"] = np.array([int(d) for d in batch.keys()])
+            for d, t in batch.items():
+                out[f"train_{tag}_{bi}_{int(d)}"] = np.asarray(t)
+    te = ref_ds.BrainToTextDataset(trial_idx, n_batches=None, split="test", batch_size=16, random_seed=7)
+    out["test_n"] = np.int64(len(te.batch_index))
+    for bi, batch in te.batch_index.items():
+        (d, t), = batch.items()
+        out[f"test_{bi}_day"] = np.int64(d); out[f"test_{bi}"] = np.asarray(t)
+    save("sampler_index.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "init":
         make_init()
@@ -360,6 +442,9 @@ if __name__ == "__main__":
     make_smooth()
     make_ctc()
     make_train_step()
+    make_train_step("train_step_patch.npz", ps=14, st=4, dims=(16, 48, 5, 3, 6, 73, 5))
+    make_train_step(ckpt=True, ps=14, st=4, dims=(16, 32, 4, 2, 6, 61, 4))
+    make_sampler_index()
     make_lr_table()
     make_transform()
     make_greedy()

@@ -175,3 +175,54 @@ def test_time_chunk_plan_rule():
     assert ops.time_chunks(500, 128, 512) == 6
     assert ops.time_chunks(500, 192, 512) == 1          # 2 x 384 workgroups > 512 slots
     assert ops.time_chunks(40, 64, 512) == 2 and ops.time_chunks(1, 32, 512) == 1
+
+
+def test_sampler_reproduces_reference_batch_index(golden_dir):
+    """BrainToTextDataset's batch index under a seed == the reference sampler's (dataset.py:162-242), captured by
+    tests/golden/make_golden.py:make_sampler_index: day-balanced random training batches (with and without
+    must_include_days, incl. the surplus-trial removal) and the sequential test batches."""
+    import dataset as ds
+    z = np.load(os.path.join(golden_dir, "sampler_index.npz"), allow_pickle=False)
+    trial_idx = {int(d): {"trials": [int(t) for t in z[f"trials_{int(d)}"]], "session_path": f"/nonexistent/day{int(d)}.hdf5"}
+                 for d in z["days"]}
+    for tag, kw in (("a", dict(batch_size=10, days_per_batch=3, must_include_days=None)),
+                    ("b", dict(batch_size=16, days_per_batch=4, must_include_days=[1, -1]))):
+        tr = ds.BrainToTextDataset(trial_idx, n_batches=12, split="train", random_seed=7, **kw)
+        assert len(tr) == 12
+        for bi in range(12):
+            days = [int(d) for d in tr.batch_index[bi].keys()]
+            assert days == [int(d) for d in z[f"train_{tag}_{bi}_days"]], (tag, bi)
+            for d in days:
+                np.testing.assert_array_equal(np.asarray(tr.batch_index[bi][d]), z[f"train_{tag}_{bi}_{d}"])
+            assert sum(len(v) for v in tr.batch_index[bi].values()) == kw["batch_size"]
+    te = ds.BrainToTextDataset(trial_idx, n_batches=None, split="test", batch_size=16, random_seed=7)
+    assert len(te) == int(z["test_n"])
+    for bi in range(len(te)):
+        (d, t), = te.batch_index[bi].items()
+        assert int(d) == int(z[f"test_{bi}_day"])
+        np.testing.assert_array_equal(np.asarray(t), z[f"test_{bi}"])
+
+
+def test_rank_batches_shard_the_batch_index():
+    """Data-parallel sharding of the pre-generated batch index: every rank takes the same number of steps, global step g
+    uses batches g*world .. g*world+world-1, the tail that does not fill a step is dropped."""
+    from rnn_trainer import rank_batches
+    for n, world in ((12, 1), (12, 4), (13, 4), (7, 8), (120000, 8)):
+        shards = [list(rank_batches(n, world, r)) for r in range(world)]
+        assert len(set(len(s) for s in shards)) == 1
+        steps = n // world
+        assert all(len(s) == steps for s in shards)
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(steps * world))
+        for g in range(min(steps, 5)):
+            assert [s[g] for s in shards] == list(range(g * world, (g + 1) * world))
+
+
+def test_lr_schedules_host_side(golden_dir):
+    from b2t_train_step import cosine_lr_factor, linear_lr_factor
+    z = np.load(os.path.join(golden_dir, "lr_table.npz"), allow_pickle=False)
+    tot = int(z["linear_total"])
+    for i, lrs in enumerate(z["linear_lrs"]):
+        np.testing.assert_allclose(0.005 * linear_lr_factor(i, 0.0001 / 0.005, tot), lrs[0], rtol=1e-12)
+    for s_, fac in zip(z["steps"], z["factors"]):
+        assert abs(cosine_lr_factor(int(s_), 0.0001 / 0.005, 120000, 1000) - fac[0]) < 1e-15

@@ -133,3 +133,62 @@ def test_full_size_train_step_properties(c2):
     ref = O.model_loss_and_grads(c2["sd"], c2["x"][pick].numpy(), c2["day"][pick].numpy(), tgt[pick].numpy(),
                                  adj[pick].cpu().numpy(), tl[pick].numpy(), L)[1]
     np.testing.assert_allclose(lb[pick].cpu().numpy(), ref, rtol=2e-5)
+
+
+def _grad_check(model, sd, x, day, tgt, nt, tl, L_, ps, st, dev, tag):
+    """One full training step (default execution plan of that shape) vs ONE oracle run of the whole batch: loss and every
+    parameter gradient at 1e-3 of the tensor max (SURVEY 8b numerics contract)."""
+    import oracle.b2t_oracle as O
+    from b2t_train_step import TrainStep
+    args = dict(lr_max=1e-30, lr_min=1e-30, lr_decay_steps=10, lr_warmup_steps=0, lr_max_day=1e-30, lr_min_day=1e-30,
+                lr_decay_steps_day=10, lr_warmup_steps_day=0, beta0=0.9, beta1=0.999, epsilon=0.1, weight_decay=0.0,
+                weight_decay_day=0, grad_norm_clip_value=0, _debug_keep_unclipped=True)
+    ts = TrainStep(model.train(), args)
+    loss, gn = ts.step(x.to(dev), day, tgt, nt, tl)
+    got = ts.last_unclipped_grads()
+    ts.check_status()
+    adj = O.adjusted_lens(nt.numpy(), ps, st)
+    lo, _, _, go = O.model_loss_and_grads(sd, x.numpy(), day.numpy(), tgt.numpy(), adj, tl.numpy(), L_, ps, st)
+    np.testing.assert_allclose(float(loss), float(lo), rtol=2e-5)
+    assert set(got) == set(go)
+    worst = ("", 0.0)
+    for k, ref in go.items():
+        scale = max(1e-6, float(np.abs(ref).max()))
+        err = float(np.abs(got[k] - ref).max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+        assert err <= 1e-3, (tag, k, err)
+    norm_o, _ = O.clip_grad_norm(go, 0)
+    np.testing.assert_allclose(float(gn), float(norm_o), rtol=1e-4)
+    print(f"[{tag}] loss {float(loss):.5f} (oracle {float(lo):.5f}); worst gradient error {worst[1]:.2e} of max in {worst[0]}")
+
+
+def test_full_size_c2_every_gradient_matches_oracle(c2):
+    """BASELINE configs[1] at full size under the plan bench.py times (6 time chunks, 11 streams, up to five sweeps in
+    flight): ALL parameter gradients of the 64-sentence batch against one oracle run of the same batch."""
+    import b2t_ops as ops
+    assert ops.time_chunks(T, B, H) == 6
+    _grad_check(c2["model"], c2["sd"], c2["x"], c2["day"], c2["tgt"], c2["nt"], c2["tl"], L, 0, 0, c2["dev"], "C2")
+
+
+def test_full_size_c3_shape_every_gradient_matches_oracle():
+    """BASELINE configs[2]'s model shape -- H = 768, patch 14 / stride 4 (K = 7168 input projection), B = 64, T = 500 ->
+    T' = 122, 45 day layers, 4 days in the batch -- forward + backward against one oracle run (dropout 0: the masks of
+    the two sides cannot coincide; the dropout arithmetic has its own tests)."""
+    from rnn_model import GRUDecoder
+    dev = torch.device("cuda:0")
+    H3, ps, st = 768, 14, 4
+    torch.manual_seed(77)
+    model = GRUDecoder(F, H3, D, C, 0.0, 0.0, L, ps, st)
+    sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(B, T, F, generator=g) * 0.6
+    day = torch.tensor([3, 17, 29, 44]).repeat_interleave(B // 4).to(torch.int32)
+    Sm = 40
+    tgt = torch.randint(1, C, (B, Sm), generator=g).to(torch.int32)
+    tl = torch.randint(10, Sm + 1, (B,), generator=g).to(torch.int32)
+    nt = torch.randint(420, T + 1, (B,), generator=g).to(torch.int32)
+    for b in range(B):
+        tgt[b, tl[b]:] = 0
+    _grad_check(model, sd, x, day, tgt, nt, tl, L, ps, st, dev, "C3 shape")

@@ -65,8 +65,11 @@ def test_ctc(golden_dir):
     assert np.isinf(li[0]) and np.isinf(zi["loss"][0])
 
 
-def test_train_step(golden_dir):
-    z = load(golden_dir, "train_step.npz")
+@pytest.mark.parametrize("name", ["train_step.npz", "train_step_patch.npz"])
+def test_train_step(golden_dir, name):
+    """Four steps of the reference's step body (rnn_trainer.py:527-558); train_step_patch.npz: patch_size 14 / stride 4
+    (rnn_model.py:106-119), i.e. the unfold's adjoint and layer 0's weight gradient over overlapping rows."""
+    z = load(golden_dir, name)
     F, H, D, C, L, ps, st = [int(v) for v in z["cfg"]]
     sd = sd_of(z, "sd0::")
     clip = float(z["clip"]); warm = int(z["warmup"])
@@ -78,7 +81,8 @@ def test_train_step(golden_dir):
         feats, n = O.transform_data(z["x"], z["n_time_steps"], "val")
         if it == 0:
             np.testing.assert_allclose(feats, z["feats0"], atol=2e-6)
-        loss, loss_b, logits, g = O.model_loss_and_grads(sd, feats, z["day_idx"], z["targets"], n, z["tgt_len"], L)
+        loss, loss_b, logits, g = O.model_loss_and_grads(sd, feats, z["day_idx"], z["targets"], O.adjusted_lens(n, ps, st),
+                                                         z["tgt_len"], L, ps, st)
         np.testing.assert_allclose(loss, z[f"loss{it}"], rtol=1e-5)
         if it == 0:
             np.testing.assert_allclose(logits, z["logits0"], atol=2e-5)
@@ -104,6 +108,32 @@ def test_train_step(golden_dir):
             np.testing.assert_allclose(sd[k], gold_sd[k], atol=3e-6, err_msg=f"step{it} {k}")
 
 
+@pytest.mark.parametrize("name", ["train_step.npz", "train_step_patch.npz"])
+def test_torch_cpu_step_is_the_reference_step(golden_dir, name):
+    """oracle/torch_cpu_step.py (bench.py's cpu_baseline) reproduces the reference's four steps: losses, gradient norms,
+    learning rates and every parameter after each AdamW step."""
+    import torch
+    from oracle import torch_cpu_step as TC
+    z = load(golden_dir, name)
+    F, H, D, C, L, ps, st = [int(v) for v in z["cfg"]]
+    torch.set_num_threads(4)
+    m = TC.CpuGRUDecoder(F, H, D, C, L, ps, st)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_of(z, "sd0::").items()})
+    w = int(z["warmup"])
+    args = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=120000, lr_warmup_steps=w, lr_max_day=0.005, lr_min_day=0.0001,
+                lr_decay_steps_day=120000, lr_warmup_steps_day=w, beta0=0.9, beta1=0.999, epsilon=0.1, weight_decay=0.001,
+                weight_decay_day=0, grad_norm_clip_value=float(z["clip"]))
+    tr = TC.CpuTrainer(m, args)
+    t = lambda k: torch.from_numpy(z[k])
+    for it in range(4):
+        np.testing.assert_allclose([g["lr"] for g in tr.opt.param_groups], z[f"lr{it}"], rtol=1e-12)
+        loss, gn = tr.step(t("x"), t("day_idx"), t("targets"), t("n_time_steps"), t("tgt_len"))
+        np.testing.assert_allclose(loss, z[f"loss{it}"], rtol=1e-6)
+        np.testing.assert_allclose(gn, z[f"gnorm{it}"], rtol=1e-5)
+        for k, ref in sd_of(z, f"sd{it+1}::").items():
+            np.testing.assert_allclose(m.state_dict()[k].numpy(), ref, atol=1e-6, err_msg=f"step{it} {k}")
+
+
 def test_lr_table(golden_dir):
     z = load(golden_dir, "lr_table.npz")
     for s, fac in zip(z["steps"], z["factors"]):
@@ -111,6 +141,12 @@ def test_lr_table(golden_dir):
         assert abs(f - fac[0]) < 1e-15 and abs(f - fac[2]) < 1e-15
     assert O.lr_factor(0, 0.0001, 0.005, 120000, 1000) == 0.0
     np.testing.assert_allclose(z["first_lrs"][:, 0], [0.0, 5e-6, 1e-5], rtol=1e-12)
+    # lr_scheduler_type 'linear' (torch LinearLR, rnn_trainer.py:228-234): the closed form equals torch's chained updates
+    tot = int(z["linear_total"])
+    for i, lrs in enumerate(z["linear_lrs"]):
+        f = O.linear_lr_factor(i, 0.0001, 0.005, tot)
+        np.testing.assert_allclose(lrs, [0.005 * f, 0.005 * f, 0.005 * f], rtol=1e-12)
+    assert abs(z["linear_lrs"][-1][0] - 0.0001) < 1e-15
 
 
 def test_transform(golden_dir):
@@ -123,6 +159,12 @@ def test_transform(golden_dir):
     y, n = O.transform_data(z["x"], z["n_time_steps"], "val")
     np.testing.assert_allclose(y, z["val"], atol=3e-6)
     np.testing.assert_array_equal(n, z["val_n"])
+    for tag, axis in (("last", -1), ("time", 1)):   # static gain + random walk on too (rnn_trainer.py:449-453,464-465)
+        y, n = O.transform_data(z["x"], z["n_time_steps"], "train", white_noise=z["white"], white_noise_std=1.0,
+                                offset_noise=z["offset"], constant_offset_std=0.2, cut=1,
+                                static_gain_noise=z[f"full_{tag}_sg"], static_gain_std=0.1,
+                                random_walk_noise=z[f"full_{tag}_rw"], random_walk_std=0.05, random_walk_axis=axis)
+        np.testing.assert_allclose(y, z[f"full_{tag}"], atol=5e-6)
 
 
 def test_greedy_and_edit(golden_dir):
