@@ -54,37 +54,69 @@ ARGS = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=120000, lr_warmup_steps=
             epsilon=0.1, weight_decay=0.001, weight_decay_day=0, grad_norm_clip_value=10)
 
 
-def cpu_baseline():
-    """Oracle (numpy port of the reference step, rnn_trainer.py:527-558) on ONE full C2 minibatch."""
-    from oracle import b2t_oracle as O
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((B, T, F)).astype(np.float32)
-    days = np.repeat(np.array([0, 11, 22, 33]), B // 4)
-    labels = rng.integers(1, C, (B, S)); lens = rng.integers(20, S + 1, B)
-    for b in range(B):
-        labels[b, lens[b]:] = 0
-    sd = {}
-    for i in range(D):
-        sd[f"day_weights.{i}"] = np.eye(F, dtype=np.float32); sd[f"day_biases.{i}"] = np.zeros((1, F), np.float32)
-    k = 1.0 / np.sqrt(H)
-    for l in range(L):
-        sd[f"gru.weight_ih_l{l}"] = rng.uniform(-k, k, (3 * H, F if l == 0 else H)).astype(np.float32)
-        sd[f"gru.weight_hh_l{l}"] = rng.uniform(-k, k, (3 * H, H)).astype(np.float32)
-        sd[f"gru.bias_ih_l{l}"] = rng.uniform(-k, k, 3 * H).astype(np.float32)
-        sd[f"gru.bias_hh_l{l}"] = rng.uniform(-k, k, 3 * H).astype(np.float32)
-    sd["out.weight"] = rng.uniform(-k, k, (C, H)).astype(np.float32); sd["out.bias"] = np.zeros(C, np.float32)
-    sd["h0"] = rng.uniform(-k, k, (1, 1, H)).astype(np.float32)
-    t0 = time.time()
-    wn = rng.standard_normal((B, T, F)).astype(np.float32); on = rng.standard_normal((B, 1, F)).astype(np.float32)
-    feats, n = O.transform_data(x, np.full(B, T), "train", white_noise=wn, white_noise_std=1.0, offset_noise=on,
-                                constant_offset_std=0.2, cut=1)
-    loss, _, _, g = O.model_loss_and_grads(sd, feats, days, labels, n, lens, L)
-    norm, gc = O.clip_grad_norm(g, 10.0)
-    for name in gc:
-        O.adamw_step(sd[name], gc[name], np.zeros_like(sd[name]), np.zeros_like(sd[name]), 1, 5e-6, 0.001)
-    dt = time.time() - t0
-    return dict(value=round(B / dt, 3), unit="sentences/s", cores=os.cpu_count(), kind="port",
-                sample=f"1 full step of the same workload (B={B}, T={T}; numpy/BLAS port in oracle/), {dt:.1f} s")
+def cpu_baseline(timed: int = 3):
+    """the reference's step on PyTorch-CPU operators (oracle/torch_cpu_step.py: nn.GRU + einsum + conv1d +
+    CTCLoss + AdamW, the operator sequence of rnn_trainer.py:527-558; pinned to tests/golden/train_step*.npz by
+    tests/test_oracle_golden.py), on the same C2 tensors, all host cores, 1 warm-up + `timed` steps."""
+    from oracle import torch_cpu_step as TC
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(10)
+    m = TC.CpuGRUDecoder(F, H, D, C, L, 0, 0)
+    for n_, p_ in m.gru.named_parameters():      # the reference's init (rnn_model.py:75-79)
+        if "weight_hh" in n_:
+            torch.nn.init.orthogonal_(p_)
+        if "weight_ih" in n_:
+            torch.nn.init.xavier_uniform_(p_)
+    tr = TC.CpuTrainer(m, dict(ARGS))
+    x, days, labels, nts, lens = (t.cpu() for t in make_batch(1000, "cpu"))
+    g = torch.Generator().manual_seed(5)
+    times = []
+    for i in range(1 + timed):
+        wn = torch.randn(B, T, F, generator=g); on = torch.randn(B, 1, F, generator=g)
+        t0 = time.perf_counter()
+        loss, _ = tr.step(x, days.long(), labels.long(), nts.long(), lens.long(), white=wn, offset=on, cut=i % 3)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.mean(times[1:]))
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return dict(value=round(B / dt, 3), unit="sentences/s", cores=cores, kind="torch-cpu", cpu=model,
+                sample=f"{timed} timed steps (after 1 warm-up) of the same workload (B={B}, T={T}, fp32) on PyTorch-CPU operators, "
+                       f"torch.set_num_threads({cores}); {dt:.2f} s/step, final loss {loss:.3f}")
+
+
+def dry_run(a, world, rank):
+    """The launch contract without the GPU: rendezvous from the environment, --gpus == WORLD_SIZE, barrier-bracketed
+    timed region, MAX over ranks, one JSON line from rank 0.  The "step" is a sleep; nothing is measured."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    for _ in range(a.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.02 if rank == world - 1 else 0.001)
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps(dict(metric="GRU+CTC train sentences/sec", value=round(B * world * a.steps / dt, 2), unit="sentences/s",
+                              n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
+                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
+                              config=dict(workload="dry run (no GPU work)", global_batch=B * world, seq_len=T, parallelism=f"dp{world}"))))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -94,11 +126,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gru-mode", type=int, default=int(os.environ.get("B2T_GRU_MODE", "-1")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a GPU (tests): gloo rendezvous, argument handling, max-over-ranks; measures nothing")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2..4] numbers reported under `secondary`")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dry_run:
+        return dry_run(a, world, rank)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
@@ -217,6 +254,11 @@ def main():
                                gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),
                    host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
+        if world == 1 and not a.no_secondary:
+            # BASELINE configs[2..4] measured by the same process, reported beside (never instead of) the headline
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_secondary
+            out["secondary"] = bench_secondary.all_secondary()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

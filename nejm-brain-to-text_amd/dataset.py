@@ -212,8 +212,8 @@ class ResidentDataset:
     indices into the trial table: batch_rows[batch_off[i]:batch_off[i+1]]).
     `save(path)` / `load(path, device)`: a flat binary (.npz, uncompressed) so that later runs skip the conversion."""
 
-    KEYS = ('feat', 'feat_off', 'lab', 'lab_off', 'trans', 'n_time_steps', 'seq_len', 'day', 'block', 'trial', 'batch_rows',
-            'batch_off')
+    KEYS = ('feat', 'feat_off', 'lab', 'lab_off', 'lab_n', 'trans', 'n_time_steps', 'seq_len', 'day', 'block', 'trial',
+            'batch_rows', 'batch_off')
     MAX_BYTES = int(float(os.environ.get("B2T_RESIDENT_MAX_GB", "200")) * 1e9)   # refuse conversions that cannot fit in HBM
 
     def __init__(self, arrays: dict, device='cuda:0'):
@@ -229,6 +229,7 @@ class ResidentDataset:
         self.lab_off = to(h['lab_off'], torch.int64)
         self.n_time_steps = to(h['n_time_steps'], torch.int32)
         self.seq_len = to(h['seq_len'], torch.int32)
+        self.lab_n = to(h['lab_n'], torch.int32)   # stored label-row lengths (the session files pad them with zeros)
         self.day = to(h['day'], torch.int64)
         self.block = to(h['block'], torch.int64)
         self.trial = to(h['trial'], torch.int64)
@@ -251,8 +252,10 @@ class ResidentDataset:
             for (t, x, lab, tr, nt, sl, bn, tn) in dataset.read_trials(d, wanted):
                 row_of[(d, t)] = len(nts)
                 T, S = int(nt), int(sl)
-                feats.append(x[:T].numpy().astype(np.float32)); labs.append(lab[:S].numpy().astype(np.int32))
-                foff.append(foff[-1] + T); loff.append(loff[-1] + S)
+                # label rows are kept as stored (the session files zero-pad them to max_seq_elements): pad_sequence in the
+                # reference's collate then yields the same [B, S_stored] array
+                feats.append(x[:T].numpy().astype(np.float32)); labs.append(lab.numpy().astype(np.int32))
+                foff.append(foff[-1] + T); loff.append(loff[-1] + int(lab.shape[0]))
                 nts.append(T); sls.append(S); days.append(int(d)); blocks.append(int(bn)); trials.append(int(tn))
                 trans.append(tr.numpy().astype(np.int64))
             if feats and foff[-1] * feats[0].shape[1] * 4 > cls.MAX_BYTES:
@@ -266,12 +269,13 @@ class ResidentDataset:
 
     @staticmethod
     def _arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off):
+        lab_n = np.diff(np.asarray(loff, np.int64)).astype(np.int32)
         wt = max(len(t) for t in trans)
         tr = np.zeros((len(trans), wt), dtype=np.int64)
         for i, t in enumerate(trans):
             tr[i, :len(t)] = t
         return dict(feat=np.concatenate(feats, 0), feat_off=np.asarray(foff, np.int64), lab=np.concatenate(labs, 0),
-                    lab_off=np.asarray(loff, np.int64), trans=tr, n_time_steps=np.asarray(nts, np.int32),
+                    lab_off=np.asarray(loff, np.int64), lab_n=lab_n, trans=tr, n_time_steps=np.asarray(nts, np.int32),
                     seq_len=np.asarray(sls, np.int32), day=np.asarray(days, np.int64), block=np.asarray(blocks, np.int64),
                     trial=np.asarray(trials, np.int64), batch_rows=np.asarray(rows, np.int64),
                     batch_off=np.asarray(off, np.int64))
@@ -327,16 +331,16 @@ class ResidentDataset:
         rows_h = torch.as_tensor(rows, dtype=torch.int64).cpu()
         B = int(rows_h.shape[0])
         T = int(self.host['n_time_steps'][rows_h.numpy()].max())       # pad_sequence pads to the longest trial of the batch
-        S = int(self.host['seq_len'][rows_h.numpy()].max())
+        S = int(self.host['lab_n'][rows_h.numpy()].max())
         r = rows_h.to(self.device)
-        nts, sls = self.n_time_steps[r].contiguous(), self.seq_len[r].contiguous()
+        nts, sls, labn = self.n_time_steps[r].contiguous(), self.seq_len[r].contiguous(), self.lab_n[r].contiguous()
         x = torch.empty((B, T, self.F), dtype=torch.float32, device=self.device)
         y = torch.empty((B, max(S, 1)), dtype=torch.int32, device=self.device)
         lib = N.load()
         with torch.cuda.device(self.device):
             N.check(lib.b2t_batch_gather_b32(ops._p(self.feat), ops._p(self.feat_off[r].contiguous()), ops._p(nts), ops._p(x),
                                              B, T, self.F, ops._stream()), "b2t_batch_gather_b32")
-            N.check(lib.b2t_batch_gather_b32(ops._p(self.lab), ops._p(self.lab_off[r].contiguous()), ops._p(sls), ops._p(y),
+            N.check(lib.b2t_batch_gather_b32(ops._p(self.lab), ops._p(self.lab_off[r].contiguous()), ops._p(labn), ops._p(y),
                                              B, max(S, 1), 1, ops._stream()), "b2t_batch_gather_b32")
         # tensors the step consumes stay on the device; the bookkeeping fields are host tensors, as a DataLoader yields them
         hn = rows_h.numpy()

@@ -119,6 +119,22 @@ class _ResidentLoader:
             yield self.rd.batch_of(i)
 
 
+def broadcast_val_metrics(val_metrics, is_main: bool, world: int, device):
+    """Data parallel: validation runs on rank 0 only; every rank gets (avg_PER, avg_loss) so that best-checkpoint
+    tracking, early stopping and the break out of the loop are the same decision on all ranks (a rank that stopped alone
+    would leave the others hanging in the next gradient all-reduce)."""
+    if world == 1:
+        return val_metrics
+    import torch.distributed as dist
+    t = torch.zeros(2, dtype=torch.float64, device=device)
+    if is_main:
+        t[0], t[1] = val_metrics['avg_PER'], val_metrics['avg_loss']
+    dist.broadcast(t, src=0)
+    if not is_main:
+        val_metrics = {'avg_PER': float(t[0]), 'avg_loss': float(t[1]), 'day_PERs': {}}
+    return val_metrics
+
+
 def rank_batches(n_batches: int, world: int, rank: int):
     """Data-parallel shard of the pre-generated batch index (model_training/dataset.py:162-211): global step g consumes
     the `world` consecutive batches g*world .. g*world + world-1, one per rank; the tail that does not fill a global step
@@ -368,18 +384,7 @@ class BrainToTextDecoder_Trainer:
 
     # ------------------------------------------------------------------ train --------------------
     def _sync_val(self, val_metrics):
-        """Data parallel: validation runs on rank 0 only; every rank gets (avg_PER, avg_loss) so that best-checkpoint
-        tracking, early stopping and the break out of the loop are the same decision on all ranks."""
-        if self.world == 1:
-            return val_metrics
-        import torch.distributed as dist
-        t = torch.zeros(2, dtype=torch.float64, device=self.device)
-        if self.is_main:
-            t[0], t[1] = val_metrics['avg_PER'], val_metrics['avg_loss']
-        dist.broadcast(t, src=0)
-        if not self.is_main:
-            val_metrics = {'avg_PER': float(t[0]), 'avg_loss': float(t[1]), 'day_PERs': {}}
-        return val_metrics
+        return broadcast_val_metrics(val_metrics, self.is_main, self.world, self.device)
 
     def train(self):
         """The reference's loop (rnn_trainer.py:486-651).  `i` is the GLOBAL step (= optimizer step = LR-schedule step);

@@ -101,4 +101,4 @@ class CpuTrainer:
         gn = torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=clip, error_if_nonfinite=True) if clip > 0 else torch.tensor(0.0)
         self.opt.step()
         self.sched.step()
-        return float(loss), float(gn)
+        return float(loss.detach()), float(gn)

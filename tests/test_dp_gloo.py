@@ -69,3 +69,84 @@ def test_grad_reducer_world2():
         assert ok_sum and changed
         assert days == [0, 1, 4]
     assert sorted(res[0][3] + res[1][3]) == list(range(10)) and not set(res[0][3]) & set(res[1][3])
+
+
+def _loop_worker(rank, world, port, q):
+    """The trainer's data-parallel loop control (rnn_trainer.py: rank_batches + broadcast_val_metrics + the early-stopping
+    rule of train()) with a stub step: one all-reduce per global step (a rank that took a different number of steps, or
+    broke out alone, would hang here), validation on rank 0 only."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "nejm-brain-to-text_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from rnn_trainer import rank_batches, broadcast_val_metrics
+        n_batches, val_every, patience = 23, 2, 2          # 23 batches over 2 ranks: 11 global steps, one batch dropped
+        mine = list(rank_batches(n_batches, world, rank))
+        last_step = n_batches // world - 1
+        pers = iter([0.9, 0.5, 0.6, 0.7, 0.1, 0.1])         # improvement stops after the 2nd validation -> stop at the 4th
+        best, since, stopped_at, steps, vals = float("inf"), 0, None, 0, []
+        for i, b in enumerate(mine):
+            t = torch.tensor([float(b)])
+            dist.all_reduce(t)                              # the step's gradient exchange
+            steps += 1
+            assert float(t) == sum(range(i * world, (i + 1) * world))
+            if i % val_every == 0 or i == last_step:
+                vm = dict(avg_PER=next(pers), avg_loss=1.0, day_PERs={}) if rank == 0 else None   # only rank 0 validates
+                vm = broadcast_val_metrics(vm, rank == 0, world, torch.device("cpu"))
+                vals.append(vm["avg_PER"])
+                if vm["avg_PER"] < best:
+                    best, since = vm["avg_PER"], 0
+                else:
+                    since += 1
+                if since >= patience:
+                    stopped_at = i
+                    break
+            if i >= last_step:
+                break
+        q.put((rank, len(mine), steps, stopped_at, best, vals))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_loop_control_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, s0, stop0, best0, v0), (r1, n1, s1, stop1, best1, v1) = res
+    assert n0 == n1 == 11
+    assert s0 == s1 == 7 and stop0 == stop1 == 6           # validations at steps 0,2,4,6: 0.9, 0.5, 0.6, 0.7 -> stop
+    assert best0 == best1 == 0.5 and v0 == v1 == [0.9, 0.5, 0.6, 0.7]
+
+
+def test_bench_rendezvous_path_world2():
+    """bench.py under `python -m torch.distributed.run` exactly as the driver launches it for N > 1 (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the environment, --gpus N must equal WORLD_SIZE, max-over-ranks of the time, rank 0 prints the
+    one JSON line) -- with --dry-run, which swaps RCCL for gloo and the step for a sleep: the plumbing, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # only rank 0 prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["dry_run"] is True
+    assert out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
+    assert out["ms_per_step"] >= 20.0                      # rank 1 sleeps 20 ms per "step": the MAX over ranks is reported
+    # a mismatch between --gpus and the launched world is an error, not a silent single-GPU run
+    cmd[cmd.index("--gpus") + 1] = "4"
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0

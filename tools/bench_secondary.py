@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Secondary measurements bench.py reports beside the headline line (BASELINE.json configs[2..4]); each returns a dict with
+its workload string and dtype.  One MI355X, synthetic inputs, inputs resident in HBM.
+
+  c3_f32 / c3_amp : shipped t15 shape (H=768, patch 14/4 -> T'=122, dropout 0.4/0.2, 45 days), full training step
+  c2_amp          : the headline workload with bf16 matmul operands (the reference's use_amp regime, opt-in)
+  decode_beam100_3gram : configs[3] -- 32 utterances x 120 patch frames, prologue + prefix beam 10/100 + token 3-gram
+  stream_32utt_5gram   : configs[4] -- 32 concurrent utterances, one 80 ms patch frame per call: GRU step with carried
+                         state (H=768) -> prologue -> 5-gram beam 10/10 -> host reads the running best
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "nejm-brain-to-text_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import b2t_native as N      # noqa: E402
+import b2t_ops as ops       # noqa: E402
+import ngram_lm             # noqa: E402
+from rnn_model import GRUDecoder       # noqa: E402
+from b2t_train_step import TrainStep   # noqa: E402
+
+ARGS = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=120000, lr_warmup_steps=1000, lr_max_day=0.005,
+            lr_min_day=0.0001, lr_decay_steps_day=120000, lr_warmup_steps_day=1000, beta0=0.9, beta1=0.999,
+            epsilon=0.1, weight_decay=0.001, weight_decay_day=0, grad_norm_clip_value=10)
+
+
+def train_ms(shape: str, amp: bool, steps: int = 8, warmup: int = 3):
+    dev = torch.device("cuda:0")
+    B, T, F, C, D, S = 64, 500, 512, 41, 45, 60
+    old = ops.AMP["on"]
+    ops.set_amp(amp)
+    try:
+        torch.manual_seed(10)
+        if shape == "c3":
+            m = GRUDecoder(F, 768, D, C, 0.4, 0.2, 5, 14, 4).to(dev).train()
+            smax, what = 50, "shipped t15 shape: 5-layer GRU-768, patch 14/4 (T'=122), dropout 0.4/0.2, 45 day layers, B=64, T=500"
+        else:
+            m = GRUDecoder(F, 512, D, C, 0.0, 0.0, 5, 0, 0).to(dev).train()
+            smax, what = 60, "BASELINE configs[1] workload (5-layer GRU-512, B=64, T=500)"
+        ts = TrainStep(m, dict(ARGS))
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(B, T, F, generator=g).to(dev)
+        days = torch.tensor([0, 11, 22, 33]).repeat_interleave(B // 4).to(dev, torch.int32)
+        labels = torch.randint(1, C, (B, S), generator=g)
+        lens = torch.clamp(torch.randint(20, S + 1, (B,), generator=g), max=smax)
+        for b in range(B):
+            labels[b, lens[b]:] = 0
+        labels, lens = labels.to(dev, torch.int32), lens.to(dev, torch.int32)
+        nts = torch.full((B,), T, dtype=torch.int32, device=dev)
+
+        def step(i):
+            f = ops.augment_smooth(x, 2, 100, "same", cut=i % 3, white_std=1.0, offset_std=0.2, seed=i)
+            return ts.step(f, days, labels, nts - (i % 3), lens)
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            loss, _ = step(warmup + i)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        ts.check_status()
+        assert np.isfinite(float(loss))
+        return dict(ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1), workload=what + ", full training step",
+                    dtype="bf16 matmul + recurrent-product operands, f32 accumulate / gates / CTC / optimizer" if amp else "f32")
+    finally:
+        ops.set_amp(old)
+
+
+def _beam_buffers(lib, U, T, second, dev):
+    L, NN = T + 1, T * second + 2
+    return dict(L=L, NN=NN, state=torch.empty((lib.b2t_beam_state_bytes(L, NN) * U,), dtype=torch.uint8, device=dev),
+                hyps=torch.zeros((U, second, L), dtype=torch.int32, device=dev), hl=torch.empty((U, second), dtype=torch.int32, device=dev),
+                sc=torch.empty((U, second), device=dev), vs=torch.empty((U, second), device=dev), lms=torch.empty((U, second), device=dev),
+                tm=torch.zeros((U, second, L), dtype=torch.int32, device=dev))
+
+
+def _lm_search(lib, x, nt, U, Cc, first, second, b, lm, d):
+    _p = ops._p
+    N.check(lib.b2t_prefix_beam_search_lm_f32(_p(x), None, U, nt, Cc, first, second, 0, _p(b["state"]), b["L"], b["NN"], _p(b["hyps"]),
+                                              _p(b["hl"]), _p(b["sc"]), _p(b["vs"]), _p(b["tm"]), _p(d["child"]), _p(d["logp"]),
+                                              _p(d["bow"]), _p(d["suffix"]), _p(d["nstate"]), lm.V, lm.start_state, -1, 0.6, 0.2,
+                                              float(lm.unk_logp), _p(b["lms"]), ops._stream()), "beam")
+
+
+def decode_beam100_3gram():
+    lib = N.load(); dev = torch.device("cuda:0"); _p = ops._p
+    Cc, T, U, first, second = 41, 120, 32, 10, 100
+    words = [None] + [f"p{i}" for i in range(1, 41)]
+    rng = np.random.default_rng(0)
+    logits = torch.from_numpy((rng.standard_normal((U, T, Cc)) * 3.0).astype(np.float32)).to(dev)
+    pri = torch.zeros_like(logits); lp = torch.empty_like(logits)
+    lm = ngram_lm.NGramLM.from_arpa(ngram_lm.synthetic_arpa(words, 3, 20000, seed=3), words)
+    d = lm.to_device(dev)
+    b = _beam_buffers(lib, U, T, second, dev)
+    ts = []
+    for rep in range(5):
+        N.check(lib.b2t_beam_reset(_p(b["state"]), U, b["L"], b["NN"], ops._stream()), "reset")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        N.check(lib.b2t_lm_prologue_f32(_p(logits), _p(pri), float(np.log(90.0)), _p(lp), U * T, Cc, ops._stream()), "prologue")
+        _lm_search(lib, lp, T, U, Cc, first, second, b, lm, d)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return dict(p50_ms_per_utterance=round(float(np.median(ts)) / U * 1e3, 4), ms_per_call_32_utterances=round(float(np.median(ts)) * 1e3, 3),
+                workload=f"BASELINE configs[3]: {U} utterances x {T} patch frames, DecodeNumpy prologue + CTC prefix beam "
+                         f"{first}/{second} with a token-level 3-gram ({lm.n_nodes} nodes, synthetic ARPA) in HBM, one call",
+                dtype="f32")
+
+
+def stream_32utt_5gram(frames: int = 100):
+    lib = N.load(); dev = torch.device("cuda:0"); _p = ops._p
+    U, F, H, L, C, PATCH, STRIDE = 32, 512, 768, 5, 41, 14, 4
+    torch.manual_seed(0)
+    model = GRUDecoder(F, H, 4, C, 0.0, 0.0, L, PATCH, STRIDE).to(dev).eval()
+    day = torch.zeros(U, dtype=torch.int32, device=dev)
+    x_all = torch.randn(U, PATCH + STRIDE * (frames - 1), F, device=dev) * 0.5
+    words = [None] + [f"p{i}" for i in range(1, 41)]
+    lm = ngram_lm.NGramLM.from_arpa(ngram_lm.synthetic_arpa(words, 5, 20000, seed=5), words)
+    d = lm.to_device(dev)
+    first, second = 10, 10
+    b = _beam_buffers(lib, U, frames, second, dev)
+    pri = torch.zeros((U, 1, C), device=dev); lp = torch.empty((U, 1, C), device=dev)
+    N.check(lib.b2t_beam_reset(_p(b["state"]), U, b["L"], b["NN"], ops._stream()), "reset")
+    states, t_gru, t_all = None, [], []
+    with torch.no_grad():
+        for f in range(frames):
+            xf = x_all[:, f * STRIDE: f * STRIDE + PATCH].contiguous()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            logits, states = model(xf, day, states, True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            N.check(lib.b2t_lm_prologue_f32(_p(logits), _p(pri), float(np.log(90.0)), _p(lp), U, C, ops._stream()), "prologue")
+            _lm_search(lib, lp, 1, U, C, first, second, b, lm, d)
+            b["hl"][:, 0].cpu()
+            t_gru.append(t1 - t0); t_all.append(time.perf_counter() - t0)
+    g, a = np.array(t_gru[10:]) * 1e3, np.array(t_all[10:]) * 1e3
+    return dict(p50_ms_per_frame=round(float(np.percentile(a, 50)), 4), p95_ms_per_frame=round(float(np.percentile(a, 95)), 4),
+                gru_step_p50_ms=round(float(np.percentile(g, 50)), 4), fraction_of_real_time=round(float(np.percentile(a, 50)) / 80.0, 5),
+                workload=f"BASELINE configs[4]: {U} concurrent utterances, one 80 ms patch frame (14 x 20 ms bins, stride 4) per call: "
+                         f"GRU-768 x5 step with carried state -> prologue -> 5-gram ({lm.n_nodes} nodes) prefix beam {first}/{second} "
+                         "-> host reads the running best", dtype="f32")
+
+
+def all_secondary():
+    out = {}
+    for name, fn in (("c3_f32", lambda: train_ms("c3", False)), ("c3_amp", lambda: train_ms("c3", True)),
+                     ("c2_amp", lambda: train_ms("c2", True)), ("decode_beam100_3gram", decode_beam100_3gram),
+                     ("stream_32utt_5gram", stream_32utt_5gram)):
+        try:
+            out[name] = fn()
+        except Exception as e:   # a secondary number must never take the headline line down
+            out[name] = dict(error=f"{type(e).__name__}: {e}")
+        torch.cuda.synchronize()
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(all_secondary(), indent=1))
