@@ -54,13 +54,36 @@ ARGS = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=120000, lr_warmup_steps=
             epsilon=0.1, weight_decay=0.001, weight_decay_day=0, grad_norm_clip_value=10)
 
 
-def cpu_baseline(timed: int = 3):
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    machine's 256 hardware threads even inside a container that is scheduled on a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, q // int(g.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def cpu_baseline_worker(timed: int, budget_s: float):
     """the reference's step on PyTorch-CPU operators (oracle/torch_cpu_step.py: nn.GRU + einsum + conv1d +
     CTCLoss + AdamW, the operator sequence of rnn_trainer.py:527-558; pinned to tests/golden/train_step*.npz by
-    tests/test_oracle_golden.py), on the same C2 tensors, all host cores, 1 warm-up + `timed` steps."""
+    tests/test_oracle_golden.py), on the same C2 tensors: 1 warm-up + up to `timed` steps within `budget_s` seconds.
+    Thread count: the best of {usable cores, 64, 32, 16} on a short probe (T = 40) -- oneDNN's GRU gets slower, not
+    faster, when 256 threads share its [64 x 512] per-step products."""
     from oracle import torch_cpu_step as TC
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    t_start = time.perf_counter()
+    cores = usable_cores()
     torch.manual_seed(10)
     m = TC.CpuGRUDecoder(F, H, D, C, L, 0, 0)
     for n_, p_ in m.gru.named_parameters():      # the reference's init (rnn_model.py:75-79)
@@ -70,23 +93,58 @@ def cpu_baseline(timed: int = 3):
             torch.nn.init.xavier_uniform_(p_)
     tr = TC.CpuTrainer(m, dict(ARGS))
     x, days, labels, nts, lens = (t.cpu() for t in make_batch(1000, "cpu"))
+    days, labels, nts, lens = days.long(), labels.long(), nts.long(), lens.long()
+    probe = {}
+    for nt_ in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True):
+        torch.set_num_threads(nt_)
+        ts_ = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tr.step(x[:, :40].contiguous(), days, labels[:, :8].contiguous(), torch.full((B,), 40), torch.full((B,), 8))
+            ts_.append(time.perf_counter() - t0)
+        probe[nt_] = min(ts_)
+        if time.perf_counter() - t_start > 0.3 * budget_s:
+            break
+    threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(5)
-    times = []
+    times, loss = [], float("nan")
     for i in range(1 + timed):
         wn = torch.randn(B, T, F, generator=g); on = torch.randn(B, 1, F, generator=g)
         t0 = time.perf_counter()
-        loss, _ = tr.step(x, days.long(), labels.long(), nts.long(), lens.long(), white=wn, offset=on, cut=i % 3)
+        loss, _ = tr.step(x, days, labels, nts, lens, white=wn, offset=on, cut=i % 3)
         times.append(time.perf_counter() - t0)
-    dt = float(np.mean(times[1:]))
+        if i >= 1 and time.perf_counter() - t_start + times[-1] > budget_s:
+            break
+    timed_t = times[1:] if len(times) > 1 else times
+    dt = float(np.mean(timed_t))
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except (OSError, StopIteration):
         pass
-    return dict(value=round(B / dt, 3), unit="sentences/s", cores=cores, kind="torch-cpu", cpu=model,
-                sample=f"{timed} timed steps (after 1 warm-up) of the same workload (B={B}, T={T}, fp32) on PyTorch-CPU operators, "
-                       f"torch.set_num_threads({cores}); {dt:.2f} s/step, final loss {loss:.3f}")
+    return dict(value=round(B / dt, 3), unit="sentences/s", cores=threads, kind="torch-cpu", cpu=model,
+                cores_usable=cores, cores_reported=os.cpu_count(),
+                sample=f"{len(timed_t)} timed step(s) after {1 if len(times) > 1 else 0} warm-up of the same workload (B={B}, T={T}, fp32) on "
+                       f"PyTorch-CPU operators with {threads} threads (probe at T=40, s/step by thread count: "
+                       f"{ {k: round(v, 3) for k, v in probe.items()} }); {dt:.2f} s/step, final loss {loss:.3f}")
+
+
+def cpu_baseline(timed: int = 3, budget_s: float = 120.0):
+    """Runs cpu_baseline_worker in a child process with a hard wall-clock limit: the CPU leg can never hang the bench."""
+    import subprocess
+    code = ("import json, sys; sys.path.insert(0, %r); import bench; "
+            "print('CPUBASE ' + json.dumps(bench.cpu_baseline_worker(%d, %f)))" % (ROOT, timed, budget_s))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s + 90, cwd=ROOT)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPUBASE "):
+                return json.loads(line[8:])
+        return dict(value=None, unit="sentences/s", cores=usable_cores(), kind="torch-cpu", sample="failed: " + r.stderr[-300:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="sentences/s", cores=usable_cores(), kind="torch-cpu",
+                    sample=f"no result within {budget_s + 90:.0f} s on this host")
 
 
 def dry_run(a, world, rank):
@@ -254,12 +312,14 @@ def main():
                                gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),
                    host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
+        sys.stderr.write("[bench] headline done: " + json.dumps(out)[:200] + "\n"); sys.stderr.flush()
         if world == 1 and not a.no_secondary:
             # BASELINE configs[2..4] measured by the same process, reported beside (never instead of) the headline
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_secondary
             out["secondary"] = bench_secondary.all_secondary()
         if world == 1 and not a.no_cpu_baseline:
+            sys.stderr.write("[bench] cpu baseline ...\n"); sys.stderr.flush()
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -149,6 +149,7 @@ def all_secondary():
     for name, fn in (("c3_f32", lambda: train_ms("c3", False)), ("c3_amp", lambda: train_ms("c3", True)),
                      ("c2_amp", lambda: train_ms("c2", True)), ("decode_beam100_3gram", decode_beam100_3gram),
                      ("stream_32utt_5gram", stream_32utt_5gram)):
+        sys.stderr.write(f"[secondary] {name} ...\n"); sys.stderr.flush()
         try:
             out[name] = fn()
         except Exception as e:   # a secondary number must never take the headline line down
