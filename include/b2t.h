@@ -58,7 +58,8 @@ int b2t_augment_smooth_f32(const float* x, float* y, int B, int T, int F, int cu
  * Same for B with n.  C row m: rowoff_c(m), columns contiguous.
  * b_zmap (optional, int32[Z]): B batch index = b_zmap[z] (day-indexed weights, no gather copy:
  * replaces the torch.stack at rnn_model.py:95).
- * epilogue: 0 = none, 1 = softsign(v) (rnn_model.py:47,99).  accumulate: C += result. */
+ * epilogue: 0 = none, 1 = softsign(v) (rnn_model.py:47,99), 2 = v * (1 - |u|)^2 with u = ep_aux at C's index (the
+ * Softsign backward fused into the GEMM that produces the gradient wrt its output).  accumulate: C += result. */
 typedef struct b2t_gemm_desc {
   const float* A; const float* B; float* C; const float* bias;
   int M, N, K, Z;
@@ -76,6 +77,7 @@ typedef struct b2t_gemm_desc {
    * Lets dGi = dG[:, 0:2H] ++ dG[:, 3H:4H] be ONE operand (a_brk = 2H, a_gap = H).  a_brk = 0: off; must be a
    * multiple of 16 (k) / 128 (m, with M % 128 == 0). */
   int a_brk; int a_gap;
+  const float* ep_aux;   /* epilogue 2 only: same layout as C (z*c_sz + row offset + column) */
 } b2t_gemm_desc;
 int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream);
 /* The same GEMM with the operands rounded to bf16 (nearest-even) on their way to the matrix cores, fp32 accumulation and

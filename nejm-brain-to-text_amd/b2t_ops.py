@@ -263,9 +263,16 @@ GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup (bf16 operands 
 AMP["wide"] = os.environ.get("B2T_AMP_WIDE", "fb")
 
 
+# exact-fp32 sweeps with 32 hidden units per workgroup (the fp32 weight slice of 32 units takes 192 of a lane's 512
+# registers, one workgroup per CU): "" none, "f" forward, "b" backward, "fb" both (B2T_WIDE_F32)
+WIDE_F32 = {"dirs": os.environ.get("B2T_WIDE_F32", "f")}   # measured at C2: forward 23.9 -> 23.3 ms per step, backward no gain
+
+
 def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
     """`mode` argument of b2t_gru_layer_fwd/bwd_f32: under set_amp(True) the persistent sweeps take bf16 operands."""
     if not (AMP["on"] and AMP.get("sweeps", True) and mode == 1):
+        if mode == 1 and direction in WIDE_F32["dirs"] and H % 32 == 0 and H <= 512:
+            return mode | GRU_WIDE
         return mode
     wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= 512) else 0   # (LDS staging of H > 512 exceeds 64 KB)
     return mode | GRU_BF16 | wide

@@ -197,10 +197,10 @@ class TrainStep:
             day_dev = day_idx.to(dtype=torch.int32).contiguous()
         else:   # pageable H2D copies block the host until the stream drains: stage through pinned memory
             day_dev = day_idx.to(torch.int32).pin_memory().to(dev, non_blocking=True)
-        adj = self.adjusted_lens(n_time_steps.to(dev))
         logits, hidden, ctx = ops.model_forward(model._dims, model._kernel_params(), feats, day_dev, None, model._ws,
                                                 save=True, in_drop=model._p_in(), rnn_drop=model._p_rnn(),
                                                 seed=model._next_seed(), reuse_saved=True)
+        adj = self.adjusted_lens(n_time_steps.to(dev))   # (small torch kernels: behind the forward, only the CTC needs them)
         loss_b, dl, ldd = ops.ctc_loss(logits, targets, adj, phone_seq_lens, True, 1.0 / (B * self.world), model._ws)
         N.check(lib.b2t_opt_prepare(ops._p(day_dev), B, ops._p(self.seg_day), self.nseg, ops._p(self.active), st),
                 "b2t_opt_prepare")

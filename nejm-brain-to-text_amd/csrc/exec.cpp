@@ -482,21 +482,32 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   }
 
   // dIn = dGi W_ih for rows of chunk [t0, t0+n): into dY[l-1] (l > 0) or dU / dV (l == 0).
-  // dGi = dG[:, 0:2H] ++ dG[:, 3H:4H] is one A operand with a gap (a_brk / a_gap), K = 3H
+  // Day-layer backward chunk by chunk (no patching, no input dropout): the Softsign backward rides in the epilogue of
+  // layer 0's dX GEMM, the per-sample day-gradient GEMM and bias sums accumulate chunk after chunk behind it, so that
+  // only the last chunk's share is left behind the last backward sweep (it was 1.4 ms of tail as whole-sequence passes).
+  const bool fast_day = prm->patch == 0 && !(p->in_drop > 0.f);
+  const long long bias_ld = (long long)align_up(F, 4);
   auto dx_gemm = [&](hipStream_t s, int l, int t0, int n) {
-    const long long a_off = (long long)t0 * B * 4 * H;
-    const bool gap = (2 * H) % 16 == 0;
+    // dGi = dG[:, 0:2H] ++ dG[:, 3H:4H] is ONE A operand with a gap at k = 2H (H % 16 == 0 makes 2H a multiple of the k tile)
     const int N = l > 0 ? H : In0;
-    auto one = [&](int K, long long a_extra, long long b_off, int brk, int g, int acc) {
-      b2t_gemm_desc d = gd(w.dG[l] + a_off + a_extra, prm->w_ih[l] + b_off, nullptr, n * B, N, K);
-      d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = N; d.a_brk = brk; d.a_gap = g;
-      if (l > 0) { d.C = w.dY[l - 1] + (long long)t0 * B * H; d.c_s0 = H; }
-      else if (prm->patch > 0) { d.C = w.dV + (long long)t0 * In0; d.c_div = B; d.c_s1 = In0; d.c_s0 = (long long)Tp * In0; }
-      else { d.C = w.dU + (long long)t0 * F; d.c_div = B; d.c_s1 = F; d.c_s0 = (long long)T * F; }
-      c.gemm(s, d, 1, nullptr, acc);
-    };
-    if (gap) one(3 * H, 0, 0, 2 * H, H, 0);
-    else { one(2 * H, 0, 0, 0, 0, 0); one(H, 3 * H, (long long)2 * H * N, 0, 0, 1); }
+    b2t_gemm_desc d = gd(w.dG[l] + (long long)t0 * B * 4 * H, prm->w_ih[l], nullptr, n * B, N, 3 * H);
+    d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = N; d.a_brk = 2 * H; d.a_gap = H;
+    if (l > 0) { d.C = w.dY[l - 1] + (long long)t0 * B * H; d.c_s0 = H; }
+    else if (prm->patch > 0) { d.C = w.dV + (long long)t0 * In0; d.c_div = B; d.c_s1 = In0; d.c_s0 = (long long)Tp * In0; }
+    else {
+      d.C = w.dU + (long long)t0 * F; d.c_div = B; d.c_s1 = F; d.c_s0 = (long long)T * F;
+      if (fast_day) { d.epilogue = 2; d.ep_aux = w.U + (long long)t0 * F; }   // dpre = dU * (1 - |U|)^2
+    }
+    c.gemm(s, d);
+    if (l == 0 && fast_day) {
+      const int first = t0 + n == Tp ? 0 : 1;   // the top time chunk is swept first: it overwrites, the others accumulate
+      b2t_gemm_desc d = gd(x + (long long)t0 * F, w.dU + (long long)t0 * F, w.day_slab, F, F, n);
+      d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;
+      d.c_s0 = F; d.c_sz = (long long)F * F;
+      c.gemm(s, d, 1, nullptr, first);
+      c.call(b2t_colsum_f32(w.dU + (long long)t0 * F, n, F, F, w.day_bslab, first, w.cs_day, B, (long long)T * F, bias_ld,
+                            reinterpret_cast<void*>(s)));
+    }
   };
 
   hipEvent_t ev_dx[MAXL][MAXC] = {}, ev_bs[MAXL][MAXC] = {};
@@ -544,20 +555,19 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   {
     hipStream_t s = piped ? ex->s_gemm[0] : main;
     void* sp = reinterpret_cast<void*>(s);
-    if (prm->patch > 0) c.call(b2t_patch_fold_f32(w.dV, w.dU, B, T, F, Tp, prm->patch, prm->stride, sp));
-    if (p->in_drop > 0.f) c.call(b2t_dropout_f32(w.dU, w.dU, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, sp));
-    c.call(b2t_softsign_bwd_f32(w.U, w.dU, (long long)B * T * F, sp));   // dpre = dU * (1-|U|)^2, in place
-    // per-sample partial day gradients, then deterministic reduction by day
-    {
+    if (!fast_day) {
+      if (prm->patch > 0) c.call(b2t_patch_fold_f32(w.dV, w.dU, B, T, F, Tp, prm->patch, prm->stride, sp));
+      if (p->in_drop > 0.f) c.call(b2t_dropout_f32(w.dU, w.dU, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, sp));
+      c.call(b2t_softsign_bwd_f32(w.U, w.dU, (long long)B * T * F, sp));   // dpre = dU * (1-|U|)^2, in place
+      // per-sample partial day gradients, then deterministic reduction by day
       b2t_gemm_desc d = gd(x, w.dU, w.day_slab, F, F, T);
       d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;
       d.c_s0 = F; d.c_sz = (long long)F * F;
       c.gemm(s, d);
+      c.call(b2t_colsum_f32(w.dU, T, F, F, w.day_bslab, 0, w.cs_day, B, (long long)T * F, bias_ld, sp));
     }
     c.call(b2t_day_reduce_f32(w.day_slab, day_idx, B, (long long)F * F, grd->day_w, grd->day_w_stride, sp));
-    const long long bs = (long long)align_up(F, 4);
-    c.call(b2t_colsum_f32(w.dU, T, F, F, w.day_bslab, 0, w.cs_day, B, (long long)T * F, bs, sp));
-    c.call(b2t_day_reduce_f32(w.day_bslab, day_idx, B, bs, grd->day_b, grd->day_b_stride, sp));
+    c.call(b2t_day_reduce_f32(w.day_bslab, day_idx, B, bias_ld, grd->day_b, grd->day_b_stride, sp));
     cb(L + 2, s);
   }
   // h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)

@@ -14,6 +14,7 @@ struct GemmArgs {
   int epilogue; int accumulate;
   int splitk; int kchunk; long long c_ks;
   int a_brk; int a_gap;   // contiguous index i of A (k if a_kcontig, else m): i >= a_brk reads from i + a_gap
+  const float* ep_aux;    // epilogue 2: u, laid out like C
 };
 
 __device__ __forceinline__ long long rowoff(int i, long long s0, long long s1, int div) {
@@ -35,6 +36,8 @@ inline int fill_gemm_args(const b2t_gemm_desc* d, GemmArgs& g, int bk, int bm, c
   g.kchunk = ((d->K + g.splitk - 1) / g.splitk + bk - 1) / bk * bk;
   g.c_ks = d->c_ks;
   g.a_brk = d->a_brk; g.a_gap = d->a_gap;
+  g.ep_aux = d->ep_aux;
+  B2T_REQUIRE(d->epilogue != 2 || d->ep_aux != nullptr, "%s: epilogue 2 needs ep_aux", name);
   B2T_REQUIRE(d->a_brk == 0 || (d->a_brk > 0 && d->a_gap % 4 == 0 &&
                                 (d->a_kcontig ? d->a_brk % bk == 0 : (d->a_brk % bm == 0 && d->M % bm == 0))),
               "%s: a_brk must be a multiple of the tile extent (%d along k, %d along m with M %% %d == 0), a_gap of 4", name, bk, bm, bm);

@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs g) {
         if (row < g.M) {
           float v = acc[i][j][e] + bv;
           if (g.epilogue == 1) v = v / (1.0f + fabsf(v));
-          float* p = C + rowoff(row, g.c_s0, g.c_s1, g.c_div) + col;
+          const long long coff = rowoff(row, g.c_s0, g.c_s1, g.c_div) + col;
+          if (g.epilogue == 2) { const float a = 1.0f - fabsf(g.ep_aux[(long long)z * g.c_sz + coff]); v *= a * a; }   // softsign backward
+          float* p = C + coff;
           if (g.accumulate) v += *p;
           *p = v;
         }

@@ -32,13 +32,12 @@ namespace b2t {
 // NT: 16-unit tiles per workgroup (1, or 2 with bf16 operands, whose weight slice is half the registers): 32 units per
 // workgroup halve the workgroups of a sweep -- five concurrent sweeps then crowd the CUs half as much.
 template <int NCH, bool BF16, int NT = 1>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
-__global__ __launch_bounds__(256, (NT == 2 ? 2 : (NCH <= 8 ? 3 : 1))) void gru_persist_fwd_kernel(const float* __restrict__ gi,
+__global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1))) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
                                                                  float* __restrict__ reserve, int T, int B, int H,
                                                                  unsigned* sync) {
-  static_assert(NT == 1 || BF16, "two tiles per workgroup need the bf16 weight slice");
   constexpr int TPN = 16 * NT + 4;    // LDS pitch of the staged tile (= TP for one tile)
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * NT * 4 * 64 + 16 * TPN];
   __shared__ __attribute__((aligned(16))) float stage[4][NCH * SLOT_F];   // per-wave operand staging (gru_sync.h)
@@ -207,7 +206,6 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  const float* __restrict__ w_hh_t, float* dG,
                                                                  float* __restrict__ dh_init, int T, int B, int H,
                                                                  unsigned* sync) {
-  static_assert(NT == 1 || BF16, "two tiles per workgroup need the bf16 weight slice");
   constexpr int TPN = 16 * NT + 4;
   __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64 + 4 * 16 * TPN];
   constexpr int NSLOT = NCB < 8 ? NCB : 8;   // staging slots per wave, recycled every NSLOT instructions
@@ -395,7 +393,7 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
                        bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
-  if (wide && (!bf16 || (H % 32) != 0 || H > 512)) { set_error("gru_layer_fwd: 32-unit workgroups need bf16 operands, H %% 32 == 0 and H <= 512"); return 2; }
+  if (wide && ((H % 32) != 0 || H > 512)) { set_error("gru_layer_fwd: 32-unit workgroups need H %% 32 == 0 and H <= 512"); return 2; }
   const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
@@ -404,6 +402,12 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
       want_exclusive(gru_persist_fwd_kernel<NCH, true, 2>);                                                            \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
                          B, H, sync);                                                                              \
+    } else if (wide) {                                                                                                 \
+      if constexpr (NCH <= 8) {                                                                                        \
+        want_exclusive(gru_persist_fwd_kernel<NCH, false, 2>);                                                         \
+        hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                           B, H, sync);                                                                                \
+      }                                                                                                                \
     } else if (bf16) {                                                                                                 \
       want_exclusive(gru_persist_fwd_kernel<NCH, true>);                                                               \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
@@ -429,7 +433,7 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
                        void* sync_ws, hipStream_t s, bool bf16, bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
-  if (wide && (!bf16 || (H % 32) != 0 || H > 512)) { set_error("gru_layer_bwd: 32-unit workgroups need bf16 operands, H %% 32 == 0 and H <= 512"); return 2; }
+  if (wide && ((H % 32) != 0 || H > 512)) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512"); return 2; }
   const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
@@ -438,6 +442,12 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
       want_exclusive(gru_persist_bwd_kernel<NCB, true, 2>);                                                           \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
                          w_hh_t, dG, dh_init, T, B, H, sync);                                                     \
+    } else if (wide) {                                                                                                \
+      if constexpr (NCB <= 24) {                                                                                      \
+        want_exclusive(gru_persist_bwd_kernel<NCB, false, 2>);                                                        \
+        hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
+                           w_hh_t, dG, dh_init, T, B, H, sync);                                                       \
+      }                                                                                                               \
     } else if (bf16) {                                                                                                \
       want_exclusive(gru_persist_bwd_kernel<NCB, true>);                                                              \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \

@@ -501,8 +501,9 @@ def test_train_step_modes_vs_oracle(mode):
         ops.GRU_MODE["value"] = old
 
 
-@pytest.mark.parametrize("B,H,T", [(5, 48, 9), (17, 80, 13), (33, 272, 11), (64, 512, 24), (70, 768, 7)])
-def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T):
+@pytest.mark.parametrize("B,H,T,wide", [(5, 48, 9, 0), (17, 80, 13, 0), (33, 272, 11, 0), (64, 512, 24, 0), (70, 768, 7, 0),
+                                         (64, 512, 24, 1), (23, 96, 7, 1), (40, 288, 9, 1)])
+def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T, wide):
     """Persistent sweeps (line-wise operand loads + LDS transpose, clamped rows / columns) against the step-launch
     kernels on shapes that are not multiples of the tile sizes: forward out / reserve, backward dG / dh0."""
     import b2t_native as Nn
@@ -529,6 +530,6 @@ def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T):
 
     ref = run(0)
     for rep in range(3):
-        got = run(1)
+        got = run(1 | (ops.GRU_WIDE if wide else 0))   # wide: 32 hidden units per workgroup, exact fp32
         for a, r, name in zip(got, ref, ("out", "reserve", "dG", "dh0")):
             np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=3e-6 * max(1.0, float(r.abs().max())), err_msg=name)
