@@ -329,6 +329,56 @@ int b2t_prefix_beam_search_lex_f32(const float* logp, const int32_t* lens, int U
                                    int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
                                    const b2t_lexlm_t* d, float* lm_score, void* stream);
 
+/* ---- a15/a16: WFST token passing (the reference's LM decode proper) ---------------------------------------------------
+ * CtcWfstBeamSearch::Search / FinalizeSearch (language_model/runtime/core/decoder/ctc_wfst_beam_search.cc:70-160) over
+ * kaldi's LatticeFasterDecoder (language_model/runtime/core/kaldi/decoder/lattice-faster-decoder.cc: ProcessEmitting
+ * :722-824, ProcessNonemitting :839-909, GetCutoff :650-720, FindOrAddToken :250-295, FinalizeDecoding :632-647), batched:
+ * one workgroup per utterance, the decode graph (T o L o G, nejm-brain-to-text_amd/wfst.py) in device memory as CSR arrays
+ * shared by all utterances, each frame's token hash in LDS, tokens and forward links appended to the utterance's state
+ * block (U * b2t_wfst_state_bytes bytes; persists between calls: logp may be fed chunk by chunk).
+ * Graph arrays: row [n_states + 1], arcs sorted by ilabel within a state (input-epsilon arcs first, n_eps[s] of them);
+ * ilabel 0 = epsilon, ilabel i > 0 reads acoustic_scale * logp[i - 1] (DecodableTensorScaled, :27-33); final_cost +inf =
+ * not final.  Options: LatticeFasterDecoderConfig + CtcWfstBeamSearchOptions (production values:
+ * language-model-standalone.py:486-496 -- beam 17, max_active 7000, min_active 200, lattice_beam 8, acoustic_scale
+ * 0.325, blank_skip_thresh 1.0); max_frames / max_tokens / max_links / hash_size (power of two; <= 8192 keeps the hash in
+ * LDS) are per-utterance capacities -- exhaustion sets the overflow word (header word 3) and invalidates the result. */
+typedef struct {
+  const int32_t* row; const int32_t* ilabel; const int32_t* olabel; const float* weight; const int32_t* next;
+  const int32_t* n_eps; const float* final_cost; int32_t n_states, start;
+} b2t_wfst_graph_t;
+typedef struct {
+  float beam, lattice_beam, beam_delta, acoustic_scale, length_penalty, blank_skip_thresh;
+  int32_t max_active, min_active;
+  int32_t max_frames, max_tokens, max_links, hash_size;
+} b2t_wfst_opts_t;
+size_t b2t_wfst_state_bytes(int max_frames, int max_tokens, int max_links, int hash_size);
+int b2t_wfst_reset(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream);   /* InitDecoding */
+/* logp [U][T][C] (C <= 64), lens [U] or NULL: blank-frame skipping + AdvanceDecoding(.., 1) per kept frame */
+int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, const float* logp,
+                        const int32_t* lens, int U, int T, int C, void* stream);
+/* Best path by backpointers (lattice-faster-online-decoder.cc:58-150): alignment [U][max_len] (graph ilabels) with the
+ * input frame of each entry, words [U][max_len] (olabels), costs [U][2] = {graph (+ final), acoustic}.
+ * use_final = 0: partial result (Search's GetBestPath(.., false)); 1: after b2t_wfst_finalize. */
+int b2t_wfst_best_path(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, const void* state, int U, int use_final,
+                       int max_len, int32_t* alignment, int32_t* align_frame, int32_t* n_align, int32_t* words,
+                       int32_t* n_words, float* costs, void* stream);
+/* FinalizeDecoding: final costs + backward pruning with lattice_beam; marks the surviving forward links. */
+int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream);
+/* Byte offsets of the arrays inside ONE utterance's state block, for copying the pruned lattice out:
+ * off16 = {header, mapping, tok_off, link_off, cost_offset, tok_state, tok_cost (order-preserving u32 of the f32 cost),
+ * tok_extra, link_src, link_dst, link_arc, link_ac, link_graph, link_alive (u8), tok_best, last_prob}. */
+int b2t_wfst_state_offsets(int max_frames, int max_tokens, int max_links, int hash_size, long long* off16);
+/* HOST function: the n-best distinct word sequences of a pruned lattice (what GetLattice's DeterminizeLatticePruned +
+ * ShortestPath(nbest) yield, ctc_wfst_beam_search.cc:138-143): arcs (src, dst, ilabel, olabel, graph, acoustic) over
+ * n_states lattice states, finals (state, cost).  Outputs: for entry k the words out_words[w_off[k] .. w_off[k+1]), the
+ * alignment out_ali[a_off[k] .. a_off[k+1]) (ilabels of its best path) and costs[2k] = graph (+ final), costs[2k+1] =
+ * acoustic.  Returns the number of entries (<= nbest), < 0 on error (buffers too small: -2). */
+int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
+                           const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
+                           int n_final, const int32_t* final_state, const float* final_cost, int nbest, float beam,
+                           int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
+                           float* costs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,18 @@ class PassDesc(C.Structure):
 BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 
+class WfstGraph(C.Structure):
+    """Mirror of b2t_wfst_graph_t (include/b2t.h)."""
+    _fields_ = [(n, VP) for n in ("row", "ilabel", "olabel", "weight", "next", "n_eps", "final_cost")] + \
+               [("n_states", C.c_int32), ("start", C.c_int32)]
+
+
+class WfstOpts(C.Structure):
+    """Mirror of b2t_wfst_opts_t (include/b2t.h)."""
+    _fields_ = [(n, C.c_float) for n in ("beam", "lattice_beam", "beam_delta", "acoustic_scale", "length_penalty", "blank_skip_thresh")] + \
+               [(n, C.c_int32) for n in ("max_active", "min_active", "max_frames", "max_tokens", "max_links", "hash_size")]
+
+
 class LexLmDesc(C.Structure):
     """Mirror of b2t_lexlm_t (include/b2t.h)."""
     _fields_ = [(n, VP) for n in ("lex_child", "lex_wbeg", "lex_wend", "wlist", "lm_cb", "lm_ce", "lm_ctok", "lm_cnode",
@@ -115,6 +127,15 @@ _SIGNATURES = {
                                 C.POINTER(C.c_float), C.c_double, C.c_double, C.c_float, VP]),
     "b2t_greedy_decode_f32": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_edit_distance_i32": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, VP, C.c_int, VP]),
+    "b2t_wfst_state_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "b2t_wfst_reset": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, VP]),
+    "b2t_wfst_search_f32": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "b2t_wfst_best_path": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP,
+                                    VP, VP, VP]),
+    "b2t_wfst_finalize": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, VP]),
+    "b2t_wfst_state_offsets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LL)]),
+    "b2t_lattice_nbest_host": (C.c_int, [C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, C.c_int, VP, VP, C.c_int,
+                                         C.c_float, VP, VP, C.c_int, VP, VP, C.c_int, VP]),
     "b2t_lm_prologue_f32": (C.c_int, [VP, VP, C.c_float, VP, C.c_int, C.c_int, VP]),
     "b2t_beam_state_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "b2t_beam_reset": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),

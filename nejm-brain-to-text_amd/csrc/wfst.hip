@@ -1,0 +1,651 @@
+// wfst.hip — batched WFST token passing for gfx950: the search inner loop of the reference's LM decoder
+// (language_model/runtime/core/kaldi/decoder/lattice-faster-decoder.cc: ProcessEmitting :722-824, ProcessNonemitting
+// :839-909, GetCutoff :650-720, FindOrAddToken :250-295, PruneForwardLinks(Final) :297-470) under the frame loop of
+// CtcWfstBeamSearch::Search (language_model/runtime/core/decoder/ctc_wfst_beam_search.cc:70-121).
+//
+// One workgroup per utterance; the decode graph (T o L o G as CSR arcs: nejm-brain-to-text_amd/wfst.py) lives in HBM and is
+// shared by all utterances; a frame's token hash (state -> token) lives in LDS when it fits (<= 8192 slots), tokens and
+// forward links of every frame are appended to the utterance's state block in HBM (they ARE the lattice).
+//
+// What is data-parallel here and sequential in the reference:
+//   * ProcessEmitting tightens `next_cutoff` while it walks the token list, so which over-the-cutoff dead-end tokens get
+//     created depends on hash-list order.  Here the frame's minimum candidate cost is reduced first and every candidate
+//     below min + adaptive_beam is kept -- the reference's FINAL cutoff.  Tokens the reference creates beyond it are never
+//     expanded (ProcessNonemitting and the next frame's cutoff skip them) and disappear in FinalizeDecoding, so the
+//     pruned lattice, best path and n-best are the same.  (Only GetCutoff's max_active / min_active COUNTS can see such
+//     tokens: a difference exists only while max_active binds in consecutive frames.)
+//   * ProcessNonemitting's work queue becomes Bellman-Ford sweeps over the frame's tokens until no cost changes; forward
+//     links are generated once, after convergence, with the final costs (what the queue leaves behind).
+//   * PruneActiveTokens every prune_interval frames is a memory optimisation (it only removes what FinalizeDecoding would
+//     remove as well: its extra_costs are lower bounds); here pruning runs once, in b2t_wfst_finalize.
+#include <float.h>
+#include "common.h"
+
+namespace b2t {
+namespace {
+
+constexpr int NT = 256;
+constexpr unsigned UMAX = 0xffffffffu;
+constexpr int MAX_C = 64;
+
+struct Graph {
+  const int* row; const int* ilabel; const int* olabel; const float* weight; const int* next; const int* n_eps;
+  const float* final_cost; int start;
+};
+
+// state block of one utterance (HBM), carved by layout(): header words then arrays
+struct Hdr {
+  int n_frames;        // decoded frames (emitting steps taken)
+  int n_tok;           // tokens so far (all frames)
+  int n_link;          // links so far
+  int overflow;        // capacity exhausted (tokens / links / hash / frames): results invalid
+  int num_input;       // input frames seen (incl. skipped ones)
+  int is_last_blank, last_best;
+  int finalized;
+  float final_best;    // best (cost + final cost) on the last frame
+  int has_final;
+  int pad[6];
+};
+
+struct Lay {
+  Hdr* h; float* last_prob; int* mapping; int* tok_off; int* link_off; float* cost_offset;
+  int* tok_state; unsigned* tok_cost; int* tok_best; unsigned* tok_extra; unsigned* tok_prev;
+  int* link_src; int* link_dst; int* link_arc; float* link_ac; float* link_graph; unsigned char* link_alive;
+  int* gkey; int* gidx;
+};
+
+__host__ __device__ inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+__host__ __device__ inline size_t layout(char* base, int max_frames, int max_tok, int max_link, int hash, Lay* l) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
+  Hdr* h = reinterpret_cast<Hdr*>(take(sizeof(Hdr)));
+  float* lp = reinterpret_cast<float*>(take(sizeof(float) * MAX_C));
+  int* mp = reinterpret_cast<int*>(take(sizeof(int) * (max_frames + 1)));
+  int* to = reinterpret_cast<int*>(take(sizeof(int) * (max_frames + 3)));
+  int* lo = reinterpret_cast<int*>(take(sizeof(int) * 2 * (max_frames + 3)));
+  float* co = reinterpret_cast<float*>(take(sizeof(float) * (max_frames + 1)));
+  int* ts = reinterpret_cast<int*>(take(sizeof(int) * max_tok));
+  unsigned* tc = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * max_tok));
+  int* tb = reinterpret_cast<int*>(take(sizeof(int) * max_tok));
+  unsigned* te = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * max_tok));
+  unsigned* tp = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * max_tok));
+  int* ls = reinterpret_cast<int*>(take(sizeof(int) * max_link));
+  int* ld = reinterpret_cast<int*>(take(sizeof(int) * max_link));
+  int* la = reinterpret_cast<int*>(take(sizeof(int) * max_link));
+  float* lac = reinterpret_cast<float*>(take(sizeof(float) * max_link));
+  float* lg = reinterpret_cast<float*>(take(sizeof(float) * max_link));
+  unsigned char* lv = reinterpret_cast<unsigned char*>(take(max_link));
+  int* gk = reinterpret_cast<int*>(take(sizeof(int) * hash));
+  int* gi = reinterpret_cast<int*>(take(sizeof(int) * hash));
+  if (l) *l = Lay{h, lp, mp, to, lo, co, ts, tc, tb, te, tp, ls, ld, la, lac, lg, lv, gk, gi};
+  return o;
+}
+
+// order-preserving float <-> unsigned (atomicMin on costs)
+__device__ __forceinline__ unsigned f2o(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float o2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+struct Opts {
+  float beam, lattice_beam, beam_delta, acoustic_scale, length_penalty, blank_skip_thresh;
+  int max_active, min_active;
+};
+
+struct Ctx {
+  Graph g; Lay l; Opts o;
+  int max_frames, max_tok, max_link, hash;
+  int* key; int* idx;          // the frame's hash (LDS or HBM)
+  float* ll;                   // LDS: acoustic_scale * logp of the frame
+  float* redf; int* redi;      // LDS reduction scratch [NT]
+  int* sh;                     // LDS scalars: [0] n_tok, [1] n_link, [2] changed, [3] overflow
+};
+
+__device__ __forceinline__ float block_min(Ctx& c, float v) {
+  c.redf[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) c.redf[threadIdx.x] = fminf(c.redf[threadIdx.x], c.redf[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const float r = c.redf[0];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ int block_sum(Ctx& c, int v) {
+  c.redi[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) c.redi[threadIdx.x] += c.redi[threadIdx.x + s];
+    __syncthreads();
+  }
+  const int r = c.redi[0];
+  __syncthreads();
+  return r;
+}
+
+// k-th smallest (0-based) of the ordered cost keys of tokens [t0, t1): bisection on the key bits (std::nth_element's value)
+__device__ float kth_cost(Ctx& c, int t0, int t1, int k) {
+  unsigned lo = 0u, hi = UMAX;
+  while (lo < hi) {
+    const unsigned mid = lo + (hi - lo) / 2u;
+    int cnt = 0;
+    for (int t = t0 + threadIdx.x; t < t1; t += NT) cnt += (c.l.tok_cost[t] <= mid);
+    cnt = block_sum(c, cnt);
+    if (cnt >= k + 1) hi = mid; else lo = mid + 1u;
+  }
+  return o2f(lo);
+}
+
+__device__ __forceinline__ unsigned hash_of(int state, int mask) { return ((unsigned)state * 2654435761u) & (unsigned)mask; }
+
+// FindOrAddToken, claim phase: make sure `state` has a slot (and a token) in the frame being built
+__device__ __forceinline__ void claim(Ctx& c, int state) {
+  const int mask = c.hash - 1;
+  unsigned s = hash_of(state, mask);
+  for (int probe = 0; probe < c.hash; ++probe, s = (s + 1) & mask) {
+    const int k = __hip_atomic_load(&c.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k == state) return;
+    if (k == -1) {
+      int expected = -1;
+      if (__hip_atomic_compare_exchange_strong(&c.key[s], &expected, state, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        const int id = atomicAdd(&c.sh[0], 1);
+        if (id < c.max_tok) {
+          c.idx[s] = id;
+          c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = 0x7fffffff; c.l.tok_extra[id] = 0u;
+        } else {
+          c.idx[s] = -1; c.sh[3] = 1;
+        }
+        return;
+      }
+      if (expected == state) return;
+    }
+  }
+  c.sh[3] = 1;   // hash full
+}
+__device__ __forceinline__ int find(Ctx& c, int state) {
+  const int mask = c.hash - 1;
+  unsigned s = hash_of(state, mask);
+  for (int probe = 0; probe < c.hash; ++probe, s = (s + 1) & mask) {
+    const int k = c.key[s];
+    if (k == state) return c.idx[s];
+    if (k == -1) return -1;
+  }
+  return -1;
+}
+
+// ProcessNonemitting over the tokens [n0, ...) of the frame being built + generation of their epsilon links
+__device__ void nonemitting(Ctx& c, int n0, float cutoff) {
+  const Graph& g = c.g;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) c.sh[2] = 0;
+    __syncthreads();
+    const int n_now = min(c.sh[0], c.max_tok);
+    for (int phase = 0; phase < 2; ++phase) {
+      for (int t = n0 + threadIdx.x; t < n_now; t += NT) {
+        const int s = c.l.tok_state[t];
+        const int ne = g.n_eps[s];
+        if (ne == 0) continue;
+        const float cur = o2f(c.l.tok_cost[t]);
+        if (!(cur < cutoff)) continue;
+        const int a0 = g.row[s];
+        for (int a = a0; a < a0 + ne; ++a) {
+          const float tot = cur + g.weight[a];
+          if (tot < cutoff) {
+            if (phase == 0) {
+              claim(c, g.next[a]);
+            } else {
+              const int id = find(c, g.next[a]);
+              if (id >= 0) {
+                const unsigned nb = f2o(tot);
+                const unsigned old = atomicMin(&c.l.tok_cost[id], nb);
+                if (nb < old) c.sh[2] = 1;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (c.sh[2] == 0) break;
+  }
+  // forward links of the epsilon arcs, with the converged costs
+  const int n_now = min(c.sh[0], c.max_tok);
+  for (int t = n0 + threadIdx.x; t < n_now; t += NT) {
+    const int s = c.l.tok_state[t];
+    const int ne = g.n_eps[s];
+    if (ne == 0) continue;
+    const float cur = o2f(c.l.tok_cost[t]);
+    if (!(cur < cutoff)) continue;
+    const int a0 = g.row[s];
+    for (int a = a0; a < a0 + ne; ++a) {
+      const float tot = cur + g.weight[a];
+      if (tot < cutoff) {
+        const int id = find(c, g.next[a]);
+        if (id < 0) continue;
+        const int li = atomicAdd(&c.sh[1], 1);
+        if (li < c.max_link) {
+          c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = 0.f; c.l.link_graph[li] = g.weight[a];
+        } else {
+          c.sh[3] = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// backpointers: among the links into the tokens of the new frame, the one whose cost equals the token's final cost
+__device__ void best_links(Ctx& c, int l0, int l1) {
+  for (int li = l0 + threadIdx.x; li < l1; li += NT) {
+    const int src = c.l.link_src[li], dst = c.l.link_dst[li];
+    const float tot = o2f(c.l.tok_cost[src]) + c.l.link_ac[li] + c.l.link_graph[li];
+    if (f2o(tot) == c.l.tok_cost[dst]) atomicMin(&c.l.tok_best[dst], li);
+  }
+  __syncthreads();
+}
+
+__device__ void clear_hash(Ctx& c) {
+  for (int i = threadIdx.x; i < c.hash; i += NT) c.key[i] = -1;
+  __syncthreads();
+}
+
+// InitDecoding (:57-75)
+__device__ void init_decoding(Ctx& c) {
+  clear_hash(c);
+  if (threadIdx.x == 0) {
+    Hdr* h = c.l.h;
+    h->n_frames = 0; h->overflow = 0; h->num_input = 0; h->is_last_blank = 0; h->last_best = 0; h->finalized = 0;
+    h->final_best = 0.f; h->has_final = 0;
+    c.sh[0] = 0; c.sh[1] = 0; c.sh[3] = 0;
+    c.l.tok_off[0] = 0;
+    c.l.link_off[0] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) claim(c, c.g.start);
+  __syncthreads();
+  if (threadIdx.x == 0) { c.l.tok_cost[0] = f2o(0.f); c.l.tok_best[0] = -1; }
+  __syncthreads();
+  nonemitting(c, 0, c.o.beam);
+  best_links(c, 0, min(c.sh[1], c.max_link));
+  if (threadIdx.x == 0) {
+    c.l.tok_best[0] = -1;
+    c.l.tok_off[1] = min(c.sh[0], c.max_tok);
+    c.l.link_off[1] = min(c.sh[1], c.max_link);    // [eps links of frame 0]
+    c.l.h->n_tok = c.sh[0]; c.l.h->n_link = c.sh[1]; c.l.h->overflow = c.sh[3];
+  }
+  __syncthreads();
+}
+
+// one AdvanceDecoding(.., 1): ProcessEmitting + ProcessNonemitting on the row `logp` (already in c.ll, scaled)
+__device__ void advance(Ctx& c) {
+  const Graph& g = c.g;
+  const int f = c.l.h->n_frames;
+  if (f >= c.max_frames) { if (threadIdx.x == 0) c.sh[3] = 1; __syncthreads(); return; }
+  const int t0 = c.l.tok_off[f], t1 = c.l.tok_off[f + 1];
+  // ---- GetCutoff (:650-720)
+  float best = INFINITY;
+  for (int t = t0 + threadIdx.x; t < t1; t += NT) best = fminf(best, o2f(c.l.tok_cost[t]));
+  best = block_min(c, best);
+  const int n = t1 - t0;
+  const float beam_cutoff = best + c.o.beam;
+  float cur_cutoff = beam_cutoff, adaptive = c.o.beam;
+  {
+    float max_cut = INFINITY, min_cut = INFINITY;
+    if (n > c.o.max_active) max_cut = kth_cost(c, t0, t1, c.o.max_active);
+    if (max_cut < beam_cutoff) {
+      cur_cutoff = max_cut; adaptive = max_cut - best + c.o.beam_delta;
+    } else {
+      if (n > c.o.min_active) min_cut = c.o.min_active == 0 ? best : kth_cost(c, t0, t1, c.o.min_active);
+      if (min_cut > beam_cutoff) { cur_cutoff = min_cut; adaptive = min_cut - best + c.o.beam_delta; }
+    }
+  }
+  const float cost_offset = -best;
+  const float lp = c.o.length_penalty;
+  // ---- ProcessEmitting (:722-824), pass A: the frame's best candidate -> next_cutoff
+  float mn = INFINITY;
+  for (int t = t0 + threadIdx.x; t < t1; t += NT) {
+    const float cur = o2f(c.l.tok_cost[t]);
+    if (!(cur <= cur_cutoff)) continue;
+    const int s = c.l.tok_state[t];
+    for (int a = g.row[s] + g.n_eps[s]; a < g.row[s + 1]; ++a) {
+      const float ac = cost_offset - c.ll[g.ilabel[a] - 1];
+      float gc = g.weight[a];
+      if (g.next[a] != s) gc += lp;
+      mn = fminf(mn, cur + ac + gc);
+    }
+  }
+  mn = block_min(c, mn);
+  const float next_cutoff = mn + adaptive;
+  clear_hash(c);
+  const int n0 = min(c.sh[0], c.max_tok), l0 = min(c.sh[1], c.max_link);
+  // pass B: claim tokens, then record links and minimise costs
+  for (int phase = 0; phase < 2; ++phase) {
+    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
+      const float cur = o2f(c.l.tok_cost[t]);
+      if (!(cur <= cur_cutoff)) continue;
+      const int s = c.l.tok_state[t];
+      for (int a = g.row[s] + g.n_eps[s]; a < g.row[s + 1]; ++a) {
+        const float ac = cost_offset - c.ll[g.ilabel[a] - 1];
+        float gc = g.weight[a];
+        if (g.next[a] != s) gc += lp;
+        const float tot = cur + ac + gc;
+        if (!(tot < next_cutoff)) continue;
+        if (phase == 0) {
+          claim(c, g.next[a]);
+        } else {
+          const int id = find(c, g.next[a]);
+          if (id < 0) continue;
+          const int li = atomicAdd(&c.sh[1], 1);
+          if (li < c.max_link) {
+            c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = ac; c.l.link_graph[li] = gc;
+            atomicMin(&c.l.tok_cost[id], f2o(tot));
+          } else {
+            c.sh[3] = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) c.l.link_off[2 * f + 2] = min(c.sh[1], c.max_link);   // [emitting links f -> f+1]
+  __syncthreads();
+  nonemitting(c, n0, next_cutoff);
+  best_links(c, l0, min(c.sh[1], c.max_link));
+  if (threadIdx.x == 0) {
+    c.l.cost_offset[f] = cost_offset;
+    c.l.tok_off[f + 2] = min(c.sh[0], c.max_tok);
+    c.l.link_off[2 * f + 3] = min(c.sh[1], c.max_link);                       // [eps links of frame f+1]
+    c.l.h->n_frames = f + 1;
+    c.l.h->n_tok = c.sh[0]; c.l.h->n_link = c.sh[1]; c.l.h->overflow = c.sh[3];
+  }
+  __syncthreads();
+}
+
+__device__ void setup(Ctx& c, const Graph& g, char* state, int u, size_t state_bytes, const Opts& o, int max_frames, int max_tok,
+                      int max_link, int hash, int* smem_hash, float* ll, float* redf, int* redi, int* sh) {
+  c.g = g; c.o = o; c.max_frames = max_frames; c.max_tok = max_tok; c.max_link = max_link; c.hash = hash;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &c.l);
+  if (smem_hash) { c.key = smem_hash; c.idx = smem_hash + hash; } else { c.key = c.l.gkey; c.idx = c.l.gidx; }
+  c.ll = ll; c.redf = redf; c.redi = redi; c.sh = sh;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(NT) void wfst_reset_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
+                                                         int max_tok, int max_link, int hash, int use_lds) {
+  extern __shared__ int dyn[];
+  __shared__ float ll[MAX_C], redf[NT];
+  __shared__ int redi[NT], sh[4];
+  Ctx c;
+  setup(c, g, state, blockIdx.x, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
+  init_decoding(c);
+}
+
+// CtcWfstBeamSearch::Search (ctc_wfst_beam_search.cc:70-121) over rows [0, lens[u]) of logp[u]
+__global__ __launch_bounds__(NT) void wfst_search_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
+                                                          int max_tok, int max_link, int hash, int use_lds,
+                                                          const float* __restrict__ logp, const int* __restrict__ lens, int T, int C) {
+  extern __shared__ int dyn[];
+  __shared__ float ll[MAX_C], redf[NT];
+  __shared__ int redi[NT], sh[4];
+  __shared__ int dec[2];
+  Ctx c;
+  const int u = blockIdx.x;
+  setup(c, g, state, u, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
+  if (threadIdx.x == 0) { sh[0] = c.l.h->n_tok; sh[1] = c.l.h->n_link; sh[2] = 0; sh[3] = c.l.h->overflow; }
+  __syncthreads();
+  const int n = lens ? min(lens[u], T) : T;
+  for (int i = 0; i < n; ++i) {
+    const float* row = logp + ((size_t)u * T + i) * C;
+    if (threadIdx.x == 0) {
+      Hdr* h = c.l.h;
+      const float blank_score = expf(row[0]);
+      int mode = 0;                      // 0: skip the frame, 1: decode it, 2: re-insert the remembered blank frame first
+      if (blank_score > o.blank_skip_thresh) {
+        h->is_last_blank = 1;
+        for (int k = 0; k < C; ++k) c.l.last_prob[k] = row[k];
+      } else {
+        int cur_best = 0; float bv = row[0];
+        for (int k = 1; k < C; ++k) if (row[k] > bv) { bv = row[k]; cur_best = k; }
+        mode = (cur_best != 0 && h->is_last_blank && cur_best == h->last_best) ? 2 : 1;
+        h->last_best = cur_best;
+      }
+      dec[0] = mode;
+    }
+    __syncthreads();
+    const int mode = dec[0];
+    if (mode == 2) {
+      if ((int)threadIdx.x < C) ll[threadIdx.x] = o.acoustic_scale * c.l.last_prob[threadIdx.x];
+      if (threadIdx.x == 0 && c.l.h->n_frames < max_frames) c.l.mapping[c.l.h->n_frames] = c.l.h->num_input - 1;
+      __syncthreads();
+      advance(c);
+    }
+    if (mode >= 1) {
+      if ((int)threadIdx.x < C) ll[threadIdx.x] = o.acoustic_scale * row[threadIdx.x];
+      if (threadIdx.x == 0 && c.l.h->n_frames < max_frames) c.l.mapping[c.l.h->n_frames] = c.l.h->num_input;
+      __syncthreads();
+      advance(c);
+      if (threadIdx.x == 0) c.l.h->is_last_blank = 0;
+    }
+    if (threadIdx.x == 0) c.l.h->num_input += 1;
+    __syncthreads();
+  }
+}
+
+// Best path by backpointers (lattice-faster-online-decoder.cc:58-150): alignment (ilabels), words (olabels), costs.
+// use_final: 0 = partial result (any token of the last frame), 1 = with final costs (after b2t_wfst_finalize).
+__global__ void wfst_best_path_kernel(Graph g, char* state, size_t state_bytes, int max_frames, int max_tok, int max_link, int hash,
+                                      int use_final, int max_len, int* ali, int* ali_frame, int* n_ali, int* words, int* n_words,
+                                      float* costs) {
+  const int u = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  Lay l;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
+  const int F = l.h->n_frames;
+  n_ali[u] = 0; n_words[u] = 0; costs[2 * u] = 0.f; costs[2 * u + 1] = 0.f;
+  if (F == 0) return;
+  const int t0 = l.tok_off[F], t1 = l.tok_off[F + 1];
+  float best = INFINITY, best_fc = 0.f; int bt = -1;
+  for (int t = t0; t < t1; ++t) {
+    float cost = o2f(l.tok_cost[t]), fc = 0.f;
+    if (use_final && l.h->has_final) {
+      fc = g.final_cost[l.tok_state[t]];
+      cost = fc == INFINITY ? INFINITY : cost + fc;
+    }
+    if (cost < best) { best = cost; bt = t; best_fc = fc; }
+  }
+  if (bt < 0) return;
+  // walk back, writing from the end of the buffers; then shift to the front
+  int na = 0, nw = 0, t = bt, frame = F - 1;
+  float gc = best_fc, ac = 0.f;
+  int* a_out = ali + (size_t)u * max_len; int* f_out = ali_frame + (size_t)u * max_len; int* w_out = words + (size_t)u * max_len;
+  while (l.tok_best[t] >= 0 && l.tok_best[t] != 0x7fffffff) {
+    const int li = l.tok_best[t];
+    const int a = l.link_arc[li];
+    const int il = g.ilabel[a], ol = g.olabel[a];
+    gc += l.link_graph[li];
+    if (il != 0) {
+      ac += l.link_ac[li] - l.cost_offset[frame];
+      if (na < max_len) { a_out[max_len - 1 - na] = il; f_out[max_len - 1 - na] = l.mapping[frame]; }
+      ++na; --frame;
+    }
+    if (ol != 0) { if (nw < max_len) w_out[max_len - 1 - nw] = ol; ++nw; }
+    t = l.link_src[li];
+  }
+  const int ka = min(na, max_len), kw = min(nw, max_len);
+  for (int i = 0; i < ka; ++i) { a_out[i] = a_out[max_len - ka + i]; f_out[i] = f_out[max_len - ka + i]; }
+  for (int i = 0; i < kw; ++i) w_out[i] = w_out[max_len - kw + i];
+  n_ali[u] = ka; n_words[u] = kw; costs[2 * u] = gc; costs[2 * u + 1] = ac;
+}
+
+// FinalizeDecoding (:632-647): PruneForwardLinksFinal on the last frame, then PruneForwardLinks(delta = 0) +
+// PruneTokensForFrame backwards.  Marks link_alive; tok_extra = inf for tokens that leave the lattice.
+__global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
+                                                            int max_tok, int max_link, int hash) {
+  __shared__ float redf[NT];
+  __shared__ int changed;
+  const int u = blockIdx.x;
+  Lay l;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
+  const int F = l.h->n_frames;
+  const unsigned INF_BITS = 0x7f800000u;
+  auto bmin = [&](float v) {
+    redf[threadIdx.x] = v; __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) redf[threadIdx.x] = fminf(redf[threadIdx.x], redf[threadIdx.x + s]); __syncthreads(); }
+    const float r = redf[0]; __syncthreads(); return r;
+  };
+  // ComputeFinalCosts (:547-590)
+  const int t0 = l.tok_off[F], t1 = l.tok_off[F + 1];
+  float b = INFINITY, bf = INFINITY;
+  for (int t = t0 + threadIdx.x; t < t1; t += NT) {
+    const float cst = o2f(l.tok_cost[t]);
+    b = fminf(b, cst); bf = fminf(bf, cst + g.final_cost[l.tok_state[t]]);
+  }
+  b = bmin(b); bf = bmin(bf);
+  const int has_final = bf != INFINITY;
+  const float final_best = has_final ? bf : b;
+  if (threadIdx.x == 0) { l.h->final_best = final_best; l.h->has_final = has_final; l.h->finalized = 1; }
+  for (int li = threadIdx.x; li < min(l.h->n_link, max_link); li += NT) l.link_alive[li] = 1;
+  __syncthreads();
+  for (int f = F; f >= 0; --f) {
+    const int a0 = l.tok_off[f], a1 = l.tok_off[f + 1];
+    // links leaving the tokens of frame f: its epsilon links, and (f < F) the emitting links into frame f + 1
+    const int e0 = f == 0 ? 0 : l.link_off[2 * f], e1 = l.link_off[2 * f + 1];                 // eps links of frame f
+    const int m0 = f < F ? l.link_off[2 * f + 1] : 0, m1 = f < F ? l.link_off[2 * f + 2] : 0;   // emitting f -> f+1
+    for (int iter = 0; iter < 1000; ++iter) {
+      __syncthreads();
+      if (threadIdx.x == 0) changed = 0;
+      __syncthreads();
+      // Jacobi sweep: remember the previous values, reset to the base term (final-cost term on the last frame, +inf
+      // elsewhere), minimise over the surviving links, compare.  Values only grow from their initial 0 (lower bounds),
+      // so a link found beyond the lattice beam in any sweep is beyond it at the fixed point too.
+      for (int t = a0 + threadIdx.x; t < a1; t += NT) {
+        float base = INFINITY;
+        if (f == F) {
+          const float fc = has_final ? g.final_cost[l.tok_state[t]] : 0.f;
+          base = o2f(l.tok_cost[t]) + fc - final_best;
+          if (base < 0.f) base = 0.f;
+        }
+        l.tok_prev[t] = l.tok_extra[t];
+        l.tok_extra[t] = __float_as_uint(base);
+      }
+      __syncthreads();
+      for (int pass = 0; pass < 2; ++pass) {
+        const int q0 = pass == 0 ? e0 : m0, q1 = pass == 0 ? e1 : m1;
+        for (int li = q0 + threadIdx.x; li < q1; li += NT) {
+          if (!l.link_alive[li]) continue;
+          const int src = l.link_src[li], dst = l.link_dst[li];
+          // epsilon links stay inside frame f: the destination's value of the previous sweep; emitting links point into
+          // frame f + 1, whose values are final
+          const float dst_extra = __uint_as_float(pass == 0 ? l.tok_prev[dst] : l.tok_extra[dst]);
+          float lec = dst_extra + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+          if (lec > o.lattice_beam) { l.link_alive[li] = 0; continue; }
+          if (lec < 0.f) lec = 0.f;
+          atomicMin(&l.tok_extra[src], __float_as_uint(lec));   // non-negative floats order like their bits
+        }
+      }
+      __syncthreads();
+      for (int t = a0 + threadIdx.x; t < a1; t += NT) {
+        unsigned nv = l.tok_extra[t];
+        if (f == F && __uint_as_float(nv) > o.lattice_beam) { nv = INF_BITS; l.tok_extra[t] = nv; }
+        if (nv != l.tok_prev[t]) changed = 1;
+      }
+      __syncthreads();
+      if (!changed) break;
+    }
+  }
+}
+
+}  // namespace b2t
+
+using namespace b2t;
+
+extern "C" size_t b2t_wfst_state_bytes(int max_frames, int max_tokens, int max_links, int hash_size) {
+  return layout(nullptr, max_frames, max_tokens, max_links, hash_size, nullptr);
+}
+
+namespace {
+int check_args(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, const char* what) {
+  B2T_REQUIRE(g && o && state && U > 0, "%s: null argument", what);
+  B2T_REQUIRE(g->row && g->ilabel && g->olabel && g->weight && g->next && g->n_eps && g->final_cost && g->n_states > 0,
+              "%s: incomplete graph", what);
+  B2T_REQUIRE(o->hash_size >= 64 && (o->hash_size & (o->hash_size - 1)) == 0, "%s: hash_size must be a power of two >= 64", what);
+  B2T_REQUIRE(o->max_frames > 0 && o->max_tokens > 0 && o->max_links > 0, "%s: bad capacities", what);
+  B2T_REQUIRE(o->beam > 0.f && o->lattice_beam > 0.f && o->max_active > 1 && o->min_active >= 0 && o->min_active <= o->max_active,
+              "%s: bad search options", what);
+  return 0;
+}
+Graph to_graph(const b2t_wfst_graph_t* g) {
+  return Graph{g->row, g->ilabel, g->olabel, g->weight, g->next, g->n_eps, g->final_cost, g->start};
+}
+Opts to_opts(const b2t_wfst_opts_t* o) {
+  return Opts{o->beam, o->lattice_beam, o->beam_delta, o->acoustic_scale, o->length_penalty, o->blank_skip_thresh, o->max_active, o->min_active};
+}
+size_t lds_hash_bytes(const b2t_wfst_opts_t* o) { return o->hash_size <= 8192 ? (size_t)o->hash_size * 2 * sizeof(int) : 0; }
+template <typename K> void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+}  // namespace
+
+extern "C" int b2t_wfst_reset(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream) {
+  { int rc = check_args(g, o, state, U, "wfst_reset"); if (rc) return rc; }
+  const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size), lds = lds_hash_bytes(o);
+  allow_lds(wfst_reset_kernel, lds);
+  hipLaunchKernelGGL(wfst_reset_kernel, dim3(U), dim3(NT), lds, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, lds ? 1 : 0);
+  B2T_CHECK_LAUNCH("b2t_wfst_reset");
+  return 0;
+}
+
+extern "C" int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, const float* logp,
+                                   const int32_t* lens, int U, int T, int C, void* stream) {
+  { int rc = check_args(g, o, state, U, "wfst_search"); if (rc) return rc; }
+  B2T_REQUIRE(logp && T > 0 && C > 1 && C <= MAX_C, "wfst_search: bad logp shape T=%d C=%d", T, C);
+  const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size), lds = lds_hash_bytes(o);
+  allow_lds(wfst_search_kernel, lds);
+  hipLaunchKernelGGL(wfst_search_kernel, dim3(U), dim3(NT), lds, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, lds ? 1 : 0, logp, lens, T, C);
+  B2T_CHECK_LAUNCH("b2t_wfst_search_f32");
+  return 0;
+}
+
+extern "C" int b2t_wfst_best_path(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, const void* state, int U, int use_final,
+                                  int max_len, int32_t* alignment, int32_t* align_frame, int32_t* n_align, int32_t* words,
+                                  int32_t* n_words, float* costs, void* stream) {
+  { int rc = check_args(g, o, const_cast<void*>(state), U, "wfst_best_path"); if (rc) return rc; }
+  B2T_REQUIRE(max_len > 0 && alignment && align_frame && n_align && words && n_words && costs, "wfst_best_path: null output");
+  const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
+  hipLaunchKernelGGL(wfst_best_path_kernel, dim3(U), dim3(64), 0, as_stream(stream), to_graph(g), (char*)const_cast<void*>(state), sb,
+                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, use_final, max_len, alignment, align_frame, n_align,
+                     words, n_words, costs);
+  B2T_CHECK_LAUNCH("b2t_wfst_best_path");
+  return 0;
+}
+
+extern "C" int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream) {
+  { int rc = check_args(g, o, state, U, "wfst_finalize"); if (rc) return rc; }
+  const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
+  hipLaunchKernelGGL(wfst_finalize_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                     o->max_frames, o->max_tokens, o->max_links, o->hash_size);
+  B2T_CHECK_LAUNCH("b2t_wfst_finalize");
+  return 0;
+}
+
+// Host views into one utterance's state block (offsets in bytes from the block's start), for copying the lattice out.
+extern "C" int b2t_wfst_state_offsets(int max_frames, int max_tokens, int max_links, int hash_size, long long* off16) {
+  B2T_REQUIRE(off16 != nullptr, "wfst_state_offsets: null output");
+  Lay l;
+  char* base = reinterpret_cast<char*>(0x1000);   // any non-null base: only differences are used
+  layout(base, max_frames, max_tokens, max_links, hash_size, &l);
+  const char* ptrs[16] = {(char*)l.h, (char*)l.mapping, (char*)l.tok_off, (char*)l.link_off, (char*)l.cost_offset, (char*)l.tok_state,
+                          (char*)l.tok_cost, (char*)l.tok_extra, (char*)l.link_src, (char*)l.link_dst, (char*)l.link_arc,
+                          (char*)l.link_ac, (char*)l.link_graph, (char*)l.link_alive, (char*)l.tok_best, (char*)l.last_prob};
+  for (int i = 0; i < 16; ++i) off16[i] = (long long)(ptrs[i] - base);
+  return 0;
+}

@@ -1,14 +1,15 @@
 """lm_decoder — Python surface of the reference's pybind11 module
 (language_model/runtime/server/x86/python/lm_decoder.cc:51-75) over the HIP decoder kernels.
 
-Built so far: the DecodeNumpy prologue (log_softmax - priors, blank penalty) and the LM-free searcher the
-reference's BrainSpeechDecoder falls back to when no TLG graph is loaded (CtcPrefixBeamSearch,
-brain_speech_decoder.cc:23-28) — as a batched, streaming-capable GPU kernel (csrc/beam.hip) — optionally fused with a
-token-level ARPA n-gram LM resident in HBM (ngram_lm.NGramLM; DecodeResource.set_token_lm, DecodeOptions.lm_alpha /
-lm_beta): every emitted token adds lm_alpha * ln p(token | history) + lm_beta, pruning and ranking use the sum.
-NOT built: WFST (TLG.fst) token passing over a word-level lexicon/LM graph, lattice n-best and LM rescoring
-(SURVEY §8 a15/a16): constructing a DecodeResource with an FST path raises NotImplementedError instead of silently
-decoding without that graph.
+Two searchers, chosen like the reference's BrainSpeechDecoder does (brain_speech_decoder.cc:23-28):
+  * a decode graph is loaded (DecodeResource(fst_path, ..) -- an OpenFST vector/standard TLG.fst or an .npz written by
+    wfst.save_graph -- or DecodeResource.set_graph(wfst.build_tlg(lexicon, arpa))): CtcWfstBeamSearch, i.e. Kaldi's
+    lattice-generating token passing over T o L o G, as batched GPU kernels (csrc/wfst.hip, wfst_decoder.WfstSearch):
+    partial best path after every Decode(), n-best word sequences with separate graph / acoustic scores after
+    FinishDecoding(), Rescore() with a second grammar;
+  * no graph: the LM-free CtcPrefixBeamSearch (csrc/beam.hip), optionally fused with a token-level ARPA n-gram
+    (DecodeResource.set_token_lm) or constrained by a lexicon + word n-gram (set_lexicon_lm).
+The DecodeNumpy prologue (log_softmax - priors, blank penalty) is a kernel of its own.
 """
 from __future__ import annotations
 
@@ -43,14 +44,28 @@ class DecodeResource:
     """DecodeResource(fst_path, lm_fst_path, rescore_lm_fst_path, dict_path, unit_path)."""
 
     def __init__(self, fst_path, lm_fst_path, rescore_lm_fst_path, dict_path, unit_path):
-        if fst_path or lm_fst_path or rescore_lm_fst_path:
-            raise NotImplementedError("WFST (TLG.fst / G.fst) decoding is not built on the HIP path yet; "
-                                      "pass empty FST paths to use the CTC prefix beam searcher")
+        import wfst
+        self.graph = wfst.graph_from_files(fst_path, dict_path) if fst_path else None
+        # the grammars used by Rescore(): G.fst (its scores are taken out) and G_no_prune.fst (its scores are put in)
+        self.lm_fst = wfst.read_openfst_vector(lm_fst_path) if lm_fst_path else None
+        self.rescore_lm_fst = wfst.read_openfst_vector(rescore_lm_fst_path) if rescore_lm_fst_path else None
+        self.backoff_label = None     # word id of #0 on the grammars' back-off arcs (set_graph / set_rescore_grammars)
         self.symbols = self._read_table(dict_path) if dict_path else None
         self.units = self._read_table(unit_path) if unit_path else None
         self.token_lm = None
         self.lexicon = self.word_lm = None
         self.sil = 1
+
+    def set_graph(self, graph):
+        """Attach a wfst.DecodeGraph built in memory (wfst.build_tlg); its word table becomes the symbol table."""
+        self.graph = graph
+        self.symbols = {i: w for i, w in enumerate(graph.words)}
+        if "#0" in graph.words:
+            self.backoff_label = graph.words.index("#0")
+
+    def set_rescore_grammars(self, lm_fst, rescore_lm_fst, backoff_label):
+        """wfst.Fst grammars for Rescore(): the one composed into the graph and the one to rescore with."""
+        self.lm_fst, self.rescore_lm_fst, self.backoff_label = lm_fst, rescore_lm_fst, backoff_label
 
     def set_token_lm(self, lm):
         """Attach an ngram_lm.NGramLM over the decoder's output tokens (fused into the prefix beam search)."""
@@ -98,6 +113,14 @@ class BrainSpeechDecoder:
         self.res, self.opts = resource, opts
         self.device = torch.device(device)
         self.max_len = max_len
+        self.wfst = None
+        if resource.graph is not None:      # CtcWfstBeamSearch (brain_speech_decoder.cc:26-28)
+            from wfst_decoder import WfstSearch
+            self.wfst = WfstSearch(resource.graph, opts, U=1, device=self.device, max_frames=max_len)
+            self.acoustic_scale = float(opts.acoustic_scale)
+            self._result = []
+            self._entries = []
+            return
         self.max_nodes = max_len * max(1, opts.second_beam_size) + 2
         lib = N.load()
         nbytes = lib.b2t_beam_state_bytes(self.max_len, self.max_nodes)
@@ -109,9 +132,25 @@ class BrainSpeechDecoder:
 
     def SetOpt(self, opts: DecodeOptions):
         self.opts = opts
+        if self.wfst is not None:
+            self.wfst.set_opts(opts)
+            self.acoustic_scale = float(opts.acoustic_scale)
+
+    def _wfst_results(self, entries):
+        """UpdateResult (brain_speech_decoder.cc:113-137): word strings, ac_score = acoustic / acoustic_scale, lm_score = graph."""
+        table = self.res.symbols or {}
+        self._entries = entries
+        self._result = []
+        for inp, tm, words, lm, ac in entries:
+            r = DecodeResult(process_blank("".join(" " + table.get(int(w), str(int(w))) for w in words)), ac / self.acoustic_scale, lm)
+            r.tokens, r.times, r.word_ids = np.asarray(inp), np.asarray(tm), list(words)
+            self._result.append(r)
 
     def Reset(self):
         self._result = []
+        if self.wfst is not None:
+            self.wfst.reset()
+            return
         with torch.cuda.device(self.device):
             N.check(N.load().b2t_beam_reset(ops._p(self.state), 1, self.max_len, self.max_nodes, ops._stream()),
                     "b2t_beam_reset")
@@ -120,6 +159,13 @@ class BrainSpeechDecoder:
         lp = torch.as_tensor(logp, dtype=torch.float32).to(self.device).contiguous()
         if lp.dim() != 2:
             raise ValueError("logp must be [T, C]")
+        if self.wfst is not None:
+            if lp.shape[0] == 0:
+                return
+            self.wfst.search(lp.unsqueeze(0))
+            bp = self.wfst.best_path(False)[0]
+            self._wfst_results([bp] if self.wfst.frames_decoded()[0] > 0 else [])
+            return
         T, Cc = lp.shape
         bm = self.opts.second_beam_size
         hyps = torch.zeros((1, bm, self.max_len), dtype=torch.int32, device=self.device)
@@ -191,10 +237,37 @@ class BrainSpeechDecoder:
             self._result.sort(key=lambda r: -r.total_score)
 
     def FinishDecoding(self):
-        pass   # CtcPrefixBeamSearch::FinalizeSearch is a no-op (ctc_prefix_beam_search.h)
+        if self.wfst is not None:           # FinalizeSearch + UpdateResult (brain_speech_decoder.cc:41-44)
+            self._wfst_results(self.wfst.finalize()[0])
+        # (CtcPrefixBeamSearch::FinalizeSearch is a no-op, ctc_prefix_beam_search.h)
 
     def Rescore(self):
-        raise NotImplementedError("lattice LM rescoring needs the WFST decoder (not built)")
+        """brain_speech_decoder.cc:61-101: take the scores of the grammar that is composed into the graph out of the
+        lattice and put the scores of the rescoring grammar in (two lattice compositions in the reference), then list the
+        n-best again.  Here the exchange is done per word sequence on a deep n-best list of the same pruned lattice
+        (lattice composition with a deterministic-per-sequence grammar changes each sequence's graph cost by exactly
+        G_new(W) - G_old(W)); the list is then re-ranked and cut to the previous length."""
+        if self.wfst is None:
+            raise RuntimeError("Rescore() needs the WFST searcher (load a decode graph)")
+        if self.res.lm_fst is None or self.res.rescore_lm_fst is None or self.res.backoff_label is None:
+            raise RuntimeError("Rescore() needs both grammars (DecodeResource lm_fst_path / rescore_lm_fst_path or set_rescore_grammars)")
+        import wfst
+        keep = len(self._result)
+        old_n = self.wfst.nbest
+        self.wfst.nbest = max(10 * keep, 100)
+        try:
+            deep = self.wfst._nbest_of(0, self.wfst._header()[0])
+        finally:
+            self.wfst.nbest = old_n
+        rescored = []
+        for inp, tm, words, lm, ac in deep:
+            g_old = wfst.grammar_score(self.res.lm_fst, words, self.res.backoff_label)
+            g_new = wfst.grammar_score(self.res.rescore_lm_fst, words, self.res.backoff_label)
+            if not np.isfinite(g_new):
+                continue
+            rescored.append((inp, tm, words, lm + g_old - g_new, ac))
+        rescored.sort(key=lambda e: -(e[3] + e[4]))
+        self._wfst_results(rescored[:keep])
 
     def DecodedSomething(self):
         return bool(self._result) and bool(self._result[0].sentence)

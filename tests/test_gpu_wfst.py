@@ -1,0 +1,259 @@
+"""GPU: the batched WFST token-passing search (csrc/wfst.hip + wfst_decoder.py, through the C ABI) against the oracle's
+restatement of the reference decoder (oracle/wfst_oracle.py) on the same graph and log-probabilities, with the production
+options (language-model-standalone.py:486-496: beam 17, max_active 7000, min_active 200, lattice_beam 8, acoustic_scale
+0.325, no blank skipping) and with blank skipping / tight pruning.  Costs: abs 2e-3 (fp32 sums in a different order);
+word sequences and phoneme alignments identical wherever the oracle's cost gap to the next entry exceeds that."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ngram_lm
+import wfst
+from oracle import wfst_oracle as W
+
+TOL = 2e-3
+
+
+class Opt:
+    def __init__(self, **kw):
+        d = dict(max_active=7000, min_active=200, beam=17.0, lattice_beam=8.0, acoustic_scale=0.325,
+                 ctc_blank_skip_threshold=1.0, length_penalty=0.0, nbest=20)
+        d.update(kw)
+        self.__dict__.update(d)
+
+
+def cfg_of(o):
+    return W.Config(beam=o.beam, max_active=o.max_active, min_active=o.min_active, lattice_beam=o.lattice_beam,
+                    acoustic_scale=o.acoustic_scale, nbest=o.nbest, blank_skip_thresh=o.ctc_blank_skip_threshold,
+                    length_penalty=o.length_penalty)
+
+
+@pytest.fixture(scope="module")
+def toy():
+    prons = ngram_lm.synthetic_lexicon(60, 41, seed=11)
+    words = sorted(prons)
+    arpa = ngram_lm.synthetic_word_arpa(words, 3, 400, seed=12)
+    return prons, words, wfst.build_tlg(prons, arpa, sil_prob=0.5), arpa
+
+
+def utterances(prons, words, U, rs, noise=1.2, blank_bias=math.log(90.0), n_words=(2, 5)):
+    """Noisy log-probabilities spelling random word sequences, after the DecodeNumpy prologue (blank penalty)."""
+    seqs, lps = [], []
+    for u in range(U):
+        seq = [words[i] for i in rs.randint(len(words), size=rs.randint(*n_words))]
+        frames = []
+        for w in seq:
+            for c in list(prons[w][0]) + [1]:
+                frames += [c] * rs.randint(1, 3) + [0] * rs.randint(0, 3)
+        lg = np.full((len(frames), 41), -2.0, np.float32)
+        for t, c in enumerate(frames):
+            lg[t, c] = 3.0
+        lg += rs.standard_normal(lg.shape).astype(np.float32) * noise
+        lp = lg - np.log(np.exp(lg).sum(-1, keepdims=True))
+        lp[:, 0] -= blank_bias
+        seqs.append(seq); lps.append(lp.astype(np.float32))
+    T = max(l.shape[0] for l in lps)
+    batch = np.zeros((U, T, 41), np.float32)
+    lens = np.array([l.shape[0] for l in lps], np.int32)
+    for u, l in enumerate(lps):
+        batch[u, :l.shape[0]] = l
+    return seqs, lps, batch, lens
+
+
+def compare_lists(got, ref_search, tag):
+    """got: [(inputs, times, words, lm, ac)] from the HIP search; ref_search: the oracle's CtcWfstBeamSearch after finalize."""
+    ref = list(zip(ref_search.inputs, ref_search.times, ref_search.outputs, ref_search.likelihood))
+    assert len(got) == len(ref), (tag, len(got), len(ref))
+    tot_ref = [-(l[0] + l[1]) for _, _, _, l in ref]
+    for k, ((gi, gt, gw, glm, gac), (ri, rt, rw, (rlm, rac))) in enumerate(zip(got, ref)):
+        assert abs((glm + gac) - (rlm + rac)) < TOL, (tag, k)
+        gap_prev = tot_ref[k] - tot_ref[k - 1] if k > 0 else 1.0
+        gap_next = tot_ref[k + 1] - tot_ref[k] if k + 1 < len(ref) else 1.0
+        if min(gap_prev, gap_next) > 2 * TOL:          # unambiguous rank: same words, same graph / acoustic split, same alignment
+            assert gw == list(rw), (tag, k)
+            assert abs(glm - rlm) < TOL and abs(gac - rac) < TOL, (tag, k)
+            assert gi == list(ri) and gt == list(rt), (tag, k)
+
+
+def test_wfst_search_matches_oracle_production_options(toy):
+    """8 utterances in one call, production options: partial best path after Search, n-best (20) after FinalizeSearch."""
+    from wfst_decoder import WfstSearch
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(3)
+    seqs, lps, batch, lens = utterances(prons, words, 8, rs)
+    o = Opt()
+    S = WfstSearch(g, o, U=8, max_frames=batch.shape[1] + 8)
+    S.search(torch.from_numpy(batch).cuda(), lens)
+    part = S.best_path(False)
+    fin = S.finalize()
+    hits = 0
+    for u in range(8):
+        R = W.CtcWfstBeamSearch(g, cfg_of(o))
+        R.search(lps[u])
+        assert S.frames_decoded()[u] == len(R.mapping)
+        pi, pt, pw, plm, pac = part[u]
+        assert pw == R.outputs[0] and pi == R.inputs[0]
+        assert abs(plm - R.likelihood[0][0]) < TOL and abs(pac - R.likelihood[0][1]) < TOL
+        R.finalize_search()
+        compare_lists(fin[u], R, f"utt{u}")
+        hits += [g.words[w] for w in fin[u][0][2]] == seqs[u]
+    assert hits >= 6        # the search really decodes the spelled sentences (noise makes a few differ)
+
+
+def test_wfst_streaming_equals_one_shot_and_blank_skipping(toy):
+    """Chunk-by-chunk Search (state persists in HBM) == one call, bit for bit; blank-frame skipping with the re-insertion
+    rule (ctc_wfst_beam_search.cc:79-94) reproduces the oracle's frame mapping, times and results."""
+    from wfst_decoder import WfstSearch
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(5)
+    seqs, lps, batch, lens = utterances(prons, words, 4, rs, noise=0.6, blank_bias=0.0)
+    for u in range(4):                         # make many frames near-certain blanks so that skipping happens
+        blanks = np.argmax(lps[u], -1) == 0
+        lps[u][blanks, 0] = math.log(0.995); batch[u, :lens[u]] = lps[u]
+    o = Opt(ctc_blank_skip_threshold=0.98, nbest=10, acoustic_scale=0.5)
+    dev_batch = torch.from_numpy(batch).cuda()
+    A = WfstSearch(g, o, U=4, max_frames=batch.shape[1] + 8)
+    A.search(dev_batch, lens)
+    B = WfstSearch(g, o, U=4, max_frames=batch.shape[1] + 8)
+    for t0 in range(0, batch.shape[1], 7):
+        chunk = dev_batch[:, t0:t0 + 7].contiguous()
+        B.search(chunk, np.clip(lens - t0, 0, chunk.shape[1]).astype(np.int32))
+    assert A.frames_decoded() == B.frames_decoded()
+    fa, fb = A.finalize(), B.finalize()
+    assert fa == fb
+    for u in range(4):
+        R = W.CtcWfstBeamSearch(g, cfg_of(o))
+        R.search(lps[u])
+        assert len(R.mapping) < lens[u] and A.frames_decoded()[u] == len(R.mapping)
+        R.finalize_search()
+        compare_lists(fa[u], R, f"skip{u}")
+
+
+def test_wfst_tight_pruning_and_overflow(toy):
+    """max_active / min_active that bind (GetCutoff's nth_element branches): the best path still equals the oracle's;
+    exhausted capacities are reported, never silently truncated."""
+    from wfst_decoder import WfstSearch
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(9)
+    seqs, lps, batch, lens = utterances(prons, words, 3, rs, noise=1.0)
+    o = Opt(max_active=300, min_active=50, beam=9.0, nbest=1, lattice_beam=4.0)
+    S = WfstSearch(g, o, U=3, max_frames=batch.shape[1] + 8)
+    S.search(torch.from_numpy(batch).cuda(), lens)
+    fin = S.finalize()
+    for u in range(3):
+        R = W.CtcWfstBeamSearch(g, cfg_of(o))
+        R.search(lps[u]); R.finalize_search()
+        assert fin[u][0][2] == R.outputs[0]
+        assert abs((fin[u][0][3] + fin[u][0][4]) + (-(R.likelihood[0][0] + R.likelihood[0][1]))) < 5e-2 or \
+            abs((fin[u][0][3] + fin[u][0][4]) - (R.likelihood[0][0] + R.likelihood[0][1])) < TOL
+    small = WfstSearch(g, Opt(), U=1, max_frames=batch.shape[1] + 8, max_tokens=2000, max_links=4000)
+    small.search(torch.from_numpy(batch[:1]).cuda(), lens[:1])
+    with pytest.raises(RuntimeError, match="capacity"):
+        small.finalize()
+
+
+def test_lm_decoder_surface_with_a_graph(toy, tmp_path):
+    """The reference's call sequence (language-model-standalone.py:486-496,763-772; brain_speech_decoder.h:112-124):
+    DecodeOptions(8 args) / DecodeResource(5 paths: TLG in the OpenFST vector container + words.txt) / BrainSpeechDecoder /
+    DecodeNumpy per chunk / FinishDecoding / result()[i].sentence, .ac_score, .lm_score / Rescore / Reset."""
+    import lm_decoder
+    prons, words, g, arpa = toy
+    f = wfst.Fst()
+    f.n, f.start = g.n_states, g.start
+    src = np.repeat(np.arange(g.n_states), np.diff(g.row))
+    f.arcs = [(int(s), int(il), int(ol), float(w), int(d)) for s, il, ol, w, d in zip(src, g.ilabel, g.olabel, g.weight, g.next)]
+    f.final = {int(s): float(c) for s, c in enumerate(g.final) if np.isfinite(c)}
+    wfst.write_openfst_vector(f, str(tmp_path / "TLG.fst"))
+    with open(str(tmp_path / "words.txt"), "w") as fh:
+        for i, w in enumerate(g.words):
+            fh.write(f"{w} {i}\n")
+    opts = lm_decoder.DecodeOptions(7000, 200, 17.0, 8.0, 0.325, 1.0, 0.0, 10)
+    res = lm_decoder.DecodeResource(str(tmp_path / "TLG.fst"), "", "", str(tmp_path / "words.txt"), "")
+    dec = lm_decoder.BrainSpeechDecoder(res, opts)
+    rs = np.random.RandomState(21)
+    seqs, lps, batch, lens = utterances(prons, words, 1, rs, noise=0.8, blank_bias=0.0)
+    logits = lps[0] + 1.7                                   # un-normalised, like the RNN's outputs
+    for t0 in range(0, logits.shape[0], 10):                # streamed, one DecodeNumpy per chunk
+        lm_decoder.DecodeNumpy(dec, logits[t0:t0 + 10], np.zeros_like(logits[t0:t0 + 10]), math.log(90.0))
+        assert len(dec.result()) == 1
+    assert dec.DecodedSomething()
+    dec.FinishDecoding()
+    out = dec.result()
+    lp = logits - np.log(np.exp(logits).sum(-1, keepdims=True)); lp[:, 0] -= math.log(90.0)
+    R = W.CtcWfstBeamSearch(g, W.Config(beam=17, max_active=7000, min_active=200, lattice_beam=8, acoustic_scale=0.325, nbest=10, blank_skip_thresh=1.0))
+    R.search(lp.astype(np.float32)); R.finalize_search()
+    want = W.decode_results(R, g.words)
+    assert len(out) == len(want) and out[0].sentence == want[0][0] == " ".join(seqs[0])
+    for r, (sent, ac, lm) in zip(out, want):
+        assert abs(r.ac_score * 0.325 + r.lm_score - (ac * 0.325 + lm)) < TOL
+    assert abs(out[0].ac_score - want[0][1]) < 1e-2 and abs(out[0].lm_score - want[0][2]) < TOL
+    # Rescore with a second grammar: every sequence's graph score moves by G_old(W) - G_new(W); the list is re-ranked
+    word_id = {w: i for i, w in enumerate(g.words) if 0 < i <= len(words)}
+    wd0 = g.words.index("#0")
+    G_old = wfst.grammar_fst(arpa, word_id, wd0)
+    G_new = wfst.grammar_fst(ngram_lm.synthetic_word_arpa(words, 3, 400, seed=99), word_id, wd0)
+    res.set_rescore_grammars(G_old, G_new, wd0)
+    before = {r.sentence: (r.lm_score, r.ac_score) for r in out}
+    dec.Rescore()
+    after = dec.result()
+    assert len(after) <= len(out) and len(after) >= 1
+    tot = [r.lm_score + r.ac_score * 0.325 for r in after]
+    assert all(a >= b - 1e-5 for a, b in zip(tot, tot[1:]))
+    for r in after:
+        if r.sentence in before:
+            ids = r.word_ids
+            delta = wfst.grammar_score(G_old, ids, wd0) - wfst.grammar_score(G_new, ids, wd0)
+            assert abs(r.lm_score - (before[r.sentence][0] + delta)) < TOL and abs(r.ac_score - before[r.sentence][1]) < 1e-4
+    dec.Reset()
+    assert dec.result() == [] and not dec.DecodedSomething()
+    lm_decoder.DecodeNumpyLogProbs(dec, lp.astype(np.float32))
+    dec.FinishDecoding()
+    assert dec.result()[0].sentence == out[0].sentence
+
+
+def test_lattice_nbest_host_against_enumeration():
+    """b2t_lattice_nbest_host (csrc/lattice.cpp) on a small random acyclic lattice: the cheapest path of every distinct word
+    sequence, in order, with its graph / acoustic split and alignment -- against exhaustive enumeration."""
+    import ctypes as C
+    import b2t_native as N
+    lib = N.load()
+    rs = np.random.RandomState(4)
+    n = 14
+    src, dst, il, ol, gr, ac = [], [], [], [], [], []
+    for s in range(n - 1):
+        for _ in range(3):
+            d = rs.randint(s + 1, min(n, s + 4))
+            src.append(s); dst.append(d); il.append(rs.randint(0, 5)); ol.append(int(rs.choice([0, 0, 7, 8, 9])))
+            gr.append(float(rs.rand())); ac.append(float(rs.rand() * 2))
+    A = [np.array(x, dtype=t) for x, t in ((src, np.int32), (dst, np.int32), (il, np.int32), (ol, np.int32), (gr, np.float32), (ac, np.float32))]
+    fs, fc = np.array([n - 1, n - 2], np.int32), np.array([0.25, 1.0], np.float32)
+    best = {}
+    stack = [(0, (), (), 0.0, 0.0)]
+    while stack:
+        s, w, a, g_, a_ = stack.pop()
+        for k, st in enumerate(fs):
+            if s == st:
+                c = g_ + a_ + float(fc[k])
+                if c < best.get(w, (math.inf,))[0]:
+                    best[w] = (c, g_ + float(fc[k]), a_, a)
+        for i in range(len(src)):
+            if src[i] == s:
+                stack.append((dst[i], w + ((ol[i],) if ol[i] else ()), a + ((il[i],) if il[i] else ()), g_ + gr[i], a_ + ac[i]))
+    ranked = sorted(best.items(), key=lambda kv: kv[1][0])
+    nb, beam = 6, 2.5
+    ranked = [r for r in ranked if r[1][0] <= ranked[0][1][0] + beam][:nb]
+    ow, oa = np.zeros(256, np.int32), np.zeros(256, np.int32)
+    woff, aoff, costs = np.zeros(nb + 1, np.int32), np.zeros(nb + 1, np.int32), np.zeros(2 * nb, np.float32)
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    k = lib.b2t_lattice_nbest_host(n, 0, len(src), P(A[0]), P(A[1]), P(A[2]), P(A[3]), P(A[4]), P(A[5]), 2, P(fs), P(fc), nb,
+                                   C.c_float(beam), P(ow), P(woff), 256, P(oa), P(aoff), 256, P(costs))
+    assert k == len(ranked) and k >= 2
+    for j, (w, (c, g_, a_, a)) in enumerate(ranked):
+        assert tuple(ow[woff[j]:woff[j + 1]]) == w
+        assert abs(costs[2 * j] - g_) < 1e-5 and abs(costs[2 * j + 1] - a_) < 1e-5
+        assert tuple(oa[aoff[j]:aoff[j + 1]]) == a
