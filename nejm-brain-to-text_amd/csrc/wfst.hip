@@ -38,7 +38,7 @@ struct Hdr {
   int n_frames;        // decoded frames (emitting steps taken)
   int n_tok;           // tokens so far (all frames)
   int n_link;          // links so far
-  int overflow;        // capacity exhausted (tokens / links / hash / frames): results invalid
+  int overflow;        // capacity exhausted (bit 0 tokens, 1 links, 2 hash slots, 3 frames): results invalid
   int num_input;       // input frames seen (incl. skipped ones)
   int is_last_blank, last_best;
   int finalized;
@@ -158,14 +158,14 @@ __device__ __forceinline__ void claim(Ctx& c, int state) {
           c.idx[s] = id;
           c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = 0x7fffffff; c.l.tok_extra[id] = 0u;
         } else {
-          c.idx[s] = -1; c.sh[3] = 1;
+          c.idx[s] = -1; atomicOr(&c.sh[3], 1);
         }
         return;
       }
       if (expected == state) return;
     }
   }
-  c.sh[3] = 1;   // hash full
+  atomicOr(&c.sh[3], 4);   // hash full
 }
 __device__ __forceinline__ int find(Ctx& c, int state) {
   const int mask = c.hash - 1;
@@ -232,7 +232,7 @@ __device__ void nonemitting(Ctx& c, int n0, float cutoff) {
         if (li < c.max_link) {
           c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = 0.f; c.l.link_graph[li] = g.weight[a];
         } else {
-          c.sh[3] = 1;
+          atomicOr(&c.sh[3], 2);
         }
       }
     }
@@ -286,7 +286,7 @@ __device__ void init_decoding(Ctx& c) {
 __device__ void advance(Ctx& c) {
   const Graph& g = c.g;
   const int f = c.l.h->n_frames;
-  if (f >= c.max_frames) { if (threadIdx.x == 0) c.sh[3] = 1; __syncthreads(); return; }
+  if (f >= c.max_frames) { if (threadIdx.x == 0) atomicOr(&c.sh[3], 8); __syncthreads(); return; }
   const int t0 = c.l.tok_off[f], t1 = c.l.tok_off[f + 1];
   // ---- GetCutoff (:650-720)
   float best = INFINITY;
@@ -346,7 +346,7 @@ __device__ void advance(Ctx& c) {
             c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = ac; c.l.link_graph[li] = gc;
             atomicMin(&c.l.tok_cost[id], f2o(tot));
           } else {
-            c.sh[3] = 1;
+            atomicOr(&c.sh[3], 2);
           }
         }
       }

@@ -104,8 +104,11 @@ class WfstSearch:
     def _check_overflow(self):
         h = self._header()
         if h[:, 3].any():
-            raise RuntimeError("WFST search: a capacity (tokens / links / hash slots / frames per utterance) was exhausted; "
-                               "results are invalid -- construct WfstSearch with larger max_tokens / max_links / hash_size")
+            bits = int(np.bitwise_or.reduce(h[:, 3]))
+            what = [n for b, n in ((1, "max_tokens"), (2, "max_links"), (4, "hash_size"), (8, "max_frames")) if bits & b]
+            raise RuntimeError(f"WFST search: a capacity was exhausted ({', '.join(what)} of {self.caps}; peak tokens "
+                               f"{int(h[:, 1].max())}, links {int(h[:, 2].max())}); results are invalid -- construct WfstSearch "
+                               "with larger capacities")
 
     def frames_decoded(self):
         return [int(v) for v in self._header()[:, 0]]

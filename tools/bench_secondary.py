@@ -144,11 +144,23 @@ def stream_32utt_5gram(frames: int = 100):
                          "-> host reads the running best", dtype="f32")
 
 
+def decode_wfst_tlg():
+    """configs[3]/[4] with the reference's own searcher: token passing over T o L o G (production options), and the agreement
+    of the lexicon prefix beam with it (tools/bench_wfst.py)."""
+    import bench_wfst
+    r = bench_wfst.run()
+    r["workload"] = ("32 utterances, WFST token passing (beam 17, max_active 7000, min_active 200, lattice_beam 8, acoustic_scale "
+                     "0.325, nbest 100) over a synthetic 400-word lexicon x word 3-gram T o L o G in HBM; offline = one call + "
+                     "finalize + n-best, streaming = one frame per call with the partial best path read back")
+    r["dtype"] = "f32"
+    return r
+
+
 def all_secondary():
     out = {}
     for name, fn in (("c3_f32", lambda: train_ms("c3", False)), ("c3_amp", lambda: train_ms("c3", True)),
                      ("c2_amp", lambda: train_ms("c2", True)), ("decode_beam100_3gram", decode_beam100_3gram),
-                     ("stream_32utt_5gram", stream_32utt_5gram)):
+                     ("stream_32utt_5gram", stream_32utt_5gram), ("decode_wfst_tlg", decode_wfst_tlg)):
         sys.stderr.write(f"[secondary] {name} ...\n"); sys.stderr.flush()
         try:
             out[name] = fn()

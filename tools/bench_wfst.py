@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""WFST decode on one MI355X (BASELINE configs[3]/[4] with the reference's searcher: token passing over T o L o G with the
+production options, language-model-standalone.py:486-496) and the measured gap of the lexicon prefix beam that stood in
+for it in round 1:
+  * offline: 32 utterances in one call (search + finalize + n-best 100) -> ms per utterance
+  * streaming: 32 concurrent utterances, one frame per call, partial best path read back every frame -> p50 / p95 per frame
+  * agreement: 1-best word error rate and n-best overlap of b2t_prefix_beam_search_lex_f32 (beams 10/16 and 16/64) against
+    the WFST search, and of the WFST search against the spelled truth
+Synthetic lexicon + word 3-gram (the reference's LMs are not in the checkout); sizes are printed."""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "nejm-brain-to-text_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import b2t_native as N      # noqa: E402
+import b2t_ops as ops       # noqa: E402
+import ngram_lm             # noqa: E402
+import wfst                 # noqa: E402
+from wfst_decoder import WfstSearch   # noqa: E402
+import lm_decoder           # noqa: E402
+
+
+def edit(a, b):
+    prev = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        cur = [i] + [0] * len(b)
+        for j in range(1, len(b) + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (a[i - 1] != b[j - 1]))
+        prev = cur
+    return prev[len(b)]
+
+
+def make(n_words=int(os.environ.get("B2T_WFST_WORDS", "400")), n_per_order=3000, U=32, seed=0, noise=0.9):
+    t0 = time.time()
+    prons = ngram_lm.synthetic_lexicon(n_words, 41, seed=seed + 1)
+    words = sorted(prons)
+    arpa = ngram_lm.synthetic_word_arpa(words, 3, n_per_order, seed=seed + 2)
+    g = wfst.build_tlg(prons, arpa, sil_prob=0.5)
+    build_s = time.time() - t0
+    rs = np.random.RandomState(seed)
+    seqs, rows = [], []
+    for u in range(U):
+        seq = [words[i] for i in rs.randint(n_words, size=rs.randint(4, 9))]
+        frames = []
+        for w in seq:
+            prev = -1
+            for c in list(prons[w][0]) + [1]:
+                if c == prev:
+                    frames.append(0)
+                frames += [c] * rs.randint(1, 3) + [0] * rs.randint(0, 2)
+                prev = c
+        lg = np.full((len(frames), 41), -2.0, np.float32)
+        for t, c in enumerate(frames):
+            lg[t, c] = 3.0
+        lg += rs.standard_normal(lg.shape).astype(np.float32) * noise
+        seqs.append(seq); rows.append(lg)
+    T = max(r.shape[0] for r in rows)
+    logits = np.zeros((U, T, 41), np.float32); logits[:, :, 0] = 5.0      # padding frames: blank
+    lens = np.array([r.shape[0] for r in rows], np.int32)
+    for u, r in enumerate(rows):
+        logits[u, :r.shape[0]] = r
+    return prons, words, arpa, g, seqs, logits, lens, build_s
+
+
+class Opt:
+    max_active, min_active, beam, lattice_beam, acoustic_scale = 7000, 200, 17.0, 8.0, 0.325
+    ctc_blank_skip_threshold, length_penalty, nbest = 1.0, 0.0, 100
+
+
+def run():
+    lib = N.load(); dev = torch.device("cuda:0"); _p = ops._p
+    prons, words, arpa, g, seqs, logits, lens, build_s = make()
+    U, T, C = logits.shape
+    lg = torch.from_numpy(logits).to(dev); pri = torch.zeros_like(lg); lp = torch.empty_like(lg)
+    N.check(lib.b2t_lm_prologue_f32(_p(lg), _p(pri), float(math.log(90.0)), _p(lp), U * T, C, ops._stream()), "prologue")
+    sys.stderr.write(f"TLG: {g.n_states} states, {g.n_arcs} arcs, built in {build_s:.1f} s; {U} x {T} frames\n")
+    S = WfstSearch(g, Opt, U=U, max_frames=T + 8, max_tokens=1 << 22, max_links=1 << 24)
+    ts = []
+    for rep in range(3):
+        S.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        N.check(lib.b2t_lm_prologue_f32(_p(lg), _p(pri), float(math.log(90.0)), _p(lp), U * T, C, ops._stream()), "prologue")
+        S.search(lp, lens)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        fin = S.finalize()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        ts.append((t1 - t0, t2 - t1))
+    search_ms, fin_ms = min(t[0] for t in ts) * 1e3, min(t[1] for t in ts) * 1e3
+    hdr = S._header()
+    tok_per_frame = float(hdr[:, 1].sum()) / float(hdr[:, 0].sum())
+    # streaming: one frame per call for all U utterances, partial best path read back
+    S.reset()
+    lat = []
+    for t in range(T):
+        fr = lp[:, t:t + 1].contiguous()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        S.search(fr, np.minimum(1, np.maximum(0, lens - t)).astype(np.int32))
+        S.best_path(False, max_len=2 * T + 8)
+        lat.append(time.perf_counter() - t0)
+    lat = np.array(lat[5:]) * 1e3
+    S.finalize()
+    # agreement
+    wfst_1 = [[g.words[w] for w in f[0][2]] if f else [] for f in fin]
+    err_truth = sum(edit(h, r) for h, r in zip(wfst_1, seqs)); nref = sum(len(r) for r in seqs)
+    out = dict(graph=dict(words=len(words), tlg_states=int(g.n_states), tlg_arcs=int(g.n_arcs), mb=round(g.nbytes() / 1e6, 1),
+                          host_build_s=round(build_s, 1)),
+               offline=dict(utterances=U, frames=int(T), search_ms=round(search_ms, 2), finalize_nbest100_ms=round(fin_ms, 2),
+                            ms_per_utterance=round((search_ms + fin_ms) / U, 3), tokens_per_frame=round(tok_per_frame, 1)),
+               streaming=dict(p50_ms_per_frame=round(float(np.percentile(lat, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat, 95)), 3)),
+               wfst_wer_vs_truth=round(err_truth / nref, 4))
+    # the round-1 substitute: lexicon-constrained prefix beam + word n-gram (b2t_prefix_beam_search_lex_f32)
+    lex = ngram_lm.Lexicon(prons, C)
+    wlm = ngram_lm.SparseNGramLM.from_arpa(arpa, lex.words)
+    for fb, sb in ((10, 16), (16, 64), (16, 128)):
+        opts = lm_decoder.DecodeOptions(7000, 200, 17.0, 8.0, 0.325, 1.0, 0.0, 100)
+        opts.first_beam_size, opts.second_beam_size = fb, sb
+        opts.lm_alpha, opts.lm_beta, opts.lm_eos = 1.0 / 0.325, 0.0, True     # graph cost : acoustic cost = 1 : 0.325
+        res = lm_decoder.DecodeResource("", "", "", "", "")
+        res.set_lexicon_lm(lex, wlm, sil=1)
+        errs, overlap, n_over = 0, 0, 0
+        t0 = time.perf_counter()
+        for u in range(U):
+            dec = lm_decoder.BrainSpeechDecoder(res, opts, max_len=T + 8)
+            dec.Decode(lp[u, :lens[u]])
+            hyp = dec.result()
+            h1 = hyp[0].sentence.split() if hyp else []
+            errs += edit(h1, wfst_1[u])
+            ref_set = set(" ".join(g.words[w] for w in e[2]) for e in fin[u][:10])
+            got_set = set(r.sentence for r in hyp[:10])
+            overlap += len(ref_set & got_set); n_over += len(ref_set)
+        dt = time.perf_counter() - t0
+        out[f"prefix_beam_lex_{fb}_{sb}"] = dict(wer_vs_wfst_1best=round(errs / max(1, sum(len(w) for w in wfst_1)), 4),
+                                                  top10_overlap_with_wfst=round(overlap / max(1, n_over), 3),
+                                                  ms_per_utterance_incl_host=round(dt / U * 1e3, 2))
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(), indent=1))
