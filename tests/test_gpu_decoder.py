@@ -133,10 +133,10 @@ def test_lm_decoder_surface_and_prologue():
     lm_decoder.DecodeNumpyLogProbs(dec, lp)
     assert tuple(int(t) for t in dec.result()[0].tokens) == tuple(ref[0][0])
     assert lm_decoder.process_blank("▁HELLO▁▁WORLD▁") == "hello world"
-    with pytest.raises(NotImplementedError):
-        lm_decoder.DecodeResource("TLG.fst", "", "", "words.txt", "")
-    with pytest.raises(NotImplementedError):
-        dec.Rescore()
+    with pytest.raises(FileNotFoundError):          # a graph path is read (tests/test_gpu_wfst.py decodes with one)
+        lm_decoder.DecodeResource("/nonexistent/TLG.fst", "", "", "", "")
+    with pytest.raises(RuntimeError, match="WFST"):
+        dec.Rescore()                                # lattice rescoring belongs to the graph searcher
 
 
 # ---- n-gram fusion (b2t_prefix_beam_search_lm_f32) ---------------------------------------------------------------
