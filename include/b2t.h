@@ -180,6 +180,8 @@ typedef struct b2t_pass_t {
   int save;                  /* != 0: keep what backward needs (gate reserves, layer outputs, U) */
   float in_drop, rnn_drop;   /* dropout probabilities (rnn_model.py:102-103, nn.GRU dropout); 0 in eval */
   uint64_t seed;             /* Philox key of this pass's dropout masks (backward must get the same) */
+  int chunks_bwd;            /* time chunks of the backward pass (0: same as `chunks`) */
+  int wgrad_chunk_mask;      /* bit l: layer l's weight gradients accumulate chunk by chunk instead of once per layer */
 } b2t_pass_t;
 typedef struct b2t_exec b2t_exec;
 int b2t_exec_create(int n_layers, b2t_exec** out);
@@ -364,6 +366,13 @@ int b2t_wfst_best_path(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, cons
                        int32_t* n_words, float* costs, void* stream);
 /* FinalizeDecoding: final costs + backward pruning with lattice_beam; marks the surviving forward links. */
 int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream);
+/* The pruned lattice in compact form, after b2t_wfst_finalize (GetRawLattice, lattice-faster-decoder.cc:106-186): surviving
+ * tokens renumbered, surviving links as arcs with acoustic = link acoustic cost - the frame's cost offset, final costs of
+ * the last frame's tokens.  Per utterance u: arcs at [u * cap_arcs ..), finals at [u * cap_final ..),
+ * counts[5u ..] = {n_states, n_arcs, n_final, start state, 1 if a capacity was too small}. */
+int b2t_wfst_lattice(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, int cap_arcs, int cap_final,
+                     int32_t* counts, int32_t* src, int32_t* dst, int32_t* ilabel, int32_t* olabel, float* graph,
+                     float* acoustic, int32_t* final_state, float* final_cost, void* stream);
 /* Byte offsets of the arrays inside ONE utterance's state block, for copying the pruned lattice out:
  * off16 = {header, mapping, tok_off, link_off, cost_offset, tok_state, tok_cost (order-preserving u32 of the f32 cost),
  * tok_extra, link_src, link_dst, link_arc, link_ac, link_graph, link_alive (u8), tok_best, last_prob}. */

@@ -59,7 +59,7 @@ class PassDesc(C.Structure):
     """Mirror of b2t_pass_t (include/b2t.h)."""
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("chunks", C.c_int), ("fwd_mode", C.c_int), ("bwd_mode", C.c_int),
                 ("bf16_gemm", C.c_int), ("save", C.c_int), ("in_drop", C.c_float), ("rnn_drop", C.c_float),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("chunks_bwd", C.c_int), ("wgrad_chunk_mask", C.c_int)]
 
 
 BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
@@ -133,6 +133,8 @@ _SIGNATURES = {
     "b2t_wfst_best_path": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP,
                                     VP, VP, VP]),
     "b2t_wfst_finalize": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, VP]),
+    "b2t_wfst_lattice": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP,
+                                  VP, VP, VP, VP, VP]),
     "b2t_wfst_state_offsets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LL)]),
     "b2t_lattice_nbest_host": (C.c_int, [C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, C.c_int, VP, VP, C.c_int,
                                          C.c_float, VP, VP, C.c_int, VP, VP, C.c_int, VP]),

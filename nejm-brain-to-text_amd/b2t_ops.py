@@ -246,7 +246,13 @@ class Grads(Params):
 GRU_MODE = {"value": int(os.environ.get("B2T_GRU_MODE", "-1"))}
 MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its workgroups resident at once
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer on the caller's stream).
-PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "6"))}
+PIPELINE = {"chunks": int(os.environ.get("B2T_CHUNKS", "6")),
+            # the backward pass is bound by its GEMMs (0.75 TFLOP next to the sweeps) and prefers fewer, larger launches:
+            # 6 / 4 measured 23.2 ms against 23.6 for 6 / 6 (6 / 3: 23.6, 6 / 2: 24.2, 8 / 4: 23.1-23.2); 0 = same as forward
+            "chunks_bwd": int(os.environ.get("B2T_CHUNKS_BWD", "4")),
+            # bit l: layer l's weight gradients accumulate per chunk (measured slower again under the C++ plan: layer 0 only
+            # 24.5 ms, layers 0-1 24.8 ms against 23.6 -- the extra GEMM launches take CUs from the sweeps they run next to)
+            "wgrad_chunk_mask": int(os.environ.get("B2T_WGRAD_CHUNK_MASK", "0"))}
 
 
 def gru_mode_for(B: int, H: int) -> int:
@@ -415,6 +421,8 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ps.fwd_mode, ps.bwd_mode = sweep_mode_arg(mode, H, "f"), sweep_mode_arg(mode, H, "b")
     ps.bf16_gemm, ps.save = int(AMP["on"]), int(bool(save))
     ps.in_drop, ps.rnn_drop, ps.seed = float(in_drop), float(rnn_drop if L > 1 else 0.0), int(seed) & (2 ** 64 - 1)
+    ps.chunks_bwd = 0 if ps.chunks == 1 else max(0, min(PIPELINE["chunks_bwd"], Tp // 16))
+    ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
     md = prm.desc(dims)
     nbytes = lib.b2t_pass_ws_bytes(C.byref(md), C.byref(ps))
     if nbytes == 0:

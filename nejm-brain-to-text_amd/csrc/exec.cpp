@@ -386,30 +386,34 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
 namespace b2t {
 namespace {
 
-// dW_hh = dGh^T h_prev, dW_ih = dGi^T in, bias gradients = column sums of dG (layer l) over all T' time rows
+// dW_hh = dGh^T h_prev, dW_ih = dGi^T in, bias gradients = column sums of dG (layer l) over the time rows [t0, t1):
+// the whole sequence at once (t0 = 0, t1 = T', accumulate = 0), or chunk by chunk as soon as a chunk is swept (the first
+// chunk processed overwrites, later ones accumulate in a fixed order: deterministic); `final` copies the bias sums out.
 void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t_model_t* grd, const b2t_pass_t* p,
-                        Layout& w, int l, int Tp) {
+                        Layout& w, int l, int t0, int t1, int accumulate, bool final) {
   const int B = p->B, T = p->T, F = prm->F, H = prm->H;
-  const long long K = (long long)Tp * B;
+  const long long K = (long long)(t1 - t0) * B;
+  const long long a0 = (long long)t0 * B * 4 * H;
   void* sp = reinterpret_cast<void*>(s);
   {
-    b2t_gemm_desc d = gd(w.dG[l], w.out[l], grd->w_hh[l], 3 * H, H, (int)K);
+    b2t_gemm_desc d = gd(w.dG[l] + a0, w.out[l] + (long long)t0 * B * H, grd->w_hh[l], 3 * H, H, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    c.gemm(s, d, splitk_for(3 * H, H, K), w.slab[l]);
+    c.gemm(s, d, splitk_for(3 * H, H, K), w.slab[l], accumulate);
   }
   int In; const float* inp; long long b_s0, b_s1 = 0; int b_div = 0;
   if (l == 0) {
-    In = in0(prm); inp = w.Ud;
+    In = in0(prm);
     b_div = B; b_s1 = prm->patch > 0 ? (long long)prm->stride * F : F; b_s0 = (long long)T * F;
+    inp = w.Ud + (long long)t0 * b_s1;
   } else {
-    In = H; inp = w.outd[l - 1] + (long long)B * H;   // skip the initial-state slot
+    In = H; inp = w.outd[l - 1] + (long long)(1 + t0) * B * H;   // skip the initial-state slot
     b_s0 = H;
   }
   auto wih = [&](int M, long long a_off, long long c_off, int brk, int gap) {
-    b2t_gemm_desc d = gd(w.dG[l] + a_off, inp, grd->w_ih[l] + c_off, M, In, (int)K);
+    b2t_gemm_desc d = gd(w.dG[l] + a0 + a_off, inp, grd->w_ih[l] + c_off, M, In, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = b_s0; d.b_s1 = b_s1; d.b_div = b_div; d.c_s0 = In;
     d.a_brk = brk; d.a_gap = gap;
-    c.gemm(s, d, splitk_for(M, In, K), w.slab[l]);
+    c.gemm(s, d, splitk_for(M, In, K), w.slab[l], accumulate);
   };
   if ((2 * H) % 128 == 0 && (3 * H) % 128 == 0) {   // dGi^T as ONE operand with a gap along m
     wih(3 * H, 0, 0, 2 * H, H);
@@ -417,7 +421,8 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     wih(2 * H, 0, 0, 0, 0);
     wih(H, 3 * H, (long long)2 * H * In, 0, 0);
   }
-  c.call(b2t_colsum_f32(w.dG[l], K, 4 * H, 4 * H, w.s4[l], 0, w.cs_layer[l], 1, 0, 0, sp));   // (s_r, s_z, s_nr, s_n)
+  c.call(b2t_colsum_f32(w.dG[l] + a0, K, 4 * H, 4 * H, w.s4[l], accumulate, w.cs_layer[l], 1, 0, 0, sp));   // (s_r, s_z, s_nr, s_n)
+  if (!final) return;
   auto cp = [&](float* dst, const float* src, size_t n) {
     c.call(check_hip(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s), "model_backward: bias gradient copy"));
   };
@@ -452,7 +457,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   auto cb = [&](int id, hipStream_t s) { if (bucket_cb && !c.rc) bucket_cb(user, id, reinterpret_cast<void*>(s)); };
 
   int chunks[MAXC][2];
-  const int nc = make_chunks(Tp, p->chunks, chunks);
+  const int nc = make_chunks(Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks, chunks);
   const bool piped = nc > 1;
 
   // head: d_out[t,b,:] = dlogits[b,t,:] W_out ; dW_out = dlogits^T out ; db_out = colsum
@@ -539,14 +544,18 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       if (piped) c.wait(sg, ev_bs[l][ci]);
       dx_gemm(sg, l, t0, n);
       if (piped) ev_dx[l][ci] = c.record(sg);
-      if (ci == 0) {
-        // weight gradients of the whole layer once its last chunk is swept, on a GEMM stream (they overlap the sweeps of
-        // the layers below).  Layer 0's go to the top layer's GEMM stream (idle by then) so that they overlap the
-        // day-layer backward instead of queueing in front of it.
+      // Weight gradients on a GEMM stream.  Layers >= 1: the whole layer once its last chunk is swept (they overlap the
+      // sweeps of the layers below; per-chunk launches there were measured slower: more launches competing for the
+      // sweeps' CUs).  Layer 0 has no layer below to hide behind -- its 100 GFLOP used to sit in the step's tail -- so its
+      // weight gradients accumulate chunk by chunk on the top layer's GEMM stream (idle by then), and only the last
+      // chunk's share follows the last sweep.
+      const bool per_chunk = piped && ((p->wgrad_chunk_mask >> l) & 1);
+      if (per_chunk || ci == 0) {
         hipStream_t swg = !piped ? main : ((l == 0 && L > 1) ? ex->s_gemm[L - 1] : ex->s_gemm[l]);
         if (piped) c.wait(swg, ev_bs[l][ci]);
-        layer_weight_grads(c, swg, prm, grd, p, w, l, Tp);
-        cb(1 + l, swg);
+        if (per_chunk) layer_weight_grads(c, swg, prm, grd, p, w, l, t0, t1, ci == nc - 1 ? 0 : 1, ci == 0);
+        else layer_weight_grads(c, swg, prm, grd, p, w, l, 0, Tp, 0, true);
+        if (ci == 0) cb(1 + l, swg);
       }
     }
   }

@@ -24,7 +24,7 @@
 namespace b2t {
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 1024;   // one workgroup per utterance; a frame holds thousands of tokens, each a dependent chain of gathers
 constexpr unsigned UMAX = 0xffffffffu;
 constexpr int MAX_C = 64;
 
@@ -44,7 +44,8 @@ struct Hdr {
   int finalized;
   float final_best;    // best (cost + final cost) on the last frame
   int has_final;
-  int pad[6];
+  unsigned arcs_lo, arcs_hi;   // emitting arcs expanded so far (64-bit): 16 B of graph each, the algorithmic traffic of the search
+  int pad[4];
 };
 
 struct Lay {
@@ -261,7 +262,7 @@ __device__ void init_decoding(Ctx& c) {
   if (threadIdx.x == 0) {
     Hdr* h = c.l.h;
     h->n_frames = 0; h->overflow = 0; h->num_input = 0; h->is_last_blank = 0; h->last_best = 0; h->finalized = 0;
-    h->final_best = 0.f; h->has_final = 0;
+    h->final_best = 0.f; h->has_final = 0; h->arcs_lo = 0u; h->arcs_hi = 0u;
     c.sh[0] = 0; c.sh[1] = 0; c.sh[3] = 0;
     c.l.tok_off[0] = 0;
     c.l.link_off[0] = 0;
@@ -309,10 +310,12 @@ __device__ void advance(Ctx& c) {
   const float lp = c.o.length_penalty;
   // ---- ProcessEmitting (:722-824), pass A: the frame's best candidate -> next_cutoff
   float mn = INFINITY;
+  int narcs = 0;
   for (int t = t0 + threadIdx.x; t < t1; t += NT) {
     const float cur = o2f(c.l.tok_cost[t]);
     if (!(cur <= cur_cutoff)) continue;
     const int s = c.l.tok_state[t];
+    narcs += g.row[s + 1] - g.row[s] - g.n_eps[s];
     for (int a = g.row[s] + g.n_eps[s]; a < g.row[s + 1]; ++a) {
       const float ac = cost_offset - c.ll[g.ilabel[a] - 1];
       float gc = g.weight[a];
@@ -321,6 +324,12 @@ __device__ void advance(Ctx& c) {
     }
   }
   mn = block_min(c, mn);
+  narcs = block_sum(c, narcs);
+  if (threadIdx.x == 0) {
+    const unsigned lo = c.l.h->arcs_lo + (unsigned)narcs;
+    if (lo < c.l.h->arcs_lo) c.l.h->arcs_hi += 1u;
+    c.l.h->arcs_lo = lo;
+  }
   const float next_cutoff = mn + adaptive;
   clear_hash(c);
   const int n0 = min(c.sh[0], c.max_tok), l0 = min(c.sh[1], c.max_link);
@@ -562,6 +571,58 @@ __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state,
   }
 }
 
+// The pruned lattice in compact form (GetRawLattice, lattice-faster-decoder.cc:106-186, after FinalizeDecoding): surviving
+// tokens renumbered 0..n-1, surviving links as arcs (src, dst, ilabel, olabel, graph, acoustic - cost_offset), final costs
+// of the last frame's tokens.  counts[u] = {n_states, n_arcs, n_final, start state, overflow}.
+__global__ __launch_bounds__(NT) void wfst_lattice_kernel(Graph g, char* state, size_t state_bytes, int max_frames, int max_tok,
+                                                           int max_link, int hash, int cap_arcs, int cap_final, int* counts,
+                                                           int* a_src, int* a_dst, int* a_il, int* a_ol, float* a_graph,
+                                                           float* a_ac, int* f_state, float* f_cost) {
+  __shared__ int cnt[3];
+  const int u = blockIdx.x;
+  Lay l;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
+  const int F = l.h->n_frames;
+  const int n_tok = min(l.h->n_tok, max_tok);
+  const unsigned INF_BITS = 0x7f800000u;
+  if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int* newid = reinterpret_cast<int*>(l.tok_prev);     // free after finalize
+  for (int t = threadIdx.x; t < n_tok; t += NT) newid[t] = l.tok_extra[t] != INF_BITS ? atomicAdd(&cnt[0], 1) : -1;
+  __syncthreads();
+  const size_t ao = (size_t)u * cap_arcs, fo = (size_t)u * cap_final;
+  for (int f = 0; f <= F; ++f) {
+    const int e0 = l.link_off[2 * f], e1 = l.link_off[2 * f + 1];
+    const int m1 = f < F ? l.link_off[2 * f + 2] : e1;
+    const float off = f < F ? l.cost_offset[f] : 0.f;
+    for (int li = e0 + threadIdx.x; li < m1; li += NT) {
+      if (!l.link_alive[li]) continue;
+      const int s = newid[l.link_src[li]], d = newid[l.link_dst[li]];
+      if (s < 0 || d < 0) continue;
+      const int k = atomicAdd(&cnt[1], 1);
+      if (k >= cap_arcs) continue;
+      const int a = l.link_arc[li];
+      a_src[ao + k] = s; a_dst[ao + k] = d; a_il[ao + k] = g.ilabel[a]; a_ol[ao + k] = g.olabel[a];
+      a_graph[ao + k] = l.link_graph[li];
+      a_ac[ao + k] = li >= e1 ? l.link_ac[li] - off : l.link_ac[li];   // emitting links carry the frame's cost offset
+    }
+  }
+  const int t0 = l.tok_off[F], t1 = l.tok_off[F + 1];
+  for (int t = t0 + threadIdx.x; t < t1; t += NT) {
+    if (newid[t] < 0) continue;
+    const float fc = l.h->has_final ? g.final_cost[l.tok_state[t]] : 0.f;
+    if (fc == INFINITY) continue;
+    const int k = atomicAdd(&cnt[2], 1);
+    if (k < cap_final) { f_state[fo + k] = newid[t]; f_cost[fo + k] = fc; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counts[5 * u] = cnt[0]; counts[5 * u + 1] = min(cnt[1], cap_arcs); counts[5 * u + 2] = min(cnt[2], cap_final);
+    counts[5 * u + 3] = n_tok > 0 ? newid[0] : -1;
+    counts[5 * u + 4] = (cnt[1] > cap_arcs || cnt[2] > cap_final) ? 1 : 0;
+  }
+}
+
 }  // namespace b2t
 
 using namespace b2t;
@@ -634,6 +695,20 @@ extern "C" int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_
   hipLaunchKernelGGL(wfst_finalize_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
                      o->max_frames, o->max_tokens, o->max_links, o->hash_size);
   B2T_CHECK_LAUNCH("b2t_wfst_finalize");
+  return 0;
+}
+
+extern "C" int b2t_wfst_lattice(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, int cap_arcs, int cap_final,
+                                int32_t* counts, int32_t* src, int32_t* dst, int32_t* ilabel, int32_t* olabel, float* graph,
+                                float* acoustic, int32_t* final_state, float* final_cost, void* stream) {
+  { int rc = check_args(g, o, state, U, "wfst_lattice"); if (rc) return rc; }
+  B2T_REQUIRE(cap_arcs > 0 && cap_final > 0 && counts && src && dst && ilabel && olabel && graph && acoustic && final_state && final_cost,
+              "wfst_lattice: null output / zero capacity");
+  const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
+  hipLaunchKernelGGL(wfst_lattice_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, o->max_frames,
+                     o->max_tokens, o->max_links, o->hash_size, cap_arcs, cap_final, counts, src, dst, ilabel, olabel, graph, acoustic,
+                     final_state, final_cost);
+  B2T_CHECK_LAUNCH("b2t_wfst_lattice");
   return 0;
 }
 

@@ -253,12 +253,7 @@ class BrainSpeechDecoder:
             raise RuntimeError("Rescore() needs both grammars (DecodeResource lm_fst_path / rescore_lm_fst_path or set_rescore_grammars)")
         import wfst
         keep = len(self._result)
-        old_n = self.wfst.nbest
-        self.wfst.nbest = max(10 * keep, 100)
-        try:
-            deep = self.wfst._nbest_of(0, self.wfst._header()[0])
-        finally:
-            self.wfst.nbest = old_n
+        deep = self.wfst._nbest_all(max(10 * keep, 100))[0]
         rescored = []
         for inp, tm, words, lm, ac in deep:
             g_old = wfst.grammar_score(self.res.lm_fst, words, self.res.backoff_label)

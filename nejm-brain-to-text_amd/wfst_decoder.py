@@ -99,7 +99,7 @@ class WfstSearch:
 
     def _header(self):
         st = self.state.view(self.U, self.state_bytes)
-        return st[:, self.off[0]:self.off[0] + 40].contiguous().view(torch.int32).cpu().numpy()
+        return st[:, self.off[0]:self.off[0] + 48].contiguous().view(torch.int32).cpu().numpy()
 
     def _check_overflow(self):
         h = self._header()
@@ -109,6 +109,11 @@ class WfstSearch:
             raise RuntimeError(f"WFST search: a capacity was exhausted ({', '.join(what)} of {self.caps}; peak tokens "
                                f"{int(h[:, 1].max())}, links {int(h[:, 2].max())}); results are invalid -- construct WfstSearch "
                                "with larger capacities")
+
+    def arcs_expanded(self):
+        """Emitting graph arcs examined so far, per utterance (16 B of graph each: the search's algorithmic traffic)."""
+        h = self._header().astype(np.int64)
+        return [int((h[u, 11] & 0xffffffff) << 32 | (h[u, 10] & 0xffffffff)) for u in range(self.U)]
 
     def frames_decoded(self):
         return [int(v) for v in self._header()[:, 0]]
@@ -123,58 +128,60 @@ class WfstSearch:
         self._check_overflow()
         if self.nbest == 1:
             return [[r] if self.frames_decoded()[u] > 0 else [] for u, r in enumerate(self.best_path(True))]
+        return self._nbest_all(self.nbest)
+
+    def _lattices(self, cap_arcs: int = 1 << 18, cap_final: int = 1 << 13):
+        """The pruned lattices of all utterances, compacted on the GPU (b2t_wfst_lattice) and copied out once."""
+        U, dev = self.U, self.device
+        while True:
+            counts = torch.zeros((U, 5), dtype=torch.int32, device=dev)
+            ia = [torch.empty((U, cap_arcs), dtype=torch.int32, device=dev) for _ in range(4)]
+            fa = [torch.empty((U, cap_arcs), dtype=torch.float32, device=dev) for _ in range(2)]
+            fs = torch.empty((U, cap_final), dtype=torch.int32, device=dev); fc = torch.empty((U, cap_final), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                N.check(self.lib.b2t_wfst_lattice(C.byref(self.cg), C.byref(self.co), ops._p(self.state), U, cap_arcs, cap_final,
+                                                  ops._p(counts), ops._p(ia[0]), ops._p(ia[1]), ops._p(ia[2]), ops._p(ia[3]), ops._p(fa[0]),
+                                                  ops._p(fa[1]), ops._p(fs), ops._p(fc), self._s()), "b2t_wfst_lattice")
+            cn = counts.cpu().numpy()
+            if not cn[:, 4].any():
+                break
+            cap_arcs, cap_final = cap_arcs * 4, cap_final * 4      # a lattice did not fit: retry with more room
+        na = int(cn[:, 1].max()); nf = int(cn[:, 2].max())
+        host = [t[:, :max(na, 1)].cpu().numpy() for t in ia + fa] + [fs[:, :max(nf, 1)].cpu().numpy(), fc[:, :max(nf, 1)].cpu().numpy()]
+        return cn, host
+
+    def _nbest_all(self, nbest: int):
         hdr = self._header()
+        cn, (src, dst, il, ol, gr, ac, fs, fc) = self._lattices()
+        mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
         out = []
+        P = lambda x: x.ctypes.data_as(C.c_void_p)
         for u in range(self.U):
-            out.append(self._nbest_of(u, hdr[u]))
+            F = int(hdr[u, 0])
+            n_states, n_arcs, n_final, start = (int(v) for v in cn[u, :4])
+            if F == 0 or n_states == 0 or start < 0:
+                out.append([]); continue
+            a = [np.ascontiguousarray(x[u, :n_arcs]) for x in (src, dst, il, ol, gr, ac)]
+            f_s, f_c = np.ascontiguousarray(fs[u, :n_final]), np.ascontiguousarray(fc[u, :n_final])
+            w_cap = a_cap = nbest * (2 * F + 16) + 16
+            ow = np.zeros(w_cap, dtype=np.int32); oa = np.zeros(a_cap, dtype=np.int32)
+            woff = np.zeros(nbest + 1, dtype=np.int32); aoff = np.zeros(nbest + 1, dtype=np.int32); costs = np.zeros(2 * nbest, dtype=np.float32)
+            n = self.lib.b2t_lattice_nbest_host(n_states, start, n_arcs, P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(a[4]), P(a[5]), n_final,
+                                                P(f_s), P(f_c), nbest, C.c_float(self.lattice_beam), P(ow), P(woff), w_cap, P(oa),
+                                                P(aoff), a_cap, P(costs))
+            if n < 0:
+                raise RuntimeError("b2t_lattice_nbest_host failed: " + N.last_error())
+            mapping = mapping_all[u, :F]
+            res = []
+            for k in range(n):
+                ali = oa[aoff[k]:aoff[k + 1]]
+                inp, tm = convert_to_inputs(ali, mapping if len(ali) == F else np.arange(len(ali)))
+                res.append((inp, tm, [int(w) for w in ow[woff[k]:woff[k + 1]]], -float(costs[2 * k]), -float(costs[2 * k + 1])))
+            out.append(res)
         return out
 
-    def _arr(self, u, which, count, dtype):
-        base = u * self.state_bytes + self.off[which]
-        nb = count * np.dtype(dtype).itemsize
-        return np.frombuffer(self.state[base:base + nb].cpu().numpy().tobytes(), dtype=dtype)
-
-    def _nbest_of(self, u, h):
-        F, n_tok, n_link = int(h[0]), int(h[1]), int(h[2])
-        if F == 0:
-            return []
-        mf = self.caps[0]
-        tok_off = self._arr(u, 2, F + 2, np.int32); link_off = self._arr(u, 3, 2 * F + 2, np.int32)
-        mapping = self._arr(u, 1, F, np.int32); cost_off = self._arr(u, 4, F, np.float32)
-        tok_state = self._arr(u, 5, n_tok, np.int32); tok_extra = self._arr(u, 7, n_tok, np.float32)
-        src, dst, arc = (self._arr(u, k, n_link, np.int32) for k in (8, 9, 10))
-        ac, gr = self._arr(u, 11, n_link, np.float32), self._arr(u, 12, n_link, np.float32)
-        alive = self._arr(u, 13, n_link, np.uint8).astype(bool)
-        # acoustic cost of an emitting link has the frame's cost offset in it (GetRawLattice takes it out, :150-160)
-        il, ol = self.g.ilabel[arc], self.g.olabel[arc]
-        frame_of_link = np.zeros(n_link, dtype=np.int64)
-        for f in range(F):
-            frame_of_link[link_off[2 * f + 1]:link_off[2 * f + 2]] = f
-        ac = np.where(il != 0, ac - cost_off[frame_of_link], ac).astype(np.float32)
-        keep = alive & np.isfinite(tok_extra[src]) & np.isfinite(tok_extra[dst])
-        t0, t1 = int(tok_off[F]), int(tok_off[F + 1])
-        has_final = bool(h[9])
-        last = np.arange(t0, t1, dtype=np.int32)
-        fc = self.g.final[tok_state[t0:t1]] if has_final else np.zeros(t1 - t0, dtype=np.float32)
-        ok = np.isfinite(fc) & np.isfinite(tok_extra[t0:t1])
-        fs, fcost = np.ascontiguousarray(last[ok]), np.ascontiguousarray(fc[ok].astype(np.float32))
-        a = [np.ascontiguousarray(x[keep]) for x in (src, dst, il.astype(np.int32), ol.astype(np.int32), gr, ac)]
-        nb = self.nbest
-        w_cap = a_cap = nb * (2 * F + 16) + 16
-        ow = np.zeros(w_cap, dtype=np.int32); oa = np.zeros(a_cap, dtype=np.int32)
-        woff = np.zeros(nb + 1, dtype=np.int32); aoff = np.zeros(nb + 1, dtype=np.int32); costs = np.zeros(2 * nb, dtype=np.float32)
-        P = lambda x: x.ctypes.data_as(C.c_void_p)
-        n = self.lib.b2t_lattice_nbest_host(n_tok, 0, int(a[0].shape[0]), P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(a[4]), P(a[5]),
-                                            int(fs.shape[0]), P(fs), P(fcost), nb, C.c_float(self.lattice_beam), P(ow), P(woff), w_cap,
-                                            P(oa), P(aoff), a_cap, P(costs))
-        if n < 0:
-            raise RuntimeError("b2t_lattice_nbest_host failed: " + N.last_error())
-        res = []
-        for k in range(n):
-            ali = oa[aoff[k]:aoff[k + 1]]
-            inp, tm = convert_to_inputs(ali, mapping[:len(ali)] if len(ali) == F else np.arange(len(ali)))
-            res.append((inp, tm, [int(w) for w in ow[woff[k]:woff[k + 1]]], -float(costs[2 * k]), -float(costs[2 * k + 1])))
-        return res
+    def _nbest_of(self, u, h, nbest=None):
+        return self._nbest_all(nbest or self.nbest)[u]
 
 
 def convert_to_inputs(alignment, frames):

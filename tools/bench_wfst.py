@@ -95,6 +95,8 @@ def run():
     search_ms, fin_ms = min(t[0] for t in ts) * 1e3, min(t[1] for t in ts) * 1e3
     hdr = S._header()
     tok_per_frame = float(hdr[:, 1].sum()) / float(hdr[:, 0].sum())
+    # algorithmic bytes of the search: 16 B per expanded arc + 20 B per token + 21 B per forward link
+    alg_bytes = 16.0 * sum(S.arcs_expanded()) + 20.0 * float(hdr[:, 1].sum()) + 21.0 * float(hdr[:, 2].sum())
     # streaming: one frame per call for all U utterances, partial best path read back
     S.reset()
     lat = []
@@ -112,7 +114,9 @@ def run():
     out = dict(graph=dict(words=len(words), tlg_states=int(g.n_states), tlg_arcs=int(g.n_arcs), mb=round(g.nbytes() / 1e6, 1),
                           host_build_s=round(build_s, 1)),
                offline=dict(utterances=U, frames=int(T), search_ms=round(search_ms, 2), finalize_nbest100_ms=round(fin_ms, 2),
-                            ms_per_utterance=round((search_ms + fin_ms) / U, 3), tokens_per_frame=round(tok_per_frame, 1)),
+                            ms_per_utterance=round((search_ms + fin_ms) / U, 3), tokens_per_frame=round(tok_per_frame, 1),
+                            algorithmic_mb=round(alg_bytes / 1e6, 1), achieved_gb_s=round(alg_bytes / (search_ms * 1e-3) / 1e9, 2),
+                            hbm_roofline_frac=round(alg_bytes / (search_ms * 1e-3) / 8.0e12, 5)),
                streaming=dict(p50_ms_per_frame=round(float(np.percentile(lat, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat, 95)), 3)),
                wfst_wer_vs_truth=round(err_truth / nref, 4))
     # the round-1 substitute: lexicon-constrained prefix beam + word n-gram (b2t_prefix_beam_search_lex_f32)
