@@ -469,7 +469,12 @@ def model_backward(dims: ModelDims, prm: Params, grd: Grads, ctx: ForwardCtx, dl
 
     def _cb(user, bucket, stream):
         try:
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+            # The producing stream as a torch stream.  A NULL hipStream_t (ctypes hands it over as None) is torch's DEFAULT
+            # stream -- torch.cuda.ExternalStream(0) is NOT: events recorded on it are not ordered after work launched on
+            # stream 0 (measured: tools/stream_probe.py; an all-reduce hooked there read the head gradients before the
+            # kernels producing them had run -- found by tests/test_gpu_dp_procs.py).
+            prod = torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.stream(prod):
                 bucket_cb(names[bucket])
         except BaseException as e:   # never unwind through the C frames
             err.append(e)

@@ -1,0 +1,112 @@
+"""Data parallel END TO END on one GPU: two processes share cuda:0 and exchange gradients through torch.distributed (gloo
+moves the CUDA buckets through the host here; on a multi-GPU node the same code runs over RCCL).  Exercises what the
+single-process arithmetic test cannot: the bucket callback out of the C++ executor (b2t_model_backward -> ctypes callback ->
+torch ExternalStream -> asynchronous all_reduce per bucket, in backward-completion order), the MAX-union of the
+'has a gradient' flags, loss scaling by 1/(B * world) -- three optimizer steps, then every parameter is compared with a
+one-rank run on the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+F, H, D, C, L, B, T, S = 32, 64, 8, 41, 3, 16, 40, 5
+ARGS = dict(lr_max=0.01, lr_min=0.001, lr_decay_steps=100, lr_warmup_steps=0, lr_max_day=0.01, lr_min_day=0.001,
+            lr_decay_steps_day=100, lr_warmup_steps_day=0, beta0=0.9, beta1=0.999, epsilon=0.1, weight_decay=0.001,
+            weight_decay_day=0, grad_norm_clip_value=0.5)
+
+
+def _data():
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, T, F, generator=g)
+    day = torch.tensor([0, 0, 3, 3, 3, 3, 5, 5, 5, 5, 6, 6, 6, 6, 1, 1])
+    tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(2, S + 1, (B,), generator=g)
+    nt = torch.randint(30, T + 1, (B,), generator=g)
+    for b in range(B):
+        tgt[b, tl[b]:] = 0
+    return x, day, tgt, nt, tl
+
+
+def _model():
+    from rnn_model import GRUDecoder
+    torch.manual_seed(21)
+    m = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0)
+    with torch.no_grad():
+        for w in m.day_weights:
+            w.add_(torch.randn(w.shape) * 0.05)
+    return m.to("cuda:0").train()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "nejm-brain-to-text_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from b2t_train_step import TrainStep
+        m = _model()
+        ts = TrainStep(m, dict(ARGS))
+        assert ts.world == world and ts.reducer is not None
+        launched = []
+        orig = ts.reducer.launch
+        ts.reducer.launch = lambda name: (launched.append(name), orig(name))[1]
+        x, day, tgt, nt, tl = _data()
+        n = B // world
+        sl = slice(rank * n, (rank + 1) * n)
+        losses = []
+        for it in range(3):
+            loss, gn = ts.step(x[sl].cuda().contiguous(), day[sl], tgt[sl], nt[sl], tl[sl])
+            losses.append((float(loss), float(gn)))
+        ts.check_status()
+        q.put((rank, m.arena().cpu().numpy(), losses, launched[:L + 3], float(ts.stat[1])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank():
+    from b2t_train_step import TrainStep
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_m = _model()
+    ref = TrainStep(ref_m, dict(ARGS))
+    x, day, tgt, nt, tl = _data()
+    ref_losses = []
+    for it in range(3):
+        loss, gn = ref.step(x.cuda(), day, tgt, nt, tl)
+        ref_losses.append((float(loss), float(gn)))
+    want = ref_m.arena().cpu().numpy()
+    (r0, a0, l0, order0, gn0), (r1, a1, l1, order1, gn1) = res
+    lay = ref_m.layout()
+    bad = [(n, float(np.abs(a0[o:o + c] - a1[o:o + c]).max()), float(np.abs(a0[o:o + c] - want[o:o + c]).max()))
+           for n, (o, c) in zip(lay["names"], lay["spans"]) if not np.array_equal(a0[o:o + c], a1[o:o + c])]
+    assert not bad, (bad[:8], l0, l1, ref_losses, gn0, gn1)
+    np.testing.assert_array_equal(a0, a1)                          # replicas stay bit-identical
+    np.testing.assert_allclose(a0, want, atol=5e-6)
+    np.testing.assert_allclose(gn0, float(ref.stat[1]), rtol=1e-4)  # norm of the REDUCED gradient, same on both ranks
+    assert gn0 == gn1
+    # per-rank losses are shard means: their average is the global mean
+    np.testing.assert_allclose((np.array(l0)[:, 0] + np.array(l1)[:, 0]) / 2, np.array(ref_losses)[:, 0], rtol=2e-5)
+    np.testing.assert_allclose(np.array(l0)[:, 1], np.array(ref_losses)[:, 1], rtol=1e-4)
+    # buckets launched in backward-completion order: head, GRU layers top-down, then h0 / day layers
+    assert order0[0] == "head" and order0[1:1 + L] == [f"layer{l}" for l in reversed(range(L))] and set(order0[1 + L:]) == {"h0", "day"}
+    assert order0 == order1
