@@ -199,7 +199,11 @@ class BrainToTextDecoder_Trainer:
         torch.cuda.set_device(self.device)
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=self.device)
+            backend = os.environ.get("B2T_DIST_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; tests run "gloo" (2 ranks on one GPU)
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.device)
+            else:
+                dist.init_process_group(backend=backend)
         self.logger.info(f'Using device: {self.device}')
 
         if self.args['seed'] != -1:

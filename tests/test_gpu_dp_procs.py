@@ -110,3 +110,52 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
     # buckets launched in backward-completion order: head, GRU layers top-down, then h0 / day layers
     assert order0[0] == "head" and order0[1:1 + L] == [f"layer{l}" for l in reversed(range(L))] and set(order0[1 + L:]) == {"h0", "day"}
     assert order0 == order1
+
+
+def _trainer_worker(rank, world, port, tmp, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "nejm-brain-to-text_amd")); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      B2T_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from test_gpu_trainer import make_args
+    from rnn_trainer import BrainToTextDecoder_Trainer
+    args = make_args(tmp, n_batches=41, patch=(0, 0), dropout=(0.0, 0.0))
+    args.update(batches_per_val_step=4, early_stopping=True, early_stopping_val_steps=2, lr_max=1e-30, lr_min=1e-30, lr_max_day=1e-30,
+                lr_min_day=1e-30, batches_per_train_log=5)      # lr ~ 0: validation PER cannot improve after the first one
+    try:
+        tr = BrainToTextDecoder_Trainer(args)
+        st = tr.train()
+        q.put((rank, len(st['train_losses']), st['val_PERs'], float(tr.best_val_PER), tr.train_step.it,
+               tr.model.arena().cpu().numpy()))
+    except BaseException as e:       # report instead of letting the parent wait for its queue timeout
+        q.put((rank, "error", repr(e)))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_stop_together(tmp_path):
+    """BrainToTextDecoder_Trainer.train() with two ranks (on one GPU, gloo): each rank loads only its own batches, takes the
+    same number of optimizer steps, validation runs on rank 0 and its metrics reach rank 1, early stopping breaks both
+    loops in the same global step, rank 0 writes the checkpoint -- the loop the advisor found rank-inconsistent in round 1."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda r: r[0])
+    assert not any(r[1] == "error" for r in res), res
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, n0, v0, b0, it0, a0), (r1, n1, v1, b1, it1, a1) = res
+    # 41 batches over 2 ranks = 20 global steps; validations at steps 0, 4, 8: no improvement twice -> stop at step 8
+    assert n0 == n1 == 9 and it0 == it1 == 9
+    assert v0 == v1 and len(v0) == 3 and b0 == b1 == v0[0]
+    np.testing.assert_array_equal(a0, a1)
+    assert os.path.exists(os.path.join(str(tmp_path), "out", "checkpoint", "best_checkpoint"))
+    assert os.path.exists(os.path.join(str(tmp_path), "out", "training_log"))
