@@ -289,7 +289,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             pmc = json.load(f)
-        if dname in pmc and pmc.get("time_chunks") == ops.PIPELINE["chunks"]:
+        if dname in pmc and pmc.get("time_chunks") == ops.PIPELINE["chunks"] and pmc.get("time_chunks_bwd") == ops.PIPELINE["chunks_bwd"]:
             traffic, traffic_src = round(pmc[dname]["bytes_per_launch"] / 1e9, 4), pmc["source"]
     except OSError:
         pass
@@ -309,7 +309,8 @@ def main():
                    config=dict(workload="BASELINE.json configs[1]: 5-layer GRU-512 + CTC, synthetic [B=64,T=500,F=512] -> 41 "
                                         "phonemes, fp32, full training step incl. on-GPU augmentation, clip and AdamW",
                                global_batch=B * world, seq_len=T, parallelism=f"dp{world}",
-                               gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"]),
+                               gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
+                               time_chunks_bwd=ops.PIPELINE["chunks_bwd"] or ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),
                    host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
         sys.stderr.write("[bench] headline done: " + json.dumps(out)[:200] + "\n"); sys.stderr.flush()
