@@ -342,7 +342,7 @@ int b2t_prefix_beam_search_lex_f32(const float* logp, const int32_t* lens, int U
  * ilabel 0 = epsilon, ilabel i > 0 reads acoustic_scale * logp[i - 1] (DecodableTensorScaled, :27-33); final_cost +inf =
  * not final.  Options: LatticeFasterDecoderConfig + CtcWfstBeamSearchOptions (production values:
  * language-model-standalone.py:486-496 -- beam 17, max_active 7000, min_active 200, lattice_beam 8, acoustic_scale
- * 0.325, blank_skip_thresh 1.0); max_frames / max_tokens / max_links / hash_size (power of two; <= 8192 keeps the hash in
+ * 0.325, blank_skip_thresh 1.0); max_frames / max_tokens / max_links / hash_size (power of two; <= 16384 keeps the hash in
  * LDS) are per-utterance capacities -- exhaustion sets the overflow word (header word 3) and invalidates the result. */
 typedef struct {
   const int32_t* row; const int32_t* ilabel; const int32_t* olabel; const float* weight; const int32_t* next;

@@ -324,6 +324,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       const int ci = diag - l;
       if (ci < 0 || ci >= nc) continue;
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
+      // (bounding the forward sweeps in flight to 4 / 3 by sharing sweep streams was measured: 23.8 / 24.1 ms against 23.2)
       hipStream_t sg = piped ? ex->s_gemm[l] : main, ss = piped ? ex->s_sweep[l] : main;
       // 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
       if (l == 0) {

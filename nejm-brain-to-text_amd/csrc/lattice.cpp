@@ -40,12 +40,21 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
     return -1;
   }
   const double INF = INFINITY;
-  std::vector<std::vector<Arc>> out(n_states);
-  std::vector<std::vector<std::pair<int, double>>> rev(n_states);
+  // CSR adjacency both ways (lattices reach 10^5 arcs: no per-state vectors)
+  std::vector<int> out_off(n_states + 1, 0), rev_off(n_states + 1, 0);
   for (int i = 0; i < n_arcs; ++i) {
     if (src[i] < 0 || src[i] >= n_states || dst[i] < 0 || dst[i] >= n_states) { b2t::set_error("lattice_nbest: arc %d out of range", i); return -1; }
-    out[src[i]].push_back(Arc{ilabel[i], olabel[i], dst[i], graph[i], acoustic[i]});
-    rev[dst[i]].push_back({src[i], std::max(0.0, (double)graph[i] + (double)acoustic[i])});
+    ++out_off[src[i] + 1]; ++rev_off[dst[i] + 1];
+  }
+  for (int s = 0; s < n_states; ++s) { out_off[s + 1] += out_off[s]; rev_off[s + 1] += rev_off[s]; }
+  std::vector<Arc> out_arc(n_arcs);
+  std::vector<std::pair<int, double>> rev_arc(n_arcs);
+  {
+    std::vector<int> po(out_off.begin(), out_off.end() - 1), pr(rev_off.begin(), rev_off.end() - 1);
+    for (int i = 0; i < n_arcs; ++i) {                       // arc order within a state = input order (deterministic ties)
+      out_arc[po[src[i]]++] = Arc{ilabel[i], olabel[i], dst[i], graph[i], acoustic[i]};
+      rev_arc[pr[dst[i]]++] = {src[i], std::max(0.0, (double)graph[i] + (double)acoustic[i])};
+    }
   }
   std::vector<double> fin(n_states, INF), beta(n_states, INF);
   for (int i = 0; i < n_final; ++i) fin[final_state[i]] = std::min(fin[final_state[i]], (double)final_cost[i]);
@@ -56,7 +65,8 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
     while (!pq.empty()) {
       P t = pq.top(); pq.pop();
       if (t.first > beta[t.second]) continue;
-      for (auto& pr : rev[t.second]) {
+      for (int k = rev_off[t.second]; k < rev_off[t.second + 1]; ++k) {
+        const std::pair<int, double>& pr = rev_arc[k];
         const double c = t.first + pr.second;
         if (c < beta[pr.first]) { beta[pr.first] = c; pq.push({c, pr.first}); }
       }
@@ -76,7 +86,8 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       P t = pq.top(); pq.pop();
       const Entry e = sub[t.second];
       if (t.first > e.tot) continue;
-      for (const Arc& a : out[t.second]) {
+      for (int k = out_off[t.second]; k < out_off[t.second + 1]; ++k) {
+        const Arc& a = out_arc[k];
         if (a.ol != 0) continue;
         const double nt = e.tot + a.g + a.a;
         if (nt + beta[a.dst] > limit) continue;
@@ -127,7 +138,8 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
     if (has && best.tot <= limit) { finished.push_back(best); pq.push(Item{best.tot, 1, tie++, it.words, (int)finished.size() - 1}); }
     std::unordered_map<int, Subset> by_word;
     for (auto& kv : sub) {
-      for (const Arc& a : out[kv.first]) {
+      for (int k = out_off[kv.first]; k < out_off[kv.first + 1]; ++k) {
+        const Arc& a = out_arc[k];
         if (a.ol == 0) continue;
         const double nt = kv.second.tot + a.g + a.a;
         if (nt + beta[a.dst] > limit) continue;

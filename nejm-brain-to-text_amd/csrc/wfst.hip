@@ -4,7 +4,7 @@
 // CtcWfstBeamSearch::Search (language_model/runtime/core/decoder/ctc_wfst_beam_search.cc:70-121).
 //
 // One workgroup per utterance; the decode graph (T o L o G as CSR arcs: nejm-brain-to-text_amd/wfst.py) lives in HBM and is
-// shared by all utterances; a frame's token hash (state -> token) lives in LDS when it fits (<= 8192 slots), tokens and
+// shared by all utterances; a frame's token hash (state -> token) lives in LDS when it fits (<= 16384 slots = 128 KB), tokens and
 // forward links of every frame are appended to the utterance's state block in HBM (they ARE the lattice).
 //
 // What is data-parallel here and sequential in the reference:
@@ -648,7 +648,7 @@ Graph to_graph(const b2t_wfst_graph_t* g) {
 Opts to_opts(const b2t_wfst_opts_t* o) {
   return Opts{o->beam, o->lattice_beam, o->beam_delta, o->acoustic_scale, o->length_penalty, o->blank_skip_thresh, o->max_active, o->min_active};
 }
-size_t lds_hash_bytes(const b2t_wfst_opts_t* o) { return o->hash_size <= 8192 ? (size_t)o->hash_size * 2 * sizeof(int) : 0; }
+size_t lds_hash_bytes(const b2t_wfst_opts_t* o) { return o->hash_size <= 16384 ? (size_t)o->hash_size * 2 * sizeof(int) : 0; }   // <= 128 KB of the CU's 160 KB
 template <typename K> void allow_lds(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }

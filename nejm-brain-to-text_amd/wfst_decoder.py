@@ -11,6 +11,8 @@ utterance) is the C++ host function b2t_lattice_nbest_host.
 from __future__ import annotations
 
 import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
 from typing import List
 
 import numpy as np
@@ -18,6 +20,17 @@ import torch
 
 import b2t_native as N
 import b2t_ops as ops
+
+
+def _host_threads() -> int:
+    """Cores this process may run on (affinity mask), overridable with B2T_HOST_THREADS."""
+    env = os.environ.get("B2T_HOST_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
 
 
 def _pow2_at_least(n: int) -> int:
@@ -154,13 +167,13 @@ class WfstSearch:
         hdr = self._header()
         cn, (src, dst, il, ol, gr, ac, fs, fc) = self._lattices()
         mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
-        out = []
         P = lambda x: x.ctypes.data_as(C.c_void_p)
-        for u in range(self.U):
+
+        def one(u):
             F = int(hdr[u, 0])
             n_states, n_arcs, n_final, start = (int(v) for v in cn[u, :4])
             if F == 0 or n_states == 0 or start < 0:
-                out.append([]); continue
+                return []
             a = [np.ascontiguousarray(x[u, :n_arcs]) for x in (src, dst, il, ol, gr, ac)]
             f_s, f_c = np.ascontiguousarray(fs[u, :n_final]), np.ascontiguousarray(fc[u, :n_final])
             w_cap = a_cap = nbest * (2 * F + 16) + 16
@@ -177,8 +190,14 @@ class WfstSearch:
                 ali = oa[aoff[k]:aoff[k + 1]]
                 inp, tm = convert_to_inputs(ali, mapping if len(ali) == F else np.arange(len(ali)))
                 res.append((inp, tm, [int(w) for w in ow[woff[k]:woff[k + 1]]], -float(costs[2 * k]), -float(costs[2 * k + 1])))
-            out.append(res)
-        return out
+            return res
+
+        # utterances are independent and the C call releases the GIL: one host thread per utterance up to the usable cores
+        workers = min(self.U, _host_threads())
+        if workers <= 1:
+            return [one(u) for u in range(self.U)]
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            return list(pool.map(one, range(self.U)))
 
     def _nbest_of(self, u, h, nbest=None):
         return self._nbest_all(nbest or self.nbest)[u]

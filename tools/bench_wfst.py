@@ -82,7 +82,7 @@ def run():
     lg = torch.from_numpy(logits).to(dev); pri = torch.zeros_like(lg); lp = torch.empty_like(lg)
     N.check(lib.b2t_lm_prologue_f32(_p(lg), _p(pri), float(math.log(90.0)), _p(lp), U * T, C, ops._stream()), "prologue")
     sys.stderr.write(f"TLG: {g.n_states} states, {g.n_arcs} arcs, built in {build_s:.1f} s; {U} x {T} frames\n")
-    S = WfstSearch(g, Opt, U=U, max_frames=T + 8, max_tokens=1 << 22, max_links=1 << 24)
+    S = WfstSearch(g, Opt, U=U, max_frames=T + 8, max_tokens=1 << 22, max_links=1 << 24, hash_size=int(os.environ.get("B2T_WFST_HASH", "0")))
     ts = []
     for rep in range(3):
         S.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
