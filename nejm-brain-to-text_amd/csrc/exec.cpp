@@ -8,6 +8,9 @@
 // l+1 runs its input-projection GEMM + sweep on chunk c-1; in the backward pass the weight-gradient GEMMs of layer l
 // run on that layer's GEMM stream while the layers below are still sweeping.  Dependencies are HIP events; the
 // caller's stream joins the side streams before the function returns (nothing synchronises with the host).
+#include <stdio.h>
+#include <stdlib.h>
+#include <functional>
 #include <vector>
 #include <algorithm>
 #include "common.h"
@@ -25,7 +28,8 @@ struct ProfRec { int kind; double flops; hipEvent_t e0, e1; };
 
 struct b2t_exec {
   int L = 0;
-  hipStream_t s_sweep[b2t::MAXL] = {}, s_gemm[b2t::MAXL] = {};
+  std::vector<hipStream_t> phys;                    // worker queues (the caller's stream is queue 0 of a pass)
+  unsigned sweep_qmask = 0;                         // queues a sweep may be scheduled on
   std::vector<hipEvent_t> pool;   // ordering events (timing disabled), handed out round-robin within a pass
   size_t next_ev = 0;
   bool profile = false;
@@ -198,6 +202,102 @@ b2t_gemm_desc gd(const float* A, const float* Bm, float* C, int M, int N, int K)
 
 uint64_t mix_seed(uint64_t seed, uint64_t k) { return seed * 1000003ull + k; }
 
+// ---- task graph + list scheduler ------------------------------------------------------------------------------------
+// A pass is a DAG of tasks (a GEMM with its epilogue kernels, one sweep chunk, a reduction ...) with rough duration
+// estimates.  The command processor serves the hardware queues that share one of its 4 pipes in time slices: with the 11
+// streams of the round-1 plan a cross-stream dependency cost 110-140 us inside a step (15 us on an idle chip,
+// tools/bench_hop_*.py).  So the plan runs on FOUR in-order queues -- the caller's stream and three workers, one per
+// pipe -- and a list scheduler (HEFT: longest path to the end first, earliest finish, gaps may be filled) decides which
+// queue a task goes to.  Results do not depend on the schedule: every accumulation order is a dependency of the graph.
+constexpr float HOP_US = 20.f;   // event record -> wait on another queue -> launch
+constexpr unsigned Q_ANY = 0xffffffffu, Q_MAIN = 1u;
+
+struct Task {
+  const char* name; float est; unsigned qmask; std::vector<int> deps; std::function<void(hipStream_t)> run;
+  int q = -1; float start = 0.f, end = 0.f, rank = 0.f; bool cross = false; hipEvent_t ev = nullptr;
+};
+
+struct Plan {
+  std::vector<Task> t;
+  int add(const char* name, float est, unsigned qmask, std::initializer_list<int> deps, std::function<void(hipStream_t)> run) {
+    Task k;
+    k.name = name; k.est = est; k.qmask = qmask; k.run = std::move(run);
+    for (int d : deps) if (d >= 0) k.deps.push_back(d);
+    t.push_back(std::move(k));
+    return (int)t.size() - 1;
+  }
+  void dep(int task, int on) { if (task >= 0 && on >= 0) t[task].deps.push_back(on); }
+};
+
+float est_gemm(double M, double N, double K, double Z = 1) { return 12.f + (float)(2.0 * M * N * K * Z / 80e6); }   // ~80 TF/s + launch
+
+void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
+  const int n = (int)P.t.size();
+  std::vector<std::vector<int>> succ(n);
+  for (int i = 0; i < n; ++i) for (int d : P.t[i].deps) succ[d].push_back(i);
+  for (int i = n - 1; i >= 0; --i) {
+    float r = 0.f;
+    for (int s : succ[i]) r = std::max(r, P.t[s].rank + HOP_US);
+    P.t[i].rank = P.t[i].est + r;
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return P.t[a].rank > P.t[b].rank; });
+  std::vector<std::vector<std::pair<float, float>>> busy(nq);
+  for (int id : order) {
+    Task& k = P.t[id];
+    int bq = -1; float bs = 0.f;
+    for (int q = 0; q < nq; ++q) {
+      if (!((k.qmask >> q) & 1u) && nq > 1) continue;
+      float s = 0.f;
+      for (int d : k.deps) s = std::max(s, P.t[d].end + (P.t[d].q != q ? HOP_US : 0.f));
+      for (const auto& iv : busy[q]) {
+        if (s + k.est <= iv.first) break;
+        s = std::max(s, iv.second);
+      }
+      if (bq < 0 || s < bs - 0.5f) { bq = q; bs = s; }
+    }
+    if (bq < 0) bq = 0;
+    k.q = bq; k.start = bs; k.end = bs + k.est;
+    auto& b = busy[bq];
+    b.insert(std::upper_bound(b.begin(), b.end(), std::make_pair(k.start, k.end)), std::make_pair(k.start, k.end));
+  }
+  for (int i = 0; i < n; ++i) for (int s : succ[i]) if (P.t[s].q != P.t[i].q) P.t[i].cross = true;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return P.t[a].start != P.t[b].start ? P.t[a].start < P.t[b].start : a < b;
+  });
+  static const bool dump = getenv("B2T_PLAN_DUMP") != nullptr;
+  if (dump) {
+    fprintf(stderr, "plan: %d tasks on %d queues\n", n, nq);
+    for (int id : order) fprintf(stderr, "  %9.1f %8.1f q%d %s\n", P.t[id].start, P.t[id].est, P.t[id].q, P.t[id].name);
+  }
+  std::vector<int> pos(n);
+  for (int i = 0; i < n; ++i) pos[order[i]] = i;
+  for (int id : order) {
+    if (c.rc) return;
+    Task& k = P.t[id];
+    hipStream_t s = qs[k.q];
+    int last[8]; for (int q = 0; q < 8; ++q) last[q] = -1;   // per foreign queue: the dependency issued last covers the others
+    for (int d : k.deps) {
+      const int dq = P.t[d].q;
+      if (dq != k.q && (last[dq] < 0 || pos[d] > pos[last[dq]])) last[dq] = d;
+    }
+    for (int q = 0; q < nq; ++q) if (last[q] >= 0) c.wait(s, P.t[last[q]].ev);
+    if (k.run) k.run(s);
+    if (k.cross) k.ev = c.record(s);
+  }
+}
+
+// queue 0 = the caller's stream; the workers only when the plan is pipelined (shapes whose sweeps cannot share the chip
+// run as one in-order sequence)
+int plan_queues(b2t_exec* ex, hipStream_t main, bool piped, hipStream_t* qs) {
+  qs[0] = main;
+  if (!piped) return 1;
+  int n = 1;
+  for (hipStream_t st : ex->phys) if (n < 8) qs[n++] = st;
+  return n;
+}
+
 int check_common(const b2t_exec* ex, const b2t_model_t* m, const b2t_pass_t* p, const char* what) {
   B2T_REQUIRE(ex && m && p, "%s: null argument", what);
   B2T_REQUIRE(m->L >= 1 && m->L <= MAXL && m->L <= ex->L, "%s: %d layers (executor has %d, max %d)", what, m->L, ex->L, MAXL);
@@ -216,23 +316,26 @@ extern "C" int b2t_exec_create(int n_layers, b2t_exec** out) {
   B2T_REQUIRE(out && n_layers >= 1 && n_layers <= MAXL, "exec_create: 1..%d layers", MAXL);
   b2t_exec* ex = new b2t_exec();
   ex->L = n_layers;
-  for (int l = 0; l < n_layers; ++l) {
-    if (check_hip(hipStreamCreateWithFlags(&ex->s_sweep[l], hipStreamNonBlocking), "hipStreamCreate") ||
-        check_hip(hipStreamCreateWithFlags(&ex->s_gemm[l], hipStreamNonBlocking), "hipStreamCreate")) {
-      delete ex;
+  // Worker queues: three, so that with the caller's stream the plan occupies four hardware queues -- one per pipe of the
+  // command processor (queues are assigned to pipes round-robin in creation order; a fifth queue shares a pipe with
+  // another one and every dependency that crosses them then waits for a time slice: 26.7 vs 22.2 ms per step with 5 + 1).
+  int n_workers = 3;
+  if (const char* env = getenv("B2T_WORKERS")) n_workers = std::max(1, std::min(7, atoi(env)));
+  ex->phys.assign(n_workers, nullptr);
+  for (int i = 0; i < n_workers; ++i) {
+    if (check_hip(hipStreamCreateWithFlags(&ex->phys[i], hipStreamNonBlocking), "hipStreamCreate")) {
+      b2t_exec_destroy(ex);
       return 1;
     }
   }
+  ex->sweep_qmask = getenv("B2T_SWEEP_ANYQ") ? 0xffffffffu : (((1u << n_workers) - 1u) << 1);
   *out = ex;
   return 0;
 }
 
 extern "C" int b2t_exec_destroy(b2t_exec* ex) {
   if (!ex) return 0;
-  for (int l = 0; l < ex->L; ++l) {
-    if (ex->s_sweep[l]) (void)hipStreamDestroy(ex->s_sweep[l]);
-    if (ex->s_gemm[l]) (void)hipStreamDestroy(ex->s_gemm[l]);
-  }
+  for (hipStream_t st : ex->phys) if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t e : ex->pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->tpool) (void)hipEventDestroy(e);
   delete ex;
@@ -285,63 +388,63 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   carve(prm, p, reinterpret_cast<char*>(ws), w);
   Ctx c{ex, as_stream(stream), p->bf16_gemm != 0};
   ex->next_ev = 0;
-  hipStream_t main = c.main;
-  void* mainp = stream;
   const size_t sync_block = b2t_gru_sync_bytes(0);
   auto sync_of = [&](int l) { return sync_ws ? reinterpret_cast<char*>(sync_ws) + (size_t)l * sync_block : nullptr; };
 
-  // 1. day layer: U[b] = softsign(x[b] @ W[day[b]] + c[day[b]])   (rnn_model.py:95-99); the [B,512,512] gather of the
-  //    reference does not exist: the GEMM indexes the day weights by day_idx (b_zmap)
-  {
-    b2t_gemm_desc d = gd(x, prm->day_w, w.U, T, F, F);
-    d.Z = B; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = prm->day_w_stride;
-    d.c_s0 = F; d.c_sz = (long long)T * F; d.bias = prm->day_b; d.bias_sz = prm->day_b_stride; d.b_zmap = day_idx; d.epilogue = 1;
-    c.gemm(main, d);
-  }
-  if (p->in_drop > 0.f)
-    c.call(b2t_dropout_f32(w.U, w.Ud, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, mainp));
-
   int chunks[MAXC][2];
   const int nc = make_chunks(Tp, p->chunks, chunks);
-  const bool piped = nc > 1;
   const long long a_s0_l0 = prm->patch > 0 ? (long long)prm->stride * F : F;
+  const float hs = std::max(0.25f, (float)H * H / (512.f * 512.f)) * std::max(1, (B + 63) / 64);   // sweep cost scale
+  const unsigned q_sweep = ex->sweep_qmask;
 
-  if (piped) {
-    hipEvent_t ev0 = c.record(main);
-    for (int l = 0; l < L; ++l) { c.wait(ex->s_sweep[l], ev0); c.wait(ex->s_gemm[l], ev0); }
-  }
-  // slot 0 of out[l] = initial state, so out[l][0:T'] is the h_{t-1} matrix (on the layer's sweep stream)
+  Plan P;
+  const int t_start = P.add("start", 0.f, Q_MAIN, {}, nullptr);
+  // 1. day layer: U[b] = softsign(x[b] @ W[day[b]] + c[day[b]])   (rnn_model.py:95-99); the [B,512,512] gather of the
+  //    reference does not exist: the GEMM indexes the day weights by day_idx (b_zmap).  Without patching and input
+  //    dropout the day layer runs chunk by chunk like everything behind it (the first sweep starts ~0.25 ms earlier).
+  const bool day_chunked = prm->patch == 0 && !(p->in_drop > 0.f) && nc > 1;
+  int t_day[MAXC];
+  auto day_task = [&](int t0, int n) {
+    return P.add("day", est_gemm(n, F, F, B), Q_ANY, {t_start}, [&, t0, n](hipStream_t s) {
+      b2t_gemm_desc d = gd(x + (long long)t0 * F, prm->day_w, w.U + (long long)t0 * F, n, F, F);
+      d.Z = B; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = prm->day_w_stride;
+      d.c_s0 = F; d.c_sz = (long long)T * F; d.bias = prm->day_b; d.bias_sz = prm->day_b_stride; d.b_zmap = day_idx; d.epilogue = 1;
+      c.gemm(s, d);
+      if (p->in_drop > 0.f)
+        c.call(b2t_dropout_f32(w.U, w.Ud, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, reinterpret_cast<void*>(s)));
+    });
+  };
+  if (day_chunked) for (int ci = 0; ci < nc; ++ci) t_day[ci] = day_task(chunks[ci][0], chunks[ci][1] - chunks[ci][0]);
+  else { const int t = day_task(0, T); for (int ci = 0; ci < nc; ++ci) t_day[ci] = t; }
+
+  // slot 0 of out[l] = initial state, so out[l][0:T'] is the h_{t-1} matrix
+  int t_init[MAXL], t_sw[MAXL][MAXC];
+  for (int l = 0; l < L; ++l)
+    t_init[l] = P.add("init", 5.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
+      if (states) c.call(check_hip(hipMemcpyAsync(w.out[l], states + (size_t)l * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s), "model_forward: state copy"));
+      else c.call(b2t_broadcast_rows_f32(prm->h0, w.out[l], B, H, reinterpret_cast<void*>(s)));
+    });
   for (int l = 0; l < L; ++l) {
-    hipStream_t s = piped ? ex->s_sweep[l] : main;
-    if (states) c.call(check_hip(hipMemcpyAsync(w.out[l], states + (size_t)l * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s), "model_forward: state copy"));
-    else c.call(b2t_broadcast_rows_f32(prm->h0, w.out[l], B, H, s));
-  }
-  hipEvent_t ev_sw[MAXL][MAXC] = {};
-  // cells (chunk c, layer l) are enqueued diagonal by diagonal (c + l), a topological order in which no stream waits on
-  // work that is queued behind it
-  for (int diag = 0; diag < nc + L - 1 && !c.rc; ++diag) {
-    for (int l = 0; l < L; ++l) {
-      const int ci = diag - l;
-      if (ci < 0 || ci >= nc) continue;
+    for (int ci = 0; ci < nc; ++ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
-      // (bounding the forward sweeps in flight to 4 / 3 by sharing sweep streams was measured: 23.8 / 24.1 ms against 23.2)
-      hipStream_t sg = piped ? ex->s_gemm[l] : main, ss = piped ? ex->s_sweep[l] : main;
       // 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
-      if (l == 0) {
-        if ((long long)n * B <= 512 && In0 >= 2048) {
-          // streaming-sized calls (a few frames, patch input K = 7168): one GEMM over all (t, b) rows through the
-          // two-level row map, K split over the chip (as B per-sentence GEMMs the K loop runs serially in 18 workgroups)
-          b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
-          d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
-          c.gemm(sg, d, std::max(1, std::min(16, In0 / 448)), w.slab_gi[0]);
-        } else {
-          b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n, 3 * H, In0);
-          d.Z = B; d.a_s0 = a_s0_l0; d.a_sz = (long long)T * F; d.b_s0 = In0; d.c_s0 = (long long)B * 3 * H; d.c_sz = 3 * H;
-          d.bias = prm->b_ih[0];
-          c.gemm(sg, d);
+      const int t_gi = P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci]},
+                             [&, l, t0, n](hipStream_t sg) {
+        if (l == 0) {
+          if ((long long)n * B <= 512 && In0 >= 2048) {
+            // streaming-sized calls (a few frames, patch input K = 7168): one GEMM over all (t, b) rows through the
+            // two-level row map, K split over the chip (as B per-sentence GEMMs the K loop runs serially in 18 workgroups)
+            b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
+            d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
+            c.gemm(sg, d, std::max(1, std::min(16, In0 / 448)), w.slab_gi[0]);
+          } else {
+            b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n, 3 * H, In0);
+            d.Z = B; d.a_s0 = a_s0_l0; d.a_sz = (long long)T * F; d.b_s0 = In0; d.c_s0 = (long long)B * 3 * H; d.c_sz = 3 * H;
+            d.bias = prm->b_ih[0];
+            c.gemm(sg, d);
+          }
+          return;
         }
-      } else {
-        if (piped) c.wait(sg, ev_sw[l - 1][ci]);
         const float* src = w.out[l - 1];
         if (w.outd[l - 1] != w.out[l - 1]) {   // nn.GRU inter-layer dropout (rnn_model.py:70)
           c.call(b2t_dropout_f32(w.out[l - 1] + (long long)(1 + t0) * B * H, w.outd[l - 1] + (long long)(1 + t0) * B * H,
@@ -354,30 +457,33 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         const bool small = (long long)n * B <= 512 && H >= 384;   // streaming-sized call: split K (one 128-row tile otherwise)
         if (small) c.gemm(sg, d, std::max(1, H / 192), w.slab_gi[l]);
         else c.gemm(sg, d);
-      }
-      hipEvent_t ev_gi = piped ? c.record(sg) : nullptr;
+      });
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
-      if (piped) c.wait(ss, ev_gi);
-      if (!c.rc) {
+      t_sw[l][ci] = P.add("sweep", 40.f + n * 5.5f * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n](hipStream_t ss) {
+        if (c.rc) return;
         Ctx::Scope sc(c, ss, 8, 2.0 * n * B * 3.0 * H * H);
         c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], w.out[l] + (long long)t0 * B * H,
                                      w.out[l] + (long long)(1 + t0) * B * H, p->save ? w.res[l] + (long long)t0 * B * 4 * H : nullptr,
                                      t1 == Tp ? hidden + (size_t)l * B * H : nullptr, n, B, H, mode, sync_of(l),
                                      reinterpret_cast<void*>(ss)));
-      }
-      if (piped) ev_sw[l][ci] = c.record(ss);
+      });
     }
   }
-  // One join is enough: the last chunk of the top layer's sweep transitively depends on every GEMM and sweep enqueued
-  // above (each wait is a barrier packet the command processor works through one by one, ~50 us apiece).
-  if (piped) c.wait(main, ev_sw[L - 1][nc - 1]);
-
   // 4. head: logits[b,t,:] = out W^T + b  (rnn_model.py:129), written batch-first
-  {
+  const int t_head = P.add("head", est_gemm((double)Tp * B, Cc, H), Q_ANY, {t_sw[L - 1][nc - 1]}, [&](hipStream_t s) {
     b2t_gemm_desc d = gd(w.out[L - 1] + (long long)B * H, prm->out_w, logits, Tp * B, Cc, H);
     d.a_s0 = H; d.b_s0 = H; d.c_div = B; d.c_s1 = Cc; d.c_s0 = (long long)Tp * Cc; d.bias = prm->out_b;
-    c.gemm(main, d);
+    c.gemm(s, d);
+  });
+  // the caller's stream leaves ordered after everything: the head transitively depends on every sweep and GEMM except
+  // the last chunks of the lower layers' sweeps (their final hidden state)
+  {
+    const int t_end = P.add("end", 0.f, Q_MAIN, {t_head}, nullptr);
+    for (int l = 0; l + 1 < L; ++l) P.dep(t_end, t_sw[l][nc - 1]);
   }
+  hipStream_t qs[8];
+  const int nq = plan_queues(ex, c.main, nc > 1, qs);
+  run_plan(c, P, nq, qs);
   return c.rc;
 }
 
@@ -451,8 +557,6 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   carve(prm, p, reinterpret_cast<char*>(ws), w);
   Ctx c{ex, as_stream(stream), p->bf16_gemm != 0};
   ex->next_ev = 0;
-  hipStream_t main = c.main;
-  void* mainp = stream;
   const size_t sync_block = b2t_gru_sync_bytes(0);
   auto sync_of = [&](int l) { return sync_ws ? reinterpret_cast<char*>(sync_ws) + (size_t)(L + l) * sync_block : nullptr; };
   auto cb = [&](int id, hipStream_t s) { if (bucket_cb && !c.rc) bucket_cb(user, id, reinterpret_cast<void*>(s)); };
@@ -463,33 +567,30 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // the weight-gradient GEMMs of layer l on a side stream under the sweep of layer l - 1 was measured: C3 fp32 19.7 -> 23.0 ms,
   // bf16 operands 12.7 -> 15.1 ms: a 768-unit sweep workgroup needs a CU's whole register file, and GEMM workgroups that
   // arrive first keep its row group from becoming resident.)
-  const bool piped = nc > 1;
+  const float hs = std::max(0.25f, (float)H * H / (512.f * 512.f)) * std::max(1, (B + 63) / 64);
+  const unsigned q_sweep = ex->sweep_qmask;
 
+  Plan P;
+  const int t_start = P.add("start", 0.f, Q_MAIN, {}, nullptr);
   // head: d_out[t,b,:] = dlogits[b,t,:] W_out ; dW_out = dlogits^T out ; db_out = colsum
-  {
+  const int t_top = P.add("head_dx", est_gemm((double)M, H, Cc), Q_ANY, {t_start}, [&](hipStream_t s) {
     b2t_gemm_desc d = gd(dlogits, prm->out_w, w.dY[L - 1], (int)M, H, Cc);
     d.a_div = B; d.a_s1 = ldd; d.a_s0 = (long long)Tp * ldd; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    c.gemm(main, d);
-  }
-  hipEvent_t ev_top = piped ? c.record(main) : nullptr;
-  {
+    c.gemm(s, d);
+  });
+  int t_bucket = P.add("head_w", est_gemm(Cc, H, (double)M) + 40.f, Q_ANY, {t_start}, [&](hipStream_t s) {
     b2t_gemm_desc d = gd(dlogits, w.out[L - 1] + (long long)B * H, grd->out_w, Cc, H, (int)M);
     d.a_kcontig = 0; d.a_div = B; d.a_s1 = ldd; d.a_s0 = (long long)Tp * ldd; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    c.gemm(main, d, splitk_for(Cc, H, M), w.slab_head);
-  }
-  c.call(b2t_colsum_f32(dlogits, M, Cc, ldd, grd->out_b, 0, w.cs_head, 1, 0, 0, mainp));
-  cb(0, main);
-
-  hipEvent_t ev_wt[MAXL] = {};
-  if (piped) {
-    // W_hh^T for the backward sweeps depends on the parameters only: enqueued BEFORE the streams wait for the head (it
-    // runs while the CTC kernel has the chip to itself instead of in front of the first backward sweep)
-    for (int l = 0; l < L; ++l) {
-      c.call(b2t_transpose_f32(prm->w_hh[l], w.whh_t[l], 3 * H, H, reinterpret_cast<void*>(ex->s_gemm[l])));
-      ev_wt[l] = c.record(ex->s_gemm[l]);
-    }
-    for (int l = 0; l < L; ++l) { c.wait(ex->s_sweep[l], ev_top); c.wait(ex->s_gemm[l], ev_top); }
-  }
+    c.gemm(s, d, splitk_for(Cc, H, M), w.slab_head);
+    c.call(b2t_colsum_f32(dlogits, M, Cc, ldd, grd->out_b, 0, w.cs_head, 1, 0, 0, reinterpret_cast<void*>(s)));
+    cb(0, s);
+  });
+  // W_hh^T for the backward sweeps depends on the parameters only
+  int t_wt[MAXL];
+  for (int l = 0; l < L; ++l)
+    t_wt[l] = P.add("whh_t", 8.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
+      c.call(b2t_transpose_f32(prm->w_hh[l], w.whh_t[l], 3 * H, H, reinterpret_cast<void*>(s)));
+    });
 
   // dIn = dGi W_ih for rows of chunk [t0, t0+n): into dY[l-1] (l > 0) or dU / dV (l == 0).
   // Day-layer backward chunk by chunk (no patching, no input dropout): the Softsign backward rides in the epilogue of
@@ -520,54 +621,51 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     }
   };
 
-  hipEvent_t ev_dx[MAXL][MAXC] = {}, ev_bs[MAXL][MAXC] = {};
-  for (int diag = 0; diag < nc + L - 1 && !c.rc; ++diag) {
-    for (int l = L - 1; l >= 0; --l) {
-      const int ci = nc - 1 - (diag - (L - 1 - l));
-      if (ci < 0 || ci >= nc) continue;
+  // Weight gradients: per chunk (bit l of wgrad_chunk_mask: the first chunk swept overwrites, the others accumulate in sweep
+  // order -- a dependency chain, so the sums do not depend on the schedule) or once per layer after its last chunk.
+  int t_bs[MAXL][MAXC], t_dx[MAXL][MAXC], t_wg_last[MAXL];
+  for (int l = L - 1; l >= 0; --l) {
+    const bool per_chunk = nc > 1 && ((p->wgrad_chunk_mask >> l) & 1);
+    const int In = l == 0 ? In0 : H;
+    int t_wg = -1;
+    for (int ci = nc - 1; ci >= 0; --ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
-      hipStream_t ss = piped ? ex->s_sweep[l] : main, sg = piped ? ex->s_gemm[l] : main;
-      void* ssp = reinterpret_cast<void*>(ss);
-      if (piped) {
-        if (l < L - 1) c.wait(ss, ev_dx[l + 1][ci]);
-        if (ci == nc - 1) c.wait(ss, ev_wt[l]);
-      } else if (ci == nc - 1) {
-        c.call(b2t_transpose_f32(prm->w_hh[l], w.whh_t[l], 3 * H, H, ssp));
-      }
-      if (p->rnn_drop > 0.f && l < L - 1)   // gradient through the inter-layer dropout mask
-        c.call(b2t_dropout_f32(w.dY[l] + (long long)t0 * B * H, w.dY[l] + (long long)t0 * B * H, (long long)n * B * H, p->rnn_drop,
-                               mix_seed(p->seed, 101 + l), (long long)t0 * B * H, ssp));
-      const float* dh_last = ci == nc - 1 ? (dhidden ? dhidden + (size_t)l * B * H : nullptr) : w.carry[l] + (size_t)((ci + 1) % 2) * B * H;
-      float* dh_out = ci == 0 ? w.dh_init + (size_t)l * B * H : w.carry[l] + (size_t)(ci % 2) * B * H;
-      if (!c.rc) {
+      t_bs[l][ci] = P.add("bsweep", 40.f + n * 6.0f * hs, q_sweep,
+                          {l < L - 1 ? t_dx[l + 1][ci] : t_top, ci == nc - 1 ? t_wt[l] : t_bs[l][ci + 1]}, [&, l, ci, t0, n](hipStream_t ss) {
+        void* ssp = reinterpret_cast<void*>(ss);
+        if (p->rnn_drop > 0.f && l < L - 1)   // gradient through the inter-layer dropout mask
+          c.call(b2t_dropout_f32(w.dY[l] + (long long)t0 * B * H, w.dY[l] + (long long)t0 * B * H, (long long)n * B * H, p->rnn_drop,
+                                 mix_seed(p->seed, 101 + l), (long long)t0 * B * H, ssp));
+        const float* dh_last = ci == nc - 1 ? (dhidden ? dhidden + (size_t)l * B * H : nullptr) : w.carry[l] + (size_t)((ci + 1) % 2) * B * H;
+        float* dh_out = ci == 0 ? w.dh_init + (size_t)l * B * H : w.carry[l] + (size_t)(ci % 2) * B * H;
+        if (c.rc) return;
         Ctx::Scope sc(c, ss, 9, 2.0 * n * B * 3.0 * H * H);
         c.call(b2t_gru_layer_bwd_f32(w.dY[l] + (long long)t0 * B * H, dh_last, w.res[l] + (long long)t0 * B * 4 * H,
                                      w.out[l] + (long long)(1 + t0) * B * H, w.out[l] + (long long)t0 * B * H, w.whh_t[l],
                                      w.dG[l] + (long long)t0 * B * 4 * H, dh_out, w.scratch[l], n, B, H, mode, sync_of(l), ssp));
-      }
-      if (piped) ev_bs[l][ci] = c.record(ss);
-      if (piped) c.wait(sg, ev_bs[l][ci]);
-      dx_gemm(sg, l, t0, n);
-      if (piped) ev_dx[l][ci] = c.record(sg);
-      // Weight gradients on a GEMM stream.  Layers >= 1: the whole layer once its last chunk is swept (they overlap the
-      // sweeps of the layers below; per-chunk launches there were measured slower: more launches competing for the
-      // sweeps' CUs).  Layer 0 has no layer below to hide behind -- its 100 GFLOP used to sit in the step's tail -- so its
-      // weight gradients accumulate chunk by chunk on the top layer's GEMM stream (idle by then), and only the last
-      // chunk's share follows the last sweep.
-      const bool per_chunk = piped && ((p->wgrad_chunk_mask >> l) & 1);
+      });
+      float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
+      if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
+      t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1},
+                          [&, l, t0, n](hipStream_t s) { dx_gemm(s, l, t0, n); });
       if (per_chunk || ci == 0) {
-        hipStream_t swg = !piped ? main : ((l == 0 && L > 1) ? ex->s_gemm[L - 1] : ex->s_gemm[l]);
-        if (piped) c.wait(swg, ev_bs[l][ci]);
-        if (per_chunk) layer_weight_grads(c, swg, prm, grd, p, w, l, t0, t1, ci == nc - 1 ? 0 : 1, ci == 0);
-        else layer_weight_grads(c, swg, prm, grd, p, w, l, 0, Tp, 0, true);
-        if (ci == 0) cb(1 + l, swg);
+        const int w0 = per_chunk ? t0 : 0, w1 = per_chunk ? t1 : Tp;
+        const int acc = per_chunk && ci != nc - 1 ? 1 : 0;
+        const bool fin = ci == 0;
+        const double K = (double)(w1 - w0) * B;
+        t_wg = P.add("wgrad", est_gemm(3 * H, H, K) + est_gemm(3 * H, In, K) + 60.f, Q_ANY, {t_bs[l][ci], t_wg, fin ? t_bucket : -1},
+                     [&, l, w0, w1, acc, fin](hipStream_t s) {
+          layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin);
+          if (fin) cb(1 + l, s);
+        });
       }
     }
+    t_wg_last[l] = t_wg;
+    t_bucket = t_wg;   // buckets are handed to the reducer in a fixed order (head, layers L-1 .. 0, day, h0) on every rank
   }
 
-  // layer-0 input gradient -> day layer (on layer 0's GEMM stream: its dU/dV GEMMs are already ordered there)
-  {
-    hipStream_t s = piped ? ex->s_gemm[0] : main;
+  // layer-0 input gradient -> day layer
+  const int t_dayfin = P.add("day_w", fast_day ? 60.f : est_gemm(F, F, T, B) + 200.f, Q_ANY, {t_dx[0][0], t_bucket}, [&](hipStream_t s) {
     void* sp = reinterpret_cast<void*>(s);
     if (!fast_day) {
       if (prm->patch > 0) c.call(b2t_patch_fold_f32(w.dV, w.dU, B, T, F, Tp, prm->patch, prm->stride, sp));
@@ -583,30 +681,24 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     c.call(b2t_day_reduce_f32(w.day_slab, day_idx, B, (long long)F * F, grd->day_w, grd->day_w_stride, sp));
     c.call(b2t_day_reduce_f32(w.day_bslab, day_idx, B, bias_ld, grd->day_b, grd->day_b_stride, sp));
     cb(L + 2, s);
-  }
+  });
+  if (!fast_day) for (int ci = 1; ci < nc; ++ci) P.dep(t_dayfin, t_dx[0][ci]);
   // h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
-  auto h0_grad = [&](hipStream_t s) {
+  const int t_h0 = P.add("h0", 20.f, Q_ANY, {t_dayfin}, [&](hipStream_t s) {
     void* sp = reinterpret_cast<void*>(s);
     if (!custom_states) c.call(b2t_colsum_f32(w.dh_init, (long long)L * B, H, H, grd->h0, 0, w.cs_h0, 1, 0, 0, sp));
     else c.call(check_hip(hipMemsetAsync(grd->h0, 0, sizeof(float) * H, s), "model_backward: h0 gradient"));
     if (dstates) c.call(check_hip(hipMemcpyAsync(dstates, w.dh_init, sizeof(float) * L * B * H, hipMemcpyDeviceToDevice, s), "model_backward: dstates"));
     cb(L + 1, s);
-  };
-  if (piped && L > 2) {
-    // Every sweep stream's last launch is followed by a GEMM on that layer's GEMM stream, and the weight-gradient
-    // streams are GEMM streams: joining the L GEMM streams joins everything.  The streams that finish early (layers
-    // 1 .. L-2) are joined into one of them while the last two are still busy; the caller's stream then waits for three
-    // events instead of L.  The h0 reduction rides on that idle stream (layer 0's sweep is the last one to finish).
-    hipStream_t s1 = ex->s_gemm[1];
-    for (int l = 2; l < L - 1; ++l) c.wait(s1, c.record(ex->s_gemm[l]));
-    c.wait(s1, ev_bs[0][0]);
-    h0_grad(s1);
-    c.wait(main, c.record(s1));
-    c.wait(main, c.record(ex->s_gemm[L - 1]));
-    c.wait(main, c.record(ex->s_gemm[0]));
-  } else {
-    if (piped) for (int l = 0; l < L; ++l) c.wait(main, c.record(ex->s_gemm[l]));
-    h0_grad(main);
+  });
+  for (int l = 0; l < L; ++l) P.dep(t_h0, t_bs[l][0]);
+  {
+    const int t_end = P.add("end", 0.f, Q_MAIN, {t_h0}, nullptr);
+    for (int l = 0; l < L; ++l) { P.dep(t_end, t_wg_last[l]); P.dep(t_end, t_dx[l][0]); }
+    P.dep(t_end, t_top);
   }
+  hipStream_t qs[8];
+  const int nq = plan_queues(ex, c.main, nc > 1, qs);
+  run_plan(c, P, nq, qs);
   return c.rc;
 }
