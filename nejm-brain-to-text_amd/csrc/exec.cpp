@@ -29,6 +29,10 @@ struct ProfRec { int kind; double flops; hipEvent_t e0, e1; };
 struct b2t_exec {
   int L = 0;
   std::vector<hipStream_t> phys;                    // worker queues (the caller's stream is queue 0 of a pass)
+  int n_workers = 3;
+  bool have_workers = false;
+  hipStream_t workers_for = nullptr;                // the caller's stream the workers were chosen against
+  float* scratch = nullptr;                         // 256 bytes of device memory for the calibration launches
   unsigned sweep_qmask = 0;                         // queues a sweep may be scheduled on
   std::vector<hipEvent_t> pool;   // ordering events (timing disabled), handed out round-robin within a pass
   size_t next_ev = 0;
@@ -288,11 +292,85 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   }
 }
 
+// Cost of one cross-queue dependency between two streams on the otherwise idle chip: a chain of tiny launches that hop
+// from one to the other through events (microseconds per hop; < 0 on a HIP error).
+float hop_us(b2t_exec* ex, hipStream_t a, hipStream_t b) {
+  const int warm = 2, n = 8;
+  std::vector<hipEvent_t> evs;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  auto hop = [&](hipStream_t from, hipStream_t to) {
+    hipEvent_t e = nullptr;
+    ok = ok && hipMemsetAsync(ex->scratch, 0, 64, from) == hipSuccess && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (e) evs.push_back(e);
+    ok = ok && hipEventRecord(e, from) == hipSuccess && hipStreamWaitEvent(to, e, 0) == hipSuccess;
+  };
+  for (int i = 0; i < warm + n && ok; ++i) {
+    if (i == warm) ok = ok && hipEventRecord(e0, a) == hipSuccess;
+    hop(a, b); hop(b, a);
+  }
+  ok = ok && hipEventRecord(e1, a) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+  float ms = 0.f;
+  ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+  for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  return ok ? ms * 1e3f / (2 * n) : -1.f;
+}
+
+// Worker queues.  The command processor has 4 pipes; a hardware queue lives on one of them (assigned round-robin as HIP
+// creates its queues) and queues that share a pipe are served in time slices: a dependency between two such queues costs
+// 35-85 us on an idle chip instead of 15, and 110-140 us inside a step (tools/bench_hop_matrix.py, bench_hop_neighbors.py).
+// So the plan wants the caller's stream plus n_workers streams that are pairwise on different pipes.  Which pipe a new
+// stream lands on depends on everything the process created before, so it is MEASURED: candidates are created, each
+// is kept if its hop to the caller's stream and to every worker kept so far is a fast one, the rest are destroyed.
+int choose_workers(b2t_exec* ex, hipStream_t main) {
+  for (hipStream_t st : ex->phys) if (st) (void)hipStreamDestroy(st);
+  ex->phys.clear();
+  const int want = ex->n_workers, n_cand = 2 * (want + 1) + 2;
+  std::vector<hipStream_t> cand(n_cand, nullptr);
+  for (int i = 0; i < n_cand; ++i)
+    if (check_hip(hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking), "hipStreamCreate")) return 1;
+  static const bool verbose = getenv("B2T_PLAN_DUMP") != nullptr;
+  std::vector<float> to_main(n_cand);
+  float best = 1e30f;
+  for (int i = 0; i < n_cand; ++i) {
+    to_main[i] = hop_us(ex, main, cand[i]);
+    if (to_main[i] < 0.f) { set_error("exec: queue calibration failed (HIP error)"); return 1; }
+    best = std::min(best, to_main[i]);
+  }
+  const float thr = 1.6f * best + 2.f;
+  std::vector<int> kept;
+  for (int i = 0; i < n_cand && (int)kept.size() < want; ++i) {
+    bool fast = to_main[i] <= thr;
+    for (size_t k = 0; k < kept.size() && fast; ++k) fast = hop_us(ex, cand[kept[k]], cand[i]) <= thr;
+    if (fast) kept.push_back(i);
+  }
+  for (int i = 0; i < n_cand && (int)kept.size() < want; ++i)   // fewer pipes than queues wanted: take what is there
+    if (std::find(kept.begin(), kept.end(), i) == kept.end()) kept.push_back(i);
+  if (verbose) {
+    fprintf(stderr, "exec: hop to the caller's stream (us):");
+    for (int i = 0; i < n_cand; ++i) fprintf(stderr, " %.1f", to_main[i]);
+    fprintf(stderr, " -> workers");
+    for (int k : kept) fprintf(stderr, " %d", k);
+    fprintf(stderr, "\n");
+  }
+  for (int i = 0; i < n_cand; ++i) {
+    if (std::find(kept.begin(), kept.end(), i) != kept.end()) ex->phys.push_back(cand[i]);
+    else (void)hipStreamDestroy(cand[i]);
+  }
+  ex->have_workers = true;
+  ex->workers_for = main;
+  return 0;
+}
+
 // queue 0 = the caller's stream; the workers only when the plan is pipelined (shapes whose sweeps cannot share the chip
 // run as one in-order sequence)
-int plan_queues(b2t_exec* ex, hipStream_t main, bool piped, hipStream_t* qs) {
-  qs[0] = main;
+int plan_queues(Ctx& c, bool piped, hipStream_t* qs) {
+  b2t_exec* ex = c.ex;
+  qs[0] = c.main;
   if (!piped) return 1;
+  if (!ex->have_workers || ex->workers_for != c.main) c.call(choose_workers(ex, c.main));
   int n = 1;
   for (hipStream_t st : ex->phys) if (n < 8) qs[n++] = st;
   return n;
@@ -316,19 +394,10 @@ extern "C" int b2t_exec_create(int n_layers, b2t_exec** out) {
   B2T_REQUIRE(out && n_layers >= 1 && n_layers <= MAXL, "exec_create: 1..%d layers", MAXL);
   b2t_exec* ex = new b2t_exec();
   ex->L = n_layers;
-  // Worker queues: three, so that with the caller's stream the plan occupies four hardware queues -- one per pipe of the
-  // command processor (queues are assigned to pipes round-robin in creation order; a fifth queue shares a pipe with
-  // another one and every dependency that crosses them then waits for a time slice: 26.7 vs 22.2 ms per step with 5 + 1).
-  int n_workers = 3;
-  if (const char* env = getenv("B2T_WORKERS")) n_workers = std::max(1, std::min(7, atoi(env)));
-  ex->phys.assign(n_workers, nullptr);
-  for (int i = 0; i < n_workers; ++i) {
-    if (check_hip(hipStreamCreateWithFlags(&ex->phys[i], hipStreamNonBlocking), "hipStreamCreate")) {
-      b2t_exec_destroy(ex);
-      return 1;
-    }
-  }
-  ex->sweep_qmask = getenv("B2T_SWEEP_ANYQ") ? 0xffffffffu : (((1u << n_workers) - 1u) << 1);
+  // Worker queues are created at the first pipelined pass, when the caller's stream is known (choose_workers).
+  if (const char* env = getenv("B2T_WORKERS")) ex->n_workers = std::max(1, std::min(7, atoi(env)));
+  ex->sweep_qmask = getenv("B2T_SWEEP_WORKERS_ONLY") ? (((1u << ex->n_workers) - 1u) << 1) : 0xffffffffu;
+  if (check_hip(hipMalloc(reinterpret_cast<void**>(&ex->scratch), 256), "hipMalloc")) { delete ex; return 1; }
   *out = ex;
   return 0;
 }
@@ -336,6 +405,7 @@ extern "C" int b2t_exec_create(int n_layers, b2t_exec** out) {
 extern "C" int b2t_exec_destroy(b2t_exec* ex) {
   if (!ex) return 0;
   for (hipStream_t st : ex->phys) if (st) (void)hipStreamDestroy(st);
+  if (ex->scratch) (void)hipFree(ex->scratch);
   for (hipEvent_t e : ex->pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->tpool) (void)hipEventDestroy(e);
   delete ex;
@@ -482,7 +552,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
     for (int l = 0; l + 1 < L; ++l) P.dep(t_end, t_sw[l][nc - 1]);
   }
   hipStream_t qs[8];
-  const int nq = plan_queues(ex, c.main, nc > 1, qs);
+  const int nq = plan_queues(c, nc > 1, qs);
   run_plan(c, P, nq, qs);
   return c.rc;
 }
@@ -698,7 +768,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     P.dep(t_end, t_top);
   }
   hipStream_t qs[8];
-  const int nq = plan_queues(ex, c.main, nc > 1, qs);
+  const int nq = plan_queues(c, nc > 1, qs);
   run_plan(c, P, nq, qs);
   return c.rc;
 }
