@@ -157,10 +157,12 @@ int b2t_transpose_f32(const float* in, float* out, int rows, int cols, void* str
 int b2t_broadcast_rows_f32(const float* src, float* dst, int rows, int n, void* stream);
 
 /* ---- a3-a6 + a8: the model pass as ONE host call (GRUDecoder.forward, rnn_model.py:88-134, and its autograd
- * backward, rnn_trainer.py:547).  The executor owns the HIP streams and events of the execution plan (one sweep stream +
- * one GEMM stream per layer; the L layers are software-pipelined over `chunks` time chunks) and issues every launch of a
- * pass from C++ -- ~250 launches and ~100 event operations per training step that cost 14 ms of Python/ctypes time per
- * 25 ms step when they were issued one by one from the host language.  All device memory still comes from the caller:
+ * backward, rnn_trainer.py:547).  The executor owns the HIP streams and events of the execution plan (the L layers are
+ * software-pipelined over `chunks` time chunks; the pass is a task graph list-scheduled onto the caller's stream plus
+ * three worker streams that the first pipelined pass picks on different command-processor pipes, a one-time ~30 ms
+ * measurement that synchronises with the device) and issues every launch of a pass from C++ -- ~250 launches and ~100
+ * event operations per training step that cost 14 ms of Python/ctypes time per 25 ms step when they were issued one by
+ * one from the host language.  All device memory of a pass still comes from the caller:
  * `ws` (b2t_pass_ws_bytes bytes, any contents; holds the activations forward saves for backward, so one forward/backward
  * pair per ws at a time) and `sync_ws` (b2t_exec_sync_bytes bytes, zeroed once, persistent: the sweeps' counters and
  * error words).  Asynchronous: on return everything is enqueued and the caller's stream has joined the side streams. */

@@ -4,10 +4,12 @@
 //
 // Execution plan.  A GRU layer is a strictly serial chain over time and one layer's persistent sweep keeps only
 // (H/16) x ceil(B/16) workgroups busy, each mostly waiting on the inter-workgroup hand-off.  The time axis is cut into
-// chunks and the layers are software-pipelined over them on per-layer HIP streams: while layer l sweeps chunk c, layer
-// l+1 runs its input-projection GEMM + sweep on chunk c-1; in the backward pass the weight-gradient GEMMs of layer l
-// run on that layer's GEMM stream while the layers below are still sweeping.  Dependencies are HIP events; the
-// caller's stream joins the side streams before the function returns (nothing synchronises with the host).
+// chunks and the layers are software-pipelined over them: while layer l sweeps chunk c, layer l+1 runs its
+// input-projection GEMM + sweep on chunk c-1; in the backward pass the weight-gradient GEMMs of layer l run while the
+// layers below are still sweeping.  The pass is built as a task graph and list-scheduled onto FOUR in-order queues (the
+// caller's stream + three workers on different command-processor pipes, see run_plan / choose_workers); dependencies
+// that cross queues are HIP events; the caller's stream joins the workers before the function returns (nothing
+// synchronises with the host).
 #include <stdio.h>
 #include <stdlib.h>
 #include <functional>

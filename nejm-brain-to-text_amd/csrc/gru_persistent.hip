@@ -251,6 +251,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
 #pragma unroll
   for (int n = 0; n < NT; ++n) dzterm[n] = 0.f;
 
+#ifdef B2T_TIMING
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = T - 1; t >= -1; --t) {
    {
     // operands of the elementwise part do not depend on the recurrence: fetch them first
@@ -266,8 +270,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
         dy[n] = dyp[0];
       }
     }
+    TSTAMP(0)   // operand prefetch issue
     if (t < T - 1) {
       wait_count(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
+      TSTAMP(1)   // poll + barrier
       const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
       f32x4 acc[NT];
 #pragma unroll
@@ -286,8 +292,11 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
           for (int n = 0; n < NT; ++n) acc[n] = mfma_chunk16<BF16>(a[h2], w[n][ci], acc[n]);
         }
       }
+      asm volatile("s_nop 0" :: "v"(acc[0][0]));
+      TSTAMP(2)   // loads + MFMA
       float s[NT];
       cross_wave_reduce<NT>(red, acc, s, wave, lane);
+      TSTAMP(3)   // reduce
 #pragma unroll
       for (int n = 0; n < NT; ++n) carry[n] = s[n] + dzterm[n];
     } else if (dh_last && live) {
@@ -318,7 +327,9 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
         dzterm[n] = d * z[n];
       }
     }
+    TSTAMP(4)   // gate gradients (waits for the prefetched operands)
     __syncthreads();
+    TSTAMP(5)   // stage barrier
     {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores per 16-unit tile
       const int r2 = lane >> 2;
 #pragma unroll
@@ -331,9 +342,14 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       }
     }
     publish_count(cnt + (size_t)t * CSTRIDE);
+    TSTAMP(6)   // tile store + drain + publish
    }
   }
   finish_call(sync, pset);
+#ifdef B2T_TIMING
+  if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 17))
+    for (int i = 0; i < 7; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+#endif
 }
 
 size_t gru_persistent_sync_bytes(int T) { (void)T; return ((size_t)2 * SETW + 64) * sizeof(unsigned); }

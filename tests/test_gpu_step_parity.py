@@ -525,3 +525,47 @@ def test_resident_dataset_from_hdf5_sessions_stores_each_trial_once(tmp_path, mo
     monkeypatch.setattr(ds.ResidentDataset, "MAX_BYTES", 1000)
     with pytest.raises(RuntimeError, match="exceed"):
         ds.ResidentDataset.from_batches(ds.SyntheticTrials(50, 8, 3, 20, 41, 2), device='cuda:0')
+
+
+# ------------------------------------------------------------------------------------------------
+def test_schedule_independent(monkeypatch):
+    """The pass is a task graph list-scheduled onto the caller's stream + worker queues (csrc/exec.cpp): which queue a
+    task lands on must not change a single bit.  Same model, batch, chunking: 1, 2 and 3 workers, sweeps on any queue or
+    on the workers only, weight gradients per chunk -> identical gradient arenas and logits (every accumulation order is a
+    dependency edge of the graph, not a property of the schedule)."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    F, H, D, C, L, B, T, S = 64, 128, 6, 41, 3, 32, 160, 12
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, F, generator=g).to(dev)
+    day = torch.randint(0, D, (B,), generator=g)
+    tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(3, S + 1, (B,), generator=g)
+    nt = torch.randint(120, T + 1, (B,), generator=g)
+    for b in range(B):
+        tgt[b, tl[b]:] = 0
+    monkeypatch.setitem(ops.PIPELINE, "chunks", 5)
+    monkeypatch.setitem(ops.PIPELINE, "chunks_bwd", 3)
+
+    def grads(workers, workers_only, mask):
+        monkeypatch.setenv("B2T_WORKERS", str(workers))
+        if workers_only:
+            monkeypatch.setenv("B2T_SWEEP_WORKERS_ONLY", "1")
+        else:
+            monkeypatch.delenv("B2T_SWEEP_WORKERS_ONLY", raising=False)
+        monkeypatch.setitem(ops.PIPELINE, "wgrad_chunk_mask", mask)
+        torch.manual_seed(3)
+        m = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()     # a fresh model = a fresh executor
+        ts = TrainStep(m, step_args())
+        loss_b = ts.compute_grads(x, day, tgt, nt, tl)
+        torch.cuda.synchronize()
+        return ts.grad_arena.clone(), loss_b.clone()
+
+    for mask in (0, 0b111):
+        ref, loss = grads(3, False, mask)
+        assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
+        for workers, only in ((1, False), (2, False), (3, True), (5, False)):
+            got, l2 = grads(workers, only, mask)
+            assert torch.equal(got, ref), f"workers={workers} workers_only={only} mask={mask}: gradients differ"
+            assert torch.equal(l2, loss)

@@ -21,6 +21,12 @@ for i in range(6):
 torch.cuda.synchronize()
 sync = model._ws.sync(bench.L, dev).cpu().numpy()
 names = ["poll", "loads+mfma", "reduce", "gates", "stagebar", "store+pub", "(split:loads)"]
+bnames = ["prefetch", "poll", "loads+mfma", "reduce", "gates", "stagebar", "store+pub"]
+for l in range(bench.L):
+    w = sync[bench.L + l][8:24]
+    for blk, off in ((0, 0), (17, 8)):
+        tot = int(sum(w[off:off + 7]))
+        print(f"bwd layer {l} block {blk:2d}: " + " ".join(f"{n}={int(w[off + i])}" for i, n in enumerate(bnames)) + f" | total {tot}")
 for l in range(bench.L):
     w = sync[l][8:24]
     for blk, off in ((0, 0), (17, 8)):
