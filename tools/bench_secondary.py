@@ -156,10 +156,31 @@ def decode_wfst_tlg():
     return r
 
 
+def trainer_loop_c2():
+    """rnn_trainer.train() at the C2 shape on a synthetic device-resident dataset (tools/bench_trainer.py): the whole loop
+    around the step that `value` times."""
+    import contextlib, io, logging
+    import bench_trainer
+    logging.disable(logging.CRITICAL)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            bench_trainer.run(12)
+            t0, _ = bench_trainer.run(40)
+            t1, st = bench_trainer.run(160)
+    finally:
+        logging.disable(logging.NOTSET)
+    ms = (t1 - t0) / 120 * 1e3
+    return dict(ms_per_step=round(ms, 3), sentences_per_s=round(64e3 / ms, 1), dtype="f32",
+                workload="BrainToTextDecoder_Trainer.train() (rnn_trainer.py:486-651 counterpart): 5-layer GRU-512, B=64, T=500, 45 sessions, "
+                         "4 days per batch, device-resident synthetic dataset, on-GPU augmentation, lagged loss read, logging; "
+                         "(160-step run - 40-step run) / 120")
+
+
 def all_secondary():
     out = {}
     for name, fn in (("c3_f32", lambda: train_ms("c3", False)), ("c3_amp", lambda: train_ms("c3", True)),
-                     ("c2_amp", lambda: train_ms("c2", True)), ("decode_beam100_3gram", decode_beam100_3gram),
+                     ("c2_amp", lambda: train_ms("c2", True)), ("trainer_loop_c2_f32", trainer_loop_c2),
+                     ("decode_beam100_3gram", decode_beam100_3gram),
                      ("stream_32utt_5gram", stream_32utt_5gram), ("decode_wfst_tlg", decode_wfst_tlg)):
         sys.stderr.write(f"[secondary] {name} ...\n"); sys.stderr.flush()
         try:
