@@ -1,9 +1,11 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_step_parity.py tests/test_gpu_trainer.py -m gpu -q -x 2>&1 | tail -3
-python - <<'PY'
-import sys, json
-sys.path.insert(0, 'tools'); sys.path.insert(0, 'nejm-brain-to-text_amd')
-import bench_secondary as S
-for name, fn in (("c3_f32", lambda: S.train_ms("c3", False)), ("c3_amp", lambda: S.train_ms("c3", True))):
-    print(name, fn()["ms_per_step"])
-PY
+run() { env "$@" timeout 120 python tools/bench_c3.py 2>&1 | tail -1 | cut -c1-110; }
+echo "amp serial:        $(run B2T_AMP=1)"
+echo "amp 2/2:           $(run B2T_AMP=1 B2T_CHUNKS=2 B2T_CHUNKS_BWD=2)"
+echo "amp 3/2:           $(run B2T_AMP=1 B2T_CHUNKS=3 B2T_CHUNKS_BWD=2)"
+echo "amp 4/3:           $(run B2T_AMP=1 B2T_CHUNKS=4 B2T_CHUNKS_BWD=3)"
+echo "amp 6/4:           $(run B2T_AMP=1 B2T_CHUNKS=6 B2T_CHUNKS_BWD=4)"
+echo "amp 4/3 workers-only: $(run B2T_AMP=1 B2T_CHUNKS=4 B2T_CHUNKS_BWD=3 B2T_SWEEP_WORKERS_ONLY=1)"
+echo "f32 serial:        $(run A=1)"
+echo "f32 2/2:           $(run B2T_CHUNKS=2 B2T_CHUNKS_BWD=2)"
+echo "f32 3/2:           $(run B2T_CHUNKS=3 B2T_CHUNKS_BWD=2)"
