@@ -188,6 +188,14 @@ typedef struct b2t_pass_t {
 typedef struct b2t_exec b2t_exec;
 int b2t_exec_create(int n_layers, b2t_exec** out);
 int b2t_exec_destroy(b2t_exec* ex);
+/* HOST ONLY: the list scheduler the executor places a pass's task graph with (HEFT: longest remaining path first, earliest
+ * start on one of n_queues in-order queues, gaps may be filled; a dependency that crosses queues costs a fixed hop).  Task i
+ * has duration est_us[i], may run on the queues set in qmask[i] (bit q; ignored when n_queues == 1) and depends on
+ * deps[dep_off[i] .. dep_off[i+1]) (ids < i: tasks are listed in a topological order).  Outputs: queue[i], the planned
+ * start_us[i], and order[0..n) = the order in which the executor issues the tasks (planned start, ties by id).  Pure host
+ * arithmetic, deterministic; exported so that the CPU tests can check the schedule's invariants without a GPU. */
+int b2t_plan_schedule_host(int n_tasks, const float* est_us, const uint32_t* qmask, const int32_t* dep_off,
+                           const int32_t* deps, int n_queues, int32_t* queue, float* start_us, int32_t* order);
 size_t b2t_exec_sync_bytes(int n_layers);          /* 2 * n_layers blocks of b2t_gru_sync_bytes(0): fwd l, then bwd l */
 size_t b2t_pass_ws_bytes(const b2t_model_t* m, const b2t_pass_t* p);
 /* x [B][T][F], day_idx [B], states [L][B][H] or NULL (h0)  ->  logits [B][T'][C], hidden [L][B][H] */

@@ -237,7 +237,10 @@ struct Plan {
 
 float est_gemm(double M, double N, double K, double Z = 1) { return 12.f + (float)(2.0 * M * N * K * Z / 80e6); }   // ~80 TF/s + launch
 
-void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
+// The scheduling step alone (host arithmetic, no HIP): fills q / start / end / rank / cross of every task and returns the
+// issue order (planned start, ties by task id).  Tasks must be listed in a topological order (dependencies have smaller
+// ids).  Exposed for the CPU tests as b2t_plan_schedule_host.
+std::vector<int> schedule_plan(Plan& P, int nq) {
   const int n = (int)P.t.size();
   std::vector<std::vector<int>> succ(n);
   for (int i = 0; i < n; ++i) for (int d : P.t[i].deps) succ[d].push_back(i);
@@ -252,19 +255,20 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   std::vector<std::vector<std::pair<float, float>>> busy(nq);
   for (int id : order) {
     Task& k = P.t[id];
+    const float dur = std::max(k.est, 0.5f);   // bookkeeping tasks occupy a slot too: two tasks of a queue never share a start
     int bq = -1; float bs = 0.f;
     for (int q = 0; q < nq; ++q) {
       if (!((k.qmask >> q) & 1u) && nq > 1) continue;
       float s = 0.f;
       for (int d : k.deps) s = std::max(s, P.t[d].end + (P.t[d].q != q ? HOP_US : 0.f));
       for (const auto& iv : busy[q]) {
-        if (s + k.est <= iv.first) break;
+        if (s + dur <= iv.first) break;
         s = std::max(s, iv.second);
       }
       if (bq < 0 || s < bs - 0.5f) { bq = q; bs = s; }
     }
     if (bq < 0) bq = 0;
-    k.q = bq; k.start = bs; k.end = bs + k.est;
+    k.q = bq; k.start = bs; k.end = bs + dur;
     auto& b = busy[bq];
     b.insert(std::upper_bound(b.begin(), b.end(), std::make_pair(k.start, k.end)), std::make_pair(k.start, k.end));
   }
@@ -272,6 +276,12 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
     return P.t[a].start != P.t[b].start ? P.t[a].start < P.t[b].start : a < b;
   });
+  return order;
+}
+
+void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
+  const int n = (int)P.t.size();
+  const std::vector<int> order = schedule_plan(P, nq);
   static const bool dump = getenv("B2T_PLAN_DUMP") != nullptr;
   if (dump) {
     fprintf(stderr, "plan: %d tasks on %d queues\n", n, nq);
@@ -411,6 +421,24 @@ extern "C" int b2t_exec_destroy(b2t_exec* ex) {
   for (hipEvent_t e : ex->pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->tpool) (void)hipEventDestroy(e);
   delete ex;
+  return 0;
+}
+
+extern "C" int b2t_plan_schedule_host(int n_tasks, const float* est_us, const uint32_t* qmask, const int32_t* dep_off,
+                                      const int32_t* deps, int n_queues, int32_t* queue, float* start_us, int32_t* order) {
+  B2T_REQUIRE(n_tasks >= 0 && n_queues >= 1 && n_queues <= 8 && (n_tasks == 0 || (est_us && qmask && dep_off && queue && start_us && order)),
+              "plan_schedule_host: bad arguments");
+  Plan P;
+  for (int i = 0; i < n_tasks; ++i) {
+    B2T_REQUIRE(est_us[i] >= 0.f && dep_off[i] <= dep_off[i + 1], "plan_schedule_host: task %d: negative estimate / bad dependency offsets", i);
+    const int t = P.add("task", est_us[i], qmask[i], {}, nullptr);
+    for (int k = dep_off[i]; k < dep_off[i + 1]; ++k) {
+      B2T_REQUIRE(deps && deps[k] >= 0 && deps[k] < i, "plan_schedule_host: task %d depends on %d (tasks must be listed in topological order)", i, deps ? deps[k] : -1);
+      P.dep(t, deps[k]);
+    }
+  }
+  const std::vector<int> ord = schedule_plan(P, n_queues);
+  for (int i = 0; i < n_tasks; ++i) { queue[i] = P.t[i].q; start_us[i] = P.t[i].start; order[i] = ord[i]; }
   return 0;
 }
 
