@@ -24,6 +24,7 @@
 namespace b2t {
 namespace {
 
+constexpr int BIG_DEG = 24, BIG_CAP = 4096;   // out-degree above which a token's arcs are walked by a whole wave; list capacity
 constexpr int NT = 1024;   // one workgroup per utterance; a frame holds thousands of tokens, each a dependent chain of gathers
 constexpr unsigned UMAX = 0xffffffffu;
 constexpr int MAX_C = 64;
@@ -97,60 +98,115 @@ struct Opts {
   int max_active, min_active;
 };
 
+#ifdef B2T_WFST_TIMING
+#define WT(i) { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); c.tacc[i] += now_ - c.tprev; c.tprev = now_; } }
+#else
+#define WT(i)
+#endif
+
 struct Ctx {
+#ifdef B2T_WFST_TIMING
+  unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
   Graph g; Lay l; Opts o;
   int max_frames, max_tok, max_link, hash;
   int* key; int* idx;          // the frame's hash (LDS or HBM)
   float* ll;                   // LDS: acoustic_scale * logp of the frame
   float* redf; int* redi;      // LDS reduction scratch [NT]
-  int* sh;                     // LDS scalars: [0] n_tok, [1] n_link, [2] changed, [3] overflow
+  int* sh;                     // LDS scalars: [0] n_tok, [1] n_link, [2] changed, [3] overflow, [4] number of wide tokens
+  int* big;                    // LDS [BIG_CAP]: the frame's tokens with more than BIG_DEG emitting arcs
 };
 
+// Block reductions: within a wave through lane permutes, across the NT / 64 waves through LDS -- two barriers instead
+// of the 2 log2(NT) of a tree over the whole block (a frame makes several of them on its serial path).
 __device__ __forceinline__ float block_min(Ctx& c, float v) {
-  c.redf[threadIdx.x] = v;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) c.redf[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int s = NT / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) c.redf[threadIdx.x] = fminf(c.redf[threadIdx.x], c.redf[threadIdx.x + s]);
-    __syncthreads();
-  }
-  const float r = c.redf[0];
+  float r = c.redf[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r = fminf(r, c.redf[w]);
   __syncthreads();
   return r;
 }
 __device__ __forceinline__ int block_sum(Ctx& c, int v) {
-  c.redi[threadIdx.x] = v;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) c.redi[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int s = NT / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) c.redi[threadIdx.x] += c.redi[threadIdx.x + s];
-    __syncthreads();
-  }
-  const int r = c.redi[0];
+  int r = c.redi[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r += c.redi[w];
   __syncthreads();
   return r;
 }
 
-// k-th smallest (0-based) of the ordered cost keys of tokens [t0, t1): bisection on the key bits (std::nth_element's value)
+// k-th smallest (0-based) of the ordered cost keys of tokens [t0, t1) (std::nth_element's value): radix select, four
+// rounds of 8 bits from the top -- a 256-bin histogram in LDS per round, the bin that holds rank k found by wave 0 with a
+// lane prefix sum -- instead of a 32-step bisection with a pass over the tokens and a block reduction per step.
 __device__ float kth_cost(Ctx& c, int t0, int t1, int k) {
-  unsigned lo = 0u, hi = UMAX;
-  while (lo < hi) {
-    const unsigned mid = lo + (hi - lo) / 2u;
-    int cnt = 0;
-    for (int t = t0 + threadIdx.x; t < t1; t += NT) cnt += (c.l.tok_cost[t] <= mid);
-    cnt = block_sum(c, cnt);
-    if (cnt >= k + 1) hi = mid; else lo = mid + 1u;
+  int* hist = c.redi + 64;           // [256]; redi[0 .. 63] stay free for block_sum, redi[320 ..] hold the round's result
+  int* res = c.redi + 320;           // [0] chosen digit, [1] rank inside the chosen bin
+  unsigned prefix = 0u;
+  int rank = k;
+  for (int round = 0; round < 4; ++round) {
+    const int shift = 24 - 8 * round;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int tb = t0; tb < t1; tb += NT) {
+      const int t = tb + (int)threadIdx.x;
+      const unsigned key = t < t1 ? c.l.tok_cost[t] : 0u;
+      const bool act = t < t1 && (round == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
+      const int d = (int)((key >> shift) & 255u);
+      if (round < 2) {
+        // the costs of a frame lie within a beam of each other: their top bits fall into a handful of bins, so the lanes
+        // of a wave that share a digit send ONE LDS atomic
+        unsigned long long todo = __ballot(act);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const int dl = __shfl(d, leader);
+          const unsigned long long peers = __ballot(act && d == dl);
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], __popcll(peers));
+          todo &= ~peers;
+        }
+      } else if (act) {
+        atomicAdd(&hist[d], 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+      const int excl = incl - mine;
+      if (rank >= excl && rank < incl) {      // exactly one lane (0 <= rank < number of candidates)
+        int r = rank - excl, d = 4 * lane;
+        if (r >= h0) { r -= h0; ++d; if (r >= h1) { r -= h1; ++d; if (r >= h2) { r -= h2; ++d; } } }
+        res[0] = d; res[1] = r;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)res[0] << shift;
+    rank = res[1];
   }
-  return o2f(lo);
+  __syncthreads();
+  return o2f(prefix);
 }
 
 __device__ __forceinline__ unsigned hash_of(int state, int mask) { return ((unsigned)state * 2654435761u) & (unsigned)mask; }
 
-// FindOrAddToken, claim phase: make sure `state` has a slot (and a token) in the frame being built
-__device__ __forceinline__ void claim(Ctx& c, int state) {
+// FindOrAddToken, claim phase: make sure `state` has a slot (and a token) in the frame being built; returns the slot
+// (idx[slot] is valid after the next barrier) or -1 when the hash is full
+__device__ __forceinline__ int claim(Ctx& c, int state) {
   const int mask = c.hash - 1;
   unsigned s = hash_of(state, mask);
   for (int probe = 0; probe < c.hash; ++probe, s = (s + 1) & mask) {
     const int k = __hip_atomic_load(&c.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (k == state) return;
+    if (k == state) return (int)s;
     if (k == -1) {
       int expected = -1;
       if (__hip_atomic_compare_exchange_strong(&c.key[s], &expected, state, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
@@ -161,12 +217,13 @@ __device__ __forceinline__ void claim(Ctx& c, int state) {
         } else {
           c.idx[s] = -1; atomicOr(&c.sh[3], 1);
         }
-        return;
+        return (int)s;
       }
-      if (expected == state) return;
+      if (expected == state) return (int)s;
     }
   }
   atomicOr(&c.sh[3], 4);   // hash full
+  return -1;
 }
 __device__ __forceinline__ int find(Ctx& c, int state) {
   const int mask = c.hash - 1;
@@ -289,6 +346,7 @@ __device__ void advance(Ctx& c) {
   const int f = c.l.h->n_frames;
   if (f >= c.max_frames) { if (threadIdx.x == 0) atomicOr(&c.sh[3], 8); __syncthreads(); return; }
   const int t0 = c.l.tok_off[f], t1 = c.l.tok_off[f + 1];
+  WT(0)
   // ---- GetCutoff (:650-720)
   float best = INFINITY;
   for (int t = t0 + threadIdx.x; t < t1; t += NT) best = fminf(best, o2f(c.l.tok_cost[t]));
@@ -306,22 +364,55 @@ __device__ void advance(Ctx& c) {
       if (min_cut > beam_cutoff) { cur_cutoff = min_cut; adaptive = min_cut - best + c.o.beam_delta; }
     }
   }
+  WT(1)   // best + k-th cost
   const float cost_offset = -best;
   const float lp = c.o.length_penalty;
-  // ---- ProcessEmitting (:722-824), pass A: the frame's best candidate -> next_cutoff
+  // ---- ProcessEmitting (:722-824).  A thread owns a token, but out-degrees are skewed (the word-boundary states of L o G
+  // fan out into every word: hundreds of arcs, each a dependent chain of gathers + a hash probe): tokens with more than
+  // BIG_DEG emitting arcs go to an LDS list and a whole WAVE walks their arcs, 64 at a time.
+  // Pass A: the frame's best candidate -> next_cutoff
   float mn = INFINITY;
   int narcs = 0;
+  if (threadIdx.x == 0) c.sh[4] = 0;
+  __syncthreads();
+  auto arc_cost = [&](float cur, int s, int a, float& ac, float& gc) {
+    ac = cost_offset - c.ll[g.ilabel[a] - 1];
+    gc = g.weight[a];
+    if (g.next[a] != s) gc += lp;
+    return cur + ac + gc;
+  };
   for (int t = t0 + threadIdx.x; t < t1; t += NT) {
     const float cur = o2f(c.l.tok_cost[t]);
     if (!(cur <= cur_cutoff)) continue;
     const int s = c.l.tok_state[t];
-    narcs += g.row[s + 1] - g.row[s] - g.n_eps[s];
-    for (int a = g.row[s] + g.n_eps[s]; a < g.row[s + 1]; ++a) {
-      const float ac = cost_offset - c.ll[g.ilabel[a] - 1];
-      float gc = g.weight[a];
-      if (g.next[a] != s) gc += lp;
-      mn = fminf(mn, cur + ac + gc);
+    const int a0 = g.row[s] + g.n_eps[s], a1 = g.row[s + 1];
+    narcs += a1 - a0;
+    if (a1 - a0 > BIG_DEG) {
+      const int i = atomicAdd(&c.sh[4], 1);
+      if (i < BIG_CAP) c.big[i] = t;
+      continue;                            // (a list overflow is handled below: the frame then runs thread-per-token)
     }
+    for (int a = a0; a < a1; ++a) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); }
+  }
+  __syncthreads();
+  const bool listed = c.sh[4] <= BIG_CAP;
+  const int nbig = listed ? c.sh[4] : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!listed) {                           // more wide tokens than the list holds: walk them per thread after all
+    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
+      const float cur = o2f(c.l.tok_cost[t]);
+      if (!(cur <= cur_cutoff)) continue;
+      const int s = c.l.tok_state[t];
+      const int a0 = g.row[s] + g.n_eps[s], a1 = g.row[s + 1];
+      if (a1 - a0 <= BIG_DEG) continue;
+      for (int a = a0; a < a1; ++a) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); }
+    }
+  }
+  for (int b = wave; b < nbig; b += NT / 64) {
+    const int t = c.big[b];
+    const float cur = o2f(c.l.tok_cost[t]);
+    const int s = c.l.tok_state[t];
+    for (int a = g.row[s] + g.n_eps[s] + lane; a < g.row[s + 1]; a += 64) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); }
   }
   mn = block_min(c, mn);
   narcs = block_sum(c, narcs);
@@ -331,41 +422,60 @@ __device__ void advance(Ctx& c) {
     c.l.h->arcs_lo = lo;
   }
   const float next_cutoff = mn + adaptive;
+  WT(2)   // pass A
   clear_hash(c);
+  WT(3)   // clear hash
   const int n0 = min(c.sh[0], c.max_tok), l0 = min(c.sh[1], c.max_link);
-  // pass B: claim tokens, then record links and minimise costs
-  for (int phase = 0; phase < 2; ++phase) {
+  // pass B.  Phase 0 walks the arcs once: every surviving arc claims its destination's hash slot and is recorded as a
+  // forward link that still names the SLOT (token ids are handed out by the claim's winner and are only safe to read after
+  // a barrier).  Phase 1 is a flat, perfectly balanced loop over those links: slot -> token id, cost minimisation.
+  {
+    auto visit = [&](int t, float cur, int s, int a) {
+      float ac, gc;
+      const float tot = arc_cost(cur, s, a, ac, gc);
+      if (!(tot < next_cutoff)) return;
+      const int slot = claim(c, g.next[a]);
+      if (slot < 0) return;
+      const int li = atomicAdd(&c.sh[1], 1);
+      if (li < c.max_link) {
+        c.l.link_src[li] = t; c.l.link_dst[li] = slot; c.l.link_arc[li] = a; c.l.link_ac[li] = ac; c.l.link_graph[li] = gc;
+      } else {
+        atomicOr(&c.sh[3], 2);
+      }
+    };
     for (int t = t0 + threadIdx.x; t < t1; t += NT) {
       const float cur = o2f(c.l.tok_cost[t]);
       if (!(cur <= cur_cutoff)) continue;
       const int s = c.l.tok_state[t];
-      for (int a = g.row[s] + g.n_eps[s]; a < g.row[s + 1]; ++a) {
-        const float ac = cost_offset - c.ll[g.ilabel[a] - 1];
-        float gc = g.weight[a];
-        if (g.next[a] != s) gc += lp;
-        const float tot = cur + ac + gc;
-        if (!(tot < next_cutoff)) continue;
-        if (phase == 0) {
-          claim(c, g.next[a]);
-        } else {
-          const int id = find(c, g.next[a]);
-          if (id < 0) continue;
-          const int li = atomicAdd(&c.sh[1], 1);
-          if (li < c.max_link) {
-            c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = ac; c.l.link_graph[li] = gc;
-            atomicMin(&c.l.tok_cost[id], f2o(tot));
-          } else {
-            atomicOr(&c.sh[3], 2);
-          }
-        }
-      }
+      const int a0 = g.row[s] + g.n_eps[s], a1 = g.row[s + 1];
+      if (listed && a1 - a0 > BIG_DEG) continue;
+      for (int a = a0; a < a1; ++a) visit(t, cur, s, a);
+    }
+    for (int b = wave; b < nbig; b += NT / 64) {
+      const int t = c.big[b];
+      const float cur = o2f(c.l.tok_cost[t]);
+      const int s = c.l.tok_state[t];
+      for (int a = g.row[s] + g.n_eps[s] + lane; a < g.row[s + 1]; a += 64) visit(t, cur, s, a);
     }
     __syncthreads();
+    WT(4)   // pass B: arc walk (claim + link records)
+    const int l1 = min(c.sh[1], c.max_link);
+    for (int li = l0 + threadIdx.x; li < l1; li += NT) {
+      int id = c.idx[c.l.link_dst[li]];
+      if (id < 0) id = 0;                  // token capacity exceeded: the overflow bit is set and the caller discards the result
+      const float tot = o2f(c.l.tok_cost[c.l.link_src[li]]) + c.l.link_ac[li] + c.l.link_graph[li];
+      c.l.link_dst[li] = id;
+      atomicMin(&c.l.tok_cost[id], f2o(tot));
+    }
+    __syncthreads();
+    WT(5)   // pass B: link walk (token ids, costs)
   }
   if (threadIdx.x == 0) c.l.link_off[2 * f + 2] = min(c.sh[1], c.max_link);   // [emitting links f -> f+1]
   __syncthreads();
   nonemitting(c, n0, next_cutoff);
+  WT(6)   // epsilon closure + links
   best_links(c, l0, min(c.sh[1], c.max_link));
+  WT(7)   // best links
   if (threadIdx.x == 0) {
     c.l.cost_offset[f] = cost_offset;
     c.l.tok_off[f + 2] = min(c.sh[0], c.max_tok);
@@ -390,9 +500,10 @@ __global__ __launch_bounds__(NT) void wfst_reset_kernel(Graph g, char* state, si
                                                          int max_tok, int max_link, int hash, int use_lds) {
   extern __shared__ int dyn[];
   __shared__ float ll[MAX_C], redf[NT];
-  __shared__ int redi[NT], sh[4];
+  __shared__ int redi[NT], sh[8], big[BIG_CAP];
   Ctx c;
   setup(c, g, state, blockIdx.x, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
+  c.big = big;
   init_decoding(c);
 }
 
@@ -402,11 +513,12 @@ __global__ __launch_bounds__(NT) void wfst_search_kernel(Graph g, char* state, s
                                                           const float* __restrict__ logp, const int* __restrict__ lens, int T, int C) {
   extern __shared__ int dyn[];
   __shared__ float ll[MAX_C], redf[NT];
-  __shared__ int redi[NT], sh[4];
+  __shared__ int redi[NT], sh[8], big[BIG_CAP];
   __shared__ int dec[2];
   Ctx c;
   const int u = blockIdx.x;
   setup(c, g, state, u, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
+  c.big = big;
   if (threadIdx.x == 0) { sh[0] = c.l.h->n_tok; sh[1] = c.l.h->n_link; sh[2] = 0; sh[3] = c.l.h->overflow; }
   __syncthreads();
   const int n = lens ? min(lens[u], T) : T;
@@ -445,6 +557,11 @@ __global__ __launch_bounds__(NT) void wfst_search_kernel(Graph g, char* state, s
     if (threadIdx.x == 0) c.l.h->num_input += 1;
     __syncthreads();
   }
+#ifdef B2T_WFST_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("wfst u0 cycles: other %llu | cutoff %llu | passA %llu | clear %llu | claim %llu | relax %llu | eps %llu | best_links %llu\n", c.tacc[0], c.tacc[1],
+           c.tacc[2], c.tacc[3], c.tacc[4], c.tacc[5], c.tacc[6], c.tacc[7]);
+#endif
 }
 
 // Best path by backpointers (lattice-faster-online-decoder.cc:58-150): alignment (ilabels), words (olabels), costs.
