@@ -24,6 +24,7 @@
 namespace b2t {
 namespace {
 
+constexpr int BP_NT = 256;   // threads of the best-path kernel (parallel argmin over the last frame, serial backtrace)
 constexpr int BIG_DEG = 24, BIG_CAP = 4096;   // out-degree above which a token's arcs are walked by a whole wave; list capacity
 constexpr int NT = 1024;   // one workgroup per utterance; a frame holds thousands of tokens, each a dependent chain of gathers
 constexpr unsigned UMAX = 0xffffffffu;
@@ -570,22 +571,40 @@ __global__ void wfst_best_path_kernel(Graph g, char* state, size_t state_bytes, 
                                       int use_final, int max_len, int* ali, int* ali_frame, int* n_ali, int* words, int* n_words,
                                       float* costs) {
   const int u = blockIdx.x;
-  if (threadIdx.x != 0) return;
   Lay l;
   layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
   const int F = l.h->n_frames;
-  n_ali[u] = 0; n_words[u] = 0; costs[2 * u] = 0.f; costs[2 * u + 1] = 0.f;
+  if (threadIdx.x == 0) { n_ali[u] = 0; n_words[u] = 0; costs[2 * u] = 0.f; costs[2 * u + 1] = 0.f; }
   if (F == 0) return;
+  // the cheapest token of the last frame (first one among equals, as a serial scan finds it): all threads, then a reduction
+  __shared__ float r_cost[BP_NT], r_fc[BP_NT];
+  __shared__ int r_tok[BP_NT];
   const int t0 = l.tok_off[F], t1 = l.tok_off[F + 1];
   float best = INFINITY, best_fc = 0.f; int bt = -1;
-  for (int t = t0; t < t1; ++t) {
+  const bool with_final = use_final && l.h->has_final;
+  for (int t = t0 + (int)threadIdx.x; t < t1; t += BP_NT) {
     float cost = o2f(l.tok_cost[t]), fc = 0.f;
-    if (use_final && l.h->has_final) {
+    if (with_final) {
       fc = g.final_cost[l.tok_state[t]];
       cost = fc == INFINITY ? INFINITY : cost + fc;
     }
     if (cost < best) { best = cost; bt = t; best_fc = fc; }
   }
+  r_cost[threadIdx.x] = best; r_fc[threadIdx.x] = best_fc; r_tok[threadIdx.x] = bt;
+  __syncthreads();
+  for (int sft = BP_NT / 2; sft > 0; sft >>= 1) {
+    if ((int)threadIdx.x < sft) {
+      const float oc = r_cost[threadIdx.x + sft]; const int ot = r_tok[threadIdx.x + sft];
+      const float mc = r_cost[threadIdx.x]; const int mt = r_tok[threadIdx.x];
+      if (ot >= 0 && (mt < 0 || oc < mc || (oc == mc && ot < mt))) {
+        r_cost[threadIdx.x] = oc; r_tok[threadIdx.x] = ot; r_fc[threadIdx.x] = r_fc[threadIdx.x + sft];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  best = r_cost[0]; bt = r_tok[0]; best_fc = r_fc[0];
+  (void)best;
   if (bt < 0) return;
   // walk back, writing from the end of the buffers; then shift to the front
   int na = 0, nw = 0, t = bt, frame = F - 1;
@@ -799,7 +818,7 @@ extern "C" int b2t_wfst_best_path(const b2t_wfst_graph_t* g, const b2t_wfst_opts
   { int rc = check_args(g, o, const_cast<void*>(state), U, "wfst_best_path"); if (rc) return rc; }
   B2T_REQUIRE(max_len > 0 && alignment && align_frame && n_align && words && n_words && costs, "wfst_best_path: null output");
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
-  hipLaunchKernelGGL(wfst_best_path_kernel, dim3(U), dim3(64), 0, as_stream(stream), to_graph(g), (char*)const_cast<void*>(state), sb,
+  hipLaunchKernelGGL(wfst_best_path_kernel, dim3(U), dim3(BP_NT), 0, as_stream(stream), to_graph(g), (char*)const_cast<void*>(state), sb,
                      o->max_frames, o->max_tokens, o->max_links, o->hash_size, use_final, max_len, alignment, align_frame, n_align,
                      words, n_words, costs);
   B2T_CHECK_LAUNCH("b2t_wfst_best_path");
