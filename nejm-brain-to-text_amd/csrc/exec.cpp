@@ -409,6 +409,7 @@ extern "C" int b2t_exec_create(int n_layers, b2t_exec** out) {
   // Worker queues are created at the first pipelined pass, when the caller's stream is known (choose_workers).
   if (const char* env = getenv("B2T_WORKERS")) ex->n_workers = std::max(1, std::min(7, atoi(env)));
   ex->sweep_qmask = getenv("B2T_SWEEP_WORKERS_ONLY") ? (((1u << ex->n_workers) - 1u) << 1) : 0xffffffffu;
+  if (const char* env = getenv("B2T_SWEEP_QMASK")) ex->sweep_qmask = (unsigned)strtoul(env, nullptr, 0);   // experiments: bit q = queue q
   if (check_hip(hipMalloc(reinterpret_cast<void**>(&ex->scratch), 256), "hipMalloc")) { delete ex; return 1; }
   *out = ex;
   return 0;
@@ -678,13 +679,21 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     d.a_div = B; d.a_s1 = ldd; d.a_s0 = (long long)Tp * ldd; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
     c.gemm(s, d);
   });
-  int t_bucket = P.add("head_w", est_gemm(Cc, H, (double)M) + 40.f, Q_ANY, {t_start}, [&](hipStream_t s) {
+  // Gradient buckets reach the data-parallel reducer through tiny tasks of their own, chained in a fixed order (head,
+  // layers L-1 .. 0, day, h0 -- every rank must start its collectives in the same order whatever its batch length did to
+  // the schedule); the GEMMs that fill the buckets stay free to run wherever and whenever the scheduler finds room.
+  int t_bucket = -1;
+  auto bucket = [&](int id, int producer) {
+    if (!bucket_cb) return;
+    t_bucket = P.add("bucket", 1.f, Q_ANY, {producer, t_bucket}, [&, id](hipStream_t s) { cb(id, s); });
+  };
+  const int t_head_w = P.add("head_w", est_gemm(Cc, H, (double)M) + 40.f, Q_ANY, {t_start}, [&](hipStream_t s) {
     b2t_gemm_desc d = gd(dlogits, w.out[L - 1] + (long long)B * H, grd->out_w, Cc, H, (int)M);
     d.a_kcontig = 0; d.a_div = B; d.a_s1 = ldd; d.a_s0 = (long long)Tp * ldd; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
     c.gemm(s, d, splitk_for(Cc, H, M), w.slab_head);
     c.call(b2t_colsum_f32(dlogits, M, Cc, ldd, grd->out_b, 0, w.cs_head, 1, 0, 0, reinterpret_cast<void*>(s)));
-    cb(0, s);
   });
+  bucket(0, t_head_w);
   // W_hh^T for the backward sweeps depends on the parameters only
   int t_wt[MAXL];
   for (int l = 0; l < L; ++l)
@@ -753,19 +762,16 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
         const int acc = per_chunk && ci != nc - 1 ? 1 : 0;
         const bool fin = ci == 0;
         const double K = (double)(w1 - w0) * B;
-        t_wg = P.add("wgrad", est_gemm(3 * H, H, K) + est_gemm(3 * H, In, K) + 60.f, Q_ANY, {t_bs[l][ci], t_wg, fin ? t_bucket : -1},
-                     [&, l, w0, w1, acc, fin](hipStream_t s) {
-          layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin);
-          if (fin) cb(1 + l, s);
-        });
+        t_wg = P.add("wgrad", est_gemm(3 * H, H, K) + est_gemm(3 * H, In, K) + 60.f, Q_ANY, {t_bs[l][ci], t_wg},
+                     [&, l, w0, w1, acc, fin](hipStream_t s) { layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin); });
       }
     }
     t_wg_last[l] = t_wg;
-    t_bucket = t_wg;   // buckets are handed to the reducer in a fixed order (head, layers L-1 .. 0, day, h0) on every rank
+    bucket(1 + l, t_wg);
   }
 
   // layer-0 input gradient -> day layer
-  const int t_dayfin = P.add("day_w", fast_day ? 60.f : est_gemm(F, F, T, B) + 200.f, Q_ANY, {t_dx[0][0], t_bucket}, [&](hipStream_t s) {
+  const int t_dayfin = P.add("day_w", fast_day ? 60.f : est_gemm(F, F, T, B) + 200.f, Q_ANY, {t_dx[0][0]}, [&](hipStream_t s) {
     void* sp = reinterpret_cast<void*>(s);
     if (!fast_day) {
       if (prm->patch > 0) c.call(b2t_patch_fold_f32(w.dV, w.dU, B, T, F, Tp, prm->patch, prm->stride, sp));
@@ -780,20 +786,20 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     }
     c.call(b2t_day_reduce_f32(w.day_slab, day_idx, B, (long long)F * F, grd->day_w, grd->day_w_stride, sp));
     c.call(b2t_day_reduce_f32(w.day_bslab, day_idx, B, bias_ld, grd->day_b, grd->day_b_stride, sp));
-    cb(L + 2, s);
   });
   if (!fast_day) for (int ci = 1; ci < nc; ++ci) P.dep(t_dayfin, t_dx[0][ci]);
+  bucket(L + 2, t_dayfin);
   // h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
-  const int t_h0 = P.add("h0", 20.f, Q_ANY, {t_dayfin}, [&](hipStream_t s) {
+  const int t_h0 = P.add("h0", 20.f, Q_ANY, {t_bs[0][0]}, [&](hipStream_t s) {
     void* sp = reinterpret_cast<void*>(s);
     if (!custom_states) c.call(b2t_colsum_f32(w.dh_init, (long long)L * B, H, H, grd->h0, 0, w.cs_h0, 1, 0, 0, sp));
     else c.call(check_hip(hipMemsetAsync(grd->h0, 0, sizeof(float) * H, s), "model_backward: h0 gradient"));
     if (dstates) c.call(check_hip(hipMemcpyAsync(dstates, w.dh_init, sizeof(float) * L * B * H, hipMemcpyDeviceToDevice, s), "model_backward: dstates"));
-    cb(L + 1, s);
   });
-  for (int l = 0; l < L; ++l) P.dep(t_h0, t_bs[l][0]);
+  for (int l = 1; l < L; ++l) P.dep(t_h0, t_bs[l][0]);
+  bucket(L + 1, t_h0);
   {
-    const int t_end = P.add("end", 0.f, Q_MAIN, {t_h0}, nullptr);
+    const int t_end = P.add("end", 0.f, Q_MAIN, {t_h0, t_dayfin, t_head_w, t_bucket}, nullptr);
     for (int l = 0; l < L; ++l) { P.dep(t_end, t_wg_last[l]); P.dep(t_end, t_dx[l][0]); }
     P.dep(t_end, t_top);
   }
