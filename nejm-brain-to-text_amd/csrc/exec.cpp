@@ -235,7 +235,15 @@ struct Plan {
   void dep(int task, int on) { if (task >= 0 && on >= 0) t[task].deps.push_back(on); }
 };
 
-float est_gemm(double M, double N, double K, double Z = 1) { return 12.f + (float)(2.0 * M * N * K * Z / 80e6); }   // ~80 TF/s + launch
+float est_step_us(int bwd) {   // microseconds per time step of a sweep inside the step (H = 512, B = 64)
+  static const float f = getenv("B2T_EST_FWD_US") ? (float)atof(getenv("B2T_EST_FWD_US")) : 5.5f;
+  static const float b = getenv("B2T_EST_BWD_US") ? (float)atof(getenv("B2T_EST_BWD_US")) : 6.0f;
+  return bwd ? b : f;
+}
+float est_gemm(double M, double N, double K, double Z = 1) {   // launch + FLOPs at the rate a GEMM reaches next to the sweeps
+  static const double tfs = getenv("B2T_EST_GEMM_TFS") ? atof(getenv("B2T_EST_GEMM_TFS")) : 80.0;
+  return 12.f + (float)(2.0 * M * N * K * Z / (tfs * 1e6));
+}
 
 // The scheduling step alone (host arithmetic, no HIP): fills q / start / end / rank / cross of every task and returns the
 // issue order (planned start, ties by task id).  Tasks must be listed in a topological order (dependencies have smaller
@@ -560,7 +568,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         else c.gemm(sg, d);
       });
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
-      t_sw[l][ci] = P.add("sweep", 40.f + n * 5.5f * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n](hipStream_t ss) {
+      t_sw[l][ci] = P.add("sweep", 40.f + n * est_step_us(0) * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n](hipStream_t ss) {
         if (c.rc) return;
         Ctx::Scope sc(c, ss, 8, 2.0 * n * B * 3.0 * H * H);
         c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], w.out[l] + (long long)t0 * B * H,
@@ -739,7 +747,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     int t_wg = -1;
     for (int ci = nc - 1; ci >= 0; --ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
-      t_bs[l][ci] = P.add("bsweep", 40.f + n * 6.0f * hs, q_sweep,
+      t_bs[l][ci] = P.add("bsweep", 40.f + n * est_step_us(1) * hs, q_sweep,
                           {l < L - 1 ? t_dx[l + 1][ci] : t_top, ci == nc - 1 ? t_wt[l] : t_bs[l][ci + 1]}, [&, l, ci, t0, n](hipStream_t ss) {
         void* ssp = reinterpret_cast<void*>(ss);
         if (p->rnn_drop > 0.f && l < L - 1)   // gradient through the inter-layer dropout mask
