@@ -92,6 +92,8 @@ _SIGNATURES = {
                                          C.c_uint64, VP, VP, C.POINTER(C.c_float), C.c_int, C.c_int, VP]),
     "b2t_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), VP]),
     "b2t_gemm_bf16_f32": (C.c_int, [C.POINTER(GemmDesc), VP]),
+    "b2t_gemm_bf16p_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "b2t_gemm_bf16p_f32": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "b2t_softsign_bwd_f32": (C.c_int, [VP, VP, LL, VP]),
     "b2t_colsum_ws_bytes": (C.c_size_t, [LL, C.c_int]),
     "b2t_colsum_f32": (C.c_int, [VP, LL, C.c_int, LL, VP, C.c_int, VP, C.c_int, LL, LL, VP]),

@@ -22,6 +22,7 @@ namespace {
 
 constexpr int MAXL = B2T_MAX_LAYERS;
 constexpr int MAXC = 32;   // time chunks
+constexpr int NPACK = 4;   // queues with a pack scratch of their own (caller's stream + 3 workers)
 
 struct ProfRec { int kind; double flops; hipEvent_t e0, e1; };
 
@@ -74,6 +75,8 @@ struct Layout {
   float *U, *Ud, *out[MAXL], *outd[MAXL], *gi[MAXL], *res[MAXL], *slab_gi[MAXL];
   float *dY[MAXL], *dG[MAXL], *dh_init, *carry[MAXL], *scratch[MAXL], *whh_t[MAXL], *dU, *dV, *day_slab, *day_bslab;
   float *slab[MAXL], *slab_head, *s4[MAXL], *cs_layer[MAXL], *cs_head, *cs_day, *cs_h0;
+  char* pack[NPACK];       // amp mode: per-queue scratch of the two-pass bf16 GEMM (packed operands)
+  size_t pack_bytes;
   size_t bytes;
 };
 
@@ -100,6 +103,17 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     const size_t sk = l == 0 ? (In0 >= 2048 ? std::max<size_t>(1, std::min<size_t>(16, In0 / 448)) : 0)
                              : (H >= 384 ? std::max<size_t>(1, H / 192) : 0);
     w.slab_gi[l] = sk > 1 ? take(sk * std::min<size_t>(512, Tp * B) * 3 * H) : nullptr;
+  }
+  // amp mode: packed-operand scratch, sized for the largest GEMM of either pass, one per queue
+  w.pack_bytes = 0;
+  for (int q = 0; q < NPACK; ++q) w.pack[q] = nullptr;
+  if (p->bf16_gemm) {
+    const int R = (int)(Tp * B);
+    const int shapes[][3] = {{R, (int)(3 * H), (int)In0}, {R, (int)(3 * H), (int)H}, {R, (int)C, (int)H}, {R, (int)In0, (int)(3 * H)},
+                             {R, (int)H, (int)(3 * H)}, {(int)(3 * H), (int)H, R}, {(int)(3 * H), (int)In0, R}, {(int)C, (int)H, R}, {R, (int)H, (int)C}};
+    for (const auto& sh : shapes) w.pack_bytes = std::max(w.pack_bytes, b2t_gemm_bf16p_ws_bytes(sh[0], sh[1], sh[2]));
+    w.pack_bytes = align_up(w.pack_bytes, 256);
+    for (int q = 0; q < NPACK; ++q) { w.pack[q] = base + off; off += w.pack_bytes; }
   }
   if (!p->save) { w.bytes = off; return; }
   for (size_t l = 0; l < L; ++l) w.res[l] = take(Tp * B * 4 * H);
@@ -135,6 +149,9 @@ struct Ctx {
   hipStream_t main;
   bool bf16_gemm;
   int rc = 0;
+  hipStream_t qs[8] = {};      // the pass's queues (plan_queues); qs[0] = main
+  int nq = 0;
+  const Layout* lay = nullptr;  // for the per-queue pack scratch of the amp-mode GEMM
 
   hipEvent_t record(hipStream_t s) {
     if (ex->next_ev == ex->pool.size()) {
@@ -186,14 +203,25 @@ struct Ctx {
       d.C = slab; d.splitk = splitk; d.c_ks = (long long)d.M * d.N; d.accumulate = 0;
       {
         Scope sc(*this, s, kind, flops);
-        rc = bf16_gemm ? b2t_gemm_bf16_f32(&d, st) : b2t_gemm_f32(&d, st);
+        rc = bf16_gemm ? gemm_amp(d, s) : b2t_gemm_f32(&d, st);
       }
       if (!rc) rc = b2t_slab_reduce_f32(slab, splitk, (long long)d.M * d.N, Cdst, accumulate, st);
       return;
     }
     d.accumulate = accumulate;
     Scope sc(*this, s, kind, flops);
-    rc = bf16_gemm ? b2t_gemm_bf16_f32(&d, st) : b2t_gemm_f32(&d, st);
+    rc = bf16_gemm ? gemm_amp(d, s) : b2t_gemm_f32(&d, st);
+  }
+  // amp mode: the two-pass kernel (pack to dense bf16, then 128x128x64 tiles on packed operands: 2.5-3x the one-pass kernel)
+  // for plain GEMMs big enough to pay for the pack passes, on a queue that has pack scratch; the one-pass kernel otherwise
+  int gemm_amp(const b2t_gemm_desc& d, hipStream_t s) {
+    void* st = reinterpret_cast<void*>(s);
+    int q = -1;
+    for (int i = 0; i < nq && i < NPACK; ++i) if (qs[i] == s) q = i;
+    if (nq == 0 && s == main) q = 0;
+    const bool packed = lay && q >= 0 && lay->pack[q] && d.Z == 1 && !d.b_zmap && 2.0 * d.M * d.N * (double)d.K >= 2e9 &&
+                        b2t_gemm_bf16p_ws_bytes(d.M, d.N, d.K) <= lay->pack_bytes && (d.a_brk % 8) == 0;
+    return packed ? b2t_gemm_bf16p_f32(&d, lay->pack[q], lay->pack_bytes, st) : b2t_gemm_bf16_f32(&d, st);
   }
   void call(int r) { if (!rc) rc = r; }
 };
@@ -496,6 +524,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   Layout w;
   carve(prm, p, reinterpret_cast<char*>(ws), w);
   Ctx c{ex, as_stream(stream), p->bf16_gemm != 0};
+  c.lay = &w;
   ex->next_ev = 0;
   const size_t sync_block = b2t_gru_sync_bytes(0);
   auto sync_of = [&](int l) { return sync_ws ? reinterpret_cast<char*>(sync_ws) + (size_t)l * sync_block : nullptr; };
@@ -590,9 +619,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
     const int t_end = P.add("end", 0.f, Q_MAIN, {t_head}, nullptr);
     for (int l = 0; l + 1 < L; ++l) P.dep(t_end, t_sw[l][nc - 1]);
   }
-  hipStream_t qs[8];
-  const int nq = plan_queues(c, nc > 1, qs);
-  run_plan(c, P, nq, qs);
+  c.nq = plan_queues(c, nc > 1, c.qs);
+  run_plan(c, P, c.nq, c.qs);
   return c.rc;
 }
 
@@ -665,6 +693,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   Layout w;
   carve(prm, p, reinterpret_cast<char*>(ws), w);
   Ctx c{ex, as_stream(stream), p->bf16_gemm != 0};
+  c.lay = &w;
   ex->next_ev = 0;
   const size_t sync_block = b2t_gru_sync_bytes(0);
   auto sync_of = [&](int l) { return sync_ws ? reinterpret_cast<char*>(sync_ws) + (size_t)(L + l) * sync_block : nullptr; };
@@ -811,8 +840,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     for (int l = 0; l < L; ++l) { P.dep(t_end, t_wg_last[l]); P.dep(t_end, t_dx[l][0]); }
     P.dep(t_end, t_top);
   }
-  hipStream_t qs[8];
-  const int nq = plan_queues(c, nc > 1, qs);
-  run_plan(c, P, nq, qs);
+  c.nq = plan_queues(c, nc > 1, c.qs);
+  run_plan(c, P, c.nq, c.qs);
   return c.rc;
 }

@@ -1,0 +1,225 @@
+// gemm_bf16p.hip — the amp-mode GEMM (use_amp / autocast(bfloat16), rnn_trainer.py:535) in two passes:
+//   1. PACK: each operand is read once through the descriptor's generalized addressing (row maps, gaps, either storage
+//      order) and written as a dense, k-contiguous bf16 matrix [rows padded to 128][K padded to 64] (round-to-nearest-even,
+//      zero fill) into caller-provided scratch;
+//   2. GEMM: C = A_p . B_p^T on 128x128x64 tiles, v_mfma_f32_32x32x16_bf16, 16-byte global loads that go to LDS unconverted,
+//      register prefetch of the next k-tile, double-buffered LDS (144-byte rows: a fragment is one conflict-free 16-byte
+//      read), one barrier per k-tile, fp32 accumulation and the fp32 epilogue of gemm_bf16.hip (bias, Softsign and its
+//      backward, accumulate, row-mapped C, split-K slabs).
+// Same numerics contract as b2t_gemm_bf16_f32 (operands rounded to bf16, fp32 accumulate, fp32 out).  Why two passes: the
+// one-pass kernel converts fp32 operands on their way into LDS and reaches 315 TF/s at 4096^3; with packed operands the
+// same tile shape runs at 700-840 TF/s (tools/ubench/gemm_bf16p.hip), and a pack pass is bandwidth-bound and small next
+// to it.  Z-batched GEMMs (the day layer) stay on the one-pass kernel.
+#include "common.h"
+#include "gemm_args.h"
+
+namespace b2t {
+namespace {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+
+constexpr int PM = 128, PN = 128, PK = 64, PPITCH = PK + 8;   // block tile; LDS row pitch in bf16 elements (144 B)
+
+__device__ __forceinline__ unsigned pk2(float lo, float hi) {
+  using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+struct PackArgs {
+  const float* P; __bf16* out;
+  int rows, rows_pad, K, Kp;
+  long long s0, s1; int div;     // row map of the source (rows if k-contiguous, k if row-contiguous)
+  int brk, gap;                  // contiguous index i >= brk reads from i + gap (A operand only)
+};
+
+// k-contiguous source: element (r, k) at P + rowoff(r) + k (+ gap for k >= brk).  One thread = 8 consecutive k of one row.
+__global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
+  const int g8 = a.Kp >> 3;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.rows_pad * g8) return;
+  const int r = (int)(i / g8), k = (int)(i % g8) * 8;
+  uint4 o = make_uint4(0u, 0u, 0u, 0u);
+  if (r < a.rows && k < a.K) {
+    const float* p = a.P + rowoff(r, a.s0, a.s1, a.div) + k + ((a.brk > 0 && k >= a.brk) ? a.gap : 0);
+    if (k + 8 <= a.K) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+      o.x = pk2(v0.x, v0.y); o.y = pk2(v0.z, v0.w); o.z = pk2(v1.x, v1.y); o.w = pk2(v1.z, v1.w);
+    } else {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = k + j < a.K ? p[j] : 0.f;
+      o.x = pk2(v[0], v[1]); o.y = pk2(v[2], v[3]); o.z = pk2(v[4], v[5]); o.w = pk2(v[6], v[7]);
+    }
+  }
+  *reinterpret_cast<uint4*>(a.out + (long long)r * a.Kp + k) = o;
+}
+
+// row-contiguous source (k-major storage): element (r, k) at P + rowoff(k) + r (+ gap for r >= brk).  A block transposes a
+// 64 (r) x 64 (k) tile through LDS: float4 loads along r, 16-byte bf16 stores along k.
+__global__ __launch_bounds__(256) void pack_mc_kernel(PackArgs a) {
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + 256 * it;          // 1024 float4: k = idx / 16, r4 = (idx % 16) * 4
+    const int k = k0 + (idx >> 4), r = r0 + (idx & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < a.K && r < a.rows) {
+      const float* p = a.P + rowoff(k, a.s0, a.s1, a.div) + r + ((a.brk > 0 && r >= a.brk) ? a.gap : 0);
+      if (r + 4 <= a.rows) v = *reinterpret_cast<const float4*>(p);
+      else { v.x = p[0]; if (r + 1 < a.rows) v.y = p[1]; if (r + 2 < a.rows) v.z = p[2]; }
+    }
+    float* d = &t[idx >> 4][(idx & 15) * 4];
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + 256 * it;          // 512 stores: r = idx % 64, k8 = idx / 64
+    const int r = idx & 63, k8 = (idx >> 6) * 8;
+    uint4 o;
+    o.x = pk2(t[k8][r], t[k8 + 1][r]); o.y = pk2(t[k8 + 2][r], t[k8 + 3][r]);
+    o.z = pk2(t[k8 + 4][r], t[k8 + 5][r]); o.w = pk2(t[k8 + 6][r], t[k8 + 7][r]);
+    if (r0 + r < a.rows_pad && k0 + k8 < a.Kp) *reinterpret_cast<uint4*>(a.out + (long long)(r0 + r) * a.Kp + k0 + k8) = o;
+  }
+}
+
+#define B2T_PFETCH(k0)                                                                                                    \
+  ra0 = *reinterpret_cast<const uint4*>(ag + (k0)); ra1 = *reinterpret_cast<const uint4*>(ag + 32ll * Kp + (k0));          \
+  ra2 = *reinterpret_cast<const uint4*>(ag + 64ll * Kp + (k0)); ra3 = *reinterpret_cast<const uint4*>(ag + 96ll * Kp + (k0)); \
+  rb0 = *reinterpret_cast<const uint4*>(bg + (k0)); rb1 = *reinterpret_cast<const uint4*>(bg + 32ll * Kp + (k0));          \
+  rb2 = *reinterpret_cast<const uint4*>(bg + 64ll * Kp + (k0)); rb3 = *reinterpret_cast<const uint4*>(bg + 96ll * Kp + (k0));
+#define B2T_PSTASH(buf)                                                                                                   \
+  { __bf16* ad = As + (buf) * PM * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
+    __bf16* bd = Bs + (buf) * PM * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
+    *reinterpret_cast<uint4*>(ad) = ra0; *reinterpret_cast<uint4*>(ad + 32 * PPITCH) = ra1;                               \
+    *reinterpret_cast<uint4*>(ad + 64 * PPITCH) = ra2; *reinterpret_cast<uint4*>(ad + 96 * PPITCH) = ra3;                 \
+    *reinterpret_cast<uint4*>(bd) = rb0; *reinterpret_cast<uint4*>(bd + 32 * PPITCH) = rb1;                               \
+    *reinterpret_cast<uint4*>(bd + 64 * PPITCH) = rb2; *reinterpret_cast<uint4*>(bd + 96 * PPITCH) = rb3; }
+
+// (plain variables for the prefetch registers, no lambdas over arrays: the array form was demoted to scratch memory by the
+// compiler -- 230 TF/s instead of 840)
+__global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp, int Kp) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 2 * PM * PPITCH];
+  __bf16* As = smem; __bf16* Bs = smem + 2 * PM * PPITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int ks = blockIdx.z;
+  int m0, n0;
+  {   // XCD-aware tile order (see gemm.hip)
+    const int gx = (g.N + PN - 1) / PN, nwg = gridDim.x;
+    const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    m0 = (tile / gx) * PM; n0 = (tile % gx) * PN;
+  }
+  const float* bias = (g.bias && ks == 0) ? g.bias : nullptr;
+  float* C = g.C + (long long)ks * g.c_ks;
+  const int kb = ks * g.kchunk, ke = min(Kp, kb + g.kchunk), nk = (ke - kb) / PK;
+  const __bf16* ag = Ap + (long long)(m0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
+  const __bf16* bg = Bp + (long long)(n0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
+  const int lk = lane >> 5, li = lane & 31;
+  if (nk > 0) {
+    B2T_PFETCH(0) B2T_PSTASH(0)
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int knext = (kt + 1 < nk ? kt + 1 : kt) * PK;   // the last iteration re-reads its own tile: no branch around the loads
+      B2T_PFETCH(knext)
+      const __bf16* a0p = As + cur * PM * PPITCH + (wm * 64 + li) * PPITCH + 8 * lk;
+      const __bf16* a1p = a0p + 32 * PPITCH;
+      const __bf16* b0p = Bs + cur * PM * PPITCH + (wn * 64 + li) * PPITCH + 8 * lk;
+      const __bf16* b1p = b0p + 32 * PPITCH;
+#pragma unroll
+      for (int kk = 0; kk < PK; kk += 16) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a0p + kk), a1 = *reinterpret_cast<const bf16x8*>(a1p + kk);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b0p + kk), b1 = *reinterpret_cast<const bf16x8*>(b1p + kk);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);
+      }
+      B2T_PSTASH(cur ^ 1)
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // epilogue (gemm_bf16.hip): C/D layout of the 32x32 MFMAs: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const f32x16 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (row < g.M) {
+          float v = acc[i][j][e] + bv;
+          if (g.epilogue == 1) v = v / (1.0f + fabsf(v));
+          const long long coff = rowoff(row, g.c_s0, g.c_s1, g.c_div) + col;
+          if (g.epilogue == 2) { const float a = 1.0f - fabsf(g.ep_aux[coff]); v *= a * a; }   // softsign backward
+          float* p = C + coff;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+int pad_to(int v, int a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+}  // namespace b2t
+
+extern "C" size_t b2t_gemm_bf16p_ws_bytes(int M, int N, int K) {
+  using namespace b2t;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const size_t Kp = (size_t)pad_to(K, PK);
+  return ((size_t)pad_to(M, PM) + (size_t)pad_to(N, PN)) * Kp * sizeof(__bf16) + 512;
+}
+
+extern "C" int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_bytes, void* stream) {
+  using namespace b2t;
+  B2T_REQUIRE(d != nullptr && ws != nullptr, "b2t_gemm_bf16p_f32: null descriptor / workspace");
+  B2T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->Z == 1 && d->b_zmap == nullptr, "b2t_gemm_bf16p_f32: bad shape M=%d N=%d K=%d Z=%d (Z must be 1)",
+              d->M, d->N, d->K, d->Z);
+  B2T_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && ((uintptr_t)ws & 255) == 0, "b2t_gemm_bf16p_f32: A/B must be 16-byte, ws 256-byte aligned");
+  B2T_REQUIRE((d->a_s0 % 4) == 0 && (d->a_s1 % 4) == 0 && (d->b_s0 % 4) == 0 && (d->b_s1 % 4) == 0,
+              "b2t_gemm_bf16p_f32: A/B strides must be multiples of 4 elements");
+  B2T_REQUIRE(ws_bytes >= b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K), "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes,
+              b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K));
+  GemmArgs g;
+  { int rc = fill_gemm_args(d, g, PK, PM, "b2t_gemm_bf16p_f32"); if (rc) return rc; }
+  B2T_REQUIRE(d->a_brk == 0 || d->a_brk % 8 == 0, "b2t_gemm_bf16p_f32: a_brk must be a multiple of 8");
+  const int Mp = pad_to(d->M, PM), Np = pad_to(d->N, PN), Kp = pad_to(d->K, PK);
+  __bf16* Ap = reinterpret_cast<__bf16*>(ws);
+  __bf16* Bp = Ap + (size_t)Mp * Kp;
+  hipStream_t s = as_stream(stream);
+  auto pack = [&](const float* P, __bf16* out, int rows, int rows_pad, bool kc, long long s0, long long s1, int div, int brk, int gap) {
+    PackArgs a{P, out, rows, rows_pad, d->K, Kp, s0, s1, div, brk, gap};
+    if (kc) {
+      const long long items = (long long)rows_pad * (Kp / 8);
+      hipLaunchKernelGGL(pack_kc_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL(pack_mc_kernel, dim3(rows_pad / 64, Kp / 64), dim3(256), 0, s, a);
+    }
+  };
+  pack(d->A, Ap, d->M, Mp, d->a_kcontig != 0, d->a_s0, d->a_s1, d->a_div, d->a_brk, d->a_gap);
+  B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (pack A)");
+  pack(d->B, Bp, d->N, Np, d->b_kcontig != 0, d->b_s0, d->b_s1, d->b_div, 0, 0);
+  B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (pack B)");
+  g.kchunk = pad_to((Kp + g.splitk - 1) / g.splitk, PK);
+  dim3 grid((Np / PN) * (Mp / PM), 1, g.splitk), block(256);
+  hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, (const __bf16*)Ap, (const __bf16*)Bp, Kp);
+  B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32");
+  return 0;
+}

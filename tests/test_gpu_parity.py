@@ -533,3 +533,85 @@ def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T, wide):
         got = run(1 | (ops.GRU_WIDE if wide else 0))   # wide: 32 hidden units per workgroup, exact fp32
         for a, r, name in zip(got, ref, ("out", "reserve", "dG", "dh0")):
             np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=3e-6 * max(1.0, float(r.abs().max())), err_msg=name)
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 41, 37), (33, 300, 129), (512, 1536, 520), (640, 256, 4100)])
+def test_gemm_bf16_packed(akc, bkc, M, N, K):
+    """b2t_gemm_bf16p_f32 (two passes: pack both operands to dense bf16, then tiles on the packed operands): same contract
+    as b2t_gemm_bf16_f32 -- an fp64 product of the bf16-rounded operands up to fp32 summation roundoff -- for all four
+    operand layouts, ragged extents, bias / accumulate / Softsign epilogues, split-K slabs, a row-mapped C and a gap in A."""
+    import ctypes as C
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev()
+    rng = np.random.default_rng(M * 7 + N * 3 + K + 1)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    Aq, Bq = _bf16_round(A).astype(np.float64), _bf16_round(Bm).astype(np.float64)
+    ref = Aq @ Bq.T
+    Mp, Np, Kp = (M + 3) // 4 * 4, (N + 3) // 4 * 4, (K + 3) // 4 * 4
+    if akc:
+        Ad = torch.zeros(M, Kp); Ad[:, :K] = torch.from_numpy(A); a_s0 = Kp
+    else:
+        Ad = torch.zeros(K, Mp); Ad[:, :M] = torch.from_numpy(A.T); a_s0 = Mp
+    if bkc:
+        Bd = torch.zeros(N, Kp); Bd[:, :K] = torch.from_numpy(Bm); b_s0 = Kp
+    else:
+        Bd = torch.zeros(K, Np); Bd[:, :N] = torch.from_numpy(Bm.T); b_s0 = Np
+    Ad, Bd, bd = Ad.to(dev), Bd.to(dev), torch.from_numpy(bias).to(dev)
+    wsb = lib.b2t_gemm_bf16p_ws_bytes(M, N, K)
+    ws = torch.empty(wsb // 4 + 64, dtype=torch.float32, device=dev)
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+    def run(Cd, **kw):
+        d = Nn.GemmDesc()
+        d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+        d.M, d.N, d.K, d.Z = M, N, K, 1
+        d.a_kcontig, d.b_kcontig, d.a_s0, d.b_s0, d.c_s0 = akc, bkc, a_s0, b_s0, N
+        d.splitk = 1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        Nn.check(lib.b2t_gemm_bf16p_f32(C.byref(d), ops._p(ws), wsb, ops._stream()), "b2t_gemm_bf16p_f32")
+        return Cd.cpu().numpy()
+
+    got = run(torch.full((M, N), float("nan"), device=dev), bias=bd.data_ptr())
+    np.testing.assert_allclose(got, ref + bias, atol=tol)
+    if K >= 64:
+        exact = A.astype(np.float64) @ Bm.astype(np.float64).T + bias
+        assert np.abs(got - exact).max() > 10 * np.abs(got - (ref + bias)).max()       # it is the bf16 product
+    np.testing.assert_allclose(run(torch.ones((M, N), device=dev), accumulate=1), ref + 1.0, atol=tol)
+    np.testing.assert_allclose(run(torch.zeros((M, N), device=dev), epilogue=1), ref / (1 + np.abs(ref)), atol=tol)
+    U = rng.uniform(-0.9, 0.9, size=(M, N)).astype(np.float32); Ud = torch.from_numpy(U).to(dev)
+    np.testing.assert_allclose(run(torch.zeros((M, N), device=dev), epilogue=2, ep_aux=Ud.data_ptr()), ref * (1 - np.abs(U)) ** 2, atol=tol)
+    # split-K slabs
+    sk = 3
+    slab = torch.full((sk, M, N), float("nan"), device=dev)
+    part = run(slab, splitk=sk, c_ks=M * N)
+    np.testing.assert_allclose(part.sum(0), ref, atol=tol)
+    # row-mapped C (batch-first logits: row r = t * Bb + b -> C[b][t]) and a gap in A's contiguous index
+    if M % 4 == 0:
+        Bb = 4; Tt = M // Bb
+        Cm = torch.full((Bb, Tt, N), float("nan"), device=dev)
+        out = run(Cm, c_div=Bb, c_s1=N, c_s0=Tt * N)
+        np.testing.assert_allclose(out.transpose(1, 0, 2).reshape(M, N), ref, atol=tol)
+    if akc and K % 128 == 0 or (not akc and M % 256 == 0):
+        # A' = A with `gap` extra elements spliced into the contiguous index at brk
+        gap = 8
+        if akc:
+            brk = K // 2
+            Ag = torch.full((M, Kp + gap), 7.0); Ag[:, :brk] = torch.from_numpy(A[:, :brk]); Ag[:, brk + gap:K + gap] = torch.from_numpy(A[:, brk:])
+            kw = dict(a_s0=Kp + gap)
+        else:
+            brk = M // 2
+            Ag = torch.full((K, Mp + gap), 7.0); Ag[:, :brk] = torch.from_numpy(A.T[:, :brk]); Ag[:, brk + gap:M + gap] = torch.from_numpy(A.T[:, brk:])
+            kw = dict(a_s0=Mp + gap)
+        Agd = Ag.to(dev)
+        d_keep = Ad
+        Ad = Agd
+        try:
+            got = run(torch.full((M, N), float("nan"), device=dev), a_brk=brk, a_gap=gap, **kw)
+        finally:
+            Ad = d_keep
+        np.testing.assert_allclose(got, ref, atol=tol)
