@@ -569,7 +569,13 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       const int t_gi = P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci]},
                              [&, l, t0, n](hipStream_t sg) {
         if (l == 0) {
-          if ((long long)n * B <= 512 && In0 >= 2048) {
+          if (c.bf16_gemm && (long long)n * B > 512) {
+            // amp mode: ONE row-mapped GEMM over all (t, b) rows instead of B per-sentence GEMMs, so that it takes the
+            // two-pass packed kernel (Z == 1)
+            b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
+            d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
+            c.gemm(sg, d);
+          } else if ((long long)n * B <= 512 && In0 >= 2048) {
             // streaming-sized calls (a few frames, patch input K = 7168): one GEMM over all (t, b) rows through the
             // two-level row map, K split over the chip (as B per-sentence GEMMs the K loop runs serially in 18 workgroups)
             b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
