@@ -292,16 +292,18 @@ def gru_sync_check(sync_ws, T: int, B: int):
         raise RuntimeError("persistent GRU sweep: inter-workgroup hand-off timed out (results invalid)")
 
 
-def time_chunks(Tp: int, B: int = 64, H: int = 512) -> int:
+def time_chunks(Tp: int, B: int = 64, H: int = 512, amp: bool = False) -> int:
     """Number of time chunks of the layer pipeline.  Pipelining pays only when the sweeps of two layers can be resident
     together: a sweep is (H/16) * ceil(B/16) workgroups that must all run at once, and the chip holds 2 backward-sweep
     workgroups per CU up to H = 512 but only 1 beyond (the W_hh slice takes the whole register file).  At H = 768, B = 64
-    (192 workgroups of 256 slots) concurrent sweeps just block each other: 37-93 ms per step with 6 chunks against
-    19.8 ms with the layers in sequence (tools/bench_c3.py)."""
+    (192 workgroups of 256 slots) concurrent fp32 sweeps just block each other: 37-93 ms per step with 6 chunks against
+    19.8 ms with the layers in sequence (tools/bench_c3.py).  With bf16 operands (amp) the slices are half as large and the
+    GEMMs short: two chunks let the queues overlap GEMMs and sweeps (shipped shape 9.06 -> 8.53 ms per step; 3 / 4
+    chunks: 8.6 / 8.95)."""
     wgs = (H // 16) * ((B + 15) // 16)
     slots = MAX_RESIDENT_WGS * (2 if H <= 512 else 1)
     if 2 * wgs > slots and "B2T_CHUNKS" not in os.environ:
-        return 1
+        return 2 if (amp and AMP["sweeps"] and wgs <= MAX_RESIDENT_WGS and Tp >= 32) else 1
     return max(1, min(PIPELINE["chunks"], Tp // 16))
 
 
@@ -417,11 +419,11 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     dev = x.device
     mode = gru_mode_for(B, H)
     ps = N.PassDesc()
-    ps.B, ps.T, ps.chunks = B, T, time_chunks(Tp, B, H)
+    ps.B, ps.T, ps.chunks = B, T, time_chunks(Tp, B, H, AMP["on"])
     ps.fwd_mode, ps.bwd_mode = sweep_mode_arg(mode, H, "f"), sweep_mode_arg(mode, H, "b")
     ps.bf16_gemm, ps.save = int(AMP["on"]), int(bool(save))
     ps.in_drop, ps.rnn_drop, ps.seed = float(in_drop), float(rnn_drop if L > 1 else 0.0), int(seed) & (2 ** 64 - 1)
-    ps.chunks_bwd = 0 if ps.chunks == 1 else max(0, min(PIPELINE["chunks_bwd"], Tp // 16))
+    ps.chunks_bwd = 0 if ps.chunks == 1 else max(0, min(PIPELINE["chunks_bwd"], ps.chunks, Tp // 16))
     ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
     md = prm.desc(dims)
     nbytes = lib.b2t_pass_ws_bytes(C.byref(md), C.byref(ps))

@@ -172,6 +172,7 @@ def test_time_chunk_plan_rule():
     assert "B2T_CHUNKS" not in os.environ
     assert ops.time_chunks(500, 64, 512) == 6
     assert ops.time_chunks(122, 64, 768) == 1
+    assert ops.time_chunks(122, 64, 768, amp=True) == 2       # bf16 operands: two chunks let GEMMs and sweeps overlap
     assert ops.time_chunks(500, 128, 512) == 6
     assert ops.time_chunks(500, 192, 512) == 1          # 2 x 384 workgroups > 512 slots
     assert ops.time_chunks(40, 64, 512) == 2 and ops.time_chunks(1, 32, 512) == 1
