@@ -280,7 +280,7 @@ def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
         if mode == 1 and direction in WIDE_F32["dirs"] and H % 32 == 0 and H <= 512:
             return mode | GRU_WIDE
         return mode
-    wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= 512) else 0   # (LDS staging of H > 512 exceeds 64 KB)
+    wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= int(os.environ.get("B2T_AMP_WIDE_MAXH", "768"))) else 0
     return mode | GRU_BF16 | wide
 
 
@@ -292,19 +292,34 @@ def gru_sync_check(sync_ws, T: int, B: int):
         raise RuntimeError("persistent GRU sweep: inter-workgroup hand-off timed out (results invalid)")
 
 
+def _crowded(B: int, H: int) -> bool:
+    """Two sweeps of this shape cannot be resident together (see time_chunks)."""
+    wgs = (H // 16) * ((B + 15) // 16)
+    return 2 * wgs > MAX_RESIDENT_WGS * (2 if H <= 512 else 1)
+
+
 def time_chunks(Tp: int, B: int = 64, H: int = 512, amp: bool = False) -> int:
-    """Number of time chunks of the layer pipeline.  Pipelining pays only when the sweeps of two layers can be resident
-    together: a sweep is (H/16) * ceil(B/16) workgroups that must all run at once, and the chip holds 2 backward-sweep
+    """Number of time chunks of the forward layer pipeline.  Pipelining pays only when the sweeps of two layers can be
+    resident together: a sweep is (H/16) * ceil(B/16) workgroups that must all run at once, and the chip holds 2 backward-sweep
     workgroups per CU up to H = 512 but only 1 beyond (the W_hh slice takes the whole register file).  At H = 768, B = 64
     (192 workgroups of 256 slots) concurrent fp32 sweeps just block each other: 37-93 ms per step with 6 chunks against
-    19.8 ms with the layers in sequence (tools/bench_c3.py).  With bf16 operands (amp) the slices are half as large and the
-    GEMMs short: two chunks let the queues overlap GEMMs and sweeps (shipped shape 9.06 -> 8.53 ms per step; 3 / 4
-    chunks: 8.6 / 8.95)."""
-    wgs = (H // 16) * ((B + 15) // 16)
-    slots = MAX_RESIDENT_WGS * (2 if H <= 512 else 1)
-    if 2 * wgs > slots and "B2T_CHUNKS" not in os.environ:
-        return 2 if (amp and AMP["sweeps"] and wgs <= MAX_RESIDENT_WGS and Tp >= 32) else 1
+    19.8 ms with the layers in sequence (tools/bench_c3.py).  With bf16 operands (amp) the slices are half as large, the
+    sweeps run with 32-unit workgroups (96 per sweep) and the GEMMs are short: 3 forward / 2 backward chunks let the four
+    queues overlap GEMMs and sweeps of different layers (shipped shape: 9.7 ms serial, 7.8 at 2 / 2, 7.4-7.5 at 3 / 2 and
+    4 / 2, 7.9 at 6 / 4)."""
+    if _crowded(B, H) and "B2T_CHUNKS" not in os.environ:
+        wgs = (H // 16) * ((B + 15) // 16)
+        return 3 if (amp and AMP["sweeps"] and wgs <= MAX_RESIDENT_WGS and Tp >= 48) else 1
     return max(1, min(PIPELINE["chunks"], Tp // 16))
+
+
+def time_chunks_bwd(Tp: int, B: int, H: int, amp: bool, fwd_chunks: int) -> int:
+    """Time chunks of the backward pass (0: the plan runs in sequence, as the forward does with one chunk)."""
+    if fwd_chunks == 1:
+        return 0
+    if _crowded(B, H) and "B2T_CHUNKS_BWD" not in os.environ:
+        return 2
+    return max(0, min(PIPELINE["chunks_bwd"], fwd_chunks if "B2T_CHUNKS_BWD" not in os.environ else PIPELINE["chunks_bwd"], Tp // 16))
 
 
 BUCKET_NAMES = lambda L: ["head"] + [f"layer{l}" for l in range(L)] + ["h0", "day"]   # ids of b2t_bucket_cb
@@ -423,7 +438,7 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ps.fwd_mode, ps.bwd_mode = sweep_mode_arg(mode, H, "f"), sweep_mode_arg(mode, H, "b")
     ps.bf16_gemm, ps.save = int(AMP["on"]), int(bool(save))
     ps.in_drop, ps.rnn_drop, ps.seed = float(in_drop), float(rnn_drop if L > 1 else 0.0), int(seed) & (2 ** 64 - 1)
-    ps.chunks_bwd = 0 if ps.chunks == 1 else max(0, min(PIPELINE["chunks_bwd"], ps.chunks, Tp // 16))
+    ps.chunks_bwd = time_chunks_bwd(Tp, B, H, AMP["on"], ps.chunks)
     ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
     md = prm.desc(dims)
     nbytes = lib.b2t_pass_ws_bytes(C.byref(md), C.byref(ps))

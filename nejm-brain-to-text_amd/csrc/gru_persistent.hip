@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
                                                                  unsigned* sync) {
   constexpr int TPN = 16 * NT + 4;    // LDS pitch of the staged tile (= TP for one tile)
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * NT * 4 * 64 + 16 * TPN];
-  __shared__ __attribute__((aligned(16))) float stage[4][NCH * SLOT_F];   // per-wave operand staging (gru_sync.h)
+  constexpr int NSLOT_F = NCH < 8 ? NCH : 8;   // staging slots per wave, recycled every NSLOT_F instructions (as in the backward sweep)
+  __shared__ __attribute__((aligned(16))) float stage[4][NSLOT_F * SLOT_F];   // per-wave operand staging (gru_sync.h)
   float* hs = red + 4 * 3 * NT * 4 * 64;   // staged h tile [16 rows][TPN]
   constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
 #pragma unroll
     for (int p = 0; p < NCH / 2; ++p) {
       float4 a[2];
-      transpose_pair(&stage[wave][2 * p * SLOT_F], v[2 * p], v[2 * p + 1], a[0], a[1], lane);
+      transpose_pair(&stage[wave][((2 * p) % NSLOT_F) * SLOT_F], v[2 * p], v[2 * p + 1], a[0], a[1], lane);
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         const int ci = 2 * p + h2;
@@ -409,7 +410,7 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
                        bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
-  if (wide && ((H % 32) != 0 || H > 512)) { set_error("gru_layer_fwd: 32-unit workgroups need H %% 32 == 0 and H <= 512"); return 2; }
+  if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_fwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
@@ -449,7 +450,7 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
                        void* sync_ws, hipStream_t s, bool bf16, bool wide) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
-  if (wide && ((H % 32) != 0 || H > 512)) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512"); return 2; }
+  if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \

@@ -120,7 +120,7 @@ def test_gemm_bf16(akc, bkc, M, N, K):
         ops.set_amp(old)
 
 
-@pytest.mark.parametrize("B,H,T,wide", [(17, 80, 9, 0), (64, 512, 12, 0), (40, 768, 6, 0), (64, 512, 12, 1), (23, 96, 7, 1)])
+@pytest.mark.parametrize("B,H,T,wide", [(17, 80, 9, 0), (64, 512, 12, 0), (40, 768, 6, 0), (64, 512, 12, 1), (23, 96, 7, 1), (40, 768, 6, 1), (64, 768, 20, 1)])
 def test_persistent_sweep_bf16_operands(B, H, T, wide):
     """mode 1 | B2T_GRU_BF16: the recurrent products round their operands (h_{t-1} / dG_{t+1} and the W_hh slice) to bf16
     and accumulate in fp32.  Reference: the same recurrences in numpy with the operands rounded explicitly."""
