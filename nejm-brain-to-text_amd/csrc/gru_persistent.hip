@@ -80,8 +80,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
   float bhr[NT], bhz[NT], bhn[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { bhr[n] = b_hh[unit[n]]; bhz[n] = b_hh[H + unit[n]]; bhn[n] = b_hh[2 * H + unit[n]]; }
-  const int row = m0 + 4 * q + wave, arow = m0 + j;
-  const int arow_c = arow < B ? arow : B - 1;
+  const int row = m0 + 4 * q + wave;
   const bool live = row < B;
   unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
   float hp[NT];
@@ -244,8 +243,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       w[n][ci] = make_wfrag<BF16>(c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit[n] * 3 * H + c * 16 + 4 * q)
                                           : make_float4(0.f, 0.f, 0.f, 0.f));
   }
-  const int row = m0 + 4 * q + wave, arow = m0 + j;
-  const int arow_c = arow < B ? arow : B - 1;
+  const int row = m0 + 4 * q + wave;
   const bool live = row < B;
   unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
   float dzterm[NT];
