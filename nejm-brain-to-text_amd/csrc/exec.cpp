@@ -532,6 +532,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   int chunks[MAXC][2];
   const int nc = make_chunks(Tp, p->chunks, chunks);
   const long long a_s0_l0 = prm->patch > 0 ? (long long)prm->stride * F : F;
+  // rows x K that b2t_gemm_f32 serves with its skinny (weight-streaming) kernel: exact fp32 only, one frame of <= 64 utterances
+  auto skinny = [&](long long rows, int K) { return !c.bf16_gemm && rows <= 64 && K % 16 == 0 && 3 * H >= 256; };
   const float hs = std::max(0.25f, (float)H * H / (512.f * 512.f)) * std::max(1, (B + 63) / 64);   // sweep cost scale
   const unsigned q_sweep = ex->sweep_qmask;
 
@@ -580,7 +582,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
             // two-level row map, K split over the chip (as B per-sentence GEMMs the K loop runs serially in 18 workgroups)
             b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
             d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
-            c.gemm(sg, d, std::max(1, std::min(16, In0 / 448)), w.slab_gi[0]);
+            if (skinny(n * B, In0)) c.gemm(sg, d);   // <= 64 rows: the weight-streaming kernel inside b2t_gemm_f32, one launch
+            else c.gemm(sg, d, std::max(1, std::min(16, In0 / 448)), w.slab_gi[0]);
           } else {
             b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n, 3 * H, In0);
             d.Z = B; d.a_s0 = a_s0_l0; d.a_sz = (long long)T * F; d.b_s0 = In0; d.c_s0 = (long long)B * 3 * H; d.c_sz = 3 * H;
@@ -599,7 +602,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         b2t_gemm_desc d = gd(src + (long long)(1 + t0) * B * H, prm->w_ih[l], w.gi[l] + (long long)t0 * B * 3 * H, n * B, 3 * H, H);
         d.a_s0 = H; d.b_s0 = H; d.c_s0 = 3 * H; d.bias = prm->b_ih[l];
         const bool small = (long long)n * B <= 512 && H >= 384;   // streaming-sized call: split K (one 128-row tile otherwise)
-        if (small) c.gemm(sg, d, std::max(1, H / 192), w.slab_gi[l]);
+        if (small && !skinny(n * B, H)) c.gemm(sg, d, std::max(1, H / 192), w.slab_gi[l]);
         else c.gemm(sg, d);
       });
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}

@@ -16,6 +16,7 @@
 namespace b2t {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
 
 #ifndef B2T_GEMM_BK
 #define B2T_GEMM_BK 16
@@ -233,6 +234,75 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny products (M <= 64 rows: one streamed frame of a few dozen utterances, evaluate_model_helpers.py:87-115 /
+// language-model streaming): C[M][N] = A[M][K] . B[N][K]^T (+ bias) is bound by streaming B (the weights) once, and a
+// 128-row tile wastes most of its MFMA rows and, with split-K slabs, three launches.  Here a workgroup owns 16 columns of
+// C: its 4 waves split K, every lane loads 16 bytes of its weight row and of each 16-row block of A per 16-k chunk
+// straight from global memory into MFMA operands (no LDS staging: A is L2-resident, B is read exactly once), and the
+// four partial tiles are summed through LDS.  Layer 0 of the shipped shape (32 x 7168 x 2304): ~150 us as split-K -> ~30.
+template <int MT>   // 16-row blocks of A
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float red[4][MT][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int ncol = n0 + j < g.N ? n0 + j : g.N - 1;                       // clamped: columns beyond N are never stored
+  const float* brow = g.B + rowoff(ncol, g.b_s0, g.b_s1, g.b_div) + 4 * q;
+  const float* arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int r = 16 * mt + j;
+    arow[mt] = g.A + rowoff(r < g.M ? r : g.M - 1, g.a_s0, g.a_s1, g.a_div) + 4 * q;
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // K in chunks of 16, dealt to the waves round-robin in groups of 4 chunks (64 k: one 256-byte run of a weight row)
+  const int nchunk = g.K / 16;
+  for (int c0 = wave * 4; c0 < nchunk; c0 += 16) {
+    float4 bw[4], av[4][MT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = (c0 + u < nchunk ? c0 + u : c0) * 16;                 // the tail re-reads a valid chunk and is masked below
+      bw[u] = *reinterpret_cast<const float4*>(brow + k);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[u][mt] = *reinterpret_cast<const float4*>(arow[mt] + k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c0 + u < nchunk) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt].x, bw[u].x, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt].y, bw[u].y, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt].z, bw[u].z, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt].w, bw[u].w, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][mt][e][lane] = acc[mt][e];
+  __syncthreads();
+  // D layout of v_mfma_f32_16x16x4_f32: lane (j, q), element e -> row 4 q + e, column j.  Thread t sums one (mt, e, lane).
+  for (int idx = tid; idx < MT * 4 * 64; idx += 256) {
+    const int l = idx & 63, e = (idx >> 6) & 3, mt = idx >> 8;
+    const float v0 = red[0][mt][e][l] + red[1][mt][e][l], v1 = red[2][mt][e][l] + red[3][mt][e][l];
+    const int row = 16 * mt + 4 * (l >> 4) + e, col = n0 + (l & 15);
+    if (row < g.M && col < g.N) {
+      float v = v0 + v1 + (g.bias ? g.bias[col] : 0.f);
+      if (g.epilogue == 1) v = v / (1.0f + fabsf(v));
+      float* p = g.C + rowoff(row, g.c_s0, g.c_s1, g.c_div) + col;
+      if (g.accumulate) v += *p;
+      *p = v;
+    }
+  }
+}
+
 }  // namespace b2t
 
 extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
@@ -248,6 +318,17 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
   { int rc = fill_gemm_args(d, g, BKT, BM, "b2t_gemm_f32"); if (rc) return rc; }
   dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);
   hipStream_t s = as_stream(stream);
+  if (d->M <= 64 && d->Z == 1 && !d->b_zmap && g.splitk == 1 && d->a_kcontig && d->b_kcontig && (d->K % 16) == 0 && d->a_brk == 0 &&
+      d->epilogue != 2 && d->N >= 256) {
+    // a few rows against a wide weight matrix: stream the weights once (gemm_skinny_kernel)
+    const dim3 sg((d->N + 15) / 16);
+    if (d->M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<1>), sg, block, 0, s, g);
+    else if (d->M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<2>), sg, block, 0, s, g);
+    else if (d->M <= 48) hipLaunchKernelGGL((gemm_skinny_kernel<3>), sg, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<4>), sg, block, 0, s, g);
+    B2T_CHECK_LAUNCH("b2t_gemm_f32 (skinny)");
+    return 0;
+  }
   if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
   else if (d->a_kcontig && !d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
   else if (!d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, g);

@@ -615,3 +615,39 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
         finally:
             Ad = d_keep
         np.testing.assert_allclose(got, ref, atol=tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 16), (16, 300, 768), (17, 2304, 768), (32, 2304, 7168), (50, 512, 1040), (64, 257, 64)])
+def test_gemm_skinny_rows(M, N, K):
+    """b2t_gemm_f32 with <= 64 rows against a wide weight matrix (one streamed frame: evaluate_model_helpers.py:87-115)
+    takes the weight-streaming kernel (gemm_skinny_kernel): same product, bias, Softsign, accumulate, a row-mapped A and C,
+    nothing written outside the extent."""
+    import b2t_ops as ops
+    dev = _dev()
+    rng = np.random.default_rng(M * 31 + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64).T
+    tA, tB, tb = torch.from_numpy(A).to(dev), torch.from_numpy(Bm).to(dev), torch.from_numpy(bias).to(dev)
+    tol = 3e-6 * np.sqrt(K) * max(1.0, float(np.abs(ref).max()))
+    Np = N + 5
+    tC = torch.full((M + 1, Np), 7.0, device=dev)
+    ops.gemm(tA, tB, tC, M=M, N_=N, K=K, a_s0=K, b_s0=K, c_s0=Np, bias=tb)
+    got = tC.cpu().numpy()
+    np.testing.assert_allclose(got[:M, :N], ref + bias, atol=tol)
+    assert np.all(got[M:, :] == 7.0) and np.all(got[:, N:] == 7.0)          # no out-of-bounds writes
+    tC2 = torch.ones((M, N), device=dev)
+    ops.gemm(tA, tB, tC2, M=M, N_=N, K=K, a_s0=K, b_s0=K, c_s0=N, accumulate=1)
+    np.testing.assert_allclose(tC2.cpu().numpy(), ref + 1.0, atol=tol)
+    tC3 = torch.zeros((M, N), device=dev)
+    ops.gemm(tA, tB, tC3, M=M, N_=N, K=K, a_s0=K, b_s0=K, c_s0=N, epilogue=1)
+    np.testing.assert_allclose(tC3.cpu().numpy(), ref / (1 + np.abs(ref)), atol=tol)
+    if M % 4 == 0:
+        # rows r = t * Bb + b read from A stored [Bb][Tt][K] (the streamed frame's (t, b) row map) and written batch-first
+        Bb = 4; Tt = M // Bb
+        A3 = np.ascontiguousarray(A.reshape(Tt, Bb, K).transpose(1, 0, 2))
+        tA3 = torch.from_numpy(A3).to(dev)
+        tC4 = torch.full((Bb, Tt, N), float("nan"), device=dev)
+        ops.gemm(tA3, tB, tC4, M=M, N_=N, K=K, a_div=Bb, a_s1=K, a_s0=Tt * K, b_s0=K, c_div=Bb, c_s1=N, c_s0=Tt * N)
+        np.testing.assert_allclose(tC4.cpu().numpy().transpose(1, 0, 2).reshape(M, N), ref, atol=tol)
