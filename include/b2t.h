@@ -71,7 +71,10 @@ typedef struct b2t_gemm_desc {
   int epilogue; int accumulate;
   /* split-K (weight gradients: few output tiles, K = T*B): splitk > 1 launches Z*splitk slices; slice ks
    * reduces k in [ks*kc, min(K,(ks+1)*kc)) (kc = ceil(K/splitk) rounded up to 16) into the slab
-   * C + z*c_sz + ks*c_ks; the caller sums the slabs deterministically (b2t_colsum_f32). */
+   * C + z*c_sz + ks*c_ks; the caller sums the slabs deterministically (b2t_colsum_f32).
+   * splitk <= 1: one pass.  With M <= 64 rows b2t_gemm_f32 then streams the weights once through a kernel whose 8 waves
+   * split K (a streamed frame of a few dozen utterances: 5-8x faster than a 128-row tile); splitk < 0 asks for the tile
+   * kernel's k order regardless (passes that must agree bit for bit with differently chunked passes of the same data). */
   int splitk; long long c_ks;
   /* gap in A's contiguous index i (k if a_kcontig, else m): for i >= a_brk the element is read at i + a_gap.
    * Lets dGi = dG[:, 0:2H] ++ dG[:, 3H:4H] be ONE operand (a_brk = 2H, a_gap = H).  a_brk = 0: off; must be a

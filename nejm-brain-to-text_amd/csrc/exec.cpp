@@ -150,6 +150,7 @@ struct Ctx {
   bool bf16_gemm;
   int rc = 0;
   hipStream_t qs[8] = {};      // the pass's queues (plan_queues); qs[0] = main
+  bool exact_k = false;         // pipelined (chunked) passes: every GEMM keeps the tile kernel's k order, so that the result does not depend on the chunking
   int nq = 0;
   const Layout* lay = nullptr;  // for the per-queue pack scratch of the amp-mode GEMM
 
@@ -209,6 +210,7 @@ struct Ctx {
       return;
     }
     d.accumulate = accumulate;
+    if (exact_k && d.splitk <= 1) d.splitk = -1;
     Scope sc(*this, s, kind, flops);
     rc = bf16_gemm ? gemm_amp(d, s) : b2t_gemm_f32(&d, st);
   }
@@ -531,9 +533,10 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
 
   int chunks[MAXC][2];
   const int nc = make_chunks(Tp, p->chunks, chunks);
+  c.exact_k = nc > 1;
   const long long a_s0_l0 = prm->patch > 0 ? (long long)prm->stride * F : F;
   // rows x K that b2t_gemm_f32 serves with its skinny (weight-streaming) kernel: exact fp32 only, one frame of <= 64 utterances
-  auto skinny = [&](long long rows, int K) { return !c.bf16_gemm && rows <= 64 && K % 16 == 0 && 3 * H >= 256; };
+  auto skinny = [&](long long rows, int K) { return !c.bf16_gemm && !c.exact_k && rows <= 64 && K % 16 == 0; };
   const float hs = std::max(0.25f, (float)H * H / (512.f * 512.f)) * std::max(1, (B + 63) / 64);   // sweep cost scale
   const unsigned q_sweep = ex->sweep_qmask;
 
@@ -710,6 +713,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
 
   int chunks[MAXC][2];
   const int nc = make_chunks(Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks, chunks);
+  c.exact_k = nc > 1;
   // (One chunk -- shapes whose sweeps cannot be co-resident, e.g. H = 768 -- runs everything on the caller's stream.  Putting
   // the weight-gradient GEMMs of layer l on a side stream under the sweep of layer l - 1 was measured: C3 fp32 19.7 -> 23.0 ms,
   // bf16 operands 12.7 -> 15.1 ms: a 768-unit sweep workgroup needs a CU's whole register file, and GEMM workgroups that

@@ -239,17 +239,20 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
 // Skinny products (M <= 64 rows: one streamed frame of a few dozen utterances, evaluate_model_helpers.py:87-115 /
 // language-model streaming): C[M][N] = A[M][K] . B[N][K]^T (+ bias) is bound by streaming B (the weights) once, and a
 // 128-row tile wastes most of its MFMA rows and, with split-K slabs, three launches.  Here a workgroup owns 16 columns of
-// C: its 4 waves split K, every lane loads 16 bytes of its weight row and of each 16-row block of A per 16-k chunk
+// C: its 8 waves split K, every lane loads 16 bytes of its weight row and of each 16-row block of A per 16-k chunk
 // straight from global memory into MFMA operands (no LDS staging: A is L2-resident, B is read exactly once), and the
-// four partial tiles are summed through LDS.  Layer 0 of the shipped shape (32 x 7168 x 2304): ~150 us as split-K -> ~30.
-template <int MT>   // 16-row blocks of A
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-  __shared__ float red[4][MT][4][64];
+// eight partial tiles are summed through LDS.  Layer 0 of the shipped shape (32 x 7168 x 2304): ~150 us as split-K -> ~30.
+template <int MT, bool BKC>   // 16-row blocks of A; B k-contiguous ([N][K]) or n-contiguous ([K][N]: the day weights)
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float red[8][MT][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16;
+  const int z = blockIdx.y, zb = g.b_zmap ? g.b_zmap[z] : z;             // batched form: the day layer's per-sentence products
+  g.A += (long long)z * g.a_sz; g.B += (long long)zb * g.b_sz; g.C += (long long)z * g.c_sz;
+  if (g.bias) g.bias += (long long)zb * g.bias_sz;
   const int ncol = n0 + j < g.N ? n0 + j : g.N - 1;                       // clamped: columns beyond N are never stored
-  const float* brow = g.B + rowoff(ncol, g.b_s0, g.b_s1, g.b_div) + 4 * q;
+  const float* brow = BKC ? g.B + rowoff(ncol, g.b_s0, g.b_s1, g.b_div) + 4 * q : g.B + ncol;
   const float* arow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -261,12 +264,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // K in chunks of 16, dealt to the waves round-robin in groups of 4 chunks (64 k: one 256-byte run of a weight row)
   const int nchunk = g.K / 16;
-  for (int c0 = wave * 4; c0 < nchunk; c0 += 16) {
+  for (int c0 = wave * 4; c0 < nchunk; c0 += 32) {
     float4 bw[4], av[4][MT];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int k = (c0 + u < nchunk ? c0 + u : c0) * 16;                 // the tail re-reads a valid chunk and is masked below
-      bw[u] = *reinterpret_cast<const float4*>(brow + k);
+      if constexpr (BKC) {
+        bw[u] = *reinterpret_cast<const float4*>(brow + k);
+      } else {   // element (n, k) at B + rowoff(k) + n: four row-strided loads, 16 lanes (n) contiguous each
+        const int kq = k + 4 * q;
+        bw[u] = make_float4(brow[rowoff(kq, g.b_s0, g.b_s1, g.b_div)], brow[rowoff(kq + 1, g.b_s0, g.b_s1, g.b_div)],
+                            brow[rowoff(kq + 2, g.b_s0, g.b_s1, g.b_div)], brow[rowoff(kq + 3, g.b_s0, g.b_s1, g.b_div)]);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) av[u][mt] = *reinterpret_cast<const float4*>(arow[mt] + k);
     }
@@ -289,9 +298,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
     for (int e = 0; e < 4; ++e) red[wave][mt][e][lane] = acc[mt][e];
   __syncthreads();
   // D layout of v_mfma_f32_16x16x4_f32: lane (j, q), element e -> row 4 q + e, column j.  Thread t sums one (mt, e, lane).
-  for (int idx = tid; idx < MT * 4 * 64; idx += 256) {
+  for (int idx = tid; idx < MT * 4 * 64; idx += 512) {
     const int l = idx & 63, e = (idx >> 6) & 3, mt = idx >> 8;
-    const float v0 = red[0][mt][e][l] + red[1][mt][e][l], v1 = red[2][mt][e][l] + red[3][mt][e][l];
+    const float v0 = (red[0][mt][e][l] + red[1][mt][e][l]) + (red[2][mt][e][l] + red[3][mt][e][l]);
+    const float v1 = (red[4][mt][e][l] + red[5][mt][e][l]) + (red[6][mt][e][l] + red[7][mt][e][l]);
     const int row = 16 * mt + 4 * (l >> 4) + e, col = n0 + (l & 15);
     if (row < g.M && col < g.N) {
       float v = v0 + v1 + (g.bias ? g.bias[col] : 0.f);
@@ -318,14 +328,19 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
   { int rc = fill_gemm_args(d, g, BKT, BM, "b2t_gemm_f32"); if (rc) return rc; }
   dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);
   hipStream_t s = as_stream(stream);
-  if (d->M <= 64 && d->Z == 1 && !d->b_zmap && g.splitk == 1 && d->a_kcontig && d->b_kcontig && (d->K % 16) == 0 && d->a_brk == 0 &&
-      d->epilogue != 2 && d->N >= 256) {
+  if (d->M <= 64 && d->splitk >= 0 && g.splitk == 1 && d->a_kcontig && (d->K % 16) == 0 && d->a_brk == 0 && d->epilogue != 2) {
     // a few rows against a wide weight matrix: stream the weights once (gemm_skinny_kernel)
-    const dim3 sg((d->N + 15) / 16);
-    if (d->M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<1>), sg, block, 0, s, g);
-    else if (d->M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<2>), sg, block, 0, s, g);
-    else if (d->M <= 48) hipLaunchKernelGGL((gemm_skinny_kernel<3>), sg, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<4>), sg, block, 0, s, g);
+    const dim3 sg((d->N + 15) / 16, d->Z), sb(512);
+#define B2T_SKINNY(MT)                                                                                  \
+    do {                                                                                                \
+      if (d->b_kcontig) hipLaunchKernelGGL((gemm_skinny_kernel<MT, true>), sg, sb, 0, s, g);              \
+      else hipLaunchKernelGGL((gemm_skinny_kernel<MT, false>), sg, sb, 0, s, g);                          \
+    } while (0)
+    if (d->M <= 16) B2T_SKINNY(1);
+    else if (d->M <= 32) B2T_SKINNY(2);
+    else if (d->M <= 48) B2T_SKINNY(3);
+    else B2T_SKINNY(4);
+#undef B2T_SKINNY
     B2T_CHECK_LAUNCH("b2t_gemm_f32 (skinny)");
     return 0;
   }

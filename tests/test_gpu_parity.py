@@ -617,7 +617,7 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
         np.testing.assert_allclose(got, ref, atol=tol)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 256, 16), (16, 300, 768), (17, 2304, 768), (32, 2304, 7168), (50, 512, 1040), (64, 257, 64)])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 16), (16, 300, 768), (17, 2304, 768), (32, 2304, 7168), (50, 512, 1040), (64, 257, 64), (32, 41, 768), (3, 7, 32)])
 def test_gemm_skinny_rows(M, N, K):
     """b2t_gemm_f32 with <= 64 rows against a wide weight matrix (one streamed frame: evaluate_model_helpers.py:87-115)
     takes the weight-streaming kernel (gemm_skinny_kernel): same product, bias, Softsign, accumulate, a row-mapped A and C,
@@ -651,3 +651,24 @@ def test_gemm_skinny_rows(M, N, K):
         tC4 = torch.full((Bb, Tt, N), float("nan"), device=dev)
         ops.gemm(tA3, tB, tC4, M=M, N_=N, K=K, a_div=Bb, a_s1=K, a_s0=Tt * K, b_s0=K, c_div=Bb, c_s1=N, c_s0=Tt * N)
         np.testing.assert_allclose(tC4.cpu().numpy().transpose(1, 0, 2).reshape(M, N), ref, atol=tol)
+
+
+def test_gemm_skinny_batched_day_form():
+    """The day layer's per-sentence product on a short frame window (rnn_model.py:95-99): Z sentences x M <= 64 frames, weights
+    and bias picked per sentence through b_zmap, W stored [k][n] (b_kcontig = 0), Softsign epilogue -- the batched form of the
+    weight-streaming kernel."""
+    import b2t_ops as ops
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    Z, M, N, K, D = 5, 14, 48, 64, 3
+    x = rng.standard_normal((Z, M, K)).astype(np.float32)
+    W = (rng.standard_normal((D, K, N)) * 0.2).astype(np.float32)
+    b = rng.standard_normal((D, N)).astype(np.float32)
+    zmap = np.array([2, 0, 1, 2, 0], np.int32)
+    pre = np.einsum("zmk,zkn->zmn", x.astype(np.float64), W[zmap].astype(np.float64)) + b[zmap][:, None, :]
+    ref = pre / (1 + np.abs(pre))
+    tx, tW, tb = torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev), torch.from_numpy(b).to(dev)
+    out = torch.full((Z, M, N), float("nan"), device=dev)
+    ops.gemm(tx, tW, out, M=M, N_=N, K=K, Z=Z, a_kc=1, a_s0=K, a_sz=M * K, b_kc=0, b_s0=N, b_sz=K * N, c_s0=N, c_sz=M * N,
+             bias=tb, bias_sz=N, b_zmap=torch.from_numpy(zmap).to(dev), epilogue=1)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-6)
