@@ -564,6 +564,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   int t_init[MAXL], t_sw[MAXL][MAXC];
   for (int l = 0; l < L; ++l)
     t_init[l] = P.add("init", 5.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
+      if (states && !p->save) return;   // inference with carried state: the first sweep chunk reads `states` in place (below)
       if (states) c.call(check_hip(hipMemcpyAsync(w.out[l], states + (size_t)l * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s), "model_forward: state copy"));
       else c.call(b2t_broadcast_rows_f32(prm->h0, w.out[l], B, H, reinterpret_cast<void*>(s)));
     });
@@ -612,7 +613,9 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       t_sw[l][ci] = P.add("sweep", 40.f + n * est_step_us(0) * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n](hipStream_t ss) {
         if (c.rc) return;
         Ctx::Scope sc(c, ss, 8, 2.0 * n * B * 3.0 * H * H);
-        c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], w.out[l] + (long long)t0 * B * H,
+        // h_{t0-1}: slot t0 of out[l] -- or, for the first chunk of an inference pass with carried state, the caller's buffer
+        const float* h_prev = (t0 == 0 && states && !p->save) ? states + (size_t)l * B * H : w.out[l] + (long long)t0 * B * H;
+        c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], h_prev,
                                      w.out[l] + (long long)(1 + t0) * B * H, p->save ? w.res[l] + (long long)t0 * B * 4 * H : nullptr,
                                      t1 == Tp ? hidden + (size_t)l * B * H : nullptr, n, B, H, mode, sync_of(l),
                                      reinterpret_cast<void*>(ss)));
