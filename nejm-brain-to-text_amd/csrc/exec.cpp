@@ -102,7 +102,9 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
   for (size_t l = 0; l < L; ++l) {
     const size_t sk = l == 0 ? (In0 >= 2048 ? std::max<size_t>(1, std::min<size_t>(16, In0 / 448)) : 0)
                              : (H >= 384 ? std::max<size_t>(1, H / 192) : 0);
-    w.slab_gi[l] = sk > 1 ? take(sk * std::min<size_t>(512, Tp * B) * 3 * H) : nullptr;
+    // (layer 0 with a patch input, K = In0 >= 2048, also splits K three ways at full size: see b2t_model_forward)
+    const size_t big0 = (l == 0 && In0 >= 2048 && !p->bf16_gemm) ? 3 * Tp * B * 3 * H : 0;
+    w.slab_gi[l] = sk > 1 ? take(std::max(sk * std::min<size_t>(512, Tp * B) * 3 * H, big0)) : nullptr;
   }
   // amp mode: packed-operand scratch, sized for the largest GEMM of either pass, one per queue
   w.pack_bytes = 0;
@@ -588,6 +590,13 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
             d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
             if (skinny(n * B, In0)) c.gemm(sg, d);   // <= 64 rows: the weight-streaming kernel inside b2t_gemm_f32, one launch
             else c.gemm(sg, d, std::max(1, std::min(16, In0 / 448)), w.slab_gi[0]);
+          } else if (In0 >= 2048 && nc == 1) {
+            // patch input at full size (shipped shape: 7808 x 2304 x 7168): 61 x 18 = 1098 tiles are 1.07 waves of the chip's
+            // 1024 tile slots, i.e. the second wave runs almost empty (92 TF/s).  Three K slices make 3.2 waves of shorter
+            // tiles: 114 TF/s incl. the slab reduction (tools/experimental/bench_gemm_c3.py); one row-mapped GEMM over all (t, b) rows.
+            b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
+            d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
+            c.gemm(sg, d, 3, w.slab_gi[0]);
           } else {
             b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n, 3 * H, In0);
             d.Z = B; d.a_s0 = a_s0_l0; d.a_sz = (long long)T * F; d.b_s0 = In0; d.c_s0 = (long long)B * 3 * H; d.c_sz = 3 * H;
