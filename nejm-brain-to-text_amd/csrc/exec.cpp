@@ -74,7 +74,7 @@ int make_chunks(int Tp, int chunks, int (*out)[2]) {
 struct Layout {
   float *U, *Ud, *out[MAXL], *outd[MAXL], *gi[MAXL], *res[MAXL], *slab_gi[MAXL];
   float *dY[MAXL], *dG[MAXL], *dh_init, *carry[MAXL], *scratch[MAXL], *whh_t[MAXL], *dU, *dV, *day_slab, *day_bslab;
-  float *slab[MAXL], *slab_head, *s4[MAXL], *cs_layer[MAXL], *cs_head, *cs_day, *cs_h0;
+  float *slab[MAXL], *slab_head, *s4[MAXL], *cs_layer[MAXL], *cs_head, *cs_day, *cs_h0, *slab_dx;
   char* pack[NPACK];       // amp mode: per-queue scratch of the two-pass bf16 GEMM (packed operands)
   size_t pack_bytes;
   size_t bytes;
@@ -133,6 +133,8 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     w.s4[l] = take(4 * H);
     w.cs_layer[l] = take(colsum_ws_floats(K, 4 * H) + 4);
   }
+  // two K slices for the input-gradient GEMMs of the serial plan (one at a time: one slab), see b2t_model_backward
+  w.slab_dx = (!p->bf16_gemm && L > 1) ? take(2 * K * H) : nullptr;
   w.dh_init = take(L * B * H);
   w.dU = take(B * T * F);
   w.dV = m->patch > 0 ? take(B * Tp * In0) : nullptr;
@@ -780,7 +782,12 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       d.C = w.dU + (long long)t0 * F; d.c_div = B; d.c_s1 = F; d.c_s0 = (long long)T * F;
       if (fast_day) { d.epilogue = 2; d.ep_aux = w.U + (long long)t0 * F; }   // dpre = dU * (1 - |U|)^2
     }
-    c.gemm(s, d);
+    // Serial plan (shapes whose sweeps cannot share the chip, e.g. the shipped H = 768): the whole sequence's dX of a layer is
+    // 61 x 6 = 366 tiles, a third of the chip's tile slots -- two K slices fill it (79 -> 100 TF/s incl. the slab reduction,
+    // tools/experimental/bench_gemm_c3.py).  Pipelined plans share the CUs with the sweeps anyway (measured neutral there).
+    const long long tiles = (((long long)n * B + 127) / 128) * ((N + 127) / 128);
+    if (l > 0 && nc == 1 && !c.bf16_gemm && w.slab_dx && tiles <= 512 && 3 * H >= 1024) c.gemm(s, d, 2, w.slab_dx);
+    else c.gemm(s, d);
     if (l == 0 && fast_day) {
       const int first = t0 + n == Tp ? 0 : 1;   // the top time chunk is swept first: it overwrites, the others accumulate
       b2t_gemm_desc d = gd(x + (long long)t0 * F, w.dU + (long long)t0 * F, w.day_slab, F, F, n);

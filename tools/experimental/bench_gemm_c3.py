@@ -27,3 +27,13 @@ bench("dX0 7808x7168x2304 NN", lambda: ops.gemm(dG, W, dV, M=M, N_=K, K=H3, a_s0
 G = torch.empty(H3, K, device=dev)
 for sk in (ops.splitk_for(H3, K, M), 2, 3, 5, 8):
     bench(f"dW_ih0 2304x7168x7808 TN splitk {sk}", lambda: ops.gemm(dG, A, G, M=H3, N_=K, K=M, a_kc=0, a_s0=3072, b_kc=0, b_s0=K, c_s0=K, splitk=sk, ws=ws), 2.0 * M * K * H3)
+# layers >= 1 of the shipped shape
+H = 768
+X = torch.randn(M, H, device=dev); Wi = torch.randn(3 * H, H, device=dev); gi = torch.empty(M, 3 * H, device=dev)
+for sk in (1, 2, 3):
+    kw = dict(splitk=sk, ws=ws) if sk > 1 else {}
+    bench(f"gi_l {M}x2304x768 NT splitk {sk}", lambda: ops.gemm(X, Wi, gi, M=M, N_=3 * H, K=H, a_s0=H, b_s0=H, c_s0=3 * H, **kw), 2.0 * M * H * 3 * H)
+dGl = torch.randn(M, 4 * H, device=dev); dY = torch.empty(M, H, device=dev)
+for sk in (1, 2, 3, 4):
+    kw = dict(splitk=sk, ws=ws) if sk > 1 else {}
+    bench(f"dX_l {M}x768x2304 NN splitk {sk}", lambda: ops.gemm(dGl, Wi, dY, M=M, N_=H, K=3 * H, a_s0=4 * H, b_kc=0, b_s0=H, c_s0=H, **kw), 2.0 * M * H * 3 * H)
