@@ -263,7 +263,12 @@ def gru_mode_for(B: int, H: int) -> int:
 
 
 GRU_BF16 = 0x100   # B2T_GRU_BF16 (include/b2t.h): bf16 operands of the recurrent product, persistent mode 1
-GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup (bf16 operands only)
+GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup
+GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
+# which exact-fp32 sweeps hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
+# traffic of a backward sweep launch 660 -> 222 MB (1.35x its algorithmic bytes), forward 179 -> 109 MB, a backward launch
+# 940 -> 850 us, the step +0.8 % (20.12 -> 20.28 ms sustained); ignored where the library's dispatch probe fails
+LOCAL_F32 = {"dirs": os.environ.get("B2T_GRU_LOCAL", "fb")}
 # which sweeps run with 32-unit workgroups under AMP: "" none, "f" forward, "b" backward, "fb" both (B2T_AMP_WIDE;
 # measured at C2: 18.4 / 17.5 / 17.1 / 16.1 ms per step)
 AMP["wide"] = os.environ.get("B2T_AMP_WIDE", "fb")
@@ -277,9 +282,10 @@ WIDE_F32 = {"dirs": os.environ.get("B2T_WIDE_F32", "f")}   # measured at C2: for
 def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
     """`mode` argument of b2t_gru_layer_fwd/bwd_f32: under set_amp(True) the persistent sweeps take bf16 operands."""
     if not (AMP["on"] and AMP.get("sweeps", True) and mode == 1):
+        local = GRU_LOCAL if (mode == 1 and direction in LOCAL_F32["dirs"] and H <= 512) else 0
         if mode == 1 and direction in WIDE_F32["dirs"] and H % 32 == 0 and H <= 512:
-            return mode | GRU_WIDE
-        return mode
+            return mode | GRU_WIDE | local
+        return mode | local
     wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= int(os.environ.get("B2T_AMP_WIDE_MAXH", "768"))) else 0
     return mode | GRU_BF16 | wide
 

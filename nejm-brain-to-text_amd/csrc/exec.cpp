@@ -628,7 +628,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         const float* h_prev = (t0 == 0 && states && !p->save) ? states + (size_t)l * B * H : w.out[l] + (long long)t0 * B * H;
         c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], h_prev,
                                      w.out[l] + (long long)(1 + t0) * B * H, p->save ? w.res[l] + (long long)t0 * B * 4 * H : nullptr,
-                                     t1 == Tp ? hidden + (size_t)l * B * H : nullptr, n, B, H, mode, sync_of(l),
+                                     t1 == Tp ? hidden + (size_t)l * B * H : nullptr, n, B, H,
+                                     (mode & B2T_GRU_LOCAL) ? (mode | ((l & 1) ? B2T_GRU_PARITY : 0)) : mode, sync_of(l),
                                      reinterpret_cast<void*>(ss)));
       });
     }
@@ -820,7 +821,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
         Ctx::Scope sc(c, ss, 9, 2.0 * n * B * 3.0 * H * H);
         c.call(b2t_gru_layer_bwd_f32(w.dY[l] + (long long)t0 * B * H, dh_last, w.res[l] + (long long)t0 * B * 4 * H,
                                      w.out[l] + (long long)(1 + t0) * B * H, w.out[l] + (long long)t0 * B * H, w.whh_t[l],
-                                     w.dG[l] + (long long)t0 * B * 4 * H, dh_out, w.scratch[l], n, B, H, mode, sync_of(l), ssp));
+                                     w.dG[l] + (long long)t0 * B * 4 * H, dh_out, w.scratch[l], n, B, H,
+                                     (mode & B2T_GRU_LOCAL) ? (mode | ((l & 1) ? B2T_GRU_PARITY : 0)) : mode, sync_of(l), ssp));
       });
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;

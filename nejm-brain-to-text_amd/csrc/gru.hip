@@ -123,11 +123,12 @@ extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const f
   hipStream_t s = as_stream(stream);
   const bool bf16 = (mode & B2T_GRU_BF16) != 0;   // bf16 operands of the recurrent product (persistent mode 1 only)
   const bool wide = (mode & B2T_GRU_WIDE) != 0;   // 32 hidden units per workgroup (with bf16 operands)
-  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE);
+  const int local = (mode & B2T_GRU_LOCAL) ? ((mode & B2T_GRU_PARITY) ? 1 : 0) : -1;   // XCD-local hand-off, layer parity
+  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE | B2T_GRU_LOCAL | B2T_GRU_PARITY);
   B2T_REQUIRE(mode == 0 || mode == 1, "gru_layer_fwd: unknown mode %d", mode);
   B2T_REQUIRE(!bf16 || mode == 1, "gru_layer_fwd: B2T_GRU_BF16 goes with mode 1");
   if (mode == 1) {
-    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s, bf16, wide);
+    int rc = gru_persistent_fwd(gi, w_hh, b_hh, h_init, out, reserve, T, B, H, sync_ws, s, bf16, wide, local);
     if (rc) return rc;
   } else {
     dim3 grid(H / 16, (B + 15) / 16), block(256);
@@ -153,11 +154,12 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
   hipStream_t s = as_stream(stream);
   const bool bf16 = (mode & B2T_GRU_BF16) != 0;
   const bool wide = (mode & B2T_GRU_WIDE) != 0;
-  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE);
+  const int local = (mode & B2T_GRU_LOCAL) ? ((mode & B2T_GRU_PARITY) ? 1 : 0) : -1;
+  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE | B2T_GRU_LOCAL | B2T_GRU_PARITY);
   B2T_REQUIRE(mode == 0 || mode == 1, "gru_layer_bwd: unknown mode %d", mode);
   B2T_REQUIRE(!bf16 || mode == 1, "gru_layer_bwd: B2T_GRU_BF16 goes with mode 1");
   if (mode == 1)
-    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s, bf16, wide);
+    return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s, bf16, wide, local);
   B2T_REQUIRE(carry_ws != nullptr, "gru_layer_bwd: carry_ws is required in mode 0 ([B][H] floats)");
   dim3 grid(H / 16, (B + 15) / 16), block(256);
   for (int t = T - 1; t >= -1; --t)

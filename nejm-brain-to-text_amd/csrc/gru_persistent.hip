@@ -31,19 +31,19 @@ namespace b2t {
 // ---------------------------------------------------------------------------------------------------
 // NT: 16-unit tiles per workgroup (1, or 2 with bf16 operands, whose weight slice is half the registers): 32 units per
 // workgroup halve the workgroups of a sweep -- five concurrent sweeps then crowd the CUs half as much.
-template <int NCH, bool BF16, int NT = 1>  // NCH: 16-wide K chunks per wave (H <= 64*NCH)
+template <int NCH, bool BF16, int NT = 1, bool LOC = false>  // NCH: 16-wide K chunks per wave (H <= 64*NCH); LOC: XCD-local hand-off
 __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1))) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
                                                                  float* __restrict__ reserve, int T, int B, int H,
-                                                                 unsigned* sync) {
+                                                                 unsigned* sync, int par) {
   constexpr int TPN = 16 * NT + 4;    // LDS pitch of the staged tile (= TP for one tile)
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * NT * 4 * 64 + 16 * TPN];
   constexpr int NSLOT_F = NCH < 8 ? NCH : 8;   // staging slots per wave, recycled every NSLOT_F instructions (as in the backward sweep)
   __shared__ __attribute__((aligned(16))) float stage[4][NSLOT_F * SLOT_F];   // per-wave operand staging (gru_sync.h)
   float* hs = red + 4 * 3 * NT * 4 * 64;   // staged h tile [16 rows][TPN]
-  constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
+  constexpr int AUX = LOC ? 0 : 16;   // sc1 payload accesses (device scope); ordinary ones when the row group shares an L2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef B2T_NO_SETPRIO
   __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
@@ -59,8 +59,12 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
     const int nthr = gridDim.x * gridDim.y * 256;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
   }
-  const int rg = blockIdx.y, m0 = rg * 16;   // row groups are independent recurrences
-  const int j0 = blockIdx.x * 16 * NT;
+  int rg = blockIdx.y, tile = blockIdx.x;   // row groups are independent recurrences
+  if constexpr (LOC) {
+    if (!local_role(sync + 32 + (size_t)pset * SETW + (SETW - 16), (B + 15) / 16, G, par, rg, tile)) { finish_call(sync, pset); return; }
+  }
+  const int m0 = rg * 16;
+  const int j0 = tile * 16 * NT;
   int unit[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) unit[n] = j0 + 16 * n + j;
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
     }
     const float* hsrc = h_init;
     if (t > 0) {
-      wait_count(cnt + (size_t)(t - 1) * CSTRIDE, G, err);
+      if constexpr (LOC) wait_count_local(cnt + (size_t)(t - 1) * CSTRIDE, G, err);
+      else wait_count(cnt + (size_t)(t - 1) * CSTRIDE, G, err);
       hsrc = out + (long long)(t - 1) * B * H;
     }
     TSTAMP(0)   // poll + barrier
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
     // All loads go out first (branch-free, clamped: a conditional load makes the compiler wait for everything), then
     // each pair is transposed and consumed as it lands (vmcnt(6), vmcnt(4), ...).
     float4 v[NCH];
-    issue_block_loads<NCH, B2T_LOAD_AUX>(v, hsrc, m0, B, H, wave * NCH * 16, H, lane);
+    issue_block_loads<NCH, LOC ? 0 : B2T_LOAD_AUX>(v, hsrc, m0, B, H, wave * NCH * 16, H, lane);
     __builtin_amdgcn_sched_barrier(0);   // all loads are in flight before the first MFMA (the scheduler would sink them)
 #ifdef B2T_TIMING_SPLIT_LOADS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
                        *reinterpret_cast<const float4*>(&hs[r * TPN + c4]));
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT);
+      if (lane == 0) { if constexpr (LOC) l2_atomic_inc(cnt + (size_t)t * CSTRIDE); else __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT); }
     }
     // The gate values saved for the backward sweep are nobody's dependency inside this sweep: store them AFTER the
     // publish so their write acknowledgements are not part of the drain in front of the counter increment.
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
 // dGh_{t+1} row block with its register-resident W_hh[:, slice] and (B) forms the gate gradients of
 // step t for its slice, publishing them as dG[t] for the other workgroups of the row group.
 // ---------------------------------------------------------------------------------------------------
-template <int NCB, bool BF16, int NT = 1>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
+template <int NCB, bool BF16, int NT = 1, bool LOC = false>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
 __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __restrict__ dY,
                                                                  const float* __restrict__ dh_last,
                                                                  const float* __restrict__ reserve,
@@ -205,13 +210,13 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                                                                  const float* __restrict__ h_init,
                                                                  const float* __restrict__ w_hh_t, float* dG,
                                                                  float* __restrict__ dh_init, int T, int B, int H,
-                                                                 unsigned* sync) {
+                                                                 unsigned* sync, int par) {
   constexpr int TPN = 16 * NT + 4;
   __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64 + 4 * 16 * TPN];
   constexpr int NSLOT = NCB < 8 ? NCB : 8;   // staging slots per wave, recycled every NSLOT instructions
   __shared__ __attribute__((aligned(16))) float stage[4][NSLOT * SLOT_F];
   float* gs = red + 4 * NT * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TPN]
-  constexpr int AUX = 16;   // sc1 payload accesses (0 = ordinary cached accesses was measured: no faster)
+  constexpr int AUX = LOC ? 0 : 16;   // sc1 payload accesses (device scope); ordinary ones when the row group shares an L2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef B2T_NO_SETPRIO
   __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
@@ -227,8 +232,12 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     const int nthr = gridDim.x * gridDim.y * 256;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
   }
-  const int rg = blockIdx.y, m0 = rg * 16;   // row groups are independent recurrences
-  const int j0 = blockIdx.x * 16 * NT;
+  int rg = blockIdx.y, tile = blockIdx.x;   // row groups are independent recurrences
+  if constexpr (LOC) {
+    if (!local_role(sync + 32 + (size_t)pset * SETW + (SETW - 16), (B + 15) / 16, G, par, rg, tile)) { finish_call(sync, pset); return; }
+  }
+  const int m0 = rg * 16;
+  const int j0 = tile * 16 * NT;
   int unit[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) unit[n] = j0 + 16 * n + j;
@@ -271,14 +280,15 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     }
     TSTAMP(0)   // operand prefetch issue
     if (t < T - 1) {
-      wait_count(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
+      if constexpr (LOC) wait_count_local(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
+      else wait_count(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
       TSTAMP(1)   // poll + barrier
       const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
       f32x4 acc[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
       float4 v[NCB];
-      issue_block_loads<NCB, B2T_LOAD_AUX>(v, dgh, m0, B, 4 * H, wave * NCB * 16, 3 * H, lane);
+      issue_block_loads<NCB, LOC ? 0 : B2T_LOAD_AUX>(v, dgh, m0, B, 4 * H, wave * NCB * 16, 3 * H, lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < NCB / 2; ++p) {
@@ -340,7 +350,8 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                        *reinterpret_cast<const float4*>(&gs[(wave * 16 + r2) * TPN + c4]));
       }
     }
-    publish_count(cnt + (size_t)t * CSTRIDE);
+    if constexpr (LOC) publish_count_local(cnt + (size_t)t * CSTRIDE);
+    else publish_count(cnt + (size_t)t * CSTRIDE);
     TSTAMP(6)   // tile store + drain + publish
    }
   }
@@ -390,7 +401,7 @@ static unsigned exclusive_lds() {
 static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
   const int gx = H / 16, gy = (B + 15) / 16;
   if (!sync_ws) { set_error("%s: sync_ws is required in persistent mode", what); return 2; }
-  if ((long long)gy * T * CSTRIDE > SETW) {
+  if ((long long)gy * T * CSTRIDE > SETW - 16) {   // (the last 16 words of a set hold the XCD tickets of the local hand-off)
     set_error("%s: %d row groups x %d steps exceed the %d hand-off counters of one call", what, gy, T, SETW);
     return 2;
   }
@@ -403,34 +414,65 @@ static int check_grid(int B, int H, int T, void* sync_ws, const char* what) {
   return 0;
 }
 
+// The XCD-local hand-off assumes what the hardware documents for this partition mode: the workgroups of a launch are dealt to
+// the 8 XCDs round-robin.  Checked once per process with a probe launch (256 workgroups must land 32 per XCD on 8 XCDs);
+// if it does not hold the flag is ignored and the sweeps use the device-scope hand-off.
+__global__ void xcd_probe_kernel(unsigned* out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
+bool gru_xcd_dispatch_ok() {
+  static int ok = -1;
+  if (ok >= 0) return ok == 1;
+  ok = 0;
+  unsigned* d = nullptr;
+  unsigned h[256];
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  hipLaunchKernelGGL(xcd_probe_kernel, dim3(256), dim3(64), 0, nullptr, d);
+  const bool copied = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!copied) { (void)hipGetLastError(); return false; }
+  int cnt[16] = {0};
+  for (int i = 0; i < 256; ++i) { if (h[i] > 7u) return false; ++cnt[h[i]]; }
+  for (int x = 0; x < 8; ++x) if (cnt[x] != 32) return false;
+  ok = 1;
+  return true;
+}
+
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
                        float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s, bool bf16,
-                       bool wide) {
+                       bool wide, int local) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd");
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_fwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
-  const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
+  const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
+  // XCD-local hand-off (local = layer parity, -1 = off): fp32 sweeps with 32-unit workgroups whose row groups fit half an XCD
+  const bool loc = local >= 0 && wide && !bf16 && H <= 512 && G <= 16 && gy <= 4 && gru_xcd_dispatch_ok();
+  const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
+  const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
     if (bf16 && wide) {                                                                                                \
       want_exclusive(gru_persist_fwd_kernel<NCH, true, 2>);                                                            \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync);                                                                              \
+                         B, H, sync, par);                                                                         \
     } else if (wide) {                                                                                                 \
       if constexpr (NCH <= 8) {                                                                                        \
-        want_exclusive(gru_persist_fwd_kernel<NCH, false, 2>);                                                         \
-        hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                           B, H, sync);                                                                                \
+        if (loc) {                                                                                                     \
+          hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false, 2, true>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                             B, H, sync, par);                                                                     \
+        } else {                                                                                                       \
+          want_exclusive(gru_persist_fwd_kernel<NCH, false, 2>);                                                       \
+          hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
+                             B, H, sync, par);                                                                     \
+        }                                                                                                              \
       }                                                                                                                \
     } else if (bf16) {                                                                                                 \
       want_exclusive(gru_persist_fwd_kernel<NCH, true>);                                                               \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync);                                                                              \
+                         B, H, sync, par);                                                                         \
     } else {                                                                                                           \
       want_exclusive(gru_persist_fwd_kernel<NCH, false>);                                                              \
       hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync);                                                                              \
+                         B, H, sync, par);                                                                         \
     }                                                                                                                  \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
@@ -445,32 +487,41 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
 
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
-                       void* sync_ws, hipStream_t s, bool bf16, bool wide) {
+                       void* sync_ws, hipStream_t s, bool bf16, bool wide, int local) {
   int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd");
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
-  const dim3 grid(wide ? H / 32 : H / 16, (B + 15) / 16), block(256);
+  const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
+  // XCD-local hand-off: fp32 sweeps with 16-unit workgroups whose row group fits one XCD at two workgroups per CU
+  const bool loc = local >= 0 && !wide && !bf16 && H <= 512 && G <= 32 && gy <= 4 && gru_xcd_dispatch_ok();
+  const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
+  const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_LAUNCH_BWD(NCB)                                                                                           \
   do {                                                                                                                \
     if (bf16 && wide) {                                                                                               \
       want_exclusive(gru_persist_bwd_kernel<NCB, true, 2>);                                                           \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync);                                                     \
+                         w_hh_t, dG, dh_init, T, B, H, sync, par);                                                \
     } else if (wide) {                                                                                                \
       if constexpr (NCB <= 24) {                                                                                      \
         want_exclusive(gru_persist_bwd_kernel<NCB, false, 2>);                                                        \
         hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                           w_hh_t, dG, dh_init, T, B, H, sync);                                                       \
+                           w_hh_t, dG, dh_init, T, B, H, sync, par);                                                  \
       }                                                                                                               \
     } else if (bf16) {                                                                                                \
       want_exclusive(gru_persist_bwd_kernel<NCB, true>);                                                              \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync);                                                     \
+                         w_hh_t, dG, dh_init, T, B, H, sync, par);                                                \
+    } else if (loc) {                                                                                                 \
+      if constexpr (NCB <= 24) {                                                                                      \
+        hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false, 1, true>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, \
+                           w_hh_t, dG, dh_init, T, B, H, sync, par);                                                  \
+      }                                                                                                               \
     } else {                                                                                                          \
       want_exclusive(gru_persist_bwd_kernel<NCB, false>);                                                             \
       hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync);                                                     \
+                         w_hh_t, dG, dh_init, T, B, H, sync, par);                                                \
     }                                                                                                                 \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);

@@ -28,6 +28,61 @@ __device__ __forceinline__ void wait_count(unsigned* p, unsigned target, unsigne
   __syncthreads();
 }
 
+// XCD-LOCAL hand-off (all workgroups of a row group run on ONE XCD, i.e. share one L2): the counter lives in that L2 and is
+// polled with a returning L2 atomic (an ordinary load could keep hitting a stale line in the CU's vector cache), payloads are
+// ordinary stores / loads (write-through to L2; every payload address is read once per kernel, after the kernel-start
+// invalidate, so the vector cache holds no stale copy).  Nothing of the hand-off then crosses the fabric.
+__device__ __forceinline__ unsigned l2_atomic_read(unsigned* p) {
+  unsigned v; const unsigned zero = 0u;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_count_local(unsigned* p, unsigned target, unsigned* err) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (l2_atomic_read(p) < target) {
+      ++spins;
+      if ((spins & 255u) == 0u) {
+        if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+        if (spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void l2_atomic_inc(unsigned* p) {
+  const unsigned one = 1u;
+  asm volatile("global_atomic_add %0, %1, off" :: "v"(p), "v"(one) : "memory");
+}
+__device__ __forceinline__ void publish_count_local(unsigned* p) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) l2_atomic_inc(p);
+}
+__device__ __forceinline__ unsigned xcc_id() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xf; }
+
+// Role of a workgroup under the XCD-local hand-off: row group r runs on XCD (2 r + par) & 7 (sweeps of layers with different
+// parity use different XCDs, so two to four concurrent sweeps spread evenly); workgroups are dealt to the XCDs round-robin,
+// the first G that arrive on a wanted XCD take its tiles (ticket order), the others leave.  Returns false for those.
+__device__ __forceinline__ bool local_role(unsigned* tickets, int ngroups, unsigned G, int par, int& rg, int& tile) {
+  __shared__ int role[2];
+  if (threadIdx.x == 0) {
+    const unsigned x = xcc_id();
+    int r = -1;
+    for (int i = 0; i < ngroups; ++i) if ((unsigned)((2 * i + par) & 7) == x) r = i;
+    int tk = -1;
+    if (r >= 0) {
+      tk = (int)__hip_atomic_fetch_add(tickets + x, 1u, RLX_AGENT);
+      if (tk >= (int)G) r = -1;
+    }
+    role[0] = r; role[1] = tk;
+  }
+  __syncthreads();
+  rg = role[0]; tile = role[1];
+  return rg >= 0;
+}
+
 // All waves have issued their sc1 payload stores: drain, barrier, one lane publishes.
 __device__ __forceinline__ void publish_count(unsigned* p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
