@@ -569,3 +569,37 @@ def test_schedule_independent(monkeypatch):
             got, l2 = grads(workers, only, mask)
             assert torch.equal(got, ref), f"workers={workers} workers_only={only} mask={mask}: gradients differ"
             assert torch.equal(l2, loss)
+
+
+def test_xcd_local_handoff_is_bit_identical(monkeypatch):
+    """The XCD-local hand-off (row groups pinned to one XCD, counters / tiles through that XCD's L2) changes where the data
+    travels, not the arithmetic: gradients and loss equal the device-scope hand-off's bit for bit, for every combination
+    of directions, at a shape with four row groups and one with a ragged last group."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    for (F, H, D, C, L, B, T, S) in ((64, 512, 4, 41, 3, 64, 96, 10), (32, 96, 3, 41, 2, 37, 50, 6)):
+        g = torch.Generator().manual_seed(B)
+        x = torch.randn(B, T, F, generator=g).to(dev)
+        day = torch.randint(0, D, (B,), generator=g)
+        tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(2, S + 1, (B,), generator=g)
+        nt = torch.randint(T - 10, T + 1, (B,), generator=g)
+        for b in range(B):
+            tgt[b, tl[b]:] = 0
+
+        def grads(dirs):
+            monkeypatch.setitem(ops.LOCAL_F32, "dirs", dirs)
+            torch.manual_seed(3)
+            m = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
+            ts = TrainStep(m, step_args())
+            loss_b = ts.compute_grads(x, day, tgt, nt, tl)
+            torch.cuda.synchronize()
+            m._ws.check_sync()
+            return ts.grad_arena.clone(), loss_b.clone()
+
+        ref, loss = grads("")
+        assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
+        for dirs in ("f", "b", "fb"):
+            got, l2 = grads(dirs)
+            assert torch.equal(got, ref) and torch.equal(l2, loss), f"B2T_GRU_LOCAL={dirs!r} at H={H}, B={B}"
