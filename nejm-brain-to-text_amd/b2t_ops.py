@@ -287,7 +287,7 @@ def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
             return mode | GRU_WIDE | local
         return mode | local
     wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= int(os.environ.get("B2T_AMP_WIDE_MAXH", "768"))) else 0
-    return mode | GRU_BF16 | wide
+    return mode | GRU_BF16 | wide   # (the XCD-local hand-off is for the exact-fp32 sweeps: measured slower with bf16 operands)
 
 
 def gru_sync_check(sync_ws, T: int, B: int):

@@ -443,37 +443,35 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_fwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
-  // XCD-local hand-off (local = layer parity, -1 = off): fp32 sweeps with 32-unit workgroups whose row groups fit half an XCD
-  const bool loc = local >= 0 && wide && !bf16 && H <= 512 && G <= 16 && gy <= 4 && gru_xcd_dispatch_ok();
+  // XCD-local hand-off (local = layer parity, -1 = off): a row group's G workgroups must fit one XCD next to those of a second
+  // sweep of the same parity (32 CUs; two workgroups per CU with 16-unit workgroups, one with 32-unit ones: G <= 32 / 16)
+  // (exact fp32 only: with bf16 operands it was measured slower, C2 11.6 vs 11.4 ms per step)
+  const bool loc = local >= 0 && !bf16 && H <= 512 && G <= (wide ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
+#define B2T_FWD_GO(NCH, BF, NTT)                                                                                       \
+  do {                                                                                                                 \
+    bool launched = false;                                                                                             \
+    if constexpr (!(BF)) {                                                                                             \
+      if (loc) {                                                                                                       \
+        hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, BF, NTT, true>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, \
+                           H, sync, par);                                                                              \
+        launched = true;                                                                                               \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if (!launched) {                                                                                                   \
+      want_exclusive(gru_persist_fwd_kernel<NCH, BF, NTT, false>);                                                     \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, BF, NTT, false>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, \
+                         T, B, H, sync, par);                                                                          \
+    }                                                                                                                  \
+  } while (0)
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
-    if (bf16 && wide) {                                                                                                \
-      want_exclusive(gru_persist_fwd_kernel<NCH, true, 2>);                                                            \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, par);                                                                         \
-    } else if (wide) {                                                                                                 \
-      if constexpr (NCH <= 8) {                                                                                        \
-        if (loc) {                                                                                                     \
-          hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false, 2, true>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                             B, H, sync, par);                                                                     \
-        } else {                                                                                                       \
-          want_exclusive(gru_persist_fwd_kernel<NCH, false, 2>);                                                       \
-          hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false, 2>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                             B, H, sync, par);                                                                     \
-        }                                                                                                              \
-      }                                                                                                                \
-    } else if (bf16) {                                                                                                 \
-      want_exclusive(gru_persist_fwd_kernel<NCH, true>);                                                               \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, true>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, par);                                                                         \
-    } else {                                                                                                           \
-      want_exclusive(gru_persist_fwd_kernel<NCH, false>);                                                              \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, false>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, T, \
-                         B, H, sync, par);                                                                         \
-    }                                                                                                                  \
+    if (bf16 && wide) B2T_FWD_GO(NCH, true, 2);                                                                        \
+    else if (wide) { if constexpr (NCH <= 8) B2T_FWD_GO(NCH, false, 2); }                                              \
+    else if (bf16) B2T_FWD_GO(NCH, true, 1);                                                                           \
+    else B2T_FWD_GO(NCH, false, 1);                                                                                    \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
@@ -481,6 +479,7 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   else if (H <= 768) B2T_LAUNCH_FWD(12);
   else if (H <= 1024) B2T_LAUNCH_FWD(16);
   else { set_error("gru_layer_fwd: H=%d > 1024 unsupported in persistent mode", H); return 2; }
+#undef B2T_FWD_GO
 #undef B2T_LAUNCH_FWD
   return check_hip(hipGetLastError(), "gru_layer_fwd (persistent)");
 }
@@ -492,37 +491,32 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
-  // XCD-local hand-off: fp32 sweeps with 16-unit workgroups whose row group fits one XCD at two workgroups per CU
-  const bool loc = local >= 0 && !wide && !bf16 && H <= 512 && G <= 32 && gy <= 4 && gru_xcd_dispatch_ok();
+  const bool loc = local >= 0 && !bf16 && H <= 512 && G <= (wide ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();   // see gru_persistent_fwd
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-#define B2T_LAUNCH_BWD(NCB)                                                                                           \
-  do {                                                                                                                \
-    if (bf16 && wide) {                                                                                               \
-      want_exclusive(gru_persist_bwd_kernel<NCB, true, 2>);                                                           \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync, par);                                                \
-    } else if (wide) {                                                                                                \
-      if constexpr (NCB <= 24) {                                                                                      \
-        want_exclusive(gru_persist_bwd_kernel<NCB, false, 2>);                                                        \
-        hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false, 2>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                           w_hh_t, dG, dh_init, T, B, H, sync, par);                                                  \
-      }                                                                                                               \
-    } else if (bf16) {                                                                                                \
-      want_exclusive(gru_persist_bwd_kernel<NCB, true>);                                                              \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, true>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync, par);                                                \
-    } else if (loc) {                                                                                                 \
-      if constexpr (NCB <= 24) {                                                                                      \
-        hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false, 1, true>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, \
-                           w_hh_t, dG, dh_init, T, B, H, sync, par);                                                  \
-      }                                                                                                               \
-    } else {                                                                                                          \
-      want_exclusive(gru_persist_bwd_kernel<NCB, false>);                                                             \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, false>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
-                         w_hh_t, dG, dh_init, T, B, H, sync, par);                                                \
-    }                                                                                                                 \
+#define B2T_BWD_GO(NCB, BF, NTT)                                                                                       \
+  do {                                                                                                                 \
+    bool launched = false;                                                                                             \
+    if constexpr (!(BF)) {                                                                                             \
+      if (loc) {                                                                                                       \
+        hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, BF, NTT, true>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG, \
+                           dh_init, T, B, H, sync, par);                                                               \
+        launched = true;                                                                                               \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if (!launched) {                                                                                                   \
+      want_exclusive(gru_persist_bwd_kernel<NCB, BF, NTT, false>);                                                     \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, BF, NTT, false>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
+                         w_hh_t, dG, dh_init, T, B, H, sync, par);                                                     \
+    }                                                                                                                  \
+  } while (0)
+#define B2T_LAUNCH_BWD(NCB)                                                                                            \
+  do {                                                                                                                 \
+    if (bf16 && wide) B2T_BWD_GO(NCB, true, 2);                                                                        \
+    else if (wide) { if constexpr (NCB <= 24) B2T_BWD_GO(NCB, false, 2); }                                             \
+    else if (bf16) B2T_BWD_GO(NCB, true, 1);                                                                           \
+    else B2T_BWD_GO(NCB, false, 1);                                                                                    \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);
   else if (H <= 256) B2T_LAUNCH_BWD(12);
@@ -530,6 +524,7 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   else if (H <= 768) B2T_LAUNCH_BWD(36);
   else if (H <= 1024) B2T_LAUNCH_BWD(48);
   else { set_error("gru_layer_bwd: H=%d > 1024 unsupported in persistent mode", H); return 2; }
+#undef B2T_BWD_GO
 #undef B2T_LAUNCH_BWD
   return check_hip(hipGetLastError(), "gru_layer_bwd (persistent)");
 }
