@@ -267,8 +267,9 @@ GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup
 GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
 # which exact-fp32 sweeps hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
 # traffic of a backward sweep launch 660 -> 222 MB (1.35x its algorithmic bytes), forward 179 -> 109 MB, a backward launch
-# 940 -> 850 us, the step +0.8 % (20.12 -> 20.28 ms sustained); ignored where the library's dispatch probe fails
-LOCAL_F32 = {"dirs": os.environ.get("B2T_GRU_LOCAL", "fb")}
+# 940 -> 850 us -- but the STEP is 0.8 % (some boxes of the pool: 4.5 %) slower, the GEMMs lose more than the sweeps gain:
+# opt-in.  Ignored where the library's dispatch probe fails.
+LOCAL_F32 = {"dirs": os.environ.get("B2T_GRU_LOCAL", "")}
 # which sweeps run with 32-unit workgroups under AMP: "" none, "f" forward, "b" backward, "fb" both (B2T_AMP_WIDE;
 # measured at C2: 18.4 / 17.5 / 17.1 / 16.1 ms per step)
 AMP["wide"] = os.environ.get("B2T_AMP_WIDE", "fb")
