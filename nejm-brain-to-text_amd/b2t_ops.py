@@ -266,10 +266,10 @@ GRU_BF16 = 0x100   # B2T_GRU_BF16 (include/b2t.h): bf16 operands of the recurren
 GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup
 GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
 # which exact-fp32 sweeps hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
-# traffic of a backward sweep launch 660 -> 222 MB (1.35x its algorithmic bytes), forward 179 -> 109 MB, a backward launch
-# 940 -> 850 us -- but the STEP is 0.8 % (some boxes of the pool: 4.5 %) slower, the GEMMs lose more than the sweeps gain:
-# opt-in.  Ignored where the library's dispatch probe fails.
-LOCAL_F32 = {"dirs": os.environ.get("B2T_GRU_LOCAL", "")}
+# traffic of a backward sweep launch 660 -> 227 MB (1.38x its algorithmic bytes), forward 179 -> 112 MB, a backward launch
+# 935 -> 810-830 us, the step -0.1 ms on two boxes (with WRITE-THROUGH payload stores; ordinary stores cost the GEMMs 0.3-1 ms).
+# Ignored where the library's dispatch probe fails.
+LOCAL_F32 = {"dirs": os.environ.get("B2T_GRU_LOCAL", "fb")}
 # which sweeps run with 32-unit workgroups under AMP: "" none, "f" forward, "b" backward, "fb" both (B2T_AMP_WIDE;
 # measured at C2: 18.4 / 17.5 / 17.1 / 16.1 ms per step)
 AMP["wide"] = os.environ.get("B2T_AMP_WIDE", "fb")

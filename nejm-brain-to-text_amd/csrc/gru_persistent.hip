@@ -20,6 +20,9 @@
 #include "gru_cell.h"
 #include "gru_sync.h"
 
+#ifndef B2T_LOC_ST_AUX
+#define B2T_LOC_ST_AUX 16   // payload stores under the XCD-local hand-off: 16 write-through (L2 keeps a clean copy for the peers; ordinary stores, 0, left 1.3 GB of dirty dG per step in the L2s and cost the GEMMs 0.3-1 ms)
+#endif
 #ifndef B2T_LOAD_AUX
 #define B2T_LOAD_AUX 16   // cache policy of the operand loads: 16 = sc1 (never served from this XCD's L2), 0 = ordinary
 #endif
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
   constexpr int NSLOT_F = NCH < 8 ? NCH : 8;   // staging slots per wave, recycled every NSLOT_F instructions (as in the backward sweep)
   __shared__ __attribute__((aligned(16))) float stage[4][NSLOT_F * SLOT_F];   // per-wave operand staging (gru_sync.h)
   float* hs = red + 4 * 3 * NT * 4 * 64;   // staged h tile [16 rows][TPN]
-  constexpr int AUX = LOC ? 0 : 16;   // sc1 payload accesses (device scope); ordinary ones when the row group shares an L2
+  constexpr int AUX = LOC ? B2T_LOC_ST_AUX : 16;   // sc1 payload stores (device scope); under the XCD-local hand-off see B2T_LOC_ST_AUX
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef B2T_NO_SETPRIO
   __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   constexpr int NSLOT = NCB < 8 ? NCB : 8;   // staging slots per wave, recycled every NSLOT instructions
   __shared__ __attribute__((aligned(16))) float stage[4][NSLOT * SLOT_F];
   float* gs = red + 4 * NT * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TPN]
-  constexpr int AUX = LOC ? 0 : 16;   // sc1 payload accesses (device scope); ordinary ones when the row group shares an L2
+  constexpr int AUX = LOC ? B2T_LOC_ST_AUX : 16;   // sc1 payload stores (device scope); under the XCD-local hand-off see B2T_LOC_ST_AUX
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifndef B2T_NO_SETPRIO
   __builtin_amdgcn_s_setprio(3);   // the sweep is the critical path: its waves issue ahead of co-resident GEMM waves
