@@ -145,7 +145,7 @@ int b2t_batch_gather_b32(const void* flat, const int64_t* row_off, const int32_t
  * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode), zeroed ONCE by the owner (self-cleaning
  * afterwards); word 0 is a sticky error word (1 = a bounded hand-off spin gave up: results invalid). */
 #define B2T_GRU_BF16 0x100
-#define B2T_GRU_LOCAL 0x400   /* exact-fp32 persistent sweeps: XCD-local hand-off (row group r on XCD (2r + parity) & 7, counters and payloads through that XCD's L2) */
+#define B2T_GRU_LOCAL 0x400   /* persistent sweeps, H <= 512, B <= 64: XCD-local hand-off (row group r on XCD (2r + parity) & 7, counters as L2 atomics, tiles written through and read back from that XCD's L2); ignored where the dispatch probe fails */
 #define B2T_GRU_PARITY 0x800  /* with B2T_GRU_LOCAL: the layer's parity */
 #define B2T_GRU_WIDE 0x200   /* with B2T_GRU_BF16: 32 hidden units per workgroup (half the workgroups per sweep), H % 32 == 0, H <= 512 */
 size_t b2t_gru_sync_bytes(int T);

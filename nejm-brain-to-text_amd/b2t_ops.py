@@ -265,7 +265,7 @@ def gru_mode_for(B: int, H: int) -> int:
 GRU_BF16 = 0x100   # B2T_GRU_BF16 (include/b2t.h): bf16 operands of the recurrent product, persistent mode 1
 GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup
 GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
-# which exact-fp32 sweeps hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
+# which sweeps (exact fp32 or bf16 operands, H <= 512) hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
 # traffic of a backward sweep launch 660 -> 227 MB (1.38x its algorithmic bytes), forward 179 -> 112 MB, a backward launch
 # 935 -> 810-830 us, the step -0.1 ms on two boxes (with WRITE-THROUGH payload stores; ordinary stores cost the GEMMs 0.3-1 ms).
 # Ignored where the library's dispatch probe fails.
@@ -288,7 +288,8 @@ def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
             return mode | GRU_WIDE | local
         return mode | local
     wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= int(os.environ.get("B2T_AMP_WIDE_MAXH", "768"))) else 0
-    return mode | GRU_BF16 | wide   # (the XCD-local hand-off is for the exact-fp32 sweeps: measured slower with bf16 operands)
+    local = GRU_LOCAL if (direction in LOCAL_F32["dirs"] and H <= 512) else 0   # C2 with bf16 operands: 11.3 -> 11.15 ms per step
+    return mode | GRU_BF16 | wide | local
 
 
 def gru_sync_check(sync_ws, T: int, B: int):

@@ -448,15 +448,14 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
   // XCD-local hand-off (local = layer parity, -1 = off): a row group's G workgroups must fit one XCD next to those of a second
   // sweep of the same parity (32 CUs; two workgroups per CU with 16-unit workgroups, one with 32-unit ones: G <= 32 / 16)
-  // (exact fp32 only: with bf16 operands it was measured slower, C2 11.6 vs 11.4 ms per step)
-  const bool loc = local >= 0 && !bf16 && H <= 512 && G <= (wide ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();
+  const bool loc = local >= 0 && H <= 512 && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
 #define B2T_FWD_GO(NCH, BF, NTT)                                                                                       \
   do {                                                                                                                 \
     bool launched = false;                                                                                             \
-    if constexpr (!(BF)) {                                                                                             \
+    {                                                                                                                  \
       if (loc) {                                                                                                       \
         hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, BF, NTT, true>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, \
                            H, sync, par);                                                                              \
@@ -494,14 +493,14 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
-  const bool loc = local >= 0 && !bf16 && H <= 512 && G <= (wide ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();   // see gru_persistent_fwd
+  const bool loc = local >= 0 && H <= 512 && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();   // see gru_persistent_fwd
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
 #define B2T_BWD_GO(NCB, BF, NTT)                                                                                       \
   do {                                                                                                                 \
     bool launched = false;                                                                                             \
-    if constexpr (!(BF)) {                                                                                             \
+    {                                                                                                                  \
       if (loc) {                                                                                                       \
         hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, BF, NTT, true>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG, \
                            dh_init, T, B, H, sync, par);                                                               \
