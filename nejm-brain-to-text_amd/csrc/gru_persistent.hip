@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         float* rs = reserve + ((long long)t * B + row) * 4 * H + unit[n];
-        rs[0] = sv_r[n]; rs[H] = sv_z[n]; rs[2 * H] = sv_n[n]; rs[3 * H] = sv_ghn[n];
+        // streaming stores: nobody reads the reserve before the backward pass, it must not push the GEMMs' operands out of the L2s
+        __builtin_nontemporal_store(sv_r[n], rs); __builtin_nontemporal_store(sv_z[n], rs + H);
+        __builtin_nontemporal_store(sv_n[n], rs + 2 * H); __builtin_nontemporal_store(sv_ghn[n], rs + 3 * H);
       }
     }
     TSTAMP(5)   // tile store + drain + publish
