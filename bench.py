@@ -147,6 +147,53 @@ def cpu_baseline(timed: int = 3, budget_s: float = 120.0):
                     sample=f"no result within {budget_s + 90:.0f} s on this host")
 
 
+class BoxSampler:
+    """Clocks and board power of the GPU during the timed region (sysfs, every 50 ms, N=1 only): box-to-box spread of the
+    headline (+-3 % on this pool) can then be read against the clocks the box actually ran at.  Never raises."""
+
+    def __init__(self):
+        import glob
+        self.sclk = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))[:1]
+        self.mclk = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_mclk"))[:1]
+        self.pwr = (sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+                    or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")))[:1]
+        self.rows, self.stop_flag, self.thread = [], False, None
+
+    @staticmethod
+    def _star(path):
+        try:
+            for line in open(path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float("".join(ch for ch in line.split(":")[1] if ch.isdigit() or ch == "."))
+        except Exception:
+            pass
+        return None
+
+    def _loop(self):
+        while not self.stop_flag:
+            pw = None
+            try:
+                pw = float(open(self.pwr[0]).read()) * 1e-6 if self.pwr else None
+            except Exception:
+                pass
+            self.rows.append((self._star(self.sclk[0]) if self.sclk else None, self._star(self.mclk[0]) if self.mclk else None, pw))
+            time.sleep(0.05)
+
+    def start(self):
+        import threading
+        self.thread = threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        self.stop_flag = True
+        if self.thread:
+            self.thread.join(timeout=1.0)
+        def med(i):
+            v = sorted(r[i] for r in self.rows if r[i] is not None)
+            return round(v[len(v) // 2], 1) if v else None
+        return dict(sclk_mhz_p50=med(0), mclk_mhz_p50=med(1), board_w_p50=med(2), samples=len(self.rows))
+
+
 def dry_run(a, world, rank):
     """The launch contract without the GPU: rendezvous from the environment, --gpus == WORLD_SIZE, barrier-bracketed
     timed region, MAX over ranks, one JSON line from rank 0.  The "step" is a sleep; nothing is measured."""
@@ -240,7 +287,10 @@ def main():
         model._ws.check_sync()
         return loss, dt, t_enq
 
+    sampler = BoxSampler() if world == 1 else None
     try:
+        if sampler:
+            sampler.start()
         loss, dt, t_enq = timed_run()
     except RuntimeError as e:
         # The pipelined plan keeps several persistent sweeps in flight; if one of them ever reports a hand-off
@@ -252,6 +302,7 @@ def main():
                 buf.zero_()
         ts.stat.zero_()
         loss, dt, t_enq = timed_run()
+    box = sampler.stop() if sampler else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -312,7 +363,7 @@ def main():
                                gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
                                time_chunks_bwd=ops.PIPELINE["chunks_bwd"] or ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),
-                   host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3))
+                   host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3), box=box)
         sys.stderr.write("[bench] headline done: " + json.dumps(out)[:200] + "\n"); sys.stderr.flush()
         if world == 1 and not a.no_secondary:
             # BASELINE configs[2..4] measured by the same process, reported beside (never instead of) the headline

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
       gir[n] = giz[n] = gin[n] = 0.f;
       if (live) {
         const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit[n];
-        gir[n] = g3[0]; giz[n] = g3[H]; gin[n] = g3[2 * H];
+        // (single-use streams: non-temporal loads keep them from displacing the GEMMs' operand tiles in the L2s)
+        gir[n] = __builtin_nontemporal_load(g3); giz[n] = __builtin_nontemporal_load(g3 + H); gin[n] = __builtin_nontemporal_load(g3 + 2 * H);
       }
     }
     const float* hsrc = h_init;
@@ -277,10 +278,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       r[n] = z[n] = nv[n] = ghn[n] = hprev[n] = dy[n] = carry[n] = 0.f;
       if (live && t >= 0) {
         const float* rs = reserve + ((long long)t * B + row) * 4 * H + unit[n];
-        r[n] = rs[0]; z[n] = rs[H]; nv[n] = rs[2 * H]; ghn[n] = rs[3 * H];
+        r[n] = __builtin_nontemporal_load(rs); z[n] = __builtin_nontemporal_load(rs + H); nv[n] = __builtin_nontemporal_load(rs + 2 * H); ghn[n] = __builtin_nontemporal_load(rs + 3 * H);
         hprev[n] = t > 0 ? out[((long long)(t - 1) * B + row) * H + unit[n]] : h_init[(long long)row * H + unit[n]];
         const float* dyp = dY + ((long long)t * B + row) * H + unit[n];
-        dy[n] = dyp[0];
+        dy[n] = __builtin_nontemporal_load(dyp);
       }
     }
     TSTAMP(0)   // operand prefetch issue
