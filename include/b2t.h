@@ -81,6 +81,13 @@ typedef struct b2t_gemm_desc {
    * multiple of 16 (k) / 128 (m, with M % 128 == 0). */
   int a_brk; int a_gap;
   const float* ep_aux;   /* epilogue 2 only: same layout as C (z*c_sz + row offset + column) */
+  /* b2t_gemm_f32 with an m-contiguous A (a_kcontig = 0) only, NULL otherwise: a_sum[(z*max(1,splitk) + ks)*a_sum_ks + m] =
+   * sum over the slice's k of A[k][m] (m = A's logical index, after a_brk), written by the workgroups of the first
+   * column tile from the A tiles they stage anyway.  The bias gradients of a GRU layer (column sums of dG, K = T*B rows)
+   * come out of the weight-gradient GEMM that reads dG as its A operand instead of a separate pass over dG.
+   * b2t_gemm_bf16p_f32 takes it too: its pack pass over A writes one slice per 64 k, a_sum[(k / 64)*a_sum_ks + m]
+   * (ceil(K / 64) slices whatever splitk is), summed from the fp32 values before they are rounded. */
+  float* a_sum; long long a_sum_ks;
 } b2t_gemm_desc;
 int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream);
 /* The same GEMM with the operands rounded to bf16 (nearest-even) on their way to the matrix cores, fp32 accumulation and

@@ -135,7 +135,8 @@ def set_amp(on: bool):
 
 def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,
          b_sz=0, c_s0=0, c_s1=0, c_div=0, c_sz=0, bias=None, bias_sz=0, b_zmap=None, epilogue=0, accumulate=0,
-         a_off=0, b_off=0, c_off=0, splitk=1, ws=None, slab="splitk_slab", _splitk=1, _c_ks=0, a_brk=0, a_gap=0):
+         a_off=0, b_off=0, c_off=0, splitk=1, ws=None, slab="splitk_slab", _splitk=1, _c_ks=0, a_brk=0, a_gap=0,
+         a_sum=None, a_sum_ks=0):
     """C = A.B^T through b2t_gemm_f32.  splitk>1 (needs `ws`): partial products go to a workspace slab and
     are summed deterministically into C by b2t_colsum_f32 (used for the weight gradients, K = T*B)."""
     if splitk > 1:
@@ -144,7 +145,7 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
         sl = ws.get(slab, (splitk, M * N_), Cm.device)
         gemm(A, B, sl, M=M, N_=N_, K=K, a_kc=a_kc, b_kc=b_kc, a_s0=a_s0, a_s1=a_s1, a_div=a_div, b_s0=b_s0,
              b_s1=b_s1, b_div=b_div, c_s0=N_, bias=bias, a_off=a_off, b_off=b_off, _splitk=splitk, _c_ks=M * N_,
-             a_brk=a_brk, a_gap=a_gap)
+             a_brk=a_brk, a_gap=a_gap, a_sum=a_sum, a_sum_ks=a_sum_ks)
         N.check(N.load().b2t_slab_reduce_f32(_p(sl), splitk, M * N_, C.c_void_p(Cm.data_ptr() + 4 * c_off), accumulate,
                                              _stream()), "b2t_slab_reduce_f32")
         return
@@ -163,6 +164,7 @@ def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_
     d.epilogue, d.accumulate = epilogue, accumulate
     d.splitk, d.c_ks = _splitk, _c_ks
     d.a_brk, d.a_gap = a_brk, a_gap
+    d.a_sum, d.a_sum_ks = (a_sum.data_ptr() if a_sum is not None else None), a_sum_ks   # fp32 tile kernel, a_kc=0: per-slice sums over k of A
     if AMP["on"]:
         with _Prof(f"gemm_bf16_kernel<{int(bool(a_kc))},{int(bool(b_kc))}>", 2.0 * M * N_ * K * Z):
             N.check(N.load().b2t_gemm_bf16_f32(C.byref(d), _stream()), "b2t_gemm_bf16_f32")

@@ -74,7 +74,7 @@ int make_chunks(int Tp, int chunks, int (*out)[2]) {
 struct Layout {
   float *U, *Ud, *out[MAXL], *outd[MAXL], *gi[MAXL], *res[MAXL], *slab_gi[MAXL];
   float *dY[MAXL], *dG[MAXL], *dh_init, *carry[MAXL], *scratch[MAXL], *whh_t[MAXL], *dU, *dV, *day_slab, *day_bslab;
-  float *slab[MAXL], *slab_head, *s4[MAXL], *cs_layer[MAXL], *cs_head, *cs_day, *cs_h0, *slab_dx;
+  float *slab[MAXL], *slab_head, *s4[MAXL], *cs_layer[MAXL], *asum[MAXL], *cs_head, *cs_day, *cs_h0, *slab_dx;
   char* pack[NPACK];       // amp mode: per-queue scratch of the two-pass bf16 GEMM (packed operands)
   size_t pack_bytes;
   size_t bytes;
@@ -132,6 +132,7 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     w.slab[l] = take(std::max(a, std::max(b, b2)));
     w.s4[l] = take(4 * H);
     w.cs_layer[l] = take(colsum_ws_floats(K, 4 * H) + 4);
+    w.asum[l] = take((std::max(std::min<size_t>(1024, K / 256), K / 64 + 1) + 8) * 3 * H);   // per-slice column sums of dG out of the weight-gradient GEMMs + their reduction scratch
   }
   // two K slices for the input-gradient GEMMs of the serial plan (one at a time: one slab), see b2t_model_backward
   w.slab_dx = (!p->bf16_gemm && L > 1) ? take(2 * K * H) : nullptr;
@@ -220,14 +221,20 @@ struct Ctx {
   }
   // amp mode: the two-pass kernel (pack to dense bf16, then 128x128x64 tiles on packed operands: 2.5-3x the one-pass kernel)
   // for plain GEMMs big enough to pay for the pack passes, on a queue that has pack scratch; the one-pass kernel otherwise
-  int gemm_amp(const b2t_gemm_desc& d, hipStream_t s) {
-    void* st = reinterpret_cast<void*>(s);
+  int pack_queue(hipStream_t s) const {
     int q = -1;
     for (int i = 0; i < nq && i < NPACK; ++i) if (qs[i] == s) q = i;
     if (nq == 0 && s == main) q = 0;
-    const bool packed = lay && q >= 0 && lay->pack[q] && d.Z == 1 && !d.b_zmap && 2.0 * d.M * d.N * (double)d.K >= 2e9 &&
-                        b2t_gemm_bf16p_ws_bytes(d.M, d.N, d.K) <= lay->pack_bytes && (d.a_brk % 8) == 0;
-    return packed ? b2t_gemm_bf16p_f32(&d, lay->pack[q], lay->pack_bytes, st) : b2t_gemm_bf16_f32(&d, st);
+    return q;
+  }
+  bool would_pack(const b2t_gemm_desc& d, hipStream_t s) const {
+    const int q = pack_queue(s);
+    return lay && q >= 0 && lay->pack[q] && (d.Z == 1 || d.Z == 0) && !d.b_zmap && 2.0 * d.M * d.N * (double)d.K >= 2e9 &&
+           b2t_gemm_bf16p_ws_bytes(d.M, d.N, d.K) <= lay->pack_bytes && (d.a_brk % 8) == 0;
+  }
+  int gemm_amp(const b2t_gemm_desc& d, hipStream_t s) {
+    void* st = reinterpret_cast<void*>(s);
+    return would_pack(d, s) ? b2t_gemm_bf16p_f32(&d, lay->pack[pack_queue(s)], lay->pack_bytes, st) : b2t_gemm_bf16_f32(&d, st);
   }
   void call(int r) { if (!rc) rc = r; }
 };
@@ -666,10 +673,26 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
   const long long K = (long long)(t1 - t0) * B;
   const long long a0 = (long long)t0 * B * 4 * H;
   void* sp = reinterpret_cast<void*>(s);
+  // fp32: the bias gradients (column sums of dGh -> b_hh, of dGi -> b_ih) are by-products of the two GEMMs that read dG
+  // as their A operand (per-slice sums, reduced in slice order); bf16 GEMMs and odd H take a column-sum pass over dG
+  static const bool no_fused = getenv("B2T_NO_FUSED_BIAS") != nullptr;   // A/B knob
+  bool fused_bias = !no_fused && (2 * H) % 128 == 0 && (3 * H) % 128 == 0;
+  if (fused_bias && c.bf16_gemm) {   // bf16 GEMMs: the pack pass of the two-pass kernel sums (one slice per 64 k); the one-pass kernel does not
+    b2t_gemm_desc a = gd(nullptr, nullptr, nullptr, 3 * H, H, (int)K), b = gd(nullptr, nullptr, nullptr, 3 * H, l == 0 ? in0(prm) : H, (int)K);
+    b.a_brk = 2 * H;
+    fused_bias = c.would_pack(a, s) && c.would_pack(b, s);
+  }
+  auto bias_out = [&](int sk, float* dst) {
+    const int ns = c.bf16_gemm ? (int)((K + 63) / 64) : std::max(1, sk);
+    c.call(b2t_colsum_f32(w.asum[l], ns, 3 * H, 3 * H, dst, accumulate, w.asum[l] + (size_t)ns * 3 * H, 1, 0, 0, sp));
+  };
   {
     b2t_gemm_desc d = gd(w.dG[l] + a0, w.out[l] + (long long)t0 * B * H, grd->w_hh[l], 3 * H, H, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    c.gemm(s, d, splitk_for(3 * H, H, K), w.slab[l], accumulate);
+    const int sk = splitk_for(3 * H, H, K);
+    if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
+    c.gemm(s, d, sk, w.slab[l], accumulate);
+    if (fused_bias) bias_out(sk, grd->b_hh[l]);
   }
   int In; const float* inp; long long b_s0, b_s1 = 0; int b_div = 0;
   if (l == 0) {
@@ -684,7 +707,10 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     b2t_gemm_desc d = gd(w.dG[l] + a0 + a_off, inp, grd->w_ih[l] + c_off, M, In, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = b_s0; d.b_s1 = b_s1; d.b_div = b_div; d.c_s0 = In;
     d.a_brk = brk; d.a_gap = gap;
-    c.gemm(s, d, splitk_for(M, In, K), w.slab[l], accumulate);
+    const int sk = splitk_for(M, In, K);
+    if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
+    c.gemm(s, d, sk, w.slab[l], accumulate);
+    if (fused_bias) bias_out(sk, grd->b_ih[l]);
   };
   if ((2 * H) % 128 == 0 && (3 * H) % 128 == 0) {   // dGi^T as ONE operand with a gap along m
     wih(3 * H, 0, 0, 2 * H, H);
@@ -692,6 +718,7 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     wih(2 * H, 0, 0, 0, 0);
     wih(H, 3 * H, (long long)2 * H * In, 0, 0);
   }
+  if (fused_bias) return;
   c.call(b2t_colsum_f32(w.dG[l] + a0, K, 4 * H, 4 * H, w.s4[l], accumulate, w.cs_layer[l], 1, 0, 0, sp));   // (s_r, s_z, s_nr, s_n)
   if (!final) return;
   auto cp = [&](float* dst, const float* src, size_t n) {

@@ -174,7 +174,19 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
       load_tail<BKC>(B, roffB, g.N, n0, k0, K, g.b_s0, g.b_s1, g.b_div, rb, tid);
     }
   };
+  // optional by-product (m-contiguous A, first column tile only): sums over k of the A tile columns this thread stages
+  const bool do_sum = !AKC && g.a_sum != nullptr && n0 == 0;
+  float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add_a = [&]() {
+    if constexpr (!AKC) {
+      if (do_sum) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) { asum.x += ra[r].x; asum.y += ra[r].y; asum.z += ra[r].z; asum.w += ra[r].w; }
+      }
+    }
+  };
   fetch(0);
+  add_a();
   store_tile<AKC>(As, ra, tid);
   store_tile<BKC>(Bs, rb, tid);
   __syncthreads();
@@ -202,6 +214,7 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     if (more) {
+      add_a();
       store_tile<AKC>(As + (cur ^ 1) * BKT * PA, ra, tid);
       store_tile<BKC>(Bs + (cur ^ 1) * BKT * PB, rb, tid);
     }
@@ -209,6 +222,24 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
     cur ^= 1;
   }
 
+  if constexpr (!AKC) {
+    if (do_sum) {   // (uniform per workgroup; the k loop ended with a barrier, so the tile buffers are free)
+      float4* red = reinterpret_cast<float4*>(smem);
+      red[tid] = asum;                              // [k row group tid >> 5][m4 = tid & 31]
+      __syncthreads();
+      if (tid < 32) {
+        float4 t = red[tid];
+#pragma unroll
+        for (int gq = 1; gq < 8; ++gq) { const float4 u = red[gq * 32 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        float* o = g.a_sum + ((long long)z * g.splitk + ks) * g.a_sum_ks;
+        const int m = m0 + tid * 4;
+        if (m < g.M) o[m] = t.x;
+        if (m + 1 < g.M) o[m + 1] = t.y;
+        if (m + 2 < g.M) o[m + 2] = t.z;
+        if (m + 3 < g.M) o[m + 3] = t.w;
+      }
+    }
+  }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -324,6 +355,7 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
   B2T_REQUIRE((d->a_s0 % 4) == 0 && (d->a_s1 % 4) == 0 && (d->a_sz % 4) == 0 && (d->b_s0 % 4) == 0 &&
                   (d->b_s1 % 4) == 0 && (d->b_sz % 4) == 0,
               "b2t_gemm_f32: A/B strides must be multiples of 4 elements");
+  B2T_REQUIRE(d->a_sum == nullptr || !d->a_kcontig, "b2t_gemm_f32: a_sum goes with an m-contiguous A (a_kcontig = 0)");
   GemmArgs g;
   { int rc = fill_gemm_args(d, g, BKT, BM, "b2t_gemm_f32"); if (rc) return rc; }
   dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);

@@ -232,6 +232,7 @@ extern "C" int b2t_gemm_bf16_f32(const b2t_gemm_desc* d, void* stream) {
                   (d->b_s1 % 4) == 0 && (d->b_sz % 4) == 0,
               "b2t_gemm_bf16_f32: A/B strides must be multiples of 4 elements");
   GemmArgs g;
+  B2T_REQUIRE(d->a_sum == nullptr, "b2t_gemm_bf16_f32: a_sum is a by-product of the fp32 tile kernel only");
   { int rc = fill_gemm_args(d, g, HBK, HBM_, "b2t_gemm_bf16_f32"); if (rc) return rc; }
   dim3 grid(((d->N + HBN - 1) / HBN) * ((d->M + HBM_ - 1) / HBM_), 1, d->Z * g.splitk), block(256);
   hipStream_t s = as_stream(stream);

@@ -33,6 +33,7 @@ struct PackArgs {
   int rows, rows_pad, K, Kp;
   long long s0, s1; int div;     // row map of the source (rows if k-contiguous, k if row-contiguous)
   int brk, gap;                  // contiguous index i >= brk reads from i + gap (A operand only)
+  float* sum; long long sum_ks;  // row-contiguous source only (or null): sum[(k / 64) * sum_ks + r] = fp32 sum of the tile's 64 k
 };
 
 // k-contiguous source: element (r, k) at P + rowoff(r) + k (+ gap for k >= brk).  One thread = 8 consecutive k of one row.
@@ -76,6 +77,12 @@ __global__ __launch_bounds__(256) void pack_mc_kernel(PackArgs a) {
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
   __syncthreads();
+  if (a.sum && tid < 64 && r0 + tid < a.rows) {   // by-product: the tile's column sums (bias gradients of a GRU layer), from the fp32 values
+    float sacc = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) sacc += t[k][tid];
+    a.sum[(long long)blockIdx.y * a.sum_ks + r0 + tid] = sacc;
+  }
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int idx = tid + 256 * it;          // 512 stores: r = idx % 64, k8 = idx / 64
@@ -198,14 +205,16 @@ extern "C" int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_by
   B2T_REQUIRE(ws_bytes >= b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K), "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes,
               b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K));
   GemmArgs g;
+  B2T_REQUIRE(d->a_sum == nullptr || !d->a_kcontig, "b2t_gemm_bf16p_f32: a_sum goes with an m-contiguous A (a_kcontig = 0)");
   { int rc = fill_gemm_args(d, g, PK, PM, "b2t_gemm_bf16p_f32"); if (rc) return rc; }
   B2T_REQUIRE(d->a_brk == 0 || d->a_brk % 8 == 0, "b2t_gemm_bf16p_f32: a_brk must be a multiple of 8");
   const int Mp = pad_to(d->M, PM), Np = pad_to(d->N, PN), Kp = pad_to(d->K, PK);
   __bf16* Ap = reinterpret_cast<__bf16*>(ws);
   __bf16* Bp = Ap + (size_t)Mp * Kp;
   hipStream_t s = as_stream(stream);
-  auto pack = [&](const float* P, __bf16* out, int rows, int rows_pad, bool kc, long long s0, long long s1, int div, int brk, int gap) {
-    PackArgs a{P, out, rows, rows_pad, d->K, Kp, s0, s1, div, brk, gap};
+  auto pack = [&](const float* P, __bf16* out, int rows, int rows_pad, bool kc, long long s0, long long s1, int div, int brk, int gap,
+                  float* sum = nullptr, long long sum_ks = 0) {
+    PackArgs a{P, out, rows, rows_pad, d->K, Kp, s0, s1, div, brk, gap, sum, sum_ks};
     if (kc) {
       const long long items = (long long)rows_pad * (Kp / 8);
       hipLaunchKernelGGL(pack_kc_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
@@ -213,7 +222,7 @@ extern "C" int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_by
       hipLaunchKernelGGL(pack_mc_kernel, dim3(rows_pad / 64, Kp / 64), dim3(256), 0, s, a);
     }
   };
-  pack(d->A, Ap, d->M, Mp, d->a_kcontig != 0, d->a_s0, d->a_s1, d->a_div, d->a_brk, d->a_gap);
+  pack(d->A, Ap, d->M, Mp, d->a_kcontig != 0, d->a_s0, d->a_s1, d->a_div, d->a_brk, d->a_gap, d->a_sum, d->a_sum_ks);
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (pack A)");
   pack(d->B, Bp, d->N, Np, d->b_kcontig != 0, d->b_s0, d->b_s1, d->b_div, 0, 0);
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (pack B)");

@@ -590,6 +590,15 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
     slab = torch.full((sk, M, N), float("nan"), device=dev)
     part = run(slab, splitk=sk, c_ks=M * N)
     np.testing.assert_allclose(part.sum(0), ref, atol=tol)
+    if not akc:
+        # by-product of the pack pass over an m-contiguous A: per 64-k slice sums of the fp32 values (a layer's bias gradients)
+        nsl = (K + 63) // 64
+        sums = torch.full((nsl + 1, M + 2), 7.0, device=dev)
+        got = run(torch.empty((M, N), device=dev), splitk=sk, c_ks=M * N, C=slab.data_ptr(), a_sum=sums.data_ptr(), a_sum_ks=M + 2)
+        sg = sums.cpu().numpy()
+        assert np.all(sg[nsl:] == 7.0) and np.all(sg[:, M:] == 7.0)
+        for s_ in range(nsl):
+            np.testing.assert_allclose(sg[s_, :M], A[:, s_ * 64:(s_ + 1) * 64].astype(np.float64).sum(1), atol=1e-4)
     # row-mapped C (batch-first logits: row r = t * Bb + b -> C[b][t]) and a gap in A's contiguous index
     if M % 4 == 0:
         Bb = 4; Tt = M // Bb
@@ -615,6 +624,44 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
         finally:
             Ad = d_keep
         np.testing.assert_allclose(got, ref, atol=tol)
+
+
+@pytest.mark.parametrize("M,N,K,sk,brk", [(256, 128, 1000, 1, 0), (384, 200, 4100, 5, 0), (130, 64, 700, 2, 0), (1536, 512, 6000, 21, 1024),
+                                          (100, 300, 50, 1, 0), (768, 130, 40000, 30, 512)])
+def test_gemm_a_column_sums(M, N, K, sk, brk):
+    """b2t_gemm_f32, m-contiguous A (the weight-gradient form dW = dG^T X): `a_sum` receives, per K slice, the sums over k
+    of A[k][m] -- the bias gradients of a GRU layer (torch autograd of nn.GRU's b_ih / b_hh: column sums of the gate
+    gradients) as a by-product of the GEMM that reads dG anyway.  Checked against float64 sums, with split-K, with the
+    gap in A's m index (dGi = dG[:, 0:2H] ++ dG[:, 3H:4H]), ragged M and N, and nothing written outside [slices][M]."""
+    import b2t_ops as ops
+    dev = _dev()
+    rng = np.random.default_rng(M + N + K)
+    gap = 64 if brk else 0
+    At = (rng.standard_normal((K, (M + gap + 3) // 4 * 4)) + 0.25).astype(np.float32)      # [K][M (+gap), padded to 4]: m contiguous
+    Bt = np.zeros((K, (N + 3) // 4 * 4), np.float32); Bt[:, :N] = rng.standard_normal((K, N))
+    cols = np.r_[0:brk, brk + gap:M + gap] if brk else np.arange(M)
+    Al = At[:, cols].astype(np.float64)
+    ref = Al.T @ Bt[:, :N].astype(np.float64)
+    tA, tB = torch.from_numpy(At).to(dev), torch.from_numpy(Bt).to(dev)
+    ld = At.shape[1]
+    ns = max(1, sk)
+    sums = torch.full((ns + 1, M + 3), 7.0, device=dev)
+    tC = torch.empty((M, N), device=dev)
+    ws = ops.Workspace() if hasattr(ops, "Workspace") else None
+    kw = dict(M=M, N_=N, K=K, a_kc=0, b_kc=0, a_s0=ld, b_s0=Bt.shape[1], c_s0=N, a_brk=brk, a_gap=gap, a_sum=sums, a_sum_ks=M + 3)
+    if sk > 1:
+        ops.gemm(tA, tB, tC, splitk=sk, ws=ws, **kw)
+    else:
+        ops.gemm(tA, tB, tC, **kw)
+    got = sums.cpu().numpy()
+    tol = 3e-6 * np.sqrt(K) * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(tC.cpu().numpy(), ref, atol=tol)
+    np.testing.assert_allclose(got[:ns, :M].astype(np.float64).sum(0), Al.sum(0), atol=2e-6 * K ** 0.5 * (1 + np.abs(Al).sum(0).max() / K ** 0.5))
+    assert np.all(got[ns:] == 7.0) and np.all(got[:, M:] == 7.0)
+    # per-slice sums: slice s covers k in [s*kc, (s+1)*kc), kc = ceil(K / ns) rounded up to 16
+    kc = -(-(-(-K // ns)) // 16) * 16
+    for s_ in range(ns):
+        np.testing.assert_allclose(got[s_, :M], Al[s_ * kc:(s_ + 1) * kc].sum(0), atol=1e-3 + 1e-5 * kc)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 256, 16), (16, 300, 768), (17, 2304, 768), (32, 2304, 7168), (50, 512, 1040), (64, 257, 64), (32, 41, 768), (3, 7, 32)])
