@@ -53,13 +53,20 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 int out_T(const b2t_model_t* m, int T) { return m->patch > 0 ? (T - m->patch) / m->stride + 1 : T; }
 int in0(const b2t_model_t* m) { return m->patch > 0 ? m->F * m->patch : m->F; }
 
-// Number of K slices so that a weight-gradient GEMM (few 128x128 output tiles, very long K) fills the chip: ~4
-// workgroups per CU on 256 CUs, each slice at least 256 deep.
-int splitk_for(int M, int N, long long K, int target_blocks = 1024) {
+// Number of K slices so that a weight-gradient GEMM (few 128x128 output tiles, very long K) fills the chip with ONE wave of
+// resident workgroups (each slice at least 256 deep): 3 per CU for the fp32 tile kernel (768 blocks; C2 step 19.49 ms
+// against 19.56 with 1024 and 19.72 with 512), 2 per CU for the packed bf16 kernel (512; C2 bf16 10.64 against 10.78 / 10.88).
+// More slices only add slab traffic (the slabs are written and read once more by the reduction).
+int splitk_target(bool bf16) {
+  static const int env = getenv("B2T_SPLITK_TARGET") ? std::max(1, atoi(getenv("B2T_SPLITK_TARGET"))) : 0;
+  return env ? env : (bf16 ? 512 : 768);
+}
+int splitk_for(int M, int N, long long K, int target_blocks) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   long long v = std::min<long long>(target_blocks / std::max(1, tiles), K / 256);
   return (int)std::max<long long>(1, v);
 }
+int splitk_cap(int M, int N, long long K) { return std::max(splitk_for(M, N, K, splitk_target(false)), splitk_for(M, N, K, splitk_target(true))); }   // workspace sizing
 
 // Time chunks of the layer pipeline: `chunks` equal parts (at least 16 steps each).
 int make_chunks(int Tp, int chunks, int (*out)[2]) {
@@ -127,8 +134,8 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     w.scratch[l] = take(B * H);
     w.whh_t[l] = take(H * 3 * H);
     const size_t In = l == 0 ? In0 : H;
-    const size_t a = (size_t)splitk_for(3 * H, H, K) * 3 * H * H, b = (size_t)splitk_for(3 * H, In, K) * 3 * H * In;
-    const size_t b2 = (size_t)splitk_for(2 * H, In, K) * 2 * H * In;   // the two-GEMM form of dW_ih (odd H)
+    const size_t a = (size_t)splitk_cap(3 * H, H, K) * 3 * H * H, b = (size_t)splitk_cap(3 * H, In, K) * 3 * H * In;
+    const size_t b2 = (size_t)splitk_cap(2 * H, In, K) * 2 * H * In;   // the two-GEMM form of dW_ih (odd H)
     w.slab[l] = take(std::max(a, std::max(b, b2)));
     w.s4[l] = take(4 * H);
     w.cs_layer[l] = take(colsum_ws_floats(K, 4 * H) + 4);
@@ -141,7 +148,7 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
   w.dV = m->patch > 0 ? take(B * Tp * In0) : nullptr;
   w.day_slab = take(B * F * F);
   w.day_bslab = take(B * align_up(F, 4));
-  w.slab_head = take((size_t)splitk_for(C, H, K) * C * H);
+  w.slab_head = take((size_t)splitk_cap(C, H, K) * C * H);
   w.cs_head = take(colsum_ws_floats(B * Tp, C) + 4);
   w.cs_day = take(B * colsum_ws_floats(T, F) + 4);
   w.cs_h0 = take(colsum_ws_floats(L * B, H) + 4);
@@ -689,7 +696,7 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
   {
     b2t_gemm_desc d = gd(w.dG[l] + a0, w.out[l] + (long long)t0 * B * H, grd->w_hh[l], 3 * H, H, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    const int sk = splitk_for(3 * H, H, K);
+    const int sk = splitk_for(3 * H, H, K, splitk_target(c.bf16_gemm));
     if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
     c.gemm(s, d, sk, w.slab[l], accumulate);
     if (fused_bias) bias_out(sk, grd->b_hh[l]);
@@ -707,7 +714,7 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     b2t_gemm_desc d = gd(w.dG[l] + a0 + a_off, inp, grd->w_ih[l] + c_off, M, In, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = b_s0; d.b_s1 = b_s1; d.b_div = b_div; d.c_s0 = In;
     d.a_brk = brk; d.a_gap = gap;
-    const int sk = splitk_for(M, In, K);
+    const int sk = splitk_for(M, In, K, splitk_target(c.bf16_gemm));
     if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
     c.gemm(s, d, sk, w.slab[l], accumulate);
     if (fused_bias) bias_out(sk, grd->b_ih[l]);
@@ -782,7 +789,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   const int t_head_w = P.add("head_w", est_gemm(Cc, H, (double)M) + 40.f, Q_ANY, {t_start}, [&](hipStream_t s) {
     b2t_gemm_desc d = gd(dlogits, w.out[L - 1] + (long long)B * H, grd->out_w, Cc, H, (int)M);
     d.a_kcontig = 0; d.a_div = B; d.a_s1 = ldd; d.a_s0 = (long long)Tp * ldd; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    c.gemm(s, d, splitk_for(Cc, H, M), w.slab_head);
+    c.gemm(s, d, splitk_for(Cc, H, M, splitk_target(c.bf16_gemm)), w.slab_head);
     c.call(b2t_colsum_f32(dlogits, M, Cc, ldd, grd->out_b, 0, w.cs_head, 1, 0, 0, reinterpret_cast<void*>(s)));
   });
   bucket(0, t_head_w);
