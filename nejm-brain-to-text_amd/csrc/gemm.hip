@@ -116,16 +116,25 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.z / g.splitk;
-  const int ks = blockIdx.z - z * g.splitk;
-  // XCD-aware tile order: the dispatcher sends workgroup b to XCD b % 8 (private L2 each).  Remap so that every XCD
-  // walks a CONTIGUOUS range of tiles in row-major order: the n-tiles that share an A row-panel then hit the same
-  // L2 instead of fetching the panel once per XCD.  Bijective for any tile count (cdna_hip_programming.md T1).
+  int z = blockIdx.z / g.splitk;
+  int ks = blockIdx.z - z * g.splitk;
+  // XCD-aware tile order: the dispatcher sends workgroup b (linear id, x fastest) to XCD b % 8 (private L2 each).
   int m0, n0;
   {
     const int gx = (g.N + BN - 1) / BN, nwg = gridDim.x;
-    const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    int tile;
+    if (g.ks_xcd) {
+      // split-K with a multiple of 8 slices (Z = 1): ALL tiles of a K slice on one XCD.  The slice's rows of A and B are
+      // then fetched by one L2 only and shared there by the tiles that walk them in step (with tiles dealt to the XCDs
+      // instead, every XCD fetches every slice of B, and a slice of A goes to two of them).
+      const int lin = blockIdx.x + nwg * blockIdx.z, xcd = lin & 7, j = lin >> 3;
+      ks = xcd + 8 * (j / nwg); tile = j % nwg; z = 0;
+    } else {
+      // every XCD walks a CONTIGUOUS range of tiles in row-major order: the n-tiles that share an A row-panel hit the
+      // same L2 instead of fetching the panel once per XCD.  Bijective for any tile count (cdna_hip_programming.md T1).
+      const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+      tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    }
     m0 = (tile / gx) * BM; n0 = (tile % gx) * BN;
   }
 
@@ -359,6 +368,7 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
   GemmArgs g;
   { int rc = fill_gemm_args(d, g, BKT, BM, "b2t_gemm_f32"); if (rc) return rc; }
   dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);
+  { static const bool off = getenv("B2T_GEMM_KS_XCD") && atoi(getenv("B2T_GEMM_KS_XCD")) == 0; g.ks_xcd = !off && d->Z == 1 && g.splitk >= 8 && (g.splitk & 7) == 0; }
   hipStream_t s = as_stream(stream);
   if (d->M <= 64 && d->splitk >= 0 && g.splitk == 1 && d->a_kcontig && (d->K % 16) == 0 && d->a_brk == 0 && d->epilogue != 2) {
     // a few rows against a wide weight matrix: stream the weights once (gemm_skinny_kernel)

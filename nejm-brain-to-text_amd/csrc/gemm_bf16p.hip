@@ -113,12 +113,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __
   __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 2 * PM * PPITCH];
   __bf16* As = smem; __bf16* Bs = smem + 2 * PM * PPITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int ks = blockIdx.z;
+  int ks = blockIdx.z;
   int m0, n0;
-  {   // XCD-aware tile order (see gemm.hip)
+  {   // XCD-aware block order (see gemm.hip): a K slice's tiles on one XCD when the slice count allows, else tiles dealt to the XCDs
     const int gx = (g.N + PN - 1) / PN, nwg = gridDim.x;
-    const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
-    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    int tile;
+    if (g.ks_xcd) {
+      const int lin = blockIdx.x + nwg * blockIdx.z, xcd = lin & 7, j = lin >> 3;
+      ks = xcd + 8 * (j / nwg); tile = j % nwg;
+    } else {
+      const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+      tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    }
     m0 = (tile / gx) * PM; n0 = (tile % gx) * PN;
   }
   const float* bias = (g.bias && ks == 0) ? g.bias : nullptr;
@@ -228,6 +234,7 @@ extern "C" int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_by
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (pack B)");
   g.kchunk = pad_to((Kp + g.splitk - 1) / g.splitk, PK);
   dim3 grid((Np / PN) * (Mp / PM), 1, g.splitk), block(256);
+  { static const bool off = getenv("B2T_GEMM_KS_XCD") && atoi(getenv("B2T_GEMM_KS_XCD")) == 0; g.ks_xcd = !off && g.splitk >= 8 && (g.splitk & 7) == 0; }
   hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, (const __bf16*)Ap, (const __bf16*)Bp, Kp);
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32");
   return 0;

@@ -590,6 +590,9 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
     slab = torch.full((sk, M, N), float("nan"), device=dev)
     part = run(slab, splitk=sk, c_ks=M * N)
     np.testing.assert_allclose(part.sum(0), ref, atol=tol)
+    if K >= 512:       # 8 slices: the slice-per-XCD block order
+        slab8 = torch.full((8, M, N), float("nan"), device=dev)
+        np.testing.assert_allclose(run(slab8, splitk=8, c_ks=M * N).sum(0), ref, atol=tol)
     if not akc:
         # by-product of the pack pass over an m-contiguous A: per 64-k slice sums of the fp32 values (a layer's bias gradients)
         nsl = (K + 63) // 64
@@ -627,12 +630,13 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,sk,brk", [(256, 128, 1000, 1, 0), (384, 200, 4100, 5, 0), (130, 64, 700, 2, 0), (1536, 512, 6000, 21, 1024),
-                                          (100, 300, 50, 1, 0), (768, 130, 40000, 30, 512)])
+                                          (100, 300, 50, 1, 0), (768, 130, 40000, 30, 512), (256, 300, 9000, 16, 0), (384, 128, 5000, 8, 0), (1536, 512, 8000, 24, 1024)])
 def test_gemm_a_column_sums(M, N, K, sk, brk):
     """b2t_gemm_f32, m-contiguous A (the weight-gradient form dW = dG^T X): `a_sum` receives, per K slice, the sums over k
     of A[k][m] -- the bias gradients of a GRU layer (torch autograd of nn.GRU's b_ih / b_hh: column sums of the gate
     gradients) as a by-product of the GEMM that reads dG anyway.  Checked against float64 sums, with split-K, with the
-    gap in A's m index (dGi = dG[:, 0:2H] ++ dG[:, 3H:4H]), ragged M and N, and nothing written outside [slices][M]."""
+    gap in A's m index (dGi = dG[:, 0:2H] ++ dG[:, 3H:4H]), ragged M and N, and nothing written outside [slices][M].
+    Slice counts that are multiples of 8 take the slice-per-XCD block order."""
     import b2t_ops as ops
     dev = _dev()
     rng = np.random.default_rng(M + N + K)
