@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
 // dGh_{t+1} row block with its register-resident W_hh[:, slice] and (B) forms the gate gradients of
 // step t for its slice, publishing them as dG[t] for the other workgroups of the row group.
 // ---------------------------------------------------------------------------------------------------
+#ifdef B2T_TIMING
+__device__ unsigned g_bwd_t[3][512];   // timing build: per workgroup (rg * G + tile) of the LAST backward launch: start, first hand-off received, end (100 MHz wall clock, low word)
+#endif
 template <int NCB, bool BF16, int NT = 1, bool LOC = false>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
 __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __restrict__ dY,
                                                                  const float* __restrict__ dh_last,
@@ -244,6 +247,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   }
   const int m0 = rg * 16;
   const int j0 = tile * 16 * NT;
+#ifdef B2T_TIMING
+  const unsigned wgid = ((unsigned)rg * G + (unsigned)tile) & 511u;
+  if (threadIdx.x == 0) g_bwd_t[0][wgid] = (unsigned)wall_clock64();
+#endif
   int unit[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) unit[n] = j0 + 16 * n + j;
@@ -289,6 +296,9 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       if constexpr (LOC) wait_count_local(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
       else wait_count(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
       TSTAMP(1)   // poll + barrier
+#ifdef B2T_TIMING
+      if (t == T - 2 && threadIdx.x == 0) g_bwd_t[1][wgid] = (unsigned)wall_clock64();   // first hand-off complete: every workgroup of the row group is running
+#endif
       const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
       f32x4 acc[NT];
 #pragma unroll
@@ -365,8 +375,17 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
 #ifdef B2T_TIMING
   if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 17))
     for (int i = 0; i < 7; ++i) sync[8 + (blockIdx.x ? 8 : 0) + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+  if (threadIdx.x == 0) g_bwd_t[2][wgid] = (unsigned)wall_clock64();
 #endif
 }
+
+#ifdef B2T_TIMING
+}  // namespace b2t
+extern "C" int b2t_debug_bwd_times(unsigned* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(b2t::g_bwd_t), sizeof(unsigned) * 3 * 512) == hipSuccess ? 0 : 1;
+}
+namespace b2t {
+#endif
 
 size_t gru_persistent_sync_bytes(int T) { (void)T; return ((size_t)2 * SETW + 64) * sizeof(unsigned); }
 

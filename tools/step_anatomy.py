@@ -32,3 +32,17 @@ for l in range(bench.L):
     for blk, off in ((0, 0), (17, 8)):
         tot = int(sum(w[off:off + 6]))
         print(f"layer {l} block {blk:2d}: " + " ".join(f"{n}={int(w[off + i])}" for i, n in enumerate(names[:6])) + f" | total {tot}")
+
+# placement of the LAST backward launch (layer 0, first time chunk): per-workgroup start / first hand-off / end, 100 MHz wall clock
+import ctypes
+lib = ctypes.CDLL(os.environ["B2T_LIB"])
+if hasattr(lib, "b2t_debug_bwd_times"):
+    buf = (ctypes.c_uint32 * (3 * 512))()
+    lib.b2t_debug_bwd_times(buf)
+    a = np.array(buf, dtype=np.int64).reshape(3, 512)
+    n = int((a[0] != 0).sum())
+    st, first, en = a[0][:n], a[1][:n], a[2][:n]
+    t0 = st.min()
+    print(f"last backward launch: {n} workgroups; start spread {(st.max() - t0) / 100:.1f} us; first hand-off received at "
+          f"{(first.min() - t0) / 100:.1f} .. {(first.max() - t0) / 100:.1f} us; end {(en.max() - t0) / 100:.1f} us after the first workgroup started")
+    print("  start times by row group (us):", [f"{(st[g * 32:(g + 1) * 32].min() - t0) / 100:.0f}-{(st[g * 32:(g + 1) * 32].max() - t0) / 100:.0f}" for g in range(n // 32)])
