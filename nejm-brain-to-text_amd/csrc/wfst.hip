@@ -25,7 +25,6 @@ namespace b2t {
 namespace {
 
 constexpr int BP_NT = 256;   // threads of the best-path kernel (parallel argmin over the last frame, serial backtrace)
-constexpr int BIG_DEG = 24, BIG_CAP = 4096;   // out-degree above which a token's arcs are walked by a whole wave; list capacity
 constexpr int NT = 1024;   // one workgroup per utterance; a frame holds thousands of tokens, each a dependent chain of gathers
 constexpr unsigned UMAX = 0xffffffffu;
 constexpr int MAX_C = 64;
@@ -114,8 +113,7 @@ struct Ctx {
   int* key; int* idx;          // the frame's hash (LDS or HBM)
   float* ll;                   // LDS: acoustic_scale * logp of the frame
   float* redf; int* redi;      // LDS reduction scratch [NT]
-  int* sh;                     // LDS scalars: [0] n_tok, [1] n_link, [2] changed, [3] overflow, [4] number of wide tokens
-  int* big;                    // LDS [BIG_CAP]: the frame's tokens with more than BIG_DEG emitting arcs
+  int* sh;                     // LDS scalars: [0] n_tok, [1] n_link, [2] changed, [3] overflow
 };
 
 // Block reductions: within a wave through lane permutes, across the NT / 64 waves through LDS -- two barriers instead
@@ -368,53 +366,46 @@ __device__ void advance(Ctx& c) {
   WT(1)   // best + k-th cost
   const float cost_offset = -best;
   const float lp = c.o.length_penalty;
-  // ---- ProcessEmitting (:722-824).  A thread owns a token, but out-degrees are skewed (the word-boundary states of L o G
-  // fan out into every word: hundreds of arcs, each a dependent chain of gathers + a hash probe): tokens with more than
-  // BIG_DEG emitting arcs go to an LDS list and a whole WAVE walks their arcs, 64 at a time.
-  // Pass A: the frame's best candidate -> next_cutoff
+  // ---- ProcessEmitting (:722-824).  Out-degrees are skewed (1-3 arcs inside a word, hundreds at the word-boundary states
+  // of L o G, each arc a dependent chain of gathers + a hash probe), so a thread that owned a token would idle most of its
+  // wave.  A wave takes 64 consecutive tokens, scans their degrees through lane permutes and walks the FLATTENED arc list 64
+  // arcs at a time: arc j belongs to the first lane whose inclusive degree sum exceeds j (6-step search through permutes).
   float mn = INFINITY;
   int narcs = 0;
-  if (threadIdx.x == 0) c.sh[4] = 0;
-  __syncthreads();
   auto arc_cost = [&](float cur, int s, int a, float& ac, float& gc) {
     ac = cost_offset - c.ll[g.ilabel[a] - 1];
     gc = g.weight[a];
     if (g.next[a] != s) gc += lp;
     return cur + ac + gc;
   };
-  for (int t = t0 + threadIdx.x; t < t1; t += NT) {
-    const float cur = o2f(c.l.tok_cost[t]);
-    if (!(cur <= cur_cutoff)) continue;
-    const int s = c.l.tok_state[t];
-    const int a0 = g.row[s] + g.n_eps[s], a1 = g.row[s + 1];
-    narcs += a1 - a0;
-    if (a1 - a0 > BIG_DEG) {
-      const int i = atomicAdd(&c.sh[4], 1);
-      if (i < BIG_CAP) c.big[i] = t;
-      continue;                            // (a list overflow is handled below: the frame then runs thread-per-token)
+  const int lane = threadIdx.x & 63;
+  auto walk = [&](auto&& visit) {          // visit(token, its cost, its state, arc) for every emitting arc of every token under the cutoff
+    for (int base = t0 + (int)threadIdx.x - lane; base < t1; base += NT) {    // wave-uniform
+      const int t = base + lane;
+      float cur = INFINITY; int s = 0, a0 = 0, deg = 0;
+      if (t < t1) {
+        cur = o2f(c.l.tok_cost[t]);
+        if (cur <= cur_cutoff) { s = c.l.tok_state[t]; a0 = g.row[s] + g.n_eps[s]; deg = g.row[s + 1] - a0; }
+      }
+      int incl = deg;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+      const int total = __shfl(incl, 63, 64), excl = incl - deg;
+      for (int jb = 0; jb < total; jb += 64) {
+        const int jj = jb + lane;
+        int owner = 0;                      // number of lanes whose inclusive sum is <= jj
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) { const int v = __shfl(incl, owner + step - 1, 64); if (v <= jj) owner += step; }
+        owner = min(owner, 63);
+        const int oa0 = __shfl(a0, owner, 64), oex = __shfl(excl, owner, 64), os = __shfl(s, owner, 64);
+        const float ocur = __shfl(cur, owner, 64);
+        if (jj < total) visit(base + owner, ocur, os, oa0 + (jj - oex));
+      }
+      narcs += deg;
     }
-    for (int a = a0; a < a1; ++a) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); }
-  }
-  __syncthreads();
-  const bool listed = c.sh[4] <= BIG_CAP;
-  const int nbig = listed ? c.sh[4] : 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (!listed) {                           // more wide tokens than the list holds: walk them per thread after all
-    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
-      const float cur = o2f(c.l.tok_cost[t]);
-      if (!(cur <= cur_cutoff)) continue;
-      const int s = c.l.tok_state[t];
-      const int a0 = g.row[s] + g.n_eps[s], a1 = g.row[s + 1];
-      if (a1 - a0 <= BIG_DEG) continue;
-      for (int a = a0; a < a1; ++a) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); }
-    }
-  }
-  for (int b = wave; b < nbig; b += NT / 64) {
-    const int t = c.big[b];
-    const float cur = o2f(c.l.tok_cost[t]);
-    const int s = c.l.tok_state[t];
-    for (int a = g.row[s] + g.n_eps[s] + lane; a < g.row[s + 1]; a += 64) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); }
-  }
+  };
+  // Pass A: the frame's best candidate -> next_cutoff
+  walk([&](int, float cur, int s, int a) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); });
   mn = block_min(c, mn);
   narcs = block_sum(c, narcs);
   if (threadIdx.x == 0) {
@@ -444,20 +435,7 @@ __device__ void advance(Ctx& c) {
         atomicOr(&c.sh[3], 2);
       }
     };
-    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
-      const float cur = o2f(c.l.tok_cost[t]);
-      if (!(cur <= cur_cutoff)) continue;
-      const int s = c.l.tok_state[t];
-      const int a0 = g.row[s] + g.n_eps[s], a1 = g.row[s + 1];
-      if (listed && a1 - a0 > BIG_DEG) continue;
-      for (int a = a0; a < a1; ++a) visit(t, cur, s, a);
-    }
-    for (int b = wave; b < nbig; b += NT / 64) {
-      const int t = c.big[b];
-      const float cur = o2f(c.l.tok_cost[t]);
-      const int s = c.l.tok_state[t];
-      for (int a = g.row[s] + g.n_eps[s] + lane; a < g.row[s + 1]; a += 64) visit(t, cur, s, a);
-    }
+    { const int keep = narcs; walk(visit); narcs = keep; }
     __syncthreads();
     WT(4)   // pass B: arc walk (claim + link records)
     const int l1 = min(c.sh[1], c.max_link);
@@ -501,10 +479,9 @@ __global__ __launch_bounds__(NT) void wfst_reset_kernel(Graph g, char* state, si
                                                          int max_tok, int max_link, int hash, int use_lds) {
   extern __shared__ int dyn[];
   __shared__ float ll[MAX_C], redf[NT];
-  __shared__ int redi[NT], sh[8], big[BIG_CAP];
+  __shared__ int redi[NT], sh[8];
   Ctx c;
   setup(c, g, state, blockIdx.x, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
-  c.big = big;
   init_decoding(c);
 }
 
@@ -514,12 +491,11 @@ __global__ __launch_bounds__(NT) void wfst_search_kernel(Graph g, char* state, s
                                                           const float* __restrict__ logp, const int* __restrict__ lens, int T, int C) {
   extern __shared__ int dyn[];
   __shared__ float ll[MAX_C], redf[NT];
-  __shared__ int redi[NT], sh[8], big[BIG_CAP];
+  __shared__ int redi[NT], sh[8];
   __shared__ int dec[2];
   Ctx c;
   const int u = blockIdx.x;
   setup(c, g, state, u, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
-  c.big = big;
   if (threadIdx.x == 0) { sh[0] = c.l.h->n_tok; sh[1] = c.l.h->n_link; sh[2] = 0; sh[3] = c.l.h->overflow; }
   __syncthreads();
   const int n = lens ? min(lens[u], T) : T;
