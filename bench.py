@@ -151,12 +151,23 @@ class BoxSampler:
     """Clocks and board power of the GPU during the timed region (sysfs, every 50 ms, N=1 only): box-to-box spread of the
     headline (+-3 % on this pool) can then be read against the clocks the box actually ran at.  Never raises."""
 
-    def __init__(self):
+    def __init__(self, dev=None):
         import glob
-        self.sclk = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))[:1]
-        self.mclk = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_mclk"))[:1]
-        self.pwr = (sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
-                    or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")))[:1]
+        # the host's sysfs lists every GPU of the node: take the card whose PCI address is the device this process runs on
+        self.bus, base = None, None
+        try:
+            pr = torch.cuda.get_device_properties(dev if dev is not None else 0)
+            self.bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+                if os.path.basename(os.path.realpath(os.path.join(card, "device"))) == self.bus:
+                    base = os.path.join(card, "device")
+        except Exception:
+            pass
+        self.matched = base is not None
+        self.sclk = [os.path.join(base, "pp_dpm_sclk")] if base else []
+        self.mclk = [os.path.join(base, "pp_dpm_mclk")] if base else []
+        self.pwr = ((sorted(glob.glob(os.path.join(base, "hwmon/hwmon*/power1_average")))
+                     or sorted(glob.glob(os.path.join(base, "hwmon/hwmon*/power1_input"))))[:1]) if base else []
         self.rows, self.stop_flag, self.thread = [], False, None
 
     @staticmethod
@@ -191,7 +202,7 @@ class BoxSampler:
         def med(i):
             v = sorted(r[i] for r in self.rows if r[i] is not None)
             return round(v[len(v) // 2], 1) if v else None
-        return dict(sclk_mhz_p50=med(0), mclk_mhz_p50=med(1), board_w_p50=med(2), samples=len(self.rows))
+        return dict(pci=self.bus, sysfs_card_found=self.matched, sclk_mhz_p50=med(0), mclk_mhz_p50=med(1), board_w_p50=med(2), samples=len(self.rows))
 
 
 def dry_run(a, world, rank):
@@ -287,7 +298,7 @@ def main():
         model._ws.check_sync()
         return loss, dt, t_enq
 
-    sampler = BoxSampler() if world == 1 else None
+    sampler = BoxSampler(dev) if world == 1 else None
     try:
         if sampler:
             sampler.start()
