@@ -88,6 +88,11 @@ typedef struct b2t_gemm_desc {
    * b2t_gemm_bf16p_f32 takes it too: its pack pass over A writes one slice per 64 k, a_sum[(k / 64)*a_sum_ks + m]
    * (ceil(K / 64) slices whatever splitk is), summed from the fp32 values before they are rounded. */
   float* a_sum; long long a_sum_ks;
+  /* b2t_gemm_f32 with splitk > 1, Z = 1, N % 4 == 0 (NULL otherwise): in-kernel slab reduction.  ks_counters: one zeroed
+   * 32-bit word per 128x128 output tile (left zero again); the LAST slice workgroup of a tile to finish sums the tile's
+   * slabs in slice order (the order b2t_slab_reduce_f32 uses: bit-identical) into ks_out, a dense row-major [M][N]
+   * matrix (+= when ks_accumulate).  No separate reduction launch; C still names the slab area. */
+  unsigned* ks_counters; float* ks_out; int ks_accumulate;
 } b2t_gemm_desc;
 int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream);
 /* The same GEMM with the operands rounded to bf16 (nearest-even) on their way to the matrix cores, fp32 accumulation and
@@ -215,7 +220,7 @@ int b2t_exec_destroy(b2t_exec* ex);
  * arithmetic, deterministic; exported so that the CPU tests can check the schedule's invariants without a GPU. */
 int b2t_plan_schedule_host(int n_tasks, const float* est_us, const uint32_t* qmask, const int32_t* dep_off,
                            const int32_t* deps, int n_queues, int32_t* queue, float* start_us, int32_t* order);
-size_t b2t_exec_sync_bytes(int n_layers);          /* 2 * n_layers blocks of b2t_gru_sync_bytes(0): fwd l, then bwd l */
+size_t b2t_exec_sync_bytes(int n_layers);          /* 2 * n_layers + 1 blocks of b2t_gru_sync_bytes(0): fwd l, then bwd l, then the tile counters of the split-K GEMMs */
 size_t b2t_pass_ws_bytes(const b2t_model_t* m, const b2t_pass_t* p);
 /* x [B][T][F], day_idx [B], states [L][B][H] or NULL (h0)  ->  logits [B][T'][C], hidden [L][B][H] */
 int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t_pass_t* p, const float* x,

@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
         ("b_zmap", VP), ("bias_sz", LL),
         ("epilogue", C.c_int), ("accumulate", C.c_int),
         ("splitk", C.c_int), ("c_ks", LL),
-        ("a_brk", C.c_int), ("a_gap", C.c_int), ("ep_aux", VP), ("a_sum", VP), ("a_sum_ks", C.c_longlong),
+        ("a_brk", C.c_int), ("a_gap", C.c_int), ("ep_aux", VP), ("a_sum", VP), ("a_sum_ks", C.c_longlong), ("ks_counters", VP), ("ks_out", VP), ("ks_accumulate", C.c_int),
     ]
 
 

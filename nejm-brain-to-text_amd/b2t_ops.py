@@ -375,7 +375,7 @@ class Workspace:
         """[2L][words] int32: block l = forward sweep of layer l, block L + l = its backward sweep; word 0 of a block is
         the sweep's sticky error word."""
         words = N.load().b2t_gru_sync_bytes(0) // 4
-        return self.get("exec_sync", (2 * L, words), device, torch.int32)
+        return self.get("exec_sync", (2 * L + 1, words), device, torch.int32)   # last block: tile counters of the split-K GEMMs (b2t_exec_sync_bytes)
 
     def error_words(self, L: int, device):
         """(pointer, count, stride in words) of the sweeps' error words, for b2t_grad_norm_clip_f32."""

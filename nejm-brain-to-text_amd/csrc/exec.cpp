@@ -158,6 +158,8 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
 }
 
 // ---- pass context: streams, events, profiling ----------------------------------------------------------------------
+constexpr int KSLOT = 4096;   // tile counters per split-K call site (slot = layer, MAXL = output layer)
+
 struct Ctx {
   b2t_exec* ex;
   hipStream_t main;
@@ -167,6 +169,7 @@ struct Ctx {
   bool exact_k = false;         // pipelined (chunked) passes: every GEMM keeps the tile kernel's k order, so that the result does not depend on the chunking
   int nq = 0;
   const Layout* lay = nullptr;  // for the per-queue pack scratch of the amp-mode GEMM
+  unsigned* kcnt = nullptr;     // tile counters of the split-K GEMMs' in-kernel slab reduction (last block of sync_ws): KSLOT words per slot
 
   hipEvent_t record(hipStream_t s) {
     if (ex->next_ev == ex->pool.size()) {
@@ -204,7 +207,7 @@ struct Ctx {
 
   // C = A.B^T through b2t_gemm_f32 / b2t_gemm_bf16_f32.  splitk > 1: partial products go to `slab` ([splitk][M*N]) and
   // are summed deterministically into C by b2t_slab_reduce_f32 (weight gradients, K = T*B; streaming-sized projections).
-  void gemm(hipStream_t s, b2t_gemm_desc d, int splitk = 1, float* slab = nullptr, int accumulate = 0) {
+  void gemm(hipStream_t s, b2t_gemm_desc d, int splitk = 1, float* slab = nullptr, int accumulate = 0, int kslot = -1) {
     if (rc) return;
     void* st = reinterpret_cast<void*>(s);
     const int kind = (bf16_gemm ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
@@ -216,11 +219,19 @@ struct Ctx {
         set_error("exec: split-K gemm supports Z=1, dense row-major C, no epilogue"); rc = 2; return;
       }
       d.C = slab; d.splitk = splitk; d.c_ks = (long long)d.M * d.N; d.accumulate = 0;
+      // opt-in (B2T_FUSED_SLABS=1): the tile's last slice workgroup sums the slabs inside the GEMM (same order as the reduction
+      // pass: bit-identical).  Measured slower than the separate pass: 19.64-19.71 vs 19.46-19.54 ms per C2 step -- 48 workgroups
+      // re-read 50 MB of written-through slabs at the GEMM's tail where the reduction kernel uses the whole chip.
+      static const bool want_fused = getenv("B2T_FUSED_SLABS") != nullptr;
+      const int tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128);
+      const bool fused = want_fused && !bf16_gemm && kcnt && kslot >= 0 && tiles <= KSLOT && (d.N % 4) == 0 &&
+                         ((uintptr_t)Cdst & 15) == 0 && (long long)d.M * d.N * 4 < (1ll << 31);
+      if (fused) { d.ks_counters = kcnt + (size_t)kslot * KSLOT; d.ks_out = Cdst; d.ks_accumulate = accumulate; }
       {
         Scope sc(*this, s, kind, flops);
         rc = bf16_gemm ? gemm_amp(d, s) : b2t_gemm_f32(&d, st);
       }
-      if (!rc) rc = b2t_slab_reduce_f32(slab, splitk, (long long)d.M * d.N, Cdst, accumulate, st);
+      if (!rc && !fused) rc = b2t_slab_reduce_f32(slab, splitk, (long long)d.M * d.N, Cdst, accumulate, st);
       return;
     }
     d.accumulate = accumulate;
@@ -501,7 +512,7 @@ extern "C" int b2t_plan_schedule_host(int n_tasks, const float* est_us, const ui
   return 0;
 }
 
-extern "C" size_t b2t_exec_sync_bytes(int n_layers) { return (size_t)2 * n_layers * b2t_gru_sync_bytes(0); }
+extern "C" size_t b2t_exec_sync_bytes(int n_layers) { return ((size_t)2 * n_layers + 1) * b2t_gru_sync_bytes(0); }   // + the split-K tile counters
 
 extern "C" size_t b2t_pass_ws_bytes(const b2t_model_t* m, const b2t_pass_t* p) {
   if (!m || !p || p->B <= 0 || p->T <= 0 || out_T(m, p->T) <= 0 || m->L < 1 || m->L > MAXL) return 0;
@@ -700,7 +711,7 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
     const int sk = splitk_for(3 * H, H, K, splitk_target(c.bf16_gemm));
     if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
-    c.gemm(s, d, sk, w.slab[l], accumulate);
+    c.gemm(s, d, sk, w.slab[l], accumulate, l);
     if (fused_bias) bias_out(sk, grd->b_hh[l]);
   }
   int In; const float* inp; long long b_s0, b_s1 = 0; int b_div = 0;
@@ -718,7 +729,7 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     d.a_brk = brk; d.a_gap = gap;
     const int sk = splitk_for(M, In, K, splitk_target(c.bf16_gemm));
     if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
-    c.gemm(s, d, sk, w.slab[l], accumulate);
+    c.gemm(s, d, sk, w.slab[l], accumulate, l);
     if (fused_bias) bias_out(sk, grd->b_ih[l]);
   };
   if ((2 * H) % 128 == 0 && (3 * H) % 128 == 0) {   // dGi^T as ONE operand with a gap along m
@@ -760,6 +771,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   ex->next_ev = 0;
   const size_t sync_block = b2t_gru_sync_bytes(0);
   auto sync_of = [&](int l) { return sync_ws ? reinterpret_cast<char*>(sync_ws) + (size_t)(L + l) * sync_block : nullptr; };
+  static_assert((MAXL + 1) * KSLOT + 64 <= 2 * 64 * 1024, "split-K tile counters must fit one sync block");
+  if (sync_ws) c.kcnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sync_ws) + (size_t)2 * L * sync_block) + 64;
   auto cb = [&](int id, hipStream_t s) { if (bucket_cb && !c.rc) bucket_cb(user, id, reinterpret_cast<void*>(s)); };
 
   int chunks[MAXC][2];
@@ -791,7 +804,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   const int t_head_w = P.add("head_w", est_gemm(Cc, H, (double)M) + 40.f, Q_ANY, {t_start}, [&](hipStream_t s) {
     b2t_gemm_desc d = gd(dlogits, w.out[L - 1] + (long long)B * H, grd->out_w, Cc, H, (int)M);
     d.a_kcontig = 0; d.a_div = B; d.a_s1 = ldd; d.a_s0 = (long long)Tp * ldd; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    c.gemm(s, d, splitk_for(Cc, H, M, splitk_target(c.bf16_gemm)), w.slab_head);
+    c.gemm(s, d, splitk_for(Cc, H, M, splitk_target(c.bf16_gemm)), w.slab_head, 0, MAXL);
     c.call(b2t_colsum_f32(dlogits, M, Cc, ldd, grd->out_b, 0, w.cs_head, 1, 0, 0, reinterpret_cast<void*>(s)));
   });
   bucket(0, t_head_w);

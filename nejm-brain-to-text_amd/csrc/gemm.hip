@@ -106,6 +106,14 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (
   }
 }
 
+// 16-byte device-scope (sc1) load: never served from a stale line of this XCD's L2 (slab tiles written by other XCDs)
+__device__ __forceinline__ float4 load_f4_sc1(const float* base_uniform, unsigned byte_off) {
+  using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base_uniform), 0, 0x7fffffff, 0x00020000);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKT * PITCH_MAX];
@@ -267,8 +275,38 @@ __global__ __launch_bounds__(256, B2T_GEMM_OCC) void gemm_f32_kernel(GemmArgs g)
           if (g.epilogue == 2) { const float a = 1.0f - fabsf(g.ep_aux[(long long)z * g.c_sz + coff]); v *= a * a; }   // softsign backward
           float* p = C + coff;
           if (g.accumulate) v += *p;
-          *p = v;
+          if (g.ks_cnt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // slab tile: written through (read by another XCD's workgroup)
+          else *p = v;
         }
+      }
+    }
+  }
+  // In-kernel slab reduction (split-K): the last slice workgroup of this tile to get here sums the tile's slabs in slice
+  // order -- the order the separate reduction pass uses, so the result is bit-identical and does not depend on arrival.
+  if (g.ks_cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    const int gx = (g.N + BN - 1) / BN, tile_id = (m0 / BM) * gx + n0 / BN;
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(g.ks_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (unsigned)g.splitk - 1u;
+      if (last) __hip_atomic_store(g.ks_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0]) {
+      for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+        const int r = m0 + idx / (BN / 4), cc = n0 + (idx % (BN / 4)) * 4;
+        if (r >= g.M || cc >= g.N) continue;                 // (N % 4 == 0: a float4 is inside the row or beyond it)
+        const long long e = (long long)r * g.N + cc;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.ks_acc) acc = *reinterpret_cast<const float4*>(g.ks_out + e);
+        for (int sl = 0; sl < g.splitk; ++sl) {
+          const float4 v = load_f4_sc1(g.C + (long long)sl * g.c_ks, (unsigned)(e * 4));
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(g.ks_out + e) = acc;
       }
     }
   }
@@ -365,6 +403,9 @@ extern "C" int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream) {
                   (d->b_s1 % 4) == 0 && (d->b_sz % 4) == 0,
               "b2t_gemm_f32: A/B strides must be multiples of 4 elements");
   B2T_REQUIRE(d->a_sum == nullptr || !d->a_kcontig, "b2t_gemm_f32: a_sum goes with an m-contiguous A (a_kcontig = 0)");
+  B2T_REQUIRE(d->ks_counters == nullptr || (d->splitk > 1 && d->Z == 1 && (d->N % 4) == 0 && d->ks_out != nullptr && ((uintptr_t)d->ks_out & 15) == 0 &&
+                                            (long long)d->M * d->N * 4 < (1ll << 31)),
+              "b2t_gemm_f32: the in-kernel slab reduction needs splitk > 1, Z = 1, N %% 4 == 0 and a 16-byte aligned ks_out");
   GemmArgs g;
   { int rc = fill_gemm_args(d, g, BKT, BM, "b2t_gemm_f32"); if (rc) return rc; }
   dim3 grid(((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM), 1, d->Z * g.splitk), block(256);

@@ -16,6 +16,7 @@ struct GemmArgs {
   int a_brk; int a_gap;   // contiguous index i of A (k if a_kcontig, else m): i >= a_brk reads from i + a_gap
   const float* ep_aux;    // epilogue 2: u, laid out like C
   float* a_sum; long long a_sum_ks;   // fp32 tile kernel, m-contiguous A: per-slice sums over k of A[k][m]
+  unsigned* ks_cnt; float* ks_out; int ks_acc;   // fp32 tile kernel, split-K: in-kernel slab reduction by a tile's last slice workgroup
   int ks_xcd;             // split-K: 1 = a K slice's tiles all run on one XCD (slices dealt to the XCDs), 0 = tiles dealt to the XCDs
 };
 
@@ -41,6 +42,7 @@ inline int fill_gemm_args(const b2t_gemm_desc* d, GemmArgs& g, int bk, int bm, c
   g.ep_aux = d->ep_aux;
   g.a_sum = d->a_sum; g.a_sum_ks = d->a_sum_ks;
   g.ks_xcd = 0;
+  g.ks_cnt = d->ks_counters; g.ks_out = d->ks_out; g.ks_acc = d->ks_accumulate;
   B2T_REQUIRE(d->epilogue != 2 || d->ep_aux != nullptr, "%s: epilogue 2 needs ep_aux", name);
   B2T_REQUIRE(d->a_brk == 0 || (d->a_brk > 0 && d->a_gap % 4 == 0 &&
                                 (d->a_kcontig ? d->a_brk % bk == 0 : (d->a_brk % bm == 0 && d->M % bm == 0))),

@@ -668,6 +668,50 @@ def test_gemm_a_column_sums(M, N, K, sk, brk):
         np.testing.assert_allclose(got[s_, :M], Al[s_ * kc:(s_ + 1) * kc].sum(0), atol=1e-3 + 1e-5 * kc)
 
 
+@pytest.mark.parametrize("M,N,K,sk,akc", [(1536, 512, 6000, 16, 0), (384, 200, 4100, 5, 0), (130, 64, 700, 2, 1), (256, 256, 9000, 24, 1), (2304, 768, 3000, 7, 0)])
+def test_gemm_splitk_in_kernel_reduction(M, N, K, sk, akc):
+    """b2t_gemm_f32 split-K with `ks_counters`: the last slice workgroup of every tile sums the slabs inside the GEMM.
+    Bit-identical to slabs + b2t_slab_reduce_f32 (same slice order), with and without accumulation, counters left at zero,
+    repeated calls on the same counters."""
+    import ctypes as C
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev()
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32); Bm = rng.standard_normal((N, K)).astype(np.float32)
+    Mp = (M + 3) // 4 * 4
+    if akc:
+        Ad = torch.from_numpy(A).to(dev); a_s0 = K
+    else:
+        At = np.zeros((K, Mp), np.float32); At[:, :M] = A.T; Ad = torch.from_numpy(At).to(dev); a_s0 = Mp
+    Bd = torch.from_numpy(np.ascontiguousarray(Bm.T)).to(dev)           # [K][N]: n contiguous
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    cnt = torch.zeros(tiles + 8, dtype=torch.int32, device=dev)
+
+    def run(out, fused, acc):
+        slab = torch.full((sk, M, N), float("nan"), device=dev)
+        d = Nn.GemmDesc()
+        d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), slab.data_ptr()
+        d.M, d.N, d.K, d.Z = M, N, K, 1
+        d.a_kcontig, d.b_kcontig, d.a_s0, d.b_s0, d.c_s0 = akc, 0, a_s0, N, N
+        d.splitk, d.c_ks = sk, M * N
+        if fused:
+            d.ks_counters, d.ks_out, d.ks_accumulate = cnt.data_ptr(), out.data_ptr(), acc
+        Nn.check(lib.b2t_gemm_f32(C.byref(d), ops._stream()), "b2t_gemm_f32")
+        if not fused:
+            Nn.check(lib.b2t_slab_reduce_f32(ops._p(slab), sk, M * N, ops._p(out), acc, ops._stream()), "b2t_slab_reduce_f32")
+        return out.cpu().numpy()
+
+    base = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(dev)
+    for acc in (0, 1, 1, 0):
+        want = run(base.clone(), False, acc)
+        got = run(base.clone(), True, acc)
+        assert np.array_equal(got, want)
+        assert int(cnt.abs().max().item()) == 0
+    ref = A.astype(np.float64) @ Bm.astype(np.float64).T
+    np.testing.assert_allclose(run(base.clone(), True, 0), ref, atol=3e-6 * np.sqrt(K) * max(1.0, float(np.abs(ref).max())))
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 256, 16), (16, 300, 768), (17, 2304, 768), (32, 2304, 7168), (50, 512, 1040), (64, 257, 64), (32, 41, 768), (3, 7, 32)])
 def test_gemm_skinny_rows(M, N, K):
     """b2t_gemm_f32 with <= 64 rows against a wide weight matrix (one streamed frame: evaluate_model_helpers.py:87-115)
