@@ -132,14 +132,24 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
   out[c] = accumulate ? out[c] + s : s;
 }
 
+using f32x4 = float __attribute__((ext_vector_type(4)));
 // out[i] (+)= sum_s slab[s][i]  — deterministic split-K reduction, float4 per lane, slabs summed in order
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslab, long long n4, float* __restrict__ out,
                                    int accumulate) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 acc = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nslab; ++s) {
-      const float4 v = reinterpret_cast<const float4*>(slab + (long long)s * n4 * 4)[i];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    // eight slab loads in flight, added in slab order (the order is part of the contract); the slabs are read once: non-temporal
+    int s = 0;
+    for (; s + 8 <= nslab; s += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slab + (long long)(s + k) * n4 * 4) + i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { acc.x += v[k][0]; acc.y += v[k][1]; acc.z += v[k][2]; acc.w += v[k][3]; }
+    }
+    for (; s < nslab; ++s) {
+      const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slab + (long long)s * n4 * 4) + i);
+      acc.x += v[0]; acc.y += v[1]; acc.z += v[2]; acc.w += v[3];
     }
     reinterpret_cast<float4*>(out)[i] = acc;
   }
