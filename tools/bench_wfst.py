@@ -97,6 +97,24 @@ def run():
     tok_per_frame = float(hdr[:, 1].sum()) / float(hdr[:, 0].sum())
     # algorithmic bytes of the search: 16 B per expanded arc + 20 B per token + 21 B per forward link
     alg_bytes = 16.0 * sum(S.arcs_expanded()) + 20.0 * float(hdr[:, 1].sum()) + 21.0 * float(hdr[:, 2].sum())
+    # the same search with every CU busy: one workgroup per utterance means 32 utterances use 32 of the 256 CUs
+    wide = None
+    UW = int(os.environ.get("B2T_WFST_WIDE_U", "256"))
+    if UW > U:
+        try:
+            rep = (UW + U - 1) // U
+            lpw = lp.repeat(rep, 1, 1)[:UW].contiguous(); lensw = np.tile(lens, rep)[:UW]
+            SW = WfstSearch(g, Opt, U=UW, max_frames=T + 8, max_tokens=1 << 21, max_links=1 << 23, hash_size=int(os.environ.get("B2T_WFST_HASH", "0")))
+            tw = []
+            for rep_ in range(2):
+                SW.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                SW.search(lpw, lensw); torch.cuda.synchronize(); tw.append(time.perf_counter() - t0)
+            wide = dict(utterances=UW, search_ms=round(min(tw) * 1e3, 2), search_ms_per_utterance=round(min(tw) * 1e3 / UW, 3),
+                        achieved_gb_s=round(alg_bytes * (UW / U) / min(tw) / 1e9, 1))
+            del SW, lpw
+            torch.cuda.empty_cache()
+        except Exception as e:     # capacity of the box
+            wide = dict(error=str(e)[:200])
     # streaming: one frame per call for all U utterances, partial best path read back
     S.reset()
     lat = []
@@ -117,6 +135,7 @@ def run():
                             ms_per_utterance=round((search_ms + fin_ms) / U, 3), tokens_per_frame=round(tok_per_frame, 1),
                             algorithmic_mb=round(alg_bytes / 1e6, 1), achieved_gb_s=round(alg_bytes / (search_ms * 1e-3) / 1e9, 2),
                             hbm_roofline_frac=round(alg_bytes / (search_ms * 1e-3) / 8.0e12, 5)),
+               offline_all_cus=wide,
                streaming=dict(p50_ms_per_frame=round(float(np.percentile(lat, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat, 95)), 3)),
                wfst_wer_vs_truth=round(err_truth / nref, 4))
     # the round-1 substitute: lexicon-constrained prefix beam + word n-gram (b2t_prefix_beam_search_lex_f32)
