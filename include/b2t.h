@@ -220,6 +220,13 @@ int b2t_exec_destroy(b2t_exec* ex);
  * arithmetic, deterministic; exported so that the CPU tests can check the schedule's invariants without a GPU. */
 int b2t_plan_schedule_host(int n_tasks, const float* est_us, const uint32_t* qmask, const int32_t* dep_off,
                            const int32_t* deps, int n_queues, int32_t* queue, float* start_us, int32_t* order);
+/* The same scheduler with the executor's admission control: cls[i] = -1, 0 or 1; tasks of one class (the sweeps whose
+ * XCD-local hand-off shares an XCD set) are chained so that the k-th in planned start order waits for the (k-2)-th to
+ * finish -- an XCD holds the row groups of two sweeps, and a third one that became partly resident would deadlock all
+ * three.  end_us[i] = planned end.  No GPU involved. */
+int b2t_plan_admission_host(int n_tasks, const float* est_us, const uint32_t* qmask, const int32_t* dep_off,
+                            const int32_t* deps, const int32_t* cls, int n_queues, int32_t* queue, float* start_us,
+                            float* end_us, int32_t* order);
 size_t b2t_exec_sync_bytes(int n_layers);          /* 2 * n_layers + 1 blocks of b2t_gru_sync_bytes(0): fwd l, then bwd l, then the tile counters of the split-K GEMMs */
 size_t b2t_pass_ws_bytes(const b2t_model_t* m, const b2t_pass_t* p);
 /* x [B][T][F], day_idx [B], states [L][B][H] or NULL (h0)  ->  logits [B][T'][C], hidden [L][B][H] */

@@ -282,6 +282,7 @@ constexpr unsigned Q_ANY = 0xffffffffu, Q_MAIN = 1u;
 struct Task {
   const char* name; float est; unsigned qmask; std::vector<int> deps; std::function<void(hipStream_t)> run;
   int q = -1; float start = 0.f, end = 0.f, rank = 0.f; bool cross = false; hipEvent_t ev = nullptr;
+  int cls = -1;   // admission class (XCD set of a sweep under the XCD-local hand-off): at most two tasks of a class in flight
 };
 
 struct Plan {
@@ -348,8 +349,28 @@ std::vector<int> schedule_plan(Plan& P, int nq) {
   return order;
 }
 
+// Admission control for the XCD-local sweeps.  A row group's workgroups must ALL be resident on their XCD before its recurrence
+// can move, and an XCD holds the row groups of exactly two sweeps (32-unit forward workgroups: 16 + 16 CUs; backward: 32 + 32
+// workgroups at two per CU).  Layers of one parity share an XCD set, and nothing in the data dependencies keeps layers 0, 2 and
+// 4 from being in flight together: each then gets part of its workgroups resident, the XCD is full and all three spin until
+// the hand-off timeout (seen under rocprofv3 in the trainer loop, about once in 150 steps).  So the k-th task of a class, in
+// planned start order, waits for the (k-2)-th to finish: never more than two in flight.  The extra edges point forward in a
+// topological order, so the graph stays acyclic; they rarely bind (the third sweep of a parity normally starts later anyway).
+void add_admission_edges(Plan& P, const std::vector<int>& order) {
+  std::vector<int> seen[2];
+  for (int id : order) {
+    const int k = P.t[id].cls;
+    if (k < 0 || k > 1) continue;
+    if (seen[k].size() >= 2) P.dep(id, seen[k][seen[k].size() - 2]);
+    seen[k].push_back(id);
+  }
+}
+
 void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   const int n = (int)P.t.size();
+  bool classes = false;
+  for (const Task& k : P.t) classes = classes || k.cls >= 0;
+  if (classes && nq > 1) add_admission_edges(P, schedule_plan(P, nq));
   const std::vector<int> order = schedule_plan(P, nq);
   static const bool dump = getenv("B2T_PLAN_DUMP") != nullptr;
   if (dump) {
@@ -479,6 +500,11 @@ extern "C" int b2t_exec_create(int n_layers, b2t_exec** out) {
   if (const char* env = getenv("B2T_WORKERS")) ex->n_workers = std::max(1, std::min(7, atoi(env)));
   ex->sweep_qmask = getenv("B2T_SWEEP_WORKERS_ONLY") ? (((1u << ex->n_workers) - 1u) << 1) : 0xffffffffu;
   if (const char* env = getenv("B2T_SWEEP_QMASK")) ex->sweep_qmask = (unsigned)strtoul(env, nullptr, 0);   // experiments: bit q = queue q
+  // Never more than four sweeps in flight, whatever B2T_WORKERS says: with the device-scope hand-off a sweep's workgroups are
+  // spread over the chip and four sweeps fill it exactly (forward 4 x 64 workgroups at one per CU, backward 4 x 128 at two); a
+  // fifth could leave several of them partly resident, i.e. deadlocked until the hand-off timeout.
+  ex->sweep_qmask &= 0xfu;
+  if (!ex->sweep_qmask) ex->sweep_qmask = 0xfu;
   if (check_hip(hipMalloc(reinterpret_cast<void**>(&ex->scratch), 256), "hipMalloc")) { delete ex; return 1; }
   *out = ex;
   return 0;
@@ -509,6 +535,27 @@ extern "C" int b2t_plan_schedule_host(int n_tasks, const float* est_us, const ui
   }
   const std::vector<int> ord = schedule_plan(P, n_queues);
   for (int i = 0; i < n_tasks; ++i) { queue[i] = P.t[i].q; start_us[i] = P.t[i].start; order[i] = ord[i]; }
+  return 0;
+}
+
+extern "C" int b2t_plan_admission_host(int n_tasks, const float* est_us, const uint32_t* qmask, const int32_t* dep_off,
+                                       const int32_t* deps, const int32_t* cls, int n_queues, int32_t* queue, float* start_us,
+                                       float* end_us, int32_t* order) {
+  B2T_REQUIRE(n_tasks >= 0 && n_queues >= 1 && n_queues <= 8 && (n_tasks == 0 || (est_us && qmask && dep_off && cls && queue && start_us && end_us && order)),
+              "plan_admission_host: bad arguments");
+  Plan P;
+  for (int i = 0; i < n_tasks; ++i) {
+    B2T_REQUIRE(est_us[i] >= 0.f && dep_off[i] <= dep_off[i + 1], "plan_admission_host: task %d: negative estimate / bad dependency offsets", i);
+    const int t = P.add("task", est_us[i], qmask[i], {}, nullptr);
+    P.t[t].cls = cls[i];
+    for (int k = dep_off[i]; k < dep_off[i + 1]; ++k) {
+      B2T_REQUIRE(deps && deps[k] >= 0 && deps[k] < i, "plan_admission_host: task %d depends on %d (tasks must be listed in topological order)", i, deps ? deps[k] : -1);
+      P.dep(t, deps[k]);
+    }
+  }
+  if (n_queues > 1) add_admission_edges(P, schedule_plan(P, n_queues));
+  const std::vector<int> ord = schedule_plan(P, n_queues);
+  for (int i = 0; i < n_tasks; ++i) { queue[i] = P.t[i].q; start_us[i] = P.t[i].start; end_us[i] = P.t[i].end; order[i] = ord[i]; }
   return 0;
 }
 
@@ -565,6 +612,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   int chunks[MAXC][2];
   const int nc = make_chunks(Tp, p->chunks, chunks);
   c.exact_k = nc > 1;
+  c.nq = plan_queues(c, nc > 1, c.qs);   // the queues of this pass (the plan below refers to them by index)
   const long long a_s0_l0 = prm->patch > 0 ? (long long)prm->stride * F : F;
   // rows x K that b2t_gemm_f32 serves with its skinny (weight-streaming) kernel: exact fp32 only, one frame of <= 64 utterances
   auto skinny = [&](long long rows, int K) { return !c.bf16_gemm && !c.exact_k && rows <= 64 && K % 16 == 0; };
@@ -659,6 +707,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
                                      (mode & B2T_GRU_LOCAL) ? (mode | ((l & 1) ? B2T_GRU_PARITY : 0)) : mode, sync_of(l),
                                      reinterpret_cast<void*>(ss)));
       });
+      if (mode & B2T_GRU_LOCAL) P.t[t_sw[l][ci]].cls = l & 1;   // XCD set by layer parity: admission-controlled (run_plan)
     }
   }
   // 4. head: logits[b,t,:] = out W^T + b  (rnn_model.py:129), written batch-first
@@ -673,7 +722,6 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
     const int t_end = P.add("end", 0.f, Q_MAIN, {t_head}, nullptr);
     for (int l = 0; l + 1 < L; ++l) P.dep(t_end, t_sw[l][nc - 1]);
   }
-  c.nq = plan_queues(c, nc > 1, c.qs);
   run_plan(c, P, c.nq, c.qs);
   return c.rc;
 }
@@ -778,6 +826,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   int chunks[MAXC][2];
   const int nc = make_chunks(Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks, chunks);
   c.exact_k = nc > 1;
+  c.nq = plan_queues(c, nc > 1, c.qs);   // the queues of this pass (the plan below refers to them by index)
   // (One chunk -- shapes whose sweeps cannot be co-resident, e.g. H = 768 -- runs everything on the caller's stream.  Putting
   // the weight-gradient GEMMs of layer l on a side stream under the sweep of layer l - 1 was measured: C3 fp32 19.7 -> 23.0 ms,
   // bf16 operands 12.7 -> 15.1 ms: a 768-unit sweep workgroup needs a CU's whole register file, and GEMM workgroups that
@@ -873,6 +922,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
                                      w.dG[l] + (long long)t0 * B * 4 * H, dh_out, w.scratch[l], n, B, H,
                                      (mode & B2T_GRU_LOCAL) ? (mode | ((l & 1) ? B2T_GRU_PARITY : 0)) : mode, sync_of(l), ssp));
       });
+      if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
       t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1},
@@ -923,7 +973,6 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     for (int l = 0; l < L; ++l) { P.dep(t_end, t_wg_last[l]); P.dep(t_end, t_dx[l][0]); }
     P.dep(t_end, t_top);
   }
-  c.nq = plan_queues(c, nc > 1, c.qs);
   run_plan(c, P, c.nq, c.qs);
   return c.rc;
 }

@@ -127,3 +127,80 @@ def test_rejects_non_topological_input():
     P = lambda a: a.ctypes.data_as(C.c_void_p)
     assert lib.b2t_plan_schedule_host(2, P(est), P(qm), P(off), P(deps), 4, P(q), P(s), P(o)) != 0
     assert "topological" in N.last_error()
+
+
+def schedule_admission(est, deps, cls, nq):
+    lib = N.load()
+    n = len(est)
+    est = np.asarray(est, np.float32)
+    qm = np.full(n, 0xffffffff, np.uint32)
+    off = np.zeros(n + 1, np.int32)
+    flat = []
+    for i, d in enumerate(deps):
+        flat += list(d); off[i + 1] = len(flat)
+    flat = np.asarray(flat if flat else [0], np.int32)
+    cl = np.asarray(cls, np.int32)
+    q = np.zeros(n, np.int32); start = np.zeros(n, np.float32); end = np.zeros(n, np.float32); order = np.zeros(n, np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    N.check(lib.b2t_plan_admission_host(n, P(est), P(qm), P(off), P(flat), P(cl), nq, P(q), P(start), P(end), P(order)),
+            "b2t_plan_admission_host")
+    return q, start, end, order
+
+
+def _wavefront(L, nc, sweep_us, gemm_us):
+    """The forward pass's shape: sweep (l, c) after its projection gi (l, c) and after sweep (l, c-1); gi (l, c) after sweep
+    (l-1, c).  Returns est, deps, cls (layer parity for the sweeps, -1 for the GEMMs)."""
+    est, deps, cls, sw = [], [], [], {}
+    for l in range(L):
+        for c in range(nc):
+            est.append(gemm_us); deps.append([sw[(l - 1, c)]] if l > 0 else []); cls.append(-1)
+            gi = len(est) - 1
+            est.append(sweep_us); deps.append([gi] + ([sw[(l, c - 1)]] if c > 0 else [])); cls.append(l & 1)
+            sw[(l, c)] = len(est) - 1
+    return est, deps, cls
+
+
+@pytest.mark.parametrize("L,nc,sweep_us,gemm_us", [(5, 6, 450.0, 120.0), (5, 4, 800.0, 60.0), (7, 8, 300.0, 10.0), (3, 6, 500.0, 100.0), (8, 3, 200.0, 400.0)])
+def test_admission_never_more_than_two_of_a_class_in_flight(L, nc, sweep_us, gemm_us):
+    """Sweeps of one layer parity share an XCD set that holds the row groups of exactly two sweeps (exec.cpp: admission edges).
+    In the planned schedule of the wavefront no instant has three sweeps of a parity running -- without the edges five layers
+    put layers 0, 2 and 4 in flight together -- and, by construction (k-th waits for the (k-2)-th to FINISH), neither can
+    the executed one.  The schedule stays valid: dependencies, hops, in-order queues."""
+    est, deps, cls = _wavefront(L, nc, sweep_us, gemm_us)
+    q, start, end, order = schedule_admission(est, deps, cls, 4)
+    n = len(est)
+    pos = np.empty(n, int); pos[order] = np.arange(n)
+    for i in range(n):
+        for d in deps[i]:
+            assert pos[d] < pos[i] and start[i] + 1e-3 >= end[d] + (HOP if q[d] != q[i] else 0.0)
+    for qq in range(4):
+        ids = [i for i in order if q[i] == qq]
+        for a, b in zip(ids, ids[1:]):
+            assert start[b] + 1e-3 >= end[a]
+    for k in (0, 1):
+        ids = sorted((i for i in range(n) if cls[i] == k), key=lambda i: (start[i], i))
+        for a, b in zip(ids, ids[2:]):
+            assert start[b] + 1e-3 >= end[a], f"class {k}: task {b} planned to start while {a} and its successor are still in flight"
+        events = sorted([(start[i], 1) for i in ids] + [(end[i] - 1e-3, -1) for i in ids])
+        live = peak = 0
+        for _, dlt in events:
+            live += dlt; peak = max(peak, live)
+        assert peak <= 2
+    if L >= 5 and gemm_us < sweep_us:      # the unconstrained plan does overlap three of a parity (what the edges are for)
+        q0, s0, o0 = schedule(est, deps, 4)
+        e0 = s0 + np.asarray(est, np.float32)
+        ids = [i for i in range(n) if cls[i] == 0]
+        ev = sorted([(s0[i], 1) for i in ids] + [(e0[i] - 1e-3, -1) for i in ids])
+        live = peak = 0
+        for _, dlt in ev:
+            live += dlt; peak = max(peak, live)
+        assert peak >= 2
+
+
+def test_admission_without_classes_is_the_plain_schedule():
+    est = [0.0] + [100.0] * 4 + [0.0]
+    deps = [[]] + [[0]] * 4 + [[1, 2, 3, 4]]
+    q, start, order = schedule(est, deps, 4)
+    q2, start2, end2, order2 = schedule_admission(est, deps, [-1] * 6, 4)
+    assert q.tolist() == q2.tolist() and order.tolist() == order2.tolist()
+    np.testing.assert_allclose(start, start2)
