@@ -48,7 +48,7 @@ def run(n):
 
 
 def main():
-    n0, n1 = 40, 160
+    n0, n1 = 40, int(os.environ.get("B2T_TRAINER_STEPS", "160"))
     run(12)                                   # first touch: library load, queue calibration, allocator
     t0, _ = run(n0)
     t1, st = run(n1)
