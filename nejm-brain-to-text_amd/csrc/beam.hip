@@ -187,7 +187,41 @@ __device__ int trie_find_or_add(int parent, int token, int* par, int* tok, int* 
 // (0 copy, 1 copy + append t, 2 copy + overwrite last with t, 3 empty)
 struct TSrc { short h; char vec; char op; };
 
-__global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restrict__ logp, const int32_t* __restrict__ lens,
+// rank[ci] = number of keys larger than key[ci] (0 keys = invalid candidates get 1 << 20).  NP = candidates per thread.
+template <int NP>
+__device__ __forceinline__ void rank_by_counting(const unsigned long long* __restrict__ key, int* __restrict__ rank, int n) {
+  unsigned long long mine[NP];
+  int r[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int ci = (int)threadIdx.x + j * (int)blockDim.x;
+    mine[j] = ci < n ? key[ci] : ~0ull;     // nothing is larger than the padding
+    r[j] = 0;
+  }
+  int x = 0;
+  for (; x + 2 <= n; x += 2) {
+    const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(key + x);     // 16-byte aligned: the key array starts the dynamic LDS
+#pragma unroll
+    for (int j = 0; j < NP; ++j) r[j] += (k.x > mine[j]) + (k.y > mine[j]);
+  }
+  if (x < n) {
+    const unsigned long long k = key[x];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) r[j] += (k > mine[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int ci = (int)threadIdx.x + j * (int)blockDim.x;
+    if (ci < n) rank[ci] = mine[j] != 0ull ? r[j] : (1 << 20);
+  }
+}
+
+#ifdef B2T_BEAM_TIMING
+#define BT(i) { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bt_acc[i] += now_ - bt_prev; bt_prev = now_; } }
+#else
+#define BT(i)
+#endif
+__global__ __launch_bounds__(1024) void prefix_beam_kernel(const float* __restrict__ logp, const int32_t* __restrict__ lens,
                                                           int T, int C, int K, int beam, int blank,
                                                           unsigned char* state, size_t per_utt, int NN, int L,
                                                           int32_t* __restrict__ hyps, int32_t* __restrict__ hyp_len,
@@ -236,6 +270,8 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   __shared__ float cp[64];        // class log-probs of the frame; selection marks
   __shared__ int s_nb, s_cur, s_abs, s_nvalid;
   __shared__ int s_rk2ci[BMAX];
+  __shared__ int h_pidx[BMAX];                    // beam index of a hypothesis' parent prefix (-1: the parent is not in the beam)
+  __shared__ unsigned long long h_cmask[BMAX];    // tokens c for which prefix h + c is itself in the beam (C <= 64)
 
   if (tid == 0) {
     s_nb = hdr[0]; s_abs = hdr[1]; s_cur = hdr[3];
@@ -258,8 +294,12 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
   if (Tu > T) Tu = T;
   const float* lp_u = logp + (long long)u * T * C;
 
+#ifdef B2T_BEAM_TIMING
+  unsigned long long bt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bt_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int f = 0; f < Tu; ++f) {
     const int nb = s_nb, cur = s_cur, at = s_abs;
+    BT(0)
     // ---- 1. first beam: top-K classes of the frame (one wave; ties -> lowest class id) --------------
     if (tid < 64) {
       float v = tid < C ? lp_u[(long long)f * C + tid] : -INFINITY;
@@ -278,9 +318,21 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
     if (tid < nb) {
       h_score[tid] = log_add(h_s[tid], h_ns[tid]);
       h_vit[tid] = h_vs[tid] > h_vns[tid] ? h_vs[tid] : h_vns[tid];
+      h_cmask[tid] = 0ull;
+    }
+    __syncthreads();
+    // Who is whose parent, once per frame (trie nodes are unique in the beam): every candidate used to search the beam for
+    // its parent / for an existing child -- 100 LDS reads each, 110 k per beam-100 frame.
+    if (tid < nb) {
+      int hp = -1;
+      const int want = h_par[tid];
+      for (int x = 0; x < nb; ++x) if (h_node[x] == want) hp = x;
+      h_pidx[tid] = hp;
+      if (hp >= 0 && h_dep[tid] > 0 && h_tok[tid] >= 0 && h_tok[tid] < 64) atomicOr(&h_cmask[hp], 1ull << h_tok[tid]);
     }
     __syncthreads();
 
+    BT(1)   // top-K classes
     // ---- 2. candidates (gather form) --------------------------------------------------------------------
     const int ncand = nb * (K + 1);
     for (int ci = tid; ci < ncand; ci += blockDim.x) {
@@ -310,8 +362,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
           }
         }
         if (h_dep[h] > 0) {                              // extension of the parent prefix that lands on h
-          int hp = -1;
-          for (int x = 0; x < nb; ++x) if (h_node[x] == h_par[h]) hp = x;
+          const int hp = h_pidx[h];
           if (hp >= 0) {
             for (int k = 0; k < K; ++k) {
               if (tk_id[k] != last || last == blank) continue;
@@ -332,8 +383,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       } else {                                           // prefix h extended by class c (new prefix)
         const int c = tk_id[slot - 1]; const float p = tk_p[slot - 1];
         if (c != blank) {
-          bool merged = false;                           // already a live prefix: gathered by its "stay" slot
-          for (int x = 0; x < nb; ++x) merged |= (h_par[x] == h_node[h] && h_tok[x] == c && h_dep[x] > 0);
+          const bool merged = (h_cmask[h] >> c) & 1ull;   // already a live prefix: gathered by its "stay" slot
           // word-level mode: the extension must follow the pronunciation trie; SIL closes a word (or is free at the root)
           bool ok = true;
           if (lexm && !merged) {
@@ -382,18 +432,23 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
     }
     __syncthreads();
 
+    BT(2)   // candidates (+ LM)
     // ---- 3. second beam: rank by counting (ties -> lower candidate index), keep the best `beam` ---------
-    for (int ci = tid; ci < ncand; ci += blockDim.x) {
-      const unsigned long long mine = c_key[ci];
-      int r = 0;
-      int x = 0;
-      for (; x + 4 <= ncand; x += 4)
-        r += (c_key[x] > mine) + (c_key[x + 1] > mine) + (c_key[x + 2] > mine) + (c_key[x + 3] > mine);
-      for (; x < ncand; ++x) r += (c_key[x] > mine);
-      c_rank[ci] = mine != 0ull ? r : (1 << 20);
+    // (every thread keeps its candidates' keys in registers and streams over the key array ONCE, two keys per LDS read:
+    // with one pass over the array per candidate this phase was 47 % of a beam-100 frame)
+    switch ((ncand + (int)blockDim.x - 1) / (int)blockDim.x) {
+      case 0: break;
+      case 1: rank_by_counting<1>(c_key, c_rank, ncand); break;
+      case 2: rank_by_counting<2>(c_key, c_rank, ncand); break;
+      case 3: rank_by_counting<3>(c_key, c_rank, ncand); break;
+      case 4: rank_by_counting<4>(c_key, c_rank, ncand); break;
+      case 5: rank_by_counting<5>(c_key, c_rank, ncand); break;
+      case 6: rank_by_counting<6>(c_key, c_rank, ncand); break;
+      default: rank_by_counting<9>(c_key, c_rank, ncand); break;     // ncmax <= 128 * 17 = 2176 <= 9 * 256
     }
     __syncthreads();
 
+    BT(3)   // ranking
     // ---- 4. write survivors (sorted) into the other hypothesis buffer ------------------------------------
     HypBuf hc(st, lay, cur), hn(st, lay, cur ^ 1);
     if (tid < BMAX) s_rk2ci[tid] = -1;
@@ -420,6 +475,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       s_rk2ci[r] = ci;
     }
     __syncthreads();
+    BT(4)   // survivors: trie + scores
     // token-time vectors of the survivors: all threads share the copies (one element each) -- a survivor copying its
     // own two vectors serially was ~80 % of a frame's time (2 x depth dependent HBM round trips)
     {
@@ -440,6 +496,7 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
       }
     }
     __syncthreads();
+    BT(5)   // time vectors
     if (tid == 0) {
       const int cnt = s_nvalid;
       s_nb = cnt < beam ? cnt : beam; s_cur = cur ^ 1; s_abs = at + 1;
@@ -460,6 +517,12 @@ __global__ __launch_bounds__(256) void prefix_beam_kernel(const float* __restric
     __syncthreads();
   }
 
+#ifdef B2T_BEAM_TIMING
+  BT(6)
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("beam u0 cycles: topk %llu | candidates %llu | ranking %llu | survivors %llu | times %llu | reload %llu (loop head %llu)\n", bt_acc[1], bt_acc[2],
+           bt_acc[3], bt_acc[4], bt_acc[5], bt_acc[6], bt_acc[0]);
+#endif
   // ---- results: hypotheses (token sequences by walking the trie), scores, Viterbi times ------------------
   if (tid == 0) { hdr[0] = s_nb; hdr[1] = s_abs; hdr[3] = s_cur; }
   {
@@ -501,6 +564,14 @@ using namespace b2t;
 
 // candidate slots of a frame and the dynamic LDS they take (one 8-byte and 14 4-byte arrays)
 static int first_beam_ncmax(int first_beam, int second_beam) { return second_beam * (first_beam + 1); }
+// Threads of a search workgroup (one per utterance).  Every phase of a frame is a strided loop over beam * (K + 1) candidates or
+// over the survivors' time vectors, so wide beams take the full 1024 (beam 100: 0.80 -> 0.26 ms per utterance together with the
+// single-pass ranking and the per-frame parent / child tables); a narrow beam has nothing to spread and keeps 256.
+static int beam_threads(int second_beam) {
+  static const int env = getenv("B2T_BEAM_THREADS") ? atoi(getenv("B2T_BEAM_THREADS")) : 0;
+  if (env == 256 || env == 512 || env == 1024) return env;
+  return second_beam >= 64 ? 1024 : (second_beam >= 24 ? 512 : 256);
+}
 static size_t beam_cand_bytes(int first_beam, int second_beam) {   // <= 128 * 17 * 64 B = 139 KB of the CU's 160 KB
   const size_t b = (size_t)first_beam_ncmax(first_beam, second_beam) * 16 * 4;
   static size_t raised = 0;
@@ -534,7 +605,7 @@ extern "C" int b2t_prefix_beam_search_f32(const float* logp, const int32_t* lens
   if (first_beam > C) first_beam = C;
   B2T_REQUIRE(first_beam <= KMAX, "prefix_beam_search: first_beam_size <= %d", KMAX);
   BeamLayout lay(max_nodes, max_len);
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(beam_threads(second_beam)), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
                      vscore, times, LmArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
                      static_cast<float*>(nullptr), first_beam_ncmax(first_beam, second_beam));
@@ -556,7 +627,7 @@ extern "C" int b2t_prefix_beam_search_lm_f32(const float* logp, const int32_t* l
   if (first_beam > C) first_beam = C;
   B2T_REQUIRE(first_beam <= KMAX, "prefix_beam_search_lm: first_beam_size <= %d", KMAX);
   BeamLayout lay(max_nodes, max_len);
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(beam_threads(second_beam)), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
                      vscore, times,
                      LmArgs{lm_child, lm_logp, lm_bow, lm_suffix, lm_nstate, lm_vocab, lm_start_state, lm_eos, alpha, beta, unk_logp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0},
@@ -579,7 +650,7 @@ extern "C" int b2t_prefix_beam_search_lex_f32(const float* logp, const int32_t* 
   BeamLayout lay(max_nodes, max_len);
   LmArgs lm{nullptr, d->lm_logp, d->lm_bow, d->lm_suffix, d->lm_nstate, 0, d->lm_start_state, d->lm_eos, d->alpha, d->beta,
             d->unk_logp, d->lex_child, d->lex_wbeg, d->lex_wend, d->wlist, d->lm_cb, d->lm_ce, d->lm_ctok, d->lm_cnode, d->sil};
-  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(256), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
+  hipLaunchKernelGGL(prefix_beam_kernel, dim3(U), dim3(beam_threads(second_beam)), beam_cand_bytes(first_beam, second_beam), as_stream(stream), logp, lens, T, C, first_beam, second_beam,
                      blank, reinterpret_cast<unsigned char*>(state), lay.total, max_nodes, max_len, hyps, hyp_len, score,
                      vscore, times, lm, lm_score, first_beam_ncmax(first_beam, second_beam));
   B2T_CHECK_LAUNCH("b2t_prefix_beam_search_lex_f32");
