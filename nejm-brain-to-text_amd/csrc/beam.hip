@@ -187,32 +187,39 @@ __device__ int trie_find_or_add(int parent, int token, int* par, int* tok, int* 
 // (0 copy, 1 copy + append t, 2 copy + overwrite last with t, 3 empty)
 struct TSrc { short h; char vec; char op; };
 
-// rank[ci] = number of keys larger than key[ci] (0 keys = invalid candidates get 1 << 20).  NP = candidates per thread.
+// rank[ci] = number of keys larger than key[ci] (0 keys = invalid candidates get 1 << 20).  The workgroup is split into
+// blockDim / 256 parts: a thread keeps NP candidates' keys in registers (candidates lane, lane + 256, ...) and streams over ITS
+// part's share of the key array, two keys per LDS read; the partial counts meet in LDS atomics.
 template <int NP>
 __device__ __forceinline__ void rank_by_counting(const unsigned long long* __restrict__ key, int* __restrict__ rank, int n) {
+  const int lane = (int)threadIdx.x & 255, part = (int)threadIdx.x >> 8, nparts = ((int)blockDim.x + 255) >> 8;
+  for (int ci = (int)threadIdx.x; ci < n; ci += (int)blockDim.x) rank[ci] = key[ci] != 0ull ? 0 : (1 << 20);
+  __syncthreads();
   unsigned long long mine[NP];
   int r[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    const int ci = (int)threadIdx.x + j * (int)blockDim.x;
+    const int ci = lane + j * 256;
     mine[j] = ci < n ? key[ci] : ~0ull;     // nothing is larger than the padding
     r[j] = 0;
   }
-  int x = 0;
-  for (; x + 2 <= n; x += 2) {
-    const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(key + x);     // 16-byte aligned: the key array starts the dynamic LDS
+  const int pairs = n >> 1, per = (pairs + nparts - 1) / nparts;
+  const int p0 = part * per, p1 = min(pairs, p0 + per);
+#pragma unroll 2
+  for (int x = p0; x < p1; ++x) {
+    const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(key + 2 * x);     // 16-byte aligned: the key array starts the dynamic LDS
 #pragma unroll
     for (int j = 0; j < NP; ++j) r[j] += (k.x > mine[j]) + (k.y > mine[j]);
   }
-  if (x < n) {
-    const unsigned long long k = key[x];
+  if ((n & 1) && part == nparts - 1) {
+    const unsigned long long k = key[n - 1];
 #pragma unroll
     for (int j = 0; j < NP; ++j) r[j] += (k > mine[j]);
   }
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    const int ci = (int)threadIdx.x + j * (int)blockDim.x;
-    if (ci < n) rank[ci] = mine[j] != 0ull ? r[j] : (1 << 20);
+    const int ci = lane + j * 256;
+    if (ci < n && mine[j] != 0ull && r[j]) atomicAdd(&rank[ci], r[j]);
   }
 }
 
@@ -434,9 +441,9 @@ __global__ __launch_bounds__(1024) void prefix_beam_kernel(const float* __restri
 
     BT(2)   // candidates (+ LM)
     // ---- 3. second beam: rank by counting (ties -> lower candidate index), keep the best `beam` ---------
-    // (every thread keeps its candidates' keys in registers and streams over the key array ONCE, two keys per LDS read:
-    // with one pass over the array per candidate this phase was 47 % of a beam-100 frame)
-    switch ((ncand + (int)blockDim.x - 1) / (int)blockDim.x) {
+    // (every thread keeps its candidates' keys in registers and streams over a share of the key array once, two keys per LDS
+    // read: with one pass over the whole array per candidate this phase was 47 % of a beam-100 frame)
+    switch ((ncand + 255) / 256) {
       case 0: break;
       case 1: rank_by_counting<1>(c_key, c_rank, ncand); break;
       case 2: rank_by_counting<2>(c_key, c_rank, ncand); break;
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(1024) void prefix_beam_kernel(const float* __restri
       case 4: rank_by_counting<4>(c_key, c_rank, ncand); break;
       case 5: rank_by_counting<5>(c_key, c_rank, ncand); break;
       case 6: rank_by_counting<6>(c_key, c_rank, ncand); break;
-      default: rank_by_counting<9>(c_key, c_rank, ncand); break;     // ncmax <= 128 * 17 = 2176 <= 9 * 256
+      default: rank_by_counting<9>(c_key, c_rank, ncand); break;     // ncmax <= 128 * 17 = 2176 <= 9 * 256 candidates
     }
     __syncthreads();
 
@@ -565,7 +572,7 @@ using namespace b2t;
 // candidate slots of a frame and the dynamic LDS they take (one 8-byte and 14 4-byte arrays)
 static int first_beam_ncmax(int first_beam, int second_beam) { return second_beam * (first_beam + 1); }
 // Threads of a search workgroup (one per utterance).  Every phase of a frame is a strided loop over beam * (K + 1) candidates or
-// over the survivors' time vectors, so wide beams take the full 1024 (beam 100: 0.80 -> 0.26 ms per utterance together with the
+// over the survivors' time vectors, so wide beams take the full 1024 (beam 100: 0.80 -> 0.20 ms per utterance together with the
 // single-pass ranking and the per-frame parent / child tables); a narrow beam has nothing to spread and keeps 256.
 static int beam_threads(int second_beam) {
   static const int env = getenv("B2T_BEAM_THREADS") ? atoi(getenv("B2T_BEAM_THREADS")) : 0;
