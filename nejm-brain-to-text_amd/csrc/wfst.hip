@@ -104,6 +104,8 @@ struct Opts {
 #define WT(i)
 #endif
 
+constexpr int WL_CAP = 4096;   // work-list capacity (a frame that has more tokens with epsilon arcs scans all its tokens, as before)
+
 struct Ctx {
 #ifdef B2T_WFST_TIMING
   unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -113,7 +115,8 @@ struct Ctx {
   int* key; int* idx;          // the frame's hash (LDS or HBM)
   float* ll;                   // LDS: acoustic_scale * logp of the frame
   float* redf; int* redi;      // LDS reduction scratch [NT]
-  int* sh;                     // LDS scalars: [0] n_tok, [1] n_link, [2] changed, [3] overflow
+  int* sh;                     // LDS scalars: [0] n_tok, [1] n_link, [2] changed, [3] overflow, [4] work-list length, [5] tokens scanned so far, [6] work list overflowed
+  int* wl;                     // LDS [WL_CAP]: the frame's tokens whose state has epsilon arcs (ProcessNonemitting's work list)
 };
 
 // Block reductions: within a wave through lane permutes, across the NT / 64 waves through LDS -- two barriers instead
@@ -235,21 +238,42 @@ __device__ __forceinline__ int find(Ctx& c, int state) {
   return -1;
 }
 
-// ProcessNonemitting over the tokens [n0, ...) of the frame being built + generation of their epsilon links
+// ProcessNonemitting over the tokens [n0, ...) of the frame being built + generation of their epsilon links.
+// Only the tokens of states WITH epsilon arcs matter (word ends: a few hundred of a frame's thousands), and the closure takes
+// several Bellman-Ford rounds of two passes each: the tokens are classified once (token -> state -> n_eps, two dependent
+// gathers) into an LDS work list that grows as the closure creates tokens; the rounds walk the list.
 __device__ void nonemitting(Ctx& c, int n0, float cutoff) {
   const Graph& g = c.g;
-  for (;;) {
+  __syncthreads();
+  if (threadIdx.x == 0) { c.sh[4] = 0; c.sh[5] = n0; c.sh[6] = 0; }
+  auto extend = [&]() {                       // classify the tokens created since the last call (ends with a barrier)
     __syncthreads();
+    const int from = c.sh[5], upto = min(c.sh[0], c.max_tok);
+    for (int t = from + threadIdx.x; t < upto; t += NT) {
+      if (g.n_eps[c.l.tok_state[t]] == 0) continue;
+      const int i = atomicAdd(&c.sh[4], 1);
+      if (i < WL_CAP) c.wl[i] = t; else c.sh[6] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) c.sh[5] = upto;
+    __syncthreads();
+    return upto;
+  };
+  auto for_each = [&](int n_now, auto&& body) {   // body(t) for every token of [n0, n_now) whose state has epsilon arcs
+    if (c.sh[6]) { for (int t = n0 + threadIdx.x; t < n_now; t += NT) body(t); }
+    else { const int n = c.sh[4]; for (int i = threadIdx.x; i < n; i += NT) body(c.wl[i]); }
+  };
+  for (;;) {
+    const int n_now = extend();
     if (threadIdx.x == 0) c.sh[2] = 0;
     __syncthreads();
-    const int n_now = min(c.sh[0], c.max_tok);
     for (int phase = 0; phase < 2; ++phase) {
-      for (int t = n0 + threadIdx.x; t < n_now; t += NT) {
+      for_each(n_now, [&](int t) {
         const int s = c.l.tok_state[t];
         const int ne = g.n_eps[s];
-        if (ne == 0) continue;
+        if (ne == 0) return;
         const float cur = o2f(c.l.tok_cost[t]);
-        if (!(cur < cutoff)) continue;
+        if (!(cur < cutoff)) return;
         const int a0 = g.row[s];
         for (int a = a0; a < a0 + ne; ++a) {
           const float tot = cur + g.weight[a];
@@ -266,19 +290,19 @@ __device__ void nonemitting(Ctx& c, int n0, float cutoff) {
             }
           }
         }
-      }
+      });
       __syncthreads();
     }
     if (c.sh[2] == 0) break;
   }
   // forward links of the epsilon arcs, with the converged costs
-  const int n_now = min(c.sh[0], c.max_tok);
-  for (int t = n0 + threadIdx.x; t < n_now; t += NT) {
+  const int n_now = extend();
+  for_each(n_now, [&](int t) {
     const int s = c.l.tok_state[t];
     const int ne = g.n_eps[s];
-    if (ne == 0) continue;
+    if (ne == 0) return;
     const float cur = o2f(c.l.tok_cost[t]);
-    if (!(cur < cutoff)) continue;
+    if (!(cur < cutoff)) return;
     const int a0 = g.row[s];
     for (int a = a0; a < a0 + ne; ++a) {
       const float tot = cur + g.weight[a];
@@ -293,7 +317,7 @@ __device__ void nonemitting(Ctx& c, int n0, float cutoff) {
         }
       }
     }
-  }
+  });
   __syncthreads();
 }
 
@@ -466,11 +490,11 @@ __device__ void advance(Ctx& c) {
 }
 
 __device__ void setup(Ctx& c, const Graph& g, char* state, int u, size_t state_bytes, const Opts& o, int max_frames, int max_tok,
-                      int max_link, int hash, int* smem_hash, float* ll, float* redf, int* redi, int* sh) {
+                      int max_link, int hash, int* smem_hash, float* ll, float* redf, int* redi, int* sh, int* wl) {
   c.g = g; c.o = o; c.max_frames = max_frames; c.max_tok = max_tok; c.max_link = max_link; c.hash = hash;
   layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &c.l);
   if (smem_hash) { c.key = smem_hash; c.idx = smem_hash + hash; } else { c.key = c.l.gkey; c.idx = c.l.gidx; }
-  c.ll = ll; c.redf = redf; c.redi = redi; c.sh = sh;
+  c.ll = ll; c.redf = redf; c.redi = redi; c.sh = sh; c.wl = wl;
 }
 
 }  // namespace
@@ -479,9 +503,9 @@ __global__ __launch_bounds__(NT) void wfst_reset_kernel(Graph g, char* state, si
                                                          int max_tok, int max_link, int hash, int use_lds) {
   extern __shared__ int dyn[];
   __shared__ float ll[MAX_C], redf[NT];
-  __shared__ int redi[NT], sh[8];
+  __shared__ int redi[NT], sh[8], wl[WL_CAP];
   Ctx c;
-  setup(c, g, state, blockIdx.x, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
+  setup(c, g, state, blockIdx.x, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh, wl);
   init_decoding(c);
 }
 
@@ -491,11 +515,11 @@ __global__ __launch_bounds__(NT) void wfst_search_kernel(Graph g, char* state, s
                                                           const float* __restrict__ logp, const int* __restrict__ lens, int T, int C) {
   extern __shared__ int dyn[];
   __shared__ float ll[MAX_C], redf[NT];
-  __shared__ int redi[NT], sh[8];
+  __shared__ int redi[NT], sh[8], wl[WL_CAP];
   __shared__ int dec[2];
   Ctx c;
   const int u = blockIdx.x;
-  setup(c, g, state, u, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh);
+  setup(c, g, state, u, state_bytes, o, max_frames, max_tok, max_link, hash, use_lds ? dyn : nullptr, ll, redf, redi, sh, wl);
   if (threadIdx.x == 0) { sh[0] = c.l.h->n_tok; sh[1] = c.l.h->n_link; sh[2] = 0; sh[3] = c.l.h->overflow; }
   __syncthreads();
   const int n = lens ? min(lens[u], T) : T;
