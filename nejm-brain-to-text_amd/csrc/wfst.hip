@@ -399,7 +399,7 @@ __device__ void advance(Ctx& c) {
   auto arc_cost = [&](float cur, int s, int a, float& ac, float& gc) {
     ac = cost_offset - c.ll[g.ilabel[a] - 1];
     gc = g.weight[a];
-    if (g.next[a] != s) gc += lp;
+    if (lp != 0.f && g.next[a] != s) gc += lp;     // (no gather of the destination when there is no length penalty)
     return cur + ac + gc;
   };
   const int lane = threadIdx.x & 63;
