@@ -4,12 +4,17 @@
 // definition computed directly: subset construction over the word labels (a determinised state is a set of lattice states
 // with their best cost so far), expanded best-first with the exact backward cost as the bound, so that sequences come
 // out in order of total cost and the search stops after `nbest` of them or at `beam` above the best.
-// Runs once per utterance on a lattice of a few thousand arcs; the per-frame hot loop is csrc/wfst.hip.
+// Runs once per utterance (lattices reach 10^5 arcs); the per-frame hot loop is csrc/wfst.hip.
+// A determinised state is kept as two parallel vectors in insertion order (deterministic iteration, unlike a hash map's) and
+// membership is a scratch array over the lattice states, marked while one subset is being built: no hashing, no node
+// allocations, no subset copies (first version with std::unordered_map subsets: 135 ms for a 175 k-arc lattice, now ~1/4).
 #include <algorithm>
 #include <queue>
-#include <unordered_map>
 #include <vector>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -17,7 +22,8 @@ namespace {
 struct Arc { int il, ol, dst; float g, a; };
 struct Entry { double tot, gr, ac; int ali; };          // ali: node of the alignment list (-1 = empty)
 struct Node { int parent, label; };
-typedef std::unordered_map<int, Entry> Subset;
+struct Subset { std::vector<int> st; std::vector<Entry> en; };   // lattice states and their best entries, insertion order
+struct Trans { int ol, dst; double tot, gr, ac; int ali, il; };   // a word arc out of a subset
 
 struct Item {
   double bound; int kind; long long tie; int words; int payload;   // kind 0: subset (payload = index), 1: finished (payload = index)
@@ -40,6 +46,7 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
     return -1;
   }
   const double INF = INFINITY;
+  const auto tm_in = std::chrono::steady_clock::now();
   // CSR adjacency both ways (lattices reach 10^5 arcs: no per-state vectors)
   std::vector<int> out_off(n_states + 1, 0), rev_off(n_states + 1, 0);
   for (int i = 0; i < n_arcs; ++i) {
@@ -58,7 +65,29 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   }
   std::vector<double> fin(n_states, INF), beta(n_states, INF);
   for (int i = 0; i < n_final; ++i) fin[final_state[i]] = std::min(fin[final_state[i]], (double)final_cost[i]);
-  {   // beta: cheapest completion incl. the final cost (arc costs are >= 0 once the per-frame offsets are taken out)
+  // beta: cheapest completion incl. the final cost (arc costs are >= 0 once the per-frame offsets are taken out).  The
+  // lattice is acyclic, so one relaxation sweep in reverse topological order (Kahn, O(states + arcs)) gives it; should a
+  // cycle of epsilon arcs ever leave states unordered, Dijkstra below takes over.
+  bool have_beta = false;
+  {
+    std::vector<int> pending(n_states);
+    for (int s = 0; s < n_states; ++s) pending[s] = out_off[s + 1] - out_off[s];
+    std::vector<int> order; order.reserve(n_states);
+    for (int s = 0; s < n_states; ++s) if (pending[s] == 0) order.push_back(s);
+    for (int s = 0; s < n_states; ++s) beta[s] = fin[s];
+    for (size_t h = 0; h < order.size(); ++h) {
+      const int s = order[h];
+      for (int k = rev_off[s]; k < rev_off[s + 1]; ++k) {
+        const std::pair<int, double>& pr = rev_arc[k];
+        const double c = beta[s] + pr.second;
+        if (c < beta[pr.first]) beta[pr.first] = c;
+        if (--pending[pr.first] == 0) order.push_back(pr.first);
+      }
+    }
+    have_beta = (int)order.size() == n_states;
+    if (!have_beta) std::fill(beta.begin(), beta.end(), INF);
+  }
+  if (!have_beta) {
     typedef std::pair<double, int> P;
     std::priority_queue<P, std::vector<P>, std::greater<P>> pq;
     for (int s = 0; s < n_states; ++s) if (fin[s] != INF) { beta[s] = fin[s]; pq.push({fin[s], s}); }
@@ -72,30 +101,36 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       }
     }
   }
+  static const bool lat_timing = getenv("B2T_LAT_TIMING") != nullptr;
+  const auto tm0 = std::chrono::steady_clock::now();
   w_off[0] = 0; a_off[0] = 0;
   if (beta[start] == INF) return 0;
   const double limit = beta[start] + beam + 1e-4;
   std::vector<Node> ali_pool, word_pool;
   auto push_node = [](std::vector<Node>& pool, int parent, int label) { pool.push_back(Node{parent, label}); return (int)pool.size() - 1; };
 
-  auto closure = [&](Subset& sub) {
+  std::vector<int> slot(n_states, -1);     // index of a lattice state in the subset under construction
+  auto mark = [&](const Subset& sub) { for (size_t i = 0; i < sub.st.size(); ++i) slot[sub.st[i]] = (int)i; };
+  auto unmark = [&](const Subset& sub) { for (int st : sub.st) slot[st] = -1; };
+  auto closure = [&](Subset& sub) {        // epsilon-output closure, cheapest first (sub's states are marked on entry and on exit)
     typedef std::pair<double, int> P;
     std::priority_queue<P, std::vector<P>, std::greater<P>> pq;
-    for (auto& kv : sub) pq.push({kv.second.tot, kv.first});
+    for (size_t i = 0; i < sub.st.size(); ++i) pq.push({sub.en[i].tot, sub.st[i]});
     while (!pq.empty()) {
       P t = pq.top(); pq.pop();
-      const Entry e = sub[t.second];
+      const Entry e = sub.en[slot[t.second]];
       if (t.first > e.tot) continue;
       for (int k = out_off[t.second]; k < out_off[t.second + 1]; ++k) {
         const Arc& a = out_arc[k];
         if (a.ol != 0) continue;
         const double nt = e.tot + a.g + a.a;
         if (nt + beta[a.dst] > limit) continue;
-        auto it = sub.find(a.dst);
-        if (it == sub.end() || nt < it->second.tot) {
-          sub[a.dst] = Entry{nt, e.gr + a.g, e.ac + a.a, a.il ? push_node(ali_pool, e.ali, a.il) : e.ali};
-          pq.push({nt, a.dst});
-        }
+        const int j = slot[a.dst];
+        if (j >= 0 && !(nt < sub.en[j].tot)) continue;
+        const Entry ne{nt, e.gr + a.g, e.ac + a.a, a.il ? push_node(ali_pool, e.ali, a.il) : e.ali};
+        if (j < 0) { slot[a.dst] = (int)sub.st.size(); sub.st.push_back(a.dst); sub.en.push_back(ne); }
+        else sub.en[j] = ne;
+        pq.push({nt, a.dst});
       }
     }
   };
@@ -104,10 +139,10 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   std::vector<Subset> subsets;
   std::vector<Done> finished;
   std::priority_queue<Item> pq;
+  std::vector<Trans> trans;
   long long tie = 0;
   subsets.emplace_back();
-  subsets[0][start] = Entry{0.0, 0.0, 0.0, -1};
-  closure(subsets[0]);
+  subsets[0].st.push_back(start); subsets[0].en.push_back(Entry{0.0, 0.0, 0.0, -1});
   pq.push(Item{beta[start], 0, tie++, -1, 0});
   int n_out = 0;
   while (!pq.empty() && n_out < nbest) {
@@ -128,38 +163,59 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       ++n_out;
       continue;
     }
-    const Subset sub = subsets[it.payload];   // (copy: `subsets` grows below)
+    // A subset is expanded once: take it out (`subsets` grows below).  Its epsilon-output closure is computed only now: the
+    // bound it was queued with, min (cost so far + backward cost) over its entries, does not need it -- the backward cost of
+    // an entry already is the cheapest way on through the closure -- and four of five queued subsets are never popped.
+    Subset sub = std::move(subsets[it.payload]);
+    mark(sub); closure(sub); unmark(sub);
     bool has = false; Done best{INF, 0, 0, it.words, -1};
-    for (auto& kv : sub) {
-      if (fin[kv.first] == INF) continue;
-      const double c = kv.second.tot + fin[kv.first];
-      if (c < best.tot) { best = Done{c, kv.second.gr + fin[kv.first], kv.second.ac, it.words, kv.second.ali}; has = true; }
+    for (size_t i = 0; i < sub.st.size(); ++i) {
+      const int st = sub.st[i];
+      if (fin[st] == INF) continue;
+      const Entry& e = sub.en[i];
+      const double c = e.tot + fin[st];
+      if (c < best.tot) { best = Done{c, e.gr + fin[st], e.ac, it.words, e.ali}; has = true; }
     }
     if (has && best.tot <= limit) { finished.push_back(best); pq.push(Item{best.tot, 1, tie++, it.words, (int)finished.size() - 1}); }
-    std::unordered_map<int, Subset> by_word;
-    for (auto& kv : sub) {
-      for (int k = out_off[kv.first]; k < out_off[kv.first + 1]; ++k) {
+    // the word arcs out of the subset, grouped by word (ascending label: deterministic expansion order; within a word in
+    // the order the subset and the lattice list them)
+    trans.clear();
+    for (size_t i = 0; i < sub.st.size(); ++i) {
+      const Entry& e = sub.en[i];
+      for (int k = out_off[sub.st[i]]; k < out_off[sub.st[i] + 1]; ++k) {
         const Arc& a = out_arc[k];
         if (a.ol == 0) continue;
-        const double nt = kv.second.tot + a.g + a.a;
+        const double nt = e.tot + a.g + a.a;
         if (nt + beta[a.dst] > limit) continue;
-        Subset& tgt = by_word[a.ol];
-        auto f = tgt.find(a.dst);
-        if (f == tgt.end() || nt < f->second.tot)
-          tgt[a.dst] = Entry{nt, kv.second.gr + a.g, kv.second.ac + a.a, a.il ? push_node(ali_pool, kv.second.ali, a.il) : kv.second.ali};
+        trans.push_back(Trans{a.ol, a.dst, nt, e.gr + a.g, e.ac + a.a, e.ali, a.il});
       }
     }
-    std::vector<int> labels;
-    for (auto& kv : by_word) labels.push_back(kv.first);
-    std::sort(labels.begin(), labels.end());          // deterministic expansion order
-    for (int ol : labels) {
-      Subset& tgt = by_word[ol];
-      closure(tgt);
+    std::stable_sort(trans.begin(), trans.end(), [](const Trans& x, const Trans& y) { return x.ol < y.ol; });
+    for (size_t g0 = 0; g0 < trans.size();) {
+      size_t g1 = g0;
+      while (g1 < trans.size() && trans[g1].ol == trans[g0].ol) ++g1;
+      Subset tgt;
+      for (size_t q = g0; q < g1; ++q) {
+        const Trans& tr = trans[q];
+        const int j = slot[tr.dst];
+        if (j >= 0 && !(tr.tot < tgt.en[j].tot)) continue;
+        const Entry ne{tr.tot, tr.gr, tr.ac, tr.il ? push_node(ali_pool, tr.ali, tr.il) : tr.ali};
+        if (j < 0) { slot[tr.dst] = (int)tgt.st.size(); tgt.st.push_back(tr.dst); tgt.en.push_back(ne); }
+        else tgt.en[j] = ne;
+      }
       double b = INF;
-      for (auto& kv : tgt) b = std::min(b, kv.second.tot + beta[kv.first]);
-      subsets.push_back(tgt);
+      for (size_t i = 0; i < tgt.st.size(); ++i) b = std::min(b, tgt.en[i].tot + beta[tgt.st[i]]);
+      unmark(tgt);
+      const int ol = trans[g0].ol;
+      subsets.push_back(std::move(tgt));
       pq.push(Item{b, 0, tie++, push_node(word_pool, it.words, ol), (int)subsets.size() - 1});
+      g0 = g1;
     }
+  }
+  if (lat_timing) {
+    size_t ents = 0; for (const Subset& x : subsets) ents += x.st.size();
+    fprintf(stderr, "lattice_nbest: setup (adjacency + backward costs) %.1f ms, main loop %.1f ms, %zu subsets created, %zu alignment nodes, %zu entries left in unexpanded subsets\n",
+            std::chrono::duration<double, std::milli>(tm0 - tm_in).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count(), subsets.size(), ali_pool.size(), ents);
   }
   return n_out;
 }
