@@ -185,12 +185,8 @@ class WfstSearch:
             if n < 0:
                 raise RuntimeError("b2t_lattice_nbest_host failed: " + N.last_error())
             mapping = mapping_all[u, :F]
-            res = []
-            for k in range(n):
-                ali = oa[aoff[k]:aoff[k + 1]]
-                inp, tm = convert_to_inputs(ali, mapping if len(ali) == F else np.arange(len(ali)))
-                res.append((inp, tm, [int(w) for w in ow[woff[k]:woff[k + 1]]], -float(costs[2 * k]), -float(costs[2 * k + 1])))
-            return res
+            inps, tms = convert_all_to_inputs(oa, aoff, n, mapping)
+            return [(inps[k], tms[k], ow[woff[k]:woff[k + 1]].tolist(), -float(costs[2 * k]), -float(costs[2 * k + 1])) for k in range(n)]
 
         # utterances are independent and the C call releases the GIL: one host thread per utterance up to the usable cores
         workers = min(self.U, _host_threads())
@@ -201,6 +197,38 @@ class WfstSearch:
 
     def _nbest_of(self, u, h, nbest=None):
         return self._nbest_all(nbest or self.nbest)[u]
+
+
+def convert_all_to_inputs(ali, off, n, mapping):
+    """convert_to_inputs for the n alignments ali[off[k]:off[k+1]] of one utterance in one vectorised pass (100 n-best entries
+    x ~100 frames in a Python loop per utterance were most of what was left of finalize): runs of equal labels, cut at the
+    entries' boundaries; a run of a non-blank label gives (label - 1, frame of the run's last position).  Frames come from
+    `mapping` (decoded frame -> input frame) for alignments that cover all decoded frames, else they are positions."""
+    inps, tms = [[] for _ in range(n)], [[] for _ in range(n)]
+    tot = int(off[n])
+    if n == 0 or tot == 0:
+        return inps, tms
+    a = np.asarray(ali[:tot])
+    offs = np.asarray(off[:n + 1], dtype=np.int64)
+    brk = np.empty(tot, dtype=bool)
+    brk[:-1] = a[1:] != a[:-1]
+    brk[-1] = True
+    last = offs[1:][offs[1:] > offs[:-1]] - 1        # last position of every non-empty entry
+    brk[last] = True
+    ends = np.flatnonzero(brk)
+    labs = a[ends]
+    keep = labs != 1                                  # ilabel 1 = blank
+    ends, labs = ends[keep], labs[keep] - 1
+    owner = np.searchsorted(offs[1:], ends, side="right")
+    pos = ends - offs[owner]
+    F = len(mapping)
+    full = (offs[1:] - offs[:-1]) == F
+    times = np.where(full[owner], np.asarray(mapping, dtype=np.int64)[np.minimum(pos, max(F - 1, 0))] if F else pos, pos)
+    cut = np.searchsorted(owner, np.arange(n + 1))
+    labs_l, times_l = labs.tolist(), times.tolist()
+    for k in range(n):
+        inps[k] = labs_l[cut[k]:cut[k + 1]]; tms[k] = times_l[cut[k]:cut[k + 1]]
+    return inps, tms
 
 
 def convert_to_inputs(alignment, frames):

@@ -229,3 +229,31 @@ def test_lr_schedules_host_side(golden_dir):
         np.testing.assert_allclose(0.005 * linear_lr_factor(i, 0.0001 / 0.005, tot), lrs[0], rtol=1e-12)
     for s_, fac in zip(z["steps"], z["factors"]):
         assert abs(cosine_lr_factor(int(s_), 0.0001 / 0.005, 120000, 1000) - fac[0]) < 1e-15
+
+
+def test_convert_all_to_inputs_matches_the_scalar_form():
+    """wfst_decoder.convert_all_to_inputs (one vectorised pass over an utterance's n-best alignments) against
+    convert_to_inputs (CtcWfstBeamSearch::ConvertToInputs, ctc_wfst_beam_search.cc:162-188) entry by entry: blanks dropped,
+    repeats merged, times of the runs' last positions, the frame map only for alignments that cover every decoded frame;
+    empty entries, entries that end in the label the next one starts with, all-blank entries."""
+    import numpy as np
+    from wfst_decoder import convert_all_to_inputs, convert_to_inputs
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        F = int(rng.integers(1, 40))
+        n = int(rng.integers(0, 12))
+        mapping = np.sort(rng.choice(200, size=F, replace=False)).astype(np.int32)
+        parts = []
+        for k in range(n):
+            kind = rng.integers(0, 6)
+            ln = F if kind < 3 else (0 if kind == 3 else int(rng.integers(1, 50)))
+            parts.append(rng.choice([1, 1, 1, 2, 2, 3, 7, 41], size=ln).astype(np.int32) if kind != 5 else np.ones(ln, np.int32))
+        off = np.zeros(n + 1, np.int32)
+        for k, pp in enumerate(parts):
+            off[k + 1] = off[k] + len(pp)
+        ali = np.concatenate(parts + [np.full(5, 9, np.int32)]) if parts else np.full(5, 9, np.int32)   # trailing garbage beyond off[n]
+        inps, tms = convert_all_to_inputs(ali, off, n, mapping)
+        assert len(inps) == n and len(tms) == n
+        for k, pp in enumerate(parts):
+            want = convert_to_inputs(pp, mapping if len(pp) == F else np.arange(len(pp)))
+            assert (inps[k], tms[k]) == (want[0], want[1]), (trial, k)
