@@ -405,6 +405,7 @@ class BrainToTextDecoder_Trainer:
         train_start_time = time.time()
         last_step = self.args['num_training_batches'] // self.world - 1
         pending = None      # (step, pinned stat copy, event, enqueue time)
+        stat_ring = [torch.empty(5, dtype=torch.float32).pin_memory() for _ in range(4)]   # pinned once, not once per step
 
         def drain():
             """Read the previous step's numbers (it has normally finished long ago)."""
@@ -435,7 +436,7 @@ class BrainToTextDecoder_Trainer:
             day_indicies = batch['day_indicies']
             features, n_time_steps = self.transform_data(features, n_time_steps, 'train')
             self.train_step.step(features, day_indicies, labels, n_time_steps, phone_seq_lens)
-            host = torch.empty(5, dtype=torch.float32).pin_memory()
+            host = stat_ring[i % len(stat_ring)]           # (read one step later: the slot is free again three steps on)
             host.copy_(self.train_step.stat, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
