@@ -257,3 +257,31 @@ def test_convert_all_to_inputs_matches_the_scalar_form():
         for k, pp in enumerate(parts):
             want = convert_to_inputs(pp, mapping if len(pp) == F else np.arange(len(pp)))
             assert (inps[k], tms[k]) == (want[0], want[1]), (trial, k)
+
+
+@pytest.mark.parametrize("cls,ctype", [("GemmDesc", "b2t_gemm_desc"), ("ModelDesc", "b2t_model_t"), ("PassDesc", "b2t_pass_t"),
+                                       ("WfstGraph", "b2t_wfst_graph_t"), ("WfstOpts", "b2t_wfst_opts_t"), ("LexLmDesc", "b2t_lexlm_t")])
+def test_struct_layouts_match_the_header(tmp_path, cls, ctype):
+    """The ctypes mirrors in b2t_native against the C compiler's view of include/b2t.h: size and the offset of every
+    (scalar or pointer) field -- a field added to one side only would silently shift everything behind it."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    import b2t_native as Nn
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    K = getattr(Nn, cls)
+    fields = [f[0] for f in K._fields_]
+    src = tmp_path / "lay.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "b2t.h"\nint main(void){ printf("%zu\\n", sizeof(' + ctype + '));\n' +
+                   "".join(f'printf("{f} %zu\\n", offsetof({ctype}, {f}));\n' for f in fields) + "return 0; }\n")
+    exe = tmp_path / "lay"
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert int(out[0]) == C.sizeof(K)
+    for line in out[1:]:
+        if line.strip():
+            name, off = line.split()
+            assert getattr(K, name).offset == int(off), name
