@@ -8,9 +8,14 @@ One "step" = one pass of the hot path over one synthetic minibatch already resid
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI), 64 sentences per rank
 (weak scaling), bucketed gradient all-reduce overlapped with the backward sweeps.
 
+Launch forms: `python bench.py --gpus N` with no launcher environment starts its N ranks itself (one child process
+per GPU, rendezvous on 127.0.0.1 and a free port); under `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N` the ranks come from the environment.  `--scaling strong` shards the SAME 64-sentence batch (64/N rows per
+rank, SURVEY 8e parity mode) instead of giving every rank its own 64 sentences.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
-timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle's numpy port of the
-same step, timed on this host's cores, rank 0 / N=1 only).
+timed live with HIP events on the launch stream) and `cpu_baseline` (the reference step's operator sequence on
+PyTorch-CPU operators, oracle/torch_cpu_step.py, timed on this host's cores, rank 0 / N=1 only).
 """
 import argparse
 import json
@@ -205,6 +210,37 @@ class BoxSampler:
         return dict(pci=self.bus, sysfs_card_found=self.matched, sclk_mhz_p50=med(0), mclk_mhz_p50=med(1), board_w_p50=med(2), samples=len(self.rows))
 
 
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher (the driver's form): start the N ranks here, one process per GPU,
+    rendezvous on 127.0.0.1 and a free port.  Rank 0's stdout (the one JSON line) passes through; a rank that dies takes
+    the others down (exact PIDs) and its exit code becomes ours."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), B2T_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:        # one rank failed: the others would wait in a collective until the RCCL timeout
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def dry_run(a, world, rank):
     """The launch contract without the GPU: rendezvous from the environment, --gpus == WORLD_SIZE, barrier-bracketed
     timed region, MAX over ranks, one JSON line from rank 0.  The "step" is a sleep; nothing is measured."""
@@ -213,6 +249,9 @@ def dry_run(a, world, rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    rows = B // world if a.scaling == "strong" else B
+    if os.environ.get("B2T_BENCH_DRY_FAIL_RANK") == str(rank):      # tests: a rank that dies before the timed region
+        sys.exit(7)
     for _ in range(a.warmup):
         time.sleep(0.001)
     if world > 1:
@@ -227,10 +266,12 @@ def dry_run(a, world, rank):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     if rank == 0:
-        print(json.dumps(dict(metric="GRU+CTC train sentences/sec", value=round(B * world * a.steps / dt, 2), unit="sentences/s",
+        print(json.dumps(dict(metric="GRU+CTC train sentences/sec", value=round(rows * world * a.steps / dt, 2), unit="sentences/s",
                               n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
-                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
-                              config=dict(workload="dry run (no GPU work)", global_batch=B * world, seq_len=T, parallelism=f"dp{world}"))))
+                              higher_is_better=True, scaling=a.scaling, vs_baseline=None, dtype="f32", data="synthetic", dry_run=True,
+                              world_size_seen=(dist.get_world_size() if world > 1 else 1),
+                              config=dict(workload="dry run (no GPU work)", global_batch=rows * world, rows_per_rank=rows,
+                                          seq_len=T, parallelism=f"dp{world}"))))
     if world > 1:
         dist.destroy_process_group()
 
@@ -245,7 +286,13 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check without a GPU (tests): gloo rendezvous, argument handling, max-over-ranks; measures nothing")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2..4] numbers reported under `secondary`")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 64 sentences per rank (default); strong: the same 64-sentence batch split 64/N rows per rank")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a, sys.argv[1:]))
+    if a.scaling == "strong":
+        assert B % a.gpus == 0, f"--scaling strong needs --gpus to divide {B}"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -270,8 +317,17 @@ def main():
     torch.manual_seed(10)
     model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
     ts = TrainStep(model, dict(ARGS))
-    x, days, labels, nts, lens = make_batch(1000 + rank, dev)
-    cut_rng = np.random.RandomState(1 + rank)
+    if a.scaling == "strong":
+        # SURVEY 8e parity mode: every rank builds the SAME global batch and keeps its 64/N contiguous rows; the loss scale
+        # 1 / (rows * world) = 1 / 64 makes the all-reduced SUM the one-GPU mean gradient
+        rows = B // world
+        x, days, labels, nts, lens = (t[rank * rows:(rank + 1) * rows].contiguous() for t in make_batch(1000, dev))
+        cut_rng = np.random.RandomState(1)        # the cut is one draw for the whole (global) batch, rnn_trainer.py:468
+    else:
+        rows = B
+        x, days, labels, nts, lens = make_batch(1000 + rank, dev)
+        cut_rng = np.random.RandomState(1 + rank)
+    world_seen = dist.get_world_size() if world > 1 else 1
 
     def step(i):
         cut = int(cut_rng.randint(0, 3))          # rnn_trainer.py:468-471
@@ -305,9 +361,13 @@ def main():
         loss, dt, t_enq = timed_run()
     except RuntimeError as e:
         # The pipelined plan keeps several persistent sweeps in flight; if one of them ever reports a hand-off
-        # timeout the measurement is discarded and repeated with the layers strictly in sequence (no side streams).
+        # timeout the measurement is discarded and repeated with the layers strictly in sequence (no side streams)
+        # and, data-parallel, with the gradient all-reduce AFTER the backward pass instead of next to its sweeps.
+        # The refusal is rank-consistent (TrainStep all-reduces the status word), so every rank takes this branch.
         sys.stderr.write(f"[bench] {e}; re-running with the serial execution plan\n")
         ops.PIPELINE["chunks"] = 1
+        if ts.reducer is not None:
+            ts.reducer.deferred = True
         for buf in model._ws.bufs.values():
             if buf.dtype == torch.int32:
                 buf.zero_()
@@ -319,7 +379,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms = dt / a.steps * 1e3
-    value = B * world * a.steps / dt
+    value = rows * world * a.steps / dt
     lossv = float(loss)
     assert np.isfinite(lossv), "non-finite loss in the bench step"
 
@@ -360,17 +420,20 @@ def main():
                     traffic_source=traffic_src,
                     avg_launch_us=round(dtime / max(1, dlaunch) * 1e6, 2), launches_per_step=dlaunch // NPROF,
                     summed_stream_time_over_step=round(dtime / NPROF / (ms * 1e-3), 3),   # >1: launches overlap on side streams
-                    step_flops_frac=round(FLOPS_PER_STEP / (ms * 1e-3) / PEAK_F32_MFMA, 4),
-                    step_hbm_frac=round(ALG_BYTES_PER_STEP / (ms * 1e-3) / PEAK_HBM, 4),
+                    step_flops_frac=round(FLOPS_PER_STEP * rows / B / (ms * 1e-3) / PEAK_F32_MFMA, 4),   # per GPU
+                    step_hbm_frac=round(ALG_BYTES_PER_STEP * rows / B / (ms * 1e-3) / PEAK_HBM, 4),
                     breakdown_ms={k: round(v[0] / NPROF * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])})
 
     if rank == 0:
         out = dict(metric="GRU+CTC train sentences/sec", value=round(value, 2), unit="sentences/s", n_gpus=world,
-                   steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
+                   steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling=a.scaling,
                    vs_baseline=None, dtype=("f32" if not ops.AMP["on"] else "bf16 matmul operands, f32 accumulate/sweeps (B2T_AMP)"), data="synthetic",
                    config=dict(workload="BASELINE.json configs[1]: 5-layer GRU-512 + CTC, synthetic [B=64,T=500,F=512] -> 41 "
                                         "phonemes, fp32, full training step incl. on-GPU augmentation, clip and AdamW",
-                               global_batch=B * world, seq_len=T, parallelism=f"dp{world}",
+                               global_batch=rows * world, rows_per_rank=rows, seq_len=T, parallelism=f"dp{world}",
+                               world_size_seen=world_seen, collective=("RCCL all-reduce, bucketed, overlapped with backward"
+                                                                       + (" (deferred after a refused step)" if getattr(ts.reducer, "deferred", False) else "")
+                                                                       if world > 1 else None),
                                gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
                                time_chunks_bwd=ops.PIPELINE["chunks_bwd"] or ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),

@@ -283,6 +283,11 @@ int b2t_grad_norm_clip_f32(const float* grads, const int32_t* chunk2seg, const i
                            int nchunks, float max_norm, float* partial_ws, float* out4,
                            int32_t* seg_step, int nseg, const uint32_t* err_words, int n_err,
                            long long err_stride, void* stream);
+/* Data parallel only (no reference counterpart: the reference is single-process): the step counters
+ * advance AFTER the ranks have MAX-reduced out4[3], so that a step one rank refuses is refused -- counters included -- by
+ * all: call b2t_grad_norm_clip_f32 with seg_step = NULL, all-reduce out4[3], then this (advances the counters of active
+ * tensors iff out4[3] == 0), then b2t_adamw_f32. */
+int b2t_opt_advance(const int32_t* active, int32_t* seg_step, int nseg, const float* out4, void* stream);
 /* AdamW (torch.optim.AdamW, rnn_trainer.py:283-290), active tensors only, k = seg_step (1-based):
  *   g *= clip4[2] (if apply_clip); p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^k) * m / (sqrt(v)/sqrt(1-b2^k) + eps)      (bias corrections evaluated in fp64)

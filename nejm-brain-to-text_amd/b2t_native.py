@@ -127,6 +127,7 @@ _SIGNATURES = {
                                    C.c_float, VP]),
     "b2t_opt_prepare": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP]),
     "b2t_grad_norm_clip_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_float, VP, VP, VP, C.c_int, VP, C.c_int, LL, VP]),
+    "b2t_opt_advance": (C.c_int, [VP, VP, C.c_int, VP, VP]),
     "b2t_adamw_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, VP, C.c_int, C.POINTER(C.c_float),
                                 C.POINTER(C.c_float), C.c_double, C.c_double, C.c_float, VP]),
     "b2t_greedy_decode_f32": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),

@@ -84,18 +84,39 @@ class GradReducer:
         self.buckets = {n: (a, b) for n, a, b in buckets}
         self.pending = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # deferred = True: buckets are only noted while the backward runs and all-reduced in finish(), i.e. AFTER the last
+        # backward kernel is enqueued -- no collective kernel then competes with resident persistent sweeps for CUs.  The
+        # fallback a trainer / bench switches to when a step was refused with a hand-off timeout (status 1).
+        self.deferred = False
+        self._noted = []
 
-    def launch(self, name: str):
-        if self.world == 1:
-            return
+    def _start(self, name: str):
         a, b = self.buckets[name]
         self.pending.append(self.dist.all_reduce(self.arena[a:b], op=self.dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
 
+    def launch(self, name: str):
+        if self.world == 1:
+            return
+        if self.deferred:
+            self._noted.append(name)
+            return
+        self._start(name)
+
     def finish(self):
+        for name in self._noted:
+            self._start(name)
+        self._noted = []
         for w in self.pending:
             w.wait()
         self.pending = []
+
+    def union_status(self, status: torch.Tensor):
+        """status word = max over ranks: a step one rank refuses (hand-off timeout) is refused by every rank, and every
+        rank raises at its next read instead of one raising while the others block in the next collective."""
+        if self.world > 1:
+            self.dist.all_reduce(status, op=self.dist.ReduceOp.MAX, group=self.group)
+        return status
 
     def union_active(self, active: torch.Tensor):
         """active[seg] = max over ranks (a day tensor is updated if ANY rank saw that day)."""
@@ -233,8 +254,15 @@ class TrainStep:
         ew, n_err, ew_stride = model._ws.error_words(model.n_layers, dev)
         N.check(lib.b2t_grad_norm_clip_f32(ops._p(self.grad_arena), ops._p(self.chunk2seg), ops._p(self.active),
                                            self.nchunks, clip, ops._p(self.partial), ops._p(self.out3),
-                                           ops._p(self.seg_step), self.nseg, ops._p(ew), n_err, ew_stride, st),
+                                           (None if self.reducer is not None else ops._p(self.seg_step)), self.nseg,
+                                           ops._p(ew), n_err, ew_stride, st),
                 "b2t_grad_norm_clip_f32")
+        if self.reducer is not None:
+            # a hand-off timeout is a per-rank event: MAX-reduce the status so that every rank refuses the step (and
+            # raises at its next read) instead of one raising while the others block in the next bucket all-reduce
+            self.reducer.union_status(self.stat[3:4])
+            N.check(lib.b2t_opt_advance(ops._p(self.active), ops._p(self.seg_step), self.nseg, ops._p(self.out3), st),
+                    "b2t_opt_advance")
         lrs = self.current_lrs()
         a = self.args
         lr3 = (C.c_float * 3)(*lrs)
@@ -266,6 +294,16 @@ class TrainStep:
         if st == 2:
             raise RuntimeError(f"The total norm of order 2.0 for gradients is non-finite ({float(v[1])}), so it cannot be "
                                "clipped; the step was NOT applied")
+
+    def clear_refusal(self, n_steps: int = 0):
+        """Forget a refused step: zero the sticky status and the sweeps' error / hand-off words, and take the schedule back
+        by the `n_steps` refused steps (their AdamW updates never happened; step counters did not advance)."""
+        torch.cuda.synchronize()
+        for buf in self.model._ws.bufs.values():
+            if buf.dtype == torch.int32:
+                buf.zero_()
+        self.stat.zero_()
+        self.it -= int(n_steps)
 
     # -- helpers for tests / checkpoints ---------------------------------------------------------------
     def last_unclipped_grads(self) -> Dict[str, np.ndarray]:

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <functional>
 #include <vector>
+#include <queue>
 #include <algorithm>
 #include "common.h"
 
@@ -308,19 +309,33 @@ float est_gemm(double M, double N, double K, double Z = 1) {   // launch + FLOPs
 }
 
 // The scheduling step alone (host arithmetic, no HIP): fills q / start / end / rank / cross of every task and returns the
-// issue order (planned start, ties by task id).  Tasks must be listed in a topological order (dependencies have smaller
-// ids).  Exposed for the CPU tests as b2t_plan_schedule_host.
+// issue order (planned start, ties by task id).  The graph may list its tasks in any order (the admission edges added
+// after a first pass point from a later-created task to an earlier-created one): ranks are computed over a true topological
+// order (Kahn, smallest id first), and since rank(task) > rank(successor) the rank-ordered placement below sees every
+// dependency before its dependants.  Returns an empty order if the graph has a cycle.  Exposed for the CPU tests as
+// b2t_plan_schedule_host.
 std::vector<int> schedule_plan(Plan& P, int nq) {
   const int n = (int)P.t.size();
   std::vector<std::vector<int>> succ(n);
-  for (int i = 0; i < n; ++i) for (int d : P.t[i].deps) succ[d].push_back(i);
-  for (int i = n - 1; i >= 0; --i) {
+  std::vector<int> indeg(n, 0), topo;
+  for (int i = 0; i < n; ++i) for (int d : P.t[i].deps) { succ[d].push_back(i); ++indeg[i]; }
+  {
+    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+    for (int i = 0; i < n; ++i) if (!indeg[i]) ready.push(i);
+    while (!ready.empty()) {
+      const int i = ready.top(); ready.pop();
+      topo.push_back(i);
+      for (int s2 : succ[i]) if (--indeg[s2] == 0) ready.push(s2);
+    }
+    if ((int)topo.size() != n) return {};
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    const int i = topo[k];
     float r = 0.f;
-    for (int s : succ[i]) r = std::max(r, P.t[s].rank + HOP_US);
+    for (int s2 : succ[i]) r = std::max(r, P.t[s2].rank + HOP_US);
     P.t[i].rank = P.t[i].est + r;
   }
-  std::vector<int> order(n);
-  for (int i = 0; i < n; ++i) order[i] = i;
+  std::vector<int> order = topo;    // stable sort of a topological order: equal ranks (zero-cost chains) keep dependencies first
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return P.t[a].rank > P.t[b].rank; });
   std::vector<std::vector<std::pair<float, float>>> busy(nq);
   for (int id : order) {
@@ -372,6 +387,7 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   for (const Task& k : P.t) classes = classes || k.cls >= 0;
   if (classes && nq > 1) add_admission_edges(P, schedule_plan(P, nq));
   const std::vector<int> order = schedule_plan(P, nq);
+  if ((int)order.size() != n) { c.call(1); set_error("exec: the plan's task graph has a cycle"); return; }
   static const bool dump = getenv("B2T_PLAN_DUMP") != nullptr;
   if (dump) {
     fprintf(stderr, "plan: %d tasks on %d queues\n", n, nq);
@@ -386,6 +402,12 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
     int last[8]; for (int q = 0; q < 8; ++q) last[q] = -1;   // per foreign queue: the dependency issued last covers the others
     for (int d : k.deps) {
       const int dq = P.t[d].q;
+      // a dependency must have been issued already; across queues it must have left an event (never drop an edge silently)
+      if (pos[d] >= pos[id] || (dq != k.q && !P.t[d].ev)) {
+        c.call(1);
+        set_error("exec: task '%s' would be issued before its dependency '%s' (plan order broken)", k.name, P.t[d].name);
+        return;
+      }
       if (dq != k.q && (last[dq] < 0 || pos[d] > pos[last[dq]])) last[dq] = d;
     }
     for (int q = 0; q < nq; ++q) if (last[q] >= 0) c.wait(s, P.t[last[q]].ev);
@@ -555,6 +577,7 @@ extern "C" int b2t_plan_admission_host(int n_tasks, const float* est_us, const u
   }
   if (n_queues > 1) add_admission_edges(P, schedule_plan(P, n_queues));
   const std::vector<int> ord = schedule_plan(P, n_queues);
+  B2T_REQUIRE((int)ord.size() == n_tasks, "plan_admission_host: the graph with its admission edges has a cycle");
   for (int i = 0; i < n_tasks; ++i) { queue[i] = P.t[i].q; start_us[i] = P.t[i].start; end_us[i] = P.t[i].end; order[i] = ord[i]; }
   return 0;
 }

@@ -84,6 +84,15 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
     for (int i = threadIdx.x; i < nseg; i += blockDim.x) seg_step[i] += (active[i] != 0);
 }
 
+// Data parallel: the status word is MAX-reduced over the ranks between the norm and the update, so the step counters
+// may only advance once the GLOBAL status is known (b2t_grad_norm_clip_f32 is then called with seg_step = NULL).
+__global__ void opt_advance_kernel(const int* __restrict__ active, int* __restrict__ seg_step, int nseg,
+                                   const float* __restrict__ out4) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg || out4[3] != 0.f) return;
+  seg_step[s] += (active[s] != 0);
+}
+
 struct GroupHyp { float lr[3]; float wd[3]; };
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -136,6 +145,14 @@ extern "C" int b2t_opt_prepare(const int32_t* day_idx, int B, const int32_t* seg
   hipLaunchKernelGGL(opt_prepare_kernel, dim3((nseg + 127) / 128), dim3(128), 0, as_stream(stream), day_idx, B, seg_day,
                      nseg, active);
   B2T_CHECK_LAUNCH("b2t_opt_prepare");
+  return 0;
+}
+
+extern "C" int b2t_opt_advance(const int32_t* active, int32_t* seg_step, int nseg, const float* out4, void* stream) {
+  B2T_REQUIRE(active && seg_step && out4 && nseg > 0, "opt_advance: bad args");
+  hipLaunchKernelGGL(opt_advance_kernel, dim3((nseg + 127) / 128), dim3(128), 0, as_stream(stream), active, seg_step, nseg,
+                     out4);
+  B2T_CHECK_LAUNCH("b2t_opt_advance");
   return 0;
 }
 

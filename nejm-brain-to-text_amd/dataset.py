@@ -204,6 +204,10 @@ class SyntheticTrials(Dataset):
                         list(range(self.B)))
 
 
+class ResidentFormatError(RuntimeError):
+    pass
+
+
 class ResidentDataset:
     """All trials of a split resident on the device: features [sum_T, F] f32 and labels [sum_S] i32 back to back with
     row offsets, plus the per-trial scalars.  `batch(rows)` returns the reference's batch dict (dataset.py:100-159) for
@@ -308,13 +312,36 @@ class ResidentDataset:
             rows.extend(range(first, first + B)); off.append(len(rows))
         return cls(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), device)
 
+    FORMAT = 2      # 1: before lab_n / batch_rows / batch_off (one stored row per batch row)
+
     def save(self, path):
-        np.savez(path, **self.host)
+        np.savez(path, format=np.int32(self.FORMAT), **self.host)
 
     @classmethod
     def load(cls, path, device='cuda:0'):
+        """Raises ResidentFormatError for a file an older version of this class wrote (or one that lacks a table):
+        `load_or_build` then re-converts the source instead of failing on a KeyError."""
         with np.load(path) as z:
+            fmt = int(z['format']) if 'format' in z.files else 1
+            missing = [k for k in cls.KEYS if k not in z.files]
+            if fmt != cls.FORMAT or missing:
+                raise ResidentFormatError(f"{path}: resident-dataset format {fmt} (this build reads {cls.FORMAT})"
+                                          + (f", missing tables {missing}" if missing else ""))
             return cls({k: z[k] for k in cls.KEYS}, device)
+
+    @classmethod
+    def load_or_build(cls, path, dataset, device='cuda:0'):
+        """The cached flat binary if it is there and current, else converted from `dataset` and written back."""
+        if path and os.path.exists(path):
+            try:
+                return cls.load(path, device)
+            except ResidentFormatError as e:
+                import warnings
+                warnings.warn(f"{e}; rebuilding from the source dataset")
+        rd = cls.from_dataset(dataset, device)
+        if path:
+            rd.save(path)
+        return rd
 
     # ---- batches ---------------------------------------------------------------------------------------------------
     def __len__(self):

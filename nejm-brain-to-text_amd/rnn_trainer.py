@@ -281,6 +281,11 @@ class BrainToTextDecoder_Trainer:
         # data parallel: a rank loads only the batches it owns (sampler-level sharding of the pre-generated batch index)
         mine = list(rank_batches(len(self.train_dataset), self.world, self.rank)) if self.world > 1 else None
         if mine is not None:
+            if dsa.get('loader_shuffle', False):
+                # the ranks' shards come from ONE pre-generated batch index (already random, dataset.py:162-211); a
+                # per-rank shuffle on top would make ranks draw overlapping batches, so it is not applied
+                self.logger.warning("dataset.loader_shuffle is ignored with WORLD_SIZE > 1: batches are sharded from the "
+                                    "pre-generated (seeded, random) batch index")
             self.train_loader = DataLoader(self.train_dataset, batch_size=None, sampler=mine, num_workers=nw, pin_memory=True)
         else:
             self.train_loader = DataLoader(self.train_dataset, batch_size=None, shuffle=dsa.get('loader_shuffle', False),
@@ -289,8 +294,10 @@ class BrainToTextDecoder_Trainer:
         if dsa.get('device_resident'):
             # flatten both splits into HBM once (each unique trial once); batches are then assembled on the
             # device (no per-batch file reads, padding or PCIe copy).  Same batch composition and order as the loaders above.
-            self.train_loader = _ResidentLoader(ds.ResidentDataset.from_dataset(self.train_dataset, self.device), mine)
-            self.val_loader = _ResidentLoader(ds.ResidentDataset.from_dataset(self.val_dataset, self.device))
+            cache = dsa.get('resident_cache_dir')          # optional: flat binaries written once, re-read by later runs
+            cpath = (lambda split: os.path.join(cache, f'resident_{split}.npz')) if cache else (lambda split: None)
+            self.train_loader = _ResidentLoader(ds.ResidentDataset.load_or_build(cpath('train'), self.train_dataset, self.device), mine)
+            self.val_loader = _ResidentLoader(ds.ResidentDataset.load_or_build(cpath('val'), self.val_dataset, self.device))
         if 'dataset_probability_val' not in dsa:
             dsa['dataset_probability_val'] = [1] * len(dsa['sessions'])
         self.logger.info("Successfully initialized datasets")
@@ -406,6 +413,42 @@ class BrainToTextDecoder_Trainer:
         last_step = self.args['num_training_batches'] // self.world - 1
         pending = None      # (step, pinned stat copy, event, enqueue time)
         stat_ring = [torch.empty(5, dtype=torch.float32).pin_memory() for _ in range(4)]   # pinned once, not once per step
+        recent = []         # inputs of the steps whose status has not been read yet (at most two): re-run if refused
+        slot = [0]
+
+        def run_step(step, inputs, t0):
+            self.train_step.step(*inputs)
+            host = stat_ring[slot[0] % len(stat_ring)]     # (read one step later: the slot is free again three steps on)
+            slot[0] += 1
+            host.copy_(self.train_step.stat, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return step, host, ev, t0
+
+        def recover():
+            """Data parallel only: a step refused with a hand-off timeout (status 1; rank-consistent, TrainStep MAX-reduces
+            the word, and never applied) is taken as a sign that a collective kernel kept a persistent sweep's workgroups
+            from becoming resident.  Switch the reducer to all-reduce AFTER the backward pass, clear the refusal and re-run
+            the refused steps (the one read and, if one is enqueued behind it, that one too) instead of failing the job.
+            Every re-run but the last is read here (records returned); the last is left in `pending`."""
+            nonlocal pending
+            ts = self.train_step
+            torch.cuda.synchronize()
+            self.logger.warning("persistent sweep hand-off timed out next to a gradient all-reduce: the step was not applied; "
+                                "re-running it with the all-reduce deferred until after the backward pass")
+            ts.reducer.deferred = True
+            ts.clear_refusal(len(recent))
+            todo, pending, recs = list(recent), None, []
+            for k, (step, inputs, t0) in enumerate(todo):
+                pending = run_step(step, inputs, t0)
+                if k + 1 < len(todo):
+                    _, host, ev, _ = pending
+                    ev.synchronize()
+                    ts.check_status(host)
+                    train_losses.append(float(host[4]))
+                    recs.append((step, float(host[4]), float(host[1]), time.time() - t0))
+            del recent[:-1]
+            return recs
 
         def drain():
             """Read the previous step's numbers (it has normally finished long ago)."""
@@ -413,9 +456,18 @@ class BrainToTextDecoder_Trainer:
             if pending is None:
                 return None
             step, host, ev, t0 = pending
-            pending = None
             ev.synchronize()
-            self.train_step.check_status(host)            # refused step (hand-off timeout / non-finite norm): raise
+            ts = self.train_step
+            if int(host[3]) == 1 and ts.reducer is not None and not ts.reducer.deferred:
+                recs = recover()
+                if recs:                     # `step` was re-run and read inside recover(); a later one is pending again
+                    return recs[0]
+                step, host, ev, t0 = pending
+                ev.synchronize()
+            pending = None
+            ts.check_status(host)            # refused step (hand-off timeout / non-finite norm): raise
+            while recent and recent[0][0] <= step:
+                recent.pop(0)
             lossv, gnv = float(host[4]), float(host[1])
             train_losses.append(lossv)
             return step, lossv, gnv, time.time() - t0
@@ -435,13 +487,12 @@ class BrainToTextDecoder_Trainer:
             phone_seq_lens = batch['phone_seq_lens'].to(self.device, non_blocking=True)
             day_indicies = batch['day_indicies']
             features, n_time_steps = self.transform_data(features, n_time_steps, 'train')
-            self.train_step.step(features, day_indicies, labels, n_time_steps, phone_seq_lens)
-            host = stat_ring[i % len(stat_ring)]           # (read one step later: the slot is free again three steps on)
-            host.copy_(self.train_step.stat, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            inputs = (features, day_indicies, labels, n_time_steps, phone_seq_lens)
+            if self.train_step.reducer is not None:
+                recent.append((i, inputs, start_time))
+            new = run_step(i, inputs, start_time)
             prev = drain()
-            pending = (i, host, ev, start_time)
+            pending = new if pending is None else pending      # (recover() leaves the re-run of step i pending)
             log(prev)
             if i % self.args['batches_per_val_step'] == 0 or i == last_step:
                 log(drain())                   # the weights validated / checkpointed are those of an ACCEPTED step i

@@ -150,3 +150,38 @@ def test_bench_rendezvous_path_world2():
     cmd[cmd.index("--gpus") + 1] = "4"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_spawns_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (the driver's N > 1 form, VERDICT
+    round 2 weak #4): bench.py starts the two ranks itself (rendezvous on 127.0.0.1, free port), still prints exactly one
+    JSON line, reports the world size the process group saw, and `--scaling strong` shards the one 64-sentence batch."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run",
+           "--scaling", scaling]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and out["scaling"] == scaling
+    assert out["config"]["global_batch"] == (128 if scaling == "weak" else 64)
+    assert out["config"]["rows_per_rank"] == (64 if scaling == "weak" else 32)
+    assert out["ms_per_step"] >= 20.0
+
+
+def test_bench_spawn_propagates_a_rank_failure():
+    """A rank that dies must end the job with a non-zero code (and take the other ranks with it), not hang the driver."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["B2T_BENCH_DRY_FAIL_RANK"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=root, env=env)
+    assert r.returncode != 0

@@ -204,3 +204,34 @@ def test_admission_without_classes_is_the_plain_schedule():
     q2, start2, end2, order2 = schedule_admission(est, deps, [-1] * 6, 4)
     assert q.tolist() == q2.tolist() and order.tolist() == order2.tolist()
     np.testing.assert_allclose(start, start2)
+
+
+def test_admission_fuzz_random_estimates():
+    """Random wavefront graphs with random per-task estimates (the advisor's round-2 fuzz: ranks and placement used to
+    follow task ids, admission edges can point from a later-created task to an earlier-created one, and a dependant could
+    be placed before its admission dependency): every data dependency AND every admission edge must hold in the planned
+    schedule, i.e. never three sweeps of a parity in flight, and the issue order must respect them."""
+    rng = np.random.RandomState(1234)
+    for trial in range(400):
+        L, nc = int(rng.randint(2, 9)), int(rng.randint(1, 9))
+        est, deps, cls = _wavefront(L, nc, 1.0, 1.0)
+        est = [float(rng.choice([0.0, 5.0, 40.0, 120.0, 450.0, 900.0]) * rng.uniform(0.5, 1.5)) for _ in est]
+        nq = int(rng.choice([2, 3, 4]))
+        q, start, end, order = schedule_admission(est, deps, cls, nq)
+        n = len(est)
+        assert sorted(order.tolist()) == list(range(n))
+        pos = np.empty(n, int); pos[order] = np.arange(n)
+        for i in range(n):
+            for d in deps[i]:
+                assert pos[d] < pos[i] and start[i] + 1e-3 >= end[d] + (HOP if q[d] != q[i] else 0.0), (trial, i, d)
+        for qq in range(nq):
+            ids = [i for i in order if q[i] == qq]
+            for a, b in zip(ids, ids[1:]):
+                assert start[b] + 1e-3 >= end[a]
+        for k in (0, 1):
+            ids = [i for i in range(n) if cls[i] == k]
+            events = sorted([(start[i], 1) for i in ids] + [(end[i] - 1e-3, -1) for i in ids])
+            live = peak = 0
+            for _, dlt in events:
+                live += dlt; peak = max(peak, live)
+            assert peak <= 2, (trial, L, nc, nq, k, peak)
