@@ -18,6 +18,7 @@ Reference entry points exercised:
   rnn_trainer.py:527-558 with patch_size 14 / stride 4                   (train_step_patch.npz)
   rnn_trainer.py:365-406 save_model_checkpoint after 3 steps + the 4th step (ckpt_ref.pt, ckpt_ref_step4.npz)
   dataset.py:162-242 create_batch_index_train / _test                    (sampler_index.npz)
+  dataset.py:100-159 BrainToTextDataset.__getitem__ on an in-memory h5py   (dataset_batches.npz)
   rnn_trainer.py:228-234 LinearLR                                        (lr_table.npz: linear_*)
   rnn_trainer.py:449-465 static gain + random walk with injected draws   (transform.npz: full_*)
 """
@@ -56,7 +57,37 @@ def _edit_distance(a, b):
     return prev[len(b)]
 
 
-_stub("h5py")
+# h5py: an in-memory File so that the reference's BrainToTextDataset.__getitem__ (dataset.py:100-159) can run without the
+# package or the Dryad files.  MEMFILES[path][f"trial_{t:04d}"] = {"input_features": ..., "seq_class_ids": ...,
+# "transcription": ..., "attrs": {...}}; only what __getitem__ touches is modelled (File as a context manager, group
+# lookup raising KeyError, dataset[:] and group.attrs[...]).
+MEMFILES = {}
+
+
+class _MemGroup:
+    def __init__(self, d):
+        self._d = d
+        self.attrs = d["attrs"]
+
+    def __getitem__(self, k):
+        return self._d[k]
+
+
+class _MemFile:
+    def __init__(self, path, mode="r"):
+        self._f = MEMFILES[path]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def __getitem__(self, k):
+        return _MemGroup(self._f[k])
+
+
+_stub("h5py", File=_MemFile)
 ta = _stub("torchaudio")
 taf = _stub("torchaudio.functional", edit_distance=_edit_distance)
 ta.functional = taf
@@ -433,7 +464,69 @@ def make_sampler_index():
     save("sampler_index.npz", **out)
 
 
+def make_dataset_batches():
+    """Batch dicts of the reference's BrainToTextDataset.__getitem__ (dataset.py:100-159: per-day file reads, feature
+    subset, pad_sequence, dtypes, key set, a listed-but-missing trial skipped) on an in-memory h5py stand-in: two random
+    train batches, the sequential test batches, and a train batch with feature_subset.  The fixture carries the trial
+    store itself so that the tests can serve the same "files" to the product's dataset and to ResidentDataset."""
+    import dataset as ref_ds
+    rng = np.random.RandomState(11)
+    F, LAB, TR = 32, 20, 24
+    store = {}
+    trial_idx = {}
+    for d in range(3):
+        path = f"/mem/day{d}/data_train.hdf5"
+        ids = sorted(rng.choice(60, size=int(rng.randint(9, 14)), replace=False).tolist())
+        trial_idx[d] = {"trials": ids, "session_path": path}
+        MEMFILES[path] = {}
+        for t in ids:
+            if d == 1 and t == ids[2]:
+                continue                      # listed in the index, absent from the file: printed and skipped (dataset.py:144-146)
+            T = int(rng.randint(17, 49)); S = int(rng.randint(3, 12))
+            lab = np.zeros(LAB, np.int32); lab[:S] = rng.randint(1, 41, size=S)
+            g = dict(input_features=rng.randn(T, F).astype(np.float32), seq_class_ids=lab,
+                     transcription=rng.randint(0, 128, size=TR).astype(np.int32),
+                     attrs=dict(n_time_steps=np.int64(T), seq_len=np.int64(S), block_num=np.int64(rng.randint(1, 9)),
+                                trial_num=np.int64(t)))
+            MEMFILES[path][f"trial_{t:04d}"] = g
+            for k in ("input_features", "seq_class_ids", "transcription"):
+                store[f"store_{d}_{t}_{k}"] = g[k]
+            store[f"store_{d}_{t}_attrs"] = np.array([g["attrs"][k] for k in ("n_time_steps", "seq_len", "block_num", "trial_num")], np.int64)
+    out = dict(store)
+    out["days"] = np.arange(3)
+    for d, v in trial_idx.items():
+        out[f"trials_{d}"] = np.array(v["trials"])
+    KEYS = ("input_features", "seq_class_ids", "n_time_steps", "phone_seq_lens", "day_indicies", "transcriptions", "block_nums", "trial_nums")
+
+    def dump(tag, ds, n):
+        out[f"{tag}_n"] = np.int64(n)
+        for bi in range(n):
+            b = ds[bi]
+            assert tuple(b.keys()) == KEYS
+            for k in KEYS:
+                out[f"{tag}_{bi}_{k}"] = b[k].numpy()
+                out[f"{tag}_{bi}_{k}_dtype"] = np.array(str(b[k].dtype))
+            idx = ds.batch_index[bi]
+            out[f"{tag}_{bi}_index_days"] = np.array([int(d) for d in idx.keys()])
+            for d, t in idx.items():
+                out[f"{tag}_{bi}_index_{int(d)}"] = np.asarray(t)
+
+    tr = ref_ds.BrainToTextDataset(trial_idx, n_batches=2, split="train", batch_size=8, days_per_batch=2, random_seed=3)
+    dump("train", tr, 2)
+    te = ref_ds.BrainToTextDataset(trial_idx, n_batches=None, split="test", batch_size=8, random_seed=3)
+    dump("test", te, len(te.batch_index))
+    sub = [3, 1, 30, 7, 8, 9, 10, 31]
+    trs = ref_ds.BrainToTextDataset(trial_idx, n_batches=1, split="train", batch_size=6, days_per_batch=3, random_seed=4,
+                                    feature_subset=sub)
+    out["subset"] = np.array(sub)
+    dump("trainsub", trs, 1)
+    save("dataset_batches.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        make_dataset_batches()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "init":
         make_init()
         sys.exit(0)
@@ -445,6 +538,7 @@ if __name__ == "__main__":
     make_train_step("train_step_patch.npz", ps=14, st=4, dims=(16, 48, 5, 3, 6, 73, 5))
     make_train_step(ckpt=True, ps=14, st=4, dims=(16, 32, 4, 2, 6, 61, 4))
     make_sampler_index()
+    make_dataset_batches()
     make_lr_table()
     make_transform()
     make_greedy()

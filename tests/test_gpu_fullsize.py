@@ -164,7 +164,7 @@ def _grad_check(model, sd, x, day, tgt, nt, tl, L_, ps, st, dev, tag):
 
 
 def test_full_size_c2_every_gradient_matches_oracle(c2):
-    """BASELINE configs[1] at full size under the plan bench.py times (6 time chunks, 11 streams, up to five sweeps in
+    """BASELINE configs[1] at full size under the plan bench.py times (6 forward / 4 backward time chunks as a task graph on four queues, up to four sweeps in
     flight): ALL parameter gradients of the 64-sentence batch against one oracle run of the same batch."""
     import b2t_ops as ops
     assert ops.time_chunks(T, B, H) == 6
