@@ -238,6 +238,11 @@ class ResidentDataset:
         self.block = to(h['block'], torch.int64)
         self.trial = to(h['trial'], torch.int64)
         self.trans = to(h['trans'], torch.int64)
+        # dtypes the source's label / transcription rows had (the reference's collate keeps them: dataset.py:136-137)
+        self.lab_dtype = getattr(torch, str(arrays.get('lab_dtype', 'int64')).replace('torch.', ''))
+        self.trans_dtype = getattr(torch, str(arrays.get('trans_dtype', 'int64')).replace('torch.', ''))
+        self.host['lab_dtype'] = np.array(str(self.lab_dtype))
+        self.host['trans_dtype'] = np.array(str(self.trans_dtype))
 
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
@@ -251,10 +256,12 @@ class ResidentDataset:
         feats, labs, foff, loff = [], [], [0], [0]
         nts, sls, days, blocks, trials, trans = [], [], [], [], [], []
         row_of = {}
+        dts = {}
         for d, info in dataset.trial_indicies.items():
             wanted = sorted(set(int(t) for t in info['trials']))
             for (t, x, lab, tr, nt, sl, bn, tn) in dataset.read_trials(d, wanted):
                 row_of[(d, t)] = len(nts)
+                dts.setdefault('lab_dtype', str(lab.dtype)); dts.setdefault('trans_dtype', str(tr.dtype))
                 T, S = int(nt), int(sl)
                 # label rows are kept as stored (the session files zero-pad them to max_seq_elements): pad_sequence in the
                 # reference's collate then yields the same [B, S_stored] array
@@ -269,7 +276,7 @@ class ResidentDataset:
             for d, tlist in dataset.batch_index[bi].items():
                 rows.extend(row_of[(d, int(t))] for t in tlist if (d, int(t)) in row_of)   # unreadable trials were skipped
             off.append(len(rows))
-        return cls(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), device)
+        return cls(dict(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), **dts), device)
 
     @staticmethod
     def _arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off):
@@ -297,8 +304,10 @@ class ResidentDataset:
                                    "trial index, or keep the DataLoader path")
         feats, labs, foff, loff = [], [], [0], [0]
         nts, sls, days, blocks, trials, trans, rows, off = [], [], [], [], [], [], [], [0]
+        dts = {}
         for bi in range(len(dataset)):
             b = dataset[bi]
+            dts.setdefault('lab_dtype', str(b['seq_class_ids'].dtype)); dts.setdefault('trans_dtype', str(b['transcriptions'].dtype))
             first = len(nts)
             B = int(b['n_time_steps'].shape[0])
             for i in range(B):
@@ -310,7 +319,7 @@ class ResidentDataset:
                 blocks.append(int(b['block_nums'][i])); trials.append(int(b['trial_nums'][i]))
                 trans.append(b['transcriptions'][i].numpy().astype(np.int64))
             rows.extend(range(first, first + B)); off.append(len(rows))
-        return cls(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), device)
+        return cls(dict(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), **dts), device)
 
     FORMAT = 2      # 1: before lab_n / batch_rows / batch_off (one stored row per batch row)
 
@@ -327,7 +336,7 @@ class ResidentDataset:
             if fmt != cls.FORMAT or missing:
                 raise ResidentFormatError(f"{path}: resident-dataset format {fmt} (this build reads {cls.FORMAT})"
                                           + (f", missing tables {missing}" if missing else ""))
-            return cls({k: z[k] for k in cls.KEYS}, device)
+            return cls({k: z[k] for k in cls.KEYS + tuple(m for m in ('lab_dtype', 'trans_dtype') if m in z.files)}, device)
 
     @classmethod
     def load_or_build(cls, path, dataset, device='cuda:0'):
@@ -372,8 +381,8 @@ class ResidentDataset:
         # tensors the step consumes stay on the device; the bookkeeping fields are host tensors, as a DataLoader yields them
         hn = rows_h.numpy()
         host = lambda k: torch.from_numpy(self.host[k][hn])
-        return {'input_features': x, 'seq_class_ids': y.to(torch.int64), 'n_time_steps': nts.to(torch.int64),
-                'phone_seq_lens': sls.to(torch.int64), 'day_indicies': host('day'), 'transcriptions': host('trans'),
+        return {'input_features': x, 'seq_class_ids': y.to(self.lab_dtype), 'n_time_steps': nts.to(torch.int64),
+                'phone_seq_lens': sls.to(torch.int64), 'day_indicies': host('day'), 'transcriptions': host('trans').to(self.trans_dtype),
                 'block_nums': host('block'), 'trial_nums': host('trial')}
 
 

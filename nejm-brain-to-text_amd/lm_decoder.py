@@ -49,8 +49,14 @@ class DecodeResource:
         # the grammars used by Rescore(): G.fst (its scores are taken out) and G_no_prune.fst (its scores are put in)
         self.lm_fst = wfst.read_openfst_vector(lm_fst_path) if lm_fst_path else None
         self.rescore_lm_fst = wfst.read_openfst_vector(rescore_lm_fst_path) if rescore_lm_fst_path else None
-        self.backoff_label = None     # word id of #0 on the grammars' back-off arcs (set_graph / set_rescore_grammars)
         self.symbols = self._read_table(dict_path) if dict_path else None
+        # word id of #0 on the grammars' back-off arcs: eps2disambig.pl rewrites the back-off ilabel <eps> to #0 before
+        # fstcompile (make_tlg.sh:35-38), so G.fst / G_no_prune.fst read from files carry words.txt's id of "#0" there;
+        # a grammar compiled without that step keeps epsilon (0).  (set_graph / set_rescore_grammars override it.)
+        self.backoff_label = None
+        if self.lm_fst is not None and self.rescore_lm_fst is not None:
+            ids = [i for i, w in (self.symbols or {}).items() if w == "#0"]
+            self.backoff_label = ids[0] if ids else 0
         self.units = self._read_table(unit_path) if unit_path else None
         self.token_lm = None
         self.lexicon = self.word_lm = None

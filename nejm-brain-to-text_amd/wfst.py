@@ -38,18 +38,34 @@ class Fst:
         self.arcs: List[Tuple[int, int, int, float, int]] = []
         self.final: Dict[int, float] = {}
 
+        self._csr = None
+
     def add_state(self) -> int:
         self.n += 1
         return self.n - 1
 
     def add_arc(self, s, il, ol, w, d):
         self.arcs.append((s, il, ol, float(w), d))
+        self._csr = None
 
     def out(self):
         o: List[List[Tuple[int, int, float, int]]] = [[] for _ in range(self.n)]
         for s, il, ol, w, d in self.arcs:
             o[s].append((il, ol, w, d))
         return o
+
+    def csr(self):
+        """(row[n+1], ilabel, olabel, weight, next) with the arcs of a state sorted by ilabel; built once (numpy) and
+        cached until the next add_arc: what grammar_score walks (one bisection per (state, label))."""
+        if self._csr is None or self._csr[5] != len(self.arcs):
+            a = np.array(self.arcs, dtype=np.float64).reshape(-1, 5)
+            src, il = a[:, 0].astype(np.int64), a[:, 1].astype(np.int64)
+            order = np.lexsort((il, src))
+            row = np.zeros(self.n + 1, dtype=np.int64)
+            np.add.at(row, src + 1, 1)
+            self._csr = (np.cumsum(row), il[order], a[order, 2].astype(np.int64), a[order, 3], a[order, 4].astype(np.int64),
+                         len(self.arcs))
+        return self._csr[:5]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -444,26 +460,34 @@ def save_graph(g: DecodeGraph, path: str):
 def grammar_score(G: Fst, word_ids: Sequence[int], backoff_label: int):
     """Cheapest path through G accepting the word sequence (back-off arcs carry `backoff_label` on the input side and
     may be taken freely) plus the final cost: the LM cost a lattice path picks up when composed with G
-    (BrainSpeechDecoder::LatticeRescore, brain_speech_decoder.cc:44-58)."""
-    out = G.out()
-    cur = {G.start: 0.0}
+    (BrainSpeechDecoder::LatticeRescore, brain_speech_decoder.cc:44-58).  Walks G's cached CSR form: the arcs of a state
+    are sorted by ilabel, so a (state, label) lookup is one bisection, whatever the size of the grammar."""
+    row, il, ol, wt, nx = G.csr()
+
+    def arcs(s, label):
+        a, e = int(row[s]), int(row[s + 1])
+        lo = a + int(np.searchsorted(il[a:e], label, "left"))
+        hi = a + int(np.searchsorted(il[a:e], label, "right"))
+        return range(lo, hi)
 
     def close(d):
         st = list(d)
         while st:
             s = st.pop()
-            for il, ol, w, nx in out[s]:
-                if il == backoff_label and (nx not in d or d[s] + w < d[nx]):
-                    d[nx] = d[s] + w; st.append(nx)
+            for k in arcs(s, backoff_label):
+                n_, c = int(nx[k]), d[s] + float(wt[k])
+                if n_ not in d or c < d[n_]:
+                    d[n_] = c; st.append(n_)
         return d
 
-    cur = close(cur)
+    cur = close({G.start: 0.0})
     for wid in word_ids:
         nxt = {}
         for s, c in cur.items():
-            for il, ol, w, nx in out[s]:
-                if il == wid and (nx not in nxt or c + w < nxt[nx]):
-                    nxt[nx] = c + w
+            for k in arcs(s, int(wid)):
+                n_, c2 = int(nx[k]), c + float(wt[k])
+                if n_ not in nxt or c2 < nxt[n_]:
+                    nxt[n_] = c2
         if not nxt:
             return math.inf
         cur = close(nxt)

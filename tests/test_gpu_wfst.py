@@ -214,6 +214,21 @@ def test_lm_decoder_surface_with_a_graph(toy, tmp_path):
     lm_decoder.DecodeNumpyLogProbs(dec, lp.astype(np.float32))
     dec.FinishDecoding()
     assert dec.result()[0].sentence == out[0].sentence
+    # the reference's own way in (brain_speech_decoder.cc:61-101 via DecodeResource's five paths): both grammars as OpenFST
+    # files, the back-off label taken from words.txt's "#0" -- must give what set_rescore_grammars gave
+    wfst.write_openfst_vector(G_old, str(tmp_path / "G.fst"))
+    wfst.write_openfst_vector(G_new, str(tmp_path / "G_no_prune.fst"))
+    res2 = lm_decoder.DecodeResource(str(tmp_path / "TLG.fst"), str(tmp_path / "G.fst"), str(tmp_path / "G_no_prune.fst"),
+                                     str(tmp_path / "words.txt"), "")
+    assert res2.backoff_label == wd0
+    dec2 = lm_decoder.BrainSpeechDecoder(res2, opts)
+    lm_decoder.DecodeNumpy(dec2, logits, np.zeros_like(logits), math.log(90.0))
+    dec2.FinishDecoding()
+    dec2.Rescore()
+    got2 = dec2.result()
+    assert [r.sentence for r in got2] == [r.sentence for r in after]
+    for r2, r1 in zip(got2, after):
+        assert abs(r2.lm_score - r1.lm_score) < TOL and abs(r2.ac_score - r1.ac_score) < 1e-4
 
 
 def test_lattice_nbest_host_against_enumeration():
