@@ -60,14 +60,16 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
     std::vector<int> po(out_off.begin(), out_off.end() - 1), pr(rev_off.begin(), rev_off.end() - 1);
     for (int i = 0; i < n_arcs; ++i) {                       // arc order within a state = input order (deterministic ties)
       out_arc[po[src[i]]++] = Arc{ilabel[i], olabel[i], dst[i], graph[i], acoustic[i]};
-      rev_arc[pr[dst[i]]++] = {src[i], std::max(0.0, (double)graph[i] + (double)acoustic[i])};
+      rev_arc[pr[dst[i]]++] = {src[i], (double)graph[i] + (double)acoustic[i]};   // as the forward search adds them
     }
   }
   std::vector<double> fin(n_states, INF), beta(n_states, INF);
   for (int i = 0; i < n_final; ++i) fin[final_state[i]] = std::min(fin[final_state[i]], (double)final_cost[i]);
-  // beta: cheapest completion incl. the final cost (arc costs are >= 0 once the per-frame offsets are taken out).  The
-  // lattice is acyclic, so one relaxation sweep in reverse topological order (Kahn, O(states + arcs)) gives it; should a
-  // cycle of epsilon arcs ever leave states unordered, Dijkstra below takes over.
+  // beta: cheapest completion incl. the final cost.  The lattice is acyclic, so one relaxation sweep in reverse
+  // topological order (Kahn, O(states + arcs)) gives it EXACTLY, whatever the sign of the arc costs (an acoustic cost
+  // logp - log_prior can be negative after the DecodeNumpy prologue; an over-estimated beta would prune valid paths below).
+  // Should a cycle of epsilon arcs ever leave states unordered, Dijkstra takes over -- on costs clamped at 0, the only
+  // place the clamp is needed.
   bool have_beta = false;
   {
     std::vector<int> pending(n_states);
@@ -96,7 +98,7 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       if (t.first > beta[t.second]) continue;
       for (int k = rev_off[t.second]; k < rev_off[t.second + 1]; ++k) {
         const std::pair<int, double>& pr = rev_arc[k];
-        const double c = t.first + pr.second;
+        const double c = t.first + std::max(0.0, pr.second);
         if (c < beta[pr.first]) { beta[pr.first] = c; pq.push({c, pr.first}); }
       }
     }

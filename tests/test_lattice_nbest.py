@@ -72,6 +72,23 @@ def test_random_lattices_against_the_oracle(seed, n, fan, nbest, beam):
     compare(host_nbest(*args), oracle_nbest(*args))
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_negative_acoustic_costs(seed):
+    """Acoustic costs -(logp - log_prior) can be negative after the DecodeNumpy prologue (lm_decoder.cc:30-35): the backward
+    bound must use the same unclamped costs as the forward search, or valid paths are pruned (lattice.cpp:62)."""
+    rs = np.random.RandomState(seed)
+    n, fan = 150, 4
+    src, dst, il, ol, gr, ac = [], [], [], [], [], []
+    for s in range(n - 1):
+        for _ in range(fan):
+            d = rs.randint(s + 1, min(n, s + 6))
+            src.append(s); dst.append(d); il.append(int(rs.randint(0, 6))); ol.append(int(rs.choice([0, 0, 0, 7, 8, 9, 10])))
+            gr.append(float(rs.rand())); ac.append(float(rs.rand() * 3 - 2.0))          # mostly negative
+    fs = np.array([n - 1, n - 2]); fc = np.array([0.0, -0.5], np.float32)
+    args = (n, 0, np.array(src), np.array(dst), il, ol, gr, ac, fs, fc, 40, 3.0)
+    compare(host_nbest(*args), oracle_nbest(*args))
+
+
 def test_real_lattice_against_the_oracle():
     Z = np.load(os.path.join(ROOT, "tests", "golden", "wfst_lattice_u2.npz"))
     n_states, n_arcs, n_final, start, frames = (int(v) for v in Z["meta"])
