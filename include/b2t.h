@@ -412,6 +412,11 @@ int b2t_wfst_best_path(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, cons
                        int32_t* n_words, float* costs, void* stream);
 /* FinalizeDecoding: final costs + backward pruning with lattice_beam; marks the surviving forward links. */
 int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream);
+/* PruneActiveTokens(delta) (lattice-faster-decoder.cc:516-545; the reference calls it every prune_interval = 25 decoded
+ * frames with delta = lattice_beam * prune_scale, :592-630): call between two b2t_wfst_search_f32 calls.  Prunes forward links
+ * and tokens of every frame but the newest against the best path so far and COMPACTS the utterance's token / link arrays, so
+ * a streamed utterance holds its pruned lattice plus the frames since the last call.  Never changes the final lattice. */
+int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, float delta, void* stream);
 /* The pruned lattice in compact form, after b2t_wfst_finalize (GetRawLattice, lattice-faster-decoder.cc:106-186): surviving
  * tokens renumbered, surviving links as arcs with acoustic = link acoustic cost - the frame's cost offset, final costs of
  * the last frame's tokens.  Per utterance u: arcs at [u * cap_arcs ..), finals at [u * cap_final ..),

@@ -138,6 +138,7 @@ _SIGNATURES = {
     "b2t_wfst_best_path": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP,
                                     VP, VP, VP]),
     "b2t_wfst_finalize": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, VP]),
+    "b2t_wfst_prune": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_float, VP]),
     "b2t_wfst_lattice": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP,
                                   VP, VP, VP, VP, VP]),
     "b2t_wfst_state_offsets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LL)]),

@@ -46,7 +46,9 @@ struct Hdr {
   float final_best;    // best (cost + final cost) on the last frame
   int has_final;
   unsigned arcs_lo, arcs_hi;   // emitting arcs expanded so far (64-bit): 16 B of graph each, the algorithmic traffic of the search
-  int pad[4];
+  int links_marked;    // links [0, links_marked) survived the last PruneActiveTokens pass (link_alive valid, all 1)
+  int n_prunes;        // PruneActiveTokens passes so far
+  int peak_tok, peak_link;   // high-water marks of n_tok / n_link (before the passes compacted them)
 };
 
 struct Lay {
@@ -343,6 +345,7 @@ __device__ void init_decoding(Ctx& c) {
     Hdr* h = c.l.h;
     h->n_frames = 0; h->overflow = 0; h->num_input = 0; h->is_last_blank = 0; h->last_best = 0; h->finalized = 0;
     h->final_best = 0.f; h->has_final = 0; h->arcs_lo = 0u; h->arcs_hi = 0u;
+    h->links_marked = 0; h->n_prunes = 0; h->peak_tok = 0; h->peak_link = 0;
     c.sh[0] = 0; c.sh[1] = 0; c.sh[3] = 0;
     c.l.tok_off[0] = 0;
     c.l.link_off[0] = 0;
@@ -707,6 +710,168 @@ __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state,
   }
 }
 
+
+// PruneActiveTokens (lattice-faster-decoder.cc:516-545, called every prune_interval frames at :592-630) as a pass of its own
+// between two search calls: PruneForwardLinks (:297-374) on the frames F-1 .. 0 -- the tokens of the newest frame F are
+// never pruned and count with extra_cost 0 --, going back only as far as something still changes, then PruneTokensForFrame
+// (:489-514) as a stable in-place COMPACTION of the token and link arrays (the reference frees list nodes; here the arrays
+// of the state block shrink, so a streamed utterance holds its pruned lattice plus at most prune_interval raw frames).
+// Extra costs computed against the best path SO FAR are lower bounds of the final ones, so this removes only what
+// FinalizeDecoding would remove: the final lattice is the same with or without these passes (tested).
+__global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
+                                                         int max_tok, int max_link, int hash, float delta) {
+  __shared__ float redf[NT];
+  __shared__ int scan[NT / 64 + 1];
+  __shared__ int changed, big_change, run_s, jb_s;
+  const int u = blockIdx.x;
+  Lay l;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
+  const int F = l.h->n_frames;
+  if (F < 2 || l.h->overflow || l.h->finalized) return;
+  const unsigned INF_BITS = 0x7f800000u;
+  const int n_tok = min(l.h->n_tok, max_tok), n_link = min(l.h->n_link, max_link);
+  for (int li = l.h->links_marked + (int)threadIdx.x; li < n_link; li += NT) l.link_alive[li] = 1;
+  __syncthreads();
+  // ---- PruneForwardLinks, frames F-1 .. 0, stopping at the first frame where nothing moved by more than delta
+  int f_stop = -1;
+  for (int f = F - 1; f >= 0; --f) {
+    const int a0 = l.tok_off[f], a1 = l.tok_off[f + 1];
+    const int e0 = f == 0 ? 0 : l.link_off[2 * f], e1 = l.link_off[2 * f + 1];      // eps links of frame f
+    const int m0 = l.link_off[2 * f + 1], m1 = l.link_off[2 * f + 2];                 // emitting f -> f+1
+    __syncthreads();
+    if (threadIdx.x == 0) big_change = 0;
+    for (int iter = 0; iter < 1000; ++iter) {
+      __syncthreads();
+      if (threadIdx.x == 0) changed = 0;
+      __syncthreads();
+      for (int t = a0 + threadIdx.x; t < a1; t += NT) { l.tok_prev[t] = l.tok_extra[t]; l.tok_extra[t] = INF_BITS; }
+      __syncthreads();
+      for (int pass = 0; pass < 2; ++pass) {
+        const int q0 = pass == 0 ? e0 : m0, q1 = pass == 0 ? e1 : m1;
+        for (int li = q0 + threadIdx.x; li < q1; li += NT) {
+          if (!l.link_alive[li]) continue;
+          const int src = l.link_src[li], dst = l.link_dst[li];
+          const float dst_extra = __uint_as_float(pass == 0 ? l.tok_prev[dst] : l.tok_extra[dst]);
+          float lec = dst_extra + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+          if (lec > o.lattice_beam) { l.link_alive[li] = 0; big_change = 1; continue; }
+          if (lec < 0.f) lec = 0.f;
+          atomicMin(&l.tok_extra[src], __float_as_uint(lec));
+        }
+      }
+      __syncthreads();
+      for (int t = a0 + threadIdx.x; t < a1; t += NT) {
+        const unsigned nv = l.tok_extra[t], ov = l.tok_prev[t];
+        if (nv != ov) {
+          changed = 1;
+          if (nv == INF_BITS || ov == INF_BITS || fabsf(__uint_as_float(nv) - __uint_as_float(ov)) > delta) big_change = 1;
+        }
+      }
+      __syncthreads();
+      if (!changed) break;
+    }
+    __syncthreads();
+    if (!big_change) { f_stop = f; break; }
+  }
+  // ---- compaction of the tokens of frames f_stop+1 .. F-1 and of every link that starts in frame f_stop or later
+  const int T0 = l.tok_off[f_stop + 1];
+  const int TF = l.tok_off[F];                      // tokens of the newest frame always stay
+  const int L0 = f_stop >= 0 ? l.link_off[2 * f_stop + 1] : 0;
+  int* excl = reinterpret_cast<int*>(l.tok_prev);   // [t] = surviving tokens in [T0, t): new id = T0 + excl[t]
+  auto block_excl = [&](int flag, int& total) {     // exclusive prefix of `flag` over the block (two barriers)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = flag;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) scan[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int k = 0; k < NT / 64; ++k) { const int v = scan[k]; if (k < w) base += v; tot += v; }
+    __syncthreads();
+    total = tot;
+    return base + incl - flag;
+  };
+  auto tok_alive = [&](int t) { return t >= TF || l.tok_extra[t] != INF_BITS; };
+  if (threadIdx.x == 0) { run_s = 0; jb_s = f_stop + 2; }
+  __syncthreads();
+  for (int base = T0; base < n_tok; base += NT) {           // pass 1: new ids; new tok_off of every frame boundary met
+    const int t = base + (int)threadIdx.x;
+    const int a = t < n_tok ? (int)tok_alive(t) : 0;
+    int tot;
+    const int ex = block_excl(a, tot);
+    const int run = run_s;
+    if (t < n_tok) excl[t] = run + ex;
+    redf[threadIdx.x] = __int_as_float(run + ex);            // (LDS copy for the boundary look-ups below)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int jb = jb_s;
+      while (jb <= F + 1 && l.tok_off[jb] < base + NT && l.tok_off[jb] < n_tok) {
+        l.tok_off[jb] = T0 + __float_as_int(redf[l.tok_off[jb] - base]);
+        ++jb;
+      }
+      jb_s = jb; run_s = run + tot;
+    }
+    __syncthreads();
+  }
+  const int n_tok_new = T0 + run_s;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (int jb = jb_s; jb <= F + 1; ++jb) l.tok_off[jb] = n_tok_new; run_s = 0; jb_s = f_stop >= 0 ? 2 * f_stop + 2 : 1; }
+  __syncthreads();
+  for (int base = L0; base < n_link; base += NT) {          // pass 2: links -- drop, remap, move; new link_off
+    const int li = base + (int)threadIdx.x;
+    int a = 0, src = 0, dst = 0, arc = 0; float ac = 0.f, gr = 0.f;
+    if (li < n_link) {
+      src = l.link_src[li]; dst = l.link_dst[li]; arc = l.link_arc[li]; ac = l.link_ac[li]; gr = l.link_graph[li];
+      a = l.link_alive[li] && (src < T0 || tok_alive(src)) && (dst < T0 || tok_alive(dst));
+      if (src >= T0) src = T0 + excl[src];
+      if (dst >= T0) dst = T0 + excl[dst];
+    }
+    int tot;
+    const int ex = block_excl(a, tot);
+    const int run = run_s;
+    redf[threadIdx.x] = __int_as_float(run + ex);
+    __syncthreads();
+    if (a) {
+      const int k = L0 + run + ex;                           // k <= li, and every read of this chunk is done
+      l.link_src[k] = src; l.link_dst[k] = dst; l.link_arc[k] = arc; l.link_ac[k] = ac; l.link_graph[k] = gr; l.link_alive[k] = 1;
+    }
+    if (threadIdx.x == 0) {
+      int jb = jb_s;
+      while (jb <= 2 * F + 1 && l.link_off[jb] < base + NT && l.link_off[jb] < n_link) {
+        l.link_off[jb] = L0 + __float_as_int(redf[l.link_off[jb] - base]);
+        ++jb;
+      }
+      jb_s = jb; run_s = run + tot;
+    }
+    __syncthreads();
+  }
+  const int n_link_new = L0 + run_s;
+  __syncthreads();
+  if (threadIdx.x == 0) for (int jb = jb_s; jb <= 2 * F + 1; ++jb) l.link_off[jb] = n_link_new;
+  __syncthreads();
+  for (int base = T0; base < n_tok; base += NT) {           // pass 3: move the surviving tokens
+    const int t = base + (int)threadIdx.x;
+    int a = 0, st = 0, k = 0; unsigned cs = 0u, ex = 0u;
+    if (t < n_tok) { a = tok_alive(t); st = l.tok_state[t]; cs = l.tok_cost[t]; ex = l.tok_extra[t]; k = T0 + excl[t]; }
+    __syncthreads();
+    if (a) { l.tok_state[k] = st; l.tok_cost[k] = cs; l.tok_extra[k] = ex; l.tok_best[k] = 0x7fffffff; }
+    __syncthreads();
+  }
+  // backpointers of the moved tokens: the first surviving link whose cost equals the token's (best_links' rule)
+  for (int li = L0 + (int)threadIdx.x; li < n_link_new; li += NT) {
+    const int src = l.link_src[li], dst = l.link_dst[li];
+    if (dst < T0) continue;
+    const float tot = o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li];
+    if (f2o(tot) == l.tok_cost[dst]) atomicMin(&l.tok_best[dst], li);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (T0 == 0) l.tok_best[0] = -1;
+    Hdr* h = l.h;
+    h->peak_tok = max(h->peak_tok, n_tok); h->peak_link = max(h->peak_link, n_link);
+    h->n_tok = n_tok_new; h->n_link = n_link_new; h->links_marked = n_link_new; h->n_prunes += 1;
+  }
+}
+
 // The pruned lattice in compact form (GetRawLattice, lattice-faster-decoder.cc:106-186, after FinalizeDecoding): surviving
 // tokens renumbered 0..n-1, surviving links as arcs (src, dst, ilabel, olabel, graph, acoustic - cost_offset), final costs
 // of the last frame's tokens.  counts[u] = {n_states, n_arcs, n_final, start state, overflow}.
@@ -831,6 +996,16 @@ extern "C" int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_
   hipLaunchKernelGGL(wfst_finalize_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
                      o->max_frames, o->max_tokens, o->max_links, o->hash_size);
   B2T_CHECK_LAUNCH("b2t_wfst_finalize");
+  return 0;
+}
+
+extern "C" int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, float delta, void* stream) {
+  { int rc = check_args(g, o, state, U, "wfst_prune"); if (rc) return rc; }
+  B2T_REQUIRE(delta >= 0.f, "wfst_prune: negative delta");
+  const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
+  hipLaunchKernelGGL(wfst_prune_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, delta);
+  B2T_CHECK_LAUNCH("b2t_wfst_prune");
   return 0;
 }
 

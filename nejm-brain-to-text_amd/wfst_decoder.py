@@ -42,7 +42,7 @@ def _pow2_at_least(n: int) -> int:
 
 class WfstSearch:
     def __init__(self, graph, opts, U: int = 1, device="cuda:0", max_frames: int = 1024, max_tokens: int = 1 << 19,
-                 max_links: int = 1 << 21, hash_size: int = 0):
+                 max_links: int = 1 << 21, hash_size: int = 0, prune_interval: int = 25, prune_scale: float = 0.1):
         """graph: wfst.DecodeGraph.  opts: an object with the reference's DecodeOptions fields (max_active, min_active, beam,
         lattice_beam, acoustic_scale, ctc_blank_skip_threshold, length_penalty, nbest)."""
         self.g, self.U, self.device = graph, int(U), torch.device(device)
@@ -54,6 +54,11 @@ class WfstSearch:
         if hash_size <= 0:   # a frame can hold at most one token per graph state
             hash_size = max(1024, min(1 << 16, _pow2_at_least(2 * min(graph.n_states, 1 << 15))))
         self.caps = (int(max_frames), int(max_tokens), int(max_links), int(hash_size))
+        # LatticeFasterDecoderConfig::prune_interval / prune_scale (lattice-faster-decoder.h:62-72): PruneActiveTokens every
+        # prune_interval frames; 0 = never (everything is pruned once, in finalize -- same lattice, more memory)
+        self.prune_interval = int(os.environ.get("B2T_WFST_PRUNE_INTERVAL", prune_interval))
+        self.prune_scale = float(prune_scale)
+        self._since_prune = 0
         self.set_opts(opts)
         self.state_bytes = self.lib.b2t_wfst_state_bytes(*self.caps)
         self.state = torch.zeros((self.U * self.state_bytes,), dtype=torch.uint8, device=self.device)
@@ -78,6 +83,14 @@ class WfstSearch:
         with torch.cuda.device(self.device):
             N.check(self.lib.b2t_wfst_reset(C.byref(self.cg), C.byref(self.co), ops._p(self.state), self.U, self._s()), "b2t_wfst_reset")
         self.finalized = False
+        self._since_prune = 0
+
+    def prune(self):
+        """PruneActiveTokens(lattice_beam * prune_scale) for every utterance + compaction of their token / link arrays."""
+        with torch.cuda.device(self.device):
+            N.check(self.lib.b2t_wfst_prune(C.byref(self.cg), C.byref(self.co), ops._p(self.state), self.U,
+                                            C.c_float(self.lattice_beam * self.prune_scale), self._s()), "b2t_wfst_prune")
+        self._since_prune = 0
 
     # ---- Search ------------------------------------------------------------------------------------------------------
     def search(self, logp: torch.Tensor, lens=None):
@@ -87,9 +100,21 @@ class WfstSearch:
         if U != self.U:
             raise ValueError(f"expected {self.U} utterances")
         lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32).to(self.device).contiguous()
-        with torch.cuda.device(self.device):
-            N.check(self.lib.b2t_wfst_search_f32(C.byref(self.cg), C.byref(self.co), ops._p(self.state), ops._p(logp),
-                                                 ops._p(lens_t), U, T, Cc, self._s()), "b2t_wfst_search_f32")
+        iv = self.prune_interval
+        t0 = 0
+        while t0 < T:
+            # the reference prunes whenever NumFramesDecoded() % prune_interval == 0 (lattice-faster-decoder.cc:592-630): a
+            # long call is cut into pieces of at most prune_interval input frames with a PruneActiveTokens pass between them
+            t1 = T if iv <= 0 else min(T, t0 + max(1, iv - self._since_prune))
+            piece = logp if (t0 == 0 and t1 == T) else logp[:, t0:t1].contiguous()
+            ln = lens_t if (lens_t is None or (t0 == 0 and t1 == T)) else (lens_t - t0).clamp(0, t1 - t0).to(torch.int32).contiguous()
+            with torch.cuda.device(self.device):
+                N.check(self.lib.b2t_wfst_search_f32(C.byref(self.cg), C.byref(self.co), ops._p(self.state), ops._p(piece),
+                                                     ops._p(ln), U, t1 - t0, Cc, self._s()), "b2t_wfst_search_f32")
+            self._since_prune += t1 - t0
+            if iv > 0 and self._since_prune >= iv:
+                self.prune()
+            t0 = t1
 
     def best_path(self, use_final: bool = False, max_len: int = 0):
         """[(inputs, times, words, lm_score, ac_score)] per utterance: GetBestPath + ConvertToInputs + the likelihood pair."""
@@ -112,7 +137,13 @@ class WfstSearch:
 
     def _header(self):
         st = self.state.view(self.U, self.state_bytes)
-        return st[:, self.off[0]:self.off[0] + 48].contiguous().view(torch.int32).cpu().numpy()
+        return st[:, self.off[0]:self.off[0] + 64].contiguous().view(torch.int32).cpu().numpy()
+
+    def memory_stats(self):
+        """Per utterance: tokens / links held now, their high-water marks, PruneActiveTokens passes so far."""
+        h = self._header()
+        return [dict(tokens=int(r[1]), links=int(r[2]), peak_tokens=max(int(r[14]), int(r[1])), peak_links=max(int(r[15]), int(r[2])),
+                     prunes=int(r[13])) for r in h]
 
     def _check_overflow(self):
         h = self._header()

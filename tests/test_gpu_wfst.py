@@ -156,6 +156,53 @@ def test_wfst_tight_pruning_and_overflow(toy):
         small.finalize()
 
 
+def test_prune_active_tokens_bounds_memory_and_keeps_the_lattice(toy):
+    """PruneActiveTokens every prune_interval frames (lattice-faster-decoder.cc:516-545, :592-630) as b2t_wfst_prune between
+    search calls: the n-best lists, the partial best paths and the decoded frames are those of a search that prunes only once,
+    at the end (interval 0) -- for the reference's interval 25, for 7 (many passes, early stops, repeated compaction) and for a
+    frame-by-frame stream -- while the tokens and links an utterance holds stay a fraction of what it created."""
+    from wfst_decoder import WfstSearch
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(31)
+    seqs, lps, batch, lens = utterances(prons, words, 4, rs, noise=1.1, n_words=(9, 14))
+    assert batch.shape[1] > 90
+    dev_batch = torch.from_numpy(batch).cuda()
+    o = Opt(nbest=30)
+    runs = {}
+    for tag, iv, stream in (("never", 0, False), ("ref25", 25, False), ("iv7", 7, False), ("stream25", 25, True)):
+        # (without the passes these four utterances overflow WfstSearch's default 512 k tokens: what the pruning is for)
+        big = dict(max_tokens=1 << 21, max_links=1 << 23) if iv == 0 else {}
+        S = WfstSearch(g, o, U=4, max_frames=batch.shape[1] + 8, prune_interval=iv, **big)
+        parts = []
+        if stream:
+            for t in range(batch.shape[1]):
+                S.search(dev_batch[:, t:t + 1].contiguous(), np.clip(lens - t, 0, 1))
+                if t % 20 == 19 or t == batch.shape[1] - 1:
+                    parts.append([p[2] for p in S.best_path(False)])
+        else:
+            for t0 in range(0, batch.shape[1], 20):
+                S.search(dev_batch[:, t0:t0 + 20].contiguous(), np.clip(lens - t0, 0, 20))
+                parts.append([p[2] for p in S.best_path(False)])
+        mem = S.memory_stats()
+        runs[tag] = (parts, S.frames_decoded(), mem, S.finalize())
+    base = runs["never"]
+    assert all(m["prunes"] == 0 for m in base[2])
+    for tag in ("ref25", "iv7", "stream25"):
+        parts, frames, mem, fin = runs[tag]
+        assert frames == base[1] and parts == base[0], tag
+        for u in range(4):
+            assert len(fin[u]) == len(base[3][u]) > 0, (tag, u)
+            for a, b in zip(fin[u], base[3][u]):
+                assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[4] == b[4], (tag, u)   # bit-identical
+            assert mem[u]["prunes"] >= (3 if tag != "iv7" else 10)
+            # held at the end (pruned lattice + the frames since the last pass) vs everything the search created
+            assert mem[u]["tokens"] < 0.5 * base[2][u]["tokens"] and mem[u]["links"] < 0.5 * base[2][u]["links"], (tag, u, mem[u], base[2][u])
+    # one utterance against the oracle too (which runs PruneActiveTokens every 25 frames itself)
+    R = W.CtcWfstBeamSearch(g, cfg_of(o))
+    R.search(lps[0]); R.finalize_search()
+    compare_lists(runs["iv7"][3][0], R, "iv7 vs oracle")
+
+
 def test_wfst_binding_regime_bench_graph():
     """The regime production runs in: the tools/bench_wfst.py graph (400 words x word 3-gram,
     120 k states / 419 k arcs), production options, 5 utterances with 8.3-8.6 k tokens per frame -- max_active = 7000 decides
