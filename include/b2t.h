@@ -400,6 +400,11 @@ typedef struct {
   int32_t max_frames, max_tokens, max_links, hash_size;
 } b2t_wfst_opts_t;
 size_t b2t_wfst_state_bytes(int max_frames, int max_tokens, int max_links, int hash_size);
+/* Workgroups per utterance b2t_wfst_search_f32 will use for U utterances: 8 / 4 / 2 share one utterance's frame (a cluster
+ * behind one XCD's L2, cluster barriers and L2 atomics) while every cluster fits the chip, else 1 (one workgroup per
+ * utterance, frame hash in LDS).  No reference counterpart (the reference's search is one CPU thread). */
+int b2t_wfst_cluster_size(int U);
+int b2t_wfst_set_cluster(int G);   /* process-wide override: 1 / 2 / 4 / 8 workgroups per utterance, 0 = automatic (B2T_WFST_CLUSTER) */
 int b2t_wfst_reset(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream);   /* InitDecoding */
 /* logp [U][T][C] (C <= 64), lens [U] or NULL: blank-frame skipping + AdvanceDecoding(.., 1) per kept frame */
 int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, const float* logp,
@@ -415,8 +420,11 @@ int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void*
 /* PruneActiveTokens(delta) (lattice-faster-decoder.cc:516-545; the reference calls it every prune_interval = 25 decoded
  * frames with delta = lattice_beam * prune_scale, :592-630): call between two b2t_wfst_search_f32 calls.  Prunes forward links
  * and tokens of every frame but the newest against the best path so far and COMPACTS the utterance's token / link arrays, so
- * a streamed utterance holds its pruned lattice plus the frames since the last call.  Never changes the final lattice. */
-int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, float delta, void* stream);
+ * a streamed utterance holds its pruned lattice plus the frames since the last call.  Never changes the final lattice.
+ * min_fill in [0, 1]: an utterance whose token AND link arrays are filled below that fraction of their capacity skips the
+ * pass (the pass only bounds memory); 0 = always prune, the reference's behaviour. */
+int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, float delta, float min_fill,
+                   void* stream);
 /* The pruned lattice in compact form, after b2t_wfst_finalize (GetRawLattice, lattice-faster-decoder.cc:106-186): surviving
  * tokens renumbered, surviving links as arcs with acoustic = link acoustic cost - the frame's cost offset, final costs of
  * the last frame's tokens.  Per utterance u: arcs at [u * cap_arcs ..), finals at [u * cap_final ..),

@@ -133,12 +133,14 @@ _SIGNATURES = {
     "b2t_greedy_decode_f32": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_edit_distance_i32": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, VP, C.c_int, VP]),
     "b2t_wfst_state_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "b2t_wfst_cluster_size": (C.c_int, [C.c_int]),
+    "b2t_wfst_set_cluster": (C.c_int, [C.c_int]),
     "b2t_wfst_reset": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, VP]),
     "b2t_wfst_search_f32": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_wfst_best_path": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP,
                                     VP, VP, VP]),
     "b2t_wfst_finalize": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, VP]),
-    "b2t_wfst_prune": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_float, VP]),
+    "b2t_wfst_prune": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_float, C.c_float, VP]),
     "b2t_wfst_lattice": (C.c_int, [C.POINTER(WfstGraph), C.POINTER(WfstOpts), VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP,
                                   VP, VP, VP, VP, VP]),
     "b2t_wfst_state_offsets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LL)]),

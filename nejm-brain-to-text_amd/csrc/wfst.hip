@@ -49,6 +49,22 @@ struct Hdr {
   int links_marked;    // links [0, links_marked) survived the last PruneActiveTokens pass (link_alive valid, all 1)
   int n_prunes;        // PruneActiveTokens passes so far
   int peak_tok, peak_link;   // high-water marks of n_tok / n_link (before the passes compacted them)
+  int removed_tok, removed_link;   // what the PruneActiveTokens passes removed so far (created = held + removed)
+};
+
+// Scratch of the CLUSTER search (several workgroups per utterance, wfst_cluster_kernel below): every word is written with L2
+// atomics or plain stores and read with L1-bypassing (sc1) loads by the workgroups of one cluster, which share an XCD's L2.
+constexpr int WLG_CAP = 1 << 16;   // epsilon work list of a frame (tokens whose state has input-epsilon arcs)
+constexpr int HEAVY_CAP = 1 << 14; // heavy-token list of a frame
+constexpr int HEAVY_DEG = 32;
+struct Clu {
+  unsigned bar, bar_base; int pad0[14];          // cluster barrier: monotonic arrival counter, its value when the last launch ended
+  int n_tok, n_link, overflow, wl_n;             // the counters the single-workgroup kernel keeps in LDS
+  unsigned best[2], cand_min[2]; int narcs[2];   // per frame parity: cheapest token of the frame, cheapest candidate, arcs walked
+  int changed[8];                                // per closure round (mod 8): a cost went down
+  int xcc[8];                                    // XCC_ID each member saw (placement check)
+  int n_heavy, pad1;                             // tokens of the frame with more than HEAVY_DEG emitting arcs (word-boundary states)
+  int hist[2][4][256];                           // radix-select histograms: [max_active / min_active][round][digit]
 };
 
 struct Lay {
@@ -56,6 +72,7 @@ struct Lay {
   int* tok_state; unsigned* tok_cost; int* tok_best; unsigned* tok_extra; unsigned* tok_prev;
   int* link_src; int* link_dst; int* link_arc; float* link_ac; float* link_graph; unsigned char* link_alive;
   int* gkey; int* gidx;
+  Clu* clu; int* wlg; int* gkey2; int* gidx2; int* heavy;
 };
 
 __host__ __device__ inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -82,7 +99,12 @@ __host__ __device__ inline size_t layout(char* base, int max_frames, int max_tok
   unsigned char* lv = reinterpret_cast<unsigned char*>(take(max_link));
   int* gk = reinterpret_cast<int*>(take(sizeof(int) * hash));
   int* gi = reinterpret_cast<int*>(take(sizeof(int) * hash));
-  if (l) *l = Lay{h, lp, mp, to, lo, co, ts, tc, tb, te, tp, ls, ld, la, lac, lg, lv, gk, gi};
+  Clu* cl = reinterpret_cast<Clu*>(take(sizeof(Clu)));
+  int* wg = reinterpret_cast<int*>(take(sizeof(int) * WLG_CAP));
+  int* gk2 = reinterpret_cast<int*>(take(sizeof(int) * hash));
+  int* gi2 = reinterpret_cast<int*>(take(sizeof(int) * hash));
+  int* hv = reinterpret_cast<int*>(take(sizeof(int) * HEAVY_CAP));
+  if (l) *l = Lay{h, lp, mp, to, lo, co, ts, tc, tb, te, tp, ls, ld, la, lac, lg, lv, gk, gi, cl, wg, gk2, gi2, hv};
   return o;
 }
 
@@ -201,6 +223,7 @@ __device__ float kth_cost(Ctx& c, int t0, int t1, int k) {
   return o2f(prefix);
 }
 
+__device__ __forceinline__ unsigned xcc_of() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 0xf; }
 __device__ __forceinline__ unsigned hash_of(int state, int mask) { return ((unsigned)state * 2654435761u) & (unsigned)mask; }
 
 // FindOrAddToken, claim phase: make sure `state` has a slot (and a token) in the frame being built; returns the slot
@@ -345,7 +368,8 @@ __device__ void init_decoding(Ctx& c) {
     Hdr* h = c.l.h;
     h->n_frames = 0; h->overflow = 0; h->num_input = 0; h->is_last_blank = 0; h->last_best = 0; h->finalized = 0;
     h->final_best = 0.f; h->has_final = 0; h->arcs_lo = 0u; h->arcs_hi = 0u;
-    h->links_marked = 0; h->n_prunes = 0; h->peak_tok = 0; h->peak_link = 0;
+    h->links_marked = 0; h->n_prunes = 0; h->peak_tok = 0; h->peak_link = 0; h->removed_tok = 0; h->removed_link = 0;
+    c.l.clu->bar = 0u; c.l.clu->bar_base = 0u; c.l.clu->overflow = 0;
     c.sh[0] = 0; c.sh[1] = 0; c.sh[3] = 0;
     c.l.tok_off[0] = 0;
     c.l.link_off[0] = 0;
@@ -500,6 +524,538 @@ __device__ void setup(Ctx& c, const Graph& g, char* state, int u, size_t state_b
   c.ll = ll; c.redf = redf; c.redi = redi; c.sh = sh; c.wl = wl;
 }
 
+
+// =====================================================================================================================
+// CLUSTER search: G workgroups (G = 2, 4 or 8) per utterance instead of one, so that 32 utterances use the whole chip
+// instead of 32 of its 256 CUs.  The G workgroups of an utterance are placed on ONE XCD (block b runs on XCD b % 8; checked
+// at run time through XCC_ID), i.e. behind one L2:
+//   * the frame's token hash, the tokens, the links and a handful of counters live in the utterance's state block and are
+//     shared through that L2: plain stores (write-through the CU's vector cache into L2), L2 atomics (hash CAS, cost
+//     atomicMin, counters) and L1-bypassing sc1 loads for everything another workgroup may have written;
+//   * a frame is a sequence of phases separated by CLUSTER barriers (a monotonic arrival counter in L2, one lane per
+//     workgroup arrives and polls) -- 6 per frame, + 4 when max_active binds -- instead of the ~45 workgroup barriers of the
+//     single-workgroup kernel: claim and relax are ONE phase (the claim's winner publishes the token id AFTER the token's
+//     fields have reached L2; a loser polls the slot), the epsilon work list is appended to by whoever creates a token, the
+//     frame's best cost is kept by atomicMin while costs are written, two hashes alternate so that clearing one hides
+//     under pass A, and the backpointer pass of a frame runs inside pass A of the next.
+// Same arithmetic and the same results as wfst_search_kernel (tests/test_gpu_wfst.py runs both against the oracle).
+// =====================================================================================================================
+constexpr int UNSET = -2;
+constexpr unsigned CBAR_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ int ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldf(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#ifdef B2T_WFST_TIMING
+#define CT(i) { if (c.gtid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); c.tacc[i] += now_ - c.tprev; c.tprev = now_; } }
+#else
+#define CT(i)
+#endif
+
+struct CCtx {
+#ifdef B2T_WFST_TIMING
+  unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
+  Graph g; Lay l; Opts o; Clu* cl;
+  int max_frames, max_tok, max_link, hash;
+  int G, j, gtid, gthreads;
+  unsigned bar_target;
+  float* ll; float* redf; int* redi; int* lsh;   // LDS: frame log-likelihoods, reduction scratch, [0] dead flag, [1..] scalars
+  int* key; int* idx;                            // hash of the frame being built
+};
+
+// Cluster barrier.  Every store this workgroup issued has reached L2 (vmcnt(0): stores are acknowledged by L2) before its
+// arrival is counted; readers use sc1 loads, so nothing has to be invalidated.  Returns false after a timeout (a member is
+// not resident or died): the overflow word gets bit 32 and every member leaves at its next barrier.
+__device__ bool cbar(CCtx& c) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  c.bar_target += (unsigned)c.G;
+  if (threadIdx.x == 0 && !c.lsh[0]) {
+    __hip_atomic_fetch_add(&c.cl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while ((int)(ldu(&c.cl->bar) - c.bar_target) < 0) {
+      if (++spins > CBAR_SPIN_LIMIT || ((spins & 1023u) == 0u && (ldi(&c.cl->overflow) & 32))) { atomicOr(&c.cl->overflow, 32); c.lsh[0] = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  return c.lsh[0] == 0;
+}
+
+__device__ __forceinline__ float cblock_min(CCtx& c, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) c.redf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = c.redf[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r = fminf(r, c.redf[w]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ int cblock_sum(CCtx& c, int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) c.redi[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = c.redi[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) r += c.redi[w];
+  __syncthreads();
+  return r;
+}
+
+// k-th smallest cost of the tokens [t0, t1): the radix select of kth_cost with the histogram of a round summed over the
+// cluster in L2 (every member then picks the digit from the same 256 numbers): one cluster barrier per round.
+__device__ float ckth_cost(CCtx& c, int t0, int t1, int k, int set, bool& ok) {
+  int* hist = c.redi + 64;
+  int* res = c.redi + 320;
+  unsigned prefix = 0u;
+  int rank = k;
+  for (int round = 0; round < 4; ++round) {
+    const int shift = 24 - 8 * round;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int tb = t0 + c.j * NT; tb < t1; tb += c.gthreads) {
+      const int t = tb + (int)threadIdx.x;
+      const unsigned key = t < t1 ? ldu(&c.l.tok_cost[t]) : 0u;
+      const bool act = t < t1 && (round == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
+      const int d = (int)((key >> shift) & 255u);
+      if (round < 2) {
+        unsigned long long todo = __ballot(act);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const int dl = __shfl(d, leader);
+          const unsigned long long peers = __ballot(act && d == dl);
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], __popcll(peers));
+          todo &= ~peers;
+        }
+      } else if (act) {
+        atomicAdd(&hist[d], 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&c.cl->hist[set][round][threadIdx.x], hist[threadIdx.x]);
+    if (!cbar(c)) { ok = false; return 0.f; }
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      const int* gh = c.cl->hist[set][round];
+      const int h0 = ldi(gh + 4 * lane), h1 = ldi(gh + 4 * lane + 1), h2 = ldi(gh + 4 * lane + 2), h3 = ldi(gh + 4 * lane + 3);
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+      const int excl = incl - mine;
+      if (rank >= excl && rank < incl) {
+        int r = rank - excl, d = 4 * lane;
+        if (r >= h0) { r -= h0; ++d; if (r >= h1) { r -= h1; ++d; if (r >= h2) { r -= h2; ++d; } } }
+        res[0] = d; res[1] = r;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)res[0] << shift;
+    rank = res[1];
+    __syncthreads();
+  }
+  return o2f(prefix);
+}
+
+// One slot per ACTIVE lane from a shared counter with ONE atomic per wave: a counter word in L2 serves ~90 atomics per
+// microsecond, and a frame allocates ~50 k links and ~8 k tokens (one atomic each: 60 ms of the first version's 72).
+__device__ __forceinline__ int wave_alloc(int* counter) {
+  const unsigned long long m = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader, 64);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// FindOrAddToken across the cluster: returns the token id of `state` in the frame being built (-1: hash or token capacity
+// exhausted).  A hash slot is ONE 8-byte word {state, token id} (the two int arrays of the layout are contiguous), so the
+// common case -- the token exists -- is a single L1-bypassing 8-byte load.  The CAS (on the state half) winner allocates the
+// token, writes its fields, waits until they are in L2 and only then publishes the id in the other half; everyone else polls
+// the word.  A new token whose state has epsilon arcs joins the work list.
+__device__ __forceinline__ int cclaim(CCtx& c, int state) {
+  const int mask = c.hash - 1;
+  unsigned s = hash_of(state, mask);
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(c.key);
+  for (int probe = 0; probe < c.hash; ++probe, s = (s + 1) & mask) {
+    unsigned long long v = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int k = (int)(unsigned)(v & 0xffffffffull);
+    if (k == -1) {
+      int* kp = reinterpret_cast<int*>(&slots[s]);
+      int expected = -1;
+      if (__hip_atomic_compare_exchange_strong(kp, &expected, state, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        int id = wave_alloc(&c.cl->n_tok);
+        if (id < c.max_tok) {
+          c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = 0x7fffffff; c.l.tok_extra[id] = 0u;
+          if (c.g.n_eps[state] > 0) {
+            const int w = wave_alloc(&c.cl->wl_n);
+            if (w < WLG_CAP) c.l.wlg[w] = id; else atomicOr(&c.cl->overflow, 16);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          atomicOr(&c.cl->overflow, 1); id = -1;
+        }
+        __hip_atomic_store(kp + 1, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return id;
+      }
+      k = expected;
+      v = ((unsigned long long)(unsigned)UNSET << 32) | (unsigned)k;
+    }
+    if (k == state) {
+      int id = (int)(unsigned)(v >> 32), spins = 0;
+      while (id == UNSET) {
+        if (++spins > (1 << 24)) { atomicOr(&c.cl->overflow, 32); return -1; }
+        id = (int)(unsigned)(__hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+      }
+      return id;
+    }
+  }
+  atomicOr(&c.cl->overflow, 4);
+  return -1;
+}
+
+// best_links over the links [l0, l1) (deferred: runs in pass A of the next frame / at the end of the launch)
+__device__ __forceinline__ void cbest_links(CCtx& c, int l0, int l1) {
+  for (int li = l0 + c.gtid; li < l1; li += c.gthreads) {
+    const int src = ldi(&c.l.link_src[li]), dst = ldi(&c.l.link_dst[li]);
+    const float tot = o2f(ldu(&c.l.tok_cost[src])) + ldf(&c.l.link_ac[li]) + ldf(&c.l.link_graph[li]);
+    if (f2o(tot) == ldu(&c.l.tok_cost[dst])) atomicMin(&c.l.tok_best[dst], li);
+  }
+}
+
+struct CFrame { int f, t0, t1, pl0, pl1; };   // decoded frames so far, tokens of the newest frame, links awaiting best_links
+
+// One AdvanceDecoding(.., 1) by the whole cluster.  fr is cluster-uniform private state, updated on success.
+__device__ bool cadvance(CCtx& c, CFrame& fr) {
+  const Graph& g = c.g;
+  Clu* cl = c.cl;
+  const int f = fr.f, t0 = fr.t0, t1 = fr.t1, par = f & 1, npar = par ^ 1;
+  if (f >= c.max_frames) { if (c.gtid == 0) atomicOr(&cl->overflow, 8); return cbar(c) && false; }
+  CT(0)
+  // ---- GetCutoff (:650-720): the frame's best cost was kept by atomicMin while the costs were written
+  const float best = o2f(ldu(&cl->best[par]));
+  const int n = t1 - t0;
+  const float beam_cutoff = best + c.o.beam;
+  float cur_cutoff = beam_cutoff, adaptive = c.o.beam;
+  {
+    bool ok = true;
+    float max_cut = INFINITY, min_cut = INFINITY;
+    if (n > c.o.max_active) { max_cut = ckth_cost(c, t0, t1, c.o.max_active, 0, ok); if (!ok) return false; }
+    if (max_cut < beam_cutoff) {
+      cur_cutoff = max_cut; adaptive = max_cut - best + c.o.beam_delta;
+    } else {
+      if (n > c.o.min_active) {
+        if (c.o.min_active == 0) min_cut = best;
+        else { min_cut = ckth_cost(c, t0, t1, c.o.min_active, 1, ok); if (!ok) return false; }
+      }
+      if (min_cut > beam_cutoff) { cur_cutoff = min_cut; adaptive = min_cut - best + c.o.beam_delta; }
+    }
+  }
+  CT(1)   // cutoff (k-th cost)
+  const float cost_offset = -best;
+  const float lp = c.o.length_penalty;
+  auto arc_cost = [&](float cur, int s, int a, float& ac, float& gc) {
+    ac = cost_offset - c.ll[g.ilabel[a] - 1];
+    gc = g.weight[a];
+    if (lp != 0.f && g.next[a] != s) gc += lp;
+    return cur + ac + gc;
+  };
+  const int lane = threadIdx.x & 63;
+  int narcs = 0;
+  // Work distribution.  Out-degrees are bimodal: ~3 arcs inside a word, hundreds at the word-boundary states of L o G, and
+  // the word-boundary tokens sit together at the end of a frame's token range (the epsilon closure creates them last).
+  //   light tokens (<= HEAVY_DEG arcs): 64-token blocks dealt round-robin over ALL waves of the cluster (block q -> member
+  //     q % G), arcs flattened inside the wave as in the single-workgroup kernel;
+  //   heavy tokens: collected in a list by pass A's light walk, then one whole wave per heavy token, round-robin.
+  // (With the blocks dealt member by member the members that got the frame's last blocks took 3-4x as long as the others.)
+  const int gwave = (int)(threadIdx.x >> 6) * c.G + c.j, nwaves = c.G * (NT / 64);
+  auto walk_light = [&](bool collect, auto&& visit) {
+    for (int base = t0 + gwave * 64; base < t1; base += nwaves * 64) {    // wave-uniform
+      const int t = base + lane;
+      float cur = INFINITY; int s = 0, a0 = 0, deg = 0;
+      if (t < t1) {
+        cur = o2f(ldu(&c.l.tok_cost[t]));
+        if (cur <= cur_cutoff) { s = ldi(&c.l.tok_state[t]); a0 = g.row[s] + g.n_eps[s]; deg = g.row[s + 1] - a0; }
+      }
+      narcs += deg;
+      if (deg > HEAVY_DEG) {
+        if (collect) {
+          const int hi = wave_alloc(&cl->n_heavy);
+          if (hi < HEAVY_CAP) c.l.heavy[hi] = t; else atomicOr(&cl->overflow, 16);   // (16 k heavy tokens in one frame: capacity error)
+        }
+        deg = 0;
+      }
+      int incl = deg;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+      const int total = __shfl(incl, 63, 64), excl = incl - deg;
+      for (int jb = 0; jb < total; jb += 64) {
+        const int jj = jb + lane;
+        int owner = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) { const int v = __shfl(incl, owner + step - 1, 64); if (v <= jj) owner += step; }
+        owner = min(owner, 63);
+        const int oa0 = __shfl(a0, owner, 64), oex = __shfl(excl, owner, 64), os = __shfl(s, owner, 64);
+        const float ocur = __shfl(cur, owner, 64);
+        if (jj < total) visit(base + owner, ocur, os, oa0 + (jj - oex));
+      }
+    }
+  };
+  auto walk_heavy = [&](auto&& visit) {
+    const int nh = min(ldi(&cl->n_heavy), HEAVY_CAP);
+#ifdef B2T_WFST_TIMING
+    if (c.gtid == 0) { c.tacc[12] += nh; c.tacc[13] += 1; }
+#endif
+    for (int i = gwave; i < nh; i += nwaves) {
+      const int t = ldi(&c.l.heavy[i]);
+      const float cur = o2f(ldu(&c.l.tok_cost[t]));
+      const int s = ldi(&c.l.tok_state[t]);
+      const int a0 = g.row[s] + g.n_eps[s], deg = g.row[s + 1] - a0;
+      for (int jb = 0; jb < deg; jb += 64) if (jb + lane < deg) visit(t, cur, s, a0 + jb + lane);
+    }
+  };
+  // ---- pass A: the frame's cheapest candidate.  Under it: the previous frame's backpointers, the other hash cleared,
+  //      the next parity's accumulators and the histograms reset.
+  float mn = INFINITY;
+  auto visit_a = [&](int, float cur, int s, int a) { float ac, gc; mn = fminf(mn, arc_cost(cur, s, a, ac, gc)); };
+  walk_light(true, visit_a);
+  CT(11)  // pass A, light tokens
+  if (!cbar(c)) return false;                    // the heavy list is complete
+  walk_heavy(visit_a);
+  mn = cblock_min(c, mn);
+  narcs = cblock_sum(c, narcs);
+  if (threadIdx.x == 0) { atomicMin(&cl->cand_min[par], f2o(mn)); atomicAdd(&cl->narcs[par], narcs); }
+  CT(2)   // pass A walk
+  cbest_links(c, fr.pl0, fr.pl1);
+  CT(3)   // deferred best links
+  int* nkey = npar ? c.l.gkey2 : c.l.gkey; int* nidx = nkey + c.hash;    // (key / idx arrays are adjacent: 8-byte slots)
+  {
+    unsigned long long* ns = reinterpret_cast<unsigned long long*>(nkey);
+    const unsigned long long empty = ((unsigned long long)(unsigned)UNSET << 32) | 0xffffffffull;
+    for (int i = c.gtid; i < c.hash; i += c.gthreads) ns[i] = empty;
+  }
+  if (c.j == 0) {
+    int* hz = &cl->hist[0][0][0];
+    for (int i = threadIdx.x; i < 2 * 4 * 256; i += NT) hz[i] = 0;
+    if (threadIdx.x < 8) cl->changed[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { cl->best[npar] = UMAX; cl->wl_n = 0; }
+  }
+  CT(4)   // clears
+  if (!cbar(c)) return false;
+  CT(5)   // barrier A
+  c.key = nkey; c.idx = nidx;
+  const unsigned cmin = ldu(&cl->cand_min[par]);
+  const float next_cutoff = (cmin == UMAX ? INFINITY : o2f(cmin)) + adaptive;
+  const int n0 = ldi(&cl->n_tok), l0 = ldi(&cl->n_link);
+  if (c.gtid == 0) {
+    const unsigned na = (unsigned)ldi(&cl->narcs[par]);
+    const unsigned lo = c.l.h->arcs_lo + na;
+    if (lo < c.l.h->arcs_lo) c.l.h->arcs_hi += 1u;
+    c.l.h->arcs_lo = lo;
+  }
+  // ---- pass B: claim + relax + link record in one walk
+  auto visit_b = [&](int t, float cur, int s, int a) {
+    float ac, gc;
+    const float tot = arc_cost(cur, s, a, ac, gc);
+    if (!(tot < next_cutoff)) return;
+    const int id = cclaim(c, g.next[a]);
+    if (id < 0) return;
+    const unsigned nb = f2o(tot);
+    atomicMin(&c.l.tok_cost[id], nb);
+    const int li = wave_alloc(&cl->n_link);
+    if (li < c.max_link) {
+      c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = ac; c.l.link_graph[li] = gc;
+    } else {
+      atomicOr(&cl->overflow, 2);
+    }
+  };
+  walk_light(false, visit_b);
+  walk_heavy(visit_b);
+  if (c.gtid == 0) { cl->cand_min[npar] = UMAX; cl->narcs[npar] = 0; }   // (read above by everyone, not needed before frame f + 1's pass A)
+  CT(6)   // pass B walk
+  if (!cbar(c)) return false;
+  CT(7)   // barrier B
+  const int lem = min(ldi(&cl->n_link), c.max_link);
+  // ---- ProcessNonemitting: Bellman-Ford rounds over the work list (it grows while tokens are created)
+  int wl_seen = -1;
+  for (int round = 0;; ++round) {
+    const int wn = min(ldi(&cl->wl_n), WLG_CAP);
+    if (round > 0 && wn == wl_seen && ldi(&cl->changed[(round - 1) & 7]) == 0) break;
+    wl_seen = wn;
+    if (c.gtid == 0) cl->changed[(round + 2) & 7] = 0;
+    for (int i = c.gtid; i < wn; i += c.gthreads) {
+      const int t = ldi(&c.l.wlg[i]);
+      const int s = ldi(&c.l.tok_state[t]);
+      const float cur = o2f(ldu(&c.l.tok_cost[t]));
+      if (!(cur < next_cutoff)) continue;
+      const int a0 = g.row[s], ne = g.n_eps[s];
+      for (int a = a0; a < a0 + ne; ++a) {
+        const float tot = cur + g.weight[a];
+        if (tot < next_cutoff) {
+          const int id = cclaim(c, g.next[a]);
+          if (id < 0) continue;
+          const unsigned nb = f2o(tot);
+          const unsigned old = atomicMin(&c.l.tok_cost[id], nb);
+          if (nb < old) __hip_atomic_store(&cl->changed[round & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (!cbar(c)) return false;
+    if (round > 4096) { atomicOr(&cl->overflow, 32); break; }
+  }
+  CT(8)   // closure rounds incl. their barriers
+  // ---- the epsilon links with the converged costs, and the new frame's best cost
+  {
+    const int wn = min(ldi(&cl->wl_n), WLG_CAP);
+    for (int i = c.gtid; i < wn; i += c.gthreads) {
+      const int t = ldi(&c.l.wlg[i]);
+      const int s = ldi(&c.l.tok_state[t]);
+      const float cur = o2f(ldu(&c.l.tok_cost[t]));
+      if (!(cur < next_cutoff)) continue;
+      const int a0 = g.row[s], ne = g.n_eps[s];
+      for (int a = a0; a < a0 + ne; ++a) {
+        const float tot = cur + g.weight[a];
+        if (tot < next_cutoff) {
+          const int id = cclaim(c, g.next[a]);      // exists: the closure has converged
+          if (id < 0) continue;
+          const int li = wave_alloc(&cl->n_link);
+          if (li < c.max_link) {
+            c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = 0.f; c.l.link_graph[li] = g.weight[a];
+          } else {
+            atomicOr(&cl->overflow, 2);
+          }
+        }
+      }
+    }
+    if (c.gtid == 0) cl->n_heavy = 0;            // (last read in pass B; next written in the next frame's pass A)
+    float b2 = INFINITY;
+    const int n1 = min(ldi(&cl->n_tok), c.max_tok);
+    for (int t = n0 + c.gtid; t < n1; t += c.gthreads) b2 = fminf(b2, o2f(ldu(&c.l.tok_cost[t])));
+    b2 = cblock_min(c, b2);
+    if (threadIdx.x == 0 && b2 != INFINITY) atomicMin(&cl->best[npar], f2o(b2));
+  }
+  CT(9)   // epsilon links + best
+  if (!cbar(c)) return false;
+  CT(10)  // barrier end
+  const int n1 = min(ldi(&cl->n_tok), c.max_tok), l1 = min(ldi(&cl->n_link), c.max_link);
+  if (c.gtid == 0) {
+    c.l.cost_offset[f] = cost_offset;
+    c.l.link_off[2 * f + 2] = lem;
+    c.l.tok_off[f + 2] = n1;
+    c.l.link_off[2 * f + 3] = l1;
+  }
+  fr.f = f + 1; fr.t0 = n0; fr.t1 = n1; fr.pl0 = l0; fr.pl1 = l1;
+  return true;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(NT) void wfst_cluster_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
+                                                           int max_tok, int max_link, int hash, int G, int U,
+                                                           const float* __restrict__ logp, const int* __restrict__ lens, int T, int C) {
+  __shared__ float ll[MAX_C], lastp[MAX_C], redf[NT];
+  __shared__ int redi[NT], lsh[8];
+  // block b = (k / 8) * 8G + j * 8 + (k % 8): the G members of cluster (utterance) k all have b % 8 == k % 8, i.e. one XCD
+  const int b = blockIdx.x, grp = b / (8 * G), r = b % (8 * G);
+  const int j = r / 8, u = grp * 8 + (r % 8);
+  if (u >= U) return;
+  CCtx c;
+  c.g = g; c.o = o; c.max_frames = max_frames; c.max_tok = max_tok; c.max_link = max_link; c.hash = hash;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &c.l);
+  c.cl = c.l.clu; c.G = G; c.j = j; c.gtid = j * NT + (int)threadIdx.x; c.gthreads = G * NT;
+  c.ll = ll; c.redf = redf; c.redi = redi; c.lsh = lsh;
+  c.key = c.l.gkey; c.idx = c.l.gidx;
+  if (threadIdx.x < 8) lsh[threadIdx.x] = 0;
+  if ((int)threadIdx.x < MAX_C) lastp[threadIdx.x] = c.l.last_prob[threadIdx.x];   // every member keeps its own copy of the remembered blank frame
+  __syncthreads();
+  Clu* cl = c.cl;
+  Hdr* h = c.l.h;
+  c.bar_target = cl->bar_base;                 // written before the previous launch ended (kernel boundary: visible)
+  // launch prologue: counters from the header, placement check, the newest frame's best cost
+  int nf = h->n_frames, num_input = h->num_input, is_last_blank = h->is_last_blank, last_best = h->last_best;
+  if (c.gtid == 0) { cl->n_tok = h->n_tok; cl->n_link = h->n_link; cl->overflow = h->overflow; cl->best[nf & 1] = UMAX; cl->cand_min[nf & 1] = UMAX; cl->narcs[nf & 1] = 0; cl->n_heavy = 0; }
+  if (threadIdx.x == 0) cl->xcc[j] = (int)xcc_of();
+  if (!cbar(c)) return;
+  {
+    int same = 1;
+    for (int m = 1; m < G; ++m) same &= (ldi(&cl->xcc[m]) == ldi(&cl->xcc[0]));
+    if (!same) {                               // not behind one L2: plain stores + sc1 loads would not be coherent
+      if (c.gtid == 0) { h->overflow |= 64; cl->bar_base = c.bar_target; }
+      return;
+    }
+  }
+  CFrame fr;
+  fr.f = nf; fr.t0 = c.l.tok_off[nf]; fr.t1 = c.l.tok_off[nf + 1];
+  fr.pl0 = fr.pl1 = 0;
+  {
+    float b0 = INFINITY;
+    for (int t = fr.t0 + c.gtid; t < fr.t1; t += c.gthreads) b0 = fminf(b0, o2f(c.l.tok_cost[t]));
+    b0 = cblock_min(c, b0);
+    if (threadIdx.x == 0 && b0 != INFINITY) atomicMin(&cl->best[nf & 1], f2o(b0));
+  }
+  bool ok = cbar(c);
+#ifdef B2T_WFST_TIMING
+  c.tprev = __builtin_amdgcn_s_memtime();
+#endif
+  const int n = lens ? min(lens[u], T) : T;
+  for (int i = 0; i < n && ok; ++i) {
+    const float* row = logp + ((size_t)u * T + i) * C;
+    // the blank-skipping decision (ctc_wfst_beam_search.cc:70-121) is taken by every member from the same numbers
+    int mode = 0;
+    const float blank_score = expf(row[0]);
+    if (blank_score > o.blank_skip_thresh) {
+      is_last_blank = 1;
+      __syncthreads();
+      if ((int)threadIdx.x < C) lastp[threadIdx.x] = row[threadIdx.x];
+    } else {
+      int cur_best = 0; float bv = row[0];
+      for (int k = 1; k < C; ++k) if (row[k] > bv) { bv = row[k]; cur_best = k; }
+      mode = (cur_best != 0 && is_last_blank && cur_best == last_best) ? 2 : 1;
+      last_best = cur_best;
+    }
+    if (mode == 2) {
+      __syncthreads();
+      if ((int)threadIdx.x < C) ll[threadIdx.x] = o.acoustic_scale * lastp[threadIdx.x];
+      if (c.gtid == 0 && fr.f < max_frames) c.l.mapping[fr.f] = num_input - 1;
+      __syncthreads();
+      ok = cadvance(c, fr);
+    }
+    if (mode >= 1 && ok) {
+      __syncthreads();
+      if ((int)threadIdx.x < C) ll[threadIdx.x] = o.acoustic_scale * row[threadIdx.x];
+      if (c.gtid == 0 && fr.f < max_frames) c.l.mapping[fr.f] = num_input;
+      __syncthreads();
+      ok = cadvance(c, fr);
+      is_last_blank = 0;
+    }
+    num_input += 1;
+  }
+  if (ok) {
+    cbest_links(c, fr.pl0, fr.pl1);            // the last frame's backpointers
+    ok = cbar(c);
+  }
+#ifdef B2T_WFST_TIMING
+  if (c.gtid == 0 && u == 0)
+    printf("wfst cluster u0 ticks: other %llu | cutoff %llu | passA light %llu | passA bar+heavy %llu | bestlinks %llu | clears %llu | barA %llu | passB %llu | barB %llu | closure %llu | epslinks %llu | barEnd %llu\n",
+           c.tacc[0], c.tacc[1], c.tacc[11], c.tacc[2], c.tacc[3], c.tacc[4], c.tacc[5], c.tacc[6], c.tacc[7], c.tacc[8], c.tacc[9], c.tacc[10]);
+  if (c.gtid == 0 && u == 0) printf("wfst cluster u0: heavy tokens %llu over %llu walks; frames %d, tokens %d, links %d, arcs %u\n", c.tacc[12], c.tacc[13], fr.f, ldi(&cl->n_tok), ldi(&cl->n_link), h->arcs_lo);
+#endif
+  __syncthreads();
+  if (c.j == 0 && (int)threadIdx.x < MAX_C) c.l.last_prob[threadIdx.x] = lastp[threadIdx.x];
+  if (c.gtid == 0) {
+    h->n_frames = fr.f; h->num_input = num_input; h->is_last_blank = is_last_blank; h->last_best = last_best;
+    h->n_tok = ldi(&cl->n_tok); h->n_link = ldi(&cl->n_link); h->overflow = ldi(&cl->overflow);
+    cl->bar_base = c.bar_target;
+  }
+}
+
+namespace {
 }  // namespace
 
 __global__ __launch_bounds__(NT) void wfst_reset_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
@@ -632,17 +1188,101 @@ __global__ void wfst_best_path_kernel(Graph g, char* state, size_t state_bytes, 
   n_ali[u] = ka; n_words[u] = kw; costs[2 * u] = gc; costs[2 * u + 1] = ac;
 }
 
+
+namespace {
+// PruneForwardLinks (:297-374) / PruneForwardLinksFinal (:380-470) for ONE frame f, by one workgroup.
+// extra_cost(t) = min over the surviving forward links of t of (extra_cost(dst) + link cost - cost gap), plus, on the last
+// frame of a finished utterance, the final-cost term.  The emitting links of f end in frame f + 1, whose values are final:
+// ONE pass over them gives each token a base value (and prunes the links beyond lattice_beam).  The epsilon links stay
+// inside the frame and form chains a few arcs deep: they are relaxed IN PLACE from above (atomicMin, Bellman-Ford) until
+// nothing moves -- a few passes over a few thousand links instead of over all ~25 k links of the frame each time --, and one
+// more pass then prunes the epsilon links beyond the beam with the converged values.  (Pruning while the values are still
+// upper bounds would remove links that belong in the lattice.)
+// keep_all: the frame's tokens are never removed and count with extra cost 0 (the newest frame in PruneActiveTokens).
+// Returns through *flags: [0] scratch, [1] |= an extra cost moved by more than delta (vs tok_prev = its old value: the
+// reference's extra_costs_changed, which alone sends PruneActiveTokens one frame further back, :528-531), [2] |= a link was pruned.
+__device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, int F, bool final_frame, int has_final, float final_best,
+                            float delta, int* flags) {
+  const unsigned INF_BITS = 0x7f800000u;
+  const int a0 = l.tok_off[f], a1 = l.tok_off[f + 1];
+  const int e0 = f == 0 ? 0 : l.link_off[2 * f], e1 = l.link_off[2 * f + 1];                 // eps links of frame f
+  const int m0 = f < F ? l.link_off[2 * f + 1] : 0, m1 = f < F ? l.link_off[2 * f + 2] : 0;   // emitting f -> f+1
+  for (int t = a0 + threadIdx.x; t < a1; t += NT) {
+    float base = INFINITY;
+    if (final_frame) {
+      const float fc = has_final ? g.final_cost[l.tok_state[t]] : 0.f;
+      base = o2f(l.tok_cost[t]) + fc - final_best;
+      if (base < 0.f) base = 0.f;
+    }
+    l.tok_prev[t] = l.tok_extra[t];
+    l.tok_extra[t] = __float_as_uint(base);
+  }
+  __syncthreads();
+  // (4 links per thread and trip, every load of the four issued before the first use: the pass is a chain of dependent
+  //  gathers -- link -> its two tokens -> their costs -- and one workgroup has to hide their latency by itself)
+  for (int base = m0; base < m1; base += 4 * NT) {
+    int li[4], src[4], dst[4]; unsigned char al[4]; float ac[4], gr[4], cs[4], cd[4], xd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      li[k] = base + k * NT + (int)threadIdx.x;
+      const int q = li[k] < m1 ? li[k] : m1 - 1;
+      al[k] = l.link_alive[q]; src[k] = l.link_src[q]; dst[k] = l.link_dst[q]; ac[k] = l.link_ac[q]; gr[k] = l.link_graph[q];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cs[k] = o2f(l.tok_cost[src[k]]); cd[k] = o2f(l.tok_cost[dst[k]]); xd[k] = __uint_as_float(l.tok_extra[dst[k]]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (li[k] >= m1 || !al[k]) continue;
+      float lec = xd[k] + ((cs[k] + ac[k] + gr[k]) - cd[k]);
+      if (lec > o.lattice_beam) { l.link_alive[li[k]] = 0; flags[2] = 1; continue; }
+      if (lec < 0.f) lec = 0.f;
+      atomicMin(&l.tok_extra[src[k]], __float_as_uint(lec));
+    }
+  }
+  __syncthreads();
+  for (int iter = 0; iter < 4096 && e1 > e0; ++iter) {
+    if (threadIdx.x == 0) flags[0] = 0;
+    __syncthreads();
+    for (int li = e0 + threadIdx.x; li < e1; li += NT) {
+      if (!l.link_alive[li]) continue;
+      const int src = l.link_src[li], dst = l.link_dst[li];
+      const unsigned de = __hip_atomic_load(&l.tok_extra[dst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      float lec = __uint_as_float(de) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+      if (!(lec <= o.lattice_beam)) continue;        // cannot survive, and cannot lower anything below the beam
+      if (lec < 0.f) lec = 0.f;
+      const unsigned nb = __float_as_uint(lec);
+      if (nb < atomicMin(&l.tok_extra[src], nb)) flags[0] = 1;
+    }
+    __syncthreads();
+    if (!flags[0]) break;
+    __syncthreads();
+  }
+  for (int li = e0 + threadIdx.x; li < e1; li += NT) {
+    if (!l.link_alive[li]) continue;
+    const int src = l.link_src[li], dst = l.link_dst[li];
+    const float lec = __uint_as_float(l.tok_extra[dst]) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+    if (lec > o.lattice_beam) { l.link_alive[li] = 0; flags[2] = 1; }
+  }
+  __syncthreads();
+  for (int t = a0 + threadIdx.x; t < a1; t += NT) {
+    unsigned nv = l.tok_extra[t];
+    if (final_frame && __uint_as_float(nv) > o.lattice_beam) { nv = INF_BITS; l.tok_extra[t] = nv; }
+    const unsigned ov = l.tok_prev[t];
+    if (nv != ov && (nv == INF_BITS || ov == INF_BITS || fabsf(__uint_as_float(nv) - __uint_as_float(ov)) > delta)) flags[1] = 1;
+  }
+  __syncthreads();
+}
+}  // namespace
+
 // FinalizeDecoding (:632-647): PruneForwardLinksFinal on the last frame, then PruneForwardLinks(delta = 0) +
 // PruneTokensForFrame backwards.  Marks link_alive; tok_extra = inf for tokens that leave the lattice.
 __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
                                                             int max_tok, int max_link, int hash) {
   __shared__ float redf[NT];
-  __shared__ int changed;
   const int u = blockIdx.x;
   Lay l;
   layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
   const int F = l.h->n_frames;
-  const unsigned INF_BITS = 0x7f800000u;
   auto bmin = [&](float v) {
     redf[threadIdx.x] = v; __syncthreads();
     for (int s = NT / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) redf[threadIdx.x] = fminf(redf[threadIdx.x], redf[threadIdx.x + s]); __syncthreads(); }
@@ -661,55 +1301,9 @@ __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state,
   if (threadIdx.x == 0) { l.h->final_best = final_best; l.h->has_final = has_final; l.h->finalized = 1; }
   for (int li = threadIdx.x; li < min(l.h->n_link, max_link); li += NT) l.link_alive[li] = 1;
   __syncthreads();
-  for (int f = F; f >= 0; --f) {
-    const int a0 = l.tok_off[f], a1 = l.tok_off[f + 1];
-    // links leaving the tokens of frame f: its epsilon links, and (f < F) the emitting links into frame f + 1
-    const int e0 = f == 0 ? 0 : l.link_off[2 * f], e1 = l.link_off[2 * f + 1];                 // eps links of frame f
-    const int m0 = f < F ? l.link_off[2 * f + 1] : 0, m1 = f < F ? l.link_off[2 * f + 2] : 0;   // emitting f -> f+1
-    for (int iter = 0; iter < 1000; ++iter) {
-      __syncthreads();
-      if (threadIdx.x == 0) changed = 0;
-      __syncthreads();
-      // Jacobi sweep: remember the previous values, reset to the base term (final-cost term on the last frame, +inf
-      // elsewhere), minimise over the surviving links, compare.  Values only grow from their initial 0 (lower bounds),
-      // so a link found beyond the lattice beam in any sweep is beyond it at the fixed point too.
-      for (int t = a0 + threadIdx.x; t < a1; t += NT) {
-        float base = INFINITY;
-        if (f == F) {
-          const float fc = has_final ? g.final_cost[l.tok_state[t]] : 0.f;
-          base = o2f(l.tok_cost[t]) + fc - final_best;
-          if (base < 0.f) base = 0.f;
-        }
-        l.tok_prev[t] = l.tok_extra[t];
-        l.tok_extra[t] = __float_as_uint(base);
-      }
-      __syncthreads();
-      for (int pass = 0; pass < 2; ++pass) {
-        const int q0 = pass == 0 ? e0 : m0, q1 = pass == 0 ? e1 : m1;
-        for (int li = q0 + threadIdx.x; li < q1; li += NT) {
-          if (!l.link_alive[li]) continue;
-          const int src = l.link_src[li], dst = l.link_dst[li];
-          // epsilon links stay inside frame f: the destination's value of the previous sweep; emitting links point into
-          // frame f + 1, whose values are final
-          const float dst_extra = __uint_as_float(pass == 0 ? l.tok_prev[dst] : l.tok_extra[dst]);
-          float lec = dst_extra + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
-          if (lec > o.lattice_beam) { l.link_alive[li] = 0; continue; }
-          if (lec < 0.f) lec = 0.f;
-          atomicMin(&l.tok_extra[src], __float_as_uint(lec));   // non-negative floats order like their bits
-        }
-      }
-      __syncthreads();
-      for (int t = a0 + threadIdx.x; t < a1; t += NT) {
-        unsigned nv = l.tok_extra[t];
-        if (f == F && __uint_as_float(nv) > o.lattice_beam) { nv = INF_BITS; l.tok_extra[t] = nv; }
-        if (nv != l.tok_prev[t]) changed = 1;
-      }
-      __syncthreads();
-      if (!changed) break;
-    }
-  }
+  __shared__ int flags[3];
+  for (int f = F; f >= 0; --f) prune_frame(l, g, o, f, F, f == F, has_final, final_best, 0.f, flags);
 }
-
 
 // PruneActiveTokens (lattice-faster-decoder.cc:516-545, called every prune_interval frames at :592-630) as a pass of its own
 // between two search calls: PruneForwardLinks (:297-374) on the frames F-1 .. 0 -- the tokens of the newest frame F are
@@ -719,141 +1313,150 @@ __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state,
 // Extra costs computed against the best path SO FAR are lower bounds of the final ones, so this removes only what
 // FinalizeDecoding would remove: the final lattice is the same with or without these passes (tested).
 __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
-                                                         int max_tok, int max_link, int hash, float delta) {
+                                                         int max_tok, int max_link, int hash, float delta, float min_fill) {
   __shared__ float redf[NT];
-  __shared__ int scan[NT / 64 + 1];
-  __shared__ int changed, big_change, run_s, jb_s;
   const int u = blockIdx.x;
   Lay l;
   layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
   const int F = l.h->n_frames;
   if (F < 2 || l.h->overflow || l.h->finalized) return;
+  // memory-pressure policy (min_fill > 0): the pass only exists to bound memory, so an utterance whose arrays are still
+  // mostly empty skips it (min_fill = 0: every call prunes, the reference's fixed prune_interval)
+  if ((float)l.h->n_tok < min_fill * (float)max_tok && (float)l.h->n_link < min_fill * (float)max_link) return;
   const unsigned INF_BITS = 0x7f800000u;
   const int n_tok = min(l.h->n_tok, max_tok), n_link = min(l.h->n_link, max_link);
   for (int li = l.h->links_marked + (int)threadIdx.x; li < n_link; li += NT) l.link_alive[li] = 1;
   __syncthreads();
   // ---- PruneForwardLinks, frames F-1 .. 0, stopping at the first frame where nothing moved by more than delta
+  __shared__ int flags[3];
+#ifdef B2T_WFST_TIMING
+  unsigned long long tp0 = __builtin_amdgcn_s_memtime(), tp1, tp2, tp3, tp4;
+#endif
   int f_stop = -1;
   for (int f = F - 1; f >= 0; --f) {
-    const int a0 = l.tok_off[f], a1 = l.tok_off[f + 1];
-    const int e0 = f == 0 ? 0 : l.link_off[2 * f], e1 = l.link_off[2 * f + 1];      // eps links of frame f
-    const int m0 = l.link_off[2 * f + 1], m1 = l.link_off[2 * f + 2];                 // emitting f -> f+1
     __syncthreads();
-    if (threadIdx.x == 0) big_change = 0;
-    for (int iter = 0; iter < 1000; ++iter) {
-      __syncthreads();
-      if (threadIdx.x == 0) changed = 0;
-      __syncthreads();
-      for (int t = a0 + threadIdx.x; t < a1; t += NT) { l.tok_prev[t] = l.tok_extra[t]; l.tok_extra[t] = INF_BITS; }
-      __syncthreads();
-      for (int pass = 0; pass < 2; ++pass) {
-        const int q0 = pass == 0 ? e0 : m0, q1 = pass == 0 ? e1 : m1;
-        for (int li = q0 + threadIdx.x; li < q1; li += NT) {
-          if (!l.link_alive[li]) continue;
-          const int src = l.link_src[li], dst = l.link_dst[li];
-          const float dst_extra = __uint_as_float(pass == 0 ? l.tok_prev[dst] : l.tok_extra[dst]);
-          float lec = dst_extra + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
-          if (lec > o.lattice_beam) { l.link_alive[li] = 0; big_change = 1; continue; }
-          if (lec < 0.f) lec = 0.f;
-          atomicMin(&l.tok_extra[src], __float_as_uint(lec));
-        }
-      }
-      __syncthreads();
-      for (int t = a0 + threadIdx.x; t < a1; t += NT) {
-        const unsigned nv = l.tok_extra[t], ov = l.tok_prev[t];
-        if (nv != ov) {
-          changed = 1;
-          if (nv == INF_BITS || ov == INF_BITS || fabsf(__uint_as_float(nv) - __uint_as_float(ov)) > delta) big_change = 1;
-        }
-      }
-      __syncthreads();
-      if (!changed) break;
-    }
+    if (threadIdx.x == 0) flags[1] = 0;
     __syncthreads();
-    if (!big_change) { f_stop = f; break; }
+    prune_frame(l, g, o, f, F, false, 0, 0.f, delta, flags);
+    if (!flags[1]) { f_stop = f; break; }
   }
-  // ---- compaction of the tokens of frames f_stop+1 .. F-1 and of every link that starts in frame f_stop or later
+  // ---- compaction of the tokens of frames f_stop+1 .. F-1 and of every link that starts in frame f_stop or later.
+  // Stable and in place, one array SEGMENT at a time (a frame's tokens; a frame's epsilon links; its emitting links), each in
+  // chunks of 4 x NT elements: 4 flags per thread, ONE barrier per chunk (wave scans + the 4 x 16 wave totals read by
+  // everyone from a double-buffered LDS table; the same barrier separates the chunk's reads from its writes).  The first
+  // version scanned NT elements per chunk with four barriers and a serial boundary loop: 18 ms per pass, mostly barriers.
+#ifdef B2T_WFST_TIMING
+  tp1 = __builtin_amdgcn_s_memtime();
+#endif
   const int T0 = l.tok_off[f_stop + 1];
   const int TF = l.tok_off[F];                      // tokens of the newest frame always stay
+  // (epsilon links of the stop frame that were pruned just now stay behind as dead entries -- link_alive 0 --: the stop frame's
+  //  tokens keep their ids and their backpointers into that range; FinalizeDecoding prunes them again)
   const int L0 = f_stop >= 0 ? l.link_off[2 * f_stop + 1] : 0;
-  int* excl = reinterpret_cast<int*>(l.tok_prev);   // [t] = surviving tokens in [T0, t): new id = T0 + excl[t]
-  auto block_excl = [&](int flag, int& total) {     // exclusive prefix of `flag` over the block (two barriers)
+  int* excl = reinterpret_cast<int*>(l.tok_prev);   // [t] = new id of token t (or -1)
+  __shared__ int wtot[2][4][NT / 64];
+  int flip = 0;
+  // exclusive positions of 4 flags per thread (element e_k = base + k * NT + tid: coalesced) + the chunk's total
+  auto scan4 = [&](const int (&fl)[4], int (&pos)[4], int& total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int incl = flag;
+    int incl[4];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-    if (lane == 63) scan[w] = incl;
+    for (int k = 0; k < 4; ++k) {
+      int v = fl[k];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int x = __shfl_up(v, off, 64); if (lane >= off) v += x; }
+      incl[k] = v;
+      if (lane == 63) wtot[flip][k][w] = v;
+    }
     __syncthreads();
-    int base = 0, tot = 0;
-    for (int k = 0; k < NT / 64; ++k) { const int v = scan[k]; if (k < w) base += v; tot += v; }
-    __syncthreads();
-    total = tot;
-    return base + incl - flag;
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int before = 0, row = 0;
+      for (int ww = 0; ww < NT / 64; ++ww) { const int v = wtot[flip][k][ww]; if (ww < w) before += v; row += v; }
+      pos[k] = run + before + incl[k] - fl[k];
+      run += row;
+    }
+    total = run;
+    flip ^= 1;
   };
   auto tok_alive = [&](int t) { return t >= TF || l.tok_extra[t] != INF_BITS; };
-  if (threadIdx.x == 0) { run_s = 0; jb_s = f_stop + 2; }
-  __syncthreads();
-  for (int base = T0; base < n_tok; base += NT) {           // pass 1: new ids; new tok_off of every frame boundary met
-    const int t = base + (int)threadIdx.x;
-    const int a = t < n_tok ? (int)tok_alive(t) : 0;
-    int tot;
-    const int ex = block_excl(a, tot);
-    const int run = run_s;
-    if (t < n_tok) excl[t] = run + ex;
-    redf[threadIdx.x] = __int_as_float(run + ex);            // (LDS copy for the boundary look-ups below)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int jb = jb_s;
-      while (jb <= F + 1 && l.tok_off[jb] < base + NT && l.tok_off[jb] < n_tok) {
-        l.tok_off[jb] = T0 + __float_as_int(redf[l.tok_off[jb] - base]);
-        ++jb;
+  // pass 1: new token ids frame by frame; tok_off rewritten as the frames are finished
+  int run_t = T0;
+  {
+    int seg0 = T0;
+    for (int fb = f_stop + 1; fb <= F; ++fb) {
+      const int seg1 = min(l.tok_off[fb + 1], n_tok);       // (old value: rewritten below, after everyone has read it)
+      for (int base = seg0; base < seg1; base += 4 * NT) {
+        int fl[4], pos[4], tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int t = base + k * NT + (int)threadIdx.x; fl[k] = t < seg1 ? (int)tok_alive(t) : 0; }
+        scan4(fl, pos, tot);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int t = base + k * NT + (int)threadIdx.x; if (t < seg1) excl[t] = fl[k] ? run_t + pos[k] : -1; }
+        run_t += tot;
       }
-      jb_s = jb; run_s = run + tot;
+      __syncthreads();
+      if (threadIdx.x == 0) l.tok_off[fb + 1] = run_t;
+      seg0 = seg1;
     }
-    __syncthreads();
   }
-  const int n_tok_new = T0 + run_s;
+  const int n_tok_new = run_t;
   __syncthreads();
-  if (threadIdx.x == 0) { for (int jb = jb_s; jb <= F + 1; ++jb) l.tok_off[jb] = n_tok_new; run_s = 0; jb_s = f_stop >= 0 ? 2 * f_stop + 2 : 1; }
-  __syncthreads();
-  for (int base = L0; base < n_link; base += NT) {          // pass 2: links -- drop, remap, move; new link_off
-    const int li = base + (int)threadIdx.x;
-    int a = 0, src = 0, dst = 0, arc = 0; float ac = 0.f, gr = 0.f;
-    if (li < n_link) {
-      src = l.link_src[li]; dst = l.link_dst[li]; arc = l.link_arc[li]; ac = l.link_ac[li]; gr = l.link_graph[li];
-      a = l.link_alive[li] && (src < T0 || tok_alive(src)) && (dst < T0 || tok_alive(dst));
-      if (src >= T0) src = T0 + excl[src];
-      if (dst >= T0) dst = T0 + excl[dst];
-    }
-    int tot;
-    const int ex = block_excl(a, tot);
-    const int run = run_s;
-    redf[threadIdx.x] = __int_as_float(run + ex);
-    __syncthreads();
-    if (a) {
-      const int k = L0 + run + ex;                           // k <= li, and every read of this chunk is done
-      l.link_src[k] = src; l.link_dst[k] = dst; l.link_arc[k] = arc; l.link_ac[k] = ac; l.link_graph[k] = gr; l.link_alive[k] = 1;
-    }
-    if (threadIdx.x == 0) {
-      int jb = jb_s;
-      while (jb <= 2 * F + 1 && l.link_off[jb] < base + NT && l.link_off[jb] < n_link) {
-        l.link_off[jb] = L0 + __float_as_int(redf[l.link_off[jb] - base]);
-        ++jb;
+#ifdef B2T_WFST_TIMING
+  tp2 = __builtin_amdgcn_s_memtime();
+#endif
+  // pass 2: links -- drop, remap, move; link_off rewritten segment by segment
+  int run_l = L0;
+  {
+    int seg0 = L0;
+    for (int jb = (f_stop >= 0 ? 2 * f_stop + 1 : 0); jb <= 2 * F; ++jb) {
+      const int seg1 = min(l.link_off[jb + 1], n_link);
+      for (int base = seg0; base < seg1; base += 4 * NT) {
+        int fl[4], pos[4], tot, src[4], dst[4], arc[4]; float ac[4], gr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int li = base + k * NT + (int)threadIdx.x;
+          fl[k] = 0;
+          if (li < seg1) {
+            src[k] = l.link_src[li]; dst[k] = l.link_dst[li]; arc[k] = l.link_arc[li]; ac[k] = l.link_ac[li]; gr[k] = l.link_graph[li];
+            if (l.link_alive[li]) {
+              if (src[k] >= T0) src[k] = excl[src[k]];
+              if (dst[k] >= T0) dst[k] = excl[dst[k]];
+              fl[k] = src[k] >= 0 && dst[k] >= 0;
+            }
+          }
+        }
+        scan4(fl, pos, tot);                               // (its barrier: every read of this chunk is done)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (fl[k]) {
+          const int q = run_l + pos[k];                    // q <= li
+          l.link_src[q] = src[k]; l.link_dst[q] = dst[k]; l.link_arc[q] = arc[k]; l.link_ac[q] = ac[k]; l.link_graph[q] = gr[k]; l.link_alive[q] = 1;
+        }
+        run_l += tot;
       }
-      jb_s = jb; run_s = run + tot;
+      __syncthreads();
+      if (threadIdx.x == 0) l.link_off[jb + 1] = run_l;
+      seg0 = seg1;
+    }
+  }
+  const int n_link_new = run_l;
+  __syncthreads();
+#ifdef B2T_WFST_TIMING
+  tp3 = __builtin_amdgcn_s_memtime();
+#endif
+  // pass 3: move the surviving tokens (ids only go down; a chunk's reads are done before its writes)
+  for (int base = T0; base < n_tok; base += 4 * NT) {
+    int k2[4], st[4]; unsigned cs[4], ex[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = base + k * NT + (int)threadIdx.x;
+      k2[k] = -1;
+      if (t < n_tok) { k2[k] = excl[t]; st[k] = l.tok_state[t]; cs[k] = l.tok_cost[t]; ex[k] = l.tok_extra[t]; }
     }
     __syncthreads();
-  }
-  const int n_link_new = L0 + run_s;
-  __syncthreads();
-  if (threadIdx.x == 0) for (int jb = jb_s; jb <= 2 * F + 1; ++jb) l.link_off[jb] = n_link_new;
-  __syncthreads();
-  for (int base = T0; base < n_tok; base += NT) {           // pass 3: move the surviving tokens
-    const int t = base + (int)threadIdx.x;
-    int a = 0, st = 0, k = 0; unsigned cs = 0u, ex = 0u;
-    if (t < n_tok) { a = tok_alive(t); st = l.tok_state[t]; cs = l.tok_cost[t]; ex = l.tok_extra[t]; k = T0 + excl[t]; }
-    __syncthreads();
-    if (a) { l.tok_state[k] = st; l.tok_cost[k] = cs; l.tok_extra[k] = ex; l.tok_best[k] = 0x7fffffff; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k2[k] >= 0) { l.tok_state[k2[k]] = st[k]; l.tok_cost[k2[k]] = cs[k]; l.tok_extra[k2[k]] = ex[k]; l.tok_best[k2[k]] = 0x7fffffff; }
     __syncthreads();
   }
   // backpointers of the moved tokens: the first surviving link whose cost equals the token's (best_links' rule)
@@ -864,10 +1467,16 @@ __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, si
     if (f2o(tot) == l.tok_cost[dst]) atomicMin(&l.tok_best[dst], li);
   }
   __syncthreads();
+#ifdef B2T_WFST_TIMING
+  tp4 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0 && u == 0) printf("wfst prune u0: F %d f_stop %d | sweeps %llu | tok ids %llu | links %llu | tok move + best %llu | tokens %d -> %d, links %d -> %d\n",
+                                         F, f_stop, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3, n_tok, n_tok_new, n_link, n_link_new);
+#endif
   if (threadIdx.x == 0) {
     if (T0 == 0) l.tok_best[0] = -1;
     Hdr* h = l.h;
     h->peak_tok = max(h->peak_tok, n_tok); h->peak_link = max(h->peak_link, n_link);
+    h->removed_tok += n_tok - n_tok_new; h->removed_link += n_link - n_link_new;
     h->n_tok = n_tok_new; h->n_link = n_link_new; h->links_marked = n_link_new; h->n_prunes += 1;
   }
 }
@@ -965,11 +1574,32 @@ extern "C" int b2t_wfst_reset(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* 
   return 0;
 }
 
+// Workgroups per utterance of the search: the largest of 8 / 4 / 2 / 1 that keeps every cluster resident (one 1024-thread
+// workgroup per CU, 256 CUs); B2T_WFST_CLUSTER overrides (1 = the single-workgroup kernel with its LDS hash).
+static int g_cluster_override = 0;
+extern "C" int b2t_wfst_set_cluster(int G) { g_cluster_override = G < 0 ? 0 : G; return 0; }   // 0 = automatic
+extern "C" int b2t_wfst_cluster_size(int U) {
+  static const int env = getenv("B2T_WFST_CLUSTER") ? atoi(getenv("B2T_WFST_CLUSTER")) : 0;
+  const int forced = g_cluster_override ? g_cluster_override : env;
+  if (forced >= 1) return forced >= 8 ? 8 : forced >= 4 ? 4 : forced >= 2 ? 2 : 1;
+  const int slots = 256;
+  for (int G = 8; G > 1; G >>= 1) if ((U + 7) / 8 * 8 * G <= slots) return G;
+  return 1;
+}
+
 extern "C" int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, const float* logp,
                                    const int32_t* lens, int U, int T, int C, void* stream) {
   { int rc = check_args(g, o, state, U, "wfst_search"); if (rc) return rc; }
   B2T_REQUIRE(logp && T > 0 && C > 1 && C <= MAX_C, "wfst_search: bad logp shape T=%d C=%d", T, C);
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size), lds = lds_hash_bytes(o);
+  const int G = b2t_wfst_cluster_size(U);
+  if (G > 1) {
+    const int grid = (U + 7) / 8 * 8 * G;
+    hipLaunchKernelGGL(wfst_cluster_kernel, dim3(grid), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                       o->max_frames, o->max_tokens, o->max_links, o->hash_size, G, U, logp, lens, T, C);
+    B2T_CHECK_LAUNCH("b2t_wfst_search_f32 (cluster)");
+    return 0;
+  }
   allow_lds(wfst_search_kernel, lds);
   hipLaunchKernelGGL(wfst_search_kernel, dim3(U), dim3(NT), lds, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
                      o->max_frames, o->max_tokens, o->max_links, o->hash_size, lds ? 1 : 0, logp, lens, T, C);
@@ -999,12 +1629,13 @@ extern "C" int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_
   return 0;
 }
 
-extern "C" int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, float delta, void* stream) {
+extern "C" int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, float delta, float min_fill,
+                              void* stream) {
   { int rc = check_args(g, o, state, U, "wfst_prune"); if (rc) return rc; }
-  B2T_REQUIRE(delta >= 0.f, "wfst_prune: negative delta");
+  B2T_REQUIRE(delta >= 0.f && min_fill >= 0.f && min_fill <= 1.f, "wfst_prune: bad delta / min_fill");
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
   hipLaunchKernelGGL(wfst_prune_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
-                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, delta);
+                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, delta, min_fill);
   B2T_CHECK_LAUNCH("b2t_wfst_prune");
   return 0;
 }

@@ -42,7 +42,8 @@ def _pow2_at_least(n: int) -> int:
 
 class WfstSearch:
     def __init__(self, graph, opts, U: int = 1, device="cuda:0", max_frames: int = 1024, max_tokens: int = 1 << 19,
-                 max_links: int = 1 << 21, hash_size: int = 0, prune_interval: int = 25, prune_scale: float = 0.1):
+                 max_links: int = 1 << 21, hash_size: int = 0, prune_interval: int = 25, prune_scale: float = 0.1,
+                 prune_min_fill: float = 0.0):
         """graph: wfst.DecodeGraph.  opts: an object with the reference's DecodeOptions fields (max_active, min_active, beam,
         lattice_beam, acoustic_scale, ctc_blank_skip_threshold, length_penalty, nbest)."""
         self.g, self.U, self.device = graph, int(U), torch.device(device)
@@ -58,6 +59,9 @@ class WfstSearch:
         # prune_interval frames; 0 = never (everything is pruned once, in finalize -- same lattice, more memory)
         self.prune_interval = int(os.environ.get("B2T_WFST_PRUNE_INTERVAL", prune_interval))
         self.prune_scale = float(prune_scale)
+        # > 0: a pass is skipped for an utterance whose token / link arrays are filled below this fraction (memory-pressure
+        # policy: the passes only bound memory and cost about as much as the frames between them); 0 = the reference's policy
+        self.prune_min_fill = float(os.environ.get("B2T_WFST_PRUNE_MIN_FILL", prune_min_fill))
         self._since_prune = 0
         self.set_opts(opts)
         self.state_bytes = self.lib.b2t_wfst_state_bytes(*self.caps)
@@ -89,7 +93,8 @@ class WfstSearch:
         """PruneActiveTokens(lattice_beam * prune_scale) for every utterance + compaction of their token / link arrays."""
         with torch.cuda.device(self.device):
             N.check(self.lib.b2t_wfst_prune(C.byref(self.cg), C.byref(self.co), ops._p(self.state), self.U,
-                                            C.c_float(self.lattice_beam * self.prune_scale), self._s()), "b2t_wfst_prune")
+                                            C.c_float(self.lattice_beam * self.prune_scale), C.c_float(self.prune_min_fill), self._s()),
+                    "b2t_wfst_prune")
         self._since_prune = 0
 
     # ---- Search ------------------------------------------------------------------------------------------------------
@@ -137,19 +142,26 @@ class WfstSearch:
 
     def _header(self):
         st = self.state.view(self.U, self.state_bytes)
-        return st[:, self.off[0]:self.off[0] + 64].contiguous().view(torch.int32).cpu().numpy()
+        return st[:, self.off[0]:self.off[0] + 72].contiguous().view(torch.int32).cpu().numpy()
 
     def memory_stats(self):
         """Per utterance: tokens / links held now, their high-water marks, PruneActiveTokens passes so far."""
         h = self._header()
         return [dict(tokens=int(r[1]), links=int(r[2]), peak_tokens=max(int(r[14]), int(r[1])), peak_links=max(int(r[15]), int(r[2])),
-                     prunes=int(r[13])) for r in h]
+                     prunes=int(r[13]), created_tokens=int(r[1]) + int(r[16]), created_links=int(r[2]) + int(r[17])) for r in h]
 
     def _check_overflow(self):
         h = self._header()
         if h[:, 3].any():
             bits = int(np.bitwise_or.reduce(h[:, 3]))
-            what = [n for b, n in ((1, "max_tokens"), (2, "max_links"), (4, "hash_size"), (8, "max_frames")) if bits & b]
+            if bits & 64:
+                raise RuntimeError("WFST cluster search: the workgroups of an utterance were not placed on one XCD (block b is "
+                                   "expected on XCD b % 8); nothing was decoded -- call b2t_wfst_set_cluster(1) / set "
+                                   "B2T_WFST_CLUSTER=1 to use one workgroup per utterance")
+            if bits & 32:
+                raise RuntimeError("WFST cluster search: a cluster barrier timed out (a workgroup of the cluster was not resident: "
+                                   "is another kernel holding CUs?); results are invalid -- reset() and retry, or B2T_WFST_CLUSTER=1")
+            what = [n for b, n in ((1, "max_tokens"), (2, "max_links"), (4, "hash_size"), (8, "max_frames"), (16, "epsilon work list (65536)")) if bits & b]
             raise RuntimeError(f"WFST search: a capacity was exhausted ({', '.join(what)} of {self.caps}; peak tokens "
                                f"{int(h[:, 1].max())}, links {int(h[:, 2].max())}); results are invalid -- construct WfstSearch "
                                "with larger capacities")
@@ -166,13 +178,39 @@ class WfstSearch:
     def finalize(self):
         """FinalizeDecoding on the GPU, then per utterance the n-best word sequences of the pruned lattice:
         [[(inputs, times, words, lm_score, ac_score), ...] best first]."""
+        return self.finalize_async().result()
+
+    _pool = None
+
+    def finalize_async(self):
+        """finalize() split where the GPU's part ends: FinalizeDecoding, lattice compaction and ONE copy to the host happen
+        here; the n-best extraction (host C++, one thread per utterance) runs on a background pool and is returned as a
+        future -- the caller may reset() and decode the next batch of utterances while it runs (the state block is no longer
+        needed), which takes the host n-best off the decode loop's critical path."""
+        from concurrent.futures import Future
         with torch.cuda.device(self.device):
             N.check(self.lib.b2t_wfst_finalize(C.byref(self.cg), C.byref(self.co), ops._p(self.state), self.U, self._s()), "b2t_wfst_finalize")
         self.finalized = True
         self._check_overflow()
+        fut = Future()
         if self.nbest == 1:
-            return [[r] if self.frames_decoded()[u] > 0 else [] for u, r in enumerate(self.best_path(True))]
-        return self._nbest_all(self.nbest)
+            fut.set_result([[r] if self.frames_decoded()[u] > 0 else [] for u, r in enumerate(self.best_path(True))])
+            return fut
+        hdr = self._header()
+        cn, host = self._lattices()
+        mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
+        if WfstSearch._pool is None:
+            WfstSearch._pool = ThreadPoolExecutor(max_workers=_host_threads())
+        nbest = self.nbest
+
+        def job():
+            try:
+                fut.set_result(self._nbest_host(nbest, hdr, cn, host, mapping_all))
+            except BaseException as e:          # noqa: BLE001 -- delivered through the future
+                fut.set_exception(e)
+        import threading
+        threading.Thread(target=job, daemon=True).start()
+        return fut
 
     def _lattices(self, cap_arcs: int = 1 << 18, cap_final: int = 1 << 13):
         """The pruned lattices of all utterances, compacted on the GPU (b2t_wfst_lattice) and copied out once."""
@@ -196,8 +234,13 @@ class WfstSearch:
 
     def _nbest_all(self, nbest: int):
         hdr = self._header()
-        cn, (src, dst, il, ol, gr, ac, fs, fc) = self._lattices()
+        cn, host = self._lattices()
         mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
+        return self._nbest_host(nbest, hdr, cn, host, mapping_all)
+
+    def _nbest_host(self, nbest, hdr, cn, host, mapping_all):
+        """Host half of FinalizeSearch: nothing here touches the device or this object's state block."""
+        src, dst, il, ol, gr, ac, fs, fc = host
         P = lambda x: x.ctypes.data_as(C.c_void_p)
 
         def one(u):
@@ -223,8 +266,9 @@ class WfstSearch:
         workers = min(self.U, _host_threads())
         if workers <= 1:
             return [one(u) for u in range(self.U)]
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            return list(pool.map(one, range(self.U)))
+        if WfstSearch._pool is None:
+            WfstSearch._pool = ThreadPoolExecutor(max_workers=_host_threads())
+        return list(WfstSearch._pool.map(one, range(self.U)))
 
     def _nbest_of(self, u, h, nbest=None):
         return self._nbest_all(nbest or self.nbest)[u]

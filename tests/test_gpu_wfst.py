@@ -156,6 +156,44 @@ def test_wfst_tight_pruning_and_overflow(toy):
         small.finalize()
 
 
+def test_cluster_search_equals_single_workgroup(toy):
+    """The search with 2 / 4 / 8 workgroups per utterance (clusters behind one XCD's L2: L2 atomics, sc1 loads, cluster
+    barriers) returns what one workgroup per utterance returns: frames, partial best path after every chunk, the 30-best
+    list with both scores, alignment and times -- for the production options, with blank skipping and with binding
+    max_active / min_active.  (Costs are compared to 1e-5: equal-cost ties aside, the arithmetic is the same.)"""
+    import b2t_native as N
+    from wfst_decoder import WfstSearch
+    lib = N.load()
+    assert [lib.b2t_wfst_cluster_size(u) for u in (1, 8, 32, 33, 64, 65, 128, 129, 256)] == [8, 8, 8, 4, 4, 2, 2, 1, 1]
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(41)
+    seqs, lps, batch, lens = utterances(prons, words, 6, rs, noise=1.0, n_words=(3, 7))
+    dev_batch = torch.from_numpy(batch).cuda()
+    cases = [Opt(nbest=30), Opt(nbest=30, ctc_blank_skip_threshold=0.9), Opt(nbest=30, max_active=250, min_active=60, beam=11.0)]
+    try:
+        for o in cases:
+            out = {}
+            for G in (1, 2, 4, 8):
+                lib.b2t_wfst_set_cluster(G)
+                assert lib.b2t_wfst_cluster_size(6) == G
+                S = WfstSearch(g, o, U=6, max_frames=batch.shape[1] + 8, prune_interval=16)
+                parts = []
+                for t0 in range(0, batch.shape[1], 13):
+                    S.search(dev_batch[:, t0:t0 + 13].contiguous(), np.clip(lens - t0, 0, 13))
+                    parts.append([(p[2], round(p[3] + p[4], 3)) for p in S.best_path(False)])
+                out[G] = (parts, S.frames_decoded(), S.finalize())
+            for G in (2, 4, 8):
+                assert out[G][1] == out[1][1] and out[G][0] == out[1][0], G
+                for u in range(6):
+                    a, b = out[G][2][u], out[1][2][u]
+                    assert len(a) == len(b) > 0
+                    for x, y in zip(a, b):
+                        assert abs((x[3] + x[4]) - (y[3] + y[4])) < 1e-5, (G, u)
+                        assert x[2] == y[2] and x[0] == y[0] and x[1] == y[1] and abs(x[3] - y[3]) < 1e-5, (G, u)
+    finally:
+        lib.b2t_wfst_set_cluster(0)
+
+
 def test_prune_active_tokens_bounds_memory_and_keeps_the_lattice(toy):
     """PruneActiveTokens every prune_interval frames (lattice-faster-decoder.cc:516-545, :592-630) as b2t_wfst_prune between
     search calls: the n-best lists, the partial best paths and the decoded frames are those of a search that prunes only once,

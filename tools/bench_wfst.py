@@ -38,17 +38,44 @@ def edit(a, b):
     return prev[len(b)]
 
 
-def make(n_words=int(os.environ.get("B2T_WFST_WORDS", "400")), n_per_order=3000, U=32, seed=0, noise=0.9):
+def sample_sentence(lm, rs, n):
+    """n words drawn from the word n-gram itself (explicit continuations of the current history, proportional to their
+    probability; back off when the history has none): sentences the LM likes, as real text is to a real LM."""
+    s, out = lm.start_state, []
+    for _ in range(n):
+        st = s
+        while True:
+            a, e = int(lm.cb[st]), int(lm.ce[st])
+            toks, nodes = lm.ctok[a:e], lm.cnode[a:e]
+            keep = toks < lm.W
+            if st == 0 or (keep.any() and rs.rand() < 0.85):
+                break
+            st = int(lm.suffix[st])
+        pr = np.exp(lm.logp[nodes[keep]].astype(np.float64)); pr /= pr.sum()
+        k = int(rs.choice(int(keep.sum()), p=pr))
+        out.append(int(toks[keep][k])); s = int(lm.nstate[nodes[keep][k]])
+    return out
+
+
+def make(n_words=int(os.environ.get("B2T_WFST_WORDS", "400")), n_per_order=3000, U=32, seed=0, noise=0.9, graph=None, truth="uniform", blank_boost=0.0):
     t0 = time.time()
-    prons = ngram_lm.synthetic_lexicon(n_words, 41, seed=seed + 1)
-    words = sorted(prons)
-    arpa = ngram_lm.synthetic_word_arpa(words, 3, n_per_order, seed=seed + 2)
-    g = wfst.build_tlg(prons, arpa, sil_prob=0.5)
+    if graph is not None:
+        prons, words, arpa, g = graph
+        n_words = len(words)
+    else:
+        prons = ngram_lm.synthetic_lexicon(n_words, 41, seed=seed + 1)
+        words = sorted(prons)
+        arpa = ngram_lm.synthetic_word_arpa(words, 3, n_per_order, seed=seed + 2)
+        g = wfst.build_tlg(prons, arpa, sil_prob=0.5)
     build_s = time.time() - t0
     rs = np.random.RandomState(seed)
     seqs, rows = [], []
+    wlm = ngram_lm.SparseNGramLM.from_arpa(arpa, words) if truth == "lm" else None
     for u in range(U):
-        seq = [words[i] for i in rs.randint(n_words, size=rs.randint(4, 9))]
+        if wlm is not None:
+            seq = [words[i] for i in sample_sentence(wlm, rs, int(rs.randint(4, 9)))]
+        else:
+            seq = [words[i] for i in rs.randint(n_words, size=rs.randint(4, 9))]
         frames = []
         for w in seq:
             prev = -1
@@ -59,7 +86,7 @@ def make(n_words=int(os.environ.get("B2T_WFST_WORDS", "400")), n_per_order=3000,
                 prev = c
         lg = np.full((len(frames), 41), -2.0, np.float32)
         for t, c in enumerate(frames):
-            lg[t, c] = 3.0
+            lg[t, c] = 3.0 + (blank_boost if c == 0 else 0.0)
         lg += rs.standard_normal(lg.shape).astype(np.float32) * noise
         seqs.append(seq); rows.append(lg)
     T = max(r.shape[0] for r in rows)
@@ -75,93 +102,173 @@ class Opt:
     ctc_blank_skip_threshold, length_penalty, nbest = 1.0, 0.0, 100
 
 
+def _logp(logits, dev, lib):
+    lg = torch.from_numpy(logits).to(dev); pri = torch.zeros_like(lg); lp = torch.empty_like(lg)
+    U, T, C = logits.shape
+    N.check(lib.b2t_lm_prologue_f32(ops._p(lg), ops._p(pri), float(math.log(90.0)), ops._p(lp), U * T, C, ops._stream()), "prologue")
+    return lg, pri, lp
+
+
+def accuracy(prons, words, arpa, g, noise_levels=(0.9, 1.5, 2.0, 3.0), U=32, seed=0):
+    """BASELINE configs[3] asks for WER / PER against the language_model/ reference.  With the reference's searcher rebuilt
+    (WFST token passing) and its data absent, what can be reported is: word error rate AGAINST THE SPELLED TRUTH of the WFST
+    1-best and of the lexicon prefix beam (b2t_prefix_beam_search_lex_f32: pronunciation trie + word 3-gram in HBM) at beams
+    10/16 and 10/100, at three noise levels, plus how far the prefix beam's answers are from the graph search's."""
+    lib = N.load(); dev = torch.device("cuda:0")
+    C = 41
+    lex = ngram_lm.Lexicon(prons, C)
+    wlm = ngram_lm.SparseNGramLM.from_arpa(arpa, lex.words)
+    rows = []
+    for noise in noise_levels:
+        # blank frames carry the margin real CTC outputs have (the decoder's blank penalty ln 90 is tuned for it): without
+        # it every blank frame is a coin flip after the penalty and no searcher with a beam of 100 prefixes can cope
+        _, _, _, _, seqs, logits, lens, _ = make(U=U, seed=seed, noise=noise, graph=(prons, words, arpa, g), truth="lm",
+                                                 blank_boost=math.log(90.0))
+        _, _, lp = _logp(logits, dev, lib)
+        T = logits.shape[1]
+        S = WfstSearch(g, Opt, U=U, max_frames=T + 8, max_tokens=1 << 21, max_links=1 << 23)
+        S.search(lp, lens)
+        fin = S.finalize()
+        del S
+        wfst_1 = [[g.words[w] for w in f[0][2]] if f else [] for f in fin]
+        nref = sum(len(r) for r in seqs)
+        row = dict(noise=noise, wfst_wer_vs_truth=round(sum(edit(h, r) for h, r in zip(wfst_1, seqs)) / nref, 4))
+        for fb, sb in ((10, 16), (10, 100)):
+            opts = lm_decoder.DecodeOptions(7000, 200, 17.0, 8.0, 0.325, 1.0, 0.0, 100)
+            opts.first_beam_size, opts.second_beam_size = fb, sb
+            opts.lm_alpha, opts.lm_beta, opts.lm_eos = 1.0 / 0.325, 0.0, True     # graph cost : acoustic cost = 1 : 0.325
+            res = lm_decoder.DecodeResource("", "", "", "", "")
+            res.set_lexicon_lm(lex, wlm, sil=1)
+            e_truth = e_wfst = overlap = n_over = 0
+            t0 = time.perf_counter()
+            for u in range(U):
+                dec = lm_decoder.BrainSpeechDecoder(res, opts, max_len=T + 8)
+                dec.Decode(lp[u, :lens[u]])
+                hyp = dec.result()
+                h1 = hyp[0].sentence.split() if hyp else []
+                e_truth += edit(h1, seqs[u]); e_wfst += edit(h1, wfst_1[u])
+                ref_set = set(" ".join(g.words[w] for w in e[2]) for e in fin[u][:10])
+                overlap += len(ref_set & set(r.sentence for r in hyp[:10])); n_over += len(ref_set)
+            dt = time.perf_counter() - t0
+            row[f"lexicon_prefix_beam_{fb}_{sb}"] = dict(wer_vs_truth=round(e_truth / nref, 4),
+                                                         wer_vs_wfst_1best=round(e_wfst / max(1, sum(len(w) for w in wfst_1)), 4),
+                                                         top10_overlap_with_wfst=round(overlap / max(1, n_over), 3),
+                                                         ms_per_utterance_incl_host=round(dt / U * 1e3, 2))
+        rows.append(row)
+    return rows
+
+
 def run():
     lib = N.load(); dev = torch.device("cuda:0"); _p = ops._p
     prons, words, arpa, g, seqs, logits, lens, build_s = make()
     U, T, C = logits.shape
-    lg = torch.from_numpy(logits).to(dev); pri = torch.zeros_like(lg); lp = torch.empty_like(lg)
-    N.check(lib.b2t_lm_prologue_f32(_p(lg), _p(pri), float(math.log(90.0)), _p(lp), U * T, C, ops._stream()), "prologue")
+    lg, pri, lp = _logp(logits, dev, lib)
     sys.stderr.write(f"TLG: {g.n_states} states, {g.n_arcs} arcs, built in {build_s:.1f} s; {U} x {T} frames\n")
-    S = WfstSearch(g, Opt, U=U, max_frames=T + 8, max_tokens=1 << 22, max_links=1 << 24, hash_size=int(os.environ.get("B2T_WFST_HASH", "0")))
-    ts = []
-    for rep in range(3):
-        S.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        N.check(lib.b2t_lm_prologue_f32(_p(lg), _p(pri), float(math.log(90.0)), _p(lp), U * T, C, ops._stream()), "prologue")
-        S.search(lp, lens)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        fin = S.finalize()
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        ts.append((t1 - t0, t2 - t1))
-    search_ms, fin_ms = min(t[0] for t in ts) * 1e3, min(t[1] for t in ts) * 1e3
+    hs = int(os.environ.get("B2T_WFST_HASH", "0"))
+
+    def timed(S, reps=3):
+        ts, mem, fin = [], None, None
+        for rep in range(reps):
+            S.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            N.check(lib.b2t_lm_prologue_f32(_p(lg), _p(pri), float(math.log(90.0)), _p(lp), U * T, C, ops._stream()), "prologue")
+            S.search(lp, lens)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            mem = S.memory_stats()
+            torch.cuda.synchronize(); t1b = time.perf_counter()
+            fut = S.finalize_async()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            fin = fut.result(); t3 = time.perf_counter()
+            ts.append((t1 - t0, t2 - t1b, t3 - t2))
+        return [min(t[i] for t in ts) * 1e3 for i in range(3)] + [mem, fin]
+
+    G_auto = lib.b2t_wfst_cluster_size(U)
+    big = dict(max_frames=T + 8, max_tokens=1 << 22, max_links=1 << 24, hash_size=hs)
+    # (a) round 2's form: one workgroup per utterance (32 of the 256 CUs), everything pruned once, at the end
+    lib.b2t_wfst_set_cluster(1)
+    S1 = WfstSearch(g, Opt, U=U, prune_interval=0, **big)
+    search1_ms, _, _, _, _ = timed(S1, 2)
+    del S1
+    lib.b2t_wfst_set_cluster(0)
+    # (b) clusters; PruneActiveTokens every 25 frames like the reference (lattice-faster-decoder.cc:592-630)
+    Sr = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.0, **big)
+    search_ref_ms, fin_gpu_ref_ms, nbest_ref_ms, mem_ref, _ = timed(Sr, 2)
+    del Sr
+    # (c) clusters; the passes only when an utterance's arrays are half full (they only bound memory): the default here
+    S = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.5, **big)
+    search_ms, fin_gpu_ms, nbest_ms, mem, fin = timed(S, 3)
     hdr = S._header()
-    tok_per_frame = float(hdr[:, 1].sum()) / float(hdr[:, 0].sum())
+    created_tok = float(sum(m["created_tokens"] for m in mem)); created_link = float(sum(m["created_links"] for m in mem))
+    tok_per_frame = created_tok / float(hdr[:, 0].sum())
     # algorithmic bytes of the search (SURVEY 8d): 16 B per expanded arc + 20 B per token + 21 B per forward link
-    alg_bytes = 16.0 * sum(S.arcs_expanded()) + 20.0 * float(hdr[:, 1].sum()) + 21.0 * float(hdr[:, 2].sum())
-    # the same search with every CU busy: one workgroup per utterance means 32 utterances use 32 of the 256 CUs
+    alg_bytes = 16.0 * sum(S.arcs_expanded()) + 20.0 * created_tok + 21.0 * created_link
+    # (d) steady state over 6 batches with the host n-best of batch b running under the search of batch b + 1
+    S2 = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.5, **big)
+    pend, t0 = None, None
+    for b in range(7):
+        if b == 1:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        Sx = S if b % 2 == 0 else S2
+        Sx.reset(); Sx.search(lp, lens)
+        f = Sx.finalize_async()
+        if pend is not None:
+            pend.result()
+        pend = f
+    pend.result()
+    pipelined_ms = (time.perf_counter() - t0) * 1e3 / 6
+    del S2
+    # the same search with one workgroup per utterance and every CU busy: 256 utterances in one call
     wide = None
     UW = int(os.environ.get("B2T_WFST_WIDE_U", "256"))
     if UW > U:
         try:
             rep = (UW + U - 1) // U
             lpw = lp.repeat(rep, 1, 1)[:UW].contiguous(); lensw = np.tile(lens, rep)[:UW]
-            SW = WfstSearch(g, Opt, U=UW, max_frames=T + 8, max_tokens=1 << 21, max_links=1 << 23, hash_size=int(os.environ.get("B2T_WFST_HASH", "0")))
+            SW = WfstSearch(g, Opt, U=UW, max_frames=T + 8, max_tokens=1 << 21, max_links=1 << 23, hash_size=hs, prune_interval=0)
             tw = []
             for rep_ in range(2):
                 SW.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
                 SW.search(lpw, lensw); torch.cuda.synchronize(); tw.append(time.perf_counter() - t0)
-            wide = dict(utterances=UW, search_ms=round(min(tw) * 1e3, 2), search_ms_per_utterance=round(min(tw) * 1e3 / UW, 3),
-                        achieved_gb_s=round(alg_bytes * (UW / U) / min(tw) / 1e9, 1))
+            wide = dict(utterances=UW, workgroups_per_utterance=int(lib.b2t_wfst_cluster_size(UW)), search_ms=round(min(tw) * 1e3, 2),
+                        search_ms_per_utterance=round(min(tw) * 1e3 / UW, 3), achieved_gb_s=round(alg_bytes * (UW / U) / min(tw) / 1e9, 1))
             del SW, lpw
             torch.cuda.empty_cache()
         except Exception as e:     # capacity of the box
             wide = dict(error=str(e)[:200])
-    # streaming: one frame per call for all U utterances, partial best path read back
-    S.reset()
+    # streaming: one frame per call for all U utterances, partial best path read back; PruneActiveTokens every 25 frames
+    Ss = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.0, max_frames=T + 8, max_tokens=1 << 20, max_links=1 << 22, hash_size=hs)
     lat = []
     for t in range(T):
         fr = lp[:, t:t + 1].contiguous()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        S.search(fr, np.minimum(1, np.maximum(0, lens - t)).astype(np.int32))
-        S.best_path(False, max_len=2 * T + 8)
+        Ss.search(fr, np.minimum(1, np.maximum(0, lens - t)).astype(np.int32))
+        Ss.best_path(False, max_len=2 * T + 8)
         lat.append(time.perf_counter() - t0)
     lat = np.array(lat[5:]) * 1e3
-    S.finalize()
-    # agreement
+    smem = Ss.memory_stats()
+    Ss.finalize()
+    del Ss
     wfst_1 = [[g.words[w] for w in f[0][2]] if f else [] for f in fin]
     err_truth = sum(edit(h, r) for h, r in zip(wfst_1, seqs)); nref = sum(len(r) for r in seqs)
+    gbs = lambda ms: round(alg_bytes / (ms * 1e-3) / 1e9, 2)
     out = dict(graph=dict(words=len(words), tlg_states=int(g.n_states), tlg_arcs=int(g.n_arcs), mb=round(g.nbytes() / 1e6, 1),
                           host_build_s=round(build_s, 1)),
-               offline=dict(utterances=U, frames=int(T), search_ms=round(search_ms, 2), finalize_nbest100_ms=round(fin_ms, 2),
-                            ms_per_utterance=round((search_ms + fin_ms) / U, 3), tokens_per_frame=round(tok_per_frame, 1),
-                            algorithmic_mb=round(alg_bytes / 1e6, 1), achieved_gb_s=round(alg_bytes / (search_ms * 1e-3) / 1e9, 2),
+               offline=dict(utterances=U, frames=int(T), workgroups_per_utterance=int(G_auto), search_ms=round(search_ms, 2),
+                            search_ms_prune_every_25_frames=round(search_ref_ms, 2),
+                            search_ms_one_workgroup_per_utterance=round(search1_ms, 2),
+                            finalize_gpu_ms=round(fin_gpu_ms, 2), nbest100_host_ms=round(nbest_ms, 2),
+                            ms_per_utterance=round((search_ms + fin_gpu_ms + nbest_ms) / U, 3),
+                            pipelined_ms_per_batch=round(pipelined_ms, 2), pipelined_ms_per_utterance=round(pipelined_ms / U, 3),
+                            held_vs_created_tokens_with_pruning=round(sum(m["tokens"] for m in mem_ref) / max(1.0, created_tok), 3),
+                            tokens_per_frame=round(tok_per_frame, 1), algorithmic_mb=round(alg_bytes / 1e6, 1),
+                            achieved_gb_s=gbs(search_ms), achieved_gb_s_one_workgroup_per_utterance=gbs(search1_ms),
                             hbm_roofline_frac=round(alg_bytes / (search_ms * 1e-3) / 8.0e12, 5)),
                offline_all_cus=wide,
-               streaming=dict(p50_ms_per_frame=round(float(np.percentile(lat, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat, 95)), 3)),
+               streaming=dict(p50_ms_per_frame=round(float(np.percentile(lat, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat, 95)), 3),
+                              max_ms_per_frame=round(float(lat.max()), 3),
+                              held_tokens_at_end=int(max(m["tokens"] for m in smem)), created_tokens=int(max(m["created_tokens"] for m in smem)),
+                              prune_passes=int(smem[0]["prunes"])),
                wfst_wer_vs_truth=round(err_truth / nref, 4))
-    # the round-1 substitute: lexicon-constrained prefix beam + word n-gram (b2t_prefix_beam_search_lex_f32)
-    lex = ngram_lm.Lexicon(prons, C)
-    wlm = ngram_lm.SparseNGramLM.from_arpa(arpa, lex.words)
-    for fb, sb in ((10, 16), (16, 64), (16, 128)):
-        opts = lm_decoder.DecodeOptions(7000, 200, 17.0, 8.0, 0.325, 1.0, 0.0, 100)
-        opts.first_beam_size, opts.second_beam_size = fb, sb
-        opts.lm_alpha, opts.lm_beta, opts.lm_eos = 1.0 / 0.325, 0.0, True     # graph cost : acoustic cost = 1 : 0.325
-        res = lm_decoder.DecodeResource("", "", "", "", "")
-        res.set_lexicon_lm(lex, wlm, sil=1)
-        errs, overlap, n_over = 0, 0, 0
-        t0 = time.perf_counter()
-        for u in range(U):
-            dec = lm_decoder.BrainSpeechDecoder(res, opts, max_len=T + 8)
-            dec.Decode(lp[u, :lens[u]])
-            hyp = dec.result()
-            h1 = hyp[0].sentence.split() if hyp else []
-            errs += edit(h1, wfst_1[u])
-            ref_set = set(" ".join(g.words[w] for w in e[2]) for e in fin[u][:10])
-            got_set = set(r.sentence for r in hyp[:10])
-            overlap += len(ref_set & got_set); n_over += len(ref_set)
-        dt = time.perf_counter() - t0
-        out[f"prefix_beam_lex_{fb}_{sb}"] = dict(wer_vs_wfst_1best=round(errs / max(1, sum(len(w) for w in wfst_1)), 4),
-                                                  top10_overlap_with_wfst=round(overlap / max(1, n_over), 3),
-                                                  ms_per_utterance_incl_host=round(dt / U * 1e3, 2))
+    out["accuracy_by_noise"] = accuracy(prons, words, arpa, g)
     return out
 
 
