@@ -377,6 +377,42 @@ int b2t_prefix_beam_search_lex_f32(const float* logp, const int32_t* lens, int U
                                    int32_t* hyps, int32_t* hyp_len, float* score, float* vscore, int32_t* times,
                                    const b2t_lexlm_t* d, float* lm_score, void* stream);
 
+/* ---- f4: decode-graph compiler on the host (csrc/graphc.cpp; no device work, no stream) ------------------------------------
+ * The FST algebra of the reference's graph recipe, language_model/tools/fst/make_tlg.sh:29-46
+ *   fsttablecompose L.fst G.fst | fstdeterminizestar --use-log=true | fstminimizeencoded | fstarcsort --sort_type=ilabel > LG.fst
+ *   fsttablecompose T.fst LG.fst > TLG.fst
+ * over handles to host FSTs in CSR form (tropical weights = costs; +inf final cost = not final).  A handle is owned by the
+ * caller (b2t_fst_free); every operation returns a NEW handle or NULL (b2t_last_error()).
+ *   b2t_fst_from_arrays     arcs in any order (src, ilabel, olabel, weight, dst); arc order within a state is kept
+ *   b2t_fst_info            {n_states, n_arcs, start, n_final}
+ *   b2t_fst_to_arrays       row[n_states + 1] (int64), ilabel / olabel / weight / next [n_arcs], final_cost [n_states]
+ *   b2t_fst_compose         a o b (a's olabels against b's ilabels), epsilon-matching filter: fst::Compose / fsttablecompose
+ *   b2t_fst_trim            fstconnect: accessible and co-accessible states only; start state 0
+ *   b2t_fst_determinize_star  kaldi/fstext/determinize-star-inl.h (epsilon removal + determinisation on the input side, output
+ *                           strings as chains of input-epsilon arcs); use_log: weights of merged paths are log-added
+ *                           (--use-log=true), else the minimum; delta: weight tolerance of subset equality (Kaldi 1/1024);
+ *                           max_states <= 0: unlimited.  Fails on non-functional input (needs the lexicon's disambiguation
+ *                           symbols, tools/fst/add_lex_disambig.pl)
+ *   b2t_fst_minimize_encoded  kaldi/fstext/fstext-utils.h:110-116: weights quantised to multiples of delta, (ilabel, olabel,
+ *                           weight) as one label, acceptor minimisation
+ *   b2t_fst_arcsort         fstarcsort --sort_type=ilabel (by_olabel = 0) / olabel (1), stable
+ *   b2t_fst_read_openfst / b2t_fst_write_openfst   OpenFST binary container, fst type "vector", arc type "standard"
+ *   b2t_fst_grammar_score   cost of a word-id sequence through an ilabel-sorted grammar whose back-off arcs carry `backoff_label`
+ *                           (what composing a lattice path with G adds: brain_speech_decoder.cc:44-58); +inf = not accepted */
+void* b2t_fst_from_arrays(int n_states, int start, long long n_arcs, const int32_t* src, const int32_t* ilabel, const int32_t* olabel,
+                          const float* weight, const int32_t* dst, const float* final_cost);
+void b2t_fst_free(void* fst);
+int b2t_fst_info(const void* fst, long long* out4);
+int b2t_fst_to_arrays(const void* fst, long long* row, int32_t* ilabel, int32_t* olabel, float* weight, int32_t* next, float* final_cost);
+void* b2t_fst_compose(const void* a, const void* b);
+void* b2t_fst_trim(const void* fst);
+void* b2t_fst_determinize_star(const void* fst, int use_log, float delta, long long max_states);
+void* b2t_fst_minimize_encoded(const void* fst, float delta);
+void* b2t_fst_arcsort(const void* fst, int by_olabel);
+void* b2t_fst_read_openfst(const char* path);
+int b2t_fst_write_openfst(const void* fst, const char* path);
+double b2t_fst_grammar_score(const void* fst, const int32_t* words, int n_words, int backoff_label);
+
 /* ---- a15/a16: WFST token passing (the reference's LM decode proper) ---------------------------------------------------
  * CtcWfstBeamSearch::Search / FinalizeSearch (language_model/runtime/core/decoder/ctc_wfst_beam_search.cc:70-160) over
  * kaldi's LatticeFasterDecoder (language_model/runtime/core/kaldi/decoder/lattice-faster-decoder.cc: ProcessEmitting

@@ -132,6 +132,18 @@ _SIGNATURES = {
                                 C.POINTER(C.c_float), C.c_double, C.c_double, C.c_float, VP]),
     "b2t_greedy_decode_f32": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "b2t_edit_distance_i32": (C.c_int, [VP, VP, C.c_int, VP, VP, C.c_int, VP, C.c_int, VP]),
+    "b2t_fst_from_arrays": (VP, [C.c_int, C.c_int, LL, VP, VP, VP, VP, VP, VP]),
+    "b2t_fst_free": (None, [VP]),
+    "b2t_fst_info": (C.c_int, [VP, C.POINTER(LL)]),
+    "b2t_fst_to_arrays": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
+    "b2t_fst_compose": (VP, [VP, VP]),
+    "b2t_fst_trim": (VP, [VP]),
+    "b2t_fst_determinize_star": (VP, [VP, C.c_int, C.c_float, LL]),
+    "b2t_fst_minimize_encoded": (VP, [VP, C.c_float]),
+    "b2t_fst_arcsort": (VP, [VP, C.c_int]),
+    "b2t_fst_read_openfst": (VP, [C.c_char_p]),
+    "b2t_fst_write_openfst": (C.c_int, [VP, C.c_char_p]),
+    "b2t_fst_grammar_score": (C.c_double, [VP, VP, C.c_int, C.c_int]),
     "b2t_wfst_state_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "b2t_wfst_cluster_size": (C.c_int, [C.c_int]),
     "b2t_wfst_set_cluster": (C.c_int, [C.c_int]),

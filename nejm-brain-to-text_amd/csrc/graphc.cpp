@@ -1,0 +1,628 @@
+// graphc.cpp — host-side decode-graph compiler: the FST algebra the reference's recipe runs through OpenFST /
+// Kaldi binaries (language_model/tools/fst/make_tlg.sh:29-46: fsttablecompose | fstdeterminizestar --use-log=true |
+// fstminimizeencoded | fstarcsort, then fsttablecompose with T) on flat arrays, behind a C ABI (include/b2t.h, b2t_fst_*).
+// Written for graphs of the reference's size class (125 k words, 10^6-10^8 arcs): CSR storage, hashed state tuples, no
+// per-arc heap objects.  Semantics restated from:
+//   composition            epsilon-matching filter of fst::Compose (filter states 0 / 1 / 2), as nejm-brain-to-text_amd/wfst.py
+//   determinize-star       language_model/runtime/core/kaldi/fstext/determinize-star-inl.h:184-1130 (subsets of (state, output
+//                          string, residual weight); epsilon closure; common output prefix and total weight divided out of a
+//                          transition; output strings expanded into chains of input-epsilon arcs), tropical or log semiring
+//   minimize-encoded       language_model/runtime/core/kaldi/fstext/fstext-utils.h:110-116 (quantise weights, encode (ilabel,
+//                          olabel, weight) as one label, minimise the deterministic acceptor, decode)
+// OpenFST itself is not in the image and not in the reference checkout: nothing here can be compared with its output
+// files; tests/test_graphc.py checks the definitions instead (same weighted relation before and after, determinism,
+// minimality against a brute-force Myhill-Nerode partition, equality with the Python composition).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <deque>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "common.h"
+
+namespace b2t {
+namespace {
+
+struct HArc { int il, ol; float w; int nx; };
+struct HFst {
+  int start = -1;
+  std::vector<int64_t> row;      // [n + 1]
+  std::vector<HArc> arcs;
+  std::vector<float> fin;        // [n], +inf = not final
+  int n() const { return (int)fin.size(); }
+};
+
+const float FINF = INFINITY;
+
+HFst* from_lists(int n, int start, const std::vector<int>& src, std::vector<HArc>& arcs, std::vector<float>& fin) {
+  HFst* f = new HFst;
+  f->start = start;
+  f->fin.swap(fin);
+  f->row.assign((size_t)n + 1, 0);
+  for (int s : src) ++f->row[(size_t)s + 1];
+  for (int s = 0; s < n; ++s) f->row[(size_t)s + 1] += f->row[s];
+  f->arcs.resize(arcs.size());
+  std::vector<int64_t> pos(f->row.begin(), f->row.end() - 1);
+  for (size_t i = 0; i < arcs.size(); ++i) f->arcs[(size_t)pos[src[i]]++] = arcs[i];     // stable: arc order within a state kept
+  return f;
+}
+
+inline float plus_w(float a, float b, bool log_sr) {
+  if (!log_sr) return a < b ? a : b;
+  if (a == FINF) return b;
+  if (b == FINF) return a;
+  const float m = a < b ? a : b, d = fabsf(a - b);
+  return m - log1pf(expf(-d));
+}
+
+struct VecHash {
+  size_t operator()(const std::vector<int>& v) const {
+    size_t h = 1469598103934665603ull;
+    for (int x : v) { h ^= (size_t)(unsigned)x; h *= 1099511628211ull; }
+    return h;
+  }
+};
+
+// ---- output-string repository (determinize-star-inl.h:42-180): id 0 = the empty string -------------------------------------
+struct Strings {
+  std::vector<std::vector<int>> seq{std::vector<int>()};
+  std::unordered_map<std::vector<int>, int, VecHash> id{{std::vector<int>(), 0}};
+  int of(const std::vector<int>& v) {
+    auto it = id.find(v);
+    if (it != id.end()) return it->second;
+    seq.push_back(v);
+    id.emplace(v, (int)seq.size() - 1);
+    return (int)seq.size() - 1;
+  }
+  int append(int s, int label) { std::vector<int> v = seq[s]; v.push_back(label); return of(v); }
+  int remove_prefix(int s, size_t k) { if (k == 0) return s; std::vector<int> v(seq[s].begin() + k, seq[s].end()); return of(v); }
+};
+
+struct Elem { int state, str; float w; };
+
+struct SubsetHash {
+  size_t operator()(const std::vector<Elem>* v) const {
+    size_t h = 1469598103934665603ull;
+    for (const Elem& e : *v) { h ^= (size_t)(unsigned)e.state * 0x9e3779b97f4a7c15ull + (size_t)(unsigned)e.str; h *= 1099511628211ull; }
+    return h;
+  }
+};
+struct SubsetEq {
+  float delta;
+  bool operator()(const std::vector<Elem>* a, const std::vector<Elem>* b) const {
+    if (a->size() != b->size()) return false;
+    for (size_t i = 0; i < a->size(); ++i) {
+      const Elem &x = (*a)[i], &y = (*b)[i];
+      if (x.state != y.state || x.str != y.str) return false;
+      if (!(fabsf(x.w - y.w) <= delta) && !(x.w == y.w)) return false;
+    }
+    return true;
+  }
+};
+
+}  // namespace
+}  // namespace b2t
+
+using namespace b2t;
+
+#define FST(h) (reinterpret_cast<HFst*>(h))
+#define CFST(h) (reinterpret_cast<const HFst*>(h))
+
+extern "C" void* b2t_fst_from_arrays(int n_states, int start, long long n_arcs, const int32_t* src, const int32_t* il, const int32_t* ol,
+                                     const float* w, const int32_t* dst, const float* final_cost) {
+  if (n_states <= 0 || start < 0 || start >= n_states || n_arcs < 0 || !final_cost || (n_arcs > 0 && (!src || !il || !ol || !w || !dst))) {
+    set_error("fst_from_arrays: bad arguments");
+    return nullptr;
+  }
+  std::vector<int> s((size_t)n_arcs);
+  std::vector<HArc> a((size_t)n_arcs);
+  for (long long i = 0; i < n_arcs; ++i) {
+    if (src[i] < 0 || src[i] >= n_states || dst[i] < 0 || dst[i] >= n_states) { set_error("fst_from_arrays: arc %lld out of range", i); return nullptr; }
+    s[(size_t)i] = src[i]; a[(size_t)i] = HArc{il[i], ol[i], w[i], dst[i]};
+  }
+  std::vector<float> fin(final_cost, final_cost + n_states);
+  return from_lists(n_states, start, s, a, fin);
+}
+
+extern "C" void b2t_fst_free(void* h) { delete FST(h); }
+
+extern "C" int b2t_fst_info(const void* h, long long* out4) {
+  B2T_REQUIRE(h && out4, "fst_info: null argument");
+  const HFst* f = CFST(h);
+  long long nf = 0;
+  for (float c : f->fin) nf += c != FINF;
+  out4[0] = f->n(); out4[1] = (long long)f->arcs.size(); out4[2] = f->start; out4[3] = nf;
+  return 0;
+}
+
+extern "C" int b2t_fst_to_arrays(const void* h, long long* row, int32_t* il, int32_t* ol, float* w, int32_t* nx, float* final_cost) {
+  B2T_REQUIRE(h && row && final_cost, "fst_to_arrays: null argument");
+  const HFst* f = CFST(h);
+  for (size_t i = 0; i < f->row.size(); ++i) row[i] = f->row[i];
+  for (size_t i = 0; i < f->arcs.size(); ++i) { il[i] = f->arcs[i].il; ol[i] = f->arcs[i].ol; w[i] = f->arcs[i].w; nx[i] = f->arcs[i].nx; }
+  for (size_t i = 0; i < f->fin.size(); ++i) final_cost[i] = f->fin[i];
+  return 0;
+}
+
+// ---- arc sort (fstarcsort --sort_type=ilabel / olabel), stable -----------------------------------------------------------------
+extern "C" void* b2t_fst_arcsort(const void* h, int by_olabel) {
+  if (!h) { set_error("fst_arcsort: null"); return nullptr; }
+  HFst* g = new HFst(*CFST(h));
+  for (int s = 0; s < g->n(); ++s)
+    std::stable_sort(g->arcs.begin() + g->row[s], g->arcs.begin() + g->row[(size_t)s + 1],
+                     [&](const HArc& a, const HArc& b) { return by_olabel ? a.ol < b.ol : a.il < b.il; });
+  return g;
+}
+
+// ---- composition with the epsilon-matching filter ---------------------------------------------------------------------------
+extern "C" void* b2t_fst_compose(const void* ha, const void* hb) {
+  if (!ha || !hb) { set_error("fst_compose: null"); return nullptr; }
+  const HFst &a = *CFST(ha), &b = *CFST(hb);
+  if ((uint64_t)a.n() >= (1ull << 30)) { set_error("fst_compose: the left operand has too many states"); return nullptr; }
+  // b's arcs by (state, ilabel), original order kept among equal labels
+  std::vector<HArc> bs(b.arcs);
+  for (int s = 0; s < b.n(); ++s)
+    std::stable_sort(bs.begin() + b.row[s], bs.begin() + b.row[(size_t)s + 1], [](const HArc& x, const HArc& y) { return x.il < y.il; });
+  auto brange = [&](int s, int label, int64_t& lo, int64_t& hi) {
+    const HArc* p0 = bs.data() + b.row[s];
+    const HArc* p1 = bs.data() + b.row[(size_t)s + 1];
+    lo = std::lower_bound(p0, p1, label, [](const HArc& x, int l) { return x.il < l; }) - bs.data();
+    hi = std::upper_bound(p0, p1, label, [](int l, const HArc& x) { return l < x.il; }) - bs.data();
+  };
+  std::unordered_map<uint64_t, int> ids;
+  ids.reserve(1 << 20);
+  std::vector<uint64_t> keys;
+  std::vector<int> src;
+  std::vector<HArc> arcs;
+  std::vector<float> fin;
+  auto sid = [&](int sa, int sb, int fs) {
+    const uint64_t k = ((uint64_t)sa << 34) | ((uint64_t)(uint32_t)sb << 2) | (uint64_t)fs;
+    auto it = ids.find(k);
+    if (it != ids.end()) return it->second;
+    const int id = (int)keys.size();
+    ids.emplace(k, id);
+    keys.push_back(k);
+    fin.push_back(FINF);
+    return id;
+  };
+  if ((uint64_t)b.n() >= (1ull << 32)) { set_error("fst_compose: the right operand has too many states"); return nullptr; }
+  sid(a.start, b.start, 0);
+  for (size_t q = 0; q < keys.size(); ++q) {
+    const uint64_t k = keys[q];
+    const int sa = (int)(k >> 34), sb = (int)((k >> 2) & 0xffffffffu), fs = (int)(k & 3);
+    const int s = (int)q;
+    if (a.fin[sa] != FINF && b.fin[sb] != FINF) fin[s] = a.fin[sa] + b.fin[sb];
+    int64_t e0, e1;
+    brange(sb, 0, e0, e1);
+    for (int64_t i = a.row[sa]; i < a.row[(size_t)sa + 1]; ++i) {
+      const HArc& x = a.arcs[(size_t)i];
+      if (x.ol != 0) {
+        int64_t lo, hi;
+        brange(sb, x.ol, lo, hi);
+        for (int64_t j = lo; j < hi; ++j) {
+          const HArc& y = bs[(size_t)j];
+          const int d = sid(x.nx, y.nx, 0);
+          src.push_back(s); arcs.push_back(HArc{x.il, y.ol, x.w + y.w, d});
+        }
+      } else {
+        if (fs != 2) { const int d = sid(x.nx, sb, 1); src.push_back(s); arcs.push_back(HArc{x.il, 0, x.w, d}); }
+        if (fs == 0)
+          for (int64_t j = e0; j < e1; ++j) {
+            const HArc& y = bs[(size_t)j];
+            const int d = sid(x.nx, y.nx, 0);
+            src.push_back(s); arcs.push_back(HArc{x.il, y.ol, x.w + y.w, d});
+          }
+      }
+    }
+    if (fs != 1)
+      for (int64_t j = e0; j < e1; ++j) {
+        const HArc& y = bs[(size_t)j];
+        const int d = sid(sa, y.nx, 2);
+        src.push_back(s); arcs.push_back(HArc{0, y.ol, y.w, d});
+      }
+    if (keys.size() > (size_t)INT32_MAX - 8) { set_error("fst_compose: more than 2^31 states"); return nullptr; }
+  }
+  return from_lists((int)keys.size(), 0, src, arcs, fin);
+}
+
+// ---- trim (fstconnect): accessible and co-accessible states; start becomes 0, the others keep their order -------------------------
+extern "C" void* b2t_fst_trim(const void* h) {
+  if (!h) { set_error("fst_trim: null"); return nullptr; }
+  const HFst& f = *CFST(h);
+  const int n = f.n();
+  std::vector<char> fw((size_t)n, 0), bw((size_t)n, 0);
+  std::vector<int> st{f.start};
+  fw[(size_t)f.start] = 1;
+  while (!st.empty()) {
+    const int s = st.back(); st.pop_back();
+    for (int64_t i = f.row[s]; i < f.row[(size_t)s + 1]; ++i) { const int d = f.arcs[(size_t)i].nx; if (!fw[(size_t)d]) { fw[(size_t)d] = 1; st.push_back(d); } }
+  }
+  std::vector<int64_t> rrow((size_t)n + 1, 0);
+  for (const HArc& a : f.arcs) ++rrow[(size_t)a.nx + 1];
+  for (int s = 0; s < n; ++s) rrow[(size_t)s + 1] += rrow[s];
+  std::vector<int> rsrc(f.arcs.size());
+  {
+    std::vector<int64_t> pos(rrow.begin(), rrow.end() - 1);
+    for (int s = 0; s < n; ++s) for (int64_t i = f.row[s]; i < f.row[(size_t)s + 1]; ++i) rsrc[(size_t)pos[f.arcs[(size_t)i].nx]++] = s;
+  }
+  for (int s = 0; s < n; ++s) if (f.fin[s] != FINF) { bw[(size_t)s] = 1; st.push_back(s); }
+  while (!st.empty()) {
+    const int s = st.back(); st.pop_back();
+    for (int64_t i = rrow[s]; i < rrow[(size_t)s + 1]; ++i) { const int p = rsrc[(size_t)i]; if (!bw[(size_t)p]) { bw[(size_t)p] = 1; st.push_back(p); } }
+  }
+  if (!(fw[(size_t)f.start] && bw[(size_t)f.start])) { set_error("fst_trim: the graph accepts nothing"); return nullptr; }
+  std::vector<int> nid((size_t)n, -1);
+  int m = 0;
+  nid[(size_t)f.start] = m++;
+  for (int s = 0; s < n; ++s) if (s != f.start && fw[(size_t)s] && bw[(size_t)s]) nid[(size_t)s] = m++;
+  std::vector<int> src;
+  std::vector<HArc> arcs;
+  std::vector<float> fin((size_t)m, FINF);
+  // arcs in the order of the ORIGINAL arc list of surviving states, sources renumbered (stable per state in from_lists)
+  for (int s = 0; s < n; ++s) {
+    if (nid[(size_t)s] < 0) continue;
+    fin[(size_t)nid[(size_t)s]] = f.fin[s];
+    for (int64_t i = f.row[s]; i < f.row[(size_t)s + 1]; ++i) {
+      const HArc& a = f.arcs[(size_t)i];
+      if (nid[(size_t)a.nx] >= 0) { src.push_back(nid[(size_t)s]); arcs.push_back(HArc{a.il, a.ol, a.w, nid[(size_t)a.nx]}); }
+    }
+  }
+  return from_lists(m, 0, src, arcs, fin);
+}
+
+// ---- determinize-star ------------------------------------------------------------------------------------------------------------
+extern "C" void* b2t_fst_determinize_star(const void* h, int use_log, float delta, long long max_states) {
+  if (!h) { set_error("fst_determinize_star: null"); return nullptr; }
+  const HFst& f = *CFST(h);
+  const bool lg = use_log != 0;
+  Strings rep;
+  struct TArc { int il, str, nx; float w; };              // nx == -1: final weight
+  std::vector<std::vector<TArc>> out;
+  SubsetEq eq{delta};
+  std::unordered_map<const std::vector<Elem>*, int, SubsetHash, SubsetEq> hash(1 << 16, SubsetHash(), eq);
+  std::vector<std::vector<Elem>*> owned;
+  std::deque<std::pair<std::vector<Elem>*, int>> Q;
+  auto subset_id = [&](const std::vector<Elem>& sub) {
+    auto it = hash.find(&sub);
+    if (it != hash.end()) return it->second;
+    std::vector<Elem>* keep = new std::vector<Elem>(sub);
+    owned.push_back(keep);
+    const int id = (int)out.size();
+    hash.emplace(keep, id);
+    out.emplace_back();
+    Q.push_front({keep, id});                              // (allow_partial = false: determinize-star-inl.h:617-621)
+    return id;
+  };
+  bool failed = false;
+  std::string why;
+  // epsilon closure of a subset: weights of all epsilon paths are combined with Plus; re-propagation while a state's
+  // weight still moves by more than delta (determinize-star-inl.h:705-870)
+  std::vector<int> idx_of((size_t)f.n(), -1);
+  auto closure = [&](const std::vector<Elem>& in, std::vector<Elem>& outset) {
+    struct Info { Elem e; float pending; bool queued; };
+    std::vector<Info> info;
+    std::deque<int> q;
+    auto add = [&](int state, int str, float w) {
+      int ix = idx_of[(size_t)state];
+      if (ix < 0 || ix >= (int)info.size() || info[(size_t)ix].e.state != state) {
+        idx_of[(size_t)state] = (int)info.size();
+        info.push_back(Info{Elem{state, str, FINF}, w, true});
+        q.push_back(state);
+        return;
+      }
+      Info& I = info[(size_t)ix];
+      if (I.e.str != str) { failed = true; why = "FST was not functional -> not determinizable (epsilon closure)"; return; }
+      I.pending = plus_w(I.pending, w, lg);
+      if (!I.queued) {
+        const float tot = plus_w(I.e.w, I.pending, lg);
+        if (!(fabsf(tot - I.e.w) <= delta)) { I.queued = true; q.push_back(state); }
+      }
+    };
+    for (const Elem& e : in) add(e.state, e.str, e.w);
+    long long guard = 0;
+    while (!q.empty() && !failed) {
+      const int s = q.front(); q.pop_front();
+      Info& I = info[(size_t)idx_of[(size_t)s]];
+      const float wproc = I.pending;
+      I.e.w = plus_w(I.e.w, wproc, lg); I.pending = FINF; I.queued = false;
+      const int str = I.e.str;
+      for (int64_t i = f.row[s]; i < f.row[(size_t)s + 1]; ++i) {
+        const HArc& a = f.arcs[(size_t)i];
+        if (a.il != 0) continue;
+        add(a.nx, a.ol == 0 ? str : rep.append(str, a.ol), wproc + a.w);
+        if (failed) break;
+      }
+      if (++guard > 100000000ll) { failed = true; why = "epsilon closure did not converge (epsilon cycle in the log semiring?)"; }
+    }
+    outset.clear();
+    for (Info& I : info) { if (I.pending != FINF) I.e.w = plus_w(I.e.w, I.pending, lg); outset.push_back(I.e); }
+    std::sort(outset.begin(), outset.end(), [](const Elem& x, const Elem& y) { return x.state < y.state; });
+    for (const Info& I : info) idx_of[(size_t)I.e.state] = -1;
+  };
+  {
+    std::vector<Elem> init{Elem{f.start, 0, 0.f}};
+    subset_id(init);
+  }
+  std::vector<Elem> closed, sub;
+  std::vector<std::pair<int, Elem>> all;
+  while (!Q.empty() && !failed) {
+    auto pr = Q.front(); Q.pop_front();
+    const int state = pr.second;
+    closure(*pr.first, closed);
+    if (failed) break;
+    {  // ProcessFinal (:472-510)
+      bool is_final = false; int fstr = 0; float fw = 0.f;
+      for (const Elem& e : closed) {
+        const float c = f.fin[(size_t)e.state];
+        if (c == FINF) continue;
+        if (!is_final) { fstr = e.str; fw = e.w + c; is_final = true; }
+        else {
+          if (fstr != e.str) { failed = true; why = "FST was not functional -> not determinizable (final weights)"; break; }
+          fw = plus_w(fw, e.w + c, lg);
+        }
+      }
+      if (is_final) out[(size_t)state].push_back(TArc{0, fstr, -1, fw});
+    }
+    if (failed) break;
+    // ProcessTransitions (:545-600)
+    all.clear();
+    for (const Elem& e : closed)
+      for (int64_t i = f.row[e.state]; i < f.row[(size_t)e.state + 1]; ++i) {
+        const HArc& a = f.arcs[(size_t)i];
+        if (a.il == 0) continue;
+        all.push_back({a.il, Elem{a.nx, a.ol == 0 ? e.str : rep.append(e.str, a.ol), e.w + a.w}});
+      }
+    std::stable_sort(all.begin(), all.end(), [](const std::pair<int, Elem>& x, const std::pair<int, Elem>& y) {
+      return x.first != y.first ? x.first < y.first : x.second.state < y.second.state;
+    });
+    size_t cur = 0;
+    while (cur < all.size() && !failed) {
+      const int il = all[cur].first;
+      sub.clear();
+      while (cur < all.size() && all[cur].first == il) {        // one Element per destination state, weights added (:1055-1080)
+        const Elem& e = all[cur].second;
+        if (!sub.empty() && sub.back().state == e.state) {
+          if (sub.back().str != e.str) { failed = true; why = "FST was not functional -> not determinizable (transition)"; break; }
+          sub.back().w = plus_w(sub.back().w, e.w, lg);
+        } else {
+          sub.push_back(e);
+        }
+        ++cur;
+      }
+      if (failed) break;
+      // common output prefix and total weight, divided out (:1082-1118)
+      std::vector<int> pre = rep.seq[(size_t)sub[0].str];
+      float tot = sub[0].w;
+      for (size_t i = 1; i < sub.size(); ++i) {
+        const std::vector<int>& s2 = rep.seq[(size_t)sub[i].str];
+        if (s2.size() < pre.size()) pre.resize(s2.size());
+        for (size_t k = 0; k < pre.size(); ++k) if (s2[k] != pre[k]) { pre.resize(k); break; }
+        tot = plus_w(tot, sub[i].w, lg);
+      }
+      const int common = rep.of(pre);
+      for (Elem& e : sub) { e.w -= tot; e.str = rep.remove_prefix(e.str, pre.size()); }
+      const int nx = subset_id(sub);
+      out[(size_t)state].push_back(TArc{il, common, nx, tot});
+    }
+    if (max_states > 0 && (long long)out.size() > max_states) { failed = true; why = "more than max_states determinized states"; }
+  }
+  for (std::vector<Elem>* p : owned) delete p;
+  if (failed) { set_error("fst_determinize_star: %s", why.c_str()); return nullptr; }
+  // Output (:930-1040): strings become chains of arcs, all but the first with an epsilon on the input side
+  const int base = (int)out.size();
+  std::vector<int> src;
+  std::vector<HArc> arcs;
+  std::vector<float> fin((size_t)base, FINF);
+  auto new_state = [&]() { fin.push_back(FINF); return (int)fin.size() - 1; };
+  for (int s = 0; s < base; ++s)
+    for (const TArc& t : out[(size_t)s]) {
+      const std::vector<int>& seq = rep.seq[(size_t)t.str];
+      if (t.nx < 0) {
+        int cur = s;
+        for (size_t i = 0; i < seq.size(); ++i) {
+          const int nxt = new_state();
+          src.push_back(cur); arcs.push_back(HArc{0, seq[i], i == 0 ? t.w : 0.f, nxt});
+          cur = nxt;
+        }
+        fin[(size_t)cur] = seq.empty() ? t.w : 0.f;
+      } else {
+        int cur = s;
+        for (size_t i = 0; i + 1 < seq.size(); ++i) {
+          const int nxt = new_state();
+          src.push_back(cur); arcs.push_back(HArc{i == 0 ? t.il : 0, seq[i], i == 0 ? t.w : 0.f, nxt});
+          cur = nxt;
+        }
+        src.push_back(cur);
+        arcs.push_back(HArc{seq.size() <= 1 ? t.il : 0, seq.empty() ? 0 : seq.back(), seq.size() <= 1 ? t.w : 0.f, t.nx});
+      }
+    }
+  return from_lists((int)fin.size(), 0, src, arcs, fin);
+}
+
+// ---- minimize-encoded: the deterministic acceptor over labels (ilabel, olabel, quantised weight) minimised by partition
+//      refinement (states start out split by their quantised final weight; a state's signature is the sorted list of
+//      (label, class of the destination); repeated until the number of classes stops growing: the coarsest congruence) --------
+extern "C" void* b2t_fst_minimize_encoded(const void* h, float delta) {
+  if (!h) { set_error("fst_minimize_encoded: null"); return nullptr; }
+  const HFst& f = *CFST(h);
+  const int n = f.n();
+  auto quant = [&](float w) { return w == FINF ? FINF : floorf(w / delta + 0.5f) * delta; };   // QuantizeMapper
+  // encode: dense ids for (il, ol, quantised w)
+  struct Key { int il, ol; float w; bool operator==(const Key& o) const { return il == o.il && ol == o.ol && w == o.w; } };
+  struct KeyHash { size_t operator()(const Key& k) const { uint32_t wb; memcpy(&wb, &k.w, 4); return ((size_t)(unsigned)k.il * 0x9e3779b97f4a7c15ull) ^ ((size_t)(unsigned)k.ol << 21) ^ wb; } };
+  std::unordered_map<Key, int, KeyHash> lab;
+  std::vector<int> alab(f.arcs.size());
+  std::vector<float> aw(f.arcs.size());
+  for (size_t i = 0; i < f.arcs.size(); ++i) {
+    aw[i] = quant(f.arcs[i].w);
+    const Key k{f.arcs[i].il, f.arcs[i].ol, aw[i]};
+    auto it = lab.find(k);
+    if (it == lab.end()) it = lab.emplace(k, (int)lab.size()).first;
+    alab[i] = it->second;
+  }
+  // determinism on the encoded label is what acceptor minimisation needs
+  for (int s = 0; s < n; ++s) {
+    std::vector<int> ls;
+    for (int64_t i = f.row[s]; i < f.row[(size_t)s + 1]; ++i) ls.push_back(alab[(size_t)i]);
+    std::sort(ls.begin(), ls.end());
+    if (std::adjacent_find(ls.begin(), ls.end()) != ls.end()) { set_error("fst_minimize_encoded: state %d has two arcs with the same (ilabel, olabel, weight): determinize first", s); return nullptr; }
+  }
+  std::vector<int> cls((size_t)n), ncls((size_t)n);
+  {
+    std::unordered_map<uint32_t, int> by_final;
+    for (int s = 0; s < n; ++s) {
+      const float q = quant(f.fin[(size_t)s]);
+      uint32_t b; memcpy(&b, &q, 4);
+      auto it = by_final.find(b);
+      if (it == by_final.end()) it = by_final.emplace(b, (int)by_final.size()).first;
+      cls[(size_t)s] = it->second;
+    }
+  }
+  int ncl = 0;
+  for (int c : cls) ncl = std::max(ncl, c + 1);
+  std::vector<std::pair<int, int>> sig;
+  for (int iter = 0; iter < 100000; ++iter) {
+    std::unordered_map<std::vector<int>, int, VecHash> seen;
+    seen.reserve((size_t)ncl * 2 + 16);
+    std::vector<int> key;
+    for (int s = 0; s < n; ++s) {
+      sig.clear();
+      for (int64_t i = f.row[s]; i < f.row[(size_t)s + 1]; ++i) sig.push_back({alab[(size_t)i], cls[(size_t)f.arcs[(size_t)i].nx]});
+      std::sort(sig.begin(), sig.end());
+      key.clear();
+      key.push_back(cls[(size_t)s]);
+      for (auto& p : sig) { key.push_back(p.first); key.push_back(p.second); }
+      auto it = seen.find(key);
+      if (it == seen.end()) it = seen.emplace(key, (int)seen.size()).first;
+      ncls[(size_t)s] = it->second;
+    }
+    const int m = (int)seen.size();
+    cls.swap(ncls);
+    if (m == ncl) break;
+    ncl = m;
+  }
+  // quotient automaton: class of the start state first, the other classes in order of their first member
+  std::vector<int> cid((size_t)ncl, -1), rep_state;
+  int m = 0;
+  cid[(size_t)cls[(size_t)f.start]] = m++; rep_state.push_back(f.start);
+  for (int s = 0; s < n; ++s) if (cid[(size_t)cls[(size_t)s]] < 0) { cid[(size_t)cls[(size_t)s]] = m++; rep_state.push_back(s); }
+  std::vector<int> src;
+  std::vector<HArc> arcs;
+  std::vector<float> fin((size_t)m, FINF);
+  for (int c = 0; c < m; ++c) {
+    const int s = rep_state[(size_t)c];
+    fin[(size_t)c] = quant(f.fin[(size_t)s]);
+    for (int64_t i = f.row[s]; i < f.row[(size_t)s + 1]; ++i) {
+      const HArc& a = f.arcs[(size_t)i];
+      src.push_back(c); arcs.push_back(HArc{a.il, a.ol, aw[(size_t)i], cid[(size_t)cls[(size_t)a.nx]]});
+    }
+  }
+  return from_lists(m, 0, src, arcs, fin);
+}
+
+// ---- OpenFST "vector" / "standard" container (fst/fst.h FstHeader::Write, fst/vector-fst.h VectorFstImpl::Write) ---------------
+extern "C" void* b2t_fst_read_openfst(const char* path) {
+  FILE* fp = path ? fopen(path, "rb") : nullptr;
+  if (!fp) { set_error("fst_read_openfst: cannot open %s", path ? path : "(null)"); return nullptr; }
+  auto fail = [&](const char* why) { fclose(fp); set_error("fst_read_openfst: %s: %s", path, why); return (void*)nullptr; };
+  int32_t magic = 0;
+  if (fread(&magic, 4, 1, fp) != 1 || magic != 2125659606) return fail("not an OpenFST binary");
+  auto rstr = [&](std::string& s) { int32_t n = 0; if (fread(&n, 4, 1, fp) != 1 || n < 0 || n > 4096) return false; s.resize((size_t)n); return n == 0 || fread(&s[0], 1, (size_t)n, fp) == (size_t)n; };
+  std::string ftype, atype;
+  if (!rstr(ftype) || !rstr(atype)) return fail("truncated header");
+  if (ftype != "vector" || atype != "standard") return fail("fst type / arc type not supported (need vector / standard: fstconvert --fst_type=vector)");
+  int32_t version, flags; uint64_t props; int64_t start, ns, na;
+  if (fread(&version, 4, 1, fp) != 1 || fread(&flags, 4, 1, fp) != 1 || fread(&props, 8, 1, fp) != 1 || fread(&start, 8, 1, fp) != 1 ||
+      fread(&ns, 8, 1, fp) != 1 || fread(&na, 8, 1, fp) != 1) return fail("truncated header");
+  if (flags & 3) return fail("embedded symbol tables are not supported (the recipe compiles with --keep_isymbols=false)");
+  if (ns <= 0 || ns > INT32_MAX || start < 0 || start >= ns) return fail("bad state count / start state");
+  HFst* f = new HFst;
+  f->start = (int)start;
+  f->fin.assign((size_t)ns, FINF);
+  f->row.assign((size_t)ns + 1, 0);
+  if (na > 0) f->arcs.reserve((size_t)na);
+  for (int64_t s = 0; s < ns; ++s) {
+    float fw; int64_t n;
+    if (fread(&fw, 4, 1, fp) != 1 || fread(&n, 8, 1, fp) != 1 || n < 0) { delete f; return fail("truncated state"); }
+    f->fin[(size_t)s] = fw;
+    const size_t at = f->arcs.size();
+    f->arcs.resize(at + (size_t)n);
+    static_assert(sizeof(HArc) == 16, "arc record");
+    if (n > 0 && fread(&f->arcs[at], 16, (size_t)n, fp) != (size_t)n) { delete f; return fail("truncated arcs"); }
+    f->row[(size_t)s + 1] = (int64_t)f->arcs.size();
+  }
+  fclose(fp);
+  return f;
+}
+
+extern "C" int b2t_fst_write_openfst(const void* h, const char* path) {
+  B2T_REQUIRE(h && path, "fst_write_openfst: null argument");
+  const HFst& f = *CFST(h);
+  FILE* fp = fopen(path, "wb");
+  B2T_REQUIRE(fp != nullptr, "fst_write_openfst: cannot open %s", path);
+  auto wstr = [&](const char* s) { const int32_t n = (int32_t)strlen(s); fwrite(&n, 4, 1, fp); fwrite(s, 1, (size_t)n, fp); };
+  const int32_t magic = 2125659606, version = 2, flags = 0; const uint64_t props = 0;
+  const int64_t start = f.start, ns = f.n(), na = (int64_t)f.arcs.size();
+  fwrite(&magic, 4, 1, fp); wstr("vector"); wstr("standard");
+  fwrite(&version, 4, 1, fp); fwrite(&flags, 4, 1, fp); fwrite(&props, 8, 1, fp); fwrite(&start, 8, 1, fp); fwrite(&ns, 8, 1, fp); fwrite(&na, 8, 1, fp);
+  for (int64_t s = 0; s < ns; ++s) {
+    const float fw = f.fin[(size_t)s]; const int64_t n = f.row[(size_t)s + 1] - f.row[(size_t)s];
+    fwrite(&fw, 4, 1, fp); fwrite(&n, 8, 1, fp);
+    if (n > 0) fwrite(&f.arcs[(size_t)f.row[(size_t)s]], 16, (size_t)n, fp);
+  }
+  fclose(fp);
+  return 0;
+}
+
+// ---- cost of a word sequence through a grammar (BrainSpeechDecoder::LatticeRescore's composition, brain_speech_decoder.cc:44-58):
+//      arcs carrying `backoff_label` on the input side may be taken freely; cheapest path + final cost.  The grammar must be
+//      arc-sorted by ilabel (b2t_fst_arcsort): a (state, label) lookup is one bisection -------------------------------------------
+extern "C" double b2t_fst_grammar_score(const void* h, const int32_t* words, int n_words, int backoff_label) {
+  if (!h || (n_words > 0 && !words)) { set_error("fst_grammar_score: null argument"); return NAN; }
+  const HFst& f = *CFST(h);
+  auto range = [&](int s, int label, int64_t& lo, int64_t& hi) {
+    const HArc* p0 = f.arcs.data() + f.row[s];
+    const HArc* p1 = f.arcs.data() + f.row[(size_t)s + 1];
+    lo = std::lower_bound(p0, p1, label, [](const HArc& x, int l) { return x.il < l; }) - f.arcs.data();
+    hi = std::upper_bound(p0, p1, label, [](int l, const HArc& x) { return l < x.il; }) - f.arcs.data();
+  };
+  std::unordered_map<int, double> cur, nxt;
+  auto close = [&](std::unordered_map<int, double>& d) {
+    std::vector<int> st;
+    for (auto& kv : d) st.push_back(kv.first);
+    while (!st.empty()) {
+      const int s = st.back(); st.pop_back();
+      const double c = d[s];
+      int64_t lo, hi;
+      range(s, backoff_label, lo, hi);
+      for (int64_t i = lo; i < hi; ++i) {
+        const HArc& a = f.arcs[(size_t)i];
+        auto it = d.find(a.nx);
+        if (it == d.end() || c + a.w < it->second) { d[a.nx] = c + a.w; st.push_back(a.nx); }
+      }
+    }
+  };
+  cur[f.start] = 0.0;
+  close(cur);
+  for (int k = 0; k < n_words; ++k) {
+    nxt.clear();
+    for (auto& kv : cur) {
+      int64_t lo, hi;
+      range(kv.first, words[k], lo, hi);
+      for (int64_t i = lo; i < hi; ++i) {
+        const HArc& a = f.arcs[(size_t)i];
+        auto it = nxt.find(a.nx);
+        if (it == nxt.end() || kv.second + a.w < it->second) nxt[a.nx] = kv.second + a.w;
+      }
+    }
+    if (nxt.empty()) return INFINITY;
+    close(nxt);
+    cur.swap(nxt);
+  }
+  double best = INFINITY;
+  for (auto& kv : cur) if (f.fin[(size_t)kv.first] != FINF) best = std::min(best, kv.second + (double)f.fin[(size_t)kv.first]);
+  return best;
+}

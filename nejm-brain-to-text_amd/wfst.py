@@ -492,3 +492,227 @@ def grammar_score(G: Fst, word_ids: Sequence[int], backoff_label: int):
             return math.inf
         cur = close(nxt)
     return min((c + G.final[s] for s, c in cur.items() if s in G.final), default=math.inf)
+
+
+# ------------------------------------------------------------------------------------------------
+# Native graph compiler (csrc/graphc.cpp through the C ABI): the same algebra on flat arrays, for graphs of the reference's
+# size class, plus the two optimisation passes of make_tlg.sh:43-44 that the Python path above leaves out.
+# ------------------------------------------------------------------------------------------------
+class HostFst:
+    """Handle to a host FST of libb2t_hip.so (b2t_fst_*: CSR arrays in C++).  Operations return new HostFst objects."""
+
+    def __init__(self, handle):
+        if not handle:
+            import b2t_native as N
+            raise RuntimeError("graph compiler: " + N.last_error())
+        self._h = handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                import b2t_native as N
+                N.load().b2t_fst_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _lib():
+        import b2t_native as N
+        return N.load()
+
+    @classmethod
+    def from_arrays(cls, n_states, start, src, il, ol, w, dst, final_cost):
+        import ctypes as C
+        A = [np.ascontiguousarray(x, dtype=t) for x, t in ((src, np.int32), (il, np.int32), (ol, np.int32), (w, np.float32), (dst, np.int32))]
+        fc = np.ascontiguousarray(final_cost, dtype=np.float32)
+        assert fc.shape[0] == n_states
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        return cls(cls._lib().b2t_fst_from_arrays(int(n_states), int(start), len(A[0]), P(A[0]), P(A[1]), P(A[2]), P(A[3]), P(A[4]), P(fc)))
+
+    @classmethod
+    def from_fst(cls, f: Fst):
+        a = np.array(f.arcs, dtype=np.float64).reshape(-1, 5)
+        fc = np.full(f.n, np.inf, np.float32)
+        for s, c in f.final.items():
+            fc[s] = c
+        return cls.from_arrays(f.n, f.start, a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4], fc)
+
+    @classmethod
+    def read_openfst(cls, path: str):
+        return cls(cls._lib().b2t_fst_read_openfst(path.encode()))
+
+    def write_openfst(self, path: str):
+        import b2t_native as N
+        N.check(self._lib().b2t_fst_write_openfst(self._h, path.encode()), "b2t_fst_write_openfst")
+
+    def info(self):
+        import b2t_native as N
+        out = (N.LL * 4)()
+        N.check(self._lib().b2t_fst_info(self._h, out), "b2t_fst_info")
+        return dict(n_states=int(out[0]), n_arcs=int(out[1]), start=int(out[2]), n_final=int(out[3]))
+
+    def arrays(self):
+        """(row int64 [n+1], ilabel, olabel, weight, next, final_cost)"""
+        import ctypes as C
+        import b2t_native as N
+        i = self.info()
+        row = np.zeros(i["n_states"] + 1, np.int64)
+        il, ol, nx = (np.zeros(max(1, i["n_arcs"]), np.int32) for _ in range(3))
+        w = np.zeros(max(1, i["n_arcs"]), np.float32); fc = np.zeros(i["n_states"], np.float32)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        N.check(self._lib().b2t_fst_to_arrays(self._h, P(row), P(il), P(ol), P(w), P(nx), P(fc)), "b2t_fst_to_arrays")
+        n = i["n_arcs"]
+        return row, il[:n], ol[:n], w[:n], nx[:n], fc
+
+    def compose(self, other: "HostFst"):
+        return HostFst(self._lib().b2t_fst_compose(self._h, other._h))
+
+    def trim(self):
+        return HostFst(self._lib().b2t_fst_trim(self._h))
+
+    def determinize_star(self, use_log: bool = True, delta: float = 1.0 / 1024, max_states: int = 0):
+        import ctypes as C
+        return HostFst(self._lib().b2t_fst_determinize_star(self._h, int(use_log), C.c_float(delta), int(max_states)))
+
+    def minimize_encoded(self, delta: float = 1.0 / 1024):
+        import ctypes as C
+        return HostFst(self._lib().b2t_fst_minimize_encoded(self._h, C.c_float(delta)))
+
+    def arcsort(self, by_olabel: bool = False):
+        return HostFst(self._lib().b2t_fst_arcsort(self._h, int(by_olabel)))
+
+    def grammar_score(self, word_ids: Sequence[int], backoff_label: int) -> float:
+        """Needs an ilabel-sorted grammar (arcsort())."""
+        import ctypes as C
+        w = np.ascontiguousarray(word_ids, dtype=np.int32)
+        return float(self._lib().b2t_fst_grammar_score(self._h, w.ctypes.data_as(C.c_void_p), len(w), int(backoff_label)))
+
+    def to_fst(self) -> Fst:
+        row, il, ol, w, nx, fc = self.arrays()
+        f = Fst()
+        f.n, f.start = len(fc), self.info()["start"]
+        src = np.repeat(np.arange(f.n), np.diff(row))
+        f.arcs = [(int(s), int(a), int(b), float(c), int(d)) for s, a, b, c, d in zip(src, il, ol, w, nx)]
+        f.final = {int(s): float(c) for s, c in enumerate(fc) if np.isfinite(c)}
+        return f
+
+    def to_graph(self, words: Sequence[str]) -> "DecodeGraph":
+        """DecodeGraph (CSR for the device) of an ilabel-sorted FST, without going through Python tuples."""
+        row, il, ol, w, nx, fc = self.arrays()
+        g = DecodeGraph.__new__(DecodeGraph)
+        g.n_states, g.n_arcs, g.start = len(fc), len(il), self.info()["start"]
+        if g.n_arcs >= 2 ** 31:
+            raise ValueError("graph too large for 32-bit arc offsets")
+        g.row = row.astype(np.int32)
+        g.ilabel, g.olabel, g.weight, g.next = il, ol, w, nx
+        src = np.repeat(np.arange(g.n_states), np.diff(row))
+        if np.any(np.diff(il.astype(np.int64) + src.astype(np.int64) * (1 << 32)) < 0):
+            raise ValueError("to_graph needs arcs sorted by ilabel within each state (arcsort())")
+        g.n_eps = np.bincount(src[il == 0], minlength=g.n_states).astype(np.int32)
+        g.final = fc
+        g.words = list(words)
+        g._dev = None
+        return g
+
+
+def lex_disambig(prons: Dict[str, Sequence[Sequence[int]]]):
+    """tools/fst/add_lex_disambig.pl: a disambiguation symbol #k (k >= 1) after every pronunciation that is shared by several
+    entries or is a proper prefix of another, numbered per phone sequence.  Returns ({(word, i): k or 0}, max k).  Entries are
+    visited in the order of the sorted word list (the recipe's lexicon is `sort | uniq`-ed)."""
+    count: Dict[Tuple[int, ...], int] = {}
+    issub = set()
+    order = [(w, i, tuple(p)) for w in sorted(prons) for i, p in enumerate(prons[w])]
+    for _, _, p in order:
+        count[p] = count.get(p, 0) + 1
+        for k in range(len(p)):
+            issub.add(p[:k])
+    last: Dict[Tuple[int, ...], int] = {}
+    out, mx = {}, 0
+    for w, i, p in order:
+        if p not in issub and count[p] == 1:
+            out[(w, i)] = 0
+            continue
+        k = last.get(p, 0) + 1
+        last[p] = k
+        mx = max(mx, k)
+        out[(w, i)] = k
+    return out, mx
+
+
+def lexicon_fst_disambig(prons, word_id, sil_prob, sil_token, tok_disambig0, word_disambig0):
+    """L as ctc_compile_dict_token.sh:57-98 builds it: add_lex_disambig.pl, then make_lexicon_fst.pl --pron-probs with optional
+    silence AND the silence disambiguation symbol '#'$ndisambig (make_lexicon_fst.pl:101-152), then fstaddselfloops for #0.
+    Token of #k = tok_disambig0 + k.  Returns (Fst, number of disambiguation tokens incl. #0)."""
+    dis, mx = lex_disambig(prons)
+    ndis = mx + 1                              # '#'$ndisambig with ndisambig = max + 1 is the silence disambiguation symbol
+    f = Fst()
+    silcost, nosilcost = -math.log(sil_prob), -math.log(1.0 - sil_prob)
+    start, loop, sil, disst = f.add_state(), f.add_state(), f.add_state(), f.add_state()
+    f.start = start
+    f.add_arc(start, EPS, EPS, nosilcost, loop)
+    f.add_arc(start, sil_token, EPS, silcost, disst)
+    f.add_arc(sil, sil_token, EPS, 0.0, disst)
+    f.add_arc(disst, tok_disambig0 + ndis, EPS, 0.0, loop)
+    for w in sorted(prons):
+        for i, pron in enumerate(prons[w]):
+            seq = list(pron) + ([tok_disambig0 + dis[(w, i)]] if dis[(w, i)] else [])
+            s, wo = loop, word_id[w]
+            for k, p in enumerate(seq):
+                if k + 1 < len(seq):
+                    ns = f.add_state()
+                    f.add_arc(s, p, wo, 0.0, ns)
+                    wo, s = EPS, ns
+                elif p != sil_token:
+                    f.add_arc(s, p, wo, nosilcost, loop)
+                    f.add_arc(s, p, wo, silcost, sil)
+                else:
+                    f.add_arc(s, p, wo, 0.0, loop)
+    f.final[loop] = 0.0
+    needs = set(f.final)
+    for s, il, ol, w_, d in f.arcs:
+        if ol != EPS:
+            needs.add(s)
+    for s in sorted(needs):
+        f.add_arc(s, tok_disambig0, word_disambig0, 0.0, s)
+    return f, ndis + 1
+
+
+def build_tlg_native(prons: Dict[str, Sequence[Sequence[int]]], arpa_text: str, n_classes: int = 41, sil_prob: float = 0.5,
+                     sil_class: int = 1, optimize: bool = True, stats: dict = None) -> DecodeGraph:
+    """make_tlg.sh:29-46 end to end with the native compiler: L (with lexicon disambiguation symbols) o G, then -- optimize --
+    fstdeterminizestar --use-log=true | fstminimizeencoded, fstarcsort, and T o LG.  `stats` (a dict) receives sizes and times."""
+    import time
+    t0 = time.time()
+    words = sorted(prons)
+    table = ["<eps>"] + words + ["#0", "<s>", "</s>"]
+    word_id = {w: i for i, w in enumerate(table) if 0 < i <= len(words)}
+    wd0 = len(words) + 1
+    n_units = n_classes - 1
+    td0 = n_units + 2
+    tok_prons = {w: [[int(c) + 1 for c in p] for p in ps] for w, ps in prons.items()}
+    Lf, n_dis = lexicon_fst_disambig(tok_prons, word_id, sil_prob, sil_class + 1, td0, wd0)
+    Tf = token_fst(n_units, [td0 + k for k in range(n_dis)])
+    Gf = grammar_fst(arpa_text, word_id, wd0)
+    t1 = time.time()
+    L, T, G = HostFst.from_fst(Lf), HostFst.from_fst(Tf), HostFst.from_fst(Gf).arcsort()
+    LG = L.compose(G)
+    t2 = time.time()
+    raw = LG.info()
+    if optimize:
+        LG = LG.determinize_star(use_log=True)
+        det = LG.info()
+        LG = LG.minimize_encoded()
+    t3 = time.time()
+    opt = LG.info()
+    TLG = T.arcsort(by_olabel=True).compose(LG.arcsort()).trim().arcsort()
+    t4 = time.time()
+    g = TLG.to_graph(table)
+    if np.any(g.ilabel > n_classes):
+        raise AssertionError("a disambiguation token survived as an input label")
+    if stats is not None:
+        stats.update(words=len(words), disambig_tokens=n_dis, L=L.info(), G=G.info(), LG_raw=raw, LG=opt,
+                     LG_determinized=(det if optimize else None), TLG=TLG.info(), tlg_bytes=g.nbytes(),
+                     s_build_LTG_python=round(t1 - t0, 2), s_compose_LG=round(t2 - t1, 2), s_determinize_minimize=round(t3 - t2, 2),
+                     s_compose_TLG=round(t4 - t3, 2), s_total=round(time.time() - t0, 2))
+    return g
