@@ -189,6 +189,19 @@ extern "C" void* b2t_fst_compose(const void* ha, const void* hb) {
     return id;
   };
   if ((uint64_t)b.n() >= (1ull << 32)) { set_error("fst_compose: the right operand has too many states"); return nullptr; }
+  // a's arcs by (state, olabel) with their position in the state's arc list: when the right-hand state has far fewer arcs
+  // than the left-hand one (L's loop state carries two arcs per WORD, a state of G a handful), the labels are matched from
+  // b's side -- what fsttablecompose's table matcher is for; 125 k words x 10^6 grammar states would otherwise be 10^11 probes.
+  // The matches are then emitted in a's arc order, so the result (state numbering included) does not depend on the side.
+  struct AO { int ol; int idx; };
+  std::vector<AO> as(a.arcs.size());
+  std::vector<int> a_nz((size_t)a.n(), 0);
+  for (int s = 0; s < a.n(); ++s) {
+    for (int64_t i = a.row[s]; i < a.row[(size_t)s + 1]; ++i) { as[(size_t)i] = AO{a.arcs[(size_t)i].ol, (int)(i - a.row[s])}; a_nz[(size_t)s] += a.arcs[(size_t)i].ol != 0; }
+    std::stable_sort(as.begin() + a.row[s], as.begin() + a.row[(size_t)s + 1], [](const AO& x, const AO& y) { return x.ol < y.ol; });
+  }
+  struct Ev { int aidx; int64_t j; };          // j >= 0: a's arc aidx matched with b's (sorted) arc j; j = -1: a's arc has an epsilon output
+  std::vector<Ev> ev;
   sid(a.start, b.start, 0);
   for (size_t q = 0; q < keys.size(); ++q) {
     const uint64_t k = keys[q];
@@ -197,24 +210,45 @@ extern "C" void* b2t_fst_compose(const void* ha, const void* hb) {
     if (a.fin[sa] != FINF && b.fin[sb] != FINF) fin[s] = a.fin[sa] + b.fin[sb];
     int64_t e0, e1;
     brange(sb, 0, e0, e1);
-    for (int64_t i = a.row[sa]; i < a.row[(size_t)sa + 1]; ++i) {
-      const HArc& x = a.arcs[(size_t)i];
-      if (x.ol != 0) {
-        int64_t lo, hi;
-        brange(sb, x.ol, lo, hi);
-        for (int64_t j = lo; j < hi; ++j) {
+    const int64_t nb_nz = (b.row[(size_t)sb + 1] - b.row[sb]) - (e1 - e0);
+    auto emit_match = [&](const HArc& x, const HArc& y) {
+      const int d = sid(x.nx, y.nx, 0);
+      src.push_back(s); arcs.push_back(HArc{x.il, y.ol, x.w + y.w, d});
+    };
+    auto emit_a_eps = [&](const HArc& x) {
+      if (fs != 2) { const int d = sid(x.nx, sb, 1); src.push_back(s); arcs.push_back(HArc{x.il, 0, x.w, d}); }
+      if (fs == 0)
+        for (int64_t j = e0; j < e1; ++j) {
           const HArc& y = bs[(size_t)j];
           const int d = sid(x.nx, y.nx, 0);
           src.push_back(s); arcs.push_back(HArc{x.il, y.ol, x.w + y.w, d});
         }
-      } else {
-        if (fs != 2) { const int d = sid(x.nx, sb, 1); src.push_back(s); arcs.push_back(HArc{x.il, 0, x.w, d}); }
-        if (fs == 0)
-          for (int64_t j = e0; j < e1; ++j) {
-            const HArc& y = bs[(size_t)j];
-            const int d = sid(x.nx, y.nx, 0);
-            src.push_back(s); arcs.push_back(HArc{x.il, y.ol, x.w + y.w, d});
-          }
+    };
+    if (nb_nz * 4 < (int64_t)a_nz[(size_t)sa]) {
+      ev.clear();
+      const AO* p0 = as.data() + a.row[sa];
+      const AO* p1 = as.data() + a.row[(size_t)sa + 1];
+      for (const AO* p = p0; p < p1 && p->ol == 0; ++p) ev.push_back(Ev{p->idx, -1});
+      for (int64_t j = e1; j < b.row[(size_t)sb + 1]; ++j) {
+        const int label = bs[(size_t)j].il;
+        const AO* lo = std::lower_bound(p0, p1, label, [](const AO& x, int l) { return x.ol < l; });
+        for (const AO* p = lo; p < p1 && p->ol == label; ++p) ev.push_back(Ev{p->idx, j});
+      }
+      std::sort(ev.begin(), ev.end(), [](const Ev& x, const Ev& y) { return x.aidx != y.aidx ? x.aidx < y.aidx : x.j < y.j; });
+      for (const Ev& e : ev) {
+        const HArc& x = a.arcs[(size_t)(a.row[sa] + e.aidx)];
+        if (e.j < 0) emit_a_eps(x); else emit_match(x, bs[(size_t)e.j]);
+      }
+    } else {
+      for (int64_t i = a.row[sa]; i < a.row[(size_t)sa + 1]; ++i) {
+        const HArc& x = a.arcs[(size_t)i];
+        if (x.ol != 0) {
+          int64_t lo, hi;
+          brange(sb, x.ol, lo, hi);
+          for (int64_t j = lo; j < hi; ++j) emit_match(x, bs[(size_t)j]);
+        } else {
+          emit_a_eps(x);
+        }
       }
     }
     if (fs != 1)

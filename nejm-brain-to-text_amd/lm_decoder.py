@@ -47,8 +47,9 @@ class DecodeResource:
         import wfst
         self.graph = wfst.graph_from_files(fst_path, dict_path) if fst_path else None
         # the grammars used by Rescore(): G.fst (its scores are taken out) and G_no_prune.fst (its scores are put in)
-        self.lm_fst = wfst.read_openfst_vector(lm_fst_path) if lm_fst_path else None
-        self.rescore_lm_fst = wfst.read_openfst_vector(rescore_lm_fst_path) if rescore_lm_fst_path else None
+        # (read and kept as CSR arrays in C++, arc-sorted once: G_no_prune.fst has 10^7-10^9 arcs in the reference's setup)
+        self.lm_fst = wfst.HostFst.read_openfst(lm_fst_path).arcsort() if lm_fst_path else None
+        self.rescore_lm_fst = wfst.HostFst.read_openfst(rescore_lm_fst_path).arcsort() if rescore_lm_fst_path else None
         self.symbols = self._read_table(dict_path) if dict_path else None
         # word id of #0 on the grammars' back-off arcs: eps2disambig.pl rewrites the back-off ilabel <eps> to #0 before
         # fstcompile (make_tlg.sh:35-38), so G.fst / G_no_prune.fst read from files carry words.txt's id of "#0" there;
@@ -70,8 +71,10 @@ class DecodeResource:
             self.backoff_label = graph.words.index("#0")
 
     def set_rescore_grammars(self, lm_fst, rescore_lm_fst, backoff_label):
-        """wfst.Fst grammars for Rescore(): the one composed into the graph and the one to rescore with."""
-        self.lm_fst, self.rescore_lm_fst, self.backoff_label = lm_fst, rescore_lm_fst, backoff_label
+        """Grammars for Rescore() (wfst.Fst or wfst.HostFst): the one composed into the graph and the one to rescore with."""
+        import wfst
+        conv = lambda g: g if isinstance(g, wfst.HostFst) else wfst.HostFst.from_fst(g).arcsort()
+        self.lm_fst, self.rescore_lm_fst, self.backoff_label = conv(lm_fst), conv(rescore_lm_fst), backoff_label
 
     def set_token_lm(self, lm):
         """Attach an ngram_lm.NGramLM over the decoder's output tokens (fused into the prefix beam search)."""
@@ -250,20 +253,23 @@ class BrainSpeechDecoder:
     def Rescore(self):
         """brain_speech_decoder.cc:61-101: take the scores of the grammar that is composed into the graph out of the
         lattice and put the scores of the rescoring grammar in (two lattice compositions in the reference), then list the
-        n-best again.  Here the exchange is done per word sequence on a deep n-best list of the same pruned lattice
+        n-best again.  Here the exchange is done per word sequence on a DEEP n-best list of the same pruned lattice
         (lattice composition with a deterministic-per-sequence grammar changes each sequence's graph cost by exactly
-        G_new(W) - G_old(W)); the list is then re-ranked and cut to the previous length."""
+        G_new(W) - G_old(W)); the list is then re-ranked and cut to the previous length.  An approximation of the
+        reference's lattice composition: a sequence outside the deep list (10 x the requested length, at least 500) cannot
+        be promoted into the result however much the new grammar likes it.  Grammar scores are computed in C++ on CSR
+        arrays (b2t_fst_grammar_score: one bisection per (state, word))."""
         if self.wfst is None:
             raise RuntimeError("Rescore() needs the WFST searcher (load a decode graph)")
         if self.res.lm_fst is None or self.res.rescore_lm_fst is None or self.res.backoff_label is None:
             raise RuntimeError("Rescore() needs both grammars (DecodeResource lm_fst_path / rescore_lm_fst_path or set_rescore_grammars)")
         import wfst
         keep = len(self._result)
-        deep = self.wfst._nbest_all(max(10 * keep, 100))[0]
+        deep = self.wfst._nbest_all(max(10 * keep, 500))[0]
         rescored = []
         for inp, tm, words, lm, ac in deep:
-            g_old = wfst.grammar_score(self.res.lm_fst, words, self.res.backoff_label)
-            g_new = wfst.grammar_score(self.res.rescore_lm_fst, words, self.res.backoff_label)
+            g_old = self.res.lm_fst.grammar_score(words, self.res.backoff_label)
+            g_new = self.res.rescore_lm_fst.grammar_score(words, self.res.backoff_label)
             if not np.isfinite(g_new):
                 continue
             rescored.append((inp, tm, words, lm + g_old - g_new, ac))

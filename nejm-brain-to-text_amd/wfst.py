@@ -449,7 +449,8 @@ def graph_from_files(fst_path: str, dict_path: str) -> DecodeGraph:
         g.words = words or [str(w) for w in z["words"]]
         g._dev = None
         return g
-    return DecodeGraph(read_openfst_vector(fst_path), words)
+    # the OpenFST container is parsed and arc-sorted in C++ (b2t_fst_read_openfst): no Python object per arc
+    return HostFst.read_openfst(fst_path).arcsort().to_graph(words)
 
 
 def save_graph(g: DecodeGraph, path: str):

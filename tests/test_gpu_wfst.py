@@ -156,6 +156,35 @@ def test_wfst_tight_pruning_and_overflow(toy):
         small.finalize()
 
 
+def test_search_on_the_determinised_minimised_graph(toy):
+    """The graph as the reference's recipe leaves it (make_tlg.sh:43-46: L with lexicon disambiguation symbols o G,
+    fstdeterminizestar --use-log, fstminimizeencoded, then T o LG; built by the native compiler, wfst.build_tlg_native): the
+    disambiguation symbols become input-epsilon arcs, so the epsilon closure works harder than on the plain graph.  The HIP
+    search on it equals the oracle on it (20-best lists), and its 1-best equals the plain graph's (same words; costs within
+    the 1/1024-per-arc quantisation of minimize-encoded)."""
+    from wfst_decoder import WfstSearch
+    prons, words, g_plain, arpa = toy
+    st = {}
+    g_opt = wfst.build_tlg_native(prons, arpa, sil_prob=0.5, optimize=True, stats=st)
+    assert g_opt.n_arcs < 0.8 * st["TLG"]["n_arcs"] or st["LG"]["n_states"] < st["LG_raw"]["n_states"]
+    assert int((g_opt.n_eps > 0).sum()) > int((g_plain.n_eps > 0).sum())
+    rs = np.random.RandomState(51)
+    seqs, lps, batch, lens = utterances(prons, words, 4, rs, noise=1.0)
+    o = Opt()
+    out = {}
+    for tag, g in (("opt", g_opt), ("plain", g_plain)):
+        S = WfstSearch(g, o, U=4, max_frames=batch.shape[1] + 8)
+        S.search(torch.from_numpy(batch).cuda(), lens)
+        out[tag] = S.finalize()
+    for u in range(4):
+        R = W.CtcWfstBeamSearch(g_opt, cfg_of(o))
+        R.search(lps[u]); R.finalize_search()
+        compare_lists(out["opt"][u], R, f"optimised graph, utterance {u}")
+        a, b = out["opt"][u][0], out["plain"][u][0]
+        assert [g_opt.words[w] for w in a[2]] == [g_plain.words[w] for w in b[2]], u
+        assert abs((a[3] + a[4]) - (b[3] + b[4])) < 0.05
+
+
 def test_cluster_search_equals_single_workgroup(toy):
     """The search with 2 / 4 / 8 workgroups per utterance (clusters behind one XCD's L2: L2 atomics, sc1 loads, cluster
     barriers) returns what one workgroup per utterance returns: frames, partial best path after every chunk, the 30-best
