@@ -159,3 +159,66 @@ def test_trainer_two_ranks_stop_together(tmp_path):
     np.testing.assert_array_equal(a0, a1)
     assert os.path.exists(os.path.join(str(tmp_path), "out", "checkpoint", "best_checkpoint"))
     assert os.path.exists(os.path.join(str(tmp_path), "out", "training_log"))
+
+
+def _recovery_worker(rank, world, port, tmp, inject, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "nejm-brain-to-text_amd")); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      B2T_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from test_gpu_trainer import make_args
+    from rnn_trainer import BrainToTextDecoder_Trainer
+    args = make_args(os.path.join(tmp, "inj" if inject else "clean"), n_batches=24, patch=(0, 0), dropout=(0.0, 0.0))
+    args.update(batches_per_val_step=10 ** 9, early_stopping=False, batches_per_train_log=1)
+    try:
+        tr = BrainToTextDecoder_Trainer(args)
+        ts = tr.train_step
+        if inject and rank == 1:
+            calls, orig = [0], ts.step
+
+            def step(*a):
+                calls[0] += 1
+                if calls[0] == 5:                   # this rank's 5th step "times out" in a backward sweep (sticky error word)
+                    sync = tr.model._ws.sync(tr.model.n_layers, tr.device)
+                    sync[tr.model.n_layers + 1, 0] = 1
+                return orig(*a)
+            ts.step = step
+        st = tr.train()
+        q.put((rank, len(st['train_losses']), st['train_losses'], ts.it, bool(ts.reducer.deferred), tr.model.arena().cpu().numpy(),
+               ts.seg_step.cpu().numpy()))
+    except BaseException as e:
+        q.put((rank, "error", repr(e)))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_refused_step_is_rank_consistent_and_recovered(tmp_path):
+    """A hand-off timeout on ONE rank: the status word is MAX-reduced before
+    AdamW, so both ranks refuse the step -- parameters, moments and step counters stay in lockstep --; the trainer then switches
+    the reducer to all-reduce after the backward pass, clears the refusal and re-runs the refused steps.  The run ends with
+    the parameters, the step counters and the losses of a run in which nothing happened."""
+    out = {}
+    for inject in (False, True):
+        world, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_recovery_worker, args=(r, world, port, str(tmp_path), inject, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted((q.get(timeout=200) for _ in range(world)), key=lambda r: r[0])
+        assert not any(r[1] == "error" for r in res), res
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        out[inject] = res
+    (c0, c1), (i0, i1) = out[False], out[True]
+    assert c0[1] == c1[1] == i0[1] == i1[1] == 12 and c0[3] == i0[3] == i1[3] == 12          # 24 batches / 2 ranks, every step accepted once
+    assert not c0[4] and not c1[4] and i0[4] and i1[4]                                     # both ranks switched to the deferred reducer
+    np.testing.assert_array_equal(i0[5], i1[5])                                            # replicas in lockstep
+    np.testing.assert_array_equal(i0[6], i1[6]); np.testing.assert_array_equal(i0[6], c0[6])
+    np.testing.assert_allclose(i0[5], c0[5], atol=1e-6)                                    # and equal to the clean run
+    np.testing.assert_allclose(i0[2], c0[2], rtol=1e-5); np.testing.assert_allclose(i1[2], c1[2], rtol=1e-5)

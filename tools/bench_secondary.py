@@ -31,6 +31,31 @@ ARGS = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=120000, lr_warmup_steps=
             epsilon=0.1, weight_decay=0.001, weight_decay_day=0, grad_norm_clip_value=10)
 
 
+def step_model(B, T, F, H, L, C, S, patch, stride, n_active_params, act_bytes=4):
+    """SURVEY 8(d)'s byte / FLOP model of one training step, generalised from its C2 paragraph (activations act_bytes each,
+    parameters / optimizer / CTC 4 B): returns (algorithmic bytes, FLOPs)."""
+    Tp = (T - patch) // stride + 1 if patch > 0 else T
+    BT, BTp = B * T, B * Tp
+    in0 = patch * F if patch > 0 else F
+    a = act_bytes
+    by = 2 * BT * F * 4                                      # fused augment + smooth (fp32 features in, fp32 out)
+    by += BT * F * (4 + a)                                   # day layer + softsign: read, write
+    fl = 2.0 * BT * F * F
+    for l in range(L):
+        In = in0 if l == 0 else H
+        by += BTp * (In + 3 * H) * a                         # input projection: R In, W 3H
+        by += BTp * (3 * H + H + 4 * H) * a                  # sweep: R 3H, W H, W 4H (reserve)
+        by += BTp * (6 * H + 4 * H) * a                      # backward sweep: R (H + 4H + H), W 4H
+        by += BTp * ((3 * H + H) + (3 * H + In) + (3 * H + In)) * a      # dW_hh, dW_ih, dX operands / results
+        fl += 3 * (2.0 * BTp * In * 3 * H + 2.0 * BTp * H * 3 * H)      # projections + recurrent products, forward + 2x backward
+    by += BTp * (H * a + C * 4) + BTp * (C + 2 * S + 1) * 4  # head, CTC alpha
+    by += BTp * (2 * C + 2 * S + 1) * 4 + BTp * ((C + H) + H) * a
+    by += 3 * BT * F * a                                     # day-layer backward
+    by += n_active_params * 10 * 4                           # clip + AdamW: 6 reads + 4 writes
+    fl += 3 * 2.0 * BTp * H * C + 2 * 2.0 * BT * F * F
+    return float(by), float(fl)
+
+
 def train_ms(shape: str, amp: bool, steps: int = 8, warmup: int = 3):
     dev = torch.device("cuda:0")
     B, T, F, C, D, S = 64, 500, 512, 41, 45, 60
@@ -66,8 +91,17 @@ def train_ms(shape: str, amp: bool, steps: int = 8, warmup: int = 3):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
         ts.check_status()
         assert np.isfinite(float(loss))
+        H = 768 if shape == "c3" else 512
+        n_act = sum(int(p.numel()) for n_, p in m.named_parameters() if "day_" not in n_) + 4 * (F * F + F)
+        by, fl = step_model(B, T, F, H, 5, C, 60, 14 if shape == "c3" else 0, 4 if shape == "c3" else 0, n_act)
+        peak = 2516.6e12 if amp else 157.3e12                # MI355X_MICROARCH.md: dense bf16 / fp32-input MFMA
+        roof = dict(bound="mfma" if not amp else "hbm", step_flops=round(fl / 1e12, 3), step_algorithmic_gb=round(by / 1e9, 2),
+                    mfma_peak_tflops=round(peak / 1e12, 1), mfma_frac=round(fl / dt / peak, 4), hbm_frac=round(by / dt / 8.0e12, 4),
+                    note=("tensors in HBM are fp32 in this mode too (operands are rounded to bf16 on their way to the matrix cores): "
+                          "the byte model is the fp32 one" if amp else "SURVEY 8(d)'s byte / FLOP model at this shape"))
         return dict(ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1), workload=what + ", full training step",
-                    dtype="bf16 matmul + recurrent-product operands, f32 accumulate / gates / CTC / optimizer" if amp else "f32")
+                    dtype="bf16 matmul + recurrent-product operands, f32 accumulate / gates / CTC / optimizer" if amp else "f32",
+                    roofline=roof)
     finally:
         ops.set_amp(old)
 
