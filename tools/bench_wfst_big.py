@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""WFST search on a graph of the reference's vocabulary size: 125,078 words (the size of the
+reference's words.txt) x synthetic word 3-gram (1 M bigrams + 1 M trigrams), compiled on this host by the native compiler
+(tools/bench_graph_build.py: L o G, determinize-star, minimize-encoded, T o LG) and searched on one MI355X with the
+production options: 32 utterances offline (clusters of 8 workgroups), and frame-by-frame streaming."""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "nejm-brain-to-text_amd"), ROOT, os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+import b2t_native as N               # noqa: E402
+import bench_graph_build as GB       # noqa: E402
+import bench_wfst as BW              # noqa: E402
+from wfst_decoder import WfstSearch  # noqa: E402
+
+
+def run(n_words=125078, n_grams=1000000, U=32):
+    lib = N.load(); dev = torch.device("cuda:0")
+    prons, words, arpa, g, st = GB.build(n_words, n_grams, optimize=True)
+    _, _, _, _, seqs, logits, lens, _ = BW.make(U=U, seed=0, noise=0.9, graph=(prons, words, arpa, g), truth="lm", blank_boost=math.log(90.0))
+    _, _, lp = BW._logp(logits, dev, lib)
+    T = logits.shape[1]
+    t0 = time.perf_counter(); g.to_device(dev); torch.cuda.synchronize(); up_s = time.perf_counter() - t0
+    S = WfstSearch(g, BW.Opt, U=U, max_frames=T + 8, max_tokens=1 << 21, max_links=1 << 23, prune_interval=25, prune_min_fill=0.5)
+    ts = []
+    for rep in range(3):
+        S.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        S.search(lp, lens); torch.cuda.synchronize(); t1 = time.perf_counter()
+        mem = S.memory_stats()
+        fin = S.finalize(); t2 = time.perf_counter()
+        ts.append((t1 - t0, t2 - t1))
+    frames = sum(S.frames_decoded())
+    created = sum(m["created_tokens"] for m in mem)
+    wfst_1 = [[g.words[w] for w in f[0][2]] if f else [] for f in fin]
+    wer = sum(BW.edit(h, r) for h, r in zip(wfst_1, seqs)) / sum(len(r) for r in seqs)
+    Ss = WfstSearch(g, BW.Opt, U=U, max_frames=T + 8, max_tokens=1 << 20, max_links=1 << 22, prune_interval=25)
+    lat = []
+    for t in range(T):
+        fr = lp[:, t:t + 1].contiguous()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        Ss.search(fr, np.minimum(1, np.maximum(0, lens - t)).astype(np.int32)); Ss.best_path(False, max_len=2 * T + 8)
+        lat.append(time.perf_counter() - t0)
+    lat = np.array(lat[5:]) * 1e3
+    return dict(build=st, upload_s=round(up_s, 2), hbm_graph_gb=round(g.nbytes() / 1e9, 3),
+                offline=dict(utterances=U, frames_max=int(T), search_ms=round(min(t[0] for t in ts) * 1e3, 2),
+                             finalize_nbest100_ms=round(min(t[1] for t in ts) * 1e3, 2),
+                             search_ms_per_frame_all_utterances=round(min(t[0] for t in ts) * 1e3 / T, 3),
+                             tokens_per_frame=round(created / frames, 1), wer_vs_truth=round(wer, 4)),
+                streaming=dict(p50_ms_per_frame=round(float(np.percentile(lat, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat, 95)), 3)))
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:]]
+    print(json.dumps(run(*a), indent=1))
