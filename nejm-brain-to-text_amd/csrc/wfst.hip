@@ -54,8 +54,8 @@ struct Hdr {
 
 // Scratch of the CLUSTER search (several workgroups per utterance, wfst_cluster_kernel below): every word is written with L2
 // atomics or plain stores and read with L1-bypassing (sc1) loads by the workgroups of one cluster, which share an XCD's L2.
-constexpr int WLG_CAP = 1 << 16;   // epsilon work list of a frame (tokens whose state has input-epsilon arcs)
-constexpr int HEAVY_CAP = 1 << 14; // heavy-token list of a frame
+constexpr int WLG_CAP = 1 << 19;   // epsilon work list of a frame (tokens whose state has input-epsilon arcs; 125 k-word graphs put > 65 k of them into peak frames)
+constexpr int HEAVY_CAP = 1 << 17; // heavy-token list of a frame
 constexpr int HEAVY_DEG = 32;
 struct Clu {
   unsigned bar, bar_base; int pad0[14];          // cluster barrier: monotonic arrival counter, its value when the last launch ended

@@ -52,8 +52,11 @@ class WfstSearch:
         self._keep = d
         self.cg = N.WfstGraph(d["row"].data_ptr(), d["ilabel"].data_ptr(), d["olabel"].data_ptr(), d["weight"].data_ptr(),
                               d["next"].data_ptr(), d["n_eps"].data_ptr(), d["final"].data_ptr(), graph.n_states, graph.start)
-        if hash_size <= 0:   # a frame can hold at most one token per graph state
-            hash_size = max(1024, min(1 << 16, _pow2_at_least(2 * min(graph.n_states, 1 << 15))))
+        if hash_size <= 0:
+            # a frame can hold at most one token per graph state; graphs of the reference's size class (10^6+ states) put
+            # 10-30 k tokens into a frame with the production beam: 2^18 slots keep the linear probing short there
+            cap = 1 << 18 if graph.n_states > 500000 else 1 << 16
+            hash_size = max(1024, min(cap, _pow2_at_least(2 * min(graph.n_states, cap // 2))))
         self.caps = (int(max_frames), int(max_tokens), int(max_links), int(hash_size))
         # LatticeFasterDecoderConfig::prune_interval / prune_scale (lattice-faster-decoder.h:62-72): PruneActiveTokens every
         # prune_interval frames; 0 = never (everything is pruned once, in finalize -- same lattice, more memory)
@@ -161,7 +164,7 @@ class WfstSearch:
             if bits & 32:
                 raise RuntimeError("WFST cluster search: a cluster barrier timed out (a workgroup of the cluster was not resident: "
                                    "is another kernel holding CUs?); results are invalid -- reset() and retry, or B2T_WFST_CLUSTER=1")
-            what = [n for b, n in ((1, "max_tokens"), (2, "max_links"), (4, "hash_size"), (8, "max_frames"), (16, "epsilon work list (65536)")) if bits & b]
+            what = [n for b, n in ((1, "max_tokens"), (2, "max_links"), (4, "hash_size"), (8, "max_frames"), (16, "epsilon work list / heavy-token list of a frame (524288 / 131072)")) if bits & b]
             raise RuntimeError(f"WFST search: a capacity was exhausted ({', '.join(what)} of {self.caps}; peak tokens "
                                f"{int(h[:, 1].max())}, links {int(h[:, 2].max())}); results are invalid -- construct WfstSearch "
                                "with larger capacities")
