@@ -541,6 +541,9 @@ class HostFst:
 
     @classmethod
     def read_openfst(cls, path: str):
+        import os
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
         return cls(cls._lib().b2t_fst_read_openfst(path.encode()))
 
     def write_openfst(self, path: str):
