@@ -33,6 +33,13 @@ def _host_threads() -> int:
         return max(1, os.cpu_count() or 1)
 
 
+def _pool_threads() -> int:
+    """Threads of the n-best pool: a quarter of the usable cores stays free for the thread that drives the GPU (with every
+    core busy in b2t_lattice_nbest_host the next batch's launches and copies crawl: measured 67 vs 43 ms per pipelined batch)."""
+    n = _host_threads()
+    return max(1, n - max(1, n // 4)) if not os.environ.get("B2T_HOST_THREADS") else n
+
+
 def _pow2_at_least(n: int) -> int:
     p = 1
     while p < n:
@@ -203,7 +210,7 @@ class WfstSearch:
         cn, host = self._lattices()
         mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
         if WfstSearch._pool is None:
-            WfstSearch._pool = ThreadPoolExecutor(max_workers=_host_threads())
+            WfstSearch._pool = ThreadPoolExecutor(max_workers=_pool_threads())
         nbest = self.nbest
 
         def job():
@@ -231,9 +238,14 @@ class WfstSearch:
             if not cn[:, 4].any():
                 break
             cap_arcs, cap_final = cap_arcs * 4, cap_final * 4      # a lattice did not fit: retry with more room
-        na = int(cn[:, 1].max()); nf = int(cn[:, 2].max())
-        host = [t[:, :max(na, 1)].cpu().numpy() for t in ia + fa] + [fs[:, :max(nf, 1)].cpu().numpy(), fc[:, :max(nf, 1)].cpu().numpy()]
-        return cn, host
+        # ONE compact copy: the utterances' arcs back to back (the slabs are U x cap_arcs, of which a few per cent are used:
+        # copying U x max-arcs rows moved 134 MB for 29 MB of lattice and was most of finalize's GPU half)
+        n_arc = torch.from_numpy(cn[:, 1].astype(np.int64)).to(dev); n_fin = torch.from_numpy(cn[:, 2].astype(np.int64)).to(dev)
+        ia_idx = torch.nonzero((torch.arange(cap_arcs, device=dev)[None, :] < n_arc[:, None]).flatten()).flatten()
+        fa_idx = torch.nonzero((torch.arange(cap_final, device=dev)[None, :] < n_fin[:, None]).flatten()).flatten()
+        flat = [t.flatten()[ia_idx].cpu().numpy() for t in ia + fa] + [fs.flatten()[fa_idx].cpu().numpy(), fc.flatten()[fa_idx].cpu().numpy()]
+        a_off = np.concatenate([[0], np.cumsum(cn[:, 1].astype(np.int64))]); f_off = np.concatenate([[0], np.cumsum(cn[:, 2].astype(np.int64))])
+        return cn, (flat, a_off, f_off)
 
     def _nbest_all(self, nbest: int):
         hdr = self._header()
@@ -243,7 +255,7 @@ class WfstSearch:
 
     def _nbest_host(self, nbest, hdr, cn, host, mapping_all):
         """Host half of FinalizeSearch: nothing here touches the device or this object's state block."""
-        src, dst, il, ol, gr, ac, fs, fc = host
+        (src, dst, il, ol, gr, ac, fs, fc), a_off, f_off = host
         P = lambda x: x.ctypes.data_as(C.c_void_p)
 
         def one(u):
@@ -251,8 +263,8 @@ class WfstSearch:
             n_states, n_arcs, n_final, start = (int(v) for v in cn[u, :4])
             if F == 0 or n_states == 0 or start < 0:
                 return []
-            a = [np.ascontiguousarray(x[u, :n_arcs]) for x in (src, dst, il, ol, gr, ac)]
-            f_s, f_c = np.ascontiguousarray(fs[u, :n_final]), np.ascontiguousarray(fc[u, :n_final])
+            a = [np.ascontiguousarray(x[a_off[u]:a_off[u] + n_arcs]) for x in (src, dst, il, ol, gr, ac)]
+            f_s, f_c = np.ascontiguousarray(fs[f_off[u]:f_off[u] + n_final]), np.ascontiguousarray(fc[f_off[u]:f_off[u] + n_final])
             w_cap = a_cap = nbest * (2 * F + 16) + 16
             ow = np.zeros(w_cap, dtype=np.int32); oa = np.zeros(a_cap, dtype=np.int32)
             woff = np.zeros(nbest + 1, dtype=np.int32); aoff = np.zeros(nbest + 1, dtype=np.int32); costs = np.zeros(2 * nbest, dtype=np.float32)
@@ -270,7 +282,7 @@ class WfstSearch:
         if workers <= 1:
             return [one(u) for u in range(self.U)]
         if WfstSearch._pool is None:
-            WfstSearch._pool = ThreadPoolExecutor(max_workers=_host_threads())
+            WfstSearch._pool = ThreadPoolExecutor(max_workers=_pool_threads())
         return list(WfstSearch._pool.map(one, range(self.U)))
 
     def _nbest_of(self, u, h, nbest=None):
