@@ -1576,6 +1576,30 @@ extern "C" int b2t_wfst_reset(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* 
 
 // Workgroups per utterance of the search: the largest of 8 / 4 / 2 / 1 that keeps every cluster resident (one 1024-thread
 // workgroup per CU, 256 CUs); B2T_WFST_CLUSTER overrides (1 = the single-workgroup kernel with its LDS hash).
+// The clusters assume what the hardware does in this partition mode: workgroup b of a launch runs on XCD b % 8.  Probed once
+// per process (256 one-wave workgroups report their XCC_ID): if blocks with equal b % 8 do not share an XCD, or the eight
+// classes are not on eight different XCDs, the search falls back to one workgroup per utterance.  (The kernel checks again,
+// per launch, and refuses to decode on a mismatch.)
+__global__ void wfst_xcd_probe_kernel(unsigned* out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_of(); }
+static bool wfst_xcd_roundrobin_ok() {
+  static int ok = -1;
+  if (ok >= 0) return ok == 1;
+  ok = 0;
+  unsigned* d = nullptr;
+  unsigned h[256];
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  hipLaunchKernelGGL(wfst_xcd_probe_kernel, dim3(256), dim3(64), 0, nullptr, d);
+  const bool copied = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!copied) { (void)hipGetLastError(); return false; }
+  unsigned seen = 0;
+  for (int i = 0; i < 256; ++i) if (h[i] > 7u || h[i] != h[i & 7]) return false;
+  for (int i = 0; i < 8; ++i) seen |= 1u << h[i];
+  if (seen != 0xffu) return false;
+  ok = 1;
+  return true;
+}
+
 static int g_cluster_override = 0;
 extern "C" int b2t_wfst_set_cluster(int G) { g_cluster_override = G < 0 ? 0 : G; return 0; }   // 0 = automatic
 extern "C" int b2t_wfst_cluster_size(int U) {
@@ -1583,7 +1607,7 @@ extern "C" int b2t_wfst_cluster_size(int U) {
   const int forced = g_cluster_override ? g_cluster_override : env;
   if (forced >= 1) return forced >= 8 ? 8 : forced >= 4 ? 4 : forced >= 2 ? 2 : 1;
   const int slots = 256;
-  for (int G = 8; G > 1; G >>= 1) if ((U + 7) / 8 * 8 * G <= slots) return G;
+  for (int G = 8; G > 1; G >>= 1) if ((U + 7) / 8 * 8 * G <= slots) return wfst_xcd_roundrobin_ok() ? G : 1;
   return 1;
 }
 
