@@ -210,15 +210,19 @@ class BoxSampler:
         return dict(pci=self.bus, sysfs_card_found=self.matched, sclk_mhz_p50=med(0), mclk_mhz_p50=med(1), board_w_p50=med(2), samples=len(self.rows))
 
 
+def free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
 def spawn_ranks(a, argv):
     """`python bench.py --gpus N` without a launcher (the driver's form): start the N ranks here, one process per GPU,
     rendezvous on 127.0.0.1 and a free port.  Rank 0's stdout (the one JSON line) passes through; a rank that dies takes
     the others down (exact PIDs) and its exit code becomes ours."""
-    import socket
     import subprocess
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
+    port = free_port()
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
@@ -303,8 +307,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     import torch.distributed as dist
-    if world > 1:
+    force_dp = os.environ.get("B2T_DP_FORCE", "0") == "1"     # one-rank group that still runs every collective (RCCL path on a 1-GPU box)
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
@@ -327,7 +335,7 @@ def main():
         rows = B
         x, days, labels, nts, lens = make_batch(1000 + rank, dev)
         cut_rng = np.random.RandomState(1 + rank)
-    world_seen = dist.get_world_size() if world > 1 else 1
+    world_seen = dist.get_world_size() if dist.is_initialized() else 1
 
     def step(i):
         cut = int(cut_rng.randint(0, 3))          # rnn_trainer.py:468-471
@@ -336,7 +344,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -374,7 +382,7 @@ def main():
         ts.stat.zero_()
         loss, dt, t_enq = timed_run()
     box = sampler.stop() if sampler else None
-    if world > 1:
+    if world > 1 or force_dp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -433,7 +441,7 @@ def main():
                                global_batch=rows * world, rows_per_rank=rows, seq_len=T, parallelism=f"dp{world}",
                                world_size_seen=world_seen, collective=("RCCL all-reduce, bucketed, overlapped with backward"
                                                                        + (" (deferred after a refused step)" if getattr(ts.reducer, "deferred", False) else "")
-                                                                       if world > 1 else None),
+                                                                       if ts.reducer is not None else None),
                                gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
                                time_chunks_bwd=ops.PIPELINE["chunks_bwd"] or ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),
@@ -448,7 +456,7 @@ def main():
             sys.stderr.write("[bench] cpu baseline ...\n"); sys.stderr.flush()
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -84,6 +85,10 @@ class GradReducer:
         self.buckets = {n: (a, b) for n, a, b in buckets}
         self.pending = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # B2T_DP_FORCE=1: run every collective even in a one-rank group (identity results).  A one-GPU box can then take the
+        # whole RCCL path -- communicator set-up, bucket all-reduces hooked from the executor's streams, the MAX-reduced status
+        # word -- which a two-rank test cannot (RCCL refuses two ranks on one device): tests/test_gpu_dp_procs.py.
+        self.force = os.environ.get("B2T_DP_FORCE", "0") == "1"
         # deferred = True: buckets are only noted while the backward runs and all-reduced in finish(), i.e. AFTER the last
         # backward kernel is enqueued -- no collective kernel then competes with resident persistent sweeps for CUs.  The
         # fallback a trainer / bench switches to when a step was refused with a hand-off timeout (status 1).
@@ -96,7 +101,7 @@ class GradReducer:
                                                  async_op=True))
 
     def launch(self, name: str):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.deferred:
             self._noted.append(name)
@@ -114,13 +119,13 @@ class GradReducer:
     def union_status(self, status: torch.Tensor):
         """status word = max over ranks: a step one rank refuses (hand-off timeout) is refused by every rank, and every
         rank raises at its next read instead of one raising while the others block in the next collective."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.all_reduce(status, op=self.dist.ReduceOp.MAX, group=self.group)
         return status
 
     def union_active(self, active: torch.Tensor):
         """active[seg] = max over ranks (a day tensor is updated if ANY rank saw that day)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.dist.all_reduce(active, op=self.dist.ReduceOp.MAX, group=self.group)
         return active
 
@@ -169,7 +174,7 @@ class TrainStep:
         # (tests/test_gpu_trainer.py) runs the shards of several "ranks" one after the other and sums their arenas itself
         self.world = int(world) if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.reducer = (GradReducer(self.grad_arena, bucket_spans(lay, model.n_layers), group)
-                        if (self.world > 1 and dist.is_initialized()) else None)
+                        if ((self.world > 1 or os.environ.get("B2T_DP_FORCE", "0") == "1") and dist.is_initialized()) else None)
         self.day_range = None
         if self.world > 1:
             b = dict((n, (a, e)) for n, a, e in bucket_spans(lay, model.n_layers))

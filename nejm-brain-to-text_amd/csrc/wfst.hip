@@ -3,9 +3,14 @@
 // :839-909, GetCutoff :650-720, FindOrAddToken :250-295, PruneForwardLinks(Final) :297-470) under the frame loop of
 // CtcWfstBeamSearch::Search (language_model/runtime/core/decoder/ctc_wfst_beam_search.cc:70-121).
 //
-// One workgroup per utterance; the decode graph (T o L o G as CSR arcs: nejm-brain-to-text_amd/wfst.py) lives in HBM and is
-// shared by all utterances; a frame's token hash (state -> token) lives in LDS when it fits (<= 16384 slots = 128 KB), tokens and
-// forward links of every frame are appended to the utterance's state block in HBM (they ARE the lattice).
+// Two searchers with identical results (tests/test_gpu_wfst.py::test_cluster_search_equals_single_workgroup):
+//   * wfst_search_kernel: one workgroup per utterance; a frame's token hash (state -> token) lives in LDS when it fits
+//     (<= 16384 slots = 128 KB);
+//   * wfst_cluster_kernel (the default when the XCD round-robin probe passes): 8 workgroups per utterance placed on one
+//     XCD, sharing the frame through that XCD's L2 (hash, work lists, counters in HBM-backed scratch read with L1-bypassing
+//     loads), a monotonic L2 counter as the cluster barrier.
+// The decode graph (T o L o G as CSR arcs: nejm-brain-to-text_amd/wfst.py, csrc/graphc.cpp) lives in HBM and is shared by all
+// utterances; tokens and forward links of every frame are appended to the utterance's state block in HBM (they ARE the lattice).
 //
 // What is data-parallel here and sequential in the reference:
 //   * ProcessEmitting tightens `next_cutoff` while it walks the token list, so which over-the-cutoff dead-end tokens get
@@ -17,7 +22,8 @@
 //   * ProcessNonemitting's work queue becomes Bellman-Ford sweeps over the frame's tokens until no cost changes; forward
 //     links are generated once, after convergence, with the final costs (what the queue leaves behind).
 //   * PruneActiveTokens every prune_interval frames is a memory optimisation (it only removes what FinalizeDecoding would
-//     remove as well: its extra_costs are lower bounds); here pruning runs once, in b2t_wfst_finalize.
+//     remove as well: its extra_costs are lower bounds), so it is a pass of its own between search calls (wfst_prune_kernel,
+//     b2t_wfst_prune) that shares prune_frame() with b2t_wfst_finalize; n-best lists are bit-identical with and without it.
 #include <float.h>
 #include "common.h"
 

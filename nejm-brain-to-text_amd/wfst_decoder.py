@@ -227,24 +227,38 @@ class WfstSearch:
         U, dev = self.U, self.device
         while True:
             counts = torch.zeros((U, 5), dtype=torch.int32, device=dev)
-            ia = [torch.empty((U, cap_arcs), dtype=torch.int32, device=dev) for _ in range(4)]
-            fa = [torch.empty((U, cap_arcs), dtype=torch.float32, device=dev) for _ in range(2)]
-            fs = torch.empty((U, cap_final), dtype=torch.int32, device=dev); fc = torch.empty((U, cap_final), dtype=torch.float32, device=dev)
+            arcs = torch.empty((6, U, cap_arcs), dtype=torch.int32, device=dev)      # src, dst, ilabel, olabel | graph, acoustic (fp32 bits)
+            fins = torch.empty((2, U, cap_final), dtype=torch.int32, device=dev)     # final state | final cost (fp32 bits)
             with torch.cuda.device(dev):
                 N.check(self.lib.b2t_wfst_lattice(C.byref(self.cg), C.byref(self.co), ops._p(self.state), U, cap_arcs, cap_final,
-                                                  ops._p(counts), ops._p(ia[0]), ops._p(ia[1]), ops._p(ia[2]), ops._p(ia[3]), ops._p(fa[0]),
-                                                  ops._p(fa[1]), ops._p(fs), ops._p(fc), self._s()), "b2t_wfst_lattice")
+                                                  ops._p(counts), ops._p(arcs[0]), ops._p(arcs[1]), ops._p(arcs[2]), ops._p(arcs[3]),
+                                                  ops._p(arcs[4]), ops._p(arcs[5]), ops._p(fins[0]), ops._p(fins[1]), self._s()),
+                        "b2t_wfst_lattice")
             cn = counts.cpu().numpy()
             if not cn[:, 4].any():
                 break
             cap_arcs, cap_final = cap_arcs * 4, cap_final * 4      # a lattice did not fit: retry with more room
         # ONE compact copy: the utterances' arcs back to back (the slabs are U x cap_arcs, of which a few per cent are used:
-        # copying U x max-arcs rows moved 134 MB for 29 MB of lattice and was most of finalize's GPU half)
-        n_arc = torch.from_numpy(cn[:, 1].astype(np.int64)).to(dev); n_fin = torch.from_numpy(cn[:, 2].astype(np.int64)).to(dev)
-        ia_idx = torch.nonzero((torch.arange(cap_arcs, device=dev)[None, :] < n_arc[:, None]).flatten()).flatten()
-        fa_idx = torch.nonzero((torch.arange(cap_final, device=dev)[None, :] < n_fin[:, None]).flatten()).flatten()
-        flat = [t.flatten()[ia_idx].cpu().numpy() for t in ia + fa] + [fs.flatten()[fa_idx].cpu().numpy(), fc.flatten()[fa_idx].cpu().numpy()]
+        # copying U x max-arcs rows moved 134 MB for 29 MB of lattice and was most of finalize's GPU half).  One gather for
+        # the six arc arrays and one for the finals, indices from the counts already on the host (no data-dependent sizes on
+        # the device), one copy each into pinned memory.
         a_off = np.concatenate([[0], np.cumsum(cn[:, 1].astype(np.int64))]); f_off = np.concatenate([[0], np.cumsum(cn[:, 2].astype(np.int64))])
+
+        def compact(slab, cap, off):
+            tot = int(off[-1])
+            if tot == 0:
+                return np.zeros((slab.shape[0], 0), dtype=np.int32)
+            n = torch.from_numpy(np.diff(off)).to(dev, non_blocking=True)
+            base = torch.from_numpy(np.arange(U, dtype=np.int64) * cap - off[:-1]).to(dev, non_blocking=True)
+            idx = torch.arange(tot, device=dev) + torch.repeat_interleave(base, n, output_size=tot)
+            host = torch.empty((slab.shape[0], tot), dtype=torch.int32, pin_memory=True)
+            host.copy_(slab.view(slab.shape[0], -1).index_select(1, idx), non_blocking=True)
+            return host
+
+        ha, hf = compact(arcs, cap_arcs, a_off), compact(fins, cap_final, f_off)
+        torch.cuda.current_stream(dev).synchronize()
+        ha, hf = (x.numpy() if isinstance(x, torch.Tensor) else x for x in (ha, hf))
+        flat = [ha[0], ha[1], ha[2], ha[3], ha[4].view(np.float32), ha[5].view(np.float32), hf[0], hf[1].view(np.float32)]
         return cn, (flat, a_off, f_off)
 
     def _nbest_all(self, nbest: int):

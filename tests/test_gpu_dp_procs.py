@@ -222,3 +222,29 @@ def test_refused_step_is_rank_consistent_and_recovered(tmp_path):
     np.testing.assert_array_equal(i0[6], i1[6]); np.testing.assert_array_equal(i0[6], c0[6])
     np.testing.assert_allclose(i0[5], c0[5], atol=1e-6)                                    # and equal to the clean run
     np.testing.assert_allclose(i0[2], c0[2], rtol=1e-5); np.testing.assert_allclose(i1[2], c1[2], rtol=1e-5)
+
+
+def test_rccl_path_on_one_rank():
+    """The collectives of the data-parallel step through RCCL itself (backend "nccl"), which the two-rank tests above cannot
+    use (RCCL refuses two ranks on one device, so they run gloo): `bench.py` in a one-rank group with B2T_DP_FORCE=1 sets up
+    the communicator and runs every bucket all-reduce from the executor's streams, the MAX-reduced day flags and status word and
+    the barriers of the timed region.  With one rank every collective is the identity: the loss must equal the plain run's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"]
+
+    def run(extra_env):
+        env = dict(os.environ, **extra_env)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    plain = run({})
+    forced = run({"B2T_DP_FORCE": "1"})
+    assert plain["config"]["collective"] is None
+    assert forced["config"]["collective"].startswith("RCCL all-reduce")
+    assert forced["config"]["world_size_seen"] == 1 and forced["n_gpus"] == 1
+    assert forced["final_loss"] == plain["final_loss"]
