@@ -240,7 +240,9 @@ def test_rccl_path_on_one_rank():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+        return json.loads(lines[0])
 
     plain = run({})
     forced = run({"B2T_DP_FORCE": "1"})
