@@ -482,6 +482,13 @@ int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const int32_t* s
                            int n_final, const int32_t* final_state, const float* final_cost, int nbest, float beam,
                            int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
                            float* costs);
+/* HOST function: CtcWfstBeamSearch::ConvertToInputs (ctc_wfst_beam_search.cc:162-188) for the n alignments
+ * ali[a_off[k] .. a_off[k+1]) that b2t_lattice_nbest_host returned: blanks (ilabel 1) dropped, repeats merged, ilabel - 1;
+ * the time of a unit is the frame of its LAST repeated label -- mapping[position] (decoded frame -> input frame, F entries)
+ * when the alignment covers all F decoded frames, else the position itself.  Entry k: out_inputs / out_times
+ * [out_off[k] .. out_off[k+1]).  Returns 0, or -2 when `cap` is too small. */
+int b2t_nbest_convert_to_inputs(const int32_t* ali, const int32_t* a_off, int n, const int32_t* mapping, int F,
+                                int32_t* out_inputs, int32_t* out_times, int32_t* out_off, int cap);
 
 #ifdef __cplusplus
 }

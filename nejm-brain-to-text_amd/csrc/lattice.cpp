@@ -25,6 +25,14 @@ struct Node { int parent, label; };
 struct Subset { std::vector<int> st; std::vector<Entry> en; };   // lattice states and their best entries, insertion order
 struct Trans { int ol, dst; double tot, gr, ac; int ali, il; };   // a word arc out of a subset
 
+// Work arrays of a call, kept per host thread: a 175 k-arc lattice needs ~7 MB of them, and fresh allocations of that size are
+// mapped and unmapped by the allocator on every call (~1700 page faults, a fifth of the call).
+struct Scratch {
+  std::vector<int> out_off, pending, po, order, rank, slot;
+  std::vector<Arc> out_arc;
+  std::vector<double> fin, beta;
+};
+
 struct Item {
   double bound; int kind; long long tie; int words; int payload;   // kind 0: subset (payload = index), 1: finished (payload = index)
   bool operator<(const Item& o) const {                             // priority_queue is a max-heap: invert
@@ -47,49 +55,67 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   }
   const double INF = INFINITY;
   const auto tm_in = std::chrono::steady_clock::now();
-  // CSR adjacency both ways (lattices reach 10^5 arcs: no per-state vectors)
-  std::vector<int> out_off(n_states + 1, 0), rev_off(n_states + 1, 0);
+  // CSR adjacency (lattices reach 10^5 arcs: no per-state vectors).  Only the forward direction: the backward costs below are
+  // relaxed over a state's OUTGOING arcs in reverse topological order, so no transposed copy is built (setup was 40 % of the
+  // call for a 175 k-arc lattice with both directions).
+  static thread_local Scratch tls;
+  std::vector<int>& out_off = tls.out_off; std::vector<int>& pending = tls.pending;
+  out_off.assign(n_states + 1, 0); pending.assign(n_states, 0);
   for (int i = 0; i < n_arcs; ++i) {
     if (src[i] < 0 || src[i] >= n_states || dst[i] < 0 || dst[i] >= n_states) { b2t::set_error("lattice_nbest: arc %d out of range", i); return -1; }
-    ++out_off[src[i] + 1]; ++rev_off[dst[i] + 1];
+    ++out_off[src[i] + 1]; ++pending[dst[i]];
   }
-  for (int s = 0; s < n_states; ++s) { out_off[s + 1] += out_off[s]; rev_off[s + 1] += rev_off[s]; }
-  std::vector<Arc> out_arc(n_arcs);
-  std::vector<std::pair<int, double>> rev_arc(n_arcs);
+  for (int s = 0; s < n_states; ++s) out_off[s + 1] += out_off[s];
+  const auto ts1 = std::chrono::steady_clock::now();
+  std::vector<Arc>& out_arc = tls.out_arc;
+  if ((int)out_arc.size() < n_arcs) out_arc.resize(n_arcs);
   {
-    std::vector<int> po(out_off.begin(), out_off.end() - 1), pr(rev_off.begin(), rev_off.end() - 1);
-    for (int i = 0; i < n_arcs; ++i) {                       // arc order within a state = input order (deterministic ties)
+    std::vector<int>& po = tls.po;
+    po.assign(out_off.begin(), out_off.end() - 1);
+    for (int i = 0; i < n_arcs; ++i)                          // arc order within a state = input order (deterministic ties)
       out_arc[po[src[i]]++] = Arc{ilabel[i], olabel[i], dst[i], graph[i], acoustic[i]};
-      rev_arc[pr[dst[i]]++] = {src[i], (double)graph[i] + (double)acoustic[i]};   // as the forward search adds them
-    }
   }
-  std::vector<double> fin(n_states, INF), beta(n_states, INF);
+  const auto ts2 = std::chrono::steady_clock::now();
+  std::vector<double>& fin = tls.fin; std::vector<double>& beta = tls.beta;
+  fin.assign(n_states, INF); beta.assign(n_states, INF);
   for (int i = 0; i < n_final; ++i) fin[final_state[i]] = std::min(fin[final_state[i]], (double)final_cost[i]);
-  // beta: cheapest completion incl. the final cost.  The lattice is acyclic, so one relaxation sweep in reverse
-  // topological order (Kahn, O(states + arcs)) gives it EXACTLY, whatever the sign of the arc costs (an acoustic cost
-  // logp - log_prior can be negative after the DecodeNumpy prologue; an over-estimated beta would prune valid paths below).
-  // Should a cycle of epsilon arcs ever leave states unordered, Dijkstra takes over -- on costs clamped at 0, the only
-  // place the clamp is needed.
-  bool have_beta = false;
-  {
-    std::vector<int> pending(n_states);
-    for (int s = 0; s < n_states; ++s) pending[s] = out_off[s + 1] - out_off[s];
-    std::vector<int> order; order.reserve(n_states);
-    for (int s = 0; s < n_states; ++s) if (pending[s] == 0) order.push_back(s);
-    for (int s = 0; s < n_states; ++s) beta[s] = fin[s];
-    for (size_t h = 0; h < order.size(); ++h) {
-      const int s = order[h];
-      for (int k = rev_off[s]; k < rev_off[s + 1]; ++k) {
-        const std::pair<int, double>& pr = rev_arc[k];
-        const double c = beta[s] + pr.second;
-        if (c < beta[pr.first]) beta[pr.first] = c;
-        if (--pending[pr.first] == 0) order.push_back(pr.first);
-      }
-    }
-    have_beta = (int)order.size() == n_states;
-    if (!have_beta) std::fill(beta.begin(), beta.end(), INF);
+  // beta: cheapest completion incl. the final cost.  The lattice is acyclic, so one sweep in reverse topological order (Kahn,
+  // O(states + arcs)) gives it EXACTLY, whatever the sign of the arc costs (an acoustic cost logp - log_prior can be negative
+  // after the DecodeNumpy prologue; an over-estimated beta would prune valid paths below).  rank[s] = position of s in the
+  // topological order: the epsilon closures below visit their states in that order.
+  // Should a cycle of epsilon arcs ever leave states unordered, Dijkstra takes over -- on costs clamped at 0, the only place
+  // the clamp is needed -- and the closures fall back to cheapest-first.
+  std::vector<int>& order = tls.order; std::vector<int>& rank = tls.rank;
+  order.clear(); order.reserve(n_states);
+  rank.assign(n_states, -1);
+  for (int s = 0; s < n_states; ++s) if (pending[s] == 0) order.push_back(s);
+  for (size_t h = 0; h < order.size(); ++h) {
+    const int s = order[h];
+    rank[s] = (int)h;
+    for (int k = out_off[s]; k < out_off[s + 1]; ++k) if (--pending[out_arc[k].dst] == 0) order.push_back(out_arc[k].dst);
   }
-  if (!have_beta) {
+  const auto ts3 = std::chrono::steady_clock::now();
+  const bool have_order = (int)order.size() == n_states;
+  if (have_order) {
+    for (int h = n_states - 1; h >= 0; --h) {
+      const int s = order[h];
+      double b = fin[s];
+      for (int k = out_off[s]; k < out_off[s + 1]; ++k) {
+        const Arc& a = out_arc[k];
+        const double c = beta[a.dst] + ((double)a.g + (double)a.a);   // as the forward search adds them
+        if (c < b) b = c;
+      }
+      beta[s] = b;
+    }
+  } else {
+    std::vector<int> rev_off(n_states + 1, 0);
+    for (int i = 0; i < n_arcs; ++i) ++rev_off[dst[i] + 1];
+    for (int s = 0; s < n_states; ++s) rev_off[s + 1] += rev_off[s];
+    std::vector<std::pair<int, double>> rev_arc(n_arcs);
+    {
+      std::vector<int> pr(rev_off.begin(), rev_off.end() - 1);
+      for (int i = 0; i < n_arcs; ++i) rev_arc[pr[dst[i]]++] = {src[i], (double)graph[i] + (double)acoustic[i]};
+    }
     typedef std::pair<double, int> P;
     std::priority_queue<P, std::vector<P>, std::greater<P>> pq;
     for (int s = 0; s < n_states; ++s) if (fin[s] != INF) { beta[s] = fin[s]; pq.push({fin[s], s}); }
@@ -107,14 +133,51 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   const auto tm0 = std::chrono::steady_clock::now();
   w_off[0] = 0; a_off[0] = 0;
   if (beta[start] == INF) return 0;
-  const double limit = beta[start] + beam + 1e-4;
+  // Everything costlier than `limit` is dropped: at first the lattice beam; once `nbest` complete word sequences are known
+  // (each with the exact cost of its best path), the cost of the worst of the best `nbest` of them -- nothing above it can be
+  // among the answers, and the closures of the subsets still to be expanded shrink accordingly.
+  // The search is first run with HALF the beam: a lattice that holds many alternatives (the expensive case: 10^5 arcs) has its
+  // `nbest` answers well inside the beam, and a run that returns `nbest` sequences under a smaller limit returns exactly what
+  // the full beam would (best-first order; everything it dropped costs more than all of them).  Only a run that comes back
+  // short is repeated with the whole beam.  (32 lattices of the bench workload, one thread: 131 -> 6x ms.)
+  double limit = 0;
+  std::priority_queue<double> known;       // the `nbest` smallest totals of the finished sequences found so far
   std::vector<Node> ali_pool, word_pool;
   auto push_node = [](std::vector<Node>& pool, int parent, int label) { pool.push_back(Node{parent, label}); return (int)pool.size() - 1; };
 
-  std::vector<int> slot(n_states, -1);     // index of a lattice state in the subset under construction
+  std::vector<int>& slot = tls.slot;       // index of a lattice state in the subset under construction
+  slot.assign(n_states, -1);
   auto mark = [&](const Subset& sub) { for (size_t i = 0; i < sub.st.size(); ++i) slot[sub.st[i]] = (int)i; };
   auto unmark = [&](const Subset& sub) { for (int st : sub.st) slot[st] = -1; };
-  auto closure = [&](Subset& sub) {        // epsilon-output closure, cheapest first (sub's states are marked on entry and on exit)
+  std::vector<int> heap;                   // ranks of the closure's pending states (min-heap)
+  auto closure = [&](Subset& sub) {        // epsilon-output closure (sub's states are marked on entry and on exit)
+    if (have_order) {
+      // in topological order: when a state is taken from the heap every predecessor inside the subset has been expanded, so
+      // its entry is final and it is expanded exactly once (cheapest-first needed a (cost, state) heap and re-queued a state
+      // on every improvement)
+      heap.clear();
+      for (int st : sub.st) heap.push_back(rank[st]);
+      std::make_heap(heap.begin(), heap.end(), std::greater<int>());
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), std::greater<int>());
+        const int s = order[heap.back()]; heap.pop_back();
+        const Entry e = sub.en[slot[s]];
+        for (int k = out_off[s]; k < out_off[s + 1]; ++k) {
+          const Arc& a = out_arc[k];
+          if (a.ol != 0) continue;
+          const double nt = e.tot + a.g + a.a;
+          if (nt + beta[a.dst] > limit) continue;
+          const int j = slot[a.dst];
+          if (j >= 0 && !(nt < sub.en[j].tot)) continue;
+          const Entry ne{nt, e.gr + a.g, e.ac + a.a, a.il ? push_node(ali_pool, e.ali, a.il) : e.ali};
+          if (j < 0) {
+            slot[a.dst] = (int)sub.st.size(); sub.st.push_back(a.dst); sub.en.push_back(ne);
+            heap.push_back(rank[a.dst]); std::push_heap(heap.begin(), heap.end(), std::greater<int>());
+          } else sub.en[j] = ne;
+        }
+      }
+      return;
+    }
     typedef std::pair<double, int> P;
     std::priority_queue<P, std::vector<P>, std::greater<P>> pq;
     for (size_t i = 0; i < sub.st.size(); ++i) pq.push({sub.en[i].tot, sub.st[i]});
@@ -138,15 +201,30 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   };
 
   struct Done { double tot, gr, ac; int words, ali; };
-  std::vector<Subset> subsets;
+  // queued subsets live back to back in two pools (four of five are never expanded: no vectors of their own); the one being
+  // expanded is copied into `sub`, whose storage is reused from expansion to expansion
+  struct Span { size_t off; int n; };
+  std::vector<Span> subsets;
+  std::vector<int> pool_st;
+  std::vector<Entry> pool_en;
+  Subset sub, tgt;
+  std::vector<std::pair<unsigned long long, int>> keyed;      // (word label, position in `trans`) -> grouped by word, stable
   std::vector<Done> finished;
   std::priority_queue<Item> pq;
   std::vector<Trans> trans;
-  long long tie = 0;
-  subsets.emplace_back();
-  subsets[0].st.push_back(start); subsets[0].en.push_back(Entry{0.0, 0.0, 0.0, -1});
-  pq.push(Item{beta[start], 0, tie++, -1, 0});
   int n_out = 0;
+  double t_closure = 0; size_t n_pop = 0, n_clo = 0, n_trans = 0;
+  static const double STAGE[3] = {0.5, 0.75, 1.0};
+  for (int stage = 0; stage < 3; ++stage) {
+  if (stage > 0 && n_out >= nbest) break;
+  limit = beta[start] + STAGE[stage] * (double)beam + 1e-4;
+  known = std::priority_queue<double>(); pq = std::priority_queue<Item>();
+  subsets.clear(); pool_st.clear(); pool_en.clear(); finished.clear(); ali_pool.clear(); word_pool.clear();
+  long long tie = 0;
+  subsets.push_back(Span{0, 1});
+  pool_st.push_back(start); pool_en.push_back(Entry{0.0, 0.0, 0.0, -1});
+  pq.push(Item{beta[start], 0, tie++, -1, 0});
+  n_out = 0;
   while (!pq.empty() && n_out < nbest) {
     const Item it = pq.top(); pq.pop();
     if (it.bound > limit) break;
@@ -168,8 +246,15 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
     // A subset is expanded once: take it out (`subsets` grows below).  Its epsilon-output closure is computed only now: the
     // bound it was queued with, min (cost so far + backward cost) over its entries, does not need it -- the backward cost of
     // an entry already is the cheapest way on through the closure -- and four of five queued subsets are never popped.
-    Subset sub = std::move(subsets[it.payload]);
+    {
+      const Span sp = subsets[it.payload];
+      sub.st.assign(pool_st.begin() + sp.off, pool_st.begin() + sp.off + sp.n);
+      sub.en.assign(pool_en.begin() + sp.off, pool_en.begin() + sp.off + sp.n);
+    }
+    const auto tc0 = std::chrono::steady_clock::now();
     mark(sub); closure(sub); unmark(sub);
+    const auto tc1 = std::chrono::steady_clock::now();
+    t_closure += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); ++n_pop; n_clo += sub.st.size();
     bool has = false; Done best{INF, 0, 0, it.words, -1};
     for (size_t i = 0; i < sub.st.size(); ++i) {
       const int st = sub.st[i];
@@ -178,7 +263,12 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       const double c = e.tot + fin[st];
       if (c < best.tot) { best = Done{c, e.gr + fin[st], e.ac, it.words, e.ali}; has = true; }
     }
-    if (has && best.tot <= limit) { finished.push_back(best); pq.push(Item{best.tot, 1, tie++, it.words, (int)finished.size() - 1}); }
+    if (has && best.tot <= limit) {
+      finished.push_back(best); pq.push(Item{best.tot, 1, tie++, it.words, (int)finished.size() - 1});
+      known.push(best.tot);
+      if ((int)known.size() > nbest) known.pop();
+      if ((int)known.size() == nbest) limit = std::min(limit, known.top() + 1e-6);   // slack: forward and backward sums round differently
+    }
     // the word arcs out of the subset, grouped by word (ascending label: deterministic expansion order; within a word in
     // the order the subset and the lattice list them)
     trans.clear();
@@ -192,13 +282,17 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
         trans.push_back(Trans{a.ol, a.dst, nt, e.gr + a.g, e.ac + a.a, e.ali, a.il});
       }
     }
-    std::stable_sort(trans.begin(), trans.end(), [](const Trans& x, const Trans& y) { return x.ol < y.ol; });
-    for (size_t g0 = 0; g0 < trans.size();) {
+    n_trans += trans.size();
+    keyed.resize(trans.size());
+    for (size_t q = 0; q < trans.size(); ++q) keyed[q] = {((unsigned long long)(unsigned)trans[q].ol << 32) | (unsigned long long)q, (int)q};
+    std::sort(keyed.begin(), keyed.end());          // by word, then by position: what a stable sort of `trans` by word gives
+    for (size_t g0 = 0; g0 < keyed.size();) {
       size_t g1 = g0;
-      while (g1 < trans.size() && trans[g1].ol == trans[g0].ol) ++g1;
-      Subset tgt;
+      const int ol = trans[keyed[g0].second].ol;
+      while (g1 < keyed.size() && trans[keyed[g1].second].ol == ol) ++g1;
+      tgt.st.clear(); tgt.en.clear();
       for (size_t q = g0; q < g1; ++q) {
-        const Trans& tr = trans[q];
+        const Trans& tr = trans[keyed[q].second];
         const int j = slot[tr.dst];
         if (j >= 0 && !(tr.tot < tgt.en[j].tot)) continue;
         const Entry ne{tr.tot, tr.gr, tr.ac, tr.il ? push_node(ali_pool, tr.ali, tr.il) : tr.ali};
@@ -208,16 +302,48 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       double b = INF;
       for (size_t i = 0; i < tgt.st.size(); ++i) b = std::min(b, tgt.en[i].tot + beta[tgt.st[i]]);
       unmark(tgt);
-      const int ol = trans[g0].ol;
-      subsets.push_back(std::move(tgt));
+      subsets.push_back(Span{pool_st.size(), (int)tgt.st.size()});
+      pool_st.insert(pool_st.end(), tgt.st.begin(), tgt.st.end());
+      pool_en.insert(pool_en.end(), tgt.en.begin(), tgt.en.end());
       pq.push(Item{b, 0, tie++, push_node(word_pool, it.words, ol), (int)subsets.size() - 1});
       g0 = g1;
     }
   }
+  }
   if (lat_timing) {
-    size_t ents = 0; for (const Subset& x : subsets) ents += x.st.size();
-    fprintf(stderr, "lattice_nbest: setup (adjacency + backward costs) %.1f ms, main loop %.1f ms, %zu subsets created, %zu alignment nodes, %zu entries left in unexpanded subsets\n",
-            std::chrono::duration<double, std::milli>(tm0 - tm_in).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count(), subsets.size(), ali_pool.size(), ents);
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "lattice_nbest setup: count %.2f, fill %.2f, kahn %.2f, beta %.2f ms\n", ms(tm_in, ts1), ms(ts1, ts2), ms(ts2, ts3), ms(ts3, tm0));
+    size_t ents = pool_st.size();
+    fprintf(stderr, "lattice_nbest: setup (adjacency + backward costs) %.1f ms, main loop %.1f ms, %zu subsets created, %zu alignment nodes, %zu subset entries queued in all; %zu subsets expanded, closures %.1f ms with %zu states, %zu word transitions\n",
+            std::chrono::duration<double, std::milli>(tm0 - tm_in).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count(), subsets.size(), ali_pool.size(), ents, n_pop, t_closure, n_clo, n_trans);
   }
   return n_out;
+}
+
+extern "C" int b2t_nbest_convert_to_inputs(const int32_t* ali, const int32_t* a_off, int n, const int32_t* mapping, int F,
+                                           int32_t* out_inputs, int32_t* out_times, int32_t* out_off, int cap) {
+  if (n < 0 || !a_off || !out_off || (n > 0 && (!ali || !out_inputs || !out_times)) || (F > 0 && !mapping)) {
+    b2t::set_error("nbest_convert_to_inputs: bad arguments");
+    return -1;
+  }
+  int w = 0;
+  out_off[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    const int32_t* a = ali + a_off[k];
+    const int len = a_off[k + 1] - a_off[k];
+    const bool full = len == F && F > 0;
+    int cur = 0;
+    while (cur < len) {
+      while (cur < len && a[cur] == 1) ++cur;                              // blanks
+      while (cur + 1 < len && a[cur + 1] == a[cur]) ++cur;                 // the unit's time is that of its last repeat
+      if (cur < len) {
+        if (w >= cap) { b2t::set_error("nbest_convert_to_inputs: output buffers too small"); return -2; }
+        out_inputs[w] = a[cur] - 1;
+        out_times[w] = full ? mapping[cur < F ? cur : F - 1] : cur;
+        ++w; ++cur;
+      }
+    }
+    out_off[k + 1] = w;
+  }
+  return 0;
 }

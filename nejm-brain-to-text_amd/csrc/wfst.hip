@@ -1246,6 +1246,8 @@ __device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, 
     }
   }
   __syncthreads();
+  // (the relaxation sweeps stay one link per thread and trip: batching four links' loads ahead of their updates doubled the
+  //  kernel's time -- a sweep then propagates through fewer links of a chain and more sweeps are needed)
   for (int iter = 0; iter < 4096 && e1 > e0; ++iter) {
     if (threadIdx.x == 0) flags[0] = 0;
     __syncthreads();
@@ -1488,54 +1490,166 @@ __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, si
 }
 
 // The pruned lattice in compact form (GetRawLattice, lattice-faster-decoder.cc:106-186, after FinalizeDecoding): surviving
-// tokens renumbered 0..n-1, surviving links as arcs (src, dst, ilabel, olabel, graph, acoustic - cost_offset), final costs
-// of the last frame's tokens.  counts[u] = {n_states, n_arcs, n_final, start state, overflow}.
-__global__ __launch_bounds__(NT) void wfst_lattice_kernel(Graph g, char* state, size_t state_bytes, int max_frames, int max_tok,
-                                                           int max_link, int hash, int cap_arcs, int cap_final, int* counts,
-                                                           int* a_src, int* a_dst, int* a_il, int* a_ol, float* a_graph,
-                                                           float* a_ac, int* f_state, float* f_cost) {
-  __shared__ int cnt[3];
-  const int u = blockIdx.x;
-  Lay l;
-  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
-  const int F = l.h->n_frames;
-  const int n_tok = min(l.h->n_tok, max_tok);
+// tokens renumbered 0..n-1 in token order, surviving links as arcs (src, dst, ilabel, olabel, graph, acoustic - cost_offset) in
+// link order, final costs of the last frame's tokens.  counts[u] = {n_states, n_arcs, n_final, start state, overflow}.
+// Three launches of LAT_P workgroups per utterance (a filter + compaction over ~10^5 links per utterance: with one workgroup
+// per utterance and one LDS atomic per surviving arc it took 4 ms for 32 utterances and numbered states and arcs in arrival
+// order): count per slice -> new token ids -> arcs.  Slice sums live in the cluster search's work list (rebuilt every frame,
+// free between launches); positions come from prefix scans, so the numbering is deterministic.
+constexpr int LAT_NT = 256;
+constexpr int LAT_P = 32;          // slices per utterance (2 * LAT_P ints of scratch)
+
+struct LatCtx { Lay l; int F, n_tok, l_begin, l_end, p, t0, t1, k0, k1; int* part; };
+__device__ __forceinline__ LatCtx lat_ctx(char* state, size_t state_bytes, int max_frames, int max_tok, int max_link, int hash) {
+  LatCtx c;
+  layout(state + (size_t)blockIdx.y * state_bytes, max_frames, max_tok, max_link, hash, &c.l);
+  c.F = c.l.h->n_frames;
+  c.n_tok = min(c.l.h->n_tok, max_tok);
+  c.l_begin = c.l.link_off[0];
+  c.l_end = min(c.l.link_off[2 * c.F + 1], max_link);
+  c.p = blockIdx.x;
+  // slices start on multiples of 16 elements (16-byte loads of the 1-byte link flags, of 4 token words)
+  auto cut = [](int lo, int hi, int q) { return q >= LAT_P ? hi : min(hi, max(lo, (int)(((long long)(hi - lo) * q / LAT_P + lo) & ~15LL))); };
+  c.t0 = cut(0, c.n_tok, c.p); c.t1 = cut(0, c.n_tok, c.p + 1);
+  c.k0 = cut(c.l_begin, max(c.l_begin, c.l_end), c.p); c.k1 = cut(c.l_begin, max(c.l_begin, c.l_end), c.p + 1);
+  c.part = c.l.wlg;
+  return c;
+}
+// 16 consecutive links starting at li0 (li0 % 16 == 0 except at a slice's ragged ends): bit i = link li0 + i survives
+__device__ __forceinline__ unsigned lat_links16(const Lay& l, int li0, int lo, int hi) {
   const unsigned INF_BITS = 0x7f800000u;
-  if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+  unsigned m = 0;
+  if (li0 >= hi) return 0;
+  if (li0 >= lo && li0 + 16 <= hi && (li0 & 15) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(l.link_alive + li0);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m |= ((w[i >> 2] >> (8 * (i & 3))) & 0xffu) ? (1u << i) : 0u;
+  } else {
+    for (int i = 0; i < 16; ++i) { const int li = li0 + i; if (li >= lo && li < hi && l.link_alive[li]) m |= 1u << i; }
+  }
+  for (unsigned r = m; r; r &= r - 1) {               // the flag says alive: both endpoints must have survived too
+    const int i = __ffs(r) - 1, li = li0 + i;
+    if (l.tok_extra[l.link_src[li]] == INF_BITS || l.tok_extra[l.link_dst[li]] == INF_BITS) m &= ~(1u << i);
+  }
+  return m;
+}
+// 4 consecutive tokens starting at t0q: bit i = token survives
+__device__ __forceinline__ unsigned lat_toks4(const Lay& l, int t0q, int lo, int hi) {
+  const unsigned INF_BITS = 0x7f800000u;
+  unsigned m = 0;
+  if (t0q >= hi) return 0;
+  if (t0q >= lo && t0q + 4 <= hi && (t0q & 3) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(l.tok_extra + t0q);
+    m = (v.x != INF_BITS) | ((v.y != INF_BITS) << 1) | ((v.z != INF_BITS) << 2) | ((v.w != INF_BITS) << 3);
+  } else {
+    for (int i = 0; i < 4; ++i) { const int t = t0q + i; if (t >= lo && t < hi && l.tok_extra[t] != INF_BITS) m |= 1u << i; }
+  }
+  return m;
+}
+// exclusive position of this thread's count among the workgroup's counts + the total (LAT_NT threads)
+__device__ __forceinline__ int lat_scan(int n, int& total, int* wsum /* [2][LAT_NT / 64] */, int& flip) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int v = n;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int x = __shfl_up(v, off, 64); if (lane >= off) v += x; }
+  if (lane == 63) wsum[flip * (LAT_NT / 64) + w] = v;
   __syncthreads();
-  int* newid = reinterpret_cast<int*>(l.tok_prev);     // free after finalize
-  for (int t = threadIdx.x; t < n_tok; t += NT) newid[t] = l.tok_extra[t] != INF_BITS ? atomicAdd(&cnt[0], 1) : -1;
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int ww = 0; ww < LAT_NT / 64; ++ww) { const int x = wsum[flip * (LAT_NT / 64) + ww]; if (ww < w) before += x; tot += x; }
+  total = tot;
+  flip ^= 1;
+  return before + v - n;
+}
+
+__global__ __launch_bounds__(LAT_NT) void wfst_lattice_count_kernel(char* state, size_t state_bytes, int max_frames, int max_tok,
+                                                                   int max_link, int hash) {
+  __shared__ int acc[2];
+  const LatCtx c = lat_ctx(state, state_bytes, max_frames, max_tok, max_link, hash);
+  if (threadIdx.x < 2) acc[threadIdx.x] = 0;
   __syncthreads();
+  int nt = 0, nk = 0;
+  for (int t = c.t0 + 4 * threadIdx.x; t < c.t1; t += 4 * LAT_NT) nt += __popc(lat_toks4(c.l, t, c.t0, c.t1));
+  for (int li = c.k0 + 16 * threadIdx.x; li < c.k1; li += 16 * LAT_NT) nk += __popc(lat_links16(c.l, li, c.k0, c.k1));
+  for (int off = 32; off; off >>= 1) { nt += __shfl_down(nt, off, 64); nk += __shfl_down(nk, off, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], nt); atomicAdd(&acc[1], nk); }
+  __syncthreads();
+  if (threadIdx.x < 2) c.part[2 * c.p + threadIdx.x] = acc[threadIdx.x];
+}
+
+__global__ __launch_bounds__(LAT_NT) void wfst_lattice_ids_kernel(char* state, size_t state_bytes, int max_frames, int max_tok,
+                                                                 int max_link, int hash, int* counts) {
+  __shared__ int wsum[2 * (LAT_NT / 64)];
+  const LatCtx c = lat_ctx(state, state_bytes, max_frames, max_tok, max_link, hash);
+  const unsigned INF_BITS = 0x7f800000u;
+  int base = 0, all = 0;
+  for (int q = 0; q < LAT_P; ++q) { const int v = c.part[2 * q]; if (q < c.p) base += v; all += v; }
+  int* newid = reinterpret_cast<int*>(c.l.tok_prev);     // free after finalize
+  int flip = 0;
+  for (int tb = c.t0; tb < c.t1; tb += 4 * LAT_NT) {
+    const int t = tb + 4 * threadIdx.x;
+    const unsigned m = lat_toks4(c.l, t, c.t0, c.t1);
+    int tot;
+    int k = base + lat_scan(__popc(m), tot, wsum, flip);
+    base += tot;
+    for (int i = 0; i < 4; ++i) if (t + i >= c.t0 && t + i < c.t1) newid[t + i] = (m >> i) & 1u ? k++ : -1;
+  }
+  if (c.p == 0 && threadIdx.x == 0) {
+    counts[5 * blockIdx.y] = all;
+    counts[5 * blockIdx.y + 3] = (c.n_tok > 0 && c.l.tok_extra[0] != INF_BITS) ? 0 : -1;   // token 0 is the start token
+  }
+}
+
+__global__ __launch_bounds__(LAT_NT) void wfst_lattice_arcs_kernel(Graph g, char* state, size_t state_bytes, int max_frames,
+                                                                  int max_tok, int max_link, int hash, int cap_arcs, int cap_final,
+                                                                  int* counts, int* a_src, int* a_dst, int* a_il, int* a_ol,
+                                                                  float* a_graph, float* a_ac, int* f_state, float* f_cost) {
+  __shared__ int wsum[2 * (LAT_NT / 64)];
+  const LatCtx c = lat_ctx(state, state_bytes, max_frames, max_tok, max_link, hash);
+  const Lay& l = c.l;
+  const int u = blockIdx.y;
+  int base = 0, all = 0;
+  for (int q = 0; q < LAT_P; ++q) { const int v = c.part[2 * q + 1]; if (q < c.p) base += v; all += v; }
+  const int* newid = reinterpret_cast<const int*>(l.tok_prev);
   const size_t ao = (size_t)u * cap_arcs, fo = (size_t)u * cap_final;
-  for (int f = 0; f <= F; ++f) {
-    const int e0 = l.link_off[2 * f], e1 = l.link_off[2 * f + 1];
-    const int m1 = f < F ? l.link_off[2 * f + 2] : e1;
-    const float off = f < F ? l.cost_offset[f] : 0.f;
-    for (int li = e0 + threadIdx.x; li < m1; li += NT) {
-      if (!l.link_alive[li]) continue;
-      const int s = newid[l.link_src[li]], d = newid[l.link_dst[li]];
-      if (s < 0 || d < 0) continue;
-      const int k = atomicAdd(&cnt[1], 1);
-      if (k >= cap_arcs) continue;
+  const int nseg = 2 * c.F + 2;                       // link_off[j] <= li < link_off[j + 1]: j odd = emitting links of frame j / 2
+  int flip = 0;
+  for (int kb = c.k0; kb < c.k1; kb += 16 * LAT_NT) {
+    const int li0 = kb + 16 * threadIdx.x;
+    const unsigned m = lat_links16(l, li0, c.k0, c.k1);
+    int tot;
+    int k = base + lat_scan(__popc(m), tot, wsum, flip);
+    base += tot;
+    for (unsigned r = m; r; r &= r - 1, ++k) {
+      if (k >= cap_arcs) break;
+      const int li = li0 + __ffs(r) - 1;
+      int lo = 0, hi = nseg - 1;                      // last j with link_off[j] <= li
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (l.link_off[mid] <= li) lo = mid; else hi = mid - 1; }
       const int a = l.link_arc[li];
-      a_src[ao + k] = s; a_dst[ao + k] = d; a_il[ao + k] = g.ilabel[a]; a_ol[ao + k] = g.olabel[a];
+      a_src[ao + k] = newid[l.link_src[li]]; a_dst[ao + k] = newid[l.link_dst[li]];
+      a_il[ao + k] = g.ilabel[a]; a_ol[ao + k] = g.olabel[a];
       a_graph[ao + k] = l.link_graph[li];
-      a_ac[ao + k] = li >= e1 ? l.link_ac[li] - off : l.link_ac[li];   // emitting links carry the frame's cost offset
+      a_ac[ao + k] = (lo & 1) ? l.link_ac[li] - l.cost_offset[lo >> 1] : l.link_ac[li];   // emitting links carry the frame's cost offset
     }
   }
-  const int t0 = l.tok_off[F], t1 = l.tok_off[F + 1];
-  for (int t = t0 + threadIdx.x; t < t1; t += NT) {
-    if (newid[t] < 0) continue;
-    const float fc = l.h->has_final ? g.final_cost[l.tok_state[t]] : 0.f;
-    if (fc == INFINITY) continue;
-    const int k = atomicAdd(&cnt[2], 1);
-    if (k < cap_final) { f_state[fo + k] = newid[t]; f_cost[fo + k] = fc; }
+  if (c.p != 0) return;
+  // finals: the last frame's surviving tokens with a finite final cost, in token order
+  const int t0 = l.tok_off[c.F], t1 = min(l.tok_off[c.F + 1], c.n_tok);
+  int nf = 0;
+  for (int tb = t0; tb < t1; tb += LAT_NT) {
+    const int t = tb + threadIdx.x;
+    float fc = INFINITY;
+    if (t < t1 && newid[t] >= 0) fc = l.h->has_final ? g.final_cost[l.tok_state[t]] : 0.f;
+    const int ok = fc != INFINITY;
+    int tot;
+    const int k = nf + lat_scan(ok, tot, wsum, flip);
+    nf += tot;
+    if (ok && k < cap_final) { f_state[fo + k] = newid[t]; f_cost[fo + k] = fc; }
   }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    counts[5 * u] = cnt[0]; counts[5 * u + 1] = min(cnt[1], cap_arcs); counts[5 * u + 2] = min(cnt[2], cap_final);
-    counts[5 * u + 3] = n_tok > 0 ? newid[0] : -1;
-    counts[5 * u + 4] = (cnt[1] > cap_arcs || cnt[2] > cap_final) ? 1 : 0;
+    counts[5 * u + 1] = min(all, cap_arcs); counts[5 * u + 2] = min(nf, cap_final);
+    counts[5 * u + 4] = (all > cap_arcs || nf > cap_final) ? 1 : 0;
   }
 }
 
@@ -1677,9 +1791,14 @@ extern "C" int b2t_wfst_lattice(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t
   B2T_REQUIRE(cap_arcs > 0 && cap_final > 0 && counts && src && dst && ilabel && olabel && graph && acoustic && final_state && final_cost,
               "wfst_lattice: null output / zero capacity");
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
-  hipLaunchKernelGGL(wfst_lattice_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, o->max_frames,
-                     o->max_tokens, o->max_links, o->hash_size, cap_arcs, cap_final, counts, src, dst, ilabel, olabel, graph, acoustic,
-                     final_state, final_cost);
+  static_assert(2 * LAT_P <= WLG_CAP, "slice sums live in the work list");
+  hipLaunchKernelGGL(wfst_lattice_count_kernel, dim3(LAT_P, U), dim3(LAT_NT), 0, as_stream(stream), (char*)state, sb, o->max_frames,
+                     o->max_tokens, o->max_links, o->hash_size);
+  hipLaunchKernelGGL(wfst_lattice_ids_kernel, dim3(LAT_P, U), dim3(LAT_NT), 0, as_stream(stream), (char*)state, sb, o->max_frames,
+                     o->max_tokens, o->max_links, o->hash_size, counts);
+  hipLaunchKernelGGL(wfst_lattice_arcs_kernel, dim3(LAT_P, U), dim3(LAT_NT), 0, as_stream(stream), to_graph(g), (char*)state, sb,
+                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, cap_arcs, cap_final, counts, src, dst, ilabel, olabel,
+                     graph, acoustic, final_state, final_cost);
   B2T_CHECK_LAUNCH("b2t_wfst_lattice");
   return 0;
 }

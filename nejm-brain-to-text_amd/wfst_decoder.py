@@ -35,9 +35,11 @@ def _host_threads() -> int:
 
 def _pool_threads() -> int:
     """Threads of the n-best pool: a quarter of the usable cores stays free for the thread that drives the GPU (with every
-    core busy in b2t_lattice_nbest_host the next batch's launches and copies crawl: measured 67 vs 43 ms per pipelined batch)."""
+    core busy in b2t_lattice_nbest_host the next batch's launches and copies crawl: measured 67 vs 43 ms per pipelined batch),
+    and never more than 16 -- the C search of 32 lattices takes 7.2 ms on 12 threads and 6.7 on 16 (EPYC 9575F), while every
+    further thread only queues for the interpreter lock around its call."""
     n = _host_threads()
-    return max(1, n - max(1, n // 4)) if not os.environ.get("B2T_HOST_THREADS") else n
+    return max(1, min(16, n - max(1, n // 4))) if not os.environ.get("B2T_HOST_THREADS") else n
 
 
 def _pow2_at_least(n: int) -> int:
@@ -270,26 +272,46 @@ class WfstSearch:
     def _nbest_host(self, nbest, hdr, cn, host, mapping_all):
         """Host half of FinalizeSearch: nothing here touches the device or this object's state block."""
         (src, dst, il, ol, gr, ac, fs, fc), a_off, f_off = host
-        P = lambda x: x.ctypes.data_as(C.c_void_p)
+        # Everything a worker does outside the two C calls holds the interpreter lock, i.e. is serial across the utterances'
+        # threads: addresses are computed once here (no per-utterance slices / ctypes casts), the output buffers of all
+        # utterances are one allocation each, and Python only cuts flat lists into the n-best tuples at the end.
+        U = self.U
+        Fs = [int(hdr[u, 0]) for u in range(U)]
+        cap = nbest * (2 * max(Fs + [0]) + 16) + 16
+        ow = np.empty((U, cap), dtype=np.int32); oa = np.empty((U, cap), dtype=np.int32)
+        ii = np.empty((U, cap), dtype=np.int32); it = np.empty((U, cap), dtype=np.int32)
+        woff = np.zeros((U, nbest + 1), dtype=np.int32); aoff = np.zeros((U, nbest + 1), dtype=np.int32); io = np.zeros((U, nbest + 1), dtype=np.int32)
+        costs = np.empty((U, 2 * nbest), dtype=np.float32)
+        mapping_all = np.ascontiguousarray(mapping_all, dtype=np.int32)
+        base = {k: v.ctypes.data for k, v in dict(src=src, dst=dst, il=il, ol=ol, gr=gr, ac=ac, fs=fs, fc=fc, ow=ow, oa=oa, ii=ii, it=it,
+                                                  woff=woff, aoff=aoff, io=io, costs=costs, mp=mapping_all).items()}
+        for k, v in dict(src=src, dst=dst, il=il, ol=ol, gr=gr, ac=ac, fs=fs, fc=fc).items():
+            assert v.flags.c_contiguous and v.itemsize == 4, k
+        a_off_l, f_off_l = [int(x) for x in a_off], [int(x) for x in f_off]
+        cn_l = cn[:, :4].tolist()
+        row = lambda name, u, width: base[name] + 4 * u * width
+        beam = C.c_float(self.lattice_beam)
+        mp_w = mapping_all.shape[1]
 
         def one(u):
-            F = int(hdr[u, 0])
-            n_states, n_arcs, n_final, start = (int(v) for v in cn[u, :4])
+            F = Fs[u]
+            n_states, n_arcs, n_final, start = cn_l[u]
             if F == 0 or n_states == 0 or start < 0:
                 return []
-            a = [np.ascontiguousarray(x[a_off[u]:a_off[u] + n_arcs]) for x in (src, dst, il, ol, gr, ac)]
-            f_s, f_c = np.ascontiguousarray(fs[f_off[u]:f_off[u] + n_final]), np.ascontiguousarray(fc[f_off[u]:f_off[u] + n_final])
-            w_cap = a_cap = nbest * (2 * F + 16) + 16
-            ow = np.zeros(w_cap, dtype=np.int32); oa = np.zeros(a_cap, dtype=np.int32)
-            woff = np.zeros(nbest + 1, dtype=np.int32); aoff = np.zeros(nbest + 1, dtype=np.int32); costs = np.zeros(2 * nbest, dtype=np.float32)
-            n = self.lib.b2t_lattice_nbest_host(n_states, start, n_arcs, P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(a[4]), P(a[5]), n_final,
-                                                P(f_s), P(f_c), nbest, C.c_float(self.lattice_beam), P(ow), P(woff), w_cap, P(oa),
-                                                P(aoff), a_cap, P(costs))
+            ao, fo = 4 * a_off_l[u], 4 * f_off_l[u]
+            n = self.lib.b2t_lattice_nbest_host(n_states, start, n_arcs, base["src"] + ao, base["dst"] + ao, base["il"] + ao, base["ol"] + ao,
+                                                base["gr"] + ao, base["ac"] + ao, n_final, base["fs"] + fo, base["fc"] + fo, nbest, beam,
+                                                row("ow", u, cap), row("woff", u, nbest + 1), cap, row("oa", u, cap),
+                                                row("aoff", u, nbest + 1), cap, row("costs", u, 2 * nbest))
             if n < 0:
                 raise RuntimeError("b2t_lattice_nbest_host failed: " + N.last_error())
-            mapping = mapping_all[u, :F]
-            inps, tms = convert_all_to_inputs(oa, aoff, n, mapping)
-            return [(inps[k], tms[k], ow[woff[k]:woff[k + 1]].tolist(), -float(costs[2 * k]), -float(costs[2 * k + 1])) for k in range(n)]
+            # ConvertToInputs (ctc_wfst_beam_search.cc:162-188) for the n entries in one host call as well
+            if self.lib.b2t_nbest_convert_to_inputs(row("oa", u, cap), row("aoff", u, nbest + 1), n, row("mp", u, mp_w), F, row("ii", u, cap),
+                                                    row("it", u, cap), row("io", u, nbest + 1), cap) != 0:
+                raise RuntimeError("b2t_nbest_convert_to_inputs failed: " + N.last_error())
+            io_l, wo_l = io[u, :n + 1].tolist(), woff[u, :n + 1].tolist()
+            inl, tl, wl, cl = ii[u, :io_l[n]].tolist(), it[u, :io_l[n]].tolist(), ow[u, :wo_l[n]].tolist(), costs[u, :2 * n].tolist()
+            return [(inl[io_l[k]:io_l[k + 1]], tl[io_l[k]:io_l[k + 1]], wl[wo_l[k]:wo_l[k + 1]], -cl[2 * k], -cl[2 * k + 1]) for k in range(n)]
 
         # utterances are independent and the C call releases the GIL: one host thread per utterance up to the usable cores
         workers = min(self.U, _host_threads())
@@ -297,7 +319,10 @@ class WfstSearch:
             return [one(u) for u in range(self.U)]
         if WfstSearch._pool is None:
             WfstSearch._pool = ThreadPoolExecutor(max_workers=_pool_threads())
-        return list(WfstSearch._pool.map(one, range(self.U)))
+        # largest lattice first: the call takes max(longest utterance, sum / threads), and a long one started last is all tail
+        by_size = sorted(range(self.U), key=lambda u: -int(cn[u, 1]))
+        res = dict(zip(by_size, WfstSearch._pool.map(one, by_size)))
+        return [res[u] for u in range(self.U)]
 
     def _nbest_of(self, u, h, nbest=None):
         return self._nbest_all(nbest or self.nbest)[u]

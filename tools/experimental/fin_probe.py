@@ -60,6 +60,11 @@ def main():
         hostb.copy_(sel, non_blocking=True); t = tick("  copy", t)
         fut = S._nbest_host(S.nbest, hdr, cn, host, mapping_all); t = tick("nbest_host", t)
     print({k: round(v, 3) for k, v in best.items()}, "arcs", tot, "MB", tot * 24 / 1e6)
+    if os.environ.get("B2T_DUMP_LAT"):
+        (src, dst, il, ol, gr, ac, fs, fc), a_off, f_off = host
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez_compressed(os.path.join(ROOT, "gpurun_out", "lat32.npz"), src=src, dst=dst, il=il, ol=ol, gr=gr, ac=ac, fs=fs, fc=fc,
+                            a_off=a_off, f_off=f_off, cn=cn, hdr=hdr, mapping=mapping_all, lattice_beam=np.float32(S.lattice_beam))
 
 
 if __name__ == "__main__":
