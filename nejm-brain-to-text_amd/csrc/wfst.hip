@@ -83,7 +83,7 @@ struct Lay {
 
 __host__ __device__ inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
-__host__ __device__ inline size_t layout(char* base, int max_frames, int max_tok, int max_link, int hash, Lay* l) {
+__host__ __device__ __forceinline__ size_t layout(char* base, int max_frames, int max_tok, int max_link, int hash, Lay* l) {
   size_t o = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += al(bytes); return p; };
   Hdr* h = reinterpret_cast<Hdr*>(take(sizeof(Hdr)));
@@ -1207,12 +1207,163 @@ namespace {
 // keep_all: the frame's tokens are never removed and count with extra cost 0 (the newest frame in PruneActiveTokens).
 // Returns through *flags: [0] scratch, [1] |= an extra cost moved by more than delta (vs tok_prev = its old value: the
 // reference's extra_costs_changed, which alone sends PruneActiveTokens one frame further back, :528-531), [2] |= a link was pruned.
-__device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, int F, bool final_frame, int has_final, float final_best,
-                            float delta, int* flags) {
+#ifdef B2T_FIN_TIMING
+__device__ unsigned long long fin_t[8];   // [0..4] cycles in: token init, emitting links, epsilon sweeps, epsilon prune, token pass; [5] sweeps; [6] frames
+#define FT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); fin_t[i] += now_ - ft_; ft_ = now_; } } while (0)
+#else
+#define FT(i) do {} while (0)
+#endif
+constexpr int PRUNE_LDS_WORDS = 36000;   // dynamic LDS of the finalize / prune kernels (144 000 B of the CU's 160 KB)
+// (l, g, o BY VALUE, and the kernels below hold their Lay as a by-value copy: with a reference to the struct the compiler kept
+//  all 25 array pointers in scratch memory, reloaded them around every barrier and -- their address space lost on the way
+//  through memory -- turned every access into a FLAT instruction, which also waits on the LDS counter)
+__device__ __forceinline__ void prune_frame(const Lay l, const Graph g, const Opts o, int f, int F, bool final_frame, int has_final, float final_best,
+                            float delta, int* flags, unsigned* lds) {
   const unsigned INF_BITS = 0x7f800000u;
+#ifdef B2T_FIN_TIMING
+  unsigned long long ft_ = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) ++fin_t[6];
+#endif
   const int a0 = l.tok_off[f], a1 = l.tok_off[f + 1];
   const int e0 = f == 0 ? 0 : l.link_off[2 * f], e1 = l.link_off[2 * f + 1];                 // eps links of frame f
   const int m0 = f < F ? l.link_off[2 * f + 1] : 0, m1 = f < F ? l.link_off[2 * f + 2] : 0;   // emitting f -> f+1
+  // The pass is bound by ONE CU's rate of random gathers (64 cache lines per wave instruction): per emitting link the costs of
+  // its two tokens, the extra cost of its destination, and an atomic on the extra cost of its source (62 % of finalize's
+  // time).  A frame's tokens are contiguous, so the three arrays that are hit at random -- extra costs of frame f (atomics),
+  // costs and extra costs of frame f + 1 -- are staged in LDS when they fit (a frame holds ~8 k tokens: 100 KB); the source
+  // costs stay in memory (links are created token by token: a wave's sources share a few lines).
+  const int b0 = a1, b1 = f < F ? l.tok_off[f + 2] : a1;
+  const int nA = a1 - a0, nB = b1 - b0;
+  if (lds != nullptr && nA + 2 * nB <= PRUNE_LDS_WORDS) {
+    unsigned* xA = lds; unsigned* cB = lds + nA; unsigned* xB = cB + nB;
+    // (four tokens per thread and trip, a trip's loads before its stores: tok_prev / tok_extra may alias for all the compiler
+    //  knows, so a one-token loop waits out a memory round trip per token)
+    for (int tb = a0; tb < a1; tb += 4 * NT) {
+      unsigned ex[4]; float base[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = tb + k * NT + (int)threadIdx.x, q = t < a1 ? t : a1 - 1;
+        ex[k] = l.tok_extra[q];
+        base[k] = INFINITY;
+        if (final_frame) {
+          const float fc = has_final ? g.final_cost[l.tok_state[q]] : 0.f;
+          base[k] = fmaxf(o2f(l.tok_cost[q]) + fc - final_best, 0.f);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = tb + k * NT + (int)threadIdx.x;
+        if (t < a1) { l.tok_prev[t] = ex[k]; xA[t - a0] = __float_as_uint(base[k]); }
+      }
+    }
+    for (int tb = b0; tb < b1; tb += 4 * NT) {
+      unsigned c4[4], x4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int t = tb + k * NT + (int)threadIdx.x, q = t < b1 ? t : b1 - 1; c4[k] = l.tok_cost[q]; x4[k] = l.tok_extra[q]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int t = tb + k * NT + (int)threadIdx.x; if (t < b1) { cB[t - b0] = c4[k]; xB[t - b0] = x4[k]; } }
+    }
+    __syncthreads();
+    FT(0);
+    // A frame has ~22 k emitting links (up to 54 k).  What bounds the pass on ONE CU is the address path of the vector memory
+    // unit: a wave's load instruction costs it 16 clocks whatever its width, and a link read field by field is six of them
+    // (measured 1.5 clocks per link = 6 x 16 / 64).  So a thread takes FOUR CONSECUTIVE links: one 16-byte load per field, the
+    // four alive bytes as one word, and only the source costs remain single gathers; dead links are marked by rewriting that
+    // word once.  A trip is still two dependent round trips (links, then source costs), and the marks may alias anything for
+    // all the compiler knows, so three trips are kept in flight by hand: trip i + 2 loads its links, trip i + 1 gathers its
+    // source costs, trip i is evaluated (LDS reads, LDS atomics, marks).
+    const int mb = m0 & ~3;                                   // quads are 16-byte aligned in every link array
+    const int n_trips = (m1 - mb + 4 * NT - 1) / (4 * NT);
+    const int q_last = m1 > mb ? (m1 - 1 - mb) / 4 : 0;
+    int4 srcA, dstA; float4 acA, grA; unsigned alA;
+    int4 srcB, dstB; float4 acB, grB; unsigned alB; unsigned csB[4];
+#define B2T_LOAD_A(trip)                                                                                                  \
+    {                                                                                                                       \
+      int q_ = (trip) * NT + (int)threadIdx.x; if (q_ > q_last) q_ = q_last;                                                \
+      const int i_ = mb + 4 * q_;                                                                                           \
+      alA = *reinterpret_cast<const unsigned*>(l.link_alive + i_);                                                          \
+      srcA = *reinterpret_cast<const int4*>(l.link_src + i_); dstA = *reinterpret_cast<const int4*>(l.link_dst + i_);       \
+      acA = *reinterpret_cast<const float4*>(l.link_ac + i_); grA = *reinterpret_cast<const float4*>(l.link_graph + i_);    \
+    }
+#define B2T_A_TO_B(trip)                                                                                                  \
+    {                                                                                                                       \
+      alB = alA; srcB = srcA; dstB = dstA; acB = acA; grB = grA;                                                            \
+      const int i_ = mb + 4 * ((trip) * NT + (int)threadIdx.x);                                                             \
+      const int s_[4] = {srcA.x, srcA.y, srcA.z, srcA.w};                                                                   \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) csB[k] = (i_ + k >= m0 && i_ + k < m1) ? l.tok_cost[s_[k]] : 0u;        \
+    }
+    if (n_trips > 0) {
+      B2T_LOAD_A(0);
+      B2T_A_TO_B(0);
+      if (n_trips > 1) { B2T_LOAD_A(1); }
+    }
+    for (int tr = 0; tr < n_trips; ++tr) {
+      const int4 srcC = srcB, dstC = dstB; const float4 acC = acB, grC = grB; const unsigned alC = alB;
+      unsigned csC[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) csC[k] = csB[k];
+      if (tr + 1 < n_trips) { B2T_A_TO_B(tr + 1); }
+      if (tr + 2 < n_trips) { B2T_LOAD_A(tr + 2); }
+      const int i0 = mb + 4 * (tr * NT + (int)threadIdx.x);
+      const int s4[4] = {srcC.x, srcC.y, srcC.z, srcC.w}, d4[4] = {dstC.x, dstC.y, dstC.z, dstC.w};
+      const float a4[4] = {acC.x, acC.y, acC.z, acC.w}, g4[4] = {grC.x, grC.y, grC.z, grC.w};
+      unsigned al_new = alC;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int li = i0 + k;
+        if (li < m0 || li >= m1 || !((alC >> (8 * k)) & 0xffu)) continue;
+        float lec = __uint_as_float(xB[d4[k] - b0]) + ((o2f(csC[k]) + a4[k] + g4[k]) - o2f(cB[d4[k] - b0]));
+        if (lec > o.lattice_beam) { al_new &= ~(0xffu << (8 * k)); continue; }
+        if (lec < 0.f) lec = 0.f;
+        atomicMin(&xA[s4[k] - a0], __float_as_uint(lec));
+      }
+      // (the word's other bytes, if any, are links of neighbouring segments: finished, or not started before the next barrier)
+      if (al_new != alC) { *reinterpret_cast<unsigned*>(l.link_alive + i0) = al_new; flags[2] = 1; }
+    }
+#undef B2T_LOAD_A
+#undef B2T_A_TO_B
+    __syncthreads();
+    FT(1);
+    for (int iter = 0; iter < 4096 && e1 > e0; ++iter) {
+      if (threadIdx.x == 0) flags[0] = 0;
+      __syncthreads();
+      for (int li = e1 - 1 - (int)threadIdx.x; li >= e0; li -= NT) {
+        if (!l.link_alive[li]) continue;
+        const int src = l.link_src[li], dst = l.link_dst[li];
+        const unsigned de = __hip_atomic_load(&xA[dst - a0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        float lec = __uint_as_float(de) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+        if (!(lec <= o.lattice_beam)) continue;
+        if (lec < 0.f) lec = 0.f;
+        const unsigned nb = __float_as_uint(lec);
+        if (nb < atomicMin(&xA[src - a0], nb)) flags[0] = 1;
+      }
+      __syncthreads();
+#ifdef B2T_FIN_TIMING
+      if (blockIdx.x == 0 && threadIdx.x == 0) ++fin_t[5];
+#endif
+      if (!flags[0]) break;
+      __syncthreads();
+    }
+    FT(2);
+    for (int li = e0 + threadIdx.x; li < e1; li += NT) {
+      if (!l.link_alive[li]) continue;
+      const int src = l.link_src[li], dst = l.link_dst[li];
+      const float lec = __uint_as_float(xA[dst - a0]) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+      if (lec > o.lattice_beam) { l.link_alive[li] = 0; flags[2] = 1; }
+    }
+    __syncthreads();
+    FT(3);
+    for (int t = a0 + threadIdx.x; t < a1; t += NT) {
+      unsigned nv = xA[t - a0];
+      if (final_frame && __uint_as_float(nv) > o.lattice_beam) nv = INF_BITS;
+      l.tok_extra[t] = nv;
+      const unsigned ov = l.tok_prev[t];
+      if (nv != ov && (nv == INF_BITS || ov == INF_BITS || fabsf(__uint_as_float(nv) - __uint_as_float(ov)) > delta)) flags[1] = 1;
+    }
+    __syncthreads();
+    FT(4);
+    return;
+  }
   for (int t = a0 + threadIdx.x; t < a1; t += NT) {
     float base = INFINITY;
     if (final_frame) {
@@ -1224,6 +1375,7 @@ __device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, 
     l.tok_extra[t] = __float_as_uint(base);
   }
   __syncthreads();
+  FT(0);
   // (4 links per thread and trip, every load of the four issued before the first use: the pass is a chain of dependent
   //  gathers -- link -> its two tokens -> their costs -- and one workgroup has to hide their latency by itself)
   for (int base = m0; base < m1; base += 4 * NT) {
@@ -1246,12 +1398,15 @@ __device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, 
     }
   }
   __syncthreads();
+  FT(1);
   // (the relaxation sweeps stay one link per thread and trip: batching four links' loads ahead of their updates doubled the
   //  kernel's time -- a sweep then propagates through fewer links of a chain and more sweeps are needed)
   for (int iter = 0; iter < 4096 && e1 > e0; ++iter) {
     if (threadIdx.x == 0) flags[0] = 0;
     __syncthreads();
-    for (int li = e0 + threadIdx.x; li < e1; li += NT) {
+    // newest links first: the closure appends the links of deeper tokens later, and extra costs flow from a link's destination
+    // to its source, so a sweep in creation order needs one pass per level of the closure and a backward sweep about one in all
+    for (int li = e1 - 1 - (int)threadIdx.x; li >= e0; li -= NT) {
       if (!l.link_alive[li]) continue;
       const int src = l.link_src[li], dst = l.link_dst[li];
       const unsigned de = __hip_atomic_load(&l.tok_extra[dst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1262,9 +1417,13 @@ __device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, 
       if (nb < atomicMin(&l.tok_extra[src], nb)) flags[0] = 1;
     }
     __syncthreads();
+#ifdef B2T_FIN_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) ++fin_t[5];
+#endif
     if (!flags[0]) break;
     __syncthreads();
   }
+  FT(2);
   for (int li = e0 + threadIdx.x; li < e1; li += NT) {
     if (!l.link_alive[li]) continue;
     const int src = l.link_src[li], dst = l.link_dst[li];
@@ -1272,6 +1431,7 @@ __device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, 
     if (lec > o.lattice_beam) { l.link_alive[li] = 0; flags[2] = 1; }
   }
   __syncthreads();
+  FT(3);
   for (int t = a0 + threadIdx.x; t < a1; t += NT) {
     unsigned nv = l.tok_extra[t];
     if (final_frame && __uint_as_float(nv) > o.lattice_beam) { nv = INF_BITS; l.tok_extra[t] = nv; }
@@ -1279,6 +1439,7 @@ __device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, 
     if (nv != ov && (nv == INF_BITS || ov == INF_BITS || fabsf(__uint_as_float(nv) - __uint_as_float(ov)) > delta)) flags[1] = 1;
   }
   __syncthreads();
+  FT(4);
 }
 }  // namespace
 
@@ -1287,6 +1448,7 @@ __device__ void prune_frame(const Lay& l, const Graph& g, const Opts& o, int f, 
 __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
                                                             int max_tok, int max_link, int hash) {
   __shared__ float redf[NT];
+  extern __shared__ unsigned prune_lds[];          // PRUNE_LDS_WORDS words (prune_frame's staging area)
   const int u = blockIdx.x;
   Lay l;
   layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
@@ -1310,7 +1472,12 @@ __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state,
   for (int li = threadIdx.x; li < min(l.h->n_link, max_link); li += NT) l.link_alive[li] = 1;
   __syncthreads();
   __shared__ int flags[3];
-  for (int f = F; f >= 0; --f) prune_frame(l, g, o, f, F, f == F, has_final, final_best, 0.f, flags);
+  for (int f = F; f >= 0; --f) prune_frame(l, g, o, f, F, f == F, has_final, final_best, 0.f, flags, prune_lds);
+#ifdef B2T_FIN_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("finalize (utterance 0, 100 MHz ticks): tokens-init %llu, emitting %llu, eps sweeps %llu (%llu sweeps), eps prune %llu, tokens %llu, frames %llu\n",
+           fin_t[0], fin_t[1], fin_t[2], fin_t[5], fin_t[3], fin_t[4], fin_t[6]);
+#endif
 }
 
 // PruneActiveTokens (lattice-faster-decoder.cc:516-545, called every prune_interval frames at :592-630) as a pass of its own
@@ -1323,9 +1490,11 @@ __global__ __launch_bounds__(NT) void wfst_finalize_kernel(Graph g, char* state,
 __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
                                                          int max_tok, int max_link, int hash, float delta, float min_fill) {
   __shared__ float redf[NT];
+  extern __shared__ unsigned prune_lds[];          // PRUNE_LDS_WORDS words (prune_frame's staging area)
   const int u = blockIdx.x;
-  Lay l;
-  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l);
+  Lay l0;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &l0);
+  const Lay l = l0;         // a copy, not a reference: see prune_frame
   const int F = l.h->n_frames;
   if (F < 2 || l.h->overflow || l.h->finalized) return;
   // memory-pressure policy (min_fill > 0): the pass only exists to bound memory, so an utterance whose arrays are still
@@ -1345,7 +1514,7 @@ __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, si
     __syncthreads();
     if (threadIdx.x == 0) flags[1] = 0;
     __syncthreads();
-    prune_frame(l, g, o, f, F, false, 0, 0.f, delta, flags);
+    prune_frame(l, g, o, f, F, false, 0, 0.f, delta, flags, prune_lds);
     if (!flags[1]) { f_stop = f; break; }
   }
   // ---- compaction of the tokens of frames f_stop+1 .. F-1 and of every link that starts in frame f_stop or later.
@@ -1607,7 +1776,7 @@ __global__ __launch_bounds__(LAT_NT) void wfst_lattice_arcs_kernel(Graph g, char
                                                                   float* a_graph, float* a_ac, int* f_state, float* f_cost) {
   __shared__ int wsum[2 * (LAT_NT / 64)];
   const LatCtx c = lat_ctx(state, state_bytes, max_frames, max_tok, max_link, hash);
-  const Lay& l = c.l;
+  const Lay l = c.l;        // a copy, not a reference: see prune_frame
   const int u = blockIdx.y;
   int base = 0, all = 0;
   for (int q = 0; q < LAT_P; ++q) { const int v = c.part[2 * q + 1]; if (q < c.p) base += v; all += v; }
@@ -1767,8 +1936,9 @@ extern "C" int b2t_wfst_best_path(const b2t_wfst_graph_t* g, const b2t_wfst_opts
 extern "C" int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream) {
   { int rc = check_args(g, o, state, U, "wfst_finalize"); if (rc) return rc; }
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
-  hipLaunchKernelGGL(wfst_finalize_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
-                     o->max_frames, o->max_tokens, o->max_links, o->hash_size);
+  allow_lds(wfst_finalize_kernel, PRUNE_LDS_WORDS * sizeof(unsigned));
+  hipLaunchKernelGGL(wfst_finalize_kernel, dim3(U), dim3(NT), PRUNE_LDS_WORDS * sizeof(unsigned), as_stream(stream), to_graph(g), (char*)state,
+                     sb, to_opts(o), o->max_frames, o->max_tokens, o->max_links, o->hash_size);
   B2T_CHECK_LAUNCH("b2t_wfst_finalize");
   return 0;
 }
@@ -1778,8 +1948,9 @@ extern "C" int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* 
   { int rc = check_args(g, o, state, U, "wfst_prune"); if (rc) return rc; }
   B2T_REQUIRE(delta >= 0.f && min_fill >= 0.f && min_fill <= 1.f, "wfst_prune: bad delta / min_fill");
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
-  hipLaunchKernelGGL(wfst_prune_kernel, dim3(U), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
-                     o->max_frames, o->max_tokens, o->max_links, o->hash_size, delta, min_fill);
+  allow_lds(wfst_prune_kernel, PRUNE_LDS_WORDS * sizeof(unsigned));
+  hipLaunchKernelGGL(wfst_prune_kernel, dim3(U), dim3(NT), PRUNE_LDS_WORDS * sizeof(unsigned), as_stream(stream), to_graph(g), (char*)state, sb,
+                     to_opts(o), o->max_frames, o->max_tokens, o->max_links, o->hash_size, delta, min_fill);
   B2T_CHECK_LAUNCH("b2t_wfst_prune");
   return 0;
 }

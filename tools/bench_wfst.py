@@ -204,8 +204,8 @@ def run():
     # (d) steady state over 6 batches with the host n-best of batch b running under the search of batch b + 1
     S2 = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.5, **big)
     pend, t0 = None, None
-    for b in range(7):
-        if b == 1:
+    for b in range(8):
+        if b == 2:                                 # both searchers have decoded one batch (first use touches the state blocks)
             torch.cuda.synchronize(); t0 = time.perf_counter()
         Sx = S if b % 2 == 0 else S2
         Sx.reset(); Sx.search(lp, lens)

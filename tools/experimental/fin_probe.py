@@ -34,6 +34,14 @@ def main():
 
     for rep in range(4):
         S.reset(); S.search(lp, lens); sync()
+        if rep == 0:
+            st = S.state.view(S.U, S.state_bytes)
+            F0 = int(S._header()[0, 0])
+            lo = st[0, S.off[3]:S.off[3] + 4 * (2 * F0 + 3)].contiguous().view(torch.int32).cpu().numpy()
+            to = st[0, S.off[2]:S.off[2] + 4 * (F0 + 2)].contiguous().view(torch.int32).cpu().numpy()
+            eps = lo[1:2 * F0 + 2:2] - lo[0:2 * F0 + 1:2]; emi = lo[2:2 * F0 + 2:2] - lo[1:2 * F0 + 1:2]
+            print("utt 0: frames", F0, "tokens/frame mean", np.diff(to[:F0 + 2]).mean().round(0), "max", np.diff(to[:F0 + 2]).max(),
+                  "| eps links/frame mean", eps.mean().round(0), "max", eps.max(), "| emitting links/frame mean", emi.mean().round(0), "max", emi.max())
         t = time.perf_counter()
         N.check(lib.b2t_wfst_finalize(C.byref(S.cg), C.byref(S.co), ops._p(S.state), S.U, S._s()), "fin"); t = tick("finalize_kernel", t)
         S.finalized = True
