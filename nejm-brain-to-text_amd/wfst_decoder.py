@@ -209,6 +209,12 @@ class WfstSearch:
             fut.set_result([[r] if self.frames_decoded()[u] > 0 else [] for u, r in enumerate(self.best_path(True))])
             return fut
         hdr = self._header()
+        prev = self.__dict__.get("_last_nbest")
+        if prev is not None and not prev.done():
+            try:
+                prev.exception()          # waits; whatever it raised was (or will be) delivered through that future
+            except BaseException:         # noqa: BLE001
+                pass
         cn, host = self._lattices()
         mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
         if WfstSearch._pool is None:
@@ -221,8 +227,21 @@ class WfstSearch:
             except BaseException as e:          # noqa: BLE001 -- delivered through the future
                 fut.set_exception(e)
         import threading
+        self._last_nbest = fut
         threading.Thread(target=job, daemon=True).start()
         return fut
+
+    def _pinned(self, rows: int, cols: int) -> torch.Tensor:
+        """Page-locked staging for the lattice copy, owned by this searcher and reused from utterance batch to utterance batch
+        (a fresh pinned allocation is a ~50 ms driver call; torch's caching host allocator hands one out whenever its blocks
+        are still referenced -- seen as one 80 ms finalize in six).  The previous batch's host n-best reads these buffers:
+        finalize_async waits for it before they are overwritten."""
+        pool = self.__dict__.setdefault("_pin_pool", {})
+        t = pool.get(rows)
+        if t is None or t.numel() < rows * cols:
+            t = torch.empty(rows * max(1024, int(cols * 1.5)), dtype=torch.int32, pin_memory=True)
+            pool[rows] = t
+        return t[:rows * cols].view(rows, cols)
 
     def _lattices(self, cap_arcs: int = 1 << 18, cap_final: int = 1 << 13):
         """The pruned lattices of all utterances, compacted on the GPU (b2t_wfst_lattice) and copied out once."""
@@ -253,7 +272,7 @@ class WfstSearch:
             n = torch.from_numpy(np.diff(off)).to(dev, non_blocking=True)
             base = torch.from_numpy(np.arange(U, dtype=np.int64) * cap - off[:-1]).to(dev, non_blocking=True)
             idx = torch.arange(tot, device=dev) + torch.repeat_interleave(base, n, output_size=tot)
-            host = torch.empty((slab.shape[0], tot), dtype=torch.int32, pin_memory=True)
+            host = self._pinned(slab.shape[0], tot)
             host.copy_(slab.view(slab.shape[0], -1).index_select(1, idx), non_blocking=True)
             return host
 
@@ -265,6 +284,12 @@ class WfstSearch:
 
     def _nbest_all(self, nbest: int):
         hdr = self._header()
+        prev = self.__dict__.get("_last_nbest")
+        if prev is not None and not prev.done():
+            try:
+                prev.exception()          # waits; whatever it raised was (or will be) delivered through that future
+            except BaseException:         # noqa: BLE001
+                pass
         cn, host = self._lattices()
         mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
         return self._nbest_host(nbest, hdr, cn, host, mapping_all)

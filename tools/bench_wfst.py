@@ -203,18 +203,30 @@ def run():
     alg_bytes = 16.0 * sum(S.arcs_expanded()) + 20.0 * created_tok + 21.0 * created_link
     # (d) steady state over 6 batches with the host n-best of batch b running under the search of batch b + 1
     S2 = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.5, **big)
-    pend, t0 = None, None
+    # a decode server freezes the interpreter's long-lived objects once it is set up: every n-best list is 10^4 new Python
+    # objects, and the full garbage collection they trigger now and then walks every tracked object of the process (torch,
+    # numpy, the graph: ~200 k) under the interpreter lock -- measured as one 60-90 ms finalize in ten without the freeze
+    import gc
+    gc.collect(); gc.freeze()
+    pend, t0, stamps = None, None, []
     for b in range(8):
         if b == 2:                                 # both searchers have decoded one batch (first use touches the state blocks)
             torch.cuda.synchronize(); t0 = time.perf_counter()
         Sx = S if b % 2 == 0 else S2
+        ta = time.perf_counter()
         Sx.reset(); Sx.search(lp, lens)
+        tb = time.perf_counter()
         f = Sx.finalize_async()
+        tc = time.perf_counter()
         if pend is not None:
             pend.result()
         pend = f
+        stamps.append((ta, tb, tc, time.perf_counter()))
     pend.result()
     pipelined_ms = (time.perf_counter() - t0) * 1e3 / 6
+    # per batch: enqueue of reset + search, finalize_async (waits for the GPU, copies the lattices out), wait for the PREVIOUS
+    # batch's host n-best
+    pipe_stages = [[round((y - x) * 1e3, 2) for x, y in zip(st[:-1], st[1:])] for st in stamps[2:]]
     del S2
     # the same search with one workgroup per utterance and every CU busy: 256 utterances in one call
     wide = None
@@ -258,6 +270,7 @@ def run():
                             finalize_gpu_ms=round(fin_gpu_ms, 2), nbest100_host_ms=round(nbest_ms, 2),
                             ms_per_utterance=round((search_ms + fin_gpu_ms + nbest_ms) / U, 3),
                             pipelined_ms_per_batch=round(pipelined_ms, 2), pipelined_ms_per_utterance=round(pipelined_ms / U, 3),
+                            pipelined_stages_ms_enqueue_finalize_wait=pipe_stages,
                             held_vs_created_tokens_with_pruning=round(sum(m["tokens"] for m in mem_ref) / max(1.0, created_tok), 3),
                             tokens_per_frame=round(tok_per_frame, 1), algorithmic_mb=round(alg_bytes / 1e6, 1),
                             achieved_gb_s=gbs(search_ms), achieved_gb_s_one_workgroup_per_utterance=gbs(search1_ms),

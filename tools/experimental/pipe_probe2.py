@@ -36,8 +36,14 @@ def main():
         marks.append(("nb0", time.perf_counter())); r = orig_nb(self, *a, **k); marks.append(("nb1", time.perf_counter())); return r
 
     WfstSearch._lattices = lat; WfstSearch._check_overflow = chk; WfstSearch._nbest_host = nb
+    import gc
+    gcl = []
+    def cb(phase, info):
+        if phase == "start": cb.t = time.perf_counter()
+        else: gcl.append((info["generation"], round((time.perf_counter() - cb.t) * 1e3, 2), info["collected"]))
+    gc.callbacks.append(cb)
     pend = None
-    for b in range(7):
+    for b in range(12):
         Sx = S[b % 2]
         marks.append((f"batch{b}", time.perf_counter()))
         Sx.reset(); Sx.search(lp, lens)
@@ -49,6 +55,9 @@ def main():
         marks.append(("pend_done", time.perf_counter()))
         pend = f
     pend.result()
+    bt = [t for n, t in marks if n.startswith("batch")]
+    print("batch durations ms:", [round((y - x) * 1e3, 1) for x, y in zip(bt[:-1], bt[1:])])
+    print("gc events (gen, ms, collected) over 1 ms:", [g for g in gcl if g[1] > 1.0], "n events", len(gcl), "tracked objects", len(gc.get_objects()))
     t0 = [t for n, t in marks if n == "batch3"][0]
     for n, t in marks:
         if t >= t0 and t < t0 + 0.13:
