@@ -651,27 +651,43 @@ def lexicon_fst_disambig(prons, word_id, sil_prob, sil_token, tok_disambig0, wor
     dis, mx = lex_disambig(prons)
     ndis = mx + 1                              # '#'$ndisambig with ndisambig = max + 1 is the silence disambiguation symbol
     f = Fst()
-    silcost, nosilcost = -math.log(sil_prob), -math.log(1.0 - sil_prob)
-    start, loop, sil, disst = f.add_state(), f.add_state(), f.add_state(), f.add_state()
-    f.start = start
-    f.add_arc(start, EPS, EPS, nosilcost, loop)
-    f.add_arc(start, sil_token, EPS, silcost, disst)
-    f.add_arc(sil, sil_token, EPS, 0.0, disst)
-    f.add_arc(disst, tok_disambig0 + ndis, EPS, 0.0, loop)
-    for w in sorted(prons):
-        for i, pron in enumerate(prons[w]):
-            seq = list(pron) + ([tok_disambig0 + dis[(w, i)]] if dis[(w, i)] else [])
-            s, wo = loop, word_id[w]
-            for k, p in enumerate(seq):
-                if k + 1 < len(seq):
-                    ns = f.add_state()
+    if not (0.0 <= sil_prob < 1.0):
+        raise ValueError("sil_prob must be in [0, 1)")
+    if sil_prob == 0.0:
+        # make_lexicon_fst.pl:62-98 (the script's default in ctc_compile_dict_token.sh:22): no optional silence, ONE state
+        # that is start, loop and final; the silence disambiguation symbol stays in tokens.txt but is on no arc
+        loop = f.add_state()
+        f.start = loop
+        for w in sorted(prons):
+            for i, pron in enumerate(prons[w]):
+                seq = list(pron) + ([tok_disambig0 + dis[(w, i)]] if dis[(w, i)] else [])
+                s, wo = loop, word_id[w]
+                for k, p in enumerate(seq):
+                    ns = f.add_state() if k + 1 < len(seq) else loop
                     f.add_arc(s, p, wo, 0.0, ns)
                     wo, s = EPS, ns
-                elif p != sil_token:
-                    f.add_arc(s, p, wo, nosilcost, loop)
-                    f.add_arc(s, p, wo, silcost, sil)
-                else:
-                    f.add_arc(s, p, wo, 0.0, loop)
+    else:
+        silcost, nosilcost = -math.log(sil_prob), -math.log(1.0 - sil_prob)
+        start, loop, sil, disst = f.add_state(), f.add_state(), f.add_state(), f.add_state()
+        f.start = start
+        f.add_arc(start, EPS, EPS, nosilcost, loop)
+        f.add_arc(start, sil_token, EPS, silcost, disst)
+        f.add_arc(sil, sil_token, EPS, 0.0, disst)
+        f.add_arc(disst, tok_disambig0 + ndis, EPS, 0.0, loop)
+        for w in sorted(prons):
+            for i, pron in enumerate(prons[w]):
+                seq = list(pron) + ([tok_disambig0 + dis[(w, i)]] if dis[(w, i)] else [])
+                s, wo = loop, word_id[w]
+                for k, p in enumerate(seq):
+                    if k + 1 < len(seq):
+                        ns = f.add_state()
+                        f.add_arc(s, p, wo, 0.0, ns)
+                        wo, s = EPS, ns
+                    elif p != sil_token:
+                        f.add_arc(s, p, wo, nosilcost, loop)
+                        f.add_arc(s, p, wo, silcost, sil)
+                    else:
+                        f.add_arc(s, p, wo, 0.0, loop)
     f.final[loop] = 0.0
     needs = set(f.final)
     for s, il, ol, w_, d in f.arcs:
