@@ -482,6 +482,20 @@ int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const int32_t* s
                            int n_final, const int32_t* final_state, const float* final_cost, int nbest, float beam,
                            int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
                            float* costs);
+/* HOST function: BrainSpeechDecoder::Rescore (brain_speech_decoder.cc:47-101 -- LatticeRescore with the graph's grammar at
+ * scale -1, then with the rescoring grammar at scale +1, then ShortestPath(n)) on the same pruned lattice: every word sequence
+ * W of the lattice gets graph(W) - G_old(W) + G_new(W) (each the cheapest route through the grammar, back-off arcs -- those
+ * carrying `backoff_label` on the input side -- free to take anywhere; final costs included), by composing the lattice with
+ * both grammars determinised on the fly; the n-best distinct word sequences are ranked by the NEW total cost among the
+ * sequences whose OLD cost is within `beam` of the best OLD cost (the contents of the reference's lat_).  g_old / g_new:
+ * b2t_fst_* handles, arc-sorted by ilabel.  Outputs as b2t_lattice_nbest_host (costs[2k] = the exchanged graph cost);
+ * stats4 (optional) = {product states, product arcs, determinised states of g_old, of g_new}. */
+int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
+                                   const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
+                                   int n_final, const int32_t* final_state, const float* final_cost,
+                                   const void* g_old, const void* g_new, int backoff_label, int nbest, float beam,
+                                   int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
+                                   float* costs, long long* stats4);
 /* HOST function: CtcWfstBeamSearch::ConvertToInputs (ctc_wfst_beam_search.cc:162-188) for the n alignments
  * ali[a_off[k] .. a_off[k+1]) that b2t_lattice_nbest_host returned: blanks (ilabel 1) dropped, repeats merged, ilabel - 1;
  * the time of a unit is the frame of its LAST repeated label -- mapping[position] (decoded frame -> input frame, F entries)

@@ -158,6 +158,8 @@ _SIGNATURES = {
     "b2t_wfst_state_offsets": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LL)]),
     "b2t_lattice_nbest_host": (C.c_int, [C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, C.c_int, VP, VP, C.c_int,
                                          C.c_float, VP, VP, C.c_int, VP, VP, C.c_int, VP]),
+    "b2t_lattice_rescore_nbest_host": (C.c_int, [C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, C.c_int,
+                                                 C.c_int, C.c_float, VP, VP, C.c_int, VP, VP, C.c_int, VP, VP]),
     "b2t_nbest_convert_to_inputs": (C.c_int, [VP, VP, C.c_int, VP, C.c_int, VP, VP, VP, C.c_int]),
     "b2t_lm_prologue_f32": (C.c_int, [VP, VP, C.c_float, VP, C.c_int, C.c_int, VP]),
     "b2t_beam_state_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <array>
 #include <deque>
 #include <string>
 #include <unordered_map>
@@ -659,4 +660,183 @@ extern "C" double b2t_fst_grammar_score(const void* h, const int32_t* words, int
   double best = INFINITY;
   for (auto& kv : cur) if (f.fin[(size_t)kv.first] != FINF) best = std::min(best, kv.second + (double)f.fin[(size_t)kv.first]);
   return best;
+}
+
+// ---- BrainSpeechDecoder::Rescore (brain_speech_decoder.cc:47-101) as lattice composition ------------------------------------
+// The reference composes the lattice with the grammar that is inside the decode graph at scale -1, determinises, composes with
+// the rescoring grammar at scale +1, determinises, and lists the n shortest paths.  Per word sequence W that amounts to
+//     graph(W) - min over routes of G_old(W) + min over routes of G_new(W),   acoustic(W) unchanged
+// (DeterminizeLattice keeps, per word sequence, the cheapest (path, route) pair; a route may take back-off arcs anywhere).
+// Done here on EVERY word sequence of the lattice, not on a list: each grammar is determinised lazily in the tropical semiring
+// along the words the lattice actually holds (a determinised state is the weighted set of grammar states a word prefix can be
+// in, closed under back-off arcs and normalised to residuals; for an n-gram grammar that is a history's back-off chain, so
+// the sets stay tiny and few), the lattice is multiplied with the two deterministic machines (product state = lattice
+// state x old set x new set; a lattice path then has exactly ONE route in each, so its exchanged cost is a plain sum and the
+// min / max conflict of subtracting a minimum disappears), and the n-best distinct word sequences of the product come from
+// the same best-first subset construction as the first pass (lattice.cpp), ranked by the new costs and confined to the
+// word sequences within `beam` of the best on the OLD costs (what GetLattice left in lat_ before Rescore() ran).
+namespace b2t {
+namespace {
+
+struct LmDet {
+  const HFst& g;
+  const int backoff;
+  struct St { std::vector<std::pair<int, double>> set; double fin; };      // sorted by grammar state; residuals (min = 0)
+  std::vector<St> states;
+  std::unordered_map<std::string, int> index;
+  std::unordered_map<uint64_t, std::pair<int, double>> memo;               // (state id, word) -> (state id or -1, cost)
+  LmDet(const HFst& f, int backoff_label) : g(f), backoff(backoff_label) {}
+
+  void range(int s, int label, int64_t& lo, int64_t& hi) const {
+    const HArc* p0 = g.arcs.data() + g.row[s];
+    const HArc* p1 = g.arcs.data() + g.row[(size_t)s + 1];
+    lo = std::lower_bound(p0, p1, label, [](const HArc& x, int l) { return x.il < l; }) - g.arcs.data();
+    hi = std::upper_bound(p0, p1, label, [](int l, const HArc& x) { return l < x.il; }) - g.arcs.data();
+  }
+  // closure under back-off arcs, normalisation, interning: -> (id, the minimum that was taken out)
+  std::pair<int, double> intern(std::vector<std::pair<int, double>>& v) {
+    std::unordered_map<int, double> d;
+    std::vector<int> st;
+    for (auto& kv : v) { auto it = d.find(kv.first); if (it == d.end() || kv.second < it->second) d[kv.first] = kv.second; }
+    for (auto& kv : d) st.push_back(kv.first);
+    while (!st.empty()) {
+      const int s = st.back(); st.pop_back();
+      const double c = d[s];
+      int64_t lo, hi;
+      range(s, backoff, lo, hi);
+      for (int64_t i = lo; i < hi; ++i) {
+        const HArc& a = g.arcs[(size_t)i];
+        auto it = d.find(a.nx);
+        if (it == d.end() || c + a.w < it->second) { d[a.nx] = c + a.w; st.push_back(a.nx); }
+      }
+    }
+    St n;
+    n.set.assign(d.begin(), d.end());
+    std::sort(n.set.begin(), n.set.end());
+    double m = INFINITY;
+    for (auto& kv : n.set) m = std::min(m, kv.second);
+    n.fin = INFINITY;
+    std::string key;
+    for (auto& kv : n.set) {
+      kv.second -= m;
+      const float r = (float)kv.second;                                     // residuals compared at float precision
+      key.append((const char*)&kv.first, sizeof(int)); key.append((const char*)&r, sizeof(float));
+      if (g.fin[(size_t)kv.first] != FINF) n.fin = std::min(n.fin, kv.second + (double)g.fin[(size_t)kv.first]);
+    }
+    auto it = index.find(key);
+    if (it != index.end()) return {it->second, m};
+    states.push_back(std::move(n));
+    index.emplace(std::move(key), (int)states.size() - 1);
+    return {(int)states.size() - 1, m};
+  }
+  int start() { std::vector<std::pair<int, double>> v{{g.start, 0.0}}; return intern(v).first; }
+  std::pair<int, double> step(int id, int word) {
+    const uint64_t k = ((uint64_t)(uint32_t)id << 32) | (uint32_t)word;
+    auto it = memo.find(k);
+    if (it != memo.end()) return it->second;
+    std::vector<std::pair<int, double>> v;
+    const size_t n = states[(size_t)id].set.size();
+    for (size_t q = 0; q < n; ++q) {
+      const std::pair<int, double> kv = states[(size_t)id].set[q];
+      int64_t lo, hi;
+      range(kv.first, word, lo, hi);
+      for (int64_t i = lo; i < hi; ++i) v.push_back({g.arcs[(size_t)i].nx, kv.second + (double)g.arcs[(size_t)i].w});
+    }
+    std::pair<int, double> r{-1, INFINITY};
+    if (!v.empty()) r = intern(v);
+    memo.emplace(k, r);
+    return r;
+  }
+};
+
+struct TripleHash {
+  size_t operator()(const std::array<int, 3>& t) const {
+    size_t h = 1469598103934665603ull;
+    for (int x : t) { h ^= (size_t)(unsigned)x; h *= 1099511628211ull; }
+    return h;
+  }
+};
+
+}  // namespace
+}  // namespace b2t
+
+int b2t_lattice_nbest_core(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
+                           const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
+                           const float* delta, int n_final, const int32_t* final_state, const float* final_cost,
+                           const float* final_delta, int nbest, float beam,
+                           int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
+                           float* costs);
+
+extern "C" int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
+                                              const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
+                                              int n_final, const int32_t* final_state, const float* final_cost,
+                                              const void* g_old, const void* g_new, int backoff_label, int nbest, float beam,
+                                              int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
+                                              float* costs, long long* stats4) {
+  using namespace b2t;
+  if (!g_old || !g_new || n_states <= 0 || start < 0 || start >= n_states || n_arcs < 0 || nbest <= 0) {
+    set_error("lattice_rescore: bad arguments");
+    return -1;
+  }
+  LmDet Lo(*CFST(g_old), backoff_label), Ln(*CFST(g_new), backoff_label);
+  // lattice adjacency
+  std::vector<int> off((size_t)n_states + 1, 0);
+  for (int i = 0; i < n_arcs; ++i) {
+    if (src[i] < 0 || src[i] >= n_states || dst[i] < 0 || dst[i] >= n_states) { set_error("lattice_rescore: arc %d out of range", i); return -1; }
+    ++off[(size_t)src[i] + 1];
+  }
+  for (int s = 0; s < n_states; ++s) off[(size_t)s + 1] += off[s];
+  std::vector<int> arc_of((size_t)n_arcs);
+  {
+    std::vector<int> po(off.begin(), off.end() - 1);
+    for (int i = 0; i < n_arcs; ++i) arc_of[(size_t)po[src[i]]++] = i;
+  }
+  std::vector<float> fin((size_t)n_states, FINF);
+  for (int i = 0; i < n_final; ++i) fin[(size_t)final_state[i]] = std::min(fin[(size_t)final_state[i]], final_cost[i]);
+  // product states in discovery order
+  std::unordered_map<std::array<int, 3>, int, TripleHash> pid;
+  std::vector<std::array<int, 3>> pst;
+  auto state_of = [&](int l, int o, int n) {
+    const std::array<int, 3> k{l, o, n};
+    auto it = pid.find(k);
+    if (it != pid.end()) return it->second;
+    pst.push_back(k);
+    pid.emplace(k, (int)pst.size() - 1);
+    return (int)pst.size() - 1;
+  };
+  std::vector<int32_t> psrc, pdst, pil, pol;
+  std::vector<float> pg, pa, pd;
+  state_of(start, Lo.start(), Ln.start());
+  for (size_t q = 0; q < pst.size(); ++q) {
+    const std::array<int, 3> k = pst[q];
+    for (int e = off[(size_t)k[0]]; e < off[(size_t)k[0] + 1]; ++e) {
+      const int i = arc_of[(size_t)e];
+      int o = k[1], n = k[2];
+      double d = 0.0;
+      if (olabel[i] != 0) {
+        const std::pair<int, double> so = Lo.step(k[1], olabel[i]);
+        const std::pair<int, double> sn = Ln.step(k[2], olabel[i]);
+        if (so.first < 0 || sn.first < 0) continue;            // a word one of the grammars does not accept: the composition drops the path
+        o = so.first; n = sn.first; d = sn.second - so.second;
+      }
+      const int t = state_of(dst[i], o, n);
+      psrc.push_back((int32_t)q); pdst.push_back(t); pil.push_back(ilabel[i]); pol.push_back(olabel[i]);
+      pg.push_back((float)((double)graph[i] + d)); pa.push_back(acoustic[i]); pd.push_back((float)d);
+    }
+  }
+  std::vector<int32_t> fst_;
+  std::vector<float> fc, fd;
+  for (size_t q = 0; q < pst.size(); ++q) {
+    const std::array<int, 3> k = pst[q];
+    if (fin[(size_t)k[0]] == FINF) continue;
+    const double fo = Lo.states[(size_t)k[1]].fin, fn = Ln.states[(size_t)k[2]].fin;
+    if (fo == INFINITY || fn == INFINITY) continue;
+    fst_.push_back((int32_t)q); fc.push_back((float)((double)fin[(size_t)k[0]] + fn - fo)); fd.push_back((float)(fn - fo));
+  }
+  if (stats4) { stats4[0] = (long long)pst.size(); stats4[1] = (long long)psrc.size(); stats4[2] = (long long)Lo.states.size(); stats4[3] = (long long)Ln.states.size(); }
+  w_off[0] = 0; a_off[0] = 0;
+  if (fst_.empty()) return 0;
+  return b2t_lattice_nbest_core((int)pst.size(), 0, (int)psrc.size(), psrc.data(), pdst.data(), pil.data(), pol.data(), pg.data(), pa.data(),
+                                pd.data(), (int)fst_.size(), fst_.data(), fc.data(), fd.data(), nbest, beam, out_words, w_off, w_cap,
+                                out_ali, a_off, a_cap, costs);
 }

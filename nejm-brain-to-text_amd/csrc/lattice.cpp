@@ -19,18 +19,18 @@
 
 namespace {
 
-struct Arc { int il, ol, dst; float g, a; };
-struct Entry { double tot, gr, ac; int ali; };          // ali: node of the alignment list (-1 = empty)
+struct Arc { int il, ol, dst; float g, a, d; };         // d: the part of g that a rescoring pass exchanged (0 otherwise)
+struct Entry { double tot, gr, ac; int ali; double dl; };   // ali: node of the alignment list (-1 = empty); dl: sum of d so far
 struct Node { int parent, label; };
 struct Subset { std::vector<int> st; std::vector<Entry> en; };   // lattice states and their best entries, insertion order
-struct Trans { int ol, dst; double tot, gr, ac; int ali, il; };   // a word arc out of a subset
+struct Trans { int ol, dst; double tot, gr, ac; int ali, il; double dl; };   // a word arc out of a subset
 
 // Work arrays of a call, kept per host thread: a 175 k-arc lattice needs ~7 MB of them, and fresh allocations of that size are
 // mapped and unmapped by the allocator on every call (~1700 page faults, a fifth of the call).
 struct Scratch {
   std::vector<int> out_off, pending, po, order, rank, slot;
   std::vector<Arc> out_arc;
-  std::vector<double> fin, beta;
+  std::vector<double> fin, beta, fin_o, beta_o;
 };
 
 struct Item {
@@ -44,11 +44,17 @@ struct Item {
 
 }  // namespace
 
-extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
-                                      const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
-                                      int n_final, const int32_t* final_state, const float* final_cost, int nbest, float beam,
-                                      int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
-                                      float* costs) {
+// `delta` / `final_delta` (both or neither): the lattice has been through a rescoring exchange (b2t_lattice_rescore_nbest_host
+// below) that moved graph[i] by delta[i] and a final cost by final_delta[i].  The answers are then ranked by the costs as given
+// (the NEW ones), while `beam` keeps its meaning on the OLD ones (graph - delta): a word sequence takes part iff its best OLD
+// path is within `beam` of the best OLD path, which is what the reference's GetLattice left in lat_ before Rescore() ran.
+// Precondition: the accumulated delta of a path depends on its word sequence only (true for the product lattice built below).
+int b2t_lattice_nbest_core(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
+                           const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
+                           const float* delta, int n_final, const int32_t* final_state, const float* final_cost,
+                           const float* final_delta, int nbest, float beam,
+                           int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
+                           float* costs) {
   if (n_states <= 0 || start < 0 || start >= n_states || n_arcs < 0 || nbest <= 0 || !w_off || !a_off || !costs) {
     b2t::set_error("lattice_nbest: bad arguments");
     return -1;
@@ -73,12 +79,19 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
     std::vector<int>& po = tls.po;
     po.assign(out_off.begin(), out_off.end() - 1);
     for (int i = 0; i < n_arcs; ++i)                          // arc order within a state = input order (deterministic ties)
-      out_arc[po[src[i]]++] = Arc{ilabel[i], olabel[i], dst[i], graph[i], acoustic[i]};
+      out_arc[po[src[i]]++] = Arc{ilabel[i], olabel[i], dst[i], graph[i], acoustic[i], delta ? delta[i] : 0.f};
   }
   const auto ts2 = std::chrono::steady_clock::now();
   std::vector<double>& fin = tls.fin; std::vector<double>& beta = tls.beta;
   fin.assign(n_states, INF); beta.assign(n_states, INF);
   for (int i = 0; i < n_final; ++i) fin[final_state[i]] = std::min(fin[final_state[i]], (double)final_cost[i]);
+  const bool resc = delta != nullptr;
+  if (resc && !final_delta) { b2t::set_error("lattice_nbest: delta without final_delta"); return -1; }
+  std::vector<double>& fin_o = tls.fin_o; std::vector<double>& beta_o = tls.beta_o;   // the OLD costs' counterparts (rescoring only)
+  if (resc) {
+    fin_o.assign(n_states, INF); beta_o.assign(n_states, INF);
+    for (int i = 0; i < n_final; ++i) fin_o[final_state[i]] = std::min(fin_o[final_state[i]], (double)final_cost[i] - (double)final_delta[i]);
+  }
   // beta: cheapest completion incl. the final cost.  The lattice is acyclic, so one sweep in reverse topological order (Kahn,
   // O(states + arcs)) gives it EXACTLY, whatever the sign of the arc costs (an acoustic cost logp - log_prior can be negative
   // after the DecodeNumpy prologue; an over-estimated beta would prune valid paths below).  rank[s] = position of s in the
@@ -107,7 +120,19 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       }
       beta[s] = b;
     }
+    if (resc)
+      for (int h = n_states - 1; h >= 0; --h) {
+        const int s = order[h];
+        double b = fin_o[s];
+        for (int k = out_off[s]; k < out_off[s + 1]; ++k) {
+          const Arc& a = out_arc[k];
+          const double c = beta_o[a.dst] + ((double)a.g + (double)a.a - (double)a.d);
+          if (c < b) b = c;
+        }
+        beta_o[s] = b;
+      }
   } else {
+    if (resc) { b2t::set_error("lattice_nbest: a rescored lattice must be acyclic"); return -1; }
     std::vector<int> rev_off(n_states + 1, 0);
     for (int i = 0; i < n_arcs; ++i) ++rev_off[dst[i] + 1];
     for (int s = 0; s < n_states; ++s) rev_off[s + 1] += rev_off[s];
@@ -133,6 +158,7 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   const auto tm0 = std::chrono::steady_clock::now();
   w_off[0] = 0; a_off[0] = 0;
   if (beta[start] == INF) return 0;
+  if (resc && beta_o[start] == INF) return 0;
   // Everything costlier than `limit` is dropped: at first the lattice beam; once `nbest` complete word sequences are known
   // (each with the exact cost of its best path), the cost of the worst of the best `nbest` of them -- nothing above it can be
   // among the answers, and the closures of the subsets still to be expanded shrink accordingly.
@@ -140,7 +166,7 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   // `nbest` answers well inside the beam, and a run that returns `nbest` sequences under a smaller limit returns exactly what
   // the full beam would (best-first order; everything it dropped costs more than all of them).  Only a run that comes back
   // short is repeated with the whole beam.  (32 lattices of the bench workload, one thread: 131 -> 6x ms.)
-  double limit = 0;
+  double limit = 0, limit_o = 0;   // limit_o: the beam on the OLD costs (rescoring only)
   std::priority_queue<double> known;       // the `nbest` smallest totals of the finished sequences found so far
   std::vector<Node> ali_pool, word_pool;
   auto push_node = [](std::vector<Node>& pool, int parent, int label) { pool.push_back(Node{parent, label}); return (int)pool.size() - 1; };
@@ -167,9 +193,10 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
           if (a.ol != 0) continue;
           const double nt = e.tot + a.g + a.a;
           if (nt + beta[a.dst] > limit) continue;
+          if (resc && nt - (e.dl + a.d) + beta_o[a.dst] > limit_o) continue;
           const int j = slot[a.dst];
           if (j >= 0 && !(nt < sub.en[j].tot)) continue;
-          const Entry ne{nt, e.gr + a.g, e.ac + a.a, a.il ? push_node(ali_pool, e.ali, a.il) : e.ali};
+          const Entry ne{nt, e.gr + a.g, e.ac + a.a, a.il ? push_node(ali_pool, e.ali, a.il) : e.ali, e.dl + a.d};
           if (j < 0) {
             slot[a.dst] = (int)sub.st.size(); sub.st.push_back(a.dst); sub.en.push_back(ne);
             heap.push_back(rank[a.dst]); std::push_heap(heap.begin(), heap.end(), std::greater<int>());
@@ -192,7 +219,7 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
         if (nt + beta[a.dst] > limit) continue;
         const int j = slot[a.dst];
         if (j >= 0 && !(nt < sub.en[j].tot)) continue;
-        const Entry ne{nt, e.gr + a.g, e.ac + a.a, a.il ? push_node(ali_pool, e.ali, a.il) : e.ali};
+        const Entry ne{nt, e.gr + a.g, e.ac + a.a, a.il ? push_node(ali_pool, e.ali, a.il) : e.ali, e.dl + a.d};
         if (j < 0) { slot[a.dst] = (int)sub.st.size(); sub.st.push_back(a.dst); sub.en.push_back(ne); }
         else sub.en[j] = ne;
         pq.push({nt, a.dst});
@@ -215,14 +242,15 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
   int n_out = 0;
   double t_closure = 0; size_t n_pop = 0, n_clo = 0, n_trans = 0;
   static const double STAGE[3] = {0.5, 0.75, 1.0};
-  for (int stage = 0; stage < 3; ++stage) {
+  for (int stage = resc ? 2 : 0; stage < 3; ++stage) {      // a rescored lattice is ranked by other costs than its beam: one run
   if (stage > 0 && n_out >= nbest) break;
-  limit = beta[start] + STAGE[stage] * (double)beam + 1e-4;
+  limit = resc ? INF : beta[start] + STAGE[stage] * (double)beam + 1e-4;
+  limit_o = resc ? beta_o[start] + (double)beam + 1e-4 : INF;
   known = std::priority_queue<double>(); pq = std::priority_queue<Item>();
   subsets.clear(); pool_st.clear(); pool_en.clear(); finished.clear(); ali_pool.clear(); word_pool.clear();
   long long tie = 0;
   subsets.push_back(Span{0, 1});
-  pool_st.push_back(start); pool_en.push_back(Entry{0.0, 0.0, 0.0, -1});
+  pool_st.push_back(start); pool_en.push_back(Entry{0.0, 0.0, 0.0, -1, 0.0});
   pq.push(Item{beta[start], 0, tie++, -1, 0});
   n_out = 0;
   while (!pq.empty() && n_out < nbest) {
@@ -261,6 +289,7 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
       if (fin[st] == INF) continue;
       const Entry& e = sub.en[i];
       const double c = e.tot + fin[st];
+      if (resc && e.tot - e.dl + fin_o[st] > limit_o) continue;
       if (c < best.tot) { best = Done{c, e.gr + fin[st], e.ac, it.words, e.ali}; has = true; }
     }
     if (has && best.tot <= limit) {
@@ -279,7 +308,8 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
         if (a.ol == 0) continue;
         const double nt = e.tot + a.g + a.a;
         if (nt + beta[a.dst] > limit) continue;
-        trans.push_back(Trans{a.ol, a.dst, nt, e.gr + a.g, e.ac + a.a, e.ali, a.il});
+        if (resc && nt - (e.dl + a.d) + beta_o[a.dst] > limit_o) continue;
+        trans.push_back(Trans{a.ol, a.dst, nt, e.gr + a.g, e.ac + a.a, e.ali, a.il, e.dl + a.d});
       }
     }
     n_trans += trans.size();
@@ -295,7 +325,7 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
         const Trans& tr = trans[keyed[q].second];
         const int j = slot[tr.dst];
         if (j >= 0 && !(tr.tot < tgt.en[j].tot)) continue;
-        const Entry ne{tr.tot, tr.gr, tr.ac, tr.il ? push_node(ali_pool, tr.ali, tr.il) : tr.ali};
+        const Entry ne{tr.tot, tr.gr, tr.ac, tr.il ? push_node(ali_pool, tr.ali, tr.il) : tr.ali, tr.dl};
         if (j < 0) { slot[tr.dst] = (int)tgt.st.size(); tgt.st.push_back(tr.dst); tgt.en.push_back(ne); }
         else tgt.en[j] = ne;
       }
@@ -318,6 +348,15 @@ extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const
             std::chrono::duration<double, std::milli>(tm0 - tm_in).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count(), subsets.size(), ali_pool.size(), ents, n_pop, t_closure, n_clo, n_trans);
   }
   return n_out;
+}
+
+extern "C" int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
+                                      const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
+                                      int n_final, const int32_t* final_state, const float* final_cost, int nbest, float beam,
+                                      int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
+                                      float* costs) {
+  return b2t_lattice_nbest_core(n_states, start, n_arcs, src, dst, ilabel, olabel, graph, acoustic, nullptr, n_final, final_state,
+                                final_cost, nullptr, nbest, beam, out_words, w_off, w_cap, out_ali, a_off, a_cap, costs);
 }
 
 extern "C" int b2t_nbest_convert_to_inputs(const int32_t* ali, const int32_t* a_off, int n, const int32_t* mapping, int F,

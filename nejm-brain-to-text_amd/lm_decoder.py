@@ -250,22 +250,24 @@ class BrainSpeechDecoder:
             self._wfst_results(self.wfst.finalize()[0])
         # (CtcPrefixBeamSearch::FinalizeSearch is a no-op, ctc_prefix_beam_search.h)
 
-    def Rescore(self):
+    def Rescore(self, deep_list: int = 0):
         """brain_speech_decoder.cc:61-101: take the scores of the grammar that is composed into the graph out of the
-        lattice and put the scores of the rescoring grammar in (two lattice compositions in the reference), then list the
-        n-best again.  Here the exchange is done per word sequence on a DEEP n-best list of the same pruned lattice
-        (lattice composition with a deterministic-per-sequence grammar changes each sequence's graph cost by exactly
-        G_new(W) - G_old(W)); the list is then re-ranked and cut to the previous length.  An approximation of the
-        reference's lattice composition: a sequence outside the deep list (10 x the requested length, at least 500) cannot
-        be promoted into the result however much the new grammar likes it.  Grammar scores are computed in C++ on CSR
-        arrays (b2t_fst_grammar_score: one bisection per (state, word))."""
+        lattice and put the scores of the rescoring grammar in (LatticeRescore at scale -1, then at scale +1: two lattice
+        compositions + determinisations), then list the n-best again.  Done as the reference does it, on the LATTICE
+        (b2t_lattice_rescore_nbest_host, csrc/graphc.cpp): both grammars are determinised on the fly along the lattice's words,
+        the lattice is composed with them, and the n-best distinct word sequences of the product are ranked by the new cost --
+        every word sequence of the pruned lattice takes part, so the new grammar can promote one from arbitrarily far down.
+        deep_list > 0 selects the round-2 approximation instead (the exchange on an n-best list of that length; kept for the
+        comparison in tests/test_gpu_wfst.py)."""
         if self.wfst is None:
             raise RuntimeError("Rescore() needs the WFST searcher (load a decode graph)")
         if self.res.lm_fst is None or self.res.rescore_lm_fst is None or self.res.backoff_label is None:
             raise RuntimeError("Rescore() needs both grammars (DecodeResource lm_fst_path / rescore_lm_fst_path or set_rescore_grammars)")
-        import wfst
         keep = len(self._result)
-        deep = self.wfst._nbest_all(max(10 * keep, 500))[0]
+        if not deep_list:
+            self._wfst_results(self.wfst._nbest_all(keep, rescore=(self.res.lm_fst, self.res.rescore_lm_fst, self.res.backoff_label))[0])
+            return
+        deep = self.wfst._nbest_all(max(deep_list, keep))[0]
         rescored = []
         for inp, tm, words, lm, ac in deep:
             g_old = self.res.lm_fst.grammar_score(words, self.res.backoff_label)

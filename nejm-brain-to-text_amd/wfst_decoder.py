@@ -282,7 +282,9 @@ class WfstSearch:
         flat = [ha[0], ha[1], ha[2], ha[3], ha[4].view(np.float32), ha[5].view(np.float32), hf[0], hf[1].view(np.float32)]
         return cn, (flat, a_off, f_off)
 
-    def _nbest_all(self, nbest: int):
+    def _nbest_all(self, nbest: int, rescore=None):
+        """rescore = (old grammar, new grammar, back-off label), wfst.HostFst handles arc-sorted by ilabel: the n-best of the lattice
+        composed with both (BrainSpeechDecoder::Rescore, b2t_lattice_rescore_nbest_host) instead of the lattice's own."""
         hdr = self._header()
         prev = self.__dict__.get("_last_nbest")
         if prev is not None and not prev.done():
@@ -292,9 +294,9 @@ class WfstSearch:
                 pass
         cn, host = self._lattices()
         mapping_all = self.state.view(self.U, self.state_bytes)[:, self.off[1]:self.off[1] + 4 * (self.caps[0] + 1)].contiguous().view(torch.int32).cpu().numpy()
-        return self._nbest_host(nbest, hdr, cn, host, mapping_all)
+        return self._nbest_host(nbest, hdr, cn, host, mapping_all, rescore)
 
-    def _nbest_host(self, nbest, hdr, cn, host, mapping_all):
+    def _nbest_host(self, nbest, hdr, cn, host, mapping_all, rescore=None):
         """Host half of FinalizeSearch: nothing here touches the device or this object's state block."""
         (src, dst, il, ol, gr, ac, fs, fc), a_off, f_off = host
         # Everything a worker does outside the two C calls holds the interpreter lock, i.e. is serial across the utterances'
@@ -324,10 +326,17 @@ class WfstSearch:
             if F == 0 or n_states == 0 or start < 0:
                 return []
             ao, fo = 4 * a_off_l[u], 4 * f_off_l[u]
-            n = self.lib.b2t_lattice_nbest_host(n_states, start, n_arcs, base["src"] + ao, base["dst"] + ao, base["il"] + ao, base["ol"] + ao,
-                                                base["gr"] + ao, base["ac"] + ao, n_final, base["fs"] + fo, base["fc"] + fo, nbest, beam,
-                                                row("ow", u, cap), row("woff", u, nbest + 1), cap, row("oa", u, cap),
-                                                row("aoff", u, nbest + 1), cap, row("costs", u, 2 * nbest))
+            if rescore is None:
+                n = self.lib.b2t_lattice_nbest_host(n_states, start, n_arcs, base["src"] + ao, base["dst"] + ao, base["il"] + ao, base["ol"] + ao,
+                                                    base["gr"] + ao, base["ac"] + ao, n_final, base["fs"] + fo, base["fc"] + fo, nbest, beam,
+                                                    row("ow", u, cap), row("woff", u, nbest + 1), cap, row("oa", u, cap),
+                                                    row("aoff", u, nbest + 1), cap, row("costs", u, 2 * nbest))
+            else:
+                n = self.lib.b2t_lattice_rescore_nbest_host(n_states, start, n_arcs, base["src"] + ao, base["dst"] + ao, base["il"] + ao,
+                                                            base["ol"] + ao, base["gr"] + ao, base["ac"] + ao, n_final, base["fs"] + fo,
+                                                            base["fc"] + fo, rescore[0]._h, rescore[1]._h, int(rescore[2]), nbest, beam,
+                                                            row("ow", u, cap), row("woff", u, nbest + 1), cap, row("oa", u, cap),
+                                                            row("aoff", u, nbest + 1), cap, row("costs", u, 2 * nbest), None)
             if n < 0:
                 raise RuntimeError("b2t_lattice_nbest_host failed: " + N.last_error())
             # ConvertToInputs (ctc_wfst_beam_search.cc:162-188) for the n entries in one host call as well

@@ -359,6 +359,15 @@ def test_lm_decoder_surface_with_a_graph(toy, tmp_path):
             ids = r.word_ids
             delta = wfst.grammar_score(G_old, ids, wd0) - wfst.grammar_score(G_new, ids, wd0)
             assert abs(r.lm_score - (before[r.sentence][0] + delta)) < TOL and abs(r.ac_score - before[r.sentence][1]) < 1e-4
+    # Rescore() composes the LATTICE with both grammars (b2t_lattice_rescore_nbest_host); the exchange on an exhaustive list of
+    # the same lattice (the round-2 form, deep_list) must give the same ranking and scores
+    after_scores = [(r.sentence, r.lm_score, r.ac_score) for r in after]
+    dec.Rescore(deep_list=100000)
+    listed = dec.result()
+    assert len(listed) == len(after_scores)
+    for (s1, lm1, ac1), r2 in zip(after_scores, listed):
+        assert abs((lm1 + ac1 * 0.325) - (r2.lm_score + r2.ac_score * 0.325)) < TOL
+    assert [s for s, _, _ in after_scores][0] == listed[0].sentence
     dec.Reset()
     assert dec.result() == [] and not dec.DecodedSomething()
     lm_decoder.DecodeNumpyLogProbs(dec, lp.astype(np.float32))

@@ -105,3 +105,151 @@ def test_unreachable_and_single_state():
     assert host_nbest(3, 0, [0], [1], [2], [7], [0.5], [0.5], [2], [0.0], 5, 8.0) == []
     got = host_nbest(1, 0, [], [], [], [], [], [], [0], [1.5], 5, 8.0)
     assert got == [((), 1.5, 0.0, ())]
+
+
+# ---- BrainSpeechDecoder::Rescore as lattice composition (b2t_lattice_rescore_nbest_host, csrc/graphc.cpp) --------------------------
+def host_rescore(n_states, start, src, dst, il, ol, gr, ac, fs, fc, g_old, g_new, backoff, nbest, beam, cap=1 << 16):
+    lib = N.load()
+    A = [np.ascontiguousarray(x, dtype=t) for x, t in ((src, np.int32), (dst, np.int32), (il, np.int32), (ol, np.int32), (gr, np.float32), (ac, np.float32))]
+    fs, fc = np.ascontiguousarray(fs, np.int32), np.ascontiguousarray(fc, np.float32)
+    ow, oa = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    woff, aoff, costs = np.zeros(nbest + 1, np.int32), np.zeros(nbest + 1, np.int32), np.zeros(2 * nbest, np.float32)
+    stats = np.zeros(4, np.int64)
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    k = lib.b2t_lattice_rescore_nbest_host(n_states, start, len(A[0]), P(A[0]), P(A[1]), P(A[2]), P(A[3]), P(A[4]), P(A[5]), len(fs), P(fs), P(fc),
+                                           g_old._h, g_new._h, backoff, nbest, C.c_float(beam), P(ow), P(woff), cap, P(oa), P(aoff), cap, P(costs),
+                                           P(stats))
+    assert k >= 0, N.last_error()
+    return [(tuple(ow[woff[j]:woff[j + 1]].tolist()), float(costs[2 * j]), float(costs[2 * j + 1]), tuple(oa[aoff[j]:aoff[j + 1]].tolist()))
+            for j in range(k)], stats
+
+
+def reference_rescore(n_states, start, src, dst, il, ol, gr, ac, fs, fc, G_old, G_new, backoff, nbest, beam):
+    """brain_speech_decoder.cc:47-101 by enumeration.  lat_ (ctc_wfst_beam_search.cc:138-141: GetLattice = determinised, pruned
+    with lattice_beam) holds ONE path per word sequence, the cheapest, for the sequences within the beam.  LatticeRescore(-1):
+    graph := -graph; compose with G_old (a route may take back-off arcs anywhere); DeterminizeLattice keeps the cheapest (path,
+    route) per word sequence = -graph + min-route G_old; graph := -graph again  ->  graph - G_old(W).  LatticeRescore(+1) adds
+    min-route G_new(W).  ShortestPath(n) on graph + acoustic."""
+    import wfst
+    out = [[] for _ in range(n_states)]
+    for i in range(len(src)):
+        out[int(src[i])].append(i)
+    fin = {}
+    for s, c in zip(fs, fc):
+        fin[int(s)] = min(fin.get(int(s), float("inf")), float(np.float32(c)))
+    best = {}
+
+    def walk(s, words, ali, g, a):
+        if s in fin:
+            t = (g + fin[s] + a, g + fin[s], a, ali)
+            if words not in best or t[0] < best[words][0]:
+                best[words] = t
+        for i in out[s]:
+            walk(int(dst[i]), words + ((int(ol[i]),) if ol[i] else ()), ali + ((int(il[i]),) if il[i] else ()),
+                 g + float(np.float32(gr[i])), a + float(np.float32(ac[i])))
+    walk(start, (), (), 0.0, 0.0)
+    if not best:
+        return []
+    cut = min(t[0] for t in best.values()) + beam
+    res = []
+    for words, (tot, g, a, ali) in best.items():
+        if tot > cut:
+            continue
+        go, gn = wfst.grammar_score(G_old, list(words), backoff), wfst.grammar_score(G_new, list(words), backoff)
+        if not (np.isfinite(go) and np.isfinite(gn)):
+            continue
+        res.append((words, g - go + gn, a, ali))
+    res.sort(key=lambda e: e[1] + e[2])
+    return res[:nbest]
+
+
+@pytest.mark.parametrize("seed,n,nbest,beam", [(0, 24, 10, 3.0), (1, 28, 25, 5.0), (2, 30, 200, 100.0), (3, 26, 5, 1.5), (4, 22, 40, 8.0)])
+def test_rescore_by_lattice_composition_against_enumeration(seed, n, nbest, beam):
+    import ngram_lm
+    import wfst
+    rs = np.random.RandomState(100 + seed)
+    vocab = [f"w{k}" for k in range(6)]
+    table = ["<eps>"] + vocab + ["#0", "<s>", "</s>"]
+    word_id = {w: i for i, w in enumerate(table) if 0 < i <= len(vocab)}
+    wd0 = table.index("#0")
+    # two back-off grammars of different order over the same words: the graph's (2-gram) and the rescoring one (3-gram)
+    G_old = wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 2, 14, seed=seed), word_id, wd0)
+    G_new = wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 3, 30, seed=50 + seed), word_id, wd0)
+    H_old, H_new = wfst.HostFst.from_fst(G_old).arcsort(), wfst.HostFst.from_fst(G_new).arcsort()
+    src, dst, il, ol, gr, ac = [], [], [], [], [], []
+    for s in range(n - 1):
+        for _ in range(2):
+            d = rs.randint(s + 1, min(n, s + 4))
+            src.append(s); dst.append(d); il.append(int(rs.randint(0, 6))); ol.append(int(rs.choice([0, 0, 1, 2, 3, 4, 5, 6])))
+            gr.append(float(rs.rand() * 2)); ac.append(float(rs.rand() * 3 - 1.0))
+    perm = rs.permutation(n)
+    src, dst = perm[np.array(src)], perm[np.array(dst)]
+    fs = perm[np.array([n - 1, n - 2])]; fc = np.array([0.3, 0.0], np.float32)
+    args = (n, int(perm[0]), src, dst, il, ol, gr, ac, fs, fc)
+    got, stats = host_rescore(*args, H_old, H_new, wd0, nbest, beam)
+    want = reference_rescore(*args, G_old, G_new, wd0, nbest, beam)
+    assert len(want) > 0 and len(got) == len(want), (len(got), len(want))
+    tot_g = np.array([g + a for _, g, a, _ in got]); tot_w = np.array([g + a for _, g, a, _ in want])
+    np.testing.assert_allclose(tot_g, tot_w, rtol=0, atol=3e-4)
+    n_checked = 0
+    for j, (gw, ww) in enumerate(zip(got, want)):
+        tied = (j > 0 and abs(tot_w[j] - tot_w[j - 1]) < 1e-3) or (j + 1 < len(want) and abs(tot_w[j + 1] - tot_w[j]) < 1e-3)
+        if tied:
+            continue
+        assert gw[0] == ww[0], f"entry {j}: words differ"
+        assert abs(gw[1] - ww[1]) < 3e-4 and abs(gw[2] - ww[2]) < 3e-4
+        n_checked += 1
+    assert n_checked >= min(3, len(want)) and len({w for w, _, _, _ in got}) == len(got)
+    assert stats[0] >= n // 2 and stats[2] >= 2 and stats[3] >= 2            # it did build a product with several grammar states
+    # the exchange matters on this lattice: the rescored order is not the first-pass order
+    first = host_nbest(*args, max(nbest, 50), beam)
+    if len(want) >= 3:
+        assert [w for w, _, _, _ in first[:len(got)]] != [w for w, _, _, _ in got] or seed == 3
+
+
+def test_rescore_real_lattice_promotes_from_below_the_list():
+    """On a real lattice (one utterance of the bench workload, 9329 arcs) with a rescoring grammar that strongly prefers some
+    words: the composition ranks over ALL sequences of the lattice, so it must (a) contain, for every entry of a very deep
+    first-pass list, the exchanged score the list-based exchange computes, in the right place, and (b) equal the list-based
+    exchange when that list is deep enough to hold everything within the beam."""
+    import ngram_lm
+    import wfst
+    Z = np.load(os.path.join(ROOT, "tests", "golden", "wfst_lattice_u2.npz"))
+    n_states, n_arcs, n_final, start, frames = (int(v) for v in Z["meta"])
+    words_used = sorted(set(int(w) for w in Z["ol"] if w > 0))
+    V = max(words_used)
+    vocab = [f"w{k}" for k in range(1, V + 1)]
+    table = ["<eps>"] + vocab + ["#0", "<s>", "</s>"]
+    word_id = {w: i for i, w in enumerate(table) if 0 < i <= V}
+    wd0 = V + 1
+    G_old = wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 2, 3 * V, seed=5), word_id, wd0)
+    G_new = wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 3, 6 * V, seed=6), word_id, wd0)
+    H_old, H_new = wfst.HostFst.from_fst(G_old).arcsort(), wfst.HostFst.from_fst(G_new).arcsort()
+    args = (n_states, start, Z["src"], Z["dst"], Z["il"], Z["ol"], Z["gr"], Z["ac"], Z["fs"], Z["fc"])
+    cap = 4000 * (2 * frames + 16)
+    got, stats = host_rescore(*args, H_old, H_new, wd0, 50, 8.0, cap=cap)
+    deep = host_nbest(*args, 4000, 8.0, cap=cap)            # everything the beam holds, if fewer than 4000
+    ex = []
+    for w, g, a, ali in deep:
+        go, gn = H_old.grammar_score(list(w), wd0), H_new.grammar_score(list(w), wd0)
+        if np.isfinite(go) and np.isfinite(gn):
+            ex.append((w, g - go + gn, a))
+    ex.sort(key=lambda e: e[1] + e[2])
+    assert len(got) == 50
+    if len(deep) < 4000:                                      # the list was exhaustive: the two must agree entry by entry
+        for j in range(50):
+            assert abs((got[j][1] + got[j][2]) - (ex[j][1] + ex[j][2])) < 1e-3, j
+    else:                                                     # never worse than the list's exchange, entry by entry
+        for j in range(50):
+            assert got[j][1] + got[j][2] <= ex[j][1] + ex[j][2] + 1e-3, j
+    by_words = {w: (g, a) for w, g, a in ex}
+    hit = 0
+    for w, g, a, _ in got:
+        if w in by_words:
+            assert abs(g - by_words[w][0]) < 1e-3 and abs(a - by_words[w][1]) < 1e-3
+            hit += 1
+    assert hit >= 25
+    # a shallow list (the round-2 approximation at its old default depth relative to n) misses promoted sequences or not --
+    # either way the composition's k-th total is never above the shallow exchange's k-th total
+    shallow = sorted((g - H_old.grammar_score(list(w), wd0) + H_new.grammar_score(list(w), wd0) + a) for w, g, a, _ in deep[:60])
+    assert all(got[j][1] + got[j][2] <= shallow[j] + 1e-3 for j in range(min(50, len(shallow))))
