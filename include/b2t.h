@@ -233,6 +233,23 @@ size_t b2t_pass_ws_bytes(const b2t_model_t* m, const b2t_pass_t* p);
 int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t_pass_t* p, const float* x,
                       const int32_t* day_idx, const float* states, float* logits, float* hidden,
                       void* ws, void* sync_ws, void* stream);
+/* The STREAMING frame as one launch (BASELINE configs[4]; csrc/stream.hip): GRUDecoder.forward(x, day_idx, states,
+ * return_state=True) (model_training/rnn_model.py:88-134) for a handful of patch frames -- day layer, patch, L GRU layers one
+ * time step each, head -- in ONE persistent kernel (a workgroup per CU, phases separated by grid barriers, every weight read
+ * once), instead of the ~12 dependent launches b2t_model_forward issues for such a call.  Inference only (no dropout, nothing
+ * saved), exact fp32, same results as b2t_model_forward up to summation order.
+ *   b2t_stream_supported   1 if (model, B, T) can take this path: B <= 64, 1..8 output frames, F and H multiples of 16
+ *   b2t_stream_ws_bytes    workspace for one call (any contents)
+ *   b2t_stream_forward_f32 x [B][T][F], day_idx [B], states [L][B][H] or NULL (h0) -> logits [B][T'][C], hidden [L][B][H];
+ *                          sync: b2t_stream_sync_bytes() bytes, zeroed once, persistent (barrier counters, re-armed by every
+ *                          call; word 2 = sticky error: a barrier that timed out -- the launch could not become fully
+ *                          resident -- poisons logits[0] with NaN; the last 64 words = phase stamps of workgroup 0 on the
+ *                          100 MHz clock, for profiling).  Asynchronous on `stream`. */
+int b2t_stream_supported(const b2t_model_t* prm, int B, int T);
+size_t b2t_stream_ws_bytes(const b2t_model_t* prm, int B, int T);
+size_t b2t_stream_sync_bytes(void);
+int b2t_stream_forward_f32(const b2t_model_t* prm, int B, int T, const float* x, const int32_t* day_idx, const float* states,
+                           float* logits, float* hidden, void* ws, size_t ws_bytes, void* sync, void* stream);
 /* Gradients of every parameter given dlogits [B][T'][ldd] (ldd % 4 == 0, >= C), written (not accumulated) into `grd`;
  * days absent from day_idx are not touched.  dhidden [L][B][H] optional gradient wrt the final states; dstates
  * [L][B][H] optional output = gradient wrt the initial states (when the forward got `states`, h0 receives no gradient).

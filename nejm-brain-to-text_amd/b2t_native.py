@@ -119,6 +119,10 @@ _SIGNATURES = {
     "b2t_exec_sync_bytes": (C.c_size_t, [C.c_int]),
     "b2t_pass_ws_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.POINTER(PassDesc)]),
     "b2t_model_forward": (C.c_int, [VP, C.POINTER(ModelDesc), C.POINTER(PassDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
+    "b2t_stream_supported": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "b2t_stream_ws_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "b2t_stream_sync_bytes": (C.c_size_t, []),
+    "b2t_stream_forward_f32": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, C.c_size_t, VP, VP]),
     "b2t_model_backward": (C.c_int, [VP, C.POINTER(ModelDesc), C.POINTER(ModelDesc), C.POINTER(PassDesc), VP, VP, VP,
                                      C.c_int, VP, VP, C.c_int, VP, VP, BUCKET_CB, VP, VP]),
     "b2t_exec_profile": (C.c_int, [VP, C.c_int]),

@@ -272,6 +272,9 @@ GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
 # 935 -> 810-830 us, the step -0.1 ms on two boxes (with WRITE-THROUGH payload stores; ordinary stores cost the GEMMs 0.3-1 ms).
 # Ignored where the library's dispatch probe fails.
 LOCAL_F32 = {"dirs": os.environ.get("B2T_GRU_LOCAL", "fb")}
+# streaming calls (inference, <= 8 output frames, B <= 64) as one fused launch, csrc/stream.hip: opt-in (B2T_STREAM_FUSED=1) --
+# measured 151-159 us per frame against 163 through the executor, and a grid-barrier kernel wants the chip to itself
+STREAM = {"fused": os.environ.get("B2T_STREAM_FUSED", "0") not in ("0", "", "false", "False")}
 # which sweeps run with 32-unit workgroups under AMP: "" none, "f" forward, "b" backward, "fb" both (B2T_AMP_WIDE;
 # measured at C2: 18.4 / 17.5 / 17.1 / 16.1 ms per step)
 AMP["wide"] = os.environ.get("B2T_AMP_WIDE", "fb")
@@ -442,6 +445,23 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     if day_idx.numel() != B:
         raise RuntimeError("day_idx must have one entry per batch row")
     dev = x.device
+    md = prm.desc(dims)
+    # A streaming call -- inference on a handful of patch frames with carried state (the online decoder's frame-by-frame use,
+    # BASELINE configs[4]) -- as ONE launch (csrc/stream.hip) instead of the executor's ~12 dependent ones: opt-in, fp32 only.
+    if (not save) and STREAM["fused"] and not AMP["on"] and in_drop == 0.0 and rnn_drop == 0.0 and \
+            lib.b2t_stream_supported(C.byref(md), B, T):
+        nb = lib.b2t_stream_ws_bytes(C.byref(md), B, T)
+        buf = ws.get("stream_ws", ((nb + 3) // 4,), dev)
+        sync = ws.get("stream_sync", (lib.b2t_stream_sync_bytes() // 4,), dev, torch.int32)
+        logits = torch.empty((B, Tp, Cc), dtype=torch.float32, device=dev)
+        hidden = torch.empty((L, B, H), dtype=torch.float32, device=dev)
+        if states is not None:
+            _need(states, name="states")
+            if tuple(states.shape) != (L, B, H):
+                raise RuntimeError(f"states must be [{L},{B},{H}]")
+        N.check(lib.b2t_stream_forward_f32(C.byref(md), B, T, _p(x), _p(day_idx), _p(states), _p(logits), _p(hidden), _p(buf),
+                                           nb, _p(sync), _stream()), "b2t_stream_forward_f32")
+        return logits, hidden, None
     mode = gru_mode_for(B, H)
     ps = N.PassDesc()
     ps.B, ps.T, ps.chunks = B, T, time_chunks(Tp, B, H, AMP["on"])
@@ -450,7 +470,6 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ps.in_drop, ps.rnn_drop, ps.seed = float(in_drop), float(rnn_drop if L > 1 else 0.0), int(seed) & (2 ** 64 - 1)
     ps.chunks_bwd = time_chunks_bwd(Tp, B, H, AMP["on"], ps.chunks)
     ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
-    md = prm.desc(dims)
     nbytes = lib.b2t_pass_ws_bytes(C.byref(md), C.byref(ps))
     if nbytes == 0:
         raise RuntimeError("b2t_pass_ws_bytes: bad model / pass description")

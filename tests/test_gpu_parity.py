@@ -767,3 +767,41 @@ def test_gemm_skinny_batched_day_form():
     ops.gemm(tx, tW, out, M=M, N_=N, K=K, Z=Z, a_kc=1, a_s0=K, a_sz=M * K, b_kc=0, b_s0=N, b_sz=K * N, c_s0=N, c_sz=M * N,
              bias=tb, bias_sz=N, b_zmap=torch.from_numpy(zmap).to(dev), epilogue=1)
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,F,H,L,patch,stride,frames,per_call", [(32, 512, 768, 5, 14, 4, 3, 1), (5, 64, 64, 2, 0, 0, 4, 1),
+                                                                    (3, 32, 96, 5, 14, 4, 3, 2), (40, 64, 128, 3, 4, 2, 2, 3)])
+def test_stream_forward_equals_executor(B, F, H, L, patch, stride, frames, per_call):
+    """The opt-in fused streaming frame (csrc/stream.hip, b2t_stream_forward_f32: day layer, patch, L GRU steps and the head in
+    one persistent launch with grid barriers) returns the executor path's logits and carried states (rnn_model.py:88-134 with
+    `states`), frame after frame: 1 / 2 / 4 batch tiles, with and without patching, several output frames per call."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = GRUDecoder(F, H, 4, 41, 0.0, 0.0, L, patch, stride).to(dev).eval()
+    day = (torch.arange(B, dtype=torch.int32, device=dev) % 4)
+    T_all = (patch if patch else 1) + (stride if patch else 1) * (frames * per_call - 1)
+    x_all = torch.randn(B, T_all, F, device=dev) * 0.5
+    outs = {}
+    was = ops.STREAM["fused"]
+    try:
+        for fused in (False, True):
+            ops.STREAM["fused"] = fused
+            states, got = None, []
+            with torch.no_grad():
+                for f in range(frames):
+                    if patch:
+                        t0 = f * per_call * stride
+                        xf = x_all[:, t0: t0 + patch + stride * (per_call - 1)].contiguous()
+                    else:
+                        xf = x_all[:, f * per_call:(f + 1) * per_call].contiguous()
+                    logits, states = model(xf, day, states, True)
+                    got.append(logits)
+            outs[fused] = (torch.cat(got, 1), states)
+    finally:
+        ops.STREAM["fused"] = was
+    assert not torch.isnan(outs[True][0]).any()
+    assert float((outs[True][0] - outs[False][0]).abs().max()) < 5e-6
+    assert float((outs[True][1] - outs[False][1]).abs().max()) < 5e-6
