@@ -719,15 +719,25 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         else c.gemm(sg, d);
       });
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
-      t_sw[l][ci] = P.add("sweep", 40.f + n * est_step_us(0) * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n](hipStream_t ss) {
+      t_sw[l][ci] = P.add("sweep", 40.f + n * est_step_us(0) * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n, ci](hipStream_t ss) {
         if (c.rc) return;
         Ctx::Scope sc(c, ss, 8, 2.0 * n * B * 3.0 * H * H);
         // h_{t0-1}: slot t0 of out[l] -- or, for the first chunk of an inference pass with carried state, the caller's buffer
         const float* h_prev = (t0 == 0 && states && !p->save) ? states + (size_t)l * B * H : w.out[l] + (long long)t0 * B * H;
+        // In the wavefront's fill and drain stages, where at most B2T_NARROW_EDGE (default 2) layers are at work, the exact-fp32
+        // sweep runs with 16-unit workgroups (twice the workgroups, half the MFMA time per step: the chip is mostly empty there
+        // and the stage is pure latency) instead of the 32-unit ones that crowd the CUs less in the full stages:
+        // 19.51-19.57 -> 19.36-19.39 ms per step (k = 1: 19.40-19.42, k = 3: 19.52-19.56; 0 = off).  Same results bit for bit.
+        static const int narrow_edge = getenv("B2T_NARROW_EDGE") ? atoi(getenv("B2T_NARROW_EDGE")) : 2;
+        int m2 = mode;
+        if (narrow_edge > 0 && (mode & B2T_GRU_WIDE) && !(mode & B2T_GRU_BF16) && nc > 1) {
+          const int stage = l + ci, active = std::min(std::min(stage + 1, L + nc - 1 - stage), std::min(L, nc));
+          if (active <= narrow_edge) m2 &= ~B2T_GRU_WIDE;
+        }
         c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], h_prev,
                                      w.out[l] + (long long)(1 + t0) * B * H, p->save ? w.res[l] + (long long)t0 * B * 4 * H : nullptr,
                                      t1 == Tp ? hidden + (size_t)l * B * H : nullptr, n, B, H,
-                                     (mode & B2T_GRU_LOCAL) ? (mode | ((l & 1) ? B2T_GRU_PARITY : 0)) : mode, sync_of(l),
+                                     (m2 & B2T_GRU_LOCAL) ? (m2 | ((l & 1) ? B2T_GRU_PARITY : 0)) : m2, sync_of(l),
                                      reinterpret_cast<void*>(ss)));
       });
       if (mode & B2T_GRU_LOCAL) P.t[t_sw[l][ci]].cls = l & 1;   // XCD set by layer parity: admission-controlled (run_plan)

@@ -16,7 +16,8 @@ function, with the line ranges it follows:
   CtcWfstBeamSearch         language_model/runtime/core/decoder/ctc_wfst_beam_search.cc  Search :70-121 (blank-frame
                             skipping, partial best path) · FinalizeSearch :123-160 · ConvertToInputs :162-188 ·
                             DecodableTensorScaled::LogLikelihood :27-33
-  BrainSpeechDecoder        brain_speech_decoder.cc:113-137 UpdateResult (scores, word strings)
+  BrainSpeechDecoder        brain_speech_decoder.cc:113-137 UpdateResult (scores, word strings) · Rescore / LatticeRescore :47-101
+                            (rescore_by_definition, grammar_min_cost below: by enumeration, small lattices only)
 
 The graph is data: CSR arrays (row, ilabel, olabel, weight, next, final) as nejm-brain-to-text_amd/wfst.DecodeGraph holds them.
 """
@@ -416,6 +417,66 @@ def nbest_word_sequences(arcs, finals, start, nbest, beam):
             counter += 1
             heapq.heappush(pq, (b, 0, counter, words + (ol,), sub2))
     return results
+
+
+def grammar_min_cost(arcs, finals, start, words, backoff):
+    """What composing ONE word sequence with a grammar and determinising costs (brain_speech_decoder.cc:47-58: fst::Compose with the
+    grammar read by ReadAndPrepareLmFst -- back-off arcs are epsilons, so a route may take them anywhere --, then
+    DeterminizeLattice keeps the cheapest route): min over routes of arc weights + the final cost.  arcs[s] = [(ilabel, weight,
+    next)], finals {state: cost}; arcs labelled `backoff` are the free ones.  inf = not accepted."""
+    def close(d):
+        stack = list(d)
+        while stack:
+            s = stack.pop()
+            for il, w, n in arcs[s]:
+                if il == backoff and d[s] + w < d.get(n, INF):
+                    d[n] = d[s] + w
+                    stack.append(n)
+        return d
+    cur = close({start: 0.0})
+    for word in words:
+        nxt = {}
+        for s, c in cur.items():
+            for il, w, n in arcs[s]:
+                if il == word and c + w < nxt.get(n, INF):
+                    nxt[n] = c + w
+        if not nxt:
+            return INF
+        cur = close(nxt)
+    return min([c + finals[s] for s, c in cur.items() if s in finals] or [INF])
+
+
+def rescore_by_definition(arcs, finals, start, g_old, g_new, backoff, nbest, beam):
+    """BrainSpeechDecoder::Rescore (brain_speech_decoder.cc:61-101) by enumeration of a SMALL acyclic lattice.
+    lat_ (ctc_wfst_beam_search.cc:138-141: GetLattice = determinised and pruned with lattice_beam) holds ONE path per word sequence,
+    the cheapest, for the sequences within the beam.  LatticeRescore(-1) (:47-58): graph := -graph; compose with the old grammar;
+    DeterminizeLattice keeps the cheapest (path, route) per word sequence = -graph + min-route G_old; graph := -graph again, i.e.
+    graph - G_old(W).  LatticeRescore(+1) adds min-route G_new(W).  ShortestPath(n) on graph + acoustic.
+    arcs[s] = [(ilabel, olabel, graph, acoustic, next)] as for nbest_word_sequences; g_old / g_new = (arcs, finals, start) for
+    grammar_min_cost.  Returns [(words, graph', acoustic, alignment)] best first."""
+    best = {}
+    stack = [(start, (), (), 0.0, 0.0)]
+    while stack:
+        s, words, ali, g, a = stack.pop()
+        if s in finals:
+            t = (g + finals[s] + a, g + finals[s], a, ali)
+            if words not in best or t[0] < best[words][0]:
+                best[words] = t
+        for il, ol, gr, ac, n in arcs[s]:
+            stack.append((n, words + ((ol,) if ol else ()), ali + ((il,) if il else ()), g + gr, a + ac))
+    if not best:
+        return []
+    cut = min(t[0] for t in best.values()) + beam
+    res = []
+    for words, (tot, g, a, ali) in best.items():
+        if tot > cut:
+            continue
+        go, gn = grammar_min_cost(*g_old, list(words), backoff), grammar_min_cost(*g_new, list(words), backoff)
+        if go == INF or gn == INF:
+            continue
+        res.append((words, g - go + gn, a, ali))
+    res.sort(key=lambda e: e[1] + e[2])
+    return res[:nbest]
 
 
 class CtcWfstBeamSearch:

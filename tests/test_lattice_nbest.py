@@ -124,43 +124,23 @@ def host_rescore(n_states, start, src, dst, il, ol, gr, ac, fs, fc, g_old, g_new
             for j in range(k)], stats
 
 
-def reference_rescore(n_states, start, src, dst, il, ol, gr, ac, fs, fc, G_old, G_new, backoff, nbest, beam):
-    """brain_speech_decoder.cc:47-101 by enumeration.  lat_ (ctc_wfst_beam_search.cc:138-141: GetLattice = determinised, pruned
-    with lattice_beam) holds ONE path per word sequence, the cheapest, for the sequences within the beam.  LatticeRescore(-1):
-    graph := -graph; compose with G_old (a route may take back-off arcs anywhere); DeterminizeLattice keeps the cheapest (path,
-    route) per word sequence = -graph + min-route G_old; graph := -graph again  ->  graph - G_old(W).  LatticeRescore(+1) adds
-    min-route G_new(W).  ShortestPath(n) on graph + acoustic."""
-    import wfst
-    out = [[] for _ in range(n_states)]
-    for i in range(len(src)):
-        out[int(src[i])].append(i)
-    fin = {}
-    for s, c in zip(fs, fc):
-        fin[int(s)] = min(fin.get(int(s), float("inf")), float(np.float32(c)))
-    best = {}
+def _grammar_lists(G):
+    """wfst.Fst -> (arcs[s] = [(ilabel, weight, next)], finals, start) for the oracle's grammar_min_cost"""
+    arcs = [[] for _ in range(G.n)]
+    for s, il, ol, w, d in G.arcs:
+        arcs[s].append((il, float(w), d))
+    return arcs, {int(s): float(c) for s, c in G.final.items()}, G.start
 
-    def walk(s, words, ali, g, a):
-        if s in fin:
-            t = (g + fin[s] + a, g + fin[s], a, ali)
-            if words not in best or t[0] < best[words][0]:
-                best[words] = t
-        for i in out[s]:
-            walk(int(dst[i]), words + ((int(ol[i]),) if ol[i] else ()), ali + ((int(il[i]),) if il[i] else ()),
-                 g + float(np.float32(gr[i])), a + float(np.float32(ac[i])))
-    walk(start, (), (), 0.0, 0.0)
-    if not best:
-        return []
-    cut = min(t[0] for t in best.values()) + beam
-    res = []
-    for words, (tot, g, a, ali) in best.items():
-        if tot > cut:
-            continue
-        go, gn = wfst.grammar_score(G_old, list(words), backoff), wfst.grammar_score(G_new, list(words), backoff)
-        if not (np.isfinite(go) and np.isfinite(gn)):
-            continue
-        res.append((words, g - go + gn, a, ali))
-    res.sort(key=lambda e: e[1] + e[2])
-    return res[:nbest]
+
+def reference_rescore(n_states, start, src, dst, il, ol, gr, ac, fs, fc, G_old, G_new, backoff, nbest, beam):
+    """oracle/wfst_oracle.py: rescore_by_definition (brain_speech_decoder.cc:47-101 by enumeration)."""
+    arcs = [[] for _ in range(n_states)]
+    for i in range(len(src)):
+        arcs[int(src[i])].append((int(il[i]), int(ol[i]), float(np.float32(gr[i])), float(np.float32(ac[i])), int(dst[i])))
+    finals = {}
+    for s, c in zip(fs, fc):
+        finals[int(s)] = min(finals.get(int(s), float("inf")), float(np.float32(c)))
+    return O.rescore_by_definition(arcs, finals, start, _grammar_lists(G_old), _grammar_lists(G_new), backoff, nbest, beam)
 
 
 @pytest.mark.parametrize("seed,n,nbest,beam", [(0, 24, 10, 3.0), (1, 28, 25, 5.0), (2, 30, 200, 100.0), (3, 26, 5, 1.5), (4, 22, 40, 8.0)])
