@@ -16,16 +16,21 @@
 // global gather, a full __syncthreads and log-space class sums inside each of the 2T dependent steps; 0.63 ms with the
 // log-probabilities in LDS, LDS-only barriers and a dedicated gradient wave; this version splits the two recursions
 // over two workgroups and takes the gradient off the serial path altogether.
+#include <stdlib.h>
 #include "common.h"
 
 namespace b2t {
 
+// log(e^a + e^b + e^c) on the chain of T dependent steps: raw v_exp_f32 / v_log_f32 (base 2, ~1 ulp).  The sum lies in [1, 3]
+// and every exponent argument is <= 0, so none of what __expf / __logf add around the instructions (denormal rescaling by
+// ldexp, a four-operation exact multiply by ln 2) is needed: 18 VALU operations per state instead of 33 -- the recursions are
+// bound by exactly this instruction stream (one wave, K states per lane, no memory on the chain).
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   float m = fmaxf(fmaxf(a, b), c);
   if (m == -INFINITY) m = 0.f;
-  // hardware exp2 / log2 (v_exp_f32, v_log_f32: ~1 ulp): the sum is in [1, 3], the arguments are <= 0 -- the libm forms
-  // are ~80 instructions each on the chain of T dependent steps
-  return __logf(__expf(a - m) + __expf(b - m) + __expf(c - m)) + m;
+  const float L2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  const float sum = __builtin_amdgcn_exp2f((a - m) * L2E) + __builtin_amdgcn_exp2f((b - m) * L2E) + __builtin_amdgcn_exp2f((c - m) * L2E);
+  return __builtin_amdgcn_logf(sum) * LN2 + m;
 }
 __device__ __forceinline__ float lse2(float a, float b) {
   float m = fmaxf(a, b);
@@ -38,13 +43,107 @@ __device__ __forceinline__ float lse2(float a, float b) {
 // global is communicated between threads inside the loops.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- the recursions inside ONE wave (2 S + 1 <= 64 K states, K = 2 / 4 / 8 consecutive states per lane) ---------------------
+// The T dependent steps were 0.38 us each with a thread per state: three LDS reads of the previous row, the log-sum-exp, an
+// LDS write and a workgroup barrier between the two waves.  With lane l holding states K l .. K l + K - 1 in registers the
+// previous row never leaves the register file: a state's left (alpha) / right (beta) neighbours are the lane's own values or
+// the neighbouring lane's edge values, fetched with two whole-wave DPP shifts (v_mov_b32 wave_shr:1 / wave_shl:1; the lane
+// without a neighbour keeps -inf) -- no LDS traffic on the chain, no barrier, no wait for the row stores.  The emission
+// log-probabilities of step t + 1 are read from LDS while step t computes.
+__device__ __forceinline__ float from_lane_below(float v) {   // lane l <- lane l - 1; lane 0 <- -inf
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)0xff800000u, (int)__float_as_uint(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float v) {   // lane l <- lane l + 1; lane 63 <- -inf
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)0xff800000u, (int)__float_as_uint(v), 0x130, 0xf, 0xf, false));
+}
+
+// LPL: the emission log-probabilities are staged in LDS -- a COMPILE-time split: with the choice made inside the loop the
+// compiler has to assume pending global loads at the join and drains the memory counter there, i.e. waits for the previous
+// row's store on every step (the loop then runs at the store round trip, ~800 cycles per step, whatever else is removed).
+template <int K, bool LPL>
+__device__ __forceinline__ void ctc_wave_recursion(bool is_beta, const float* __restrict__ lg, const float* lse, const float* lpl,
+                                                   const int* ext, float* abuf, float* __restrict__ rows,
+                                                   float* __restrict__ loss_b, int Tb, int C, int Lx, int LxMax) {
+  const int lane = threadIdx.x;            // wave 0 only
+  const int s0 = K * lane;
+  int es[K]; bool live[K], skip[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int s = s0 + k;
+    live[k] = s < Lx;
+    es[k] = live[k] ? ext[s] : 0;
+    skip[k] = !is_beta ? (live[k] && s >= 2 && es[k] != 0 && es[k] != ext[s - 2])
+                       : (live[k] && s + 2 < Lx && ext[s + 2] != 0 && ext[s + 2] != es[k]);
+  }
+  auto lp_of = [&](int t, int k) { return LPL ? lpl[t * C + es[k]] : (lg[(long long)t * C + es[k]] - lse[t]); };
+  float p[K], lpn[K];
+  if (!is_beta) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int s = s0 + k;
+      p[k] = (live[k] && s <= 1) ? lp_of(0, k) : -INFINITY;
+      if (live[k]) rows[s] = p[k];
+      lpn[k] = Tb > 1 ? lp_of(1, k) : 0.f;
+    }
+    // unrolled: a row's store reads its registers when it EXECUTES, so a register may not be rewritten before the store has
+    // left (the compiler waits on the memory counter for that); four steps' values in different registers leave the stores
+    // three steps to drain instead of putting their round trip on every step
+#pragma unroll 4
+    for (int t = 1; t < Tb; ++t) {
+      float lpc[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { lpc[k] = lpn[k]; lpn[k] = lp_of(min(t + 1, Tb - 1), k); }
+      const float up1 = from_lane_below(p[K - 1]), up2 = from_lane_below(p[K - 2]);
+      float v[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float a2 = k >= 1 ? p[k - 1] : up1;
+        const float a3 = k >= 2 ? p[k - 2] : (k == 1 ? up1 : up2);
+        v[k] = live[k] ? lse3(p[k], a2, skip[k] ? a3 : -INFINITY) + lpc[k] : -INFINITY;
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) { p[k] = v[k]; if (live[k]) rows[(long long)t * LxMax + s0 + k] = v[k]; }
+    }
+    // -log(alpha_T(Lx-1) + alpha_T(Lx-2)): through LDS (once)
+#pragma unroll
+    for (int k = 0; k < K; ++k) if (live[k]) abuf[s0 + k] = p[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *loss_b = -(Lx > 1 ? lse2(abuf[Lx - 1], abuf[Lx - 2]) : abuf[0]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int s = s0 + k;
+      p[k] = (live[k] && (s == Lx - 1 || s == Lx - 2)) ? lp_of(Tb - 1, k) : -INFINITY;
+      if (live[k]) rows[(long long)(Tb - 1) * LxMax + s] = p[k];
+      lpn[k] = Tb > 1 ? lp_of(Tb - 2, k) : 0.f;
+    }
+#pragma unroll 4
+    for (int t = Tb - 2; t >= 0; --t) {
+      float lpc[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { lpc[k] = lpn[k]; lpn[k] = lp_of(max(t - 1, 0), k); }
+      const float dn1 = from_lane_above(p[0]), dn2 = from_lane_above(p[1]);
+      float v[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float b2 = k + 1 < K ? p[k + 1] : dn1;
+        const float b3 = k + 2 < K ? p[k + 2] : (k + 1 < K ? dn1 : dn2);
+        // a state past the end never feeds a live one: its own value stays -inf
+        v[k] = live[k] ? lse3(p[k], b2, skip[k] ? b3 : -INFINITY) + lpc[k] : -INFINITY;
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) { p[k] = v[k]; if (live[k]) rows[(long long)t * LxMax + s0 + k] = v[k]; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void ctc_recursion_kernel(const float* __restrict__ logits,
                                                              const int32_t* __restrict__ targets,
                                                              const int32_t* __restrict__ in_len,
                                                              const int32_t* __restrict__ tgt_len,
                                                              float* __restrict__ loss, float* __restrict__ alpha_ws,
                                                              float* __restrict__ beta_ws, int T, int C, int S_max,
-                                                             int lp_in_lds) {
+                                                             int lp_in_lds, int wave_k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int b = blockIdx.x;
   const bool is_beta = blockIdx.y == 1;
@@ -84,6 +183,17 @@ __global__ __launch_bounds__(1024) void ctc_recursion_kernel(const float* __rest
   __syncthreads();
 #define LP(t, k) (lp_in_lds ? lpl[(t) * C + (k)] : (lg[(long long)(t) * C + (k)] - lse[(t)]))
 
+  if (wave_k) {   // the whole recursion in wave 0, K states per lane (no barrier below: the other waves are done)
+    if (tid >= 64) return;
+#define B2T_CTC_WAVE_CALL(KK)                                                                                              \
+    { if (lp_in_lds) ctc_wave_recursion<KK, true>(is_beta, lg, lse, lpl, ext, abuf, rows, loss + b, Tb, C, Lx, LxMax);           \
+      else ctc_wave_recursion<KK, false>(is_beta, lg, lse, lpl, ext, abuf, rows, loss + b, Tb, C, Lx, LxMax); }
+    if (wave_k == 2) B2T_CTC_WAVE_CALL(2)
+    else if (wave_k == 4) B2T_CTC_WAVE_CALL(4)
+    else B2T_CTC_WAVE_CALL(8)
+#undef B2T_CTC_WAVE_CALL
+    return;
+  }
   const int s = tid;
   const bool live = s < Lx;
   const int es = live ? ext[s] : 0;
@@ -262,8 +372,13 @@ extern "C" int b2t_ctc_loss_f32(const float* logits, const int32_t* targets, con
     if (rc) return rc;
   }
   float* beta_ws = alpha_ws + (size_t)B * T * LxMax;   // second half of the caller's scratch (only touched with dlogits)
+  // <= 512 extended states: the recursion runs inside one wave with 2 / 4 / 8 states per lane (B2T_CTC_WAVE=0: a thread per state)
+  const char* env_wave = getenv("B2T_CTC_WAVE");          // read per call: the tests switch it
+  const bool wave_ok = !(env_wave && atoi(env_wave) == 0);
+  const int wave_k = !wave_ok ? 0 : LxMax <= 128 ? 2 : LxMax <= 256 ? 4 : LxMax <= 512 ? 8 : 0;
+  if (wave_k && threads < 256) threads = 256;   // the prologue (log-sum-exp per frame, staging) still uses the whole workgroup
   hipLaunchKernelGGL(ctc_recursion_kernel, dim3(B, dlogits ? 2 : 1), dim3(threads), smem, s, logits, targets, in_len, tgt_len,
-                     loss, alpha_ws, beta_ws, T, C, S_max, lp_in_lds);
+                     loss, alpha_ws, beta_ws, T, C, S_max, lp_in_lds, wave_k);
   B2T_CHECK_LAUNCH("b2t_ctc_loss_f32 (recursions)");
   if (dlogits) {
     const int fpb = 64;   // frames per workgroup (16 per wave)

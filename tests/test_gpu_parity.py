@@ -805,3 +805,36 @@ def test_stream_forward_equals_executor(B, F, H, L, patch, stride, frames, per_c
     assert not torch.isnan(outs[True][0]).any()
     assert float((outs[True][0] - outs[False][0]).abs().max()) < 5e-6
     assert float((outs[True][1] - outs[False][1]).abs().max()) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [1, 7, 60, 64, 100, 128, 150, 255, 300])
+def test_ctc_wave_recursion_equals_thread_per_state(S, monkeypatch):
+    """The alpha / beta recursions inside one wave (2 / 4 / 8 states per lane, neighbours through whole-wave DPP shifts; up to 512
+    extended states) against the thread-per-state form with LDS rows and barriers (B2T_CTC_WAVE=0, also what longer label sequences
+    still use): the same operations in the same order, so losses and gradients must be IDENTICAL, ragged lengths, repeats and an
+    infeasible sentence included."""
+    import b2t_ops as ops
+    rng = np.random.default_rng(100 + S)
+    dev = _dev()
+    B, T, C = 6, 2 * S + 40, 41
+    logits = torch.from_numpy((rng.standard_normal((B, T, C)) * 1.5).astype(np.float32)).to(dev)
+    tg = rng.integers(1, C, (B, S)).astype(np.int32)
+    tl = np.array([S, 1, max(1, S // 2), max(1, S - 1), S, max(1, S // 3)], dtype=np.int32)
+    il = np.array([T, min(T, 17), T, T - 3, S, T], dtype=np.int32)       # sentence 4: T_b = S frames: infeasible with repeats
+    if S >= 3:
+        tg[0, :3] = [7, 7, 7]
+        tg[4, :2] = [5, 5]
+    for b in range(B):
+        tg[b, tl[b]:] = 0
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("B2T_CTC_WAVE", mode)
+        loss, dl, _ = ops.ctc_loss(logits, torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl), True, 1.0 / B, ops.Workspace())
+        out[mode] = (loss.cpu().numpy().copy(), dl.cpu().numpy().copy())
+    assert np.array_equal(out["0"][0], out["1"][0], equal_nan=True), (out["0"][0], out["1"][0])
+    fin = np.isfinite(out["0"][0])
+    assert fin.sum() >= 4
+    assert np.array_equal(out["0"][1][fin], out["1"][1][fin])
+    lo, _ = O.ctc_loss_fwd_bwd(logits.cpu().numpy(), tg, il, tl)
+    np.testing.assert_allclose(out["1"][0][fin], lo[fin], rtol=2e-5)
