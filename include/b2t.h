@@ -177,6 +177,13 @@ int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, const float* re
                           float* dG, float* dh_init, float* carry_ws,
                           int T, int B, int H, int mode, void* sync_ws, void* stream);
 int b2t_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+/* n (1..4) device-to-device copies of 32-bit words in ONE launch: dst[k][0 .. words[k]) = src[k][..] (the static input / output
+ * buffers of a replayed streaming graph; no reference counterpart) */
+int b2t_copy_segments_b32(const void* const* src, void* const* dst, const long long* words, int n, void* stream);
+/* The same with the segment list read when the kernel RUNS, from a device-visible table in pinned host memory: table = {n, src[4],
+ * dst[4], words[4]} as 13 int64.  Captured in front of and behind a streaming call's graph, so that a replay serves that call's
+ * own input and output tensors (the host rewrites the table; it must not do so while a replay that reads it is in flight). */
+int b2t_copy_indirect_b32(const long long* table, int blocks, void* stream);
 /* dst[b][0:n] = src[0:n] for b < rows (the learnt initial state h0 broadcast over the batch, rnn_model.py:122-123) */
 int b2t_broadcast_rows_f32(const float* src, float* dst, int rows, int n, void* stream);
 

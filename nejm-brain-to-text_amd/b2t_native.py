@@ -119,6 +119,8 @@ _SIGNATURES = {
     "b2t_exec_sync_bytes": (C.c_size_t, [C.c_int]),
     "b2t_pass_ws_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.POINTER(PassDesc)]),
     "b2t_model_forward": (C.c_int, [VP, C.POINTER(ModelDesc), C.POINTER(PassDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
+    "b2t_copy_segments_b32": (C.c_int, [VP, VP, VP, C.c_int, VP]),
+    "b2t_copy_indirect_b32": (C.c_int, [VP, C.c_int, VP]),
     "b2t_stream_supported": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "b2t_stream_ws_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "b2t_stream_sync_bytes": (C.c_size_t, []),

@@ -274,7 +274,9 @@ GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
 LOCAL_F32 = {"dirs": os.environ.get("B2T_GRU_LOCAL", "fb")}
 # streaming calls (inference, <= 8 output frames, B <= 64) as one fused launch, csrc/stream.hip: opt-in (B2T_STREAM_FUSED=1) --
 # measured 151-159 us per frame against 163 through the executor, and a grid-barrier kernel wants the chip to itself
-STREAM = {"fused": os.environ.get("B2T_STREAM_FUSED", "0") not in ("0", "", "false", "False")}
+STREAM = {"fused": os.environ.get("B2T_STREAM_FUSED", "0") not in ("0", "", "false", "False"),
+          # streaming calls of a model in eval() mode replayed as hipGraphs from their third call on (rnn_model._graph_forward)
+          "graph": os.environ.get("B2T_STREAM_GRAPH", "1") not in ("0", "", "false", "False")}
 # which sweeps run with 32-unit workgroups under AMP: "" none, "f" forward, "b" backward, "fb" both (B2T_AMP_WIDE;
 # measured at C2: 18.4 / 17.5 / 17.1 / 16.1 ms per step)
 AMP["wide"] = os.environ.get("B2T_AMP_WIDE", "fb")
@@ -426,6 +428,17 @@ class ForwardCtx:
 # ------------------------------------------------------------------------------------------------
 # forward / backward: one C-ABI call each (csrc/exec.cpp issues the launches of the plan)
 # ------------------------------------------------------------------------------------------------
+def copy_segments(pairs):
+    """[(src, dst)] contiguous 32-bit tensors of equal size, at most four: all copied by ONE launch on the current stream."""
+    n = len(pairs)
+    src = (C.c_void_p * n)(*[p[0].data_ptr() for p in pairs]); dst = (C.c_void_p * n)(*[p[1].data_ptr() for p in pairs])
+    words = (C.c_longlong * n)(*[p[0].numel() for p in pairs])
+    for s_, d_ in pairs:
+        if s_.numel() != d_.numel() or s_.element_size() != 4 or d_.element_size() != 4 or not (s_.is_contiguous() and d_.is_contiguous()):
+            raise RuntimeError("copy_segments: contiguous 32-bit tensors of equal size expected")
+    N.check(N.load().b2t_copy_segments_b32(src, dst, words, n, _stream()), "b2t_copy_segments_b32")
+
+
 def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.Tensor,
                   states: Optional[torch.Tensor], ws: Workspace, save: bool,
                   in_drop: float = 0.0, rnn_drop: float = 0.0, seed: int = 0, reuse_saved: bool = False):

@@ -1,6 +1,7 @@
 // elementwise.hip — HBM-bound passes of the hot path: fused augmentation + Gaussian smoothing,
 // softsign backward, column sums, patch fold, dropout, transpose, per-day gradient reduction.
 // All kernels read/write 16 B per lane along the contiguous (feature) axis.
+#include <algorithm>
 #include "common.h"
 
 namespace b2t {
@@ -394,5 +395,59 @@ extern "C" int b2t_day_reduce_f32(const float* slab, const int32_t* day_idx, int
   dim3 block(256), grid((unsigned)((n / 4 + 255) / 256), B);
   hipLaunchKernelGGL(day_reduce_kernel, grid, block, 0, as_stream(stream), slab, day_idx, B, n, out, out_stride);
   B2T_CHECK_LAUNCH("b2t_day_reduce_f32");
+  return 0;
+}
+
+// ---- up to four device-to-device copies in ONE launch (the static input / output buffers of a replayed streaming graph,
+//      rnn_model._graph_forward: a copy per tensor costs a launch each, ~10 us of host time apiece) ----------------------------
+namespace b2t {
+struct CopySegs { const uint32_t* src[4]; uint32_t* dst[4]; long long words[4]; int n; };
+__global__ void copy_segments_kernel(CopySegs c) {
+  const long long stride = (long long)gridDim.x * blockDim.x, i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = 0; k < c.n; ++k)
+    for (long long i = i0; i < c.words[k]; i += stride) c.dst[k][i] = c.src[k][i];
+}
+}  // namespace b2t
+
+extern "C" int b2t_copy_segments_b32(const void* const* src, void* const* dst, const long long* words, int n, void* stream) {
+  using namespace b2t;
+  B2T_REQUIRE(src && dst && words && n >= 1 && n <= 4, "copy_segments: 1..4 segments");
+  CopySegs c;
+  long long most = 0;
+  for (int k = 0; k < 4; ++k) {
+    c.src[k] = k < n ? static_cast<const uint32_t*>(src[k]) : nullptr;
+    c.dst[k] = k < n ? static_cast<uint32_t*>(dst[k]) : nullptr;
+    c.words[k] = k < n ? words[k] : 0;
+    B2T_REQUIRE(k >= n || (c.src[k] && c.dst[k] && c.words[k] >= 0), "copy_segments: null segment %d", k);
+    most = std::max(most, c.words[k]);
+  }
+  c.n = n;
+  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, (most + 255) / 256));
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), c);
+  B2T_CHECK_LAUNCH("b2t_copy_segments_b32");
+  return 0;
+}
+
+// The same copies with the segment list read AT EXECUTION TIME from a table in pinned host memory: table = {n, src[4], dst[4],
+// words[4]} (13 x int64).  Captured into a streaming call's hipGraph in front of and behind the model pass, it lets one replay
+// take that call's input tensors and fill that call's fresh output tensors -- the host only rewrites the table.
+namespace b2t {
+__global__ void copy_indirect_kernel(const long long* __restrict__ table) {
+  const int n = (int)table[0];
+  const long long stride = (long long)gridDim.x * blockDim.x, i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = 0; k < n && k < 4; ++k) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(table[1 + k]);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(table[5 + k]);
+    const long long words = table[9 + k];
+    for (long long i = i0; i < words; i += stride) dst[i] = src[i];
+  }
+}
+}  // namespace b2t
+
+extern "C" int b2t_copy_indirect_b32(const long long* table, int blocks, void* stream) {
+  using namespace b2t;
+  B2T_REQUIRE(table && blocks >= 1 && blocks <= 4096, "copy_indirect: bad arguments");
+  hipLaunchKernelGGL(copy_indirect_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), table);
+  B2T_CHECK_LAUNCH("b2t_copy_indirect_b32");
   return 0;
 }

@@ -105,6 +105,8 @@ class GRUDecoder(nn.Module):
 
         self._dims = ops.ModelDims(neural_dim, n_units, n_days, n_classes, n_layers, patch_size, patch_stride)
         self._ws = ops.Workspace()
+        self._graphs = {}          # streaming shapes replayed as hipGraphs (_graph_forward)
+        self._expect = None        # [(getter of a Parameter, its address inside the arena)] (_arena_ok)
         self._arena: Optional[torch.Tensor] = None
         self._grad_arena: Optional[torch.Tensor] = None
         self._layout = None
@@ -124,13 +126,30 @@ class GRUDecoder(nn.Module):
         return order
 
     def _arena_ok(self) -> bool:
+        """Every Parameter still is the view into the arena that pack() made it (a .to(), a `p.data = ...` or a replaced
+        Parameter object breaks that).  Runs on every forward: the expected addresses are kept in a flat list so that the check
+        is one data_ptr() comparison per tensor (113 tensors: ~15 us; building the name list each time cost 60-80 us, which was
+        a third of a streaming call)."""
         if self._arena is None:
             return False
-        base = self._arena.data_ptr()
-        for (name, p), (off, n) in zip(self._param_order(), self._layout["spans"]):
-            if p.data_ptr() != base + 4 * off or p.device != self._arena.device:
+        exp = self._expect
+        if exp is None:
+            return False
+        if self._parameters["h0"].device != self._arena.device:
+            return False
+        for params, key, want in exp:
+            if params[key].data_ptr() != want:
                 return False
         return True
+
+    def _build_expect(self):
+        base = self._arena.data_ptr()
+        exp = []
+        for (name, _), (off, n) in zip(self._param_order(), self._layout["spans"]):
+            mod_name, _, leaf = name.rpartition(".")
+            owner = getattr(self, mod_name) if mod_name else self      # nn.ParameterList / nn.GRU / nn.Linear / the model itself
+            exp.append((owner._parameters, leaf, base + 4 * off))
+        self._expect = exp
 
     def pack(self, device=None):
         """(Re)build the parameter arena on `device` and re-point every Parameter's storage into it.
@@ -150,6 +169,7 @@ class GRUDecoder(nn.Module):
         self._grad_arena = torch.zeros_like(arena)
         self._layout = dict(spans=spans, names=[n for n, _ in order], total=off)
         self._kp = None
+        self._build_expect()
         return self
 
     def arena(self):
@@ -233,6 +253,79 @@ class GRUDecoder(nn.Module):
             raise RuntimeError("day_idx must have one entry per batch row")
         return x, day_idx
 
+    # ------------------------------------------------------------------ streaming calls as hipGraphs -----
+    # The online decoder calls forward() once per 80 ms frame with the carried states (evaluate_model_helpers.py:87-115): a dozen
+    # dependent launches of a few microseconds each -- 0.17 ms of device time, 0.29 ms per call with the host's share.  The
+    # call is fixed-shape and runs on one stream, so from the third call of a shape on it is replayed as ONE hipGraph
+    # (torch.cuda.CUDAGraph around the same executor call: same kernels, same results bit for bit): 38 us of host time per call
+    # instead of 99, 0.210 ms per call with the synchronisation instead of 0.219 (the device's 0.166 ms are the floor; the larger
+    # gain of late round 3, 0.288 -> 0.219, was the parameter-arena check in front of every forward, see _arena_ok).
+    # Inputs are copied into the graph's static buffers and the results into fresh tensors by kernels inside the graph (the
+    # caller may keep them across calls).  The graph reads the parameter arena in place, so weight updates between calls are
+    # seen; a re-packed arena, a different shape or precision mode gets a graph of its own (at most 8 are kept).
+    # B2T_STREAM_GRAPH=0 turns it off.
+    def _graph_eligible(self, x):
+        if not ops.STREAM["graph"] or self.training or x.shape[0] > 64:
+            return False
+        Tp = self._dims.out_T(x.shape[1])
+        return 0 < Tp <= 8 and not torch.cuda.is_current_stream_capturing()
+
+    def _graph_forward(self, x, day_idx, states):
+        arena = self.arena()
+        key = (tuple(x.shape), states is None, arena.data_ptr(), x.device.index, bool(ops.AMP["on"]), bool(ops.STREAM["fused"]))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = {"calls": 0, "graph": None}
+        ent["calls"] += 1
+        if ent["graph"] is None:
+            if ent["calls"] < 3:          # the first calls of a shape run eagerly (they are also the warm-up the capture needs)
+                lg, hd, _ = ops.model_forward(self._dims, self._kernel_params(), x, day_idx, states, self._ws, save=False)
+                return lg, hd
+            self._capture(ent, x, day_idx, states)
+        # One replay = copy this call's inputs into the static buffers, the pass, copy the results into this call's fresh output
+        # tensors: the two copies are kernels INSIDE the graph that read their pointers from a pinned table when they run
+        # (b2t_copy_indirect_b32), so the host's share of a call is two allocations, ten table entries and the graph launch.
+        if not ent["done"].query():
+            ent["done"].synchronize()     # the previous replay still reads the table (back-to-back calls without a host read)
+        logits, hidden = torch.empty_like(ent["logits"]), torch.empty_like(ent["hidden"])
+        ti, to = ent["tab_in"], ent["tab_out"]
+        ti[1], ti[2] = x.data_ptr(), day_idx.data_ptr()
+        if states is not None:
+            ti[3] = states.data_ptr()
+        to[5], to[6] = logits.data_ptr(), hidden.data_ptr()
+        ent["graph"].replay()
+        ent["done"].record()
+        ent["keep"] = (x, day_idx, states)   # the replay reads them asynchronously: keep them alive until the next call
+        return logits, hidden
+
+    def _capture(self, ent, x, day_idx, states):
+        import ctypes as C
+        import b2t_native as N
+        lib = N.load()
+        sx, sd = torch.empty_like(x), torch.empty_like(day_idx)
+        ss = torch.empty_like(states) if states is not None else None
+        pins = torch.zeros((2, 16), dtype=torch.int64).pin_memory()
+        ti, to = pins[0].numpy(), pins[1].numpy()
+        ins = [(x, sx), (day_idx, sd)] + ([(states, ss)] if states is not None else [])
+        ti[0] = len(ins)
+        for k, (src, dst) in enumerate(ins):
+            ti[1 + k], ti[5 + k], ti[9 + k] = src.data_ptr(), dst.data_ptr(), src.numel()
+        blocks = 256
+        stream_of = lambda: C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads (n-best pool, loaders) are left alone
+            N.check(lib.b2t_copy_indirect_b32(C.c_void_p(pins[0].data_ptr()), blocks, stream_of()), "b2t_copy_indirect_b32")
+            lg, hd, _ = ops.model_forward(self._dims, self._kernel_params(), sx, sd, ss, self._ws, save=False)
+            to[0] = 2
+            to[1], to[2] = lg.data_ptr(), hd.data_ptr()
+            to[9], to[10] = lg.numel(), hd.numel()
+            N.check(lib.b2t_copy_indirect_b32(C.c_void_p(pins[1].data_ptr()), blocks, stream_of()), "b2t_copy_indirect_b32")
+        ent.update(graph=g, logits=lg, hidden=hd, x=sx, day=sd, states=ss, pins=pins, tab_in=ti, tab_out=to,
+                   done=torch.cuda.Event())
+        ent["done"].record()
+
     # ------------------------------------------------------------------ forward ----------------
     def forward(self, x, day_idx, states=None, return_state=False):
         """x [B,T,neural_dim]; day_idx [B]; states [n_layers,B,n_units] or None.
@@ -246,6 +339,8 @@ class GRUDecoder(nn.Module):
         if want_grad:
             params = [p for _, p in self._param_order()]
             logits, hidden = _ModelFn.apply(self, x, day_idx, states, True, *params)
+        elif self._graph_eligible(x):
+            logits, hidden = self._graph_forward(x, day_idx, states)
         else:
             logits, hidden, _ = ops.model_forward(self._dims, self._kernel_params(), x, day_idx, states, self._ws,
                                                   save=False, in_drop=self._p_in(), rnn_drop=self._p_rnn(),

@@ -838,3 +838,51 @@ def test_ctc_wave_recursion_equals_thread_per_state(S, monkeypatch):
     assert np.array_equal(out["0"][1][fin], out["1"][1][fin])
     lo, _ = O.ctc_loss_fwd_bwd(logits.cpu().numpy(), tg, il, tl)
     np.testing.assert_allclose(out["1"][0][fin], lo[fin], rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,F,H,L,patch,stride", [(32, 512, 768, 5, 14, 4), (3, 32, 96, 2, 0, 0)])
+def test_streaming_calls_replayed_as_graphs(B, F, H, L, patch, stride):
+    """From its third call of a shape on, an eval-mode streaming call (forward with carried states, <= 8 output frames) is
+    replayed as one hipGraph around the same executor call (rnn_model._graph_forward): bit-identical to the eager calls frame
+    after frame, results stay valid across later calls (they are copies), parameter updates between calls are seen."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    model = GRUDecoder(F, H, 4, 41, 0.0, 0.0, L, patch, stride).to(dev).eval()
+    day = (torch.arange(B, dtype=torch.int32, device=dev) % 4)
+    frames = 7
+    T_all = (patch if patch else 1) + (stride if patch else 1) * (frames - 1)
+    x_all = torch.randn(B, T_all, F, device=dev) * 0.5
+
+    def run(use_graph, bump_at=None):
+        was = ops.STREAM["graph"]
+        ops.STREAM["graph"] = use_graph
+        model._graphs.clear()
+        bias0 = model.out.bias.data.clone()
+        try:
+            states, outs, sts = None, [], []
+            with torch.no_grad():
+                for f in range(frames):
+                    if f == bump_at:
+                        model.out.bias.data.add_(0.5)          # a parameter update between two streaming calls
+                    xf = (x_all[:, f * stride: f * stride + patch] if patch else x_all[:, f:f + 1]).contiguous()
+                    lg, states = model(xf, day, states, True)
+                    outs.append(lg); sts.append(states)        # kept WITHOUT cloning: later calls must not overwrite them
+            torch.cuda.synchronize()
+            return [o.clone() for o in outs], [s.clone() for s in sts]
+        finally:
+            ops.STREAM["graph"] = was
+            model.out.bias.data.copy_(bias0)                  # exactly (b + 0.5 - 0.5 need not be b)
+
+    eager_l, eager_s = run(False)
+    graph_l, graph_s = run(True)
+    assert any(e.get("graph") is not None for e in model._graphs.values()), "no graph was captured"
+    for f in range(frames):
+        assert torch.equal(eager_l[f], graph_l[f]) and torch.equal(eager_s[f], graph_s[f]), f
+    bump_e, _ = run(False, bump_at=5)
+    bump_g, _ = run(True, bump_at=5)
+    for f in range(frames):
+        assert torch.equal(bump_e[f], bump_g[f]), f
+    assert float((bump_g[5] - graph_l[5]).abs().max()) > 0.4     # the update did reach the replayed graph
