@@ -282,3 +282,19 @@ def test_openfst_vector_container_round_trip(toy, tmp_path):
         fh.write(b"\0\0\0\0")
     with pytest.raises(ValueError, match="not an OpenFST"):
         wfst.read_openfst_vector(p)
+
+
+def test_convert_rows_to_inputs_equals_the_scalar_form():
+    """wfst_decoder.convert_rows_to_inputs (all utterances' partial best paths in one vectorised pass, the per-frame host side of a
+    streaming decoder) == CtcWfstBeamSearch::ConvertToInputs (ctc_wfst_beam_search.cc:162-188) row by row."""
+    import wfst_decoder as WD
+    rs = np.random.RandomState(0)
+    for _ in range(300):
+        U, ML = rs.randint(1, 6), rs.randint(1, 40)
+        ali = rs.choice([1, 1, 1, 2, 3, 3, 5, 7], size=(U, ML)).astype(np.int32)
+        fr = np.sort(rs.randint(0, 100, size=(U, ML)), axis=1).astype(np.int32)
+        n = rs.randint(0, ML + 1, size=U)
+        a, b = WD.convert_rows_to_inputs(ali, fr, n)
+        for u in range(U):
+            i, t = WD.convert_to_inputs(ali[u, :n[u]], fr[u, :n[u]])
+            assert a[u] == i and b[u] == t
