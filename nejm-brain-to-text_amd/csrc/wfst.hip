@@ -68,7 +68,7 @@ struct Clu {
   int n_tok, n_link, overflow, wl_n;             // the counters the single-workgroup kernel keeps in LDS
   unsigned best[2], cand_min[2]; int narcs[2];   // per frame parity: cheapest token of the frame, cheapest candidate, arcs walked
   int changed[8];                                // per closure round (mod 8): a cost went down
-  int xcc[8];                                    // XCC_ID each member saw (placement check)
+  int xcc[32];                                   // XCC_ID each member saw (placement check; up to 32 members: a whole XCD)
   int n_heavy, pad1;                             // tokens of the frame with more than HEAVY_DEG emitting arcs (word-boundary states)
   int hist[2][4][256];                           // radix-select histograms: [max_active / min_active][round][digit]
 };
@@ -1894,7 +1894,11 @@ extern "C" int b2t_wfst_set_cluster(int G) { g_cluster_override = G < 0 ? 0 : G;
 extern "C" int b2t_wfst_cluster_size(int U) {
   static const int env = getenv("B2T_WFST_CLUSTER") ? atoi(getenv("B2T_WFST_CLUSTER")) : 0;
   const int forced = g_cluster_override ? g_cluster_override : env;
-  if (forced >= 1) return forced >= 8 ? 8 : forced >= 4 ? 4 : forced >= 2 ? 2 : 1;
+  if (forced >= 1) return forced >= 32 ? 32 : forced >= 16 ? 16 : forced >= 8 ? 8 : forced >= 4 ? 4 : forced >= 2 ? 2 : 1;
+  // 8 workgroups per utterance where they are all resident.  Larger clusters work (b2t_wfst_set_cluster(16 / 32): up to a whole
+  // XCD per utterance, tested against the single-workgroup search) but buy nothing: one utterance takes 11.7 / 11.1 / 11.7 ms
+  // with 8 / 16 / 32 workgroups, eight take 14.9 / 14.1 / 14.9 -- beyond 8 members a frame is its ~6 cluster barriers and the
+  // chains of dependent L2 round trips between them (~100 us), not the walk over its tokens and arcs.
   const int slots = 256;
   for (int G = 8; G > 1; G >>= 1) if ((U + 7) / 8 * 8 * G <= slots) return wfst_xcd_roundrobin_ok() ? G : 1;
   return 1;
