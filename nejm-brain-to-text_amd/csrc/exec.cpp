@@ -12,6 +12,7 @@
 // synchronises with the host).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <functional>
 #include <vector>
 #include <queue>
@@ -732,7 +733,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         int m2 = mode;
         if (narrow_edge > 0 && (mode & B2T_GRU_WIDE) && !(mode & B2T_GRU_BF16) && nc > 1) {
           const int stage = l + ci, active = std::min(std::min(stage + 1, L + nc - 1 - stage), std::min(L, nc));
-          if (active <= narrow_edge) m2 &= ~B2T_GRU_WIDE;
+          if (active <= narrow_edge) m2 &= ~B2T_GRU_WIDE;   // (fill stages only: 19.38-19.50, drain only: 19.25-19.35, both: 19.17-19.39)
         }
         c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], h_prev,
                                      w.out[l] + (long long)(1 + t0) * B * H, p->save ? w.res[l] + (long long)t0 * B * 4 * H : nullptr,
