@@ -18,6 +18,8 @@
 #include <string.h>
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <stdlib.h>
 #include <deque>
 #include <string>
 #include <unordered_map>
@@ -778,6 +780,7 @@ extern "C" int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arc
     set_error("lattice_rescore: bad arguments");
     return -1;
   }
+  const auto t_in = std::chrono::steady_clock::now();
   LmDet Lo(*CFST(g_old), backoff_label), Ln(*CFST(g_new), backoff_label);
   // lattice adjacency
   std::vector<int> off((size_t)n_states + 1, 0);
@@ -836,6 +839,10 @@ extern "C" int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arc
   if (stats4) { stats4[0] = (long long)pst.size(); stats4[1] = (long long)psrc.size(); stats4[2] = (long long)Lo.states.size(); stats4[3] = (long long)Ln.states.size(); }
   w_off[0] = 0; a_off[0] = 0;
   if (fst_.empty()) return 0;
+  static const bool timing = getenv("B2T_LAT_TIMING") != nullptr;
+  if (timing) fprintf(stderr, "lattice_rescore: %d lattice arcs -> product %zu states / %zu arcs, %zu + %zu determinised grammar states, %zu + %zu memo entries, built in %.1f ms\n",
+                      n_arcs, pst.size(), psrc.size(), Lo.states.size(), Ln.states.size(), Lo.memo.size(), Ln.memo.size(),
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
   return b2t_lattice_nbest_core((int)pst.size(), 0, (int)psrc.size(), psrc.data(), pdst.data(), pil.data(), pol.data(), pg.data(), pa.data(),
                                 pd.data(), (int)fst_.size(), fst_.data(), fc.data(), fd.data(), nbest, beam, out_words, w_off, w_cap,
                                 out_ali, a_off, a_cap, costs);

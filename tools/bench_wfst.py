@@ -246,6 +246,26 @@ def run():
             torch.cuda.empty_cache()
         except Exception as e:     # capacity of the box
             wide = dict(error=str(e)[:200])
+    # Rescore() by lattice composition (brain_speech_decoder.cc:47-101) on the 32 lattices the search just left: the graph's 3-gram
+    # out, an unpruned 4-gram over the same words in; 100-best by the new costs
+    rescore = None
+    try:
+        word_id = {w: i for i, w in enumerate(g.words) if 0 < i <= len(words)}
+        wd0 = g.words.index("#0")
+        G_old = wfst.HostFst.from_fst(wfst.grammar_fst(arpa, word_id, wd0)).arcsort()
+        G_new = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(words, 4, 6000, seed=77), word_id, wd0)).arcsort()
+        t0 = time.perf_counter(); first = S._nbest_all(100); t1 = time.perf_counter()
+        resc = S._nbest_all(100, rescore=(G_old, G_new, wd0)); t2 = time.perf_counter()
+        changed = sum(1 for a, b in zip(first, resc) if a and b and a[0][2] != b[0][2])
+        promoted = 0
+        for a, b in zip(first, resc):
+            seen = set(tuple(e[2]) for e in a)
+            promoted += sum(1 for e in b[:10] if tuple(e[2]) not in seen)
+        rescore = dict(nbest100_ms_32_utterances=round((t1 - t0) * 1e3, 2), rescore_nbest100_ms_32_utterances=round((t2 - t1) * 1e3, 2),
+                       utterances_whose_1best_changed=changed, top10_entries_from_below_the_first_100=promoted,
+                       grammars="word 3-gram (in the graph) -> word 4-gram, 6000 n-grams per order")
+    except Exception as e:     # noqa: BLE001
+        rescore = dict(error=str(e)[:200])
     # streaming: one frame per call for all U utterances, partial best path read back; PruneActiveTokens every 25 frames
     Ss = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.0, max_frames=T + 8, max_tokens=1 << 20, max_links=1 << 22, hash_size=hs)
     lat = []
@@ -280,6 +300,7 @@ def run():
                               max_ms_per_frame=round(float(lat.max()), 3),
                               held_tokens_at_end=int(max(m["tokens"] for m in smem)), created_tokens=int(max(m["created_tokens"] for m in smem)),
                               prune_passes=int(smem[0]["prunes"])),
+               rescore=rescore,
                wfst_wer_vs_truth=round(err_truth / nref, 4))
     out["accuracy_by_noise"] = accuracy(prons, words, arpa, g)
     return out
