@@ -680,14 +680,44 @@ extern "C" double b2t_fst_grammar_score(const void* h, const int32_t* words, int
 namespace b2t {
 namespace {
 
+// Open-addressing table of 64-bit keys -> 32-bit payload index (the product construction does ~10^7 lookups for a wide lattice:
+// std::unordered_map's node allocations and pointer chasing were most of its time).
+struct FlatMap {
+  std::vector<uint64_t> keys; std::vector<int> vals; size_t n = 0, mask = 0;
+  static uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+  explicit FlatMap(size_t cap = 1 << 12) { size_t c = 16; while (c < cap) c <<= 1; keys.assign(c, ~0ull); vals.assign(c, -1); mask = c - 1; }
+  void grow() {
+    FlatMap g(2 * (mask + 1));
+    for (size_t i = 0; i <= mask; ++i) if (keys[i] != ~0ull) g.put(keys[i], vals[i]);
+    keys.swap(g.keys); vals.swap(g.vals); mask = g.mask; n = g.n;
+  }
+  int* find(uint64_t k) {                           // key ~0 is reserved (never produced: ids and labels are < 2^31)
+    for (size_t i = mix(k) & mask;; i = (i + 1) & mask) {
+      if (keys[i] == k) return &vals[i];
+      if (keys[i] == ~0ull) return nullptr;
+    }
+  }
+  void put(uint64_t k, int v) {
+    if (2 * (n + 1) > mask + 1) grow();
+    for (size_t i = mix(k) & mask;; i = (i + 1) & mask) {
+      if (keys[i] == ~0ull) { keys[i] = k; vals[i] = v; ++n; return; }
+      if (keys[i] == k) { vals[i] = v; return; }
+    }
+  }
+};
+
 struct LmDet {
   const HFst& g;
   const int backoff;
-  struct St { std::vector<std::pair<int, double>> set; double fin; };      // sorted by grammar state; residuals (min = 0)
-  std::vector<St> states;
-  std::unordered_map<std::string, int> index;
-  std::unordered_map<uint64_t, std::pair<int, double>> memo;               // (state id, word) -> (state id or -1, cost)
-  LmDet(const HFst& f, int backoff_label) : g(f), backoff(backoff_label) {}
+  // determinised states: sorted (grammar state, residual) lists back to back in `pool`; residuals compared at float precision
+  struct Ref { size_t off; int n; double fin; };
+  std::vector<Ref> states;
+  std::vector<std::pair<int, double>> pool;
+  std::unordered_multimap<uint64_t, int> index;                            // content hash -> state id (verified against the pool)
+  FlatMap memo;                                                            // (state id, word) -> slot in memo_val
+  std::vector<std::pair<int, double>> memo_val, scratch;
+  LmDet(const HFst& f, int backoff_label) : g(f), backoff(backoff_label), memo(1 << 14) {}
+  size_t memo_size() const { return memo_val.size(); }
 
   void range(int s, int label, int64_t& lo, int64_t& hi) const {
     const HArc* p0 = g.arcs.data() + g.row[s];
@@ -695,58 +725,72 @@ struct LmDet {
     lo = std::lower_bound(p0, p1, label, [](const HArc& x, int l) { return x.il < l; }) - g.arcs.data();
     hi = std::upper_bound(p0, p1, label, [](int l, const HArc& x) { return l < x.il; }) - g.arcs.data();
   }
-  // closure under back-off arcs, normalisation, interning: -> (id, the minimum that was taken out)
+  // closure of v under back-off arcs, normalisation, interning: -> (id, the minimum that was taken out).  v is small (a
+  // history's back-off chain): linear searches, no allocation besides the pool's growth.
   std::pair<int, double> intern(std::vector<std::pair<int, double>>& v) {
-    std::unordered_map<int, double> d;
-    std::vector<int> st;
-    for (auto& kv : v) { auto it = d.find(kv.first); if (it == d.end() || kv.second < it->second) d[kv.first] = kv.second; }
-    for (auto& kv : d) st.push_back(kv.first);
-    while (!st.empty()) {
-      const int s = st.back(); st.pop_back();
-      const double c = d[s];
-      int64_t lo, hi;
-      range(s, backoff, lo, hi);
-      for (int64_t i = lo; i < hi; ++i) {
-        const HArc& a = g.arcs[(size_t)i];
-        auto it = d.find(a.nx);
-        if (it == d.end() || c + a.w < it->second) { d[a.nx] = c + a.w; st.push_back(a.nx); }
+    auto relax = [&](int st, double c) {
+      for (auto& kv : v) if (kv.first == st) { if (c < kv.second) { kv.second = c; return true; } return false; }
+      v.push_back({st, c});
+      return true;
+    };
+    {                                                                        // duplicates of the input: keep the cheapest
+      size_t w = 0;
+      for (size_t i = 0; i < v.size(); ++i) {
+        bool dup = false;
+        for (size_t k = 0; k < w; ++k) if (v[k].first == v[i].first) { v[k].second = std::min(v[k].second, v[i].second); dup = true; break; }
+        if (!dup) v[w++] = v[i];
+      }
+      v.resize(w);
+    }
+    for (bool moved = true; moved;) {                                        // back-off chains are short: to the fixed point
+      moved = false;
+      for (size_t i = 0; i < v.size(); ++i) {
+        const int s = v[i].first; const double c = v[i].second;
+        int64_t lo, hi;
+        range(s, backoff, lo, hi);
+        for (int64_t a = lo; a < hi; ++a) moved |= relax(g.arcs[(size_t)a].nx, c + (double)g.arcs[(size_t)a].w);
       }
     }
-    St n;
-    n.set.assign(d.begin(), d.end());
-    std::sort(n.set.begin(), n.set.end());
-    double m = INFINITY;
-    for (auto& kv : n.set) m = std::min(m, kv.second);
-    n.fin = INFINITY;
-    std::string key;
-    for (auto& kv : n.set) {
+    std::sort(v.begin(), v.end());
+    double m = INFINITY, fin = INFINITY;
+    for (auto& kv : v) m = std::min(m, kv.second);
+    uint64_t h = 1469598103934665603ull;
+    for (auto& kv : v) {
       kv.second -= m;
-      const float r = (float)kv.second;                                     // residuals compared at float precision
-      key.append((const char*)&kv.first, sizeof(int)); key.append((const char*)&r, sizeof(float));
-      if (g.fin[(size_t)kv.first] != FINF) n.fin = std::min(n.fin, kv.second + (double)g.fin[(size_t)kv.first]);
+      const float r = (float)kv.second;
+      uint32_t rb; memcpy(&rb, &r, 4);
+      h = (h ^ (uint64_t)(uint32_t)kv.first) * 1099511628211ull; h = (h ^ rb) * 1099511628211ull;
+      if (g.fin[(size_t)kv.first] != FINF) fin = std::min(fin, kv.second + (double)g.fin[(size_t)kv.first]);
     }
-    auto it = index.find(key);
-    if (it != index.end()) return {it->second, m};
-    states.push_back(std::move(n));
-    index.emplace(std::move(key), (int)states.size() - 1);
+    auto rng = index.equal_range(h);
+    for (auto it = rng.first; it != rng.second; ++it) {
+      const Ref& r = states[(size_t)it->second];
+      if (r.n != (int)v.size()) continue;
+      bool same = true;
+      for (int k = 0; k < r.n && same; ++k) same = pool[r.off + k].first == v[k].first && (float)pool[r.off + k].second == (float)v[k].second;
+      if (same) return {it->second, m};
+    }
+    states.push_back(Ref{pool.size(), (int)v.size(), fin});
+    pool.insert(pool.end(), v.begin(), v.end());
+    index.emplace(h, (int)states.size() - 1);
     return {(int)states.size() - 1, m};
   }
-  int start() { std::vector<std::pair<int, double>> v{{g.start, 0.0}}; return intern(v).first; }
+  int start() { scratch.assign(1, {g.start, 0.0}); return intern(scratch).first; }
   std::pair<int, double> step(int id, int word) {
     const uint64_t k = ((uint64_t)(uint32_t)id << 32) | (uint32_t)word;
-    auto it = memo.find(k);
-    if (it != memo.end()) return it->second;
-    std::vector<std::pair<int, double>> v;
-    const size_t n = states[(size_t)id].set.size();
-    for (size_t q = 0; q < n; ++q) {
-      const std::pair<int, double> kv = states[(size_t)id].set[q];
+    if (int* slot = memo.find(k)) return memo_val[(size_t)*slot];
+    scratch.clear();
+    const Ref r0 = states[(size_t)id];
+    for (int q = 0; q < r0.n; ++q) {
+      const std::pair<int, double> kv = pool[r0.off + q];
       int64_t lo, hi;
       range(kv.first, word, lo, hi);
-      for (int64_t i = lo; i < hi; ++i) v.push_back({g.arcs[(size_t)i].nx, kv.second + (double)g.arcs[(size_t)i].w});
+      for (int64_t i = lo; i < hi; ++i) scratch.push_back({g.arcs[(size_t)i].nx, kv.second + (double)g.arcs[(size_t)i].w});
     }
     std::pair<int, double> r{-1, INFINITY};
-    if (!v.empty()) r = intern(v);
-    memo.emplace(k, r);
+    if (!scratch.empty()) r = intern(scratch);
+    memo.put(k, (int)memo_val.size());
+    memo_val.push_back(r);
     return r;
   }
 };
@@ -797,18 +841,23 @@ extern "C" int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arc
   std::vector<float> fin((size_t)n_states, FINF);
   for (int i = 0; i < n_final; ++i) fin[(size_t)final_state[i]] = std::min(fin[(size_t)final_state[i]], final_cost[i]);
   // product states in discovery order
-  std::unordered_map<std::array<int, 3>, int, TripleHash> pid;
+  // product states in discovery order; (old set, new set) pairs are interned first so that a product state is ONE 64-bit key
+  FlatMap pair_id(1 << 12), pid((size_t)4 * n_states);
+  std::vector<std::array<int, 2>> pairs;
   std::vector<std::array<int, 3>> pst;
   auto state_of = [&](int l, int o, int n) {
-    const std::array<int, 3> k{l, o, n};
-    auto it = pid.find(k);
-    if (it != pid.end()) return it->second;
-    pst.push_back(k);
-    pid.emplace(k, (int)pst.size() - 1);
+    const uint64_t pk = ((uint64_t)(uint32_t)o << 32) | (uint32_t)n;
+    int p;
+    if (int* f = pair_id.find(pk)) p = *f; else { p = (int)pairs.size(); pairs.push_back({o, n}); pair_id.put(pk, p); }
+    const uint64_t k = ((uint64_t)(uint32_t)l << 32) | (uint32_t)p;
+    if (int* f = pid.find(k)) return *f;
+    pst.push_back({l, o, n});
+    pid.put(k, (int)pst.size() - 1);
     return (int)pst.size() - 1;
   };
   std::vector<int32_t> psrc, pdst, pil, pol;
   std::vector<float> pg, pa, pd;
+  { const size_t r = (size_t)4 * n_arcs; psrc.reserve(r); pdst.reserve(r); pil.reserve(r); pol.reserve(r); pg.reserve(r); pa.reserve(r); pd.reserve(r); pst.reserve((size_t)4 * n_states); }
   state_of(start, Lo.start(), Ln.start());
   for (size_t q = 0; q < pst.size(); ++q) {
     const std::array<int, 3> k = pst[q];
@@ -841,7 +890,7 @@ extern "C" int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arc
   if (fst_.empty()) return 0;
   static const bool timing = getenv("B2T_LAT_TIMING") != nullptr;
   if (timing) fprintf(stderr, "lattice_rescore: %d lattice arcs -> product %zu states / %zu arcs, %zu + %zu determinised grammar states, %zu + %zu memo entries, built in %.1f ms\n",
-                      n_arcs, pst.size(), psrc.size(), Lo.states.size(), Ln.states.size(), Lo.memo.size(), Ln.memo.size(),
+                      n_arcs, pst.size(), psrc.size(), Lo.states.size(), Ln.states.size(), Lo.memo_size(), Ln.memo_size(),
                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
   return b2t_lattice_nbest_core((int)pst.size(), 0, (int)psrc.size(), psrc.data(), pdst.data(), pil.data(), pol.data(), pg.data(), pa.data(),
                                 pd.data(), (int)fst_.size(), fst_.data(), fc.data(), fd.data(), nbest, beam, out_words, w_off, w_cap,
