@@ -106,7 +106,8 @@ class GRUDecoder(nn.Module):
         self._dims = ops.ModelDims(neural_dim, n_units, n_days, n_classes, n_layers, patch_size, patch_stride)
         self._ws = ops.Workspace()
         self._graphs = {}          # streaming shapes replayed as hipGraphs (_graph_forward)
-        self._expect = None        # [(getter of a Parameter, its address inside the arena)] (_arena_ok)
+        self._expect = None        # [(parameter dict, key, the tensor's address inside the arena)] (_arena_ok)
+        self._owners = []
         self._arena: Optional[torch.Tensor] = None
         self._grad_arena: Optional[torch.Tensor] = None
         self._layout = None
@@ -137,6 +138,9 @@ class GRUDecoder(nn.Module):
             return False
         if self._parameters["h0"].device != self._arena.device:
             return False
+        for name, owner in self._owners:          # a replaced submodule (model.gru = ...) brings parameters that are not in the arena
+            if getattr(self, name) is not owner:
+                return False
         for params, key, want in exp:
             if params[key].data_ptr() != want:
                 return False
@@ -144,12 +148,14 @@ class GRUDecoder(nn.Module):
 
     def _build_expect(self):
         base = self._arena.data_ptr()
-        exp = []
+        exp, owners = [], {}
         for (name, _), (off, n) in zip(self._param_order(), self._layout["spans"]):
             mod_name, _, leaf = name.rpartition(".")
             owner = getattr(self, mod_name) if mod_name else self      # nn.ParameterList / nn.GRU / nn.Linear / the model itself
+            if mod_name:
+                owners[mod_name] = owner
             exp.append((owner._parameters, leaf, base + 4 * off))
-        self._expect = exp
+        self._expect, self._owners = exp, list(owners.items())
 
     def pack(self, device=None):
         """(Re)build the parameter arena on `device` and re-point every Parameter's storage into it.
