@@ -271,7 +271,7 @@ class GRUDecoder(nn.Module):
     # seen; a re-packed arena, a different shape or precision mode gets a graph of its own (at most 8 are kept).
     # B2T_STREAM_GRAPH=0 turns it off.
     def _graph_eligible(self, x):
-        if not ops.STREAM["graph"] or self.training or x.shape[0] > 64:
+        if not ops.STREAM["graph"] or self.training or x.shape[0] > 64 or x.device.index != torch.cuda.current_device():
             return False
         Tp = self._dims.out_T(x.shape[1])
         return 0 < Tp <= 8 and not torch.cuda.is_current_stream_capturing()
