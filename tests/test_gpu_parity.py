@@ -886,3 +886,36 @@ def test_streaming_calls_replayed_as_graphs(B, F, H, L, patch, stride):
     for f in range(frames):
         assert torch.equal(bump_e[f], bump_g[f]), f
     assert float((bump_g[5] - graph_l[5]).abs().max()) > 0.4     # the update did reach the replayed graph
+
+
+@pytest.mark.gpu
+def test_copy_segments_and_indirect_table():
+    """b2t_copy_segments_b32 (up to four device copies in one launch) and b2t_copy_indirect_b32 (the same with the segment list read
+    from a pinned table when the kernel runs: rewritten between two launches, the second launch copies the new segments)."""
+    import ctypes as C
+    import b2t_native as N
+    import b2t_ops as ops
+    dev = _dev()
+    lib = N.load()
+    g = torch.Generator().manual_seed(1)
+    src = [torch.randn(n, generator=g).to(dev) for n in (1, 1000, 70001)] + [torch.arange(257, dtype=torch.int32, device=dev)]
+    dst = [torch.zeros_like(t) for t in src]
+    ops.copy_segments(list(zip(src, dst)))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(src, dst))
+    with pytest.raises(RuntimeError):
+        ops.copy_segments([(src[0], dst[1])])                       # sizes differ
+    tab = torch.zeros(16, dtype=torch.int64).pin_memory()
+    t = tab.numpy()
+    out = [torch.zeros_like(x) for x in src[:2]]
+    t[0] = 2
+    for k in range(2):
+        t[1 + k], t[5 + k], t[9 + k] = src[k].data_ptr(), out[k].data_ptr(), src[k].numel()
+    N.check(lib.b2t_copy_indirect_b32(C.c_void_p(tab.data_ptr()), 64, ops._stream()), "b2t_copy_indirect_b32")
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], src[0]) and torch.equal(out[1], src[1])
+    out2 = torch.zeros_like(src[2])
+    t[0] = 1; t[1], t[5], t[9] = src[2].data_ptr(), out2.data_ptr(), src[2].numel()
+    N.check(lib.b2t_copy_indirect_b32(C.c_void_p(tab.data_ptr()), 64, ops._stream()), "b2t_copy_indirect_b32")
+    torch.cuda.synchronize()
+    assert torch.equal(out2, src[2])
