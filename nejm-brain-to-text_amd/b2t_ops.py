@@ -295,7 +295,10 @@ def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
             return mode | GRU_WIDE | local
         return mode | local
     wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= int(os.environ.get("B2T_AMP_WIDE_MAXH", "768"))) else 0
-    local = GRU_LOCAL if (direction in LOCAL_F32["dirs"] and H <= 512) else 0   # C2 with bf16 operands: 11.3 -> 11.15 ms per step
+    # C2 with bf16 operands: 11.3 -> 11.15 ms per step; with 32-unit workgroups a row group of H = 768 is 24 workgroups and still
+    # fits one XCD (B2T_GRU_LOCAL_MAXH, also read by the library)
+    local_maxh = int(os.environ.get("B2T_GRU_LOCAL_MAXH", "512")) if wide else 512
+    local = GRU_LOCAL if (direction in LOCAL_F32["dirs"] and H <= local_maxh) else 0
     return mode | GRU_BF16 | wide | local
 
 

@@ -18,6 +18,8 @@
 // The entry point requires grid <= CU count (one row group resident is what correctness needs).
 #include <stdlib.h>
 #include "gru_cell.h"
+#include <algorithm>
+#include <stdlib.h>
 #include "gru_sync.h"
 
 #ifndef B2T_LOC_ST_AUX
@@ -461,6 +463,14 @@ bool gru_xcd_dispatch_ok() {
   return true;
 }
 
+// Largest H whose sweeps may hand off inside one XCD.  512 by default; bf16 operands with 32-unit workgroups make a row group of
+// H = 768 24 workgroups -- it fits an XCD's 32 CUs, alone: a second sweep of the same parity waits, partly resident, for the
+// first to finish (the plan's admission edges keep a third one out) -- B2T_GRU_LOCAL_MAXH opts in.
+static int local_max_h(bool bf16, bool wide) {
+  static const int env = getenv("B2T_GRU_LOCAL_MAXH") ? atoi(getenv("B2T_GRU_LOCAL_MAXH")) : 512;
+  return (bf16 && wide) ? std::max(512, std::min(env, 1024)) : 512;
+}
+
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
                        float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s, bool bf16,
                        bool wide, int local) {
@@ -470,7 +480,7 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
   // XCD-local hand-off (local = layer parity, -1 = off): a row group's G workgroups must fit one XCD next to those of a second
   // sweep of the same parity (32 CUs; two workgroups per CU with 16-unit workgroups, one with 32-unit ones: G <= 32 / 16)
-  const bool loc = local >= 0 && H <= 512 && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();
+  const bool loc = local >= 0 && H <= local_max_h(bf16, wide) && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
@@ -515,7 +525,7 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
-  const bool loc = local >= 0 && H <= 512 && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();   // see gru_persistent_fwd
+  const bool loc = local >= 0 && H <= local_max_h(bf16, wide) && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();   // see gru_persistent_fwd
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
