@@ -660,6 +660,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         c.call(b2t_dropout_f32(w.U, w.Ud, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, reinterpret_cast<void*>(s)));
     });
   };
+  // (the per-sentence day GEMMs of a chunk have the same 83-of-128-row tiles; whole-sequence or first-chunk-plus-rest day layers
+  //  were measured equal, 19.00-19.12 ms all three: 17 GFLOP)
   if (day_chunked) for (int ci = 0; ci < nc; ++ci) t_day[ci] = day_task(chunks[ci][0], chunks[ci][1] - chunks[ci][0]);
   else { const int t = day_task(0, T); for (int ci = 0; ci < nc; ++ci) t_day[ci] = t; }
 
@@ -678,9 +680,12 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       const int t_gi = P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci]},
                              [&, l, t0, n](hipStream_t sg) {
         if (l == 0) {
-          if (c.bf16_gemm && (long long)n * B > 512) {
-            // amp mode: ONE row-mapped GEMM over all (t, b) rows instead of B per-sentence GEMMs, so that it takes the
-            // two-pass packed kernel (Z == 1)
+          static const bool rowmap = !(getenv("B2T_L0_ROWMAP") && atoi(getenv("B2T_L0_ROWMAP")) == 0);
+          if ((c.bf16_gemm || rowmap) && (long long)n * B > 512) {
+            // ONE row-mapped GEMM over all (t, b) rows of the chunk instead of B per-sentence GEMMs.  amp mode: so that it takes
+            // the two-pass packed kernel (Z == 1).  fp32 (late round 3): a per-sentence GEMM of a time chunk has M = 83 rows, i.e.
+            // one 128-row tile of which 35 % is padding -- 4608 tiles per step where 3024 dense ones do: 19.24-19.38 -> 18.94-19.12 ms
+            // per step, same results bit for bit (B2T_L0_ROWMAP=0: the per-sentence form)
             b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
             d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
             c.gemm(sg, d);
