@@ -926,7 +926,12 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     const long long tiles = (((long long)n * B + 127) / 128) * ((N + 127) / 128);
     if (l > 0 && nc == 1 && !c.bf16_gemm && w.slab_dx && tiles <= 512 && 3 * H >= 1024) c.gemm(s, d, 2, w.slab_dx);
     else c.gemm(s, d);
-    if (l == 0 && fast_day) {
+    // The day layer's weight gradient (per-sentence x^T dpre, then the reduction by day) ONCE over the whole sequence behind the
+    // last chunk instead of chunk by chunk: the per-chunk GEMMs had K = 125 (14 TF/s, and 128 MB of slab read-modify-write
+    // each) and four column-sum passes -- 1.9 ms of queue time per step for 17 GFLOP; as one K = 500 GEMM it adds ~0.3 ms to the
+    // tail and the step goes from 18.90-19.05 to 18.75-18.88 ms (B2T_DAY_WGRAD_LATE=0: per chunk)
+    static const bool day_late = !(getenv("B2T_DAY_WGRAD_LATE") && atoi(getenv("B2T_DAY_WGRAD_LATE")) == 0);
+    if (l == 0 && fast_day && !day_late) {
       const int first = t0 + n == Tp ? 0 : 1;   // the top time chunk is swept first: it overwrites, the others accumulate
       b2t_gemm_desc d = gd(x + (long long)t0 * F, w.dU + (long long)t0 * F, w.day_slab, F, F, n);
       d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;
@@ -982,6 +987,14 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // layer-0 input gradient -> day layer
   const int t_dayfin = P.add("day_w", fast_day ? 60.f : est_gemm(F, F, T, B) + 200.f, Q_ANY, {t_dx[0][0]}, [&](hipStream_t s) {
     void* sp = reinterpret_cast<void*>(s);
+    static const bool day_late = !(getenv("B2T_DAY_WGRAD_LATE") && atoi(getenv("B2T_DAY_WGRAD_LATE")) == 0);
+    if (fast_day && day_late) {
+      b2t_gemm_desc d = gd(x, w.dU, w.day_slab, F, F, T);
+      d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;
+      d.c_s0 = F; d.c_sz = (long long)F * F;
+      c.gemm(s, d);
+      c.call(b2t_colsum_f32(w.dU, T, F, F, w.day_bslab, 0, w.cs_day, B, (long long)T * F, bias_ld, sp));
+    }
     if (!fast_day) {
       if (prm->patch > 0) c.call(b2t_patch_fold_f32(w.dV, w.dU, B, T, F, Tp, prm->patch, prm->stride, sp));
       if (p->in_drop > 0.f) c.call(b2t_dropout_f32(w.dU, w.dU, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, sp));
@@ -996,7 +1009,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     c.call(b2t_day_reduce_f32(w.day_slab, day_idx, B, (long long)F * F, grd->day_w, grd->day_w_stride, sp));
     c.call(b2t_day_reduce_f32(w.day_bslab, day_idx, B, bias_ld, grd->day_b, grd->day_b_stride, sp));
   });
-  if (!fast_day) for (int ci = 1; ci < nc; ++ci) P.dep(t_dayfin, t_dx[0][ci]);
+  if (!fast_day || !(getenv("B2T_DAY_WGRAD_LATE") && atoi(getenv("B2T_DAY_WGRAD_LATE")) == 0)) for (int ci = 1; ci < nc; ++ci) P.dep(t_dayfin, t_dx[0][ci]);
   bucket(L + 2, t_dayfin);
   // h0 gradient: sum over layers and batch rows of the carry after t=0 (rnn_model.py:86,123)
   const int t_h0 = P.add("h0", 20.f, Q_ANY, {t_bs[0][0]}, [&](hipStream_t s) {
