@@ -61,8 +61,9 @@ struct Hdr {
 // Scratch of the CLUSTER search (several workgroups per utterance, wfst_cluster_kernel below): every word is written with L2
 // atomics or plain stores and read with L1-bypassing (sc1) loads by the workgroups of one cluster, which share an XCD's L2.
 constexpr int WLG_CAP = 1 << 19;   // epsilon work list of a frame (tokens whose state has input-epsilon arcs; 125 k-word graphs put > 65 k of them into peak frames)
-constexpr int HEAVY_CAP = 1 << 17; // heavy-token list of a frame
+constexpr int HEAVY_CAP = 1 << 17; // heavy-token list of a frame: one 8-byte entry per CHUNK of a heavy token's arcs (below)
 constexpr int HEAVY_DEG = 32;
+constexpr int CHASE_DEPTH = 4;    // tokens a thread of the epsilon closure may have pending (lowered, arcs not yet relaxed)
 struct Clu {
   unsigned bar, bar_base; int pad0[14];          // cluster barrier: monotonic arrival counter, its value when the last launch ended
   int n_tok, n_link, overflow, wl_n;             // the counters the single-workgroup kernel keeps in LDS
@@ -78,7 +79,7 @@ struct Lay {
   int* tok_state; unsigned* tok_cost; int* tok_best; unsigned* tok_extra; unsigned* tok_prev;
   int* link_src; int* link_dst; int* link_arc; float* link_ac; float* link_graph; unsigned char* link_alive;
   int* gkey; int* gidx;
-  Clu* clu; int* wlg; int* gkey2; int* gidx2; int* heavy;
+  Clu* clu; int* wlg; int* gkey2; int* gidx2; unsigned long long* heavy;
 };
 
 __host__ __device__ inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -109,7 +110,7 @@ __host__ __device__ __forceinline__ size_t layout(char* base, int max_frames, in
   int* wg = reinterpret_cast<int*>(take(sizeof(int) * WLG_CAP));
   int* gk2 = reinterpret_cast<int*>(take(sizeof(int) * hash));
   int* gi2 = reinterpret_cast<int*>(take(sizeof(int) * hash));
-  int* hv = reinterpret_cast<int*>(take(sizeof(int) * HEAVY_CAP));
+  unsigned long long* hv = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * HEAVY_CAP));
   if (l) *l = Lay{h, lp, mp, to, lo, co, ts, tc, tb, te, tp, ls, ld, la, lac, lg, lv, gk, gi, cl, wg, gk2, gi2, hv};
   return o;
 }
@@ -569,6 +570,7 @@ struct CCtx {
   unsigned bar_target;
   float* ll; float* redf; int* redi; int* lsh;   // LDS: frame log-likelihoods, reduction scratch, [0] dead flag, [1..] scalars
   int* key; int* idx;                            // hash of the frame being built
+  int* stk_t; float* stk_c;                      // LDS: per-thread stack of the epsilon closure's chase ([CHASE_DEPTH][NT])
 };
 
 // Cluster barrier.  Every store this workgroup issued has reached L2 (vmcnt(0): stores are acknowledged by L2) before its
@@ -778,7 +780,9 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
   // the word-boundary tokens sit together at the end of a frame's token range (the epsilon closure creates them last).
   //   light tokens (<= HEAVY_DEG arcs): 64-token blocks dealt round-robin over ALL waves of the cluster (block q -> member
   //     q % G), arcs flattened inside the wave as in the single-workgroup kernel;
-  //   heavy tokens: collected in a list by pass A's light walk, then one whole wave per heavy token, round-robin.
+  //   heavy tokens: pass A's light walk lists them CHUNK by chunk (64 arcs, up to 16 chunks; longer rows get wider chunks),
+  //     then one wave per chunk, round-robin: a 400-arc token is seven waves' work, not seven trips of one wave while its
+  //     neighbours idle (~66 heavy tokens per frame for 128 waves).
   // (With the blocks dealt member by member the members that got the frame's last blocks took 3-4x as long as the others.)
   const int gwave = (int)(threadIdx.x >> 6) * c.G + c.j, nwaves = c.G * (NT / 64);
   auto walk_light = [&](bool collect, auto&& visit) {
@@ -790,12 +794,26 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
         if (cur <= cur_cutoff) { s = ldi(&c.l.tok_state[t]); a0 = g.row[s] + g.n_eps[s]; deg = g.row[s + 1] - a0; }
       }
       narcs += deg;
+      int nch = 0, sh = 0;
       if (deg > HEAVY_DEG) {
-        if (collect) {
-          const int hi = wave_alloc(&cl->n_heavy);
-          if (hi < HEAVY_CAP) c.l.heavy[hi] = t; else atomicOr(&cl->overflow, 16);   // (16 k heavy tokens in one frame: capacity error)
+        if (collect) {                             // chunks of 64 << sh arcs, at most 16 per token
+          while (((deg - 1) >> (6 + sh)) >= 16) ++sh;
+          nch = ((deg - 1) >> (6 + sh)) + 1;
         }
         deg = 0;
+      }
+      if (collect && __ballot(nch > 0)) {          // wave-uniform: one counter atomic per wave for all its chunks
+        int ci = nch;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(ci, off, 64); if (lane >= off) ci += v; }
+        const int ctot = __shfl(ci, 63, 64);
+        int cb = 0;
+        if (lane == 0) cb = atomicAdd(&cl->n_heavy, ctot);
+        cb = __shfl(cb, 0, 64) + ci - nch;
+        for (int k = 0; k < nch; ++k) {
+          if (cb + k < HEAVY_CAP) c.l.heavy[cb + k] = ((unsigned long long)(unsigned)((k << 8) | sh) << 32) | (unsigned)t;
+          else atomicOr(&cl->overflow, 16);        // (128 k chunks in one frame: capacity error; every entry below the cap is written)
+        }
       }
       int incl = deg;
 #pragma unroll
@@ -819,11 +837,13 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
     if (c.gtid == 0) { c.tacc[12] += nh; c.tacc[13] += 1; }
 #endif
     for (int i = gwave; i < nh; i += nwaves) {
-      const int t = ldi(&c.l.heavy[i]);
+      const unsigned long long e = __hip_atomic_load(&c.l.heavy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = (int)(unsigned)(e & 0xffffffffull), span = 64 << (int)((e >> 32) & 0xffull), k = (int)(e >> 40);
       const float cur = o2f(ldu(&c.l.tok_cost[t]));
       const int s = ldi(&c.l.tok_state[t]);
       const int a0 = g.row[s] + g.n_eps[s], deg = g.row[s + 1] - a0;
-      for (int jb = 0; jb < deg; jb += 64) if (jb + lane < deg) visit(t, cur, s, a0 + jb + lane);
+      const int hi = min(deg, (k + 1) * span);
+      for (int jb = k * span; jb < hi; jb += 64) if (jb + lane < hi) visit(t, cur, s, a0 + jb + lane);
     }
   };
   // ---- pass A: the frame's cheapest candidate.  Under it: the previous frame's backpointers, the other hash cleared,
@@ -888,27 +908,40 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
   if (!cbar(c)) return false;
   CT(7)   // barrier B
   const int lem = min(ldi(&cl->n_link), c.max_link);
-  // ---- ProcessNonemitting: Bellman-Ford rounds over the work list (it grows while tokens are created)
-  int wl_seen = -1;
+  // ---- ProcessNonemitting.  One pass over the work list in which whoever LOWERS a token's cost goes on to relax that token's
+  //      epsilon arcs itself, with the value it wrote (a small per-thread stack in LDS): every final cost was written by a
+  //      thread that then relaxed the token's arcs with exactly that cost, so the pass ends at the fixed point and needs no
+  //      second sweep to notice it -- one cluster barrier instead of one per level of the epsilon chains plus one (4-5 rounds
+  //      of ~10 us each before).  Only a stack overflow (CHASE_DEPTH pending tokens in one thread) asks for another round.
   for (int round = 0;; ++round) {
     const int wn = min(ldi(&cl->wl_n), WLG_CAP);
-    if (round > 0 && wn == wl_seen && ldi(&cl->changed[(round - 1) & 7]) == 0) break;
-    wl_seen = wn;
+    if (round > 0 && ldi(&cl->changed[(round - 1) & 7]) == 0) break;
     if (c.gtid == 0) cl->changed[(round + 2) & 7] = 0;
     for (int i = c.gtid; i < wn; i += c.gthreads) {
-      const int t = ldi(&c.l.wlg[i]);
-      const int s = ldi(&c.l.tok_state[t]);
-      const float cur = o2f(ldu(&c.l.tok_cost[t]));
-      if (!(cur < next_cutoff)) continue;
-      const int a0 = g.row[s], ne = g.n_eps[s];
-      for (int a = a0; a < a0 + ne; ++a) {
-        const float tot = cur + g.weight[a];
-        if (tot < next_cutoff) {
-          const int id = cclaim(c, g.next[a]);
-          if (id < 0) continue;
-          const unsigned nb = f2o(tot);
-          const unsigned old = atomicMin(&c.l.tok_cost[id], nb);
-          if (nb < old) __hip_atomic_store(&cl->changed[round & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int sp = 1;
+      c.stk_t[threadIdx.x] = ldi(&c.l.wlg[i]);
+      c.stk_c[threadIdx.x] = INFINITY;             // (the listed token's cost is read below; chased ones carry theirs)
+      while (sp > 0) {
+        --sp;
+        const int t = c.stk_t[sp * NT + threadIdx.x];
+        float cur = c.stk_c[sp * NT + threadIdx.x];
+        if (cur == INFINITY) cur = o2f(ldu(&c.l.tok_cost[t]));
+        if (!(cur < next_cutoff)) continue;
+        const int s = ldi(&c.l.tok_state[t]);
+        const int a0 = g.row[s], ne = g.n_eps[s];
+        for (int a = a0; a < a0 + ne; ++a) {
+          const float tot = cur + g.weight[a];
+          if (tot < next_cutoff) {
+            const int ns = g.next[a];
+            const int id = cclaim(c, ns);
+            if (id < 0) continue;
+            const unsigned nb = f2o(tot);
+            const unsigned old = atomicMin(&c.l.tok_cost[id], nb);
+            if (nb < old && g.n_eps[ns] > 0) {
+              if (sp < CHASE_DEPTH) { c.stk_t[sp * NT + threadIdx.x] = id; c.stk_c[sp * NT + threadIdx.x] = tot; ++sp; }
+              else __hip_atomic_store(&cl->changed[round & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
         }
       }
     }
@@ -966,7 +999,8 @@ __global__ __launch_bounds__(NT) void wfst_cluster_kernel(Graph g, char* state, 
                                                            int max_tok, int max_link, int hash, int G, int U,
                                                            const float* __restrict__ logp, const int* __restrict__ lens, int T, int C) {
   __shared__ float ll[MAX_C], lastp[MAX_C], redf[NT];
-  __shared__ int redi[NT], lsh[8];
+  __shared__ int redi[NT], lsh[8], stk_t[CHASE_DEPTH * NT];
+  __shared__ float stk_c[CHASE_DEPTH * NT];
   // block b = (k / 8) * 8G + j * 8 + (k % 8): the G members of cluster (utterance) k all have b % 8 == k % 8, i.e. one XCD
   const int b = blockIdx.x, grp = b / (8 * G), r = b % (8 * G);
   const int j = r / 8, u = grp * 8 + (r % 8);
@@ -975,7 +1009,7 @@ __global__ __launch_bounds__(NT) void wfst_cluster_kernel(Graph g, char* state, 
   c.g = g; c.o = o; c.max_frames = max_frames; c.max_tok = max_tok; c.max_link = max_link; c.hash = hash;
   layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &c.l);
   c.cl = c.l.clu; c.G = G; c.j = j; c.gtid = j * NT + (int)threadIdx.x; c.gthreads = G * NT;
-  c.ll = ll; c.redf = redf; c.redi = redi; c.lsh = lsh;
+  c.ll = ll; c.redf = redf; c.redi = redi; c.lsh = lsh; c.stk_t = stk_t; c.stk_c = stk_c;
   c.key = c.l.gkey; c.idx = c.l.gidx;
   if (threadIdx.x < 8) lsh[threadIdx.x] = 0;
   if ((int)threadIdx.x < MAX_C) lastp[threadIdx.x] = c.l.last_prob[threadIdx.x];   // every member keeps its own copy of the remembered blank frame
