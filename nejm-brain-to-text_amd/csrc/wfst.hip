@@ -19,7 +19,8 @@
 //     expanded (ProcessNonemitting and the next frame's cutoff skip them) and disappear in FinalizeDecoding, so the
 //     pruned lattice, best path and n-best are the same.  (Only GetCutoff's max_active / min_active COUNTS can see such
 //     tokens: a difference exists only while max_active binds in consecutive frames.)
-//   * ProcessNonemitting's work queue becomes Bellman-Ford sweeps over the frame's tokens until no cost changes; forward
+//   * ProcessNonemitting's work queue becomes Bellman-Ford sweeps over the frame's tokens until no cost changes (the
+//     cluster search: one pass in which the thread that lowers a token's cost relaxes that token's arcs itself); forward
 //     links are generated once, after convergence, with the final costs (what the queue leaves behind).
 //   * PruneActiveTokens every prune_interval frames is a memory optimisation (it only removes what FinalizeDecoding would
 //     remove as well: its extra_costs are lower bounds), so it is a pass of its own between search calls (wfst_prune_kernel,
