@@ -461,10 +461,10 @@ typedef struct {
 } b2t_wfst_opts_t;
 size_t b2t_wfst_state_bytes(int max_frames, int max_tokens, int max_links, int hash_size);
 /* Workgroups per utterance b2t_wfst_search_f32 will use for U utterances: 8 / 4 / 2 share one utterance's frame (a cluster
- * behind one XCD's L2, cluster barriers and L2 atomics) while every cluster fits the chip, else 1 (one workgroup per
- * utterance, frame hash in LDS).  No reference counterpart (the reference's search is one CPU thread). */
+ * behind one XCD's L2, cluster barriers and L2 atomics) while every cluster fits the chip, else 1 (the same kernel with one
+ * member per utterance).  No reference counterpart (the reference's search is one CPU thread). */
 int b2t_wfst_cluster_size(int U);
-int b2t_wfst_set_cluster(int G);   /* process-wide override: 1 / 2 / 4 / 8 / 16 / 32 workgroups per utterance, 0 = automatic (B2T_WFST_CLUSTER) */
+int b2t_wfst_set_cluster(int G);   /* process-wide override: 2 / 4 / 8 / 16 / 32 workgroups per utterance; 1 = the single-workgroup kernel (frame hash in LDS; the form the cluster search is tested against); -1 = the cluster kernel with one member; 0 = automatic (B2T_WFST_CLUSTER) */
 int b2t_wfst_reset(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, void* stream);   /* InitDecoding */
 /* logp [U][T][C] (C <= 64), lens [U] or NULL: blank-frame skipping + AdvanceDecoding(.., 1) per kept frame */
 int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, const float* logp,

@@ -1925,10 +1925,16 @@ static bool wfst_xcd_roundrobin_ok() {
 }
 
 static int g_cluster_override = 0;
-extern "C" int b2t_wfst_set_cluster(int G) { g_cluster_override = G < 0 ? 0 : G; return 0; }   // 0 = automatic
-extern "C" int b2t_wfst_cluster_size(int U) {
+// 0 = automatic; 2 .. 32 = that many workgroups per utterance; 1 = the single-workgroup kernel (frame hash in LDS: round 2's
+// search, kept as the reference the cluster search is tested against); -1 = the cluster kernel with ONE member
+extern "C" int b2t_wfst_set_cluster(int G) { g_cluster_override = G < -1 ? 0 : G; return 0; }
+static int wfst_forced_cluster() {
   static const int env = getenv("B2T_WFST_CLUSTER") ? atoi(getenv("B2T_WFST_CLUSTER")) : 0;
-  const int forced = g_cluster_override ? g_cluster_override : env;
+  return g_cluster_override ? g_cluster_override : env;
+}
+extern "C" int b2t_wfst_cluster_size(int U) {
+  const int forced = wfst_forced_cluster();
+  if (forced == -1) return 1;
   if (forced >= 1) return forced >= 32 ? 32 : forced >= 16 ? 16 : forced >= 8 ? 8 : forced >= 4 ? 4 : forced >= 2 ? 2 : 1;
   // 8 workgroups per utterance where they are all resident.  Larger clusters work (b2t_wfst_set_cluster(16 / 32): up to a whole
   // XCD per utterance, tested against the single-workgroup search) but buy nothing: one utterance takes 11.7 / 11.1 / 11.7 ms
@@ -1945,7 +1951,10 @@ extern "C" int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opt
   B2T_REQUIRE(logp && T > 0 && C > 1 && C <= MAX_C, "wfst_search: bad logp shape T=%d C=%d", T, C);
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size), lds = lds_hash_bytes(o);
   const int G = b2t_wfst_cluster_size(U);
-  if (G > 1) {
+  // More utterances than clusters fit: still the cluster kernel, with one member each (its barriers then cost an atomic, and
+  // its one-pass epsilon closure and single claim-relax-link walk make it faster than the single-workgroup kernel with its
+  // ~45 __syncthreads per frame: 55.4 against 63.1 ms for 256 utterances).
+  if (G > 1 || wfst_forced_cluster() != 1) {
     const int grid = (U + 7) / 8 * 8 * G;
     hipLaunchKernelGGL(wfst_cluster_kernel, dim3(grid), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
                        o->max_frames, o->max_tokens, o->max_links, o->hash_size, G, U, logp, lens, T, C);
