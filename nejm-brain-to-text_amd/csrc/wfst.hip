@@ -64,7 +64,10 @@ struct Hdr {
 constexpr int WLG_CAP = 1 << 19;   // epsilon work list of a frame (tokens whose state has input-epsilon arcs; 125 k-word graphs put > 65 k of them into peak frames)
 constexpr int HEAVY_CAP = 1 << 17; // heavy-token list of a frame: one 8-byte entry per CHUNK of a heavy token's arcs (below)
 constexpr int HEAVY_DEG = 32;
-constexpr int CHASE_DEPTH = 4;    // tokens a thread of the epsilon closure may have pending (lowered, arcs not yet relaxed)
+#ifndef B2T_CHASE_DEPTH
+#define B2T_CHASE_DEPTH 4     // (-DB2T_CHASE_DEPTH=1 builds a library whose closure overflows all the time: the fallback rounds under test)
+#endif
+constexpr int CHASE_DEPTH = B2T_CHASE_DEPTH;    // tokens a thread of the epsilon closure may have pending (lowered, arcs not yet relaxed)
 struct Clu {
   unsigned bar, bar_base; int pad0[14];          // cluster barrier: monotonic arrival counter, its value when the last launch ended
   int n_tok, n_link, overflow, wl_n;             // the counters the single-workgroup kernel keeps in LDS
