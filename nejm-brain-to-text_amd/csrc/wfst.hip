@@ -922,10 +922,11 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
     if (round > 0 && ldi(&cl->changed[(round - 1) & 7]) == 0) break;
     if (c.gtid == 0) cl->changed[(round + 2) & 7] = 0;
     for (int i = c.gtid; i < wn; i += c.gthreads) {
-      int sp = 1;
+      int sp = 1, pops = 0;
       c.stk_t[threadIdx.x] = ldi(&c.l.wlg[i]);
       c.stk_c[threadIdx.x] = INFINITY;             // (the listed token's cost is read below; chased ones carry theirs)
       while (sp > 0) {
+        if (++pops > (1 << 14)) { atomicOr(&cl->overflow, 32); break; }   // (an epsilon cycle of negative weight: refuse, do not hang)
         --sp;
         const int t = c.stk_t[sp * NT + threadIdx.x];
         float cur = c.stk_c[sp * NT + threadIdx.x];

@@ -205,7 +205,8 @@ class WfstSearch:
                                    "B2T_WFST_CLUSTER=1 to use one workgroup per utterance")
             if bits & 32:
                 raise RuntimeError("WFST cluster search: a cluster barrier timed out (a workgroup of the cluster was not resident: "
-                                   "is another kernel holding CUs?); results are invalid -- reset() and retry, or B2T_WFST_CLUSTER=1")
+                                   "is another kernel holding CUs?) or a frame's epsilon closure did not converge (an epsilon cycle of negative "
+                                   "weight in the graph); results are invalid -- reset() and retry, or B2T_WFST_CLUSTER=1")
             what = [n for b, n in ((1, "max_tokens"), (2, "max_links"), (4, "hash_size"), (8, "max_frames"), (16, "epsilon work list / heavy-token list of a frame (524288 / 131072)")) if bits & b]
             raise RuntimeError(f"WFST search: a capacity was exhausted ({', '.join(what)} of {self.caps}; peak tokens "
                                f"{int(h[:, 1].max())}, links {int(h[:, 2].max())}); results are invalid -- construct WfstSearch "
