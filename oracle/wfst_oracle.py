@@ -239,7 +239,11 @@ class LatticeFasterDecoder:
                 if tok_extra > self.cfg.lattice_beam:
                     tok_extra = F32(INF)
                 a, b = float(tok.extra_cost), float(tok_extra)
-                if not (a == b or abs(a - b) <= delta * (abs(a) + abs(b))):   # ApproxEqual
+                # ApproxEqual (kaldi/base/kaldi-math.h:265-273): equal values (incl. both infinite) are equal; an infinite or
+                # NaN difference is NOT (without this rule a token going 0 -> inf passed as unchanged, inf <= delta * inf, and an
+                # epsilon link into it survived its destination: tests/test_gpu_wfst.py::test_deep_epsilon_fans_equal_the_oracle)
+                diff = abs(a - b) if a != b else 0.0
+                if not (a == b or (diff != INF and diff == diff and diff <= delta * (abs(a) + abs(b)))):
                     changed = True
                 tok.extra_cost = tok_extra
 

@@ -224,6 +224,72 @@ def test_cluster_search_equals_single_workgroup(toy):
         lib.b2t_wfst_set_cluster(0)
 
 
+def test_deep_epsilon_fans_equal_the_oracle():
+    """ProcessNonemitting (lattice-faster-decoder.cc:839-909) where the epsilon closure is deep and wide: a ternary tree of
+    epsilon arcs, three levels deep, hung below the start state and below five mid-graph states, its 27 leaves re-entering the
+    graph.  The cluster search closes a frame in ONE pass (whoever lowers a token relaxes its arcs, four pending tokens per
+    thread at most): here a thread that pops a tree node pushes three children, so the stack overflows and the fallback rounds
+    run as well.  Frames, partial path and n-best lists equal the oracle's for 8 / 1 cluster members and the single-workgroup
+    kernel."""
+    import b2t_native as N
+    from wfst_decoder import WfstSearch
+    lib = N.load()
+    prons = ngram_lm.synthetic_lexicon(40, 41, seed=21)
+    words = sorted(prons)
+    arpa = ngram_lm.synthetic_word_arpa(words, 3, 300, seed=22)
+    table = ["<eps>"] + words + ["#0", "<s>", "</s>"]
+    word_id = {w: i for i, w in enumerate(table) if 0 < i <= len(words)}
+    wd0, td0 = len(words) + 1, 42
+    tok_prons = {w: [[int(c) + 1 for c in p] for p in ps] for w, ps in prons.items()}
+    f = wfst.trim(wfst.compose(wfst.token_fst(40, [td0]), wfst.compose(wfst.lexicon_fst(tok_prons, word_id, 0.5, 2, td0, wd0),
+                                                                     wfst.grammar_fst(arpa, word_id, wd0))))
+    n_eps = np.zeros(f.n, np.int64)
+    for a in f.arcs:
+        n_eps[a[0]] += a[1] == 0
+    rs = np.random.RandomState(3)
+    no_eps = [s for s in range(f.n) if n_eps[s] == 0 and s != f.start]           # the leaves land here: no epsilon cycle arises
+    with_eps = [s for s in range(f.n) if n_eps[s] > 0 and s != f.start]
+    root = f.add_state()
+    level = [root]
+    for depth in range(3):
+        nxt = []
+        for i, s in enumerate(level):
+            for k in range(3):
+                d = f.add_state(); nxt.append(d)
+                f.add_arc(s, 0, 0, 0.05 + 0.03 * ((7 * i + 3 * k + depth) % 5), d)
+        level = nxt
+    assert len(level) == 27
+    for i, s in enumerate(level):
+        for d in rs.choice(no_eps, 2, replace=False):
+            f.add_arc(s, 0, 0, 0.1 + 0.02 * (i % 4), int(d))
+    f.add_arc(f.start, 0, 0, 0.3, root)
+    for s in rs.choice(with_eps, 5, replace=False):
+        f.add_arc(int(s), 0, 0, 0.4, root)
+    g = wfst.DecodeGraph(f, table)
+    seqs, lps, batch, lens = utterances(prons, words, 3, np.random.RandomState(8), noise=1.0)
+    dev_batch = torch.from_numpy(batch).cuda()
+    o = Opt(nbest=15)
+    refs, partial = [], []
+    for u in range(3):
+        R = W.CtcWfstBeamSearch(g, cfg_of(o)); R.search(lps[u])
+        partial.append((len(R.mapping), list(R.outputs[0]), list(R.inputs[0])))
+        R.finalize_search(); refs.append(R)
+    try:
+        for G in (0, -1, 1):
+            lib.b2t_wfst_set_cluster(G)
+            S = WfstSearch(g, o, U=3, max_frames=batch.shape[1] + 8)
+            S.search(dev_batch, lens)
+            part = S.best_path(False)
+            for u in range(3):
+                assert S.frames_decoded()[u] == partial[u][0]
+                assert part[u][2] == partial[u][1] and part[u][0] == partial[u][2], (G, u)
+            fin = S.finalize()
+            for u in range(3):
+                compare_lists(fin[u], refs[u], f"fan G={G} utt{u}")
+    finally:
+        lib.b2t_wfst_set_cluster(0)
+
+
 def test_prune_active_tokens_bounds_memory_and_keeps_the_lattice(toy):
     """PruneActiveTokens every prune_interval frames (lattice-faster-decoder.cc:516-545, :592-630) as b2t_wfst_prune between
     search calls: the n-best lists, the partial best paths and the decoded frames are those of a search that prunes only once,

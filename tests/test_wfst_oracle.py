@@ -298,3 +298,27 @@ def test_convert_rows_to_inputs_equals_the_scalar_form():
         for u in range(U):
             i, t = WD.convert_to_inputs(ali[u, :n[u]], fr[u, :n[u]])
             assert a[u] == i and b[u] == t
+
+
+def test_final_pruning_uses_kaldis_approx_equal():
+    """PruneForwardLinksFinal (lattice-faster-decoder.cc:380-470) iterates while a token's extra cost is not ApproxEqual to its
+    old one, and ApproxEqual (kaldi/base/kaldi-math.h:265-273) calls an infinite difference unequal.  Graph: 0 -a-> 1 (final),
+    1 -eps-> 2 (dead end).  On the last frame the token of state 1 is visited first and keeps its epsilon link (the destination
+    still carries extra cost 0); the dead end then goes 0 -> inf, which must count as a change so that a second sweep removes the
+    link -- otherwise it outlives its destination and GetRawLattice meets a token that is gone."""
+    import wfst
+    f = wfst.Fst()
+    for _ in range(3):
+        f.add_state()
+    f.start = 0
+    f.add_arc(0, 2, 1, 0.5, 1)
+    f.add_arc(1, 0, 0, 0.25, 2)
+    f.final[1] = 0.0
+    g = wfst.DecodeGraph(f, ["<eps>", "w"])
+    lp = np.full((1, 41), -5.0, np.float32); lp[0, 1] = -0.1
+    R = W.CtcWfstBeamSearch(g, W.Config(nbest=5))
+    R.search(lp)
+    R.finalize_search()
+    assert [list(o) for o in R.outputs] == [[1]] and [list(i) for i in R.inputs] == [[1]]
+    arcs, finals, start = R.dec.raw_lattice()
+    assert sum(len(a) for a in arcs) == 1 and len(finals) == 1
