@@ -81,7 +81,7 @@ struct Clu {
 
 struct Lay {
   Hdr* h; float* last_prob; int* mapping; int* tok_off; int* link_off; float* cost_offset;
-  int* tok_state; unsigned* tok_cost; int* tok_best; unsigned* tok_extra; unsigned* tok_prev;
+  int* tok_state; unsigned* tok_cost; long long* tok_best; unsigned* tok_extra; unsigned* tok_prev;   // tok_best: {best link (high word), its source token}
   int* link_src; int* link_dst; int* link_arc; float* link_ac; float* link_graph; unsigned char* link_alive;
   int* gkey; int* gidx;
   Clu* clu; int* wlg; int* gkey2; int* gidx2; unsigned long long* heavy;
@@ -100,7 +100,7 @@ __host__ __device__ __forceinline__ size_t layout(char* base, int max_frames, in
   float* co = reinterpret_cast<float*>(take(sizeof(float) * (max_frames + 1)));
   int* ts = reinterpret_cast<int*>(take(sizeof(int) * max_tok));
   unsigned* tc = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * max_tok));
-  int* tb = reinterpret_cast<int*>(take(sizeof(int) * max_tok));
+  long long* tb = reinterpret_cast<long long*>(take(sizeof(long long) * max_tok));
   unsigned* te = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * max_tok));
   unsigned* tp = reinterpret_cast<unsigned*>(take(sizeof(unsigned) * max_tok));
   int* ls = reinterpret_cast<int*>(take(sizeof(int) * max_link));
@@ -128,6 +128,12 @@ __device__ __forceinline__ unsigned f2o(float f) {
 __device__ __forceinline__ float o2f(unsigned o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
+
+// A token's backpointer: the cheapest-arriving link with the smallest index (best_links' rule) AND that link's source token, one
+// 8-byte word {link (high, signed), source token (low)} so that the best-path walk is ONE dependent load per hop; atomicMin on
+// the word orders by link.  -1 = the start token, BEST_UNSET = not computed yet.
+constexpr long long BEST_UNSET = 0x7fffffffffffffffLL;
+__device__ __forceinline__ long long best_word(int li, int src) { return ((long long)li << 32) | (long long)(unsigned)src; }
 
 struct Opts {
   float beam, lattice_beam, beam_delta, acoustic_scale, length_penalty, blank_skip_thresh;
@@ -252,7 +258,7 @@ __device__ __forceinline__ int claim(Ctx& c, int state) {
         const int id = atomicAdd(&c.sh[0], 1);
         if (id < c.max_tok) {
           c.idx[s] = id;
-          c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = 0x7fffffff; c.l.tok_extra[id] = 0u;
+          c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = BEST_UNSET; c.l.tok_extra[id] = 0u;
         } else {
           c.idx[s] = -1; atomicOr(&c.sh[3], 1);
         }
@@ -363,7 +369,7 @@ __device__ void best_links(Ctx& c, int l0, int l1) {
   for (int li = l0 + threadIdx.x; li < l1; li += NT) {
     const int src = c.l.link_src[li], dst = c.l.link_dst[li];
     const float tot = o2f(c.l.tok_cost[src]) + c.l.link_ac[li] + c.l.link_graph[li];
-    if (f2o(tot) == c.l.tok_cost[dst]) atomicMin(&c.l.tok_best[dst], li);
+    if (f2o(tot) == c.l.tok_cost[dst]) atomicMin(&c.l.tok_best[dst], best_word(li, src));
   }
   __syncthreads();
 }
@@ -705,7 +711,7 @@ __device__ __forceinline__ int cclaim(CCtx& c, int state) {
       if (__hip_atomic_compare_exchange_strong(kp, &expected, state, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         int id = wave_alloc(&c.cl->n_tok);
         if (id < c.max_tok) {
-          c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = 0x7fffffff; c.l.tok_extra[id] = 0u;
+          c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = BEST_UNSET; c.l.tok_extra[id] = 0u;
           if (c.g.n_eps[state] > 0) {
             const int w = wave_alloc(&c.cl->wl_n);
             if (w < WLG_CAP) c.l.wlg[w] = id; else atomicOr(&c.cl->overflow, 16);
@@ -738,7 +744,7 @@ __device__ __forceinline__ void cbest_links(CCtx& c, int l0, int l1) {
   for (int li = l0 + c.gtid; li < l1; li += c.gthreads) {
     const int src = ldi(&c.l.link_src[li]), dst = ldi(&c.l.link_dst[li]);
     const float tot = o2f(ldu(&c.l.tok_cost[src])) + ldf(&c.l.link_ac[li]) + ldf(&c.l.link_graph[li]);
-    if (f2o(tot) == ldu(&c.l.tok_cost[dst])) atomicMin(&c.l.tok_best[dst], li);
+    if (f2o(tot) == ldu(&c.l.tok_cost[dst])) atomicMin(&c.l.tok_best[dst], best_word(li, src));
   }
 }
 
@@ -1210,7 +1216,7 @@ __global__ void wfst_best_path_kernel(Graph g, char* state, size_t state_bytes, 
   best = r_cost[0]; bt = r_tok[0]; best_fc = r_fc[0];
   (void)best;
   if (bt < 0) return;
-  // Walk back.  The chain itself -- token -> its best link -> that link's source token -- is two dependent loads per hop and is
+  // Walk back.  The chain itself -- token -> {its best link, that link's source token} -- is ONE dependent load per hop and is
   // all thread 0 does per hop (the link ids go to LDS); what a link contributes (labels, costs, the frame it belongs to, that
   // frame's cost offset and input frame) is then fetched by all threads at once, frames from a prefix count of the emitting
   // links, and thread 0 only sums and emits from LDS, in walk order (the sums are the serial walk's, bit for bit).  The
@@ -1227,10 +1233,10 @@ __global__ void wfst_best_path_kernel(Graph g, char* state, size_t state_bytes, 
     if (threadIdx.x == 0) {
       int t = s_ctl[0], n = 0, done = 0;
       while (n < BP_CAP) {
-        const int li = l.tok_best[t];
-        if (li < 0 || li == 0x7fffffff) { done = 1; break; }
-        s_li[n++] = li;
-        t = l.link_src[li];
+        const long long bw = l.tok_best[t];
+        if (bw < 0 || bw == BEST_UNSET) { done = 1; break; }
+        s_li[n++] = (int)(bw >> 32);
+        t = (int)(unsigned)(bw & 0xffffffffLL);
       }
       s_ctl[0] = t; s_ctl[1] = n; s_ctl[2] = done;
     }
@@ -1733,7 +1739,7 @@ __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, si
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k2[k] >= 0) { l.tok_state[k2[k]] = st[k]; l.tok_cost[k2[k]] = cs[k]; l.tok_extra[k2[k]] = ex[k]; l.tok_best[k2[k]] = 0x7fffffff; }
+    for (int k = 0; k < 4; ++k) if (k2[k] >= 0) { l.tok_state[k2[k]] = st[k]; l.tok_cost[k2[k]] = cs[k]; l.tok_extra[k2[k]] = ex[k]; l.tok_best[k2[k]] = BEST_UNSET; }
     __syncthreads();
   }
   // backpointers of the moved tokens: the first surviving link whose cost equals the token's (best_links' rule)
@@ -1741,7 +1747,7 @@ __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, si
     const int src = l.link_src[li], dst = l.link_dst[li];
     if (dst < T0) continue;
     const float tot = o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li];
-    if (f2o(tot) == l.tok_cost[dst]) atomicMin(&l.tok_best[dst], li);
+    if (f2o(tot) == l.tok_cost[dst]) atomicMin(&l.tok_best[dst], best_word(li, src));
   }
   __syncthreads();
 #ifdef B2T_WFST_TIMING
