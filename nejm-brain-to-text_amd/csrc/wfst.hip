@@ -63,19 +63,25 @@ struct Hdr {
 // Scratch of the CLUSTER search (several workgroups per utterance, wfst_cluster_kernel below): every word is written with L2
 // atomics or plain stores and read with L1-bypassing (sc1) loads by the workgroups of one cluster, which share an XCD's L2.
 constexpr int WLG_CAP = 1 << 19;   // epsilon work list of a frame (tokens whose state has input-epsilon arcs; 125 k-word graphs put > 65 k of them into peak frames)
-constexpr int HEAVY_CAP = 1 << 17; // heavy-token list of a frame: one 8-byte entry per CHUNK of a heavy token's arcs (below)
+constexpr int HEAVY_CAP = 1 << 17; // heavy-token list of a frame: one 16-byte entry {token, its cost, first arc, end arc} per CHUNK of a heavy token's arcs (below)
 constexpr int HEAVY_DEG = 32;
 #ifndef B2T_CHASE_DEPTH
 #define B2T_CHASE_DEPTH 4     // (-DB2T_CHASE_DEPTH=1 builds a library whose closure overflows all the time: the fallback rounds under test)
 #endif
 constexpr int CHASE_DEPTH = B2T_CHASE_DEPTH;    // tokens a thread of the epsilon closure may have pending (lowered, arcs not yet relaxed)
 struct Clu {
-  unsigned bar, bar_base; int pad0[14];          // cluster barrier: monotonic arrival counter, its value when the last launch ended
-  int n_tok, n_link, overflow, wl_n;             // the counters the single-workgroup kernel keeps in LDS
+  unsigned bar, bar_base; int pad0[62];          // cluster barrier: monotonic arrival counter, its value when the last launch ended
+  // the counters the single-workgroup kernel keeps in LDS -- each on a 256-byte block of its own: they take ~2500 atomics per
+  // frame between them (one per wave and trip), and atomics on words of one cache line are served one after the other
+  // (all four in one line: 14.8 ms for the 32-utterance search; apart: 13.5)
+  int n_tok, padt[63];
+  int n_link, padl[63];
+  int wl_n, padw[63];
+  int overflow, pado[63];
   unsigned best[2], cand_min[2]; int narcs[2];   // per frame parity: cheapest token of the frame, cheapest candidate, arcs walked
   int changed[8];                                // per closure round (mod 8): a cost went down
   int xcc[32];                                   // XCC_ID each member saw (placement check; up to 32 members: a whole XCD)
-  int n_heavy, pad1;                             // tokens of the frame with more than HEAVY_DEG emitting arcs (word-boundary states)
+  int n_heavy, pad1[63];                         // chunks of the frame's tokens with more than HEAVY_DEG emitting arcs (word-boundary states)
   int hist[2][4][256];                           // radix-select histograms: [max_active / min_active][round][digit]
 };
 
@@ -84,7 +90,7 @@ struct Lay {
   int* tok_state; unsigned* tok_cost; long long* tok_best; unsigned* tok_extra; unsigned* tok_prev;   // tok_best: {best link (high word), its source token}
   int* link_src; int* link_dst; int* link_arc; float* link_ac; float* link_graph; unsigned char* link_alive;
   int* gkey; int* gidx;
-  Clu* clu; int* wlg; int* gkey2; int* gidx2; unsigned long long* heavy;
+  Clu* clu; int* wlg; int* gkey2; int* gidx2; unsigned long long* heavy;   // heavy: 2 words per entry
 };
 
 __host__ __device__ inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -115,7 +121,7 @@ __host__ __device__ __forceinline__ size_t layout(char* base, int max_frames, in
   int* wg = reinterpret_cast<int*>(take(sizeof(int) * WLG_CAP));
   int* gk2 = reinterpret_cast<int*>(take(sizeof(int) * hash));
   int* gi2 = reinterpret_cast<int*>(take(sizeof(int) * hash));
-  unsigned long long* hv = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * HEAVY_CAP));
+  unsigned long long* hv = reinterpret_cast<unsigned long long*>(take(sizeof(unsigned long long) * 2 * HEAVY_CAP));
   if (l) *l = Lay{h, lp, mp, to, lo, co, ts, tc, tb, te, tp, ls, ld, la, lac, lg, lv, gk, gi, cl, wg, gk2, gi2, hv};
   return o;
 }
@@ -821,9 +827,17 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
         int cb = 0;
         if (lane == 0) cb = atomicAdd(&cl->n_heavy, ctot);
         cb = __shfl(cb, 0, 64) + ci - nch;
+        // (an entry carries everything a walk needs -- the token's cost is final by now --: the walks below go from the entry
+        //  straight to the arcs, two dependent round trips fewer than through tok_cost / tok_state / row)
+        const int hspan = 64 << sh, ha0 = a0, hdeg = g.row[s + 1] - a0;
         for (int k = 0; k < nch; ++k) {
-          if (cb + k < HEAVY_CAP) c.l.heavy[cb + k] = ((unsigned long long)(unsigned)((k << 8) | sh) << 32) | (unsigned)t;
-          else atomicOr(&cl->overflow, 16);        // (128 k chunks in one frame: capacity error; every entry below the cap is written)
+          if (cb + k < HEAVY_CAP) {
+            const int ab = ha0 + k * hspan, ae = ha0 + min(hdeg, (k + 1) * hspan);
+            c.l.heavy[2 * (cb + k)] = ((unsigned long long)__float_as_uint(cur) << 32) | (unsigned)t;
+            c.l.heavy[2 * (cb + k) + 1] = ((unsigned long long)(unsigned)ae << 32) | (unsigned)ab;
+          } else {
+            atomicOr(&cl->overflow, 16);           // (128 k chunks in one frame: capacity error; every entry below the cap is written)
+          }
         }
       }
       int incl = deg;
@@ -848,13 +862,12 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
     if (c.gtid == 0) { c.tacc[12] += nh; c.tacc[13] += 1; }
 #endif
     for (int i = gwave; i < nh; i += nwaves) {
-      const unsigned long long e = __hip_atomic_load(&c.l.heavy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int t = (int)(unsigned)(e & 0xffffffffull), span = 64 << (int)((e >> 32) & 0xffull), k = (int)(e >> 40);
-      const float cur = o2f(ldu(&c.l.tok_cost[t]));
-      const int s = ldi(&c.l.tok_state[t]);
-      const int a0 = g.row[s] + g.n_eps[s], deg = g.row[s + 1] - a0;
-      const int hi = min(deg, (k + 1) * span);
-      for (int jb = k * span; jb < hi; jb += 64) if (jb + lane < hi) visit(t, cur, s, a0 + jb + lane);
+      const unsigned long long e0 = __hip_atomic_load(&c.l.heavy[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long e1 = __hip_atomic_load(&c.l.heavy[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = (int)(unsigned)(e0 & 0xffffffffull), ab = (int)(unsigned)(e1 & 0xffffffffull), ae = (int)(unsigned)(e1 >> 32);
+      const float cur = __uint_as_float((unsigned)(e0 >> 32));
+      const int s = lp != 0.f ? ldi(&c.l.tok_state[t]) : -1;      // (only the length penalty looks at the source state)
+      for (int jb = ab; jb < ae; jb += 64) if (jb + lane < ae) visit(t, cur, s, jb + lane);
     }
   };
   // ---- pass A: the frame's cheapest candidate.  Under it: the previous frame's backpointers, the other hash cleared,
@@ -929,28 +942,33 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
     if (round > 0 && ldi(&cl->changed[(round - 1) & 7]) == 0) break;
     if (c.gtid == 0) cl->changed[(round + 2) & 7] = 0;
     for (int i = c.gtid; i < wn; i += c.gthreads) {
+      // (the stack holds STATES and the costs written for them: relaxing a token's arcs needs nothing else, so a chased token
+      //  costs no load of its own -- a level of the chain is row -> arc -> {hash slot, n_eps of the target} -> cost atomic)
       int sp = 1, pops = 0;
-      c.stk_t[threadIdx.x] = ldi(&c.l.wlg[i]);
-      c.stk_c[threadIdx.x] = INFINITY;             // (the listed token's cost is read below; chased ones carry theirs)
+      {
+        const int t = ldi(&c.l.wlg[i]);
+        const unsigned c0 = ldu(&c.l.tok_cost[t]);
+        c.stk_t[threadIdx.x] = ldi(&c.l.tok_state[t]);
+        c.stk_c[threadIdx.x] = o2f(c0);
+      }
       while (sp > 0) {
         if (++pops > (1 << 14)) { atomicOr(&cl->overflow, 32); break; }   // (an epsilon cycle of negative weight: refuse, do not hang)
         --sp;
-        const int t = c.stk_t[sp * NT + threadIdx.x];
-        float cur = c.stk_c[sp * NT + threadIdx.x];
-        if (cur == INFINITY) cur = o2f(ldu(&c.l.tok_cost[t]));
+        const int s = c.stk_t[sp * NT + threadIdx.x];
+        const float cur = c.stk_c[sp * NT + threadIdx.x];
         if (!(cur < next_cutoff)) continue;
-        const int s = ldi(&c.l.tok_state[t]);
         const int a0 = g.row[s], ne = g.n_eps[s];
         for (int a = a0; a < a0 + ne; ++a) {
           const float tot = cur + g.weight[a];
           if (tot < next_cutoff) {
             const int ns = g.next[a];
+            const int nne = g.n_eps[ns];           // (in flight next to the claim's slot load)
             const int id = cclaim(c, ns);
             if (id < 0) continue;
             const unsigned nb = f2o(tot);
             const unsigned old = atomicMin(&c.l.tok_cost[id], nb);
-            if (nb < old && g.n_eps[ns] > 0) {
-              if (sp < CHASE_DEPTH) { c.stk_t[sp * NT + threadIdx.x] = id; c.stk_c[sp * NT + threadIdx.x] = tot; ++sp; }
+            if (nb < old && nne > 0) {
+              if (sp < CHASE_DEPTH) { c.stk_t[sp * NT + threadIdx.x] = ns; c.stk_c[sp * NT + threadIdx.x] = tot; ++sp; }
               else __hip_atomic_store(&cl->changed[round & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
