@@ -233,10 +233,30 @@ class WfstSearch:
         here; the n-best extraction (host C++, one thread per utterance) runs on a background pool and is returned as a
         future -- the caller may reset() and decode the next batch of utterances while it runs (the state block is no longer
         needed), which takes the host n-best off the decode loop's critical path."""
-        from concurrent.futures import Future
+        self.finalize_begin()
+        return self.finalize_collect()
+
+    def finalize_begin(self):
+        """The first half of finalize_async(): FinalizeDecoding is launched, nothing is waited for.  `finalize_event` is
+        recorded behind it: a SECOND searcher working on another stream makes that stream wait for it
+        (`torch.cuda.current_stream().wait_event(first.finalize_event)`), resets and searches the next batch of utterances at
+        once -- two cluster searches must never be in flight together (neither would get all its workgroups resident), but
+        the lattice extraction, the copy to the host and the host's share of this batch then run under the next search
+        (tools/bench_wfst.py, `pipelined`)."""
         with torch.cuda.device(self.device):
             N.check(self.lib.b2t_wfst_finalize(C.byref(self.cg), C.byref(self.co), ops._p(self.state), self.U, self._s()), "b2t_wfst_finalize")
+            ev = self.__dict__.get("finalize_event")
+            if ev is None:
+                ev = self.finalize_event = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
         self.finalized = True
+
+    def finalize_collect(self):
+        """The second half of finalize_async() (call it under the stream finalize_begin() ran on): waits for the GPU, copies the
+        lattices out, starts the host n-best and returns its future."""
+        from concurrent.futures import Future
+        if not self.finalized:
+            raise RuntimeError("finalize_collect() before finalize_begin()")
         self._check_overflow()
         fut = Future()
         if self.nbest == 1:

@@ -208,24 +208,42 @@ def run():
     # numpy, the graph: ~200 k) under the interpreter lock -- measured as one 60-90 ms finalize in ten without the freeze
     import gc
     gc.collect(); gc.freeze()
+    # Two searchers on two streams.  Batch b + 1 is reset and searched (on the other stream, behind batch b's FinalizeDecoding
+    # kernel: two cluster searches are never in flight together) BEFORE the host waits for batch b's lattices, so the lattice
+    # extraction, the copy out and the host's share of batch b run under the next search instead of leaving the GPU idle
+    # (22.9 ms per batch with one stream, where the GPU waited ~4 ms per batch for the host).
+    st_a, st_b = torch.cuda.Stream(), torch.cuda.Stream()
+    st_a.wait_stream(torch.cuda.current_stream()); st_b.wait_stream(torch.cuda.current_stream())
     pend, t0, stamps = None, None, []
-    for b in range(8):
-        if b == 2:                                 # both searchers have decoded one batch (first use touches the state blocks)
+    NB = 10
+    with torch.cuda.stream(st_a):
+        S.reset(); S.search(lp, lens)
+    for b in range(NB):
+        if b == 2:
             torch.cuda.synchronize(); t0 = time.perf_counter()
-        Sx = S if b % 2 == 0 else S2
+        cur, cur_st = (S, st_a) if b % 2 == 0 else (S2, st_b)
+        nxt, nxt_st = (S2, st_b) if b % 2 == 0 else (S, st_a)
         ta = time.perf_counter()
-        Sx.reset(); Sx.search(lp, lens)
+        with torch.cuda.stream(cur_st):
+            cur.finalize_begin()
+        if b + 1 < NB:
+            with torch.cuda.stream(nxt_st):
+                nxt_st.wait_event(cur.finalize_event)
+                nxt.reset(); nxt.search(lp, lens)
         tb = time.perf_counter()
-        f = Sx.finalize_async()
+        with torch.cuda.stream(cur_st):
+            f = cur.finalize_collect()
         tc = time.perf_counter()
         if pend is not None:
             pend.result()
         pend = f
         stamps.append((ta, tb, tc, time.perf_counter()))
-    pend.result()
-    pipelined_ms = (time.perf_counter() - t0) * 1e3 / 6
-    # per batch: enqueue of reset + search, finalize_async (waits for the GPU, copies the lattices out), wait for the PREVIOUS
-    # batch's host n-best
+    fin_pipe = pend.result()
+    torch.cuda.synchronize()
+    pipelined_ms = (time.perf_counter() - t0) * 1e3 / (NB - 2)
+    pipe_same = [[(e[2], round(e[3] + e[4], 3)) for e in u_] for u_ in fin_pipe] == [[(e[2], round(e[3] + e[4], 3)) for e in u_] for u_ in fin]
+    # per batch: enqueue of FinalizeDecoding + the NEXT batch's reset and search, finalize_collect (waits for this batch's
+    # lattices, copies them out), wait for the PREVIOUS batch's host n-best
     pipe_stages = [[round((y - x) * 1e3, 2) for x, y in zip(st[:-1], st[1:])] for st in stamps[2:]]
     del S2
     # the same search with one workgroup per utterance and every CU busy: 256 utterances in one call
@@ -290,7 +308,7 @@ def run():
                             finalize_gpu_ms=round(fin_gpu_ms, 2), nbest100_host_ms=round(nbest_ms, 2),
                             ms_per_utterance=round((search_ms + fin_gpu_ms + nbest_ms) / U, 3),
                             pipelined_ms_per_batch=round(pipelined_ms, 2), pipelined_ms_per_utterance=round(pipelined_ms / U, 3),
-                            pipelined_stages_ms_enqueue_finalize_wait=pipe_stages,
+                            pipelined_stages_ms_enqueue_finalize_wait=pipe_stages, pipelined_lists_equal_one_shot=bool(pipe_same),
                             held_vs_created_tokens_with_pruning=round(sum(m["tokens"] for m in mem_ref) / max(1.0, created_tok), 3),
                             tokens_per_frame=round(tok_per_frame, 1), algorithmic_mb=round(alg_bytes / 1e6, 1),
                             achieved_gb_s=gbs(search_ms), achieved_gb_s_one_workgroup_per_utterance=gbs(search1_ms),
