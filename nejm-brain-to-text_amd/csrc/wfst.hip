@@ -388,6 +388,10 @@ __device__ void clear_hash(Ctx& c) {
 // InitDecoding (:57-75)
 __device__ void init_decoding(Ctx& c) {
   clear_hash(c);
+  // the cluster search's scratch starts from zero whatever the caller's buffer held (its histograms are only re-zeroed AFTER a
+  // frame's cut-off used them)
+  for (int i = threadIdx.x; i < (int)(sizeof(Clu) / sizeof(int)); i += NT) reinterpret_cast<int*>(c.l.clu)[i] = 0;
+  __syncthreads();
   if (threadIdx.x == 0) {
     Hdr* h = c.l.h;
     h->n_frames = 0; h->overflow = 0; h->num_input = 0; h->is_last_blank = 0; h->last_best = 0; h->finalized = 0;
