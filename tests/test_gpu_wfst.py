@@ -291,9 +291,10 @@ def test_deep_epsilon_fans_equal_the_oracle():
 
 
 def test_two_searchers_on_two_streams_pipeline(toy):
-    """finalize_begin() / finalize_collect(): a second searcher on another stream starts the next batch behind the first one's
-    FinalizeDecoding kernel (its `finalize_event`), so that lattice extraction, copy-out and host n-best of a batch run under
-    the next batch's search.  Four batches alternating between two searchers return what finalize() returns for each."""
+    """WfstPipeline (finalize_begin() / finalize_collect()): a second searcher on another stream starts the next batch behind
+    the first one's FinalizeDecoding kernel (its `finalize_event`), so that lattice extraction, copy-out and host n-best of a
+    batch run under the next batch's search.  Four batches alternating between two searchers return what finalize() returns
+    for each."""
     from wfst_decoder import WfstSearch
     prons, words, g, _ = toy
     o = Opt(nbest=12)
@@ -306,25 +307,10 @@ def test_two_searchers_on_two_streams_pipeline(toy):
     R = WfstSearch(g, o, U=5, max_frames=T + 8)
     for b, lens in batches:
         R.reset(); R.search(b, lens); ref.append(R.finalize())
-    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    sa.wait_stream(torch.cuda.current_stream()); sb.wait_stream(torch.cuda.current_stream())
-    S = [WfstSearch(g, o, U=5, max_frames=T + 8), WfstSearch(g, o, U=5, max_frames=T + 8)]
-    st = [sa, sb]
-    with torch.cuda.stream(sa):
-        S[0].reset(); S[0].search(*batches[0])
-    futs = []
-    for i in range(4):
-        cur, nxt = i % 2, (i + 1) % 2
-        with torch.cuda.stream(st[cur]):
-            S[cur].finalize_begin()
-        if i + 1 < 4:
-            with torch.cuda.stream(st[nxt]):
-                st[nxt].wait_event(S[cur].finalize_event)
-                S[nxt].reset(); S[nxt].search(*batches[i + 1])
-        with torch.cuda.stream(st[cur]):
-            futs.append(S[cur].finalize_collect())
-    torch.cuda.synchronize()
-    assert [f.result() for f in futs] == ref
+    from wfst_decoder import WfstPipeline
+    pipe = WfstPipeline(g, o, U=5, max_frames=T + 8)
+    assert list(pipe.decode(batches)) == ref
+    assert list(pipe.decode(batches[:1])) == ref[:1] and list(pipe.decode([])) == []     # reusable; one batch; none
 
 
 def test_prune_active_tokens_bounds_memory_and_keeps_the_lattice(toy):
