@@ -168,6 +168,14 @@ int b2t_gru_sync_status(const void* sync_ws, int T, int B, int* status_host, voi
 int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const float* b_hh,
                           const float* h_init, float* out, float* reserve, float* h_last,
                           int T, int B, int H, int mode, void* sync_ws, void* stream);
+/* The same forward sweep of layer l that ALSO produces the next layer's input projection (torch.nn.GRU applies W_ih of
+ * layer l+1 to the outputs of layer l, rnn_model.py:65-72,126): gi_next [T][B][3H] = out_t w_ih_next^T + b_ih_next, computed
+ * in the sweep's idle matrix-core slots from the h fragments a step already holds in LDS -- the projection GEMM of layers >= 1
+ * then does not exist.  Exact fp32, persistent mode only (mode = 1, optionally | B2T_GRU_LOCAL | B2T_GRU_PARITY), H <= 512.
+ * w_ih_next [3H][H], b_ih_next [3H].  Not usable when dropout sits between the two layers (training with rnn_dropout > 0). */
+int b2t_gru_layer_fwd_fused_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
+                                float* reserve, float* h_last, const float* w_ih_next, const float* b_ih_next,
+                                float* gi_next, int T, int B, int H, int mode, void* sync_ws, void* stream);
 /* Backward sweep.  dY [T][B][H] grad wrt this layer's outputs (plus dh_last
  * [B][H] optional grad wrt the final state).  w_hh_t [H][3H] is W_hh transposed (b2t_transpose).
  * dG [T][B][4H] = (dr_pre, dz_pre, dn_pre*r, dn_pre): dGh = cols [0,3H), dGi = cols [0,2H)+[3H,4H).

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "b2t_gru_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "b2t_gru_sync_status": (C.c_int, [VP, C.c_int, C.c_int, C.POINTER(C.c_int), VP]),
     "b2t_gru_layer_fwd_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "b2t_gru_layer_fwd_fused_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "b2t_gru_layer_bwd_f32": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int,
                                         VP, VP]),
     "b2t_transpose_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP]),

@@ -665,6 +665,15 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   if (day_chunked) for (int ci = 0; ci < nc; ++ci) t_day[ci] = day_task(chunks[ci][0], chunks[ci][1] - chunks[ci][0]);
   else { const int t = day_task(0, T); for (int ci = 0; ci < nc; ++ci) t_day[ci] = t; }
 
+  // Round 4: the sweep of layer l makes the input projection of layer l + 1 itself, in its idle matrix-core slots, from the h
+  // fragments each step holds in LDS anyway (b2t_gru_layer_fwd_fused_f32): the projection GEMMs of layers >= 1 -- 0.2 TFLOP per
+  // C2 step and one GEMM + two queue hops on the critical path of every wavefront stage -- are gone.  Exact-fp32 persistent
+  // sweeps, H <= 512, no dropout between the layers (training with rnn_dropout > 0 keeps the GEMMs: the mask sits between
+  // out[l] and the projection), passes of at least 32 output frames (a streaming call would pay the per-chunk epilogue).
+  const char* fused_s = getenv("B2T_FUSED_PROJ");   // read per pass (the tests compare the two forms in one process)
+  const bool fused_env = !(fused_s && atoi(fused_s) == 0);
+  const bool fuse_ok = fused_env && (mode & 0xff) == 1 && !(mode & B2T_GRU_BF16) && !c.bf16_gemm && H <= 512 && Tp >= 32;
+  auto fused_from = [&](int l) { return fuse_ok && l >= 0 && l + 1 < L && w.outd[l] == w.out[l]; };   // layer l's sweep writes gi[l + 1]
   // slot 0 of out[l] = initial state, so out[l][0:T'] is the h_{t-1} matrix
   int t_init[MAXL], t_sw[MAXL][MAXC];
   for (int l = 0; l < L; ++l)
@@ -677,7 +686,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
     for (int ci = 0; ci < nc; ++ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
       // 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
-      const int t_gi = P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci]},
+      const int t_gi = fused_from(l - 1) ? t_sw[l - 1][ci] :
+                       P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci]},
                              [&, l, t0, n](hipStream_t sg) {
         if (l == 0) {
           static const bool rowmap = !(getenv("B2T_L0_ROWMAP") && atoi(getenv("B2T_L0_ROWMAP")) == 0);
@@ -727,9 +737,20 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
       t_sw[l][ci] = P.add("sweep", 40.f + n * est_step_us(0) * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n, ci](hipStream_t ss) {
         if (c.rc) return;
-        Ctx::Scope sc(c, ss, 8, 2.0 * n * B * 3.0 * H * H);
+        const bool fused = fused_from(l);
+        Ctx::Scope sc(c, ss, 8, (fused ? 2.0 : 1.0) * 2.0 * n * B * 3.0 * H * H);
         // h_{t0-1}: slot t0 of out[l] -- or, for the first chunk of an inference pass with carried state, the caller's buffer
         const float* h_prev = (t0 == 0 && states && !p->save) ? states + (size_t)l * B * H : w.out[l] + (long long)t0 * B * H;
+        if (fused) {
+          const int mf = (mode & ~(0xff | B2T_GRU_WIDE)) | 1;
+          c.call(b2t_gru_layer_fwd_fused_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], h_prev,
+                                             w.out[l] + (long long)(1 + t0) * B * H, p->save ? w.res[l] + (long long)t0 * B * 4 * H : nullptr,
+                                             t1 == Tp ? hidden + (size_t)l * B * H : nullptr, prm->w_ih[l + 1], prm->b_ih[l + 1],
+                                             w.gi[l + 1] + (long long)t0 * B * 3 * H, n, B, H,
+                                             (mf & B2T_GRU_LOCAL) ? (mf | ((l & 1) ? B2T_GRU_PARITY : 0)) : mf, sync_of(l),
+                                             reinterpret_cast<void*>(ss)));
+          return;
+        }
         // In the wavefront's fill and drain stages, where at most B2T_NARROW_EDGE (default 2) layers are at work, the exact-fp32
         // sweep runs with 16-unit workgroups (twice the workgroups, half the MFMA time per step: the chip is mostly empty there
         // and the stage is pure latency) instead of the 32-unit ones that crowd the CUs less in the full stages:
@@ -740,6 +761,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
           const int stage = l + ci, active = std::min(std::min(stage + 1, L + nc - 1 - stage), std::min(L, nc));
           if (active <= narrow_edge) m2 &= ~B2T_GRU_WIDE;   // (fill stages only: 19.38-19.50, drain only: 19.25-19.35, both: 19.17-19.39)
         }
+        // next to the fused sweeps of the layers below (256 registers per lane, two per CU) only a 16-unit workgroup (168) fits a CU
+        if (fuse_ok) m2 &= ~B2T_GRU_WIDE;
         c.call(b2t_gru_layer_fwd_f32(w.gi[l] + (long long)t0 * B * 3 * H, prm->w_hh[l], prm->b_hh[l], h_prev,
                                      w.out[l] + (long long)(1 + t0) * B * H, p->save ? w.res[l] + (long long)t0 * B * 4 * H : nullptr,
                                      t1 == Tp ? hidden + (size_t)l * B * H : nullptr, n, B, H,

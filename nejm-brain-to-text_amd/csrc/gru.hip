@@ -147,6 +147,24 @@ extern "C" int b2t_gru_layer_fwd_f32(const float* gi, const float* w_hh, const f
   return 0;
 }
 
+extern "C" int b2t_gru_layer_fwd_fused_f32(const float* gi, const float* w_hh, const float* b_hh, const float* h_init,
+                                           float* out, float* reserve, float* h_last, const float* w_ih_next,
+                                           const float* b_ih_next, float* gi_next, int T, int B, int H, int mode,
+                                           void* sync_ws, void* stream) {
+  B2T_REQUIRE(T > 0 && B > 0 && H > 0 && (H % 16) == 0 && H <= 512, "gru_layer_fwd_fused: bad shape T=%d B=%d H=%d (H%%16 must be 0, H <= 512)", T, B, H);
+  B2T_REQUIRE(gi && w_hh && b_hh && h_init && out && w_ih_next && b_ih_next && gi_next, "gru_layer_fwd_fused: null argument");
+  hipStream_t s = as_stream(stream);
+  const int local = (mode & B2T_GRU_LOCAL) ? ((mode & B2T_GRU_PARITY) ? 1 : 0) : -1;
+  mode &= ~(B2T_GRU_LOCAL | B2T_GRU_PARITY);
+  B2T_REQUIRE(mode == 1, "gru_layer_fwd_fused: persistent exact-fp32 sweeps only (mode 1, optionally | B2T_GRU_LOCAL | B2T_GRU_PARITY), got %d", mode);
+  int rc = gru_persistent_fwd_fused(gi, w_hh, b_hh, h_init, out, reserve, w_ih_next, b_ih_next, gi_next, T, B, H, sync_ws, s, local);
+  if (rc) return rc;
+  if (h_last)
+    return check_hip(hipMemcpyAsync(h_last, out + (long long)(T - 1) * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s),
+                     "gru_layer_fwd_fused: h_last copy");
+  return 0;
+}
+
 extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, const float* reserve, const float* out,
                                      const float* h_init, const float* w_hh_t, float* dG, float* dh_init,
                                      float* carry_ws, int T, int B, int H, int mode, void* sync_ws, void* stream) {

@@ -72,6 +72,9 @@ size_t gru_persistent_sync_bytes(int T);
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
                        float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s, bool bf16 = false,
                        bool wide = false, int local = -1);
+int gru_persistent_fwd_fused(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
+                             float* reserve, const float* w_ih2, const float* b_ih2, float* gi2, int T, int B, int H,
+                             void* sync_ws, hipStream_t s, int local = -1);
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
                        void* sync_ws, hipStream_t s, bool bf16 = false, bool wide = false, int local = -1);

@@ -206,6 +206,180 @@ __global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// forward, with the NEXT layer's input projection computed in the sweep's idle matrix-core slots (round 4).
+//
+// A sweep workgroup uses the matrix cores ~3072 of the ~8-10 k cycles of a step; the rest is the hand-off (store drain,
+// counter, poll, first operand load).  The A operand of a step -- the full h_{t-1} row block of this layer, transposed into
+// MFMA fragments in the per-wave LDS slots -- is exactly the A operand of the next layer's input projection
+// gi'_{t-1} = h_{t-1} W_ih'^T + b_ih' (rnn_model.py:126: nn.GRU applies W_ih of layer l+1 to the outputs of layer l).  So
+// after publishing h_t the workgroup contracts the fragments that still sit in its LDS slots with ITS slice of W_ih' (the 48
+// gate rows of its 16 units; kept in registers and, for NLDS chunks per wave, in LDS as ready-made B fragments) at LOW wave
+// priority, reduces over the four waves and stores its 16 x 48 tile of gi'.  The projection GEMM of layers >= 1
+// (0.2 TFLOP per C2 step, and one GEMM + two queue hops on the critical path of every wavefront stage) disappears.
+// Time t of the projection is produced during step t+1; the chunk's last one in an epilogue that waits for the peers'
+// last tiles like a step does.
+// ---------------------------------------------------------------------------------------------------
+template <int NCH, int NLDS, bool LOC>   // NLDS: 16-wide K chunks (per wave) of the W_ih' slice kept in LDS, the rest in registers
+__global__ __launch_bounds__(256, 2) void gru_persist_fwd_fused_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                                      const float* __restrict__ b_hh, const float* __restrict__ h_init,
+                                                                      float* out, float* __restrict__ reserve,
+                                                                      const float* __restrict__ w_ih2, const float* __restrict__ b_ih2,
+                                                                      float* __restrict__ gi2, int T, int B, int H, unsigned* sync, int par) {
+  constexpr int TPN = 20;
+  constexpr int NREG = NCH - NLDS;
+  __shared__ __attribute__((aligned(16))) float red[4 * 3 * 4 * 64 + 16 * TPN];
+  __shared__ __attribute__((aligned(16))) float stage[4][NCH * SLOT_F];   // per-wave operand staging: every slot is kept until the next step (the projection re-reads it)
+  __shared__ __attribute__((aligned(16))) float4 w2l[4][NLDS > 0 ? NLDS : 1][3][64];
+  float* hs = red + 4 * 3 * 4 * 64;
+  constexpr int AUX = LOC ? B2T_LOC_ST_AUX : 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);
+  const unsigned G = (unsigned)H / 16u;
+  const int j = lane & 15, q = lane >> 4;
+  unsigned* err = sync;
+  const unsigned pset = __hip_atomic_load(sync + 1, RLX_AGENT) & 1u;
+  {
+    unsigned* other = sync + 32 + (size_t)(1u - pset) * SETW;
+    const int nthr = gridDim.x * gridDim.y * 256;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
+  }
+  int rg = blockIdx.y, tile = blockIdx.x;
+  if constexpr (LOC) {
+    if (!local_role(sync + 32 + (size_t)pset * SETW + (SETW - 16), (B + 15) / 16, G, par, rg, tile)) { finish_call(sync, pset); return; }
+  }
+  const int m0 = rg * 16;
+  const int unit = tile * 16 + j;
+  const int nch = H / 16;
+
+  float4 w[3][NCH], w2[3][NREG > 0 ? NREG : 1];
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci) {
+    const int c = KCHUNK(wave, ci, NCH);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const bool in = c < nch;
+      w[g][ci] = in ? *reinterpret_cast<const float4*>(w_hh + ((long long)g * H + unit) * H + c * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 x2 = in ? *reinterpret_cast<const float4*>(w_ih2 + ((long long)g * H + unit) * H + c * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ci < NREG) w2[g][ci < NREG ? ci : 0] = x2;
+      else w2l[wave][ci - NREG][g][lane] = x2;   // written and read by the same lane of the same wave: no barrier needed
+    }
+  }
+  const float bhr = b_hh[unit], bhz = b_hh[H + unit], bhn = b_hh[2 * H + unit];
+  const float b2r = b_ih2[unit], b2z = b_ih2[H + unit], b2n = b_ih2[2 * H + unit];
+  const int row = m0 + 4 * q + wave;
+  const bool live = row < B;
+  unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)rg * T * CSTRIDE;
+  float hp = live ? h_init[(long long)row * H + unit] : 0.f;
+
+  // The projection of the h block whose fragments sit in this wave's LDS slots -> gi2[tt].  At LOW wave priority: the slack
+  // work yields the matrix pipe to the co-resident workgroup's (another sweep's) recurrent product.  (Measured: splitting it
+  // -- most of the chunks here, the rest + the reduction behind the next step's operand loads -- costs registers (15 spilled)
+  // and a barrier in front of the recurrent product: one sweep alone 5.9 instead of 5.1 us per step, the C2 step 19.5 instead
+  // of 18.6 ms.)
+  auto project = [&](int tt) {
+    __builtin_amdgcn_s_setprio(1);
+    f32x4 acc2[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const float* sp = &stage[wave][(ci & ~1) * SLOT_F] + (j >> 3) * SLOT_F + (j & 7) * 36 + 4 * q + 16 * (ci & 1);
+      const float4 a = *reinterpret_cast<const float4*>(sp);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float4 b;
+        if (ci < NREG) b = w2[g][ci < NREG ? ci : 0];
+        else b = w2l[wave][ci >= NREG ? ci - NREG : 0][g][lane];
+        acc2[g] = mfma_chunk16<false>(a, b, acc2[g]);
+      }
+    }
+    float g2[3];
+    cross_wave_reduce<3>(red, acc2, g2, wave, lane);
+    if (live) {
+      float* gp = gi2 + ((long long)tt * B + row) * 3 * H + unit;
+      gp[0] = g2[0] + b2r; gp[H] = g2[1] + b2z; gp[2 * H] = g2[2] + b2n;
+    }
+    __builtin_amdgcn_s_setprio(3);
+  };
+
+  for (int t = 0; t < T; ++t) {
+    float gir = 0.f, giz = 0.f, gin = 0.f;
+    if (live) {
+      const float* g3 = gi + ((long long)t * B + row) * 3 * H + unit;
+      gir = __builtin_nontemporal_load(g3); giz = __builtin_nontemporal_load(g3 + H); gin = __builtin_nontemporal_load(g3 + 2 * H);
+    }
+    const float* hsrc = h_init;
+    if (t > 0) {
+      if constexpr (LOC) wait_count_local(cnt + (size_t)(t - 1) * CSTRIDE, G, err);
+      else wait_count(cnt + (size_t)(t - 1) * CSTRIDE, G, err);
+      hsrc = out + (long long)(t - 1) * B * H;
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 v[NCH];
+    issue_block_loads<NCH, LOC ? 0 : B2T_LOAD_AUX>(v, hsrc, m0, B, H, wave * NCH * 16, H, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < NCH / 2; ++p) {
+      float4 a[2];
+      transpose_pair(&stage[wave][(2 * p) * SLOT_F], v[2 * p], v[2 * p + 1], a[0], a[1], lane);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = mfma_chunk16<false>(a[h2], w[g][2 * p + h2], acc[g]);
+    }
+    asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
+    float gh[3];
+    cross_wave_reduce<3>(red, acc, gh, wave, lane);
+    float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_ghn = 0.f;
+    if (live) {
+      const float ghn = gh[2] + bhn;
+      const float r = fast_sigmoid(gir + gh[0] + bhr);
+      const float z = fast_sigmoid(giz + gh[1] + bhz);
+      const float nn = fast_tanh(gin + r * ghn);
+      const float h = (1.0f - z) * nn + z * hp;
+      hs[(4 * q + wave) * TPN + j] = h;
+      sv_r = r; sv_z = z; sv_n = nn; sv_ghn = ghn;
+      hp = h;
+    }
+    __syncthreads();                       // tile staged; also fences `red` (every wave has read its sums of this step)
+    if (wave == 0) {
+      const int r = lane >> 2, c4 = (lane & 3) * 4;
+      if (m0 + r < B)
+        store_f4<AUX>(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + tile * 16 + c4) * 4),
+                     *reinterpret_cast<const float4*>(&hs[r * TPN + c4]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) { if constexpr (LOC) l2_atomic_inc(cnt + (size_t)t * CSTRIDE); else __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT); }
+    }
+    if (live && reserve) {
+      float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
+      __builtin_nontemporal_store(sv_r, rs); __builtin_nontemporal_store(sv_z, rs + H);
+      __builtin_nontemporal_store(sv_n, rs + 2 * H); __builtin_nontemporal_store(sv_ghn, rs + 3 * H);
+    }
+    // slack: the LDS slots hold h_{t-1} (this chunk's local time t - 1; at t = 0 the previous chunk's last state, whose
+    // projection that chunk's epilogue made).  `red` is free: the barrier above is behind this step's reduction, and the next
+    // step's reduction writes it behind the poll barrier, which every wave reaches after it has read the projection's sums.
+    if (t > 0) project(t - 1);
+  }
+  // epilogue: the projection of the chunk's last state h_{T-1}
+  {
+    if constexpr (LOC) wait_count_local(cnt + (size_t)(T - 1) * CSTRIDE, G, err);
+    else wait_count(cnt + (size_t)(T - 1) * CSTRIDE, G, err);
+    float4 v[NCH];
+    issue_block_loads<NCH, LOC ? 0 : B2T_LOAD_AUX>(v, out + (long long)(T - 1) * B * H, m0, B, H, wave * NCH * 16, H, lane);
+#pragma unroll
+    for (int p = 0; p < NCH / 2; ++p) {
+      float4 a[2];
+      transpose_pair(&stage[wave][(2 * p) * SLOT_F], v[2 * p], v[2 * p + 1], a[0], a[1], lane);
+      asm volatile("" :: "v"(a[0].x), "v"(a[1].x));
+    }
+    project(T - 1);
+  }
+  finish_call(sync, pset);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward.  Workgroup (ks, mb) owns dh columns [16ks,16ks+16): each step it (A) contracts the full
 // dGh_{t+1} row block with its register-resident W_hh[:, slice] and (B) forms the gate gradients of
 // step t for its slice, publishing them as dG[t] for the other workgroups of the row group.
@@ -516,6 +690,31 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
 #undef B2T_FWD_GO
 #undef B2T_LAUNCH_FWD
   return check_hip(hipGetLastError(), "gru_layer_fwd (persistent)");
+}
+
+int gru_persistent_fwd_fused(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
+                             float* reserve, const float* w_ih2, const float* b_ih2, float* gi2, int T, int B, int H,
+                             void* sync_ws, hipStream_t s, int local) {
+  int rc = check_grid(B, H, T, sync_ws, "gru_layer_fwd_fused");
+  if (rc) return rc;
+  if (H > 512) { set_error("gru_layer_fwd_fused: H=%d > 512 unsupported (the two weight slices must fit a workgroup's registers + LDS)", H); return 2; }
+  const int G = H / 16, gy = (B + 15) / 16;
+  const bool loc = local >= 0 && G <= 32 && gy <= 4 && gru_xcd_dispatch_ok();
+  const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
+  const int par = loc ? (local & 1) : 0;
+  unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
+#define B2T_FUSED_GO(NCH, NLDS)                                                                                        \
+  do {                                                                                                                 \
+    if (loc) hipLaunchKernelGGL((gru_persist_fwd_fused_kernel<NCH, NLDS, true>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, \
+                                w_ih2, b_ih2, gi2, T, B, H, sync, par);                                                \
+    else hipLaunchKernelGGL((gru_persist_fwd_fused_kernel<NCH, NLDS, false>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, \
+                            w_ih2, b_ih2, gi2, T, B, H, sync, par);                                                    \
+  } while (0)
+  if (H <= 128) B2T_FUSED_GO(2, 0);
+  else if (H <= 256) B2T_FUSED_GO(4, 0);
+  else B2T_FUSED_GO(8, 2);
+#undef B2T_FUSED_GO
+  return check_hip(hipGetLastError(), "gru_layer_fwd_fused (persistent)");
 }
 
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,
