@@ -133,6 +133,21 @@ def set_amp(on: bool):
     AMP["on"] = bool(on)
 
 
+def precision_from_args(args) -> bool:
+    """Whether a run configured by the reference's yaml dict computes in the bf16 regime.  The reference wraps its forward
+    in torch.autocast(dtype=bfloat16, enabled=args['use_amp']) (rnn_trainer.py:527,704; evaluate_model_helpers.py:90) and
+    ships `use_amp: true` (rnn_args.yaml:19), so `use_amp` maps to the bf16 mode here too: bf16 operands on the matrix cores
+    for every GEMM and recurrent product, fp32 accumulation / gates / CTC / optimizer / master weights.  Order of precedence:
+    args['amd_bf16_matmul'] (explicit True / False: the opt-out is `amd_bf16_matmul: false`), the B2T_AMP environment
+    variable when set, then `use_amp`."""
+    if isinstance(args, dict) and args.get("amd_bf16_matmul") is not None:
+        return bool(args["amd_bf16_matmul"])
+    env = os.environ.get("B2T_AMP")
+    if env is not None:
+        return env not in ("0", "", "false", "False")
+    return bool(args.get("use_amp", False)) if isinstance(args, dict) else False
+
+
 def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,
          b_sz=0, c_s0=0, c_s1=0, c_div=0, c_sz=0, bias=None, bias_sz=0, b_zmap=None, epilogue=0, accumulate=0,
          a_off=0, b_off=0, c_off=0, splitk=1, ws=None, slab="splitk_slab", _splitk=1, _c_ks=0, a_brk=0, a_gap=0,

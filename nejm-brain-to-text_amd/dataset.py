@@ -321,35 +321,94 @@ class ResidentDataset:
             rows.extend(range(first, first + B)); off.append(len(rows))
         return cls(dict(cls._arrays(feats, labs, foff, loff, trans, nts, sls, days, blocks, trials, rows, off), **dts), device)
 
-    FORMAT = 2      # 1: before lab_n / batch_rows / batch_off (one stored row per batch row)
+    FORMAT = 3      # 1: before lab_n / batch_rows / batch_off (one stored row per batch row); 2: before the source fingerprint
 
-    def save(self, path):
-        np.savez(path, format=np.int32(self.FORMAT), **self.host)
+    @staticmethod
+    def source_fingerprint(dataset) -> str:
+        """What a cached flat binary was built FROM: the trial lists, the pre-generated batch index and the arguments that shape
+        them (sessions / days, seed, batch size, number of batches, days per batch, feature subset, split, bad-trial filter as far
+        as it shows in the trial lists).  A cache whose fingerprint differs from the source's is rebuilt, never reused."""
+        import hashlib
+        h = hashlib.sha256()
+
+        def put(x):
+            if isinstance(x, dict):
+                h.update(b"{")
+                for k in sorted(x, key=lambda v: str(v)):
+                    put(k); put(x[k])
+                h.update(b"}")
+            elif isinstance(x, (list, tuple)):
+                a = None
+                try:
+                    a = np.asarray(x)
+                except Exception:
+                    a = None
+                if a is not None and a.dtype.kind in "iuf" and a.ndim >= 1:
+                    h.update(str(a.shape).encode()); h.update(np.ascontiguousarray(a.astype(np.float64 if a.dtype.kind == "f" else np.int64)).tobytes())
+                else:
+                    h.update(b"[")
+                    for v in x:
+                        put(v)
+                    h.update(b"]")
+            elif isinstance(x, np.ndarray):
+                h.update(str(x.shape).encode()); h.update(np.ascontiguousarray(x).tobytes())
+            elif torch.is_tensor(x):
+                put(x.detach().cpu().numpy())
+            else:
+                h.update(repr(x).encode()); h.update(b";")
+
+        put(type(dataset).__name__); put(len(dataset))
+        for name in ("split", "days_per_batch", "batch_size", "n_batches", "seed", "random_seed", "feature_subset", "n_days", "n_features",
+                     "n_classes", "max_T", "min_T", "max_S", "one_day_per_batch", "must_include_days", "B", "D", "F", "C", "dpb", "one_day"):
+            if hasattr(dataset, name):
+                put(name); put(getattr(dataset, name))
+        if hasattr(dataset, "trial_indicies"):
+            put({int(d): dict(trials=[int(t) for t in info["trials"]], path=str(info.get("session_path", ""))) for d, info in dataset.trial_indicies.items()})
+        if hasattr(dataset, "batch_index"):
+            bi = dataset.batch_index
+            put({int(i): {int(d): [int(t) for t in tl] for d, tl in bi[i].items()} for i in (bi.keys() if isinstance(bi, dict) else range(len(bi)))})
+        return h.hexdigest()
+
+    def save(self, path, fingerprint: str = ""):
+        """Atomic: written next to `path` and renamed over it, so a reader never sees a torn file."""
+        tmp = f"{path}.tmp.{os.getpid()}.npz"
+        np.savez(tmp, format=np.int32(self.FORMAT), fingerprint=np.array(str(fingerprint)), **self.host)
+        os.replace(tmp, path)
 
     @classmethod
-    def load(cls, path, device='cuda:0'):
-        """Raises ResidentFormatError for a file an older version of this class wrote (or one that lacks a table):
-        `load_or_build` then re-converts the source instead of failing on a KeyError."""
+    def load(cls, path, device='cuda:0', fingerprint=None):
+        """Raises ResidentFormatError for a file an older version of this class wrote, one that lacks a table, or (when
+        `fingerprint` is given) one built from a different source: `load_or_build` then re-converts the source."""
         with np.load(path) as z:
             fmt = int(z['format']) if 'format' in z.files else 1
             missing = [k for k in cls.KEYS if k not in z.files]
             if fmt != cls.FORMAT or missing:
                 raise ResidentFormatError(f"{path}: resident-dataset format {fmt} (this build reads {cls.FORMAT})"
                                           + (f", missing tables {missing}" if missing else ""))
+            have = str(z['fingerprint']) if 'fingerprint' in z.files else ""
+            if fingerprint is not None and have != fingerprint:
+                raise ResidentFormatError(f"{path}: built from a different source (sessions / seed / batch index / filters changed)")
             return cls({k: z[k] for k in cls.KEYS + tuple(m for m in ('lab_dtype', 'trans_dtype') if m in z.files)}, device)
 
     @classmethod
-    def load_or_build(cls, path, dataset, device='cuda:0'):
-        """The cached flat binary if it is there and current, else converted from `dataset` and written back."""
+    def load_or_build(cls, path, dataset, device='cuda:0', writer=True):
+        """The cached flat binary if it is there, readable and built from THIS source (fingerprint), else converted from
+        `dataset` and -- by the one process with writer=True (rank 0 under data parallel) -- written back atomically.  Any failure
+        to read the cache (torn or foreign file included) means 'rebuild', never a crash and never a silently stale batch index."""
+        fp = cls.source_fingerprint(dataset) if path else None
         if path and os.path.exists(path):
             try:
-                return cls.load(path, device)
-            except ResidentFormatError as e:
+                return cls.load(path, device, fingerprint=fp)
+            except Exception as e:   # noqa: BLE001 -- ResidentFormatError, BadZipFile, ValueError, OSError ...: all mean rebuild
                 import warnings
-                warnings.warn(f"{e}; rebuilding from the source dataset")
+                warnings.warn(f"{type(e).__name__}: {e}; rebuilding from the source dataset")
         rd = cls.from_dataset(dataset, device)
-        if path:
-            rd.save(path)
+        if path and writer:
+            try:
+                rd.save(path, fp)
+            except OSError as e:
+                import warnings
+                warnings.warn(f"could not write the resident-dataset cache {path}: {e}")
         return rd
 
     # ---- batches ---------------------------------------------------------------------------------------------------

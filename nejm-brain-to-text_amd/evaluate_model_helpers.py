@@ -34,8 +34,14 @@ def runSingleDecodingStep(x, input_layer, model, model_args, device):
     x = x.to(device)
     x = gauss_smooth(inputs=x, device=device, smooth_kernel_std=tr['smooth_kernel_std'],
                      smooth_kernel_size=tr['smooth_kernel_size'], padding='valid')
-    with torch.no_grad():
-        logits, _ = model(x=x, day_idx=torch.tensor([input_layer], device=device), states=None, return_state=True)
+    import b2t_ops as ops
+    was = ops.AMP["on"]
+    ops.set_amp(ops.precision_from_args(model_args))   # autocast(enabled=model_args['use_amp']) at evaluate_model_helpers.py:90
+    try:
+        with torch.no_grad():
+            logits, _ = model(x=x, day_idx=torch.tensor([input_layer], device=device), states=None, return_state=True)
+    finally:
+        ops.set_amp(was)
     return logits.float().cpu().numpy()
 
 

@@ -48,16 +48,25 @@ class DecodeResource:
         self.graph = wfst.graph_from_files(fst_path, dict_path) if fst_path else None
         # the grammars used by Rescore(): G.fst (its scores are taken out) and G_no_prune.fst (its scores are put in)
         # (read and kept as CSR arrays in C++, arc-sorted once: G_no_prune.fst has 10^7-10^9 arcs in the reference's setup)
-        self.lm_fst = wfst.HostFst.read_openfst(lm_fst_path).arcsort() if lm_fst_path else None
-        self.rescore_lm_fst = wfst.HostFst.read_openfst(rescore_lm_fst_path).arcsort() if rescore_lm_fst_path else None
         self.symbols = self._read_table(dict_path) if dict_path else None
-        # word id of #0 on the grammars' back-off arcs: eps2disambig.pl rewrites the back-off ilabel <eps> to #0 before
-        # fstcompile (make_tlg.sh:35-38), so G.fst / G_no_prune.fst read from files carry words.txt's id of "#0" there;
-        # a grammar compiled without that step keeps epsilon (0).  (set_graph / set_rescore_grammars override it.)
+        # ReadAndPrepareLmFst (kaldi-fst-io.cc:129-147, called at brain_speech_decoder.h:59,71): a grammar with #0 on the input
+        # side of its back-off arcs (eps2disambig.pl, make_tlg.sh:35-38) is projected on its output labels, so the back-off
+        # label is epsilon afterwards; an acceptor (already projected, or compiled without that step) is used as it is.  The
+        # label is determined from the arcs, not from words.txt listing "#0" (Kaldi's word tables almost always do).
+        ids = [i for i, w in (self.symbols or {}).items() if w == "#0"]
+        disambig = ids[0] if ids else None
+        self.lm_fst = self.rescore_lm_fst = None
         self.backoff_label = None
+        labels = []
+        if lm_fst_path:
+            self.lm_fst, b = wfst.HostFst.read_openfst(lm_fst_path).prepare_lm(disambig); labels.append(b)
+        if rescore_lm_fst_path:
+            self.rescore_lm_fst, b = wfst.HostFst.read_openfst(rescore_lm_fst_path).prepare_lm(disambig); labels.append(b)
         if self.lm_fst is not None and self.rescore_lm_fst is not None:
-            ids = [i for i, w in (self.symbols or {}).items() if w == "#0"]
-            self.backoff_label = ids[0] if ids else 0
+            if labels[0] != labels[1]:
+                raise ValueError(f"G.fst backs off through label {labels[0]} and the rescoring grammar through {labels[1]}: "
+                                 "compile both the same way (with or without eps2disambig)")
+            self.backoff_label = labels[0]
         self.units = self._read_table(unit_path) if unit_path else None
         self.token_lm = None
         self.lexicon = self.word_lm = None

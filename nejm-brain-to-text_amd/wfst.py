@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import math
 from collections import deque
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -585,6 +585,22 @@ class HostFst:
 
     def arcsort(self, by_olabel: bool = False):
         return HostFst(self._lib().b2t_fst_arcsort(self._h, int(by_olabel)))
+
+    def prepare_lm(self, disambig_id: Optional[int] = None):
+        """fst::ReadAndPrepareLmFst (kaldi/fstext/kaldi-fst-io.cc:129-147): a grammar that is not an acceptor is projected on
+        its OUTPUT labels (the #0 that eps2disambig.pl put on the back-off arcs' input side becomes the epsilon of their output
+        side), an acceptor is left as it is; then arcs are sorted by input label.  Returns (prepared HostFst, back-off label):
+        0 after a projection, and for an acceptor 0 too -- unless no arc carries label 0 while arcs carry `disambig_id`
+        (words.txt's id of "#0"): a grammar compiled with #0 on both sides, which fst::Compose could not back off through at
+        all; following those arcs is the friendlier reading."""
+        row, il, ol, w, nx, fc = self.arrays()
+        if il.shape[0] and np.any(il != ol):
+            src = np.repeat(np.arange(len(fc)), np.diff(row))
+            return HostFst.from_arrays(len(fc), self.info()["start"], src, ol, ol, w, nx, fc).arcsort(), 0
+        backoff = 0
+        if disambig_id is not None and il.shape[0] and not np.any(il == 0) and np.any(il == disambig_id):
+            backoff = int(disambig_id)
+        return self.arcsort(), backoff
 
     def grammar_score(self, word_ids: Sequence[int], backoff_label: int) -> float:
         """Needs an ilabel-sorted grammar (arcsort())."""

@@ -165,6 +165,23 @@ def test_dataset_sampler_semantics():
     assert torch.equal(syn[1]["input_features"], b["input_features"])
 
 
+def test_use_amp_selects_the_bf16_mode(monkeypatch):
+    """rnn_args.yaml:19 `use_amp: true` -> autocast(bfloat16) (rnn_trainer.py:527,704; evaluate_model_helpers.py:90): the
+    yaml's switch selects the bf16 mode here too; `amd_bf16_matmul` in the args and B2T_AMP override it in that order."""
+    import b2t_ops as ops
+    monkeypatch.delenv("B2T_AMP", raising=False)
+    assert ops.precision_from_args({"use_amp": True}) is True
+    assert ops.precision_from_args({"use_amp": False}) is False
+    assert ops.precision_from_args({}) is False
+    assert ops.precision_from_args({"use_amp": True, "amd_bf16_matmul": False}) is False     # the opt-out
+    assert ops.precision_from_args({"use_amp": False, "amd_bf16_matmul": True}) is True
+    monkeypatch.setenv("B2T_AMP", "0")
+    assert ops.precision_from_args({"use_amp": True}) is False
+    assert ops.precision_from_args({"use_amp": True, "amd_bf16_matmul": True}) is True       # the args win over the environment
+    monkeypatch.setenv("B2T_AMP", "1")
+    assert ops.precision_from_args({"use_amp": False}) is True
+
+
 def test_time_chunk_plan_rule():
     """Layer pipelining only when two sweeps can be resident together (b2t_ops.time_chunks): C2 pipelines over 6 chunks,
     the H = 768 shape runs the layers in sequence, short sequences are not cut below 16 steps per chunk."""

@@ -16,7 +16,7 @@ def make_args(tmp, n_batches=40, patch=(4, 2), dropout=(0.1, 0.1)):
                   'patch_size': patch[0], 'patch_stride': patch[1],
                   'input_network': {'n_input_layers': 1, 'input_layer_sizes': [32], 'input_trainable': True,
                                     'input_layer_dropout': dropout[1]}},
-        'gpu_number': '0', 'mode': 'train', 'use_amp': True,
+        'gpu_number': '0', 'mode': 'train', 'use_amp': True, 'amd_bf16_matmul': False,   # exact fp32: these tests compare with the fp32 oracle
         'output_dir': os.path.join(tmp, 'out'), 'checkpoint_dir': os.path.join(tmp, 'out', 'checkpoint'),
         'init_from_checkpoint': False, 'init_checkpoint_path': None, 'save_best_checkpoint': True,
         'save_all_val_steps': False, 'save_final_model': False, 'save_val_metrics': True, 'early_stopping': False,
@@ -125,6 +125,40 @@ def test_resident_dataset_matches_source_batches(tmp_path):
                            max_S=4, seed=1)
     rd7 = ResidentDataset.from_batches(src7, device='cuda:0')
     np.testing.assert_array_equal(rd7.batch_of(0)['input_features'].cpu().numpy(), src7[0]['input_features'].numpy())
+
+
+def test_resident_cache_is_tied_to_its_source(tmp_path):
+    """The flat-binary cache carries a fingerprint of what it was built from: a changed source (seed, batch count, ...) or a
+    torn / foreign file means REBUILD -- never a silently stale batch index, never a crash; only the writer process writes,
+    atomically (advisor, round 3)."""
+    import warnings
+    from dataset import SyntheticTrials, ResidentDataset
+    kw = dict(batch_size=6, n_days=3, n_features=16, n_classes=41, days_per_batch=2, max_T=40, min_T=20, max_S=5)
+    a, b = SyntheticTrials(n_batches=3, seed=3, **kw), SyntheticTrials(n_batches=3, seed=4, **kw)
+    assert ResidentDataset.source_fingerprint(a) == ResidentDataset.source_fingerprint(SyntheticTrials(n_batches=3, seed=3, **kw))
+    assert ResidentDataset.source_fingerprint(a) != ResidentDataset.source_fingerprint(b)
+    assert ResidentDataset.source_fingerprint(a) != ResidentDataset.source_fingerprint(SyntheticTrials(n_batches=4, seed=3, **kw))
+    p = str(tmp_path / "cache.npz")
+    ra = ResidentDataset.load_or_build(p, a, 'cuda:0', writer=False)
+    assert not os.path.exists(p), "a non-writer rank must not write the cache"
+    ra = ResidentDataset.load_or_build(p, a, 'cuda:0')
+    assert os.path.exists(p) and not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ra2 = ResidentDataset.load_or_build(p, a, 'cuda:0')          # same source: served from the file, silently
+    assert torch.equal(ra.batch_of(1)['input_features'], ra2.batch_of(1)['input_features'])
+    with pytest.warns(UserWarning, match="different source"):
+        rb = ResidentDataset.load_or_build(p, b, 'cuda:0')           # other seed: rebuilt, and the file now belongs to b
+    np.testing.assert_array_equal(rb.batch_of(1)['input_features'].cpu().numpy(), b[1]['input_features'].numpy())
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ResidentDataset.load_or_build(p, b, 'cuda:0')
+    with open(p, "r+b") as f:                                        # a torn file: rebuilt, not a BadZipFile crash
+        f.truncate(os.path.getsize(p) // 2)
+    with pytest.warns(UserWarning, match="rebuilding"):
+        rb2 = ResidentDataset.load_or_build(p, b, 'cuda:0')
+    assert torch.equal(rb.batch_of(2)['input_features'], rb2.batch_of(2)['input_features'])
+    ResidentDataset.load(p, 'cuda:0', fingerprint=ResidentDataset.source_fingerprint(b))   # and the rewritten file is whole again
 
 
 def test_trainer_with_device_resident_dataset(tmp_path):

@@ -469,15 +469,42 @@ def test_lm_decoder_surface_with_a_graph(toy, tmp_path):
     wfst.write_openfst_vector(G_new, str(tmp_path / "G_no_prune.fst"))
     res2 = lm_decoder.DecodeResource(str(tmp_path / "TLG.fst"), str(tmp_path / "G.fst"), str(tmp_path / "G_no_prune.fst"),
                                      str(tmp_path / "words.txt"), "")
-    assert res2.backoff_label == wd0
-    dec2 = lm_decoder.BrainSpeechDecoder(res2, opts)
-    lm_decoder.DecodeNumpy(dec2, logits, np.zeros_like(logits), math.log(90.0))
-    dec2.FinishDecoding()
-    dec2.Rescore()
-    got2 = dec2.result()
-    assert [r.sentence for r in got2] == [r.sentence for r in after]
-    for r2, r1 in zip(got2, after):
-        assert abs(r2.lm_score - r1.lm_score) < TOL and abs(r2.ac_score - r1.ac_score) < 1e-4
+    # (the files carry #0:<eps> back-off arcs; ReadAndPrepareLmFst projects them on the output side: label 0 afterwards)
+    assert res2.backoff_label == 0
+
+    def rescored(res_x):
+        dec2 = lm_decoder.BrainSpeechDecoder(res_x, opts)
+        lm_decoder.DecodeNumpy(dec2, logits, np.zeros_like(logits), math.log(90.0))
+        dec2.FinishDecoding()
+        dec2.Rescore()
+        return dec2.result()
+
+    def same(got2):
+        assert [r.sentence for r in got2] == [r.sentence for r in after]
+        for r2, r1 in zip(got2, after):
+            assert abs(r2.lm_score - r1.lm_score) < TOL and abs(r2.ac_score - r1.ac_score) < 1e-4
+
+    same(rescored(res2))
+    # grammars that ALREADY are acceptors with epsilon back-off arcs (projected beforehand, or compiled without eps2disambig),
+    # next to a words.txt that lists "#0" as Kaldi's always do: the label comes from the arcs, not from the table (advisor,
+    # round 3: with id("#0") no sequence that needs a back-off survived and Rescore() silently returned fewer hypotheses)
+    def variant(G, mapper):
+        H = wfst.Fst(); H.n, H.start, H.final = G.n, G.start, dict(G.final)
+        H.arcs = [mapper(a) for a in G.arcs]
+        return H
+    proj = lambda a: (a[0], a[2], a[2], a[3], a[4])
+    wfst.write_openfst_vector(variant(G_old, proj), str(tmp_path / "Ga.fst"))
+    wfst.write_openfst_vector(variant(G_new, proj), str(tmp_path / "Gb.fst"))
+    res3 = lm_decoder.DecodeResource(str(tmp_path / "TLG.fst"), str(tmp_path / "Ga.fst"), str(tmp_path / "Gb.fst"), str(tmp_path / "words.txt"), "")
+    assert res3.backoff_label == 0
+    same(rescored(res3))
+    # #0 on BOTH sides of the back-off arcs (an acceptor no arc of which carries epsilon): followed through id("#0")
+    both = lambda a: (a[0], a[1], a[1], a[3], a[4])
+    wfst.write_openfst_vector(variant(G_old, both), str(tmp_path / "Gc.fst"))
+    wfst.write_openfst_vector(variant(G_new, both), str(tmp_path / "Gd.fst"))
+    res4 = lm_decoder.DecodeResource(str(tmp_path / "TLG.fst"), str(tmp_path / "Gc.fst"), str(tmp_path / "Gd.fst"), str(tmp_path / "words.txt"), "")
+    assert res4.backoff_label == wd0
+    same(rescored(res4))
 
 
 def test_lattice_nbest_host_against_enumeration():

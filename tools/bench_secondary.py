@@ -244,6 +244,36 @@ def trainer_loop_c2():
                          "(160-step run - 40-step run) / 120")
 
 
+def relabel(out):
+    """Name the decode numbers for what they are (round-3 verdict, item 5): BASELINE configs[3] / [4] ask for the reference's
+    searcher -- WFST token passing over T o L o G -- so ITS numbers are the configs[3] / [4] lines; the lexicon prefix beam (the
+    north star's 'prefix beam + n-gram in HBM') is an approximation that holds on clean inputs only and is reported as a curve."""
+    w, pb, st = out.get("decode_wfst_tlg") or {}, out.get("decode_beam100_3gram") or {}, out.get("stream_32utt_5gram") or {}
+    unpinned = ("searcher == oracle/wfst_oracle.py (100-best lists identical in the binding regime); the oracle itself cannot be pinned to "
+                "the reference here: its decoder needs OpenFST, which the image lacks")
+    if "offline" in w:
+        acc = {str(r["noise"]): r["wfst_wer_vs_truth"] for r in w.get("accuracy_by_noise", [])}
+        out["configs3_decode_wfst_3gram"] = dict(
+            searcher="WFST token passing over T o L o G (ctc_wfst_beam_search.cc / lattice-faster-decoder.cc), beam 17, max_active 7000, nbest 100",
+            ms_per_utterance=w["offline"]["ms_per_utterance"], pipelined_ms_per_utterance=w["offline"]["pipelined_ms_per_utterance"],
+            search_ms_32_utterances=w["offline"]["search_ms"], wer_vs_truth_by_noise=acc, graph=w.get("graph"), parity=unpinned, dtype="f32")
+    if "streaming" in w:
+        out["configs4_stream_wfst"] = dict(
+            searcher="the same token passing, 32 concurrent utterances, one frame per call + the partial best path",
+            word_3gram_graph=w["streaming"], word_5gram_graph=w.get("streaming_word_5gram"),
+            gru_768x5_step_p50_ms=st.get("gru_step_p50_ms"), parity=unpinned, dtype="f32")
+    if pb or st:
+        curve = {}
+        for r in w.get("accuracy_by_noise", []):
+            curve[str(r["noise"])] = {k: v["wer_vs_truth"] for k, v in r.items() if k.startswith("lexicon_prefix_beam")}
+            curve[str(r["noise"])]["wfst"] = r["wfst_wer_vs_truth"]
+        out["ns1_lexicon_prefix_beam"] = dict(
+            label="APPROXIMATE, clean inputs only: SIL-delimited dictionary words, no optional silence, no alternative-pronunciation "
+                  "handling; its WER leaves the graph search's beyond noise ~1.0 (curve below); rule pinned by oracle/b2t_oracle.py only",
+            beam_10_100_word_3gram=pb, streaming_token_5gram_beam_10_10=st, wer_vs_truth_by_noise=curve)
+    return out
+
+
 def all_secondary():
     out = {}
     for name, fn in (("c3_f32", lambda: train_ms("c3", False)), ("c3_amp", lambda: train_ms("c3", True)),
@@ -256,7 +286,7 @@ def all_secondary():
         except Exception as e:   # a secondary number must never take the headline line down
             out[name] = dict(error=f"{type(e).__name__}: {e}")
         torch.cuda.synchronize()
-    return out
+    return relabel(out)
 
 
 if __name__ == "__main__":

@@ -297,6 +297,35 @@ def run():
     smem = Ss.memory_stats()
     Ss.finalize()
     del Ss
+    # BASELINE configs[4] names a 5-gram LM: the same streaming loop over a WORD-LEVEL 5-gram graph (synthetic ARPA of the same
+    # vocabulary, `n_per_order` n-grams per order as the recipe's pruned LM would keep; T o L o G by the same builder)
+    stream5 = None
+    try:
+        t0 = time.time()
+        arpa5 = ngram_lm.synthetic_word_arpa(words, 5, int(os.environ.get("B2T_WFST_5GRAM_PER_ORDER", "3000")), seed=12)
+        g5 = wfst.build_tlg(prons, arpa5, sil_prob=0.5)
+        b5 = time.time() - t0
+        _, _, _, _, seqs5, logits5, lens5, _ = make(U=U, seed=5, noise=0.9, graph=(prons, words, arpa5, g5), truth="lm", blank_boost=math.log(90.0))
+        _, _, lp5 = _logp(logits5, dev, lib)
+        T5 = logits5.shape[1]
+        S5 = WfstSearch(g5, Opt, U=U, prune_interval=25, prune_min_fill=0.0, max_frames=T5 + 8, max_tokens=1 << 20, max_links=1 << 22, hash_size=hs)
+        lat5 = []
+        for t in range(T5):
+            fr = lp5[:, t:t + 1].contiguous()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            S5.search(fr, np.minimum(1, np.maximum(0, lens5 - t)).astype(np.int32))
+            S5.best_path(False, max_len=2 * T5 + 8)
+            lat5.append(time.perf_counter() - t0)
+        fin5 = S5.finalize()
+        lat5 = np.array(lat5[5:]) * 1e3
+        h5 = [[g5.words[w] for w in f[0][2]] if f else [] for f in fin5]
+        stream5 = dict(graph=dict(words=len(words), order=5, tlg_states=int(g5.n_states), tlg_arcs=int(g5.n_arcs), mb=round(g5.nbytes() / 1e6, 1), host_build_s=round(b5, 1)),
+                       p50_ms_per_frame=round(float(np.percentile(lat5, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat5, 95)), 3),
+                       max_ms_per_frame=round(float(lat5.max()), 3),
+                       wer_vs_truth=round(sum(edit(h, r) for h, r in zip(h5, seqs5)) / max(1, sum(len(r) for r in seqs5)), 4))
+        del S5
+    except Exception as e:     # noqa: BLE001
+        stream5 = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
     wfst_1 = [[g.words[w] for w in f[0][2]] if f else [] for f in fin]
     err_truth = sum(edit(h, r) for h, r in zip(wfst_1, seqs)); nref = sum(len(r) for r in seqs)
     gbs = lambda ms: round(alg_bytes / (ms * 1e-3) / 1e9, 2)
@@ -318,6 +347,7 @@ def run():
                               max_ms_per_frame=round(float(lat.max()), 3),
                               held_tokens_at_end=int(max(m["tokens"] for m in smem)), created_tokens=int(max(m["created_tokens"] for m in smem)),
                               prune_passes=int(smem[0]["prunes"])),
+               streaming_word_5gram=stream5,
                rescore=rescore,
                wfst_wer_vs_truth=round(err_truth / nref, 4))
     out["accuracy_by_noise"] = accuracy(prons, words, arpa, g)
