@@ -21,6 +21,8 @@
 #include <chrono>
 #include <stdlib.h>
 #include <deque>
+#include <functional>
+#include <queue>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -813,6 +815,414 @@ int b2t_lattice_nbest_core(int n_states, int start, int n_arcs, const int32_t* s
                            int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap,
                            float* costs);
 
+// ---- Rescore() on the DETERMINISED lattice (round 4) --------------------------------------------------------------------------
+// The reference composes `lat_` with the grammars: the lattice GetLattice has determinised over words (one path per word
+// sequence; lattice-faster-decoder.cc:193-213 -> DeterminizeLatticePruned; brain_speech_decoder.cc:47-101).  Composing the RAW
+// token lattice instead multiplies every alignment variant of a word sequence by the grammar histories that reach it (3-28x the
+// arcs: 5 M product arcs and 0.84 s for a 175 k-arc lattice).  So: (1) subset construction over the word labels with residual
+// weights in the tropical semiring -- a determinised state is a sorted set of (lattice state, residual (total, graph, acoustic))
+// (in the lattice's topological order) with the cheapest entry at (0, 0, 0), equal sets are ONE state, the normalisation offsets are the arc weights -- pruned with
+// the lattice beam through the exact backward costs; states are expanded in the order of their earliest lattice state, so every
+// predecessor has been expanded and a state's forward cost is final when it is popped; (2) the determinised word lattice x both
+// lazily determinised grammars (LmDet): a DETERMINISTIC product, every path a distinct word sequence; (3) its paths in order of
+// the NEW cost (best-first over partial paths with the exact backward cost as bound) among those within the beam on the OLD cost.
+// Alignments: a determinised arc keeps, per entry of its target, the entry of its source it came from and the input labels on
+// the way; a hypothesis' alignment is read back from its final entry.
+namespace b2t {
+namespace {
+
+struct DetRescore {
+  struct RArc { int lab, nlab, ol, dst; double g, a; };      // lab / nlab: its input labels (non-epsilon) in `labels`: chains of single-entry single-exit states are contracted into one arc
+  struct Ent { int s; double tot, gr, ac; };
+  struct St { size_t off; int n; double alpha; int minrank; double fin_tot, fin_gr, fin_ac; int fin_ent; bool queued; };
+  struct DArc { int src, dst, word; double tot, gr, ac; size_t bp; };
+  struct ANode { int parent, label; };
+  int n_states = 0;
+  std::vector<int> off, order, rank, slot, heap;
+  std::vector<RArc> arc;
+  std::vector<int> labels;
+  std::vector<double> fin, beta;
+  std::vector<St> st;
+  std::vector<Ent> ent;
+  std::vector<DArc> darc;
+  std::vector<int> bp_src, bp_ali, start_ali;
+  std::vector<ANode> ali;
+  std::unordered_multimap<uint64_t, int> index;
+  // working subset
+  std::vector<Ent> we; std::vector<int> wsrc, wali, pop_perm;
+
+  bool setup(int n, int start, int n_arcs, const int32_t* src, const int32_t* dst, const int32_t* il, const int32_t* ol, const float* gr,
+             const float* ac, int n_final, const int32_t* fs, const float* fc) {
+    n_states = n;
+    fin.assign((size_t)n, INFINITY); beta.assign((size_t)n, INFINITY);
+    for (int i = 0; i < n_final; ++i) fin[(size_t)fs[i]] = std::min(fin[(size_t)fs[i]], (double)fc[i]);
+    // raw adjacency
+    std::vector<int> roff((size_t)n + 1, 0), indeg((size_t)n, 0);
+    for (int i = 0; i < n_arcs; ++i) { ++roff[(size_t)src[i] + 1]; ++indeg[(size_t)dst[i]]; }
+    for (int s = 0; s < n; ++s) roff[(size_t)s + 1] += roff[s];
+    std::vector<int> rarc((size_t)n_arcs);
+    { std::vector<int> po(roff.begin(), roff.end() - 1); for (int i = 0; i < n_arcs; ++i) rarc[(size_t)po[src[i]]++] = i; }
+    // Chain contraction: a state with ONE incoming arc and ONE outgoing arc whose output is epsilon (a token that merely lives on
+    // through a frame) is absorbed into its incoming arc -- labels concatenated, costs added.  The token lattice is mostly such
+    // chains (2.1 arcs per state); the epsilon closures of the subset construction then walk a third of the states.
+    auto link = [&](int v) { return v != start && indeg[(size_t)v] == 1 && roff[(size_t)v + 1] - roff[v] == 1 && fin[(size_t)v] == INFINITY && ol[rarc[(size_t)roff[v]]] == 0; };
+    off.assign((size_t)n + 1, 0);
+    std::vector<char> keep((size_t)n, 0);
+    for (int v = 0; v < n; ++v) keep[(size_t)v] = !link(v);
+    for (int i = 0; i < n_arcs; ++i) if (keep[(size_t)src[i]]) ++off[(size_t)src[i] + 1];
+    for (int s = 0; s < n; ++s) off[(size_t)s + 1] += off[s];
+    arc.resize((size_t)off[(size_t)n]);
+    labels.clear();
+    std::vector<int> pending((size_t)n, 0);
+    {
+      std::vector<int> po(off.begin(), off.end() - 1);
+      for (int u = 0; u < n; ++u) {
+        if (!keep[(size_t)u]) continue;
+        for (int k = roff[u]; k < roff[(size_t)u + 1]; ++k) {
+          int i = rarc[(size_t)k];
+          RArc x{(int)labels.size(), 0, ol[i], dst[i], (double)gr[i], (double)ac[i]};
+          if (il[i]) labels.push_back(il[i]);
+          int guard = 0;
+          while (!keep[(size_t)x.dst] && guard++ < n) {                       // follow the chain
+            i = rarc[(size_t)roff[x.dst]];
+            if (il[i]) labels.push_back(il[i]);
+            x.g += (double)gr[i]; x.a += (double)ac[i]; x.dst = dst[i];
+          }
+          if (!keep[(size_t)x.dst]) return false;                             // a cycle of chain links
+          x.nlab = (int)labels.size() - x.lab;
+          arc[(size_t)po[u]++] = x;
+          ++pending[(size_t)x.dst];
+        }
+      }
+    }
+    order.clear(); rank.assign((size_t)n, -1);
+    int n_kept = 0;
+    for (int s = 0; s < n; ++s) if (keep[(size_t)s]) { ++n_kept; if (!pending[(size_t)s]) order.push_back(s); }
+    for (size_t h = 0; h < order.size(); ++h) {
+      const int s = order[h]; rank[(size_t)s] = (int)h;
+      for (int k = off[s]; k < off[(size_t)s + 1]; ++k) if (--pending[(size_t)arc[(size_t)k].dst] == 0) order.push_back(arc[(size_t)k].dst);
+    }
+    if ((int)order.size() != n_kept) return false;                 // a cycle: the caller falls back to the raw composition
+    for (int h = n_kept - 1; h >= 0; --h) {
+      const int s = order[(size_t)h];
+      double b = fin[(size_t)s];
+      for (int k = off[s]; k < off[(size_t)s + 1]; ++k) b = std::min(b, beta[(size_t)arc[(size_t)k].dst] + (arc[(size_t)k].g + arc[(size_t)k].a));
+      beta[(size_t)s] = b;
+    }
+    slot.assign((size_t)n, -1);
+    return true;
+  }
+  int push_ali(int parent, const RArc& x) {                      // the arc's input labels behind `parent`
+    for (int k = 0; k < x.nlab; ++k) { ali.push_back(ANode{parent, labels[(size_t)x.lab + (size_t)k]}); parent = (int)ali.size() - 1; }
+    return parent;
+  }
+
+  // epsilon-output closure of the working subset (states marked in `slot`), in topological order; `base` = forward cost of the
+  // subset's reference point (for the beam), costs in `we` are relative to it
+  void closure(double base, double limit) {
+    heap.clear(); pop_perm.clear();
+    for (const Ent& e : we) heap.push_back(rank[(size_t)e.s]);
+    std::make_heap(heap.begin(), heap.end(), std::greater<int>());
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), std::greater<int>());
+      const int s = order[(size_t)heap.back()]; heap.pop_back();
+      const int i = slot[(size_t)s];
+      pop_perm.push_back(i);                                     // topological order = the canonical order of a stored state's entries
+      const Ent e = we[(size_t)i]; const int esrc = wsrc[(size_t)i], eali = wali[(size_t)i];
+      for (int k = off[s]; k < off[(size_t)s + 1]; ++k) {
+        const RArc& a = arc[(size_t)k];
+        if (a.ol != 0) continue;
+        const double nt = e.tot + a.g + a.a;
+        if (base + nt + beta[(size_t)a.dst] > limit) continue;
+        const int j = slot[(size_t)a.dst];
+        if (j >= 0 && !(nt < we[(size_t)j].tot)) continue;
+        const Ent ne{a.dst, nt, e.gr + a.g, e.ac + a.a};
+        const int na = a.nlab ? push_ali(eali, a) : eali;
+        if (j < 0) {
+          slot[(size_t)a.dst] = (int)we.size(); we.push_back(ne); wsrc.push_back(esrc); wali.push_back(na);
+          heap.push_back(rank[(size_t)a.dst]); std::push_heap(heap.begin(), heap.end(), std::greater<int>());
+        } else { we[(size_t)j] = ne; wsrc[(size_t)j] = esrc; wali[(size_t)j] = na; }
+      }
+    }
+  }
+  // normalise the working subset, sort it by lattice state, intern it.  Returns the state id; the offset taken out in (t, g, a);
+  // the permutation applied in `perm` (position in the stored state -> position in the working subset).
+  int intern(double& t, double& g, double& a, std::vector<int>& perm, double alpha_via) {
+    for (const Ent& e : we) slot[(size_t)e.s] = -1;
+    perm = pop_perm;                                               // (the closure popped every state exactly once, in topological order)
+    size_t b = 0;
+    for (size_t i = 1; i < we.size(); ++i)
+      if (we[i].tot < we[b].tot || (we[i].tot == we[b].tot && we[i].s < we[b].s)) b = i;
+    t = we[b].tot; g = we[b].gr; a = we[b].ac;
+    uint64_t h = 1469598103934665603ull;
+    int minrank = 0x7fffffff;
+    for (int p : perm) {
+      Ent& e = we[(size_t)p];
+      e.tot -= t; e.gr -= g; e.ac -= a;
+      const float rt = (float)e.tot, rg = (float)e.gr;
+      uint32_t b1, b2; memcpy(&b1, &rt, 4); memcpy(&b2, &rg, 4);
+      h = (h ^ (uint64_t)(uint32_t)e.s) * 1099511628211ull; h = (h ^ b1) * 1099511628211ull; h = (h ^ b2) * 1099511628211ull;
+      minrank = std::min(minrank, rank[(size_t)e.s]);
+    }
+    auto rng = index.equal_range(h);
+    for (auto it = rng.first; it != rng.second; ++it) {
+      St& r = st[(size_t)it->second];
+      if (r.n != (int)we.size()) continue;
+      bool same = true;
+      for (int k = 0; k < r.n && same; ++k) {
+        const Ent& x = ent[r.off + (size_t)k]; const Ent& y = we[(size_t)perm[(size_t)k]];
+        same = x.s == y.s && (float)x.tot == (float)y.tot && (float)x.gr == (float)y.gr;
+      }
+      if (same) { r.alpha = std::min(r.alpha, alpha_via + t); return it->second; }
+    }
+    St ns{ent.size(), (int)we.size(), alpha_via + t, minrank, INFINITY, 0.0, 0.0, -1, false};
+    for (size_t k = 0; k < perm.size(); ++k) {
+      const Ent& e = we[(size_t)perm[k]];
+      ent.push_back(e);
+      if (fin[(size_t)e.s] != INFINITY) {
+        const double c = e.tot + fin[(size_t)e.s];
+        if (c < ns.fin_tot) { ns.fin_tot = c; ns.fin_gr = e.gr + fin[(size_t)e.s]; ns.fin_ac = e.ac; ns.fin_ent = (int)k; }
+      }
+    }
+    st.push_back(ns);
+    index.emplace(h, (int)st.size() - 1);
+    return (int)st.size() - 1;
+  }
+
+  // the whole determinisation; returns false if the lattice has no path
+  bool run(int start, double beam) {
+    if (beta[(size_t)start] == INFINITY) return false;
+    const double limit = beta[(size_t)start] + beam + 1e-4;
+    std::vector<int> perm;
+    we.assign(1, Ent{start, 0.0, 0.0, 0.0}); wsrc.assign(1, -1); wali.assign(1, -1);
+    slot[(size_t)start] = 0;
+    closure(0.0, limit);
+    double t, g, a;
+    intern(t, g, a, perm, 0.0);                           // state 0; its offset (the start's closure may hold a cheaper entry than the start itself: costs can be negative) is start_off / start_g / start_a
+    start_ali.resize(perm.size());
+    for (size_t k = 0; k < perm.size(); ++k) start_ali[k] = wali[(size_t)perm[k]];
+    start_off = t; start_g = g; start_a = a;
+    typedef std::pair<int, int> QI;                        // (earliest lattice state, determinised state)
+    std::priority_queue<QI, std::vector<QI>, std::greater<QI>> pq;
+    pq.push({st[0].minrank, 0}); st[0].queued = true;
+    struct Tr { int ol, dst, src_ent, karc; double tot, gr, ac; };
+    std::vector<Tr> trans;
+    std::vector<std::pair<uint64_t, int>> keyed;
+    while (!pq.empty()) {
+      const int D = pq.top().second; pq.pop();
+      const St sd = st[(size_t)D];
+      const auto tg0 = std::chrono::steady_clock::now();
+      n_entries_expanded += (size_t)sd.n;
+      trans.clear();
+      for (int i = 0; i < sd.n; ++i) {
+        const Ent e = ent[sd.off + (size_t)i];
+        if (sd.alpha + e.tot + beta[(size_t)e.s] > limit) continue;                 // (a cheaper history may have made it worth keeping: harmless)
+        for (int k = off[e.s]; k < off[(size_t)e.s + 1]; ++k) {
+          const RArc& x = arc[(size_t)k];
+          if (x.ol == 0) continue;
+          const double nt = e.tot + x.g + x.a;
+          if (sd.alpha + nt + beta[(size_t)x.dst] > limit) continue;
+          trans.push_back(Tr{x.ol, x.dst, i, k, nt, e.gr + x.g, e.ac + x.a});
+        }
+      }
+      keyed.resize(trans.size());
+      for (size_t q = 0; q < trans.size(); ++q) keyed[q] = {((uint64_t)(uint32_t)trans[q].ol << 32) | (uint64_t)q, (int)q};
+      std::sort(keyed.begin(), keyed.end());
+      t_gather += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count();
+      for (size_t g0 = 0; g0 < keyed.size();) {
+        size_t g1 = g0;
+        const int ol = trans[(size_t)keyed[g0].second].ol;
+        while (g1 < keyed.size() && trans[(size_t)keyed[g1].second].ol == ol) ++g1;
+        const auto tc0 = std::chrono::steady_clock::now();
+        we.clear(); wsrc.clear(); wali.clear();
+        for (size_t q = g0; q < g1; ++q) {
+          const Tr& tr = trans[(size_t)keyed[q].second];
+          const int j = slot[(size_t)tr.dst];
+          if (j >= 0 && !(tr.tot < we[(size_t)j].tot)) continue;
+          const Ent ne{tr.dst, tr.tot, tr.gr, tr.ac};
+          const int na = arc[(size_t)tr.karc].nlab ? push_ali(-1, arc[(size_t)tr.karc]) : -1;
+          if (j < 0) { slot[(size_t)tr.dst] = (int)we.size(); we.push_back(ne); wsrc.push_back(tr.src_ent); wali.push_back(na); }
+          else { we[(size_t)j] = ne; wsrc[(size_t)j] = tr.src_ent; wali[(size_t)j] = na; }
+        }
+        closure(sd.alpha, limit);
+        const auto tc1 = std::chrono::steady_clock::now();
+        n_closure_states += we.size();
+        const size_t before = st.size();
+        const int T = intern(t, g, a, perm, sd.alpha);
+        t_closure += std::chrono::duration<double, std::milli>(tc1 - tc0).count();
+        t_intern += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count();
+        darc.push_back(DArc{D, T, ol, t, g, a, bp_src.size()});
+        for (size_t k = 0; k < perm.size(); ++k) { bp_src.push_back(wsrc[(size_t)perm[k]]); bp_ali.push_back(wali[(size_t)perm[k]]); }
+        if (st.size() > before || !st[(size_t)T].queued) {
+          if (!st[(size_t)T].queued) { st[(size_t)T].queued = true; pq.push({st[(size_t)T].minrank, T}); }
+        }
+        g0 = g1;
+      }
+    }
+    return true;
+  }
+  double start_off = 0, start_g = 0, start_a = 0;
+  double t_gather = 0, t_closure = 0, t_intern = 0; size_t n_closure_states = 0, n_entries_expanded = 0;
+};
+
+}  // namespace
+}  // namespace b2t
+
+static int rescore_on_determinised(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst, const int32_t* ilabel,
+                                   const int32_t* olabel, const float* graph, const float* acoustic, int n_final, const int32_t* final_state,
+                                   const float* final_cost, const void* g_old, const void* g_new, int backoff_label, int nbest, float beam,
+                                   int32_t* out_words, int32_t* w_off, int w_cap, int32_t* out_ali, int32_t* a_off, int a_cap, float* costs,
+                                   long long* stats4, bool* fell_back) {
+  using namespace b2t;
+  const auto t_in = std::chrono::steady_clock::now();
+  *fell_back = false;
+  for (int i = 0; i < n_arcs; ++i)
+    if (src[i] < 0 || src[i] >= n_states || dst[i] < 0 || dst[i] >= n_states) { set_error("lattice_rescore: arc %d out of range", i); return -1; }
+  for (int i = 0; i < n_final; ++i)
+    if (final_state[i] < 0 || final_state[i] >= n_states) { set_error("lattice_rescore: final state %d out of range", i); return -1; }
+  DetRescore dr;
+  if (!dr.setup(n_states, start, n_arcs, src, dst, ilabel, olabel, graph, acoustic, n_final, final_state, final_cost)) { *fell_back = true; return 0; }
+  w_off[0] = 0; a_off[0] = 0;
+  if (!dr.run(start, (double)beam)) { if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0; return 0; }
+  const auto t_det = std::chrono::steady_clock::now();
+  LmDet Lo(*CFST(g_old), backoff_label), Ln(*CFST(g_new), backoff_label);
+  // determinised-lattice adjacency
+  const int ND = (int)dr.st.size();
+  std::vector<int> doff((size_t)ND + 1, 0);
+  for (const auto& a : dr.darc) ++doff[(size_t)a.src + 1];
+  for (int s = 0; s < ND; ++s) doff[(size_t)s + 1] += doff[s];
+  std::vector<int> darc_of(dr.darc.size());
+  { std::vector<int> po(doff.begin(), doff.end() - 1); for (size_t i = 0; i < dr.darc.size(); ++i) darc_of[(size_t)po[dr.darc[i].src]++] = (int)i; }
+  // product with the two grammars (deterministic)
+  struct PS { int d, o, n; };
+  struct PA { int src, dst, darc; double w_new, dl; };
+  FlatMap pair_id(1 << 10), pid((size_t)4 * ND + 16);
+  std::vector<std::array<int, 2>> pairs;
+  std::vector<PS> ps;
+  std::vector<PA> pa;
+  auto state_of = [&](int d, int o, int n) {
+    const uint64_t pk = ((uint64_t)(uint32_t)o << 32) | (uint32_t)n;
+    int p;
+    if (int* f = pair_id.find(pk)) p = *f; else { p = (int)pairs.size(); pairs.push_back({o, n}); pair_id.put(pk, p); }
+    const uint64_t k = ((uint64_t)(uint32_t)d << 32) | (uint32_t)p;
+    if (int* f = pid.find(k)) return *f;
+    ps.push_back(PS{d, o, n});
+    pid.put(k, (int)ps.size() - 1);
+    return (int)ps.size() - 1;
+  };
+  state_of(0, Lo.start(), Ln.start());
+  for (size_t q = 0; q < ps.size(); ++q) {
+    const PS k = ps[q];
+    for (int e = doff[(size_t)k.d]; e < doff[(size_t)k.d + 1]; ++e) {
+      const auto& a = dr.darc[(size_t)darc_of[(size_t)e]];
+      const std::pair<int, double> so = Lo.step(k.o, a.word), sn = Ln.step(k.n, a.word);
+      if (so.first < 0 || sn.first < 0) continue;
+      const double d = sn.second - so.second;
+      const int t = state_of(a.dst, so.first, sn.first);
+      pa.push_back(PA{(int)q, t, darc_of[(size_t)e], a.tot + d, d});
+    }
+  }
+  const int NP = (int)ps.size();
+  std::vector<int> poff((size_t)NP + 1, 0);
+  for (const PA& a : pa) ++poff[(size_t)a.src + 1];
+  for (int s = 0; s < NP; ++s) poff[(size_t)s + 1] += poff[s];          // (arcs were appended in source order: already grouped)
+  std::vector<double> pfin_new((size_t)NP, INFINITY), pfin_dl((size_t)NP, 0.0);
+  for (int q = 0; q < NP; ++q) {
+    const auto& sd = dr.st[(size_t)ps[(size_t)q].d];
+    if (sd.fin_ent < 0) continue;
+    const double fo = Lo.states[(size_t)ps[(size_t)q].o].fin, fn = Ln.states[(size_t)ps[(size_t)q].n].fin;
+    if (fo == INFINITY || fn == INFINITY) continue;
+    pfin_new[(size_t)q] = sd.fin_tot + (fn - fo); pfin_dl[(size_t)q] = fn - fo;
+  }
+  // backward costs (new and old) over the product: a determinised arc strictly advances the earliest lattice state of its
+  // determinised state, so the product states sorted by that rank, descending, are in reverse topological order
+  std::vector<int> topo((size_t)NP);
+  for (int q = 0; q < NP; ++q) topo[(size_t)q] = q;
+  std::sort(topo.begin(), topo.end(), [&](int x, int y) {
+    const int rx = dr.st[(size_t)ps[(size_t)x].d].minrank, ry = dr.st[(size_t)ps[(size_t)y].d].minrank;
+    return rx != ry ? rx > ry : x > y;
+  });
+  std::vector<double> hn((size_t)NP, INFINITY), ho((size_t)NP, INFINITY);
+  for (int q : topo) {
+    double bn = pfin_new[(size_t)q], bo = pfin_new[(size_t)q] == INFINITY ? INFINITY : pfin_new[(size_t)q] - pfin_dl[(size_t)q];
+    for (int e = poff[(size_t)q]; e < poff[(size_t)q + 1]; ++e) {
+      const PA& a = pa[(size_t)e];
+      bn = std::min(bn, a.w_new + hn[(size_t)a.dst]);
+      bo = std::min(bo, a.w_new - a.dl + ho[(size_t)a.dst]);
+    }
+    hn[(size_t)q] = bn; ho[(size_t)q] = bo;
+  }
+  if (stats4) { stats4[0] = NP; stats4[1] = (long long)pa.size(); stats4[2] = (long long)Lo.states.size(); stats4[3] = (long long)Ln.states.size(); }
+  static const bool timing = getenv("B2T_LAT_TIMING") != nullptr;
+  const auto t_prod = std::chrono::steady_clock::now();
+  int n_out = 0;
+  if (hn[0] != INFINITY && ho[0] != INFINITY) {
+    // paths in order of the new cost: best-first over partial paths, bound = cost so far + exact backward cost
+    const double limit_o = dr.start_off + ho[0] + (double)beam + 1e-4;
+    struct PN { int parent, parc; };
+    std::vector<PN> path;
+    struct It { double f, gnew, dl; int state, node; long long tie; bool done;
+                bool operator<(const It& o) const { if (f != o.f) return f > o.f; if (done != o.done) return !done; return tie > o.tie; } };
+    std::priority_queue<It> pq;
+    long long tie = 0;
+    pq.push(It{dr.start_off + hn[0], dr.start_off, 0.0, 0, -1, tie++, false});
+    std::vector<int> wv, av, arcs_rev;
+    while (!pq.empty() && n_out < nbest) {
+      const It it = pq.top(); pq.pop();
+      if (it.done) {
+        // read the hypothesis back: words along the path, the alignment from the final entry through the arcs' back pointers
+        arcs_rev.clear();
+        for (int n = it.node; n >= 0; n = path[(size_t)n].parent) arcs_rev.push_back(path[(size_t)n].parc);
+        wv.clear(); av.clear();
+        double gr = 0.0, ac = 0.0;
+        const auto& sdf = dr.st[(size_t)ps[(size_t)it.state].d];
+        int e = sdf.fin_ent;
+        gr += sdf.fin_gr + pfin_dl[(size_t)it.state]; ac += sdf.fin_ac;
+        for (int parc : arcs_rev) {                                  // last arc first
+          const PA& x = pa[(size_t)parc];
+          const auto& da = dr.darc[(size_t)x.darc];
+          wv.push_back(da.word);
+          gr += da.gr + x.dl; ac += da.ac;
+          for (int n = dr.bp_ali[da.bp + (size_t)e]; n >= 0; n = dr.ali[(size_t)n].parent) av.push_back(dr.ali[(size_t)n].label);
+          e = dr.bp_src[da.bp + (size_t)e];
+        }
+        for (int n = dr.start_ali[(size_t)e]; n >= 0; n = dr.ali[(size_t)n].parent) av.push_back(dr.ali[(size_t)n].label);
+        gr += dr.start_g; ac += dr.start_a;
+        if (w_off[n_out] + (int)wv.size() > w_cap || a_off[n_out] + (int)av.size() > a_cap) { set_error("lattice_rescore: output buffers too small"); return -2; }
+        std::reverse(wv.begin(), wv.end()); std::reverse(av.begin(), av.end());
+        if (out_words) std::copy(wv.begin(), wv.end(), out_words + w_off[n_out]);
+        if (out_ali) std::copy(av.begin(), av.end(), out_ali + a_off[n_out]);
+        w_off[n_out + 1] = w_off[n_out] + (int)wv.size();
+        a_off[n_out + 1] = a_off[n_out] + (int)av.size();
+        costs[2 * n_out] = (float)gr; costs[2 * n_out + 1] = (float)ac;
+        ++n_out;
+        continue;
+      }
+      const int q = it.state;
+      if (pfin_new[(size_t)q] != INFINITY) {
+        const double old_tot = (it.gnew - it.dl) + (pfin_new[(size_t)q] - pfin_dl[(size_t)q]);
+        if (old_tot <= limit_o) pq.push(It{it.gnew + pfin_new[(size_t)q], it.gnew + pfin_new[(size_t)q], it.dl + pfin_dl[(size_t)q], q, it.node, tie++, true});
+      }
+      for (int e = poff[(size_t)q]; e < poff[(size_t)q + 1]; ++e) {
+        const PA& a = pa[(size_t)e];
+        if (hn[(size_t)a.dst] == INFINITY) continue;
+        const double gn = it.gnew + a.w_new, dl = it.dl + a.dl;
+        if ((gn - dl) + ho[(size_t)a.dst] > limit_o) continue;          // no completion of this prefix is within the beam on the old costs
+        path.push_back(PN{it.node, e});
+        pq.push(It{gn + hn[(size_t)a.dst], gn, dl, a.dst, (int)path.size() - 1, tie++, false});
+      }
+    }
+  }
+  if (timing) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "lattice_rescore (determinised): %d lattice arcs -> %zu determinised states / %zu arcs (%.1f ms) -> product %d states / %zu arcs (%.1f ms), "
+                    "%d hypotheses (%.1f ms); det: gather %.1f closure %.1f intern %.1f ms, %zu closure states, %zu entries expanded\n", n_arcs, dr.st.size(), dr.darc.size(), ms(t_in, t_det), NP, pa.size(), ms(t_det, t_prod), n_out,
+            ms(t_prod, std::chrono::steady_clock::now()), dr.t_gather, dr.t_closure, dr.t_intern, dr.n_closure_states, dr.n_entries_expanded);
+  }
+  return n_out;
+}
+
+
 extern "C" int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
                                               const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
                                               int n_final, const int32_t* final_state, const float* final_cost,
@@ -823,6 +1233,18 @@ extern "C" int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arc
   if (!g_old || !g_new || n_states <= 0 || start < 0 || start >= n_states || n_arcs < 0 || nbest <= 0) {
     set_error("lattice_rescore: bad arguments");
     return -1;
+  }
+  // Default: on the determinised lattice, as the reference composes lat_ (above).  B2T_RESCORE_RAW=1, and lattices with a cycle
+  // of epsilon arcs, take the composition of the raw token lattice below (the first version: 3-28x the product arcs).
+  {
+    const char* raw_s = getenv("B2T_RESCORE_RAW");
+    if (!(raw_s && atoi(raw_s) != 0)) {
+      bool fell_back = false;
+      const int r = rescore_on_determinised(n_states, start, n_arcs, src, dst, ilabel, olabel, graph, acoustic, n_final, final_state, final_cost,
+                                            g_old, g_new, backoff_label, nbest, beam, out_words, w_off, w_cap, out_ali, a_off, a_cap, costs, stats4,
+                                            &fell_back);
+      if (!fell_back) return r;
+    }
   }
   const auto t_in = std::chrono::steady_clock::now();
   LmDet Lo(*CFST(g_old), backoff_label), Ln(*CFST(g_new), backoff_label);

@@ -233,3 +233,39 @@ def test_rescore_real_lattice_promotes_from_below_the_list():
     # either way the composition's k-th total is never above the shallow exchange's k-th total
     shallow = sorted((g - H_old.grammar_score(list(w), wd0) + H_new.grammar_score(list(w), wd0) + a) for w, g, a, _ in deep[:60])
     assert all(got[j][1] + got[j][2] <= shallow[j] + 1e-3 for j in range(min(50, len(shallow))))
+
+
+def test_rescore_on_the_determinised_lattice_equals_the_raw_composition(monkeypatch):
+    """Round 4: Rescore() determinises the lattice over words before composing it with the grammars (as the reference composes
+    lat_, lattice-faster-decoder.cc:193-213 + brain_speech_decoder.cc:47-101).  On a real lattice: the same word sequences in the
+    same order with the same graph / acoustic costs as the composition of the RAW lattice (B2T_RESCORE_RAW=1, the round-3 form),
+    a product two orders of magnitude smaller, and alignments that span every frame."""
+    import ngram_lm
+    import wfst
+    Z = np.load(os.path.join(ROOT, "tests", "golden", "wfst_lattice_u2.npz"))
+    n_states, n_arcs, n_final, start, frames = (int(v) for v in Z["meta"])
+    V = max(int(w) for w in Z["ol"] if w > 0)
+    vocab = [f"w{k}" for k in range(1, V + 1)]
+    table = ["<eps>"] + vocab + ["#0", "<s>", "</s>"]
+    word_id = {w: i for i, w in enumerate(table) if 0 < i <= V}
+    wd0 = V + 1
+    H_old = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 2, 3 * V, seed=5), word_id, wd0)).arcsort()
+    H_new = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 3, 6 * V, seed=6), word_id, wd0)).arcsort()
+    args = (n_states, start, Z["src"], Z["dst"], Z["il"], Z["ol"], Z["gr"], Z["ac"], Z["fs"], Z["fc"])
+    cap = 400 * (2 * frames + 16)
+    monkeypatch.setenv("B2T_RESCORE_RAW", "1")
+    raw, st_raw = host_rescore(*args, H_old, H_new, wd0, 200, 8.0, cap=cap)
+    monkeypatch.setenv("B2T_RESCORE_RAW", "0")
+    det, st_det = host_rescore(*args, H_old, H_new, wd0, 200, 8.0, cap=cap)
+    assert len(det) == len(raw) >= 50
+    tr, td = np.array([g + a for _, g, a, _ in raw]), np.array([g + a for _, g, a, _ in det])
+    np.testing.assert_allclose(td, tr, atol=2e-3)
+    for j, (x, y) in enumerate(zip(det, raw)):
+        tied = (j > 0 and abs(tr[j] - tr[j - 1]) < 2e-3) or (j + 1 < len(raw) and abs(tr[j + 1] - tr[j]) < 2e-3)
+        if not tied:
+            assert x[0] == y[0], j
+            assert abs(x[1] - y[1]) < 2e-3 and abs(x[2] - y[2]) < 2e-3, j
+        assert len(x[3]) == frames == len(y[3]), "an alignment has one input label per decoded frame"
+    assert det[0][3] == raw[0][3]                       # the best hypothesis' alignment (no tie at the top of this lattice)
+    assert {w for w, *_ in det} == {w for w, *_ in raw} and len({w for w, *_ in det}) == len(det)
+    assert st_det[1] * 10 < st_raw[1], (st_det, st_raw)  # product arcs: determinised first vs raw

@@ -18,9 +18,9 @@ fin = S.finalize()
 hdr = S._header()
 cn, ((src, dst, il, ol, gr, ac, fs, fc), a_off, f_off) = S._lattices()   # flat arrays, utterance u at [a_off[u], a_off[u + 1])
 out = {}
-for u in range(4):
+for u in range(int(os.environ.get("B2T_DUMP_U", "4"))):
     n_states, n_arcs, n_final, start = (int(v) for v in cn[u, :4])
     out.update({f"u{u}_{k}": v for k, v in dict(src=src[a_off[u]:a_off[u + 1]], dst=dst[a_off[u]:a_off[u + 1]], il=il[a_off[u]:a_off[u + 1]], ol=ol[a_off[u]:a_off[u + 1]], gr=gr[a_off[u]:a_off[u + 1]],
                                                  ac=ac[a_off[u]:a_off[u + 1]], fs=fs[f_off[u]:f_off[u + 1]], fc=fc[f_off[u]:f_off[u + 1]], meta=np.array([n_states, n_arcs, n_final, start, int(hdr[u, 0])])).items()})
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "lattices.npz"), **out)
-print("saved", {k: v.shape for k, v in out.items() if k.endswith("meta")}, [out[f"u{u}_meta"].tolist() for u in range(4)])
+print("saved", {k: v.shape for k, v in out.items() if k.endswith("meta")}, "...")
