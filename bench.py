@@ -324,7 +324,7 @@ def main():
 
     torch.manual_seed(10)
     model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
-    ts = TrainStep(model, dict(ARGS))
+    ts = TrainStep(model, dict(ARGS, dp_max_days_per_rank=4))     # make_batch: 4 days per rank's batch (days_per_batch of rnn_args.yaml)
     if a.scaling == "strong":
         # SURVEY 8e parity mode: every rank builds the SAME global batch and keeps its 64/N contiguous rows; the loss scale
         # 1 / (rows * world) = 1 / 64 makes the all-reduced SUM the one-GPU mean gradient
@@ -362,6 +362,8 @@ def main():
         model._ws.check_sync()
         return loss, dt, t_enq
 
+    if ts.reducer is not None and os.environ.get("B2T_DP_DEFERRED", "0") == "1":
+        ts.reducer.deferred = True                 # measurement knob: all-reduce behind the backward pass (the post-refusal fallback)
     sampler = BoxSampler(dev) if world == 1 else None
     try:
         if sampler:

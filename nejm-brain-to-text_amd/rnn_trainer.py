@@ -315,6 +315,9 @@ class BrainToTextDecoder_Trainer:
                                           'lr_min_day', 'lr_decay_steps_day', 'lr_warmup_steps_day', 'beta0', 'beta1',
                                           'epsilon', 'weight_decay', 'weight_decay_day', 'grad_norm_clip_value',
                                           'lr_scheduler_type')}
+        # data parallel: a rank's batch touches at most days_per_batch day layers (dataset.py: the pre-generated batch index), so the
+        # reducer all-reduces world x days_per_batch day records instead of all of them (b2t_train_step.GradReducer.set_sparse_days)
+        flat['dp_max_days_per_rank'] = self.args.get('dataset', {}).get('days_per_batch')
         self.train_step = TrainStep(self.model, flat)
         frozen = [n for n, p in self.model.named_parameters() if not p.requires_grad]
         if frozen:

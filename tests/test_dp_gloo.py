@@ -54,6 +54,74 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _sparse_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "nejm-brain-to-text_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import b2t_ops as ops
+        from rnn_model import GRUDecoder
+        from b2t_train_step import GradReducer, bucket_spans
+        torch.manual_seed(0)
+        F, D = 16, 9
+        m = GRUDecoder(F, 32, D, 41, 0, 0, 2, 0, 0)
+        lay = m.layout()
+        names = lay["names"]
+        buckets = bucket_spans(lay, 2)
+        seg = torch.tensor([names.index(f"day_weights.{d}") for d in range(D)], dtype=torch.int64)
+        w0, b0 = lay["spans"][names.index("day_weights.0")][0], lay["spans"][names.index("day_biases.0")][0]
+        ws, bs = ops.pad_to(F * F), ops.pad_to(F)
+        res = {}
+        for case, seen, cap in (("disjoint", {0: {1, 7}, 1: {3, 4}}, 4), ("overlap", {0: {0, 8}, 1: {8, 2}}, 4), ("overflow", {0: {0, 1, 2}, 1: {3, 4, 5}}, 4)):
+            arenas = []
+            for r in range(world):      # what each rank would hold: gradients only in the day records it saw (the rest zeroed)
+                a = torch.randn(lay["total"], generator=torch.Generator().manual_seed(7 + r))
+                for d in range(D):
+                    if d not in seen[r]:
+                        a[w0 + d * ws: w0 + (d + 1) * ws] = 0; a[b0 + d * bs: b0 + (d + 1) * bs] = 0
+                arenas.append(a)
+            arena = arenas[rank].clone()
+            active = torch.ones(len(names), dtype=torch.int32)
+            for s_, n in enumerate(names):
+                if n.startswith("day_"):
+                    active[s_] = int(int(n.split(".")[1]) in seen[rank])
+            status = torch.zeros(1)
+            red = GradReducer(arena, buckets)
+            red.set_sparse_days(active, seg, w0, ws, b0, bs, D, cap, status)
+            red.union_active(active)
+            for name, _, _ in buckets:
+                red.launch(name)
+            red.finish()
+            want = sum(arenas)
+            res[case] = (bool(torch.allclose(arena, want, atol=1e-6)), float(status[0]), tuple(red.sparse["stage"].shape))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_day_reduction_world2():
+    """Round 4 (verdict item 7b): only the union of the active day layers is all-reduced -- ranks with disjoint and with
+    overlapping day sets end with the dense sum; the staging buffer holds `capacity` day records, not all of them; more active
+    days than it holds set status 3 (the step is refused) instead of silently dropping a day's gradient."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert res["disjoint"][0] and res["disjoint"][1] == 0.0 and res["disjoint"][2][0] == 4
+        assert res["overlap"][0] and res["overlap"][1] == 0.0
+        assert res["overflow"][1] == 3.0                                 # six active days, four slots: the step is refused ...
+    assert not all(res["overflow"][0] for _, res in out)                  # ... because a rank would otherwise miss a day's gradient
+
+
 def test_grad_reducer_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

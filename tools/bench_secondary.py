@@ -244,6 +244,41 @@ def trainer_loop_c2():
                          "(160-step run - 40-step run) / 120")
 
 
+def dp_forced_one_rank(steps: int = 30):
+    """What one GPU can say about the data-parallel step (round-3 verdict, item 7a): bench.py in a ONE-rank RCCL group with
+    B2T_DP_FORCE=1 runs every collective of the N-rank step -- the bucketed all-reduces launched from the executor's bucket
+    callback NEXT TO the resident persistent sweeps, the MAX-reduced day flags and status word, the sparse day-record reduce --
+    against the plain step, with the all-reduces deferred behind the backward pass (the fallback after a refused step), and with
+    the dense 47 MB day bucket.  Child processes (a process group cannot be torn down and re-made inside this one)."""
+    import json, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", str(steps), "--warmup", "6", "--no-cpu-baseline", "--no-secondary"]
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        best = None
+        for _ in range(2):
+            r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return dict(error=r.stderr[-300:])
+            d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0])
+            if best is None or d["ms_per_step"] < best["ms_per_step"]:
+                best = d
+        return dict(ms_per_step=best["ms_per_step"], final_loss=best["final_loss"], collective=best["config"]["collective"])
+    plain = run({})
+    forced = run({"B2T_DP_FORCE": "1"})
+    deferred = run({"B2T_DP_FORCE": "1", "B2T_DP_DEFERRED": "1"})
+    dense = run({"B2T_DP_FORCE": "1", "B2T_DP_DENSE_DAYS": "1"})
+    comm_stream = run({"B2T_DP_FORCE": "1", "B2T_DP_INLINE": "0"})
+    out = dict(plain=plain, forced_rccl_next_to_sweeps=forced, forced_rccl_deferred_behind_backward=deferred,
+               forced_rccl_dense_day_bucket=dense, forced_rccl_on_the_process_groups_comm_stream=comm_stream,
+               workload="the headline C2 step, one rank: every collective of the N-rank step runs (identity results); best of two child runs each")
+    if "ms_per_step" in plain and "ms_per_step" in forced:
+        out["forced_over_plain"] = round(forced["ms_per_step"] / plain["ms_per_step"], 4)
+    return out
+
+
 def relabel(out):
     """Name the decode numbers for what they are (round-3 verdict, item 5): BASELINE configs[3] / [4] ask for the reference's
     searcher -- WFST token passing over T o L o G -- so ITS numbers are the configs[3] / [4] lines; the lexicon prefix beam (the
@@ -278,6 +313,7 @@ def all_secondary():
     out = {}
     for name, fn in (("c3_f32", lambda: train_ms("c3", False)), ("c3_amp", lambda: train_ms("c3", True)),
                      ("c2_amp", lambda: train_ms("c2", True)), ("trainer_loop_c2_f32", trainer_loop_c2),
+                     ("dp_forced_one_rank", dp_forced_one_rank),
                      ("decode_beam100_3gram", decode_beam100_3gram),
                      ("stream_32utt_5gram", stream_32utt_5gram), ("decode_wfst_tlg", decode_wfst_tlg)):
         sys.stderr.write(f"[secondary] {name} ...\n"); sys.stderr.flush()
