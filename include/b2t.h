@@ -461,6 +461,11 @@ double b2t_fst_grammar_score(const void* fst, const int32_t* words, int n_words,
 typedef struct {
   const int32_t* row; const int32_t* ilabel; const int32_t* olabel; const float* weight; const int32_t* next;
   const int32_t* n_eps; const float* final_cost; int32_t n_states, start;
+  /* compact arcs (compact != 0): 10 bytes per arc instead of 16 -- labels[a] = ilabel | olabel << 7 (ilabel <= 127, olabel <
+   * 2^25), weight_f16[a] = the weight as IEEE binary16 (relative error <= 2^-11), next as above; ilabel / olabel / weight are
+   * then not read and may be NULL.  A search on a compact graph equals the search on the full-width graph whose weights were
+   * rounded to binary16 beforehand, bit for bit.  No reference counterpart (OpenFST's ConstFst keeps 16-byte arcs). */
+  const uint32_t* labels; const uint16_t* weight_f16; int32_t compact;
 } b2t_wfst_graph_t;
 typedef struct {
   float beam, lattice_beam, beam_delta, acoustic_scale, length_penalty, blank_skip_thresh;

@@ -68,7 +68,7 @@ BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 class WfstGraph(C.Structure):
     """Mirror of b2t_wfst_graph_t (include/b2t.h)."""
     _fields_ = [(n, VP) for n in ("row", "ilabel", "olabel", "weight", "next", "n_eps", "final_cost")] + \
-               [("n_states", C.c_int32), ("start", C.c_int32)]
+               [("n_states", C.c_int32), ("start", C.c_int32), ("labels", VP), ("weight_f16", VP), ("compact", C.c_int32)]
 
 
 class WfstOpts(C.Structure):

@@ -1007,6 +1007,14 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     bucket(1 + l, t_wg);
   }
 
+  // probe (B2T_WGRAD_AFTER=k): the weight-gradient GEMMs of layers >= k wait for the LAST backward sweep (they block the
+  // placement of sweep workgroups and are slowed by them in turn: tools/r4_sweep_probe.py)
+  if (const char* wa = getenv("B2T_WGRAD_AFTER")) {
+    const int k0 = atoi(wa);
+    for (int l = std::max(0, k0); l < L; ++l)
+      for (size_t i = 0; i < P.t.size(); ++i)
+        if (P.t[i].name && !strcmp(P.t[i].name, "wgrad") && (int)i == t_wg_last[l]) P.dep((int)i, t_bs[0][0]);
+  }
   // layer-0 input gradient -> day layer
   const int t_dayfin = P.add("day_w", fast_day ? 60.f : est_gemm(F, F, T, B) + 200.f, Q_ANY, {t_dx[0][0]}, [&](hipStream_t s) {
     void* sp = reinterpret_cast<void*>(s);

@@ -40,7 +40,13 @@ constexpr int MAX_C = 64;
 struct Graph {
   const int* row; const int* ilabel; const int* olabel; const float* weight; const int* next; const int* n_eps;
   const float* final_cost; int start;
+  // compact arcs (round 4; b2t_wfst_graph_t.compact): 10 bytes per arc instead of 16 -- labels = ilabel | olabel << 7 (one
+  // word), the weight as IEEE half (|error| <= 2^-11 relative), next as before; the full-width arrays are then not read
+  const unsigned* labels; const _Float16* w16; int compact;
 };
+__device__ __forceinline__ int g_il(const Graph& g, int a) { return g.compact ? (int)(g.labels[a] & 127u) : g.ilabel[a]; }
+__device__ __forceinline__ int g_ol(const Graph& g, int a) { return g.compact ? (int)(g.labels[a] >> 7) : g.olabel[a]; }
+__device__ __forceinline__ float g_w(const Graph& g, int a) { return g.compact ? (float)g.w16[a] : g.weight[a]; }
 
 // state block of one utterance (HBM), carved by layout(): header words then arrays
 struct Hdr {
@@ -325,7 +331,7 @@ __device__ void nonemitting(Ctx& c, int n0, float cutoff) {
         if (!(cur < cutoff)) return;
         const int a0 = g.row[s];
         for (int a = a0; a < a0 + ne; ++a) {
-          const float tot = cur + g.weight[a];
+          const float tot = cur + g_w(g, a);
           if (tot < cutoff) {
             if (phase == 0) {
               claim(c, g.next[a]);
@@ -354,13 +360,13 @@ __device__ void nonemitting(Ctx& c, int n0, float cutoff) {
     if (!(cur < cutoff)) return;
     const int a0 = g.row[s];
     for (int a = a0; a < a0 + ne; ++a) {
-      const float tot = cur + g.weight[a];
+      const float tot = cur + g_w(g, a);
       if (tot < cutoff) {
         const int id = find(c, g.next[a]);
         if (id < 0) continue;
         const int li = atomicAdd(&c.sh[1], 1);
         if (li < c.max_link) {
-          c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = 0.f; c.l.link_graph[li] = g.weight[a];
+          c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = 0.f; c.l.link_graph[li] = g_w(g, a);
         } else {
           atomicOr(&c.sh[3], 2);
         }
@@ -452,8 +458,8 @@ __device__ void advance(Ctx& c) {
   float mn = INFINITY;
   int narcs = 0;
   auto arc_cost = [&](float cur, int s, int a, float& ac, float& gc) {
-    ac = cost_offset - c.ll[g.ilabel[a] - 1];
-    gc = g.weight[a];
+    ac = cost_offset - c.ll[g_il(g, a) - 1];
+    gc = g_w(g, a);
     if (lp != 0.f && g.next[a] != s) gc += lp;     // (no gather of the destination when there is no length penalty)
     return cur + ac + gc;
   };
@@ -790,8 +796,8 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
   const float cost_offset = -best;
   const float lp = c.o.length_penalty;
   auto arc_cost = [&](float cur, int s, int a, float& ac, float& gc) {
-    ac = cost_offset - c.ll[g.ilabel[a] - 1];
-    gc = g.weight[a];
+    ac = cost_offset - c.ll[g_il(g, a) - 1];
+    gc = g_w(g, a);
     if (lp != 0.f && g.next[a] != s) gc += lp;
     return cur + ac + gc;
   };
@@ -963,7 +969,7 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
         if (!(cur < next_cutoff)) continue;
         const int a0 = g.row[s], ne = g.n_eps[s];
         for (int a = a0; a < a0 + ne; ++a) {
-          const float tot = cur + g.weight[a];
+          const float tot = cur + g_w(g, a);
           if (tot < next_cutoff) {
             const int ns = g.next[a];
             const int nne = g.n_eps[ns];           // (in flight next to the claim's slot load)
@@ -993,13 +999,13 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
       if (!(cur < next_cutoff)) continue;
       const int a0 = g.row[s], ne = g.n_eps[s];
       for (int a = a0; a < a0 + ne; ++a) {
-        const float tot = cur + g.weight[a];
+        const float tot = cur + g_w(g, a);
         if (tot < next_cutoff) {
           const int id = cclaim(c, g.next[a]);      // exists: the closure has converged
           if (id < 0) continue;
           const int li = wave_alloc(&cl->n_link);
           if (li < c.max_link) {
-            c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = 0.f; c.l.link_graph[li] = g.weight[a];
+            c.l.link_src[li] = t; c.l.link_dst[li] = id; c.l.link_arc[li] = a; c.l.link_ac[li] = 0.f; c.l.link_graph[li] = g_w(g, a);
           } else {
             atomicOr(&cl->overflow, 2);
           }
@@ -1272,8 +1278,8 @@ __global__ void wfst_best_path_kernel(Graph g, char* state, size_t state_bytes, 
       const int i = i0 + k;
       if (i < n) {
         const int li = s_li[i], a = l.link_arc[li];
-        const int il = g.ilabel[a];
-        s_il[i] = il; s_ol[i] = g.olabel[a]; s_gc[i] = l.link_graph[li]; s_ac[i] = l.link_ac[li];
+        const int il = g_il(g, a);
+        s_il[i] = il; s_ol[i] = g_ol(g, a); s_gc[i] = l.link_graph[li]; s_ac[i] = l.link_ac[li];
         emit += il != 0;
       }
     }
@@ -1925,7 +1931,7 @@ __global__ __launch_bounds__(LAT_NT) void wfst_lattice_arcs_kernel(Graph g, char
       while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (l.link_off[mid] <= li) lo = mid; else hi = mid - 1; }
       const int a = l.link_arc[li];
       a_src[ao + k] = newid[l.link_src[li]]; a_dst[ao + k] = newid[l.link_dst[li]];
-      a_il[ao + k] = g.ilabel[a]; a_ol[ao + k] = g.olabel[a];
+      a_il[ao + k] = g_il(g, a); a_ol[ao + k] = g_ol(g, a);
       a_graph[ao + k] = l.link_graph[li];
       a_ac[ao + k] = (lo & 1) ? l.link_ac[li] - l.cost_offset[lo >> 1] : l.link_ac[li];   // emitting links carry the frame's cost offset
     }
@@ -1961,8 +1967,8 @@ extern "C" size_t b2t_wfst_state_bytes(int max_frames, int max_tokens, int max_l
 namespace {
 int check_args(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state, int U, const char* what) {
   B2T_REQUIRE(g && o && state && U > 0, "%s: null argument", what);
-  B2T_REQUIRE(g->row && g->ilabel && g->olabel && g->weight && g->next && g->n_eps && g->final_cost && g->n_states > 0,
-              "%s: incomplete graph", what);
+  B2T_REQUIRE(g->row && g->next && g->n_eps && g->final_cost && g->n_states > 0 &&
+              (g->compact ? (g->labels && g->weight_f16) : (g->ilabel && g->olabel && g->weight)), "%s: incomplete graph", what);
   B2T_REQUIRE(o->hash_size >= 64 && (o->hash_size & (o->hash_size - 1)) == 0, "%s: hash_size must be a power of two >= 64", what);
   B2T_REQUIRE(o->max_frames > 0 && o->max_tokens > 0 && o->max_links > 0, "%s: bad capacities", what);
   B2T_REQUIRE(o->beam > 0.f && o->lattice_beam > 0.f && o->max_active > 1 && o->min_active >= 0 && o->min_active <= o->max_active,
@@ -1970,7 +1976,8 @@ int check_args(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* o, void* state,
   return 0;
 }
 Graph to_graph(const b2t_wfst_graph_t* g) {
-  return Graph{g->row, g->ilabel, g->olabel, g->weight, g->next, g->n_eps, g->final_cost, g->start};
+  return Graph{g->row, g->ilabel, g->olabel, g->weight, g->next, g->n_eps, g->final_cost, g->start,
+               g->labels, reinterpret_cast<const _Float16*>(g->weight_f16), g->compact};
 }
 Opts to_opts(const b2t_wfst_opts_t* o) {
   return Opts{o->beam, o->lattice_beam, o->beam_delta, o->acoustic_scale, o->length_penalty, o->blank_skip_thresh, o->max_active, o->min_active};

@@ -59,8 +59,13 @@ class WfstSearch:
         self.lib = N.load()
         d = graph.to_device(self.device)
         self._keep = d
-        self.cg = N.WfstGraph(d["row"].data_ptr(), d["ilabel"].data_ptr(), d["olabel"].data_ptr(), d["weight"].data_ptr(),
-                              d["next"].data_ptr(), d["n_eps"].data_ptr(), d["final"].data_ptr(), graph.n_states, graph.start)
+        if getattr(graph, "compact", False):
+            self.cg = N.WfstGraph(d["row"].data_ptr(), None, None, None, d["next"].data_ptr(), d["n_eps"].data_ptr(), d["final"].data_ptr(),
+                                  graph.n_states, graph.start, d["labels"].data_ptr(), d["weight_f16"].data_ptr(), 1)
+        else:
+            self.cg = N.WfstGraph(d["row"].data_ptr(), d["ilabel"].data_ptr(), d["olabel"].data_ptr(), d["weight"].data_ptr(),
+                                  d["next"].data_ptr(), d["n_eps"].data_ptr(), d["final"].data_ptr(), graph.n_states, graph.start,
+                                  None, None, 0)
         if hash_size <= 0:
             # a frame can hold at most one token per graph state; graphs of the reference's size class (10^6+ states) put
             # 10-30 k tokens into a frame with the production beam: 2^18 slots keep the linear probing short there

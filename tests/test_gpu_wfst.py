@@ -105,6 +105,43 @@ def test_wfst_search_matches_oracle_production_options(toy):
     print(f"spelled sentences recovered exactly: {hits}/8 (the LM weight and merged repeats change the others; the oracle agrees on all)")
 
 
+def test_compact_arcs_equal_the_half_rounded_graph_bit_for_bit(toy):
+    """Round 4: 10-byte arcs (labels = ilabel | olabel << 7 in one word, the weight as IEEE half; b2t_wfst_graph_t.compact).
+    The search, the partial best path, FinalizeDecoding, the lattice and the n-best on the compact graph are those of the
+    full-width graph whose weights were rounded to half beforehand -- bit for bit, in both search kernels, with pruning passes
+    in between -- and the stated error bound of the rounding holds (the oracle legs above keep running on full-width arcs)."""
+    import b2t_native as N
+    from wfst_decoder import WfstSearch
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(11)
+    seqs, lps, batch, lens = utterances(prons, words, 6, rs, noise=0.7, blank_bias=0.0)
+    o = Opt(nbest=30)
+    import copy
+    gc = copy.copy(g); gc._dev = None; gc.set_compact(True)
+    gh = g.half_rounded()
+    w = g.weight[np.isfinite(g.weight)]
+    assert np.all(np.abs(gh.weight[np.isfinite(g.weight)] - w) <= np.abs(w) * 2.0 ** -11 + 1e-7)
+    assert gc.nbytes() < g.nbytes() and (g.nbytes() - gc.nbytes()) == 6 * g.n_arcs
+    dev_batch = torch.from_numpy(batch).cuda()
+    lib = N.load()
+    for cluster in (0, 1):
+        lib.b2t_wfst_set_cluster(cluster)
+        try:
+            outs = []
+            for graph in (gc, gh):
+                S = WfstSearch(graph, o, U=6, max_frames=batch.shape[1] + 8, prune_interval=10, prune_min_fill=0.0)
+                for t0 in range(0, batch.shape[1], 13):
+                    chunk = dev_batch[:, t0:t0 + 13].contiguous()
+                    S.search(chunk, np.clip(lens - t0, 0, chunk.shape[1]).astype(np.int32))
+                part = S.best_path(False)
+                fin = S.finalize()
+                outs.append((S.frames_decoded(), part, fin))
+            assert outs[0] == outs[1], f"compact arcs differ from the half-rounded graph (cluster setting {cluster})"
+            assert any(len(f) > 3 for f in outs[0][2])
+        finally:
+            lib.b2t_wfst_set_cluster(0)
+
+
 def test_wfst_streaming_equals_one_shot_and_blank_skipping(toy):
     """Chunk-by-chunk Search (state persists in HBM) == one call, bit for bit; blank-frame skipping with the re-insertion
     rule (ctc_wfst_beam_search.cc:79-94) reproduces the oracle's frame mapping, times and results."""

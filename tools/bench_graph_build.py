@@ -16,11 +16,11 @@ import ngram_lm   # noqa: E402
 import wfst       # noqa: E402
 
 
-def build(n_words, n_per_order, optimize=True, seed=0):
+def build(n_words, n_per_order, optimize=True, seed=0, order=3):
     t0 = time.time()
     prons = ngram_lm.synthetic_lexicon(n_words, 41, seed=seed + 1)
     words = sorted(prons)
-    arpa = ngram_lm.synthetic_word_arpa(words, 3, n_per_order, seed=seed + 2)
+    arpa = ngram_lm.synthetic_word_arpa(words, order, n_per_order, seed=seed + 2)
     t1 = time.time()
     st = {}
     g = wfst.build_tlg_native(prons, arpa, optimize=optimize, stats=st)
@@ -33,10 +33,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--words", type=int, default=125078)
     ap.add_argument("--ngrams", type=int, default=1000000, help="bigrams and trigrams each")
+    ap.add_argument("--order", type=int, default=3)
     ap.add_argument("--plain", action="store_true", help="skip determinize-star / minimize-encoded")
     ap.add_argument("--save", default="")
     a = ap.parse_args()
-    prons, words, arpa, g, st = build(a.words, a.ngrams, optimize=not a.plain)
+    prons, words, arpa, g, st = build(a.words, a.ngrams, optimize=not a.plain, order=a.order)
     print(json.dumps(st, indent=1))
     if a.save:
         wfst.save_graph(g, a.save)
