@@ -1,7 +1,7 @@
 """Save the pruned token lattices of a few utterances of the tools/bench_wfst.py workload (for profiling csrc/lattice.cpp on the host)."""
 import math, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "nejm-brain-to-text_amd")); sys.path.insert(0, ROOT)
 import bench_wfst as B
 import b2t_native as N, b2t_ops as ops

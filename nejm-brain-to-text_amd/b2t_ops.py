@@ -259,7 +259,7 @@ class Grads(Params):
 # GRU sweep mode: 0 = one launch per time step; 1 = persistent single-launch sweep with counter hand-off
 # (csrc/gru_persistent.hip).  -1 = choose per call: mode 1 whenever its (H/16) x ceil(B/16) workgroups can be
 # co-resident, else 0.  (The granule / 4-row-group / fused-stack variants of round 1 lost to mode 1 inside the full step
-# and live in tools/experimental/ with their measurements in DESIGN.md.)
+# and live in attic/ with their measurements in DESIGN.md.)
 GRU_MODE = {"value": int(os.environ.get("B2T_GRU_MODE", "-1"))}
 MAX_RESIDENT_WGS = 256   # MI355X: 256 CUs; a persistent sweep needs all its workgroups resident at once
 # Number of time chunks the layers are software-pipelined over (1 = layer-by-layer on the caller's stream).

@@ -709,7 +709,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
           } else if (In0 >= 2048 && nc == 1) {
             // patch input at full size (shipped shape: 7808 x 2304 x 7168): 61 x 18 = 1098 tiles are 1.07 waves of the chip's
             // 1024 tile slots, i.e. the second wave runs almost empty (92 TF/s).  Three K slices make 3.2 waves of shorter
-            // tiles: 114 TF/s incl. the slab reduction (tools/experimental/bench_gemm_c3.py); one row-mapped GEMM over all (t, b) rows.
+            // tiles: 114 TF/s incl. the slab reduction (attic/bench_gemm_c3.py); one row-mapped GEMM over all (t, b) rows.
             b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
             d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
             c.gemm(sg, d, 3, w.slab_gi[0]);
@@ -945,7 +945,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     }
     // Serial plan (shapes whose sweeps cannot share the chip, e.g. the shipped H = 768): the whole sequence's dX of a layer is
     // 61 x 6 = 366 tiles, a third of the chip's tile slots -- two K slices fill it (79 -> 100 TF/s incl. the slab reduction,
-    // tools/experimental/bench_gemm_c3.py).  Pipelined plans share the CUs with the sweeps anyway (measured neutral there).
+    // attic/bench_gemm_c3.py).  Pipelined plans share the CUs with the sweeps anyway (measured neutral there).
     const long long tiles = (((long long)n * B + 127) / 128) * ((N + 127) / 128);
     if (l > 0 && nc == 1 && !c.bf16_gemm && w.slab_dx && tiles <= 512 && 3 * H >= 1024) c.gemm(s, d, 2, w.slab_dx);
     else c.gemm(s, d);

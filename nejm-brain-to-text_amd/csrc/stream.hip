@@ -17,7 +17,7 @@
 // (the eight L2s are not coherent with each other: MI355X_MICROARCH, per-XCD L2).
 // Arithmetic is the executor path's: exact fp32 MFMA products, the same gate formulas (gru_cell.h): the two agree to summation
 // order (tests/test_gpu_parity.py::test_stream_forward_equals_executor).
-// MEASURED (tools/experimental/stream_probe.py, phase stamps of workgroup 0): 151-159 us per frame against the executor's 163 --
+// MEASURED (attic/stream_probe.py, phase stamps of workgroup 0): 151-159 us per frame against the executor's 163 --
 // day layer 11, layer 0 47 (66 MB of W_ih), layers 1-4 13.6 each (14 MB each), head 11, barriers 4 each -- i.e. the single launch
 // removes the launches and NOT the time: a phase is 3-4 dependent memory round trips of ~3 us (all 154 busy CUs burst their
 // 16-rows-x-64-byte fragment loads at once) plus the barrier.  What the stamps found on the way: (1) all 8 waves issuing the

@@ -2040,7 +2040,13 @@ extern "C" int b2t_wfst_cluster_size(int U) {
   // XCD per utterance, tested against the single-workgroup search) but buy nothing: one utterance takes 11.7 / 11.1 / 11.7 ms
   // with 8 / 16 / 32 workgroups, eight take 14.9 / 14.1 / 14.9 -- beyond 8 members a frame is its ~6 cluster barriers and the
   // chains of dependent L2 round trips between them (~100 us), not the walk over its tokens and arcs.
-  const int slots = 256;
+  // one workgroup (1024 threads) per CU: the members of every cluster must be co-resident (their barrier is an L2 spin counter),
+  // so the slot count is the device's CU count, not a constant (a partition or a smaller part has fewer)
+  static int slots = -1;
+  if (slots < 0) {
+    int dev = 0; hipDeviceProp_t p;
+    slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
   for (int G = 8; G > 1; G >>= 1) if ((U + 7) / 8 * 8 * G <= slots) return wfst_xcd_roundrobin_ok() ? G : 1;
   return 1;
 }

@@ -278,7 +278,12 @@ class GRUDecoder(nn.Module):
 
     def _graph_forward(self, x, day_idx, states):
         arena = self.arena()
-        key = (tuple(x.shape), states is None, arena.data_ptr(), x.device.index, bool(ops.AMP["on"]), bool(ops.STREAM["fused"]))
+        if states is not None and tuple(states.shape) != (self.n_layers, x.shape[0], self.n_units):
+            raise ValueError(f"states must be [{self.n_layers},{x.shape[0]},{self.n_units}], got {tuple(states.shape)}")   # (the replay copies the captured element count: never read a smaller tensor out of bounds)
+        # the capture stream is part of the key: the static buffers and the `done` event are ordered on that stream only, a call
+        # from another current stream gets (eager calls, then) a graph of its own
+        key = (tuple(x.shape), None if states is None else tuple(states.shape), arena.data_ptr(), x.device.index, bool(ops.AMP["on"]),
+               bool(ops.STREAM["fused"]), int(torch.cuda.current_stream(x.device).cuda_stream))
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 8:

@@ -2,7 +2,7 @@
 DeterminizeLatticePruned + ShortestPath(nbest), ctc_wfst_beam_search.cc:123-160) against the oracle's restatement
 (oracle/wfst_oracle.py: nbest_word_sequences) -- no GPU involved.  Random acyclic lattices with epsilon-output arcs, and a
 real lattice the GPU search left behind for one utterance of the tools/bench_wfst.py workload (tests/golden/wfst_lattice_u2.npz,
-written by tools/experimental/dump_lattice.py: 4868 states, 9329 arcs, 217 final states)."""
+written by attic/dump_lattice.py: 4868 states, 9329 arcs, 217 final states)."""
 import ctypes as C
 import os
 import sys

@@ -48,9 +48,9 @@ def decode(g, lp, lens, U, T, hash_size, cluster):
         lib.b2t_wfst_set_cluster(0)
 
 
-def run(n_words=125078, n_grams=1000000, U=32):
+def run(n_words=125078, n_grams=1000000, U=32, order=3):
     lib = N.load(); dev = torch.device("cuda:0")
-    prons, words, arpa, g, st = GB.build(n_words, n_grams, optimize=True)
+    prons, words, arpa, g, st = GB.build(n_words, n_grams, optimize=True, order=order)
     _, _, _, _, seqs, logits, lens, _ = BW.make(U=U, seed=0, noise=0.9, graph=(prons, words, arpa, g), truth="lm", blank_boost=math.log(90.0))
     _, _, lp = BW._logp(logits, dev, lib)
     T = logits.shape[1]
@@ -69,6 +69,23 @@ def run(n_words=125078, n_grams=1000000, U=32):
             out[tag] = dict(error=repr(e)[:300])
         print(tag, json.dumps(out[tag]), flush=True)
         torch.cuda.empty_cache()
+    # round 4: the same graph with 10-byte arcs (b2t_wfst_graph_t.compact): graph bytes against search time
+    try:
+        import copy
+        full_gb = g.nbytes() / 1e9
+        g._dev = None; torch.cuda.empty_cache()
+        gc = copy.copy(g); gc._dev = None; gc.set_compact(True)
+        r = decode(gc, lp, lens, U, T, 1 << 18, 0)
+        if isinstance(r, tuple):
+            r, fin = r
+            wfst_1 = [[g.words[w] for w in f[0][2]] if f else [] for f in fin]
+            r["wer_vs_truth"] = round(sum(BW.edit(h, q) for h, q in zip(wfst_1, seqs[:U])) / sum(len(q) for q in seqs[:U]), 4)
+        r["hbm_graph_gb"] = round(gc.nbytes() / 1e9, 3); r["hbm_graph_gb_full_width"] = round(full_gb, 3)
+        out["u32_cluster_compact_arcs"] = r
+        print("u32_cluster_compact_arcs", json.dumps(r), flush=True)
+        gc._dev = None; torch.cuda.empty_cache()
+    except Exception as e:           # noqa: BLE001
+        out["u32_cluster_compact_arcs"] = dict(error=repr(e)[:300])
     try:
         Ss = WfstSearch(g, BW.Opt, U=U, max_frames=T + 8, max_tokens=1 << 21, max_links=1 << 23, hash_size=1 << 18, prune_interval=25)
         lat = []

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host-side profile of Rescore() (b2t_lattice_rescore_nbest_host) on the 32 lattices tools/experimental/dump_lattice.py saved
+"""Host-side profile of Rescore() (b2t_lattice_rescore_nbest_host) on the 32 lattices attic/dump_lattice.py saved
 (gpurun_out/lattices.npz): time per utterance, product size, and the n-best lists for comparing two builds (B2T_LIB)."""
 import ctypes as C, os, sys, time
 import numpy as np
