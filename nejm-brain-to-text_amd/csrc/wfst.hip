@@ -397,6 +397,13 @@ __device__ void init_decoding(Ctx& c) {
   // the cluster search's scratch starts from zero whatever the caller's buffer held (its histograms are only re-zeroed AFTER a
   // frame's cut-off used them)
   for (int i = threadIdx.x; i < (int)(sizeof(Clu) / sizeof(int)); i += NT) reinterpret_cast<int*>(c.l.clu)[i] = 0;
+  // ... and from two EMPTY frame hashes: the cluster search stamps its slots with the frame (below) instead of clearing a hash
+  // per frame, so what an earlier utterance left in this state block must not look like a live entry of this one
+  {
+    unsigned long long* s0 = reinterpret_cast<unsigned long long*>(c.l.gkey);
+    unsigned long long* s1 = reinterpret_cast<unsigned long long*>(c.l.gkey2);
+    for (int i = threadIdx.x; i < c.hash; i += NT) { s0[i] = ~0ull; s1[i] = ~0ull; }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     Hdr* h = c.l.h;
@@ -597,6 +604,11 @@ struct CCtx {
   unsigned bar_target;
   float* ll; float* redf; int* redi; int* lsh;   // LDS: frame log-likelihoods, reduction scratch, [0] dead flag, [1..] scalars
   int* key; int* idx;                            // hash of the frame being built
+  // Frame-stamped slots (round 4): the key half of a slot is stamp << 27 | state, a slot whose stamp is not the current frame's
+  // reads as empty -- no hash is cleared per frame any more (0.42 GB of the 1.13 GB a 25-frame launch of 32 utterances wrote).
+  // Stamps 1 .. 30 cycle over a hash's uses (0 = zeroed memory, 31 = cleared marker: never live), so a hash is cleared once per
+  // 30 uses.  Needs states < 2^27; larger graphs (stamped = 0) clear per frame as before.
+  int stamped; unsigned stamp;
   int* stk_t; float* stk_c;                      // LDS: per-thread stack of the epsilon closure's chase ([CHASE_DEPTH][NT])
 };
 
@@ -718,6 +730,45 @@ __device__ __forceinline__ int cclaim(CCtx& c, int state) {
   const int mask = c.hash - 1;
   unsigned s = hash_of(state, mask);
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(c.key);
+  if (c.stamped) {
+    const unsigned want = (c.stamp << 27) | (unsigned)state;
+    for (int probe = 0; probe < c.hash; ++probe, s = (s + 1) & mask) {
+      unsigned long long v = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (;;) {
+        const unsigned k = (unsigned)(v & 0xffffffffull);
+        if ((k >> 27) != c.stamp) {               // not of this frame: empty.  ONE 64-bit CAS takes the slot and unsets the stale id with it
+          const unsigned long long mine = ((unsigned long long)(unsigned)UNSET << 32) | want;
+          if (__hip_atomic_compare_exchange_strong(&slots[s], &v, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            int id = wave_alloc(&c.cl->n_tok);
+            if (id < c.max_tok) {
+              c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = BEST_UNSET; c.l.tok_extra[id] = 0u;
+              if (c.g.n_eps[state] > 0) {
+                const int w = wave_alloc(&c.cl->wl_n);
+                if (w < WLG_CAP) c.l.wlg[w] = id; else atomicOr(&c.cl->overflow, 16);
+              }
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+              atomicOr(&c.cl->overflow, 1); id = -1;
+            }
+            __hip_atomic_store(reinterpret_cast<int*>(&slots[s]) + 1, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return id;
+          }
+          continue;                                 // lost the race: v holds what is there now, look at it again
+        }
+        if (k == want) {
+          int id = (int)(unsigned)(v >> 32), spins = 0;
+          while (id == UNSET) {
+            if (++spins > (1 << 24)) { atomicOr(&c.cl->overflow, 32); return -1; }
+            id = (int)(unsigned)(__hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+          }
+          return id;
+        }
+        break;                                      // another state of this frame: next slot
+      }
+    }
+    atomicOr(&c.cl->overflow, 4);
+    return -1;
+  }
   for (int probe = 0; probe < c.hash; ++probe, s = (s + 1) & mask) {
     unsigned long long v = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int k = (int)(unsigned)(v & 0xffffffffull);
@@ -895,7 +946,9 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
   cbest_links(c, fr.pl0, fr.pl1);
   CT(3)   // deferred best links
   int* nkey = npar ? c.l.gkey2 : c.l.gkey; int* nidx = nkey + c.hash;    // (key / idx arrays are adjacent: 8-byte slots)
-  {
+  const unsigned use = (unsigned)(f + 1) >> 1;     // how often this hash has been used before (frame f + 1 is built in hash (f + 1) & 1)
+  c.stamp = 1u + use % 30u;
+  if (!c.stamped || (c.stamp == 1u && use > 0u)) {   // stamped: only when the stamps wrap; InitDecoding left both hashes empty
     unsigned long long* ns = reinterpret_cast<unsigned long long*>(nkey);
     const unsigned long long empty = ((unsigned long long)(unsigned)UNSET << 32) | 0xffffffffull;
     for (int i = c.gtid; i < c.hash; i += c.gthreads) ns[i] = empty;
@@ -1037,7 +1090,7 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
 
 __global__ __launch_bounds__(NT) void wfst_cluster_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
                                                            int max_tok, int max_link, int hash, int G, int U,
-                                                           const float* __restrict__ logp, const int* __restrict__ lens, int T, int C) {
+                                                           const float* __restrict__ logp, const int* __restrict__ lens, int T, int C, int stamped) {
   __shared__ float ll[MAX_C], lastp[MAX_C], redf[NT];
   __shared__ int redi[NT], lsh[8], stk_t[CHASE_DEPTH * NT];
   __shared__ float stk_c[CHASE_DEPTH * NT];
@@ -1051,6 +1104,7 @@ __global__ __launch_bounds__(NT) void wfst_cluster_kernel(Graph g, char* state, 
   c.cl = c.l.clu; c.G = G; c.j = j; c.gtid = j * NT + (int)threadIdx.x; c.gthreads = G * NT;
   c.ll = ll; c.redf = redf; c.redi = redi; c.lsh = lsh; c.stk_t = stk_t; c.stk_c = stk_c;
   c.key = c.l.gkey; c.idx = c.l.gidx;
+  c.stamped = stamped; c.stamp = 0u;
   if (threadIdx.x < 8) lsh[threadIdx.x] = 0;
   if ((int)threadIdx.x < MAX_C) lastp[threadIdx.x] = c.l.last_prob[threadIdx.x];   // every member keeps its own copy of the remembered blank frame
   __syncthreads();
@@ -2062,8 +2116,10 @@ extern "C" int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opt
   // ~45 __syncthreads per frame: 55.4 against 63.1 ms for 256 utterances).
   if (G > 1 || wfst_forced_cluster() != 1) {
     const int grid = (U + 7) / 8 * 8 * G;
+    static const bool no_stamp = getenv("B2T_WFST_STAMPED") && atoi(getenv("B2T_WFST_STAMPED")) == 0;   // A/B knob: clear a hash per frame (round 3)
+    const int stamped = (!no_stamp && g->n_states < (1 << 27)) ? 1 : 0;
     hipLaunchKernelGGL(wfst_cluster_kernel, dim3(grid), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
-                       o->max_frames, o->max_tokens, o->max_links, o->hash_size, G, U, logp, lens, T, C);
+                       o->max_frames, o->max_tokens, o->max_links, o->hash_size, G, U, logp, lens, T, C, stamped);
     B2T_CHECK_LAUNCH("b2t_wfst_search_f32 (cluster)");
     return 0;
   }

@@ -25,7 +25,7 @@ for n, d in sorted(rows.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CY
     m = d.get("SQ_VALU_MFMA_BUSY_CYCLES", (1, 0, 1)); g = d.get("GRBM_GUI_ACTIVE", (1, 0, 1))
     per_launch, cyc = m[1] / max(1, m[2]), g[1] / max(1, g[0])
     out.append(f"| `{n[:80]}` | {m[2]} | {per_launch:.4g} | {cyc:.4g} | {per_launch / (cyc * 1024) if cyc else float('nan'):.3f} |")
-open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out/r3c_pmc_mfma.md"), "w").write("\n".join(out) + "\n")
+open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out/r4a_pmc_mfma.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
 PY
 tail -2 $OUT/pmc_mfma.log | cut -c1-200
