@@ -726,11 +726,12 @@ __device__ __forceinline__ int wave_alloc(int* counter) {
 // common case -- the token exists -- is a single L1-bypassing 8-byte load.  The CAS (on the state half) winner allocates the
 // token, writes its fields, waits until they are in L2 and only then publishes the id in the other half; everyone else polls
 // the word.  A new token whose state has epsilon arcs joins the work list.
+template <bool ST>   // ST: frame-stamped slots (compile-time: both claim paths in one kernel spilled 536 B per lane to scratch, 13.6 -> 21.7 ms)
 __device__ __forceinline__ int cclaim(CCtx& c, int state) {
   const int mask = c.hash - 1;
   unsigned s = hash_of(state, mask);
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(c.key);
-  if (c.stamped) {
+  if constexpr (ST) {
     const unsigned want = (c.stamp << 27) | (unsigned)state;
     for (int probe = 0; probe < c.hash; ++probe, s = (s + 1) & mask) {
       unsigned long long v = __hip_atomic_load(&slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -738,7 +739,10 @@ __device__ __forceinline__ int cclaim(CCtx& c, int state) {
         const unsigned k = (unsigned)(v & 0xffffffffull);
         if ((k >> 27) != c.stamp) {               // not of this frame: empty.  ONE 64-bit CAS takes the slot and unsets the stale id with it
           const unsigned long long mine = ((unsigned long long)(unsigned)UNSET << 32) | want;
-          if (__hip_atomic_compare_exchange_strong(&slots[s], &v, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          const unsigned long long seen = atomicCAS(&slots[s], v, mine);   // (the value-returning form: taking &v for the builtin's `expected` put the loop's state into scratch memory, 13.6 -> 21.7 ms)
+          const bool won = seen == v;
+          v = seen;
+          if (won) {
             int id = wave_alloc(&c.cl->n_tok);
             if (id < c.max_tok) {
               c.l.tok_state[id] = state; c.l.tok_cost[id] = UMAX; c.l.tok_best[id] = BEST_UNSET; c.l.tok_extra[id] = 0u;
@@ -818,6 +822,7 @@ __device__ __forceinline__ void cbest_links(CCtx& c, int l0, int l1) {
 struct CFrame { int f, t0, t1, pl0, pl1; };   // decoded frames so far, tokens of the newest frame, links awaiting best_links
 
 // One AdvanceDecoding(.., 1) by the whole cluster.  fr is cluster-uniform private state, updated on success.
+template <bool ST>
 __device__ bool cadvance(CCtx& c, CFrame& fr) {
   const Graph& g = c.g;
   Clu* cl = c.cl;
@@ -948,7 +953,7 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
   int* nkey = npar ? c.l.gkey2 : c.l.gkey; int* nidx = nkey + c.hash;    // (key / idx arrays are adjacent: 8-byte slots)
   const unsigned use = (unsigned)(f + 1) >> 1;     // how often this hash has been used before (frame f + 1 is built in hash (f + 1) & 1)
   c.stamp = 1u + use % 30u;
-  if (!c.stamped || (c.stamp == 1u && use > 0u)) {   // stamped: only when the stamps wrap; InitDecoding left both hashes empty
+  if (!ST || (c.stamp == 1u && use > 0u)) {   // stamped: only when the stamps wrap; InitDecoding left both hashes empty
     unsigned long long* ns = reinterpret_cast<unsigned long long*>(nkey);
     const unsigned long long empty = ((unsigned long long)(unsigned)UNSET << 32) | 0xffffffffull;
     for (int i = c.gtid; i < c.hash; i += c.gthreads) ns[i] = empty;
@@ -977,7 +982,7 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
     float ac, gc;
     const float tot = arc_cost(cur, s, a, ac, gc);
     if (!(tot < next_cutoff)) return;
-    const int id = cclaim(c, g.next[a]);
+    const int id = cclaim<ST>(c, g.next[a]);
     if (id < 0) return;
     const unsigned nb = f2o(tot);
     atomicMin(&c.l.tok_cost[id], nb);
@@ -1026,7 +1031,7 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
           if (tot < next_cutoff) {
             const int ns = g.next[a];
             const int nne = g.n_eps[ns];           // (in flight next to the claim's slot load)
-            const int id = cclaim(c, ns);
+            const int id = cclaim<ST>(c, ns);
             if (id < 0) continue;
             const unsigned nb = f2o(tot);
             const unsigned old = atomicMin(&c.l.tok_cost[id], nb);
@@ -1054,7 +1059,7 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
       for (int a = a0; a < a0 + ne; ++a) {
         const float tot = cur + g_w(g, a);
         if (tot < next_cutoff) {
-          const int id = cclaim(c, g.next[a]);      // exists: the closure has converged
+          const int id = cclaim<ST>(c, g.next[a]);      // exists: the closure has converged
           if (id < 0) continue;
           const int li = wave_alloc(&cl->n_link);
           if (li < c.max_link) {
@@ -1088,6 +1093,7 @@ __device__ bool cadvance(CCtx& c, CFrame& fr) {
 
 }  // namespace
 
+template <bool ST>
 __global__ __launch_bounds__(NT) void wfst_cluster_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
                                                            int max_tok, int max_link, int hash, int G, int U,
                                                            const float* __restrict__ logp, const int* __restrict__ lens, int T, int C, int stamped) {
@@ -1158,14 +1164,14 @@ __global__ __launch_bounds__(NT) void wfst_cluster_kernel(Graph g, char* state, 
       if ((int)threadIdx.x < C) ll[threadIdx.x] = o.acoustic_scale * lastp[threadIdx.x];
       if (c.gtid == 0 && fr.f < max_frames) c.l.mapping[fr.f] = num_input - 1;
       __syncthreads();
-      ok = cadvance(c, fr);
+      ok = cadvance<ST>(c, fr);
     }
     if (mode >= 1 && ok) {
       __syncthreads();
       if ((int)threadIdx.x < C) ll[threadIdx.x] = o.acoustic_scale * row[threadIdx.x];
       if (c.gtid == 0 && fr.f < max_frames) c.l.mapping[fr.f] = num_input;
       __syncthreads();
-      ok = cadvance(c, fr);
+      ok = cadvance<ST>(c, fr);
       is_last_blank = 0;
     }
     num_input += 1;
@@ -2118,8 +2124,12 @@ extern "C" int b2t_wfst_search_f32(const b2t_wfst_graph_t* g, const b2t_wfst_opt
     const int grid = (U + 7) / 8 * 8 * G;
     static const bool no_stamp = getenv("B2T_WFST_STAMPED") && atoi(getenv("B2T_WFST_STAMPED")) == 0;   // A/B knob: clear a hash per frame (round 3)
     const int stamped = (!no_stamp && g->n_states < (1 << 27)) ? 1 : 0;
-    hipLaunchKernelGGL(wfst_cluster_kernel, dim3(grid), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
-                       o->max_frames, o->max_tokens, o->max_links, o->hash_size, G, U, logp, lens, T, C, stamped);
+    if (stamped)
+      hipLaunchKernelGGL(wfst_cluster_kernel<true>, dim3(grid), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                         o->max_frames, o->max_tokens, o->max_links, o->hash_size, G, U, logp, lens, T, C, stamped);
+    else
+      hipLaunchKernelGGL(wfst_cluster_kernel<false>, dim3(grid), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                         o->max_frames, o->max_tokens, o->max_links, o->hash_size, G, U, logp, lens, T, C, stamped);
     B2T_CHECK_LAUNCH("b2t_wfst_search_f32 (cluster)");
     return 0;
   }
