@@ -25,6 +25,11 @@
 #ifndef B2T_LOC_ST_AUX
 #define B2T_LOC_ST_AUX 16   // payload stores under the XCD-local hand-off: 16 write-through (L2 keeps a clean copy for the peers; ordinary stores, 0, left 1.3 GB of dirty dG per step in the L2s and cost the GEMMs 0.3-1 ms)
 #endif
+#ifndef B2T_BF16_WIDE_1PERCU
+// bf16 32-unit forward sweeps from this many 16-wide K chunks per wave on (H >= 64 * that) are compiled for ONE workgroup per CU:
+// at H = 768 the kernel needs ~272 registers and two per CU (256) spilled 13 of them to scratch inside the step loop
+#define B2T_BF16_WIDE_1PERCU 12
+#endif
 #ifndef B2T_LOAD_AUX
 #define B2T_LOAD_AUX 16   // cache policy of the operand loads: 16 = sc1 (never served from this XCD's L2), 0 = ordinary
 #endif
@@ -37,7 +42,7 @@ namespace b2t {
 // NT: 16-unit tiles per workgroup (1, or 2 with bf16 operands, whose weight slice is half the registers): 32 units per
 // workgroup halve the workgroups of a sweep -- five concurrent sweeps then crowd the CUs half as much.
 template <int NCH, bool BF16, int NT = 1, bool LOC = false>  // NCH: 16-wide K chunks per wave (H <= 64*NCH); LOC: XCD-local hand-off
-__global__ __launch_bounds__(256, (NT == 2 ? (BF16 ? 2 : 1) : (NCH <= 8 ? 3 : 1))) void gru_persist_fwd_kernel(const float* __restrict__ gi,
+__global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERCU) ? 2 : 1) : (NCH <= 8 ? 3 : 1))) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
                                                                  const float* __restrict__ h_init, float* out,
