@@ -282,6 +282,7 @@ def gru_mode_for(B: int, H: int) -> int:
 GRU_BF16 = 0x100   # B2T_GRU_BF16 (include/b2t.h): bf16 operands of the recurrent product, persistent mode 1
 GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup
 GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
+GRU_PARITY = 0x800  # B2T_GRU_PARITY: with GRU_LOCAL, the layer's parity (which XCDs its row groups use)
 # which sweeps (exact fp32 or bf16 operands, H <= 512) hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
 # traffic of a backward sweep launch 660 -> 227 MB (1.38x its algorithmic bytes), forward 179 -> 112 MB, a backward launch
 # 935 -> 810-830 us, the step -0.1 ms on two boxes (with WRITE-THROUGH payload stores; ordinary stores cost the GEMMs 0.3-1 ms).

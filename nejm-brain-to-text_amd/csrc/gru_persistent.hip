@@ -41,7 +41,7 @@ namespace b2t {
 // ---------------------------------------------------------------------------------------------------
 // NT: 16-unit tiles per workgroup (1, or 2 with bf16 operands, whose weight slice is half the registers): 32 units per
 // workgroup halve the workgroups of a sweep -- five concurrent sweeps then crowd the CUs half as much.
-template <int NCH, bool BF16, int NT = 1, bool LOC = false>  // NCH: 16-wide K chunks per wave (H <= 64*NCH); LOC: XCD-local hand-off
+template <int NCH, bool BF16, int NT = 1, bool LOC = false, bool RING = false>  // NCH: 16-wide K chunks per wave (H <= 64*NCH); LOC: XCD-local hand-off; RING: bf16 fragment hand-off (BF16, NT = 2)
 __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERCU) ? 2 : 1) : (NCH <= 8 ? 3 : 1))) void gru_persist_fwd_kernel(const float* __restrict__ gi,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ b_hh,
@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERC
   constexpr int TPN = 16 * NT + 4;    // LDS pitch of the staged tile (= TP for one tile)
   __shared__ __attribute__((aligned(16))) float red[4 * 3 * NT * 4 * 64 + 16 * TPN];
   constexpr int NSLOT_F = NCH < 8 ? NCH : 8;   // staging slots per wave, recycled every NSLOT_F instructions (as in the backward sweep)
-  __shared__ __attribute__((aligned(16))) float stage[4][NSLOT_F * SLOT_F];   // per-wave operand staging (gru_sync.h)
+  constexpr bool H16 = RING && BF16 && NT == 2;   // hand-off as bf16 MFMA fragments through the ring (gru_sync.h): no staging
+  __shared__ __attribute__((aligned(16))) float stage[H16 ? 1 : 4][H16 ? 4 : NSLOT_F * SLOT_F];   // per-wave operand staging (gru_sync.h)
   float* hs = red + 4 * 3 * NT * 4 * 64;   // staged h tile [16 rows][TPN]
   constexpr int AUX = LOC ? B2T_LOC_ST_AUX : 16;   // sc1 payload stores (device scope); under the XCD-local hand-off see B2T_LOC_ST_AUX
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,6 +101,13 @@ __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERC
   float hp[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) hp[n] = live ? h_init[(long long)row * H + unit[n]] : 0.f;
+  char* const ring = ring_base(sync);
+  const unsigned ngrp = (unsigned)(B + 15) / 16u;
+  const unsigned step_bytes = ngrp * G * 1024u, depth = ring_depth(step_bytes, T);   // (gru_sync.h: one slot per step when the call fits)
+  if constexpr (H16) {   // rows beyond the batch are never written: the ring must still carry finite numbers for them
+    for (int i = tid; i < 16 * TPN; i += 256) hs[i] = 0.f;
+    __syncthreads();
+  }
 
 #ifdef B2T_TIMING
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -130,6 +138,43 @@ __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERC
     f32x4 acc[3 * NT];   // [gate][tile]
 #pragma unroll
     for (int g = 0; g < 3 * NT; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (H16) {
+      if (t == 0) {
+        // the call's first step: h_init is fp32 [B][H]; fragments read directly (4 lanes per row: the slow pattern, once per call)
+        const int rj = m0 + j < B ? m0 + j : B - 1;
+#pragma unroll
+        for (int ci = 0; ci < NCH; ++ci) {
+          const int c = KCHUNK(wave, ci, NCH);
+          const float4 f = *reinterpret_cast<const float4*>(h_init + (long long)rj * H + (c < nch ? c : nch - 1) * 16 + 4 * q);
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[g * NT + n] = mfma_chunk16<true>(f, w[g][n][ci], acc[g * NT + n]);
+        }
+      } else {
+        const unsigned base = ((unsigned)(t - 1) % depth) * step_bytes + (unsigned)rg * G * 1024u + (unsigned)lane * 16u;
+        u32x4 v[NCH / 2];
+#pragma unroll
+        for (int p = 0; p < NCH / 2; ++p) {   // pairs beyond the operand meet zero weights: clamped to real (finite) data
+          const unsigned pair = (unsigned)(wave * (NCH / 2) + p);
+          v[p] = load_u4<LOC ? 0 : B2T_LOAD_AUX>(ring, base + (pair < G ? pair : G - 1u) * 1024u);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all loads are in flight before the first MFMA
+#pragma unroll
+        for (int p = 0; p < NCH / 2; ++p) {
+          const bf16x4 a0 = frag_lo(v[p]), a1 = frag_hi(v[p]);
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              if constexpr (BF16) {
+                acc[g * NT + n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, w[g][n][2 * p], acc[g * NT + n], 0, 0, 0);
+                acc[g * NT + n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, w[g][n][2 * p + 1], acc[g * NT + n], 0, 0, 0);
+              }
+            }
+        }
+      }
+    } else {
     // All loads go out first (branch-free, clamped: a conditional load makes the compiler wait for everything), then
     // each pair is transposed and consumed as it lands (vmcnt(6), vmcnt(4), ...).
     float4 v[NCH];
@@ -151,6 +196,7 @@ __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERC
 #pragma unroll
           for (int n = 0; n < NT; ++n) acc[g * NT + n] = mfma_chunk16<BF16>(a[h2], w[g][n][ci], acc[g * NT + n]);
       }
+    }
     }
     asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]));
     TSTAMP(1)   // loads + MFMA
@@ -178,6 +224,12 @@ __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERC
     __syncthreads();                       // tile staged; also fences `red` for the next iteration
     TSTAMP(4)   // stage barrier (waits for the slowest wave's gates)
     if (wave == 0) {                       // one wave writes the 16x16 tile as 64 x 16 B write-through stores
+      if constexpr (H16) {   // the peers read the ring: the tile as one pair of bf16 fragments (1 KB), published before the fp32 tile is stored
+        const float4 c0 = *reinterpret_cast<const float4*>(&hs[j * TPN + 4 * q]), c1 = *reinterpret_cast<const float4*>(&hs[j * TPN + 16 + 4 * q]);
+        store_u4<AUX>(ring, ((unsigned)t % depth) * step_bytes + ((unsigned)rg * G + (unsigned)tile) * 1024u + (unsigned)lane * 16u, pack_frag_pair(c0, c1));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) { if constexpr (LOC) l2_atomic_inc(cnt + (size_t)t * CSTRIDE); else __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT); }
+      }
       const int r = lane >> 2;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -186,8 +238,10 @@ __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERC
           store_f4<AUX>(out + (long long)t * B * H, (unsigned)(((long long)(m0 + r) * H + j0 + c4) * 4),
                        *reinterpret_cast<const float4*>(&hs[r * TPN + c4]));
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) { if constexpr (LOC) l2_atomic_inc(cnt + (size_t)t * CSTRIDE); else __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT); }
+      if constexpr (!H16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) { if constexpr (LOC) l2_atomic_inc(cnt + (size_t)t * CSTRIDE); else __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT); }
+      }
     }
     // The gate values saved for the backward sweep are nobody's dependency inside this sweep: store them AFTER the
     // publish so their write acknowledgements are not part of the drain in front of the counter increment.
@@ -392,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gru_persist_fwd_fused_kernel(const flo
 #ifdef B2T_TIMING
 __device__ unsigned g_bwd_t[3][512];   // timing build: per workgroup (rg * G + tile) of the LAST backward launch: start, first hand-off received, end (100 MHz wall clock, low word)
 #endif
-template <int NCB, bool BF16, int NT = 1, bool LOC = false>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB)
+template <int NCB, bool BF16, int NT = 1, bool LOC = false, bool RING = false>  // NCB: 16-wide chunks of the 3H contraction per wave (3H <= 64*NCB); RING: bf16 fragment hand-off (BF16, NT = 2)
 __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __restrict__ dY,
                                                                  const float* __restrict__ dh_last,
                                                                  const float* __restrict__ reserve,
@@ -404,7 +458,8 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   constexpr int TPN = 16 * NT + 4;
   __shared__ __attribute__((aligned(16))) float red[4 * NT * 4 * 64 + 4 * 16 * TPN];
   constexpr int NSLOT = NCB < 8 ? NCB : 8;   // staging slots per wave, recycled every NSLOT instructions
-  __shared__ __attribute__((aligned(16))) float stage[4][NSLOT * SLOT_F];
+  constexpr bool H16 = RING && BF16 && NT == 2;   // hand-off as bf16 MFMA fragments through the ring (gru_sync.h): no staging
+  __shared__ __attribute__((aligned(16))) float stage[H16 ? 1 : 4][H16 ? 4 : NSLOT * SLOT_F];
   float* gs = red + 4 * NT * 4 * 64;   // staged gate-gradient tiles [4 arrays][16 rows][TPN]
   constexpr int AUX = LOC ? B2T_LOC_ST_AUX : 16;   // sc1 payload stores (device scope); under the XCD-local hand-off see B2T_LOC_ST_AUX
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -452,6 +507,14 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
   float dzterm[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) dzterm[n] = 0.f;
+  char* const ring = ring_base(sync);
+  const unsigned ngrp = (unsigned)(B + 15) / 16u;
+  const unsigned npair = 3u * G;   // chunk pairs of the 3H-long contraction (a 32-unit tile of one gate is one pair)
+  const unsigned step_bytes = ngrp * npair * 1024u, depth = ring_depth(step_bytes, T);   // (gru_sync.h: one slot per step when the call fits)
+  if constexpr (H16) {   // rows beyond the batch are never written: the ring must still carry finite numbers for them
+    for (int i = tid; i < 4 * 16 * TPN; i += 256) gs[i] = 0.f;
+    __syncthreads();
+  }
 
 #ifdef B2T_TIMING
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -484,6 +547,27 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       f32x4 acc[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (H16) {
+        const unsigned base = ((unsigned)(t + 1) % depth) * step_bytes + (unsigned)rg * npair * 1024u + (unsigned)lane * 16u;
+        u32x4 v[NCB / 2];
+#pragma unroll
+        for (int p = 0; p < NCB / 2; ++p) {   // pairs beyond the operand meet zero weights: clamped to real (finite) data
+          const unsigned pair = (unsigned)(wave * (NCB / 2) + p);
+          v[p] = load_u4<LOC ? 0 : B2T_LOAD_AUX>(ring, base + (pair < npair ? pair : npair - 1u) * 1024u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < NCB / 2; ++p) {
+          const bf16x4 a0 = frag_lo(v[p]), a1 = frag_hi(v[p]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if constexpr (BF16) {
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, w[n][2 * p], acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, w[n][2 * p + 1], acc[n], 0, 0, 0);
+            }
+          }
+        }
+      } else {
       float4 v[NCB];
       issue_block_loads<NCB, LOC ? 0 : B2T_LOAD_AUX>(v, dgh, m0, B, 4 * H, wave * NCB * 16, 3 * H, lane);
       __builtin_amdgcn_sched_barrier(0);
@@ -497,6 +581,7 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
 #pragma unroll
           for (int n = 0; n < NT; ++n) acc[n] = mfma_chunk16<BF16>(a[h2], w[n][ci], acc[n]);
         }
+      }
       }
       asm volatile("s_nop 0" :: "v"(acc[0][0]));
       TSTAMP(2)   // loads + MFMA
@@ -536,6 +621,18 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
     TSTAMP(4)   // gate gradients (waits for the prefetched operands)
     __syncthreads();
     TSTAMP(5)   // stage barrier
+    if constexpr (H16) {
+      // the peers read the ring: wave w < 3 stores gate array w of the tile as one pair of bf16 fragments (1 KB); the counter
+      // moves as soon as these are acknowledged, the fp32 tile (for the GEMMs) follows unwaited
+      if (wave < 3) {
+        const float4 c0 = *reinterpret_cast<const float4*>(&gs[(wave * 16 + j) * TPN + 4 * q]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&gs[(wave * 16 + j) * TPN + 16 + 4 * q]);
+        store_u4<AUX>(ring, ((unsigned)t % depth) * step_bytes + ((unsigned)rg * npair + (unsigned)wave * G + (unsigned)tile) * 1024u + (unsigned)lane * 16u,
+                      pack_frag_pair(c0, c1));
+      }
+      if constexpr (LOC) publish_count_local(cnt + (size_t)t * CSTRIDE);
+      else publish_count(cnt + (size_t)t * CSTRIDE);
+    }
     {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores per 16-unit tile
       const int r2 = lane >> 2;
 #pragma unroll
@@ -547,8 +644,10 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
                        *reinterpret_cast<const float4*>(&gs[(wave * 16 + r2) * TPN + c4]));
       }
     }
-    if constexpr (LOC) publish_count_local(cnt + (size_t)t * CSTRIDE);
-    else publish_count(cnt + (size_t)t * CSTRIDE);
+    if constexpr (!H16) {
+      if constexpr (LOC) publish_count_local(cnt + (size_t)t * CSTRIDE);
+      else publish_count(cnt + (size_t)t * CSTRIDE);
+    }
     TSTAMP(6)   // tile store + drain + publish
    }
   }
@@ -568,7 +667,7 @@ extern "C" int b2t_debug_bwd_times(unsigned* host) {
 namespace b2t {
 #endif
 
-size_t gru_persistent_sync_bytes(int T) { (void)T; return ((size_t)2 * SETW + 64) * sizeof(unsigned); }
+size_t gru_persistent_sync_bytes(int T) { (void)T; return SYNC_WORDS * sizeof(unsigned) + RING_BYTES; }   // counters, then the bf16 hand-off ring
 
 static int cu_count() {
   static int n = -1;
@@ -650,6 +749,13 @@ static int local_max_h(bool bf16, bool wide) {
   return (bf16 && wide) ? std::max(512, std::min(env, 1024)) : 512;
 }
 
+// bf16 sweeps with 32-unit workgroups hand their tiles over as bf16 MFMA fragments (gru_sync.h); B2T_HANDOFF16=0 (read per call:
+// the tests compare the two forms in one process) selects the fp32 tiles every consumer transposes and rounds itself
+static bool ring_handoff() {
+  const char* e = getenv("B2T_HANDOFF16");
+  return B2T_HANDOFF16 && !(e && e[0] == '0');
+}
+
 int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_init, float* out,
                        float* reserve, int T, int B, int H, void* sync_ws, hipStream_t s, bool bf16,
                        bool wide, int local) {
@@ -663,28 +769,28 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
-#define B2T_FWD_GO(NCH, BF, NTT)                                                                                       \
+#define B2T_FWD_GO(NCH, BF, NTT, RG)                                                                                   \
   do {                                                                                                                 \
     bool launched = false;                                                                                             \
     {                                                                                                                  \
       if (loc) {                                                                                                       \
-        hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, BF, NTT, true>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, \
+        hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, BF, NTT, true, RG>), grid, block, 0, s, gi, w_hh, b_hh, h_init, out, reserve, T, B, \
                            H, sync, par);                                                                              \
         launched = true;                                                                                               \
       }                                                                                                                \
     }                                                                                                                  \
     if (!launched) {                                                                                                   \
-      want_exclusive(gru_persist_fwd_kernel<NCH, BF, NTT, false>);                                                     \
-      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, BF, NTT, false>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, \
+      want_exclusive(gru_persist_fwd_kernel<NCH, BF, NTT, false, RG>);                                                 \
+      hipLaunchKernelGGL((gru_persist_fwd_kernel<NCH, BF, NTT, false, RG>), grid, block, exclusive_lds(), s, gi, w_hh, b_hh, h_init, out, reserve, \
                          T, B, H, sync, par);                                                                          \
     }                                                                                                                  \
   } while (0)
 #define B2T_LAUNCH_FWD(NCH)                                                                                            \
   do {                                                                                                                 \
-    if (bf16 && wide) B2T_FWD_GO(NCH, true, 2);                                                                        \
-    else if (wide) { if constexpr (NCH <= 8) B2T_FWD_GO(NCH, false, 2); }                                              \
-    else if (bf16) B2T_FWD_GO(NCH, true, 1);                                                                           \
-    else B2T_FWD_GO(NCH, false, 1);                                                                                    \
+    if (bf16 && wide) { if (ring_handoff()) B2T_FWD_GO(NCH, true, 2, true); else B2T_FWD_GO(NCH, true, 2, false); }    \
+    else if (wide) { if constexpr (NCH <= 8) B2T_FWD_GO(NCH, false, 2, false); }                                       \
+    else if (bf16) B2T_FWD_GO(NCH, true, 1, false);                                                                    \
+    else B2T_FWD_GO(NCH, false, 1, false);                                                                             \
   } while (0)
   if (H <= 128) B2T_LAUNCH_FWD(2);
   else if (H <= 256) B2T_LAUNCH_FWD(4);
@@ -733,28 +839,28 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
-#define B2T_BWD_GO(NCB, BF, NTT)                                                                                       \
+#define B2T_BWD_GO(NCB, BF, NTT, RG)                                                                                   \
   do {                                                                                                                 \
     bool launched = false;                                                                                             \
     {                                                                                                                  \
       if (loc) {                                                                                                       \
-        hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, BF, NTT, true>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG, \
+        hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, BF, NTT, true, RG>), grid, block, 0, s, dY, dh_last, reserve, out, h_init, w_hh_t, dG, \
                            dh_init, T, B, H, sync, par);                                                               \
         launched = true;                                                                                               \
       }                                                                                                                \
     }                                                                                                                  \
     if (!launched) {                                                                                                   \
-      want_exclusive(gru_persist_bwd_kernel<NCB, BF, NTT, false>);                                                     \
-      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, BF, NTT, false>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
+      want_exclusive(gru_persist_bwd_kernel<NCB, BF, NTT, false, RG>);                                                 \
+      hipLaunchKernelGGL((gru_persist_bwd_kernel<NCB, BF, NTT, false, RG>), grid, block, exclusive_lds(), s, dY, dh_last, reserve, out, h_init, \
                          w_hh_t, dG, dh_init, T, B, H, sync, par);                                                     \
     }                                                                                                                  \
   } while (0)
 #define B2T_LAUNCH_BWD(NCB)                                                                                            \
   do {                                                                                                                 \
-    if (bf16 && wide) B2T_BWD_GO(NCB, true, 2);                                                                        \
-    else if (wide) { if constexpr (NCB <= 24) B2T_BWD_GO(NCB, false, 2); }                                             \
-    else if (bf16) B2T_BWD_GO(NCB, true, 1);                                                                           \
-    else B2T_BWD_GO(NCB, false, 1);                                                                                    \
+    if (bf16 && wide) { if (ring_handoff()) B2T_BWD_GO(NCB, true, 2, true); else B2T_BWD_GO(NCB, true, 2, false); }    \
+    else if (wide) { if constexpr (NCB <= 24) B2T_BWD_GO(NCB, false, 2, false); }                                      \
+    else if (bf16) B2T_BWD_GO(NCB, true, 1, false);                                                                    \
+    else B2T_BWD_GO(NCB, false, 1, false);                                                                             \
   } while (0)
   if (H <= 128) B2T_LAUNCH_BWD(6);
   else if (H <= 256) B2T_LAUNCH_BWD(12);

@@ -205,6 +205,52 @@ __device__ __forceinline__ f32x4 mfma_chunk16(float4 a, typename WFrag<BF16>::ty
   }
 }
 
+// ---- bf16 hand-off ring (round 4; sweeps with bf16 operands and 32-unit workgroups) --------------------------------
+// With bf16 operands the peers of a row group need a step's tile only as MFMA A fragments of v_mfma_f32_16x16x16_bf16: lane
+// (j, q) holds 4 consecutive k of row j as 4 bf16.  The fp32 hand-off made every consumer load 16 B per lane line-wise, transpose
+// each pair of loads through LDS and round to bf16 (98 KB per workgroup and step in the backward sweep at H = 512, two
+// workgroups per CU: ~3 k cycles of a CU's L2 read port).  So the PRODUCER rounds its tile once and stores it in fragment
+// order: per (ring slot, row group, chunk PAIR) 64 lanes x 16 B = {4 bf16 of chunk 2p, 4 bf16 of chunk 2p + 1} -- one 1 KB
+// contiguous store per pair; a consumer wave loads one pair per instruction (1 KB contiguous) straight into the registers the
+// MFMA reads: half the bytes, no transpose, no conversion.  The values are the ones the consumers rounded before (same
+// nearest-even rounding of the same fp32 numbers): results are bit-identical.  The fp32 tile is still written for the GEMMs
+// and the other pass, but AFTER the counter increment: it is nobody's dependency inside the sweep any more.
+// The tiles of the call's steps go to slots of a buffer behind the counter sets in the sync workspace (RING_BYTES).  A call
+// whose steps all fit -- every call of the training plans: 24.6 MB for a 125-step backward chunk at B = 64, H = 512 -- uses
+// every address ONCE, which is what the XCD-local hand-off's ordinary loads need (they may hit the CU's vector cache, and that
+// is invalidated at kernel start only; buffer_inv sc1 per step also drops the L2's lines: measured 10.5 -> 18.3 ms per step).
+// Longer calls wrap around (slot = t mod depth, depth = RING_BYTES / bytes per step >= 42): safe for the counters' protocol
+// from depth 3 on (a workgroup that writes step t has seen all peers publish the neighbouring step, i.e. consume the tiles two
+// steps away), and between two uses of a slot a CU streams >= 42 steps x 16-144 KB of tiles through its 32 KB vector cache;
+// the device-scope loads (sc1) never hit that cache anyway.
+#ifndef B2T_HANDOFF16
+#define B2T_HANDOFF16 1
+#endif
+constexpr size_t RING_BYTES = (size_t)32 << 20;   // >= 42 steps of the largest sweep (3 x 256 pairs of 1 KB per step)
+__device__ __forceinline__ unsigned ring_depth(unsigned step_bytes, int T) {
+  const unsigned fit = (unsigned)(RING_BYTES / step_bytes);
+  return fit < (unsigned)T ? fit : (unsigned)T;
+}
+constexpr size_t SYNC_WORDS = (size_t)2 * SETW + 64;
+using u32x2 = unsigned int __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ char* ring_base(unsigned* sync) { return reinterpret_cast<char*>(sync + SYNC_WORDS); }
+template <int AUX>
+__device__ __forceinline__ u32x4 load_u4(const char* base_uniform, unsigned byte_off) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base_uniform), 0, 0x7fffffff, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void store_u4(char* base_uniform, unsigned byte_off, u32x4 v) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, AUX);
+}
+__device__ __forceinline__ u32x4 pack_frag_pair(float4 c0, float4 c1) {   // {4 bf16 of chunk 2p, 4 bf16 of chunk 2p + 1}
+  const u32x2 a = __builtin_bit_cast(u32x2, to_bf16x4(c0)), b = __builtin_bit_cast(u32x2, to_bf16x4(c1));
+  return u32x4{a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ bf16x4 frag_lo(u32x4 v) { return __builtin_bit_cast(bf16x4, u32x2{v.x, v.y}); }
+__device__ __forceinline__ bf16x4 frag_hi(u32x4 v) { return __builtin_bit_cast(bf16x4, u32x2{v.z, v.w}); }
+
 constexpr int TP = 20;  // LDS pitch (floats) of a staged 16x16 tile: 16-byte aligned rows, conflict-light
 
 

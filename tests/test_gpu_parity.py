@@ -120,7 +120,7 @@ def test_gemm_bf16(akc, bkc, M, N, K):
         ops.set_amp(old)
 
 
-@pytest.mark.parametrize("B,H,T,wide", [(17, 80, 9, 0), (64, 512, 12, 0), (40, 768, 6, 0), (64, 512, 12, 1), (23, 96, 7, 1), (40, 768, 6, 1), (64, 768, 20, 1)])
+@pytest.mark.parametrize("B,H,T,wide", [(17, 80, 9, 0), (64, 512, 12, 0), (40, 768, 6, 0), (64, 512, 12, 1), (23, 96, 7, 1), (40, 768, 6, 1), (64, 768, 20, 1), (64, 512, 180, 1)])
 def test_persistent_sweep_bf16_operands(B, H, T, wide):
     """mode 1 | B2T_GRU_BF16: the recurrent products round their operands (h_{t-1} / dG_{t+1} and the W_hh slice) to bf16
     and accumulate in fp32.  Reference: the same recurrences in numpy with the operands rounded explicitly."""
@@ -174,6 +174,41 @@ def test_persistent_sweep_bf16_operands(B, H, T, wide):
     out32 = torch.zeros(T + 1, B, H, device=dev); out32[0] = h0
     Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out32[0]), p(out32[1:]), None, None, T, B, H, 1, p(sync), ops._stream()), "fwd32")
     assert float((out32 - out).abs().max()) > 1e-5
+    if wide:
+        # The 32-unit workgroups hand their tiles over as bf16 MFMA fragments through the buffer behind the counters
+        # (gru_sync.h); with B2T_HANDOFF16=0 as fp32 tiles that every consumer transposes and rounds itself: the same roundings of
+        # the same numbers, the same split of the contraction over the waves -- bit-identical results.
+        import os
+        old_env = os.environ.get("B2T_HANDOFF16")
+        os.environ["B2T_HANDOFF16"] = "0"
+        try:
+            out_n = torch.zeros(T + 1, B, H, device=dev); out_n[0] = h0
+            resv_n = torch.zeros(T, B, 4 * H, device=dev)
+            Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out_n[0]), p(out_n[1:]), p(resv_n), None, T, B, H,
+                                               1 | ops.GRU_BF16 | ops.GRU_WIDE, p(sync), ops._stream()), "fwd fp32 tiles")
+            dG_n = torch.zeros(T, B, 4 * H, device=dev); dh_n = torch.zeros(B, H, device=dev)
+            Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(resv_n), p(out_n[1:]), p(out_n[0]), p(wt), p(dG_n), p(dh_n), p(sc), T, B, H,
+                                               1 | ops.GRU_BF16 | ops.GRU_WIDE, p(sync), ops._stream()), "bwd fp32 tiles")
+            torch.cuda.synchronize()
+        finally:
+            if old_env is None: os.environ.pop("B2T_HANDOFF16", None)
+            else: os.environ["B2T_HANDOFF16"] = old_env
+        assert int(sync[0]) == 0
+        assert torch.equal(out, out_n) and torch.equal(resv, resv_n)
+        assert torch.equal(dG, dG_n) and torch.equal(dh, dh_n)
+        # ... and under the XCD-local hand-off (ordinary loads of the fragments; both layer parities).  (64, 512, 180): the backward
+        # call's 180 steps of 192 KB exceed the buffer, its slots wrap around after 170.
+        for extra in (ops.GRU_LOCAL, ops.GRU_LOCAL | ops.GRU_PARITY):
+            out_l = torch.zeros(T + 1, B, H, device=dev); out_l[0] = h0
+            resv_l = torch.zeros(T, B, 4 * H, device=dev)
+            Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out_l[0]), p(out_l[1:]), p(resv_l), None, T, B, H,
+                                               1 | ops.GRU_BF16 | ops.GRU_WIDE | extra, p(sync), ops._stream()), "fwd local")
+            dG_l = torch.zeros(T, B, 4 * H, device=dev); dh_l = torch.zeros(B, H, device=dev)
+            Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(resv_l), p(out_l[1:]), p(out_l[0]), p(wt), p(dG_l), p(dh_l), p(sc), T, B, H,
+                                               1 | ops.GRU_BF16 | ops.GRU_WIDE | extra, p(sync), ops._stream()), "bwd local")
+            torch.cuda.synchronize()
+            assert int(sync[0]) == 0
+            assert torch.equal(out, out_l) and torch.equal(dG, dG_l) and torch.equal(dh, dh_l)
 
 
 def test_train_step_bf16_matmuls_track_fp32():
