@@ -30,6 +30,9 @@
 // at H = 768 the kernel needs ~272 registers and two per CU (256) spilled 13 of them to scratch inside the step loop
 #define B2T_BF16_WIDE_1PERCU 12
 #endif
+#ifndef B2T_LOC_RING_AUX
+#define B2T_LOC_RING_AUX 16   // the bf16 fragment tiles under the XCD-local hand-off: 16 write-through, 0 ordinary stores (dirty lines in that XCD's L2; 25 MB per call)
+#endif
 #ifndef B2T_LOAD_AUX
 #define B2T_LOAD_AUX 16   // cache policy of the operand loads: 16 = sc1 (never served from this XCD's L2), 0 = ordinary
 #endif
@@ -226,10 +229,14 @@ __global__ __launch_bounds__(256, (NT == 2 ? ((BF16 && NCH < B2T_BF16_WIDE_1PERC
     if (wave == 0) {                       // one wave writes the 16x16 tile as 64 x 16 B write-through stores
       if constexpr (H16) {   // the peers read the ring: the tile as one pair of bf16 fragments (1 KB), published before the fp32 tile is stored
         const float4 c0 = *reinterpret_cast<const float4*>(&hs[j * TPN + 4 * q]), c1 = *reinterpret_cast<const float4*>(&hs[j * TPN + 16 + 4 * q]);
-        store_u4<AUX>(ring, ((unsigned)t % depth) * step_bytes + ((unsigned)rg * G + (unsigned)tile) * 1024u + (unsigned)lane * 16u, pack_frag_pair(c0, c1));
+        store_u4<(LOC ? B2T_LOC_RING_AUX : 16)>(ring, ((unsigned)t % depth) * step_bytes + ((unsigned)rg * G + (unsigned)tile) * 1024u + (unsigned)lane * 16u, pack_frag_pair(c0, c1));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) { if constexpr (LOC) l2_atomic_inc(cnt + (size_t)t * CSTRIDE); else __hip_atomic_fetch_add(cnt + (size_t)t * CSTRIDE, 1u, RLX_AGENT); }
       }
+    }
+    // (with the fragment hand-off the fp32 tile is nobody's dependency inside the sweep: ANOTHER wave stores it -- the next
+    //  step's poll is wave 0's, and its returning atomic waits for every store the wave has in flight)
+    if (wave == (H16 ? 1 : 0)) {
       const int r = lane >> 2;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -627,13 +634,26 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
       if (wave < 3) {
         const float4 c0 = *reinterpret_cast<const float4*>(&gs[(wave * 16 + j) * TPN + 4 * q]);
         const float4 c1 = *reinterpret_cast<const float4*>(&gs[(wave * 16 + j) * TPN + 16 + 4 * q]);
-        store_u4<AUX>(ring, ((unsigned)t % depth) * step_bytes + ((unsigned)rg * npair + (unsigned)wave * G + (unsigned)tile) * 1024u + (unsigned)lane * 16u,
+        store_u4<(LOC ? B2T_LOC_RING_AUX : 16)>(ring, ((unsigned)t % depth) * step_bytes + ((unsigned)rg * npair + (unsigned)wave * G + (unsigned)tile) * 1024u + (unsigned)lane * 16u,
                       pack_frag_pair(c0, c1));
       }
       if constexpr (LOC) publish_count_local(cnt + (size_t)t * CSTRIDE);
       else publish_count(cnt + (size_t)t * CSTRIDE);
     }
-    {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores per 16-unit tile
+    if constexpr (H16) {
+      // the fp32 tiles (4 gate arrays x NT 16-unit tiles) by waves 1-3: wave 0 polls the next step's counter, and its returning
+      // atomic waits for every store the wave has in flight
+      const int r2 = lane >> 2;
+      if (wave > 0 && m0 + r2 < B) {
+#pragma unroll
+        for (int idx = 0; idx < 4 * NT; ++idx) {
+          if (idx % 3 != wave - 1) continue;
+          const int ga = idx / NT, c4 = 16 * (idx % NT) + (lane & 3) * 4;
+          store_f4<AUX>(dG + (long long)t * B * 4 * H, (unsigned)(((long long)(m0 + r2) * 4 * H + ga * H + j0 + c4) * 4),
+                       *reinterpret_cast<const float4*>(&gs[(ga * 16 + r2) * TPN + c4]));
+        }
+      }
+    } else {   // wave w writes gate array w of the tile: 64 x 16 B write-through stores per 16-unit tile
       const int r2 = lane >> 2;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
