@@ -110,6 +110,9 @@ int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_bytes, void* 
 /* ---- elementwise helpers ------------------------------------------------------------------
  * softsign backward (rnn_model.py:99 autograd): du[i] *= (1-|u[i]|)^2, in place. */
 int b2t_softsign_bwd_f32(const float* u, float* du, long long n, void* stream);
+/* adjusted_lens = ((n_time_steps - patch_size) / patch_stride + 1).to(torch.int32) (rnn_trainer.py:532, :705; fp32 division,
+ * truncation), n_time_steps int32 or int64 [B]; patch_size 0: the lengths themselves (the reference divides by zero there). */
+int b2t_adjusted_lens_i32(const void* n_time_steps, int is_int64, int B, int patch_size, int patch_stride, int32_t* out, void* stream);
 /* column sums: out[z*out_sz + c] (+)= sum_r x[z*x_sz + r*ld + c], r<rows, c<cols (bias gradients);
  * two deterministic stages; ws needs Z * b2t_colsum_ws_bytes(rows, cols) bytes. */
 size_t b2t_colsum_ws_bytes(long long rows, int cols);   /* per batch entry z */

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "b2t_gemm_bf16p_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "b2t_gemm_bf16p_f32": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "b2t_softsign_bwd_f32": (C.c_int, [VP, VP, LL, VP]),
+    "b2t_adjusted_lens_i32": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "b2t_colsum_ws_bytes": (C.c_size_t, [LL, C.c_int]),
     "b2t_colsum_f32": (C.c_int, [VP, LL, C.c_int, LL, VP, C.c_int, VP, C.c_int, LL, LL, VP]),
     "b2t_slab_reduce_f32": (C.c_int, [VP, C.c_int, LL, VP, C.c_int, VP]),

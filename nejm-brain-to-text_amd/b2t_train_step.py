@@ -256,6 +256,12 @@ class TrainStep:
         """rnn_trainer.py:532 — with the patch_size==0 case handled (the reference divides by
         patch_stride=0 there)."""
         ps, st = self.model.patch_size, self.model.patch_stride
+        if n_time_steps.is_cuda and n_time_steps.dtype in (torch.int32, torch.int64) and n_time_steps.is_contiguous():
+            # one launch instead of torch's six small ones (they sit between the head GEMM and the CTC)
+            out = torch.empty(n_time_steps.shape, dtype=torch.int32, device=n_time_steps.device)
+            N.check(N.load().b2t_adjusted_lens_i32(ops._p(n_time_steps), int(n_time_steps.dtype == torch.int64), n_time_steps.numel(),
+                                                   int(ps), int(st), ops._p(out), ops._stream()), "b2t_adjusted_lens_i32")
+            return out
         n = n_time_steps.to(torch.int64)
         if ps > 0:
             return ((n - ps).to(torch.float32) / st + 1).to(torch.int32)

@@ -260,6 +260,24 @@ extern "C" int b2t_softsign_bwd_f32(const float* u, float* du, long long n, void
   return 0;
 }
 
+// rnn_trainer.py:532 / :705: adjusted_lens = ((n_time_steps - patch_size) / patch_stride + 1).to(torch.int32) -- torch divides in
+// fp32 and truncates; six small torch kernels on the path between the head GEMM and the CTC, one launch here
+__global__ void adjusted_lens_kernel(const void* n_time, int is64, int B, int patch, int stride, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const long long n = is64 ? static_cast<const long long*>(n_time)[i] : (long long)static_cast<const int32_t*>(n_time)[i];
+  out[i] = patch > 0 ? (int32_t)((float)(n - patch) / (float)stride + 1.0f) : (int32_t)n;
+}
+extern "C" int b2t_adjusted_lens_i32(const void* n_time_steps, int is_int64, int B, int patch_size, int patch_stride, int32_t* out,
+                                     void* stream) {
+  B2T_REQUIRE(n_time_steps && out && B > 0, "adjusted_lens: null argument / empty batch");
+  B2T_REQUIRE(patch_size == 0 || patch_stride > 0, "adjusted_lens: patch_size %d needs patch_stride > 0", patch_size);
+  hipLaunchKernelGGL(adjusted_lens_kernel, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), n_time_steps, is_int64, B,
+                     patch_size, patch_stride, out);
+  B2T_CHECK_LAUNCH("b2t_adjusted_lens_i32");
+  return 0;
+}
+
 extern "C" size_t b2t_colsum_ws_bytes(long long rows, int cols) {
   long long nparts = (rows + CS_RPB - 1) / CS_RPB;
   return (size_t)(nparts * cols * sizeof(float));

@@ -954,3 +954,19 @@ def test_copy_segments_and_indirect_table():
     N.check(lib.b2t_copy_indirect_b32(C.c_void_p(tab.data_ptr()), 64, ops._stream()), "b2t_copy_indirect_b32")
     torch.cuda.synchronize()
     assert torch.equal(out2, src[2])
+
+
+@pytest.mark.parametrize("ps,st", [(14, 4), (0, 0), (5, 3), (1, 7)])
+def test_adjusted_lens_kernel_equals_the_reference_expression(ps, st):
+    """b2t_adjusted_lens_i32 against rnn_trainer.py:532's expression evaluated by torch (fp32 division, truncation), every length
+    from patch_size to 4000, int32 and int64 inputs."""
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev()
+    n = torch.arange(max(ps, 1), 4000, dtype=torch.int64)
+    ref = ((n - ps).to(torch.float32) / st + 1).to(torch.int32) if ps > 0 else n.to(torch.int32)
+    for dt in (torch.int32, torch.int64):
+        nd = n.to(dt).to(dev)
+        out = torch.empty(n.numel(), dtype=torch.int32, device=dev)
+        Nn.check(lib.b2t_adjusted_lens_i32(ops._p(nd), int(dt == torch.int64), n.numel(), ps, st, ops._p(out), ops._stream()), "adj")
+        assert torch.equal(out.cpu(), ref)
