@@ -783,9 +783,13 @@ int gru_persistent_fwd(const float* gi, const float* w_hh, const float* b_hh, co
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_fwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
+  // (H % 32: the local hand-off reads the tiles with ordinary loads, which may be served by the CU's vector cache -- invalidated at
+  //  kernel start only: a 128-byte line must not hold rows of two time steps, i.e. a step's B x H floats must be whole lines.  With
+  //  H = 48, B = 5 a line held the end of step t - 1 and the start of step t, and the sweep read stale values: found in round 4,
+  //  tools/r4_local_check.py; such shapes use the device-scope hand-off.)
   // XCD-local hand-off (local = layer parity, -1 = off): a row group's G workgroups must fit one XCD next to those of a second
   // sweep of the same parity (32 CUs; two workgroups per CU with 16-unit workgroups, one with 32-unit ones: G <= 32 / 16)
-  const bool loc = local >= 0 && H <= local_max_h(bf16, wide) && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();
+  const bool loc = local >= 0 && H <= local_max_h(bf16, wide) && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && H % 32 == 0 && gru_xcd_dispatch_ok();
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);   // must start zeroed once (allocation); self-cleaning afterwards
@@ -830,7 +834,7 @@ int gru_persistent_fwd_fused(const float* gi, const float* w_hh, const float* b_
   if (rc) return rc;
   if (H > 512) { set_error("gru_layer_fwd_fused: H=%d > 512 unsupported (the two weight slices must fit a workgroup's registers + LDS)", H); return 2; }
   const int G = H / 16, gy = (B + 15) / 16;
-  const bool loc = local >= 0 && G <= 32 && gy <= 4 && gru_xcd_dispatch_ok();
+  const bool loc = local >= 0 && G <= 32 && gy <= 4 && H % 32 == 0 && gru_xcd_dispatch_ok();
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
@@ -855,7 +859,7 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
   if (rc) return rc;
   if (wide && ((H % 32) != 0 || H > (bf16 ? 768 : 512))) { set_error("gru_layer_bwd: 32-unit workgroups need H %% 32 == 0 and H <= 512 (768 with bf16 operands)"); return 2; }
   const int G = wide ? H / 32 : H / 16, gy = (B + 15) / 16;
-  const bool loc = local >= 0 && H <= local_max_h(bf16, wide) && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && gru_xcd_dispatch_ok();   // see gru_persistent_fwd
+  const bool loc = local >= 0 && H <= local_max_h(bf16, wide) && G <= ((wide && !bf16) ? 16 : 32) && gy <= 4 && H % 32 == 0 && gru_xcd_dispatch_ok();   // see gru_persistent_fwd
   const dim3 grid = loc ? dim3(8 * G, 1) : dim3(G, gy), block(256);
   const int par = loc ? (local & 1) : 0;
   unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
