@@ -129,7 +129,7 @@ def cpu_baseline_worker(timed: int, budget_s: float):
             model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except (OSError, StopIteration):
         pass
-    return dict(value=round(B / dt, 3), unit="sentences/s", cores=threads, kind="torch-cpu", impl="torch-cpu (oracle/torch_cpu_step.py: the reference step's operator sequence on PyTorch-CPU ops)", cpu=model,
+    return dict(value=round(B / dt, 3), unit="sentences/s", cores=threads, kind="port", impl="torch-cpu (oracle/torch_cpu_step.py: the reference step's operator sequence on PyTorch-CPU ops)", cpu=model,
                 cores_usable=cores, cores_reported=os.cpu_count(),
                 sample=f"{len(timed_t)} timed step(s) after {1 if len(times) > 1 else 0} warm-up of the same workload (B={B}, T={T}, fp32) on "
                        f"PyTorch-CPU operators with {threads} threads (probe at T=40, s/step by thread count: "
@@ -146,9 +146,9 @@ def cpu_baseline(timed: int = 3, budget_s: float = 120.0):
         for line in r.stdout.splitlines():
             if line.startswith("CPUBASE "):
                 return json.loads(line[8:])
-        return dict(value=None, unit="sentences/s", cores=usable_cores(), kind="torch-cpu", impl="torch-cpu (oracle/torch_cpu_step.py: the reference step's operator sequence on PyTorch-CPU ops)", sample="failed: " + r.stderr[-300:])
+        return dict(value=None, unit="sentences/s", cores=usable_cores(), kind="port", impl="torch-cpu (oracle/torch_cpu_step.py: the reference step's operator sequence on PyTorch-CPU ops)", sample="failed: " + r.stderr[-300:])
     except subprocess.TimeoutExpired:
-        return dict(value=None, unit="sentences/s", cores=usable_cores(), kind="torch-cpu", impl="torch-cpu (oracle/torch_cpu_step.py: the reference step's operator sequence on PyTorch-CPU ops)",
+        return dict(value=None, unit="sentences/s", cores=usable_cores(), kind="port", impl="torch-cpu (oracle/torch_cpu_step.py: the reference step's operator sequence on PyTorch-CPU ops)",
                     sample=f"no result within {budget_s + 90:.0f} s on this host")
 
 
