@@ -17,3 +17,40 @@ def test_sweep_variants_agree_on_random_shapes(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r4_fuzz_sweeps.py"), "70", str(seed)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "70 cases, 0 with differences" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_model_step_matches_the_oracle_on_random_small_shapes(seed):
+    """Full training steps (forward, CTC, backward under whatever execution plan the shape gets) of randomly shaped small models --
+    feature / hidden widths that are not multiples of the tile sizes, 1-4 layers, patching or not, ragged lengths, 1-24 sentences --
+    against one oracle run each: loss 2e-5, every gradient 1e-3 of its max (the contract of test_gpu_fullsize.py)."""
+    import importlib.util
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "nejm-brain-to-text_amd")); sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location("fullsize", os.path.join(ROOT, "tests", "test_gpu_fullsize.py"))
+    FS = importlib.util.module_from_spec(spec); spec.loader.exec_module(FS)
+    from rnn_model import GRUDecoder
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(100 + seed)
+    for case in range(5):
+        F = int(rng.choice([16, 32, 48, 64])); H = int(rng.choice([16, 32, 48, 64, 96, 128])); D = int(rng.randint(2, 6))
+        C = int(rng.choice([11, 41])); L = int(rng.randint(1, 5)); B = int(rng.randint(1, 25)); T = int(rng.randint(30, 100))
+        ps, st = [(0, 0), (4, 2), (6, 3), (14, 4)][int(rng.randint(0, 4))]
+        Tp = (T - ps) // st + 1 if ps else T
+        torch.manual_seed(1000 * seed + case)
+        model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, ps, st)
+        sd = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        model = model.to(dev)
+        g = torch.Generator().manual_seed(2000 * seed + case)
+        x = torch.randn(B, T, F, generator=g) * 0.6
+        day = torch.randint(0, D, (B,), generator=g).to(torch.int32)
+        nt = torch.randint(max(ps, 1) + (T // 2), T + 1, (B,), generator=g).to(torch.int32)
+        adj = ((nt - ps) // st + 1) if ps else nt
+        Sm = max(1, min(8, int(adj.min()) // 3))
+        tgt = torch.randint(1, C, (B, Sm), generator=g).to(torch.int32)
+        tl = torch.randint(1, Sm + 1, (B,), generator=g).to(torch.int32)
+        for b in range(B):
+            tgt[b, tl[b]:] = 0
+        FS._grad_check(model, sd, x, day, tgt, nt, tl, L, ps, st, dev, f"fuzz {seed}.{case}: F={F} H={H} D={D} C={C} L={L} B={B} T={T} patch={ps}/{st}")
