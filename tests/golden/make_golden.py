@@ -156,6 +156,37 @@ def make_forward():
              **extra, **arrs)
 
 
+def make_autocast_forward():
+    """The reference's forward under its own precision regime (rnn_args.yaml:19 use_amp: true; rnn_trainer.py:527, :704:
+    torch.autocast(device_type=..., dtype=torch.bfloat16) around the model call), captured on the CPU backend: the day-layer einsum
+    and the output Linear run in bf16 there, torch's CPU GRU stays fp32 (on CUDA cuDNN's GRU runs in bf16 as well).  The fp32
+    logits of the same weights are stored next to them: the repository's bf16 mode has to sit as close to the autocast logits as
+    the autocast logits sit to the fp32 ones (tests/test_gpu_step_parity.py)."""
+    cases = [dict(tag="patch", F=48, H=96, D=5, L=5, B=3, T=61, ps=14, st=4),
+             dict(tag="h256", F=64, H=256, D=3, L=2, B=4, T=40, ps=0, st=0)]
+    out = {}
+    for c in cases:
+        torch.manual_seed(10)
+        m = GRUDecoder(c["F"], c["H"], c["D"], 41, 0.0, 0.0, c["L"], c["ps"], c["st"]).eval()
+        gen = torch.Generator().manual_seed(321)
+        perturb_days(m, gen)
+        with torch.no_grad():
+            m.out.weight.mul_(4.0)     # logits of order one: margins between phonemes as in a trained model
+        x = torch.randn(c["B"], c["T"], c["F"], generator=gen)
+        day = torch.randint(0, c["D"], (c["B"],), generator=gen)
+        with torch.no_grad():
+            ref, _ = m(x, day, None, True)
+            with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+                amp, _ = m(x, day, None, True)
+        t = c["tag"]
+        out.update({f"{t}::x": x.numpy(), f"{t}::day_idx": day.numpy(), f"{t}::logits_fp32": ref.numpy(),
+                    f"{t}::logits_autocast": amp.float().numpy(),
+                    f"{t}::cfg": np.array([c["F"], c["H"], c["D"], 41, c["L"], c["ps"], c["st"]])})
+        out.update({f"{t}::sd::{k}": v for k, v in sd_np(m).items()})
+        print(t, "autocast vs fp32: max |d| %.4f of max |logit| %.3f" % (float((amp.float() - ref).abs().max()), float(ref.abs().max())))
+    save("fwd_autocast.npz", **out)
+
+
 def make_smooth():
     gen = torch.Generator().manual_seed(5)
     x = torch.randn(3, 40, 16, generator=gen)
@@ -530,8 +561,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "init":
         make_init()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "autocast":
+        make_autocast_forward()
+        sys.exit(0)
     make_init()
     make_forward()
+    make_autocast_forward()
     make_smooth()
     make_ctc()
     make_train_step()

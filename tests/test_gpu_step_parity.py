@@ -603,3 +603,43 @@ def test_xcd_local_handoff_is_bit_identical(monkeypatch):
         for dirs in ("f", "b", "fb"):
             got, l2 = grads(dirs)
             assert torch.equal(got, ref) and torch.equal(l2, loss), f"B2T_GRU_LOCAL={dirs!r} at H={H}, B={B}"
+
+
+@pytest.mark.parametrize("tag", ["patch", "h256"])
+def test_bf16_mode_forward_against_the_reference_autocast_forward(golden_dir, tag):
+    """`use_amp: true` (rnn_args.yaml:19; rnn_trainer.py:527, :704 wrap the model call in torch.autocast(dtype=bfloat16)).  Fixture:
+    the reference's GRUDecoder.forward under torch.autocast on the CPU backend, next to its fp32 logits, captured by
+    tests/golden/make_golden.py (make_autocast_forward).  The two regimes do not round at the same places -- CPU autocast runs the
+    day-layer einsum and the output Linear in bf16 and keeps torch's CPU GRU in fp32 (cuDNN's GRU is bf16 under CUDA autocast); this
+    repository's bf16 mode rounds the operands of EVERY matrix product, recurrent ones included, and keeps fp32 accumulators,
+    gates, states and outputs -- so the contract is a distance, stated here: the bf16 mode's logits are as close to the
+    reference's autocast logits as those are to the reference's own fp32 logits (max |difference| <= 1.5 x that distance,
+    which is ~0.6 % of the largest logit), the fp32 mode reproduces the fp32 logits to 1e-4, and wherever the fp32 margin
+    between the two best phonemes exceeds that distance all three argmaxes agree."""
+    import b2t_ops as ops
+    z = load(golden_dir, "fwd_autocast.npz")
+    dev = _dev()
+    m = make_model(z[f"{tag}::cfg"], sd_of(z, f"{tag}::sd::")).eval()
+    x = torch.from_numpy(z[f"{tag}::x"]).to(dev); day = torch.from_numpy(z[f"{tag}::day_idx"]).to(dev)
+    ref32, ref16 = z[f"{tag}::logits_fp32"], z[f"{tag}::logits_autocast"]
+    dist = float(np.abs(ref16 - ref32).max())
+    old = ops.AMP["on"]
+    try:
+        ops.set_amp(False)
+        with torch.no_grad():
+            l32 = m(x, day).cpu().numpy()
+        ops.set_amp(True)
+        with torch.no_grad():
+            l16 = m(x, day).cpu().numpy()
+    finally:
+        ops.set_amp(old)
+    np.testing.assert_allclose(l32, ref32, atol=1e-4)
+    assert 0.0 < float(np.abs(l16 - l32).max()), "the bf16 mode did not engage"
+    d_ref = float(np.abs(l16 - ref16).max())
+    print(f"[{tag}] reference autocast vs fp32 {dist:.4f}; bf16 mode vs reference autocast {d_ref:.4f}, vs fp32 {float(np.abs(l16 - ref32).max()):.4f}; "
+          f"max |logit| {float(np.abs(ref32).max()):.3f}")
+    assert d_ref <= 1.5 * dist
+    top2 = np.sort(ref32, axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > dist
+    assert clear.mean() > 0.5
+    assert np.array_equal(l16.argmax(-1)[clear], ref32.argmax(-1)[clear]) and np.array_equal(ref16.argmax(-1)[clear], ref32.argmax(-1)[clear])
