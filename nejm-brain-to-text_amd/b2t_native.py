@@ -119,6 +119,7 @@ _SIGNATURES = {
     "b2t_plan_schedule_host": (C.c_int, [C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP]),
     "b2t_plan_admission_host": (C.c_int, [C.c_int, VP, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP]),
     "b2t_exec_sync_bytes": (C.c_size_t, [C.c_int]),
+    "b2t_exec_graph_stats": (C.c_int, [VP, VP, VP, VP]),
     "b2t_pass_ws_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.POINTER(PassDesc)]),
     "b2t_model_forward": (C.c_int, [VP, C.POINTER(ModelDesc), C.POINTER(PassDesc), VP, VP, VP, VP, VP, VP, VP, VP]),
     "b2t_copy_segments_b32": (C.c_int, [VP, VP, VP, C.c_int, VP]),

@@ -412,6 +412,15 @@ class Workspace:
             if key[0] == "exec_sync" and int(buf[:, 0].abs().max().item()) != 0:
                 raise RuntimeError("persistent GRU sweep: inter-workgroup hand-off timed out — results invalid")
 
+    def graph_stats(self):
+        """(graphs built, passes replayed, a build failed) of this workspace's executor under B2T_EXEC_GRAPH=1."""
+        if self._exec is None:
+            return 0, 0, False
+        import ctypes as C
+        b, r, f = C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+        N.check(N.load().b2t_exec_graph_stats(self._exec, C.byref(b), C.byref(r), C.byref(f)), "b2t_exec_graph_stats")
+        return int(b.value), int(r.value), bool(f.value)
+
     def profile(self, on: bool):
         if self._exec is not None:
             N.check(N.load().b2t_exec_profile(self._exec, 1 if on else 0), "b2t_exec_profile")

@@ -17,6 +17,8 @@
 #include <vector>
 #include <queue>
 #include <algorithm>
+#include <unordered_map>
+#include <unordered_set>
 #include "common.h"
 
 namespace b2t {
@@ -45,6 +47,14 @@ struct b2t_exec {
   std::vector<b2t::ProfRec> recs;
   std::vector<hipEvent_t> tpool;  // timing events
   size_t next_tev = 0;
+  // Replayable passes (B2T_EXEC_GRAPH=1): a pass whose every argument repeats is built ONCE as a hipGraph from the plan's task
+  // graph -- each task captured alone on a stream of its own into a child graph, the plan's edges as the graph's -- and replayed
+  // with one hipGraphLaunch (run_plan_graph below).
+  std::unordered_map<uint64_t, hipGraphExec_t> graphs;
+  std::unordered_set<uint64_t> seen_keys;           // a key's first pass runs eagerly (lazy one-time initialisations happen there)
+  hipStream_t cap[8] = {};                          // capture streams, one per queue of the plan
+  bool graph_failed = false;
+  long long graph_replays = 0, graph_builds = 0;
 };
 
 namespace b2t {
@@ -172,6 +182,7 @@ struct Ctx {
   int nq = 0;
   const Layout* lay = nullptr;  // for the per-queue pack scratch of the amp-mode GEMM
   unsigned* kcnt = nullptr;     // tile counters of the split-K GEMMs' in-kernel slab reduction (last block of sync_ws): KSLOT words per slot
+  uint64_t gkey = 0;            // != 0: everything this pass launches is determined by this key (run_plan may replay it as a graph)
 
   hipEvent_t record(hipStream_t s) {
     if (ex->next_ev == ex->pool.size()) {
@@ -382,6 +393,108 @@ void add_admission_edges(Plan& P, const std::vector<int>& order) {
   }
 }
 
+// FNV-1a over the bytes that determine a pass
+uint64_t key_bytes(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+template <typename V> uint64_t key_of(uint64_t h, const V& v) { return key_bytes(h, &v, sizeof(V)); }
+
+uint64_t pass_key(int which, const b2t_model_t* prm, const b2t_model_t* grd, const b2t_pass_t* p, std::initializer_list<const void*> ptrs,
+                  std::initializer_list<long long> ints) {
+  uint64_t h = 1469598103934665603ull;
+  h = key_of(h, which);
+  h = key_bytes(h, prm, sizeof(*prm));
+  if (grd) h = key_bytes(h, grd, sizeof(*grd));
+  const bool drop = p->in_drop > 0.f || p->rnn_drop > 0.f;
+  const long long f[] = {p->B, p->T, p->chunks, p->fwd_mode, p->bwd_mode, p->bf16_gemm, p->save, p->chunks_bwd, p->wgrad_chunk_mask,
+                         (long long)(drop ? p->seed : 0ull)};
+  h = key_bytes(h, f, sizeof(f));
+  h = key_of(h, p->in_drop); h = key_of(h, p->rnn_drop);
+  for (const void* q : ptrs) h = key_of(h, q);
+  for (long long v : ints) h = key_of(h, v);
+  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16"}) {   // read per pass by the code below / the sweeps
+    const char* e = getenv(name);
+    h = key_of(h, (int)(e ? e[0] : 0));
+  }
+  return h ? h : 1;
+}
+
+// The step as a graph (round-3 candidate 6, round-4 verdict item 9).  Stream capture of the four-queue plan as a whole ends the
+// process inside the runtime (fork by event, ~100 cross-queue edges, join); so the graph is BUILT from the plan: every task is
+// captured alone, on a capture stream standing in for its queue (a task is a short in-order sequence of launches on one
+// stream: that captures cleanly), and becomes a child-graph node whose dependencies are the task's edges in the plan plus its
+// predecessor on the same queue -- the graph has exactly the plan's order and concurrency (never more than four sweeps in
+// flight).  Kernel arguments are baked into the nodes, so a graph serves only passes whose key repeats (every pointer, shape,
+// mode; the dropout seed when dropout is on); a key's first pass runs eagerly, its second builds, later ones replay with ONE
+// runtime call.  Any HIP error while building switches the mode off for the executor (the pass then runs eagerly: a capture
+// launches nothing).  Returns true if the pass was launched.
+bool run_plan_graph(Ctx& c, Plan& P, const std::vector<int>& order, int nq) {
+  static const bool on = getenv("B2T_EXEC_GRAPH") && atoi(getenv("B2T_EXEC_GRAPH")) != 0;
+  b2t_exec* ex = c.ex;
+  if (!on || ex->graph_failed || ex->profile || c.rc) return false;
+  auto it = ex->graphs.find(c.gkey);
+  if (it == ex->graphs.end()) {
+    if (ex->seen_keys.insert(c.gkey).second) return false;   // first pass with this key: eager
+    if (ex->graphs.size() >= 32) {                            // bounded: pointers that never repeat must not grow the table
+      for (auto& kv : ex->graphs) (void)hipGraphExecDestroy(kv.second);
+      ex->graphs.clear(); ex->seen_keys.clear();
+      return false;
+    }
+    const int n = (int)P.t.size();
+    hipGraph_t G = nullptr;
+    std::vector<hipGraphNode_t> node((size_t)n, nullptr);
+    hipStream_t real[8];
+    for (int q = 0; q < 8; ++q) real[q] = c.qs[q];
+    const char* where = ""; hipError_t herr = hipSuccess; const char* tname = "";
+    auto H_ = [&](hipError_t e, const char* w) { if (e != hipSuccess && herr == hipSuccess) { herr = e; where = w; } return e == hipSuccess; };
+    bool ok = H_(hipGraphCreate(&G, 0), "hipGraphCreate");
+    for (int q = 0; q < nq && ok; ++q) {
+      if (!ex->cap[q]) ok = H_(hipStreamCreateWithFlags(&ex->cap[q], hipStreamNonBlocking), "hipStreamCreate");
+      c.qs[q] = ex->cap[q];                                   // (the amp GEMMs pick their pack scratch by queue)
+    }
+    int last[8]; for (int q = 0; q < 8; ++q) last[q] = -1;
+    for (int id : order) {
+      if (!ok || c.rc) break;
+      Task& k = P.t[id];
+      hipStream_t s = ex->cap[k.q];
+      hipGraph_t sub = nullptr;
+      tname = k.name;
+      ok = H_(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
+      if (ok && k.run) k.run(s);
+      ok = ok && H_(hipStreamEndCapture(s, &sub), "hipStreamEndCapture") && !c.rc;
+      std::vector<hipGraphNode_t> deps;
+      for (int d : k.deps) if (node[(size_t)d]) deps.push_back(node[(size_t)d]);
+      if (last[k.q] >= 0 && node[(size_t)last[k.q]]) deps.push_back(node[(size_t)last[k.q]]);
+      std::sort(deps.begin(), deps.end());
+      deps.erase(std::unique(deps.begin(), deps.end()), deps.end());   // (a repeated dependency is an invalid argument)
+      size_t nn = 0;
+      if (ok && sub) ok = H_(hipGraphGetNodes(sub, nullptr, &nn), "hipGraphGetNodes");
+      if (ok) ok = nn ? H_(hipGraphAddChildGraphNode(&node[(size_t)id], G, deps.data(), deps.size(), sub), "hipGraphAddChildGraphNode")
+                      : H_(hipGraphAddEmptyNode(&node[(size_t)id], G, deps.data(), deps.size()), "hipGraphAddEmptyNode");
+      if (sub) (void)hipGraphDestroy(sub);
+      last[k.q] = id;
+    }
+    for (int q = 0; q < 8; ++q) c.qs[q] = real[q];
+    hipGraphExec_t exec = nullptr;
+    ok = ok && !c.rc && H_(hipGraphInstantiate(&exec, G, nullptr, nullptr, 0), "hipGraphInstantiate");
+    if (G) (void)hipGraphDestroy(G);
+    if (!ok) {
+      (void)hipGetLastError();
+      ex->graph_failed = true;
+      fprintf(stderr, "exec: building the pass graph failed (%s in task '%s': %s; pass rc %d, last error: %s); eager plans from here on\n", where, tname,
+              herr != hipSuccess ? hipGetErrorString(herr) : "-", c.rc, b2t_last_error());
+      return c.rc != 0;      // an error of the pass itself stays an error; a runtime refusal falls back to the eager plan
+    }
+    ++ex->graph_builds;
+    it = ex->graphs.emplace(c.gkey, exec).first;
+  }
+  if (check_hip(hipGraphLaunch(it->second, c.main), "hipGraphLaunch")) { c.rc = 1; return true; }
+  ++ex->graph_replays;
+  return true;
+}
+
 void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   const int n = (int)P.t.size();
   bool classes = false;
@@ -394,6 +507,7 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
     fprintf(stderr, "plan: %d tasks on %d queues\n", n, nq);
     for (int id : order) fprintf(stderr, "  %9.1f %8.1f q%d %s\n", P.t[id].start, P.t[id].est, P.t[id].q, P.t[id].name);
   }
+  if (c.gkey && run_plan_graph(c, P, order, nq)) return;
   std::vector<int> pos(n);
   for (int i = 0; i < n; ++i) pos[order[i]] = i;
   for (int id : order) {
@@ -539,6 +653,8 @@ extern "C" int b2t_exec_destroy(b2t_exec* ex) {
   if (ex->scratch) (void)hipFree(ex->scratch);
   for (hipEvent_t e : ex->pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->tpool) (void)hipEventDestroy(e);
+  for (auto& kv : ex->graphs) (void)hipGraphExecDestroy(kv.second);
+  for (hipStream_t st : ex->cap) if (st) (void)hipStreamDestroy(st);
   delete ex;
   return 0;
 }
@@ -592,6 +708,12 @@ extern "C" size_t b2t_pass_ws_bytes(const b2t_model_t* m, const b2t_pass_t* p) {
   return w.bytes + 256;
 }
 
+extern "C" int b2t_exec_graph_stats(const b2t_exec* ex, long long* builds, long long* replays, int* failed) {
+  B2T_REQUIRE(ex && builds && replays && failed, "exec_graph_stats: null argument");
+  *builds = ex->graph_builds; *replays = ex->graph_replays; *failed = ex->graph_failed ? 1 : 0;
+  return 0;
+}
+
 extern "C" int b2t_exec_profile(b2t_exec* ex, int on) {
   B2T_REQUIRE(ex, "exec_profile: null executor");
   ex->profile = on != 0;
@@ -637,6 +759,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   const int nc = make_chunks(Tp, p->chunks, chunks);
   c.exact_k = nc > 1;
   c.nq = plan_queues(c, nc > 1, c.qs);   // the queues of this pass (the plan below refers to them by index)
+  c.gkey = pass_key(1, prm, nullptr, p, {x, day_idx, states, logits, hidden, ws, sync_ws, stream}, {c.nq});
   const long long a_s0_l0 = prm->patch > 0 ? (long long)prm->stride * F : F;
   // rows x K that b2t_gemm_f32 serves with its skinny (weight-streaming) kernel: exact fp32 only, one frame of <= 64 utterances
   auto skinny = [&](long long rows, int K) { return !c.bf16_gemm && !c.exact_k && rows <= 64 && K % 16 == 0; };
@@ -889,6 +1012,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   const int nc = make_chunks(Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks, chunks);
   c.exact_k = nc > 1;
   c.nq = plan_queues(c, nc > 1, c.qs);   // the queues of this pass (the plan below refers to them by index)
+  // (data parallel: the bucket callbacks issue collectives from inside the plan -- not replayable)
+  if (!bucket_cb) c.gkey = pass_key(2, prm, grd, p, {x, day_idx, dlogits, dhidden, dstates, ws, sync_ws, stream}, {c.nq, ldd, custom_states});
   // (One chunk -- shapes whose sweeps cannot be co-resident, e.g. H = 768 -- runs everything on the caller's stream.  Putting
   // the weight-gradient GEMMs of layer l on a side stream under the sweep of layer l - 1 was measured: C3 fp32 19.7 -> 23.0 ms,
   // bf16 operands 12.7 -> 15.1 ms: a 768-unit sweep workgroup needs a CU's whole register file, and GEMM workgroups that
