@@ -50,7 +50,9 @@ def test_product_never_imports_oracle():
 
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_model_init_matches_reference(golden_dir, tag):
-    """Same seed -> bit-identical initial weights, names and shapes as the reference class."""
+    """Same seed -> the reference class's initial weights, names and shapes: bit-identical, except that the recurrent weights come
+    out of nn.init.orthogonal_'s QR factorisation, whose last bits depend on the host's LAPACK kernels (on the EPYC of the GPU
+    boxes they differ from this container's): those to 1e-6."""
     from rnn_model import GRUDecoder
     z = np.load(os.path.join(golden_dir, f"init_{tag}.npz"), allow_pickle=False)
     cfg = z["cfg"]
@@ -63,7 +65,10 @@ def test_model_init_matches_reference(golden_dir, tag):
     assert set(sd) == set(gold)
     for k in gold:
         assert tuple(sd[k].shape) == gold[k].shape, k
-        assert np.array_equal(sd[k].numpy(), gold[k]), k
+        if "weight_hh" in k:
+            np.testing.assert_allclose(sd[k].numpy(), gold[k], atol=1e-6, err_msg=k)
+        else:
+            assert np.array_equal(sd[k].numpy(), gold[k]), k
 
 
 def test_arena_pack_preserves_values_and_aliases():
