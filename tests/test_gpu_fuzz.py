@@ -53,7 +53,30 @@ def test_model_step_matches_the_oracle_on_random_small_shapes(seed):
         tl = torch.randint(1, Sm + 1, (B,), generator=g).to(torch.int32)
         for b in range(B):
             tgt[b, tl[b]:] = 0
-        FS._grad_check(model, sd, x, day, tgt, nt, tl, L, ps, st, dev, f"fuzz {seed}.{case}: F={F} H={H} D={D} C={C} L={L} B={B} T={T} patch={ps}/{st}")
+        tag = f"fuzz {seed}.{case}: F={F} H={H} D={D} C={C} L={L} B={B} T={T} patch={ps}/{st}"
+        FS._grad_check(model, sd, x, day, tgt, nt, tl, L, ps, st, dev, tag)
+        # the same step in the bf16 mode (packed / one-pass bf16 GEMMs, bf16 sweeps of either width on these odd shapes): within bf16
+        # distance of the fp32 step -- an indexing error would be off by the tensor's scale
+        import b2t_ops as ops
+        from b2t_train_step import TrainStep
+        args = dict(lr_max=1e-30, lr_min=1e-30, lr_decay_steps=10, lr_warmup_steps=0, lr_max_day=1e-30, lr_min_day=1e-30, lr_decay_steps_day=10,
+                    lr_warmup_steps_day=0, beta0=0.9, beta1=0.999, epsilon=0.1, weight_decay=0.0, weight_decay_day=0, grad_norm_clip_value=0,
+                    _debug_keep_unclipped=True)
+        got = {}
+        old_amp = ops.AMP["on"]
+        try:
+            for amp in (False, True):
+                ops.set_amp(amp)
+                ts = TrainStep(model.train(), dict(args))
+                loss, _ = ts.step(x.to(dev), day, tgt, nt, tl)
+                ts.check_status()
+                got[amp] = (float(loss), {k: v.copy() for k, v in ts.last_unclipped_grads().items()})
+        finally:
+            ops.set_amp(old_amp)
+        assert abs(got[True][0] - got[False][0]) <= 3e-2 * abs(got[False][0]) + 1e-3, (tag, got[True][0], got[False][0])
+        for k, ref in got[False][1].items():
+            scale = max(1e-6, float(np.abs(ref).max()))
+            assert float(np.abs(got[True][1][k] - ref).max()) <= 0.12 * scale, (tag, k)
 
 
 @pytest.mark.gpu
