@@ -471,8 +471,63 @@ bool run_plan_graph(Ctx& c, Plan& P, const std::vector<int>& order, int nq) {
       deps.erase(std::unique(deps.begin(), deps.end()), deps.end());   // (a repeated dependency is an invalid argument)
       size_t nn = 0;
       if (ok && sub) ok = H_(hipGraphGetNodes(sub, nullptr, &nn), "hipGraphGetNodes");
-      if (ok) ok = nn ? H_(hipGraphAddChildGraphNode(&node[(size_t)id], G, deps.data(), deps.size(), sub), "hipGraphAddChildGraphNode")
-                      : H_(hipGraphAddEmptyNode(&node[(size_t)id], G, deps.data(), deps.size()), "hipGraphAddEmptyNode");
+      static const bool flat = !(getenv("B2T_EXEC_GRAPH_FLAT") && atoi(getenv("B2T_EXEC_GRAPH_FLAT")) == 0);
+      bool plain = flat;   // only kernels / memsets / empty nodes are copied; a task with anything else (a captured 1-D copy) stays a child graph
+      if (ok && nn && flat) {
+        std::vector<hipGraphNode_t> ns0(nn);
+        size_t n0 = nn;
+        ok = H_(hipGraphGetNodes(sub, ns0.data(), &n0), "hipGraphGetNodes");
+        for (size_t i = 0; i < n0 && ok; ++i) {
+          hipGraphNodeType ty;
+          ok = H_(hipGraphNodeGetType(ns0[i], &ty), "hipGraphNodeGetType");
+          if (ty != hipGraphNodeTypeKernel && ty != hipGraphNodeTypeMemset && ty != hipGraphNodeTypeEmpty) plain = false;
+        }
+      }
+      if (ok && nn && plain) {
+        // the task's nodes copied into the pass graph itself (a child-graph node per task made hipGraphLaunch cost 11 ms): the
+        // capture of one stream is a chain -- walked from its root along its edges
+        std::vector<hipGraphNode_t> ns(nn), from, to;
+        size_t ne = 0;
+        ok = H_(hipGraphGetNodes(sub, ns.data(), &nn), "hipGraphGetNodes") && H_(hipGraphGetEdges(sub, nullptr, nullptr, &ne), "hipGraphGetEdges");
+        from.resize(ne); to.resize(ne);
+        if (ok && ne) ok = H_(hipGraphGetEdges(sub, from.data(), to.data(), &ne), "hipGraphGetEdges");
+        std::vector<hipGraphNode_t> chain;
+        if (ok) {
+          hipGraphNode_t cur = nullptr;
+          for (hipGraphNode_t v : ns) { bool has_in = false; for (size_t e = 0; e < ne; ++e) has_in = has_in || to[e] == v; if (!has_in) { cur = v; break; } }
+          while (cur && chain.size() < nn) {
+            chain.push_back(cur);
+            hipGraphNode_t nx = nullptr;
+            for (size_t e = 0; e < ne; ++e) if (from[e] == cur) { nx = to[e]; break; }
+            cur = nx;
+          }
+          if (chain.size() != nn) { ok = false; where = "task capture is not a chain"; }
+        }
+        hipGraphNode_t prev = nullptr;
+        for (size_t i = 0; i < chain.size() && ok; ++i) {
+          hipGraphNodeType ty;
+          ok = H_(hipGraphNodeGetType(chain[i], &ty), "hipGraphNodeGetType");
+          std::vector<hipGraphNode_t> dd = i == 0 ? deps : std::vector<hipGraphNode_t>{prev};
+          hipGraphNode_t out = nullptr;
+          if (!ok) break;
+          if (ty == hipGraphNodeTypeKernel) {
+            hipKernelNodeParams kp;
+            ok = H_(hipGraphKernelNodeGetParams(chain[i], &kp), "hipGraphKernelNodeGetParams") &&
+                 H_(hipGraphAddKernelNode(&out, G, dd.data(), dd.size(), &kp), "hipGraphAddKernelNode");
+          } else if (ty == hipGraphNodeTypeMemset) {
+            hipMemsetParams mp;
+            ok = H_(hipGraphMemsetNodeGetParams(chain[i], &mp), "hipGraphMemsetNodeGetParams") &&
+                 H_(hipGraphAddMemsetNode(&out, G, dd.data(), dd.size(), &mp), "hipGraphAddMemsetNode");
+          } else if (ty == hipGraphNodeTypeEmpty) {
+            ok = H_(hipGraphAddEmptyNode(&out, G, dd.data(), dd.size()), "hipGraphAddEmptyNode");
+          } else { ok = false; where = "unsupported node type in a task capture"; }
+          prev = out;
+        }
+        node[(size_t)id] = prev;
+      } else if (ok) {
+        ok = nn ? H_(hipGraphAddChildGraphNode(&node[(size_t)id], G, deps.data(), deps.size(), sub), "hipGraphAddChildGraphNode")
+                : H_(hipGraphAddEmptyNode(&node[(size_t)id], G, deps.data(), deps.size()), "hipGraphAddEmptyNode");
+      }
       if (sub) (void)hipGraphDestroy(sub);
       last[k.q] = id;
     }
