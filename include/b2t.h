@@ -232,7 +232,8 @@ int b2t_exec_create(int n_layers, b2t_exec** out);
 int b2t_exec_destroy(b2t_exec* ex);
 /* B2T_EXEC_GRAPH=1 (environment, read once): a pass whose every argument repeats (pointers, shapes, modes; the dropout seed when
  * dropout is on; no bucket callback) is built once as a hipGraph from the plan's task graph and replayed with one hipGraphLaunch
- * (bit-identical; measured SLOWER than the eager four-queue plan on ROCm 7.0, hence opt-in -- NOTES.md R4.12).
+ * (EXPERIMENTAL: measured SLOWER than the eager four-queue plan on ROCm 7.0, and 2 of 48 processes ended 3e-6 off the eager loss
+ * trajectory -- NOTES.md R4.12).
  * Counters of this executor: graphs built, passes replayed, and whether a build failed (the mode is then off: eager plans). */
 int b2t_exec_graph_stats(const b2t_exec* ex, long long* builds, long long* replays, int* failed);
 /* HOST ONLY: the list scheduler the executor places a pass's task graph with (HEFT: longest remaining path first, earliest
