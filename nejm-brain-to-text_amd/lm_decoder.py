@@ -134,7 +134,8 @@ class BrainSpeechDecoder:
         self.wfst = None
         if resource.graph is not None:      # CtcWfstBeamSearch (brain_speech_decoder.cc:26-28)
             from wfst_decoder import WfstSearch
-            self.wfst = WfstSearch(resource.graph, opts, U=1, device=self.device, max_frames=max_len)
+            # (a PruneActiveTokens pass that falls due runs behind the chunk's partial result, not inside the chunk: same lattice)
+            self.wfst = WfstSearch(resource.graph, opts, U=1, device=self.device, max_frames=max_len, prune_after_read=True)
             self.acoustic_scale = float(opts.acoustic_scale)
             self._result = []
             self._entries = []

@@ -52,7 +52,7 @@ def _pow2_at_least(n: int) -> int:
 class WfstSearch:
     def __init__(self, graph, opts, U: int = 1, device="cuda:0", max_frames: int = 1024, max_tokens: int = 1 << 19,
                  max_links: int = 1 << 21, hash_size: int = 0, prune_interval: int = 25, prune_scale: float = 0.1,
-                 prune_min_fill: float = 0.0):
+                 prune_min_fill: float = 0.0, prune_after_read: bool = False):
         """graph: wfst.DecodeGraph.  opts: an object with the reference's DecodeOptions fields (max_active, min_active, beam,
         lattice_beam, acoustic_scale, ctc_blank_skip_threshold, length_penalty, nbest)."""
         self.g, self.U, self.device = graph, int(U), torch.device(device)
@@ -80,6 +80,11 @@ class WfstSearch:
         # policy: the passes only bound memory and cost about as much as the frames between them); 0 = the reference's policy
         self.prune_min_fill = float(os.environ.get("B2T_WFST_PRUNE_MIN_FILL", prune_min_fill))
         self._since_prune = 0
+        # Streaming: a PruneActiveTokens pass that falls due is NOT run inside the frame that made it due but enqueued behind the
+        # frame's partial result (best_path's read-back), i.e. it runs while the host waits for the next 80 ms frame -- the
+        # frame's latency is the search's, the lattice is the same (the pass sits between the same two frames as before).
+        self.prune_after_read = bool(prune_after_read)
+        self._prune_due = False
         self.set_opts(opts)
         self.state_bytes = self.lib.b2t_wfst_state_bytes(*self.caps)
         self.state = torch.zeros((self.U * self.state_bytes,), dtype=torch.uint8, device=self.device)
@@ -105,6 +110,7 @@ class WfstSearch:
             N.check(self.lib.b2t_wfst_reset(C.byref(self.cg), C.byref(self.co), ops._p(self.state), self.U, self._s()), "b2t_wfst_reset")
         self.finalized = False
         self._since_prune = 0
+        self._prune_due = False
 
     def prune(self):
         """PruneActiveTokens(lattice_beam * prune_scale) for every utterance + compaction of their token / link arrays."""
@@ -113,6 +119,7 @@ class WfstSearch:
                                             C.c_float(self.lattice_beam * self.prune_scale), C.c_float(self.prune_min_fill), self._s()),
                     "b2t_wfst_prune")
         self._since_prune = 0
+        self._prune_due = False
 
     # ---- Search ------------------------------------------------------------------------------------------------------
     def search(self, logp: torch.Tensor, lens=None):
@@ -123,6 +130,8 @@ class WfstSearch:
             raise ValueError(f"expected {self.U} utterances")
         lens_t = None if lens is None else self._lens_on_device(lens)
         iv = self.prune_interval
+        if self._prune_due:                        # (nobody read a result in between)
+            self.prune()
         t0 = 0
         while t0 < T:
             # the reference prunes whenever NumFramesDecoded() % prune_interval == 0 (lattice-faster-decoder.cc:592-630): a
@@ -135,7 +144,10 @@ class WfstSearch:
                                                      ops._p(ln), U, t1 - t0, Cc, self._s()), "b2t_wfst_search_f32")
             self._since_prune += t1 - t0
             if iv > 0 and self._since_prune >= iv:
-                self.prune()
+                if self.prune_after_read and t1 == T:
+                    self._prune_due = True        # behind this call's result (best_path), or in front of the next search
+                else:
+                    self.prune()
             t0 = t1
 
     def _lens_on_device(self, lens):
@@ -180,6 +192,8 @@ class WfstSearch:
             d[o_hd:o_hd + 18 * U].view(U, 18).copy_(st[:, self.off[0]:self.off[0] + 72].view(torch.int32))
             buf["host"].copy_(d, non_blocking=True)
             torch.cuda.current_stream(dev).synchronize()
+            if self._prune_due and not use_final:
+                self.prune()                       # asynchronous: runs while the caller handles this frame's result
         h = buf["host"].numpy()
         self._raise_on_overflow(h[o_hd:o_hd + 18 * U].reshape(U, 18))
         na, nw = h[o_na:o_na + U], h[o_nw:o_nw + U]
@@ -248,6 +262,7 @@ class WfstSearch:
         once -- two cluster searches must never be in flight together (neither would get all its workgroups resident), but
         the lattice extraction, the copy to the host and the host's share of this batch then run under the next search
         (tools/bench_wfst.py, `pipelined`)."""
+        self._prune_due = False                    # (FinalizeDecoding prunes everything)
         with torch.cuda.device(self.device):
             N.check(self.lib.b2t_wfst_finalize(C.byref(self.cg), C.byref(self.co), ops._p(self.state), self.U, self._s()), "b2t_wfst_finalize")
             ev = self.__dict__.get("finalize_event")

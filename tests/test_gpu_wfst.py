@@ -363,14 +363,18 @@ def test_prune_active_tokens_bounds_memory_and_keeps_the_lattice(toy):
     dev_batch = torch.from_numpy(batch).cuda()
     o = Opt(nbest=30)
     runs = {}
-    for tag, iv, stream in (("never", 0, False), ("ref25", 25, False), ("iv7", 7, False), ("stream25", 25, True)):
+    # ("stream25defer": prune_after_read -- the pass that falls due is enqueued behind the frame's partial result, or in front of the
+    #  next search when nobody read one; the partial result is read every frame there, as a streaming consumer does)
+    for tag, iv, stream in (("never", 0, False), ("ref25", 25, False), ("iv7", 7, False), ("stream25", 25, True), ("stream25defer", 25, True)):
         # (without the passes these four utterances overflow WfstSearch's default 512 k tokens: what the pruning is for)
         big = dict(max_tokens=1 << 21, max_links=1 << 23) if iv == 0 else {}
-        S = WfstSearch(g, o, U=4, max_frames=batch.shape[1] + 8, prune_interval=iv, **big)
+        S = WfstSearch(g, o, U=4, max_frames=batch.shape[1] + 8, prune_interval=iv, prune_after_read=tag.endswith("defer"), **big)
         parts = []
         if stream:
             for t in range(batch.shape[1]):
                 S.search(dev_batch[:, t:t + 1].contiguous(), np.clip(lens - t, 0, 1))
+                if tag.endswith("defer") and t % 3 != 2:
+                    S.best_path(False)        # (two frames of three read their partial result: passes end up behind a read AND in front of a search)
                 if t % 20 == 19 or t == batch.shape[1] - 1:
                     parts.append([p[2] for p in S.best_path(False)])
         else:
@@ -381,7 +385,7 @@ def test_prune_active_tokens_bounds_memory_and_keeps_the_lattice(toy):
         runs[tag] = (parts, S.frames_decoded(), mem, S.finalize())
     base = runs["never"]
     assert all(m["prunes"] == 0 for m in base[2])
-    for tag in ("ref25", "iv7", "stream25"):
+    for tag in ("ref25", "iv7", "stream25", "stream25defer"):
         parts, frames, mem, fin = runs[tag]
         assert frames == base[1] and parts == base[0], tag
         for u in range(4):

@@ -285,15 +285,26 @@ def run():
     except Exception as e:     # noqa: BLE001
         rescore = dict(error=str(e)[:200])
     # streaming: one frame per call for all U utterances, partial best path read back; PruneActiveTokens every 25 frames
+    # (prune_after_read: a pass that falls due is enqueued BEHIND the frame's partial result and runs while the host waits for the
+    #  next frame -- 80 ms in real time; here the synchronize() in front of the timer stands for the idle GPU a frame arrives on, and
+    #  the time it takes is reported as the pass's own: `prune_pass_ms_between_frames`.  `max_ms_per_frame_prune_inside` is the
+    #  round-3 number: the pass inside the frame that made it due.)
+    def stream_loop(S_, lp_, lens_, T_):
+        lat_, between = [], []
+        for t in range(T_):
+            fr = lp_[:, t:t + 1].contiguous()
+            tb = time.perf_counter(); torch.cuda.synchronize(); between.append(time.perf_counter() - tb)
+            t0 = time.perf_counter()
+            S_.search(fr, np.minimum(1, np.maximum(0, lens_ - t)).astype(np.int32))
+            S_.best_path(False, max_len=2 * T_ + 8)
+            lat_.append(time.perf_counter() - t0)
+        return np.array(lat_[5:]) * 1e3, np.array(between[5:]) * 1e3
     Ss = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.0, max_frames=T + 8, max_tokens=1 << 20, max_links=1 << 22, hash_size=hs)
-    lat = []
-    for t in range(T):
-        fr = lp[:, t:t + 1].contiguous()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        Ss.search(fr, np.minimum(1, np.maximum(0, lens - t)).astype(np.int32))
-        Ss.best_path(False, max_len=2 * T + 8)
-        lat.append(time.perf_counter() - t0)
-    lat = np.array(lat[5:]) * 1e3
+    lat_inside, _ = stream_loop(Ss, lp, lens, T)
+    del Ss
+    Ss = WfstSearch(g, Opt, U=U, prune_interval=25, prune_min_fill=0.0, max_frames=T + 8, max_tokens=1 << 20, max_links=1 << 22, hash_size=hs,
+                    prune_after_read=True)
+    lat, lat_between = stream_loop(Ss, lp, lens, T)
     smem = Ss.memory_stats()
     Ss.finalize()
     del Ss
@@ -308,20 +319,14 @@ def run():
         _, _, _, _, seqs5, logits5, lens5, _ = make(U=U, seed=5, noise=0.9, graph=(prons, words, arpa5, g5), truth="lm", blank_boost=math.log(90.0))
         _, _, lp5 = _logp(logits5, dev, lib)
         T5 = logits5.shape[1]
-        S5 = WfstSearch(g5, Opt, U=U, prune_interval=25, prune_min_fill=0.0, max_frames=T5 + 8, max_tokens=1 << 20, max_links=1 << 22, hash_size=hs)
-        lat5 = []
-        for t in range(T5):
-            fr = lp5[:, t:t + 1].contiguous()
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            S5.search(fr, np.minimum(1, np.maximum(0, lens5 - t)).astype(np.int32))
-            S5.best_path(False, max_len=2 * T5 + 8)
-            lat5.append(time.perf_counter() - t0)
+        S5 = WfstSearch(g5, Opt, U=U, prune_interval=25, prune_min_fill=0.0, max_frames=T5 + 8, max_tokens=1 << 20, max_links=1 << 22, hash_size=hs,
+                        prune_after_read=True)
+        lat5, lat5_between = stream_loop(S5, lp5, lens5, T5)
         fin5 = S5.finalize()
-        lat5 = np.array(lat5[5:]) * 1e3
         h5 = [[g5.words[w] for w in f[0][2]] if f else [] for f in fin5]
         stream5 = dict(graph=dict(words=len(words), order=5, tlg_states=int(g5.n_states), tlg_arcs=int(g5.n_arcs), mb=round(g5.nbytes() / 1e6, 1), host_build_s=round(b5, 1)),
                        p50_ms_per_frame=round(float(np.percentile(lat5, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat5, 95)), 3),
-                       max_ms_per_frame=round(float(lat5.max()), 3),
+                       max_ms_per_frame=round(float(lat5.max()), 3), prune_pass_ms_between_frames=round(float(lat5_between.max()), 3),
                        wer_vs_truth=round(sum(edit(h, r) for h, r in zip(h5, seqs5)) / max(1, sum(len(r) for r in seqs5)), 4))
         del S5
     except Exception as e:     # noqa: BLE001
@@ -344,7 +349,8 @@ def run():
                             hbm_roofline_frac=round(alg_bytes / (search_ms * 1e-3) / 8.0e12, 5)),
                offline_all_cus=wide,
                streaming=dict(p50_ms_per_frame=round(float(np.percentile(lat, 50)), 3), p95_ms_per_frame=round(float(np.percentile(lat, 95)), 3),
-                              max_ms_per_frame=round(float(lat.max()), 3),
+                              max_ms_per_frame=round(float(lat.max()), 3), prune_pass_ms_between_frames=round(float(lat_between.max()), 3),
+                              max_ms_per_frame_prune_inside=round(float(lat_inside.max()), 3),
                               held_tokens_at_end=int(max(m["tokens"] for m in smem)), created_tokens=int(max(m["created_tokens"] for m in smem)),
                               prune_passes=int(smem[0]["prunes"])),
                streaming_word_5gram=stream5,
