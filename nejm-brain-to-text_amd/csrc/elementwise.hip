@@ -104,23 +104,56 @@ __global__ void softsign_bwd_kernel(const float* __restrict__ u, float* __restri
   }
 }
 
-// Column sums, two deterministic stages: block (cx, ry) sums rows [ry*RPB, ...) of 64 columns.
-constexpr int CS_RPB = 512;
+// Column sums, two deterministic stages: block (cx, ry) sums rows [ry*RPB, ...) of 64 columns (256 with 16-byte loads).
+// Rows per block: 512 for long matrices, 64 for short ones (a function of `rows` alone: it sizes the workspace) -- the day
+// layer's bias gradient is 64 sentences x [500 rows x 512]: with 512-row blocks that was 512 workgroups of 125 dependent 4-byte
+// loads per thread, 98 us for 65 MB on the step's tail; with 64-row blocks, float4 columns and all of a thread's 16 loads in flight
+// it is a bandwidth-bound pass.
+constexpr int CS_RPB = 512, CS_RPB_SHORT = 64;
+__host__ __device__ inline int cs_rpb(long long rows) { return rows <= 4096 ? CS_RPB_SHORT : CS_RPB; }
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long rows, int cols,
-                                                             long long ld, float* __restrict__ part, long long x_sz) {
+                                                             long long ld, float* __restrict__ part, long long x_sz, int rpb) {
   __shared__ float red[4][64];
   x += (long long)blockIdx.z * x_sz;
   part += (long long)blockIdx.z * gridDim.y * cols;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
-  const long long r0 = (long long)blockIdx.y * CS_RPB;
+  const long long r0 = (long long)blockIdx.y * rpb;
   float s = 0.f;
   if (c < cols)
-    for (long long r = r0 + w; r < r0 + CS_RPB && r < rows; r += 4) s += x[r * ld + c];
+    for (long long r = r0 + w; r < r0 + rpb && r < rows; r += 4) s += x[r * ld + c];
   red[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && c < cols)
     part[(long long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// the same sums (same rows per wave, same order) with four columns per lane: cols % 4 == 0, ld % 4 == 0, 16-byte aligned slabs
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ x, long long rows, int cols,
+                                                              long long ld, float* __restrict__ part, long long x_sz) {
+  __shared__ float4 red[4][64];
+  x += (long long)blockIdx.z * x_sz;
+  part += (long long)blockIdx.z * gridDim.y * cols;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const long long r0 = (long long)blockIdx.y * CS_RPB_SHORT;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols) {
+    float4 v[CS_RPB_SHORT / 4];
+#pragma unroll
+    for (int k = 0; k < CS_RPB_SHORT / 4; ++k) {
+      const long long r = r0 + w + 4 * k;
+      v[k] = r < rows ? *reinterpret_cast<const float4*>(x + r * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < CS_RPB_SHORT / 4; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < cols) {
+    const float4 a = red[0][lane], b = red[1][lane], d = red[2][lane], e = red[3][lane];
+    *reinterpret_cast<float4*>(part + (long long)blockIdx.y * cols + c) =
+        make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
+  }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out,
                                     int accumulate, long long out_sz) {
@@ -279,16 +312,20 @@ extern "C" int b2t_adjusted_lens_i32(const void* n_time_steps, int is_int64, int
 }
 
 extern "C" size_t b2t_colsum_ws_bytes(long long rows, int cols) {
-  long long nparts = (rows + CS_RPB - 1) / CS_RPB;
+  const int rpb = b2t::cs_rpb(rows);
+  long long nparts = (rows + rpb - 1) / rpb;
   return (size_t)(nparts * cols * sizeof(float));
 }
 
 extern "C" int b2t_colsum_f32(const float* x, long long rows, int cols, long long ld, float* out, int accumulate,
                               float* ws, int Z, long long x_sz, long long out_sz, void* stream) {
   B2T_REQUIRE(rows > 0 && cols > 0 && ws && Z > 0, "colsum: bad args rows=%lld cols=%d Z=%d", rows, cols, Z);
-  int nparts = (int)((rows + CS_RPB - 1) / CS_RPB);
+  const int rpb = cs_rpb(rows);
+  int nparts = (int)((rows + rpb - 1) / rpb);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nparts, Z), dim3(256), 0, s, x, rows, cols, ld, ws, x_sz);
+  const bool vec4 = rpb == CS_RPB_SHORT && (cols % 4) == 0 && (ld % 4) == 0 && (x_sz % 4) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 15) == 0;
+  if (vec4) hipLaunchKernelGGL(colsum_partial4_kernel, dim3((cols + 255) / 256, nparts, Z), dim3(256), 0, s, x, rows, cols, ld, ws, x_sz);
+  else hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nparts, Z), dim3(256), 0, s, x, rows, cols, ld, ws, x_sz, rpb);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256, Z), dim3(256), 0, s, ws, nparts, cols, out, accumulate,
                      out_sz);
   B2T_CHECK_LAUNCH("b2t_colsum_f32");
