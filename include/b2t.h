@@ -129,6 +129,11 @@ int b2t_day_reduce_f32(const float* slab, const int32_t* day_idx, int B, long lo
  * dv [B][Tp][patch*F] -> du [B][T][F] */
 int b2t_patch_fold_f32(const float* dv, float* du, int B, int T, int F, int Tp,
                        int patch, int stride, void* stream);
+/* The same fold followed by the backward of the input dropout (the forward's mask: Philox stream of b2t_dropout_f32 over the
+ * elements of [B][T][F] from element 0; drop_p = 0: none) and the Softsign backward du *= (1 - |u|)^2 (rnn_model.py:99-103 through
+ * autograd), one pass instead of three; every element goes through the same operations in the same order. */
+int b2t_patch_fold_day_bwd_f32(const float* dv, const float* u, float* du, int B, int T, int F, int Tp, int patch, int stride,
+                               float drop_p, uint64_t seed, void* stream);
 /* dropout (rnn_model.py:102-103, nn.GRU inter-layer dropout :70): y = x*mask/(1-p), Philox mask
  * keyed by (seed, elem0 + index) so that a tensor processed in chunks gets the mask of the whole tensor;
  * forward and backward apply the same mask. In place allowed. */

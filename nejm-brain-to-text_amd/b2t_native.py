@@ -101,6 +101,7 @@ _SIGNATURES = {
     "b2t_slab_reduce_f32": (C.c_int, [VP, C.c_int, LL, VP, C.c_int, VP]),
     "b2t_day_reduce_f32": (C.c_int, [VP, VP, C.c_int, LL, VP, LL, VP]),
     "b2t_patch_fold_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "b2t_patch_fold_day_bwd_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, VP]),
     "b2t_dropout_f32": (C.c_int, [VP, VP, LL, C.c_float, C.c_uint64, LL, VP]),
     "b2t_dropout_mask_f32": (C.c_int, [VP, LL, C.c_float, C.c_uint64, LL, VP]),
     "b2t_batch_gather_b32": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),

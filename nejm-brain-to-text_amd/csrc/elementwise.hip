@@ -206,6 +206,37 @@ __global__ void patch_fold_kernel(const float* __restrict__ dv, float* __restric
   *reinterpret_cast<float4*>(du + ((long long)b * T + t) * F + f) = acc;
 }
 
+// patch_fold + the backward of the input dropout + the Softsign backward in one pass (the three ran back to back on the step's
+// tail: 3 x 65 MB read and written): du = fold(dv) -> * dropout mask (the forward's Philox stream: element index of [B][T][F]) ->
+// * (1 - |u|)^2, each element through the same operations in the same order as the three kernels.
+__global__ void patch_fold_day_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ u, float* __restrict__ du, int T, int F,
+                                          int Tp, int patch, int stride, float p, float scale, uint64_t seed) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  const int f = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (f >= F) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p_hi = t / stride; if (p_hi > Tp - 1) p_hi = Tp - 1;
+  for (int q = p_hi; q >= 0; --q) {
+    const int k = t - q * stride;
+    if (k >= patch) break;
+    float4 v = *reinterpret_cast<const float4*>(dv + (((long long)b * Tp + q) * patch + k) * F + f);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const long long e = ((long long)b * T + t) * F + f;
+  if (p > 0.f) {
+    const float4 r = Philox::uniform4(seed, (uint64_t)(e / 4), 2u);
+    acc.x = r.x >= p ? acc.x * scale : 0.f; acc.y = r.y >= p ? acc.y * scale : 0.f;
+    acc.z = r.z >= p ? acc.z * scale : 0.f; acc.w = r.w >= p ? acc.w * scale : 0.f;
+  }
+  const float4 a = *reinterpret_cast<const float4*>(u + e);
+  float s;
+  s = 1.f - fabsf(a.x); acc.x *= s * s;
+  s = 1.f - fabsf(a.y); acc.y *= s * s;
+  s = 1.f - fabsf(a.z); acc.z *= s * s;
+  s = 1.f - fabsf(a.w); acc.w *= s * s;
+  *reinterpret_cast<float4*>(du + e) = acc;
+}
+
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p, float scale,
                                uint64_t seed, long long idx0) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -348,6 +379,17 @@ extern "C" int b2t_patch_fold_f32(const float* dv, float* du, int B, int T, int 
   dim3 block(128), grid((F / 4 + 127) / 128, T, B);
   hipLaunchKernelGGL(patch_fold_kernel, grid, block, 0, as_stream(stream), dv, du, T, F, Tp, patch, stride);
   B2T_CHECK_LAUNCH("b2t_patch_fold_f32");
+  return 0;
+}
+
+extern "C" int b2t_patch_fold_day_bwd_f32(const float* dv, const float* u, float* du, int B, int T, int F, int Tp, int patch, int stride,
+                                         float drop_p, uint64_t seed, void* stream) {
+  B2T_REQUIRE(B > 0 && T > 0 && F > 0 && (F % 4) == 0 && patch > 0 && stride > 0 && dv && u && du && drop_p >= 0.f && drop_p < 1.f,
+              "patch_fold_day_bwd: bad args");
+  dim3 block(128), grid((F / 4 + 127) / 128, T, B);
+  hipLaunchKernelGGL(patch_fold_day_bwd_kernel, grid, block, 0, as_stream(stream), dv, u, du, T, F, Tp, patch, stride, drop_p,
+                     1.0f / (1.0f - drop_p), seed);
+  B2T_CHECK_LAUNCH("b2t_patch_fold_day_bwd_f32");
   return 0;
 }
 

@@ -1207,9 +1207,12 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       c.call(b2t_colsum_f32(w.dU, T, F, F, w.day_bslab, 0, w.cs_day, B, (long long)T * F, bias_ld, sp));
     }
     if (!fast_day) {
-      if (prm->patch > 0) c.call(b2t_patch_fold_f32(w.dV, w.dU, B, T, F, Tp, prm->patch, prm->stride, sp));
-      if (p->in_drop > 0.f) c.call(b2t_dropout_f32(w.dU, w.dU, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, sp));
-      c.call(b2t_softsign_bwd_f32(w.U, w.dU, (long long)B * T * F, sp));   // dpre = dU * (1-|U|)^2, in place
+      if (prm->patch > 0) {   // fold + dropout backward + Softsign backward in one pass (three kernels on the step's tail before)
+        c.call(b2t_patch_fold_day_bwd_f32(w.dV, w.U, w.dU, B, T, F, Tp, prm->patch, prm->stride, p->in_drop, mix_seed(p->seed, 17), sp));
+      } else {
+        if (p->in_drop > 0.f) c.call(b2t_dropout_f32(w.dU, w.dU, (long long)B * T * F, p->in_drop, mix_seed(p->seed, 17), 0, sp));
+        c.call(b2t_softsign_bwd_f32(w.U, w.dU, (long long)B * T * F, sp));   // dpre = dU * (1-|U|)^2, in place
+      }
       // per-sample partial day gradients, then deterministic reduction by day
       b2t_gemm_desc d = gd(x, w.dU, w.day_slab, F, F, T);
       d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;

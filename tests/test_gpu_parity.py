@@ -1528,3 +1528,29 @@ def test_adjusted_lens_kernel_equals_the_reference_expression(ps, st):
         out = torch.empty(n.numel(), dtype=torch.int32, device=dev)
         Nn.check(lib.b2t_adjusted_lens_i32(ops._p(nd), int(dt == torch.int64), n.numel(), ps, st, ops._p(out), ops._stream()), "adj")
         assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,T,F,ps,st,p_drop", [(3, 61, 48, 14, 4, 0.2), (2, 30, 16, 4, 2, 0.0), (5, 100, 512, 14, 4, 0.2), (1, 17, 32, 6, 3, 0.5)])
+def test_patch_fold_day_bwd_equals_the_three_kernels(B, T, F, ps, st, p_drop):
+    import ctypes as C
+    """b2t_patch_fold_day_bwd_f32 (fold + input-dropout backward + Softsign backward, one pass) against b2t_patch_fold_f32 ->
+    b2t_dropout_f32 -> b2t_softsign_bwd_f32: every element goes through the same operations in the same order -- bit-identical."""
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev(); p = ops._p
+    Tp = (T - ps) // st + 1
+    g = torch.Generator().manual_seed(B * 100 + T)
+    dv = torch.randn(B, Tp, ps * F, generator=g).to(dev)
+    u = (torch.rand(B, T, F, generator=g) * 1.8 - 0.9).to(dev)
+    seed = 123456789
+    a = torch.empty(B, T, F, device=dev)
+    Nn.check(lib.b2t_patch_fold_f32(p(dv), p(a), B, T, F, Tp, ps, st, ops._stream()), "fold")
+    if p_drop > 0:
+        Nn.check(lib.b2t_dropout_f32(p(a), p(a), B * T * F, C.c_float(p_drop), seed, 0, ops._stream()), "dropout")
+    Nn.check(lib.b2t_softsign_bwd_f32(p(u), p(a), B * T * F, ops._stream()), "softsign")
+    b = torch.empty(B, T, F, device=dev)
+    Nn.check(lib.b2t_patch_fold_day_bwd_f32(p(dv), p(u), p(b), B, T, F, Tp, ps, st, C.c_float(p_drop), seed, ops._stream()), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    if p_drop > 0:
+        assert float((b == 0).float().mean()) > 0.5 * p_drop
