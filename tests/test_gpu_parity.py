@@ -580,555 +580,6 @@ def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T, wide):
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 41, 37), (33, 300, 129), (512, 1536, 512)])
-def test_gemm(akc, bkc, M, N, K):
-    import b2t_ops as ops
-    dev = _dev()
-    rng = np.random.default_rng(M * 7 + N * 3 + K + akc * 2 + bkc)
-    lda = (K if akc else M) + 4
-    ldb = (K if bkc else N) + 8
-    lda += (-lda) % 4; ldb += (-ldb) % 4
-    A = rng.standard_normal((M if akc else K, lda)).astype(np.float32)
-    Bm = rng.standard_normal((N if bkc else K, ldb)).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    Am = A[:, :K] if akc else A[:, :M].T            # asymmetric operands: transposes are detected
-    Bn = Bm[:, :K] if bkc else Bm[:, :N].T
-    ref = Am.astype(np.float64) @ Bn.astype(np.float64).T + bias
-    tA, tB = torch.from_numpy(A).to(dev), torch.from_numpy(Bm).to(dev)
-    tC = torch.zeros((M, N + 3), device=dev)
-    ops.gemm(tA, tB, tC, M=M, N_=N, K=K, a_kc=akc, b_kc=bkc, a_s0=lda, b_s0=ldb, c_s0=N + 3,
-             bias=torch.from_numpy(bias).to(dev))
-    got = tC.cpu().numpy()
-    np.testing.assert_allclose(got[:, :N], ref, atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
-    assert np.all(got[:, N:] == 0)                   # no out-of-bounds writes
-    # accumulate + softsign epilogue
-    tC2 = torch.ones((M, N), device=dev)
-    ops.gemm(tA, tB, tC2, M=M, N_=N, K=K, a_kc=akc, b_kc=bkc, a_s0=lda, b_s0=ldb, c_s0=N, accumulate=1)
-    np.testing.assert_allclose(tC2.cpu().numpy(), ref - bias + 1.0, atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
-    tC3 = torch.zeros((M, N), device=dev)
-    ops.gemm(tA, tB, tC3, M=M, N_=N, K=K, a_kc=akc, b_kc=bkc, a_s0=lda, b_s0=ldb, c_s0=N, epilogue=1)
-    r3 = ref - bias
-    np.testing.assert_allclose(tC3.cpu().numpy(), r3 / (1 + np.abs(r3)), atol=2e-5 * np.sqrt(K) * 4)  # d softsign <= 1
-
-
-def _bf16_round(x):
-    """fp32 -> nearest-even bf16 -> fp32 (what v_cvt_pk_bf16_f32 does to the operands)."""
-    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u >> 16) & 1) + 0x7FFF
-    return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32)
-
-
-@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 41, 37), (33, 300, 129), (512, 1536, 512), (64, 64, 41)])
-def test_gemm_bf16(akc, bkc, M, N, K):
-    """b2t_gemm_bf16_f32 (the `use_amp` matmul regime): operands rounded to bf16 (RNE), fp32 accumulate and output --
-    equal to an fp64 product of the rounded operands up to fp32 summation roundoff, for all four operand layouts."""
-    import b2t_native as Nn
-    import b2t_ops as ops
-    dev = _dev()
-    rng = np.random.default_rng(M * 7 + N * 3 + K)
-    A = rng.standard_normal((M, K)).astype(np.float32)
-    Bm = rng.standard_normal((N, K)).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    ref = _bf16_round(A).astype(np.float64) @ _bf16_round(Bm).astype(np.float64).T + bias
-    Mp, Np, Kp = (M + 3) // 4 * 4, (N + 3) // 4 * 4, (K + 3) // 4 * 4
-    if akc:
-        Ad = torch.zeros(M, Kp); Ad[:, :K] = torch.from_numpy(A); a_s0 = Kp
-    else:
-        Ad = torch.zeros(K, Mp); Ad[:, :M] = torch.from_numpy(A.T); a_s0 = Mp
-    if bkc:
-        Bd = torch.zeros(N, Kp); Bd[:, :K] = torch.from_numpy(Bm); b_s0 = Kp
-    else:
-        Bd = torch.zeros(K, Np); Bd[:, :N] = torch.from_numpy(Bm.T); b_s0 = Np
-    Ad, Bd = Ad.to(dev), Bd.to(dev)
-    Cd = torch.full((M, N), float("nan"), device=dev)
-    old = ops.AMP["on"]
-    ops.set_amp(True)
-    try:
-        ops.gemm(Ad, Bd, Cd, M=M, N_=N, K=K, a_kc=akc, a_s0=a_s0, b_kc=bkc, b_s0=b_s0, c_s0=N, bias=torch.from_numpy(bias).to(dev))
-        got = Cd.cpu().numpy()
-        np.testing.assert_allclose(got, ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
-        # and it really is the bf16 product, not the fp32 one
-        if K >= 32:
-            exact = A.astype(np.float64) @ Bm.astype(np.float64).T + bias
-            assert np.abs(got - exact).max() > 10 * np.abs(got - ref).max()
-        # split-K slabs (weight-gradient shape: long K) agree with the single pass
-        if M == 512:
-            ws = ops.Workspace()
-            C2 = torch.empty((M, N), device=dev)
-            ops.gemm(Ad, Bd, C2, M=M, N_=N, K=K, a_kc=akc, a_s0=a_s0, b_kc=bkc, b_s0=b_s0, c_s0=N, splitk=4, ws=ws)
-            np.testing.assert_allclose(C2.cpu().numpy() + bias, ref, atol=2e-5 * float(np.abs(ref).max()))
-    finally:
-        ops.set_amp(old)
-
-
-@pytest.mark.parametrize("B,H,T,wide", [(17, 80, 9, 0), (64, 512, 12, 0), (40, 768, 6, 0), (64, 512, 12, 1), (23, 96, 7, 1), (40, 768, 6, 1), (64, 768, 20, 1), (64, 512, 180, 1)])
-def test_persistent_sweep_bf16_operands(B, H, T, wide):
-    """mode 1 | B2T_GRU_BF16: the recurrent products round their operands (h_{t-1} / dG_{t+1} and the W_hh slice) to bf16
-    and accumulate in fp32.  Reference: the same recurrences in numpy with the operands rounded explicitly."""
-    import b2t_native as Nn
-    import b2t_ops as ops
-    lib = Nn.load(); dev = _dev(); p = ops._p
-    g = torch.Generator().manual_seed(B + H)
-    rnd = lambda *s: torch.randn(*s, generator=g)
-    gi, w, b_, h0 = rnd(T, B, 3 * H) * 0.5, rnd(3 * H, H) * (1.0 / H ** 0.5), rnd(3 * H) * 0.1, rnd(B, H) * 0.3
-    dY, dhl = rnd(T, B, H) * 0.05, rnd(B, H) * 0.05
-    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
-    wq = _bf16_round(w.numpy()).astype(np.float64)
-    # forward
-    h = h0.numpy().astype(np.float64)
-    outs, res = [], []
-    for t in range(T):
-        gh = _bf16_round(h.astype(np.float32)).astype(np.float64) @ wq.T + b_.numpy()
-        git = gi[t].numpy().astype(np.float64)
-        r = sig(git[:, :H] + gh[:, :H]); z = sig(git[:, H:2 * H] + gh[:, H:2 * H])
-        n = np.tanh(git[:, 2 * H:] + r * gh[:, 2 * H:])
-        hprev = h
-        h = (1 - z) * n + z * hprev
-        outs.append(h); res.append((r, z, n, gh[:, 2 * H:], hprev))
-    # backward (SURVEY A3), dGh rounded for the carry product
-    carry = dhl.numpy().astype(np.float64)
-    dG_ref = np.zeros((T, B, 4 * H))
-    for t in range(T - 1, -1, -1):
-        r, z, n, ghn, hprev = res[t]
-        d = dY[t].numpy() + carry
-        dn = d * (1 - z); dz = d * (hprev - n)
-        dn_pre = dn * (1 - n * n); dz_pre = dz * z * (1 - z); dr_pre = dn_pre * ghn * r * (1 - r)
-        dG_ref[t] = np.concatenate([dr_pre, dz_pre, dn_pre * r, dn_pre], axis=1)
-        carry = d * z + _bf16_round(dG_ref[t][:, :3 * H].astype(np.float32)).astype(np.float64) @ wq
-    gi, w, b_, h0, dY, dhl = (x.to(dev) for x in (gi, w, b_, h0, dY, dhl))
-    wt = w.t().contiguous()
-    out = torch.zeros(T + 1, B, H, device=dev); out[0] = h0
-    resv = torch.zeros(T, B, 4 * H, device=dev)
-    sync = torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev)
-    Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out[0]), p(out[1:]), p(resv), None, T, B, H, 1 | ops.GRU_BF16 | (ops.GRU_WIDE if wide else 0),
-                                       p(sync), ops._stream()), "fwd")
-    dG = torch.zeros(T, B, 4 * H, device=dev); dh = torch.zeros(B, H, device=dev); sc = torch.empty(B, H, device=dev)
-    Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(resv), p(out[1:]), p(out[0]), p(wt), p(dG), p(dh), p(sc), T, B, H,
-                                       1 | ops.GRU_BF16 | (ops.GRU_WIDE if wide else 0), p(sync), ops._stream()), "bwd")
-    torch.cuda.synchronize()
-    assert int(sync[0]) == 0
-    # rounding decisions can flip where fp32 and fp64 intermediates straddle a bf16 boundary: compare at bf16-ulp scale
-    np.testing.assert_allclose(out[1:].cpu().numpy(), np.stack(outs), atol=2e-3)
-    np.testing.assert_allclose(dG.cpu().numpy(), dG_ref, atol=2e-3 * max(1.0, float(np.abs(dG_ref).max())))
-    np.testing.assert_allclose(dh.cpu().numpy(), carry, atol=2e-3 * max(1.0, float(np.abs(carry).max())))
-    # and it is not the fp32 path
-    out32 = torch.zeros(T + 1, B, H, device=dev); out32[0] = h0
-    Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out32[0]), p(out32[1:]), None, None, T, B, H, 1, p(sync), ops._stream()), "fwd32")
-    assert float((out32 - out).abs().max()) > 1e-5
-    if wide:
-        # The 32-unit workgroups hand their tiles over as bf16 MFMA fragments through the buffer behind the counters
-        # (gru_sync.h); with B2T_HANDOFF16=0 as fp32 tiles that every consumer transposes and rounds itself: the same roundings of
-        # the same numbers, the same split of the contraction over the waves -- bit-identical results.
-        import os
-        old_env = os.environ.get("B2T_HANDOFF16")
-        os.environ["B2T_HANDOFF16"] = "0"
-        try:
-            out_n = torch.zeros(T + 1, B, H, device=dev); out_n[0] = h0
-            resv_n = torch.zeros(T, B, 4 * H, device=dev)
-            Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out_n[0]), p(out_n[1:]), p(resv_n), None, T, B, H,
-                                               1 | ops.GRU_BF16 | ops.GRU_WIDE, p(sync), ops._stream()), "fwd fp32 tiles")
-            dG_n = torch.zeros(T, B, 4 * H, device=dev); dh_n = torch.zeros(B, H, device=dev)
-            Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(resv_n), p(out_n[1:]), p(out_n[0]), p(wt), p(dG_n), p(dh_n), p(sc), T, B, H,
-                                               1 | ops.GRU_BF16 | ops.GRU_WIDE, p(sync), ops._stream()), "bwd fp32 tiles")
-            torch.cuda.synchronize()
-        finally:
-            if old_env is None: os.environ.pop("B2T_HANDOFF16", None)
-            else: os.environ["B2T_HANDOFF16"] = old_env
-        assert int(sync[0]) == 0
-        assert torch.equal(out, out_n) and torch.equal(resv, resv_n)
-        assert torch.equal(dG, dG_n) and torch.equal(dh, dh_n)
-        # ... and under the XCD-local hand-off (ordinary loads of the fragments; both layer parities).  (64, 512, 180): the backward
-        # call's 180 steps of 192 KB exceed the buffer, its slots wrap around after 170.
-        for extra in (ops.GRU_LOCAL, ops.GRU_LOCAL | ops.GRU_PARITY):
-            out_l = torch.zeros(T + 1, B, H, device=dev); out_l[0] = h0
-            resv_l = torch.zeros(T, B, 4 * H, device=dev)
-            Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out_l[0]), p(out_l[1:]), p(resv_l), None, T, B, H,
-                                               1 | ops.GRU_BF16 | ops.GRU_WIDE | extra, p(sync), ops._stream()), "fwd local")
-            dG_l = torch.zeros(T, B, 4 * H, device=dev); dh_l = torch.zeros(B, H, device=dev)
-            Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(resv_l), p(out_l[1:]), p(out_l[0]), p(wt), p(dG_l), p(dh_l), p(sc), T, B, H,
-                                               1 | ops.GRU_BF16 | ops.GRU_WIDE | extra, p(sync), ops._stream()), "bwd local")
-            torch.cuda.synchronize()
-            assert int(sync[0]) == 0
-            assert torch.equal(out, out_l) and torch.equal(dG, dG_l) and torch.equal(dh, dh_l)
-
-
-def test_train_step_bf16_matmuls_track_fp32():
-    """B2T_AMP regime end to end (bf16 matmul operands everywhere, fp32 sweeps / CTC / optimizer): loss and gradients
-    stay within bf16 distance of the fp32 step on the same batch, and a few steps of training reduce the loss."""
-    import b2t_ops as ops
-    from rnn_model import GRUDecoder
-    from b2t_train_step import TrainStep
-    dev = _dev()
-    F, H, D, C, L, B, T = 128, 256, 3, 41, 3, 32, 48
-    args = dict(lr_max=0.01, lr_min=0.001, lr_decay_steps=100, lr_warmup_steps=0, lr_scheduler_type="cosine",
-                lr_max_day=0.01, lr_min_day=0.001, lr_decay_steps_day=100, lr_warmup_steps_day=0, beta0=0.9,
-                beta1=0.999, epsilon=0.1, weight_decay=0.0, weight_decay_day=0, grad_norm_clip_value=10,
-                _debug_keep_unclipped=True)
-    torch.manual_seed(5)
-    x = torch.randn(B, T, F, device=dev) * 0.5; day = torch.randint(0, D, (B,), device=dev, dtype=torch.int32)
-    tgt = torch.randint(1, C, (B, 6), device=dev, dtype=torch.int32)
-    nt = torch.full((B,), T, device=dev, dtype=torch.int32); tl = torch.full((B,), 6, device=dev, dtype=torch.int32)
-    old = ops.AMP["on"]
-    out = {}
-    try:
-        for amp in (False, True):
-            ops.set_amp(amp)
-            torch.manual_seed(6)
-            model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
-            ts = TrainStep(model, dict(args))
-            losses = []
-            for it in range(6):
-                loss, _ = ts.step(x, day, tgt, nt, tl)
-                losses.append(float(loss))
-                if it == 0:
-                    g0 = {k: v.copy() for k, v in ts.last_unclipped_grads().items()}
-            out[amp] = (losses, g0)
-    finally:
-        ops.set_amp(old)
-    (l32, g32), (l16, g16) = out[False], out[True]
-    assert abs(l16[0] - l32[0]) < 2e-2 * abs(l32[0]) and l16[0] != l32[0]
-    assert l16[-1] < 0.9 * l16[0]
-    for k, ref in g32.items():
-        scale = max(1e-6, float(np.abs(ref).max()))
-        assert float(np.abs(g16[k] - ref).max()) < 0.08 * scale, k
-
-
-def test_smooth_golden(golden_dir):
-    from data_augmentations import gauss_smooth
-    z = load(golden_dir, "smooth.npz")
-    dev = _dev()
-    x = torch.from_numpy(z["x"]).to(dev)
-    np.testing.assert_allclose(gauss_smooth(x, dev, 2, 100, "same").cpu().numpy(), z["same"], atol=2e-6)
-    np.testing.assert_allclose(gauss_smooth(x, dev, 2, 100, "valid").cpu().numpy(), z["valid"], atol=2e-6)
-    x2 = torch.from_numpy(z["x2"]).to(dev)
-    np.testing.assert_allclose(gauss_smooth(x2, dev, 1, 50, "same").cpu().numpy(), z["same_std1"], atol=2e-6)
-
-
-def test_transform_golden(golden_dir):
-    """transform_data with the reference's noise draws injected (rnn_trainer.py:436-484)."""
-    import b2t_ops as ops
-    z = load(golden_dir, "transform.npz")
-    dev = _dev()
-    x = torch.from_numpy(z["x"]).to(dev)
-    wn = torch.from_numpy(z["white"]).to(dev)
-    on = torch.from_numpy(z["offset"].reshape(z["offset"].shape[0], -1)).to(dev)
-    for cut in (0, 1, 2):
-        y = ops.augment_smooth(x, 2, 100, "same", cut=cut, white_std=1.0, offset_std=0.2, white_noise=wn,
-                               offset_noise=on)
-        np.testing.assert_allclose(y.cpu().numpy(), z[f"train_cut{cut}"], atol=3e-6)
-    y = ops.augment_smooth(x, 2, 100, "same")
-    np.testing.assert_allclose(y.cpu().numpy(), z["val"], atol=3e-6)
-
-
-def test_augment_noise_statistics():
-    """Philox path: deterministic under seed, N(0, ws^2 + os^2) before smoothing, offset constant along T."""
-    import b2t_ops as ops
-    dev = _dev()
-    x = torch.zeros((8, 256, 512), device=dev)
-    a = ops.augment_smooth(x, 2, 100, "same", white_std=1.0, offset_std=0.2, seed=1234, smooth=False)
-    b = ops.augment_smooth(x, 2, 100, "same", white_std=1.0, offset_std=0.2, seed=1234, smooth=False)
-    c = ops.augment_smooth(x, 2, 100, "same", white_std=1.0, offset_std=0.2, seed=1235, smooth=False)
-    assert torch.equal(a, b) and not torch.equal(a, c)
-    an = a.cpu().numpy().astype(np.float64)
-    assert abs(an.mean()) < 5e-3
-    assert abs(an.var() - (1.0 + 0.04)) < 1e-2
-    off = an.mean(axis=1)                     # [B,F] ~ offset draw (+ white mean / sqrt(T))
-    assert abs(off.var() - (0.04 + 1.0 / 256)) < 4e-3
-    only_off = ops.augment_smooth(x, 2, 100, "same", white_std=0.0, offset_std=0.2, seed=7, smooth=False).cpu().numpy()
-    assert np.all(only_off == only_off[:, :1, :])
-    # independence across neighbouring elements
-    w = ops.augment_smooth(x, 2, 100, "same", white_std=1.0, seed=99, smooth=False).cpu().numpy().astype(np.float64)
-    assert abs(np.mean(w[:, :, :-1] * w[:, :, 1:])) < 5e-3 and abs(np.mean(w[:, :-1] * w[:, 1:])) < 5e-3
-
-
-@pytest.mark.parametrize("tag", ["h64", "h512", "patch", "f512"])
-def test_model_forward_golden(golden_dir, tag):
-    z = load(golden_dir, f"fwd_{tag}.npz")
-    m = make_model(z["cfg"], sd_of(z)).eval()
-    dev = _dev()
-    x = torch.from_numpy(z["x"]).to(dev)
-    day = torch.from_numpy(z["day_idx"]).to(dev)
-    with torch.no_grad():
-        logits, hidden = m(x, day, None, True)
-    lg = logits.cpu().numpy()
-    np.testing.assert_allclose(lg, z["logits"], atol=1e-4)
-    np.testing.assert_allclose(hidden.cpu().numpy(), z["hidden"], atol=1e-4)
-    # greedy argmax: identical wherever the reference's top-2 margin is > 1e-4
-    srt = np.sort(z["logits"], axis=-1)
-    safe = (srt[..., -1] - srt[..., -2]) > 1e-4
-    assert np.array_equal(np.argmax(lg, -1)[safe], np.argmax(z["logits"], -1)[safe])
-    if "stream_split" in z.files:      # carried state == whole sequence (rnn_model.py:131-132)
-        t1 = int(z["stream_split"])
-        with torch.no_grad():
-            l1, s1 = m(x[:, :t1].contiguous(), day, None, True)
-            l2, s2 = m(x[:, t1:].contiguous(), day, s1, True)
-        np.testing.assert_allclose(torch.cat([l1, l2], 1).cpu().numpy(), z["stream_logits"], atol=1e-4)
-        np.testing.assert_allclose(s2.cpu().numpy(), z["stream_state"], atol=1e-4)
-
-
-def test_ctc_golden(golden_dir):
-    import b2t_ops as ops
-    z = load(golden_dir, "ctc.npz")
-    dev = _dev()
-    B = z["logits"].shape[0]
-    loss, dl, ldd = ops.ctc_loss(torch.from_numpy(z["logits"]).to(dev), torch.from_numpy(z["targets"]),
-                                 torch.from_numpy(z["in_len"]), torch.from_numpy(z["tgt_len"]), True, 1.0 / B,
-                                 ops.Workspace())
-    np.testing.assert_allclose(loss.cpu().numpy(), z["loss"], rtol=1e-5)
-    d = dl.cpu().numpy()
-    np.testing.assert_allclose(d[:, :, :41], z["dlogits"], atol=5e-6)
-    assert np.all(d[:, :, 41:] == 0)
-    for b in range(B):
-        assert np.all(d[b, int(z["in_len"][b]):] == 0)
-    zi = load(golden_dir, "ctc_inf.npz")
-    li, _, _ = ops.ctc_loss(torch.from_numpy(zi["logits"]).to(dev), torch.tensor([[4, 4, 4]]), torch.tensor([3]),
-                            torch.tensor([3]), False, 1.0, ops.Workspace())
-    assert np.isinf(li.cpu().numpy()[0])
-
-
-def test_ctc_oracle_ragged():
-    """Seeded ragged batch incl. S=1, repeats, T_b<T, long targets (2S+1 > 256 states)."""
-    import b2t_ops as ops
-    rng = np.random.default_rng(3)
-    dev = _dev()
-    B, T, C, S = 5, 400, 41, 150
-    logits = (rng.standard_normal((B, T, C)) * 1.5).astype(np.float32)
-    tg = rng.integers(1, C, (B, S)).astype(np.int32)
-    tg[0, :6] = [7, 7, 7, 2, 2, 9]
-    tl = np.array([150, 1, 60, 33, 120], dtype=np.int32)
-    il = np.array([400, 17, 400, 250, 399], dtype=np.int32)
-    for b in range(B):
-        tg[b, tl[b]:] = 0
-    lo, dlo = O.ctc_loss_fwd_bwd(logits, tg, il, tl)
-    loss, dl, _ = ops.ctc_loss(torch.from_numpy(logits).to(dev), torch.from_numpy(tg), torch.from_numpy(il),
-                               torch.from_numpy(tl), True, 1.0 / B, ops.Workspace())
-    np.testing.assert_allclose(loss.cpu().numpy(), lo, rtol=1e-5)
-    # long sequences: log-space values reach ~1e3 where one fp32 ulp is 6e-5, so fp32 implementations
-    # (this kernel, the oracle, torch CPU) differ from each other at the 1e-4 relative level.  Bound the
-    # kernel's error against an fp64 evaluation by a small multiple of the fp32 oracle's own error.
-    l64, d64 = O.ctc_loss_fwd_bwd(logits, tg, il, tl, dtype=np.float64)
-    got = dl.cpu().numpy()[:, :, :C].astype(np.float64)
-    err_gpu = np.abs(got - d64).max()
-    err_o32 = np.abs(dlo.astype(np.float64) - d64).max()
-    assert err_gpu <= max(4 * err_o32, 5e-6), (err_gpu, err_o32)
-    np.testing.assert_allclose(loss.cpu().numpy(), l64, rtol=1e-5)
-    np.testing.assert_allclose(got, dlo, atol=5e-6, rtol=2e-3)
-
-
-def test_train_step_golden(golden_dir):
-    """Full fwd + bwd + clip + AdamW for 4 steps vs the reference's step body (rnn_trainer.py:527-558)."""
-    from rnn_trainer import TrainStep
-    z = load(golden_dir, "train_step.npz")
-    dev = _dev()
-    m = make_model(z["cfg"], sd_of(z, "sd0::")).train()
-    args = dict(lr_max=0.005, lr_min=0.0001, lr_decay_steps=120000, lr_warmup_steps=int(z["warmup"]),
-                lr_max_day=0.005, lr_min_day=0.0001, lr_decay_steps_day=120000, lr_warmup_steps_day=int(z["warmup"]),
-                beta0=0.9, beta1=0.999, epsilon=0.1, weight_decay=0.001, weight_decay_day=0,
-                grad_norm_clip_value=float(z["clip"]), _debug_keep_unclipped=True)
-    ts = TrainStep(m, args)
-    x = torch.from_numpy(z["x"]).to(dev)
-    day = torch.from_numpy(z["day_idx"])
-    tgt = torch.from_numpy(z["targets"]); tl = torch.from_numpy(z["tgt_len"]); nts = torch.from_numpy(z["n_time_steps"])
-    gold_grads = sd_of(z, "grad0::")
-    for it in range(4):
-        import b2t_ops as ops
-        feats = ops.augment_smooth(x, 2, 100, "same")
-        if it == 0:
-            np.testing.assert_allclose(feats.cpu().numpy(), z["feats0"], atol=3e-6)
-        loss, gnorm = ts.step(feats, day, tgt, nts, tl)
-        np.testing.assert_allclose(float(loss), z[f"loss{it}"], rtol=2e-5)
-        np.testing.assert_allclose(float(gnorm), z[f"gnorm{it}"], rtol=1e-4)
-        if it == 0:
-            g = ts.last_unclipped_grads()
-            for k, ref in gold_grads.items():
-                scale = max(1e-6, float(np.abs(ref).max()))
-                np.testing.assert_allclose(g[k], ref, atol=1e-3 * scale, err_msg=k)
-        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
-        for k, ref in sd_of(z, f"sd{it+1}::").items():
-            np.testing.assert_allclose(sd[k], ref, atol=2e-5, err_msg=f"step{it} {k}")
-
-
-def test_autograd_matches_fused(golden_dir):
-    """loss.backward() through GRUDecoder (autograd bridge) == oracle gradients."""
-    z = load(golden_dir, "train_step.npz")
-    dev = _dev()
-    sd0 = sd_of(z, "sd0::")
-    m = make_model(z["cfg"], sd0).train()
-    feats = torch.from_numpy(z["feats0"]).to(dev)
-    logits = m(feats, torch.from_numpy(z["day_idx"]))
-    lp = torch.permute(logits.log_softmax(2), [1, 0, 2])
-    # an arbitrary differentiable scalar of the logits (torch ops): sum of squares of log-probs
-    (lp ** 2).mean().backward()
-    L = int(z["cfg"][4])
-    lo, _, ctx = O.model_fwd(sd0, z["feats0"], z["day_idx"], L, save=True)
-    tl = torch.from_numpy(lo).requires_grad_(True)
-    (torch.permute(tl.log_softmax(2), [1, 0, 2]) ** 2).mean().backward()
-    dlog = tl.grad.numpy()
-    B, Tp, C = dlog.shape
-    p = ctx["p"]
-    d_out = (dlog.reshape(B * Tp, C) @ p["out_w"]).reshape(B, Tp, -1)
-    _, dW_ih, dW_hh, _, _, dh = O.gru_bwd(d_out, ctx["reserve"], p["w_ih"], p["w_hh"], ctx["h_init"])
-    for l in range(L):
-        for name, ref in ((f"gru.weight_ih_l{l}", dW_ih[l]), (f"gru.weight_hh_l{l}", dW_hh[l])):
-            got = dict(m.named_parameters())[name].grad.cpu().numpy()
-            np.testing.assert_allclose(got, ref, atol=1e-3 * max(1e-6, np.abs(ref).max()), err_msg=name)
-    np.testing.assert_allclose(m.h0.grad.cpu().numpy().reshape(-1), dh.sum((0, 1)), atol=1e-3 * np.abs(dh.sum((0, 1))).max())
-    active = set(int(d) for d in z["day_idx"])
-    for d in range(int(z["cfg"][2])):
-        assert (m.day_weights[d].grad is not None) == (d in active)
-
-
-def test_greedy_and_edit_golden(golden_dir):
-    import b2t_ops as ops
-    z = load(golden_dir, "greedy.npz")
-    dev = _dev()
-    ids, ln, am = ops.greedy_decode(torch.from_numpy(z["logits"]).to(dev), torch.from_numpy(z["lens"]))
-    ids, ln = ids.cpu().numpy(), ln.cpu().numpy()
-    B = z["logits"].shape[0]
-    np.testing.assert_array_equal(am.cpu().numpy(), np.argmax(z["logits"], -1))     # bit-exact argmax indices
-    for b in range(B):
-        np.testing.assert_array_equal(ids[b, :ln[b]], z[f"trainer_{b}"])
-    lab = torch.from_numpy(z["labels"]).to(dev)
-    dist = ops.edit_distance(torch.from_numpy(ids).to(dev), torch.from_numpy(ln).to(dev), lab,
-                             torch.from_numpy(z["lab_len"]).to(dev)).cpu().numpy()
-    np.testing.assert_array_equal(dist, [int(z[f"edit_{b}"]) for b in range(B)])
-
-
-def test_edit_distance_random():
-    import b2t_ops as ops
-    rng = np.random.default_rng(0)
-    dev = _dev()
-    Bn, La, Lb = 40, 150, 130
-    a = rng.integers(1, 6, (Bn, La)).astype(np.int32); b = rng.integers(1, 6, (Bn, Lb)).astype(np.int32)
-    al = rng.integers(0, La + 1, Bn).astype(np.int32); bl = rng.integers(0, Lb + 1, Bn).astype(np.int32)
-    al[0] = 0; bl[1] = 0; al[2] = La; bl[2] = Lb
-    got = ops.edit_distance(torch.from_numpy(a).to(dev), torch.from_numpy(al).to(dev), torch.from_numpy(b).to(dev),
-                            torch.from_numpy(bl).to(dev)).cpu().numpy()
-    ref = [O.edit_distance(a[i, :al[i]], b[i, :bl[i]]) for i in range(Bn)]
-    np.testing.assert_array_equal(got, ref)
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("tag", ["h64", "h512", "patch"])
-def test_gru_sweep_modes(golden_dir, tag, mode):
-    """Step-launch (0) and persistent (1) sweeps both reproduce the reference forward, and the persistent
-    hand-off reports no timeout."""
-    import b2t_ops as ops
-    z = load(golden_dir, f"fwd_{tag}.npz")
-    old = ops.GRU_MODE["value"]
-    ops.GRU_MODE["value"] = mode
-    try:
-        m = make_model(z["cfg"], sd_of(z)).eval()
-        dev = _dev()
-        with torch.no_grad():
-            logits, hidden = m(torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["day_idx"]).to(dev), None, True)
-        np.testing.assert_allclose(logits.cpu().numpy(), z["logits"], atol=1e-4)
-        np.testing.assert_allclose(hidden.cpu().numpy(), z["hidden"], atol=1e-4)
-        if mode >= 1:
-            m._ws.check_sync()
-    finally:
-        ops.GRU_MODE["value"] = old
-
-
-def N_sync(T):
-    import b2t_native as Nn
-    return Nn.load().b2t_gru_sync_bytes(T) // 4 + 16
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-def test_train_step_modes_vs_oracle(mode):
-    """C2-shaped slice (H=512, L=2, B=40 = 2.5 row groups, T=60): loss + every gradient vs the oracle, both modes,
-    run 3 times back-to-back so the persistent hand-off is exercised with warm caches."""
-    import b2t_ops as ops
-    from rnn_model import GRUDecoder
-    from rnn_trainer import TrainStep
-    dev = _dev()
-    old = ops.GRU_MODE["value"]
-    ops.GRU_MODE["value"] = mode
-    try:
-        torch.manual_seed(3)
-        F, H, D, C, L, B, T, S = 64, 512, 4, 41, 2, 40, 60, 7
-        model = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0)
-        sd0 = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
-        model = model.to(dev).train()
-        g = torch.Generator().manual_seed(5)
-        x = torch.randn(B, T, F, generator=g) * 0.5
-        day = torch.randint(0, D, (B,), generator=g)
-        tgt = torch.randint(1, C, (B, S), generator=g)
-        tl = torch.randint(1, S + 1, (B,), generator=g); nt = torch.randint(30, T + 1, (B,), generator=g)
-        for b in range(B):
-            tgt[b, tl[b]:] = 0
-        lo, _, _, go = O.model_loss_and_grads(sd0, x.numpy(), day.numpy(), tgt.numpy(), nt.numpy(), tl.numpy(), L)
-        args = dict(lr_max=0.0, lr_min=0.0, lr_decay_steps=10, lr_warmup_steps=0, lr_max_day=0.0, lr_min_day=0.0,
-                    lr_decay_steps_day=10, lr_warmup_steps_day=0, beta0=0.9, beta1=0.999, epsilon=0.1, weight_decay=0.0,
-                    weight_decay_day=0, grad_norm_clip_value=0, _debug_keep_unclipped=True)
-        args["lr_max"] = 1e-30; args["lr_max_day"] = 1e-30; args["lr_min"] = 1e-30; args["lr_min_day"] = 1e-30
-        ts = TrainStep(model, args)
-        for rep in range(3):
-            loss, gnorm = ts.step(x.to(dev), day, tgt, nt, tl)
-            np.testing.assert_allclose(float(loss), float(lo), rtol=2e-5)
-            got = ts.last_unclipped_grads()
-            assert set(got) == set(go)
-            for k, ref in go.items():
-                np.testing.assert_allclose(got[k], ref, atol=1e-3 * max(1e-6, float(np.abs(ref).max())), err_msg=f"{k} rep{rep}")
-        if mode >= 1:
-            model._ws.check_sync()
-    finally:
-        ops.GRU_MODE["value"] = old
-
-
-@pytest.mark.parametrize("B,H,T,wide", [(5, 48, 9, 0), (17, 80, 13, 0), (33, 272, 11, 0), (64, 512, 24, 0), (70, 768, 7, 0),
-                                         (64, 512, 24, 1), (23, 96, 7, 1), (40, 288, 9, 1)])
-def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T, wide):
-    """Persistent sweeps (line-wise operand loads + LDS transpose, clamped rows / columns) against the step-launch
-    kernels on shapes that are not multiples of the tile sizes: forward out / reserve, backward dG / dh0."""
-    import b2t_native as Nn
-    import b2t_ops as ops
-    lib = Nn.load(); dev = _dev(); p = ops._p
-    g = torch.Generator().manual_seed(B * 1000 + H)
-    rnd = lambda *s: (torch.randn(*s, generator=g)).to(dev)
-    gi, w, b_, h0 = rnd(T, B, 3 * H) * 0.5, rnd(3 * H, H) * (1.0 / H ** 0.5), rnd(3 * H) * 0.1, rnd(B, H) * 0.3
-    dY, dhl = rnd(T, B, H) * 0.05, rnd(B, H) * 0.05
-    wt = w.t().contiguous()
-
-    def run(mode):
-        out = torch.zeros(T + 1, B, H, device=dev); out[0] = h0
-        res = torch.zeros(T, B, 4 * H, device=dev)
-        sync = torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev)
-        Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out[0]), p(out[1:]), p(res), None, T, B, H, mode, p(sync),
-                                           ops._stream()), "fwd")
-        dG = torch.zeros(T, B, 4 * H, device=dev); dh = torch.zeros(B, H, device=dev); sc = torch.empty(B, H, device=dev)
-        Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(res), p(out[1:]), p(out[0]), p(wt), p(dG), p(dh), p(sc), T, B, H,
-                                           mode, p(sync), ops._stream()), "bwd")
-        torch.cuda.synchronize()
-        assert int(sync[0]) == 0
-        return out, res, dG, dh
-
-    ref = run(0)
-    for rep in range(3):
-        got = run(1 | (ops.GRU_WIDE if wide else 0))   # wide: 32 hidden units per workgroup, exact fp32
-        for a, r, name in zip(got, ref, ("out", "reserve", "dG", "dh0")):
-            np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=3e-6 * max(1.0, float(r.abs().max())), err_msg=name)
-    if not wide:
-        # The 16-unit backward sweep hands its tiles over as fp32 MFMA fragments (gru_persist_bwd_kernel F32R: no LDS transpose, six
-        # chunk loads in flight instead of the whole operand); B2T_HANDOFF32=0 is the form with fp32 tiles every consumer transposes:
-        # the same values accumulated in the same order -- bit-identical, device scope and XCD-local (both parities).
-        import os
-        old_env = os.environ.get("B2T_HANDOFF32")
-        try:
-            os.environ["B2T_HANDOFF32"] = "0"
-            base = run(1)
-        finally:
-            if old_env is None: os.environ.pop("B2T_HANDOFF32", None)
-            else: os.environ["B2T_HANDOFF32"] = old_env
-        for extra in (0, ops.GRU_LOCAL, ops.GRU_LOCAL | ops.GRU_PARITY):
-            got = run(1 | extra)
-            for a, r, name in zip(got, base, ("out", "reserve", "dG", "dh0")):
-                assert torch.equal(a, r), (name, extra)
-
-
-@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 41, 37), (33, 300, 129), (512, 1536, 520), (640, 256, 4100)])
 def test_gemm_bf16_packed(akc, bkc, M, N, K):
     """b2t_gemm_bf16p_f32 (two passes: pack both operands to dense bf16, then tiles on the packed operands): same contract
