@@ -385,24 +385,29 @@ def main():
         loss, dt, t_enq = timed_run()
     box = sampler.stop() if sampler else None
     # A process on this pool sometimes comes up in a mode in which every HIP call is 2.5-3x slower for the whole life of the
-    # process (NOTES.md 5: host enqueue 4-7 ms per step instead of 1.1-2.2, the GPU then waits on the plan's cross-queue hops and
-    # the step is 1.5-2 ms slower); the next process on the same box is usually fine.  A one-GPU run that finds itself there
-    # starts over, at most twice, and says so in `box` (B2T_BENCH_NO_RESTART=1: never).
+    # process (NOTES.md 5 / R5: host enqueue 4-7 ms per step instead of 1.1-2.2, the GPU then waits on the plan's cross-queue hops
+    # and the step is 1-2 ms slower).  The HEADLINE (`value`, `ms_per_step`) is always the FIRST process's measurement; a one-GPU
+    # run that finds itself in the slow mode additionally starts over, at most twice, so that the line can show what other
+    # processes on the same box measure: every process run is listed in `process_runs`, the fastest one in `best_process_ms`
+    # -- beside the headline, never instead of it (B2T_BENCH_NO_RESTART=1: never start over).
     restarts = int(os.environ.get("B2T_BENCH_RESTARTS", "0"))
     slow_ms = float(os.environ.get("B2T_BENCH_SLOW_ENQ_MS", "3.0"))
+    runs = json.loads(os.environ.get("B2T_BENCH_PROCESS_RUNS", "[]"))
+    runs.append(dict(process=restarts + 1, ms_per_step=round(dt / a.steps * 1e3, 3), host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3),
+                     sentences_per_s=round(rows * world * a.steps / dt, 2)))
     if (world == 1 and not force_dp and t_enq / a.steps * 1e3 > slow_ms and restarts < 2
             and os.environ.get("B2T_BENCH_NO_RESTART") is None):
-        hist = os.environ.get("B2T_BENCH_SLOW_RUNS", "")
-        os.environ["B2T_BENCH_SLOW_RUNS"] = (hist + ";" if hist else "") + f"{dt / a.steps * 1e3:.3f} ms/step, host enqueue {t_enq / a.steps * 1e3:.2f} ms/step"
+        os.environ["B2T_BENCH_PROCESS_RUNS"] = json.dumps(runs)
         os.environ["B2T_BENCH_RESTARTS"] = str(restarts + 1)
-        sys.stderr.write(f"[bench] slow-process mode (host enqueue {t_enq / a.steps * 1e3:.2f} ms per step, {dt / a.steps * 1e3:.3f} ms per step): starting over "
-                         f"({restarts + 1} of 2)\n")
+        sys.stderr.write(f"[bench] slow-process mode (host enqueue {t_enq / a.steps * 1e3:.2f} ms per step, {dt / a.steps * 1e3:.3f} ms per step): one more "
+                         f"process for comparison ({restarts + 1} of 2); the headline stays the first process's\n")
         sys.stdout.flush(); sys.stderr.flush()
         os.execv(sys.executable, [sys.executable] + sys.argv)
     if box is not None:
         box["process_restarts"] = restarts
-        if restarts:
-            box["discarded_slow_process_runs"] = os.environ.get("B2T_BENCH_SLOW_RUNS", "")
+    dt_this = dt
+    if world == 1 and not force_dp and runs:
+        dt = runs[0]["ms_per_step"] * 1e-3 * a.steps      # headline = the first process
     if world > 1 or force_dp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -444,11 +449,12 @@ def main():
             traffic, traffic_src = round(pmc[dname]["bytes_per_launch"] / 1e9, 4), pmc["source"]
     except OSError:
         pass
+    ms_this = dt_this / a.steps * 1e3                  # the process the per-kernel timings below were taken in
     roofline = dict(bound="mfma", kernel=dname, achieved=round(achieved / 1e12, 3), peak=round(PEAK_F32_MFMA / 1e12, 1),
                     unit="TFLOP/s", frac=round(achieved / PEAK_F32_MFMA, 4), traffic=traffic, traffic_unit="GB/launch",
                     traffic_source=traffic_src,
                     avg_launch_us=round(dtime / max(1, dlaunch) * 1e6, 2), launches_per_step=dlaunch // NPROF,
-                    summed_stream_time_over_step=round(dtime / NPROF / (ms * 1e-3), 3),   # >1: launches overlap on side streams
+                    summed_stream_time_over_step=round(dtime / NPROF / (ms_this * 1e-3), 3),   # >1: launches overlap on side streams
                     step_flops_frac=round(FLOPS_PER_STEP * rows / B / (ms * 1e-3) / PEAK_F32_MFMA, 4),   # per GPU
                     step_hbm_frac=round(ALG_BYTES_PER_STEP * rows / B / (ms * 1e-3) / PEAK_HBM, 4),
                     breakdown_ms={k: round(v[0] / NPROF * 1e3, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])})
@@ -466,7 +472,10 @@ def main():
                                gru_mode=ops.gru_mode_for(B, H), time_chunks=ops.PIPELINE["chunks"],
                                time_chunks_bwd=ops.PIPELINE["chunks_bwd"] or ops.PIPELINE["chunks"]),
                    roofline=roofline, final_loss=round(lossv, 4),
-                   host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3), box=box)
+                   host_enqueue_ms_per_step=runs[0]["host_enqueue_ms_per_step"] if runs else round(t_enq / a.steps * 1e3, 3),
+                   process_runs=runs, best_process_ms=min(r["ms_per_step"] for r in runs) if runs else round(ms, 3),
+                   headline_is="the first process's measurement (later processes, started only when the first one came up in the "
+                               "slow-host mode, are listed in process_runs; roofline kernel timings are from the last process)", box=box)
         sys.stderr.write("[bench] headline done: " + json.dumps(out)[:200] + "\n"); sys.stderr.flush()
         if world == 1 and not a.no_secondary:
             # BASELINE configs[2..4] measured by the same process, reported beside (never instead of) the headline

@@ -140,12 +140,14 @@ def precision_from_args(args) -> bool:
     for every GEMM and recurrent product, fp32 accumulation / gates / CTC / optimizer / master weights.  Order of precedence:
     args['amd_bf16_matmul'] (explicit True / False: the opt-out is `amd_bf16_matmul: false`), the B2T_AMP environment
     variable when set, then `use_amp`."""
-    if isinstance(args, dict) and args.get("amd_bf16_matmul") is not None:
-        return bool(args["amd_bf16_matmul"])
+    # any mapping with .get(): the reference's entry scripts hand over an OmegaConf DictConfig, which is not a dict subclass
+    get = getattr(args, "get", None)
+    if get is not None and get("amd_bf16_matmul") is not None:
+        return bool(get("amd_bf16_matmul"))
     env = os.environ.get("B2T_AMP")
     if env is not None:
         return env not in ("0", "", "false", "False")
-    return bool(args.get("use_amp", False)) if isinstance(args, dict) else False
+    return bool(get("use_amp", False)) if get is not None else False
 
 
 def gemm(A, B, Cm, *, M, N_, K, Z=1, a_kc=1, b_kc=1, a_s0=0, a_s1=0, a_div=0, a_sz=0, b_s0=0, b_s1=0, b_div=0,

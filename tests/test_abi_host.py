@@ -180,6 +180,20 @@ def test_use_amp_selects_the_bf16_mode(monkeypatch):
     assert ops.precision_from_args({}) is False
     assert ops.precision_from_args({"use_amp": True, "amd_bf16_matmul": False}) is False     # the opt-out
     assert ops.precision_from_args({"use_amp": False, "amd_bf16_matmul": True}) is True
+    # the reference's entry scripts pass an OmegaConf DictConfig: a Mapping that is NOT a dict subclass
+    import collections.abc
+
+    class Cfg(collections.abc.Mapping):
+        def __init__(self, d): self._d = dict(d)
+        def __getitem__(self, k): return self._d[k]
+        def __iter__(self): return iter(self._d)
+        def __len__(self): return len(self._d)
+    assert not isinstance(Cfg({}), dict)
+    assert ops.precision_from_args(Cfg({"use_amp": True})) is True
+    assert ops.precision_from_args(Cfg({"use_amp": False})) is False
+    assert ops.precision_from_args(Cfg({"use_amp": True, "amd_bf16_matmul": False})) is False
+    assert ops.precision_from_args(Cfg({"amd_bf16_matmul": True})) is True
+    assert ops.precision_from_args(None) is False
     monkeypatch.setenv("B2T_AMP", "0")
     assert ops.precision_from_args({"use_amp": True}) is False
     assert ops.precision_from_args({"use_amp": True, "amd_bf16_matmul": True}) is True       # the args win over the environment
