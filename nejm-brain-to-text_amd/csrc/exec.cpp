@@ -550,8 +550,34 @@ bool run_plan_graph(Ctx& c, Plan& P, const std::vector<int>& order, int nq) {
   return true;
 }
 
+// Timing jitter for the plan's hazard test (B2T_EXEC_JITTER=seed, read per pass; round-5 verdict item 1c): a single wave that
+// spins for `us` microseconds of the 100 MHz wall clock, enqueued in front of randomly chosen tasks on the task's own queue,
+// behind its cross-queue waits.  Results must not depend on when a task starts: an ordering the plan has only by timing (a
+// missing edge) shows up as arenas that differ between seeds (tests/test_gpu_step_parity.py, tools/r5_jitter.py).
+__global__ void jitter_spin_kernel(unsigned us) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(32);
+}
+struct Jitter {
+  bool on = false; uint64_t s = 0;
+  explicit Jitter(uint64_t pass_no) {
+    const char* e = getenv("B2T_EXEC_JITTER");
+    if (e && e[0]) { on = true; s = (strtoull(e, nullptr, 0) + 1) * 0x9E3779B97F4A7C15ull + pass_no * 0xD1B54A32D192ED03ull; }
+  }
+  uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+  void maybe(hipStream_t q) {
+    if (!on) return;
+    const uint64_t r = next();
+    if (r % 3 != 0) return;                                   // a third of the tasks start late ...
+    const unsigned us = 10u + (unsigned)((r >> 8) % 391u);    // ... by 10-400 us (a sweep chunk takes ~500, a GEMM 20-500)
+    hipLaunchKernelGGL(jitter_spin_kernel, dim3(1), dim3(64), 0, q, us);
+  }
+};
+
 void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   const int n = (int)P.t.size();
+  static uint64_t pass_no = 0;
+  Jitter jit(++pass_no);
   bool classes = false;
   for (const Task& k : P.t) classes = classes || k.cls >= 0;
   if (classes && nq > 1) add_admission_edges(P, schedule_plan(P, nq));
@@ -581,7 +607,7 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
       if (dq != k.q && (last[dq] < 0 || pos[d] > pos[last[dq]])) last[dq] = d;
     }
     for (int q = 0; q < nq; ++q) if (last[q] >= 0) c.wait(s, P.t[last[q]].ev);
-    if (k.run) k.run(s);
+    if (k.run) { jit.maybe(s); k.run(s); }
     if (k.cross) k.ev = c.record(s);
   }
 }

@@ -35,10 +35,18 @@ class Config:
     (ctc_wfst_beam_search.h:55-62); production values: language-model-standalone.py:486-496."""
 
     def __init__(self, beam=16.0, max_active=2 ** 31 - 1, min_active=200, lattice_beam=10.0, prune_interval=25,
-                 beam_delta=0.5, prune_scale=0.1, length_penalty=0.0, acoustic_scale=1.0, nbest=10, blank_skip_thresh=0.98):
+                 beam_delta=0.5, prune_scale=0.1, length_penalty=0.0, acoustic_scale=1.0, nbest=10, blank_skip_thresh=0.98,
+                 cutoff_rule="sequential"):
         self.beam, self.max_active, self.min_active, self.lattice_beam = beam, max_active, min_active, lattice_beam
         self.prune_interval, self.beam_delta, self.prune_scale, self.length_penalty = prune_interval, beam_delta, prune_scale, length_penalty
         self.acoustic_scale, self.nbest, self.blank_skip_thresh = acoustic_scale, nbest, blank_skip_thresh
+        # "sequential": ProcessEmitting as the reference runs it -- next_cutoff tightens while the hash list is walked, so the
+        # tokens created beyond the frame's final cutoff depend on the list's order (HashList below).  "final": the data-parallel
+        # rule of csrc/wfst.hip -- every candidate is compared with the frame's FINAL next_cutoff (best candidate +
+        # adaptive_beam; the reference reaches the same value at the end of its walk), no token beyond it exists.  The two
+        # differ only through GetCutoff's token COUNT / k-th cost in the next frame, i.e. while max_active (or min_active) binds.
+        assert cutoff_rule in ("sequential", "final")
+        self.cutoff_rule = cutoff_rule
 
 
 class Token:
@@ -55,7 +63,46 @@ class Link:
         self.next_tok, self.ilabel, self.olabel, self.graph_cost, self.acoustic_cost = next_tok, ilabel, olabel, graph_cost, acoustic_cost
 
 
+class HashList:
+    """kaldi/util/hash-list-inl.h restated for what the decoder observes of it: the ORDER in which GetList() / Clear() hand the
+    elements out.  Insert (:137-172) puts a key into bucket `key % hash_size_`; an unoccupied bucket is linked at the TAIL of the
+    element list (its bucket becomes bucket_list_tail_), an element of an occupied bucket goes behind that bucket's last element:
+    the list is the buckets in order of their first occupation, inside a bucket the elements in insertion order.  ProcessEmitting
+    walks that list while it tightens next_cutoff (lattice-faster-decoder.cc:786-810), so which over-the-cutoff tokens get
+    created depends on it; ProcessNonemitting seeds its LIFO queue from it (:861-865).  SetSize (:37-43) only ever grows the
+    table and is called on the empty list (PossiblyResizeHash, lattice-faster-decoder.cc:216-222: num_toks * hash_ratio)."""
+
+    def __init__(self, size):
+        self.size, self.buckets = size, {}      # bucket index -> [(key, value)]; dict order = order of first occupation
+
+    def set_size(self, size):
+        assert not self.buckets
+        self.size = size
+
+    def get(self, key):
+        for k, v in self.buckets.get(key % self.size, ()):
+            if k == key:
+                return v
+        return None
+
+    def insert(self, key, val):
+        self.buckets.setdefault(key % self.size, []).append((key, val))
+
+    def items(self):
+        return [kv for b in self.buckets.values() for kv in b]
+
+    def values(self):
+        return [v for b in self.buckets.values() for _, v in b]
+
+    def clear(self):
+        out = self.values()
+        self.buckets = {}
+        return out
+
+
 class LatticeFasterDecoder:
+    HASH_RATIO = 2.0        # LatticeFasterDecoderConfig::hash_ratio (lattice-faster-decoder.h:70)
+
     def __init__(self, graph, cfg: Config):
         self.g, self.cfg = graph, cfg
         self.row, self.il, self.ol, self.w, self.nx = (np.asarray(getattr(graph, k)) for k in ("row", "ilabel", "olabel", "weight", "next"))
@@ -64,7 +111,9 @@ class LatticeFasterDecoder:
 
     # ---- :57-75
     def init_decoding(self):
-        self.toks = {}                  # hash of the current frame: state -> Token (insertion-ordered like the Elem list)
+        # toks_: state -> Token in HashList order; SetSize(1000) in the constructor (:37-38).  (The reference keeps one decoder
+        # object, whose table only grows, across utterances; every utterance here starts from the constructor's size.)
+        self.toks = HashList(1000)
         self.active = [[]]              # active_toks_[f]: tokens of frame f
         self.must_prune_links, self.must_prune_toks = [True], [True]
         self.cost_offsets = []
@@ -72,7 +121,7 @@ class LatticeFasterDecoder:
         self.final_costs = {}
         start = Token(F32(0.0), F32(0.0), None, int(self.g.start))
         self.active[0].append(start)
-        self.toks[int(self.g.start)] = start
+        self.toks.insert(int(self.g.start), start)
         self.process_nonemitting(self.cfg.beam)
 
     def num_frames_decoded(self):
@@ -84,7 +133,7 @@ class LatticeFasterDecoder:
         if tok is None:
             tok = Token(tot_cost, F32(0.0), backpointer, state)
             self.active[frame_plus_one].append(tok)
-            self.toks[state] = tok
+            self.toks.insert(state, tok)
             return tok, True
         if tok.tot_cost > tot_cost:
             tok.tot_cost, tok.backpointer = tot_cost, backpointer
@@ -116,9 +165,11 @@ class LatticeFasterDecoder:
         cfg = self.cfg
         frame = len(self.active) - 1
         self.active.append([]); self.must_prune_links.append(True); self.must_prune_toks.append(True)
-        final_toks = list(self.toks.values())
-        self.toks = {}
+        final_toks = self.toks.clear()          # Clear(): the element list in HashList order
         cur_cutoff, adaptive_beam, best_i = self.get_cutoff(final_toks)
+        new_sz = int(F32(len(final_toks)) * F32(self.HASH_RATIO))     # PossiblyResizeHash :216-222
+        if new_sz > self.toks.size:
+            self.toks.set_size(new_sz)
         next_cutoff = F32(INF)
         cost_offset = F32(0.0)
         lp = F32(cfg.length_penalty)
@@ -133,6 +184,15 @@ class LatticeFasterDecoder:
                     if nw + adaptive_beam < next_cutoff:
                         next_cutoff = nw + adaptive_beam
         self.cost_offsets.append(cost_offset)
+        if cfg.cutoff_rule == "final":      # the frame's final cutoff first (csrc/wfst.hip pass A), then every candidate against it
+            for tok in final_toks:
+                if tok.tot_cost <= cur_cutoff:
+                    for a in range(self.row[tok.state], self.row[tok.state + 1]):
+                        if self.il[a] != 0:
+                            graph_cost = self.w[a] + lp if tok.state != self.nx[a] else self.w[a]
+                            tot = tok.tot_cost + (cost_offset - loglike[self.il[a] - 1]) + graph_cost
+                            if tot + adaptive_beam < next_cutoff:
+                                next_cutoff = tot + adaptive_beam
         for tok in final_toks:
             if tok.tot_cost <= cur_cutoff:
                 for a in range(self.row[tok.state], self.row[tok.state + 1]):
@@ -217,7 +277,7 @@ class LatticeFasterDecoder:
         self.final_costs, self.final_best_cost = self.compute_final_costs()
         self.finalized = True
         self.toks_final = self.toks
-        self.toks = {}
+        self.toks = HashList(self.toks_final.size)
         changed, delta = True, 1.0e-05
         while changed:
             changed = False

@@ -571,6 +571,46 @@ def test_schedule_independent(monkeypatch):
             assert torch.equal(l2, loss)
 
 
+def test_plan_results_do_not_depend_on_task_timing(monkeypatch):
+    """Round-5 verdict 1c: the hipGraph replay of the plan once ended 3e-6 off the eager plan's loss, i.e. either a runtime bug or
+    an ordering the eager plan gets only by TIMING (a missing edge that a handful of placements cannot see).  B2T_EXEC_JITTER=seed
+    makes csrc/exec.cpp enqueue a 10-400 us spin kernel in front of a random third of the tasks (on the task's queue, behind its
+    waits): 40 seeds x (forward + backward) at the schedule-independence shape, gradients / loss / logits must equal the
+    unjittered plan's bit for bit.  (tools/r5_jitter.py runs 200 seeds at this shape and at BASELINE configs[1].)"""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    F, H, D, C, L, B, T, S = 64, 128, 6, 41, 3, 32, 160, 12
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, F, generator=g).to(dev)
+    day = torch.randint(0, D, (B,), generator=g)
+    tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(3, S + 1, (B,), generator=g)
+    nt = torch.randint(120, T + 1, (B,), generator=g)
+    for b in range(B):
+        tgt[b, tl[b]:] = 0
+    monkeypatch.setitem(ops.PIPELINE, "chunks", 5)
+    monkeypatch.setitem(ops.PIPELINE, "chunks_bwd", 3)
+    for mask in (0, 0b111):
+        monkeypatch.setitem(ops.PIPELINE, "wgrad_chunk_mask", mask)
+        monkeypatch.delenv("B2T_EXEC_JITTER", raising=False)
+        torch.manual_seed(3)
+        m = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
+        ts = TrainStep(m, step_args())
+        loss = ts.compute_grads(x, day, tgt, nt, tl).clone()
+        torch.cuda.synchronize()
+        ref = ts.grad_arena.clone()
+        assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
+        for seed in range(20):
+            monkeypatch.setenv("B2T_EXEC_JITTER", str(seed + 100 * mask))
+            ts.grad_arena.zero_()
+            l2 = ts.compute_grads(x, day, tgt, nt, tl)
+            torch.cuda.synchronize()
+            assert torch.equal(l2, loss), f"jitter seed {seed}, mask {mask}: loss differs"
+            assert torch.equal(ts.grad_arena, ref), f"jitter seed {seed}, mask {mask}: gradients differ"
+        ts.check_status()
+
+
 def test_xcd_local_handoff_is_bit_identical(monkeypatch):
     """The XCD-local hand-off (row groups pinned to one XCD, counters / tiles through that XCD's L2) changes where the data
     travels, not the arithmetic: gradients and loss equal the device-scope hand-off's bit for bit, for every combination

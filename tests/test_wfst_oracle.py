@@ -322,3 +322,41 @@ def test_final_pruning_uses_kaldis_approx_equal():
     assert [list(o) for o in R.outputs] == [[1]] and [list(i) for i in R.inputs] == [[1]]
     arcs, finals, start = R.dec.raw_lattice()
     assert sum(len(a) for a in arcs) == 1 and len(finals) == 1
+
+
+def test_hash_list_hands_the_elements_out_in_the_reference_order():
+    """kaldi/util/hash-list-inl.h:137-172 (Insert) / :45-58 (Clear): a key goes to bucket key % size; a bucket that becomes occupied
+    is linked behind the last occupied one, a key of an occupied bucket goes behind that bucket's last element -> the list is the
+    buckets in order of first occupation, each bucket in insertion order.  Worked by hand for size 5 and the insertions
+    7, 3, 12, 8, 2, 13, 5:  buckets 2 (7, 12, 2), 3 (3, 8, 13), 0 (5)."""
+    h = W.HashList(5)
+    for k in (7, 3, 12, 8, 2, 13, 5):
+        assert h.get(k) is None
+        h.insert(k, f"v{k}")
+    assert [k for k, _ in h.items()] == [7, 12, 2, 3, 8, 13, 5]
+    assert h.get(12) == "v12" and h.get(4) is None
+    assert h.clear() == [f"v{k}" for k in (7, 12, 2, 3, 8, 13, 5)]
+    assert h.items() == [] and h.get(7) is None
+    h.set_size(1000)                      # SetSize only on the empty list (:37-43); below 1000 keys the order is insertion order
+    for k in (7, 3, 12, 8):               # per bucket, i.e. first-occupation order = insertion order when no two keys share one
+        h.insert(k, k)
+    assert h.values() == [7, 3, 12, 8]
+
+
+def test_order_dependent_cutoff_only_matters_while_max_active_binds():
+    """lattice-faster-decoder.cc:786-810: ProcessEmitting tightens next_cutoff while it walks the hash list, so tokens beyond the
+    frame's final cutoff exist or not depending on list order; the next frame's GetCutoff counts them (:650-720).  The oracle's
+    "sequential" rule restates that walk in HashList order; its "final" rule is the data-parallel form csrc/wfst.hip implements
+    (every candidate against the frame's final cutoff).  With max_active far from binding the two give identical n-best lists;
+    with max_active = 60 (binding in every frame of these graphs) they may differ in the tail of the list but not in the best
+    hypothesis (tools/r5_cutoff_order.py over the 9 fuzz graphs x 21 utterances: max_active 60 -> 1 list differs, from rank 4 on;
+    150 and 400 -> none)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import r5_cutoff_order as R
+    rows = R.run([60, 7000], seeds=(101,), verbose=False)
+    loose = [r for r in rows if r["max_active"] == 7000]
+    tight = [r for r in rows if r["max_active"] == 60]
+    assert loose and all(r["first_diff"] < 0 for r in loose)
+    assert tight and all(r["best_same"] for r in tight)
+    assert all(r["first_diff"] < 0 or r["first_diff"] >= 1 for r in tight)

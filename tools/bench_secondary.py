@@ -222,8 +222,17 @@ def decode_wfst_tlg():
                      "0.325, nbest 100) over a synthetic 400-word lexicon x word 3-gram T o L o G in HBM; offline = one call + "
                      "finalize + n-best, streaming = one frame per call with the partial best path read back; the search runs "
                      "8 workgroups per utterance (clusters behind one XCD's L2)")
+    traffic, src = None, None
+    try:   # memory-side bytes per search launch from the committed rocprofv3 --pmc passes of the same workload (tools/prof_decode.py)
+        import json
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")) as f:
+            pm = json.load(f)["decode_r5"]
+        traffic, src = round(pm["wfst_cluster_kernel"]["bytes_per_launch"] / 1e9, 4), pm["source"]
+    except (OSError, KeyError):
+        pass
     r["roofline"] = dict(bound="hbm", kernel="wfst_cluster_kernel", achieved=r["offline"]["achieved_gb_s"], peak=8000.0, unit="GB/s",
-                         frac=r["offline"]["hbm_roofline_frac"], traffic=None,
+                         frac=r["offline"]["hbm_roofline_frac"], traffic=traffic, traffic_unit="GB per search launch (5 launches of <= 25 frames per 111-frame call; algorithmic 0.6297)",
+                         traffic_source=src,
                          note="algorithmic bytes = 16 B per expanded arc + 20 B per token + 21 B per link; the search is bound by "
                               "dependent L2 / HBM round trips (token -> state -> arcs -> hash slot), not by bandwidth")
     r["dtype"] = "f32"
