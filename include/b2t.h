@@ -168,6 +168,8 @@ int b2t_batch_gather_b32(const void* flat, const int64_t* row_off, const int32_t
 #define B2T_GRU_LOCAL 0x400   /* persistent sweeps, H <= 512, B <= 64: XCD-local hand-off (row group r on XCD (2r + parity) & 7, counters as L2 atomics, tiles written through and read back from that XCD's L2); ignored where the dispatch probe fails */
 #define B2T_GRU_PARITY 0x800  /* with B2T_GRU_LOCAL: the layer's parity */
 #define B2T_GRU_WIDE 0x200   /* with B2T_GRU_BF16: 32 hidden units per workgroup (half the workgroups per sweep), H % 32 == 0, H <= 512 */
+#define B2T_GRU_PAIRED 0x1000 /* b2t_gru_layer_bwd_f32, mode 1, exact fp32, H % 32 == 0, H <= 512, B <= 64 (other shapes: ignored): the backward sweep with its W_hh^T slice in LDS -- one 512-thread workgroup per CU owns 16 dh columns of TWO row groups, ~half the registers per lane, so that a GEMM workgroup stays resident next to it; XCD-local hand-off, pair p on XCD (4 p + set) & 7 */
+#define B2T_GRU_SET_SHIFT 13  /* with B2T_GRU_PAIRED: bits 13-14 = the XCD set (0..3) of this sweep; at most ONE paired sweep of a set may be in flight */
 size_t b2t_gru_sync_bytes(int T);
 size_t b2t_gru_ws_bytes(int T, int B, int H);   /* = b2t_gru_sync_bytes (kept for callers that size by shape) */
 /* Persistent mode only: copies the sweep's error word to the host and synchronises the stream.

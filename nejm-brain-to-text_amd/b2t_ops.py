@@ -285,6 +285,10 @@ GRU_BF16 = 0x100   # B2T_GRU_BF16 (include/b2t.h): bf16 operands of the recurren
 GRU_WIDE = 0x200   # B2T_GRU_WIDE: 32 hidden units per workgroup
 GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
 GRU_PARITY = 0x800  # B2T_GRU_PARITY: with GRU_LOCAL, the layer's parity (which XCDs its row groups use)
+GRU_PAIRED = 0x1000  # B2T_GRU_PAIRED: exact-fp32 backward sweep with its W_hh^T slice in LDS (512-thread workgroups owning two row groups)
+GRU_SET_SHIFT = 13   # B2T_GRU_SET_SHIFT: with GRU_PAIRED, bits 13-14 = the sweep's XCD set
+# the exact-fp32 backward sweeps as paired sweeps (B2T_BWD_PAIRED=1; H % 32 == 0, H <= 512, B <= 64 -- other shapes ignore the flag)
+PAIRED_BWD = {"on": os.environ.get("B2T_BWD_PAIRED", "0") not in ("0", "", "false", "False")}
 # which sweeps (exact fp32 or bf16 operands, H <= 512) hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
 # traffic of a backward sweep launch 660 -> 227 MB (1.38x its algorithmic bytes), forward 179 -> 112 MB, a backward launch
 # 935 -> 810-830 us, the step -0.1 ms on two boxes (with WRITE-THROUGH payload stores; ordinary stores cost the GEMMs 0.3-1 ms).
@@ -311,6 +315,8 @@ def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
         local = GRU_LOCAL if (mode == 1 and direction in LOCAL_F32["dirs"] and H <= 512) else 0
         if mode == 1 and direction in WIDE_F32["dirs"] and H % 32 == 0 and H <= 512:
             return mode | GRU_WIDE | local
+        if mode == 1 and direction == "b" and PAIRED_BWD["on"] and local:
+            return mode | local | GRU_PAIRED
         return mode | local
     wide = GRU_WIDE if (direction in AMP["wide"] and H % 32 == 0 and H <= int(os.environ.get("B2T_AMP_WIDE_MAXH", "768"))) else 0
     # C2 with bf16 operands: 11.3 -> 11.15 ms per step; with 32-unit workgroups a row group of H = 768 is 24 workgroups and still

@@ -20,6 +20,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include "common.h"
+#include "gru_cell.h"
 
 namespace b2t {
 namespace {
@@ -295,7 +296,7 @@ constexpr unsigned Q_ANY = 0xffffffffu, Q_MAIN = 1u;
 struct Task {
   const char* name; float est; unsigned qmask; std::vector<int> deps; std::function<void(hipStream_t)> run;
   int q = -1; float start = 0.f, end = 0.f, rank = 0.f; bool cross = false; hipEvent_t ev = nullptr;
-  int cls = -1;   // admission class (XCD set of a sweep under the XCD-local hand-off): at most two tasks of a class in flight
+  int cls = -1;   // admission class (XCD set of a sweep under the XCD-local hand-off): classes 0 / 1 (layer parity) hold two tasks in flight, classes 2..5 (the paired backward sweeps' XCD sets, one workgroup per CU) one
 };
 
 struct Plan {
@@ -383,12 +384,17 @@ std::vector<int> schedule_plan(Plan& P, int nq) {
 // the hand-off timeout (seen under rocprofv3 in the trainer loop, about once in 150 steps).  So the k-th task of a class, in
 // planned start order, waits for the (k-2)-th to finish: never more than two in flight.  The extra edges point forward in a
 // topological order, so the graph stays acyclic; they rarely bind (the third sweep of a parity normally starts later anyway).
+// (Round 5: the paired backward sweeps -- one 512-thread workgroup per CU on the two XCDs of their set -- are classes 2..5 with
+// room for ONE task in flight: the k-th waits for the (k-1)-th.)
+constexpr int N_CLS = 6;
+inline int cls_capacity(int k) { return k < 2 ? 2 : 1; }
 void add_admission_edges(Plan& P, const std::vector<int>& order) {
-  std::vector<int> seen[2];
+  std::vector<int> seen[N_CLS];
   for (int id : order) {
     const int k = P.t[id].cls;
-    if (k < 0 || k > 1) continue;
-    if (seen[k].size() >= 2) P.dep(id, seen[k][seen[k].size() - 2]);
+    if (k < 0 || k >= N_CLS) continue;
+    const size_t cap = (size_t)cls_capacity(k);
+    if (seen[k].size() >= cap) P.dep(id, seen[k][seen[k].size() - cap]);
     seen[k].push_back(id);
   }
 }
@@ -1078,6 +1084,9 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   const long long M = (long long)Tp * B;
   const int mode = p->bwd_mode;
   B2T_REQUIRE((mode & 0xff) == 0 || sync_ws, "model_backward: sync_ws is required for the persistent sweeps");
+  // the backward sweeps with W_hh^T in LDS (B2T_GRU_PAIRED): where the shape allows them, each layer's sweeps go to the XCD set
+  // l & 3 and are admitted one at a time per set (class 2 + set)
+  const bool paired = (mode & B2T_GRU_PAIRED) != 0 && (mode & 0xff) == 1 && !(mode & (B2T_GRU_BF16 | B2T_GRU_WIDE)) && gru_persistent_bwd_pair_ok(B, H);
   Layout w;
   carve(prm, p, reinterpret_cast<char*>(ws), w);
   Ctx c{ex, as_stream(stream), p->bf16_gemm != 0};
@@ -1193,9 +1202,11 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
         c.call(b2t_gru_layer_bwd_f32(w.dY[l] + (long long)t0 * B * H, dh_last, w.res[l] + (long long)t0 * B * 4 * H,
                                      w.out[l] + (long long)(1 + t0) * B * H, w.out[l] + (long long)t0 * B * H, w.whh_t[l],
                                      w.dG[l] + (long long)t0 * B * 4 * H, dh_out, w.scratch[l], n, B, H,
-                                     (mode & B2T_GRU_LOCAL) ? (mode | ((l & 1) ? B2T_GRU_PARITY : 0)) : mode, sync_of(l), ssp));
+                                     paired ? (mode | ((l & 3) << B2T_GRU_SET_SHIFT)) : (mode & B2T_GRU_LOCAL) ? (mode | ((l & 1) ? B2T_GRU_PARITY : 0)) : mode,
+                                     sync_of(l), ssp));
       });
-      if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
+      if (paired) P.t[t_bs[l][ci]].cls = 2 + (l & 3);     // XCD set {l & 3, (l & 3) + 4}: one paired sweep in flight per set
+      else if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
       t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1},

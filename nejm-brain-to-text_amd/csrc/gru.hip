@@ -173,9 +173,14 @@ extern "C" int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, cons
   const bool bf16 = (mode & B2T_GRU_BF16) != 0;
   const bool wide = (mode & B2T_GRU_WIDE) != 0;
   const int local = (mode & B2T_GRU_LOCAL) ? ((mode & B2T_GRU_PARITY) ? 1 : 0) : -1;
-  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE | B2T_GRU_LOCAL | B2T_GRU_PARITY);
+  const bool paired = (mode & B2T_GRU_PAIRED) != 0;
+  const int set = (mode >> B2T_GRU_SET_SHIFT) & 3;
+  mode &= ~(B2T_GRU_BF16 | B2T_GRU_WIDE | B2T_GRU_LOCAL | B2T_GRU_PARITY | B2T_GRU_PAIRED | (3 << B2T_GRU_SET_SHIFT));
   B2T_REQUIRE(mode == 0 || mode == 1, "gru_layer_bwd: unknown mode %d", mode);
   B2T_REQUIRE(!bf16 || mode == 1, "gru_layer_bwd: B2T_GRU_BF16 goes with mode 1");
+  B2T_REQUIRE(!paired || (mode == 1 && !bf16 && !wide), "gru_layer_bwd: B2T_GRU_PAIRED goes with mode 1, exact fp32");
+  if (paired && gru_persistent_bwd_pair_ok(B, H))     // (shapes it does not serve take the register-resident sweep below)
+    return gru_persistent_bwd_pair(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s, set);
   if (mode == 1)
     return gru_persistent_bwd(dY, dh_last, reserve, out, h_init, w_hh_t, dG, dh_init, T, B, H, sync_ws, s, bf16, wide, local);
   B2T_REQUIRE(carry_ws != nullptr, "gru_layer_bwd: carry_ws is required in mode 0 ([B][H] floats)");

@@ -79,4 +79,8 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
                        void* sync_ws, hipStream_t s, bool bf16 = false, bool wide = false, int local = -1);
 
+bool gru_persistent_bwd_pair_ok(int B, int H);
+int gru_persistent_bwd_pair(const float* dY, const float* dh_last, const float* reserve, const float* out, const float* h_init,
+                            const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H, void* sync_ws, hipStream_t s, int set);
+
 }  // namespace b2t

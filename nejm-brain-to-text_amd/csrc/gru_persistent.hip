@@ -679,6 +679,161 @@ __global__ __launch_bounds__(256, 1) void gru_persist_bwd_kernel(const float* __
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward, W_hh^T slice in LDS (round 5; "paired" sweep).  The register-resident backward sweep above holds 96 registers of
+// weights + 96 of operands in flight per lane: two of its workgroups fill a CU's register file, and the 768-block weight-gradient
+// GEMMs and the sweeps then exclude each other (NOTES.md R4.1).  Here ONE 512-thread workgroup per CU owns 16 dh columns of TWO
+// row groups (a "pair": rows [32 pair, 32 pair + 32)): its 96 KB slice of W_hh^T sits in LDS as ready-made MFMA B fragments
+// (1 KB per 16-k chunk, read back with one ds_read_b128 per lane: conflict-free), the 3H-long contraction is split over the
+// EIGHT waves, and every wave uses each B fragment twice -- once per row group.  Per lane: 96 registers of operands in flight
+// (the latency buffer, NOTES.md R4.10c) + 8 accumulators + transients, so that a 128-register GEMM workgroup stays resident
+// next to it on every CU (LDS: 96 KB weights + 18 KB transpose slots, reused for the eight-way sum, + 10 KB gate tiles = 124 KB
+// of 160; the GEMM takes 33 KB).  Placement: pair p of a sweep of XCD set s (0..3, chosen by the caller per layer) runs on XCD
+// (4 p + s) & 7, one workgroup per CU, tiles by ticket order; the XCD-local hand-off as above with ONE counter per pair and step.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pair_role(unsigned* tickets, int npairs, unsigned G, int set, int& pair, int& tile) {
+  __shared__ int role[2];
+  if (threadIdx.x == 0) {
+    const unsigned x = xcc_id();
+    int r = -1;
+    for (int i = 0; i < npairs; ++i) if ((unsigned)((4 * i + set) & 7) == x) r = i;
+    int tk = -1;
+    if (r >= 0) {
+      tk = (int)__hip_atomic_fetch_add(tickets + x, 1u, RLX_AGENT);
+      if (tk >= (int)G) r = -1;
+    }
+    role[0] = r; role[1] = tk;
+  }
+  __syncthreads();
+  pair = role[0]; tile = role[1];
+  return pair >= 0;
+}
+
+constexpr int PAIR_STAGE_F = 2 * SLOT_F;          // floats of a wave's transpose slot pair (>= 2 tiles x 4 x 64 partial sums)
+constexpr int PAIR_GS_F = 2 * 4 * 16 * TP;        // staged gate-gradient tiles [2 row groups][4 arrays][16 rows][TP]
+template <int NCB8> constexpr size_t pair_lds_bytes() { return ((size_t)8 * NCB8 * 64 * 4 + 8 * PAIR_STAGE_F + PAIR_GS_F) * sizeof(float); }
+
+template <int NCB8>   // 16-wide chunks of the 3H contraction per wave (8 waves: 3H <= 128 NCB8), even
+__global__ __launch_bounds__(512) void gru_persist_bwd_pair_kernel(const float* __restrict__ dY, const float* __restrict__ dh_last,
+                                                                    const float* __restrict__ reserve, const float* __restrict__ out,
+                                                                    const float* __restrict__ h_init, const float* __restrict__ w_hh_t,
+                                                                    float* dG, float* __restrict__ dh_init, int T, int B, int H,
+                                                                    unsigned* sync, int set) {
+  extern __shared__ __attribute__((aligned(16))) float pair_lds[];
+  float4* wl = reinterpret_cast<float4*>(pair_lds);            // [8 waves][NCB8][64 lanes]: B fragments of the W_hh^T slice
+  float* stage_all = pair_lds + 8 * NCB8 * 64 * 4;             // [8 waves][PAIR_STAGE_F]
+  float* gs = stage_all + 8 * PAIR_STAGE_F;                    // [2][4][16][TP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);
+  const unsigned G = (unsigned)H / 16u;
+  const int j = lane & 15, q = lane >> 4;
+  unsigned* err = sync;
+  const unsigned pset = __hip_atomic_load(sync + 1, RLX_AGENT) & 1u;
+  {
+    unsigned* other = sync + 32 + (size_t)(1u - pset) * SETW;
+    const int nthr = gridDim.x * gridDim.y * 512;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 512 + threadIdx.x; i < SETW; i += nthr) other[i] = 0u;
+  }
+  const int ngrp = (B + 15) / 16;
+  int pair, tile;
+  if (!pair_role(sync + 32 + (size_t)pset * SETW + (SETW - 16), (ngrp + 1) / 2, G, set, pair, tile)) { finish_call(sync, pset); return; }
+  const int unit = tile * 16 + j;
+  const int nch = 3 * H / 16;
+  float4* wmine = wl + (size_t)wave * NCB8 * 64 + lane;      // written and read by the same lane of the same wave: no barrier
+#pragma unroll
+  for (int ci = 0; ci < NCB8; ++ci) {
+    const int c = wave * NCB8 + ci;
+    wmine[ci * 64] = c < nch ? *reinterpret_cast<const float4*>(w_hh_t + (long long)unit * 3 * H + c * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float* stage = stage_all + wave * PAIR_STAGE_F;
+  const int sel = wave >> 2, wq = wave & 3;                   // this thread's element: row group `sel` of the pair, row 4 q + wq, column j
+  const int m0a = 32 * pair, m0b = 32 * pair + 16;
+  const int m0 = sel ? m0b : m0a;
+  const int row = m0 + 4 * q + wq;
+  const bool live = row < B;
+  unsigned* cnt = sync + 32 + (size_t)pset * SETW + (size_t)(2 * pair) * T * CSTRIDE;   // the pair's counters: those of its first row group
+  float dzterm = 0.f;
+  const int r8 = lane >> 3, p8 = lane & 7;
+
+  for (int t = T - 1; t >= -1; --t) {
+    float r = 0.f, z = 0.f, nv = 0.f, ghn = 0.f, hprev = 0.f, dy = 0.f, carry = 0.f;
+    if (live && t >= 0) {
+      const float* rs = reserve + ((long long)t * B + row) * 4 * H + unit;
+      r = __builtin_nontemporal_load(rs); z = __builtin_nontemporal_load(rs + H); nv = __builtin_nontemporal_load(rs + 2 * H); ghn = __builtin_nontemporal_load(rs + 3 * H);
+      hprev = t > 0 ? out[((long long)(t - 1) * B + row) * H + unit] : h_init[(long long)row * H + unit];
+      dy = __builtin_nontemporal_load(dY + ((long long)t * B + row) * H + unit);
+    }
+    if (t < T - 1) {
+      wait_count_local(cnt + (size_t)(t + 1) * CSTRIDE, G, err);
+      const float* dgh = dG + (long long)(t + 1) * B * 4 * H;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      // all operand loads of BOTH row groups go out first, in the order they are consumed (pair of chunks p: row group a rows
+      // 0-7, 8-15, then row group b), line-wise as in issue_block_loads; clamped, branch-free
+      float4 v[2 * NCB8];
+#pragma unroll
+      for (int i = 0; i < 2 * NCB8; ++i) {
+        const int p = i >> 2, s2 = (i >> 1) & 1, h8 = i & 1;
+        const int rr = (s2 ? m0b : m0a) + h8 * 8 + r8, col = (wave * NCB8 + 2 * p) * 16 + p8 * 4;
+        const long long off = (long long)(rr < B ? rr : B - 1) * 4 * H + (col < 3 * H ? col : 3 * H - 4);
+        v[i] = load_f4<0>(dgh, (unsigned)(off * 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < NCB8 / 2; ++p) {
+        const float4 b0 = wmine[(2 * p) * 64], b1 = wmine[(2 * p + 1) * 64];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float4 a0, a1;
+          transpose_pair(stage, v[4 * p + 2 * s2], v[4 * p + 2 * s2 + 1], a0, a1, lane);
+          acc[s2] = mfma_chunk16<false>(a0, b0, acc[s2]);
+          acc[s2] = mfma_chunk16<false>(a1, b1, acc[s2]);
+        }
+      }
+      asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]));
+      // eight-way sum through the waves' own slot pairs (free now: a wave's LDS operations execute in order)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) stage[(s2 * 4 + rr) * 64 + lane] = acc[s2][rr];
+      __syncthreads();
+      float sum[8];
+#pragma unroll
+      for (int sw = 0; sw < 8; ++sw) sum[sw] = stage_all[sw * PAIR_STAGE_F + (sel * 4 + wq) * 64 + lane];
+      carry = (((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]))) + dzterm;
+    } else if (dh_last && live) {
+      carry = dh_last[(long long)row * H + unit];
+    }
+    if (t < 0) {
+      if (live) dh_init[(long long)row * H + unit] = carry;
+      continue;
+    }
+    if (live) {
+      const float d = dy + carry;
+      const float dn = d * (1.0f - z);
+      const float dz = d * (hprev - nv);
+      const float dn_pre = dn * (1.0f - nv * nv);
+      const float dz_pre = dz * z * (1.0f - z);
+      const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+      const int lr = 4 * q + wq;
+      float* g0 = gs + sel * 4 * 16 * TP;
+      g0[(0 * 16 + lr) * TP + j] = dr_pre;
+      g0[(1 * 16 + lr) * TP + j] = dz_pre;
+      g0[(2 * 16 + lr) * TP + j] = dn_pre * r;
+      g0[(3 * 16 + lr) * TP + j] = dn_pre;
+      dzterm = d * z;
+    }
+    __syncthreads();   // tiles staged; every wave has read its sums (the slot pairs are free for the next step's transposes)
+    {   // wave w writes gate array w & 3 of row group w >> 2: 64 x 16 B write-through stores
+      const int r2 = lane >> 2, c4 = (lane & 3) * 4;
+      if (m0 + r2 < B)
+        store_f4<B2T_LOC_ST_AUX>(dG + (long long)t * B * 4 * H, (unsigned)(((long long)(m0 + r2) * 4 * H + wq * H + tile * 16 + c4) * 4),
+                                 *reinterpret_cast<const float4*>(&gs[((sel * 4 + wq) * 16 + r2) * TP + c4]));
+    }
+    publish_count_local(cnt + (size_t)t * CSTRIDE);
+  }
+  finish_call(sync, pset);
+}
+
 #ifdef B2T_TIMING
 }  // namespace b2t
 extern "C" int b2t_debug_bwd_times(unsigned* host) {
@@ -850,6 +1005,42 @@ int gru_persistent_fwd_fused(const float* gi, const float* w_hh, const float* b_
   else B2T_FUSED_GO(8, 2);
 #undef B2T_FUSED_GO
   return check_hip(hipGetLastError(), "gru_layer_fwd_fused (persistent)");
+}
+
+// The paired backward sweep (W_hh^T in LDS): usable where the XCD-local hand-off is (H % 32 == 0, H <= 512, B <= 64, round-robin
+// dispatch verified) -- the caller falls back to gru_persistent_bwd otherwise.  set: 0..3, the XCD set {set, set + 4}.
+bool gru_persistent_bwd_pair_ok(int B, int H) {
+  return H % 32 == 0 && H <= 512 && (B + 15) / 16 <= 4 && gru_xcd_dispatch_ok();
+}
+int gru_persistent_bwd_pair(const float* dY, const float* dh_last, const float* reserve, const float* out, const float* h_init,
+                            const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H, void* sync_ws, hipStream_t s, int set) {
+  int rc = check_grid(B, H, T, sync_ws, "gru_layer_bwd (paired)");
+  if (rc) return rc;
+  if (!gru_persistent_bwd_pair_ok(B, H)) { set_error("gru_layer_bwd (paired): needs H %% 32 == 0, H <= 512, B <= 64 and round-robin XCD dispatch"); return 2; }
+  const int G = H / 16;
+  const dim3 grid(8 * G, 1), block(512);
+  unsigned* sync = reinterpret_cast<unsigned*>(sync_ws);
+#define B2T_PAIR_GO(NCB8)                                                                                                          \
+  do {                                                                                                                             \
+    static bool attr = false;                                                                                                      \
+    if (!attr) {                                                                                                                   \
+      rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_persist_bwd_pair_kernel<NCB8>),                         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds_bytes<NCB8>()), "gru_layer_bwd (paired): LDS size"); \
+      if (rc) return rc;                                                                                                           \
+      attr = true;                                                                                                                 \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gru_persist_bwd_pair_kernel<NCB8>), grid, block, pair_lds_bytes<NCB8>(), s, dY, dh_last, reserve, out, h_init, \
+                       w_hh_t, dG, dh_init, T, B, H, sync, set & 3);                                                               \
+  } while (0)
+  const int per_wave = (3 * H / 16 + 7) / 8;
+  if (per_wave <= 2) B2T_PAIR_GO(2);
+  else if (per_wave <= 4) B2T_PAIR_GO(4);
+  else if (per_wave <= 6) B2T_PAIR_GO(6);
+  else if (per_wave <= 8) B2T_PAIR_GO(8);
+  else if (per_wave <= 10) B2T_PAIR_GO(10);
+  else B2T_PAIR_GO(12);
+#undef B2T_PAIR_GO
+  return check_hip(hipGetLastError(), "gru_layer_bwd (paired)");
 }
 
 int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reserve, const float* out,

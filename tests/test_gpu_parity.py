@@ -579,6 +579,45 @@ def test_persistent_sweep_odd_shapes_match_step_launch(B, H, T, wide):
                 assert torch.equal(a, r), (name, extra)
 
 
+@pytest.mark.parametrize("B,H,T", [(64, 512, 24), (40, 288, 9), (23, 96, 7), (17, 32, 5), (64, 256, 130), (33, 384, 11), (64, 480, 6), (5, 64, 12)])
+def test_paired_backward_sweep_matches_step_launch(B, H, T):
+    """Round 5: the backward sweep with its W_hh^T slice in LDS (B2T_GRU_PAIRED: 512-thread workgroups owning 16 dh columns of two row
+    groups, the contraction split over eight waves) against the step-launch kernels -- dG and dh0, every XCD set, repeated calls on
+    one sync workspace (the counter sets alternate), odd numbers of row groups (a pair with one live group) and ragged last groups."""
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev(); p = ops._p
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    rnd = lambda *s: (torch.randn(*s, generator=g)).to(dev)
+    gi, w, b_, h0 = rnd(T, B, 3 * H) * 0.5, rnd(3 * H, H) * (1.0 / H ** 0.5), rnd(3 * H) * 0.1, rnd(B, H) * 0.3
+    dY, dhl = rnd(T, B, H) * 0.05, rnd(B, H) * 0.05
+    wt = w.t().contiguous()
+    out = torch.zeros(T + 1, B, H, device=dev); out[0] = h0
+    res = torch.zeros(T, B, 4 * H, device=dev)
+    sync = torch.zeros(lib.b2t_gru_ws_bytes(T, B, H) // 4 + 16, dtype=torch.int32, device=dev)
+    Nn.check(lib.b2t_gru_layer_fwd_f32(p(gi), p(w), p(b_), p(out[0]), p(out[1:]), p(res), None, T, B, H, 0, p(sync), ops._stream()), "fwd")
+
+    def bwd(mode):
+        dG = torch.full((T, B, 4 * H), float("nan"), device=dev); dh = torch.full((B, H), float("nan"), device=dev); sc = torch.empty(B, H, device=dev)
+        Nn.check(lib.b2t_gru_layer_bwd_f32(p(dY), p(dhl), p(res), p(out[1:]), p(out[0]), p(wt), p(dG), p(dh), p(sc), T, B, H,
+                                           mode, p(sync), ops._stream()), "bwd")
+        torch.cuda.synchronize()
+        assert int(sync[0]) == 0
+        return dG, dh
+
+    ref = bwd(0)
+    first = None
+    for rep in range(2):
+        for st in range(4):
+            got = bwd(1 | ops.GRU_LOCAL | ops.GRU_PAIRED | (st << ops.GRU_SET_SHIFT))
+            for a, r, name in zip(got, ref, ("dG", "dh0")):
+                np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), atol=3e-6 * max(1.0, float(r.abs().max())), err_msg=f"{name} set {st}")
+            if first is None:
+                first = got
+            for a, r in zip(got, first):       # placement changes where the work runs, not the arithmetic
+                assert torch.equal(a, r), st
+
+
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 41, 37), (33, 300, 129), (512, 1536, 520), (640, 256, 4100)])
 def test_gemm_bf16_packed(akc, bkc, M, N, K):

@@ -645,6 +645,53 @@ def test_xcd_local_handoff_is_bit_identical(monkeypatch):
             assert torch.equal(got, ref) and torch.equal(l2, loss), f"B2T_GRU_LOCAL={dirs!r} at H={H}, B={B}"
 
 
+def test_paired_backward_sweeps_in_the_step(monkeypatch):
+    """Round 5: the step with its backward sweeps as paired sweeps (W_hh^T in LDS, one per XCD set in flight, csrc/exec.cpp classes
+    2..5).  The eight-way split of the contraction sums in another order than the register-resident sweep's four-way split, so
+    the contract against the default path is a tolerance (2e-5 of the largest gradient); against ITSELF the path is exact: the
+    same gradient arena, bit for bit, under four timing-jitter seeds (B2T_EXEC_JITTER) of the pipelined plan."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    for (F, H, D, C, L, B, T, S, chunks) in ((64, 512, 4, 41, 5, 64, 120, 10, (6, 4)), (32, 96, 3, 41, 2, 37, 50, 6, (2, 2)), (64, 256, 4, 41, 3, 48, 96, 8, (3, 3))):
+        g = torch.Generator().manual_seed(B)
+        x = torch.randn(B, T, F, generator=g).to(dev)
+        day = torch.randint(0, D, (B,), generator=g)
+        tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(2, S + 1, (B,), generator=g)
+        nt = torch.randint(T - 10, T + 1, (B,), generator=g)
+        for b in range(B):
+            tgt[b, tl[b]:] = 0
+        monkeypatch.setitem(ops.PIPELINE, "chunks", chunks[0])
+        monkeypatch.setitem(ops.PIPELINE, "chunks_bwd", chunks[1])
+
+        def grads(paired, jitter=None):
+            monkeypatch.setitem(ops.PAIRED_BWD, "on", paired)
+            if jitter is None:
+                monkeypatch.delenv("B2T_EXEC_JITTER", raising=False)
+            else:
+                monkeypatch.setenv("B2T_EXEC_JITTER", str(jitter))
+            torch.manual_seed(3)
+            m = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
+            ts = TrainStep(m, step_args())
+            loss_b = ts.compute_grads(x, day, tgt, nt, tl)
+            torch.cuda.synchronize()
+            m._ws.check_sync()
+            ts.check_status()
+            return ts.grad_arena.clone(), loss_b.clone()
+
+        ref, loss = grads(False)
+        got, l2 = grads(True)
+        assert torch.equal(l2, loss)                       # the forward pass is the same code
+        assert not torch.equal(got, ref), "the paired sweeps did not engage"
+        worst = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert worst < 2e-5, f"H={H} B={B}: paired vs register-resident backward sweeps differ by {worst:.2e} of the largest gradient"
+        for seed in range(4):
+            again, l3 = grads(True, jitter=seed)
+            assert torch.equal(again, got) and torch.equal(l3, loss), f"H={H} B={B}: paired sweeps, jitter seed {seed}"
+    monkeypatch.delenv("B2T_EXEC_JITTER", raising=False)
+
+
 @pytest.mark.parametrize("tag", ["patch", "h256"])
 def test_bf16_mode_forward_against_the_reference_autocast_forward(golden_dir, tag):
     """`use_amp: true` (rnn_args.yaml:19; rnn_trainer.py:527, :704 wrap the model call in torch.autocast(dtype=bfloat16)).  Fixture:
