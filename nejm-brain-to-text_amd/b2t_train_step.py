@@ -99,6 +99,13 @@ class GradReducer:
         # stream of the process group joins the plan's queues (a fifth hardware queue shares a command-processor pipe and makes
         # every cross-queue hop of the pass slower), no event pair per bucket.
         self.inline = os.environ.get("B2T_DP_INLINE", "1") == "1"
+        self.test_delay_us = float(os.environ.get("B2T_DP_TEST_DELAY_US", "0"))
+        self._delay_cycles = None
+        if self.test_delay_us > 0 and grad_arena.is_cuda:      # calibrate torch's spin kernel once, outside any pass
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(1000); torch.cuda.synchronize()
+            e0.record(); torch.cuda._sleep(2_000_000); e1.record(); torch.cuda.synchronize()
+            self._delay_cycles = max(1, int(2_000_000 * self.test_delay_us * 1e-3 / max(1e-3, e0.elapsed_time(e1))))
 
     def set_sparse_days(self, active: torch.Tensor, seg_of_day: torch.Tensor, w0: int, w_stride: int, b0: int, b_stride: int,
                         n_days: int, capacity: int, status: torch.Tensor):
@@ -108,27 +115,45 @@ class GradReducer:
         into one staging buffer, all-reduces THAT (capacity x 1.05 MB) and scatters it back.  No host synchronisation: the
         records are chosen by a stable device-side sort of the flags (inactive days fill the tail: their gradients are zero on
         every rank); should more days be active than `capacity` holds, status word 3 refuses the step (check_status raises)."""
-        self.sparse = dict(active=active, seg=seg_of_day, w0=w0, ws=w_stride, b0=b0, bs=b_stride, D=n_days, K=min(capacity, n_days),
-                           status=status, stage=torch.empty((min(capacity, n_days), w_stride + b_stride), dtype=self.arena.dtype, device=self.arena.device),
-                           order=None)
+        K, dev, dt = min(capacity, n_days), self.arena.device, self.arena.dtype
+        # every tensor the reduction touches is allocated HERE, once: _start() runs inside the executor's bucket callback on one
+        # of its queues and finish() on the caller's stream -- nothing of the exchange then comes from the caching allocator of
+        # a stream other than the one that later reads it (no record_stream needed; ordering is the executor's join)
+        stage = torch.empty(K * (w_stride + b_stride), dtype=dt, device=dev)
+        self.sparse = dict(active=active, seg=seg_of_day, w0=w0, ws=w_stride, b0=b0, bs=b_stride, D=n_days, K=K, status=status,
+                           stage=stage, stage_w=stage[:K * w_stride].view(K, w_stride), stage_b=stage[K * w_stride:].view(K, b_stride),
+                           flags=torch.empty(n_days, dtype=active.dtype, device=dev), sorted=torch.empty(n_days, dtype=active.dtype, device=dev),
+                           order_full=torch.empty(n_days, dtype=torch.int64, device=dev), nact=torch.empty(1, dtype=status.dtype, device=dev),
+                           over=torch.empty(1, dtype=status.dtype, device=dev), pending=False)
 
     def _start(self, name: str):
         a, b = self.buckets[name]
         sp = getattr(self, "sparse", None)
         if name == "day" and sp is not None and sp["K"] < sp["D"]:
-            flags = sp["active"][sp["seg"]]                                   # [n_days] 0 / 1, identical on every rank (union_active ran)
-            torch.maximum(sp["status"], (flags.sum() > sp["K"]).to(sp["status"].dtype) * 3.0, out=sp["status"])
-            order = torch.sort(flags, descending=True, stable=True).indices[:sp["K"]]
+            torch.index_select(sp["active"], 0, sp["seg"], out=sp["flags"])   # [n_days] 0 / 1, identical on every rank (union_active ran)
+            # status 3 = more active days than the staging buffer holds.  Precedence: the status word is a MAX, so 3 outranks a
+            # concurrent 1 (hand-off timeout) or 2 (non-finite norm): the step is refused either way, and 3 is a configuration
+            # error the trainer raises on instead of retrying with the deferred reduction (check_status)
+            torch.sum(sp["flags"], dim=0, keepdim=True, dtype=sp["nact"].dtype, out=sp["nact"])
+            torch.sub(sp["nact"], float(sp["K"]), out=sp["over"])             # integer counts: clamp(n - K, 0, 1) = (n > K)
+            sp["over"].clamp_(0.0, 1.0).mul_(3.0)
+            torch.maximum(sp["status"], sp["over"], out=sp["status"])
+            torch.sort(sp["flags"], descending=True, stable=True, out=(sp["sorted"], sp["order_full"]))
+            order = sp["order_full"][:sp["K"]]
             W = self.arena[sp["w0"]:sp["w0"] + sp["D"] * sp["ws"]].view(sp["D"], sp["ws"])
             Bv = self.arena[sp["b0"]:sp["b0"] + sp["D"] * sp["bs"]].view(sp["D"], sp["bs"])
-            sp["stage"][:, :sp["ws"]].copy_(W.index_select(0, order))
-            sp["stage"][:, sp["ws"]:].copy_(Bv.index_select(0, order))
-            sp["order"] = order
+            torch.index_select(W, 0, order, out=sp["stage_w"])
+            torch.index_select(Bv, 0, order, out=sp["stage_b"])
+            sp["pending"] = True
             self._reduce(sp["stage"])
             return
         self._reduce(self.arena[a:b])
 
     def _reduce(self, t: torch.Tensor):
+        if self._delay_cycles is not None and t.is_cuda:
+            # measurement knob (B2T_DP_TEST_DELAY_US): a device-side spin on the stream the collective is about to run on stands for
+            # a peer that arrives late -- what a blocking all-reduce on an executor queue costs the plan (bench `dp_forced_one_rank`)
+            torch.cuda._sleep(self._delay_cycles)
         if self.inline:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=False)
         else:
@@ -150,12 +175,13 @@ class GradReducer:
             w.wait()
         self.pending = []
         sp = getattr(self, "sparse", None)
-        if sp is not None and sp["order"] is not None:                        # scatter the reduced day records back
+        if sp is not None and sp["pending"]:                                  # scatter the reduced day records back
             W = self.arena[sp["w0"]:sp["w0"] + sp["D"] * sp["ws"]].view(sp["D"], sp["ws"])
             Bv = self.arena[sp["b0"]:sp["b0"] + sp["D"] * sp["bs"]].view(sp["D"], sp["bs"])
-            W.index_copy_(0, sp["order"], sp["stage"][:, :sp["ws"]])
-            Bv.index_copy_(0, sp["order"], sp["stage"][:, sp["ws"]:])
-            sp["order"] = None
+            order = sp["order_full"][:sp["K"]]
+            W.index_copy_(0, order, sp["stage_w"])
+            Bv.index_copy_(0, order, sp["stage_b"])
+            sp["pending"] = False
 
     def union_status(self, status: torch.Tensor):
         """status word = max over ranks: a step one rank refuses (hand-off timeout) is refused by every rank, and every

@@ -95,7 +95,7 @@ def _sparse_worker(rank, world, port, q):
                 red.launch(name)
             red.finish()
             want = sum(arenas)
-            res[case] = (bool(torch.allclose(arena, want, atol=1e-6)), float(status[0]), tuple(red.sparse["stage"].shape))
+            res[case] = (bool(torch.allclose(arena, want, atol=1e-6)), float(status[0]), tuple(red.sparse["stage_w"].shape))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()

@@ -77,3 +77,26 @@ def test_model_step_matches_the_oracle_on_random_small_shapes(seed):
         for k, ref in got[False][1].items():
             scale = max(1e-6, float(np.abs(ref).max()))
             assert float(np.abs(got[True][1][k] - ref).max()) <= 0.12 * scale, (tag, k)
+
+
+@pytest.mark.gpu
+def test_passes_replayed_as_graphs_follow_the_eager_plan():
+    """B2T_EXEC_GRAPH=1 (opt-in, EXPERIMENTAL): passes whose arguments repeat are built once as hipGraphs from the plan's task graph
+    and replayed.  Restored in round 5 with what was measured since: the EAGER plan is bit-stable under 200 timing-jitter seeds at
+    this shape and at BASELINE configs[1] (test_plan_results_do_not_depend_on_task_timing, tools/r5_jitter.py: no missing edge found),
+    while a replayed graph of the same edges ended 2e-5 / 3e-6 off the eager loss trajectory in 1 of 6 / 2 of 11 processes
+    (flat graphs; child-graph form 0 of 6): the deviation is the graph runtime's, not the plan's, so this test asserts what the
+    mode guarantees -- passes really are replayed, the trajectory follows the eager plan's to 1e-4 relative -- and PRINTS whether
+    this process was bit-identical."""
+    outs = {}
+    for g in ("0", "1"):
+        env = dict(os.environ, B2T_EXEC_GRAPH=g)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r4_graph_probe.py"), "12"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[g] = [l for l in r.stdout.splitlines() if l.startswith("graph=")][-1]
+    sums = {g: float(l.split("sum")[1]) for g, l in outs.items()}
+    stats = outs["1"].split("failed (")[1].split(")")[0].split(",")
+    assert int(stats[0]) > 0 and int(stats[1]) > 0 and stats[2].strip() == "False", outs["1"]
+    print("graph replay vs eager plan:", "bit-identical loss trajectory" if outs["0"].split("losses")[1] == outs["1"].split("losses")[1]
+          else f"trajectories differ by {abs(sums['1'] - sums['0']) / abs(sums['0']):.1e} relative", "|", outs["1"])
+    assert abs(sums["1"] - sums["0"]) <= 1e-4 * abs(sums["0"]), outs

@@ -190,7 +190,7 @@ def _per_args(tmp, amp, n_batches):
     return a
 
 
-def test_bf16_mode_phoneme_error_rate_within_a_tenth_of_a_percent(tmp_path):
+def test_bf16_mode_phoneme_error_rate_same_weights_0p1_percent_trained_0p3_percent(tmp_path):
     """The acceptance BASELINE.json's north star names for the bf16 regime (`use_amp: true`, rnn_trainer.py:535 autocast):
     phoneme error rate within +-0.1 % (absolute) of the fp32 path.  Two ways, on the learnable synthetic copy task with a
     validation set of 1280 sentences (~9.6 k phonemes: one phoneme = 0.01 %):

@@ -286,8 +286,14 @@ def dp_forced_one_rank(steps: int = 30):
     deferred = run({"B2T_DP_FORCE": "1", "B2T_DP_DEFERRED": "1"})
     dense = run({"B2T_DP_FORCE": "1", "B2T_DP_DENSE_DAYS": "1"})
     comm_stream = run({"B2T_DP_FORCE": "1", "B2T_DP_INLINE": "0"})
+    # what a WAITING peer costs (round-5 verdict item 6): every collective preceded by a 0.5 ms device-side spin on the stream it
+    # runs on (B2T_DP_TEST_DELAY_US) -- blocking on the executor queue that produced the bucket against deferred behind the pass
+    slow_inline = run({"B2T_DP_FORCE": "1", "B2T_DP_TEST_DELAY_US": "500"})
+    slow_deferred = run({"B2T_DP_FORCE": "1", "B2T_DP_TEST_DELAY_US": "500", "B2T_DP_DEFERRED": "1"})
     out = dict(plain=plain, forced_rccl_next_to_sweeps=forced, forced_rccl_deferred_behind_backward=deferred,
                forced_rccl_dense_day_bucket=dense, forced_rccl_on_the_process_groups_comm_stream=comm_stream,
+               each_collective_0p5ms_late_blocking_on_the_executor_queue=slow_inline,
+               each_collective_0p5ms_late_deferred_behind_backward=slow_deferred,
                workload="the headline C2 step, one rank: every collective of the N-rank step runs (identity results); best of two child runs each")
     if "ms_per_step" in plain and "ms_per_step" in forced:
         out["forced_over_plain"] = round(forced["ms_per_step"] / plain["ms_per_step"], 4)
