@@ -365,6 +365,7 @@ def main():
     if ts.reducer is not None and os.environ.get("B2T_DP_DEFERRED", "0") == "1":
         ts.reducer.deferred = True                 # measurement knob: all-reduce behind the backward pass (the post-refusal fallback)
     sampler = BoxSampler(dev) if world == 1 else None
+    host_api = ops.host_api_probe() if world == 1 else None       # this process's runtime-call latencies (slow-host mode signature)
     try:
         if sampler:
             sampler.start()
@@ -394,7 +395,8 @@ def main():
     slow_ms = float(os.environ.get("B2T_BENCH_SLOW_ENQ_MS", "3.0"))
     runs = json.loads(os.environ.get("B2T_BENCH_PROCESS_RUNS", "[]"))
     runs.append(dict(process=restarts + 1, ms_per_step=round(dt / a.steps * 1e3, 3), host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3),
-                     sentences_per_s=round(rows * world * a.steps / dt, 2)))
+                     sentences_per_s=round(rows * world * a.steps / dt, 2),
+                     kernel_launch_us_p50=host_api["kernel_launch_us"]["p50"] if host_api else None))
     if (world == 1 and not force_dp and t_enq / a.steps * 1e3 > slow_ms and restarts < 2
             and os.environ.get("B2T_BENCH_NO_RESTART") is None):
         os.environ["B2T_BENCH_PROCESS_RUNS"] = json.dumps(runs)
@@ -405,6 +407,7 @@ def main():
         os.execv(sys.executable, [sys.executable] + sys.argv)
     if box is not None:
         box["process_restarts"] = restarts
+        box["host_api_us"] = host_api
     dt_this = dt
     if world == 1 and not force_dp and runs:
         dt = runs[0]["ms_per_step"] * 1e-3 * a.steps      # headline = the first process

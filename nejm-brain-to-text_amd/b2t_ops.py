@@ -326,6 +326,36 @@ def sweep_mode_arg(mode: int, H: int = 0, direction: str = "f") -> int:
     return mode | GRU_BF16 | wide | local
 
 
+def host_api_probe(n: int = 200) -> dict:
+    """Host latency (microseconds, p50 / p90) of the three runtime calls a pass is made of -- a small kernel launch through the C ABI,
+    hipEventRecord, hipStreamWaitEvent -- taken at start-up (~3 ms).  On this pool a process sometimes comes up in a mode in which
+    every HIP call of its whole life is 2.5-3x slower (NOTES.md 5 / R4.10d / R5.5: host enqueue 4.3-4.7 ms per C2 step instead of
+    1.1-1.6, the step 1-2 ms slower); a healthy process measures ~7.3 / 4.7 / 0.5 us here (14 processes under six environments,
+    `tools/r5_slowmode.py`).  `slow` = the kernel launch's p50 above 15 us.  The trainer logs the numbers (and a warning when slow);
+    bench.py reports them in `box`, so that a run caught in the mode carries its signature."""
+    import time
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = torch.zeros(64, 64, device=dev); b = torch.zeros(64, 64, device=dev)
+    lib = N.load()
+    s2, ev = torch.cuda.Stream(), torch.cuda.Event()
+    out = {}
+    for name, fn in (("kernel_launch_us", lambda: lib.b2t_transpose_f32(_p(a), _p(b), 64, 64, _stream())),
+                     ("event_record_us", lambda: ev.record()), ("stream_wait_event_us", lambda: s2.wait_event(ev))):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for i in range(n):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+            if i % 50 == 49:
+                torch.cuda.synchronize()
+        ts.sort()
+        out[name] = dict(p50=round(ts[len(ts) // 2] * 1e6, 2), p90=round(ts[int(len(ts) * 0.9)] * 1e6, 2))
+    torch.cuda.synchronize()
+    out["slow"] = bool(out["kernel_launch_us"]["p50"] > 15.0)
+    return out
+
+
 def gru_sync_check(sync_ws, T: int, B: int):
     """Raise if the last persistent sweep on sync_ws reported a hand-off timeout (synchronises)."""
     st = C.c_int(0)

@@ -21,6 +21,7 @@
 #include <unordered_set>
 #include "common.h"
 #include "gru_cell.h"
+#include "gemm_args.h"
 
 namespace b2t {
 namespace {
@@ -99,6 +100,7 @@ struct Layout {
   float *slab[MAXL], *slab_head, *s4[MAXL], *cs_layer[MAXL], *asum[MAXL], *cs_head, *cs_day, *cs_h0, *slab_dx;
   char* pack[NPACK];       // amp mode: per-queue scratch of the two-pass bf16 GEMM (packed operands)
   size_t pack_bytes;
+  char *wpk_f[MAXL], *wpk_b[MAXL];   // amp mode: W_ih of every layer packed once per pass -- as the projection's B operand (forward), as the input gradient's (backward)
   size_t bytes;
 };
 
@@ -139,7 +141,12 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     w.pack_bytes = align_up(w.pack_bytes, 256);
     for (int q = 0; q < NPACK; ++q) { w.pack[q] = base + off; off += w.pack_bytes; }
   }
+  for (size_t l = 0; l < MAXL; ++l) w.wpk_f[l] = w.wpk_b[l] = nullptr;
+  if (p->bf16_gemm)
+    for (size_t l = 0; l < L; ++l) { w.wpk_f[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(3 * H), (int)(l == 0 ? In0 : H)), 256); }
   if (!p->save) { w.bytes = off; return; }
+  if (p->bf16_gemm)
+    for (size_t l = 0; l < L; ++l) { w.wpk_b[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(3 * H)), 256); }
   for (size_t l = 0; l < L; ++l) w.res[l] = take(Tp * B * 4 * H);
   const size_t K = Tp * B;
   for (size_t l = 0; l < L; ++l) {
@@ -221,8 +228,12 @@ struct Ctx {
 
   // C = A.B^T through b2t_gemm_f32 / b2t_gemm_bf16_f32.  splitk > 1: partial products go to `slab` ([splitk][M*N]) and
   // are summed deterministically into C by b2t_slab_reduce_f32 (weight gradients, K = T*B; streaming-sized projections).
-  void gemm(hipStream_t s, b2t_gemm_desc d, int splitk = 1, float* slab = nullptr, int accumulate = 0, int kslot = -1) {
+  // Bp_pre: the B operand already packed for the two-pass bf16 kernel (the pass's weights, packed once: round 5); dropA: nn.GRU's
+  // inter-layer dropout folded into the A pack.  Both only where would_pack(d, s) holds (the caller checks).
+  void gemm(hipStream_t s, b2t_gemm_desc d, int splitk = 1, float* slab = nullptr, int accumulate = 0, int kslot = -1,
+            const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr) {
     if (rc) return;
+    if ((Bp_pre || dropA) && !(bf16_gemm && would_pack(d, s))) { set_error("exec: pre-packed operands need the two-pass bf16 GEMM"); rc = 2; return; }
     void* st = reinterpret_cast<void*>(s);
     const int kind = (bf16_gemm ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     const double flops = 2.0 * d.M * d.N * (double)d.K * (d.Z > 0 ? d.Z : 1);
@@ -243,7 +254,7 @@ struct Ctx {
       if (fused) { d.ks_counters = kcnt + (size_t)kslot * KSLOT; d.ks_out = Cdst; d.ks_accumulate = accumulate; }
       {
         Scope sc(*this, s, kind, flops);
-        rc = bf16_gemm ? gemm_amp(d, s) : b2t_gemm_f32(&d, st);
+        rc = bf16_gemm ? gemm_amp(d, s, Bp_pre, dropA) : b2t_gemm_f32(&d, st);
       }
       if (!rc && !fused) rc = b2t_slab_reduce_f32(slab, splitk, (long long)d.M * d.N, Cdst, accumulate, st);
       return;
@@ -251,7 +262,7 @@ struct Ctx {
     d.accumulate = accumulate;
     if (exact_k && d.splitk <= 1) d.splitk = -1;
     Scope sc(*this, s, kind, flops);
-    rc = bf16_gemm ? gemm_amp(d, s) : b2t_gemm_f32(&d, st);
+    rc = bf16_gemm ? gemm_amp(d, s, Bp_pre, dropA) : b2t_gemm_f32(&d, st);
   }
   // amp mode: the two-pass kernel (pack to dense bf16, then 128x128x64 tiles on packed operands: 2.5-3x the one-pass kernel)
   // for plain GEMMs big enough to pay for the pack passes, on a queue that has pack scratch; the one-pass kernel otherwise
@@ -261,14 +272,19 @@ struct Ctx {
     if (nq == 0 && s == main) q = 0;
     return q;
   }
+  bool pack_shape_ok(const b2t_gemm_desc& d) const {      // the part of would_pack that does not depend on the queue (plan-time decisions)
+    return bf16_gemm && lay && lay->pack[0] && (d.Z == 1 || d.Z == 0) && !d.b_zmap && 2.0 * d.M * d.N * (double)d.K >= 2e9 &&
+           b2t_gemm_bf16p_ws_bytes(d.M, d.N, d.K) <= lay->pack_bytes && (d.a_brk % 8) == 0;
+  }
   bool would_pack(const b2t_gemm_desc& d, hipStream_t s) const {
     const int q = pack_queue(s);
     return lay && q >= 0 && lay->pack[q] && (d.Z == 1 || d.Z == 0) && !d.b_zmap && 2.0 * d.M * d.N * (double)d.K >= 2e9 &&
            b2t_gemm_bf16p_ws_bytes(d.M, d.N, d.K) <= lay->pack_bytes && (d.a_brk % 8) == 0;
   }
-  int gemm_amp(const b2t_gemm_desc& d, hipStream_t s) {
+  int gemm_amp(const b2t_gemm_desc& d, hipStream_t s, const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr) {
     void* st = reinterpret_cast<void*>(s);
-    return would_pack(d, s) ? b2t_gemm_bf16p_f32(&d, lay->pack[pack_queue(s)], lay->pack_bytes, st) : b2t_gemm_bf16_f32(&d, st);
+    if (!would_pack(d, s)) return b2t_gemm_bf16_f32(&d, st);
+    return gemm_bf16p_run(&d, nullptr, Bp_pre, lay->pack[pack_queue(s)], lay->pack_bytes, s, dropA);
   }
   void call(int r) { if (!rc) rc = r; }
 };
@@ -420,7 +436,7 @@ uint64_t pass_key(int which, const b2t_model_t* prm, const b2t_model_t* grd, con
   h = key_of(h, p->in_drop); h = key_of(h, p->rnn_drop);
   for (const void* q : ptrs) h = key_of(h, q);
   for (long long v : ints) h = key_of(h, v);
-  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16"}) {   // read per pass by the code below / the sweeps
+  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK"}) {   // read per pass by the code below / the sweeps
     const char* e = getenv(name);
     h = key_of(h, (int)(e ? e[0] : 0));
   }
@@ -892,12 +908,33 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       if (states) c.call(check_hip(hipMemcpyAsync(w.out[l], states + (size_t)l * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s), "model_forward: state copy"));
       else c.call(b2t_broadcast_rows_f32(prm->h0, w.out[l], B, H, reinterpret_cast<void*>(s)));
     });
+  // Round 5, bf16 mode: W_ih of a layer is the B operand of one projection GEMM PER TIME CHUNK; the two-pass kernel packed it to bf16
+  // in front of every one of them (layer 0 of the shipped shape: 66 MB read + 33 MB written, three times per pass).  Packed once
+  // per pass now, by a task of its own that nothing but the layer's first projection waits for -- and the A pack of the layers
+  // >= 1 takes nn.GRU's inter-layer dropout with it (one kernel where there were dropout, pack A, pack B in front of the GEMM:
+  // a stage of the layer wavefront is sweep -> pack -> GEMM -> sweep).  Same values, same rounding: bit-identical.
+  const bool prepack_env = !(getenv("B2T_PREPACK") && atoi(getenv("B2T_PREPACK")) == 0);   // read per pass (the tests compare the two forms in one process)
+  int t_wpk[MAXL];
+  bool wpk_ok[MAXL];
+  for (int l = 0; l < L; ++l) {
+    t_wpk[l] = -1; wpk_ok[l] = false;
+    if (!c.bf16_gemm || !prepack_env || !w.wpk_f[l] || fused_from(l - 1)) continue;
+    const int n0 = chunks[0][1] - chunks[0][0], nl = chunks[nc - 1][1] - chunks[nc - 1][0];
+    b2t_gemm_desc d0 = gd(nullptr, prm->w_ih[l], nullptr, std::min(n0, nl) * B, 3 * H, l == 0 ? In0 : H);   // the smallest chunk decides
+    if (!c.pack_shape_ok(d0) || (l == 0 && !((long long)std::min(n0, nl) * B > 512))) continue;
+    wpk_ok[l] = true;
+    t_wpk[l] = P.add("wpack", 15.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
+      b2t_gemm_desc d = gd(nullptr, prm->w_ih[l], nullptr, 128, 3 * H, l == 0 ? In0 : H);
+      d.b_s0 = l == 0 ? In0 : H;
+      c.call(gemm_bf16p_pack(&d, 1, w.wpk_f[l], s));
+    });
+  }
   for (int l = 0; l < L; ++l) {
     for (int ci = 0; ci < nc; ++ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
       // 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
       const int t_gi = fused_from(l - 1) ? t_sw[l - 1][ci] :
-                       P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci]},
+                       P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci], t_wpk[l]},
                              [&, l, t0, n](hipStream_t sg) {
         if (l == 0) {
           static const bool rowmap = !(getenv("B2T_L0_ROWMAP") && atoi(getenv("B2T_L0_ROWMAP")) == 0);
@@ -908,7 +945,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
             // per step, same results bit for bit (B2T_L0_ROWMAP=0: the per-sentence form)
             b2t_gemm_desc d = gd(w.Ud + (long long)t0 * a_s0_l0, prm->w_ih[0], w.gi[0] + (long long)t0 * B * 3 * H, n * B, 3 * H, In0);
             d.a_div = B; d.a_s1 = a_s0_l0; d.a_s0 = (long long)T * F; d.b_s0 = In0; d.c_s0 = 3 * H; d.bias = prm->b_ih[0];
-            c.gemm(sg, d);
+            if (wpk_ok[0] && c.would_pack(d, sg)) c.gemm(sg, d, 1, nullptr, 0, -1, w.wpk_f[0]);
+            else c.gemm(sg, d);
           } else if ((long long)n * B <= 512 && In0 >= 2048) {
             // streaming-sized calls (a few frames, patch input K = 7168): one GEMM over all (t, b) rows through the
             // two-level row map, K split over the chip (as B per-sentence GEMMs the K loop runs serially in 18 workgroups)
@@ -932,7 +970,18 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
           return;
         }
         const float* src = w.out[l - 1];
-        if (w.outd[l - 1] != w.out[l - 1]) {   // nn.GRU inter-layer dropout (rnn_model.py:70)
+        const bool drop = w.outd[l - 1] != w.out[l - 1];   // nn.GRU inter-layer dropout (rnn_model.py:70)
+        {
+          b2t_gemm_desc d = gd(w.out[l - 1] + (long long)(1 + t0) * B * H, prm->w_ih[l], w.gi[l] + (long long)t0 * B * 3 * H, n * B, 3 * H, H);
+          d.a_s0 = H; d.b_s0 = H; d.c_s0 = 3 * H; d.bias = prm->b_ih[l];
+          if (wpk_ok[l] && c.would_pack(d, sg) && (!drop || H % 8 == 0)) {
+            // pre-packed weights; the dropout rides in the A pack, which also writes the dropped fp32 values the backward pass reads
+            PackDrop pd{drop ? p->rnn_drop : 0.f, mix_seed(p->seed, 101 + (l - 1)), (long long)t0 * B * H, w.outd[l - 1] + (long long)(1 + t0) * B * H};
+            c.gemm(sg, d, 1, nullptr, 0, -1, w.wpk_f[l], drop ? &pd : nullptr);
+            return;
+          }
+        }
+        if (drop) {
           c.call(b2t_dropout_f32(w.out[l - 1] + (long long)(1 + t0) * B * H, w.outd[l - 1] + (long long)(1 + t0) * B * H,
                                  (long long)n * B * H, p->rnn_drop, mix_seed(p->seed, 101 + (l - 1)), (long long)t0 * B * H,
                                  reinterpret_cast<void*>(sg)));
@@ -1147,6 +1196,25 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // only the last chunk's share is left behind the last backward sweep (it was 1.4 ms of tail as whole-sequence passes).
   const bool fast_day = prm->patch == 0 && !(p->in_drop > 0.f);
   const long long bias_ld = (long long)align_up(F, 4);
+  // bf16 mode (round 5): W_ih^T of every layer, the B operand of its input-gradient GEMM, packed once per pass (see b2t_model_forward)
+  const bool prepack_env = !(getenv("B2T_PREPACK") && atoi(getenv("B2T_PREPACK")) == 0);   // read per pass (the tests compare the two forms in one process)
+  int t_wpk[MAXL];
+  bool wpk_ok[MAXL];
+  for (int l = 0; l < L; ++l) {
+    t_wpk[l] = -1; wpk_ok[l] = false;
+    if (!c.bf16_gemm || !prepack_env || !w.wpk_b[l]) continue;
+    const int nmin = std::min(chunks[0][1] - chunks[0][0], chunks[nc - 1][1] - chunks[nc - 1][0]);
+    b2t_gemm_desc d0 = gd(nullptr, prm->w_ih[l], nullptr, nmin * B, l > 0 ? H : In0, 3 * H);
+    d0.a_brk = 2 * H;
+    if (!c.pack_shape_ok(d0)) continue;
+    wpk_ok[l] = true;
+    t_wpk[l] = P.add("wpack", 15.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
+      const int N = l > 0 ? H : In0;
+      b2t_gemm_desc d = gd(nullptr, prm->w_ih[l], nullptr, 128, N, 3 * H);
+      d.b_kcontig = 0; d.b_s0 = N;
+      c.call(gemm_bf16p_pack(&d, 1, w.wpk_b[l], s));
+    });
+  }
   auto dx_gemm = [&](hipStream_t s, int l, int t0, int n) {
     // dGi = dG[:, 0:2H] ++ dG[:, 3H:4H] is ONE A operand with a gap at k = 2H (H % 16 == 0 makes 2H a multiple of the k tile)
     const int N = l > 0 ? H : In0;
@@ -1163,6 +1231,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     // attic/bench_gemm_c3.py).  Pipelined plans share the CUs with the sweeps anyway (measured neutral there).
     const long long tiles = (((long long)n * B + 127) / 128) * ((N + 127) / 128);
     if (l > 0 && nc == 1 && !c.bf16_gemm && w.slab_dx && tiles <= 512 && 3 * H >= 1024) c.gemm(s, d, 2, w.slab_dx);
+    else if (wpk_ok[l] && c.would_pack(d, s)) c.gemm(s, d, 1, nullptr, 0, -1, w.wpk_b[l]);
     else c.gemm(s, d);
     // The day layer's weight gradient (per-sentence x^T dpre, then the reduction by day) ONCE over the whole sequence behind the
     // last chunk instead of chunk by chunk: the per-chunk GEMMs had K = 125 (14 TF/s, and 128 MB of slab read-modify-write
@@ -1209,7 +1278,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       else if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
-      t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1},
+      t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1, t_wpk[l]},
                           [&, l, t0, n](hipStream_t s) { dx_gemm(s, l, t0, n); });
       if (per_chunk || ci == 0) {
         const int w0 = per_chunk ? t0 : 0, w1 = per_chunk ? t1 : Tp;

@@ -50,4 +50,10 @@ inline int fill_gemm_args(const b2t_gemm_desc* d, GemmArgs& g, int bk, int bm, c
   return 0;
 }
 
+// gemm_bf16p.hip, internal (see there): operands of the two-pass bf16 GEMM packed ahead of it
+struct PackDrop { float p; unsigned long long seed; long long elem0; float* dup; };
+size_t gemm_bf16p_operand_bytes(int rows, int K);
+int gemm_bf16p_pack(const b2t_gemm_desc* d, int which, void* out, hipStream_t s, const PackDrop* drop = nullptr);
+int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pre, void* ws, size_t ws_bytes, hipStream_t s, const PackDrop* dropA = nullptr);
+
 }  // namespace b2t

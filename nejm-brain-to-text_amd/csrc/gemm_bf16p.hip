@@ -34,6 +34,10 @@ struct PackArgs {
   long long s0, s1; int div;     // row map of the source (rows if k-contiguous, k if row-contiguous)
   int brk, gap;                  // contiguous index i >= brk reads from i + gap (A operand only)
   float* sum; long long sum_ks;  // row-contiguous source only (or null): sum[(k / 64) * sum_ks + r] = fp32 sum of the tile's 64 k
+  // k-contiguous DENSE source only (s0 == K, no row map, no gap; round 5): the inter-layer dropout of nn.GRU folded into the pack --
+  // element (r, k) is flat element elem0 + r * K + k of the tensor b2t_dropout_f32 masks (same Philox draw, same 1 / (1 - p) scale:
+  // bit-identical to dropout-then-pack), and the dropped fp32 values are also written to `dup` (the backward pass reads them)
+  float drop_p, drop_scale; unsigned long long drop_seed; long long drop_elem0; float* dup;
 };
 
 // k-contiguous source: element (r, k) at P + rowoff(r) + k (+ gap for k >= brk).  One thread = 8 consecutive k of one row.
@@ -46,7 +50,16 @@ __global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
   if (r < a.rows && k < a.K) {
     const float* p = a.P + rowoff(r, a.s0, a.s1, a.div) + k + ((a.brk > 0 && k >= a.brk) ? a.gap : 0);
     if (k + 8 <= a.K) {
-      const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+      float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+      if (a.drop_p > 0.f) {     // (K % 8 == 0 on this path: every lane takes the full-vector branch)
+        const long long e = a.drop_elem0 + (long long)r * a.K + k;
+        const float4 u0 = Philox::uniform4(a.drop_seed, (uint64_t)(e >> 2), 2u), u1 = Philox::uniform4(a.drop_seed, (uint64_t)(e >> 2) + 1u, 2u);
+        v0.x = u0.x >= a.drop_p ? v0.x * a.drop_scale : 0.f; v0.y = u0.y >= a.drop_p ? v0.y * a.drop_scale : 0.f;
+        v0.z = u0.z >= a.drop_p ? v0.z * a.drop_scale : 0.f; v0.w = u0.w >= a.drop_p ? v0.w * a.drop_scale : 0.f;
+        v1.x = u1.x >= a.drop_p ? v1.x * a.drop_scale : 0.f; v1.y = u1.y >= a.drop_p ? v1.y * a.drop_scale : 0.f;
+        v1.z = u1.z >= a.drop_p ? v1.z * a.drop_scale : 0.f; v1.w = u1.w >= a.drop_p ? v1.w * a.drop_scale : 0.f;
+        if (a.dup) { float* q = a.dup + (long long)r * a.K + k; *reinterpret_cast<float4*>(q) = v0; *reinterpret_cast<float4*>(q + 4) = v1; }
+      }
       o.x = pk2(v0.x, v0.y); o.y = pk2(v0.z, v0.w); o.z = pk2(v1.x, v1.y); o.w = pk2(v1.z, v1.w);
     } else {
       float v[8];
@@ -200,42 +213,83 @@ extern "C" size_t b2t_gemm_bf16p_ws_bytes(int M, int N, int K) {
   return ((size_t)pad_to(M, PM) + (size_t)pad_to(N, PN)) * Kp * sizeof(__bf16) + 512;
 }
 
-extern "C" int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_bytes, void* stream) {
-  using namespace b2t;
-  B2T_REQUIRE(d != nullptr && ws != nullptr, "b2t_gemm_bf16p_f32: null descriptor / workspace");
+// ---- internal (csrc/exec.cpp): operands packed ahead of the GEMM, or by someone else ----------------------------------------
+// gemm_bf16p_pack: one operand of the GEMM `d` describes (which = 0: A, 1: B) into `out` (gemm_bf16p_operand_bytes); the weights of a
+// pass are packed ONCE (they change once per step, and a pipelined pass multiplies by them once per time chunk), and the A pack of the
+// forward's inter-layer projections carries nn.GRU's dropout (PackDrop).  gemm_bf16p_run: the GEMM with either operand pre-packed
+// (null: packed here into `ws` as b2t_gemm_bf16p_f32 does).
+namespace b2t {
+
+size_t gemm_bf16p_operand_bytes(int rows, int K) {
+  return (size_t)pad_to(rows, PM) * (size_t)pad_to(K, PK) * sizeof(__bf16);
+}
+
+static void launch_pack(const float* P, __bf16* out, int rows, int rows_pad, int K, int Kp, bool kc, long long s0, long long s1, int div, int brk,
+                        int gap, float* sum, long long sum_ks, const PackDrop* drop, hipStream_t s) {
+  PackArgs a{P, out, rows, rows_pad, K, Kp, s0, s1, div, brk, gap, sum, sum_ks, 0.f, 1.f, 0ull, 0ll, nullptr};
+  if (drop && drop->p > 0.f) { a.drop_p = drop->p; a.drop_scale = 1.0f / (1.0f - drop->p); a.drop_seed = drop->seed; a.drop_elem0 = drop->elem0; a.dup = drop->dup; }
+  if (kc) {
+    const long long items = (long long)rows_pad * (Kp / 8);
+    hipLaunchKernelGGL(pack_kc_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(pack_mc_kernel, dim3(rows_pad / 64, Kp / 64), dim3(256), 0, s, a);
+  }
+}
+
+int gemm_bf16p_pack(const b2t_gemm_desc* d, int which, void* out, hipStream_t s, const PackDrop* drop) {
+  B2T_REQUIRE(d && out && (which == 0 || which == 1), "gemm_bf16p_pack: bad arguments");
+  B2T_REQUIRE(((uintptr_t)out & 255) == 0, "gemm_bf16p_pack: the packed operand must be 256-byte aligned");
+  const int Kp = pad_to(d->K, PK);
+  if (which == 0) {
+    B2T_REQUIRE(!drop || drop->p <= 0.f || (d->a_kcontig && d->a_s0 == d->K && d->a_div == 0 && d->a_brk == 0 && d->K % 8 == 0 && (drop->elem0 % 4) == 0),
+                "gemm_bf16p_pack: dropout goes with a dense k-contiguous A (row stride = K, K %% 8 == 0)");
+    B2T_REQUIRE(d->a_brk == 0 || d->a_brk % 8 == 0, "gemm_bf16p_pack: a_brk must be a multiple of 8");
+    launch_pack(d->A, reinterpret_cast<__bf16*>(out), d->M, pad_to(d->M, PM), d->K, Kp, d->a_kcontig != 0, d->a_s0, d->a_s1, d->a_div, d->a_brk, d->a_gap,
+                d->a_sum, d->a_sum_ks, drop, s);
+  } else {
+    B2T_REQUIRE(!drop || drop->p <= 0.f, "gemm_bf16p_pack: dropout is for the A operand");
+    launch_pack(d->B, reinterpret_cast<__bf16*>(out), d->N, pad_to(d->N, PN), d->K, Kp, d->b_kcontig != 0, d->b_s0, d->b_s1, d->b_div, 0, 0, nullptr, 0, nullptr, s);
+  }
+  B2T_CHECK_LAUNCH("gemm_bf16p_pack");
+  return 0;
+}
+
+int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pre, void* ws, size_t ws_bytes, hipStream_t s, const PackDrop* dropA) {
+  B2T_REQUIRE(d != nullptr && (ws != nullptr || (Ap_pre && Bp_pre)), "b2t_gemm_bf16p_f32: null descriptor / workspace");
   B2T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->Z == 1 && d->b_zmap == nullptr, "b2t_gemm_bf16p_f32: bad shape M=%d N=%d K=%d Z=%d (Z must be 1)",
               d->M, d->N, d->K, d->Z);
   B2T_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && ((uintptr_t)ws & 255) == 0, "b2t_gemm_bf16p_f32: A/B must be 16-byte, ws 256-byte aligned");
   B2T_REQUIRE((d->a_s0 % 4) == 0 && (d->a_s1 % 4) == 0 && (d->b_s0 % 4) == 0 && (d->b_s1 % 4) == 0,
               "b2t_gemm_bf16p_f32: A/B strides must be multiples of 4 elements");
-  B2T_REQUIRE(ws_bytes >= b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K), "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes,
-              b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K));
+  const int Mp = pad_to(d->M, PM), Np = pad_to(d->N, PN), Kp = pad_to(d->K, PK);
+  const size_t needA = Ap_pre ? 0 : (size_t)Mp * Kp * sizeof(__bf16), needB = Bp_pre ? 0 : (size_t)Np * Kp * sizeof(__bf16);
+  B2T_REQUIRE(ws_bytes >= needA + needB, "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes, needA + needB);
   GemmArgs g;
   B2T_REQUIRE(d->a_sum == nullptr || !d->a_kcontig, "b2t_gemm_bf16p_f32: a_sum goes with an m-contiguous A (a_kcontig = 0)");
+  B2T_REQUIRE(d->a_sum == nullptr || !Ap_pre, "b2t_gemm_bf16p_f32: a_sum is a by-product of packing A");
   { int rc = fill_gemm_args(d, g, PK, PM, "b2t_gemm_bf16p_f32"); if (rc) return rc; }
   B2T_REQUIRE(d->a_brk == 0 || d->a_brk % 8 == 0, "b2t_gemm_bf16p_f32: a_brk must be a multiple of 8");
-  const int Mp = pad_to(d->M, PM), Np = pad_to(d->N, PN), Kp = pad_to(d->K, PK);
-  __bf16* Ap = reinterpret_cast<__bf16*>(ws);
-  __bf16* Bp = Ap + (size_t)Mp * Kp;
-  hipStream_t s = as_stream(stream);
-  auto pack = [&](const float* P, __bf16* out, int rows, int rows_pad, bool kc, long long s0, long long s1, int div, int brk, int gap,
-                  float* sum = nullptr, long long sum_ks = 0) {
-    PackArgs a{P, out, rows, rows_pad, d->K, Kp, s0, s1, div, brk, gap, sum, sum_ks};
-    if (kc) {
-      const long long items = (long long)rows_pad * (Kp / 8);
-      hipLaunchKernelGGL(pack_kc_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
-    } else {
-      hipLaunchKernelGGL(pack_mc_kernel, dim3(rows_pad / 64, Kp / 64), dim3(256), 0, s, a);
-    }
-  };
-  pack(d->A, Ap, d->M, Mp, d->a_kcontig != 0, d->a_s0, d->a_s1, d->a_div, d->a_brk, d->a_gap, d->a_sum, d->a_sum_ks);
-  B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (pack A)");
-  pack(d->B, Bp, d->N, Np, d->b_kcontig != 0, d->b_s0, d->b_s1, d->b_div, 0, 0);
-  B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (pack B)");
+  __bf16* Aw = reinterpret_cast<__bf16*>(ws);
+  __bf16* Bw = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(ws) + needA);
+  if (!Ap_pre) { int rc = gemm_bf16p_pack(d, 0, Aw, s, dropA); if (rc) return rc; }
+  if (!Bp_pre) { int rc = gemm_bf16p_pack(d, 1, Bw, s, nullptr); if (rc) return rc; }
+  const __bf16* Ap = Ap_pre ? reinterpret_cast<const __bf16*>(Ap_pre) : Aw;
+  const __bf16* Bp = Bp_pre ? reinterpret_cast<const __bf16*>(Bp_pre) : Bw;
   g.kchunk = pad_to((Kp + g.splitk - 1) / g.splitk, PK);
   dim3 grid((Np / PN) * (Mp / PM), 1, g.splitk), block(256);
   { static const bool off = getenv("B2T_GEMM_KS_XCD") && atoi(getenv("B2T_GEMM_KS_XCD")) == 0; g.ks_xcd = !off && g.splitk >= 8 && (g.splitk & 7) == 0; }
-  hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, (const __bf16*)Ap, (const __bf16*)Bp, Kp);
+  hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, Ap, Bp, Kp);
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32");
   return 0;
+}
+
+}  // namespace b2t
+
+extern "C" int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_bytes, void* stream) {
+  using namespace b2t;
+  B2T_REQUIRE(d != nullptr && ws != nullptr, "b2t_gemm_bf16p_f32: null descriptor / workspace");
+  B2T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "b2t_gemm_bf16p_f32: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+  B2T_REQUIRE(ws_bytes >= b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K), "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes,
+              b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K));
+  return gemm_bf16p_run(d, nullptr, nullptr, ws, ws_bytes, as_stream(stream), nullptr);
 }

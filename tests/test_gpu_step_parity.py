@@ -645,6 +645,52 @@ def test_xcd_local_handoff_is_bit_identical(monkeypatch):
             assert torch.equal(got, ref) and torch.equal(l2, loss), f"B2T_GRU_LOCAL={dirs!r} at H={H}, B={B}"
 
 
+def test_bf16_mode_prepacked_weights_and_dropout_in_the_pack_are_bit_identical(monkeypatch):
+    """Round 5, bf16 mode: W_ih of every layer is packed to bf16 ONCE per pass (it is the B operand of one GEMM per time chunk) and the
+    inter-layer dropout of nn.GRU rides in the A pack of the next layer's projection (which also writes the dropped fp32 values the
+    backward pass reads) -- csrc/exec.cpp `wpack` tasks, gemm_bf16p_pack / gemm_bf16p_run.  Same values, same rounding, same Philox
+    draws: logits, per-sentence losses and the whole gradient arena equal B2T_PREPACK=0 (pack per GEMM, separate dropout kernel)
+    bit for bit, with and without dropout, pipelined and serial plans, patch input."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    old_amp = ops.AMP["on"]
+    try:
+        ops.set_amp(True)
+        for (F, H, D, C, L, B, T, S, patch, drop, chunks) in ((64, 768, 4, 41, 3, 64, 100, 10, (4, 2), (0.4, 0.2), (3, 2)),
+                                                             (64, 512, 4, 41, 3, 64, 96, 10, (0, 0), (0.0, 0.0), (3, 2)),
+                                                             (64, 256, 3, 41, 2, 64, 64, 6, (0, 0), (0.3, 0.0), (1, 1))):
+            g = torch.Generator().manual_seed(B + H)
+            x = torch.randn(B, T, F, generator=g).to(dev)
+            day = torch.randint(0, D, (B,), generator=g)
+            tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(2, S + 1, (B,), generator=g)
+            nt = torch.randint(T - 10, T + 1, (B,), generator=g)
+            for b in range(B):
+                tgt[b, tl[b]:] = 0
+            monkeypatch.setitem(ops.PIPELINE, "chunks", chunks[0])
+            monkeypatch.setitem(ops.PIPELINE, "chunks_bwd", chunks[1])
+
+            def grads(prepack):
+                monkeypatch.setenv("B2T_PREPACK", "1" if prepack else "0")
+                torch.manual_seed(3)
+                m = GRUDecoder(F, H, D, C, drop[0], drop[1], L, patch[0], patch[1]).to(dev).train()
+                ts = TrainStep(m, step_args())
+                loss_b = ts.compute_grads(x, day, tgt, nt, tl)
+                torch.cuda.synchronize()
+                ts.check_status()
+                return ts.grad_arena.clone(), loss_b.clone(), ts.last_logits.clone()
+
+            ref = grads(False)
+            got = grads(True)
+            assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
+            for a, r, name in zip(got, ref, ("gradients", "losses", "logits")):
+                assert torch.equal(a, r), f"H={H} drop={drop} chunks={chunks}: {name} differ with pre-packed weights"
+    finally:
+        ops.set_amp(old_amp)
+        monkeypatch.delenv("B2T_PREPACK", raising=False)
+
+
 def test_paired_backward_sweeps_in_the_step(monkeypatch):
     """Round 5: the step with its backward sweeps as paired sweeps (W_hh^T in LDS, one per XCD set in flight, csrc/exec.cpp classes
     2..5).  The eight-way split of the contraction sums in another order than the register-resident sweep's four-way split, so
