@@ -101,6 +101,8 @@ struct Layout {
   char* pack[NPACK];       // amp mode: per-queue scratch of the two-pass bf16 GEMM (packed operands)
   size_t pack_bytes;
   char *wpk_f[MAXL], *wpk_b[MAXL];   // amp mode: W_ih of every layer packed once per pass -- as the projection's B operand (forward), as the input gradient's (backward)
+  float *slab_hh[MAXL], *asum_hh[MAXL];   // amp mode: split-K slab / per-slice sums of dW_hh when it runs as a task of its own next to dW_ih
+  char *xpk_hh[MAXL], *xpk_ih[MAXL]; // amp mode: the B operands of a layer's whole-sequence weight-gradient GEMMs (h_{t-1}^T, x^T: known when the backward pass starts), packed ahead of the tail
   size_t bytes;
 };
 
@@ -145,8 +147,15 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
   if (p->bf16_gemm)
     for (size_t l = 0; l < L; ++l) { w.wpk_f[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(3 * H), (int)(l == 0 ? In0 : H)), 256); }
   if (!p->save) { w.bytes = off; return; }
+  for (size_t l = 0; l < MAXL; ++l) { w.xpk_hh[l] = w.xpk_ih[l] = nullptr; w.slab_hh[l] = w.asum_hh[l] = nullptr; }
   if (p->bf16_gemm)
-    for (size_t l = 0; l < L; ++l) { w.wpk_b[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(3 * H)), 256); }
+    for (size_t l = 0; l < L; ++l) {
+      w.wpk_b[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(3 * H)), 256);
+      w.slab_hh[l] = take((size_t)splitk_cap(3 * H, H, Tp * B) * 3 * H * H);
+      w.asum_hh[l] = take((std::max(std::min<size_t>(1024, Tp * B / 256), Tp * B / 64 + 1) + 8) * 3 * H);
+      w.xpk_hh[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)H, (int)(Tp * B)), 256);
+      w.xpk_ih[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(Tp * B)), 256);
+    }
   for (size_t l = 0; l < L; ++l) w.res[l] = take(Tp * B * 4 * H);
   const size_t K = Tp * B;
   for (size_t l = 0; l < L; ++l) {
@@ -436,7 +445,7 @@ uint64_t pass_key(int which, const b2t_model_t* prm, const b2t_model_t* grd, con
   h = key_of(h, p->in_drop); h = key_of(h, p->rnn_drop);
   for (const void* q : ptrs) h = key_of(h, q);
   for (long long v : ints) h = key_of(h, v);
-  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK"}) {   // read per pass by the code below / the sweeps
+  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK", "B2T_WGRAD_SPLIT"}) {   // read per pass by the code below / the sweeps
     const char* e = getenv(name);
     h = key_of(h, (int)(e ? e[0] : 0));
   }
@@ -1056,8 +1065,12 @@ namespace {
 // dW_hh = dGh^T h_prev, dW_ih = dGi^T in, bias gradients = column sums of dG (layer l) over the time rows [t0, t1):
 // the whole sequence at once (t0 = 0, t1 = T', accumulate = 0), or chunk by chunk as soon as a chunk is swept (the first
 // chunk processed overwrites, later ones accumulate in a fixed order: deterministic); `final` copies the bias sums out.
+// which: 3 = the GEMMs (default); 1 = only pack their B operands (h_{t-1}^T -> w.xpk_hh[l], x^T -> w.xpk_ih[l]; bf16 mode, whole
+// sequence: round 5) -- a later call with pre = true then multiplies by the packed copies.
+// part: 0 = both weight gradients of the layer, one after the other (shared slab / sums); 1 = dW_hh (+ b_hh) only, with buffers of
+// its own (w.slab_hh / w.asum_hh), 2 = dW_ih (+ b_ih) only: the two as separate tasks of the plan (bf16 mode, round 5).
 void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t_model_t* grd, const b2t_pass_t* p,
-                        Layout& w, int l, int t0, int t1, int accumulate, bool final) {
+                        Layout& w, int l, int t0, int t1, int accumulate, bool final, int which = 3, bool pre = false, int part = 0) {
   const int B = p->B, T = p->T, F = prm->F, H = prm->H;
   const long long K = (long long)(t1 - t0) * B;
   const long long a0 = (long long)t0 * B * 4 * H;
@@ -1071,18 +1084,24 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     b.a_brk = 2 * H;
     fused_bias = c.would_pack(a, s) && c.would_pack(b, s);
   }
+  float* const asum_x = part == 1 ? w.asum_hh[l] : w.asum[l];
+  float* const slab_x = part == 1 ? w.slab_hh[l] : w.slab[l];
   auto bias_out = [&](int sk, float* dst) {
     const int ns = c.bf16_gemm ? (int)((K + 63) / 64) : std::max(1, sk);
-    c.call(b2t_colsum_f32(w.asum[l], ns, 3 * H, 3 * H, dst, accumulate, w.asum[l] + (size_t)ns * 3 * H, 1, 0, 0, sp));
+    c.call(b2t_colsum_f32(asum_x, ns, 3 * H, 3 * H, dst, accumulate, asum_x + (size_t)ns * 3 * H, 1, 0, 0, sp));
   };
-  {
+  if (part != 2) {
     b2t_gemm_desc d = gd(w.dG[l] + a0, w.out[l] + (long long)t0 * B * H, grd->w_hh[l], 3 * H, H, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
     const int sk = splitk_for(3 * H, H, K, splitk_target(c.bf16_gemm));
-    if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
-    c.gemm(s, d, sk, w.slab[l], accumulate, l);
-    if (fused_bias) bias_out(sk, grd->b_hh[l]);
+    if (which == 1) { c.call(gemm_bf16p_pack(&d, 1, w.xpk_hh[l], s)); }
+    else {
+      if (fused_bias) { d.a_sum = asum_x; d.a_sum_ks = 3 * H; }
+      c.gemm(s, d, sk, slab_x, accumulate, l, pre ? w.xpk_hh[l] : nullptr);
+      if (fused_bias) bias_out(sk, grd->b_hh[l]);
+    }
   }
+  if (part == 1) return;     // (only taken with fused bias sums: the caller checks)
   int In; const float* inp; long long b_s0, b_s1 = 0; int b_div = 0;
   if (l == 0) {
     In = in0(prm);
@@ -1097,8 +1116,9 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = b_s0; d.b_s1 = b_s1; d.b_div = b_div; d.c_s0 = In;
     d.a_brk = brk; d.a_gap = gap;
     const int sk = splitk_for(M, In, K, splitk_target(c.bf16_gemm));
+    if (which == 1) { c.call(gemm_bf16p_pack(&d, 1, w.xpk_ih[l], s)); return; }
     if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
-    c.gemm(s, d, sk, w.slab[l], accumulate, l);
+    c.gemm(s, d, sk, w.slab[l], accumulate, l, pre ? w.xpk_ih[l] : nullptr);
     if (fused_bias) bias_out(sk, grd->b_ih[l]);
   };
   if ((2 * H) % 128 == 0 && (3 * H) % 128 == 0) {   // dGi^T as ONE operand with a gap along m
@@ -1107,7 +1127,7 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     wih(2 * H, 0, 0, 0, 0);
     wih(H, 3 * H, (long long)2 * H * In, 0, 0);
   }
-  if (fused_bias) return;
+  if (fused_bias || which == 1) return;
   c.call(b2t_colsum_f32(w.dG[l] + a0, K, 4 * H, 4 * H, w.s4[l], accumulate, w.cs_layer[l], 1, 0, 0, sp));   // (s_r, s_z, s_nr, s_n)
   if (!final) return;
   auto cp = [&](float* dst, const float* src, size_t n) {
@@ -1198,6 +1218,9 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   const long long bias_ld = (long long)align_up(F, 4);
   // bf16 mode (round 5): W_ih^T of every layer, the B operand of its input-gradient GEMM, packed once per pass (see b2t_model_forward)
   const bool prepack_env = !(getenv("B2T_PREPACK") && atoi(getenv("B2T_PREPACK")) == 0);   // read per pass (the tests compare the two forms in one process)
+  // (measured NEGATIVE, opt-in: the shipped shape's bf16 step 6.20 ms against 6.00, C2 bf16 9.95 against 9.81 -- the layers' small dW_hh
+  //  GEMMs then start next to the sweeps still running, and a sweep next to a GEMM is the slower sweep: NOTES.md R5.7)
+  const bool split_env = getenv("B2T_WGRAD_SPLIT") && atoi(getenv("B2T_WGRAD_SPLIT")) == 1;
   int t_wpk[MAXL];
   bool wpk_ok[MAXL];
   for (int l = 0; l < L; ++l) {
@@ -1255,7 +1278,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   for (int l = L - 1; l >= 0; --l) {
     const bool per_chunk = nc > 1 && ((p->wgrad_chunk_mask >> l) & 1);
     const int In = l == 0 ? In0 : H;
-    int t_wg = -1;
+    int t_wg = -1, t_wg_hh = -1, t_wg_ih = -1;
     for (int ci = nc - 1; ci >= 0; --ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
       t_bs[l][ci] = P.add("bsweep", 40.f + n * est_step_us(1) * hs, q_sweep,
@@ -1285,8 +1308,32 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
         const int acc = per_chunk && ci != nc - 1 ? 1 : 0;
         const bool fin = ci == 0;
         const double K = (double)(w1 - w0) * B;
-        t_wg = P.add("wgrad", est_gemm(3 * H, H, K) + est_gemm(3 * H, In, K) + 60.f, Q_ANY, {t_bs[l][ci], t_wg},
-                     [&, l, w0, w1, acc, fin](hipStream_t s) { layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin); });
+        // bf16 mode, whole-sequence weight gradients: their B operands (h_{t-1}^T, x^T) exist when the pass starts -- packed by a
+        // task of their own that only this layer's weight gradients wait for (the transposing packs of layer 0 were 170 us of the
+        // shipped shape's 1.3 ms tail behind the last sweep)
+        int t_xp = -1;
+        bool xpre = false;
+        if (c.bf16_gemm && prepack_env && !per_chunk && w.xpk_hh[l] && (2 * H) % 128 == 0 && (3 * H) % 128 == 0) {
+          b2t_gemm_desc a = gd(nullptr, nullptr, nullptr, 3 * H, H, (int)K), b = gd(nullptr, nullptr, nullptr, 3 * H, In, (int)K);
+          b.a_brk = 2 * H;
+          if (c.pack_shape_ok(a) && c.pack_shape_ok(b)) {
+            xpre = true;
+            t_xp = P.add("xpack", 20.f + (float)((double)K * (H + In) * 6.0 / 4.0e6), Q_ANY, {t_start},
+                         [&, l, w0, w1](hipStream_t s) { layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, 0, false, 1); });
+          }
+        }
+        // ... and dW_hh / dW_ih as two tasks (own slab and sums for dW_hh): behind the last sweep of the shipped shape the small
+        // dW_hh[0] (0.25 ms at 155 TF/s) no longer stands in front of the 258-GFLOP dW_ih[0] on one queue
+        if (xpre && split_env && w.slab_hh[l]) {
+          const int t_hh = P.add("wgrad_hh", est_gemm(3 * H, H, K) + 30.f, Q_ANY, {t_bs[l][ci], t_wg_hh, t_xp},
+                                 [&, l, w0, w1, acc, fin](hipStream_t s) { layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin, 3, true, 1); });
+          const int t_ih = P.add("wgrad_ih", est_gemm(3 * H, In, K) + 30.f, Q_ANY, {t_bs[l][ci], t_wg_ih, t_xp},
+                                 [&, l, w0, w1, acc, fin](hipStream_t s) { layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin, 3, true, 2); });
+          t_wg_hh = t_hh; t_wg_ih = t_ih;
+          t_wg = P.add("wgrad_join", 0.f, Q_ANY, {t_hh, t_ih}, nullptr);
+        } else
+        t_wg = P.add("wgrad", est_gemm(3 * H, H, K) + est_gemm(3 * H, In, K) + 60.f, Q_ANY, {t_bs[l][ci], t_wg, t_xp},
+                     [&, l, w0, w1, acc, fin, xpre](hipStream_t s) { layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin, 3, xpre); });
       }
     }
     t_wg_last[l] = t_wg;

@@ -18,6 +18,7 @@ struct GemmArgs {
   float* a_sum; long long a_sum_ks;   // fp32 tile kernel, m-contiguous A: per-slice sums over k of A[k][m]
   unsigned* ks_cnt; float* ks_out; int ks_acc;   // fp32 tile kernel, split-K: in-kernel slab reduction by a tile's last slice workgroup
   int ks_xcd;             // split-K: 1 = a K slice's tiles all run on one XCD (slices dealt to the XCDs), 0 = tiles dealt to the XCDs
+  int tile_gm;            // packed bf16 kernel: tiles are numbered down groups of tile_gm tile rows (1 / 0 = row-major); see gemm_bf16p.hip
 };
 
 __device__ __forceinline__ long long rowoff(int i, long long s0, long long s1, int div) {
@@ -41,7 +42,7 @@ inline int fill_gemm_args(const b2t_gemm_desc* d, GemmArgs& g, int bk, int bm, c
   g.a_brk = d->a_brk; g.a_gap = d->a_gap;
   g.ep_aux = d->ep_aux;
   g.a_sum = d->a_sum; g.a_sum_ks = d->a_sum_ks;
-  g.ks_xcd = 0;
+  g.ks_xcd = 0; g.tile_gm = 1;
   g.ks_cnt = d->ks_counters; g.ks_out = d->ks_out; g.ks_acc = d->ks_accumulate;
   B2T_REQUIRE(d->epilogue != 2 || d->ep_aux != nullptr, "%s: epilogue 2 needs ep_aux", name);
   B2T_REQUIRE(d->a_brk == 0 || (d->a_brk > 0 && d->a_gap % 4 == 0 &&

@@ -138,7 +138,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __
       const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
       tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
     }
-    m0 = (tile / gx) * PM; n0 = (tile % gx) * PN;
+    // Round 5: an XCD's workgroups run ~64 CONSECUTIVE tiles at a time in step along k.  Numbered row-major, 64 tiles of a wide GEMM
+    // (the shipped shape's layer 0: 56 tile columns) are one tile row: 1 A panel + 56 B panels fetched per k step -- 2 GB of L2 misses
+    // per 258-GFLOP GEMM, 400-470 TF/s.  Numbered down groups of tile_gm rows (8 x 8 blocks) they share 8 + 8 panels.
+    if (g.tile_gm > 1) {
+      const int gy = nwg / gx, per_group = g.tile_gm * gx;
+      const int grp = tile / per_group, first_m = grp * g.tile_gm;
+      const int gm_eff = min(g.tile_gm, gy - first_m), r = tile - grp * per_group;
+      m0 = (first_m + r % gm_eff) * PM; n0 = (r / gm_eff) * PN;
+    } else {
+      m0 = (tile / gx) * PM; n0 = (tile % gx) * PN;
+    }
   }
   const float* bias = (g.bias && ks == 0) ? g.bias : nullptr;
   float* C = g.C + (long long)ks * g.c_ks;
@@ -278,6 +288,10 @@ int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pr
   g.kchunk = pad_to((Kp + g.splitk - 1) / g.splitk, PK);
   dim3 grid((Np / PN) * (Mp / PM), 1, g.splitk), block(256);
   { static const bool off = getenv("B2T_GEMM_KS_XCD") && atoi(getenv("B2T_GEMM_KS_XCD")) == 0; g.ks_xcd = !off && g.splitk >= 8 && (g.splitk & 7) == 0; }
+  {   // grouped tile order for wide GEMMs (B2T_GEMM_GM: 0 = row-major always, n = groups of n tile rows wherever there are > 16 tile columns)
+    static const int gm_env = getenv("B2T_GEMM_GM") ? atoi(getenv("B2T_GEMM_GM")) : 8;
+    g.tile_gm = (gm_env > 1 && Np / PN > 16 && Mp / PM >= 2) ? gm_env : 1;
+  }
   hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, Ap, Bp, Kp);
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32");
   return 0;

@@ -619,7 +619,8 @@ def test_paired_backward_sweep_matches_step_launch(B, H, T):
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 41, 37), (33, 300, 129), (512, 1536, 520), (640, 256, 4100)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 41, 37), (33, 300, 129), (512, 1536, 520), (640, 256, 4100),
+                                   (300, 2200, 130), (1100, 2304, 200)])     # > 16 tile columns: the grouped tile order (3 and 9 tile rows: one short group, a full + a short one)
 def test_gemm_bf16_packed(akc, bkc, M, N, K):
     """b2t_gemm_bf16p_f32 (two passes: pack both operands to dense bf16, then tiles on the packed operands): same contract
     as b2t_gemm_bf16_f32 -- an fp64 product of the bf16-rounded operands up to fp32 summation roundoff -- for all four

@@ -648,9 +648,10 @@ def test_xcd_local_handoff_is_bit_identical(monkeypatch):
 def test_bf16_mode_prepacked_weights_and_dropout_in_the_pack_are_bit_identical(monkeypatch):
     """Round 5, bf16 mode: W_ih of every layer is packed to bf16 ONCE per pass (it is the B operand of one GEMM per time chunk) and the
     inter-layer dropout of nn.GRU rides in the A pack of the next layer's projection (which also writes the dropped fp32 values the
-    backward pass reads) -- csrc/exec.cpp `wpack` tasks, gemm_bf16p_pack / gemm_bf16p_run.  Same values, same rounding, same Philox
-    draws: logits, per-sentence losses and the whole gradient arena equal B2T_PREPACK=0 (pack per GEMM, separate dropout kernel)
-    bit for bit, with and without dropout, pipelined and serial plans, patch input."""
+    backward pass reads) -- csrc/exec.cpp `wpack` tasks, gemm_bf16p_pack / gemm_bf16p_run; the B operands of the whole-sequence weight
+    gradients (h_{t-1}^T, x^T) are packed when the backward pass starts (`xpack`), and dW_hh / dW_ih run as two tasks.  Same values,
+    same rounding, same Philox draws: logits, per-sentence losses and the whole gradient arena equal B2T_PREPACK=0 (pack per GEMM,
+    separate dropout kernel) bit for bit, with and without dropout, pipelined and serial plans, patch input."""
     import b2t_ops as ops
     from rnn_model import GRUDecoder
     from b2t_train_step import TrainStep
@@ -671,8 +672,9 @@ def test_bf16_mode_prepacked_weights_and_dropout_in_the_pack_are_bit_identical(m
             monkeypatch.setitem(ops.PIPELINE, "chunks", chunks[0])
             monkeypatch.setitem(ops.PIPELINE, "chunks_bwd", chunks[1])
 
-            def grads(prepack):
+            def grads(prepack, split=True):
                 monkeypatch.setenv("B2T_PREPACK", "1" if prepack else "0")
+                monkeypatch.setenv("B2T_WGRAD_SPLIT", "1" if split else "0")
                 torch.manual_seed(3)
                 m = GRUDecoder(F, H, D, C, drop[0], drop[1], L, patch[0], patch[1]).to(dev).train()
                 ts = TrainStep(m, step_args())
@@ -682,13 +684,15 @@ def test_bf16_mode_prepacked_weights_and_dropout_in_the_pack_are_bit_identical(m
                 return ts.grad_arena.clone(), loss_b.clone(), ts.last_logits.clone()
 
             ref = grads(False)
-            got = grads(True)
             assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
-            for a, r, name in zip(got, ref, ("gradients", "losses", "logits")):
-                assert torch.equal(a, r), f"H={H} drop={drop} chunks={chunks}: {name} differ with pre-packed weights"
+            for split in (True, False):      # dW_hh and dW_ih as two tasks with buffers of their own, or one after the other
+                got = grads(True, split)
+                for a, r, name in zip(got, ref, ("gradients", "losses", "logits")):
+                    assert torch.equal(a, r), f"H={H} drop={drop} chunks={chunks} split={split}: {name} differ with pre-packed operands"
     finally:
         ops.set_amp(old_amp)
         monkeypatch.delenv("B2T_PREPACK", raising=False)
+        monkeypatch.delenv("B2T_WGRAD_SPLIT", raising=False)
 
 
 def test_paired_backward_sweeps_in_the_step(monkeypatch):
