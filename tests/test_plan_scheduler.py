@@ -235,3 +235,29 @@ def test_admission_fuzz_random_estimates():
             for _, dlt in events:
                 live += dlt; peak = max(peak, live)
             assert peak <= 2, (trial, L, nc, nq, k, peak)
+
+
+@pytest.mark.parametrize("L,nc,sweep_us,gemm_us", [(5, 4, 800.0, 60.0), (7, 6, 300.0, 10.0), (8, 3, 200.0, 400.0)])
+def test_admission_capacity_one_classes(L, nc, sweep_us, gemm_us):
+    """Round 5: the paired backward sweeps (one 512-thread workgroup per CU on the two XCDs of their set) are admission classes
+    2..5 = 2 + (layer & 3) with room for ONE task in flight (exec.cpp cls_capacity): in the planned schedule no two tasks of such a
+    class overlap, classes 0 / 1 keep their capacity of two, and the schedule stays valid."""
+    est, deps, cls = _wavefront(L, nc, sweep_us, gemm_us)
+    layer = 0
+    cls1 = []
+    k = 0
+    for c in cls:                      # sweeps come in layer-major order: re-class them by layer & 3
+        if c >= 0:
+            cls1.append(2 + ((k // nc) & 3)); k += 1
+        else:
+            cls1.append(-1)
+    q, start, end, order = schedule_admission(est, deps, cls1, 4)
+    n = len(est)
+    pos = np.empty(n, int); pos[order] = np.arange(n)
+    for i in range(n):
+        for d in deps[i]:
+            assert pos[d] < pos[i] and start[i] + 1e-3 >= end[d] + (HOP if q[d] != q[i] else 0.0)
+    for kcls in range(2, 6):
+        ids = sorted((i for i in range(n) if cls1[i] == kcls), key=lambda i: (start[i], i))
+        for a, b in zip(ids, ids[1:]):
+            assert start[b] + 1e-3 >= end[a], f"class {kcls}: tasks {a} and {b} planned in flight together"
