@@ -280,7 +280,10 @@ def dp_forced_one_rank(steps: int = 30):
             d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][0])
             if best is None or d["ms_per_step"] < best["ms_per_step"]:
                 best = d
-        return dict(ms_per_step=best["ms_per_step"], final_loss=best["final_loss"], collective=best["config"]["collective"])
+        pr = best.get("process_runs") or [{}]
+        return dict(ms_per_step=best["ms_per_step"], final_loss=best["final_loss"], collective=best["config"]["collective"],
+                    host_enqueue_ms_per_step=best.get("host_enqueue_ms_per_step"), kernel_launch_us_p50=pr[0].get("kernel_launch_us_p50"),
+                    best_process_ms=best.get("best_process_ms"))
     plain = run({})
     forced = run({"B2T_DP_FORCE": "1"})
     deferred = run({"B2T_DP_FORCE": "1", "B2T_DP_DEFERRED": "1"})
@@ -297,6 +300,8 @@ def dp_forced_one_rank(steps: int = 30):
                workload="the headline C2 step, one rank: every collective of the N-rank step runs (identity results); best of two child runs each")
     if "ms_per_step" in plain and "ms_per_step" in forced:
         out["forced_over_plain"] = round(forced["ms_per_step"] / plain["ms_per_step"], 4)
+        out["note"] = ("every entry is a child process's FIRST-process measurement (best of two children): a child that came up in the pool's "
+                       "slow-host mode shows in its host_enqueue_ms_per_step (> 3) -- compare entries of equal host mode only")
     return out
 
 
