@@ -13,7 +13,10 @@ dev = torch.device("cuda:0")
 torch.manual_seed(10)
 if os.environ.get("B2T_AMP"):
     ops.set_amp(True)
-model = GRUDecoder(bench.F, bench.H, bench.D, bench.C, 0.0, 0.0, bench.L, 0, 0).to(dev).train()
+if os.environ.get("B2T_STRESS_SHAPE") == "c3":     # the shipped shape: H = 768, patch 14 / 4, dropout 0.4 / 0.2
+    model = GRUDecoder(bench.F, 768, bench.D, bench.C, 0.4, 0.2, bench.L, 14, 4).to(dev).train()
+else:
+    model = GRUDecoder(bench.F, bench.H, bench.D, bench.C, 0.0, 0.0, bench.L, 0, 0).to(dev).train()
 ts = TrainStep(model, dict(bench.ARGS))
 x, days, labels, nts, lens = bench.make_batch(1000, dev)
 worst, t_all = 0.0, time.perf_counter()
