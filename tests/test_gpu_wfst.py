@@ -730,3 +730,48 @@ def test_wfst_streamed_on_a_word_5gram_graph_32_utterances():
         compare_lists(fin[u], R[u], f"5-gram stream utt {u}")
         hits += [g.words[w] for w in fin[u][0][2]] == seqs[u]
     print(f"5-gram graph, 32 streamed utterances: {hits}/32 spelled sentences recovered exactly")
+
+
+def test_cluster_finalize_equals_single_workgroup_finalize(toy, monkeypatch):
+    """Round 5 (verdict item 4): FinalizeDecoding by the utterance's cluster -- L2 atomics on the extra costs, one cluster barrier per
+    frame + one per epsilon sweep, every link's alive byte written once -- against the one-workgroup kernel (`B2T_WFST_FIN_CLUSTER=0`)
+    on the SAME search state (the state block is snapshotted behind the search and restored: two searches number their tokens in
+    arrival order, i.e. differently): the pruned lattice (states, arcs, labels, both costs, final costs) is identical array by array,
+    and so are the n-best lists -- production options, blank skipping, binding max_active, a streamed utterance with PruneActiveTokens
+    passes in between, an utterance of a single frame."""
+    from wfst_decoder import WfstSearch
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(77)
+    seqs, lps, batch, lens = utterances(prons, words, 8, rs, noise=1.0, n_words=(1, 6))
+    lens = lens.copy(); lens[7] = 1                      # F = 1: the last frame is also (almost) the first
+    dev_batch = torch.from_numpy(batch).cuda()
+    for o, interval in ((Opt(nbest=30), 0), (Opt(nbest=30, ctc_blank_skip_threshold=0.9), 0), (Opt(nbest=30, max_active=250, min_active=60, beam=11.0), 0),
+                        (Opt(nbest=30, lattice_beam=4.0), 9)):
+        S = WfstSearch(g, o, U=8, max_frames=batch.shape[1] + 8, prune_interval=interval)
+        if interval:
+            for t in range(batch.shape[1]):
+                S.search(dev_batch[:, t:t + 1].contiguous(), np.clip(lens - t, 0, 1))
+        else:
+            S.search(dev_batch, lens)
+        torch.cuda.synchronize()
+        snap = S.state.clone()
+        res = {}
+        for mode in ("0", "1", "1"):                     # (the cluster kernel twice: its barrier counters carry over in the block)
+            monkeypatch.setenv("B2T_WFST_FIN_CLUSTER", mode)
+            S.state.copy_(snap)
+            fin = S.finalize()
+            cn, (arrs, a_off, f_off) = S._lattices()
+            got = (fin, np.array(cn).copy(), [np.array(a).copy() for a in arrs], np.array(a_off).copy(), np.array(f_off).copy())
+            if mode in res:
+                a, b = res[mode], got
+            else:
+                res[mode] = got
+                if mode == "0":
+                    continue
+                a, b = res["0"], got
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), o.__dict__
+            assert int(a[1][:, 1].sum()) > 1000                    # (arcs survive: the comparison is not of empty lattices)
+            for x, y, name in zip(a[2], b[2], ("src", "dst", "ilabel", "olabel", "graph", "acoustic", "final_state", "final_cost")):
+                assert np.array_equal(x, y), (name, o.__dict__)
+            assert a[0] == b[0], o.__dict__
+    monkeypatch.delenv("B2T_WFST_FIN_CLUSTER", raising=False)
