@@ -1766,6 +1766,9 @@ __global__ __launch_bounds__(NT) void wfst_finalize_cluster_kernel(Graph g, char
       const int w = it & 7;
       if (c.gtid == 0) cl->changed[(it + 1) & 7] = 0;       // (last read seven sweeps ago; the next sweep writes it behind this sweep's barrier)
       int moved = 0;
+      // (two relaxation sweeps per meeting: the atomics of one member are in L2 for the others' next loads at once, so values travel
+      //  two links further per barrier; a round in which NOBODY lowered anything read only final values: the fixpoint)
+      for (int rep = 0; rep < 2; ++rep)
       for (int li = e1 - 1 - c.gtid; li >= e0; li -= c.gthreads) {
         const int src = l.link_src[li], dst = l.link_dst[li];
         float lec = __uint_as_float(ldu(&l.tok_extra[dst])) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
@@ -1977,6 +1980,281 @@ __global__ __launch_bounds__(NT) void wfst_prune_kernel(Graph g, char* state, si
     h->peak_tok = max(h->peak_tok, n_tok); h->peak_link = max(h->peak_link, n_link);
     h->removed_tok += n_tok - n_tok_new; h->removed_link += n_link - n_link_new;
     h->n_tok = n_tok_new; h->n_link = n_link_new; h->links_marked = n_link_new; h->n_prunes += 1;
+  }
+}
+
+// PruneActiveTokens by the utterance's CLUSTER (round 5; verdict item 4).  The one-workgroup pass above takes 3.9 ms for 32 utterances
+// (more than the 25 frames of search between two passes): ~30 frames of prune_frame on one CU, then a stable compaction that meets
+// at a barrier every 4096 elements.  Here the G workgroups that search the utterance share the pass:
+//   * PruneForwardLinks per frame as in wfst_finalize_cluster_kernel (L2 atomics on the extra costs), with the pass's own rules:
+//     a frame's tokens are re-initialised when its turn comes (the walk stops at the first frame where nothing moved by more than
+//     delta), so per frame: emitting links | barrier | epsilon sweeps (one barrier each) | epsilon prune + the 'moved' test +
+//     the NEXT frame's initialisation | barrier.  The speculative initialisation of frame f_stop - 1 is undone when the walk stops.
+//   * the compaction meets once per 8 x 4096 elements: every member scans its 4096-element share, publishes one total, and after the
+//     barrier knows its base; tokens get their new ids from per-member prefix counts (one barrier for the whole range).
+// Same surviving set, same order, same ids as the one-workgroup pass (tested array by array on the same state).
+// Scratch: the epsilon work list (rebuilt by every frame of the search) for flags and totals; old frame offsets in LDS.
+__device__ __forceinline__ unsigned ldub(const unsigned char* p) { return (unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(NT) void wfst_prune_cluster_kernel(Graph g, char* state, size_t state_bytes, Opts o, int max_frames,
+                                                                 int max_tok, int max_link, int hash, float delta, float min_fill, int G, int U) {
+  __shared__ int lsh[8], wtot[2][4][NT / 64], tots[80];     // tots[0 .. G]: token bases; tots[40 .. 40 + G]: a link chunk's bases
+  extern __shared__ int old_off[];                 // [max_frames + 3] tok_off, then [2 (max_frames + 3)] link_off, as the pass found them
+  const int b = blockIdx.x, grp = b / (8 * G), r = b % (8 * G);
+  const int j = r / 8, u = grp * 8 + (r % 8);
+  if (u >= U) return;
+  CCtx c;
+  c.g = g; c.o = o; c.max_frames = max_frames; c.max_tok = max_tok; c.max_link = max_link; c.hash = hash;
+  layout(state + (size_t)u * state_bytes, max_frames, max_tok, max_link, hash, &c.l);
+  c.cl = c.l.clu; c.G = G; c.j = j; c.gtid = j * NT + (int)threadIdx.x; c.gthreads = G * NT;
+  c.redf = nullptr; c.redi = nullptr; c.lsh = lsh;
+  c.ll = nullptr; c.key = nullptr; c.idx = nullptr; c.stk_t = nullptr; c.stk_c = nullptr; c.stamped = 0; c.stamp = 0u;
+  if (threadIdx.x < 8) lsh[threadIdx.x] = 0;
+  __syncthreads();
+  const Lay l = c.l;
+  Clu* cl = c.cl;
+  Hdr* h = l.h;
+  c.bar_target = cl->bar_base;
+  const int F = h->n_frames;
+  // (every member reads the same header, written by the previous launch: the same decision, before any barrier)
+  if (F < 2 || h->overflow || h->finalized) return;
+  if ((float)h->n_tok < min_fill * (float)max_tok && (float)h->n_link < min_fill * (float)max_link) return;
+  const unsigned INF_BITS = 0x7f800000u;
+  const float beam = o.lattice_beam;
+  const int n_tok = min(h->n_tok, max_tok), n_link = min(h->n_link, max_link);
+  int* scr = l.wlg;                                  // [0, 8): 'moved' per frame (mod 8); [64 + 32 (chunk mod 8) + member]: chunk totals; [512 + member]: token totals
+  int* tok_off_old = old_off;
+  int* link_off_old = old_off + (max_frames + 3);
+  for (int i = threadIdx.x; i <= F + 1; i += NT) tok_off_old[i] = l.tok_off[i];
+  for (int i = threadIdx.x; i <= 2 * F + 2; i += NT) link_off_old[i] = l.link_off[i];
+  if (c.gtid == 0) {
+    cl->overflow = h->overflow;
+    for (int k = 0; k < 8; ++k) { cl->changed[k] = 0; scr[k] = 0; }
+  }
+  for (int li = h->links_marked + c.gtid; li < n_link; li += c.gthreads) l.link_alive[li] = 1;
+  auto init_frame = [&](int f) {                     // tok_prev = the old extra cost, extra = inf (prune_frame's first pass)
+    const int a0 = tok_off_old[f], a1 = tok_off_old[f + 1];
+    for (int t = a0 + c.gtid; t < a1; t += c.gthreads) { l.tok_prev[t] = ldu(&l.tok_extra[t]); l.tok_extra[t] = INF_BITS; }
+  };
+  __syncthreads();
+  init_frame(F - 1);
+  bool ok = cbar(c);
+  int it = 0, f_stop = -1;
+  for (int f = F - 1; f >= 0 && ok; --f) {
+    const int a0 = tok_off_old[f], a1 = tok_off_old[f + 1];
+    {   // emitting links f -> f + 1
+      const int m0 = link_off_old[2 * f + 1], m1 = min(link_off_old[2 * f + 2], max_link);
+      for (int li = m0 + c.gtid; li < m1; li += c.gthreads) {
+        if (!ldub(&l.link_alive[li])) continue;
+        const int src = l.link_src[li], dst = l.link_dst[li];
+        float lec = __uint_as_float(ldu(&l.tok_extra[dst])) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+        if (lec > beam) { l.link_alive[li] = 0; continue; }
+        if (lec < 0.f) lec = 0.f;
+        atomicMin(&l.tok_extra[src], __float_as_uint(lec));
+      }
+    }
+    ok = cbar(c);
+    if (!ok) break;
+    const int e0 = f == 0 ? 0 : link_off_old[2 * f], e1 = min(link_off_old[2 * f + 1], max_link);
+    for (int iter = 0; iter < 4096 && e1 > e0; ++iter) {
+      const int w = it & 7;
+      if (c.gtid == 0) cl->changed[(it + 1) & 7] = 0;
+      int moved = 0;
+      for (int rep = 0; rep < 2; ++rep)                  // (two sweeps per meeting: see wfst_finalize_cluster_kernel)
+      for (int li = e1 - 1 - c.gtid; li >= e0; li -= c.gthreads) {
+        if (!ldub(&l.link_alive[li])) continue;
+        const int src = l.link_src[li], dst = l.link_dst[li];
+        float lec = __uint_as_float(ldu(&l.tok_extra[dst])) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+        if (!(lec <= beam)) continue;
+        if (lec < 0.f) lec = 0.f;
+        const unsigned nb = __float_as_uint(lec);
+        if (nb < atomicMin(&l.tok_extra[src], nb)) moved = 1;
+      }
+      if (moved) cl->changed[w] = 1;
+      ok = cbar(c);
+      ++it;
+      if (!ok || !ldi(&cl->changed[w])) break;
+    }
+    if (!ok) break;
+    // epsilon links beyond the beam; did an extra cost of this frame move by more than delta?; the next frame's initialisation
+    for (int li = e0 + c.gtid; li < e1; li += c.gthreads) {
+      if (!ldub(&l.link_alive[li])) continue;
+      const int src = l.link_src[li], dst = l.link_dst[li];
+      const float lec = __uint_as_float(ldu(&l.tok_extra[dst])) + ((o2f(l.tok_cost[src]) + l.link_ac[li] + l.link_graph[li]) - o2f(l.tok_cost[dst]));
+      if (lec > beam) l.link_alive[li] = 0;
+    }
+    {
+      int mv = 0;
+      for (int t = a0 + c.gtid; t < a1; t += c.gthreads) {
+        const unsigned nv = ldu(&l.tok_extra[t]), ov = ldu(&l.tok_prev[t]);
+        if (nv != ov && (nv == INF_BITS || ov == INF_BITS || fabsf(__uint_as_float(nv) - __uint_as_float(ov)) > delta)) mv = 1;
+      }
+      if (mv) scr[f & 7] = 1;
+      if (c.gtid == 0) scr[(f + 6) & 7] = 0;           // the word of frame f - 2 (last read two frames ago, by frame f + 6's test)
+    }
+    if (f > 0) init_frame(f - 1);
+    ok = cbar(c);
+    if (!ok) break;
+    if (!ldi(&scr[f & 7])) { f_stop = f; break; }
+  }
+  if (ok && f_stop > 0) {                              // the walk stopped: frame f_stop - 1 keeps its old extra costs
+    const int a0 = tok_off_old[f_stop - 1], a1 = tok_off_old[f_stop];
+    for (int t = a0 + c.gtid; t < a1; t += c.gthreads) l.tok_extra[t] = ldu(&l.tok_prev[t]);
+  }
+  // ---- compaction: tokens of frames f_stop + 1 .. F - 1 (the newest frame's always stay), links from frame f_stop's emitting ones on
+  const int T0 = tok_off_old[f_stop + 1], TF = tok_off_old[F];
+  const int L0 = f_stop >= 0 ? link_off_old[2 * f_stop + 1] : 0;
+  int* excl = reinterpret_cast<int*>(l.tok_prev);      // alive: number of survivors before t in its member's block; dead: the complement of that
+  int flip = 0;
+  auto scan4 = [&](const int (&fl)[4], int (&pos)[4], int& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int v = fl[k];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int x = __shfl_up(v, off, 64); if (lane >= off) v += x; }
+      incl[k] = v;
+      if (lane == 63) wtot[flip][k][w] = v;
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int before = 0, row = 0;
+      for (int ww = 0; ww < NT / 64; ++ww) { const int v = wtot[flip][k][ww]; if (ww < w) before += v; row += v; }
+      pos[k] = run + before + incl[k] - fl[k];
+      run += row;
+    }
+    total = run;
+    flip ^= 1;
+  };
+  // tokens: member j scans the j-th of G equal blocks of [T0, n_tok)
+  const int ntok_span = n_tok - T0;
+  const int tblk = max(4, ((ntok_span + G - 1) / G + 3) & ~3);
+  int n_tok_new = T0;
+  if (ok) {
+    ok = cbar(c);                                      // the undo's loads of tok_prev are done everywhere before tok_prev becomes excl; the last marks are in L2
+  }
+  if (ok) {
+    const int tb0 = T0 + j * tblk, tb1 = min(tb0 + tblk, n_tok);
+    int run = 0;
+    for (int base = tb0; base < tb1; base += 4 * NT) {
+      int fl[4], pos[4], tot;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int t = base + k * NT + (int)threadIdx.x; fl[k] = t < tb1 ? (int)(t >= TF || ldu(&l.tok_extra[t]) != INF_BITS) : 0; }
+      scan4(fl, pos, tot);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int t = base + k * NT + (int)threadIdx.x; if (t < tb1) excl[t] = fl[k] ? run + pos[k] : ~(run + pos[k]); }
+      run += tot;
+    }
+    if (threadIdx.x == 0) scr[512 + j] = run;
+    ok = cbar(c);
+  }
+  if (ok) {
+    if ((int)threadIdx.x <= G) {                       // tots[m] = survivors in the blocks before member m; tots[G] = all
+      int sum = 0;
+      for (int m = 0; m < (int)threadIdx.x; ++m) sum += ldi(&scr[512 + m]);
+      tots[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    n_tok_new = T0 + tots[G];
+  }
+  auto count_before = [&](int p) {                     // survivors in [T0, p)
+    if (p >= n_tok) return tots[G];
+    const int v = ldi(&excl[p]);
+    return tots[(p - T0) / tblk] + (v < 0 ? ~v : v);
+  };
+  auto new_id = [&](int t) {                           // t >= T0: its id after the pass, or -1
+    const int v = ldi(&excl[t]);
+    return v < 0 ? -1 : T0 + tots[(t - T0) / tblk] + v;
+  };
+  if (ok) {
+    for (int fb = f_stop + 1 + c.gtid; fb <= F; fb += c.gthreads) l.tok_off[fb + 1] = T0 + count_before(min(tok_off_old[fb + 1], n_tok));
+  }
+  // links: segment by segment (a frame's epsilon links, its emitting links), chunks of G x 4 NT, member j takes the j-th 4 NT of a chunk
+  int run_l = L0, cc = 0;
+  if (ok) {
+    int seg0 = L0;
+    for (int jb = (f_stop >= 0 ? 2 * f_stop + 1 : 0); jb <= 2 * F && ok; ++jb) {
+      const int seg1 = min(link_off_old[jb + 1], n_link);
+      for (int cb = seg0; cb < seg1 && ok; cb += G * 4 * NT, ++cc) {
+        const int base = cb + j * 4 * NT;
+        int fl[4], pos[4], tot, src[4], dst[4], arc[4]; float ac[4], gr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int li = base + k * NT + (int)threadIdx.x;
+          fl[k] = 0;
+          if (li < seg1) {
+            src[k] = l.link_src[li]; dst[k] = l.link_dst[li]; arc[k] = l.link_arc[li]; ac[k] = l.link_ac[li]; gr[k] = l.link_graph[li];
+            if (ldub(&l.link_alive[li])) {
+              if (src[k] >= T0) src[k] = new_id(src[k]);
+              if (dst[k] >= T0) dst[k] = new_id(dst[k]);
+              fl[k] = src[k] >= 0 && dst[k] >= 0;
+            }
+          }
+        }
+        scan4(fl, pos, tot);
+        if (threadIdx.x == 0) scr[64 + 32 * (cc & 7) + j] = tot;
+        ok = cbar(c);                                    // every read of this chunk is done, every member's total is out
+        if (!ok) break;
+        if ((int)threadIdx.x <= G) {
+          int sum = 0;
+          for (int m = 0; m < (int)threadIdx.x; ++m) sum += ldi(&scr[64 + 32 * (cc & 7) + m]);
+          tots[40 + threadIdx.x] = sum;                  // (tots[0 .. G] keep the token bases)
+        }
+        __syncthreads();
+        const int mybase = run_l + tots[40 + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (fl[k]) {
+          const int q = mybase + pos[k];                 // q <= li
+          l.link_src[q] = src[k]; l.link_dst[q] = dst[k]; l.link_arc[q] = arc[k]; l.link_ac[q] = ac[k]; l.link_graph[q] = gr[k]; l.link_alive[q] = 1;
+        }
+        run_l += tots[40 + G];
+        __syncthreads();                                 // tots[40 ..] are rewritten by the next chunk
+      }
+      if (c.gtid == 0) l.link_off[jb + 1] = run_l;
+      seg0 = seg1;
+    }
+  }
+  const int n_link_new = run_l;
+  // tokens move down: chunks of G x 4 NT, reads and writes of a chunk separated by a barrier (ids only go down)
+  if (ok) {
+    for (int cb = T0; cb < n_tok && ok; cb += G * 4 * NT) {
+      const int base = cb + j * 4 * NT;
+      int k2[4], st[4]; unsigned cs[4], ex[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = base + k * NT + (int)threadIdx.x;
+        k2[k] = -1;
+        if (t < n_tok) { k2[k] = new_id(t); st[k] = l.tok_state[t]; cs[k] = l.tok_cost[t]; ex[k] = ldu(&l.tok_extra[t]); }
+      }
+      ok = cbar(c);
+      if (!ok) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k2[k] >= 0) { l.tok_state[k2[k]] = st[k]; l.tok_cost[k2[k]] = cs[k]; l.tok_extra[k2[k]] = ex[k]; l.tok_best[k2[k]] = BEST_UNSET; }
+    }
+  }
+  if (ok) ok = cbar(c);
+  if (ok) {
+    // backpointers of the moved tokens: the first surviving link whose cost equals the token's (best_links' rule)
+    for (int li = L0 + c.gtid; li < n_link_new; li += c.gthreads) {
+      const int src = ldi(&l.link_src[li]), dst = ldi(&l.link_dst[li]);
+      if (dst < T0) continue;
+      const float tot = o2f(ldu(&l.tok_cost[src])) + ldf(&l.link_ac[li]) + ldf(&l.link_graph[li]);
+      if (f2o(tot) == ldu(&l.tok_cost[dst])) atomicMin(&l.tok_best[dst], best_word(li, src));
+    }
+  }
+  __syncthreads();
+  if (c.gtid == 0) {
+    if (ok) {
+      if (T0 == 0) l.tok_best[0] = -1;
+      h->peak_tok = max(h->peak_tok, n_tok); h->peak_link = max(h->peak_link, n_link);
+      h->removed_tok += n_tok - n_tok_new; h->removed_link += n_link - n_link_new;
+      h->n_tok = n_tok_new; h->n_link = n_link_new; h->links_marked = n_link_new; h->n_prunes += 1;
+    }
+    h->overflow = ldi(&cl->overflow);
+    cl->bar_base = c.bar_target;
   }
 }
 
@@ -2307,6 +2585,19 @@ extern "C" int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* 
   { int rc = check_args(g, o, state, U, "wfst_prune"); if (rc) return rc; }
   B2T_REQUIRE(delta >= 0.f && min_fill >= 0.f && min_fill <= 1.f, "wfst_prune: bad delta / min_fill");
   const size_t sb = b2t_wfst_state_bytes(o->max_frames, o->max_tokens, o->max_links, o->hash_size);
+  {   // the utterance's cluster prunes where the cluster searches (B2T_WFST_PRUNE_CLUSTER=0, read per call: one workgroup per utterance)
+    const char* e = getenv("B2T_WFST_PRUNE_CLUSTER");
+    const int G = (e && atoi(e) == 0) ? 1 : b2t_wfst_cluster_size(U);
+    const size_t lds = (size_t)3 * (o->max_frames + 3) * sizeof(int);
+    if (G > 1 && lds <= 96 * 1024) {
+      const int grid = (U + 7) / 8 * 8 * G;
+      allow_lds(wfst_prune_cluster_kernel, lds);
+      hipLaunchKernelGGL(wfst_prune_cluster_kernel, dim3(grid), dim3(NT), lds, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
+                         o->max_frames, o->max_tokens, o->max_links, o->hash_size, delta, min_fill, G, U);
+      B2T_CHECK_LAUNCH("b2t_wfst_prune (cluster)");
+      return 0;
+    }
+  }
   allow_lds(wfst_prune_kernel, PRUNE_LDS_WORDS * sizeof(unsigned));
   hipLaunchKernelGGL(wfst_prune_kernel, dim3(U), dim3(NT), PRUNE_LDS_WORDS * sizeof(unsigned), as_stream(stream), to_graph(g), (char*)state, sb,
                      to_opts(o), o->max_frames, o->max_tokens, o->max_links, o->hash_size, delta, min_fill);

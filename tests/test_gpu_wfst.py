@@ -775,3 +775,77 @@ def test_cluster_finalize_equals_single_workgroup_finalize(toy, monkeypatch):
                 assert np.array_equal(x, y), (name, o.__dict__)
             assert a[0] == b[0], o.__dict__
     monkeypatch.delenv("B2T_WFST_FIN_CLUSTER", raising=False)
+
+
+def test_cluster_prune_equals_single_workgroup_prune(toy, monkeypatch):
+    """Round 5 (verdict item 4): PruneActiveTokens by the utterance's cluster -- the per-frame walk with L2 atomics, the stable
+    compaction with one cluster barrier per 8 x 4096 elements -- against the one-workgroup pass (`B2T_WFST_PRUNE_CLUSTER=0`) on the SAME
+    search state (snapshot / restore, as in the finalize test): after the pass the state block's token and link arrays, the frame
+    offsets and the header counters are identical; decoding then continues from both and ends in identical lattices.  Several passes
+    in a row (a pass over an already pruned lattice stops after a few frames), delta 0 and the production delta, an utterance that
+    ended long ago next to running ones."""
+    import b2t_native as N
+    import ctypes as C
+    from wfst_decoder import WfstSearch
+    lib = N.load()
+    prons, words, g, _ = toy
+    rs = np.random.RandomState(91)
+    seqs, lps, batch, lens = utterances(prons, words, 8, rs, noise=1.0, n_words=(1, 6))
+    lens = lens.copy(); lens[6] = 3
+    dev_batch = torch.from_numpy(batch).cuda()
+    T = batch.shape[1]
+    for o, delta in ((Opt(nbest=30), None), (Opt(nbest=30, lattice_beam=4.0), 0.0), (Opt(nbest=30, max_active=250, min_active=60, beam=11.0), None)):
+        S = WfstSearch(g, o, U=8, max_frames=T + 8, prune_interval=0)
+        # b2t_wfst_state_offsets: h, mapping, tok_off, link_off, cost_offset, tok_state, tok_cost, tok_extra, link_src, link_dst, link_arc, link_ac, link_graph, link_alive, tok_best, last_prob
+        off = S.off
+        arrays = dict(tok_off=(2, 4), link_off=(3, 4), tok_state=(5, 4), tok_cost=(6, 4), tok_extra=(7, 4), link_src=(8, 4), link_dst=(9, 4), link_arc=(10, 4),
+                      link_ac=(11, 4), link_graph=(12, 4), link_alive=(13, 1), tok_best=(14, 8))
+        d = float(o.lattice_beam) * 0.1 if delta is None else delta
+        cuts = [0, 11, 30, 31, 55, T]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            S.search(dev_batch[:, a:b].contiguous(), np.clip(lens - a, 0, b - a))
+            torch.cuda.synchronize()
+            snap = S.state.clone()
+            outs = []
+            for mode in ("0", "1"):
+                monkeypatch.setenv("B2T_WFST_PRUNE_CLUSTER", mode)
+                S.state.copy_(snap)
+                N.check(lib.b2t_wfst_prune(C.byref(S.cg), C.byref(S.co), ops_p(S.state), 8, C.c_float(d), C.c_float(0.0), S._s()), "b2t_wfst_prune")
+                torch.cuda.synchronize()
+                outs.append(S.state.clone())
+            v0, v1 = (x.view(8, S.state_bytes) for x in outs)
+            hdr0, hdr1 = (v[:, :80].contiguous().view(torch.int32).cpu().numpy() for v in (v0, v1))
+            assert np.array_equal(hdr0, hdr1), (a, b, hdr0[:, :4], hdr1[:, :4])
+            n_tok, n_link, nfr = hdr0[:, 1], hdr0[:, 2], hdr0[:, 0]
+            assert int(hdr0[:, 17].sum()) > 0 or a == 0          # (removed_link: the passes do remove something)
+            for u in range(8):
+                for name, (k, wd) in arrays.items():
+                    n = {"tok_off": nfr[u] + 2, "link_off": 2 * nfr[u] + 2}.get(name, n_tok[u] if name.startswith("tok_") else n_link[u])
+                    x0 = v0[u, off[k]:off[k] + wd * int(n)].cpu().numpy(); x1 = v1[u, off[k]:off[k] + wd * int(n)].cpu().numpy()
+                    assert np.array_equal(x0, x1), (name, u, a, b, o.__dict__)
+            # (decoding goes on from the cluster pass's state)
+        fin = S.finalize()
+        # ... and ends where a searcher ends that took the same passes with the one-workgroup kernel (lists, not arrays: two searches
+        # number their tokens in arrival order).  Against the ORACLE only the first case is compared: with delta 0 / a 4.0 lattice beam
+        # a pass at an arbitrary frame can drop a path that sits on the beam's edge in fp32 -- either kernel, same lists.
+        monkeypatch.setenv("B2T_WFST_PRUNE_CLUSTER", "0")
+        S0 = WfstSearch(g, o, U=8, max_frames=T + 8, prune_interval=0)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            S0.search(dev_batch[:, a:b].contiguous(), np.clip(lens - a, 0, b - a))
+            N.check(lib.b2t_wfst_prune(C.byref(S0.cg), C.byref(S0.co), ops_p(S0.state), 8, C.c_float(d), C.c_float(0.0), S0._s()), "b2t_wfst_prune")
+        fin0 = S0.finalize()
+        for u in range(8):
+            assert len(fin[u]) == len(fin0[u]) > 0
+            for x, y in zip(fin[u], fin0[u]):
+                assert x[2] == y[2] and x[0] == y[0] and x[1] == y[1] and abs(x[3] - y[3]) < 1e-5 and abs(x[4] - y[4]) < 1e-5, (u, o.__dict__)
+        if delta is None and o.max_active > 1000:
+            for u in range(8):
+                R = W.CtcWfstBeamSearch(g, cfg_of(o))
+                R.search(lps[u][:lens[u]]); R.finalize_search()
+                compare_lists(fin[u], R, f"after cluster prune passes, utt {u}")
+    monkeypatch.delenv("B2T_WFST_PRUNE_CLUSTER", raising=False)
+
+
+def ops_p(t):
+    import b2t_ops as ops
+    return ops._p(t)
