@@ -2172,50 +2172,59 @@ __global__ __launch_bounds__(NT) void wfst_prune_cluster_kernel(Graph g, char* s
   if (ok) {
     for (int fb = f_stop + 1 + c.gtid; fb <= F; fb += c.gthreads) l.tok_off[fb + 1] = T0 + count_before(min(tok_off_old[fb + 1], n_tok));
   }
-  // links: segment by segment (a frame's epsilon links, its emitting links), chunks of G x 4 NT, member j takes the j-th 4 NT of a chunk
+  // links: chunks of G x 4 NT over [L0, n_link), member j takes the j-th 4 NT of a chunk; ONE barrier per chunk.  The segment offsets
+  // (a frame's epsilon links, its emitting links) come out on the way: link_off[jb + 1] = L0 + survivors before its old value p, which
+  // the thread holding element p knows once the members' totals are in (the first version walked segment by segment: a barrier per
+  // segment, ~60 of the pass's ~75 compaction barriers)
   int run_l = L0, cc = 0;
   if (ok) {
-    int seg0 = L0;
-    for (int jb = (f_stop >= 0 ? 2 * f_stop + 1 : 0); jb <= 2 * F && ok; ++jb) {
-      const int seg1 = min(link_off_old[jb + 1], n_link);
-      for (int cb = seg0; cb < seg1 && ok; cb += G * 4 * NT, ++cc) {
-        const int base = cb + j * 4 * NT;
-        int fl[4], pos[4], tot, src[4], dst[4], arc[4]; float ac[4], gr[4];
+    int jb = f_stop >= 0 ? 2 * f_stop + 1 : 0;         // the next segment end to place (offsets are sorted)
+    for (int cb = L0; cb < n_link && ok; cb += G * 4 * NT, ++cc) {
+      const int base = cb + j * 4 * NT;
+      int fl[4], pos[4], tot, src[4], dst[4], arc[4]; float ac[4], gr[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int li = base + k * NT + (int)threadIdx.x;
-          fl[k] = 0;
-          if (li < seg1) {
-            src[k] = l.link_src[li]; dst[k] = l.link_dst[li]; arc[k] = l.link_arc[li]; ac[k] = l.link_ac[li]; gr[k] = l.link_graph[li];
-            if (ldub(&l.link_alive[li])) {
-              if (src[k] >= T0) src[k] = new_id(src[k]);
-              if (dst[k] >= T0) dst[k] = new_id(dst[k]);
-              fl[k] = src[k] >= 0 && dst[k] >= 0;
-            }
+      for (int k = 0; k < 4; ++k) {
+        const int li = base + k * NT + (int)threadIdx.x;
+        fl[k] = 0;
+        if (li < n_link) {
+          src[k] = l.link_src[li]; dst[k] = l.link_dst[li]; arc[k] = l.link_arc[li]; ac[k] = l.link_ac[li]; gr[k] = l.link_graph[li];
+          if (ldub(&l.link_alive[li])) {
+            if (src[k] >= T0) src[k] = new_id(src[k]);
+            if (dst[k] >= T0) dst[k] = new_id(dst[k]);
+            fl[k] = src[k] >= 0 && dst[k] >= 0;
           }
         }
-        scan4(fl, pos, tot);
-        if (threadIdx.x == 0) scr[64 + 32 * (cc & 7) + j] = tot;
-        ok = cbar(c);                                    // every read of this chunk is done, every member's total is out
-        if (!ok) break;
-        if ((int)threadIdx.x <= G) {
-          int sum = 0;
-          for (int m = 0; m < (int)threadIdx.x; ++m) sum += ldi(&scr[64 + 32 * (cc & 7) + m]);
-          tots[40 + threadIdx.x] = sum;                  // (tots[0 .. G] keep the token bases)
-        }
-        __syncthreads();
-        const int mybase = run_l + tots[40 + j];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (fl[k]) {
-          const int q = mybase + pos[k];                 // q <= li
-          l.link_src[q] = src[k]; l.link_dst[q] = dst[k]; l.link_arc[q] = arc[k]; l.link_ac[q] = ac[k]; l.link_graph[q] = gr[k]; l.link_alive[q] = 1;
-        }
-        run_l += tots[40 + G];
-        __syncthreads();                                 // tots[40 ..] are rewritten by the next chunk
       }
-      if (c.gtid == 0) l.link_off[jb + 1] = run_l;
-      seg0 = seg1;
+      scan4(fl, pos, tot);
+      if (threadIdx.x == 0) scr[64 + 32 * (cc & 7) + j] = tot;
+      ok = cbar(c);                                    // every read of this chunk is done, every member's total is out
+      if (!ok) break;
+      if ((int)threadIdx.x <= G) {
+        int sum = 0;
+        for (int m = 0; m < (int)threadIdx.x; ++m) sum += ldi(&scr[64 + 32 * (cc & 7) + m]);
+        tots[40 + threadIdx.x] = sum;                  // (tots[0 .. G] keep the token bases)
+      }
+      __syncthreads();
+      const int mybase = run_l + tots[40 + j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (fl[k]) {
+        const int q = mybase + pos[k];                 // q <= li
+        l.link_src[q] = src[k]; l.link_dst[q] = dst[k]; l.link_arc[q] = arc[k]; l.link_ac[q] = ac[k]; l.link_graph[q] = gr[k]; l.link_alive[q] = 1;
+      }
+      // segment ends inside this chunk
+      const int cend = cb + G * 4 * NT;
+      while (jb <= 2 * F && link_off_old[jb + 1] < cend && link_off_old[jb + 1] < n_link) {
+        const int p = link_off_old[jb + 1], e = p - base;          // (p >= cb: the ends are sorted and the earlier ones are placed)
+        if (e >= 0 && e < 4 * NT && (e & (NT - 1)) == (int)threadIdx.x) {
+          const int k = e / NT;
+          l.link_off[jb + 1] = mybase + (k == 0 ? pos[0] : k == 1 ? pos[1] : k == 2 ? pos[2] : pos[3]);
+        }
+        ++jb;
+      }
+      run_l += tots[40 + G];
+      __syncthreads();                                 // tots[40 ..] are rewritten by the next chunk
     }
+    if (ok) for (int q = jb + c.gtid; q <= 2 * F; q += c.gthreads) l.link_off[q + 1] = run_l;      // ends at (or clamped to) the last link
   }
   const int n_link_new = run_l;
   // tokens move down: chunks of G x 4 NT, reads and writes of a chunk separated by a barrier (ids only go down)
