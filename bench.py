@@ -391,9 +391,12 @@ def main():
     # run that finds itself in the slow mode additionally starts over, at most twice, so that the line can show what other
     # processes on the same box measure: every process run is listed in `process_runs`, the fastest one in `best_process_ms`
     # -- beside the headline, never instead of it (B2T_BENCH_NO_RESTART=1: never start over).
-    restarts = int(os.environ.get("B2T_BENCH_RESTARTS", "0"))
+    # (the chain of processes is one pid -- execv keeps it --: a CHILD process that inherits these variables, e.g. a secondary run
+    #  spawned by a re-started parent, starts its own chain)
+    chained = os.environ.get("B2T_BENCH_CHAIN") == str(os.getpid())
+    restarts = int(os.environ.get("B2T_BENCH_RESTARTS", "0")) if chained else 0
     slow_ms = float(os.environ.get("B2T_BENCH_SLOW_ENQ_MS", "3.0"))
-    runs = json.loads(os.environ.get("B2T_BENCH_PROCESS_RUNS", "[]"))
+    runs = json.loads(os.environ.get("B2T_BENCH_PROCESS_RUNS", "[]")) if chained else []
     runs.append(dict(process=restarts + 1, ms_per_step=round(dt / a.steps * 1e3, 3), host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3),
                      sentences_per_s=round(rows * world * a.steps / dt, 2),
                      kernel_launch_us_p50=host_api["kernel_launch_us"]["p50"] if host_api else None))
@@ -401,6 +404,7 @@ def main():
             and os.environ.get("B2T_BENCH_NO_RESTART") is None):
         os.environ["B2T_BENCH_PROCESS_RUNS"] = json.dumps(runs)
         os.environ["B2T_BENCH_RESTARTS"] = str(restarts + 1)
+        os.environ["B2T_BENCH_CHAIN"] = str(os.getpid())
         sys.stderr.write(f"[bench] slow-process mode (host enqueue {t_enq / a.steps * 1e3:.2f} ms per step, {dt / a.steps * 1e3:.3f} ms per step): one more "
                          f"process for comparison ({restarts + 1} of 2); the headline stays the first process's\n")
         sys.stdout.flush(); sys.stderr.flush()

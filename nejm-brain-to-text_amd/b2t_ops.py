@@ -351,8 +351,30 @@ def host_api_probe(n: int = 200) -> dict:
                 torch.cuda.synchronize()
         ts.sort()
         out[name] = dict(p50=round(ts[len(ts) // 2] * 1e6, 2), p90=round(ts[int(len(ts) * 0.9)] * 1e6, 2))
+    # ... and the same calls the way a pass issues them: four streams, every launch behind an event of the stream before it, nothing
+    # waited for -- microseconds per runtime call with the queues filling up.  (Round 5 caught one slow process: its IDLE latencies
+    # above were those of a healthy one, 7.5 / 4.7 / 0.5 us, while its step enqueued in 5.4 ms instead of 1.5 -- the mode shows
+    # under load only.)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    evs = [torch.cuda.Event() for _ in range(4)]
+    cur = torch.cuda.current_stream()
+    ncall = 0
     torch.cuda.synchronize()
-    out["slow"] = bool(out["kernel_launch_us"]["p50"] > 15.0)
+    t0 = time.perf_counter()
+    for rnd in range(48):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if rnd or i:
+                    st.wait_event(evs[(i - 1) % 4])
+                lib.b2t_transpose_f32(_p(a), _p(b), 64, 64, _stream())
+                lib.b2t_transpose_f32(_p(b), _p(a), 64, 64, _stream())
+                evs[i].record(st)
+            ncall += 4
+    t_burst = time.perf_counter() - t0
+    cur.wait_event(evs[3])
+    torch.cuda.synchronize()
+    out["burst_us_per_call"] = round(t_burst / ncall * 1e6, 2)
+    out["slow"] = bool(out["kernel_launch_us"]["p50"] > 15.0 or out["burst_us_per_call"] > 15.0)
     return out
 
 

@@ -229,7 +229,7 @@ class BrainToTextDecoder_Trainer:
             pr = ops.host_api_probe()
             self.host_api = pr
             msg = (f"HIP host latency: kernel launch {pr['kernel_launch_us']['p50']} us, event record {pr['event_record_us']['p50']} us, "
-                   f"stream wait {pr['stream_wait_event_us']['p50']} us (p50)")
+                   f"stream wait {pr['stream_wait_event_us']['p50']} us (p50); {pr['burst_us_per_call']} us per call in a four-stream burst")
             if pr["slow"]:
                 self.logger.warning(msg + " -- this process is in the slow-host mode (healthy: ~7 / 5 / 0.5 us): expect ~3x the host enqueue "
                                           "time per step and a 5-10 % slower step; a fresh process usually is not")

@@ -272,6 +272,9 @@ def dp_forced_one_rank(steps: int = 30):
     def run(extra):
         env = dict(os.environ, **extra)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k in ("B2T_BENCH_PROCESS_RUNS", "B2T_BENCH_RESTARTS", "B2T_BENCH_CHAIN"):      # a re-started parent's chain is not the child's
+            env.pop(k, None)
+        env["B2T_BENCH_NO_RESTART"] = "1"
         best = None
         for _ in range(2):
             r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600)
