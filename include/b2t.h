@@ -460,6 +460,10 @@ void* b2t_fst_arcsort(const void* fst, int by_olabel);
 void* b2t_fst_read_openfst(const char* path);
 int b2t_fst_write_openfst(const void* fst, const char* path);
 double b2t_fst_grammar_score(const void* fst, const int32_t* words, int n_words, int backoff_label);
+/* fst::ReadAndPrepareLmFst (kaldi/fstext/kaldi-fst-io.cc:129-147): NEW handle = the grammar projected on its output labels if it is
+ * not an acceptor, arc-sorted by ilabel; *backoff_label = the label its back-off arcs carry (0; `disambig_id` for an acceptor with #0
+ * on both sides and no label-0 arc; disambig_id < 0: never). */
+void* b2t_fst_prepare_lm(const void* fst, int disambig_id, int* backoff_label);
 
 /* ---- a15/a16: WFST token passing (the reference's LM decode proper) ---------------------------------------------------
  * CtcWfstBeamSearch::Search / FinalizeSearch (language_model/runtime/core/decoder/ctc_wfst_beam_search.cc:70-160) over

@@ -154,6 +154,7 @@ _SIGNATURES = {
     "b2t_fst_read_openfst": (VP, [C.c_char_p]),
     "b2t_fst_write_openfst": (C.c_int, [VP, C.c_char_p]),
     "b2t_fst_grammar_score": (C.c_double, [VP, VP, C.c_int, C.c_int]),
+    "b2t_fst_prepare_lm": (VP, [VP, C.c_int, VP]),
     "b2t_wfst_state_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "b2t_wfst_cluster_size": (C.c_int, [C.c_int]),
     "b2t_wfst_set_cluster": (C.c_int, [C.c_int]),

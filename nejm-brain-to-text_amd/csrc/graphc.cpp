@@ -162,6 +162,28 @@ extern "C" void* b2t_fst_arcsort(const void* h, int by_olabel) {
   return g;
 }
 
+// fst::ReadAndPrepareLmFst (kaldi/fstext/kaldi-fst-io.cc:129-147) without leaving C++: a grammar that is not an acceptor is
+// projected on its OUTPUT labels, then arcs are sorted by input label.  *backoff_label: 0, unless the grammar is an acceptor in
+// which no arc carries label 0 while arcs carry `disambig_id` (>= 0: words.txt's id of "#0" -- a grammar compiled with #0 on both
+// sides).  (The Python host used to copy the whole grammar into numpy for the `ilabel != olabel` test: G_no_prune.fst has ~1e9 arcs.)
+extern "C" void* b2t_fst_prepare_lm(const void* h, int disambig_id, int* backoff_label) {
+  if (!h || !backoff_label) { set_error("fst_prepare_lm: null argument"); return nullptr; }
+  const HFst& f = *CFST(h);
+  bool acceptor = true, has0 = false, has_dis = false;
+  for (const HArc& a : f.arcs) {
+    acceptor = acceptor && a.il == a.ol;
+    has0 = has0 || a.il == 0;
+    has_dis = has_dis || (disambig_id >= 0 && a.il == disambig_id);
+  }
+  HFst* g = new HFst(f);
+  *backoff_label = 0;
+  if (!acceptor) { for (HArc& a : g->arcs) a.il = a.ol; }
+  else if (!f.arcs.empty() && !has0 && has_dis) *backoff_label = disambig_id;
+  for (int s = 0; s < g->n(); ++s)
+    std::stable_sort(g->arcs.begin() + g->row[s], g->arcs.begin() + g->row[(size_t)s + 1], [](const HArc& a, const HArc& b) { return a.il < b.il; });
+  return g;
+}
+
 // ---- composition with the epsilon-matching filter ---------------------------------------------------------------------------
 extern "C" void* b2t_fst_compose(const void* ha, const void* hb) {
   if (!ha || !hb) { set_error("fst_compose: null"); return nullptr; }

@@ -623,14 +623,10 @@ class HostFst:
         0 after a projection, and for an acceptor 0 too -- unless no arc carries label 0 while arcs carry `disambig_id`
         (words.txt's id of "#0"): a grammar compiled with #0 on both sides, which fst::Compose could not back off through at
         all; following those arcs is the friendlier reading."""
-        row, il, ol, w, nx, fc = self.arrays()
-        if il.shape[0] and np.any(il != ol):
-            src = np.repeat(np.arange(len(fc)), np.diff(row))
-            return HostFst.from_arrays(len(fc), self.info()["start"], src, ol, ol, w, nx, fc).arcsort(), 0
-        backoff = 0
-        if disambig_id is not None and il.shape[0] and not np.any(il == 0) and np.any(il == disambig_id):
-            backoff = int(disambig_id)
-        return self.arcsort(), backoff
+        import ctypes as C
+        backoff = C.c_int(0)      # (the acceptor test, the projection and the sort stay in C++: the grammar is never copied into numpy)
+        h = self._lib().b2t_fst_prepare_lm(self._h, -1 if disambig_id is None else int(disambig_id), C.byref(backoff))
+        return HostFst(h), int(backoff.value)
 
     def grammar_score(self, word_ids: Sequence[int], backoff_label: int) -> float:
         """Needs an ilabel-sorted grammar (arcsort())."""

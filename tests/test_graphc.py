@@ -281,3 +281,36 @@ def test_openfst_container_and_grammar_score(tmp_path):
         ids = [int(x) for x in rs.randint(1, len(words) + 1, size=rs.randint(0, 6))]
         a, b = wfst.grammar_score(G, ids, wd0), Gh.grammar_score(ids, wd0)
         assert (math.isinf(a) and math.isinf(b)) or abs(a - b) < 1e-4, (ids, a, b)
+
+
+def test_prepare_lm_projects_non_acceptors_and_finds_the_backoff_label():
+    """fst::ReadAndPrepareLmFst (kaldi/fstext/kaldi-fst-io.cc:129-147) in C++ (b2t_fst_prepare_lm; round 5: the Python host used to copy
+    the whole grammar into numpy for the acceptor test): a transducer grammar (#0 on the back-off arcs' INPUT side only, as
+    eps2disambig.pl leaves it) is projected on its output labels and arc-sorted, back-off label 0; an acceptor stays as it is; an
+    acceptor with #0 on BOTH sides and no label-0 arc reports #0 as its back-off label -- against the numpy statement of the same rule."""
+    rng = np.random.RandomState(3)
+    n, m, dis = 7, 40, 9
+    src = rng.randint(0, n, m).astype(np.int32); dst = rng.randint(0, n, m).astype(np.int32)
+    ol = rng.randint(1, 8, m).astype(np.int32); w = rng.rand(m).astype(np.float32)
+    fc = np.where(rng.rand(n) < 0.4, rng.rand(n), np.inf).astype(np.float32)
+    back = rng.rand(m) < 0.25
+    cases = {"transducer": (np.where(back, dis, ol).astype(np.int32), np.where(back, 0, ol).astype(np.int32)),
+             "acceptor_eps": (np.where(back, 0, ol).astype(np.int32),) * 2,
+             "acceptor_hash0": (np.where(back, dis, ol).astype(np.int32),) * 2}
+    for name, (il_c, ol_c) in cases.items():
+        f = wfst.HostFst.from_arrays(n, 0, src, il_c, ol_c, w, dst, fc)
+        got, backoff = f.prepare_lm(dis)
+        row, il, ol2, w2, nx, fc2 = got.arrays()
+        # the rule, in numpy
+        want_il = ol_c if np.any(il_c != ol_c) else il_c
+        want_back = dis if (not np.any(il_c != ol_c) and not np.any(il_c == 0) and np.any(il_c == dis)) else 0
+        assert backoff == want_back, name
+        assert np.array_equal(fc2, fc)
+        for s in range(n):
+            idx = np.flatnonzero(src == s)
+            order = idx[np.argsort(want_il[idx], kind="stable")]
+            a, b = int(row[s]), int(row[s + 1])
+            assert b - a == len(idx)
+            assert np.array_equal(il[a:b], want_il[order]) and np.array_equal(ol2[a:b], ol_c[order]), (name, s)
+            assert np.array_equal(nx[a:b], dst[order]) and np.array_equal(w2[a:b], w[order])
+        assert f.prepare_lm(None)[1] == 0
