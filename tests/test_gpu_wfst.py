@@ -631,9 +631,16 @@ def test_wfst_search_matches_oracle_on_random_graphs_and_options(seed):
             S.search(dev_batch, lens)
         fin = S.finalize()
         for u in range(U):
-            R = W.CtcWfstBeamSearch(g, cfg_of(o))
+            # lists against the oracle's data-parallel cut-off rule (what csrc/wfst.hip computes: exact in every regime); the best
+            # hypothesis also against the reference-order walk -- on these small graphs max_active = 400 can bind, and the two rules
+            # then differ in the tail of a list (tools/r5_wfst_fuzz_more.py: 2 of 12 further seeds, ranks 14 and 18; NOTES.md R5.2)
+            tag = f"seed {seed} case {case} utt {u}: words {n_words} order {order} opts {o.__dict__} interval {iv}"
+            R = W.CtcWfstBeamSearch(g, cfg_of(o, "final"))
             R.search(lps[u]); R.finalize_search()
-            compare_lists(fin[u], R, f"seed {seed} case {case} utt {u}: words {n_words} order {order} opts {o.__dict__} interval {iv}")
+            compare_lists(fin[u], R, tag)
+            Rs = W.CtcWfstBeamSearch(g, cfg_of(o, "sequential"))
+            Rs.search(lps[u]); Rs.finalize_search()
+            assert _first_diff(fin[u], Rs) != 0, tag + ": best hypothesis differs from the reference-order oracle's"
 
 
 
