@@ -10,6 +10,8 @@
 // one-pass kernel converts fp32 operands on their way into LDS and reaches 315 TF/s at 4096^3; with packed operands the
 // same tile shape runs at 700-840 TF/s (tools/ubench/gemm_bf16p.hip), and a pack pass is bandwidth-bound and small next
 // to it.  Z-batched GEMMs (the day layer) stay on the one-pass kernel.
+// Round 5: a second tile kernel, 256 x 256 x 64 with 8 waves (gemm_bf16p_kernel256, below), takes the products whose 256-tiles fill
+// the chip evenly (the shipped shape's layer-0 weight and input gradients: 660 -> 880 TF/s, bit-identical results).
 #include "common.h"
 #include "gemm_args.h"
 
@@ -211,6 +213,146 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __
   }
 }
 
+
+// ---- 256 x 256 x 64 tiles, 8 waves (2 x 4), a wave owns 128 x 64 (round 5) -----------------------------------------------------
+// Why: in the 128 x 128 kernel a wave's 64 x 64 sub-tile reads 4 fragments from LDS per 4 MFMAs; with two workgroups per CU that is
+// 256 LDS cycles per k16 step next to 256 MFMA cycles per SIMD -- the LDS port is as busy as the matrix cores, which is the
+// 450-650 TF/s the chip-filling GEMMs of the shipped shape's layer 0 run at.  A 128 x 64 wave tile reads 6 fragments per 8 MFMAs
+// (0.75 of the MFMA time), and a 256-row block fetches each operand panel half as often.  Same structure otherwise: register
+// prefetch of the next k tile, double-buffered LDS (144-byte rows), one barrier per k tile; one workgroup (144 KB of LDS) per CU,
+// two waves per SIMD.  Used when the tile count fills the chip evenly (gemm_bf16p_run); operand rows beyond the packed matrix
+// (padded to 128) are clamped -- those output rows are never stored.
+constexpr int QM = 256, QN = 256;
+constexpr size_t Q_LDS = (size_t)2 * (QM + QN) * PPITCH * sizeof(__bf16);
+
+#define B2T_QFETCH(k0)                                                                                                    \
+  ra0 = *reinterpret_cast<const uint4*>(Ap + ao0 + (k0)); ra1 = *reinterpret_cast<const uint4*>(Ap + ao1 + (k0));          \
+  ra2 = *reinterpret_cast<const uint4*>(Ap + ao2 + (k0)); ra3 = *reinterpret_cast<const uint4*>(Ap + ao3 + (k0));          \
+  rb0 = *reinterpret_cast<const uint4*>(Bp + bo0 + (k0)); rb1 = *reinterpret_cast<const uint4*>(Bp + bo1 + (k0));          \
+  rb2 = *reinterpret_cast<const uint4*>(Bp + bo2 + (k0)); rb3 = *reinterpret_cast<const uint4*>(Bp + bo3 + (k0));
+#define B2T_QSTASH(buf)                                                                                                   \
+  { __bf16* ad = As + (buf) * QM * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
+    __bf16* bd = Bs + (buf) * QN * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
+    *reinterpret_cast<uint4*>(ad) = ra0; *reinterpret_cast<uint4*>(ad + 64 * PPITCH) = ra1;                               \
+    *reinterpret_cast<uint4*>(ad + 128 * PPITCH) = ra2; *reinterpret_cast<uint4*>(ad + 192 * PPITCH) = ra3;               \
+    *reinterpret_cast<uint4*>(bd) = rb0; *reinterpret_cast<uint4*>(bd + 64 * PPITCH) = rb1;                               \
+    *reinterpret_cast<uint4*>(bd + 128 * PPITCH) = rb2; *reinterpret_cast<uint4*>(bd + 192 * PPITCH) = rb3; }
+
+__global__ __launch_bounds__(512) void gemm_bf16p_kernel256(GemmArgs g, const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp, int Kp, int Mp, int Np) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 qsmem[];
+  __bf16* As = qsmem; __bf16* Bs = qsmem + 2 * QM * PPITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  int ks = blockIdx.z;
+  int m0, n0;
+  {
+    const int gx = (Np + QN - 1) / QN, nwg = gridDim.x;
+    int tile;
+    if (g.ks_xcd) {
+      const int lin = blockIdx.x + nwg * blockIdx.z, xcd = lin & 7, j = lin >> 3;
+      ks = xcd + 8 * (j / nwg); tile = j % nwg;
+    } else {
+      const int b = blockIdx.x, xcd = b & 7, qq = nwg >> 3, rr = nwg & 7;
+      tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (b >> 3);
+    }
+    if (g.tile_gm > 1) {
+      const int gy = nwg / gx, per_group = g.tile_gm * gx;
+      const int grp = tile / per_group, first_m = grp * g.tile_gm;
+      const int gm_eff = min(g.tile_gm, gy - first_m), r = tile - grp * per_group;
+      m0 = (first_m + r % gm_eff) * QM; n0 = (r / gm_eff) * QN;
+    } else {
+      m0 = (tile / gx) * QM; n0 = (tile % gx) * QN;
+    }
+  }
+  const float* bias = (g.bias && ks == 0) ? g.bias : nullptr;
+  float* C = g.C + (long long)ks * g.c_ks;
+  const int kb = ks * g.kchunk, ke = min(Kp, kb + g.kchunk), nk = (ke - kb) / PK;
+  const int r0 = tid >> 3, kc = (tid & 7) * 8 + kb;
+  const long long ao0 = (long long)min(m0 + r0, Mp - 1) * Kp + kc, ao1 = (long long)min(m0 + r0 + 64, Mp - 1) * Kp + kc;
+  const long long ao2 = (long long)min(m0 + r0 + 128, Mp - 1) * Kp + kc, ao3 = (long long)min(m0 + r0 + 192, Mp - 1) * Kp + kc;
+  const long long bo0 = (long long)min(n0 + r0, Np - 1) * Kp + kc, bo1 = (long long)min(n0 + r0 + 64, Np - 1) * Kp + kc;
+  const long long bo2 = (long long)min(n0 + r0 + 128, Np - 1) * Kp + kc, bo3 = (long long)min(n0 + r0 + 192, Np - 1) * Kp + kc;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int lk = lane >> 5, li = lane & 31;
+  if (nk > 0) {
+    // One k tile: [MFMAs of k16 step 0 on fragments read behind the PREVIOUS barrier] [step 1] [stash of the next tile: its global
+    // loads were issued at the top] [step 2] [fragment reads of step 3] BARRIER [fragment reads of the next tile's step 0]
+    // [MFMAs of step 3].  The stash, the barrier and the first LDS reads of a tile all sit under MFMA work of the same wave.
+    // Hazards: the stash of tile t+1 goes to the buffer tile t-1 was read from -- every wave's last read of t-1 is before barrier
+    // t-1, the stash is behind it; tile t+1 is read behind barrier t, which is behind every wave's stash.
+    B2T_QFETCH(0) B2T_QSTASH(0)
+    __syncthreads();
+    const __bf16* abase = As + (wm * 128 + li) * PPITCH + 8 * lk;
+    const __bf16* bbase = Bs + (wn * 64 + li) * PPITCH + 8 * lk;
+    bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(abase), fa1 = *reinterpret_cast<const bf16x8*>(abase + 32 * PPITCH);
+    bf16x8 fa2 = *reinterpret_cast<const bf16x8*>(abase + 64 * PPITCH), fa3 = *reinterpret_cast<const bf16x8*>(abase + 96 * PPITCH);
+    bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(bbase), fb1 = *reinterpret_cast<const bf16x8*>(bbase + 32 * PPITCH);
+    int cur = 0;
+#define B2T_QMMA(a0, a1, a2, a3, b0, b1)                                                                       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);                            \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);                            \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);                            \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);                            \
+    acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[2][0], 0, 0, 0);                            \
+    acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[2][1], 0, 0, 0);                            \
+    acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b0, acc[3][0], 0, 0, 0);                            \
+    acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[3][1], 0, 0, 0);
+#define B2T_QFRAGS(ap_, bp_, kk)                                                                               \
+    const bf16x8 x0 = *reinterpret_cast<const bf16x8*>((ap_) + (kk)), x1 = *reinterpret_cast<const bf16x8*>((ap_) + 32 * PPITCH + (kk)); \
+    const bf16x8 x2 = *reinterpret_cast<const bf16x8*>((ap_) + 64 * PPITCH + (kk)), x3 = *reinterpret_cast<const bf16x8*>((ap_) + 96 * PPITCH + (kk)); \
+    const bf16x8 y0 = *reinterpret_cast<const bf16x8*>((bp_) + (kk)), y1 = *reinterpret_cast<const bf16x8*>((bp_) + 32 * PPITCH + (kk));
+    for (int kt = 0; kt < nk; ++kt) {
+      const int knext = (kt + 1 < nk ? kt + 1 : kt) * PK;
+      B2T_QFETCH(knext)
+      const __bf16* ap = abase + cur * QM * PPITCH;
+      const __bf16* bp = bbase + cur * QN * PPITCH;
+      B2T_QMMA(fa0, fa1, fa2, fa3, fb0, fb1)
+      { B2T_QFRAGS(ap, bp, 16) B2T_QMMA(x0, x1, x2, x3, y0, y1) }
+      B2T_QSTASH(cur ^ 1)
+      { B2T_QFRAGS(ap, bp, 32) B2T_QMMA(x0, x1, x2, x3, y0, y1) }
+      {
+        B2T_QFRAGS(ap, bp, 48)
+        __syncthreads();
+        const __bf16* an = abase + (cur ^ 1) * QM * PPITCH;
+        const __bf16* bn = bbase + (cur ^ 1) * QN * PPITCH;
+        fa0 = *reinterpret_cast<const bf16x8*>(an); fa1 = *reinterpret_cast<const bf16x8*>(an + 32 * PPITCH);
+        fa2 = *reinterpret_cast<const bf16x8*>(an + 64 * PPITCH); fa3 = *reinterpret_cast<const bf16x8*>(an + 96 * PPITCH);
+        fb0 = *reinterpret_cast<const bf16x8*>(bn); fb1 = *reinterpret_cast<const bf16x8*>(bn + 32 * PPITCH);
+        B2T_QMMA(x0, x1, x2, x3, y0, y1)
+      }
+      cur ^= 1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (row < g.M) {
+          float v = acc[i][j][e] + bv;
+          if (g.epilogue == 1) v = v / (1.0f + fabsf(v));
+          const long long coff = rowoff(row, g.c_s0, g.c_s1, g.c_div) + col;
+          if (g.epilogue == 2) { const float a = 1.0f - fabsf(g.ep_aux[coff]); v *= a * a; }
+          float* p = C + coff;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
 int pad_to(int v, int a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -291,6 +433,22 @@ int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pr
   {   // grouped tile order for wide GEMMs (B2T_GEMM_GM: 0 = row-major always, n = groups of n tile rows wherever there are > 16 tile columns)
     static const int gm_env = getenv("B2T_GEMM_GM") ? atoi(getenv("B2T_GEMM_GM")) : 8;
     g.tile_gm = (gm_env > 1 && Np / PN > 16 && Mp / PM >= 2) ? gm_env : 1;
+  }
+  {   // the 256 x 256 kernel where its tiles fill the chip evenly (one workgroup per CU): B2T_GEMM_256 = 0 never, 1 (default) by this rule, 2 whenever there are >= 64 tiles
+    const char* e = getenv("B2T_GEMM_256");
+    const int mode = e ? atoi(e) : 1;
+    const long long t256 = (long long)((Mp + QM - 1) / QM) * ((Np + QN - 1) / QN) * g.splitk;
+    const long long rounds = (t256 + 255) / 256;
+    const bool fills = t256 >= 200 && t256 * 100 >= rounds * 256 * 80;
+    if (mode == 2 ? t256 >= 64 : (mode == 1 && fills)) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel256), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);
+      B2T_REQUIRE(attr == hipSuccess, "b2t_gemm_bf16p_f32: %zu bytes of LDS refused", Q_LDS);
+      g.tile_gm = (g.tile_gm > 1 && (Np + QN - 1) / QN > 8 && (Mp + QM - 1) / QM >= 2) ? 4 : 1;
+      dim3 grid2(((Np + QN - 1) / QN) * ((Mp + QM - 1) / QM), 1, g.splitk);
+      hipLaunchKernelGGL(gemm_bf16p_kernel256, grid2, dim3(512), Q_LDS, s, g, Ap, Bp, Kp, Mp, Np);
+      B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32 (256)");
+      return 0;
+    }
   }
   hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, Ap, Bp, Kp);
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32");

@@ -713,6 +713,57 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
         np.testing.assert_allclose(got, ref, atol=tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(2200, 2304, 200), (520, 7168, 130), (2304, 7168, 192)])
+def test_gemm_bf16_packed_256_tiles(M, N, K, monkeypatch):
+    """The 256 x 256 kernel of b2t_gemm_bf16p_f32 (gemm_bf16p_kernel256: chosen where its tiles fill the chip evenly;
+    B2T_GEMM_256 = 2 forces it from 64 tiles on, 0 disables it; read per call): every output element sums the same products in
+    the same order as in the 128 x 128 kernel, so the two are BIT-identical -- ragged extents (operand rows clamped where the
+    packed matrix, padded to 128 rows, ends inside a 256-row tile), bias / accumulate / Softsign epilogues, split-K slabs incl.
+    the slice-per-XCD order, a row-mapped C -- and both are the bf16 product."""
+    import ctypes as C
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    Ks = (K + 3) // 4 * 4 + 4                     # row stride (a multiple of 4 elements, not K)
+    A = torch.randn(M, Ks, generator=g); Bm = torch.randn(N, Ks, generator=g); bias = torch.randn(N, generator=g)
+    ref = _bf16_round(A[:, :K].numpy()).astype(np.float64) @ _bf16_round(Bm[:, :K].numpy()).astype(np.float64).T
+    Ad, Bd, bd = A.to(dev), Bm.to(dev), bias.to(dev)
+    U = (torch.rand(M, N, generator=g) * 1.8 - 0.9).to(dev)
+    wsb = lib.b2t_gemm_bf16p_ws_bytes(M, N, K)
+    ws = torch.empty(wsb // 4 + 64, dtype=torch.float32, device=dev)
+
+    def run(Cd, **kw):
+        d = Nn.GemmDesc()
+        d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+        d.M, d.N, d.K, d.Z = M, N, K, 1
+        d.a_kcontig, d.b_kcontig, d.a_s0, d.b_s0, d.c_s0 = 1, 1, Ks, Ks, N
+        d.splitk = 1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        Nn.check(lib.b2t_gemm_bf16p_f32(C.byref(d), ops._p(ws), wsb, ops._stream()), "b2t_gemm_bf16p_f32")
+        return Cd.clone()
+
+    def all_forms():
+        out = [run(torch.full((M, N), float("nan"), device=dev), bias=bd.data_ptr()), run(torch.ones((M, N), device=dev), accumulate=1),
+               run(torch.zeros((M, N), device=dev), epilogue=1), run(torch.zeros((M, N), device=dev), epilogue=2, ep_aux=U.data_ptr()),
+               run(torch.full((3, M, N), float("nan"), device=dev), splitk=3, c_ks=M * N)]
+        out.append(run(torch.full((8, M, N), float("nan"), device=dev), splitk=8, c_ks=M * N))
+        if M % 4 == 0:
+            out.append(run(torch.full((4, M // 4, N), float("nan"), device=dev), c_div=4, c_s1=N, c_s0=(M // 4) * N))
+        return out
+
+    monkeypatch.setenv("B2T_GEMM_256", "0"); small = all_forms()
+    monkeypatch.setenv("B2T_GEMM_256", "2"); big = all_forms()
+    monkeypatch.delenv("B2T_GEMM_256"); auto = all_forms()
+    for i, (a, b, c) in enumerate(zip(small, big, auto)):
+        assert torch.equal(a, b) and torch.equal(a, c), i
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(big[0].cpu().numpy(), ref + bias.numpy(), atol=tol)
+    np.testing.assert_allclose(big[4].cpu().numpy().sum(0), ref, atol=tol)
+    np.testing.assert_allclose(big[5].cpu().numpy().sum(0), ref, atol=tol)
+
+
 @pytest.mark.parametrize("M,N,K,sk,brk", [(256, 128, 1000, 1, 0), (384, 200, 4100, 5, 0), (130, 64, 700, 2, 0), (1536, 512, 6000, 21, 1024),
                                           (100, 300, 50, 1, 0), (768, 130, 40000, 30, 512), (256, 300, 9000, 16, 0), (384, 128, 5000, 8, 0), (1536, 512, 8000, 24, 1024)])
 def test_gemm_a_column_sums(M, N, K, sk, brk):
