@@ -780,3 +780,46 @@ def test_bf16_mode_forward_against_the_reference_autocast_forward(golden_dir, ta
     clear = (top2[..., 1] - top2[..., 0]) > dist
     assert clear.mean() > 0.5
     assert np.array_equal(l16.argmax(-1)[clear], ref32.argmax(-1)[clear]) and np.array_equal(ref16.argmax(-1)[clear], ref32.argmax(-1)[clear])
+
+
+def test_bf16_mode_256_tile_gemms_in_the_step_are_bit_identical(monkeypatch):
+    """Round 5, bf16 mode: products whose 256 x 256 tiles fill the chip run on gemm_bf16p_kernel256 (csrc/gemm_bf16p.hip) -- in the step
+    these are layer 0's weight / input gradients on PRE-PACKED operands (csrc/exec.cpp `wpack` / `xpack`: packed matrices padded to 128
+    rows, so a 256-row tile can end past them: clamped loads).  Every output element sums the same products in the same order as on
+    128 x 128 tiles: gradients, losses and logits of a pass with the kernel forced from 64 tiles on (B2T_GEMM_256=2; a wide layer 0:
+    5632 input features) equal those with it disabled, bit for bit."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    old_amp = ops.AMP["on"]
+    try:
+        ops.set_amp(True)
+        F, H, D, C, L, B, T, S = 5632, 256, 3, 41, 2, 32, 168, 8       # 3H = 768 (3 tile rows; 6 packed 128-row panels), B*T = 5376 = 21 tile rows
+        g = torch.Generator().manual_seed(77)
+        x = torch.randn(B, T, F, generator=g).to(dev)
+        day = torch.randint(0, D, (B,), generator=g)
+        tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(2, S + 1, (B,), generator=g)
+        nt = torch.randint(T - 10, T + 1, (B,), generator=g)
+        for b in range(B):
+            tgt[b, tl[b]:] = 0
+        monkeypatch.setitem(ops.PIPELINE, "chunks", 3)
+        monkeypatch.setitem(ops.PIPELINE, "chunks_bwd", 2)
+
+        def grads(mode):
+            monkeypatch.setenv("B2T_GEMM_256", mode)
+            torch.manual_seed(3)
+            m = GRUDecoder(F, H, D, C, 0.2, 0.1, L, 0, 0).to(dev).train()
+            ts = TrainStep(m, step_args())
+            loss_b = ts.compute_grads(x, day, tgt, nt, tl)
+            torch.cuda.synchronize()
+            ts.check_status()
+            return ts.grad_arena.clone(), loss_b.clone(), ts.last_logits.clone()
+
+        ref = grads("0")
+        assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
+        for a, r, name in zip(grads("2"), ref, ("gradients", "losses", "logits")):
+            assert torch.equal(a, r), f"{name} differ between the 256-tile and the 128-tile kernel"
+    finally:
+        ops.set_amp(old_amp)
+        monkeypatch.delenv("B2T_GEMM_256", raising=False)
