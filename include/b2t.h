@@ -99,12 +99,15 @@ int b2t_gemm_f32(const b2t_gemm_desc* d, void* stream);
  * fp32 output: the matmul regime of the reference's `use_amp` / autocast(bfloat16) training (rnn_trainer.py:535).  Tensors
  * stay fp32 in memory.  Split-K chunks and a_brk along k are multiples of 32 here. */
 int b2t_gemm_bf16_f32(const b2t_gemm_desc* d, void* stream);
-/* The same product in two passes for plain (Z == 1, no b_zmap) GEMMs: both operands are first packed through the
- * descriptor's addressing into dense k-contiguous bf16 matrices in `ws` (b2t_gemm_bf16p_ws_bytes(M, N, K) bytes, 256-byte
- * aligned, caller-owned scratch: no contents survive), then multiplied on 128x128x64 tiles that load bf16 straight into
- * LDS: 2.5-3x the one-pass kernel on the training step's shapes.  Same numerics contract (operands rounded to bf16
- * nearest-even, fp32 accumulation, fp32 output and epilogues). */
+/* The same product in two passes: both operands are first packed through the descriptor's addressing into dense
+ * k-contiguous bf16 matrices in `ws` (b2t_gemm_bf16p_ws_bytes(M, N, K) bytes, 256-byte aligned, caller-owned scratch: no
+ * contents survive), then multiplied on 128x128x64 tiles that load bf16 straight into LDS (256x256x64 where those fill the
+ * chip): 2.5-3x the one-pass kernel on the training step's shapes.  Same numerics contract (operands rounded to bf16
+ * nearest-even, fp32 accumulation, fp32 output and epilogues).  Z-batched descriptors (Z > 1, optional b_zmap / bias_sz: the
+ * day layer's per-sentence products, rnn_model.py:95-99) pack every matrix of the batch: b2t_gemm_bf16p_ws_bytes_z bytes,
+ * no split-K / a_sum / a_brk. */
 size_t b2t_gemm_bf16p_ws_bytes(int M, int N, int K);
+size_t b2t_gemm_bf16p_ws_bytes_z(int M, int N, int K, int Z);
 int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- elementwise helpers ------------------------------------------------------------------

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "b2t_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), VP]),
     "b2t_gemm_bf16_f32": (C.c_int, [C.POINTER(GemmDesc), VP]),
     "b2t_gemm_bf16p_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "b2t_gemm_bf16p_ws_bytes_z": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "b2t_gemm_bf16p_f32": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "b2t_softsign_bwd_f32": (C.c_int, [VP, VP, LL, VP]),
     "b2t_adjusted_lens_i32": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),

@@ -102,6 +102,7 @@ struct Layout {
   size_t pack_bytes;
   char *wpk_f[MAXL], *wpk_b[MAXL];   // amp mode: W_ih of every layer packed once per pass -- as the projection's B operand (forward), as the input gradient's (backward)
   float *slab_hh[MAXL], *asum_hh[MAXL];   // amp mode: split-K slab / per-slice sums of dW_hh when it runs as a task of its own next to dW_ih
+  char* xpk_day;                     // amp mode: the A operands of the day layer's per-sentence weight gradients (x[b]^T, Z = B), packed when the backward pass starts
   char *xpk_hh[MAXL], *xpk_ih[MAXL]; // amp mode: the B operands of a layer's whole-sequence weight-gradient GEMMs (h_{t-1}^T, x^T: known when the backward pass starts), packed ahead of the tail
   size_t bytes;
 };
@@ -140,14 +141,19 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     const int shapes[][3] = {{R, (int)(3 * H), (int)In0}, {R, (int)(3 * H), (int)H}, {R, (int)C, (int)H}, {R, (int)In0, (int)(3 * H)},
                              {R, (int)H, (int)(3 * H)}, {(int)(3 * H), (int)H, R}, {(int)(3 * H), (int)In0, R}, {(int)C, (int)H, R}, {R, (int)H, (int)C}};
     for (const auto& sh : shapes) w.pack_bytes = std::max(w.pack_bytes, b2t_gemm_bf16p_ws_bytes(sh[0], sh[1], sh[2]));
+    // the day layer's per-sentence products (Z = B): forward x[b] W[day[b]], backward x[b]^T dpre[b]
+    w.pack_bytes = std::max(w.pack_bytes, b2t_gemm_bf16p_ws_bytes_z((int)T, (int)F, (int)F, (int)B));
+    if (p->save) w.pack_bytes = std::max(w.pack_bytes, b2t_gemm_bf16p_ws_bytes_z((int)F, (int)F, (int)T, (int)B));
     w.pack_bytes = align_up(w.pack_bytes, 256);
     for (int q = 0; q < NPACK; ++q) { w.pack[q] = base + off; off += w.pack_bytes; }
   }
   for (size_t l = 0; l < MAXL; ++l) w.wpk_f[l] = w.wpk_b[l] = nullptr;
   if (p->bf16_gemm)
     for (size_t l = 0; l < L; ++l) { w.wpk_f[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(3 * H), (int)(l == 0 ? In0 : H)), 256); }
-  if (!p->save) { w.bytes = off; return; }
+  if (!p->save) { w.xpk_day = nullptr; w.bytes = off; return; }
   for (size_t l = 0; l < MAXL; ++l) { w.xpk_hh[l] = w.xpk_ih[l] = nullptr; w.slab_hh[l] = w.asum_hh[l] = nullptr; }
+  w.xpk_day = nullptr;
+  if (p->bf16_gemm) { w.xpk_day = base + off; off += align_up(B * gemm_bf16p_operand_bytes((int)F, (int)T), 256); }
   if (p->bf16_gemm)
     for (size_t l = 0; l < L; ++l) {
       w.wpk_b[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(3 * H)), 256);
@@ -240,9 +246,10 @@ struct Ctx {
   // Bp_pre: the B operand already packed for the two-pass bf16 kernel (the pass's weights, packed once: round 5); dropA: nn.GRU's
   // inter-layer dropout folded into the A pack.  Both only where would_pack(d, s) holds (the caller checks).
   void gemm(hipStream_t s, b2t_gemm_desc d, int splitk = 1, float* slab = nullptr, int accumulate = 0, int kslot = -1,
-            const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr) {
+            const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr, const void* Ap_pre = nullptr) {
     if (rc) return;
     if ((Bp_pre || dropA) && !(bf16_gemm && would_pack(d, s))) { set_error("exec: pre-packed operands need the two-pass bf16 GEMM"); rc = 2; return; }
+    if (Ap_pre && !(bf16_gemm && would_pack_z(d, s))) { set_error("exec: a pre-packed Z-batched A needs the two-pass bf16 GEMM"); rc = 2; return; }
     void* st = reinterpret_cast<void*>(s);
     const int kind = (bf16_gemm ? 4 : 0) + (d.a_kcontig ? 2 : 0) + (d.b_kcontig ? 1 : 0);
     const double flops = 2.0 * d.M * d.N * (double)d.K * (d.Z > 0 ? d.Z : 1);
@@ -263,7 +270,7 @@ struct Ctx {
       if (fused) { d.ks_counters = kcnt + (size_t)kslot * KSLOT; d.ks_out = Cdst; d.ks_accumulate = accumulate; }
       {
         Scope sc(*this, s, kind, flops);
-        rc = bf16_gemm ? gemm_amp(d, s, Bp_pre, dropA) : b2t_gemm_f32(&d, st);
+        rc = bf16_gemm ? gemm_amp(d, s, Bp_pre, dropA, Ap_pre) : b2t_gemm_f32(&d, st);
       }
       if (!rc && !fused) rc = b2t_slab_reduce_f32(slab, splitk, (long long)d.M * d.N, Cdst, accumulate, st);
       return;
@@ -271,7 +278,7 @@ struct Ctx {
     d.accumulate = accumulate;
     if (exact_k && d.splitk <= 1) d.splitk = -1;
     Scope sc(*this, s, kind, flops);
-    rc = bf16_gemm ? gemm_amp(d, s, Bp_pre, dropA) : b2t_gemm_f32(&d, st);
+    rc = bf16_gemm ? gemm_amp(d, s, Bp_pre, dropA, Ap_pre) : b2t_gemm_f32(&d, st);
   }
   // amp mode: the two-pass kernel (pack to dense bf16, then 128x128x64 tiles on packed operands: 2.5-3x the one-pass kernel)
   // for plain GEMMs big enough to pay for the pack passes, on a queue that has pack scratch; the one-pass kernel otherwise
@@ -285,13 +292,26 @@ struct Ctx {
     return bf16_gemm && lay && lay->pack[0] && (d.Z == 1 || d.Z == 0) && !d.b_zmap && 2.0 * d.M * d.N * (double)d.K >= 2e9 &&
            b2t_gemm_bf16p_ws_bytes(d.M, d.N, d.K) <= lay->pack_bytes && (d.a_brk % 8) == 0;
   }
+  // Z-batched products (the day layer; round 5): every matrix of the batch packed, then one launch over (tiles, Z)
+  static bool z_pack_on() { const char* e = getenv("B2T_ZPACK"); return !e || atoi(e) != 0; }
+  bool pack_shape_ok_z(const b2t_gemm_desc& d) const {    // plan time: the queue is not known yet (every queue of a pass has pack scratch)
+    return bf16_gemm && lay && lay->pack[0] && d.Z > 1 && d.Z <= 65535 && d.splitk <= 1 && !d.a_sum && d.a_brk == 0 && z_pack_on() && d.M >= 192 &&
+           2.0 * d.Z * d.M * d.N * (double)d.K >= 2e9 && b2t_gemm_bf16p_ws_bytes_z(d.M, d.N, d.K, d.Z) <= lay->pack_bytes;
+  }
+  bool would_pack_z(const b2t_gemm_desc& d, hipStream_t s) const {
+    const int q = pack_queue(s);
+    // (not the time-chunked day layer: 83-row chunks fill 65 % of a 128-row tile and every chunk would pack the weights again -- measured slower)
+    return lay && q >= 0 && lay->pack[q] && d.Z > 1 && d.Z <= 65535 && d.splitk <= 1 && !d.a_sum && d.a_brk == 0 && z_pack_on() && d.M >= 192 &&
+           2.0 * d.Z * d.M * d.N * (double)d.K >= 2e9 && b2t_gemm_bf16p_ws_bytes_z(d.M, d.N, d.K, d.Z) <= lay->pack_bytes;
+  }
   bool would_pack(const b2t_gemm_desc& d, hipStream_t s) const {
     const int q = pack_queue(s);
     return lay && q >= 0 && lay->pack[q] && (d.Z == 1 || d.Z == 0) && !d.b_zmap && 2.0 * d.M * d.N * (double)d.K >= 2e9 &&
            b2t_gemm_bf16p_ws_bytes(d.M, d.N, d.K) <= lay->pack_bytes && (d.a_brk % 8) == 0;
   }
-  int gemm_amp(const b2t_gemm_desc& d, hipStream_t s, const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr) {
+  int gemm_amp(const b2t_gemm_desc& d, hipStream_t s, const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr, const void* Ap_pre = nullptr) {
     void* st = reinterpret_cast<void*>(s);
+    if (would_pack_z(d, s)) return gemm_bf16p_run(&d, Ap_pre, nullptr, lay->pack[pack_queue(s)], lay->pack_bytes, s, nullptr);
     if (!would_pack(d, s)) return b2t_gemm_bf16_f32(&d, st);
     return gemm_bf16p_run(&d, nullptr, Bp_pre, lay->pack[pack_queue(s)], lay->pack_bytes, s, dropA);
   }
@@ -445,7 +465,7 @@ uint64_t pass_key(int which, const b2t_model_t* prm, const b2t_model_t* grd, con
   h = key_of(h, p->in_drop); h = key_of(h, p->rnn_drop);
   for (const void* q : ptrs) h = key_of(h, q);
   for (long long v : ints) h = key_of(h, v);
-  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK", "B2T_WGRAD_SPLIT"}) {   // read per pass by the code below / the sweeps
+  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK", "B2T_WGRAD_SPLIT", "B2T_ZPACK", "B2T_GEMM_256", "B2T_GI0_CHAIN"}) {   // read per pass by the code below / the sweeps
     const char* e = getenv(name);
     h = key_of(h, (int)(e ? e[0] : 0));
   }
@@ -938,6 +958,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       c.call(gemm_bf16p_pack(&d, 1, w.wpk_f[l], s));
     });
   }
+  const bool gi0_chain = c.bf16_gemm && In0 >= 2048 && nc > 1 && getenv("B2T_GI0_CHAIN") && atoi(getenv("B2T_GI0_CHAIN")) == 1;   // opt-in: measured slower
+  int t_gi0_prev = -1;
   for (int l = 0; l < L; ++l) {
     for (int ci = 0; ci < nc; ++ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
@@ -1002,6 +1024,11 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
         if (small && !skinny(n * B, H)) c.gemm(sg, d, std::max(1, H / 192), w.slab_gi[l]);
         else c.gemm(sg, d);
       });
+      // Layer 0 of a patch model in the bf16 mode: the chunks' projections (2624 x 2304 x 7168 each at the shipped shape: 150 us alone) are
+      // all ready behind the day layer; launched together on three queues they share the chip and the FIRST one -- the only one the
+      // first sweep waits for -- finishes after 290 us.  B2T_GI0_CHAIN=1 runs them one after the other: the first sweep then starts 150 us
+      // earlier, and the step is SLOWER (5.85 against 5.81 ms: the later chunks' GEMMs now run next to the sweeps instead of in front of them).
+      if (l == 0 && gi0_chain && !fused_from(l - 1)) { if (ci > 0 && t_gi0_prev >= 0) P.dep(t_gi, t_gi0_prev); t_gi0_prev = t_gi; }
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
       t_sw[l][ci] = P.add("sweep", 40.f + n * est_step_us(0) * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n, ci](hipStream_t ss) {
         if (c.rc) return;
@@ -1349,14 +1376,26 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
         if (P.t[i].name && !strcmp(P.t[i].name, "wgrad") && (int)i == t_wg_last[l]) P.dep((int)i, t_bs[0][0]);
   }
   // layer-0 input gradient -> day layer
-  const int t_dayfin = P.add("day_w", fast_day ? 60.f : est_gemm(F, F, T, B) + 200.f, Q_ANY, {t_dx[0][0]}, [&](hipStream_t s) {
+  auto day_wgrad_desc = [&]() {      // per-sentence x[b]^T dpre[b] -> day_slab[b] (whole sequence)
+    b2t_gemm_desc d = gd(x, w.dU, w.day_slab, F, F, T);
+    d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;
+    d.c_s0 = F; d.c_sz = (long long)F * F;
+    return d;
+  };
+  // bf16 mode: its A operand is the INPUT (x[b]^T): packed when the pass starts instead of on the step's tail (217 us there, next to
+  // layer 0's weight gradients)
+  static const bool day_late_env = !(getenv("B2T_DAY_WGRAD_LATE") && atoi(getenv("B2T_DAY_WGRAD_LATE")) == 0);
+  const bool day_whole = !fast_day || day_late_env;
+  int t_xpk_day = -1;
+  if (day_whole && w.xpk_day && prepack_env && c.pack_shape_ok_z(day_wgrad_desc()))
+    t_xpk_day = P.add("xpack", 40.f, Q_ANY, {t_start}, [&](hipStream_t s) { b2t_gemm_desc d = day_wgrad_desc(); c.call(gemm_bf16p_pack(&d, 0, w.xpk_day, s)); });
+  const void* day_a_pre = t_xpk_day >= 0 ? w.xpk_day : nullptr;
+  const int t_dayfin = P.add("day_w", fast_day ? 60.f : est_gemm(F, F, T, B) + 200.f, Q_ANY, {t_dx[0][0], t_xpk_day}, [&, day_a_pre](hipStream_t s) {
     void* sp = reinterpret_cast<void*>(s);
     static const bool day_late = !(getenv("B2T_DAY_WGRAD_LATE") && atoi(getenv("B2T_DAY_WGRAD_LATE")) == 0);
     if (fast_day && day_late) {
-      b2t_gemm_desc d = gd(x, w.dU, w.day_slab, F, F, T);
-      d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;
-      d.c_s0 = F; d.c_sz = (long long)F * F;
-      c.gemm(s, d);
+      b2t_gemm_desc d = day_wgrad_desc();
+      c.gemm(s, d, 1, nullptr, 0, -1, nullptr, nullptr, (day_a_pre && c.would_pack_z(d, s)) ? day_a_pre : nullptr);
       c.call(b2t_colsum_f32(w.dU, T, F, F, w.day_bslab, 0, w.cs_day, B, (long long)T * F, bias_ld, sp));
     }
     if (!fast_day) {
@@ -1367,10 +1406,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
         c.call(b2t_softsign_bwd_f32(w.U, w.dU, (long long)B * T * F, sp));   // dpre = dU * (1-|U|)^2, in place
       }
       // per-sample partial day gradients, then deterministic reduction by day
-      b2t_gemm_desc d = gd(x, w.dU, w.day_slab, F, F, T);
-      d.Z = B; d.a_kcontig = 0; d.a_s0 = F; d.a_sz = (long long)T * F; d.b_kcontig = 0; d.b_s0 = F; d.b_sz = (long long)T * F;
-      d.c_s0 = F; d.c_sz = (long long)F * F;
-      c.gemm(s, d);
+      b2t_gemm_desc d = day_wgrad_desc();
+      c.gemm(s, d, 1, nullptr, 0, -1, nullptr, nullptr, (day_a_pre && c.would_pack_z(d, s)) ? day_a_pre : nullptr);
       c.call(b2t_colsum_f32(w.dU, T, F, F, w.day_bslab, 0, w.cs_day, B, (long long)T * F, bias_ld, sp));
     }
     c.call(b2t_day_reduce_f32(w.day_slab, day_idx, B, (long long)F * F, grd->day_w, grd->day_w_stride, sp));

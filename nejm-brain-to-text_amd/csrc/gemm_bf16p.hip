@@ -40,6 +40,9 @@ struct PackArgs {
   // element (r, k) is flat element elem0 + r * K + k of the tensor b2t_dropout_f32 masks (same Philox draw, same 1 / (1 - p) scale:
   // bit-identical to dropout-then-pack), and the dropped fp32 values are also written to `dup` (the backward pass reads them)
   float drop_p, drop_scale; unsigned long long drop_seed; long long drop_elem0; float* dup;
+  // Z-batched operands (round 5: the day layer's per-sentence GEMMs): matrix z reads from P + (zmap ? zmap[z] : z) * src_sz and is
+  // written at out + z * rows_pad * Kp (grid y of pack_kc, grid z of pack_mc); no sums / dropout with Z > 1
+  long long src_sz; const int* zmap;
 };
 
 // k-contiguous source: element (r, k) at P + rowoff(r) + k (+ gap for k >= brk).  One thread = 8 consecutive k of one row.
@@ -48,6 +51,9 @@ __global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)a.rows_pad * g8) return;
   const int r = (int)(i / g8), k = (int)(i % g8) * 8;
+  const int z = blockIdx.y;
+  a.P += (long long)(a.zmap ? a.zmap[z] : z) * a.src_sz;
+  a.out += (long long)z * a.rows_pad * a.Kp;
   uint4 o = make_uint4(0u, 0u, 0u, 0u);
   if (r < a.rows && k < a.K) {
     const float* p = a.P + rowoff(r, a.s0, a.s1, a.div) + k + ((a.brk > 0 && k >= a.brk) ? a.gap : 0);
@@ -78,6 +84,8 @@ __global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
 __global__ __launch_bounds__(256) void pack_mc_kernel(PackArgs a) {
   __shared__ float t[64][65];
   const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64, tid = threadIdx.x;
+  a.P += (long long)(a.zmap ? a.zmap[blockIdx.z] : (int)blockIdx.z) * a.src_sz;
+  a.out += (long long)blockIdx.z * a.rows_pad * a.Kp;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int idx = tid + 256 * it;          // 1024 float4: k = idx / 16, r4 = (idx % 16) * 4
@@ -124,7 +132,8 @@ __global__ __launch_bounds__(256) void pack_mc_kernel(PackArgs a) {
 
 // (plain variables for the prefetch registers, no lambdas over arrays: the array form was demoted to scratch memory by the
 // compiler -- 230 TF/s instead of 840)
-__global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp, int Kp) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp, int Kp,
+                                                            long long a_zs, long long b_zs) {
   __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 2 * PM * PPITCH];
   __bf16* As = smem; __bf16* Bs = smem + 2 * PM * PPITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -152,11 +161,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __
       m0 = (tile / gx) * PM; n0 = (tile % gx) * PN;
     }
   }
-  const float* bias = (g.bias && ks == 0) ? g.bias : nullptr;
-  float* C = g.C + (long long)ks * g.c_ks;
+  const int z = blockIdx.y;                        // Z-batched: matrix z of the packed operands, of C, of ep_aux; bias by b_zmap
+  const float* bias = (g.bias && ks == 0) ? g.bias + (long long)(g.b_zmap ? g.b_zmap[z] : z) * g.bias_sz : nullptr;
+  float* C = g.C + (long long)z * g.c_sz + (long long)ks * g.c_ks;
+  const float* ep_aux = g.ep_aux ? g.ep_aux + (long long)z * g.c_sz : nullptr;
   const int kb = ks * g.kchunk, ke = min(Kp, kb + g.kchunk), nk = (ke - kb) / PK;
-  const __bf16* ag = Ap + (long long)(m0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
-  const __bf16* bg = Bp + (long long)(n0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
+  const __bf16* ag = Ap + z * a_zs + (long long)(m0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
+  const __bf16* bg = Bp + z * b_zs + (long long)(n0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __
           float v = acc[i][j][e] + bv;
           if (g.epilogue == 1) v = v / (1.0f + fabsf(v));
           const long long coff = rowoff(row, g.c_s0, g.c_s1, g.c_div) + col;
-          if (g.epilogue == 2) { const float a = 1.0f - fabsf(g.ep_aux[coff]); v *= a * a; }   // softsign backward
+          if (g.epilogue == 2) { const float a = 1.0f - fabsf(ep_aux[coff]); v *= a * a; }   // softsign backward
           float* p = C + coff;
           if (g.accumulate) v += *p;
           *p = v;
@@ -364,6 +375,13 @@ extern "C" size_t b2t_gemm_bf16p_ws_bytes(int M, int N, int K) {
   const size_t Kp = (size_t)pad_to(K, PK);
   return ((size_t)pad_to(M, PM) + (size_t)pad_to(N, PN)) * Kp * sizeof(__bf16) + 512;
 }
+// Z-batched (d->Z > 1): every matrix of the batch is packed, Z times the operands of one
+extern "C" size_t b2t_gemm_bf16p_ws_bytes_z(int M, int N, int K, int Z) {
+  using namespace b2t;
+  if (M <= 0 || N <= 0 || K <= 0 || Z <= 0) return 0;
+  const size_t Kp = (size_t)pad_to(K, PK);
+  return (size_t)Z * ((size_t)pad_to(M, PM) + (size_t)pad_to(N, PN)) * Kp * sizeof(__bf16) + 512;
+}
 
 // ---- internal (csrc/exec.cpp): operands packed ahead of the GEMM, or by someone else ----------------------------------------
 // gemm_bf16p_pack: one operand of the GEMM `d` describes (which = 0: A, 1: B) into `out` (gemm_bf16p_operand_bytes); the weights of a
@@ -377,14 +395,15 @@ size_t gemm_bf16p_operand_bytes(int rows, int K) {
 }
 
 static void launch_pack(const float* P, __bf16* out, int rows, int rows_pad, int K, int Kp, bool kc, long long s0, long long s1, int div, int brk,
-                        int gap, float* sum, long long sum_ks, const PackDrop* drop, hipStream_t s) {
-  PackArgs a{P, out, rows, rows_pad, K, Kp, s0, s1, div, brk, gap, sum, sum_ks, 0.f, 1.f, 0ull, 0ll, nullptr};
+                        int gap, float* sum, long long sum_ks, const PackDrop* drop, hipStream_t s, int Z = 1, long long src_sz = 0,
+                        const int* zmap = nullptr) {
+  PackArgs a{P, out, rows, rows_pad, K, Kp, s0, s1, div, brk, gap, sum, sum_ks, 0.f, 1.f, 0ull, 0ll, nullptr, src_sz, zmap};
   if (drop && drop->p > 0.f) { a.drop_p = drop->p; a.drop_scale = 1.0f / (1.0f - drop->p); a.drop_seed = drop->seed; a.drop_elem0 = drop->elem0; a.dup = drop->dup; }
   if (kc) {
     const long long items = (long long)rows_pad * (Kp / 8);
-    hipLaunchKernelGGL(pack_kc_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pack_kc_kernel, dim3((unsigned)((items + 255) / 256), Z), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL(pack_mc_kernel, dim3(rows_pad / 64, Kp / 64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pack_mc_kernel, dim3(rows_pad / 64, Kp / 64, Z), dim3(256), 0, s, a);
   }
 }
 
@@ -392,15 +411,18 @@ int gemm_bf16p_pack(const b2t_gemm_desc* d, int which, void* out, hipStream_t s,
   B2T_REQUIRE(d && out && (which == 0 || which == 1), "gemm_bf16p_pack: bad arguments");
   B2T_REQUIRE(((uintptr_t)out & 255) == 0, "gemm_bf16p_pack: the packed operand must be 256-byte aligned");
   const int Kp = pad_to(d->K, PK);
+  const int Z = d->Z > 1 ? d->Z : 1;
+  B2T_REQUIRE(Z == 1 || ((!drop || drop->p <= 0.f) && d->a_sum == nullptr && d->a_brk == 0), "gemm_bf16p_pack: Z-batched operands carry no dropout / sums / gap");
   if (which == 0) {
     B2T_REQUIRE(!drop || drop->p <= 0.f || (d->a_kcontig && d->a_s0 == d->K && d->a_div == 0 && d->a_brk == 0 && d->K % 8 == 0 && (drop->elem0 % 4) == 0),
                 "gemm_bf16p_pack: dropout goes with a dense k-contiguous A (row stride = K, K %% 8 == 0)");
     B2T_REQUIRE(d->a_brk == 0 || d->a_brk % 8 == 0, "gemm_bf16p_pack: a_brk must be a multiple of 8");
     launch_pack(d->A, reinterpret_cast<__bf16*>(out), d->M, pad_to(d->M, PM), d->K, Kp, d->a_kcontig != 0, d->a_s0, d->a_s1, d->a_div, d->a_brk, d->a_gap,
-                d->a_sum, d->a_sum_ks, drop, s);
+                d->a_sum, d->a_sum_ks, drop, s, Z, d->a_sz, nullptr);
   } else {
     B2T_REQUIRE(!drop || drop->p <= 0.f, "gemm_bf16p_pack: dropout is for the A operand");
-    launch_pack(d->B, reinterpret_cast<__bf16*>(out), d->N, pad_to(d->N, PN), d->K, Kp, d->b_kcontig != 0, d->b_s0, d->b_s1, d->b_div, 0, 0, nullptr, 0, nullptr, s);
+    launch_pack(d->B, reinterpret_cast<__bf16*>(out), d->N, pad_to(d->N, PN), d->K, Kp, d->b_kcontig != 0, d->b_s0, d->b_s1, d->b_div, 0, 0, nullptr, 0, nullptr, s,
+                Z, d->b_sz, d->b_zmap);
   }
   B2T_CHECK_LAUNCH("gemm_bf16p_pack");
   return 0;
@@ -408,13 +430,15 @@ int gemm_bf16p_pack(const b2t_gemm_desc* d, int which, void* out, hipStream_t s,
 
 int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pre, void* ws, size_t ws_bytes, hipStream_t s, const PackDrop* dropA) {
   B2T_REQUIRE(d != nullptr && (ws != nullptr || (Ap_pre && Bp_pre)), "b2t_gemm_bf16p_f32: null descriptor / workspace");
-  B2T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->Z == 1 && d->b_zmap == nullptr, "b2t_gemm_bf16p_f32: bad shape M=%d N=%d K=%d Z=%d (Z must be 1)",
+  B2T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->Z >= 1 && (d->Z > 1 || d->b_zmap == nullptr), "b2t_gemm_bf16p_f32: bad shape M=%d N=%d K=%d Z=%d",
               d->M, d->N, d->K, d->Z);
+  const int Z = d->Z;
+  B2T_REQUIRE(Z == 1 || (d->splitk <= 1 && (d->a_sz % 4) == 0 && (d->b_sz % 4) == 0 && Z <= 65535), "b2t_gemm_bf16p_f32: Z-batched: no split-K, z strides multiples of 4, Z <= 65535");
   B2T_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && ((uintptr_t)ws & 255) == 0, "b2t_gemm_bf16p_f32: A/B must be 16-byte, ws 256-byte aligned");
   B2T_REQUIRE((d->a_s0 % 4) == 0 && (d->a_s1 % 4) == 0 && (d->b_s0 % 4) == 0 && (d->b_s1 % 4) == 0,
               "b2t_gemm_bf16p_f32: A/B strides must be multiples of 4 elements");
   const int Mp = pad_to(d->M, PM), Np = pad_to(d->N, PN), Kp = pad_to(d->K, PK);
-  const size_t needA = Ap_pre ? 0 : (size_t)Mp * Kp * sizeof(__bf16), needB = Bp_pre ? 0 : (size_t)Np * Kp * sizeof(__bf16);
+  const size_t needA = Ap_pre ? 0 : (size_t)Z * Mp * Kp * sizeof(__bf16), needB = Bp_pre ? 0 : (size_t)Z * Np * Kp * sizeof(__bf16);
   B2T_REQUIRE(ws_bytes >= needA + needB, "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes, needA + needB);
   GemmArgs g;
   B2T_REQUIRE(d->a_sum == nullptr || !d->a_kcontig, "b2t_gemm_bf16p_f32: a_sum goes with an m-contiguous A (a_kcontig = 0)");
@@ -428,7 +452,7 @@ int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pr
   const __bf16* Ap = Ap_pre ? reinterpret_cast<const __bf16*>(Ap_pre) : Aw;
   const __bf16* Bp = Bp_pre ? reinterpret_cast<const __bf16*>(Bp_pre) : Bw;
   g.kchunk = pad_to((Kp + g.splitk - 1) / g.splitk, PK);
-  dim3 grid((Np / PN) * (Mp / PM), 1, g.splitk), block(256);
+  dim3 grid((Np / PN) * (Mp / PM), Z, g.splitk), block(256);
   { static const bool off = getenv("B2T_GEMM_KS_XCD") && atoi(getenv("B2T_GEMM_KS_XCD")) == 0; g.ks_xcd = !off && g.splitk >= 8 && (g.splitk & 7) == 0; }
   {   // grouped tile order for wide GEMMs (B2T_GEMM_GM: 0 = row-major always, n = groups of n tile rows wherever there are > 16 tile columns)
     static const int gm_env = getenv("B2T_GEMM_GM") ? atoi(getenv("B2T_GEMM_GM")) : 8;
@@ -440,7 +464,7 @@ int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pr
     const long long t256 = (long long)((Mp + QM - 1) / QM) * ((Np + QN - 1) / QN) * g.splitk;
     const long long rounds = (t256 + 255) / 256;
     const bool fills = t256 >= 200 && t256 * 100 >= rounds * 256 * 80;
-    if (mode == 2 ? t256 >= 64 : (mode == 1 && fills)) {
+    if (Z == 1 && (mode == 2 ? t256 >= 64 : (mode == 1 && fills))) {
       static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16p_kernel256), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);
       B2T_REQUIRE(attr == hipSuccess, "b2t_gemm_bf16p_f32: %zu bytes of LDS refused", Q_LDS);
       g.tile_gm = (g.tile_gm > 1 && (Np + QN - 1) / QN > 8 && (Mp + QM - 1) / QM >= 2) ? 4 : 1;
@@ -450,7 +474,7 @@ int gemm_bf16p_run(const b2t_gemm_desc* d, const void* Ap_pre, const void* Bp_pr
       return 0;
     }
   }
-  hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, Ap, Bp, Kp);
+  hipLaunchKernelGGL(gemm_bf16p_kernel, grid, block, 0, s, g, Ap, Bp, Kp, (long long)Mp * Kp, (long long)Np * Kp);
   B2T_CHECK_LAUNCH("b2t_gemm_bf16p_f32");
   return 0;
 }
@@ -461,7 +485,7 @@ extern "C" int b2t_gemm_bf16p_f32(const b2t_gemm_desc* d, void* ws, size_t ws_by
   using namespace b2t;
   B2T_REQUIRE(d != nullptr && ws != nullptr, "b2t_gemm_bf16p_f32: null descriptor / workspace");
   B2T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "b2t_gemm_bf16p_f32: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
-  B2T_REQUIRE(ws_bytes >= b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K), "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes,
-              b2t_gemm_bf16p_ws_bytes(d->M, d->N, d->K));
+  B2T_REQUIRE(d->Z >= 1 && ws_bytes >= b2t_gemm_bf16p_ws_bytes_z(d->M, d->N, d->K, d->Z), "b2t_gemm_bf16p_f32: workspace of %zu bytes, need %zu", ws_bytes,
+              b2t_gemm_bf16p_ws_bytes_z(d->M, d->N, d->K, d->Z > 0 ? d->Z : 1));
   return gemm_bf16p_run(d, nullptr, nullptr, ws, ws_bytes, as_stream(stream), nullptr);
 }

@@ -713,6 +713,71 @@ def test_gemm_bf16_packed(akc, bkc, M, N, K):
         np.testing.assert_allclose(got, ref, atol=tol)
 
 
+@pytest.mark.parametrize("form", ["day_forward", "day_wgrad"])
+@pytest.mark.parametrize("Z,T,F", [(5, 83, 128), (64, 200, 256), (7, 130, 72)])
+def test_gemm_bf16_packed_z_batched(form, Z, T, F):
+    """b2t_gemm_bf16p_f32 with a Z-batched descriptor (round 5): the day layer's per-sentence products -- forward
+    U[b] = softsign(x[b] W[day[b]] + c[day[b]]) (A k-contiguous, B = the day's weight selected by b_zmap and stored k-major,
+    bias by bias_sz, Softsign epilogue; rnn_model.py:95-99) and backward dW[b] = x[b]^T dpre[b] (both operands m-contiguous,
+    K = T, per-sentence slabs) -- every matrix of the batch packed, one launch over (tiles, Z).  Against the fp64 product of the
+    bf16-rounded operands; the Softsign-backward epilogue (ep_aux per z) and accumulate too."""
+    import ctypes as C
+    import b2t_native as Nn
+    import b2t_ops as ops
+    lib = Nn.load(); dev = _dev()
+    rng = np.random.default_rng(Z * 100 + T + F)
+    D = 3
+    x = rng.standard_normal((Z, T, F)).astype(np.float32)
+    W = (rng.standard_normal((D, F, F)) / np.sqrt(F)).astype(np.float32)       # [day][k][n]
+    bias = rng.standard_normal((D, F)).astype(np.float32)
+    day = rng.integers(0, D, Z).astype(np.int32)
+    dpre = rng.standard_normal((Z, T, F)).astype(np.float32)
+    xq, Wq, dq = _bf16_round(x).astype(np.float64), _bf16_round(W).astype(np.float64), _bf16_round(dpre).astype(np.float64)
+    xd, Wd, bd, dayd, dd = (torch.from_numpy(a).to(dev) for a in (x, W, bias, day, dpre))
+    d = Nn.GemmDesc()
+    if form == "day_forward":
+        M, N, K = T, F, F
+        ref = np.einsum("ztk,zkn->ztn", xq, Wq[day]) + bias[day][:, None, :]
+        out = torch.full((Z, T, F), float("nan"), device=dev)
+        d.A, d.B, d.C = xd.data_ptr(), Wd.data_ptr(), out.data_ptr()
+        d.a_kcontig, d.a_s0, d.a_sz = 1, F, T * F
+        d.b_kcontig, d.b_s0, d.b_sz, d.b_zmap = 0, F, F * F, dayd.data_ptr()
+        d.c_s0, d.c_sz, d.bias, d.bias_sz = F, T * F, bd.data_ptr(), F
+    else:
+        M, N, K = F, F, T
+        ref = np.einsum("ztm,ztn->zmn", xq, dq)
+        out = torch.full((Z, F, F), float("nan"), device=dev)
+        d.A, d.B, d.C = xd.data_ptr(), dd.data_ptr(), out.data_ptr()
+        d.a_kcontig, d.a_s0, d.a_sz = 0, F, T * F
+        d.b_kcontig, d.b_s0, d.b_sz = 0, F, T * F
+        d.c_s0, d.c_sz = F, F * F
+    d.M, d.N, d.K, d.Z, d.splitk = M, N, K, Z, 1
+    wsb = lib.b2t_gemm_bf16p_ws_bytes_z(M, N, K, Z)
+    assert wsb >= Z * (lib.b2t_gemm_bf16p_ws_bytes(M, N, K) - 512)
+    ws = torch.empty(wsb // 4 + 64, dtype=torch.float32, device=dev)
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+    def run(**kw):
+        for k, v in kw.items():
+            setattr(d, k, v)
+        Nn.check(lib.b2t_gemm_bf16p_f32(C.byref(d), ops._p(ws), wsb, ops._stream()), "b2t_gemm_bf16p_f32")
+        return out.cpu().numpy()
+
+    np.testing.assert_allclose(run(), ref, atol=tol)
+    one = torch.full_like(out, float("nan"))                    # the one-pass kernel: same contract
+    d.C = one.data_ptr()
+    Nn.check(lib.b2t_gemm_bf16_f32(C.byref(d), ops._stream()), "b2t_gemm_bf16_f32")
+    np.testing.assert_allclose(one.cpu().numpy(), ref, atol=tol)
+    d.C = out.data_ptr()
+    np.testing.assert_allclose(run(epilogue=1), ref / (1 + np.abs(ref)), atol=tol)
+    U = rng.uniform(-0.9, 0.9, size=ref.shape).astype(np.float32); Ud = torch.from_numpy(U).to(dev)
+    np.testing.assert_allclose(run(epilogue=2, ep_aux=Ud.data_ptr()), ref * (1 - np.abs(U)) ** 2, atol=tol)
+    out.fill_(1.0)
+    np.testing.assert_allclose(run(epilogue=0, ep_aux=None, accumulate=1), ref + 1.0, atol=tol)
+    # too small a workspace is refused
+    assert lib.b2t_gemm_bf16p_f32(C.byref(d), ops._p(ws), lib.b2t_gemm_bf16p_ws_bytes(M, N, K), ops._stream()) != 0
+
+
 @pytest.mark.parametrize("M,N,K", [(2200, 2304, 200), (520, 7168, 130), (2304, 7168, 192)])
 def test_gemm_bf16_packed_256_tiles(M, N, K, monkeypatch):
     """The 256 x 256 kernel of b2t_gemm_bf16p_f32 (gemm_bf16p_kernel256: chosen where its tiles fill the chip evenly;

@@ -823,3 +823,50 @@ def test_bf16_mode_256_tile_gemms_in_the_step_are_bit_identical(monkeypatch):
     finally:
         ops.set_amp(old_amp)
         monkeypatch.delenv("B2T_GEMM_256", raising=False)
+
+
+def test_bf16_mode_day_layer_on_the_packed_kernel(monkeypatch):
+    """Round 5, bf16 mode: the day layer's per-sentence products (forward x[b] W[day[b]] with the Softsign epilogue, backward
+    x[b]^T dpre[b]; Z = B) run through the two-pass packed kernel with every matrix of the batch packed (gemm_bf16p_run, Z > 1;
+    the backward's A operand -- the INPUT, transposed -- is packed when the backward pass starts: `xpack` task, csrc/exec.cpp).
+    Same operands, same bf16 rounding, fp32 accumulation in another order than the one-pass kernel's: logits, losses and every
+    gradient agree with B2T_ZPACK=0 to fp32 summation roundoff -- a patch model with input dropout (the shipped form) and a plain one."""
+    import b2t_ops as ops
+    from rnn_model import GRUDecoder
+    from b2t_train_step import TrainStep
+    dev = _dev()
+    old_amp = ops.AMP["on"]
+    try:
+        ops.set_amp(True)
+        for (F, H, D, C, L, B, T, S, patch, drop, chunks) in ((128, 256, 4, 41, 2, 48, 230, 8, (6, 3), (0.3, 0.2), (3, 2)),
+                                                             (256, 256, 3, 41, 2, 32, 200, 8, (0, 0), (0.0, 0.0), (1, 1))):
+            g = torch.Generator().manual_seed(B + H + T)
+            x = torch.randn(B, T, F, generator=g).to(dev)
+            day = torch.randint(0, D, (B,), generator=g)
+            Tp = T if patch[0] == 0 else (T - patch[0]) // patch[1] + 1
+            tgt = torch.randint(1, C, (B, S), generator=g); tl = torch.randint(2, S + 1, (B,), generator=g)
+            nt = torch.randint(T - 10, T + 1, (B,), generator=g)
+            for b in range(B):
+                tgt[b, tl[b]:] = 0
+            monkeypatch.setitem(ops.PIPELINE, "chunks", chunks[0])
+            monkeypatch.setitem(ops.PIPELINE, "chunks_bwd", chunks[1])
+
+            def grads(zpack):
+                monkeypatch.setenv("B2T_ZPACK", "1" if zpack else "0")
+                torch.manual_seed(3)
+                m = GRUDecoder(F, H, D, C, drop[0], drop[1], L, patch[0], patch[1]).to(dev).train()
+                ts = TrainStep(m, step_args())
+                loss_b = ts.compute_grads(x, day, tgt, nt, tl)
+                torch.cuda.synchronize()
+                ts.check_status()
+                return ts.grad_arena.clone(), loss_b.clone(), ts.last_logits.clone()
+
+            ref, got = grads(False), grads(True)
+            assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
+            for a, r, name in zip(got, ref, ("gradients", "losses", "logits")):
+                scale = float(r.abs().max())
+                assert float((a - r).abs().max()) <= 2e-4 * scale, f"patch={patch}: {name} differ by {float((a - r).abs().max())} (scale {scale})"
+            assert not torch.equal(got[0], ref[0]) or True      # (another summation order: equality is not required)
+    finally:
+        ops.set_amp(old_amp)
+        monkeypatch.delenv("B2T_ZPACK", raising=False)

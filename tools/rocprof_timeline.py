@@ -8,7 +8,9 @@ kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 cols = [r[1] for r in db.execute(f"pragma table_info({kd})")]
 qcol = "queue_id" if "queue_id" in cols else cols[0]
-rows = list(db.execute(f"select s.kernel_name, d.start, d.end, d.{qcol} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+gcol = "d.grid_size_x / d.workgroup_size_x" if "grid_size_x" in cols and "workgroup_size_x" in cols else "0"
+gz = "d.grid_size_z" if "grid_size_z" in cols else "1"
+rows = list(db.execute(f"select s.kernel_name, d.start, d.end, d.{qcol}, {gcol}, {gz} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
 # last step = from the last augment_smooth kernel on
 idx = [i for i, r in enumerate(rows) if "augment_smooth" in r[0]]
 nsteps_back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -19,7 +21,7 @@ def fam(n):
         if k in n: return k
     return "other"
 agg = {}
-for n, s, e, q in rows:
+for n, s, e, q, gx, gzz in rows:
     a = agg.setdefault(fam(n), [1e30, 0, 0.0, 0, []])
     a[0] = min(a[0], s - t0); a[1] = max(a[1], e - t0); a[2] += e - s; a[3] += 1; a[4].append((s, e))
 print(f"step wall: {(max(r[2] for r in rows) - t0)/1e6:.3f} ms, kernels: {len(rows)}, queues: {len(set(r[3] for r in rows))}")
@@ -31,5 +33,5 @@ for k, (s, e, busy, cnt, iv) in sorted(agg.items(), key=lambda kv: kv[1][0]):
     cov += ce - cs
     print(f"{k:28s} n={cnt:4d} first={s/1e6:8.3f} last={e/1e6:8.3f} busy={busy/1e6:8.3f} union={cov/1e6:8.3f} ms")
 if len(sys.argv) > 3:
-    for n, s, e, q in rows:
-        print(f"{(s-t0)/1e3:10.1f} {(e-s)/1e3:9.1f} q{q} {n[:60]}")
+    for n, s, e, q, gx, gzz in rows:
+        print(f"{(s-t0)/1e3:10.1f} {(e-s)/1e3:9.1f} q{q} wg={gx}x{gzz} {n[:60]}")
