@@ -56,7 +56,7 @@ def step_model(B, T, F, H, L, C, S, patch, stride, n_active_params, act_bytes=4)
     return float(by), float(fl)
 
 
-def train_ms(shape: str, amp: bool, steps: int = 8, warmup: int = 3):
+def train_ms(shape: str, amp: bool, steps: int = 24, warmup: int = 6):
     dev = torch.device("cuda:0")
     B, T, F, C, D, S = 64, 500, 512, 41, 45, 60
     old = ops.AMP["on"]
@@ -91,10 +91,16 @@ def train_ms(shape: str, amp: bool, steps: int = 8, warmup: int = 3):
             return ts.step(f, days, labels, nts - (i % 3), lens)
         for i in range(warmup):
             step(i)
+        # three windows of steps / 3: the line's value is the mean over all steps; a window far off the others (a one-off stall of the
+        # box: 12.7 against 9.8 ms was seen once with 8 steps in ONE window) shows in `window_ms`
+        win = []
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for i in range(steps):
-            loss, _ = step(warmup + i)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        for k in range(3):
+            tw = time.perf_counter()
+            for i in range(k * steps // 3, (k + 1) * steps // 3):
+                loss, _ = step(warmup + i)
+            torch.cuda.synchronize(); win.append((time.perf_counter() - tw) / max(1, (k + 1) * steps // 3 - k * steps // 3))
+        dt = (time.perf_counter() - t0) / steps
         ts.check_status()
         assert np.isfinite(float(loss))
         H = 768 if shape == "c3" else 512
@@ -105,7 +111,8 @@ def train_ms(shape: str, amp: bool, steps: int = 8, warmup: int = 3):
                     mfma_peak_tflops=round(peak / 1e12, 1), mfma_frac=round(fl / dt / peak, 4), hbm_frac=round(by / dt / 8.0e12, 4),
                     note=("tensors in HBM are fp32 in this mode too (operands are rounded to bf16 on their way to the matrix cores): "
                           "the byte model is the fp32 one" if amp else "SURVEY 8(d)'s byte / FLOP model at this shape"))
-        return dict(ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1), workload=what + ", full training step",
+        return dict(ms_per_step=round(dt * 1e3, 3), sentences_per_s=round(B / dt, 1), steps=steps, window_ms=[round(v * 1e3, 3) for v in win],
+                    workload=what + ", full training step",
                     dtype="bf16 matmul + recurrent-product operands, f32 accumulate / gates / CTC / optimizer" if amp else "f32",
                     roofline=roof)
     finally:
