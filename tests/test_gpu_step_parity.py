@@ -866,7 +866,6 @@ def test_bf16_mode_day_layer_on_the_packed_kernel(monkeypatch):
             for a, r, name in zip(got, ref, ("gradients", "losses", "logits")):
                 scale = float(r.abs().max())
                 assert float((a - r).abs().max()) <= 2e-4 * scale, f"patch={patch}: {name} differ by {float((a - r).abs().max())} (scale {scale})"
-            assert not torch.equal(got[0], ref[0]) or True      # (another summation order: equality is not required)
     finally:
         ops.set_amp(old_amp)
         monkeypatch.delenv("B2T_ZPACK", raising=False)
