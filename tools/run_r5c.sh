@@ -1,6 +1,8 @@
-set -x
-cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out
-mkdir -p $OUT
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "paired" 2>&1 | tail -15
-timeout 600 python tools/r5_pair_probe.py > $OUT/r5c_probe.log 2>&1; cat $OUT/r5c_probe.log
+#!/bin/bash
+# shipped shape, bf16 mode: time chunks of the forward / backward plan (the 3 / 2 default dates from round 3, when the step took 7.4 ms)
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+for cfg in "3 2" "3 3" "4 2" "4 3" "4 4" "2 2" "5 3" "6 3" "6 4" "3 2"; do
+  set -- $cfg
+  echo "chunks $1 / $2: $(B2T_CHUNKS=$1 B2T_CHUNKS_BWD=$2 timeout 200 python tools/r4_cfgs.py c3_amp 2>&1 | tail -1)"
+done
+echo "default: $(timeout 200 python tools/r4_cfgs.py c3_amp 2>&1 | tail -1)"
