@@ -321,3 +321,17 @@ def test_struct_layouts_match_the_header(tmp_path, cls, ctype):
         if line.strip():
             name, off = line.split()
             assert getattr(K, name).offset == int(off), name
+
+
+def test_packed_gemm_workspace_sizes_are_host_arithmetic():
+    """b2t_gemm_bf16p_ws_bytes / _ws_bytes_z (include/b2t.h) are plain arithmetic and run without a GPU: operands padded to 128 rows and
+    64 k, two bytes per element, + 512; a Z-batched descriptor packs every matrix of the batch (Z times the operands of one)."""
+    import b2t_native as N
+    lib = N.load()
+    pad = lambda v, a: (v + a - 1) // a * a
+    for (M, Nn, K) in ((498, 512, 512), (512, 512, 498), (1, 1, 1), (2304, 7168, 7808)):
+        one = lib.b2t_gemm_bf16p_ws_bytes(M, Nn, K)
+        assert one == (pad(M, 128) + pad(Nn, 128)) * pad(K, 64) * 2 + 512
+        assert lib.b2t_gemm_bf16p_ws_bytes_z(M, Nn, K, 1) == one
+        assert lib.b2t_gemm_bf16p_ws_bytes_z(M, Nn, K, 64) == 64 * (one - 512) + 512
+    assert lib.b2t_gemm_bf16p_ws_bytes(0, 4, 4) == 0 and lib.b2t_gemm_bf16p_ws_bytes_z(4, 4, 4, 0) == 0
