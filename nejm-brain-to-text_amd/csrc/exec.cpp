@@ -82,7 +82,28 @@ int splitk_for(int M, int N, long long K, int target_blocks) {
   if (v >= 8) v = v / 8 * 8;   // (rounding 7 up to 8 was measured at H = 768: 19.03 -> 19.31 ms, more than one wave of blocks)
   return (int)std::max<long long>(1, v);
 }
-int splitk_cap(int M, int N, long long K) { return std::max(splitk_for(M, N, K, splitk_target(false)), splitk_for(M, N, K, splitk_target(true))); }   // workspace sizing
+// bf16 mode, round 5: a weight gradient with few output tiles and a long K on the 256 x 256 tile kernel (gemm_bf16p.hip) -- slices
+// so that tiles x slices fill ONE round of 256 workgroups (a multiple of 8 slices where that still fills 200: a slice per XCD), each
+// slice at least 512 deep.  0: stay on 128-tiles (splitk_for).  dW of the shipped shape's layers (2304 x 768 x 7808): 27 tiles x 8
+// instead of 108 x 4; configs[1] (1536 x 512 x 32000): 12 x 21 instead of 48 x 8.  OPT-IN (B2T_SPLITK256=1, under the kernel's
+// automatic choice only): measured neutral inside the step -- c3_amp 5.75 / 5.83 off, 5.87 / 5.83 on; c2_amp 9.87 / 9.91 off, 9.97 / 9.86 on:
+// these GEMMs run next to the backward sweeps, and a 144-KB-LDS workgroup per CU is no better a neighbour than two 74-KB ones.
+int splitk_for256(int M, int N, long long K) {
+  const char* e = getenv("B2T_GEMM_256");
+  const char* o = getenv("B2T_SPLITK256");
+  if ((e && atoi(e) != 1) || !(o && atoi(o) == 1)) return 0;
+  const int t = ((M + 255) / 256) * ((N + 255) / 256);
+  if (t > 128 || M < 256 || N < 256) return 0;
+  const long long v = std::min<long long>(256 / t, K / 512);
+  const long long v8 = v / 8 * 8;
+  if (v8 >= 8 && t * v8 >= 200) return (int)v8;
+  return t * v >= 200 ? (int)v : 0;
+}
+int splitk_cap(int M, int N, long long K) {   // workspace sizing
+  const int t = ((M + 255) / 256) * ((N + 255) / 256);
+  const int s256 = (t <= 128 && M >= 256 && N >= 256) ? (int)std::min<long long>(256 / t, K / 512) : 0;
+  return std::max(std::max(splitk_for(M, N, K, splitk_target(false)), splitk_for(M, N, K, splitk_target(true))), s256);
+}
 
 // Time chunks of the layer pipeline: `chunks` equal parts (at least 16 steps each).
 int make_chunks(int Tp, int chunks, int (*out)[2]) {
@@ -465,7 +486,7 @@ uint64_t pass_key(int which, const b2t_model_t* prm, const b2t_model_t* grd, con
   h = key_of(h, p->in_drop); h = key_of(h, p->rnn_drop);
   for (const void* q : ptrs) h = key_of(h, q);
   for (long long v : ints) h = key_of(h, v);
-  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK", "B2T_WGRAD_SPLIT", "B2T_ZPACK", "B2T_GEMM_256", "B2T_GI0_CHAIN"}) {   // read per pass by the code below / the sweeps
+  for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK", "B2T_WGRAD_SPLIT", "B2T_ZPACK", "B2T_GEMM_256", "B2T_GI0_CHAIN", "B2T_SPLITK256"}) {   // read per pass by the code below / the sweeps
     const char* e = getenv(name);
     h = key_of(h, (int)(e ? e[0] : 0));
   }
@@ -1120,7 +1141,8 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
   if (part != 2) {
     b2t_gemm_desc d = gd(w.dG[l] + a0, w.out[l] + (long long)t0 * B * H, grd->w_hh[l], 3 * H, H, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = H; d.c_s0 = H;
-    const int sk = splitk_for(3 * H, H, K, splitk_target(c.bf16_gemm));
+    int sk = splitk_for(3 * H, H, K, splitk_target(c.bf16_gemm));
+    if (c.bf16_gemm && which != 1 && c.would_pack(d, s)) { const int s256 = splitk_for256(3 * H, H, K); if (s256 > 0) sk = s256; }
     if (which == 1) { c.call(gemm_bf16p_pack(&d, 1, w.xpk_hh[l], s)); }
     else {
       if (fused_bias) { d.a_sum = asum_x; d.a_sum_ks = 3 * H; }
@@ -1142,7 +1164,8 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     b2t_gemm_desc d = gd(w.dG[l] + a0 + a_off, inp, grd->w_ih[l] + c_off, M, In, (int)K);
     d.a_kcontig = 0; d.a_s0 = 4 * H; d.b_kcontig = 0; d.b_s0 = b_s0; d.b_s1 = b_s1; d.b_div = b_div; d.c_s0 = In;
     d.a_brk = brk; d.a_gap = gap;
-    const int sk = splitk_for(M, In, K, splitk_target(c.bf16_gemm));
+    int sk = splitk_for(M, In, K, splitk_target(c.bf16_gemm));
+    if (c.bf16_gemm && which != 1 && c.would_pack(d, s)) { const int s256 = splitk_for256(M, In, K); if (s256 > 0) sk = s256; }
     if (which == 1) { c.call(gemm_bf16p_pack(&d, 1, w.xpk_ih[l], s)); return; }
     if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
     c.gemm(s, d, sk, w.slab[l], accumulate, l, pre ? w.xpk_ih[l] : nullptr);
