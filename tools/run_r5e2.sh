@@ -1,5 +1,5 @@
 #!/bin/bash
-# WFST search: a plain load in front of the per-link cost atomic (B2T_WFST_PRECHECK, compile time): A/B of two libraries in one call
+# WFST search: A/B of two libraries (the tree's and csrc/libb2t_hip_alt.so, a compile-time variant) in one call
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 ALT=$GRAFT_REPO_ROOT/nejm-brain-to-text_amd/csrc/libb2t_hip_alt.so
 for i in 1 2; do
@@ -10,7 +10,7 @@ sys.path.insert(0, "tools"); sys.path.insert(0, "nejm-brain-to-text_amd")
 import bench_wfst as B
 r = B.run()
 o = r["offline"]; st = r["streaming"]
-print("precheck" if not os.environ.get("B2T_LIB") else "always-atomic", "search", o["search_ms"], "with prune", o["search_ms_prune_every_25_frames"], "stream p50", st["p50_ms_per_frame"], flush=True)
+print("early-link" if not os.environ.get("B2T_LIB") else "link-after-claim", "search", o["search_ms"], "with prune", o["search_ms_prune_every_25_frames"], "stream p50", st["p50_ms_per_frame"], flush=True)
 PY
   done
 done
