@@ -236,18 +236,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __
 constexpr int QM = 256, QN = 256;
 constexpr size_t Q_LDS = (size_t)2 * (QM + QN) * PPITCH * sizeof(__bf16);
 
-#define B2T_QFETCH(k0)                                                                                                    \
-  ra0 = *reinterpret_cast<const uint4*>(Ap + ao0 + (k0)); ra1 = *reinterpret_cast<const uint4*>(Ap + ao1 + (k0));          \
-  ra2 = *reinterpret_cast<const uint4*>(Ap + ao2 + (k0)); ra3 = *reinterpret_cast<const uint4*>(Ap + ao3 + (k0));          \
-  rb0 = *reinterpret_cast<const uint4*>(Bp + bo0 + (k0)); rb1 = *reinterpret_cast<const uint4*>(Bp + bo1 + (k0));          \
-  rb2 = *reinterpret_cast<const uint4*>(Bp + bo2 + (k0)); rb3 = *reinterpret_cast<const uint4*>(Bp + bo3 + (k0));
-#define B2T_QSTASH(buf)                                                                                                   \
+#define B2T_QFETCH(R, k0)                                                                                                 \
+  R##a0 = *reinterpret_cast<const uint4*>(Ap + ao0 + (k0)); R##a1 = *reinterpret_cast<const uint4*>(Ap + ao1 + (k0));      \
+  R##a2 = *reinterpret_cast<const uint4*>(Ap + ao2 + (k0)); R##a3 = *reinterpret_cast<const uint4*>(Ap + ao3 + (k0));      \
+  R##b0 = *reinterpret_cast<const uint4*>(Bp + bo0 + (k0)); R##b1 = *reinterpret_cast<const uint4*>(Bp + bo1 + (k0));      \
+  R##b2 = *reinterpret_cast<const uint4*>(Bp + bo2 + (k0)); R##b3 = *reinterpret_cast<const uint4*>(Bp + bo3 + (k0));
+#define B2T_QSTASH(R, buf)                                                                                                \
   { __bf16* ad = As + (buf) * QM * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
     __bf16* bd = Bs + (buf) * QN * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
-    *reinterpret_cast<uint4*>(ad) = ra0; *reinterpret_cast<uint4*>(ad + 64 * PPITCH) = ra1;                               \
-    *reinterpret_cast<uint4*>(ad + 128 * PPITCH) = ra2; *reinterpret_cast<uint4*>(ad + 192 * PPITCH) = ra3;               \
-    *reinterpret_cast<uint4*>(bd) = rb0; *reinterpret_cast<uint4*>(bd + 64 * PPITCH) = rb1;                               \
-    *reinterpret_cast<uint4*>(bd + 128 * PPITCH) = rb2; *reinterpret_cast<uint4*>(bd + 192 * PPITCH) = rb3; }
+    *reinterpret_cast<uint4*>(ad) = R##a0; *reinterpret_cast<uint4*>(ad + 64 * PPITCH) = R##a1;                           \
+    *reinterpret_cast<uint4*>(ad + 128 * PPITCH) = R##a2; *reinterpret_cast<uint4*>(ad + 192 * PPITCH) = R##a3;           \
+    *reinterpret_cast<uint4*>(bd) = R##b0; *reinterpret_cast<uint4*>(bd + 64 * PPITCH) = R##b1;                           \
+    *reinterpret_cast<uint4*>(bd + 128 * PPITCH) = R##b2; *reinterpret_cast<uint4*>(bd + 192 * PPITCH) = R##b3; }
 
 __global__ __launch_bounds__(512) void gemm_bf16p_kernel256(GemmArgs g, const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp, int Kp, int Mp, int Np) {
   extern __shared__ __attribute__((aligned(16))) __bf16 qsmem[];
@@ -282,7 +282,8 @@ __global__ __launch_bounds__(512) void gemm_bf16p_kernel256(GemmArgs g, const __
   const long long ao2 = (long long)min(m0 + r0 + 128, Mp - 1) * Kp + kc, ao3 = (long long)min(m0 + r0 + 192, Mp - 1) * Kp + kc;
   const long long bo0 = (long long)min(n0 + r0, Np - 1) * Kp + kc, bo1 = (long long)min(n0 + r0 + 64, Np - 1) * Kp + kc;
   const long long bo2 = (long long)min(n0 + r0 + 128, Np - 1) * Kp + kc, bo3 = (long long)min(n0 + r0 + 192, Np - 1) * Kp + kc;
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  uint4 r0a0, r0a1, r0a2, r0a3, r0b0, r0b1, r0b2, r0b3;   // two register sets: the global loads of tile t + 2 are issued while tile t is
+  uint4 r1a0, r1a1, r1a2, r1a3, r1b0, r1b1, r1b2, r1b3;   // multiplied and land 1.5 tiles later (one set: half a tile, less than an L2 round trip under load)
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -297,14 +298,14 @@ __global__ __launch_bounds__(512) void gemm_bf16p_kernel256(GemmArgs g, const __
     // [MFMAs of step 3].  The stash, the barrier and the first LDS reads of a tile all sit under MFMA work of the same wave.
     // Hazards: the stash of tile t+1 goes to the buffer tile t-1 was read from -- every wave's last read of t-1 is before barrier
     // t-1, the stash is behind it; tile t+1 is read behind barrier t, which is behind every wave's stash.
-    B2T_QFETCH(0) B2T_QSTASH(0)
+    B2T_QFETCH(r0, 0) B2T_QSTASH(r0, 0)
+    B2T_QFETCH(r0, (nk > 1 ? 1 : 0) * PK)                                  // tile 1, stashed in the middle of tile 0
     __syncthreads();
     const __bf16* abase = As + (wm * 128 + li) * PPITCH + 8 * lk;
     const __bf16* bbase = Bs + (wn * 64 + li) * PPITCH + 8 * lk;
     bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(abase), fa1 = *reinterpret_cast<const bf16x8*>(abase + 32 * PPITCH);
     bf16x8 fa2 = *reinterpret_cast<const bf16x8*>(abase + 64 * PPITCH), fa3 = *reinterpret_cast<const bf16x8*>(abase + 96 * PPITCH);
     bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(bbase), fb1 = *reinterpret_cast<const bf16x8*>(bbase + 32 * PPITCH);
-    int cur = 0;
 #define B2T_QMMA(a0, a1, a2, a3, b0, b1)                                                                       \
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);                            \
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);                            \
@@ -318,27 +319,36 @@ __global__ __launch_bounds__(512) void gemm_bf16p_kernel256(GemmArgs g, const __
     const bf16x8 x0 = *reinterpret_cast<const bf16x8*>((ap_) + (kk)), x1 = *reinterpret_cast<const bf16x8*>((ap_) + 32 * PPITCH + (kk)); \
     const bf16x8 x2 = *reinterpret_cast<const bf16x8*>((ap_) + 64 * PPITCH + (kk)), x3 = *reinterpret_cast<const bf16x8*>((ap_) + 96 * PPITCH + (kk)); \
     const bf16x8 y0 = *reinterpret_cast<const bf16x8*>((bp_) + (kk)), y1 = *reinterpret_cast<const bf16x8*>((bp_) + 32 * PPITCH + (kk));
-    for (int kt = 0; kt < nk; ++kt) {
-      const int knext = (kt + 1 < nk ? kt + 1 : kt) * PK;
-      B2T_QFETCH(knext)
-      const __bf16* ap = abase + cur * QM * PPITCH;
-      const __bf16* bp = bbase + cur * QN * PPITCH;
-      B2T_QMMA(fa0, fa1, fa2, fa3, fb0, fb1)
-      { B2T_QFRAGS(ap, bp, 16) B2T_QMMA(x0, x1, x2, x3, y0, y1) }
-      B2T_QSTASH(cur ^ 1)
-      { B2T_QFRAGS(ap, bp, 32) B2T_QMMA(x0, x1, x2, x3, y0, y1) }
-      {
-        B2T_QFRAGS(ap, bp, 48)
-        __syncthreads();
-        const __bf16* an = abase + (cur ^ 1) * QM * PPITCH;
-        const __bf16* bn = bbase + (cur ^ 1) * QN * PPITCH;
-        fa0 = *reinterpret_cast<const bf16x8*>(an); fa1 = *reinterpret_cast<const bf16x8*>(an + 32 * PPITCH);
-        fa2 = *reinterpret_cast<const bf16x8*>(an + 64 * PPITCH); fa3 = *reinterpret_cast<const bf16x8*>(an + 96 * PPITCH);
-        fb0 = *reinterpret_cast<const bf16x8*>(bn); fb1 = *reinterpret_cast<const bf16x8*>(bn + 32 * PPITCH);
-        B2T_QMMA(x0, x1, x2, x3, y0, y1)
-      }
-      cur ^= 1;
+// tile kt out of LDS buffer CUR: loads of tile kt + 2 into set RL, tile kt + 1 (set RS, loaded a tile ago) stashed into the other buffer
+#define B2T_QTILE(CUR, RL, RS)                                                                                 \
+    {                                                                                                          \
+      const int k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * PK;                                                     \
+      B2T_QFETCH(RL, k2)                                                                                       \
+      const __bf16* ap = abase + (CUR) * QM * PPITCH;                                                          \
+      const __bf16* bp = bbase + (CUR) * QN * PPITCH;                                                          \
+      B2T_QMMA(fa0, fa1, fa2, fa3, fb0, fb1)                                                                   \
+      { B2T_QFRAGS(ap, bp, 16) B2T_QMMA(x0, x1, x2, x3, y0, y1) }                                              \
+      B2T_QSTASH(RS, (CUR) ^ 1)                                                                                \
+      { B2T_QFRAGS(ap, bp, 32) B2T_QMMA(x0, x1, x2, x3, y0, y1) }                                              \
+      {                                                                                                        \
+        B2T_QFRAGS(ap, bp, 48)                                                                                 \
+        __syncthreads();                                                                                       \
+        const __bf16* an = abase + ((CUR) ^ 1) * QM * PPITCH;                                                  \
+        const __bf16* bn = bbase + ((CUR) ^ 1) * QN * PPITCH;                                                  \
+        fa0 = *reinterpret_cast<const bf16x8*>(an); fa1 = *reinterpret_cast<const bf16x8*>(an + 32 * PPITCH);  \
+        fa2 = *reinterpret_cast<const bf16x8*>(an + 64 * PPITCH); fa3 = *reinterpret_cast<const bf16x8*>(an + 96 * PPITCH); \
+        fb0 = *reinterpret_cast<const bf16x8*>(bn); fb1 = *reinterpret_cast<const bf16x8*>(bn + 32 * PPITCH);  \
+        B2T_QMMA(x0, x1, x2, x3, y0, y1)                                                                       \
+      }                                                                                                        \
     }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      B2T_QTILE(0, r1, r0)
+      ++kt;
+      B2T_QTILE(1, r0, r1)
+      --kt;
+    }
+    if (kt < nk) { B2T_QTILE(0, r1, r0) }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
