@@ -3,13 +3,14 @@
 //      order) and written as a dense, k-contiguous bf16 matrix [rows padded to 128][K padded to 64] (round-to-nearest-even,
 //      zero fill) into caller-provided scratch;
 //   2. GEMM: C = A_p . B_p^T on 128x128x64 tiles, v_mfma_f32_32x32x16_bf16, 16-byte global loads that go to LDS unconverted,
-//      register prefetch of the next k-tile, double-buffered LDS (144-byte rows: a fragment is one conflict-free 16-byte
-//      read), one barrier per k-tile, fp32 accumulation and the fp32 epilogue of gemm_bf16.hip (bias, Softsign and its
-//      backward, accumulate, row-mapped C, split-K slabs).
+//      register prefetch two k-tiles ahead (two register sets: one tile of MFMA work is shorter than an L2 round trip under
+//      load), double-buffered LDS (144-byte rows: a fragment is one conflict-free 16-byte read), one barrier per k-tile, fp32
+//      accumulation and the fp32 epilogue of gemm_bf16.hip (bias, Softsign and its backward, accumulate, row-mapped C,
+//      split-K slabs).
 // Same numerics contract as b2t_gemm_bf16_f32 (operands rounded to bf16, fp32 accumulate, fp32 out).  Why two passes: the
 // one-pass kernel converts fp32 operands on their way into LDS and reaches 315 TF/s at 4096^3; with packed operands the
 // same tile shape runs at 700-840 TF/s (tools/ubench/gemm_bf16p.hip), and a pack pass is bandwidth-bound and small next
-// to it.  Z-batched GEMMs (the day layer) stay on the one-pass kernel.
+// to it.  Z-batched GEMMs (the day layer): every matrix of the batch packed, grid y of the tile kernel (round 5).
 // Round 5: a second tile kernel, 256 x 256 x 64 with 8 waves (gemm_bf16p_kernel256, below), takes the products whose 256-tiles fill
 // the chip evenly (the shipped shape's layer-0 weight and input gradients: 660 -> 880 TF/s, bit-identical results).
 #include "common.h"
@@ -117,18 +118,39 @@ __global__ __launch_bounds__(256) void pack_mc_kernel(PackArgs a) {
   }
 }
 
-#define B2T_PFETCH(k0)                                                                                                    \
-  ra0 = *reinterpret_cast<const uint4*>(ag + (k0)); ra1 = *reinterpret_cast<const uint4*>(ag + 32ll * Kp + (k0));          \
-  ra2 = *reinterpret_cast<const uint4*>(ag + 64ll * Kp + (k0)); ra3 = *reinterpret_cast<const uint4*>(ag + 96ll * Kp + (k0)); \
-  rb0 = *reinterpret_cast<const uint4*>(bg + (k0)); rb1 = *reinterpret_cast<const uint4*>(bg + 32ll * Kp + (k0));          \
-  rb2 = *reinterpret_cast<const uint4*>(bg + 64ll * Kp + (k0)); rb3 = *reinterpret_cast<const uint4*>(bg + 96ll * Kp + (k0));
-#define B2T_PSTASH(buf)                                                                                                   \
+#define B2T_PFETCH(R, k0)                                                                                                 \
+  R##a0 = *reinterpret_cast<const uint4*>(ag + (k0)); R##a1 = *reinterpret_cast<const uint4*>(ag + 32ll * Kp + (k0));      \
+  R##a2 = *reinterpret_cast<const uint4*>(ag + 64ll * Kp + (k0)); R##a3 = *reinterpret_cast<const uint4*>(ag + 96ll * Kp + (k0)); \
+  R##b0 = *reinterpret_cast<const uint4*>(bg + (k0)); R##b1 = *reinterpret_cast<const uint4*>(bg + 32ll * Kp + (k0));      \
+  R##b2 = *reinterpret_cast<const uint4*>(bg + 64ll * Kp + (k0)); R##b3 = *reinterpret_cast<const uint4*>(bg + 96ll * Kp + (k0));
+#define B2T_PSTASH(R, buf)                                                                                                \
   { __bf16* ad = As + (buf) * PM * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
     __bf16* bd = Bs + (buf) * PM * PPITCH + (tid >> 3) * PPITCH + (tid & 7) * 8;                                          \
-    *reinterpret_cast<uint4*>(ad) = ra0; *reinterpret_cast<uint4*>(ad + 32 * PPITCH) = ra1;                               \
-    *reinterpret_cast<uint4*>(ad + 64 * PPITCH) = ra2; *reinterpret_cast<uint4*>(ad + 96 * PPITCH) = ra3;                 \
-    *reinterpret_cast<uint4*>(bd) = rb0; *reinterpret_cast<uint4*>(bd + 32 * PPITCH) = rb1;                               \
-    *reinterpret_cast<uint4*>(bd + 64 * PPITCH) = rb2; *reinterpret_cast<uint4*>(bd + 96 * PPITCH) = rb3; }
+    *reinterpret_cast<uint4*>(ad) = R##a0; *reinterpret_cast<uint4*>(ad + 32 * PPITCH) = R##a1;                           \
+    *reinterpret_cast<uint4*>(ad + 64 * PPITCH) = R##a2; *reinterpret_cast<uint4*>(ad + 96 * PPITCH) = R##a3;             \
+    *reinterpret_cast<uint4*>(bd) = R##b0; *reinterpret_cast<uint4*>(bd + 32 * PPITCH) = R##b1;                           \
+    *reinterpret_cast<uint4*>(bd + 64 * PPITCH) = R##b2; *reinterpret_cast<uint4*>(bd + 96 * PPITCH) = R##b3; }
+// tile kt out of LDS buffer CUR; the loads of tile kt + 2 go to register set RL, tile kt + 1 (set RS, requested a tile ago) is stashed
+#define B2T_PTILE(CUR, RL, RS)                                                                                            \
+    {                                                                                                                     \
+      const int k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * PK;                                                                \
+      B2T_PFETCH(RL, k2)                                                                                                  \
+      const __bf16* a0p = As + (CUR) * PM * PPITCH + (wm * 64 + li) * PPITCH + 8 * lk;                                    \
+      const __bf16* a1p = a0p + 32 * PPITCH;                                                                              \
+      const __bf16* b0p = Bs + (CUR) * PM * PPITCH + (wn * 64 + li) * PPITCH + 8 * lk;                                    \
+      const __bf16* b1p = b0p + 32 * PPITCH;                                                                              \
+      _Pragma("unroll")                                                                                                   \
+      for (int kk = 0; kk < PK; kk += 16) {                                                                               \
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a0p + kk), a1 = *reinterpret_cast<const bf16x8*>(a1p + kk);    \
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b0p + kk), b1 = *reinterpret_cast<const bf16x8*>(b1p + kk);    \
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);                                          \
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);                                          \
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);                                          \
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);                                          \
+      }                                                                                                                   \
+      B2T_PSTASH(RS, (CUR) ^ 1)                                                                                           \
+      __syncthreads();                                                                                                    \
+    }
 
 // (plain variables for the prefetch registers, no lambdas over arrays: the array form was demoted to scratch memory by the
 // compiler -- 230 TF/s instead of 840)
@@ -168,35 +190,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16p_kernel(GemmArgs g, const __
   const int kb = ks * g.kchunk, ke = min(Kp, kb + g.kchunk), nk = (ke - kb) / PK;
   const __bf16* ag = Ap + z * a_zs + (long long)(m0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
   const __bf16* bg = Bp + z * b_zs + (long long)(n0 + (tid >> 3)) * Kp + (tid & 7) * 8 + kb;
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  uint4 r0a0, r0a1, r0a2, r0a3, r0b0, r0b1, r0b2, r0b3;   // two register sets (as in gemm_bf16p_kernel256): tile t + 2 is requested while
+  uint4 r1a0, r1a1, r1a2, r1a3, r1b0, r1b1, r1b2, r1b3;   // tile t is multiplied
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc00[e] = 0.f; acc01[e] = 0.f; acc10[e] = 0.f; acc11[e] = 0.f; }
   const int lk = lane >> 5, li = lane & 31;
   if (nk > 0) {
-    B2T_PFETCH(0) B2T_PSTASH(0)
+    B2T_PFETCH(r0, 0) B2T_PSTASH(r0, 0)
+    B2T_PFETCH(r0, (nk > 1 ? 1 : 0) * PK)
     __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int knext = (kt + 1 < nk ? kt + 1 : kt) * PK;   // the last iteration re-reads its own tile: no branch around the loads
-      B2T_PFETCH(knext)
-      const __bf16* a0p = As + cur * PM * PPITCH + (wm * 64 + li) * PPITCH + 8 * lk;
-      const __bf16* a1p = a0p + 32 * PPITCH;
-      const __bf16* b0p = Bs + cur * PM * PPITCH + (wn * 64 + li) * PPITCH + 8 * lk;
-      const __bf16* b1p = b0p + 32 * PPITCH;
-#pragma unroll
-      for (int kk = 0; kk < PK; kk += 16) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a0p + kk), a1 = *reinterpret_cast<const bf16x8*>(a1p + kk);
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(b0p + kk), b1 = *reinterpret_cast<const bf16x8*>(b1p + kk);
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);
-      }
-      B2T_PSTASH(cur ^ 1)
-      __syncthreads();
-      cur ^= 1;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      B2T_PTILE(0, r1, r0)
+      ++kt;
+      B2T_PTILE(1, r0, r1)
+      --kt;
     }
+    if (kt < nk) { B2T_PTILE(0, r1, r0) }
   }
   // epilogue (gemm_bf16.hip): C/D layout of the 32x32 MFMAs: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const f32x16 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
