@@ -18,9 +18,11 @@ n_traj = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 dev = torch.device("cuda:0")
 
 
-def hunt(tag, F, H, D, C, L, B, T, S, chunks, chunks_bwd, mask, n):
+def hunt(tag, F, H, D, C, L, B, T, S, chunks, chunks_bwd, mask, n, patch=(0, 0), amp=False):
     os.environ.pop("B2T_EXEC_JITTER", None)
     ops.PIPELINE["chunks"], ops.PIPELINE["chunks_bwd"], ops.PIPELINE["wgrad_chunk_mask"] = chunks, chunks_bwd, mask
+    old_amp = ops.AMP["on"]
+    ops.set_amp(amp)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, T, F, generator=g).to(dev)
     day = torch.randint(0, D, (B,), generator=g)
@@ -29,7 +31,7 @@ def hunt(tag, F, H, D, C, L, B, T, S, chunks, chunks_bwd, mask, n):
     for b in range(B):
         tgt[b, tl[b]:] = 0
     torch.manual_seed(3)
-    m = GRUDecoder(F, H, D, C, 0.0, 0.0, L, 0, 0).to(dev).train()
+    m = GRUDecoder(F, H, D, C, 0.0, 0.0, L, patch[0], patch[1]).to(dev).train()
     ts = TrainStep(m, dict(bench.ARGS))
     loss = ts.compute_grads(x, day, tgt, nt, tl).clone()
     torch.cuda.synchronize()
@@ -44,6 +46,7 @@ def hunt(tag, F, H, D, C, L, B, T, S, chunks, chunks_bwd, mask, n):
             d = (ts.grad_arena - ref).abs()
             bad.append((seed, float(d.max()), int((d > 0).sum()), float((l2 - loss).abs().max())))
     ts.check_status()
+    ops.set_amp(old_amp)
     os.environ.pop("B2T_EXEC_JITTER", None)
     print(f"{tag}: {n} jitter seeds, {len(bad)} differ from the unjittered plan {bad[:5]}", flush=True)
     return bad
@@ -76,6 +79,13 @@ def trajectory(n):
 
 DEF = (ops.PIPELINE["chunks"], ops.PIPELINE["chunks_bwd"], ops.PIPELINE["wgrad_chunk_mask"])
 bad = []
+if len(sys.argv) > 4 and sys.argv[4] == "amp":
+    # the bf16 plans of round 5 (pre-packed weights, xpack tasks incl. the day layer's, Z-batched day GEMMs, 256-tile kernel where it fits)
+    bad += hunt("bf16, patch 4/2 (H=256, L=3, F=512, B=32, T=208, chunks 3/2)", 512, 256, 6, 41, 3, 32, 208, 12, 3, 2, 0, n_small, patch=(4, 2), amp=True)
+    bad += hunt("bf16, no patch (H=256, L=3, F=512, B=32, T=208, chunks 3/2)", 512, 256, 6, 41, 3, 32, 208, 12, 3, 2, 0, n_small, amp=True)
+    bad += hunt("bf16, C2 default plan", bench.F, bench.H, bench.D, bench.C, bench.L, bench.B, bench.T, bench.S, *DEF, n_c2, amp=True)
+    print("RESULT:", "clean" if not bad else "HAZARD FOUND")
+    sys.exit(0 if not bad else 1)
 for mask in (0, 0b111):
     bad += hunt(f"small (H=128, L=3, B=32, T=160, chunks 5/3, wgrad mask {mask})", 64, 128, 6, 41, 3, 32, 160, 12, 5, 3, mask, n_small // 2)
 bad += hunt(f"C2 (H=512, L=5, B=64, T=500, default plan {DEF})", bench.F, bench.H, bench.D, bench.C, bench.L, bench.B, bench.T, bench.S, *DEF, n_c2)
