@@ -399,7 +399,7 @@ def time_chunks(Tp: int, B: int = 64, H: int = 512, amp: bool = False) -> int:
     workgroups per CU up to H = 512 but only 1 beyond (the W_hh slice takes the whole register file).  At H = 768, B = 64
     (192 workgroups of 256 slots) concurrent fp32 sweeps just block each other: 37-93 ms per step with 6 chunks against
     19.8 ms with the layers in sequence (tools/bench_c3.py).  With bf16 operands (amp) the slices are half as large, the
-    sweeps run with 32-unit workgroups (96 per sweep) and the GEMMs are short: 3 forward / 2 backward chunks let the four
+    sweeps run with 32-unit workgroups (96 per sweep) and the GEMMs are short: 3 forward / 3 backward chunks (2 backward until round 5) let the four
     queues overlap GEMMs and sweeps of different layers (shipped shape: 9.7 ms serial, 7.8 at 2 / 2, 7.4-7.5 at 3 / 2 and
     4 / 2, 7.9 at 6 / 4)."""
     if _crowded(B, H) and "B2T_CHUNKS" not in os.environ:
@@ -413,7 +413,9 @@ def time_chunks_bwd(Tp: int, B: int, H: int, amp: bool, fwd_chunks: int) -> int:
     if fwd_chunks == 1:
         return 0
     if _crowded(B, H) and "B2T_CHUNKS_BWD" not in os.environ:
-        return 2
+        # (only the bf16 mode gets here with fwd_chunks > 1.)  2 until the end of round 5; re-swept on that round's kernels: 3 / 3
+        # 5.64-5.67 ms against 3 / 2 5.70-5.74 (three pairs in one call), 4 / 3 5.80, 4 / 2 5.91, 2 / 2 6.01
+        return max(2, min(3, fwd_chunks, Tp // 16))
     return max(0, min(PIPELINE["chunks_bwd"], fwd_chunks if "B2T_CHUNKS_BWD" not in os.environ else PIPELINE["chunks_bwd"], Tp // 16))
 
 

@@ -209,7 +209,7 @@ def test_time_chunk_plan_rule():
     assert ops.time_chunks(500, 64, 512) == 6
     assert ops.time_chunks(122, 64, 768) == 1
     assert ops.time_chunks(122, 64, 768, amp=True) == 3       # bf16 operands: GEMMs and sweeps of different layers overlap
-    assert ops.time_chunks_bwd(122, 64, 768, True, 3) == 2 and ops.time_chunks_bwd(500, 64, 512, False, 6) == 4
+    assert ops.time_chunks_bwd(122, 64, 768, True, 3) == 3 and ops.time_chunks_bwd(500, 64, 512, False, 6) == 4
     assert ops.time_chunks_bwd(122, 64, 768, False, 1) == 0
     assert ops.time_chunks(500, 128, 512) == 6
     assert ops.time_chunks(500, 192, 512) == 1          # 2 x 384 workgroups > 512 slots
