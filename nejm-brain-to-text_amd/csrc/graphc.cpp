@@ -854,14 +854,22 @@ namespace b2t {
 namespace {
 
 struct DetRescore {
+  // Kept lattice states are renumbered by their topological rank (round 5): a state IS its rank, so the closures' heap holds
+  // states, the per-state arrays (beta, fin, slot, arc offsets) are dense and a closure -- which moves forward a frame or two --
+  // works in a narrow window of them; epsilon-output arcs and word arcs are stored apart (the closure reads only the former, the
+  // gather only the latter).  The instance is kept per host thread and reused: a 175 k-arc lattice needs ~40 MB of these vectors,
+  // and fresh ones are mapped and unmapped page by page on every call.
   struct RArc { int lab, nlab, ol, dst; double g, a; };      // lab / nlab: its input labels (non-epsilon) in `labels`: chains of single-entry single-exit states are contracted into one arc
   struct Ent { int s; double tot, gr, ac; };
-  struct St { size_t off; int n; double alpha; int minrank; double fin_tot, fin_gr, fin_ac; int fin_ent; bool queued; };
+  struct St { size_t off; int n; double alpha; int minrank; double fin_tot, fin_gr, fin_ac; int fin_ent; bool queued; size_t wl_off; int wl_n; };
   struct DArc { int src, dst, word; double tot, gr, ac; size_t bp; };
   struct ANode { int parent, label; };
-  int n_states = 0;
-  std::vector<int> off, order, rank, slot, heap;
-  std::vector<RArc> arc;
+  int n_kept = 0, start_r = -1;
+  struct SInfo { double beta; int slot, eoff; };             // what a closure needs of a state, in one 16-byte record (slot: its index in the working subset, -1 = absent)
+  std::vector<SInfo> si;
+  std::vector<int> woff, orig, heap, wl;                     // orig: the lattice's own id of a state (ties between equal costs are broken by it); wl: per determinised state, its entries that have word arcs
+  std::vector<int> eoff;
+  std::vector<RArc> earc, warc;
   std::vector<int> labels;
   std::vector<double> fin, beta;
   std::vector<St> st;
@@ -869,37 +877,43 @@ struct DetRescore {
   std::vector<DArc> darc;
   std::vector<int> bp_src, bp_ali, start_ali;
   std::vector<ANode> ali;
-  std::unordered_multimap<uint64_t, int> index;
+  std::vector<uint64_t> ikey; std::vector<int> ival; size_t imask = 0;   // content hash -> determinised state (open addressing; equal hashes sit in successive slots)
   // working subset
   std::vector<Ent> we; std::vector<int> wsrc, wali, pop_perm;
+  // set-up scratch
+  std::vector<int> roff, indeg, rarc, coff, po, pending, order, rank;
+  std::vector<char> keep;
+  std::vector<RArc> carc;
+  std::vector<double> fin_raw;
 
   bool setup(int n, int start, int n_arcs, const int32_t* src, const int32_t* dst, const int32_t* il, const int32_t* ol, const float* gr,
              const float* ac, int n_final, const int32_t* fs, const float* fc) {
-    n_states = n;
-    fin.assign((size_t)n, INFINITY); beta.assign((size_t)n, INFINITY);
-    for (int i = 0; i < n_final; ++i) fin[(size_t)fs[i]] = std::min(fin[(size_t)fs[i]], (double)fc[i]);
+    fin_raw.assign((size_t)n, INFINITY);
+    for (int i = 0; i < n_final; ++i) fin_raw[(size_t)fs[i]] = std::min(fin_raw[(size_t)fs[i]], (double)fc[i]);
+    const auto T0 = std::chrono::steady_clock::now();
     // raw adjacency
-    std::vector<int> roff((size_t)n + 1, 0), indeg((size_t)n, 0);
+    roff.assign((size_t)n + 1, 0); indeg.assign((size_t)n, 0);
     for (int i = 0; i < n_arcs; ++i) { ++roff[(size_t)src[i] + 1]; ++indeg[(size_t)dst[i]]; }
     for (int s = 0; s < n; ++s) roff[(size_t)s + 1] += roff[s];
-    std::vector<int> rarc((size_t)n_arcs);
-    { std::vector<int> po(roff.begin(), roff.end() - 1); for (int i = 0; i < n_arcs; ++i) rarc[(size_t)po[src[i]]++] = i; }
+    rarc.resize((size_t)n_arcs);
+    { po.assign(roff.begin(), roff.end() - 1); for (int i = 0; i < n_arcs; ++i) rarc[(size_t)po[src[i]]++] = i; }
+    const auto T1 = std::chrono::steady_clock::now();
     // Chain contraction: a state with ONE incoming arc and ONE outgoing arc whose output is epsilon (a token that merely lives on
     // through a frame) is absorbed into its incoming arc -- labels concatenated, costs added.  The token lattice is mostly such
     // chains (2.1 arcs per state); the epsilon closures of the subset construction then walk a third of the states.
-    auto link = [&](int v) { return v != start && indeg[(size_t)v] == 1 && roff[(size_t)v + 1] - roff[v] == 1 && fin[(size_t)v] == INFINITY && ol[rarc[(size_t)roff[v]]] == 0; };
-    off.assign((size_t)n + 1, 0);
-    std::vector<char> keep((size_t)n, 0);
+    auto link = [&](int v) { return v != start && roff[(size_t)v + 1] - roff[v] == 1 && fin_raw[(size_t)v] == INFINITY && ol[rarc[(size_t)roff[v]]] == 0; };
+    coff.assign((size_t)n + 1, 0);
+    keep.assign((size_t)n, 0);
     for (int v = 0; v < n; ++v) keep[(size_t)v] = !link(v);
-    for (int i = 0; i < n_arcs; ++i) if (keep[(size_t)src[i]]) ++off[(size_t)src[i] + 1];
-    for (int s = 0; s < n; ++s) off[(size_t)s + 1] += off[s];
-    arc.resize((size_t)off[(size_t)n]);
+    for (int i = 0; i < n_arcs; ++i) if (keep[(size_t)src[i]]) ++coff[(size_t)src[i] + 1];
+    for (int s = 0; s < n; ++s) coff[(size_t)s + 1] += coff[s];
+    carc.resize((size_t)coff[(size_t)n]);
     labels.clear();
-    std::vector<int> pending((size_t)n, 0);
+    pending.assign((size_t)n, 0);
     {
-      std::vector<int> po(off.begin(), off.end() - 1);
       for (int u = 0; u < n; ++u) {
         if (!keep[(size_t)u]) continue;
+        int w = coff[u];
         for (int k = roff[u]; k < roff[(size_t)u + 1]; ++k) {
           int i = rarc[(size_t)k];
           RArc x{(int)labels.size(), 0, ol[i], dst[i], (double)gr[i], (double)ac[i]};
@@ -912,27 +926,61 @@ struct DetRescore {
           }
           if (!keep[(size_t)x.dst]) return false;                             // a cycle of chain links
           x.nlab = (int)labels.size() - x.lab;
-          arc[(size_t)po[u]++] = x;
+          carc[(size_t)w++] = x;
           ++pending[(size_t)x.dst];
         }
       }
     }
+    const auto T2 = std::chrono::steady_clock::now();
     order.clear(); rank.assign((size_t)n, -1);
-    int n_kept = 0;
+    n_kept = 0;
     for (int s = 0; s < n; ++s) if (keep[(size_t)s]) { ++n_kept; if (!pending[(size_t)s]) order.push_back(s); }
     for (size_t h = 0; h < order.size(); ++h) {
       const int s = order[h]; rank[(size_t)s] = (int)h;
-      for (int k = off[s]; k < off[(size_t)s + 1]; ++k) if (--pending[(size_t)arc[(size_t)k].dst] == 0) order.push_back(arc[(size_t)k].dst);
+      for (int k = coff[s]; k < coff[(size_t)s + 1]; ++k) if (--pending[(size_t)carc[(size_t)k].dst] == 0) order.push_back(carc[(size_t)k].dst);
     }
     if ((int)order.size() != n_kept) return false;                 // a cycle: the caller falls back to the raw composition
-    for (int h = n_kept - 1; h >= 0; --h) {
-      const int s = order[(size_t)h];
-      double b = fin[(size_t)s];
-      for (int k = off[s]; k < off[(size_t)s + 1]; ++k) b = std::min(b, beta[(size_t)arc[(size_t)k].dst] + (arc[(size_t)k].g + arc[(size_t)k].a));
-      beta[(size_t)s] = b;
+    const auto T3 = std::chrono::steady_clock::now();
+    // the renumbered form: state = rank; a state's arcs keep their order within each of the two classes
+    const size_t nk = (size_t)n_kept;
+    eoff.assign(nk + 1, 0); woff.assign(nk + 1, 0);
+    orig.assign(order.begin(), order.end());
+    fin.resize(nk); beta.resize(nk);
+    for (size_t r = 0; r < nk; ++r) {
+      const int s = order[r];
+      fin[r] = fin_raw[(size_t)s];
+      int ne = 0, nw = 0;
+      for (int k = coff[s]; k < coff[(size_t)s + 1]; ++k) { if (carc[(size_t)k].ol == 0) ++ne; else ++nw; }
+      eoff[r + 1] = eoff[r] + ne; woff[r + 1] = woff[r] + nw;
     }
-    slot.assign((size_t)n, -1);
-    return true;
+    earc.resize((size_t)eoff[nk]); warc.resize((size_t)woff[nk]);
+    for (size_t r = 0; r < nk; ++r) {
+      const int s = order[r];
+      int pe = eoff[r], pw = woff[r];
+      for (int k = coff[s]; k < coff[(size_t)s + 1]; ++k) {
+        RArc x = carc[(size_t)k];
+        x.dst = rank[(size_t)x.dst];
+        if (x.ol == 0) earc[(size_t)pe++] = x; else warc[(size_t)pw++] = x;
+      }
+    }
+    const auto T4 = std::chrono::steady_clock::now();
+    for (size_t h = nk; h-- > 0;) {
+      double b = fin[h];
+      for (int k = eoff[h]; k < eoff[h + 1]; ++k) b = std::min(b, beta[(size_t)earc[(size_t)k].dst] + (earc[(size_t)k].g + earc[(size_t)k].a));
+      for (int k = woff[h]; k < woff[h + 1]; ++k) b = std::min(b, beta[(size_t)warc[(size_t)k].dst] + (warc[(size_t)k].g + warc[(size_t)k].a));
+      beta[h] = b;
+    }
+    const auto T5 = std::chrono::steady_clock::now();
+    si.resize(nk + 1);
+    for (size_t r = 0; r <= nk; ++r) si[r] = SInfo{r < nk ? beta[r] : INFINITY, -1, eoff[r]};
+    start_r = rank[(size_t)start];
+    st.clear(); ent.clear(); wl.clear(); darc.clear(); bp_src.clear(); bp_ali.clear(); start_ali.clear(); ali.clear();
+    if (ikey.size() < 4096) { ikey.resize(4096); ival.resize(4096); }
+    std::fill(ikey.begin(), ikey.end(), 0ull); imask = ikey.size() - 1;
+    t_gather = t_closure = t_intern = 0; n_closure_states = n_entries_expanded = 0;
+    if (getenv("B2T_LAT_TIMING")) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      fprintf(stderr, "det setup: adjacency %.2f, contraction %.2f, kahn %.2f, renumber %.2f, beta %.2f, clear %.2f ms (%d kept states, %zu + %zu arcs)\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), ms(T3, T4), ms(T4, T5), ms(T5, std::chrono::steady_clock::now()), n_kept, earc.size(), warc.size()); }
+    return start_r >= 0;
   }
   int push_ali(int parent, const RArc& x) {                      // the arc's input labels behind `parent`
     for (int k = 0; k < x.nlab; ++k) { ali.push_back(ANode{parent, labels[(size_t)x.lab + (size_t)k]}); parent = (int)ali.size() - 1; }
@@ -940,84 +988,101 @@ struct DetRescore {
   }
 
   // epsilon-output closure of the working subset (states marked in `slot`), in topological order; `base` = forward cost of the
-  // subset's reference point (for the beam), costs in `we` are relative to it
+  // subset's reference point (for the beam), costs in `we` are relative to it.  `heap` is the pending states in DESCENDING order:
+  // the next state is its back, and a state reached by an epsilon arc lies a frame or two ahead of the one being expanded, i.e.
+  // near the back -- an insertion moves a handful of elements where a binary heap sifted through log n levels on every pop.
   void closure(double base, double limit) {
     heap.clear(); pop_perm.clear();
-    for (const Ent& e : we) heap.push_back(rank[(size_t)e.s]);
-    std::make_heap(heap.begin(), heap.end(), std::greater<int>());
+    for (const Ent& e : we) heap.push_back(e.s);
+    std::sort(heap.begin(), heap.end(), std::greater<int>());
     while (!heap.empty()) {
-      std::pop_heap(heap.begin(), heap.end(), std::greater<int>());
-      const int s = order[(size_t)heap.back()]; heap.pop_back();
-      const int i = slot[(size_t)s];
+      const int s = heap.back(); heap.pop_back();
+      const int i = si[(size_t)s].slot;
       pop_perm.push_back(i);                                     // topological order = the canonical order of a stored state's entries
       const Ent e = we[(size_t)i]; const int esrc = wsrc[(size_t)i], eali = wali[(size_t)i];
-      for (int k = off[s]; k < off[(size_t)s + 1]; ++k) {
-        const RArc& a = arc[(size_t)k];
-        if (a.ol != 0) continue;
+      for (int k = si[(size_t)s].eoff, k1 = si[(size_t)s + 1].eoff; k < k1; ++k) {
+        const RArc& a = earc[(size_t)k];
         const double nt = e.tot + a.g + a.a;
-        if (base + nt + beta[(size_t)a.dst] > limit) continue;
-        const int j = slot[(size_t)a.dst];
+        SInfo& sd = si[(size_t)a.dst];
+        if (base + nt + sd.beta > limit) continue;
+        const int j = sd.slot;
         if (j >= 0 && !(nt < we[(size_t)j].tot)) continue;
         const Ent ne{a.dst, nt, e.gr + a.g, e.ac + a.a};
         const int na = a.nlab ? push_ali(eali, a) : eali;
         if (j < 0) {
-          slot[(size_t)a.dst] = (int)we.size(); we.push_back(ne); wsrc.push_back(esrc); wali.push_back(na);
-          heap.push_back(rank[(size_t)a.dst]); std::push_heap(heap.begin(), heap.end(), std::greater<int>());
+          sd.slot = (int)we.size(); we.push_back(ne); wsrc.push_back(esrc); wali.push_back(na);
+          __builtin_prefetch(&earc[(size_t)sd.eoff]);
+          size_t p = heap.size(); heap.push_back(a.dst);
+          while (p > 0 && heap[p - 1] < a.dst) { heap[p] = heap[p - 1]; --p; }
+          heap[p] = a.dst;
         } else { we[(size_t)j] = ne; wsrc[(size_t)j] = esrc; wali[(size_t)j] = na; }
       }
     }
   }
+  void index_grow() {
+    std::vector<uint64_t> k2(ikey.size() * 2, 0ull); std::vector<int> v2(ikey.size() * 2, -1);
+    const size_t m2 = k2.size() - 1;
+    for (size_t i = 0; i < ikey.size(); ++i)
+      if (ikey[i]) { size_t p = (size_t)(ikey[i] ^ (ikey[i] >> 29)) & m2; while (k2[p]) p = (p + 1) & m2; k2[p] = ikey[i]; v2[p] = ival[i]; }
+    ikey.swap(k2); ival.swap(v2); imask = m2;
+  }
   // normalise the working subset, sort it by lattice state, intern it.  Returns the state id; the offset taken out in (t, g, a);
   // the permutation applied in `perm` (position in the stored state -> position in the working subset).
   int intern(double& t, double& g, double& a, std::vector<int>& perm, double alpha_via) {
-    for (const Ent& e : we) slot[(size_t)e.s] = -1;
+    for (const Ent& e : we) si[(size_t)e.s].slot = -1;
     perm = pop_perm;                                               // (the closure popped every state exactly once, in topological order)
     size_t b = 0;
     for (size_t i = 1; i < we.size(); ++i)
-      if (we[i].tot < we[b].tot || (we[i].tot == we[b].tot && we[i].s < we[b].s)) b = i;
+      if (we[i].tot < we[b].tot || (we[i].tot == we[b].tot && orig[(size_t)we[i].s] < orig[(size_t)we[b].s])) b = i;
     t = we[b].tot; g = we[b].gr; a = we[b].ac;
     uint64_t h = 1469598103934665603ull;
-    int minrank = 0x7fffffff;
     for (int p : perm) {
       Ent& e = we[(size_t)p];
       e.tot -= t; e.gr -= g; e.ac -= a;
       const float rt = (float)e.tot, rg = (float)e.gr;
       uint32_t b1, b2; memcpy(&b1, &rt, 4); memcpy(&b2, &rg, 4);
       h = (h ^ (uint64_t)(uint32_t)e.s) * 1099511628211ull; h = (h ^ b1) * 1099511628211ull; h = (h ^ b2) * 1099511628211ull;
-      minrank = std::min(minrank, rank[(size_t)e.s]);
     }
-    auto rng = index.equal_range(h);
-    for (auto it = rng.first; it != rng.second; ++it) {
-      St& r = st[(size_t)it->second];
+    const int minrank = we[(size_t)perm[0]].s;                    // the first state popped
+    h |= 1ull;                                                     // 0 marks an empty slot
+    size_t p = (size_t)(h ^ (h >> 29)) & imask;
+    for (; ikey[p]; p = (p + 1) & imask) {
+      if (ikey[p] != h) continue;
+      St& r = st[(size_t)ival[p]];
       if (r.n != (int)we.size()) continue;
       bool same = true;
       for (int k = 0; k < r.n && same; ++k) {
         const Ent& x = ent[r.off + (size_t)k]; const Ent& y = we[(size_t)perm[(size_t)k]];
         same = x.s == y.s && (float)x.tot == (float)y.tot && (float)x.gr == (float)y.gr;
       }
-      if (same) { r.alpha = std::min(r.alpha, alpha_via + t); return it->second; }
+      if (same) { r.alpha = std::min(r.alpha, alpha_via + t); return ival[p]; }
     }
-    St ns{ent.size(), (int)we.size(), alpha_via + t, minrank, INFINITY, 0.0, 0.0, -1, false};
+    St ns{ent.size(), (int)we.size(), alpha_via + t, minrank, INFINITY, 0.0, 0.0, -1, false, wl.size(), 0};
     for (size_t k = 0; k < perm.size(); ++k) {
       const Ent& e = we[(size_t)perm[k]];
       ent.push_back(e);
+      if (woff[(size_t)e.s + 1] > woff[(size_t)e.s]) { wl.push_back((int)k); ++ns.wl_n; }
       if (fin[(size_t)e.s] != INFINITY) {
         const double c = e.tot + fin[(size_t)e.s];
         if (c < ns.fin_tot) { ns.fin_tot = c; ns.fin_gr = e.gr + fin[(size_t)e.s]; ns.fin_ac = e.ac; ns.fin_ent = (int)k; }
       }
     }
     st.push_back(ns);
-    index.emplace(h, (int)st.size() - 1);
+    ikey[p] = h; ival[p] = (int)st.size() - 1;
+    if (2 * st.size() > imask) index_grow();
     return (int)st.size() - 1;
   }
 
   // the whole determinisation; returns false if the lattice has no path
-  bool run(int start, double beam) {
+  bool run(double beam) {
+    const int start = start_r;
     if (beta[(size_t)start] == INFINITY) return false;
     const double limit = beta[(size_t)start] + beam + 1e-4;
+    static const bool timing = getenv("B2T_LAT_TIMING") != nullptr;
+    typedef std::chrono::steady_clock clk;
     std::vector<int> perm;
     we.assign(1, Ent{start, 0.0, 0.0, 0.0}); wsrc.assign(1, -1); wali.assign(1, -1);
-    slot[(size_t)start] = 0;
+    si[(size_t)start].slot = 0;
     closure(0.0, limit);
     double t, g, a;
     intern(t, g, a, perm, 0.0);                           // state 0; its offset (the start's closure may hold a cheaper entry than the start itself: costs can be negative) is start_off / start_g / start_a
@@ -1033,15 +1098,15 @@ struct DetRescore {
     while (!pq.empty()) {
       const int D = pq.top().second; pq.pop();
       const St sd = st[(size_t)D];
-      const auto tg0 = std::chrono::steady_clock::now();
+      clk::time_point tg0; if (timing) tg0 = clk::now();
       n_entries_expanded += (size_t)sd.n;
       trans.clear();
-      for (int i = 0; i < sd.n; ++i) {
+      for (int wi = 0; wi < sd.wl_n; ++wi) {
+        const int i = wl[sd.wl_off + (size_t)wi];
         const Ent e = ent[sd.off + (size_t)i];
         if (sd.alpha + e.tot + beta[(size_t)e.s] > limit) continue;                 // (a cheaper history may have made it worth keeping: harmless)
-        for (int k = off[e.s]; k < off[(size_t)e.s + 1]; ++k) {
-          const RArc& x = arc[(size_t)k];
-          if (x.ol == 0) continue;
+        for (int k = woff[(size_t)e.s], k1 = woff[(size_t)e.s + 1]; k < k1; ++k) {
+          const RArc& x = warc[(size_t)k];
           const double nt = e.tot + x.g + x.a;
           if (sd.alpha + nt + beta[(size_t)x.dst] > limit) continue;
           trans.push_back(Tr{x.ol, x.dst, i, k, nt, e.gr + x.g, e.ac + x.a});
@@ -1050,34 +1115,30 @@ struct DetRescore {
       keyed.resize(trans.size());
       for (size_t q = 0; q < trans.size(); ++q) keyed[q] = {((uint64_t)(uint32_t)trans[q].ol << 32) | (uint64_t)q, (int)q};
       std::sort(keyed.begin(), keyed.end());
-      t_gather += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count();
+      if (timing) t_gather += std::chrono::duration<double, std::milli>(clk::now() - tg0).count();
       for (size_t g0 = 0; g0 < keyed.size();) {
         size_t g1 = g0;
         const int ol = trans[(size_t)keyed[g0].second].ol;
         while (g1 < keyed.size() && trans[(size_t)keyed[g1].second].ol == ol) ++g1;
-        const auto tc0 = std::chrono::steady_clock::now();
+        clk::time_point tc0, tc1; if (timing) tc0 = clk::now();
         we.clear(); wsrc.clear(); wali.clear();
         for (size_t q = g0; q < g1; ++q) {
           const Tr& tr = trans[(size_t)keyed[q].second];
-          const int j = slot[(size_t)tr.dst];
+          const int j = si[(size_t)tr.dst].slot;
           if (j >= 0 && !(tr.tot < we[(size_t)j].tot)) continue;
           const Ent ne{tr.dst, tr.tot, tr.gr, tr.ac};
-          const int na = arc[(size_t)tr.karc].nlab ? push_ali(-1, arc[(size_t)tr.karc]) : -1;
-          if (j < 0) { slot[(size_t)tr.dst] = (int)we.size(); we.push_back(ne); wsrc.push_back(tr.src_ent); wali.push_back(na); }
+          const int na = warc[(size_t)tr.karc].nlab ? push_ali(-1, warc[(size_t)tr.karc]) : -1;
+          if (j < 0) { si[(size_t)tr.dst].slot = (int)we.size(); we.push_back(ne); wsrc.push_back(tr.src_ent); wali.push_back(na); }
           else { we[(size_t)j] = ne; wsrc[(size_t)j] = tr.src_ent; wali[(size_t)j] = na; }
         }
         closure(sd.alpha, limit);
-        const auto tc1 = std::chrono::steady_clock::now();
+        if (timing) tc1 = clk::now();
         n_closure_states += we.size();
-        const size_t before = st.size();
         const int T = intern(t, g, a, perm, sd.alpha);
-        t_closure += std::chrono::duration<double, std::milli>(tc1 - tc0).count();
-        t_intern += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count();
+        if (timing) { t_closure += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); t_intern += std::chrono::duration<double, std::milli>(clk::now() - tc1).count(); }
         darc.push_back(DArc{D, T, ol, t, g, a, bp_src.size()});
         for (size_t k = 0; k < perm.size(); ++k) { bp_src.push_back(wsrc[(size_t)perm[k]]); bp_ali.push_back(wali[(size_t)perm[k]]); }
-        if (st.size() > before || !st[(size_t)T].queued) {
-          if (!st[(size_t)T].queued) { st[(size_t)T].queued = true; pq.push({st[(size_t)T].minrank, T}); }
-        }
+        if (!st[(size_t)T].queued) { st[(size_t)T].queued = true; pq.push({st[(size_t)T].minrank, T}); }
         g0 = g1;
       }
     }
@@ -1102,10 +1163,10 @@ static int rescore_on_determinised(int n_states, int start, int n_arcs, const in
     if (src[i] < 0 || src[i] >= n_states || dst[i] < 0 || dst[i] >= n_states) { set_error("lattice_rescore: arc %d out of range", i); return -1; }
   for (int i = 0; i < n_final; ++i)
     if (final_state[i] < 0 || final_state[i] >= n_states) { set_error("lattice_rescore: final state %d out of range", i); return -1; }
-  DetRescore dr;
+  static thread_local DetRescore dr;                      // (vectors reused from call to call: see the struct's comment)
   if (!dr.setup(n_states, start, n_arcs, src, dst, ilabel, olabel, graph, acoustic, n_final, final_state, final_cost)) { *fell_back = true; return 0; }
   w_off[0] = 0; a_off[0] = 0;
-  if (!dr.run(start, (double)beam)) { if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0; return 0; }
+  if (!dr.run((double)beam)) { if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0; return 0; }
   const auto t_det = std::chrono::steady_clock::now();
   LmDet Lo(*CFST(g_old), backoff_label), Ln(*CFST(g_new), backoff_label);
   // determinised-lattice adjacency
