@@ -1164,6 +1164,7 @@ static int rescore_on_determinised(int n_states, int start, int n_arcs, const in
   for (int i = 0; i < n_final; ++i)
     if (final_state[i] < 0 || final_state[i] >= n_states) { set_error("lattice_rescore: final state %d out of range", i); return -1; }
   static thread_local DetRescore dr;                      // (vectors reused from call to call: see the struct's comment)
+  struct Trim { DetRescore& d; ~Trim() { if (d.ent.capacity() * sizeof(DetRescore::Ent) + d.ali.capacity() * sizeof(DetRescore::ANode) > ((size_t)256 << 20)) d = DetRescore(); } } trim{dr};   // an outsized lattice does not pin its arrays to the thread
   if (!dr.setup(n_states, start, n_arcs, src, dst, ilabel, olabel, graph, acoustic, n_final, final_state, final_cost)) { *fell_back = true; return 0; }
   w_off[0] = 0; a_off[0] = 0;
   if (!dr.run((double)beam)) { if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0; return 0; }

@@ -24,7 +24,7 @@ import b2t_native as N      # noqa: E402
 import b2t_ops as ops       # noqa: E402
 import ngram_lm             # noqa: E402
 import wfst                 # noqa: E402
-from wfst_decoder import WfstSearch   # noqa: E402
+from wfst_decoder import WfstSearch, _pool_threads   # noqa: E402
 import lm_decoder           # noqa: E402
 
 
@@ -274,12 +274,16 @@ def run():
         G_new = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(words, 4, 6000, seed=77), word_id, wd0)).arcsort()
         t0 = time.perf_counter(); first = S._nbest_all(100); t1 = time.perf_counter()
         resc = S._nbest_all(100, rescore=(G_old, G_new, wd0)); t2 = time.perf_counter()
+        again = []                                 # the same call twice more: the pool's threads keep their work arrays (graphc.cpp, DetRescore)
+        for _ in range(2):
+            ta = time.perf_counter(); S._nbest_all(100, rescore=(G_old, G_new, wd0)); again.append(time.perf_counter() - ta)
         changed = sum(1 for a, b in zip(first, resc) if a and b and a[0][2] != b[0][2])
         promoted = 0
         for a, b in zip(first, resc):
             seen = set(tuple(e[2]) for e in a)
             promoted += sum(1 for e in b[:10] if tuple(e[2]) not in seen)
         rescore = dict(nbest100_ms_32_utterances=round((t1 - t0) * 1e3, 2), rescore_nbest100_ms_32_utterances=round((t2 - t1) * 1e3, 2),
+                       rescore_nbest100_ms_32_utterances_repeated=[round(x * 1e3, 2) for x in again], host_pool_threads=_pool_threads(),
                        utterances_whose_1best_changed=changed, top10_entries_from_below_the_first_100=promoted,
                        grammars="word 3-gram (in the graph) -> word 4-gram, 6000 n-grams per order")
     except Exception as e:     # noqa: BLE001
