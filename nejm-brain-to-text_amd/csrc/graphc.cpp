@@ -982,9 +982,16 @@ struct DetRescore {
       fprintf(stderr, "det setup: adjacency %.2f, contraction %.2f, kahn %.2f, renumber %.2f, beta %.2f, clear %.2f ms (%d kept states, %zu + %zu arcs)\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), ms(T3, T4), ms(T4, T5), ms(T5, std::chrono::steady_clock::now()), n_kept, earc.size(), warc.size()); }
     return start_r >= 0;
   }
-  int push_ali(int parent, const RArc& x) {                      // the arc's input labels behind `parent`
-    for (int k = 0; k < x.nlab; ++k) { ali.push_back(ANode{parent, labels[(size_t)x.lab + (size_t)k]}); parent = (int)ali.size() - 1; }
-    return parent;
+  // An alignment node stands for ONE arc behind `parent`: `label` is the arc's index in earc, or ~index in warc; its input labels
+  // (labels[lab .. lab + nlab)) are spelled out only when a hypothesis is read back (a node per label was 2-3x the nodes, written
+  // on every relaxation, for the 100 paths that are ever read).
+  int push_ali(int parent, int arc_ref) { ali.push_back(ANode{parent, arc_ref}); return (int)ali.size() - 1; }
+  void read_ali(int n, std::vector<int>& out_rev) const {        // appends the labels from node n back to the chain's head, LAST label first
+    for (; n >= 0; n = ali[(size_t)n].parent) {
+      const int r = ali[(size_t)n].label;
+      const RArc& x = r >= 0 ? earc[(size_t)r] : warc[(size_t)~r];
+      for (int k = x.nlab - 1; k >= 0; --k) out_rev.push_back(labels[(size_t)x.lab + (size_t)k]);
+    }
   }
 
   // epsilon-output closure of the working subset (states marked in `slot`), in topological order; `base` = forward cost of the
@@ -1008,7 +1015,7 @@ struct DetRescore {
         const int j = sd.slot;
         if (j >= 0 && !(nt < we[(size_t)j].tot)) continue;
         const Ent ne{a.dst, nt, e.gr + a.g, e.ac + a.a};
-        const int na = a.nlab ? push_ali(eali, a) : eali;
+        const int na = a.nlab ? push_ali(eali, k) : eali;
         if (j < 0) {
           sd.slot = (int)we.size(); we.push_back(ne); wsrc.push_back(esrc); wali.push_back(na);
           __builtin_prefetch(&earc[(size_t)sd.eoff]);
@@ -1127,7 +1134,7 @@ struct DetRescore {
           const int j = si[(size_t)tr.dst].slot;
           if (j >= 0 && !(tr.tot < we[(size_t)j].tot)) continue;
           const Ent ne{tr.dst, tr.tot, tr.gr, tr.ac};
-          const int na = warc[(size_t)tr.karc].nlab ? push_ali(-1, warc[(size_t)tr.karc]) : -1;
+          const int na = warc[(size_t)tr.karc].nlab ? push_ali(-1, ~tr.karc) : -1;
           if (j < 0) { si[(size_t)tr.dst].slot = (int)we.size(); we.push_back(ne); wsrc.push_back(tr.src_ent); wali.push_back(na); }
           else { we[(size_t)j] = ne; wsrc[(size_t)j] = tr.src_ent; wali[(size_t)j] = na; }
         }
@@ -1267,10 +1274,10 @@ static int rescore_on_determinised(int n_states, int start, int n_arcs, const in
           const auto& da = dr.darc[(size_t)x.darc];
           wv.push_back(da.word);
           gr += da.gr + x.dl; ac += da.ac;
-          for (int n = dr.bp_ali[da.bp + (size_t)e]; n >= 0; n = dr.ali[(size_t)n].parent) av.push_back(dr.ali[(size_t)n].label);
+          dr.read_ali(dr.bp_ali[da.bp + (size_t)e], av);
           e = dr.bp_src[da.bp + (size_t)e];
         }
-        for (int n = dr.start_ali[(size_t)e]; n >= 0; n = dr.ali[(size_t)n].parent) av.push_back(dr.ali[(size_t)n].label);
+        dr.read_ali(dr.start_ali[(size_t)e], av);
         gr += dr.start_g; ac += dr.start_a;
         if (w_off[n_out] + (int)wv.size() > w_cap || a_off[n_out] + (int)av.size() > a_cap) { set_error("lattice_rescore: output buffers too small"); return -2; }
         std::reverse(wv.begin(), wv.end()); std::reverse(av.begin(), av.end());
