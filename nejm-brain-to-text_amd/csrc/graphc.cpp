@@ -848,8 +848,9 @@ int b2t_lattice_nbest_core(int n_states, int start, int n_arcs, const int32_t* s
 // predecessor has been expanded and a state's forward cost is final when it is popped; (2) the determinised word lattice x both
 // lazily determinised grammars (LmDet): a DETERMINISTIC product, every path a distinct word sequence; (3) its paths in order of
 // the NEW cost (best-first over partial paths with the exact backward cost as bound) among those within the beam on the OLD cost.
-// Alignments: a determinised arc keeps, per entry of its target, the entry of its source it came from and the input labels on
-// the way; a hypothesis' alignment is read back from its final entry.
+// Alignments: per entry of a determinised arc's target, the entry of its source it came from and the input labels on the way --
+// computed only for the arcs an answer passes through (DetRescore::trace repeats such an arc's closure with the tracking on: round 5);
+// a hypothesis' alignment is read back from its final entry.
 namespace b2t {
 namespace {
 
@@ -862,7 +863,7 @@ struct DetRescore {
   struct RArc { int lab, nlab, ol, dst; double g, a; };      // lab / nlab: its input labels (non-epsilon) in `labels`: chains of single-entry single-exit states are contracted into one arc
   struct Ent { int s; double tot, gr, ac; };
   struct St { size_t off; int n; double alpha; int minrank; double fin_tot, fin_gr, fin_ac; int fin_ent; bool queued; size_t wl_off; int wl_n; };
-  struct DArc { int src, dst, word; double tot, gr, ac; size_t bp; };
+  struct DArc { int src, dst, word; double tot, gr, ac; };
   struct ANode { int parent, label; };
   int n_kept = 0, start_r = -1;
   struct SInfo { double beta; int slot, eoff; };             // what a closure needs of a state, in one 16-byte record (slot: its index in the working subset, -1 = absent)
@@ -875,7 +876,9 @@ struct DetRescore {
   std::vector<St> st;
   std::vector<Ent> ent;
   std::vector<DArc> darc;
-  std::vector<int> bp_src, bp_ali, start_ali;
+  std::vector<int> tr_src, tr_ali, start_ali;                // back pointers of the traced arcs (trace()), of the start state's entries
+  std::vector<size_t> tr_off;
+  double limit = 0;
   std::vector<ANode> ali;
   std::vector<uint64_t> ikey; std::vector<int> ival; size_t imask = 0;   // content hash -> determinised state (open addressing; equal hashes sit in successive slots)
   // working subset
@@ -974,7 +977,7 @@ struct DetRescore {
     si.resize(nk + 1);
     for (size_t r = 0; r <= nk; ++r) si[r] = SInfo{r < nk ? beta[r] : INFINITY, -1, eoff[r]};
     start_r = rank[(size_t)start];
-    st.clear(); ent.clear(); wl.clear(); darc.clear(); bp_src.clear(); bp_ali.clear(); start_ali.clear(); ali.clear();
+    st.clear(); ent.clear(); wl.clear(); darc.clear(); tr_src.clear(); tr_ali.clear(); tr_off.clear(); start_ali.clear(); ali.clear();
     if (ikey.size() < 4096) { ikey.resize(4096); ival.resize(4096); }
     std::fill(ikey.begin(), ikey.end(), 0ull); imask = ikey.size() - 1;
     t_gather = t_closure = t_intern = 0; n_closure_states = n_entries_expanded = 0;
@@ -998,7 +1001,9 @@ struct DetRescore {
   // subset's reference point (for the beam), costs in `we` are relative to it.  `heap` is the pending states in DESCENDING order:
   // the next state is its back, and a state reached by an epsilon arc lies a frame or two ahead of the one being expanded, i.e.
   // near the back -- an insertion moves a handful of elements where a binary heap sifted through log n levels on every pop.
-  void closure(double base, double limit) {
+  // TRACK: also where each entry came from (wsrc: the seed's source entry; wali: its alignment chain).  The determinisation runs
+  // without (a third of what a relaxation writes); trace() below repeats the closure of the few arcs an answer passes through.
+  template <bool TRACK> void closure(double base) {
     heap.clear(); pop_perm.clear();
     for (const Ent& e : we) heap.push_back(e.s);
     std::sort(heap.begin(), heap.end(), std::greater<int>());
@@ -1006,7 +1011,7 @@ struct DetRescore {
       const int s = heap.back(); heap.pop_back();
       const int i = si[(size_t)s].slot;
       pop_perm.push_back(i);                                     // topological order = the canonical order of a stored state's entries
-      const Ent e = we[(size_t)i]; const int esrc = wsrc[(size_t)i], eali = wali[(size_t)i];
+      const Ent e = we[(size_t)i]; const int esrc = TRACK ? wsrc[(size_t)i] : -1, eali = TRACK ? wali[(size_t)i] : -1;
       for (int k = si[(size_t)s].eoff, k1 = si[(size_t)s + 1].eoff; k < k1; ++k) {
         const RArc& a = earc[(size_t)k];
         const double nt = e.tot + a.g + a.a;
@@ -1015,16 +1020,49 @@ struct DetRescore {
         const int j = sd.slot;
         if (j >= 0 && !(nt < we[(size_t)j].tot)) continue;
         const Ent ne{a.dst, nt, e.gr + a.g, e.ac + a.a};
-        const int na = a.nlab ? push_ali(eali, k) : eali;
+        const int na = TRACK && a.nlab ? push_ali(eali, k) : eali;
         if (j < 0) {
-          sd.slot = (int)we.size(); we.push_back(ne); wsrc.push_back(esrc); wali.push_back(na);
+          sd.slot = (int)we.size(); we.push_back(ne);
+          if (TRACK) { wsrc.push_back(esrc); wali.push_back(na); }
           __builtin_prefetch(&earc[(size_t)sd.eoff]);
           size_t p = heap.size(); heap.push_back(a.dst);
           while (p > 0 && heap[p - 1] < a.dst) { heap[p] = heap[p - 1]; --p; }
           heap[p] = a.dst;
-        } else { we[(size_t)j] = ne; wsrc[(size_t)j] = esrc; wali[(size_t)j] = na; }
+        } else { we[(size_t)j] = ne; if (TRACK) { wsrc[(size_t)j] = esrc; wali[(size_t)j] = na; } }
       }
     }
+  }
+  // Back pointers of determinised arc `id` (per entry of its target, in the stored order: the source state's entry it came from
+  // and its alignment chain), computed on demand: the arc's seeds are gathered and closed again exactly as run() did it -- same
+  // entries in the same order, the source's forward cost is final since it was expanded -- this time with the tracking on.
+  size_t trace(int id) {
+    if (tr_off.size() != darc.size()) tr_off.assign(darc.size(), (size_t)-1);
+    if (tr_off[(size_t)id] != (size_t)-1) return tr_off[(size_t)id];
+    const DArc& da = darc[(size_t)id];
+    const St sd = st[(size_t)da.src];
+    we.clear(); wsrc.clear(); wali.clear();
+    for (int wi = 0; wi < sd.wl_n; ++wi) {
+      const int i = wl[sd.wl_off + (size_t)wi];
+      const Ent e = ent[sd.off + (size_t)i];
+      if (sd.alpha + e.tot + beta[(size_t)e.s] > limit) continue;
+      for (int k = woff[(size_t)e.s], k1 = woff[(size_t)e.s + 1]; k < k1; ++k) {
+        const RArc& x = warc[(size_t)k];
+        if (x.ol != da.word) continue;
+        const double nt = e.tot + x.g + x.a;
+        if (sd.alpha + nt + beta[(size_t)x.dst] > limit) continue;
+        const int j = si[(size_t)x.dst].slot;
+        if (j >= 0 && !(nt < we[(size_t)j].tot)) continue;
+        const Ent ne{x.dst, nt, e.gr + x.g, e.ac + x.a};
+        const int na = x.nlab ? push_ali(-1, ~k) : -1;
+        if (j < 0) { si[(size_t)x.dst].slot = (int)we.size(); we.push_back(ne); wsrc.push_back(i); wali.push_back(na); }
+        else { we[(size_t)j] = ne; wsrc[(size_t)j] = i; wali[(size_t)j] = na; }
+      }
+    }
+    closure<true>(sd.alpha);
+    for (const Ent& e : we) si[(size_t)e.s].slot = -1;
+    const size_t off = tr_src.size();
+    for (int p : pop_perm) { tr_src.push_back(wsrc[(size_t)p]); tr_ali.push_back(wali[(size_t)p]); }
+    return tr_off[(size_t)id] = off;
   }
   void index_grow() {
     std::vector<uint64_t> k2(ikey.size() * 2, 0ull); std::vector<int> v2(ikey.size() * 2, -1);
@@ -1084,13 +1122,13 @@ struct DetRescore {
   bool run(double beam) {
     const int start = start_r;
     if (beta[(size_t)start] == INFINITY) return false;
-    const double limit = beta[(size_t)start] + beam + 1e-4;
+    limit = beta[(size_t)start] + beam + 1e-4;
     static const bool timing = getenv("B2T_LAT_TIMING") != nullptr;
     typedef std::chrono::steady_clock clk;
     std::vector<int> perm;
     we.assign(1, Ent{start, 0.0, 0.0, 0.0}); wsrc.assign(1, -1); wali.assign(1, -1);
     si[(size_t)start].slot = 0;
-    closure(0.0, limit);
+    closure<true>(0.0);
     double t, g, a;
     intern(t, g, a, perm, 0.0);                           // state 0; its offset (the start's closure may hold a cheaper entry than the start itself: costs can be negative) is start_off / start_g / start_a
     start_ali.resize(perm.size());
@@ -1099,7 +1137,7 @@ struct DetRescore {
     typedef std::pair<int, int> QI;                        // (earliest lattice state, determinised state)
     std::priority_queue<QI, std::vector<QI>, std::greater<QI>> pq;
     pq.push({st[0].minrank, 0}); st[0].queued = true;
-    struct Tr { int ol, dst, src_ent, karc; double tot, gr, ac; };
+    struct Tr { int ol, dst; double tot, gr, ac; };
     std::vector<Tr> trans;
     std::vector<std::pair<uint64_t, int>> keyed;
     while (!pq.empty()) {
@@ -1116,7 +1154,7 @@ struct DetRescore {
           const RArc& x = warc[(size_t)k];
           const double nt = e.tot + x.g + x.a;
           if (sd.alpha + nt + beta[(size_t)x.dst] > limit) continue;
-          trans.push_back(Tr{x.ol, x.dst, i, k, nt, e.gr + x.g, e.ac + x.a});
+          trans.push_back(Tr{x.ol, x.dst, nt, e.gr + x.g, e.ac + x.a});
         }
       }
       keyed.resize(trans.size());
@@ -1128,23 +1166,21 @@ struct DetRescore {
         const int ol = trans[(size_t)keyed[g0].second].ol;
         while (g1 < keyed.size() && trans[(size_t)keyed[g1].second].ol == ol) ++g1;
         clk::time_point tc0, tc1; if (timing) tc0 = clk::now();
-        we.clear(); wsrc.clear(); wali.clear();
+        we.clear();
         for (size_t q = g0; q < g1; ++q) {
           const Tr& tr = trans[(size_t)keyed[q].second];
           const int j = si[(size_t)tr.dst].slot;
           if (j >= 0 && !(tr.tot < we[(size_t)j].tot)) continue;
           const Ent ne{tr.dst, tr.tot, tr.gr, tr.ac};
-          const int na = warc[(size_t)tr.karc].nlab ? push_ali(-1, ~tr.karc) : -1;
-          if (j < 0) { si[(size_t)tr.dst].slot = (int)we.size(); we.push_back(ne); wsrc.push_back(tr.src_ent); wali.push_back(na); }
-          else { we[(size_t)j] = ne; wsrc[(size_t)j] = tr.src_ent; wali[(size_t)j] = na; }
+          if (j < 0) { si[(size_t)tr.dst].slot = (int)we.size(); we.push_back(ne); }
+          else we[(size_t)j] = ne;
         }
-        closure(sd.alpha, limit);
+        closure<false>(sd.alpha);
         if (timing) tc1 = clk::now();
         n_closure_states += we.size();
         const int T = intern(t, g, a, perm, sd.alpha);
         if (timing) { t_closure += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); t_intern += std::chrono::duration<double, std::milli>(clk::now() - tc1).count(); }
-        darc.push_back(DArc{D, T, ol, t, g, a, bp_src.size()});
-        for (size_t k = 0; k < perm.size(); ++k) { bp_src.push_back(wsrc[(size_t)perm[k]]); bp_ali.push_back(wali[(size_t)perm[k]]); }
+        darc.push_back(DArc{D, T, ol, t, g, a});
         if (!st[(size_t)T].queued) { st[(size_t)T].queued = true; pq.push({st[(size_t)T].minrank, T}); }
         g0 = g1;
       }
@@ -1274,8 +1310,9 @@ static int rescore_on_determinised(int n_states, int start, int n_arcs, const in
           const auto& da = dr.darc[(size_t)x.darc];
           wv.push_back(da.word);
           gr += da.gr + x.dl; ac += da.ac;
-          dr.read_ali(dr.bp_ali[da.bp + (size_t)e], av);
-          e = dr.bp_src[da.bp + (size_t)e];
+          const size_t bp = dr.trace(x.darc);
+          dr.read_ali(dr.tr_ali[bp + (size_t)e], av);
+          e = dr.tr_src[bp + (size_t)e];
         }
         dr.read_ali(dr.start_ali[(size_t)e], av);
         gr += dr.start_g; ac += dr.start_a;
