@@ -260,12 +260,17 @@ def test_rescore_on_the_determinised_lattice_equals_the_raw_composition(monkeypa
     assert len(det) == len(raw) >= 50
     tr, td = np.array([g + a for _, g, a, _ in raw]), np.array([g + a for _, g, a, _ in det])
     np.testing.assert_allclose(td, tr, atol=2e-3)
+    n_same_ali = n_untied = 0
     for j, (x, y) in enumerate(zip(det, raw)):
         tied = (j > 0 and abs(tr[j] - tr[j - 1]) < 2e-3) or (j + 1 < len(raw) and abs(tr[j + 1] - tr[j]) < 2e-3)
         if not tied:
             assert x[0] == y[0], j
             assert abs(x[1] - y[1]) < 2e-3 and abs(x[2] - y[2]) < 2e-3, j
+            n_same_ali += x[3] == y[3]                  # (round 5: the determinised path recomputes back pointers on demand, DetRescore::trace)
+            n_untied += 1
         assert len(x[3]) == frames == len(y[3]), "an alignment has one input label per decoded frame"
     assert det[0][3] == raw[0][3]                       # the best hypothesis' alignment (no tie at the top of this lattice)
+    print(f"alignments equal to the raw composition's: {n_same_ali} of {n_untied} untied hypotheses")
+    assert n_same_ali == n_untied                       # every untied hypothesis: the alignment of its best path, label for label
     assert {w for w, *_ in det} == {w for w, *_ in raw} and len({w for w, *_ in det}) == len(det)
     assert st_det[1] * 10 < st_raw[1], (st_det, st_raw)  # product arcs: determinised first vs raw
