@@ -274,3 +274,41 @@ def test_rescore_on_the_determinised_lattice_equals_the_raw_composition(monkeypa
     assert n_same_ali == n_untied                       # every untied hypothesis: the alignment of its best path, label for label
     assert {w for w, *_ in det} == {w for w, *_ in raw} and len({w for w, *_ in det}) == len(det)
     assert st_det[1] * 10 < st_raw[1], (st_det, st_raw)  # product arcs: determinised first vs raw
+
+
+def test_rescore_work_arrays_are_reused_without_leaking_between_calls():
+    """Round 5: the determinisation's work arrays live per host thread and are reused from call to call (csrc/graphc.cpp,
+    DetRescore).  Lattices of different sizes alternating on one thread, and the same mix on several threads at once (the
+    pool of wfst_decoder._nbest_host), must each return exactly what a first call returned: words, alignments, float costs."""
+    from concurrent.futures import ThreadPoolExecutor
+    import ngram_lm
+    import wfst
+    Z = np.load(os.path.join(ROOT, "tests", "golden", "wfst_lattice_u2.npz"))
+    n_states, n_arcs, n_final, start, frames = (int(v) for v in Z["meta"])
+    V = max(int(w) for w in Z["ol"] if w > 0)
+    vocab = [f"w{k}" for k in range(1, V + 1)]
+    table = ["<eps>"] + vocab + ["#0", "<s>", "</s>"]
+    word_id = {w: i for i, w in enumerate(table) if 0 < i <= V}
+    wd0 = V + 1
+    H_old = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 2, 3 * V, seed=5), word_id, wd0)).arcsort()
+    H_new = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 3, 6 * V, seed=6), word_id, wd0)).arcsort()
+    real = (n_states, start, Z["src"], Z["dst"], Z["il"], Z["ol"], Z["gr"], Z["ac"], Z["fs"], Z["fc"])
+    cases = [(real, 100, 8.0, 200 * (2 * frames + 16))]
+    for seed in range(3):                                  # small random lattices over the same word ids (ragged against the real one)
+        rs = np.random.RandomState(700 + seed)
+        n = 20 + 7 * seed
+        src, dst, il, ol, gr, ac = [], [], [], [], [], []
+        for s in range(n - 1):
+            for _ in range(2):
+                src.append(s); dst.append(int(rs.randint(s + 1, min(n, s + 4)))); il.append(int(rs.randint(0, 6)))
+                ol.append(int(rs.choice([0, 0, 1, 2, 3, min(4, V)]))); gr.append(float(rs.rand() * 2)); ac.append(float(rs.rand() * 3 - 1.0))
+        cases.append(((n, 0, src, dst, il, ol, gr, ac, [n - 1, n - 2], [0.3, 0.0]), 20 + 10 * seed, 4.0 + seed, 1 << 16))
+    run = lambda k: host_rescore(*cases[k][0], H_old, H_new, wd0, cases[k][1], cases[k][2], cap=cases[k][3])[0]
+    first = [run(k) for k in range(len(cases))]
+    assert all(len(f) > 0 for f in first) and len(first[0]) >= 50
+    for k in (0, 1, 0, 3, 2, 0, 1):                        # big, small, big, ...: one thread's arrays shrink and grow logically
+        assert run(k) == first[k], k
+    order = [0, 1, 2, 3] * 6
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        for k, got in zip(order, pool.map(run, order)):
+            assert got == first[k], k
