@@ -1024,7 +1024,7 @@ struct DetRescore {
         if (j < 0) {
           sd.slot = (int)we.size(); we.push_back(ne);
           if (TRACK) { wsrc.push_back(esrc); wali.push_back(na); }
-          __builtin_prefetch(&earc[(size_t)sd.eoff]);
+          __builtin_prefetch(earc.data() + sd.eoff);
           size_t p = heap.size(); heap.push_back(a.dst);
           while (p > 0 && heap[p - 1] < a.dst) { heap[p] = heap[p - 1]; --p; }
           heap[p] = a.dst;
