@@ -315,14 +315,18 @@ def test_rescore_work_arrays_are_reused_without_leaking_between_calls():
             assert got == first[k], k
 
 
+@pytest.mark.parametrize("threads", [1, 3])
 @pytest.mark.parametrize("seed", range(12))
-def test_rescore_epsilon_heavy_lattices_against_enumeration(seed):
+def test_rescore_epsilon_heavy_lattices_against_enumeration(seed, threads, monkeypatch):
     """Round 5: lattices that are mostly epsilon-output arcs (25-80 %), fan-out 1-3: chains, and single-exit states with SEVERAL
     incoming arcs, which the determinisation now absorbs into each of them (csrc/graphc.cpp, DetRescore::setup) -- words, graph /
     acoustic costs and the alignment of every untied entry against the enumeration (oracle/wfst_oracle.py rescore_by_definition).
     (600 further seeds of this generator were run once when the code was written: 0 differences.)"""
     import ngram_lm
     import wfst
+    # threads = 3: states are expanded ahead of their turn by helper threads, in batches of >= 2 here (192 in production, where
+    # only lattices of >= 60 k arcs get helpers): the answers must not know
+    monkeypatch.setenv("B2T_RESCORE_THREADS", str(threads)); monkeypatch.setenv("B2T_RESCORE_MIN_BATCH", "2")
     rs = np.random.RandomState(9000 + seed)
     n = int(rs.randint(8, 34)); nbest = int(rs.choice([5, 20, 60, 200])); beam = float(rs.choice([1.5, 3.0, 6.0, 100.0]))
     vocab = [f"w{k}" for k in range(6)]
@@ -356,3 +360,30 @@ def test_rescore_epsilon_heavy_lattices_against_enumeration(seed):
             continue
         assert gw[0] == tuple(ww[0]) and abs(gw[1] - ww[1]) < 3e-4 and abs(gw[2] - ww[2]) < 3e-4, j
         assert tuple(gw[3]) == tuple(ww[3]), j
+
+
+def test_rescore_with_helper_threads_is_bit_identical_on_the_real_lattice(monkeypatch):
+    """Round 5: DetRescore::run with n_threads > 1 prepares the expansions of queued states in parallel batches and redoes the
+    few whose forward cost was lowered past a refused candidate -- words, alignments and float costs must equal the serial
+    determinisation's bit for bit, whatever the thread count and batch threshold."""
+    import ngram_lm
+    import wfst
+    Z = np.load(os.path.join(ROOT, "tests", "golden", "wfst_lattice_u2.npz"))
+    n_states, n_arcs, n_final, start, frames = (int(v) for v in Z["meta"])
+    V = max(int(w) for w in Z["ol"] if w > 0)
+    vocab = [f"w{k}" for k in range(1, V + 1)]
+    table = ["<eps>"] + vocab + ["#0", "<s>", "</s>"]
+    word_id = {w: i for i, w in enumerate(table) if 0 < i <= V}
+    wd0 = V + 1
+    H_old = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 2, 3 * V, seed=5), word_id, wd0)).arcsort()
+    H_new = wfst.HostFst.from_fst(wfst.grammar_fst(ngram_lm.synthetic_word_arpa(vocab, 3, 6 * V, seed=6), word_id, wd0)).arcsort()
+    args = (n_states, start, Z["src"], Z["dst"], Z["il"], Z["ol"], Z["gr"], Z["ac"], Z["fs"], Z["fc"])
+    cap = 400 * (2 * frames + 16)
+    monkeypatch.setenv("B2T_RESCORE_THREADS", "1")
+    serial, _ = host_rescore(*args, H_old, H_new, wd0, 200, 8.0, cap=cap)
+    assert len(serial) >= 50
+    for threads, min_batch in ((2, 2), (4, 16), (3, 192), (6, 64)):
+        monkeypatch.setenv("B2T_RESCORE_THREADS", str(threads)); monkeypatch.setenv("B2T_RESCORE_MIN_BATCH", str(min_batch))
+        for _ in range(2):
+            got, _ = host_rescore(*args, H_old, H_new, wd0, 200, 8.0, cap=cap)
+            assert got == serial, (threads, min_batch)
