@@ -866,6 +866,7 @@ struct DetRescore {
   // and fresh ones are mapped and unmapped page by page on every call.
   struct RArc { int lab, nlab, ol, dst; double g, a; };      // lab / nlab: its input labels (non-epsilon) in `labels`: chains of single-entry single-exit states are contracted into one arc
   struct Ent { int s; double tot, gr, ac; };
+  struct Key { int s; float t, g; };                          // what makes two entries THE SAME: the lattice state, total and graph residual at float precision
   struct St { size_t off; int n; double alpha; int minrank; double fin_tot, fin_gr, fin_ac; int fin_ent; bool queued; size_t wl_off; int wl_n; };
   struct DArc { int src, dst, word; double tot, gr, ac; };
   struct ANode { int parent, label; };
@@ -879,6 +880,7 @@ struct DetRescore {
   std::vector<double> fin, beta;
   std::vector<St> st;
   std::vector<Ent> ent;
+  std::vector<Key> ekey;                                     // ent's identity keys, same indexing (a candidate state is compared with one memcmp)
   std::vector<DArc> darc;
   std::vector<int> tr_src, tr_ali, start_ali;                // back pointers of the traced arcs (trace()), of the start state's entries
   std::vector<size_t> tr_off;
@@ -979,7 +981,7 @@ struct DetRescore {
     si.resize(nk + 1);
     for (size_t r = 0; r <= nk; ++r) si[r] = SInfo{r < nk ? beta[r] : INFINITY, -1, eoff[r]};
     start_r = rank[(size_t)start];
-    st.clear(); ent.clear(); wl.clear(); darc.clear(); tr_src.clear(); tr_ali.clear(); tr_off.clear(); start_ali.clear(); ali.clear();
+    st.clear(); ent.clear(); ekey.clear(); wl.clear(); darc.clear(); tr_src.clear(); tr_ali.clear(); tr_off.clear(); start_ali.clear(); ali.clear();
     if (ikey.size() < 4096) { ikey.resize(4096); ival.resize(4096); }
     std::fill(ikey.begin(), ikey.end(), 0ull); imask = ikey.size() - 1;
     t_gather = t_closure = t_intern = 0; n_closure_states = n_entries_expanded = 0; n_spec = n_respec = n_batches = 0;
@@ -1007,7 +1009,7 @@ struct DetRescore {
     std::vector<SInfo> si;
     std::vector<Ent> we; std::vector<int> wsrc, wali, pop_perm, heap;
     std::vector<Tr> trans; std::vector<std::pair<uint64_t, int>> keyed;
-    std::vector<Ent> r_ent; std::vector<Group> r_grp;
+    std::vector<Ent> r_ent; std::vector<Key> r_key; std::vector<Group> r_grp;   // r_key: parallel to r_ent
     double m_drop = INFINITY;      // the cheapest candidate the beam refused during the current expansion (cost relative to the state's alpha, + beta)
   };
   std::vector<Ctx> ctx;
@@ -1067,10 +1069,10 @@ struct DetRescore {
     for (int p : c.pop_perm) {                                   // (the closure popped every state exactly once, in topological order)
       Ent e = we[(size_t)p];
       e.tot -= t; e.gr -= g; e.ac -= a;
-      const float rt = (float)e.tot, rg = (float)e.gr;
+      const float rt = (float)e.tot + 0.0f, rg = (float)e.gr + 0.0f;      // (+ 0: a negative zero becomes the positive one -- the keys are compared as bytes)
       uint32_t b1, b2; memcpy(&b1, &rt, 4); memcpy(&b2, &rg, 4);
       h = (h ^ (uint64_t)(uint32_t)e.s) * 1099511628211ull; h = (h ^ b1) * 1099511628211ull; h = (h ^ b2) * 1099511628211ull;
-      c.r_ent.push_back(e);
+      c.r_ent.push_back(e); c.r_key.push_back(Key{e.s, rt, rg});
     }
     c.r_grp.push_back(Group{word, off, (int)we.size(), t, g, a, h | 1ull});   // (hash 0 marks an empty slot of the table)
   }
@@ -1154,24 +1156,19 @@ struct DetRescore {
   }
   // intern a sealed group (entries L[0 .. gr.n)): the determinised state with exactly these entries (costs at float precision),
   // created if new; its forward cost lowered to alpha_via + gr.t if that is cheaper.  Calling thread only.
-  int commit(const Group& gr, const Ent* L, double alpha_via) {
+  int commit(const Group& gr, const Ent* L, const Key* K, double alpha_via) {
     const uint64_t h = gr.h;
     size_t p = (size_t)(h ^ (h >> 29)) & imask;
     for (; ikey[p]; p = (p + 1) & imask) {
       if (ikey[p] != h) continue;
       St& r = st[(size_t)ival[p]];
       if (r.n != gr.n) continue;
-      bool same = true;
-      for (int k = 0; k < r.n && same; ++k) {
-        const Ent& x = ent[r.off + (size_t)k]; const Ent& y = L[k];
-        same = x.s == y.s && (float)x.tot == (float)y.tot && (float)x.gr == (float)y.gr;
-      }
-      if (same) { r.alpha = std::min(r.alpha, alpha_via + gr.t); return ival[p]; }
+      if (memcmp(&ekey[r.off], K, (size_t)gr.n * sizeof(Key)) == 0) { r.alpha = std::min(r.alpha, alpha_via + gr.t); return ival[p]; }
     }
     St ns{ent.size(), gr.n, alpha_via + gr.t, L[0].s, INFINITY, 0.0, 0.0, -1, false, wl.size(), 0};   // minrank: the first state popped
     for (int k = 0; k < gr.n; ++k) {
       const Ent& e = L[k];
-      ent.push_back(e);
+      ent.push_back(e); ekey.push_back(K[k]);
       if (woff[(size_t)e.s + 1] > woff[(size_t)e.s]) { wl.push_back(k); ++ns.wl_n; }
       if (fin[(size_t)e.s] != INFINITY) {
         const double c = e.tot + fin[(size_t)e.s];
@@ -1198,7 +1195,7 @@ struct DetRescore {
     limit = beta[(size_t)start] + beam + 1e-4;
     if (n_threads < 1) n_threads = 1;
     if ((int)ctx.size() < n_threads) ctx.resize((size_t)n_threads);
-    for (int t = 0; t < n_threads; ++t) { ctx[(size_t)t].si = si; ctx[(size_t)t].r_ent.clear(); ctx[(size_t)t].r_grp.clear(); }
+    for (int t = 0; t < n_threads; ++t) { ctx[(size_t)t].si = si; ctx[(size_t)t].r_ent.clear(); ctx[(size_t)t].r_key.clear(); ctx[(size_t)t].r_grp.clear(); }
     spec.clear();
     Ctx& c0 = ctx[0];
     c0.we.assign(1, Ent{start, 0.0, 0.0, 0.0}); c0.wsrc.assign(1, -1); c0.wali.assign(1, -1);
@@ -1209,9 +1206,9 @@ struct DetRescore {
     seal(c0, 0);
     {
       const Group gr = c0.r_grp.back();
-      commit(gr, c0.r_ent.data() + gr.off, 0.0);              // state 0; its offset (the start's closure may hold a cheaper entry than the start itself: costs can be negative) is start_off / start_g / start_a
+      commit(gr, c0.r_ent.data() + gr.off, c0.r_key.data() + gr.off, 0.0);              // state 0; its offset (the start's closure may hold a cheaper entry than the start itself: costs can be negative) is start_off / start_g / start_a
       start_off = gr.t; start_g = gr.g; start_a = gr.a;
-      c0.r_ent.clear(); c0.r_grp.clear();
+      c0.r_ent.clear(); c0.r_key.clear(); c0.r_grp.clear();
     }
     typedef std::pair<int, int> QI;                        // (earliest lattice state, determinised state); min-heap in a vector
     std::vector<QI> pq, batch;
@@ -1225,7 +1222,7 @@ struct DetRescore {
       if (n_threads > 1 && unprepared >= MIN_BATCH && spec[(size_t)pq.front().second].who < 0) {
         // the next state has nothing prepared: the queue's earliest unprepared states are expanded in parallel (nothing shared
         // is written: st / ent / wl / the table rest).  With no prepared state left, the arenas start over.
-        if (outstanding == 0) for (int t = 0; t < n_threads; ++t) { ctx[(size_t)t].r_ent.clear(); ctx[(size_t)t].r_grp.clear(); }
+        if (outstanding == 0) for (int t = 0; t < n_threads; ++t) { ctx[(size_t)t].r_ent.clear(); ctx[(size_t)t].r_key.clear(); ctx[(size_t)t].r_grp.clear(); }
         batch.clear();
         for (const QI& x : pq) if (spec[(size_t)x.second].who < 0) batch.push_back(x);
         const size_t nb = std::min(BATCH, batch.size());
@@ -1270,11 +1267,11 @@ struct DetRescore {
       for (int q = 0; q < ng; ++q) {
         const Group& gr = c.r_grp[g0 + (size_t)q];
         n_closure_states += (size_t)gr.n;
-        const int T = commit(gr, c.r_ent.data() + gr.off, sd.alpha);
+        const int T = commit(gr, c.r_ent.data() + gr.off, c.r_key.data() + gr.off, sd.alpha);
         darc.push_back(DArc{D, T, gr.word, gr.t, gr.g, gr.a});
         if (!st[(size_t)T].queued) { st[(size_t)T].queued = true; qpush({st[(size_t)T].minrank, T}); ++unprepared; }
       }
-      if (who == 0 && g0 == keep_grp) { c0.r_grp.resize(keep_grp); c0.r_ent.resize(keep_ent); }   // groups made in turn are dropped again
+      if (who == 0 && g0 == keep_grp) { c0.r_grp.resize(keep_grp); c0.r_ent.resize(keep_ent); c0.r_key.resize(keep_ent); }   // groups made in turn are dropped again
     }
     if (!helpers.empty()) {
       { std::unique_lock<std::mutex> lk(hm); h_stop = true; }
@@ -1285,7 +1282,7 @@ struct DetRescore {
     return true;
   }
   void release_big() {                                           // (after an outsized lattice: the arrays go back to the allocator)
-    std::vector<Ent>().swap(ent); std::vector<ANode>().swap(ali); std::vector<Ctx>().swap(ctx); std::vector<Raw>().swap(raw);
+    std::vector<Ent>().swap(ent); std::vector<Key>().swap(ekey); std::vector<ANode>().swap(ali); std::vector<Ctx>().swap(ctx); std::vector<Raw>().swap(raw);
     std::vector<RArc>().swap(carc); std::vector<RArc>().swap(earc); std::vector<RArc>().swap(warc); std::vector<int>().swap(tr_src); std::vector<int>().swap(tr_ali);
   }
   // helper threads of one run(): chunks of four states of the published batch, results into the thread's own context
