@@ -549,7 +549,10 @@ int b2t_lattice_nbest_host(int n_states, int start, int n_arcs, const int32_t* s
  * both grammars determinised on the fly; the n-best distinct word sequences are ranked by the NEW total cost among the
  * sequences whose OLD cost is within `beam` of the best OLD cost (the contents of the reference's lat_).  g_old / g_new:
  * b2t_fst_* handles, arc-sorted by ilabel.  Outputs as b2t_lattice_nbest_host (costs[2k] = the exchanged graph cost);
- * stats4 (optional) = {product states, product arcs, determinised states of g_old, of g_new}. */
+ * stats4 (optional) = {product states, product arcs, determinised states of g_old, of g_new}.
+ * Threads: re-entrant (callers run one call per utterance on a pool); work arrays are kept per calling thread.  A lattice of
+ * >= 60000 arcs is determinised with helper threads of its own for the duration of the call (4 including the caller;
+ * B2T_RESCORE_BIG_THREADS=n, 1 = none; B2T_RESCORE_THREADS=n forces n for every lattice) -- the result does not depend on it. */
 int b2t_lattice_rescore_nbest_host(int n_states, int start, int n_arcs, const int32_t* src, const int32_t* dst,
                                    const int32_t* ilabel, const int32_t* olabel, const float* graph, const float* acoustic,
                                    int n_final, const int32_t* final_state, const float* final_cost,
