@@ -873,6 +873,7 @@ struct DetRescore {
   int n_kept = 0, start_r = -1;
   struct SInfo { double beta; int slot, eoff; };             // what a closure needs of a state, in one 16-byte record (slot: its index in the working subset, -1 = absent)
   std::vector<SInfo> si;
+  std::vector<unsigned char> sflag;                          // bit 0: the state has word arcs; bit 1: it is final
   std::vector<int> woff, orig, wl;                     // orig: the lattice's own id of a state (ties between equal costs are broken by it); wl: per determinised state, its entries that have word arcs
   std::vector<int> eoff;
   std::vector<RArc> earc, warc;
@@ -979,6 +980,8 @@ struct DetRescore {
     }
     const auto T5 = std::chrono::steady_clock::now();
     si.resize(nk + 1);
+    sflag.resize(nk);
+    for (size_t r = 0; r < nk; ++r) sflag[r] = (unsigned char)((woff[r + 1] > woff[r] ? 1 : 0) | (fin[r] != INFINITY ? 2 : 0));
     for (size_t r = 0; r <= nk; ++r) si[r] = SInfo{r < nk ? beta[r] : INFINITY, -1, eoff[r]};
     start_r = rank[(size_t)start];
     st.clear(); ent.clear(); ekey.clear(); wl.clear(); darc.clear(); tr_src.clear(); tr_ali.clear(); tr_off.clear(); start_ali.clear(); ali.clear();
@@ -1166,11 +1169,13 @@ struct DetRescore {
       if (memcmp(&ekey[r.off], K, (size_t)gr.n * sizeof(Key)) == 0) { r.alpha = std::min(r.alpha, alpha_via + gr.t); return ival[p]; }
     }
     St ns{ent.size(), gr.n, alpha_via + gr.t, L[0].s, INFINITY, 0.0, 0.0, -1, false, wl.size(), 0};   // minrank: the first state popped
+    ent.insert(ent.end(), L, L + gr.n); ekey.insert(ekey.end(), K, K + gr.n);
     for (int k = 0; k < gr.n; ++k) {
-      const Ent& e = L[k];
-      ent.push_back(e); ekey.push_back(K[k]);
-      if (woff[(size_t)e.s + 1] > woff[(size_t)e.s]) { wl.push_back(k); ++ns.wl_n; }
-      if (fin[(size_t)e.s] != INFINITY) {
+      const unsigned char f = sflag[(size_t)L[k].s];           // (one byte per lattice state: this loop is the calling thread's, i.e. serial)
+      if (!f) continue;
+      if (f & 1) { wl.push_back(k); ++ns.wl_n; }
+      if (f & 2) {
+        const Ent& e = L[k];
         const double c = e.tot + fin[(size_t)e.s];
         if (c < ns.fin_tot) { ns.fin_tot = c; ns.fin_gr = e.gr + fin[(size_t)e.s]; ns.fin_ac = e.ac; ns.fin_ent = k; }
       }
