@@ -283,7 +283,7 @@ def run():
             seen = set(tuple(e[2]) for e in a)
             promoted += sum(1 for e in b[:10] if tuple(e[2]) not in seen)
         rescore = dict(nbest100_ms_32_utterances=round((t1 - t0) * 1e3, 2), rescore_nbest100_ms_32_utterances=round((t2 - t1) * 1e3, 2),
-                       rescore_nbest100_ms_32_utterances_repeated=[round(x * 1e3, 2) for x in again], host_pool_threads=_pool_threads(),
+                       rescore_nbest100_ms_32_utterances_repeated=[round(x * 1e3, 2) for x in again], host_pool_threads=_pool_threads(), threads_per_lattice_of_60k_arcs_or_more=int(os.environ.get("B2T_RESCORE_BIG_THREADS", "4")),
                        utterances_whose_1best_changed=changed, top10_entries_from_below_the_first_100=promoted,
                        grammars="word 3-gram (in the graph) -> word 4-gram, 6000 n-grams per order")
     except Exception as e:     # noqa: BLE001
