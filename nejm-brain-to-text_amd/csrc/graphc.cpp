@@ -987,7 +987,7 @@ struct DetRescore {
     st.clear(); ent.clear(); ekey.clear(); wl.clear(); darc.clear(); tr_src.clear(); tr_ali.clear(); tr_off.clear(); start_ali.clear(); ali.clear();
     if (ikey.size() < 4096) { ikey.resize(4096); ival.resize(4096); }
     std::fill(ikey.begin(), ikey.end(), 0ull); imask = ikey.size() - 1;
-    t_gather = t_closure = t_intern = 0; n_closure_states = n_entries_expanded = 0; n_spec = n_respec = n_batches = 0;
+    n_closure_states = n_entries_expanded = 0; n_spec = n_respec = n_batches = 0;
     if (getenv("B2T_LAT_TIMING")) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
       fprintf(stderr, "det setup: adjacency %.2f, contraction %.2f, kahn %.2f, renumber %.2f, beta %.2f, clear %.2f ms (%d kept states, %zu + %zu arcs)\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), ms(T3, T4), ms(T4, T5), ms(T5, std::chrono::steady_clock::now()), n_kept, earc.size(), warc.size()); }
     return start_r >= 0;
@@ -1327,7 +1327,7 @@ struct DetRescore {
   }
   size_t n_spec = 0, n_respec = 0, n_batches = 0;
   double start_off = 0, start_g = 0, start_a = 0;
-  double t_gather = 0, t_closure = 0, t_intern = 0; size_t n_closure_states = 0, n_entries_expanded = 0;
+  size_t n_closure_states = 0, n_entries_expanded = 0;
 };
 
 }  // namespace
