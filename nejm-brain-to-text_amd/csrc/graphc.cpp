@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <atomic>
+#include <system_error>
 #include <thread>
 #include <math.h>
 #include <stdint.h>
@@ -1243,8 +1244,11 @@ struct DetRescore {
           h_next.store(0, std::memory_order_relaxed); h_done.store(0, std::memory_order_relaxed);
           ++h_seq;
         }
-        if (helpers.empty())
-          for (int t = 1; t < n_threads; ++t) helpers.emplace_back([this, t] { helper_loop(t); });
+        if (helpers.empty() && !h_refused)
+          for (int t = 1; t < n_threads; ++t) {
+            try { helpers.emplace_back([this, t] { helper_loop(t); }); }
+            catch (const std::system_error&) { h_refused = true; break; }      // no more threads to be had: the calling thread does what the missing ones would (work_chunks takes every chunk nobody else takes)
+          }
         hcv.notify_all();
         work_chunks(0);
         while (h_done.load(std::memory_order_acquire) < nb) std::this_thread::yield();
@@ -1284,6 +1288,7 @@ struct DetRescore {
       for (std::thread& h : helpers) h.join();
       helpers.clear(); h_stop = false;
     }
+    h_refused = false;
     return true;
   }
   void release_big() {                                           // (after an outsized lattice: the arrays go back to the allocator)
@@ -1295,7 +1300,7 @@ struct DetRescore {
   std::vector<std::thread> helpers;
   std::atomic<size_t> h_next{0}, h_done{0};
   std::atomic<int> h_active{0};
-  const std::pair<int, int>* h_batch = nullptr; size_t h_nb = 0; unsigned long long h_seq = 0; bool h_stop = false;
+  const std::pair<int, int>* h_batch = nullptr; size_t h_nb = 0; unsigned long long h_seq = 0; bool h_stop = false, h_refused = false;
   void work_chunks(int t) {
     Ctx& c = ctx[(size_t)t];
     const size_t nb = h_nb;
