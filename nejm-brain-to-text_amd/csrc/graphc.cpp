@@ -865,7 +865,7 @@ struct DetRescore {
   // works in a narrow window of them; epsilon-output arcs and word arcs are stored apart (the closure reads only the former, the
   // gather only the latter).  The instance is kept per host thread and reused: a 175 k-arc lattice needs ~40 MB of these vectors,
   // and fresh ones are mapped and unmapped page by page on every call.
-  struct RArc { int lab, nlab, ol, dst; double g, a; };      // lab / nlab: its input labels (non-epsilon) in `labels`: chains of single-entry single-exit states are contracted into one arc
+  struct RArc { int lab, nlab, ol, dst; double g, a; };      // lab / nlab: its input labels (non-epsilon) in `labels`: single-exit states are absorbed into the arcs that enter them (setup)
   struct Ent { int s; double tot, gr, ac; };
   struct Key { int s; float t, g; };                          // what makes two entries THE SAME: the lattice state, total and graph residual at float precision
   struct St { size_t off; int n; double alpha; int minrank; double fin_tot, fin_gr, fin_ac; int fin_ent; bool queued; size_t wl_off; int wl_n; };
@@ -873,7 +873,7 @@ struct DetRescore {
   struct ANode { int parent, label; };
   int n_kept = 0, start_r = -1;
   struct SInfo { double beta; int slot, eoff; };             // what a closure needs of a state, in one 16-byte record (slot: its index in the working subset, -1 = absent)
-  std::vector<SInfo> si;
+  std::vector<SInfo> si;                                     // the template: every thread's context works on a copy (Ctx::si)
   std::vector<unsigned char> sflag;                          // bit 0: the state has word arcs; bit 1: it is final
   std::vector<int> woff, orig, wl;                     // orig: the lattice's own id of a state (ties between equal costs are broken by it); wl: per determinised state, its entries that have word arcs
   std::vector<int> eoff;
