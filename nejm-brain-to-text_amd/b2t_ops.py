@@ -379,6 +379,77 @@ def host_api_probe(n: int = 200) -> dict:
     return out
 
 
+def slow_mode_probe(hops: int = 64) -> dict:
+    """What a process that found itself in the pool's slow-host mode measures about itself (round-5 verdict item 1b): the
+    cross-queue hop the plan is made of -- a chain of tiny launches that alternates between two streams through events: microseconds
+    per hop on the GPU timeline and of host time --, the burst latency of host_api_probe, and the process's scheduling state (CPU it
+    runs on, that CPU's clock, context switches during the chain, load average, NUMA node of the CPU against the GPU's)."""
+    import time
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = N.load()
+    a = torch.zeros(64, 64, device=dev); b = torch.zeros(64, 64, device=dev)
+    s0, s1 = torch.cuda.current_stream(), torch.cuda.Stream()
+    h = [C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)]
+    evs = [torch.cuda.Event() for _ in range(hops)]
+
+    def ctx():
+        try:
+            d = dict(l.split(":", 1) for l in open("/proc/self/status").read().splitlines() if "ctxt_switches" in l)
+            return int(d["voluntary_ctxt_switches"]), int(d["nonvoluntary_ctxt_switches"])
+        except Exception:
+            return None
+    out = {}
+    for rep in range(2):
+        torch.cuda.synchronize()
+        c0 = ctx()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(s0)
+        for i in range(hops):
+            src, dst = (s0, s1) if i % 2 == 0 else (s1, s0)
+            lib.b2t_transpose_f32(_p(a), _p(b), 64, 64, h[i % 2])
+            evs[i].record(src)
+            dst.wait_event(evs[i])
+        if hops % 2:
+            s0.wait_event(evs[-1])
+        e1.record(s0)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        c1 = ctx()
+        out = dict(hop_us_gpu=round(e0.elapsed_time(e1) * 1e3 / hops, 2), hop_us_host=round(t_host * 1e6 / hops, 2),
+                   ctxt_switches_during_chain=(None if not (c0 and c1) else [c1[0] - c0[0], c1[1] - c0[1]]))
+    try:
+        cpu = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36])
+        out["cpu"] = cpu
+        for name, path in (("cpu_khz", f"/sys/devices/system/cpu/cpu{cpu}/cpufreq/scaling_cur_freq"),):
+            try:
+                out[name] = int(open(path).read())
+            except Exception:
+                pass
+        import glob
+        nodes = [os.path.basename(g) for g in glob.glob(f"/sys/devices/system/cpu/cpu{cpu}/node*")]
+        out["cpu_numa_node"] = nodes[0] if nodes else None
+        pr = torch.cuda.get_device_properties(dev)
+        bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        try:
+            out["gpu_numa_node"] = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read())
+        except Exception:
+            pass
+    except Exception:
+        pass
+    try:
+        out["loadavg"] = [round(v, 2) for v in os.getloadavg()]
+        out["threads"] = len(os.listdir("/proc/self/task"))
+        out["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        out["host_api_us"] = host_api_probe(100)
+    except Exception:
+        pass
+    return out
+
+
 def gru_sync_check(sync_ws, T: int, B: int):
     """Raise if the last persistent sweep on sync_ws reported a hand-off timeout (synchronises)."""
     st = C.c_int(0)

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <functional>
+#include <atomic>
+#include <chrono>
 #include <vector>
 #include <queue>
 #include <algorithm>
@@ -228,7 +230,17 @@ struct Ctx {
   unsigned* kcnt = nullptr;     // tile counters of the split-K GEMMs' in-kernel slab reduction (last block of sync_ws): KSLOT words per slot
   uint64_t gkey = 0;            // != 0: everything this pass launches is determined by this key (run_plan may replay it as a graph)
 
+  // B2T_EXEC_HOST_DELAY_US=n (round 6): a busy wait of n microseconds in front of every runtime call the executor makes (launch, event
+  // record, stream wait) -- emulates the pool's slow-host mode (host enqueue 5-8 ms per C2 step instead of 1.3) on a healthy box, to
+  // find which call's host latency reaches the GPU timeline (tools/r6_hostdelay.sh, NOTES.md R6.1)
+  static void host_delay() {
+    static const int us = getenv("B2T_EXEC_HOST_DELAY_US") ? atoi(getenv("B2T_EXEC_HOST_DELAY_US")) : 0;
+    if (us <= 0) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() < 1000ll * us) {}
+  }
   hipEvent_t record(hipStream_t s) {
+    host_delay();
     if (ex->next_ev == ex->pool.size()) {
       hipEvent_t e;
       if (check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) { rc = 1; return nullptr; }
@@ -239,6 +251,7 @@ struct Ctx {
     return e;
   }
   void wait(hipStream_t s, hipEvent_t e) {
+    host_delay();
     if (e && check_hip(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent")) rc = 1;
   }
   hipEvent_t tev() {
@@ -269,6 +282,7 @@ struct Ctx {
   void gemm(hipStream_t s, b2t_gemm_desc d, int splitk = 1, float* slab = nullptr, int accumulate = 0, int kslot = -1,
             const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr, const void* Ap_pre = nullptr) {
     if (rc) return;
+    host_delay();
     if ((Bp_pre || dropA) && !(bf16_gemm && would_pack(d, s))) { set_error("exec: pre-packed operands need the two-pass bf16 GEMM"); rc = 2; return; }
     if (Ap_pre && !(bf16_gemm && would_pack_z(d, s))) { set_error("exec: a pre-packed Z-batched A needs the two-pass bf16 GEMM"); rc = 2; return; }
     void* st = reinterpret_cast<void*>(s);
@@ -315,7 +329,7 @@ struct Ctx {
   }
   // Z-batched products (the day layer; round 5): every matrix of the batch packed, then one launch over (tiles, Z)
   static bool z_pack_on() { const char* e = getenv("B2T_ZPACK"); return !e || atoi(e) != 0; }
-  bool pack_shape_ok_z(const b2t_gemm_desc& d) const {    // plan time: the queue is not known yet (every queue of a pass has pack scratch)
+  bool pack_shape_ok_z(const b2t_gemm_desc& d) const {    // plan time: the queue is not known yet (the first NPACK queues of a pass have pack scratch; call sites check would_pack_z on the queue)
     return bf16_gemm && lay && lay->pack[0] && d.Z > 1 && d.Z <= 65535 && d.splitk <= 1 && !d.a_sum && d.a_brk == 0 && z_pack_on() && d.M >= 192 &&
            2.0 * d.Z * d.M * d.N * (double)d.K >= 2e9 && b2t_gemm_bf16p_ws_bytes_z(d.M, d.N, d.K, d.Z) <= lay->pack_bytes;
   }
@@ -336,7 +350,7 @@ struct Ctx {
     if (!would_pack(d, s)) return b2t_gemm_bf16_f32(&d, st);
     return gemm_bf16p_run(&d, nullptr, Bp_pre, lay->pack[pack_queue(s)], lay->pack_bytes, s, dropA);
   }
-  void call(int r) { if (!rc) rc = r; }
+  void call(int r) { host_delay(); if (!rc) rc = r; }
 };
 
 b2t_gemm_desc gd(const float* A, const float* Bm, float* C, int M, int N, int K) {
@@ -488,7 +502,7 @@ uint64_t pass_key(int which, const b2t_model_t* prm, const b2t_model_t* grd, con
   for (long long v : ints) h = key_of(h, v);
   for (const char* name : {"B2T_FUSED_PROJ", "B2T_HANDOFF16", "B2T_PREPACK", "B2T_WGRAD_SPLIT", "B2T_ZPACK", "B2T_GEMM_256", "B2T_GI0_CHAIN", "B2T_SPLITK256"}) {   // read per pass by the code below / the sweeps
     const char* e = getenv(name);
-    h = key_of(h, (int)(e ? e[0] : 0));
+    h = key_bytes(h, e ? e : "", e ? strlen(e) + 1 : 1);   // the whole value ("1" and "10" are different plans)
   }
   return h ? h : 1;
 }
@@ -648,8 +662,8 @@ struct Jitter {
 
 void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
   const int n = (int)P.t.size();
-  static uint64_t pass_no = 0;
-  Jitter jit(++pass_no);
+  static std::atomic<uint64_t> pass_no{0};   // (executors may run passes from different host threads)
+  Jitter jit(pass_no.fetch_add(1) + 1);
   bool classes = false;
   for (const Task& k : P.t) classes = classes || k.cls >= 0;
   if (classes && nq > 1) add_admission_edges(P, schedule_plan(P, nq));
@@ -1146,7 +1160,9 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     if (which == 1) { c.call(gemm_bf16p_pack(&d, 1, w.xpk_hh[l], s)); }
     else {
       if (fused_bias) { d.a_sum = asum_x; d.a_sum_ks = 3 * H; }
-      c.gemm(s, d, sk, slab_x, accumulate, l, pre ? w.xpk_hh[l] : nullptr);
+      // (the pre-packed copy only where this queue has pack scratch: with B2T_WORKERS > 3 a task can land on a queue without --
+      //  the GEMM then takes the one-pass kernel on the raw operand, as before round 5)
+      c.gemm(s, d, sk, slab_x, accumulate, l, (pre && c.would_pack(d, s)) ? w.xpk_hh[l] : nullptr);
       if (fused_bias) bias_out(sk, grd->b_hh[l]);
     }
   }
@@ -1168,7 +1184,7 @@ void layer_weight_grads(Ctx& c, hipStream_t s, const b2t_model_t* prm, const b2t
     if (c.bf16_gemm && which != 1 && c.would_pack(d, s)) { const int s256 = splitk_for256(M, In, K); if (s256 > 0) sk = s256; }
     if (which == 1) { c.call(gemm_bf16p_pack(&d, 1, w.xpk_ih[l], s)); return; }
     if (fused_bias) { d.a_sum = w.asum[l]; d.a_sum_ks = 3 * H; }
-    c.gemm(s, d, sk, w.slab[l], accumulate, l, pre ? w.xpk_ih[l] : nullptr);
+    c.gemm(s, d, sk, w.slab[l], accumulate, l, (pre && c.would_pack(d, s)) ? w.xpk_ih[l] : nullptr);
     if (fused_bias) bias_out(sk, grd->b_ih[l]);
   };
   if ((2 * H) % 128 == 0 && (3 * H) % 128 == 0) {   // dGi^T as ONE operand with a gap along m

@@ -225,18 +225,17 @@ class BrainToTextDecoder_Trainer:
             patch_stride=self.args['model']['patch_stride'],
         )
         self.logger.info("Initialized RNN decoding model (HIP/gfx950 path)")
-        try:      # start-up probe of the runtime's host latencies (ops.host_api_probe): a process in the pool's slow mode says so in its log
-            pr = ops.host_api_probe()
-            self.host_api = pr
-            msg = (f"HIP host latency: kernel launch {pr['kernel_launch_us']['p50']} us, event record {pr['event_record_us']['p50']} us, "
-                   f"stream wait {pr['stream_wait_event_us']['p50']} us (p50); {pr['burst_us_per_call']} us per call in a four-stream burst")
-            if pr["slow"]:
-                self.logger.warning(msg + " -- this process is in the slow-host mode (healthy: ~7 / 5 / 0.5 us): expect ~3x the host enqueue "
-                                          "time per step and a 5-10 % slower step; a fresh process usually is not")
-            else:
-                self.logger.info(msg)
-        except Exception as e:      # noqa: BLE001 -- a diagnostic must never stop a training run
-            self.logger.info(f"HIP host latency probe skipped: {e}")
+        # Start-up probe of the runtime's host latencies (ops.host_api_probe), opt-in (B2T_HOST_API_PROBE=1; round-5 advice: it creates
+        # five streams that live as long as the process and ~400 launches, and its idle numbers do not tell a slow process from a
+        # healthy one): logged without a verdict.  bench.py runs it for its own line.
+        if os.environ.get("B2T_HOST_API_PROBE", "0") not in ("0", "", "false", "False"):
+            try:
+                pr = ops.host_api_probe()
+                self.host_api = pr
+                self.logger.info(f"HIP host latency: kernel launch {pr['kernel_launch_us']['p50']} us, event record {pr['event_record_us']['p50']} us, "
+                                 f"stream wait {pr['stream_wait_event_us']['p50']} us (p50); {pr['burst_us_per_call']} us per call in a four-stream burst")
+            except Exception as e:      # noqa: BLE001 -- a diagnostic must never stop a training run
+                self.logger.info(f"HIP host latency probe skipped: {e}")
         self.logger.info(self.model)
         total_params = sum(p.numel() for p in self.model.parameters())
         self.logger.info(f"Model has {total_params:,} parameters")
