@@ -167,11 +167,13 @@ int b2t_batch_gather_b32(const void* flat, const int64_t* row_off, const int32_t
  * autocast(bfloat16) regime for the GRU, opt-in.
  * sync_ws: device scratch of b2t_gru_sync_bytes(T) bytes (persistent mode), zeroed ONCE by the owner (self-cleaning
  * afterwards); word 0 is a sticky error word (1 = a bounded hand-off spin gave up: results invalid). */
+#define B2T_MAX_LAYERS_ 8   /* = B2T_MAX_LAYERS below */
 #define B2T_GRU_BF16 0x100
 #define B2T_GRU_LOCAL 0x400   /* persistent sweeps, H <= 512, B <= 64: XCD-local hand-off (row group r on XCD (2r + parity) & 7, counters as L2 atomics, tiles written through and read back from that XCD's L2); ignored where the dispatch probe fails */
 #define B2T_GRU_PARITY 0x800  /* with B2T_GRU_LOCAL: the layer's parity */
 #define B2T_GRU_WIDE 0x200   /* with B2T_GRU_BF16: 32 hidden units per workgroup (half the workgroups per sweep), H % 32 == 0, H <= 512 */
 #define B2T_GRU_PAIRED 0x1000 /* b2t_gru_layer_bwd_f32, mode 1, exact fp32, H % 32 == 0, H <= 512, B <= 64 (other shapes: ignored): the backward sweep with its W_hh^T slice in LDS -- one 512-thread workgroup per CU owns 16 dh columns of TWO row groups, ~half the registers per lane, so that a GEMM workgroup stays resident next to it; XCD-local hand-off, pair p on XCD (4 p + set) & 7 */
+#define B2T_GRU_WAVE 0x8000   /* b2t_pass_t fwd_mode / bwd_mode, with mode 1 | B2T_GRU_BF16 and bf16_gemm: the L sweeps of the pass as ONE launch, layer l + 1 a step or two behind layer l (b2t_gru_wave_fwd_f32 / _bwd_f32 below); ignored for shapes b2t_gru_wave_supported refuses */
 #define B2T_GRU_SET_SHIFT 13  /* with B2T_GRU_PAIRED: bits 13-14 = the XCD set (0..3) of this sweep; at most ONE paired sweep of a set may be in flight */
 size_t b2t_gru_sync_bytes(int T);
 size_t b2t_gru_ws_bytes(int T, int B, int H);   /* = b2t_gru_sync_bytes (kept for callers that size by shape) */
@@ -197,6 +199,33 @@ int b2t_gru_layer_bwd_f32(const float* dY, const float* dh_last, const float* re
                           const float* out, const float* h_init, const float* w_hh_t,
                           float* dG, float* dh_init, float* carry_ws,
                           int T, int B, int H, int mode, void* sync_ws, void* stream);
+/* ---- a5 / a8, round 6: the whole GRU stack's sweeps as ONE launch per direction -- the step-granular layer wavefront
+ * (torch.nn.GRU(num_layers = L) at rnn_model.py:65-72,126 under torch.autocast(bfloat16), rnn_trainer.py:527, and its autograd
+ * backward).  bf16 operands on the matrix cores (h_{t-1}, dG_{t+1}, W_hh, W_ih of the layers >= 1 rounded to nearest-even bf16),
+ * fp32 accumulation, gates, states and everything stored.  All L x H / 16 workgroups are resident at once; layer l + 1 runs one or
+ * two time steps behind layer l; the input projections of the layers >= 1 (forward) and the gradients wrt their inputs (backward)
+ * are computed inside the sweep of the consuming layer and never exist in memory; nn.GRU's inter-layer dropout (drop_p, Philox
+ * stream of b2t_dropout_f32 with seed[l] / elem0: flat element (t, row, unit) of layer l's output) is applied where layer l
+ * publishes its state.  H % 16 == 0, H <= 768, B <= 64, L x H / 16 <= CUs of the device (b2t_gru_wave_supported).
+ *   forward : gi0 [T][B][3H] (layer 0's projection with b_ih[0]), w_hh / b_hh [l], w_ih / b_ih [l >= 1], h_init[l] [B][H]
+ *             -> out[l] [T][B][H], outd[l] = dropout(out[l]) (drop_p > 0, l < L - 1), reserve[l] [T][B][4H] (may be NULL)
+ *   backward: dY_top [T][B][H], dh_last [L][B][H] or NULL, w_hh_t[l] = W_hh^T [H][3H], w_ih_t[l >= 1] = W_ih^T [H][3H], h_init / out /
+ *             reserve as the forward left them -> dG[l] [T][B][4H] = (dr, dz, dn r, dn), dh_init [L][B][H]
+ * ws: b2t_gru_wave_ws_bytes bytes, any contents (hand-off rings + counters, cleared by the call); err_word: one device word, zeroed
+ * once by the owner: sticky, 1 = a bounded hand-off spin gave up (results invalid).  Asynchronous on `stream`. */
+typedef struct b2t_wave_t {
+  int L, T, B, H;
+  const float* gi0;
+  const float* w_hh[B2T_MAX_LAYERS_]; const float* b_hh[B2T_MAX_LAYERS_]; const float* w_ih[B2T_MAX_LAYERS_]; const float* b_ih[B2T_MAX_LAYERS_];
+  float* h_init[B2T_MAX_LAYERS_]; float* out[B2T_MAX_LAYERS_]; float* outd[B2T_MAX_LAYERS_]; float* reserve[B2T_MAX_LAYERS_];
+  const float* dY_top; const float* dh_last; float* dh_init;
+  const float* w_hh_t[B2T_MAX_LAYERS_]; const float* w_ih_t[B2T_MAX_LAYERS_]; float* dG[B2T_MAX_LAYERS_];
+  float drop_p; uint64_t seed[B2T_MAX_LAYERS_]; long long elem0;
+} b2t_wave_t;
+int b2t_gru_wave_supported(int L, int T, int B, int H);
+size_t b2t_gru_wave_ws_bytes(int L, int T, int B, int H, int backward, int dropout);
+int b2t_gru_wave_fwd_f32(const b2t_wave_t* d, void* ws, unsigned* err_word, void* stream);
+int b2t_gru_wave_bwd_f32(const b2t_wave_t* d, void* ws, unsigned* err_word, void* stream);
 int b2t_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 /* n (1..4) device-to-device copies of 32-bit words in ONE launch: dst[k][0 .. words[k]) = src[k][..] (the static input / output
  * buffers of a replayed streaming graph; no reference counterpart) */

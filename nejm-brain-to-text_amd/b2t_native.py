@@ -65,6 +65,16 @@ class PassDesc(C.Structure):
 BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 
+class WaveDesc(C.Structure):
+    """Mirror of b2t_wave_t (include/b2t.h): the GRU stack's sweeps as one launch per direction (the layer wavefront)."""
+    _fields_ = [("L", C.c_int), ("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("gi0", FP),
+                ("w_hh", FP * MAX_LAYERS), ("b_hh", FP * MAX_LAYERS), ("w_ih", FP * MAX_LAYERS), ("b_ih", FP * MAX_LAYERS),
+                ("h_init", FP * MAX_LAYERS), ("out", FP * MAX_LAYERS), ("outd", FP * MAX_LAYERS), ("reserve", FP * MAX_LAYERS),
+                ("dY_top", FP), ("dh_last", FP), ("dh_init", FP),
+                ("w_hh_t", FP * MAX_LAYERS), ("w_ih_t", FP * MAX_LAYERS), ("dG", FP * MAX_LAYERS),
+                ("drop_p", C.c_float), ("seed", C.c_uint64 * MAX_LAYERS), ("elem0", LL)]
+
+
 class WfstGraph(C.Structure):
     """Mirror of b2t_wfst_graph_t (include/b2t.h)."""
     _fields_ = [(n, VP) for n in ("row", "ilabel", "olabel", "weight", "next", "n_eps", "final_cost")] + \
@@ -106,6 +116,10 @@ _SIGNATURES = {
     "b2t_dropout_f32": (C.c_int, [VP, VP, LL, C.c_float, C.c_uint64, LL, VP]),
     "b2t_dropout_mask_f32": (C.c_int, [VP, LL, C.c_float, C.c_uint64, LL, VP]),
     "b2t_batch_gather_b32": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "b2t_gru_wave_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "b2t_gru_wave_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "b2t_gru_wave_fwd_f32": (C.c_int, [C.POINTER(WaveDesc), VP, VP, VP]),
+    "b2t_gru_wave_bwd_f32": (C.c_int, [C.POINTER(WaveDesc), VP, VP, VP]),
     "b2t_gru_sync_bytes": (C.c_size_t, [C.c_int]),
     "b2t_gru_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "b2t_gru_sync_status": (C.c_int, [VP, C.c_int, C.c_int, C.POINTER(C.c_int), VP]),

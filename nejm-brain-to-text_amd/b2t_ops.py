@@ -287,6 +287,10 @@ GRU_LOCAL = 0x400  # B2T_GRU_LOCAL: XCD-local hand-off of the fp32 sweeps
 GRU_PARITY = 0x800  # B2T_GRU_PARITY: with GRU_LOCAL, the layer's parity (which XCDs its row groups use)
 GRU_PAIRED = 0x1000  # B2T_GRU_PAIRED: exact-fp32 backward sweep with its W_hh^T slice in LDS (512-thread workgroups owning two row groups)
 GRU_SET_SHIFT = 13   # B2T_GRU_SET_SHIFT: with GRU_PAIRED, bits 13-14 = the sweep's XCD set
+GRU_WAVE = 0x8000    # B2T_GRU_WAVE: the pass's L sweeps as ONE launch, the step-granular layer wavefront (csrc/gru_wave.hip)
+# bf16 mode (use_amp): the layer wavefront wherever the library holds the shape (H % 16 == 0, H <= 768, B <= 64, L x H / 16 workgroups
+# resident); B2T_WAVE=0 selects the round-5 chunk pipeline (the tests compare the two in one process: read per pass)
+WAVE = {"on": os.environ.get("B2T_WAVE", "1") not in ("0", "", "false", "False")}
 # the exact-fp32 backward sweeps as paired sweeps (B2T_BWD_PAIRED=1; H % 32 == 0, H <= 512, B <= 64 -- other shapes ignore the flag)
 PAIRED_BWD = {"on": os.environ.get("B2T_BWD_PAIRED", "0") not in ("0", "", "false", "False")}
 # which sweeps (exact fp32 or bf16 operands, H <= 512) hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
@@ -645,6 +649,10 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ps.in_drop, ps.rnn_drop, ps.seed = float(in_drop), float(rnn_drop if L > 1 else 0.0), int(seed) & (2 ** 64 - 1)
     ps.chunks_bwd = time_chunks_bwd(Tp, B, H, AMP["on"], ps.chunks)
     ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
+    if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and \
+            lib.b2t_gru_wave_supported(L, Tp, B, H):
+        ps.fwd_mode |= GRU_WAVE
+        ps.bwd_mode |= GRU_WAVE
     nbytes = lib.b2t_pass_ws_bytes(C.byref(md), C.byref(ps))
     if nbytes == 0:
         raise RuntimeError("b2t_pass_ws_bytes: bad model / pass description")

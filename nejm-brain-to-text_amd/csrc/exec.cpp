@@ -127,8 +127,19 @@ struct Layout {
   float *slab_hh[MAXL], *asum_hh[MAXL];   // amp mode: split-K slab / per-slice sums of dW_hh when it runs as a task of its own next to dW_ih
   char* xpk_day;                     // amp mode: the A operands of the day layer's per-sentence weight gradients (x[b]^T, Z = B), packed when the backward pass starts
   char *xpk_hh[MAXL], *xpk_ih[MAXL]; // amp mode: the B operands of a layer's whole-sequence weight-gradient GEMMs (h_{t-1}^T, x^T: known when the backward pass starts), packed ahead of the tail
+  // layer wavefront (round 6, gru_wave.hip): counters + hand-off rings of the forward / backward launch, W_ih^T of the layers >= 1
+  unsigned *wv_cnt_f, *wv_cnt_b;
+  char *wv_ring_f[MAXL], *wv_ringd_f[MAXL], *wv_ring_b[MAXL];
+  float* wih_t[MAXL];
   size_t bytes;
 };
+
+// The pass runs its sweeps as the layer wavefront: asked for by the caller (B2T_GRU_WAVE on a persistent bf16 sweep mode in the bf16
+// GEMM regime) and a shape the kernels hold (all L x H / 16 workgroups resident).  Decided the same way by carve and by both passes.
+bool wave_pass(const b2t_model_t* m, const b2t_pass_t* p, int mode) {
+  const int Tp = m->patch > 0 ? (p->T - m->patch) / m->stride + 1 : p->T;
+  return (mode & B2T_GRU_WAVE) && (mode & 0xff) == 1 && (mode & B2T_GRU_BF16) && p->bf16_gemm && gru_wave_ok(m->L, Tp, p->B, m->H, nullptr);
+}
 
 size_t colsum_ws_floats(long long rows, int cols) { return b2t_colsum_ws_bytes(rows, cols) / sizeof(float); }
 
@@ -170,6 +181,15 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     w.pack_bytes = align_up(w.pack_bytes, 256);
     for (int q = 0; q < NPACK; ++q) { w.pack[q] = base + off; off += w.pack_bytes; }
   }
+  for (size_t l = 0; l < MAXL; ++l) { w.wv_ring_f[l] = w.wv_ringd_f[l] = w.wv_ring_b[l] = nullptr; w.wih_t[l] = nullptr; }
+  w.wv_cnt_f = w.wv_cnt_b = nullptr;
+  if (wave_pass(m, p, p->fwd_mode)) {
+    w.wv_cnt_f = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_fwd((int)L, (int)Tp, (int)B) * sizeof(unsigned), 256);
+    const size_t rb = align_up(gru_wave_ring_bytes_fwd((int)Tp, (int)B, (int)H), 256);
+    const bool drop = p->rnn_drop > 0.f && L > 1;
+    for (size_t l = 0; l < L; ++l) { w.wv_ring_f[l] = base + off; off += rb; w.wv_ringd_f[l] = w.wv_ring_f[l]; }
+    if (drop) for (size_t l = 0; l + 1 < L; ++l) { w.wv_ringd_f[l] = base + off; off += rb; }
+  }
   for (size_t l = 0; l < MAXL; ++l) w.wpk_f[l] = w.wpk_b[l] = nullptr;
   if (p->bf16_gemm)
     for (size_t l = 0; l < L; ++l) { w.wpk_f[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(3 * H), (int)(l == 0 ? In0 : H)), 256); }
@@ -186,6 +206,12 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
       w.xpk_ih[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(Tp * B)), 256);
     }
   for (size_t l = 0; l < L; ++l) w.res[l] = take(Tp * B * 4 * H);
+  if (wave_pass(m, p, p->bwd_mode)) {
+    w.wv_cnt_b = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_bwd((int)L, (int)Tp, (int)B) * sizeof(unsigned), 256);
+    const size_t rb = align_up(gru_wave_ring_bytes_bwd((int)Tp, (int)B, (int)H), 256);
+    for (size_t l = 0; l < L; ++l) { w.wv_ring_b[l] = base + off; off += rb; }
+    for (size_t l = 1; l < L; ++l) w.wih_t[l] = take(H * 3 * H);
+  }
   const size_t K = Tp * B;
   for (size_t l = 0; l < L; ++l) {
     w.dY[l] = take(Tp * B * H);
@@ -922,10 +948,13 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   const size_t sync_block = b2t_gru_sync_bytes(0);
   auto sync_of = [&](int l) { return sync_ws ? reinterpret_cast<char*>(sync_ws) + (size_t)l * sync_block : nullptr; };
 
+  // Round 6: the sweeps of all L layers as ONE launch, layer l + 1 a step or two behind layer l (gru_wave.hip); the projections of the
+  // layers >= 1 happen inside it.  One "chunk": nothing is pipelined over time any more.
+  const bool wave = wave_pass(prm, p, mode);
   int chunks[MAXC][2];
-  const int nc = make_chunks(Tp, p->chunks, chunks);
+  const int nc = make_chunks(Tp, wave ? 1 : p->chunks, chunks);
   c.exact_k = nc > 1;
-  c.nq = plan_queues(c, nc > 1, c.qs);   // the queues of this pass (the plan below refers to them by index)
+  c.nq = plan_queues(c, nc > 1 || wave, c.qs);   // the queues of this pass (the plan below refers to them by index)
   c.gkey = pass_key(1, prm, nullptr, p, {x, day_idx, states, logits, hidden, ws, sync_ws, stream}, {c.nq});
   const long long a_s0_l0 = prm->patch > 0 ? (long long)prm->stride * F : F;
   // rows x K that b2t_gemm_f32 serves with its skinny (weight-streaming) kernel: exact fp32 only, one frame of <= 64 utterances
@@ -982,7 +1011,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   bool wpk_ok[MAXL];
   for (int l = 0; l < L; ++l) {
     t_wpk[l] = -1; wpk_ok[l] = false;
-    if (!c.bf16_gemm || !prepack_env || !w.wpk_f[l] || fused_from(l - 1)) continue;
+    if (!c.bf16_gemm || !prepack_env || !w.wpk_f[l] || fused_from(l - 1) || (wave && l > 0)) continue;
     const int n0 = chunks[0][1] - chunks[0][0], nl = chunks[nc - 1][1] - chunks[nc - 1][0];
     b2t_gemm_desc d0 = gd(nullptr, prm->w_ih[l], nullptr, std::min(n0, nl) * B, 3 * H, l == 0 ? In0 : H);   // the smallest chunk decides
     if (!c.pack_shape_ok(d0) || (l == 0 && !((long long)std::min(n0, nl) * B > 512))) continue;
@@ -995,11 +1024,12 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   }
   const bool gi0_chain = c.bf16_gemm && In0 >= 2048 && nc > 1 && getenv("B2T_GI0_CHAIN") && atoi(getenv("B2T_GI0_CHAIN")) == 1;   // opt-in: measured slower
   int t_gi0_prev = -1;
+  int t_gi_l0 = -1;   // wavefront: layer 0's projection task (the only one)
   for (int l = 0; l < L; ++l) {
     for (int ci = 0; ci < nc; ++ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
       // 2. input projection gi = in_t W_ih^T + b_ih for this chunk, time-major [T'][B][3H]
-      const int t_gi = fused_from(l - 1) ? t_sw[l - 1][ci] :
+      const int t_gi = fused_from(l - 1) ? t_sw[l - 1][ci] : (wave && l > 0) ? -1 :
                        P.add("gi", est_gemm((double)n * B, 3 * H, l == 0 ? In0 : H), Q_ANY, {l == 0 ? t_day[ci] : t_sw[l - 1][ci], t_wpk[l]},
                              [&, l, t0, n](hipStream_t sg) {
         if (l == 0) {
@@ -1064,6 +1094,35 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       // first sweep waits for -- finishes after 290 us.  B2T_GI0_CHAIN=1 runs them one after the other: the first sweep then starts 150 us
       // earlier, and the step is SLOWER (5.85 against 5.81 ms: the later chunks' GEMMs now run next to the sweeps instead of in front of them).
       if (l == 0 && gi0_chain && !fused_from(l - 1)) { if (ci > 0 && t_gi0_prev >= 0) P.dep(t_gi, t_gi0_prev); t_gi0_prev = t_gi; }
+      if (wave) {
+        // 3w. the layer wavefront: one task for the whole stack, created with the top layer (it needs every layer's initial state)
+        if (l == 0) t_gi_l0 = t_gi;
+        if (l + 1 < L) { t_sw[l][ci] = -1; continue; }
+        const int t_ws = P.add("wsweep", 60.f + (Tp + 2 * L) * est_step_us(0) * hs, q_sweep, {t_gi_l0}, [&](hipStream_t ss) {
+          if (c.rc) return;
+          Ctx::Scope sc(c, ss, 8, 2.0 * Tp * B * 3.0 * H * H * (2 * L - 1));
+          WaveFwdArgs a;
+          memset(&a, 0, sizeof(a));
+          a.L = L; a.T = Tp; a.B = B; a.H = H; a.gi0 = w.gi[0];
+          const bool drop = p->rnn_drop > 0.f && L > 1;
+          for (int k = 0; k < L; ++k) {
+            a.w_hh[k] = prm->w_hh[k]; a.b_hh[k] = prm->b_hh[k]; a.w_ih[k] = prm->w_ih[k]; a.b_ih[k] = prm->b_ih[k];
+            a.h_init[k] = (states && !p->save) ? states + (size_t)k * B * H : w.out[k];
+            a.out[k] = w.out[k] + (long long)B * H;
+            a.outd[k] = (drop && k + 1 < L) ? w.outd[k] + (long long)B * H : nullptr;
+            a.reserve[k] = p->save ? w.res[k] : nullptr;
+            a.ring[k] = w.wv_ring_f[k]; a.ringd[k] = w.wv_ringd_f[k];
+            a.seed[k] = mix_seed(p->seed, 101 + k);
+          }
+          a.cnt = w.wv_cnt_f; a.err = reinterpret_cast<unsigned*>(sync_of(0));
+          a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;
+          c.call(gru_wave_fwd(a, ss));
+          for (int k = 0; k < L && !c.rc; ++k)
+            c.call(check_hip(hipMemcpyAsync(hidden + (size_t)k * B * H, w.out[k] + (long long)Tp * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, ss), "model_forward: final state"));
+        });
+        for (int k = 0; k < L; ++k) { t_sw[k][ci] = t_ws; P.dep(t_ws, t_init[k]); }
+        continue;
+      }
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
       t_sw[l][ci] = P.add("sweep", 40.f + n * est_step_us(0) * hs, q_sweep, {t_gi, ci > 0 ? t_sw[l][ci - 1] : t_init[l]}, [&, l, t0, t1, n, ci](hipStream_t ss) {
         if (c.rc) return;
@@ -1233,10 +1292,11 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   if (sync_ws) c.kcnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sync_ws) + (size_t)2 * L * sync_block) + 64;
   auto cb = [&](int id, hipStream_t s) { if (bucket_cb && !c.rc) bucket_cb(user, id, reinterpret_cast<void*>(s)); };
 
+  const bool wave = wave_pass(prm, p, mode) && w.wv_cnt_b;   // round 6: every layer's backward sweep in ONE launch (gru_wave.hip), dX of the layers >= 1 inside it
   int chunks[MAXC][2];
-  const int nc = make_chunks(Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks, chunks);
+  const int nc = make_chunks(Tp, wave ? 1 : (p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks), chunks);
   c.exact_k = nc > 1;
-  c.nq = plan_queues(c, nc > 1, c.qs);   // the queues of this pass (the plan below refers to them by index)
+  c.nq = plan_queues(c, nc > 1 || wave, c.qs);   // the queues of this pass (the plan below refers to them by index)
   // (data parallel: the bucket callbacks issue collectives from inside the plan -- not replayable)
   if (!bucket_cb) c.gkey = pass_key(2, prm, grd, p, {x, day_idx, dlogits, dhidden, dstates, ws, sync_ws, stream}, {c.nq, ldd, custom_states});
   // (One chunk -- shapes whose sweeps cannot be co-resident, e.g. H = 768 -- runs everything on the caller's stream.  Putting
@@ -1276,6 +1336,15 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       c.call(b2t_transpose_f32(prm->w_hh[l], w.whh_t[l], 3 * H, H, reinterpret_cast<void*>(s)));
     });
 
+  // wavefront: W_ih^T of the layers >= 1 (the B operand of dY[l - 1] = dGi[l] W_ih[l], made inside the sweep)
+  int t_wit[MAXL];
+  for (int l = 0; l < L; ++l) {
+    t_wit[l] = -1;
+    if (wave && l > 0)
+      t_wit[l] = P.add("wih_t", 8.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
+        c.call(b2t_transpose_f32(prm->w_ih[l], w.wih_t[l], 3 * H, H, reinterpret_cast<void*>(s)));
+      });
+  }
   // dIn = dGi W_ih for rows of chunk [t0, t0+n): into dY[l-1] (l > 0) or dU / dV (l == 0).
   // Day-layer backward chunk by chunk (no patching, no input dropout): the Softsign backward rides in the epilogue of
   // layer 0's dX GEMM, the per-sample day-gradient GEMM and bias sums accumulate chunk after chunk behind it, so that
@@ -1291,7 +1360,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   bool wpk_ok[MAXL];
   for (int l = 0; l < L; ++l) {
     t_wpk[l] = -1; wpk_ok[l] = false;
-    if (!c.bf16_gemm || !prepack_env || !w.wpk_b[l]) continue;
+    if (!c.bf16_gemm || !prepack_env || !w.wpk_b[l] || (wave && l > 0)) continue;
     const int nmin = std::min(chunks[0][1] - chunks[0][0], chunks[nc - 1][1] - chunks[nc - 1][0]);
     b2t_gemm_desc d0 = gd(nullptr, prm->w_ih[l], nullptr, nmin * B, l > 0 ? H : In0, 3 * H);
     d0.a_brk = 2 * H;
@@ -1341,12 +1410,35 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // Weight gradients: per chunk (bit l of wgrad_chunk_mask: the first chunk swept overwrites, the others accumulate in sweep
   // order -- a dependency chain, so the sums do not depend on the schedule) or once per layer after its last chunk.
   int t_bs[MAXL][MAXC], t_dx[MAXL][MAXC], t_wg_last[MAXL];
+  int t_wb = -1;   // wavefront: the one backward sweep task
   for (int l = L - 1; l >= 0; --l) {
     const bool per_chunk = nc > 1 && ((p->wgrad_chunk_mask >> l) & 1);
     const int In = l == 0 ? In0 : H;
     int t_wg = -1, t_wg_hh = -1, t_wg_ih = -1;
     for (int ci = nc - 1; ci >= 0; --ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
+      if (wave) {
+        // one task for the whole stack, created with the top layer (the first iteration)
+        if (l == L - 1) {
+          t_wb = P.add("wbsweep", 60.f + (Tp + 2 * L) * est_step_us(1) * hs, q_sweep, {t_top}, [&](hipStream_t ss) {
+            if (c.rc) return;
+            Ctx::Scope sc(c, ss, 9, 2.0 * Tp * B * 3.0 * H * H * (2 * L - 1));
+            WaveBwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.L = L; a.T = Tp; a.B = B; a.H = H; a.dY_top = w.dY[L - 1]; a.dh_last = dhidden; a.dh_init = w.dh_init;
+            const bool drop = p->rnn_drop > 0.f && L > 1;
+            for (int k = 0; k < L; ++k) {
+              a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k]; a.out[k] = w.out[k] + (long long)B * H;
+              a.reserve[k] = w.res[k]; a.dG[k] = w.dG[k]; a.ring[k] = w.wv_ring_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
+            }
+            a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
+            a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;
+            c.call(gru_wave_bwd(a, ss));
+          });
+          for (int k = 0; k < L; ++k) { P.dep(t_wb, t_wt[k]); P.dep(t_wb, t_wit[k]); }
+        }
+        t_bs[l][ci] = t_wb;
+      } else
       t_bs[l][ci] = P.add("bsweep", 40.f + n * est_step_us(1) * hs, q_sweep,
                           {l < L - 1 ? t_dx[l + 1][ci] : t_top, ci == nc - 1 ? t_wt[l] : t_bs[l][ci + 1]}, [&, l, ci, t0, n](hipStream_t ss) {
         void* ssp = reinterpret_cast<void*>(ss);
@@ -1367,6 +1459,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       else if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
+      if (wave && l > 0) t_dx[l][ci] = t_wb;   // made inside the sweep
+      else
       t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1, t_wpk[l]},
                           [&, l, t0, n](hipStream_t s) { dx_gemm(s, l, t0, n); });
       if (per_chunk || ci == 0) {

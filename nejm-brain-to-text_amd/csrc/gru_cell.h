@@ -79,6 +79,43 @@ int gru_persistent_bwd(const float* dY, const float* dh_last, const float* reser
                        const float* h_init, const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H,
                        void* sync_ws, hipStream_t s, bool bf16 = false, bool wide = false, int local = -1);
 
+// the layer wavefront (gru_wave.hip, round 6): all L sweeps of a direction in ONE launch, layer l + 1 a step or two behind layer l
+struct WaveFwdArgs {
+  int L, T, B, H;
+  const float* gi0;                                        // [T][B][3H]: layer 0's input projection (b_ih[0] included)
+  const float* w_hh[B2T_MAX_LAYERS]; const float* b_hh[B2T_MAX_LAYERS];
+  const float* w_ih[B2T_MAX_LAYERS]; const float* b_ih[B2T_MAX_LAYERS];   // layers >= 1 ([3H][H], [3H])
+  const float* h_init[B2T_MAX_LAYERS];                     // [B][H]
+  float* out[B2T_MAX_LAYERS];                              // [T][B][H]
+  float* outd[B2T_MAX_LAYERS];                             // dropout(out[l]) for the layer above's weight gradient (drop_p > 0, l < L - 1)
+  float* reserve[B2T_MAX_LAYERS];                          // [T][B][4H] = (r, z, n, gh_n), or null
+  char* ring[B2T_MAX_LAYERS]; char* ringd[B2T_MAX_LAYERS]; // fragment rings: slot 0..T of h / dropped h
+  unsigned* cnt;                                           // [L][2][row groups][T + 1], zeroed by the launcher
+  unsigned* err;                                           // sticky error word (a bounded spin gave up)
+  float drop_p, drop_scale; unsigned long long seed[B2T_MAX_LAYERS]; long long elem0;
+};
+struct WaveBwdArgs {
+  int L, T, B, H;
+  const float* dY_top;                                     // [T][B][H]: gradient wrt the top layer's outputs
+  const float* dh_last;                                    // [L][B][H] or null
+  float* dh_init;                                          // [L][B][H]
+  const float* w_hh_t[B2T_MAX_LAYERS];                     // [H][3H] = W_hh^T
+  const float* w_ih_t[B2T_MAX_LAYERS];                     // [H][3H] = W_ih^T of layers >= 1
+  const float* h_init[B2T_MAX_LAYERS]; const float* out[B2T_MAX_LAYERS]; const float* reserve[B2T_MAX_LAYERS];
+  float* dG[B2T_MAX_LAYERS];                               // [T][B][4H] = (dr, dz, dn r, dn)
+  char* ring[B2T_MAX_LAYERS];                              // fragment rings: slot t, 4 arrays
+  unsigned* cnt;                                           // [L][row groups][T]
+  unsigned* err;
+  float drop_p, drop_scale; unsigned long long seed[B2T_MAX_LAYERS]; long long elem0;
+};
+bool gru_wave_ok(int L, int T, int B, int H, const char** why);
+size_t gru_wave_ring_bytes_fwd(int T, int B, int H);
+size_t gru_wave_ring_bytes_bwd(int T, int B, int H);
+size_t gru_wave_cnt_words_fwd(int L, int T, int B);
+size_t gru_wave_cnt_words_bwd(int L, int T, int B);
+int gru_wave_fwd(const WaveFwdArgs& a, hipStream_t s);
+int gru_wave_bwd(const WaveBwdArgs& a, hipStream_t s);
+
 bool gru_persistent_bwd_pair_ok(int B, int H);
 int gru_persistent_bwd_pair(const float* dY, const float* dh_last, const float* reserve, const float* out, const float* h_init,
                             const float* w_hh_t, float* dG, float* dh_init, int T, int B, int H, void* sync_ws, hipStream_t s, int set);

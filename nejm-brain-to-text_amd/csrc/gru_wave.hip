@@ -1,0 +1,568 @@
+// gru_wave.hip — the step-granular LAYER WAVEFRONT of the GRU stack for gfx950 (round 6; bf16 operands, the reference's
+// `use_amp: true` regime: rnn_args.yaml:19, rnn_trainer.py:527; replaces nn.GRU(num_layers = L) at rnn_model.py:65-72,126).
+//
+// Until round 5 the L layers overlapped at time-CHUNK granularity: layer l + 1 swept chunk c while layer l swept chunk c + 1, a
+// projection GEMM and two queue hops between them, so the serial chain of a pass was (chunks + L - 1) stages of (steps + ~100 us).
+// Here ALL L sweeps of a direction are resident at once in ONE launch and layer l + 1 runs one or two time STEPS behind layer l:
+// the chain is T + ~1.5 (L - 1) steps.
+//
+// Decomposition.  A workgroup = (layer l, 16 hidden units) for ALL batch rows: wave w of its four owns row group w (16 rows) and
+// runs its recurrence on its own -- there is NO workgroup barrier in the step loop and no cross-wave reduction: a wave contracts
+// the whole K range itself, its slice of W_hh (forward: 48 x H; backward: W_hh^T, 16 x 3H) as bf16 B fragments in ITS registers
+// (H = 768: 288 registers per lane; one workgroup per CU, 512 registers per lane).  L x H / 16 workgroups: 160 at H = 512, 240 at
+// H = 768 -- every layer of the stack fits the chip at once at both bench shapes.
+//   * own recurrence (the chain): h_t of the layer's H / 16 workgroups is exchanged as bf16 MFMA A fragments of
+//     v_mfma_f32_16x16x32_bf16 through a ring in HBM/L2 (one slot per step; sc1 stores -> vmcnt(0) -> one agent-scope counter
+//     increment per (layer, row group, step); consumers poll that word, then sc1 loads straight into the MFMA's registers).
+//   * the NEXT layer's input projection is done by the CONSUMER: workgroup (l + 1, units) keeps its 48 x H slice of W_ih[l + 1] in
+//     LDS (72 KB at H = 768) and contracts layer l's ring fragments of step t with it -- between publishing its own h_{t-1} and
+//     the arrival of its peers' tiles, i.e. in the hand-off's shadow.  gi of the layers >= 1 never exists in memory; the projection
+//     GEMMs, their pack passes and every queue hop between the layers are gone.  nn.GRU's inter-layer dropout is applied by the
+//     PRODUCER (it holds the fp32 values: same Philox draws and the same rounding as dropout-then-pack), which publishes a second,
+//     dropped ring for the layer above and writes the dropped fp32 values the backward pass's weight-gradient GEMM reads.
+//   * backward is the mirror image: the chain contracts dGh_{t+1} (3H long) with the W_hh^T slice in registers; the gradient
+//     wrt the layer's output, dY[l]_t = dGi[l + 1]_t W_ih[l + 1], is made by the consumer from layer l + 1's ring with its W_ih^T
+//     slice in LDS (the input-gradient GEMMs of the layers >= 1 are gone too); fp32 dG is still written for the weight gradients.
+// K order: lane (j, q) of pair p holds hidden units 32 p + 8 q .. + 7 in both operands -- one 16-byte load is one MFMA operand.
+// Placement-independent: device-scope hand-off everywhere; all L x H / 16 workgroups must be resident (checked: <= CU count).
+#include "gru_cell.h"
+#include "gru_sync.h"
+
+namespace b2t {
+
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
+  bf16x8 r;
+  r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+  r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+  return r;
+}
+__device__ __forceinline__ bf16x8 zero8() { return __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Every lane of the wave polls the same word (one request per poll): no barrier follows -- the wave is its own recurrence.
+__device__ __forceinline__ void wave_wait(const unsigned* p, unsigned target, unsigned* err) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(p, RLX_AGENT) < target) {
+    if ((++spins & 255u) == 0u) {
+      if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+      if (spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// the wave's stores are acknowledged, then one lane bumps the counter
+__device__ __forceinline__ void wave_publish(unsigned* p, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(p, 1u, RLX_AGENT);
+}
+
+constexpr int WTP = 20;                    // pitch (floats) of a wave's staged 16 x 16 tile
+constexpr int WTILE_F = 16 * WTP;          // one tile
+constexpr int WAVE_TILES = 4;              // tiles per wave (backward: dr, dz, dn r, dn; forward: h, dropped h)
+
+// C layout of a 16 x 16 tile (lane (j, q): rows 4 q + i, column j) -> the wave's LDS tile
+__device__ __forceinline__ void tile_put(float* tile, const f32x4& v, int j, int q) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[(4 * q + i) * WTP + j] = v[i];
+}
+// ... and back as fragment halves: lane L' < 32 = (row L' & 15, unit group L' >> 4) reads 8 consecutive units of its row
+__device__ __forceinline__ u32x4 tile_frag(const float* tile, int lane) {
+  const float* s = tile + (lane & 15) * WTP + 8 * ((lane >> 4) & 1);
+  return __builtin_bit_cast(u32x4, cvt8(ld4(s), ld4(s + 4)));
+}
+
+// pair p of a row group's fragments: one 16-byte load per lane = one MFMA A operand (units 32 p + 8 q .. + 7 of row j)
+__device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int p, int P, int H, int lane, int q) {
+  const int pc = p < P ? p : P - 1;
+  // units past H (odd H / 16: the last pair's upper half) meet zero weights: those lanes re-read the lower half (finite data)
+  const unsigned lo = (32 * pc + 8 * q < H) ? (unsigned)lane * 16u : (unsigned)(lane & 31) * 16u;
+  return load_u4<16>(ring, base + (unsigned)pc * 1024u + lo);
+}
+// One operand stream: at most 12 loads in flight (48 registers), each slot refilled as soon as its MFMAs are issued; BODY sees
+// `av` (the A operand of pair `p`) -- all loads of a short stream go out before the first MFMA.
+#define B2T_WAVE_STREAM(RING, BASE, BODY)                                                                              \
+  {                                                                                                                    \
+    constexpr int LB_ = NP > 12 ? 12 : NP;                                                                             \
+    u32x4 v_[LB_];                                                                                                     \
+    _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q);                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                   \
+      if (p < P) {                                                                                                     \
+        const bf16x8 av = __builtin_bit_cast(bf16x8, v_[p % LB_]);                                                     \
+        if (p + LB_ < NP) v_[p % LB_] = load_frag(RING, BASE, p + LB_, P, H, lane, q);                                 \
+        BODY                                                                                                           \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NP, bool DROP>   // NP: pairs of 16-unit chunks per row (H <= 32 NP)
+__global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wave_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
+  const int layer = (int)blockIdx.x / G, slice = (int)blockIdx.x % G;
+  if (layer >= L) return;
+  const int u0 = slice * 16, unit = u0 + j;
+  u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer] slice as B fragments
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * P * 1024) + wave * (WAVE_TILES * WTILE_F);
+
+  bf16x8 w[3][NP];
+  {
+    const float* whh = a.w_hh[layer];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int k0 = 32 * p + 8 * q;
+      const bool ok = p < P && k0 < H;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float* src = whh + ((long long)g * H + unit) * H + (ok ? k0 : 0);
+        w[g][p] = ok ? cvt8(ld4(src), ld4(src + 4)) : zero8();
+      }
+    }
+  }
+  if (layer > 0) {
+    const float* wih = a.w_ih[layer];
+    for (int idx = wave; idx < 3 * P; idx += 4) {
+      const int g = idx / P, p = idx % P, k0 = 32 * p + 8 * q;
+      const bool ok = k0 < H;
+      const float* src = wih + ((long long)g * H + unit) * H + (ok ? k0 : 0);
+      wl[idx * 64 + lane] = ok ? __builtin_bit_cast(u32x4, cvt8(ld4(src), ld4(src + 4))) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  __syncthreads();
+  if (wave >= ngrp) return;
+  __builtin_amdgcn_s_setprio(3);
+
+  const int rg = wave, m0 = rg * 16;
+  unsigned* err = a.err;
+  const size_t cstride = (size_t)(T + 1);
+  unsigned* cnt_own = a.cnt + ((size_t)(layer * 2 + 0) * ngrp + rg) * cstride;
+  unsigned* cnt_ownd = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + rg) * cstride;
+  const bool feeds = layer + 1 < L;                 // a layer above reads this layer's outputs
+  const bool dropping = DROP && feeds;              // ... through nn.GRU's dropout
+  const unsigned* cnt_in = layer > 0 ? a.cnt + ((size_t)((layer - 1) * 2 + (DROP ? 1 : 0)) * ngrp + rg) * cstride : nullptr;
+  char* ring = a.ring[layer];
+  char* ringd = a.ringd[layer];
+  const char* ring_in = layer > 0 ? (DROP ? a.ringd[layer - 1] : a.ring[layer - 1]) : nullptr;
+  const unsigned slot_bytes = (unsigned)ngrp * (unsigned)P * 1024u, rg_off = (unsigned)rg * (unsigned)P * 1024u;
+  const unsigned my_frag = (unsigned)(slice >> 1) * 1024u + (unsigned)(slice & 1) * 512u + (unsigned)(lane & 31) * 16u;
+  const float bhr = a.b_hh[layer][unit], bhz = a.b_hh[layer][H + unit], bhn = a.b_hh[layer][2 * H + unit];
+  float bi[3] = {0.f, 0.f, 0.f};
+  if (layer > 0) { bi[0] = a.b_ih[layer][unit]; bi[1] = a.b_ih[layer][H + unit]; bi[2] = a.b_ih[layer][2 * H + unit]; }
+  bool live[4];
+  f32x4 hp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + 4 * q + i;
+    live[i] = row < B;
+    hp[i] = live[i] ? a.h_init[layer][(long long)row * H + unit] : 0.f;
+  }
+  // slot 0 of the ring = the initial state
+  tile_put(tiles, hp, j, q);
+  {
+    const u32x4 f = tile_frag(tiles, lane);
+    if (lane < 32) store_u4<16>(ring, rg_off + my_frag, f);
+    wave_publish(cnt_own, lane);
+  }
+
+  f32x4 gi[3];
+  // gi of step t from layer - 1's (dropped) h_t = slot t + 1 of its ring, W_ih slice from LDS
+  auto project = [&](int t) {
+    wave_wait(cnt_in + (t + 1), (unsigned)G, err);
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned pbase = (unsigned)(t + 1) * slot_bytes + rg_off;
+    B2T_WAVE_STREAM(ring_in, pbase, {
+      _Pragma("unroll") for (int g = 0; g < 3; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * P + p) * 64 + lane]), acc[g], 0, 0, 0);
+    })
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gi[g][i] = acc[g][i] + bi[g];
+  };
+  if (layer > 0) project(0);
+
+  for (int t = 0; t < T; ++t) {
+    if (layer == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* g3 = a.gi0 + ((long long)t * B + (m0 + 4 * q + i)) * 3 * H + unit;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gi[g][i] = live[i] ? __builtin_nontemporal_load(g3 + (long long)g * H) : 0.f;
+      }
+    }
+    wave_wait(cnt_own + t, (unsigned)G, err);
+    f32x4 gh[3];
+    {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gh[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned cbase = (unsigned)t * slot_bytes + rg_off;
+      B2T_WAVE_STREAM(ring, cbase, {
+        _Pragma("unroll") for (int g = 0; g < 3; ++g) gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], gh[g], 0, 0, 0);
+      })
+    }
+    f32x4 sr, sz, sn, sg, h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float ghn = gh[2][i] + bhn;
+      const float r = fast_sigmoid(gi[0][i] + gh[0][i] + bhr);
+      const float z = fast_sigmoid(gi[1][i] + gh[1][i] + bhz);
+      const float nn = fast_tanh(gi[2][i] + r * ghn);
+      h[i] = (1.0f - z) * nn + z * hp[i];
+      sr[i] = r; sz[i] = z; sn[i] = nn; sg[i] = ghn;
+    }
+    hp = h;
+    // publish h_t: slot t + 1
+    tile_put(tiles, h, j, q);
+    {
+      const u32x4 f = tile_frag(tiles, lane);
+      if (lane < 32) store_u4<16>(ring, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, f);
+      wave_publish(cnt_own + (t + 1), lane);
+    }
+    // fp32 copy (backward, weight gradients, head): lane (row L & 15, unit group L >> 4) stores 4 units
+    const int rrow = m0 + (lane & 15), kg = lane >> 4;
+    const float4 hv = ld4(tiles + (lane & 15) * WTP + 4 * kg);
+    if (dropping) {
+      // nn.GRU's dropout on the way to the layer above: flat element (t, row, unit) of this layer's output, as b2t_dropout_f32
+      const long long e = a.elem0 + ((long long)t * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
+      const float4 u = Philox::uniform4(a.seed[layer], (uint64_t)(e >> 2), 2u);
+      float4 hd;
+      hd.x = u.x >= a.drop_p ? hv.x * a.drop_scale : 0.f; hd.y = u.y >= a.drop_p ? hv.y * a.drop_scale : 0.f;
+      hd.z = u.z >= a.drop_p ? hv.z * a.drop_scale : 0.f; hd.w = u.w >= a.drop_p ? hv.w * a.drop_scale : 0.f;
+      float* td = tiles + WTILE_F;
+      *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = hd;
+      const u32x4 fd = tile_frag(td, lane);
+      if (lane < 32) store_u4<16>(ringd, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, fd);
+      wave_publish(cnt_ownd + (t + 1), lane);
+      if (rrow < B) *reinterpret_cast<float4*>(a.outd[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hd;
+    }
+    if (rrow < B) *reinterpret_cast<float4*>(a.out[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hv;
+    if (a.reserve[layer]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (live[i]) {
+          float* rs = a.reserve[layer] + ((long long)t * B + (m0 + 4 * q + i)) * 4 * H + unit;
+          __builtin_nontemporal_store(sr[i], rs); __builtin_nontemporal_store(sz[i], rs + H);
+          __builtin_nontemporal_store(sn[i], rs + 2 * H); __builtin_nontemporal_store(sg[i], rs + 3 * H);
+        }
+      }
+    }
+    if (layer > 0 && t + 1 < T) project(t + 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward.  Ring of layer l, slot t: the gate gradients of step t as fragments, 4 arrays (dr, dz, dn r, dn) x P pairs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NP, bool DROP>
+__global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wave_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
+  // the TOP layer starts the wavefront: it gets the first workgroups
+  const int layer = L - 1 - (int)blockIdx.x / G, slice = (int)blockIdx.x % G;
+  if (layer < 0) return;
+  const int u0 = slice * 16, unit = u0 + j;
+  u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer + 1]^T slice
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * P * 1024) + wave * (WAVE_TILES * WTILE_F);
+  const bool has_up = layer + 1 < L;
+
+  bf16x8 w[3][NP];     // W_hh^T slice: column `unit`, k = array * H + 32 p + 8 q .. + 7
+  {
+    const float* wt = a.w_hh_t[layer] + (long long)unit * 3 * H;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int k0 = 32 * p + 8 * q;
+      const bool ok = p < P && k0 < H;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float* src = wt + (long long)g * H + (ok ? k0 : 0);
+        w[g][p] = ok ? cvt8(ld4(src), ld4(src + 4)) : zero8();
+      }
+    }
+  }
+  if (has_up) {
+    const float* wt = a.w_ih_t[layer + 1] + (long long)unit * 3 * H;
+    for (int idx = wave; idx < 3 * P; idx += 4) {
+      const int g = idx / P, p = idx % P, k0 = 32 * p + 8 * q;
+      const bool ok = k0 < H;
+      const float* src = wt + (long long)g * H + (ok ? k0 : 0);
+      wl[idx * 64 + lane] = ok ? __builtin_bit_cast(u32x4, cvt8(ld4(src), ld4(src + 4))) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  __syncthreads();
+  if (wave >= ngrp) return;
+  __builtin_amdgcn_s_setprio(3);
+
+  const int rg = wave, m0 = rg * 16;
+  unsigned* err = a.err;
+  const size_t cstride = (size_t)T;
+  unsigned* cnt_own = a.cnt + ((size_t)layer * ngrp + rg) * cstride;
+  const unsigned* cnt_up = has_up ? a.cnt + ((size_t)(layer + 1) * ngrp + rg) * cstride : nullptr;
+  char* ring = a.ring[layer];
+  const char* ring_up = has_up ? a.ring[layer + 1] : nullptr;
+  const unsigned arr_bytes = (unsigned)P * 1024u, rg_bytes = 4u * arr_bytes, slot_bytes = (unsigned)ngrp * rg_bytes, rg_off = (unsigned)rg * rg_bytes;
+  const unsigned my_frag = (unsigned)(slice >> 1) * 1024u + (unsigned)(slice & 1) * 512u + (unsigned)(lane & 31) * 16u;
+  bool live[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) live[i] = m0 + 4 * q + i < B;
+  const int rrow = m0 + (lane & 15), kg = lane >> 4;   // the (row, 4-unit group) this lane handles in row-major passes
+
+  f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dY[layer]_t = dGi[layer + 1]_t . W_ih[layer + 1][:, units] (arrays dr, dz, dn of the ring above), then the dropout mask
+  auto project = [&](int t) {
+    wave_wait(cnt_up + t, (unsigned)G, err);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const unsigned pbase = (unsigned)t * slot_bytes + rg_off + (unsigned)(g == 2 ? 3 : g) * arr_bytes;
+      B2T_WAVE_STREAM(ring_up, pbase, {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * P + p) * 64 + lane]), acc, 0, 0, 0);
+      })
+    }
+    if (DROP) {
+      // the mask of the forward's dropout on out[layer]: row-major through the wave's tile (one Philox block per lane)
+      float* td = tiles;
+      tile_put(td, acc, j, q);
+      float4 v4 = ld4(td + (lane & 15) * WTP + 4 * kg);
+      const long long e = a.elem0 + ((long long)t * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
+      const float4 u = Philox::uniform4(a.seed[layer], (uint64_t)(e >> 2), 2u);
+      v4.x = u.x >= a.drop_p ? v4.x * a.drop_scale : 0.f; v4.y = u.y >= a.drop_p ? v4.y * a.drop_scale : 0.f;
+      v4.z = u.z >= a.drop_p ? v4.z * a.drop_scale : 0.f; v4.w = u.w >= a.drop_p ? v4.w * a.drop_scale : 0.f;
+      *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = v4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = td[(4 * q + i) * WTP + j];
+    }
+    dy = acc;
+  };
+  if (has_up) project(T - 1);
+
+  f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = T - 1; t >= -1; --t) {
+    f32x4 r, z, nv, ghn, hprev;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[i] = z[i] = nv[i] = ghn[i] = hprev[i] = 0.f;
+      if (live[i] && t >= 0) {
+        const int row = m0 + 4 * q + i;
+        const float* rs = a.reserve[layer] + ((long long)t * B + row) * 4 * H + unit;
+        r[i] = __builtin_nontemporal_load(rs); z[i] = __builtin_nontemporal_load(rs + H);
+        nv[i] = __builtin_nontemporal_load(rs + 2 * H); ghn[i] = __builtin_nontemporal_load(rs + 3 * H);
+        hprev[i] = t > 0 ? a.out[layer][((long long)(t - 1) * B + row) * H + unit] : a.h_init[layer][(long long)row * H + unit];
+        if (!has_up) dy[i] = __builtin_nontemporal_load(a.dY_top + ((long long)t * B + row) * H + unit);
+      }
+    }
+    f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < T - 1) {
+      wave_wait(cnt_own + (t + 1), (unsigned)G, err);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const unsigned cbase = (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes;
+        B2T_WAVE_STREAM(ring, cbase, {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc, 0, 0, 0);
+        })
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) carry[i] = acc[i] + dzterm[i];
+    } else if (a.dh_last) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (live[i]) carry[i] = a.dh_last[((long long)layer * B + (m0 + 4 * q + i)) * H + unit];
+    }
+    if (t < 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (live[i]) a.dh_init[((long long)layer * B + (m0 + 4 * q + i)) * H + unit] = carry[i];
+      break;
+    }
+    f32x4 g0, g1, g2, g3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float d = dy[i] + carry[i];
+      const float dn = d * (1.0f - z[i]);
+      const float dz = d * (hprev[i] - nv[i]);
+      const float dn_pre = dn * (1.0f - nv[i] * nv[i]);
+      const float dz_pre = dz * z[i] * (1.0f - z[i]);
+      const float dr_pre = dn_pre * ghn[i] * r[i] * (1.0f - r[i]);
+      g0[i] = dr_pre; g1[i] = dz_pre; g2[i] = dn_pre * r[i]; g3[i] = dn_pre;
+      dzterm[i] = d * z[i];
+    }
+    tile_put(tiles + 0 * WTILE_F, g0, j, q); tile_put(tiles + 1 * WTILE_F, g1, j, q);
+    tile_put(tiles + 2 * WTILE_F, g2, j, q); tile_put(tiles + 3 * WTILE_F, g3, j, q);
+    {
+      // lanes 0-31 publish arrays 0 and 2, lanes 32-63 arrays 1 and 3
+      const int a0 = lane >> 5;
+      const u32x4 f0 = tile_frag(tiles + a0 * WTILE_F, lane), f1 = tile_frag(tiles + (a0 + 2) * WTILE_F, lane);
+      const unsigned base = (unsigned)t * slot_bytes + rg_off + my_frag;
+      store_u4<16>(ring, base + (unsigned)a0 * arr_bytes, f0);
+      store_u4<16>(ring, base + (unsigned)(a0 + 2) * arr_bytes, f1);
+      wave_publish(cnt_own + t, lane);
+    }
+    if (rrow < B) {
+      float* dg = a.dG[layer] + ((long long)t * B + rrow) * 4 * H + u0 + 4 * kg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dg + (long long)g * H) = ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg);
+    }
+    if (has_up && t > 0) project(t - 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static int wave_cus() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    n = p.multiProcessorCount;
+  }
+  return n;
+}
+
+size_t gru_wave_lds_bytes(int H) { const int P = (H / 16 + 1) / 2; return (size_t)3 * P * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
+size_t gru_wave_ring_bytes_fwd(int T, int B, int H) { return (size_t)(T + 1) * ((B + 15) / 16) * ((H / 16 + 1) / 2) * 1024; }
+size_t gru_wave_ring_bytes_bwd(int T, int B, int H) { return (size_t)T * ((B + 15) / 16) * 4 * ((H / 16 + 1) / 2) * 1024; }
+size_t gru_wave_cnt_words_fwd(int L, int T, int B) { return (size_t)L * 2 * ((B + 15) / 16) * (T + 1); }
+size_t gru_wave_cnt_words_bwd(int L, int T, int B) { return (size_t)L * ((B + 15) / 16) * T; }
+
+// Shapes the wavefront serves; `why` (optional) receives the reason when it does not.
+bool gru_wave_ok(int L, int T, int B, int H, const char** why) {
+  const char* w = nullptr;
+  if (L < 1 || L > B2T_MAX_LAYERS) w = "layer count";
+  else if (H % 16 != 0 || H < 16 || H > 768) w = "H must be a multiple of 16, <= 768";
+  else if (B < 1 || B > 64) w = "B must be <= 64 (one wave per row group)";
+  else if (T < 1) w = "T";
+  else if ((long long)L * (H / 16) > wave_cus()) w = "L x H / 16 workgroups exceed the CUs (all layers must be resident)";
+  else if (gru_wave_ring_bytes_bwd(T, B, H) >= ((size_t)1 << 31) || gru_wave_ring_bytes_fwd(T, B, H) >= ((size_t)1 << 31)) w = "ring of one layer must stay below 2 GB";
+  if (why) *why = w;
+  return w == nullptr;
+}
+
+template <typename K> static int wave_lds_attr(K kernel, size_t bytes) {
+  return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "gru_wave: LDS size");
+}
+
+int gru_wave_fwd(const WaveFwdArgs& a, hipStream_t s) {
+  const char* why = nullptr;
+  if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_fwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
+  const bool drop = a.drop_p > 0.f && a.L > 1;
+  const size_t lds = gru_wave_lds_bytes(a.H);
+  int rc = check_hip(hipMemsetAsync(a.cnt, 0, gru_wave_cnt_words_fwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_fwd: counters");
+  if (rc) return rc;
+  const dim3 grid(a.L * (a.H / 16)), block(256);
+#define B2T_WAVE_FWD(NPV)                                                                                              \
+  do {                                                                                                                 \
+    if (drop) { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_fwd_kernel<NPV, true>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
+                hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, true>), grid, block, lds, s, a); }                        \
+    else { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_fwd_kernel<NPV, false>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
+           hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, false>), grid, block, lds, s, a); }                            \
+  } while (0)
+  if (a.H <= 128) B2T_WAVE_FWD(4);
+  else if (a.H <= 256) B2T_WAVE_FWD(8);
+  else if (a.H <= 512) B2T_WAVE_FWD(16);
+  else B2T_WAVE_FWD(24);
+#undef B2T_WAVE_FWD
+  return check_hip(hipGetLastError(), "gru_wave_fwd");
+}
+
+int gru_wave_bwd(const WaveBwdArgs& a, hipStream_t s) {
+  const char* why = nullptr;
+  if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_bwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
+  const bool drop = a.drop_p > 0.f && a.L > 1;
+  const size_t lds = gru_wave_lds_bytes(a.H);
+  int rc = check_hip(hipMemsetAsync(a.cnt, 0, gru_wave_cnt_words_bwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_bwd: counters");
+  if (rc) return rc;
+  const dim3 grid(a.L * (a.H / 16)), block(256);
+#define B2T_WAVE_BWD(NPV)                                                                                              \
+  do {                                                                                                                 \
+    if (drop) { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, true>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
+                hipLaunchKernelGGL((gru_wave_bwd_kernel<NPV, true>), grid, block, lds, s, a); }                        \
+    else { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, false>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
+           hipLaunchKernelGGL((gru_wave_bwd_kernel<NPV, false>), grid, block, lds, s, a); }                            \
+  } while (0)
+  if (a.H <= 128) B2T_WAVE_BWD(4);
+  else if (a.H <= 256) B2T_WAVE_BWD(8);
+  else if (a.H <= 512) B2T_WAVE_BWD(16);
+  else B2T_WAVE_BWD(24);
+#undef B2T_WAVE_BWD
+  return check_hip(hipGetLastError(), "gru_wave_bwd");
+}
+
+}  // namespace b2t
+
+using namespace b2t;
+
+// ---- C ABI: the stack's sweeps as one launch per direction (include/b2t.h) --------------------------------------------------
+static size_t wave_align(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" int b2t_gru_wave_supported(int L, int T, int B, int H) { return gru_wave_ok(L, T, B, H, nullptr) ? 1 : 0; }
+
+extern "C" size_t b2t_gru_wave_ws_bytes(int L, int T, int B, int H, int backward, int dropout) {
+  if (L < 1 || L > B2T_MAX_LAYERS || T < 1 || B < 1 || H < 16) return 0;
+  const size_t cnt = wave_align((backward ? gru_wave_cnt_words_bwd(L, T, B) : gru_wave_cnt_words_fwd(L, T, B)) * sizeof(unsigned) + 64);
+  const size_t ring = wave_align(backward ? gru_wave_ring_bytes_bwd(T, B, H) : gru_wave_ring_bytes_fwd(T, B, H));
+  return cnt + (size_t)L * ring * ((!backward && dropout) ? 2 : 1);
+}
+
+// carve(ws): [error word + counters][ring per layer]([dropped ring per layer])
+static void wave_carve(char* ws, int L, int T, int B, int H, bool backward, bool dropout, unsigned*& err, unsigned*& cnt, char** ring, char** ringd) {
+  err = reinterpret_cast<unsigned*>(ws);
+  cnt = err + 16;
+  const size_t cb = wave_align((backward ? gru_wave_cnt_words_bwd(L, T, B) : gru_wave_cnt_words_fwd(L, T, B)) * sizeof(unsigned) + 64);
+  const size_t rb = wave_align(backward ? gru_wave_ring_bytes_bwd(T, B, H) : gru_wave_ring_bytes_fwd(T, B, H));
+  char* p = ws + cb;
+  for (int l = 0; l < L; ++l) { ring[l] = p; p += rb; }
+  for (int l = 0; l < L; ++l) { if (ringd) { ringd[l] = (!backward && dropout) ? p : ring[l]; if (!backward && dropout) p += rb; } }
+}
+
+extern "C" int b2t_gru_wave_fwd_f32(const b2t_wave_t* d, void* ws, unsigned* err_word, void* stream) {
+  B2T_REQUIRE(d && ws && err_word, "gru_wave_fwd: null argument");
+  const int L = d->L, T = d->T, B = d->B, H = d->H;
+  B2T_REQUIRE(gru_wave_ok(L, T, B, H, nullptr), "gru_wave_fwd: unsupported shape L=%d T=%d B=%d H=%d", L, T, B, H);
+  B2T_REQUIRE(d->gi0 && d->drop_p >= 0.f && d->drop_p < 1.f, "gru_wave_fwd: gi0 / dropout");
+  WaveFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.L = L; a.T = T; a.B = B; a.H = H; a.gi0 = d->gi0;
+  const bool drop = d->drop_p > 0.f && L > 1;
+  unsigned* e0 = nullptr;
+  wave_carve(reinterpret_cast<char*>(ws), L, T, B, H, false, drop, e0, a.cnt, a.ring, a.ringd);
+  a.err = err_word;
+  for (int l = 0; l < L; ++l) {
+    B2T_REQUIRE(d->w_hh[l] && d->b_hh[l] && d->h_init[l] && d->out[l] && (l == 0 || (d->w_ih[l] && d->b_ih[l])), "gru_wave_fwd: null tensor of layer %d", l);
+    B2T_REQUIRE(!drop || l + 1 == L || d->outd[l], "gru_wave_fwd: dropout needs outd[%d]", l);
+    a.w_hh[l] = d->w_hh[l]; a.b_hh[l] = d->b_hh[l]; a.w_ih[l] = d->w_ih[l]; a.b_ih[l] = d->b_ih[l];
+    a.h_init[l] = d->h_init[l]; a.out[l] = d->out[l]; a.outd[l] = d->outd[l]; a.reserve[l] = d->reserve[l];
+    a.seed[l] = d->seed[l];
+  }
+  a.drop_p = drop ? d->drop_p : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - d->drop_p) : 1.f; a.elem0 = d->elem0;
+  return gru_wave_fwd(a, as_stream(stream));
+}
+
+extern "C" int b2t_gru_wave_bwd_f32(const b2t_wave_t* d, void* ws, unsigned* err_word, void* stream) {
+  B2T_REQUIRE(d && ws && err_word, "gru_wave_bwd: null argument");
+  const int L = d->L, T = d->T, B = d->B, H = d->H;
+  B2T_REQUIRE(gru_wave_ok(L, T, B, H, nullptr), "gru_wave_bwd: unsupported shape L=%d T=%d B=%d H=%d", L, T, B, H);
+  B2T_REQUIRE(d->dY_top && d->dh_init && d->drop_p >= 0.f && d->drop_p < 1.f, "gru_wave_bwd: dY_top / dh_init / dropout");
+  WaveBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.L = L; a.T = T; a.B = B; a.H = H; a.dY_top = d->dY_top; a.dh_last = d->dh_last; a.dh_init = d->dh_init;
+  const bool drop = d->drop_p > 0.f && L > 1;
+  unsigned* e0 = nullptr;
+  wave_carve(reinterpret_cast<char*>(ws), L, T, B, H, true, false, e0, a.cnt, a.ring, nullptr);
+  a.err = err_word;
+  for (int l = 0; l < L; ++l) {
+    B2T_REQUIRE(d->w_hh_t[l] && d->h_init[l] && d->out[l] && d->reserve[l] && d->dG[l] && (l == 0 || d->w_ih_t[l]), "gru_wave_bwd: null tensor of layer %d", l);
+    a.w_hh_t[l] = d->w_hh_t[l]; a.w_ih_t[l] = d->w_ih_t[l]; a.h_init[l] = d->h_init[l]; a.out[l] = d->out[l];
+    a.reserve[l] = d->reserve[l]; a.dG[l] = d->dG[l]; a.seed[l] = d->seed[l];
+  }
+  a.drop_p = drop ? d->drop_p : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - d->drop_p) : 1.f; a.elem0 = d->elem0;
+  return gru_wave_bwd(a, as_stream(stream));
+}

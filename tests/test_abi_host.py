@@ -296,7 +296,7 @@ def test_convert_all_to_inputs_matches_the_scalar_form():
 
 
 @pytest.mark.parametrize("cls,ctype", [("GemmDesc", "b2t_gemm_desc"), ("ModelDesc", "b2t_model_t"), ("PassDesc", "b2t_pass_t"),
-                                       ("WfstGraph", "b2t_wfst_graph_t"), ("WfstOpts", "b2t_wfst_opts_t"), ("LexLmDesc", "b2t_lexlm_t")])
+                                       ("WfstGraph", "b2t_wfst_graph_t"), ("WfstOpts", "b2t_wfst_opts_t"), ("LexLmDesc", "b2t_lexlm_t"), ("WaveDesc", "b2t_wave_t")])
 def test_struct_layouts_match_the_header(tmp_path, cls, ctype):
     """The ctypes mirrors in b2t_native against the C compiler's view of include/b2t.h: size and the offset of every
     (scalar or pointer) field -- a field added to one side only would silently shift everything behind it."""
