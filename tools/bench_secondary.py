@@ -266,6 +266,30 @@ def trainer_loop_c2():
                          "(160-step run - 40-step run) / 120")
 
 
+def trainer_loop_c3_amp():
+    """BASELINE configs[2] through the trainer in its shipped regime (round-5 verdict item 3): BrainToTextDecoder_Trainer.train() with
+    the model block of rnn_args.yaml (H 768, patch 14 / 4, dropout 0.4 / 0.2, 45 sessions, 4 days per batch) and `use_amp: true`, on a
+    device-resident synthetic dataset; (160-step run - 40-step run) / 120 as trainer_loop_c2_f32 does."""
+    import contextlib, io, logging
+    import bench_trainer
+    logging.disable(logging.CRITICAL)
+    old = ops.AMP["on"]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            bench_trainer.run(12, amp=True, shipped=True)
+            t0, _ = bench_trainer.run(40, amp=True, shipped=True)
+            t1, st = bench_trainer.run(160, amp=True, shipped=True)
+    finally:
+        logging.disable(logging.NOTSET)
+        ops.set_amp(old)
+    ms = (t1 - t0) / 120 * 1e3
+    return dict(ms_per_step=round(ms, 3), sentences_per_s=round(64e3 / ms, 1), final_loss=float(st['train_losses'][-1]),
+                dtype="bf16 matmul + recurrent-product operands, f32 accumulate / gates / CTC / optimizer (use_amp: true)",
+                workload="BrainToTextDecoder_Trainer.train() (rnn_trainer.py:486-651 counterpart) with the shipped rnn_args.yaml model block: 5-layer "
+                         "GRU-768, patch 14/4, dropout 0.4/0.2, use_amp, B=64, T=500, 45 sessions, 4 days per batch, device-resident synthetic "
+                         "dataset, on-GPU augmentation, lagged loss read, logging; (160-step run - 40-step run) / 120")
+
+
 def dp_forced_one_rank(steps: int = 30):
     """What one GPU can say about the data-parallel step (round-3 verdict, item 7a): bench.py in a ONE-rank RCCL group with
     B2T_DP_FORCE=1 runs every collective of the N-rank step -- the bucketed all-reduces launched from the executor's bucket
@@ -349,7 +373,7 @@ def all_secondary():
     out = {}
     for name, fn in (("c3_f32", lambda: train_ms("c3", False)), ("c3_amp", lambda: train_ms("c3", True)),
                      ("c2_amp", lambda: train_ms("c2", True)), ("c2_f32_shipped_dropout", lambda: train_ms("c2drop", False)),
-                     ("trainer_loop_c2_f32", trainer_loop_c2),
+                     ("trainer_loop_c2_f32", trainer_loop_c2), ("trainer_loop_c3_amp", trainer_loop_c3_amp),
                      ("dp_forced_one_rank", dp_forced_one_rank),
                      ("decode_beam100_3gram", decode_beam100_3gram),
                      ("stream_32utt_5gram", stream_32utt_5gram), ("decode_wfst_tlg", decode_wfst_tlg)):

@@ -10,12 +10,14 @@ for p in (os.path.join(ROOT, "nejm-brain-to-text_amd"), ROOT):
 import torch
 
 
-def make_args(tmp, n_batches, amp=False):
+def make_args(tmp, n_batches, amp=False, shipped=False):
     sessions = [f"t15.2023.{8 + d // 28:02d}.{1 + d % 28:02d}" for d in range(45)]
+    # shipped: the model block of the reference's rnn_args.yaml (model_training/rnn_args.yaml: n_units 768, patch 14 / 4, rnn_dropout 0.4,
+    # input_layer_dropout 0.2) -- BASELINE configs[2]'s shape -- instead of configs[1]'s
     return {
-        'model': {'n_input_features': 512, 'n_units': 512, 'rnn_dropout': 0.0, 'rnn_trainable': True, 'n_layers': 5,
-                  'patch_size': 0, 'patch_stride': 0,
-                  'input_network': {'n_input_layers': 1, 'input_layer_sizes': [512], 'input_trainable': True, 'input_layer_dropout': 0.0}},
+        'model': {'n_input_features': 512, 'n_units': 768 if shipped else 512, 'rnn_dropout': 0.4 if shipped else 0.0, 'rnn_trainable': True, 'n_layers': 5,
+                  'patch_size': 14 if shipped else 0, 'patch_stride': 4 if shipped else 0,
+                  'input_network': {'n_input_layers': 1, 'input_layer_sizes': [512], 'input_trainable': True, 'input_layer_dropout': 0.2 if shipped else 0.0}},
         'gpu_number': '0', 'mode': 'train', 'use_amp': amp,
         'output_dir': os.path.join(tmp, 'out'), 'checkpoint_dir': os.path.join(tmp, 'out', 'checkpoint'),
         'init_from_checkpoint': False, 'init_checkpoint_path': None, 'save_best_checkpoint': False,
@@ -37,10 +39,11 @@ def make_args(tmp, n_batches, amp=False):
     }
 
 
-def run(n):
+def run(n, amp=None, shipped=False):
     from rnn_trainer import BrainToTextDecoder_Trainer
     with tempfile.TemporaryDirectory() as tmp:
-        tr = BrainToTextDecoder_Trainer(make_args(tmp, n, amp=bool(int(os.environ.get("B2T_TRAINER_AMP", "0")))))
+        amp = bool(int(os.environ.get("B2T_TRAINER_AMP", "0"))) if amp is None else amp
+        tr = BrainToTextDecoder_Trainer(make_args(tmp, n, amp=amp, shipped=shipped))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         stats = tr.train()
         torch.cuda.synchronize()

@@ -19,3 +19,9 @@ for shape in ("c3", "c2"):
             print("R6AMP", shape, "wave=" + wave, "ERROR", repr(e)[:300], flush=True)
 PY
 timeout 900 python /tmp/amp_ab.py > $O/amp_ab.txt 2>&1; grep R6AMP $O/amp_ab.txt | tee -a $O/summary.txt; tail -5 $O/amp_ab.txt
+# timelines of the fp32 headline step, healthy against an emulated slow host (verdict item 1d)
+export B2T_BENCH_NO_RESTART=1
+bash tools/prof_tl.sh r6_fp32_plain X=1 > /dev/null 2>&1
+bash tools/prof_tl.sh r6_fp32_delay5 B2T_EXEC_HOST_DELAY_US=5 > /dev/null 2>&1
+head -3 gpurun_out/tl_r6_fp32_plain.txt gpurun_out/tl_r6_fp32_delay5.txt
+grep -h "ms_per_step" gpurun_out/tl_r6_fp32_plain.log gpurun_out/tl_r6_fp32_delay5.log | cut -c1-200
