@@ -93,6 +93,7 @@ struct WaveFwdArgs {
   unsigned* cnt;                                           // [L][2][row groups][T + 1], zeroed by the launcher
   unsigned* err;                                           // sticky error word (a bounded spin gave up)
   float drop_p, drop_scale; unsigned long long seed[B2T_MAX_LAYERS]; long long elem0;
+  int flags;                                               // bit 0: sc1 fragment loads (A/B knob)
 };
 struct WaveBwdArgs {
   int L, T, B, H;
@@ -107,6 +108,7 @@ struct WaveBwdArgs {
   unsigned* cnt;                                           // [L][row groups][T]
   unsigned* err;
   float drop_p, drop_scale; unsigned long long seed[B2T_MAX_LAYERS]; long long elem0;
+  int flags;                                               // bit 0: sc1 fragment loads (A/B knob)
 };
 bool gru_wave_ok(int L, int T, int B, int H, const char** why);
 size_t gru_wave_ring_bytes_fwd(int T, int B, int H);

@@ -27,6 +27,7 @@
 // Placement-independent: device-scope hand-off everywhere; all L x H / 16 workgroups must be resident (checked: <= CU count).
 #include "gru_cell.h"
 #include "gru_sync.h"
+#include <stdlib.h>
 
 namespace b2t {
 
@@ -74,11 +75,17 @@ __device__ __forceinline__ u32x4 tile_frag(const float* tile, int lane) {
 }
 
 // pair p of a row group's fragments: one 16-byte load per lane = one MFMA A operand (units 32 p + 8 q .. + 7 of row j)
-__device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int p, int P, int H, int lane, int q) {
+// Cache policy of the fragment loads.  The tiles are written through to memory (sc1 stores, acknowledged before the counter moves)
+// and every ring address is written ONCE per launch and read only after its counter is complete: a line a consumer's L2 / vector
+// cache fetches is final, and neither cache can hold an older copy (both are invalidated when the kernel starts).  So ORDINARY loads
+// are safe across XCDs -- the first consumer on an XCD brings the line into that L2, the other 31 CUs hit it at L2 speed -- where
+// sc1 loads go to memory every time at ~10 B per clock and CU (measured: 6.6 / 12.7 us per step at C2, NOTES.md R6.2).
+// g_wave_plain: set from B2T_WAVE_SC1_LOADS (A/B knob) by the launcher.
+__device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int p, int P, int H, int lane, int q, bool plain = true) {
   const int pc = p < P ? p : P - 1;
   // units past H (odd H / 16: the last pair's upper half) meet zero weights: those lanes re-read the lower half (finite data)
   const unsigned lo = (32 * pc + 8 * q < H) ? (unsigned)lane * 16u : (unsigned)(lane & 31) * 16u;
-  return load_u4<16>(ring, base + (unsigned)pc * 1024u + lo);
+  return plain ? load_u4<0>(ring, base + (unsigned)pc * 1024u + lo) : load_u4<16>(ring, base + (unsigned)pc * 1024u + lo);
 }
 // One operand stream: at most 12 loads in flight (48 registers), each slot refilled as soon as its MFMAs are issued; BODY sees
 // `av` (the A operand of pair `p`) -- all loads of a short stream go out before the first MFMA.
@@ -86,12 +93,12 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
   {                                                                                                                    \
     constexpr int LB_ = NP > 12 ? 12 : NP;                                                                             \
     u32x4 v_[LB_];                                                                                                     \
-    _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q);                  \
+    _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q, plain_);                  \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                   \
       if (p < P) {                                                                                                     \
         const bf16x8 av = __builtin_bit_cast(bf16x8, v_[p % LB_]);                                                     \
-        if (p + LB_ < NP) v_[p % LB_] = load_frag(RING, BASE, p + LB_, P, H, lane, q);                                 \
+        if (p + LB_ < NP) v_[p % LB_] = load_frag(RING, BASE, p + LB_, P, H, lane, q, plain_);                                 \
         BODY                                                                                                           \
       }                                                                                                                \
     }                                                                                                                  \
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   extern __shared__ __attribute__((aligned(16))) char wave_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
+  const bool plain_ = (a.flags & 1) == 0;
   const int layer = (int)blockIdx.x / G, slice = (int)blockIdx.x % G;
   if (layer >= L) return;
   const int u0 = slice * 16, unit = u0 + j;
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
   extern __shared__ __attribute__((aligned(16))) char wave_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
+  const bool plain_ = (a.flags & 1) == 0;
   // the TOP layer starts the wavefront: it gets the first workgroups
   const int layer = L - 1 - (int)blockIdx.x / G, slice = (int)blockIdx.x % G;
   if (layer < 0) return;
@@ -450,7 +459,14 @@ template <typename K> static int wave_lds_attr(K kernel, size_t bytes) {
   return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "gru_wave: LDS size");
 }
 
-int gru_wave_fwd(const WaveFwdArgs& a, hipStream_t s) {
+static int wave_flags() {   // read per call (A/B in one process): bit 0 = sc1 (memory-side) fragment loads
+  const char* e = getenv("B2T_WAVE_SC1_LOADS");
+  return (e && atoi(e) != 0) ? 1 : 0;
+}
+
+int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
+  WaveFwdArgs a = a_in;
+  a.flags = wave_flags();
   const char* why = nullptr;
   if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_fwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
   const bool drop = a.drop_p > 0.f && a.L > 1;
@@ -473,7 +489,9 @@ int gru_wave_fwd(const WaveFwdArgs& a, hipStream_t s) {
   return check_hip(hipGetLastError(), "gru_wave_fwd");
 }
 
-int gru_wave_bwd(const WaveBwdArgs& a, hipStream_t s) {
+int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
+  WaveBwdArgs a = a_in;
+  a.flags = wave_flags();
   const char* why = nullptr;
   if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_bwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
   const bool drop = a.drop_p > 0.f && a.L > 1;

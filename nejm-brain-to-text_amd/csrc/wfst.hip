@@ -2574,6 +2574,11 @@ extern "C" int b2t_wfst_finalize(const b2t_wfst_graph_t* g, const b2t_wfst_opts_
   {   // the utterance's cluster finalizes where the cluster searched (B2T_WFST_FIN_CLUSTER=0, read per call: one workgroup per utterance)
     const char* e = getenv("B2T_WFST_FIN_CLUSTER");
     const int G = (e && atoi(e) == 0) ? 1 : b2t_wfst_cluster_size(U);
+    // (cluster kernels spin on L2 barriers: the launch must be fully resident.  b2t_wfst_cluster_size sizes clusters for ONE cluster
+    //  kernel on the device at a time -- search, prune and finalize launches of decode streams that run concurrently must be
+    //  serialised by the caller (WfstSearch does: one stream per searcher, passes behind the search) or take B2T_WFST_*_CLUSTER=0;
+    //  a partly resident launch ends in CBAR_SPIN_LIMIT with overflow | 32, never in a hang)
+    B2T_REQUIRE(G <= 32, "wfst_finalize: clusters of at most 32 workgroups (scratch layout), got %d", G);
     if (G > 1) {
       const int grid = (U + 7) / 8 * 8 * G;
       hipLaunchKernelGGL(wfst_finalize_cluster_kernel, dim3(grid), dim3(NT), 0, as_stream(stream), to_graph(g), (char*)state, sb, to_opts(o),
@@ -2598,6 +2603,8 @@ extern "C" int b2t_wfst_prune(const b2t_wfst_graph_t* g, const b2t_wfst_opts_t* 
     const char* e = getenv("B2T_WFST_PRUNE_CLUSTER");
     const int G = (e && atoi(e) == 0) ? 1 : b2t_wfst_cluster_size(U);
     const size_t lds = (size_t)3 * (o->max_frames + 3) * sizeof(int);
+    B2T_REQUIRE(G <= 32, "wfst_prune: clusters of at most 32 workgroups (tots[80] / scratch layout), got %d", G);
+    static_assert(WLG_CAP >= 64 + 32 * 8 + 32, "the cluster compaction's per-member scratch lives in the work list");
     if (G > 1 && lds <= 96 * 1024) {
       const int grid = (U + 7) / 8 * 8 * G;
       allow_lds(wfst_prune_cluster_kernel, lds);

@@ -143,16 +143,18 @@ def test_wavefront_against_the_bf16_operand_recurrences(L, T, B, H, p):
         o = got["out"][l].cpu().numpy()
         assert np.isfinite(o).all(), f"layer {l}: non-finite outputs"
         # rounding decisions can flip where fp32 and fp64 intermediates straddle a bf16 boundary: compare at bf16-ulp scale
-        np.testing.assert_allclose(o, outs[l], atol=3e-3, err_msg=f"out[{l}]")
+        # (a flipped rounding in layer l moves the inputs of every layer above it: the bound grows with the layer)
+        tol = 3e-3 * (1 + l)
+        np.testing.assert_allclose(o, outs[l], atol=tol, err_msg=f"out[{l}]")
         r_ref = np.stack([np.concatenate(rs[:4], axis=1) for rs in res[l]])
-        np.testing.assert_allclose(got["res"][l].cpu().numpy(), r_ref, atol=3e-3, err_msg=f"reserve[{l}]")
+        np.testing.assert_allclose(got["res"][l].cpu().numpy(), r_ref, atol=tol, err_msg=f"reserve[{l}]")
         if p > 0 and l < L - 1:
             # the dropped copy is EXACTLY mask x the kernel's own output (same Philox draws as b2t_dropout_f32)
             want = (got["out"][l].cpu().numpy().astype(np.float32) * got["masks"][l].astype(np.float32))
             np.testing.assert_array_equal(got["outd"][l].cpu().numpy(), want)
         sc = max(1.0, float(np.abs(dG_ref[l]).max()))
-        np.testing.assert_allclose(got["dG"][l].cpu().numpy(), dG_ref[l], atol=3e-3 * sc, err_msg=f"dG[{l}]")
-        np.testing.assert_allclose(got["dh_init"][l].cpu().numpy(), dh_ref[l], atol=3e-3 * max(1.0, float(np.abs(dh_ref[l]).max())), err_msg=f"dh_init[{l}]")
+        np.testing.assert_allclose(got["dG"][l].cpu().numpy(), dG_ref[l], atol=3e-3 * L * sc, err_msg=f"dG[{l}]")
+        np.testing.assert_allclose(got["dh_init"][l].cpu().numpy(), dh_ref[l], atol=3e-3 * L * max(1.0, float(np.abs(dh_ref[l]).max())), err_msg=f"dh_init[{l}]")
 
 
 def test_wavefront_is_repeatable_and_needs_no_clean_workspace():

@@ -16,6 +16,11 @@ import ngram_lm
 import wfst
 from oracle import wfst_oracle as W
 
+# Round 6 (verdict item 6): the oracle is sequential Python and was 55 % of the GPU suite's wall time.  By default the oracle-bound
+# cases run at reduced size (fewer utterances through the ORACLE; the HIP side keeps its full batch); B2T_TEST_FULL=1 restores
+# every comparison of rounds 3-5.
+FULL = os.environ.get("B2T_TEST_FULL", "0") == "1"
+
 TOL = 2e-3
 
 
@@ -92,7 +97,8 @@ def test_wfst_search_matches_oracle_production_options(toy):
     part = S.best_path(False)
     fin = S.finalize()
     hits = 0
-    for u in range(8):
+    checked = range(8) if FULL else (0, 2, 3, 5, 7)
+    for u in checked:
         R = W.CtcWfstBeamSearch(g, cfg_of(o))
         R.search(lps[u])
         assert S.frames_decoded()[u] == len(R.mapping)
@@ -102,7 +108,7 @@ def test_wfst_search_matches_oracle_production_options(toy):
         R.finalize_search()
         compare_lists(fin[u], R, f"utt{u}")
         hits += [g.words[w] for w in fin[u][0][2]] == seqs[u]
-    print(f"spelled sentences recovered exactly: {hits}/8 (the LM weight and merged repeats change the others; the oracle agrees on all)")
+    print(f"spelled sentences recovered exactly: {hits}/{len(checked)} (the LM weight and merged repeats change the others; the oracle agrees on all)")
 
 
 def test_compact_arcs_equal_the_half_rounded_graph_bit_for_bit(toy):
@@ -214,9 +220,10 @@ def test_search_on_the_determinised_minimised_graph(toy):
         S.search(torch.from_numpy(batch).cuda(), lens)
         out[tag] = S.finalize()
     for u in range(4):
-        R = W.CtcWfstBeamSearch(g_opt, cfg_of(o))
-        R.search(lps[u]); R.finalize_search()
-        compare_lists(out["opt"][u], R, f"optimised graph, utterance {u}")
+        if FULL or u != 2:
+            R = W.CtcWfstBeamSearch(g_opt, cfg_of(o))
+            R.search(lps[u]); R.finalize_search()
+            compare_lists(out["opt"][u], R, f"optimised graph, utterance {u}")
         a, b = out["opt"][u][0], out["plain"][u][0]
         assert [g_opt.words[w] for w in a[2]] == [g_plain.words[w] for w in b[2]], u
         assert abs((a[3] + a[4]) - (b[3] + b[4])) < 0.05
@@ -717,26 +724,30 @@ def test_wfst_streamed_on_a_word_5gram_graph_32_utterances():
     S = WfstSearch(g, o, U=U, max_frames=batch.shape[1] + 8, prune_interval=10, prune_after_read=True)
     dev_batch = torch.from_numpy(batch).cuda()
     T = batch.shape[1]
-    R = [W.CtcWfstBeamSearch(g, cfg_of(o)) for _ in range(U)]
+    # (all 32 are streamed on the GPU; by default every third one also through the oracle -- B2T_TEST_FULL=1: all of them)
+    chk = [u for u in range(U) if FULL or u % 3 == 0]
+    R = {u: W.CtcWfstBeamSearch(g, cfg_of(o)) for u in chk}
     for t in range(T):
         S.search(dev_batch[:, t:t + 1].contiguous(), np.clip(lens - t, 0, 1))
-        for u in range(U):
+        for u in chk:
             if t < lens[u]:
                 R[u].search(lps[u][t:t + 1])
         if t % 4 == 3:
             part = S.best_path(False)
-            for u in range(U):
+            for u in chk:
                 pi, pt, pw, plm, pac = part[u]
                 assert pw == R[u].outputs[0] and pi == R[u].inputs[0], (t, u)
                 assert abs(plm - R[u].likelihood[0][0]) < TOL and abs(pac - R[u].likelihood[0][1]) < TOL, (t, u)
-    assert list(S.frames_decoded()) == [len(r.mapping) for r in R]
+    fd = list(S.frames_decoded())
+    assert [fd[u] for u in chk] == [len(R[u].mapping) for u in chk]
     fin = S.finalize()
     hits = 0
     for u in range(U):
-        R[u].finalize_search()
-        compare_lists(fin[u], R[u], f"5-gram stream utt {u}")
+        if u in R:
+            R[u].finalize_search()
+            compare_lists(fin[u], R[u], f"5-gram stream utt {u}")
         hits += [g.words[w] for w in fin[u][0][2]] == seqs[u]
-    print(f"5-gram graph, 32 streamed utterances: {hits}/32 spelled sentences recovered exactly")
+    print(f"5-gram graph, 32 streamed utterances ({len(chk)} of them against the oracle): {hits}/32 spelled sentences recovered exactly")
 
 
 def test_cluster_finalize_equals_single_workgroup_finalize(toy, monkeypatch):

@@ -8,8 +8,8 @@ import torch
 import b2t_native as N, b2t_ops as ops
 lib, dev, P = N.load(), torch.device("cuda:0"), ops._p
 
-def probe(L, T, B, H, p, reps=5):
-    g = torch.Generator().manual_seed(1)
+def probe(L, T, B, H, p, reps=5, seed=1, ws=None, timing=True):
+    g = torch.Generator().manual_seed(seed)
     rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
     gi0 = rnd(T, B, 3 * H, sc=0.5)
     whh = [rnd(3 * H, H, sc=1.0 / H ** 0.5) for _ in range(L)]; wih = [rnd(3 * H, H, sc=1.0 / H ** 0.5) for _ in range(L)]
@@ -27,9 +27,17 @@ def probe(L, T, B, H, p, reps=5):
         d.h_init[l], d.out[l], d.outd[l], d.reserve[l] = h0[l].data_ptr(), out[l].data_ptr(), outd[l].data_ptr(), res[l].data_ptr()
         d.w_hh_t[l], d.dG[l], d.seed[l] = whh_t[l].data_ptr(), dG[l].data_ptr(), 77 + l
     d.dY_top, d.dh_last, d.dh_init, d.drop_p, d.elem0 = dY.data_ptr(), None, dh.data_ptr(), float(p), 0
-    wsf = torch.empty(lib.b2t_gru_wave_ws_bytes(L, T, B, H, 0, int(p > 0)) // 4 + 64, device=dev)
-    wsb = torch.empty(lib.b2t_gru_wave_ws_bytes(L, T, B, H, 1, int(p > 0)) // 4 + 64, device=dev)
-    r = dict(L=L, T=T, B=B, H=H, p=p)
+    if ws is None:
+        ws = (torch.empty(lib.b2t_gru_wave_ws_bytes(L, T, B, H, 0, int(p > 0)) // 4 + 64, device=dev),
+              torch.empty(lib.b2t_gru_wave_ws_bytes(L, T, B, H, 1, int(p > 0)) // 4 + 64, device=dev))
+    wsf, wsb = ws
+    r = dict(L=L, T=T, B=B, H=H, p=p, sc1_loads=os.environ.get("B2T_WAVE_SC1_LOADS", "0"))
+    if not timing:
+        N.check(lib.b2t_gru_wave_fwd_f32(C.byref(d), P(wsf), P(err), ops._stream()), "fwd")
+        N.check(lib.b2t_gru_wave_bwd_f32(C.byref(d), P(wsb), P(err), ops._stream()), "bwd")
+        torch.cuda.synchronize()
+        assert int(err[0]) == 0, "hand-off timeout"
+        return [o.clone() for o in out + dG] + [dh.clone()], ws
     for name, fn, ws in (("fwd", lib.b2t_gru_wave_fwd_f32, wsf), ("bwd", lib.b2t_gru_wave_bwd_f32, wsb)):
         ts = []
         for i in range(reps + 1):
@@ -41,6 +49,16 @@ def probe(L, T, B, H, p, reps=5):
     assert all(torch.isfinite(o).all() for o in out + dG)
     print("R6WAVE " + json.dumps(r), flush=True)
 
-for cfg in ((5, 500, 64, 512, 0.0), (5, 500, 64, 512, 0.4), (1, 500, 64, 512, 0.0), (2, 500, 64, 512, 0.0),
-            (5, 122, 64, 768, 0.4), (5, 122, 64, 768, 0.0), (1, 122, 64, 768, 0.0), (5, 122, 16, 768, 0.4)):
+# stale-line hunt for the ordinary (L2-served) fragment loads: inputs A then inputs B on the SAME workspace (same ring addresses)
+# must equal inputs B on a fresh workspace, bit for bit; repeated so that the tail of one pass is still in the L2s when the next starts
+for cfg in ((5, 500, 64, 512, 0.4), (5, 122, 64, 768, 0.4), (3, 40, 64, 256, 0.0)):
+    ok = True
+    for rep in range(3):
+        _, ws = probe(*cfg, seed=10 + rep, timing=False)
+        got, _ = probe(*cfg, seed=20 + rep, ws=ws, timing=False)
+        want, _ = probe(*cfg, seed=20 + rep, timing=False)
+        ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
+    print("R6STALE " + json.dumps(dict(cfg=cfg, sc1_loads=os.environ.get("B2T_WAVE_SC1_LOADS", "0"), second_pass_on_used_workspace_equals_fresh=ok)), flush=True)
+for cfg in ((5, 500, 64, 512, 0.0), (5, 500, 64, 512, 0.4), (1, 500, 64, 512, 0.0),
+            (5, 122, 64, 768, 0.4), (1, 122, 64, 768, 0.0)):
     probe(*cfg)
