@@ -364,9 +364,9 @@ def main():
 
     if ts.reducer is not None and os.environ.get("B2T_DP_DEFERRED", "0") == "1":
         ts.reducer.deferred = True                 # measurement knob: all-reduce behind the backward pass (the post-refusal fallback)
-    sampler = BoxSampler(dev) if world == 1 else None
+    sampler = BoxSampler(dev) if (world == 1 and os.environ.get("B2T_BENCH_NO_SAMPLER") != "1") else None
     host_api = None                                               # this process's runtime-call latencies (slow-host mode signature)
-    if world == 1:
+    if world == 1 and os.environ.get("B2T_BENCH_NO_PROBE") != "1":
         try:
             host_api = ops.host_api_probe()
         except Exception as e:      # noqa: BLE001 -- a diagnostic must never take the bench line down

@@ -129,7 +129,7 @@ struct Layout {
   char *xpk_hh[MAXL], *xpk_ih[MAXL]; // amp mode: the B operands of a layer's whole-sequence weight-gradient GEMMs (h_{t-1}^T, x^T: known when the backward pass starts), packed ahead of the tail
   // layer wavefront (round 6, gru_wave.hip): counters + hand-off rings of the forward / backward launch, W_ih^T of the layers >= 1
   unsigned *wv_cnt_f, *wv_cnt_b;
-  char *wv_ring_f[MAXL], *wv_ringd_f[MAXL], *wv_ring_b[MAXL];
+  char *wv_ring_f[MAXL], *wv_ringd_f[MAXL], *wv_ring_b[MAXL], *wv_ringx_b[MAXL];
   float* wih_t[MAXL];
   size_t bytes;
 };
@@ -181,14 +181,15 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
     w.pack_bytes = align_up(w.pack_bytes, 256);
     for (int q = 0; q < NPACK; ++q) { w.pack[q] = base + off; off += w.pack_bytes; }
   }
-  for (size_t l = 0; l < MAXL; ++l) { w.wv_ring_f[l] = w.wv_ringd_f[l] = w.wv_ring_b[l] = nullptr; w.wih_t[l] = nullptr; }
+  for (size_t l = 0; l < MAXL; ++l) { w.wv_ring_f[l] = w.wv_ringd_f[l] = w.wv_ring_b[l] = w.wv_ringx_b[l] = nullptr; w.wih_t[l] = nullptr; }
   w.wv_cnt_f = w.wv_cnt_b = nullptr;
   if (wave_pass(m, p, p->fwd_mode)) {
     w.wv_cnt_f = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_fwd((int)L, (int)Tp, (int)B) * sizeof(unsigned), 256);
     const size_t rb = align_up(gru_wave_ring_bytes_fwd((int)Tp, (int)B, (int)H), 256);
     const bool drop = p->rnn_drop > 0.f && L > 1;
     for (size_t l = 0; l < L; ++l) { w.wv_ring_f[l] = base + off; off += rb; w.wv_ringd_f[l] = w.wv_ring_f[l]; }
-    if (drop) for (size_t l = 0; l + 1 < L; ++l) { w.wv_ringd_f[l] = base + off; off += rb; }
+    // the ring the layer above reads when it is not the own-recurrence ring: the dropped states, or the written-through copy of the local form
+    if (drop || gru_wave_local((int)L, (int)H)) for (size_t l = 0; l + 1 < L; ++l) { w.wv_ringd_f[l] = base + off; off += rb; }
   }
   for (size_t l = 0; l < MAXL; ++l) w.wpk_f[l] = w.wpk_b[l] = nullptr;
   if (p->bf16_gemm)
@@ -209,7 +210,8 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
   if (wave_pass(m, p, p->bwd_mode)) {
     w.wv_cnt_b = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_bwd((int)L, (int)Tp, (int)B) * sizeof(unsigned), 256);
     const size_t rb = align_up(gru_wave_ring_bytes_bwd((int)Tp, (int)B, (int)H), 256);
-    for (size_t l = 0; l < L; ++l) { w.wv_ring_b[l] = base + off; off += rb; }
+    for (size_t l = 0; l < L; ++l) { w.wv_ring_b[l] = base + off; off += rb; w.wv_ringx_b[l] = w.wv_ring_b[l]; }
+    if (gru_wave_local((int)L, (int)H)) for (size_t l = 1; l < L; ++l) { w.wv_ringx_b[l] = base + off; off += rb; }
     for (size_t l = 1; l < L; ++l) w.wih_t[l] = take(H * 3 * H);
   }
   const size_t K = Tp * B;
@@ -1429,7 +1431,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
             const bool drop = p->rnn_drop > 0.f && L > 1;
             for (int k = 0; k < L; ++k) {
               a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k]; a.out[k] = w.out[k] + (long long)B * H;
-              a.reserve[k] = w.res[k]; a.dG[k] = w.dG[k]; a.ring[k] = w.wv_ring_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
+              a.reserve[k] = w.res[k]; a.dG[k] = w.dG[k]; a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
             }
             a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
             a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;

@@ -90,7 +90,9 @@ struct WaveFwdArgs {
   float* outd[B2T_MAX_LAYERS];                             // dropout(out[l]) for the layer above's weight gradient (drop_p > 0, l < L - 1)
   float* reserve[B2T_MAX_LAYERS];                          // [T][B][4H] = (r, z, n, gh_n), or null
   char* ring[B2T_MAX_LAYERS]; char* ringd[B2T_MAX_LAYERS]; // fragment rings: slot 0..T of h / dropped h
-  unsigned* cnt;                                           // [L][2][row groups][T + 1], zeroed by the launcher
+  unsigned* cnt;                                           // 16 ticket words + [L][2][row groups][T + 1], zeroed by the launcher
+  unsigned* tickets;                                       // (set by the launcher: the first 16 words of cnt)
+  unsigned* timing;                                        // timing build only: [L][8] cycles per step and phase
   unsigned* err;                                           // sticky error word (a bounded spin gave up)
   float drop_p, drop_scale; unsigned long long seed[B2T_MAX_LAYERS]; long long elem0;
   int flags;                                               // bit 0: sc1 fragment loads (A/B knob)
@@ -105,12 +107,17 @@ struct WaveBwdArgs {
   const float* h_init[B2T_MAX_LAYERS]; const float* out[B2T_MAX_LAYERS]; const float* reserve[B2T_MAX_LAYERS];
   float* dG[B2T_MAX_LAYERS];                               // [T][B][4H] = (dr, dz, dn r, dn)
   char* ring[B2T_MAX_LAYERS];                              // fragment rings: slot t, 4 arrays
-  unsigned* cnt;                                           // [L][row groups][T]
+  char* ringx[B2T_MAX_LAYERS];                             // the written-through copy the layer below reads in the local form
+  unsigned* cnt;                                           // 16 ticket words + [L][2][row groups][T]
+  unsigned* tickets;
+  unsigned* timing;
   unsigned* err;
   float drop_p, drop_scale; unsigned long long seed[B2T_MAX_LAYERS]; long long elem0;
   int flags;                                               // bit 0: sc1 fragment loads (A/B knob)
 };
 bool gru_wave_ok(int L, int T, int B, int H, const char** why);
+bool gru_wave_local(int L, int H);
+bool gru_xcd_dispatch_ok();
 size_t gru_wave_ring_bytes_fwd(int T, int B, int H);
 size_t gru_wave_ring_bytes_bwd(int T, int B, int H);
 size_t gru_wave_cnt_words_fwd(int L, int T, int B);

@@ -43,9 +43,21 @@ __device__ __forceinline__ bf16x8 zero8() { return __builtin_bit_cast(bf16x8, u3
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // Every lane of the wave polls the same word (one request per poll): no barrier follows -- the wave is its own recurrence.
-__device__ __forceinline__ void wave_wait(const unsigned* p, unsigned target, unsigned* err) {
+// LOCAL: the counter lives in this XCD's L2 (all the workgroups that bump and poll it run on this XCD): polled by one lane with a
+// returning L2 atomic (an ordinary load could keep hitting a stale line in the CU's vector cache), as gru_sync.h's local hand-off.
+template <bool LOCAL>
+__device__ __forceinline__ void wave_wait(const unsigned* p, unsigned target, unsigned* err, int lane) {
   unsigned spins = 0;
-  while (__hip_atomic_load(p, RLX_AGENT) < target) {
+  for (;;) {
+    unsigned v;
+    if constexpr (LOCAL) {
+      v = 0u;
+      if (lane == 0) v = l2_atomic_read(const_cast<unsigned*>(p));
+      v = __builtin_amdgcn_readfirstlane(v);
+    } else {
+      v = __hip_atomic_load(p, RLX_AGENT);
+    }
+    if (v >= target) break;
     if ((++spins & 255u) == 0u) {
       if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
       if (spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
@@ -53,10 +65,34 @@ __device__ __forceinline__ void wave_wait(const unsigned* p, unsigned target, un
     __builtin_amdgcn_s_sleep(1);
   }
 }
-// the wave's stores are acknowledged, then one lane bumps the counter
-__device__ __forceinline__ void wave_publish(unsigned* p, int lane) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add(p, 1u, RLX_AGENT);
+template <bool LOCAL>
+__device__ __forceinline__ void wave_bump(unsigned* p, int lane) {
+  if (lane == 0) { if constexpr (LOCAL) l2_atomic_inc(p); else __hip_atomic_fetch_add(p, 1u, RLX_AGENT); }
+}
+__device__ __forceinline__ void wave_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Which (layer, 16-unit slice) a workgroup is.  Placement-independent form: by block index.  LOCAL form (a layer's H / 16 <= 32
+// workgroups, one per CU, fill ONE XCD -- layer l on XCD l -- so that the layer's own hand-off never leaves that XCD's L2): by the
+// XCD the workgroup finds itself on and a ticket; the launch is 8 x 32 workgroups dealt round-robin (verified once per process by
+// gru_xcd_dispatch_ok), those without a role leave.
+template <bool LOCAL>
+__device__ __forceinline__ bool wave_role(unsigned* tickets, int L, int G, bool top_first, int& layer, int& slice) {
+  if constexpr (LOCAL) {
+    __shared__ int role[2];
+    if (threadIdx.x == 0) {
+      const unsigned x = xcc_id();
+      int l = x < (unsigned)L ? (int)x : -1, tk = -1;
+      if (l >= 0) { tk = (int)__hip_atomic_fetch_add(tickets + x, 1u, RLX_AGENT); if (tk >= G) l = -1; }
+      role[0] = l; role[1] = tk;
+    }
+    __syncthreads();
+    layer = role[0]; slice = role[1];
+    return layer >= 0;
+  } else {
+    const int k = (int)blockIdx.x / G;
+    layer = top_first ? L - 1 - k : k; slice = (int)blockIdx.x % G;
+    return layer >= 0 && layer < L;
+  }
 }
 
 constexpr int WTP = 20;                    // pitch (floats) of a wave's staged 16 x 16 tile
@@ -107,14 +143,14 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NP, bool DROP>   // NP: pairs of 16-unit chunks per row (H <= 32 NP)
+template <int NP, bool DROP, bool LOC>   // NP: pairs of 16-unit chunks per row (H <= 32 NP); LOC: a layer = one XCD (wave_role)
 __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wave_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
-  const bool plain_ = (a.flags & 1) == 0;
-  const int layer = (int)blockIdx.x / G, slice = (int)blockIdx.x % G;
-  if (layer >= L) return;
+  const bool plain_ = LOC || (a.flags & 1) == 0;
+  int layer, slice;
+  if (!wave_role<LOC>(a.tickets, L, G, false, layer, slice)) return;
   const int u0 = slice * 16, unit = u0 + j;
   u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer] slice as B fragments
   float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * P * 1024) + wave * (WAVE_TILES * WTILE_F);
@@ -146,17 +182,22 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   if (wave >= ngrp) return;
   __builtin_amdgcn_s_setprio(3);
 
+  // Two rings per layer when the layer above must not read the own-recurrence ring: with dropout (it reads the DROPPED states) and
+  // under LOC (it sits on another XCD: the own ring is written with ordinary stores into this XCD's L2, the copy for the layer above
+  // is written through to memory).  The cross ring's counter of slot s moves one step late -- when the NEXT own publish has drained
+  // this wave's stores anyway -- so that no step waits for a memory acknowledgement of its own.
+  constexpr bool XRING = DROP || LOC;
   const int rg = wave, m0 = rg * 16;
   unsigned* err = a.err;
   const size_t cstride = (size_t)(T + 1);
   unsigned* cnt_own = a.cnt + ((size_t)(layer * 2 + 0) * ngrp + rg) * cstride;
-  unsigned* cnt_ownd = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + rg) * cstride;
+  unsigned* cnt_x = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + rg) * cstride;
   const bool feeds = layer + 1 < L;                 // a layer above reads this layer's outputs
   const bool dropping = DROP && feeds;              // ... through nn.GRU's dropout
-  const unsigned* cnt_in = layer > 0 ? a.cnt + ((size_t)((layer - 1) * 2 + (DROP ? 1 : 0)) * ngrp + rg) * cstride : nullptr;
+  const unsigned* cnt_in = layer > 0 ? a.cnt + ((size_t)((layer - 1) * 2 + (XRING ? 1 : 0)) * ngrp + rg) * cstride : nullptr;
   char* ring = a.ring[layer];
-  char* ringd = a.ringd[layer];
-  const char* ring_in = layer > 0 ? (DROP ? a.ringd[layer - 1] : a.ring[layer - 1]) : nullptr;
+  char* ringx = a.ringd[layer];
+  const char* ring_in = layer > 0 ? (XRING ? a.ringd[layer - 1] : a.ring[layer - 1]) : nullptr;
   const unsigned slot_bytes = (unsigned)ngrp * (unsigned)P * 1024u, rg_off = (unsigned)rg * (unsigned)P * 1024u;
   const unsigned my_frag = (unsigned)(slice >> 1) * 1024u + (unsigned)(slice & 1) * 512u + (unsigned)(lane & 31) * 16u;
   const float bhr = a.b_hh[layer][unit], bhz = a.b_hh[layer][H + unit], bhn = a.b_hh[layer][2 * H + unit];
@@ -174,14 +215,23 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   tile_put(tiles, hp, j, q);
   {
     const u32x4 f = tile_frag(tiles, lane);
-    if (lane < 32) store_u4<16>(ring, rg_off + my_frag, f);
-    wave_publish(cnt_own, lane);
+    if (lane < 32) store_u4<LOC ? 0 : 16>(ring, rg_off + my_frag, f);
+    wave_drain();
+    wave_bump<LOC>(cnt_own, lane);
   }
+  int pending_x = -1;      // slot of the cross ring whose store is in flight (its counter moves at the next drain)
 
+#ifdef B2T_WAVE_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define WSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tprev; tprev = now_; }
+#else
+#define WSTAMP(i)
+#endif
   f32x4 gi[3];
   // gi of step t from layer - 1's (dropped) h_t = slot t + 1 of its ring, W_ih slice from LDS
   auto project = [&](int t) {
-    wave_wait(cnt_in + (t + 1), (unsigned)G, err);
+    wave_wait<false>(cnt_in + (t + 1), (unsigned)G, err, lane);
+    WSTAMP(5)   // wait for the layer below
     f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -194,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i) gi[g][i] = acc[g][i] + bi[g];
+    WSTAMP(6)   // projection
   };
   if (layer > 0) project(0);
 
@@ -206,7 +257,8 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
         for (int g = 0; g < 3; ++g) gi[g][i] = live[i] ? __builtin_nontemporal_load(g3 + (long long)g * H) : 0.f;
       }
     }
-    wave_wait(cnt_own + t, (unsigned)G, err);
+    wave_wait<LOC>(cnt_own + t, (unsigned)G, err, lane);
+    WSTAMP(0)   // wait for the peers' h_{t-1}
     f32x4 gh[3];
     {
 #pragma unroll
@@ -216,6 +268,8 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
         _Pragma("unroll") for (int g = 0; g < 3; ++g) gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], gh[g], 0, 0, 0);
       })
     }
+    asm volatile("s_nop 0" :: "v"(gh[0][0]), "v"(gh[1][0]), "v"(gh[2][0]));
+    WSTAMP(1)   // operand loads + recurrent product
     f32x4 sr, sz, sn, sg, h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -229,27 +283,32 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     hp = h;
     // publish h_t: slot t + 1
     tile_put(tiles, h, j, q);
-    {
-      const u32x4 f = tile_frag(tiles, lane);
-      if (lane < 32) store_u4<16>(ring, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, f);
-      wave_publish(cnt_own + (t + 1), lane);
-    }
+    const u32x4 f = tile_frag(tiles, lane);
+    if (lane < 32) store_u4<LOC ? 0 : 16>(ring, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, f);
+    WSTAMP(2)   // gates + tile
+    wave_drain();
+    wave_bump<LOC>(cnt_own + (t + 1), lane);
+    if (XRING && pending_x >= 0) wave_bump<false>(cnt_x + pending_x, lane);   // (drained above)
+    WSTAMP(3)   // store acknowledged, counters
     // fp32 copy (backward, weight gradients, head): lane (row L & 15, unit group L >> 4) stores 4 units
     const int rrow = m0 + (lane & 15), kg = lane >> 4;
     const float4 hv = ld4(tiles + (lane & 15) * WTP + 4 * kg);
-    if (dropping) {
-      // nn.GRU's dropout on the way to the layer above: flat element (t, row, unit) of this layer's output, as b2t_dropout_f32
-      const long long e = a.elem0 + ((long long)t * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
-      const float4 u = Philox::uniform4(a.seed[layer], (uint64_t)(e >> 2), 2u);
-      float4 hd;
-      hd.x = u.x >= a.drop_p ? hv.x * a.drop_scale : 0.f; hd.y = u.y >= a.drop_p ? hv.y * a.drop_scale : 0.f;
-      hd.z = u.z >= a.drop_p ? hv.z * a.drop_scale : 0.f; hd.w = u.w >= a.drop_p ? hv.w * a.drop_scale : 0.f;
-      float* td = tiles + WTILE_F;
-      *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = hd;
-      const u32x4 fd = tile_frag(td, lane);
-      if (lane < 32) store_u4<16>(ringd, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, fd);
-      wave_publish(cnt_ownd + (t + 1), lane);
-      if (rrow < B) *reinterpret_cast<float4*>(a.outd[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hd;
+    if (XRING && feeds) {
+      u32x4 fx = f;
+      if (dropping) {
+        // nn.GRU's dropout on the way to the layer above: flat element (t, row, unit) of this layer's output, as b2t_dropout_f32
+        const long long e = a.elem0 + ((long long)t * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
+        const float4 u = Philox::uniform4(a.seed[layer], (uint64_t)(e >> 2), 2u);
+        float4 hd;
+        hd.x = u.x >= a.drop_p ? hv.x * a.drop_scale : 0.f; hd.y = u.y >= a.drop_p ? hv.y * a.drop_scale : 0.f;
+        hd.z = u.z >= a.drop_p ? hv.z * a.drop_scale : 0.f; hd.w = u.w >= a.drop_p ? hv.w * a.drop_scale : 0.f;
+        float* td = tiles + WTILE_F;
+        *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = hd;
+        fx = tile_frag(td, lane);
+        if (rrow < B) *reinterpret_cast<float4*>(a.outd[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hd;
+      }
+      if (lane < 32) store_u4<16>(ringx, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, fx);
+      pending_x = t + 1;
     }
     if (rrow < B) *reinterpret_cast<float4*>(a.out[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hv;
     if (a.reserve[layer]) {
@@ -262,22 +321,28 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
         }
       }
     }
+    WSTAMP(4)   // cross ring, fp32 stores
     if (layer > 0 && t + 1 < T) project(t + 1);
   }
+  if (XRING && pending_x >= 0) { wave_drain(); wave_bump<false>(cnt_x + pending_x, lane); }
+#ifdef B2T_WAVE_TIMING
+  if (slice == 0 && wave == 0 && lane == 0 && a.timing)
+    for (int i = 0; i < 8; ++i) a.timing[layer * 8 + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward.  Ring of layer l, slot t: the gate gradients of step t as fragments, 4 arrays (dr, dz, dn r, dn) x P pairs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NP, bool DROP>
+template <int NP, bool DROP, bool LOC>
 __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wave_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
-  const bool plain_ = (a.flags & 1) == 0;
-  // the TOP layer starts the wavefront: it gets the first workgroups
-  const int layer = L - 1 - (int)blockIdx.x / G, slice = (int)blockIdx.x % G;
-  if (layer < 0) return;
+  const bool plain_ = LOC || (a.flags & 1) == 0;
+  // (placement-independent form: the TOP layer starts the wavefront and gets the first workgroups)
+  int layer, slice;
+  if (!wave_role<LOC>(a.tickets, L, G, true, layer, slice)) return;
   const int u0 = slice * 16, unit = u0 + j;
   u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer + 1]^T slice
   float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * P * 1024) + wave * (WAVE_TILES * WTILE_F);
@@ -310,24 +375,35 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
   if (wave >= ngrp) return;
   __builtin_amdgcn_s_setprio(3);
 
+  // LOC: the own-recurrence ring stays in this XCD's L2 (ordinary stores, L2 counters); the layer BELOW (another XCD) reads a
+  // second, written-through copy whose counter moves one step late (see the forward kernel)
+  constexpr bool XRING = LOC;
   const int rg = wave, m0 = rg * 16;
   unsigned* err = a.err;
   const size_t cstride = (size_t)T;
-  unsigned* cnt_own = a.cnt + ((size_t)layer * ngrp + rg) * cstride;
-  const unsigned* cnt_up = has_up ? a.cnt + ((size_t)(layer + 1) * ngrp + rg) * cstride : nullptr;
+  unsigned* cnt_own = a.cnt + ((size_t)(layer * 2 + 0) * ngrp + rg) * cstride;
+  unsigned* cnt_x = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + rg) * cstride;
+  const bool feeds = layer > 0;                     // a layer below reads this layer's gate gradients
+  const unsigned* cnt_up = has_up ? a.cnt + ((size_t)((layer + 1) * 2 + (XRING ? 1 : 0)) * ngrp + rg) * cstride : nullptr;
   char* ring = a.ring[layer];
-  const char* ring_up = has_up ? a.ring[layer + 1] : nullptr;
+  char* ringx = a.ringx[layer];
+  const char* ring_up = has_up ? (XRING ? a.ringx[layer + 1] : a.ring[layer + 1]) : nullptr;
   const unsigned arr_bytes = (unsigned)P * 1024u, rg_bytes = 4u * arr_bytes, slot_bytes = (unsigned)ngrp * rg_bytes, rg_off = (unsigned)rg * rg_bytes;
   const unsigned my_frag = (unsigned)(slice >> 1) * 1024u + (unsigned)(slice & 1) * 512u + (unsigned)(lane & 31) * 16u;
   bool live[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) live[i] = m0 + 4 * q + i < B;
   const int rrow = m0 + (lane & 15), kg = lane >> 4;   // the (row, 4-unit group) this lane handles in row-major passes
+  int pending_x = -1;
 
+#ifdef B2T_WAVE_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
   f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
   // dY[layer]_t = dGi[layer + 1]_t . W_ih[layer + 1][:, units] (arrays dr, dz, dn of the ring above), then the dropout mask
   auto project = [&](int t) {
-    wave_wait(cnt_up + t, (unsigned)G, err);
+    wave_wait<false>(cnt_up + t, (unsigned)G, err, lane);
+    WSTAMP(5)
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -350,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
       for (int i = 0; i < 4; ++i) acc[i] = td[(4 * q + i) * WTP + j];
     }
     dy = acc;
+    WSTAMP(6)
   };
   if (has_up) project(T - 1);
 
@@ -370,7 +447,8 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     }
     f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < T - 1) {
-      wave_wait(cnt_own + (t + 1), (unsigned)G, err);
+      wave_wait<LOC>(cnt_own + (t + 1), (unsigned)G, err, lane);
+      WSTAMP(0)
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
@@ -379,6 +457,8 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc, 0, 0, 0);
         })
       }
+      asm volatile("s_nop 0" :: "v"(acc[0]));
+      WSTAMP(1)
 #pragma unroll
       for (int i = 0; i < 4; ++i) carry[i] = acc[i] + dzterm[i];
     } else if (a.dh_last) {
@@ -404,22 +484,35 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     }
     tile_put(tiles + 0 * WTILE_F, g0, j, q); tile_put(tiles + 1 * WTILE_F, g1, j, q);
     tile_put(tiles + 2 * WTILE_F, g2, j, q); tile_put(tiles + 3 * WTILE_F, g3, j, q);
-    {
-      // lanes 0-31 publish arrays 0 and 2, lanes 32-63 arrays 1 and 3
-      const int a0 = lane >> 5;
-      const u32x4 f0 = tile_frag(tiles + a0 * WTILE_F, lane), f1 = tile_frag(tiles + (a0 + 2) * WTILE_F, lane);
-      const unsigned base = (unsigned)t * slot_bytes + rg_off + my_frag;
-      store_u4<16>(ring, base + (unsigned)a0 * arr_bytes, f0);
-      store_u4<16>(ring, base + (unsigned)(a0 + 2) * arr_bytes, f1);
-      wave_publish(cnt_own + t, lane);
+    // lanes 0-31 publish arrays 0 and 2, lanes 32-63 arrays 1 and 3
+    const int a0 = lane >> 5;
+    const u32x4 f0 = tile_frag(tiles + a0 * WTILE_F, lane), f1 = tile_frag(tiles + (a0 + 2) * WTILE_F, lane);
+    const unsigned base = (unsigned)t * slot_bytes + rg_off + my_frag;
+    store_u4<LOC ? 0 : 16>(ring, base + (unsigned)a0 * arr_bytes, f0);
+    store_u4<LOC ? 0 : 16>(ring, base + (unsigned)(a0 + 2) * arr_bytes, f1);
+    WSTAMP(2)
+    wave_drain();
+    wave_bump<LOC>(cnt_own + t, lane);
+    if (XRING && pending_x >= 0) wave_bump<false>(cnt_x + pending_x, lane);
+    WSTAMP(3)
+    if (XRING && feeds) {
+      store_u4<16>(ringx, base + (unsigned)a0 * arr_bytes, f0);
+      store_u4<16>(ringx, base + (unsigned)(a0 + 2) * arr_bytes, f1);
+      pending_x = t;
     }
     if (rrow < B) {
       float* dg = a.dG[layer] + ((long long)t * B + rrow) * 4 * H + u0 + 4 * kg;
 #pragma unroll
       for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dg + (long long)g * H) = ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg);
     }
+    WSTAMP(4)
     if (has_up && t > 0) project(t - 1);
   }
+  if (XRING && pending_x >= 0) { wave_drain(); wave_bump<false>(cnt_x + pending_x, lane); }
+#ifdef B2T_WAVE_TIMING
+  if (slice == 0 && wave == 0 && lane == 0 && a.timing)
+    for (int i = 0; i < 8; ++i) a.timing[layer * 8 + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -439,8 +532,8 @@ static int wave_cus() {
 size_t gru_wave_lds_bytes(int H) { const int P = (H / 16 + 1) / 2; return (size_t)3 * P * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
 size_t gru_wave_ring_bytes_fwd(int T, int B, int H) { return (size_t)(T + 1) * ((B + 15) / 16) * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_ring_bytes_bwd(int T, int B, int H) { return (size_t)T * ((B + 15) / 16) * 4 * ((H / 16 + 1) / 2) * 1024; }
-size_t gru_wave_cnt_words_fwd(int L, int T, int B) { return (size_t)L * 2 * ((B + 15) / 16) * (T + 1); }
-size_t gru_wave_cnt_words_bwd(int L, int T, int B) { return (size_t)L * ((B + 15) / 16) * T; }
+size_t gru_wave_cnt_words_fwd(int L, int T, int B) { return 16 + (size_t)L * 2 * ((B + 15) / 16) * (T + 1); }   // 16: the XCD tickets of the local form
+size_t gru_wave_cnt_words_bwd(int L, int T, int B) { return 16 + (size_t)L * 2 * ((B + 15) / 16) * T; }
 
 // Shapes the wavefront serves; `why` (optional) receives the reason when it does not.
 bool gru_wave_ok(int L, int T, int B, int H, const char** why) {
@@ -459,9 +552,28 @@ template <typename K> static int wave_lds_attr(K kernel, size_t bytes) {
   return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "gru_wave: LDS size");
 }
 
-static int wave_flags() {   // read per call (A/B in one process): bit 0 = sc1 (memory-side) fragment loads
+static int wave_flags() {   // read per call (A/B in one process): bit 0 = sc1 (memory-side) fragment loads in the placement-independent form
   const char* e = getenv("B2T_WAVE_SC1_LOADS");
   return (e && atoi(e) != 0) ? 1 : 0;
+}
+// the local form: a layer's H / 16 <= 32 workgroups on one XCD (B2T_WAVE_LOCAL=0, read per call: the placement-independent form)
+bool gru_wave_local(int L, int H) {
+  const char* e = getenv("B2T_WAVE_LOCAL");
+  if (e && atoi(e) == 0) return false;
+  return L <= 8 && H / 16 <= 32 && wave_cus() >= 256 && gru_xcd_dispatch_ok();
+}
+
+template <int NPV, bool DR, bool LC> static int wave_launch_fwd(const WaveFwdArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool at = false;
+  if (!at) { const int rc = wave_lds_attr(gru_wave_fwd_kernel<NPV, DR, LC>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; }
+  hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, DR, LC>), grid, dim3(256), lds, s, a);
+  return 0;
+}
+template <int NPV, bool DR, bool LC> static int wave_launch_bwd(const WaveBwdArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool at = false;
+  if (!at) { const int rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, DR, LC>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; }
+  hipLaunchKernelGGL((gru_wave_bwd_kernel<NPV, DR, LC>), grid, dim3(256), lds, s, a);
+  return 0;
 }
 
 int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
@@ -469,23 +581,23 @@ int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
   a.flags = wave_flags();
   const char* why = nullptr;
   if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_fwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
-  const bool drop = a.drop_p > 0.f && a.L > 1;
+  const bool drop = a.drop_p > 0.f && a.L > 1, loc = gru_wave_local(a.L, a.H);
   const size_t lds = gru_wave_lds_bytes(a.H);
-  int rc = check_hip(hipMemsetAsync(a.cnt, 0, gru_wave_cnt_words_fwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_fwd: counters");
+  a.tickets = a.cnt; a.cnt = a.cnt + 16;
+  int rc = check_hip(hipMemsetAsync(a.tickets, 0, gru_wave_cnt_words_fwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_fwd: counters");
   if (rc) return rc;
-  const dim3 grid(a.L * (a.H / 16)), block(256);
+  const dim3 grid(loc ? 256 : a.L * (a.H / 16));
 #define B2T_WAVE_FWD(NPV)                                                                                              \
   do {                                                                                                                 \
-    if (drop) { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_fwd_kernel<NPV, true>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
-                hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, true>), grid, block, lds, s, a); }                        \
-    else { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_fwd_kernel<NPV, false>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
-           hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, false>), grid, block, lds, s, a); }                            \
+    if (loc) rc = drop ? wave_launch_fwd<NPV, true, true>(a, grid, lds, s) : wave_launch_fwd<NPV, false, true>(a, grid, lds, s);   \
+    else rc = drop ? wave_launch_fwd<NPV, true, false>(a, grid, lds, s) : wave_launch_fwd<NPV, false, false>(a, grid, lds, s);     \
   } while (0)
   if (a.H <= 128) B2T_WAVE_FWD(4);
   else if (a.H <= 256) B2T_WAVE_FWD(8);
   else if (a.H <= 512) B2T_WAVE_FWD(16);
-  else B2T_WAVE_FWD(24);
+  else rc = drop ? wave_launch_fwd<24, true, false>(a, grid, lds, s) : wave_launch_fwd<24, false, false>(a, grid, lds, s);
 #undef B2T_WAVE_FWD
+  if (rc) return rc;
   return check_hip(hipGetLastError(), "gru_wave_fwd");
 }
 
@@ -494,23 +606,23 @@ int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   a.flags = wave_flags();
   const char* why = nullptr;
   if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_bwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
-  const bool drop = a.drop_p > 0.f && a.L > 1;
+  const bool drop = a.drop_p > 0.f && a.L > 1, loc = gru_wave_local(a.L, a.H);
   const size_t lds = gru_wave_lds_bytes(a.H);
-  int rc = check_hip(hipMemsetAsync(a.cnt, 0, gru_wave_cnt_words_bwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_bwd: counters");
+  a.tickets = a.cnt; a.cnt = a.cnt + 16;
+  int rc = check_hip(hipMemsetAsync(a.tickets, 0, gru_wave_cnt_words_bwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_bwd: counters");
   if (rc) return rc;
-  const dim3 grid(a.L * (a.H / 16)), block(256);
+  const dim3 grid(loc ? 256 : a.L * (a.H / 16));
 #define B2T_WAVE_BWD(NPV)                                                                                              \
   do {                                                                                                                 \
-    if (drop) { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, true>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
-                hipLaunchKernelGGL((gru_wave_bwd_kernel<NPV, true>), grid, block, lds, s, a); }                        \
-    else { static bool at = false; if (!at) { rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, false>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; } \
-           hipLaunchKernelGGL((gru_wave_bwd_kernel<NPV, false>), grid, block, lds, s, a); }                            \
+    if (loc) rc = drop ? wave_launch_bwd<NPV, true, true>(a, grid, lds, s) : wave_launch_bwd<NPV, false, true>(a, grid, lds, s);   \
+    else rc = drop ? wave_launch_bwd<NPV, true, false>(a, grid, lds, s) : wave_launch_bwd<NPV, false, false>(a, grid, lds, s);     \
   } while (0)
   if (a.H <= 128) B2T_WAVE_BWD(4);
   else if (a.H <= 256) B2T_WAVE_BWD(8);
   else if (a.H <= 512) B2T_WAVE_BWD(16);
-  else B2T_WAVE_BWD(24);
+  else rc = drop ? wave_launch_bwd<24, true, false>(a, grid, lds, s) : wave_launch_bwd<24, false, false>(a, grid, lds, s);
 #undef B2T_WAVE_BWD
+  if (rc) return rc;
   return check_hip(hipGetLastError(), "gru_wave_bwd");
 }
 
@@ -527,18 +639,18 @@ extern "C" size_t b2t_gru_wave_ws_bytes(int L, int T, int B, int H, int backward
   if (L < 1 || L > B2T_MAX_LAYERS || T < 1 || B < 1 || H < 16) return 0;
   const size_t cnt = wave_align((backward ? gru_wave_cnt_words_bwd(L, T, B) : gru_wave_cnt_words_fwd(L, T, B)) * sizeof(unsigned) + 64);
   const size_t ring = wave_align(backward ? gru_wave_ring_bytes_bwd(T, B, H) : gru_wave_ring_bytes_fwd(T, B, H));
-  return cnt + (size_t)L * ring * ((!backward && dropout) ? 2 : 1);
+  (void)dropout;
+  return cnt + (size_t)L * ring * 2;     // the own-recurrence ring + the copy the neighbouring layer reads (dropout / the local form)
 }
 
-// carve(ws): [error word + counters][ring per layer]([dropped ring per layer])
-static void wave_carve(char* ws, int L, int T, int B, int H, bool backward, bool dropout, unsigned*& err, unsigned*& cnt, char** ring, char** ringd) {
-  err = reinterpret_cast<unsigned*>(ws);
-  cnt = err + 16;
+// carve(ws): [counters][ring per layer][second ring per layer]
+static void wave_carve(char* ws, int L, int T, int B, int H, bool backward, unsigned*& cnt, char** ring, char** ring2) {
+  cnt = reinterpret_cast<unsigned*>(ws);
   const size_t cb = wave_align((backward ? gru_wave_cnt_words_bwd(L, T, B) : gru_wave_cnt_words_fwd(L, T, B)) * sizeof(unsigned) + 64);
   const size_t rb = wave_align(backward ? gru_wave_ring_bytes_bwd(T, B, H) : gru_wave_ring_bytes_fwd(T, B, H));
   char* p = ws + cb;
   for (int l = 0; l < L; ++l) { ring[l] = p; p += rb; }
-  for (int l = 0; l < L; ++l) { if (ringd) { ringd[l] = (!backward && dropout) ? p : ring[l]; if (!backward && dropout) p += rb; } }
+  for (int l = 0; l < L; ++l) { ring2[l] = p; p += rb; }
 }
 
 extern "C" int b2t_gru_wave_fwd_f32(const b2t_wave_t* d, void* ws, unsigned* err_word, void* stream) {
@@ -550,9 +662,11 @@ extern "C" int b2t_gru_wave_fwd_f32(const b2t_wave_t* d, void* ws, unsigned* err
   memset(&a, 0, sizeof(a));
   a.L = L; a.T = T; a.B = B; a.H = H; a.gi0 = d->gi0;
   const bool drop = d->drop_p > 0.f && L > 1;
-  unsigned* e0 = nullptr;
-  wave_carve(reinterpret_cast<char*>(ws), L, T, B, H, false, drop, e0, a.cnt, a.ring, a.ringd);
+  wave_carve(reinterpret_cast<char*>(ws), L, T, B, H, false, a.cnt, a.ring, a.ringd);
   a.err = err_word;
+#ifdef B2T_WAVE_TIMING
+  a.timing = err_word + 16;      // (timing build: the caller's error buffer holds 16 + 8 L words)
+#endif
   for (int l = 0; l < L; ++l) {
     B2T_REQUIRE(d->w_hh[l] && d->b_hh[l] && d->h_init[l] && d->out[l] && (l == 0 || (d->w_ih[l] && d->b_ih[l])), "gru_wave_fwd: null tensor of layer %d", l);
     B2T_REQUIRE(!drop || l + 1 == L || d->outd[l], "gru_wave_fwd: dropout needs outd[%d]", l);
@@ -573,9 +687,11 @@ extern "C" int b2t_gru_wave_bwd_f32(const b2t_wave_t* d, void* ws, unsigned* err
   memset(&a, 0, sizeof(a));
   a.L = L; a.T = T; a.B = B; a.H = H; a.dY_top = d->dY_top; a.dh_last = d->dh_last; a.dh_init = d->dh_init;
   const bool drop = d->drop_p > 0.f && L > 1;
-  unsigned* e0 = nullptr;
-  wave_carve(reinterpret_cast<char*>(ws), L, T, B, H, true, false, e0, a.cnt, a.ring, nullptr);
+  wave_carve(reinterpret_cast<char*>(ws), L, T, B, H, true, a.cnt, a.ring, a.ringx);
   a.err = err_word;
+#ifdef B2T_WAVE_TIMING
+  a.timing = err_word + 16 + 8 * B2T_MAX_LAYERS;
+#endif
   for (int l = 0; l < L; ++l) {
     B2T_REQUIRE(d->w_hh_t[l] && d->h_init[l] && d->out[l] && d->reserve[l] && d->dG[l] && (l == 0 || d->w_ih_t[l]), "gru_wave_bwd: null tensor of layer %d", l);
     a.w_hh_t[l] = d->w_hh_t[l]; a.w_ih_t[l] = d->w_ih_t[l]; a.h_init[l] = d->h_init[l]; a.out[l] = d->out[l];

@@ -112,7 +112,7 @@ def _run(L, T, B, H, p, seed, with_dhl=True, elem0=0):
     dh_init = torch.full((L, B, H), float("nan"), device=dev)
     whh_t = [w.t().contiguous() for w in d_whh]
     wih_t = [None] + [w.t().contiguous() for w in d_wih[1:]]
-    err = torch.zeros(16, dtype=torch.int32, device=dev)
+    err = torch.zeros(16 + 16 * 8, dtype=torch.int32, device=dev)
     d = N.WaveDesc()
     d.L, d.T, d.B, d.H = L, T, B, H
     d.gi0 = d_gi0.data_ptr()

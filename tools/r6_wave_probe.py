@@ -20,7 +20,7 @@ def probe(L, T, B, H, p, reps=5, seed=1, ws=None, timing=True):
     res = [torch.empty(T, B, 4 * H, device=dev) for _ in range(L)]; dG = [torch.empty(T, B, 4 * H, device=dev) for _ in range(L)]
     dh = torch.empty(L, B, H, device=dev)
     whh_t = [w.t().contiguous() for w in whh]; wih_t = [w.t().contiguous() for w in wih]
-    err = torch.zeros(16, dtype=torch.int32, device=dev)
+    err = torch.zeros(16 + 16 * 8, dtype=torch.int32, device=dev)
     d = N.WaveDesc(); d.L, d.T, d.B, d.H = L, T, B, H; d.gi0 = gi0.data_ptr()
     for l in range(L):
         d.w_hh[l], d.b_hh[l], d.w_ih[l], d.b_ih[l], d.w_ih_t[l] = whh[l].data_ptr(), bhh[l].data_ptr(), wih[l].data_ptr(), bih[l].data_ptr(), wih_t[l].data_ptr()
@@ -31,7 +31,7 @@ def probe(L, T, B, H, p, reps=5, seed=1, ws=None, timing=True):
         ws = (torch.empty(lib.b2t_gru_wave_ws_bytes(L, T, B, H, 0, int(p > 0)) // 4 + 64, device=dev),
               torch.empty(lib.b2t_gru_wave_ws_bytes(L, T, B, H, 1, int(p > 0)) // 4 + 64, device=dev))
     wsf, wsb = ws
-    r = dict(L=L, T=T, B=B, H=H, p=p, sc1_loads=os.environ.get("B2T_WAVE_SC1_LOADS", "0"))
+    r = dict(L=L, T=T, B=B, H=H, p=p, sc1_loads=os.environ.get("B2T_WAVE_SC1_LOADS", "0"), local=os.environ.get("B2T_WAVE_LOCAL", "1"))
     if not timing:
         N.check(lib.b2t_gru_wave_fwd_f32(C.byref(d), P(wsf), P(err), ops._stream()), "fwd")
         N.check(lib.b2t_gru_wave_bwd_f32(C.byref(d), P(wsb), P(err), ops._stream()), "bwd")
@@ -46,6 +46,9 @@ def probe(L, T, B, H, p, reps=5, seed=1, ws=None, timing=True):
             if i: ts.append(e0.elapsed_time(e1) * 1e3)
         assert int(err[0]) == 0, "hand-off timeout"
         r[name + "_us"] = round(min(ts), 1); r[name + "_us_per_step"] = round(min(ts) / (T + L - 1), 3); r[name + "_all"] = [round(t, 1) for t in ts]
+        if "wtiming" in os.environ.get("B2T_LIB", ""):     # cycles per step: wait own, loads + product, gates + tile, drain + counters, stores, wait neighbour, projection
+            tm = err[16 + (0 if name == "fwd" else 64):][:8 * L].view(L, 8).cpu().numpy()
+            r[name + "_cycles_per_step_by_layer"] = [[int(v) for v in row[:7]] for row in tm]
     assert all(torch.isfinite(o).all() for o in out + dG)
     print("R6WAVE " + json.dumps(r), flush=True)
 
@@ -58,7 +61,7 @@ for cfg in ((5, 500, 64, 512, 0.4), (5, 122, 64, 768, 0.4), (3, 40, 64, 256, 0.0
         got, _ = probe(*cfg, seed=20 + rep, ws=ws, timing=False)
         want, _ = probe(*cfg, seed=20 + rep, timing=False)
         ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
-    print("R6STALE " + json.dumps(dict(cfg=cfg, sc1_loads=os.environ.get("B2T_WAVE_SC1_LOADS", "0"), second_pass_on_used_workspace_equals_fresh=ok)), flush=True)
+    print("R6STALE " + json.dumps(dict(cfg=cfg, sc1_loads=os.environ.get("B2T_WAVE_SC1_LOADS", "0"), local=os.environ.get("B2T_WAVE_LOCAL", "1"), second_pass_on_used_workspace_equals_fresh=ok)), flush=True)
 for cfg in ((5, 500, 64, 512, 0.0), (5, 500, 64, 512, 0.4), (1, 500, 64, 512, 0.0),
             (5, 122, 64, 768, 0.4), (1, 122, 64, 768, 0.0)):
     probe(*cfg)
