@@ -99,6 +99,24 @@ class GradReducer:
         # stream of the process group joins the plan's queues (a fifth hardware queue shares a command-processor pipe and makes
         # every cross-queue hop of the pass slower), no event pair per bucket.
         self.inline = os.environ.get("B2T_DP_INLINE", "1") == "1"
+        # Round 6: the eight per-tensor-group buckets leave as at most THREE collectives -- head + upper layers, lower layers, day
+        # records + h0 -- each fired by the arrival of its last member (the executor hands the buckets over in a fixed order: head,
+        # layers L-1 .. 0, day, h0; members of a group are adjacent in the arena: layers in order, then out.*).  A collective that
+        # waits for a late peer holds the executor queue it was issued on; three can be late where eight could
+        # (bench `dp_forced_one_rank.each_collective_0p5ms_late_*`).  B2T_DP_COALESCE=0: one collective per bucket.
+        self.coalesce = os.environ.get("B2T_DP_COALESCE", "1") != "0"
+        layers = sorted((int(n[5:]) for n in self.buckets if n.startswith("layer")))
+        k = len(layers) // 2
+        upper, lower = [f"layer{l}" for l in layers if l >= k], [f"layer{l}" for l in layers if l < k]
+        self.groups = []
+        if "head" in self.buckets:
+            mem = ["head"] + upper
+            self.groups.append(dict(name="top", members=set(mem), span=(min(self.buckets[m][0] for m in mem), max(self.buckets[m][1] for m in mem))))
+        if lower:
+            self.groups.append(dict(name="low", members=set(lower), span=(min(self.buckets[m][0] for m in lower), max(self.buckets[m][1] for m in lower))))
+        self.groups.append(dict(name="tail", members={n for n in ("day", "h0") if n in self.buckets}, span=None))
+        self._arrived, self._fired = set(), set()
+        self.n_collectives = 0          # collectives issued since the last finish() (tests / bench)
         self.test_delay_us = float(os.environ.get("B2T_DP_TEST_DELAY_US", "0"))
         self._delay_cycles = None
         if self.test_delay_us > 0 and grad_arena.is_cuda:      # calibrate torch's spin kernel once, outside any pass
@@ -119,14 +137,16 @@ class GradReducer:
         # every tensor the reduction touches is allocated HERE, once: _start() runs inside the executor's bucket callback on one
         # of its queues and finish() on the caller's stream -- nothing of the exchange then comes from the caching allocator of
         # a stream other than the one that later reads it (no record_stream needed; ordering is the executor's join)
-        stage = torch.empty(K * (w_stride + b_stride), dtype=dt, device=dev)
+        h0a, h0b = self.buckets.get("h0", (0, 0))
+        stage = torch.empty(K * (w_stride + b_stride) + (h0b - h0a), dtype=dt, device=dev)     # ... and the h0 gradient rides in its tail (one collective)
         self.sparse = dict(active=active, seg=seg_of_day, w0=w0, ws=w_stride, b0=b0, bs=b_stride, D=n_days, K=K, status=status,
-                           stage=stage, stage_w=stage[:K * w_stride].view(K, w_stride), stage_b=stage[K * w_stride:].view(K, b_stride),
+                           stage=stage, stage_w=stage[:K * w_stride].view(K, w_stride), stage_b=stage[K * w_stride:K * (w_stride + b_stride)].view(K, b_stride),
+                           stage_h0=stage[K * (w_stride + b_stride):], h0=(h0a, h0b), h0_staged=False,
                            flags=torch.empty(n_days, dtype=active.dtype, device=dev), sorted=torch.empty(n_days, dtype=active.dtype, device=dev),
                            order_full=torch.empty(n_days, dtype=torch.int64, device=dev), nact=torch.empty(1, dtype=status.dtype, device=dev),
                            over=torch.empty(1, dtype=status.dtype, device=dev), pending=False)
 
-    def _start(self, name: str):
+    def _start(self, name: str, with_h0: bool = False):
         a, b = self.buckets[name]
         sp = getattr(self, "sparse", None)
         if name == "day" and sp is not None and sp["K"] < sp["D"]:
@@ -145,7 +165,12 @@ class GradReducer:
             torch.index_select(W, 0, order, out=sp["stage_w"])
             torch.index_select(Bv, 0, order, out=sp["stage_b"])
             sp["pending"] = True
-            self._reduce(sp["stage"])
+            if with_h0:                                   # coalesced tail: h0's gradient in the same collective
+                sp["stage_h0"].copy_(self.arena[sp["h0"][0]:sp["h0"][1]])
+                sp["h0_staged"] = True
+                self._reduce(sp["stage"])
+            else:
+                self._reduce(sp["stage"][:sp["K"] * (sp["ws"] + sp["bs"])])
             return
         self._reduce(self.arena[a:b])
 
@@ -154,6 +179,7 @@ class GradReducer:
             # measurement knob (B2T_DP_TEST_DELAY_US): a device-side spin on the stream the collective is about to run on stands for
             # a peer that arrives late -- what a blocking all-reduce on an executor queue costs the plan (bench `dp_forced_one_rank`)
             torch.cuda._sleep(self._delay_cycles)
+        self.n_collectives += 1
         if self.inline:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=False)
         else:
@@ -165,12 +191,35 @@ class GradReducer:
         if self.deferred:
             self._noted.append(name)
             return
-        self._start(name)
+        self._arrive(name)
+
+    def _arrive(self, name: str):
+        if not self.coalesce:
+            self._start(name)
+            return
+        self._arrived.add(name)
+        for g in self.groups:
+            if g["name"] in self._fired or not g["members"] or not g["members"] <= self._arrived:
+                continue
+            self._fired.add(g["name"])
+            if g["span"] is not None:
+                self._reduce(self.arena[g["span"][0]:g["span"][1]])
+            else:
+                sp = getattr(self, "sparse", None)
+                sparse_day = "day" in g["members"] and sp is not None and sp["K"] < sp["D"]
+                if sparse_day and "h0" in g["members"]:
+                    self._start("day", with_h0=True)
+                else:                                   # dense day bucket (B2T_DP_DENSE_DAYS=1 / no bound given): two ranges
+                    for m in sorted(g["members"]):
+                        self._start(m)
 
     def finish(self):
         for name in self._noted:
-            self._start(name)
+            self._arrive(name)
         self._noted = []
+        if self.coalesce and self._arrived and any(g["members"] and g["name"] not in self._fired for g in self.groups):
+            raise RuntimeError(f"data parallel: gradient buckets {sorted(self._arrived)} arrived but a group never completed")
+        self._arrived, self._fired = set(), set()
         for w in self.pending:
             w.wait()
         self.pending = []
@@ -181,6 +230,9 @@ class GradReducer:
             order = sp["order_full"][:sp["K"]]
             W.index_copy_(0, order, sp["stage_w"])
             Bv.index_copy_(0, order, sp["stage_b"])
+            if sp["h0_staged"]:
+                self.arena[sp["h0"][0]:sp["h0"][1]].copy_(sp["stage_h0"])
+                sp["h0_staged"] = False
             sp["pending"] = False
 
     def union_status(self, status: torch.Tensor):
