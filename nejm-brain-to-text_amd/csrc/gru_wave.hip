@@ -39,6 +39,12 @@ __device__ __forceinline__ bf16x8 cvt8(float4 a, float4 b) {
   r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
   return r;
 }
+// 8 floats -> 8 bf16, all-zero where !ok: an unconditional load (clamped address) + a mask, so that no branch sits around the load
+__device__ __forceinline__ u32x4 masked8(float4 a, float4 b, bool ok) {
+  const u32x4 v = __builtin_bit_cast(u32x4, cvt8(a, b));
+  const unsigned m = ok ? 0xffffffffu : 0u;
+  return u32x4{v.x & m, v.y & m, v.z & m, v.w & m};
+}
 __device__ __forceinline__ bf16x8 zero8() { return __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -123,20 +129,21 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
   const unsigned lo = (32 * pc + 8 * q < H) ? (unsigned)lane * 16u : (unsigned)(lane & 31) * 16u;
   return plain ? load_u4<0>(ring, base + (unsigned)pc * 1024u + lo) : load_u4<16>(ring, base + (unsigned)pc * 1024u + lo);
 }
-// One operand stream: at most 12 loads in flight (48 registers), each slot refilled as soon as its MFMAs are issued; BODY sees
-// `av` (the A operand of pair `p`) -- all loads of a short stream go out before the first MFMA.
+// One operand stream: every pair's load goes out before the first MFMA when the stream is at most 12 pairs long (48 registers);
+// longer streams keep 12 in flight and refill a slot as soon as its MFMAs are issued.  NO run-time branch inside (a `p < P` test per
+// pair made the compiler wait for every refill with vmcnt(0): 430 cycles per pair, R6.2): pairs beyond P re-read the last valid pair
+// and meet zero weights.  BODY sees `av` (the A operand of pair `p`).
 #define B2T_WAVE_STREAM(RING, BASE, BODY)                                                                              \
   {                                                                                                                    \
-    constexpr int LB_ = NP > 12 ? 12 : NP;                                                                             \
+    constexpr int LB_ = NP > 16 ? 8 : (NP > 12 ? 12 : NP);                                                                             \
     u32x4 v_[LB_];                                                                                                     \
-    _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q, plain_);                  \
+    _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q, plain_);          \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                   \
-      if (p < P) {                                                                                                     \
-        const bf16x8 av = __builtin_bit_cast(bf16x8, v_[p % LB_]);                                                     \
-        if (p + LB_ < NP) v_[p % LB_] = load_frag(RING, BASE, p + LB_, P, H, lane, q, plain_);                                 \
-        BODY                                                                                                           \
-      }                                                                                                                \
+      const bf16x8 av = __builtin_bit_cast(bf16x8, v_[p % LB_]);                                                       \
+      if (p + LB_ < NP) v_[p % LB_] = load_frag(RING, BASE, p + LB_, P, H, lane, q, plain_);                           \
+      BODY                                                                                                             \
+      if (NP > LB_) __builtin_amdgcn_sched_barrier(0);   /* refills stay where they are: hoisted, they would all be in flight (spills) */ \
     }                                                                                                                  \
   }
 
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   if (!wave_role<LOC>(a.tickets, L, G, false, layer, slice)) return;
   const int u0 = slice * 16, unit = u0 + j;
   u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer] slice as B fragments
-  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * P * 1024) + wave * (WAVE_TILES * WTILE_F);
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * NP * 1024) + wave * (WAVE_TILES * WTILE_F);
 
   bf16x8 w[3][NP];
   {
@@ -161,21 +168,22 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int k0 = 32 * p + 8 * q;
-      const bool ok = p < P && k0 < H;
+      const bool ok = k0 < H;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const float* src = whh + ((long long)g * H + unit) * H + (ok ? k0 : 0);
-        w[g][p] = ok ? cvt8(ld4(src), ld4(src + 4)) : zero8();
+        w[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
       }
+      __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
     }
   }
   if (layer > 0) {
     const float* wih = a.w_ih[layer];
-    for (int idx = wave; idx < 3 * P; idx += 4) {
-      const int g = idx / P, p = idx % P, k0 = 32 * p + 8 * q;
+    for (int idx = wave; idx < 3 * NP; idx += 4) {
+      const int g = idx / NP, p = idx % NP, k0 = 32 * p + 8 * q;
       const bool ok = k0 < H;
       const float* src = wih + ((long long)g * H + unit) * H + (ok ? k0 : 0);
-      wl[idx * 64 + lane] = ok ? __builtin_bit_cast(u32x4, cvt8(ld4(src), ld4(src + 4))) : u32x4{0u, 0u, 0u, 0u};
+      wl[idx * 64 + lane] = masked8(ld4(src), ld4(src + 4), ok);
     }
   }
   __syncthreads();
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     const unsigned pbase = (unsigned)(t + 1) * slot_bytes + rg_off;
     B2T_WAVE_STREAM(ring_in, pbase, {
       _Pragma("unroll") for (int g = 0; g < 3; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * P + p) * 64 + lane]), acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc[g], 0, 0, 0);
     })
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
   if (!wave_role<LOC>(a.tickets, L, G, true, layer, slice)) return;
   const int u0 = slice * 16, unit = u0 + j;
   u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer + 1]^T slice
-  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * P * 1024) + wave * (WAVE_TILES * WTILE_F);
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * NP * 1024) + wave * (WAVE_TILES * WTILE_F);
   const bool has_up = layer + 1 < L;
 
   bf16x8 w[3][NP];     // W_hh^T slice: column `unit`, k = array * H + 32 p + 8 q .. + 7
@@ -354,21 +362,22 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int k0 = 32 * p + 8 * q;
-      const bool ok = p < P && k0 < H;
+      const bool ok = k0 < H;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const float* src = wt + (long long)g * H + (ok ? k0 : 0);
-        w[g][p] = ok ? cvt8(ld4(src), ld4(src + 4)) : zero8();
+        w[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
       }
+      __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
     }
   }
   if (has_up) {
     const float* wt = a.w_ih_t[layer + 1] + (long long)unit * 3 * H;
-    for (int idx = wave; idx < 3 * P; idx += 4) {
-      const int g = idx / P, p = idx % P, k0 = 32 * p + 8 * q;
+    for (int idx = wave; idx < 3 * NP; idx += 4) {
+      const int g = idx / NP, p = idx % NP, k0 = 32 * p + 8 * q;
       const bool ok = k0 < H;
       const float* src = wt + (long long)g * H + (ok ? k0 : 0);
-      wl[idx * 64 + lane] = ok ? __builtin_bit_cast(u32x4, cvt8(ld4(src), ld4(src + 4))) : u32x4{0u, 0u, 0u, 0u};
+      wl[idx * 64 + lane] = masked8(ld4(src), ld4(src + 4), ok);
     }
   }
   __syncthreads();
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     for (int g = 0; g < 3; ++g) {
       const unsigned pbase = (unsigned)t * slot_bytes + rg_off + (unsigned)(g == 2 ? 3 : g) * arr_bytes;
       B2T_WAVE_STREAM(ring_up, pbase, {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * P + p) * 64 + lane]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc, 0, 0, 0);
       })
     }
     if (DROP) {
@@ -529,7 +538,8 @@ static int wave_cus() {
   return n;
 }
 
-size_t gru_wave_lds_bytes(int H) { const int P = (H / 16 + 1) / 2; return (size_t)3 * P * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
+static int wave_np(int H) { return H <= 128 ? 4 : H <= 256 ? 8 : H <= 512 ? 16 : 24; }   // the kernel template's pair count
+size_t gru_wave_lds_bytes(int H) { return (size_t)3 * wave_np(H) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
 size_t gru_wave_ring_bytes_fwd(int T, int B, int H) { return (size_t)(T + 1) * ((B + 15) / 16) * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_ring_bytes_bwd(int T, int B, int H) { return (size_t)T * ((B + 15) / 16) * 4 * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_cnt_words_fwd(int L, int T, int B) { return 16 + (size_t)L * 2 * ((B + 15) / 16) * (T + 1); }   // 16: the XCD tickets of the local form
