@@ -57,9 +57,12 @@ __device__ __forceinline__ void wave_wait(const unsigned* p, unsigned target, un
   for (;;) {
     unsigned v;
     if constexpr (LOCAL) {
-      v = 0u;
-      if (lane == 0) v = l2_atomic_read(const_cast<unsigned*>(p));
-      v = __builtin_amdgcn_readfirstlane(v);
+      // a SCALAR load that bypasses the scalar cache (glc): it counts in lgkmcnt, so the poll does not wait for the vector loads
+      // and stores this wave has in flight (a vector poll's vmcnt(0) put the step's HBM prefetches -- 12 to 24 loads -- and the
+      // previous step's stores in front of every first look at the counter: 2-5 k cycles per step, R6.2).  The counter is bumped
+      // by L2 atomics of the same XCD, which is where the scalar load reads it.
+      (void)lane;
+      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     } else {
       v = __hip_atomic_load(p, RLX_AGENT);
     }
@@ -133,11 +136,13 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
 // longer streams keep 12 in flight and refill a slot as soon as its MFMAs are issued.  NO run-time branch inside (a `p < P` test per
 // pair made the compiler wait for every refill with vmcnt(0): 430 cycles per pair, R6.2): pairs beyond P re-read the last valid pair
 // and meet zero weights.  BODY sees `av` (the A operand of pair `p`).
-#define B2T_WAVE_STREAM(RING, BASE, BODY)                                                                              \
+#define B2T_WAVE_STREAM(RING, BASE, BODY) B2T_WAVE_STREAM2(RING, BASE, {}, BODY)
+#define B2T_WAVE_STREAM2(RING, BASE, EXTRA, BODY)                                                                      \
   {                                                                                                                    \
     constexpr int LB_ = NP > 16 ? 8 : (NP > 12 ? 12 : NP);                                                                             \
     u32x4 v_[LB_];                                                                                                     \
     _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q, plain_);          \
+    EXTRA                                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                   \
       const bf16x8 av = __builtin_bit_cast(bf16x8, v_[p % LB_]);                                                       \
@@ -256,15 +261,18 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   };
   if (layer > 0) project(0);
 
-  for (int t = 0; t < T; ++t) {
-    if (layer == 0) {
+  // layer 0's input projection comes from memory (HBM): with the scalar poll of the local form the loads go out before the wait
+  // and land during it; a vector poll would wait for them first, so there they go out behind the recurrent product's first loads
+  auto load_gi0 = [&](int t) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* g3 = a.gi0 + ((long long)t * B + (m0 + 4 * q + i)) * 3 * H + unit;
+    for (int i = 0; i < 4; ++i) {
+      const float* g3 = a.gi0 + ((long long)t * B + (m0 + 4 * q + i)) * 3 * H + unit;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) gi[g][i] = live[i] ? __builtin_nontemporal_load(g3 + (long long)g * H) : 0.f;
-      }
+      for (int g = 0; g < 3; ++g) gi[g][i] = live[i] ? __builtin_nontemporal_load(g3 + (long long)g * H) : 0.f;
     }
+  };
+  for (int t = 0; t < T; ++t) {
+    if (LOC && layer == 0) load_gi0(t);
     wave_wait<LOC>(cnt_own + t, (unsigned)G, err, lane);
     WSTAMP(0)   // wait for the peers' h_{t-1}
     f32x4 gh[3];
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
 #pragma unroll
       for (int g = 0; g < 3; ++g) gh[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned cbase = (unsigned)t * slot_bytes + rg_off;
-      B2T_WAVE_STREAM(ring, cbase, {
+      B2T_WAVE_STREAM2(ring, cbase, { if (!LOC && layer == 0) load_gi0(t); }, {
         _Pragma("unroll") for (int g = 0; g < 3; ++g) gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], gh[g], 0, 0, 0);
       })
     }
@@ -320,12 +328,16 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     }
     if (rrow < B) *reinterpret_cast<float4*>(a.out[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hv;
     if (a.reserve[layer]) {
+      // (r, z, n, gh_n) row-major through the wave's four tiles: 4 x 16-byte stores per lane instead of 16 x 4-byte ones
+      tile_put(tiles + 0 * WTILE_F, sr, j, q); tile_put(tiles + 1 * WTILE_F, sz, j, q);
+      tile_put(tiles + 2 * WTILE_F, sn, j, q); tile_put(tiles + 3 * WTILE_F, sg, j, q);
+      if (rrow < B) {
+        float* rs = a.reserve[layer] + ((long long)t * B + rrow) * 4 * H + u0 + 4 * kg;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (live[i]) {
-          float* rs = a.reserve[layer] + ((long long)t * B + (m0 + 4 * q + i)) * 4 * H + unit;
-          __builtin_nontemporal_store(sr[i], rs); __builtin_nontemporal_store(sz[i], rs + H);
-          __builtin_nontemporal_store(sn[i], rs + 2 * H); __builtin_nontemporal_store(sg[i], rs + 3 * H);
+        for (int g = 0; g < 4; ++g) {
+          const float4 v4 = ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg);
+          __builtin_nontemporal_store(v4.x, rs + (long long)g * H); __builtin_nontemporal_store(v4.y, rs + (long long)g * H + 1);
+          __builtin_nontemporal_store(v4.z, rs + (long long)g * H + 2); __builtin_nontemporal_store(v4.w, rs + (long long)g * H + 3);
         }
       }
     }
@@ -440,8 +452,11 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
   if (has_up) project(T - 1);
 
   f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int t = T - 1; t >= -1; --t) {
-    f32x4 r, z, nv, ghn, hprev;
+  f32x4 r, z, nv, ghn, hprev;
+  // the step's elementwise operands (saved gates, h_{t-1}, the top layer's dY) come from memory (HBM): local form -- issued before
+  // the (scalar) poll, they land during the wait; placement-independent form -- behind the recurrent product's first loads (a
+  // vector poll would wait for them first)
+  auto prefetch = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       r[i] = z[i] = nv[i] = ghn[i] = hprev[i] = 0.f;
@@ -454,6 +469,9 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
         if (!has_up) dy[i] = __builtin_nontemporal_load(a.dY_top + ((long long)t * B + row) * H + unit);
       }
     }
+  };
+  for (int t = T - 1; t >= -1; --t) {
+    if (LOC || t == T - 1) prefetch(t);
     f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < T - 1) {
       wave_wait<LOC>(cnt_own + (t + 1), (unsigned)G, err, lane);
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const unsigned cbase = (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes;
-        B2T_WAVE_STREAM(ring, cbase, {
+        B2T_WAVE_STREAM2(ring, cbase, { if (!LOC && g == 0) prefetch(t); }, {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc, 0, 0, 0);
         })
       }
