@@ -62,7 +62,10 @@ __device__ __forceinline__ void wave_wait(const unsigned* p, unsigned target, un
       // previous step's stores in front of every first look at the counter: 2-5 k cycles per step, R6.2).  The counter is bumped
       // by L2 atomics of the same XCD, which is where the scalar load reads it.
       (void)lane;
-      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+      // (the address is wave-uniform but derives from the thread index: readfirstlane makes it an SGPR pair for the assembler)
+      const unsigned long long pa = reinterpret_cast<unsigned long long>(p);
+      const unsigned long long ps = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)pa);
+      asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ps) : "memory");
     } else {
       v = __hip_atomic_load(p, RLX_AGENT);
     }
