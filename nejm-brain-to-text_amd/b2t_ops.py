@@ -290,7 +290,11 @@ GRU_SET_SHIFT = 13   # B2T_GRU_SET_SHIFT: with GRU_PAIRED, bits 13-14 = the swee
 GRU_WAVE = 0x8000    # B2T_GRU_WAVE: the pass's L sweeps as ONE launch, the step-granular layer wavefront (csrc/gru_wave.hip)
 # bf16 mode (use_amp): the layer wavefront wherever the library holds the shape (H % 16 == 0, H <= 768, B <= 64, L x H / 16 workgroups
 # resident); B2T_WAVE=0 selects the round-5 chunk pipeline (the tests compare the two in one process: read per pass)
-WAVE = {"on": os.environ.get("B2T_WAVE", "1") not in ("0", "", "false", "False")}
+WAVE = {"on": os.environ.get("B2T_WAVE", "1") not in ("0", "", "false", "False"),
+        # time chunks of the wavefront passes (forward, backward): a launch per chunk, one behind the other; what overlaps is the work
+        # NEXT to the sweeps on the CUs they leave free -- layer 0's projection of the next chunk, the weight gradients of the chunk
+        # before (B2T_WAVE_CHUNKS="f,b", read per pass)
+        "chunks": (2, 4)}
 # the exact-fp32 backward sweeps as paired sweeps (B2T_BWD_PAIRED=1; H % 32 == 0, H <= 512, B <= 64 -- other shapes ignore the flag)
 PAIRED_BWD = {"on": os.environ.get("B2T_BWD_PAIRED", "0") not in ("0", "", "false", "False")}
 # which sweeps (exact fp32 or bf16 operands, H <= 512) hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
@@ -651,8 +655,15 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
     if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and \
             lib.b2t_gru_wave_supported(L, Tp, B, H):
-        ps.fwd_mode |= GRU_WAVE
-        ps.bwd_mode |= GRU_WAVE
+        wc = os.environ.get("B2T_WAVE_CHUNKS")
+        cf, cb = (int(v) for v in wc.split(",")) if wc else WAVE["chunks"]
+        dirs = os.environ.get("B2T_WAVE_DIRS", "fb")      # which passes (measurement knob: "f" / "b": the other pass keeps the chunk pipeline)
+        if "f" in dirs:
+            ps.fwd_mode |= GRU_WAVE
+            ps.chunks = max(1, min(cf, Tp // 16))
+        if "b" in dirs:
+            ps.bwd_mode |= GRU_WAVE
+            ps.chunks_bwd = max(1, min(cb, Tp // 16))
     nbytes = lib.b2t_pass_ws_bytes(C.byref(md), C.byref(ps))
     if nbytes == 0:
         raise RuntimeError("b2t_pass_ws_bytes: bad model / pass description")

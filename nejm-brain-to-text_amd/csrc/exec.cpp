@@ -116,6 +116,11 @@ int make_chunks(int Tp, int chunks, int (*out)[2]) {
   return k;
 }
 
+int chunk_len(int Tp, int chunks) {     // length of the longest chunk make_chunks cuts
+  const int n = std::max(1, std::min(std::min(chunks, MAXC), Tp / 16));
+  return (Tp + n - 1) / n;
+}
+
 // ---- workspace layout (deterministic in (model, pass): forward and backward carve the same addresses) --------------
 struct Layout {
   float *U, *Ud, *out[MAXL], *outd[MAXL], *gi[MAXL], *res[MAXL], *slab_gi[MAXL];
@@ -131,6 +136,7 @@ struct Layout {
   unsigned *wv_cnt_f, *wv_cnt_b;
   char *wv_ring_f[MAXL], *wv_ringd_f[MAXL], *wv_ring_b[MAXL], *wv_ringx_b[MAXL];
   float* wih_t[MAXL];
+  float* wv_carry;     // [2][L][B][H]: every layer's dh between two backward chunks
   size_t bytes;
 };
 
@@ -138,7 +144,8 @@ struct Layout {
 // GEMM regime) and a shape the kernels hold (all L x H / 16 workgroups resident).  Decided the same way by carve and by both passes.
 bool wave_pass(const b2t_model_t* m, const b2t_pass_t* p, int mode) {
   const int Tp = m->patch > 0 ? (p->T - m->patch) / m->stride + 1 : p->T;
-  return (mode & B2T_GRU_WAVE) && (mode & 0xff) == 1 && (mode & B2T_GRU_BF16) && p->bf16_gemm && gru_wave_ok(m->L, Tp, p->B, m->H, nullptr);
+  if (Tp < 1) return false;
+  return (mode & B2T_GRU_WAVE) && (mode & 0xff) == 1 && (mode & B2T_GRU_BF16) && p->bf16_gemm && gru_wave_ok(m->L, std::min(Tp, 4096), p->B, m->H, nullptr);
 }
 
 size_t colsum_ws_floats(long long rows, int cols) { return b2t_colsum_ws_bytes(rows, cols) / sizeof(float); }
@@ -184,8 +191,9 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
   for (size_t l = 0; l < MAXL; ++l) { w.wv_ring_f[l] = w.wv_ringd_f[l] = w.wv_ring_b[l] = w.wv_ringx_b[l] = nullptr; w.wih_t[l] = nullptr; }
   w.wv_cnt_f = w.wv_cnt_b = nullptr;
   if (wave_pass(m, p, p->fwd_mode)) {
-    w.wv_cnt_f = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_fwd((int)L, (int)Tp, (int)B) * sizeof(unsigned), 256);
-    const size_t rb = align_up(gru_wave_ring_bytes_fwd((int)Tp, (int)B, (int)H), 256);
+    const int Tc = chunk_len((int)Tp, p->chunks);     // a launch per time chunk: rings and counters hold one chunk
+    w.wv_cnt_f = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_fwd((int)L, Tc, (int)B) * sizeof(unsigned), 256);
+    const size_t rb = align_up(gru_wave_ring_bytes_fwd(Tc, (int)B, (int)H), 256);
     const bool drop = p->rnn_drop > 0.f && L > 1;
     for (size_t l = 0; l < L; ++l) { w.wv_ring_f[l] = base + off; off += rb; w.wv_ringd_f[l] = w.wv_ring_f[l]; }
     // the ring the layer above reads when it is not the own-recurrence ring: the dropped states, or the written-through copy of the local form
@@ -207,9 +215,12 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
       w.xpk_ih[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(Tp * B)), 256);
     }
   for (size_t l = 0; l < L; ++l) w.res[l] = take(Tp * B * 4 * H);
+  w.wv_carry = nullptr;
   if (wave_pass(m, p, p->bwd_mode)) {
-    w.wv_cnt_b = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_bwd((int)L, (int)Tp, (int)B) * sizeof(unsigned), 256);
-    const size_t rb = align_up(gru_wave_ring_bytes_bwd((int)Tp, (int)B, (int)H), 256);
+    const int Tc = chunk_len((int)Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks);
+    w.wv_cnt_b = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_bwd((int)L, Tc, (int)B) * sizeof(unsigned), 256);
+    w.wv_carry = take(2 * L * B * H);
+    const size_t rb = align_up(gru_wave_ring_bytes_bwd(Tc, (int)B, (int)H), 256);
     for (size_t l = 0; l < L; ++l) { w.wv_ring_b[l] = base + off; off += rb; w.wv_ringx_b[l] = w.wv_ring_b[l]; }
     if (gru_wave_local((int)L, (int)H)) for (size_t l = 1; l < L; ++l) { w.wv_ringx_b[l] = base + off; off += rb; }
     for (size_t l = 1; l < L; ++l) w.wih_t[l] = take(H * 3 * H);
@@ -954,7 +965,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   // layers >= 1 happen inside it.  One "chunk": nothing is pipelined over time any more.
   const bool wave = wave_pass(prm, p, mode);
   int chunks[MAXC][2];
-  const int nc = make_chunks(Tp, wave ? 1 : p->chunks, chunks);
+  const int nc = make_chunks(Tp, p->chunks, chunks);
   c.exact_k = nc > 1;
   c.nq = plan_queues(c, nc > 1 || wave, c.qs);   // the queues of this pass (the plan below refers to them by index)
   c.gkey = pass_key(1, prm, nullptr, p, {x, day_idx, states, logits, hidden, ws, sync_ws, stream}, {c.nq});
@@ -1026,7 +1037,8 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   }
   const bool gi0_chain = c.bf16_gemm && In0 >= 2048 && nc > 1 && getenv("B2T_GI0_CHAIN") && atoi(getenv("B2T_GI0_CHAIN")) == 1;   // opt-in: measured slower
   int t_gi0_prev = -1;
-  int t_gi_l0 = -1;   // wavefront: layer 0's projection task (the only one)
+  int t_gi_l0c[MAXC];   // wavefront: layer 0's projection task of every chunk (the only projections left)
+  for (int i = 0; i < MAXC; ++i) t_gi_l0c[i] = -1;
   for (int l = 0; l < L; ++l) {
     for (int ci = 0; ci < nc; ++ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
@@ -1097,32 +1109,36 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
       // earlier, and the step is SLOWER (5.85 against 5.81 ms: the later chunks' GEMMs now run next to the sweeps instead of in front of them).
       if (l == 0 && gi0_chain && !fused_from(l - 1)) { if (ci > 0 && t_gi0_prev >= 0) P.dep(t_gi, t_gi0_prev); t_gi0_prev = t_gi; }
       if (wave) {
-        // 3w. the layer wavefront: one task for the whole stack, created with the top layer (it needs every layer's initial state)
-        if (l == 0) t_gi_l0 = t_gi;
+        // 3w. the layer wavefront: ONE task per time chunk for the whole stack, created with the top layer (it needs every layer's
+        // initial state).  Chunks are launches one behind the other on a sweep queue: the only thing pipelined over them is what runs
+        // NEXT to the sweeps on the CUs they leave free (layer 0's projection of the next chunk; in the backward pass the weight
+        // gradients of the chunk before).
+        if (l == 0) t_gi_l0c[ci] = t_gi;
         if (l + 1 < L) { t_sw[l][ci] = -1; continue; }
-        const int t_ws = P.add("wsweep", 60.f + (Tp + 2 * L) * est_step_us(0) * hs, q_sweep, {t_gi_l0}, [&](hipStream_t ss) {
+        const int t_ws = P.add("wsweep", 60.f + (n + 2 * L) * est_step_us(0) * hs, q_sweep, {t_gi_l0c[ci], ci > 0 ? t_sw[L - 1][ci - 1] : -1}, [&, t0, t1, n](hipStream_t ss) {
           if (c.rc) return;
-          Ctx::Scope sc(c, ss, 8, 2.0 * Tp * B * 3.0 * H * H * (2 * L - 1));
+          Ctx::Scope sc(c, ss, 8, 2.0 * n * B * 3.0 * H * H * (2 * L - 1));
           WaveFwdArgs a;
           memset(&a, 0, sizeof(a));
-          a.L = L; a.T = Tp; a.B = B; a.H = H; a.gi0 = w.gi[0];
+          a.L = L; a.T = n; a.B = B; a.H = H; a.gi0 = w.gi[0] + (long long)t0 * B * 3 * H;
           const bool drop = p->rnn_drop > 0.f && L > 1;
           for (int k = 0; k < L; ++k) {
             a.w_hh[k] = prm->w_hh[k]; a.b_hh[k] = prm->b_hh[k]; a.w_ih[k] = prm->w_ih[k]; a.b_ih[k] = prm->b_ih[k];
-            a.h_init[k] = (states && !p->save) ? states + (size_t)k * B * H : w.out[k];
-            a.out[k] = w.out[k] + (long long)B * H;
-            a.outd[k] = (drop && k + 1 < L) ? w.outd[k] + (long long)B * H : nullptr;
-            a.reserve[k] = p->save ? w.res[k] : nullptr;
+            a.h_init[k] = (t0 == 0 && states && !p->save) ? states + (size_t)k * B * H : w.out[k] + (long long)t0 * B * H;
+            a.out[k] = w.out[k] + (long long)(1 + t0) * B * H;
+            a.outd[k] = (drop && k + 1 < L) ? w.outd[k] + (long long)(1 + t0) * B * H : nullptr;
+            a.reserve[k] = p->save ? w.res[k] + (long long)t0 * B * 4 * H : nullptr;
             a.ring[k] = w.wv_ring_f[k]; a.ringd[k] = w.wv_ringd_f[k];
             a.seed[k] = mix_seed(p->seed, 101 + k);
           }
           a.cnt = w.wv_cnt_f; a.err = reinterpret_cast<unsigned*>(sync_of(0));
-          a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;
+          a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = (long long)t0 * B * H;
           c.call(gru_wave_fwd(a, ss));
-          for (int k = 0; k < L && !c.rc; ++k)
-            c.call(check_hip(hipMemcpyAsync(hidden + (size_t)k * B * H, w.out[k] + (long long)Tp * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, ss), "model_forward: final state"));
+          if (t1 == Tp)
+            for (int k = 0; k < L && !c.rc; ++k)
+              c.call(check_hip(hipMemcpyAsync(hidden + (size_t)k * B * H, w.out[k] + (long long)Tp * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, ss), "model_forward: final state"));
         });
-        for (int k = 0; k < L; ++k) { t_sw[k][ci] = t_ws; P.dep(t_ws, t_init[k]); }
+        for (int k = 0; k < L; ++k) { t_sw[k][ci] = t_ws; if (ci == 0) P.dep(t_ws, t_init[k]); }
         continue;
       }
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
@@ -1296,7 +1312,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
 
   const bool wave = wave_pass(prm, p, mode) && w.wv_cnt_b;   // round 6: every layer's backward sweep in ONE launch (gru_wave.hip), dX of the layers >= 1 inside it
   int chunks[MAXC][2];
-  const int nc = make_chunks(Tp, wave ? 1 : (p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks), chunks);
+  const int nc = make_chunks(Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks, chunks);
   c.exact_k = nc > 1;
   c.nq = plan_queues(c, nc > 1 || wave, c.qs);   // the queues of this pass (the plan below refers to them by index)
   // (data parallel: the bucket callbacks issue collectives from inside the plan -- not replayable)
@@ -1412,34 +1428,40 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // Weight gradients: per chunk (bit l of wgrad_chunk_mask: the first chunk swept overwrites, the others accumulate in sweep
   // order -- a dependency chain, so the sums do not depend on the schedule) or once per layer after its last chunk.
   int t_bs[MAXL][MAXC], t_dx[MAXL][MAXC], t_wg_last[MAXL];
-  int t_wb = -1;   // wavefront: the one backward sweep task
+  int t_wbc[MAXC];   // wavefront: the backward sweep task of every time chunk
+  for (int i = 0; i < MAXC; ++i) t_wbc[i] = -1;
   for (int l = L - 1; l >= 0; --l) {
-    const bool per_chunk = nc > 1 && ((p->wgrad_chunk_mask >> l) & 1);
+    // (wavefront: the weight gradients of a chunk run on the CUs the sweep of the chunk before leaves free -- always per chunk)
+    const bool per_chunk = nc > 1 && (wave || ((p->wgrad_chunk_mask >> l) & 1));
     const int In = l == 0 ? In0 : H;
     int t_wg = -1, t_wg_hh = -1, t_wg_ih = -1;
     for (int ci = nc - 1; ci >= 0; --ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
       if (wave) {
-        // one task for the whole stack, created with the top layer (the first iteration)
+        // one task per time chunk for the whole stack, created with the top layer (the first iteration of the layer loop); between
+        // chunks every layer's dh is carried in wv_carry (double-buffered)
         if (l == L - 1) {
-          t_wb = P.add("wbsweep", 60.f + (Tp + 2 * L) * est_step_us(1) * hs, q_sweep, {t_top}, [&](hipStream_t ss) {
+          t_wbc[ci] = P.add("wbsweep", 60.f + (n + 2 * L) * est_step_us(1) * hs, q_sweep, {t_top, ci < nc - 1 ? t_wbc[ci + 1] : -1}, [&, ci, t0, n](hipStream_t ss) {
             if (c.rc) return;
-            Ctx::Scope sc(c, ss, 9, 2.0 * Tp * B * 3.0 * H * H * (2 * L - 1));
+            Ctx::Scope sc(c, ss, 9, 2.0 * n * B * 3.0 * H * H * (2 * L - 1));
             WaveBwdArgs a;
             memset(&a, 0, sizeof(a));
-            a.L = L; a.T = Tp; a.B = B; a.H = H; a.dY_top = w.dY[L - 1]; a.dh_last = dhidden; a.dh_init = w.dh_init;
+            a.L = L; a.T = n; a.B = B; a.H = H; a.dY_top = w.dY[L - 1] + (long long)t0 * B * H;
+            a.dh_last = ci == nc - 1 ? dhidden : w.wv_carry + (size_t)((ci + 1) % 2) * L * B * H;
+            a.dh_init = ci == 0 ? w.dh_init : w.wv_carry + (size_t)(ci % 2) * L * B * H;
             const bool drop = p->rnn_drop > 0.f && L > 1;
             for (int k = 0; k < L; ++k) {
-              a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k]; a.out[k] = w.out[k] + (long long)B * H;
-              a.reserve[k] = w.res[k]; a.dG[k] = w.dG[k]; a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
+              a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k] + (long long)t0 * B * H; a.out[k] = w.out[k] + (long long)(1 + t0) * B * H;
+              a.reserve[k] = w.res[k] + (long long)t0 * B * 4 * H; a.dG[k] = w.dG[k] + (long long)t0 * B * 4 * H;
+              a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
             }
             a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
-            a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;
+            a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = (long long)t0 * B * H;
             c.call(gru_wave_bwd(a, ss));
           });
-          for (int k = 0; k < L; ++k) { P.dep(t_wb, t_wt[k]); P.dep(t_wb, t_wit[k]); }
+          if (ci == nc - 1) for (int k = 0; k < L; ++k) { P.dep(t_wbc[ci], t_wt[k]); P.dep(t_wbc[ci], t_wit[k]); }
         }
-        t_bs[l][ci] = t_wb;
+        t_bs[l][ci] = t_wbc[ci];
       } else
       t_bs[l][ci] = P.add("bsweep", 40.f + n * est_step_us(1) * hs, q_sweep,
                           {l < L - 1 ? t_dx[l + 1][ci] : t_top, ci == nc - 1 ? t_wt[l] : t_bs[l][ci + 1]}, [&, l, ci, t0, n](hipStream_t ss) {
@@ -1461,7 +1483,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       else if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
-      if (wave && l > 0) t_dx[l][ci] = t_wb;   // made inside the sweep
+      if (wave && l > 0) t_dx[l][ci] = t_wbc[ci];   // made inside the sweep
       else
       t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1, t_wpk[l]},
                           [&, l, t0, n](hipStream_t s) { dx_gemm(s, l, t0, n); });

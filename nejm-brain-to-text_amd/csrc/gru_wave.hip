@@ -64,7 +64,8 @@ __device__ __forceinline__ void wave_wait(const unsigned* p, unsigned target, un
       (void)lane;
       // (the address is wave-uniform but derives from the thread index: readfirstlane makes it an SGPR pair for the assembler)
       const unsigned long long pa = reinterpret_cast<unsigned long long>(p);
-      const unsigned long long ps = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)pa);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pa), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pa >> 32));
+      const unsigned long long ps = ((unsigned long long)hi << 32) | (unsigned long long)lo;
       asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ps) : "memory");
     } else {
       v = __hip_atomic_load(p, RLX_AGENT);
@@ -264,8 +265,9 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   };
   if (layer > 0) project(0);
 
-  // layer 0's input projection comes from memory (HBM): with the scalar poll of the local form the loads go out before the wait
-  // and land during it; a vector poll would wait for them first, so there they go out behind the recurrent product's first loads
+  // layer 0's input projection comes from memory (HBM): the loads go out before the wait and land during it (local form: the scalar
+  // poll does not wait for them; behind the recurrent product's first loads instead they cost the placement-independent form 2.5 k
+  // cycles per step, R6.2)
   auto load_gi0 = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     }
   };
   for (int t = 0; t < T; ++t) {
-    if (LOC && layer == 0) load_gi0(t);
+    if (layer == 0) load_gi0(t);
     wave_wait<LOC>(cnt_own + t, (unsigned)G, err, lane);
     WSTAMP(0)   // wait for the peers' h_{t-1}
     f32x4 gh[3];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
 #pragma unroll
       for (int g = 0; g < 3; ++g) gh[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned cbase = (unsigned)t * slot_bytes + rg_off;
-      B2T_WAVE_STREAM2(ring, cbase, { if (!LOC && layer == 0) load_gi0(t); }, {
+      B2T_WAVE_STREAM2(ring, cbase, {}, {
         _Pragma("unroll") for (int g = 0; g < 3; ++g) gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], gh[g], 0, 0, 0);
       })
     }
@@ -456,9 +458,8 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
 
   f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 r, z, nv, ghn, hprev;
-  // the step's elementwise operands (saved gates, h_{t-1}, the top layer's dY) come from memory (HBM): local form -- issued before
-  // the (scalar) poll, they land during the wait; placement-independent form -- behind the recurrent product's first loads (a
-  // vector poll would wait for them first)
+  // the step's elementwise operands (saved gates, h_{t-1}, the top layer's dY) come from memory (HBM): issued before the poll,
+  // they land during the wait (the local form's scalar poll does not even wait for them)
   auto prefetch = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     }
   };
   for (int t = T - 1; t >= -1; --t) {
-    if (LOC || t == T - 1) prefetch(t);
+    prefetch(t);
     f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < T - 1) {
       wave_wait<LOC>(cnt_own + (t + 1), (unsigned)G, err, lane);
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const unsigned cbase = (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes;
-        B2T_WAVE_STREAM2(ring, cbase, { if (!LOC && g == 0) prefetch(t); }, {
+        B2T_WAVE_STREAM2(ring, cbase, {}, {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc, 0, 0, 0);
         })
       }

@@ -215,8 +215,9 @@ def test_bf16_mode_step_on_the_wavefront_tracks_the_chunk_pipeline(monkeypatch, 
         for b in range(B):
             tgt[b, tl[b]:] = 0
 
-        def grads(wave):
+        def grads(wave, chunks="1,1"):
             monkeypatch.setenv("B2T_WAVE", "1" if wave else "0")
+            monkeypatch.setenv("B2T_WAVE_CHUNKS", chunks)
             torch.manual_seed(3)
             m = GRUDecoder(F, H, D, Cc, drop[1], drop[0], L, patch[0], patch[1]).to(dev).train()
             ts = TrainStep(m, _step_args())
@@ -234,8 +235,15 @@ def test_bf16_mode_step_on_the_wavefront_tracks_the_chunk_pipeline(monkeypatch, 
             assert diff <= 5e-3 * scale, f"{name} differ by {diff} (scale {scale})"
         for a, b in zip(got, again):       # the wavefront itself is deterministic
             assert torch.equal(a, b)
+        # a launch per time chunk (what the trainer runs: the weight gradients of a chunk overlap the sweep of the next): states and
+        # dh are carried in fp32 exactly as inside one launch -- logits and losses are bit-identical; the weight gradients are
+        # accumulated chunk by chunk (another fp32 summation order)
+        cut = grads(True, "3,2")
+        assert torch.equal(cut[2], got[2]) and torch.equal(cut[1], got[1])
+        assert float((cut[0] - got[0]).abs().max()) <= 2e-4 * float(got[0].abs().max())
         # ... and it is the wavefront that ran: the two are not bit-identical
         assert not torch.equal(got[2], ref[2])
     finally:
         ops.set_amp(old_amp)
         monkeypatch.delenv("B2T_WAVE", raising=False)
+        monkeypatch.delenv("B2T_WAVE_CHUNKS", raising=False)
