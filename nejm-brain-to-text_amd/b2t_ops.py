@@ -656,8 +656,13 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and \
             lib.b2t_gru_wave_supported(L, Tp, B, H):
         wc = os.environ.get("B2T_WAVE_CHUNKS")
-        cf, cb = (int(v) for v in wc.split(",")) if wc else WAVE["chunks"]
-        dirs = os.environ.get("B2T_WAVE_DIRS", "fb")      # which passes (measurement knob: "f" / "b": the other pass keeps the chunk pipeline)
+        # a second forward chunk pays where the sweeps leave CUs free for the next chunk's day layer / layer-0 projection (C2: 160 of
+        # 256 CUs busy: 9.09 against 9.8 ms); at the shipped shape (240 busy) one launch (5.49 against 5.63 ms, 6.9 with 2 / 2)
+        cf, cb = (int(v) for v in wc.split(",")) if wc else ((WAVE["chunks"][0] if L * (H // 16) <= 192 else 1), WAVE["chunks"][1])
+        # Which passes.  Measured (NOTES.md R6.2): the FORWARD wavefront beats the chunk pipeline at both bench shapes; the backward
+        # one (7.9 us per step at C2, 15 at the shipped shape: three times the forward's operand bytes per CU) does not -- the chunk
+        # pipeline hides the weight-gradient GEMMs beside its sweeps -- so the default is "f" (B2T_WAVE_DIRS=fb / b: measurement knob)
+        dirs = os.environ.get("B2T_WAVE_DIRS", WAVE.get("dirs", "f"))
         if "f" in dirs:
             ps.fwd_mode |= GRU_WAVE
             ps.chunks = max(1, min(cf, Tp // 16))

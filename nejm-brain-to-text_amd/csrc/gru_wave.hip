@@ -129,12 +129,12 @@ __device__ __forceinline__ u32x4 tile_frag(const float* tile, int lane) {
 // cache fetches is final, and neither cache can hold an older copy (both are invalidated when the kernel starts).  So ORDINARY loads
 // are safe across XCDs -- the first consumer on an XCD brings the line into that L2, the other 31 CUs hit it at L2 speed -- where
 // sc1 loads go to memory every time at ~10 B per clock and CU (measured: 6.6 / 12.7 us per step at C2, NOTES.md R6.2).
-// g_wave_plain: set from B2T_WAVE_SC1_LOADS (A/B knob) by the launcher.
 __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int p, int P, int H, int lane, int q, bool plain = true) {
   const int pc = p < P ? p : P - 1;
   // units past H (odd H / 16: the last pair's upper half) meet zero weights: those lanes re-read the lower half (finite data)
   const unsigned lo = (32 * pc + 8 * q < H) ? (unsigned)lane * 16u : (unsigned)(lane & 31) * 16u;
-  return plain ? load_u4<0>(ring, base + (unsigned)pc * 1024u + lo) : load_u4<16>(ring, base + (unsigned)pc * 1024u + lo);
+  (void)plain;   // (the sc1 A/B of R6.2 is over: a run-time choice made the compiler issue BOTH loads per fragment)
+  return load_u4<0>(ring, base + (unsigned)pc * 1024u + lo);
 }
 // One operand stream: every pair's load goes out before the first MFMA when the stream is at most 12 pairs long (48 registers);
 // longer streams keep 12 in flight and refill a slot as soon as its MFMAs are issued.  NO run-time branch inside (a `p < P` test per
@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
       for (int g = 0; g < 3; ++g) {
         const float* src = whh + ((long long)g * H + unit) * H + (ok ? k0 : 0);
         w[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
+        // H > 512: 288 registers of weights.  Left to itself the allocator spilled 63 of the 72 fragments to scratch and re-read them
+        // in front of every MFMA; pinned -- two gates in accumulation registers (192 of the 256), the third in architectural ones --
+        // nothing spills (R6.2)
+        if constexpr (NP > 16) { if (g < 2) asm volatile("" : "+a"(w[g][p])); else asm volatile("" : "+v"(w[g][p])); }
       }
       __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
     }
@@ -384,6 +388,10 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
       for (int g = 0; g < 3; ++g) {
         const float* src = wt + (long long)g * H + (ok ? k0 : 0);
         w[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
+        // H > 512: 288 registers of weights.  Left to itself the allocator spilled 63 of the 72 fragments to scratch and re-read them
+        // in front of every MFMA; pinned -- two gates in accumulation registers (192 of the 256), the third in architectural ones --
+        // nothing spills (R6.2)
+        if constexpr (NP > 16) { if (g < 2) asm volatile("" : "+a"(w[g][p])); else asm volatile("" : "+v"(w[g][p])); }
       }
       __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
     }
