@@ -217,9 +217,8 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
   for (size_t l = 0; l < L; ++l) w.res[l] = take(Tp * B * 4 * H);
   w.wv_carry = nullptr;
   if (wave_pass(m, p, p->bwd_mode)) {
-    const int Tc = chunk_len((int)Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks);
+    const int Tc = (int)Tp;      // one launch for the whole sequence (its time chunks are the gated consumers' chunks)
     w.wv_cnt_b = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_bwd((int)L, Tc, (int)B) * sizeof(unsigned), 256);
-    w.wv_carry = take(2 * L * B * H);
     const size_t rb = align_up(gru_wave_ring_bytes_bwd(Tc, (int)B, (int)H), 256);
     for (size_t l = 0; l < L; ++l) { w.wv_ring_b[l] = base + off; off += rb; w.wv_ringx_b[l] = w.wv_ring_b[l]; }
     if (gru_wave_local((int)L, (int)H)) for (size_t l = 1; l < L; ++l) { w.wv_ringx_b[l] = base + off; off += rb; }
@@ -1428,8 +1427,12 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // Weight gradients: per chunk (bit l of wgrad_chunk_mask: the first chunk swept overwrites, the others accumulate in sweep
   // order -- a dependency chain, so the sums do not depend on the schedule) or once per layer after its last chunk.
   int t_bs[MAXL][MAXC], t_dx[MAXL][MAXC], t_wg_last[MAXL];
-  int t_wbc[MAXC];   // wavefront: the backward sweep task of every time chunk
-  for (int i = 0; i < MAXC; ++i) t_wbc[i] = -1;
+  int t_wb = -1, t_wclear = -1;   // wavefront: the one backward sweep task and the task that clears its counters
+  // gated consumers of the sweep's dG (wavefront, more than one consumer chunk): they wait on the DEVICE, so they must never sit in
+  // front of the sweep on its own queue (the caller's stream): queues 1..3 only
+  const bool gated = wave && nc > 1 && c.nq > 1;
+  const unsigned q_gated = gated ? (((1u << c.nq) - 1u) & ~1u) : Q_ANY;
+  auto gate = [&](hipStream_t s, int l, int t0) { if (gated && t0 > 0 && !c.rc) c.call(gru_wave_gate(w.wv_cnt_b, l, t0, Tp, B, H, reinterpret_cast<unsigned*>(sync_of(0)), s)); };
   for (int l = L - 1; l >= 0; --l) {
     // (wavefront: the weight gradients of a chunk run on the CUs the sweep of the chunk before leaves free -- always per chunk)
     const bool per_chunk = nc > 1 && (wave || ((p->wgrad_chunk_mask >> l) & 1));
@@ -1438,30 +1441,32 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     for (int ci = nc - 1; ci >= 0; --ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
       if (wave) {
-        // one task per time chunk for the whole stack, created with the top layer (the first iteration of the layer loop); between
-        // chunks every layer's dh is carried in wv_carry (double-buffered)
-        if (l == L - 1) {
-          t_wbc[ci] = P.add("wbsweep", 60.f + (n + 2 * L) * est_step_us(1) * hs, q_sweep, {t_top, ci < nc - 1 ? t_wbc[ci + 1] : -1}, [&, ci, t0, n](hipStream_t ss) {
+        // ONE launch for the whole stack and the whole sequence, created with the top layer (the first iteration of the layer loop).
+        // The time chunks of this pass are the CONSUMERS' chunks: layer 0's input gradient and every layer's weight gradients run chunk
+        // by chunk BESIDE the sweep, on the CUs it leaves free (H = 512: 96 of 256), each behind a one-wave gate kernel that waits for
+        // the sweep's progress word of its layer (gru_wave_gate: dG[t0 .. T') written through and acknowledged).  Launches per chunk
+        // were measured instead and lost 0.15-0.25 ms per chunk to prologues and pipeline fill (NOTES.md R6.2).
+        if (l == L - 1 && ci == nc - 1) {
+          t_wclear = P.add("wbclear", 5.f, Q_MAIN, {t_start}, [&](hipStream_t ss) { c.call(gru_wave_bwd_clear(w.wv_cnt_b, L, Tp, B, ss)); });
+          t_wb = P.add("wbsweep", 60.f + (Tp + 2 * L) * est_step_us(1) * hs, Q_MAIN, {t_top, t_wclear}, [&](hipStream_t ss) {
             if (c.rc) return;
-            Ctx::Scope sc(c, ss, 9, 2.0 * n * B * 3.0 * H * H * (2 * L - 1));
+            Ctx::Scope sc(c, ss, 9, 2.0 * Tp * B * 3.0 * H * H * (2 * L - 1));
             WaveBwdArgs a;
             memset(&a, 0, sizeof(a));
-            a.L = L; a.T = n; a.B = B; a.H = H; a.dY_top = w.dY[L - 1] + (long long)t0 * B * H;
-            a.dh_last = ci == nc - 1 ? dhidden : w.wv_carry + (size_t)((ci + 1) % 2) * L * B * H;
-            a.dh_init = ci == 0 ? w.dh_init : w.wv_carry + (size_t)(ci % 2) * L * B * H;
+            a.L = L; a.T = Tp; a.B = B; a.H = H; a.dY_top = w.dY[L - 1]; a.dh_last = dhidden; a.dh_init = w.dh_init;
             const bool drop = p->rnn_drop > 0.f && L > 1;
             for (int k = 0; k < L; ++k) {
-              a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k] + (long long)t0 * B * H; a.out[k] = w.out[k] + (long long)(1 + t0) * B * H;
-              a.reserve[k] = w.res[k] + (long long)t0 * B * 4 * H; a.dG[k] = w.dG[k] + (long long)t0 * B * 4 * H;
-              a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
+              a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k]; a.out[k] = w.out[k] + (long long)B * H;
+              a.reserve[k] = w.res[k]; a.dG[k] = w.dG[k]; a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
             }
             a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
-            a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = (long long)t0 * B * H;
+            a.flags = 2; a.prog = w.wv_cnt_b;     // counters cleared by wbclear; publish progress for the gated consumers
+            a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;
             c.call(gru_wave_bwd(a, ss));
           });
-          if (ci == nc - 1) for (int k = 0; k < L; ++k) { P.dep(t_wbc[ci], t_wt[k]); P.dep(t_wbc[ci], t_wit[k]); }
+          for (int k = 0; k < L; ++k) { P.dep(t_wb, t_wt[k]); P.dep(t_wb, t_wit[k]); }
         }
-        t_bs[l][ci] = t_wbc[ci];
+        t_bs[l][ci] = t_wb;
       } else
       t_bs[l][ci] = P.add("bsweep", 40.f + n * est_step_us(1) * hs, q_sweep,
                           {l < L - 1 ? t_dx[l + 1][ci] : t_top, ci == nc - 1 ? t_wt[l] : t_bs[l][ci + 1]}, [&, l, ci, t0, n](hipStream_t ss) {
@@ -1483,10 +1488,10 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       else if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
-      if (wave && l > 0) t_dx[l][ci] = t_wbc[ci];   // made inside the sweep
+      if (wave && l > 0) t_dx[l][ci] = t_wb;   // made inside the sweep
       else
-      t_dx[l][ci] = P.add("dx", e_dx, Q_ANY, {t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1, t_wpk[l]},
-                          [&, l, t0, n](hipStream_t s) { dx_gemm(s, l, t0, n); });
+      t_dx[l][ci] = P.add("dx", e_dx, (gated && t0 > 0) ? q_gated : Q_ANY, {(gated && t0 > 0) ? t_wclear : t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1, t_wpk[l]},
+                          [&, l, t0, n](hipStream_t s) { gate(s, l, t0); dx_gemm(s, l, t0, n); });
       if (per_chunk || ci == 0) {
         const int w0 = per_chunk ? t0 : 0, w1 = per_chunk ? t1 : Tp;
         const int acc = per_chunk && ci != nc - 1 ? 1 : 0;
@@ -1516,8 +1521,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
           t_wg_hh = t_hh; t_wg_ih = t_ih;
           t_wg = P.add("wgrad_join", 0.f, Q_ANY, {t_hh, t_ih}, nullptr);
         } else
-        t_wg = P.add("wgrad", est_gemm(3 * H, H, K) + est_gemm(3 * H, In, K) + 60.f, Q_ANY, {t_bs[l][ci], t_wg, t_xp},
-                     [&, l, w0, w1, acc, fin, xpre](hipStream_t s) { layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin, 3, xpre); });
+        t_wg = P.add("wgrad", est_gemm(3 * H, H, K) + est_gemm(3 * H, In, K) + 60.f, (gated && w0 > 0) ? q_gated : Q_ANY, {(gated && w0 > 0) ? t_wclear : t_bs[l][ci], t_wg, t_xp},
+                     [&, l, w0, w1, acc, fin, xpre](hipStream_t s) { gate(s, l, w0); layer_weight_grads(c, s, prm, grd, p, w, l, w0, w1, acc, fin, 3, xpre); });
       }
     }
     t_wg_last[l] = t_wg;
@@ -1581,10 +1586,26 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   });
   for (int l = 1; l < L; ++l) P.dep(t_h0, t_bs[l][0]);
   bucket(L + 1, t_h0);
+  int t_end = -1;
   {
-    const int t_end = P.add("end", 0.f, Q_MAIN, {t_h0, t_dayfin, t_head_w, t_bucket}, nullptr);
+    t_end = P.add("end", 0.f, Q_MAIN, {t_h0, t_dayfin, t_head_w, t_bucket}, nullptr);
     for (int l = 0; l < L; ++l) { P.dep(t_end, t_wg_last[l]); P.dep(t_end, t_dx[l][0]); }
     P.dep(t_end, t_top);
+  }
+  if (gated && t_wb >= 0) {
+    // Gated consumers wait on the DEVICE for the sweep.  The sweep runs on the caller's stream; anything issued IN FRONT of it there
+    // that (transitively) waited for a gated task would wait for a sweep queued behind itself.  So the caller's stream carries the
+    // sweep, what the sweep itself needs, and the final join -- everything else goes to the worker queues.
+    std::vector<char> need(P.t.size(), 0);
+    std::vector<int> stack{t_wb};
+    while (!stack.empty()) {
+      const int i = stack.back(); stack.pop_back();
+      if (need[(size_t)i]) continue;
+      need[(size_t)i] = 1;
+      for (int d : P.t[(size_t)i].deps) stack.push_back(d);
+    }
+    for (size_t i = 0; i < P.t.size(); ++i)
+      if (!need[i] && (int)i != t_end) P.t[i].qmask &= q_gated;
   }
   run_plan(c, P, c.nq, c.qs);
   return c.rc;

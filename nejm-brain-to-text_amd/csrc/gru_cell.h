@@ -108,8 +108,9 @@ struct WaveBwdArgs {
   float* dG[B2T_MAX_LAYERS];                               // [T][B][4H] = (dr, dz, dn r, dn)
   char* ring[B2T_MAX_LAYERS];                              // fragment rings: slot t, 4 arrays
   char* ringx[B2T_MAX_LAYERS];                             // the written-through copy the layer below reads in the local form
-  unsigned* cnt;                                           // 16 ticket words + [L][2][row groups][T]
+  unsigned* cnt;                                           // 16 ticket words + 64 progress words + [L][2][row groups][T]
   unsigned* tickets;
+  unsigned* prog;                                          // non-null (any value; the launcher points it into cnt): publish progress for gated consumers
   unsigned* timing;
   unsigned* err;
   float drop_p, drop_scale; unsigned long long seed[B2T_MAX_LAYERS]; long long elem0;
@@ -123,7 +124,9 @@ size_t gru_wave_ring_bytes_bwd(int T, int B, int H);
 size_t gru_wave_cnt_words_fwd(int L, int T, int B);
 size_t gru_wave_cnt_words_bwd(int L, int T, int B);
 int gru_wave_fwd(const WaveFwdArgs& a, hipStream_t s);
-int gru_wave_bwd(const WaveBwdArgs& a, hipStream_t s);
+int gru_wave_bwd(const WaveBwdArgs& a, hipStream_t s);   // a.flags bit 1: counters already cleared (gru_wave_bwd_clear)
+int gru_wave_bwd_clear(unsigned* cnt, int L, int T, int B, hipStream_t s);
+int gru_wave_gate(unsigned* cnt, int layer, int t0, int T, int B, int H, unsigned* err, hipStream_t s);
 
 bool gru_persistent_bwd_pair_ok(int B, int H);
 int gru_persistent_bwd_pair(const float* dY, const float* dh_last, const float* reserve, const float* out, const float* h_init,

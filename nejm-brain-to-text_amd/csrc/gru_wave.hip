@@ -533,6 +533,9 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     wave_drain();
     wave_bump<LOC>(cnt_own + t, lane);
     if (XRING && pending_x >= 0) wave_bump<false>(cnt_x + pending_x, lane);
+    // progress for consumers OUTSIDE the launch (the gated weight-gradient GEMMs, wave_gate_kernel): the drain above acknowledged
+    // every store of the steps > t, so G x (T - t) bumps of this word certify dG[t + 1 .. T) in memory (written through below)
+    if (a.prog) wave_bump<false>(a.prog + layer * ngrp + rg, lane);
     WSTAMP(3)
     if (XRING && feeds) {
       store_u4<16>(ringx, base + (unsigned)a0 * arr_bytes, f0);
@@ -540,18 +543,36 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
       pending_x = t;
     }
     if (rrow < B) {
-      float* dg = a.dG[layer] + ((long long)t * B + rrow) * 4 * H + u0 + 4 * kg;
+      float* dgl = a.dG[layer] + (long long)t * B * 4 * H;
+      const unsigned off = (unsigned)(((long long)rrow * 4 * H + u0 + 4 * kg) * 4);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dg + (long long)g * H) = ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg);
+      for (int g = 0; g < 4; ++g) store_f4<16>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
     }
     WSTAMP(4)
     if (has_up && t > 0) project(t - 1);
   }
   if (XRING && pending_x >= 0) { wave_drain(); wave_bump<false>(cnt_x + pending_x, lane); }
+  if (a.prog) { wave_drain(); wave_bump<false>(a.prog + layer * ngrp + rg, lane); }     // G x (T + 1): everything is in memory
 #ifdef B2T_WAVE_TIMING
   if (slice == 0 && wave == 0 && lane == 0 && a.timing)
     for (int i = 0; i < 8; ++i) a.timing[layer * 8 + i] = (unsigned)(tacc[i] / (unsigned long long)T);
 #endif
+}
+
+// A consumer outside the launch waits for the sweep's progress: one wave, lane r polls word r (row group r of the layer) until
+// it reaches `target` = G x (T - t0 + 1) -- dG[t0 .. T) of that layer is then in memory.  Enqueued in front of a gated GEMM on the
+// GEMM's queue; it runs on a CU the sweeps leave free.  Bounded like every spin here (sets the sticky error word).
+__global__ void wave_gate_kernel(const unsigned* prog, int n, unsigned target, unsigned* err) {
+  const int lane = threadIdx.x;
+  if (lane >= n) return;
+  unsigned spins = 0;
+  while (__hip_atomic_load(prog + lane, RLX_AGENT) < target) {
+    if ((++spins & 255u) == 0u) {
+      if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+      if (spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -573,7 +594,7 @@ size_t gru_wave_lds_bytes(int H) { return (size_t)3 * wave_np(H) * 1024 + (size_
 size_t gru_wave_ring_bytes_fwd(int T, int B, int H) { return (size_t)(T + 1) * ((B + 15) / 16) * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_ring_bytes_bwd(int T, int B, int H) { return (size_t)T * ((B + 15) / 16) * 4 * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_cnt_words_fwd(int L, int T, int B) { return 16 + (size_t)L * 2 * ((B + 15) / 16) * (T + 1); }   // 16: the XCD tickets of the local form
-size_t gru_wave_cnt_words_bwd(int L, int T, int B) { return 16 + (size_t)L * 2 * ((B + 15) / 16) * T; }
+size_t gru_wave_cnt_words_bwd(int L, int T, int B) { return 16 + 64 + (size_t)L * 2 * ((B + 15) / 16) * T; }   // tickets, progress words [L][row groups] (<= 32), counters
 
 // Shapes the wavefront serves; `why` (optional) receives the reason when it does not.
 bool gru_wave_ok(int L, int T, int B, int H, const char** why) {
@@ -641,6 +662,16 @@ int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
   return check_hip(hipGetLastError(), "gru_wave_fwd");
 }
 
+int gru_wave_bwd_clear(unsigned* cnt, int L, int T, int B, hipStream_t s) {
+  return check_hip(hipMemsetAsync(cnt, 0, gru_wave_cnt_words_bwd(L, T, B) * sizeof(unsigned), s), "gru_wave_bwd: counters");
+}
+// gate of a consumer of layer `layer`'s dG[t0 .. T) (see wave_gate_kernel); cnt = the block gru_wave_bwd counts in
+int gru_wave_gate(unsigned* cnt, int layer, int t0, int T, int B, int H, unsigned* err, hipStream_t s) {
+  const int ngrp = (B + 15) / 16, G = H / 16;
+  hipLaunchKernelGGL(wave_gate_kernel, dim3(1), dim3(64), 0, s, cnt + 16 + layer * ngrp, ngrp, (unsigned)G * (unsigned)(T - t0 + 1), err);
+  return check_hip(hipGetLastError(), "gru_wave_gate");
+}
+
 int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   WaveBwdArgs a = a_in;
   a.flags = wave_flags();
@@ -648,9 +679,9 @@ int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_bwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
   const bool drop = a.drop_p > 0.f && a.L > 1, loc = gru_wave_local(a.L, a.H);
   const size_t lds = gru_wave_lds_bytes(a.H);
-  a.tickets = a.cnt; a.cnt = a.cnt + 16;
-  int rc = check_hip(hipMemsetAsync(a.tickets, 0, gru_wave_cnt_words_bwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_bwd: counters");
-  if (rc) return rc;
+  int rc = 0;
+  if (!(a_in.flags & 2)) { rc = gru_wave_bwd_clear(a.cnt, a.L, a.T, a.B, s); if (rc) return rc; }   // (bit 1: the caller cleared them, gated consumers are already waiting)
+  a.tickets = a.cnt; a.prog = a_in.prog ? a.cnt + 16 : nullptr; a.cnt = a.cnt + 16 + 64;
   const dim3 grid(loc ? 256 : a.L * (a.H / 16));
 #define B2T_WAVE_BWD(NPV)                                                                                              \
   do {                                                                                                                 \

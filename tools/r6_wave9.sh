@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r6_wave9; mkdir -p $O
+O=gpurun_out/r6_wave10; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_wave.py -x -q -s > $O/pytest_wave.txt 2>&1; echo "pytest wave rc $?" | tee $O/summary.txt
 tail -5 $O/pytest_wave.txt
 export R6_PROBE_ONLY_TIMING=1
