@@ -294,7 +294,7 @@ WAVE = {"on": os.environ.get("B2T_WAVE", "1") not in ("0", "", "false", "False")
         # time chunks of the wavefront passes (forward, backward): a launch per chunk, one behind the other; what overlaps is the work
         # NEXT to the sweeps on the CUs they leave free -- layer 0's projection of the next chunk, the weight gradients of the chunk
         # before (B2T_WAVE_CHUNKS="f,b", read per pass)
-        "chunks": (2, 4)}
+        "chunks": (1, 1), "dirs": "f"}
 # the exact-fp32 backward sweeps as paired sweeps (B2T_BWD_PAIRED=1; H % 32 == 0, H <= 512, B <= 64 -- other shapes ignore the flag)
 PAIRED_BWD = {"on": os.environ.get("B2T_BWD_PAIRED", "0") not in ("0", "", "false", "False")}
 # which sweeps (exact fp32 or bf16 operands, H <= 512) hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
@@ -656,12 +656,13 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and \
             lib.b2t_gru_wave_supported(L, Tp, B, H):
         wc = os.environ.get("B2T_WAVE_CHUNKS")
-        # a second forward chunk pays where the sweeps leave CUs free for the next chunk's day layer / layer-0 projection (C2: 160 of
-        # 256 CUs busy: 9.09 against 9.8 ms); at the shipped shape (240 busy) one launch (5.49 against 5.63 ms, 6.9 with 2 / 2)
-        cf, cb = (int(v) for v in wc.split(",")) if wc else ((WAVE["chunks"][0] if L * (H // 16) <= 192 else 1), WAVE["chunks"][1])
-        # Which passes.  Measured (NOTES.md R6.2): the FORWARD wavefront beats the chunk pipeline at both bench shapes; the backward
-        # one (7.9 us per step at C2, 15 at the shipped shape: three times the forward's operand bytes per CU) does not -- the chunk
-        # pipeline hides the weight-gradient GEMMs beside its sweeps -- so the default is "f" (B2T_WAVE_DIRS=fb / b: measurement knob)
+        # chunks (forward launches, backward consumer chunks): 1, 1 -- forward launches per chunk measured equal (C2: 8.98 / 9.01 /
+        # 8.98 ms with 1 / 2 / 3), gated backward consumers worse with every chunk (NOTES.md R6.2)
+        cf, cb = (int(v) for v in wc.split(",")) if wc else WAVE["chunks"]
+        # Which passes.  Measured (NOTES.md R6.2): the FORWARD wavefront beats the chunk pipeline at both bench shapes (C2 9.80 ->
+        # 8.98 ms, shipped shape 5.61 -> 5.11); the backward one (8 us per step at C2, 10.4 at the shipped shape: three times the
+        # forward's operand bytes per CU, and its weight gradients then run behind it instead of beside it) does not (9.98 / 5.29) --
+        # so the default is "f" (B2T_WAVE_DIRS=fb / b: measurement knob; the backward kernel stays tested)
         dirs = os.environ.get("B2T_WAVE_DIRS", WAVE.get("dirs", "f"))
         if "f" in dirs:
             ps.fwd_mode |= GRU_WAVE

@@ -136,7 +136,6 @@ struct Layout {
   unsigned *wv_cnt_f, *wv_cnt_b;
   char *wv_ring_f[MAXL], *wv_ringd_f[MAXL], *wv_ring_b[MAXL], *wv_ringx_b[MAXL];
   float* wih_t[MAXL];
-  float* wv_carry;     // [2][L][B][H]: every layer's dh between two backward chunks
   size_t bytes;
 };
 
@@ -215,7 +214,6 @@ void carve(const b2t_model_t* m, const b2t_pass_t* p, char* base, Layout& w) {
       w.xpk_ih[l] = base + off; off += align_up(gemm_bf16p_operand_bytes((int)(l == 0 ? In0 : H), (int)(Tp * B)), 256);
     }
   for (size_t l = 0; l < L; ++l) w.res[l] = take(Tp * B * 4 * H);
-  w.wv_carry = nullptr;
   if (wave_pass(m, p, p->bwd_mode)) {
     const int Tc = (int)Tp;      // one launch for the whole sequence (its time chunks are the gated consumers' chunks)
     w.wv_cnt_b = reinterpret_cast<unsigned*>(base + off); off += align_up(gru_wave_cnt_words_bwd((int)L, Tc, (int)B) * sizeof(unsigned), 256);

@@ -143,7 +143,7 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
 #define B2T_WAVE_STREAM(RING, BASE, BODY) B2T_WAVE_STREAM2(RING, BASE, {}, BODY)
 #define B2T_WAVE_STREAM2(RING, BASE, EXTRA, BODY)                                                                      \
   {                                                                                                                    \
-    constexpr int LB_ = NP > 16 ? 8 : (NP > 12 ? 12 : NP);                                                                             \
+    constexpr int LB_ = NP > 12 ? 12 : NP;                                                                             \
     u32x4 v_[LB_];                                                                                                     \
     _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q, plain_);          \
     EXTRA                                                                                                              \

@@ -95,7 +95,7 @@ def _sparse_worker(rank, world, port, q):
                 red.launch(name)
             red.finish()
             want = sum(arenas)
-            res[case] = (bool(torch.allclose(arena, want, atol=1e-6)), float(status[0]), tuple(red.sparse["stage_w"].shape))
+            res[case] = (bool(torch.allclose(arena, want, atol=1e-6)), float(status[0]), tuple(red.sparse["stage_w"].shape), red.n_collectives)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -117,6 +117,9 @@ def test_sparse_day_reduction_world2():
         assert p.exitcode == 0
     for rank, res in out:
         assert res["disjoint"][0] and res["disjoint"][1] == 0.0 and res["disjoint"][2][0] == 4
+        # round 6: the five buckets of this two-layer model (head, layer1, layer0, day, h0) leave as THREE collectives
+        # (head + layer1 | layer0 | day records + h0)
+        assert res["disjoint"][3] == 3, res["disjoint"][3]
         assert res["overlap"][0] and res["overlap"][1] == 0.0
         assert res["overflow"][1] == 3.0                                 # six active days, four slots: the step is refused ...
     assert not all(res["overflow"][0] for _, res in out)                  # ... because a rank would otherwise miss a day's gradient

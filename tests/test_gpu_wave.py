@@ -218,6 +218,7 @@ def test_bf16_mode_step_on_the_wavefront_tracks_the_chunk_pipeline(monkeypatch, 
         def grads(wave, chunks="1,1"):
             monkeypatch.setenv("B2T_WAVE", "1" if wave else "0")
             monkeypatch.setenv("B2T_WAVE_CHUNKS", chunks)
+            monkeypatch.setenv("B2T_WAVE_DIRS", "fb")      # both passes on the wavefront (the trainer's default is the forward pass only)
             torch.manual_seed(3)
             m = GRUDecoder(F, H, D, Cc, drop[1], drop[0], L, patch[0], patch[1]).to(dev).train()
             ts = TrainStep(m, _step_args())
@@ -235,15 +236,26 @@ def test_bf16_mode_step_on_the_wavefront_tracks_the_chunk_pipeline(monkeypatch, 
             assert diff <= 5e-3 * scale, f"{name} differ by {diff} (scale {scale})"
         for a, b in zip(got, again):       # the wavefront itself is deterministic
             assert torch.equal(a, b)
-        # a launch per time chunk (what the trainer runs: the weight gradients of a chunk overlap the sweep of the next): states and
-        # dh are carried in fp32 exactly as inside one launch -- logits and losses are bit-identical; the weight gradients are
-        # accumulated chunk by chunk (another fp32 summation order)
+        # forward: a launch per time chunk (states carried in fp32 exactly as inside one launch); backward: the consumers of the sweep's
+        # dG -- layer 0's input gradient, every weight gradient -- chunk by chunk BESIDE the one sweep launch, each behind a gate on the
+        # sweep's progress word: logits and losses bit-identical, the weight gradients accumulated chunk by chunk (another fp32
+        # summation order)
         cut = grads(True, "3,2")
         assert torch.equal(cut[2], got[2]) and torch.equal(cut[1], got[1])
         assert float((cut[0] - got[0]).abs().max()) <= 2e-4 * float(got[0].abs().max())
+        # ... and the default: forward pass on the wavefront, backward pass on the chunk pipeline
+        monkeypatch.setenv("B2T_WAVE_DIRS", "f")
+        torch.manual_seed(3)
+        m = GRUDecoder(F, H, D, Cc, drop[1], drop[0], L, patch[0], patch[1]).to(dev).train()
+        ts = TrainStep(m, _step_args())
+        loss_b = ts.compute_grads(x, day, tgt, nt, tl)
+        torch.cuda.synchronize(); ts.check_status()
+        assert torch.equal(ts.last_logits, got[2]) and torch.equal(loss_b, got[1])
+        assert float((ts.grad_arena - ref[0]).abs().max()) <= 5e-3 * float(ref[0].abs().max())
         # ... and it is the wavefront that ran: the two are not bit-identical
         assert not torch.equal(got[2], ref[2])
     finally:
         ops.set_amp(old_amp)
         monkeypatch.delenv("B2T_WAVE", raising=False)
         monkeypatch.delenv("B2T_WAVE_CHUNKS", raising=False)
+        monkeypatch.delenv("B2T_WAVE_DIRS", raising=False)
