@@ -653,7 +653,8 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ps.in_drop, ps.rnn_drop, ps.seed = float(in_drop), float(rnn_drop if L > 1 else 0.0), int(seed) & (2 ** 64 - 1)
     ps.chunks_bwd = time_chunks_bwd(Tp, B, H, AMP["on"], ps.chunks)
     ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
-    if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and \
+    # (not for streaming-sized calls: a launch loads 192-288 registers of weights per wave before its first step)
+    if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and Tp >= 16 and \
             lib.b2t_gru_wave_supported(L, Tp, B, H):
         wc = os.environ.get("B2T_WAVE_CHUNKS")
         # chunks (forward launches, backward consumer chunks): 1, 1 -- forward launches per chunk measured equal (C2: 8.98 / 9.01 /

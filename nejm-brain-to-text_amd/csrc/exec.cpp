@@ -1335,7 +1335,10 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   int t_bucket = -1;
   auto bucket = [&](int id, int producer) {
     if (!bucket_cb) return;
-    t_bucket = P.add("bucket", 1.f, Q_ANY, {producer, t_bucket}, [&, id](hipStream_t s) { cb(id, s); });
+    // (the callback may issue a collective that BLOCKS this queue until every peer has arrived: the estimate is the slack the
+    //  scheduler leaves behind it -- work it would have queued there goes to another queue; B2T_BUCKET_EST_US, NOTES.md R6.3)
+    static const float est_b = getenv("B2T_BUCKET_EST_US") ? (float)atof(getenv("B2T_BUCKET_EST_US")) : 1.f;
+    t_bucket = P.add("bucket", est_b, Q_ANY, {producer, t_bucket}, [&, id](hipStream_t s) { cb(id, s); });
   };
   const int t_head_w = P.add("head_w", est_gemm(Cc, H, (double)M) + 40.f, Q_ANY, {t_start}, [&](hipStream_t s) {
     b2t_gemm_desc d = gd(dlogits, w.out[L - 1] + (long long)B * H, grd->out_w, Cc, H, (int)M);
