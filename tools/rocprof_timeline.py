@@ -17,7 +17,7 @@ nsteps_back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = rows[idx[-nsteps_back]:(idx[-nsteps_back + 1] if nsteps_back > 1 else len(rows))]
 t0 = rows[0][1]
 def fam(n):
-    for k in ("gru_persist_fwd", "gru_persist_bwd", "gemm_bf16p", "pack_mc", "pack_kc", "gemm_bf16_kernel", "dropout", "patch_fold", "gemm_f32_kernelILb0ELb0", "gemm_f32_kernelILb1ELb0", "gemm_f32_kernelILb1ELb1", "gemm_f32_kernelILb0ELb1", "ctc_kernel", "colsum", "adamw", "sumsq"):
+    for k in ("gru_wave_fwd", "gru_wave_bwd", "wave_gate", "gru_persist_fwd", "gru_persist_bwd", "gemm_bf16p", "pack_mc", "pack_kc", "gemm_bf16_kernel", "dropout", "patch_fold", "gemm_f32_kernelILb0ELb0", "gemm_f32_kernelILb1ELb0", "gemm_f32_kernelILb1ELb1", "gemm_f32_kernelILb0ELb1", "ctc_kernel", "colsum", "adamw", "sumsq"):
         if k in n: return k
     return "other"
 agg = {}
