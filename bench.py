@@ -497,6 +497,7 @@ def main():
                                process_runs=runs, best_process_ms=min(r["ms_per_step"] for r in runs) if runs else round(ms, 3),
                                host_enqueue_ms_per_step=runs[0]["host_enqueue_ms_per_step"] if runs else round(t_enq / a.steps * 1e3, 3),
                                host_api_us=host_api, slow_mode_probe=slow_probe,
+                               dp_collective_call_host_ms_per_step=(round(ts.reducer.host_s / max(1, a.steps + a.warmup + 4) * 1e3, 3) if ts.reducer is not None else None),
                                host=dict(loadavg=[round(v, 2) for v in os.getloadavg()], cores_usable=usable_cores(),
                                          exec_host_delay_us=int(os.environ.get("B2T_EXEC_HOST_DELAY_US", "0")))),
                    roofline=roofline, final_loss=round(lossv, 4),

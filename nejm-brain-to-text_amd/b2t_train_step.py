@@ -117,6 +117,7 @@ class GradReducer:
         self.groups.append(dict(name="tail", members={n for n in ("day", "h0") if n in self.buckets}, span=None))
         self._arrived, self._fired = set(), set()
         self.n_collectives = 0          # collectives issued since the last finish() (tests / bench)
+        self.host_s = 0.0               # host seconds spent inside blocking collective calls
         self.test_delay_us = float(os.environ.get("B2T_DP_TEST_DELAY_US", "0"))
         self._delay_cycles = None
         if self.test_delay_us > 0 and grad_arena.is_cuda:      # calibrate torch's spin kernel once, outside any pass
@@ -180,8 +181,12 @@ class GradReducer:
             # a peer that arrives late -- what a blocking all-reduce on an executor queue costs the plan (bench `dp_forced_one_rank`)
             torch.cuda._sleep(self._delay_cycles)
         self.n_collectives += 1
+        import time as _time
+        _t0 = _time.perf_counter()
         if self.inline:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=False)
+            self.host_s += _time.perf_counter() - _t0      # host time inside the collective calls (bench: does the CALL wait for the device?)
+            return
         else:
             self.pending.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -269,6 +269,27 @@ struct Ctx {
   // B2T_EXEC_HOST_DELAY_US=n (round 6): a busy wait of n microseconds in front of every runtime call the executor makes (launch, event
   // record, stream wait) -- emulates the pool's slow-host mode (host enqueue 5-8 ms per C2 step instead of 1.3) on a healthy box, to
   // find which call's host latency reaches the GPU timeline (tools/r6_hostdelay.sh, NOTES.md R6.1)
+  // B2T_EXEC_HOST_TIMING=1: host time between consecutive runtime calls of the executor, attributed to the call that just returned
+  // (kind 0 event record, 1 stream wait, 2 a launch inside gemm(), 3 any other launch): count, total and maximum per kind, printed
+  // to stderr every 64 passes -- which CALLS take the time in a process whose enqueue is slow (NOTES.md R6.1)
+  struct HostTiming { bool on; std::chrono::steady_clock::time_point last; double tot[4]; double mx[4]; long n[4]; long passes; };
+  static HostTiming& ht() { static HostTiming h{getenv("B2T_EXEC_HOST_TIMING") != nullptr, std::chrono::steady_clock::now(), {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0}; return h; }
+  static void ht_mark() { HostTiming& h = ht(); if (h.on) h.last = std::chrono::steady_clock::now(); }
+  static void ht_point(int kind) {
+    HostTiming& h = ht();
+    if (!h.on) return;
+    const auto now = std::chrono::steady_clock::now();
+    const double us = std::chrono::duration<double, std::micro>(now - h.last).count();
+    h.tot[kind] += us; h.mx[kind] = std::max(h.mx[kind], us); ++h.n[kind]; h.last = now;
+  }
+  static void ht_pass() {
+    HostTiming& h = ht();
+    if (!h.on || (++h.passes % 64) != 0) return;
+    static const char* nm[4] = {"event_record", "stream_wait", "gemm_launch", "other_launch"};
+    fprintf(stderr, "[exec host timing] after %ld passes:", h.passes);
+    for (int k = 0; k < 4; ++k) fprintf(stderr, " %s n=%ld mean=%.1fus max=%.0fus total/pass=%.2fms;", nm[k], h.n[k], h.n[k] ? h.tot[k] / h.n[k] : 0.0, h.mx[k], h.tot[k] / h.passes * 1e-3);
+    fprintf(stderr, "\n");
+  }
   static void host_delay() {
     static const int us = getenv("B2T_EXEC_HOST_DELAY_US") ? atoi(getenv("B2T_EXEC_HOST_DELAY_US")) : 0;
     if (us <= 0) return;
@@ -283,12 +304,16 @@ struct Ctx {
       ex->pool.push_back(e);
     }
     hipEvent_t e = ex->pool[ex->next_ev++];
+    ht_mark();
     if (check_hip(hipEventRecord(e, s), "hipEventRecord")) rc = 1;
+    ht_point(0);
     return e;
   }
   void wait(hipStream_t s, hipEvent_t e) {
     host_delay();
+    ht_mark();
     if (e && check_hip(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent")) rc = 1;
+    ht_point(1);
   }
   hipEvent_t tev() {
     if (ex->next_tev == ex->tpool.size()) {
@@ -319,6 +344,8 @@ struct Ctx {
             const void* Bp_pre = nullptr, const PackDrop* dropA = nullptr, const void* Ap_pre = nullptr) {
     if (rc) return;
     host_delay();
+    ht_mark();
+    struct HtExit { ~HtExit() { Ctx::ht_point(2); } } ht_exit;
     if ((Bp_pre || dropA) && !(bf16_gemm && would_pack(d, s))) { set_error("exec: pre-packed operands need the two-pass bf16 GEMM"); rc = 2; return; }
     if (Ap_pre && !(bf16_gemm && would_pack_z(d, s))) { set_error("exec: a pre-packed Z-batched A needs the two-pass bf16 GEMM"); rc = 2; return; }
     void* st = reinterpret_cast<void*>(s);
@@ -386,7 +413,7 @@ struct Ctx {
     if (!would_pack(d, s)) return b2t_gemm_bf16_f32(&d, st);
     return gemm_bf16p_run(&d, nullptr, Bp_pre, lay->pack[pack_queue(s)], lay->pack_bytes, s, dropA);
   }
-  void call(int r) { host_delay(); if (!rc) rc = r; }
+  void call(int r) { ht_point(3); host_delay(); if (!rc) rc = r; }     // (r: the launch that just returned)
 };
 
 b2t_gemm_desc gd(const float* A, const float* Bm, float* C, int M, int N, int K) {
@@ -711,6 +738,7 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
     for (int id : order) fprintf(stderr, "  %9.1f %8.1f q%d %s\n", P.t[id].start, P.t[id].est, P.t[id].q, P.t[id].name);
   }
   if (c.gkey && run_plan_graph(c, P, order, nq)) return;
+  Ctx::ht_pass();
   std::vector<int> pos(n);
   for (int i = 0; i < n; ++i) pos[order[i]] = i;
   for (int id : order) {
@@ -729,7 +757,7 @@ void run_plan(Ctx& c, Plan& P, int nq, const hipStream_t* qs) {
       if (dq != k.q && (last[dq] < 0 || pos[d] > pos[last[dq]])) last[dq] = d;
     }
     for (int q = 0; q < nq; ++q) if (last[q] >= 0) c.wait(s, P.t[last[q]].ev);
-    if (k.run) { jit.maybe(s); k.run(s); }
+    if (k.run) { jit.maybe(s); Ctx::ht_mark(); k.run(s); }
     if (k.cross) k.ev = c.record(s);
   }
 }
