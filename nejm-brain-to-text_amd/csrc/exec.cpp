@@ -1365,7 +1365,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     if (!bucket_cb) return;
     // (the callback may issue a collective that BLOCKS this queue until every peer has arrived: the estimate is the slack the
     //  scheduler leaves behind it -- work it would have queued there goes to another queue; B2T_BUCKET_EST_US, NOTES.md R6.3)
-    static const float est_b = getenv("B2T_BUCKET_EST_US") ? (float)atof(getenv("B2T_BUCKET_EST_US")) : 1.f;
+    static const float est_b = getenv("B2T_BUCKET_EST_US") ? (float)atof(getenv("B2T_BUCKET_EST_US")) : 600.f;   // measured: 1 / 200 / 600 / 1000 / 1500 / 3000 us -> 20.8 / 20.8 / 19.5 / 20.1 / 20.3 / 20.5 ms with every collective 0.5 ms late (18.9 on time)
     t_bucket = P.add("bucket", est_b, Q_ANY, {producer, t_bucket}, [&, id](hipStream_t s) { cb(id, s); });
   };
   const int t_head_w = P.add("head_w", est_gemm(Cc, H, (double)M) + 40.f, Q_ANY, {t_start}, [&](hipStream_t s) {

@@ -156,20 +156,52 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
     }                                                                                                                  \
   }
 
+// The same stream in the row-group form (RGF): the workgroup's four waves all need the SAME row group's fragments, so each wave
+// fetches a quarter of the pairs, the stream goes through LDS (SBUF: NP KB) and every wave reads every pair from there -- a
+// quarter of the L2 -> L1 traffic of four waves fetching four different row groups.  One workgroup barrier per stream.
+#define B2T_WAVE_STREAM_LDS(SBUF, RING, BASE, BODY)                                                                    \
+  {                                                                                                                    \
+    static_assert(NP % 4 == 0, "row-group form: pairs split over four waves");                                         \
+    u32x4 v_[NP / 4];                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NP / 4; ++i) v_[i] = load_frag(RING, BASE, wave + 4 * i, P, H, lane, q, plain_); \
+    _Pragma("unroll") for (int i = 0; i < NP / 4; ++i)                                                                 \
+      *reinterpret_cast<u32x4*>((SBUF) + (unsigned)(wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[i];             \
+    __syncthreads();                                                                                                   \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                   \
+      const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((SBUF) + (unsigned)p * 1024u + (unsigned)lane * 16u)); \
+      BODY                                                                                                             \
+    }                                                                                                                  \
+  }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NP, bool DROP, bool LOC>   // NP: pairs of 16-unit chunks per row (H <= 32 NP); LOC: a layer = one XCD (wave_role)
+// RGF (row-group form, H % 64 == 0, H <= 512): a workgroup = (layer, ROW GROUP, 64 units) -- wave w owns units 64 ub + 16 w .. + 15 of
+// that one row group -- instead of (layer, 16 units) for all row groups.  Same hand-off protocol, same tiles, same counters; but the
+// four waves now consume the SAME operand streams (B2T_WAVE_STREAM_LDS) and each holds BOTH of its weight slices in registers
+// (W_hh and W_ih: 384 at H = 512, pinned to register classes), since four different W_ih slices do not fit LDS.
+template <int NP, bool DROP, bool LOC, bool RGF = false>   // NP: pairs of 16-unit chunks per row (H <= 32 NP); LOC: a layer = one XCD (wave_role)
 __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wave_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
   const bool plain_ = LOC || (a.flags & 1) == 0;
-  int layer, slice;
-  if (!wave_role<LOC>(a.tickets, L, G, false, layer, slice)) return;
+  int layer, slice, rg_of_wg = 0;
+  if constexpr (RGF) {
+    int k;
+    if (!wave_role<LOC>(a.tickets, L, ngrp * (H / 64), false, layer, k)) return;
+    rg_of_wg = k / (H / 64);
+    slice = 4 * (k % (H / 64)) + wave;
+  } else {
+    if (!wave_role<LOC>(a.tickets, L, G, false, layer, slice)) return;
+  }
   const int u0 = slice * 16, unit = u0 + j;
-  u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer] slice as B fragments
-  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * NP * 1024) + wave * (WAVE_TILES * WTILE_F);
+  // LDS: fat form [3][NP][64] W_ih slice as B fragments; row-group form two stream buffers of NP KB; then the waves' tiles
+  u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);
+  char* sbuf_c = wave_lds;
+  char* sbuf_p = wave_lds + (size_t)NP * 1024;
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)(RGF ? 2 : 3) * NP * 1024) + wave * (WAVE_TILES * WTILE_F);
+  (void)wl; (void)sbuf_c; (void)sbuf_p;
 
   bf16x8 w[3][NP];
   {
@@ -186,11 +218,27 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
         // in front of every MFMA; pinned -- two gates in accumulation registers (192 of the 256), the third in architectural ones --
         // nothing spills (R6.2)
         if constexpr (NP > 16) { if (g < 2) asm volatile("" : "+a"(w[g][p])); else asm volatile("" : "+v"(w[g][p])); }
+        if constexpr (RGF) asm volatile("" : "+a"(w[g][p]));      // row-group form: W_hh in accumulation registers, W_ih (below) mostly in architectural ones
       }
       __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
     }
   }
-  if (layer > 0) {
+  bf16x8 w2[RGF ? 3 : 1][RGF ? NP : 1];      // row-group form: the W_ih slice
+  if constexpr (RGF) {
+    const float* wih = a.w_ih[layer > 0 ? layer : 1 < L ? 1 : 0];     // (layer 0 projects nothing: any valid matrix, never used)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int k0 = 32 * p + 8 * q;
+      const bool ok = k0 < H && layer > 0;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float* src = (layer > 0 ? wih : a.w_hh[layer]) + ((long long)g * H + unit) * H + (k0 < H ? k0 : 0);
+        w2[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
+        if (g == 0 && p < NP / 2) asm volatile("" : "+a"(w2[g][p])); else asm volatile("" : "+v"(w2[g][p]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (layer > 0) {
     const float* wih = a.w_ih[layer];
     for (int idx = wave; idx < 3 * NP; idx += 4) {
       const int g = idx / NP, p = idx % NP, k0 = 32 * p + 8 * q;
@@ -200,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     }
   }
   __syncthreads();
-  if (wave >= ngrp) return;
+  if (!RGF && wave >= ngrp) return;
   __builtin_amdgcn_s_setprio(3);
 
   // Two rings per layer when the layer above must not read the own-recurrence ring: with dropout (it reads the DROPPED states) and
@@ -208,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   // is written through to memory).  The cross ring's counter of slot s moves one step late -- when the NEXT own publish has drained
   // this wave's stores anyway -- so that no step waits for a memory acknowledgement of its own.
   constexpr bool XRING = DROP || LOC;
-  const int rg = wave, m0 = rg * 16;
+  const int rg = RGF ? rg_of_wg : wave, m0 = rg * 16;
   unsigned* err = a.err;
   const size_t cstride = (size_t)(T + 1);
   unsigned* cnt_own = a.cnt + ((size_t)(layer * 2 + 0) * ngrp + rg) * cstride;
@@ -257,10 +305,16 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned pbase = (unsigned)(t + 1) * slot_bytes + rg_off;
-    B2T_WAVE_STREAM(ring_in, pbase, {
-      _Pragma("unroll") for (int g = 0; g < 3; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc[g], 0, 0, 0);
-    })
+    if constexpr (RGF) {
+      B2T_WAVE_STREAM_LDS(sbuf_p, ring_in, pbase, {
+        _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w2[g][p], acc[g], 0, 0, 0);
+      })
+    } else {
+      B2T_WAVE_STREAM(ring_in, pbase, {
+        _Pragma("unroll") for (int g = 0; g < 3; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc[g], 0, 0, 0);
+      })
+    }
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -289,9 +343,15 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
 #pragma unroll
       for (int g = 0; g < 3; ++g) gh[g] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned cbase = (unsigned)t * slot_bytes + rg_off;
-      B2T_WAVE_STREAM2(ring, cbase, {}, {
-        _Pragma("unroll") for (int g = 0; g < 3; ++g) gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], gh[g], 0, 0, 0);
-      })
+      if constexpr (RGF) {
+        B2T_WAVE_STREAM_LDS(sbuf_c, ring, cbase, {
+          _Pragma("unroll") for (int g = 0; g < 3; ++g) gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], gh[g], 0, 0, 0);
+        })
+      } else {
+        B2T_WAVE_STREAM2(ring, cbase, {}, {
+          _Pragma("unroll") for (int g = 0; g < 3; ++g) gh[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], gh[g], 0, 0, 0);
+        })
+      }
     }
     asm volatile("s_nop 0" :: "v"(gh[0][0]), "v"(gh[1][0]), "v"(gh[2][0]));
     WSTAMP(1)   // operand loads + recurrent product
@@ -363,18 +423,29 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward.  Ring of layer l, slot t: the gate gradients of step t as fragments, 4 arrays (dr, dz, dn r, dn) x P pairs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NP, bool DROP, bool LOC>
+template <int NP, bool DROP, bool LOC, bool RGF = false>      // RGF: the row-group form (see the forward kernel)
 __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char wave_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
   const int H = a.H, B = a.B, T = a.T, G = H / 16, P = (G + 1) / 2, ngrp = (B + 15) / 16, L = a.L;
   const bool plain_ = LOC || (a.flags & 1) == 0;
   // (placement-independent form: the TOP layer starts the wavefront and gets the first workgroups)
-  int layer, slice;
-  if (!wave_role<LOC>(a.tickets, L, G, true, layer, slice)) return;
+  int layer, slice, rg_of_wg = 0;
+  if constexpr (RGF) {
+    int k;
+    if (!wave_role<LOC>(a.tickets, L, ngrp * (H / 64), true, layer, k)) return;
+    rg_of_wg = k / (H / 64);
+    slice = 4 * (k % (H / 64)) + wave;
+  } else {
+    if (!wave_role<LOC>(a.tickets, L, G, true, layer, slice)) return;
+  }
   const int u0 = slice * 16, unit = u0 + j;
-  u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);                                      // [3][P][64]: W_ih[layer + 1]^T slice
-  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)3 * NP * 1024) + wave * (WAVE_TILES * WTILE_F);
+  // LDS: fat form [3][NP][64] W_ih[layer + 1]^T slice; row-group form two stream buffers of 3 NP KB (three arrays each); then the tiles
+  u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);
+  char* sbuf_c = wave_lds;
+  char* sbuf_p = wave_lds + (size_t)3 * NP * 1024;
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)(RGF ? 6 : 3) * NP * 1024) + wave * (WAVE_TILES * WTILE_F);
+  (void)wl; (void)sbuf_c; (void)sbuf_p;
   const bool has_up = layer + 1 < L;
 
   bf16x8 w[3][NP];     // W_hh^T slice: column `unit`, k = array * H + 32 p + 8 q .. + 7
@@ -392,11 +463,27 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
         // in front of every MFMA; pinned -- two gates in accumulation registers (192 of the 256), the third in architectural ones --
         // nothing spills (R6.2)
         if constexpr (NP > 16) { if (g < 2) asm volatile("" : "+a"(w[g][p])); else asm volatile("" : "+v"(w[g][p])); }
+        if constexpr (RGF) asm volatile("" : "+a"(w[g][p]));
       }
       __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
     }
   }
-  if (has_up) {
+  bf16x8 w2[RGF ? 3 : 1][RGF ? NP : 1];      // row-group form: the W_ih[layer + 1]^T slice
+  if constexpr (RGF) {
+    const float* wt = (has_up ? a.w_ih_t[layer + 1] : a.w_hh_t[layer]) + (long long)unit * 3 * H;     // (top layer: any valid matrix, masked to zero)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int k0 = 32 * p + 8 * q;
+      const bool ok = k0 < H && has_up;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float* src = wt + (long long)g * H + (k0 < H ? k0 : 0);
+        w2[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
+        if (g == 0 && p < NP / 2) asm volatile("" : "+a"(w2[g][p])); else asm volatile("" : "+v"(w2[g][p]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (has_up) {
     const float* wt = a.w_ih_t[layer + 1] + (long long)unit * 3 * H;
     for (int idx = wave; idx < 3 * NP; idx += 4) {
       const int g = idx / NP, p = idx % NP, k0 = 32 * p + 8 * q;
@@ -406,13 +493,13 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     }
   }
   __syncthreads();
-  if (wave >= ngrp) return;
+  if (!RGF && wave >= ngrp) return;
   __builtin_amdgcn_s_setprio(3);
 
   // LOC: the own-recurrence ring stays in this XCD's L2 (ordinary stores, L2 counters); the layer BELOW (another XCD) reads a
   // second, written-through copy whose counter moves one step late (see the forward kernel)
   constexpr bool XRING = LOC;
-  const int rg = wave, m0 = rg * 16;
+  const int rg = RGF ? rg_of_wg : wave, m0 = rg * 16;
   unsigned* err = a.err;
   const size_t cstride = (size_t)T;
   unsigned* cnt_own = a.cnt + ((size_t)(layer * 2 + 0) * ngrp + rg) * cstride;
@@ -439,12 +526,34 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     wave_wait<false>(cnt_up + t, (unsigned)G, err, lane);
     WSTAMP(5)
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RGF) {
+      // the three arrays (dr, dz, dn) of the layer above, a quarter of the pairs per wave, through LDS: ONE barrier
+      static_assert(!RGF || NP % 4 == 0, "row-group form: pairs split over four waves");
+      u32x4 v_[3 * (NP / 4)];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < NP / 4; ++i)
+          v_[g * (NP / 4) + i] = load_frag(ring_up, (unsigned)t * slot_bytes + rg_off + (unsigned)(g == 2 ? 3 : g) * arr_bytes, wave + 4 * i, P, H, lane, q, plain_);
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < NP / 4; ++i)
+          *reinterpret_cast<u32x4*>(sbuf_p + (unsigned)(g * NP + wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[g * (NP / 4) + i];
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sbuf_p + (unsigned)(g * NP + p) * 1024u + (unsigned)lane * 16u)), w2[g][p], acc, 0, 0, 0);
+    } else {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       const unsigned pbase = (unsigned)t * slot_bytes + rg_off + (unsigned)(g == 2 ? 3 : g) * arr_bytes;
       B2T_WAVE_STREAM(ring_up, pbase, {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc, 0, 0, 0);
       })
+    }
     }
     if (DROP) {
       // the mask of the forward's dropout on out[layer]: row-major through the wave's tile (one Philox block per lane)
@@ -489,12 +598,32 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
       wave_wait<LOC>(cnt_own + (t + 1), (unsigned)G, err, lane);
       WSTAMP(0)
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (RGF) {
+        u32x4 v_[3 * (NP / 4)];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int i = 0; i < NP / 4; ++i)
+            v_[g * (NP / 4) + i] = load_frag(ring, (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes, wave + 4 * i, P, H, lane, q, plain_);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int i = 0; i < NP / 4; ++i)
+            *reinterpret_cast<u32x4*>(sbuf_c + (unsigned)(g * NP + wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[g * (NP / 4) + i];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sbuf_c + (unsigned)(g * NP + p) * 1024u + (unsigned)lane * 16u)), w[g][p], acc, 0, 0, 0);
+      } else {
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const unsigned cbase = (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes;
         B2T_WAVE_STREAM2(ring, cbase, {}, {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc, 0, 0, 0);
         })
+      }
       }
       asm volatile("s_nop 0" :: "v"(acc[0]));
       WSTAMP(1)
@@ -589,8 +718,10 @@ static int wave_cus() {
   return n;
 }
 
+size_t gru_wave_lds_bytes_rgf_bwd(int H);
 static int wave_np(int H) { return H <= 128 ? 4 : H <= 256 ? 8 : H <= 512 ? 16 : 24; }   // the kernel template's pair count
 size_t gru_wave_lds_bytes(int H) { return (size_t)3 * wave_np(H) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
+size_t gru_wave_lds_bytes_rgf_bwd(int H) { return (size_t)6 * wave_np(H) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }   // two stream buffers of three arrays
 size_t gru_wave_ring_bytes_fwd(int T, int B, int H) { return (size_t)(T + 1) * ((B + 15) / 16) * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_ring_bytes_bwd(int T, int B, int H) { return (size_t)T * ((B + 15) / 16) * 4 * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_cnt_words_fwd(int L, int T, int B) { return 16 + (size_t)L * 2 * ((B + 15) / 16) * (T + 1); }   // 16: the XCD tickets of the local form
@@ -624,16 +755,21 @@ bool gru_wave_local(int L, int H) {
   return L <= 8 && H / 16 <= 32 && wave_cus() >= 256 && gru_xcd_dispatch_ok();
 }
 
-template <int NPV, bool DR, bool LC> static int wave_launch_fwd(const WaveFwdArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+template <int NPV, bool DR, bool LC, bool RG = false> static int wave_launch_fwd(const WaveFwdArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool at = false;
-  if (!at) { const int rc = wave_lds_attr(gru_wave_fwd_kernel<NPV, DR, LC>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; }
-  hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, DR, LC>), grid, dim3(256), lds, s, a);
+  if (!at) { const int rc = wave_lds_attr(gru_wave_fwd_kernel<NPV, DR, LC, RG>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; }
+  hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, DR, LC, RG>), grid, dim3(256), lds, s, a);
   return 0;
 }
-template <int NPV, bool DR, bool LC> static int wave_launch_bwd(const WaveBwdArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+// the row-group form serves H % 64 == 0, H <= 512 (both weight slices of a wave in registers); B2T_WAVE_RGF=0 (read per call): the fat form
+bool gru_wave_rgf(int H) {
+  const char* e = getenv("B2T_WAVE_RGF");
+  return !(e && atoi(e) == 0) && H % 64 == 0 && H <= 512;
+}
+template <int NPV, bool DR, bool LC, bool RG = false> static int wave_launch_bwd(const WaveBwdArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool at = false;
-  if (!at) { const int rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, DR, LC>, gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; }
-  hipLaunchKernelGGL((gru_wave_bwd_kernel<NPV, DR, LC>), grid, dim3(256), lds, s, a);
+  if (!at) { const int rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, DR, LC, RG>, RG ? gru_wave_lds_bytes_rgf_bwd(32 * NPV) : gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; }
+  hipLaunchKernelGGL((gru_wave_bwd_kernel<NPV, DR, LC, RG>), grid, dim3(256), lds, s, a);
   return 0;
 }
 
@@ -647,10 +783,14 @@ int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
   a.tickets = a.cnt; a.cnt = a.cnt + 16;
   int rc = check_hip(hipMemsetAsync(a.tickets, 0, gru_wave_cnt_words_fwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_fwd: counters");
   if (rc) return rc;
-  const dim3 grid(loc ? 256 : a.L * (a.H / 16));
+  const bool rgf = gru_wave_rgf(a.H);
+  const int ngrp_ = (a.B + 15) / 16;
+  const dim3 grid(loc ? 256 : (rgf ? a.L * ngrp_ * (a.H / 64) : a.L * (a.H / 16)));
 #define B2T_WAVE_FWD(NPV)                                                                                              \
   do {                                                                                                                 \
-    if (loc) rc = drop ? wave_launch_fwd<NPV, true, true>(a, grid, lds, s) : wave_launch_fwd<NPV, false, true>(a, grid, lds, s);   \
+    if (rgf && loc) rc = drop ? wave_launch_fwd<NPV, true, true, true>(a, grid, lds, s) : wave_launch_fwd<NPV, false, true, true>(a, grid, lds, s); \
+    else if (rgf) rc = drop ? wave_launch_fwd<NPV, true, false, true>(a, grid, lds, s) : wave_launch_fwd<NPV, false, false, true>(a, grid, lds, s); \
+    else if (loc) rc = drop ? wave_launch_fwd<NPV, true, true>(a, grid, lds, s) : wave_launch_fwd<NPV, false, true>(a, grid, lds, s);   \
     else rc = drop ? wave_launch_fwd<NPV, true, false>(a, grid, lds, s) : wave_launch_fwd<NPV, false, false>(a, grid, lds, s);     \
   } while (0)
   if (a.H <= 128) B2T_WAVE_FWD(4);
@@ -682,10 +822,15 @@ int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   int rc = 0;
   if (!(a_in.flags & 2)) { rc = gru_wave_bwd_clear(a.cnt, a.L, a.T, a.B, s); if (rc) return rc; }   // (bit 1: the caller cleared them, gated consumers are already waiting)
   a.tickets = a.cnt; a.prog = a_in.prog ? a.cnt + 16 : nullptr; a.cnt = a.cnt + 16 + 64;
-  const dim3 grid(loc ? 256 : a.L * (a.H / 16));
+  const bool rgf = gru_wave_rgf(a.H);
+  const int ngrp_ = (a.B + 15) / 16;
+  const dim3 grid(loc ? 256 : (rgf ? a.L * ngrp_ * (a.H / 64) : a.L * (a.H / 16)));
+  const size_t lds_r = gru_wave_lds_bytes_rgf_bwd(a.H);
 #define B2T_WAVE_BWD(NPV)                                                                                              \
   do {                                                                                                                 \
-    if (loc) rc = drop ? wave_launch_bwd<NPV, true, true>(a, grid, lds, s) : wave_launch_bwd<NPV, false, true>(a, grid, lds, s);   \
+    if (rgf && loc) rc = drop ? wave_launch_bwd<NPV, true, true, true>(a, grid, lds_r, s) : wave_launch_bwd<NPV, false, true, true>(a, grid, lds_r, s); \
+    else if (rgf) rc = drop ? wave_launch_bwd<NPV, true, false, true>(a, grid, lds_r, s) : wave_launch_bwd<NPV, false, false, true>(a, grid, lds_r, s); \
+    else if (loc) rc = drop ? wave_launch_bwd<NPV, true, true>(a, grid, lds, s) : wave_launch_bwd<NPV, false, true>(a, grid, lds, s);   \
     else rc = drop ? wave_launch_bwd<NPV, true, false>(a, grid, lds, s) : wave_launch_bwd<NPV, false, false>(a, grid, lds, s);     \
   } while (0)
   if (a.H <= 128) B2T_WAVE_BWD(4);
