@@ -339,8 +339,11 @@ def main():
 
     def step(i):
         cut = int(cut_rng.randint(0, 3))          # rnn_trainer.py:468-471
+        TrainStep._ht()
         feats = ops.augment_smooth(x, 2, 100, "same", cut=cut, white_std=1.0, offset_std=0.2, seed=i * 7919 + rank)
-        return ts.step(feats, days, labels, nts - cut, lens)
+        nt_cut = nts - cut
+        TrainStep._ht("augment_and_lens")
+        return ts.step(feats, days, labels, nt_cut, lens)
 
     def fence():
         torch.cuda.synchronize()
@@ -497,6 +500,7 @@ def main():
                                process_runs=runs, best_process_ms=min(r["ms_per_step"] for r in runs) if runs else round(ms, 3),
                                host_enqueue_ms_per_step=runs[0]["host_enqueue_ms_per_step"] if runs else round(t_enq / a.steps * 1e3, 3),
                                host_api_us=host_api, slow_mode_probe=slow_probe,
+                               step_host_ms=({k: round(v / max(1, a.steps + a.warmup + 4) * 1e3, 3) for k, v in TrainStep.HOST_T["acc"].items()} if TrainStep.HOST_T["on"] else None),
                                dp_collective_call_host_ms_per_step=(round(ts.reducer.host_s / max(1, a.steps + a.warmup + 4) * 1e3, 3) if ts.reducer is not None else None),
                                host=dict(loadavg=[round(v, 2) for v in os.getloadavg()], cores_usable=usable_cores(),
                                          exec_host_delay_us=int(os.environ.get("B2T_EXEC_HOST_DELAY_US", "0")))),

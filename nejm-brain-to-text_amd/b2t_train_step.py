@@ -350,6 +350,20 @@ class TrainStep:
             return ((n - ps).to(torch.float32) / st + 1).to(torch.int32)
         return n.to(torch.int32)
 
+    # B2T_STEP_HOST_TIMING=1: host seconds per segment of the step (bench.py reports them per step in `config.step_host_ms`): which
+    # part of the HOST side takes the time in a process whose enqueue is slow -- the executor's own runtime calls do not (NOTES.md R6.1)
+    HOST_T = {"on": os.environ.get("B2T_STEP_HOST_TIMING") is not None, "acc": {}, "last": 0.0}
+
+    @classmethod
+    def _ht(cls, name=None):
+        if not cls.HOST_T["on"]:
+            return
+        import time
+        now = time.perf_counter()
+        if name is not None:
+            cls.HOST_T["acc"][name] = cls.HOST_T["acc"].get(name, 0.0) + (now - cls.HOST_T["last"])
+        cls.HOST_T["last"] = now
+
     def compute_grads(self, feats: torch.Tensor, day_idx: torch.Tensor, targets: torch.Tensor,
                       n_time_steps: torch.Tensor, phone_seq_lens: torch.Tensor, reduce: bool = True):
         """Forward + CTC + backward into the gradient arena (scaled 1 / (B * world): rnn_trainer.py:545's torch.mean over
@@ -360,6 +374,7 @@ class TrainStep:
         dev = self.dev
         st = ops._stream()
         B = feats.shape[0]
+        self._ht()
         if day_idx.is_cuda:
             day_dev = day_idx.to(dtype=torch.int32).contiguous()
         else:   # pageable H2D copies block the host until the stream drains: stage through pinned memory
@@ -367,8 +382,10 @@ class TrainStep:
         logits, hidden, ctx = ops.model_forward(model._dims, model._kernel_params(), feats, day_dev, None, model._ws,
                                                 save=True, in_drop=model._p_in(), rnn_drop=model._p_rnn(),
                                                 seed=model._next_seed(), reuse_saved=True)
+        self._ht("model_forward")
         adj = self.adjusted_lens(n_time_steps.to(dev))   # (small torch kernels: behind the forward, only the CTC needs them)
         loss_b, dl, ldd = ops.ctc_loss(logits, targets, adj, phone_seq_lens, True, 1.0 / (B * self.world), model._ws)
+        self._ht("lens_ctc")
         N.check(lib.b2t_opt_prepare(ops._p(day_dev), B, ops._p(self.seg_day), self.nseg, ops._p(self.active), st),
                 "b2t_opt_prepare")
         red = self.reducer if reduce else None
@@ -378,8 +395,10 @@ class TrainStep:
             self.grad_arena[a:e].zero_()
         if red is not None:
             red.union_active(self.active)
+        self._ht("opt_prepare")
         ops.model_backward(model._dims, model._kernel_params(), self.grads, ctx, dl, ldd, model._ws,
                            bucket_cb=(red.launch if red is not None else None))
+        self._ht("model_backward")
         if red is not None:
             red.finish()
         self.last_logits, self.last_adjusted = logits, adj
@@ -426,8 +445,11 @@ class TrainStep:
         Returns (mean CTC loss of this rank's shard, pre-clip gradient norm) as 0-d device tensors (no sync).
         self.stat = {sum g^2, norm, clip coefficient, status, mean loss} holds the same on the device."""
         loss_b = self.compute_grads(feats, day_idx, targets, n_time_steps, phone_seq_lens)
+        self._ht()
         self.apply_update()
+        self._ht("clip_adamw")
         torch.mean(loss_b, dim=0, keepdim=True, out=self.stat[4:5])
+        self._ht("mean")
         return self.stat[4], self.stat[1]
 
     def check_status(self, out3_host=None):

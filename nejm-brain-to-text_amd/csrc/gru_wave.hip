@@ -529,17 +529,17 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     if constexpr (RGF) {
       // the three arrays (dr, dz, dn) of the layer above, a quarter of the pairs per wave, through LDS: ONE barrier
       static_assert(!RGF || NP % 4 == 0, "row-group form: pairs split over four waves");
-      u32x4 v_[3 * (NP / 4)];
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int i = 0; i < NP / 4; ++i)
-          v_[g * (NP / 4) + i] = load_frag(ring_up, (unsigned)t * slot_bytes + rg_off + (unsigned)(g == 2 ? 3 : g) * arr_bytes, wave + 4 * i, P, H, lane, q, plain_);
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
+      for (int g = 0; g < 3; ++g) {      // (array by array: NP / 4 loads in flight per wave, not 3 NP / 4 -- registers)
+        u32x4 v_[NP / 4];
 #pragma unroll
         for (int i = 0; i < NP / 4; ++i)
-          *reinterpret_cast<u32x4*>(sbuf_p + (unsigned)(g * NP + wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[g * (NP / 4) + i];
+          v_[i] = load_frag(ring_up, (unsigned)t * slot_bytes + rg_off + (unsigned)(g == 2 ? 3 : g) * arr_bytes, wave + 4 * i, P, H, lane, q, plain_);
+#pragma unroll
+        for (int i = 0; i < NP / 4; ++i)
+          *reinterpret_cast<u32x4*>(sbuf_p + (unsigned)(g * NP + wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[i];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       __syncthreads();
 #pragma unroll
       for (int g = 0; g < 3; ++g)
@@ -599,17 +599,17 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
       WSTAMP(0)
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (RGF) {
-        u32x4 v_[3 * (NP / 4)];
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int i = 0; i < NP / 4; ++i)
-            v_[g * (NP / 4) + i] = load_frag(ring, (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes, wave + 4 * i, P, H, lane, q, plain_);
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 3; ++g) {
+          u32x4 v_[NP / 4];
 #pragma unroll
           for (int i = 0; i < NP / 4; ++i)
-            *reinterpret_cast<u32x4*>(sbuf_c + (unsigned)(g * NP + wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[g * (NP / 4) + i];
+            v_[i] = load_frag(ring, (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes, wave + 4 * i, P, H, lane, q, plain_);
+#pragma unroll
+          for (int i = 0; i < NP / 4; ++i)
+            *reinterpret_cast<u32x4*>(sbuf_c + (unsigned)(g * NP + wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[i];
+          __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 3; ++g)
