@@ -355,10 +355,12 @@ def main():
         for i in range(a.warmup):
             step(i)
         fence()
+        TrainStep.HOST_T["on"] = True; TrainStep.HOST_T["acc"] = {}     # host time per segment of the step, over the timed steps only
         t0 = time.perf_counter()
         for i in range(a.steps):
             loss, gn = step(a.warmup + i)
         t_enq = time.perf_counter() - t0           # host time to enqueue K steps (no sync inside a step)
+        TrainStep.HOST_T["on"] = False
         fence()
         dt = time.perf_counter() - t0
         ts.check_status()          # a hand-off timeout inside a persistent sweep would invalidate the run (raises)
@@ -500,7 +502,9 @@ def main():
                                process_runs=runs, best_process_ms=min(r["ms_per_step"] for r in runs) if runs else round(ms, 3),
                                host_enqueue_ms_per_step=runs[0]["host_enqueue_ms_per_step"] if runs else round(t_enq / a.steps * 1e3, 3),
                                host_api_us=host_api, slow_mode_probe=slow_probe,
-                               step_host_ms=({k: round(v / max(1, a.steps + a.warmup + 4) * 1e3, 3) for k, v in TrainStep.HOST_T["acc"].items()} if TrainStep.HOST_T["on"] else None),
+                               # where the host's time per step goes (Python + ctypes + the executor's enqueue), timed steps only: a slow
+                               # process's extra 3-6 ms are NOT in the executor's runtime calls (NOTES.md R6.1) -- this says which segment holds them
+                               step_host_ms={k: round(v / max(1, a.steps) * 1e3, 3) for k, v in TrainStep.HOST_T["acc"].items()},
                                dp_collective_call_host_ms_per_step=(round(ts.reducer.host_s / max(1, a.steps + a.warmup + 4) * 1e3, 3) if ts.reducer is not None else None),
                                host=dict(loadavg=[round(v, 2) for v in os.getloadavg()], cores_usable=usable_cores(),
                                          exec_host_delay_us=int(os.environ.get("B2T_EXEC_HOST_DELAY_US", "0")))),
