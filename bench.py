@@ -409,7 +409,8 @@ def main():
     runs = json.loads(os.environ.get("B2T_BENCH_PROCESS_RUNS", "[]")) if chained else []
     runs.append(dict(process=restarts + 1, ms_per_step=round(dt / a.steps * 1e3, 3), host_enqueue_ms_per_step=round(t_enq / a.steps * 1e3, 3),
                      sentences_per_s=round(rows * world * a.steps / dt, 2),
-                     kernel_launch_us_p50=host_api["kernel_launch_us"]["p50"] if host_api else None))
+                     kernel_launch_us_p50=host_api["kernel_launch_us"]["p50"] if host_api else None,
+                     step_host_ms={k: round(v / max(1, a.steps) * 1e3, 3) for k, v in TrainStep.HOST_T["acc"].items()}))
     # Round 6: a process that finds itself slow measures the cross-queue hop and its own scheduling state IN this process (the
     # driver's bench lease is where the mode shows up reliably); the result rides in `config`, which the driver's parser keeps.
     slow_probe = json.loads(os.environ.get("B2T_BENCH_SLOW_PROBE", "null")) if chained else None
