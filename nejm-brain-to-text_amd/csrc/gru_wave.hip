@@ -108,6 +108,19 @@ __device__ __forceinline__ bool wave_role(unsigned* tickets, int L, int G, bool 
   }
 }
 
+// LDS reads the compiler does not see as LDS reads: it may neither merge them nor put its own `s_waitcnt lgkmcnt(0)` in front of
+// the MFMA that uses one (it folded a four-deep software pipeline back to two and left ~100 cycles of LDS latency per MFMA exposed:
+// R6.2).  The caller waits with lds_wait<N>() -- "at most N of my LDS reads still in flight" (reads return in order).
+__device__ __forceinline__ u32x4 lds_read_async(const void* p) {
+  u32x4 v;
+  const unsigned a = (unsigned)reinterpret_cast<unsigned long long>(p);      // low 32 bits of a flat LDS address = the LDS offset
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+  return v;
+}
+template <int N> __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
+// make `v` (filled by an asynchronous read that lds_wait has covered) usable: ties the wait to the value for the compiler
+__device__ __forceinline__ u32x4 lds_use(u32x4 v) { asm volatile("" : "+v"(v)); return v; }
+
 constexpr int WTP = 20;                    // pitch (floats) of a wave's staged 16 x 16 tile
 constexpr int WTILE_F = 16 * WTP;          // one tile
 constexpr int WAVE_TILES = 4;              // tiles per wave (backward: dr, dz, dn r, dn; forward: h, dropped h)
@@ -167,8 +180,12 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
     _Pragma("unroll") for (int i = 0; i < NP / 4; ++i)                                                                 \
       *reinterpret_cast<u32x4*>((SBUF) + (unsigned)(wave + 4 * i) * 1024u + (unsigned)lane * 16u) = v_[i];             \
     __syncthreads();                                                                                                   \
+    u32x4 f_[4];                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) f_[i] = lds_read_async((SBUF) + (unsigned)i * 1024u + (unsigned)lane * 16u); \
     _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                   \
-      const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>((SBUF) + (unsigned)p * 1024u + (unsigned)lane * 16u)); \
+      if (p + 4 <= NP) lds_wait<3>(); else if (p + 3 == NP) lds_wait<2>(); else if (p + 2 == NP) lds_wait<1>(); else lds_wait<0>(); \
+      const bf16x8 av = __builtin_bit_cast(bf16x8, lds_use(f_[p % 4]));                                                \
+      if (p + 4 < NP) f_[p % 4] = lds_read_async((SBUF) + (unsigned)(p + 4) * 1024u + (unsigned)lane * 16u);           \
       BODY                                                                                                             \
     }                                                                                                                  \
   }
@@ -218,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
         // in front of every MFMA; pinned -- two gates in accumulation registers (192 of the 256), the third in architectural ones --
         // nothing spills (R6.2)
         if constexpr (NP > 16) { if (g < 2) asm volatile("" : "+a"(w[g][p])); else asm volatile("" : "+v"(w[g][p])); }
+        else if constexpr (NP == 16 && !RGF) asm volatile("" : "+a"(w[g][p]));
         if constexpr (RGF) asm volatile("" : "+a"(w[g][p]));      // row-group form: W_hh in accumulation registers, W_ih (below) mostly in architectural ones
       }
       __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
       for (int g = 0; g < 3; ++g) {
         const float* src = (layer > 0 ? wih : a.w_hh[layer]) + ((long long)g * H + unit) * H + (k0 < H ? k0 : 0);
         w2[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
-        if (g == 0 && p < NP / 2) asm volatile("" : "+a"(w2[g][p])); else asm volatile("" : "+v"(w2[g][p]));
+        if (g == 0 && p < (NP * 3) / 4) asm volatile("" : "+a"(w2[g][p])); else asm volatile("" : "+v"(w2[g][p]));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -310,9 +328,14 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
         _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w2[g][p], acc[g], 0, 0, 0);
       })
     } else {
+      // the B fragments come from LDS: the NEXT pair's three are requested before this pair's MFMAs (asynchronous reads, above)
+      u32x4 b_[2][3];
+      _Pragma("unroll") for (int g = 0; g < 3; ++g) b_[0][g] = lds_read_async(&wl[(g * NP + 0) * 64 + lane]);
       B2T_WAVE_STREAM(ring_in, pbase, {
+        if (p + 1 < NP) { _Pragma("unroll") for (int g = 0; g < 3; ++g) b_[(p + 1) & 1][g] = lds_read_async(&wl[(g * NP + p + 1) * 64 + lane]); }
+        if (p + 1 < NP) lds_wait<3>(); else lds_wait<0>();
         _Pragma("unroll") for (int g = 0; g < 3; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, lds_use(b_[p & 1][g])), acc[g], 0, 0, 0);
       })
     }
 #pragma unroll
@@ -463,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
         // in front of every MFMA; pinned -- two gates in accumulation registers (192 of the 256), the third in architectural ones --
         // nothing spills (R6.2)
         if constexpr (NP > 16) { if (g < 2) asm volatile("" : "+a"(w[g][p])); else asm volatile("" : "+v"(w[g][p])); }
+        else if constexpr (NP == 16 && !RGF) asm volatile("" : "+a"(w[g][p]));
         if constexpr (RGF) asm volatile("" : "+a"(w[g][p]));
       }
       __builtin_amdgcn_sched_barrier(0);   // (a pair's six loads are converted before the next pair's go out: hoisted, all 6 NP loads would be live)
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
       for (int g = 0; g < 3; ++g) {
         const float* src = wt + (long long)g * H + (k0 < H ? k0 : 0);
         w2[g][p] = __builtin_bit_cast(bf16x8, masked8(ld4(src), ld4(src + 4), ok));
-        if (g == 0 && p < NP / 2) asm volatile("" : "+a"(w2[g][p])); else asm volatile("" : "+v"(w2[g][p]));
+        if (g == 0 && p < (NP * 3) / 4) asm volatile("" : "+a"(w2[g][p])); else asm volatile("" : "+v"(w2[g][p]));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -541,19 +565,36 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
+      {
+        // LDS reads four fragments ahead, two accumulators (a read's ~128 cycles and a dependent MFMA's ~40 were the loop: 150 per pair)
+        f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 f_[4];
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+        for (int i = 0; i < 4; ++i) f_[i] = lds_read_async(sbuf_p + (unsigned)i * 1024u + (unsigned)lane * 16u);
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sbuf_p + (unsigned)(g * NP + p) * 1024u + (unsigned)lane * 16u)), w2[g][p], acc, 0, 0, 0);
+        for (int k = 0; k < 3 * NP; ++k) {
+          if (k + 4 <= 3 * NP) lds_wait<3>(); else if (k + 3 == 3 * NP) lds_wait<2>(); else if (k + 2 == 3 * NP) lds_wait<1>(); else lds_wait<0>();
+          const bf16x8 av = __builtin_bit_cast(bf16x8, lds_use(f_[k % 4]));
+          if (k + 4 < 3 * NP) f_[k % 4] = lds_read_async(sbuf_p + (unsigned)(k + 4) * 1024u + (unsigned)lane * 16u);
+          if (k & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w2[k / NP][k % NP], acc1, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w2[k / NP][k % NP], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += acc1[i];
+      }
     } else {
+    // (two accumulators, pairs alternating: one accumulator is a chain of dependent MFMAs at ~40 cycles each instead of 17)
+    f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       const unsigned pbase = (unsigned)t * slot_bytes + rg_off + (unsigned)(g == 2 ? 3 : g) * arr_bytes;
       B2T_WAVE_STREAM(ring_up, pbase, {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc, 0, 0, 0);
+        if (p & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc1, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wl[(g * NP + p) * 64 + lane]), acc, 0, 0, 0);
       })
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += acc1[i];
     }
     if (DROP) {
       // the mask of the forward's dropout on out[layer]: row-major through the wave's tile (one Philox block per lane)
@@ -611,19 +652,34 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
           __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+        {
+          f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+          u32x4 f_[4];
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+          for (int i = 0; i < 4; ++i) f_[i] = lds_read_async(sbuf_c + (unsigned)i * 1024u + (unsigned)lane * 16u);
 #pragma unroll
-          for (int p = 0; p < NP; ++p)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sbuf_c + (unsigned)(g * NP + p) * 1024u + (unsigned)lane * 16u)), w[g][p], acc, 0, 0, 0);
+          for (int k = 0; k < 3 * NP; ++k) {
+            if (k + 4 <= 3 * NP) lds_wait<3>(); else if (k + 3 == 3 * NP) lds_wait<2>(); else if (k + 2 == 3 * NP) lds_wait<1>(); else lds_wait<0>();
+          const bf16x8 av = __builtin_bit_cast(bf16x8, lds_use(f_[k % 4]));
+            if (k + 4 < 3 * NP) f_[k % 4] = lds_read_async(sbuf_c + (unsigned)(k + 4) * 1024u + (unsigned)lane * 16u);
+            if (k & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[k / NP][k % NP], acc1, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[k / NP][k % NP], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += acc1[i];
+        }
       } else {
+      f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         const unsigned cbase = (unsigned)(t + 1) * slot_bytes + rg_off + (unsigned)g * arr_bytes;
         B2T_WAVE_STREAM2(ring, cbase, {}, {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc, 0, 0, 0);
+          if (p & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc1, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[g][p], acc, 0, 0, 0);
         })
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += acc1[i];
       }
       asm volatile("s_nop 0" :: "v"(acc[0]));
       WSTAMP(1)
