@@ -760,6 +760,8 @@ __global__ void wave_gate_kernel(const unsigned* prog, int n, unsigned target, u
   }
 }
 
+#include "gru_wave_ks.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -778,8 +780,8 @@ size_t gru_wave_lds_bytes_rgf_bwd(int H);
 static int wave_np(int H) { return H <= 128 ? 4 : H <= 256 ? 8 : H <= 512 ? 16 : 24; }   // the kernel template's pair count
 size_t gru_wave_lds_bytes(int H) { return (size_t)3 * wave_np(H) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
 size_t gru_wave_lds_bytes_rgf_bwd(int H) { return (size_t)6 * wave_np(H) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }   // two stream buffers of three arrays
-size_t gru_wave_ring_bytes_fwd(int T, int B, int H) { return (size_t)(T + 1) * ((B + 15) / 16) * ((H / 16 + 1) / 2) * 1024; }
-size_t gru_wave_ring_bytes_bwd(int T, int B, int H) { return (size_t)T * ((B + 15) / 16) * 4 * ((H / 16 + 1) / 2) * 1024; }
+size_t gru_wave_ring_bytes_fwd(int T, int B, int H) { return (size_t)(T + 1 > KS_D ? T + 1 : KS_D) * ((B + 15) / 16) * ((H / 16 + 1) / 2) * 1024; }   // (>= KS_D slots: the K-split form's own ring)
+size_t gru_wave_ring_bytes_bwd(int T, int B, int H) { return (size_t)(T > KS_D ? T : KS_D) * ((B + 15) / 16) * 4 * ((H / 16 + 1) / 2) * 1024; }
 size_t gru_wave_cnt_words_fwd(int L, int T, int B) { return 16 + (size_t)L * 2 * ((B + 15) / 16) * (T + 1); }   // 16: the XCD tickets of the local form
 size_t gru_wave_cnt_words_bwd(int L, int T, int B) { return 16 + 64 + (size_t)L * 2 * ((B + 15) / 16) * T; }   // tickets, progress words [L][row groups] (<= 32), counters
 
@@ -822,6 +824,33 @@ bool gru_wave_rgf(int H) {
   const char* e = getenv("B2T_WAVE_RGF");
   return !(e && atoi(e) == 0) && H % 64 == 0 && H <= 512;
 }
+// the K-split form (gru_wave_ks.h): local placement, H % 128 == 0, H <= 512, a layer's workgroups fit one XCD; B2T_WAVE_KS=0 (read per call): off
+bool gru_wave_ks(int L, int B, int H) {
+  const char* e = getenv("B2T_WAVE_KS");
+  if (e && atoi(e) == 0) return false;
+  const int nrh = ((B + 15) / 16 + 1) / 2;
+  return gru_wave_local(L, H) && H % 128 == 0 && H <= 512 && nrh * (H / 32) <= 32;
+}
+static size_t ks_lds_bytes(bool backward) { return (size_t)2 * 4 * (backward ? 4 : 12) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
+static int ks_arm(char* const* ring, int L, size_t slot_bytes, hipStream_t s) {
+  KsArmArgs k;
+  for (int l = 0; l < B2T_MAX_LAYERS; ++l) k.ring[l] = l < L ? ring[l] : nullptr;
+  k.vec16 = (unsigned)((size_t)KS_D * slot_bytes / 16);
+  hipLaunchKernelGGL(ks_arm_kernel, dim3(32, L), dim3(256), 0, s, k);
+  return check_hip(hipGetLastError(), "gru_wave: arm");
+}
+template <int NPQ, bool DR> static int ks_launch_fwd(const WaveFwdArgs& a, hipStream_t s) {
+  static bool at = false;
+  if (!at) { const int rc = wave_lds_attr(gru_ks_fwd_kernel<NPQ, DR>, ks_lds_bytes(false)); if (rc) return rc; at = true; }
+  hipLaunchKernelGGL((gru_ks_fwd_kernel<NPQ, DR>), dim3(256), dim3(256), ks_lds_bytes(false), s, a);
+  return 0;
+}
+template <int NPQ, bool DR> static int ks_launch_bwd(const WaveBwdArgs& a, hipStream_t s) {
+  static bool at = false;
+  if (!at) { const int rc = wave_lds_attr(gru_ks_bwd_kernel<NPQ, DR>, ks_lds_bytes(true)); if (rc) return rc; at = true; }
+  hipLaunchKernelGGL((gru_ks_bwd_kernel<NPQ, DR>), dim3(256), dim3(256), ks_lds_bytes(true), s, a);
+  return 0;
+}
 template <int NPV, bool DR, bool LC, bool RG = false> static int wave_launch_bwd(const WaveBwdArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool at = false;
   if (!at) { const int rc = wave_lds_attr(gru_wave_bwd_kernel<NPV, DR, LC, RG>, RG ? gru_wave_lds_bytes_rgf_bwd(32 * NPV) : gru_wave_lds_bytes(32 * NPV)); if (rc) return rc; at = true; }
@@ -839,6 +868,18 @@ int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
   a.tickets = a.cnt; a.cnt = a.cnt + 16;
   int rc = check_hip(hipMemsetAsync(a.tickets, 0, gru_wave_cnt_words_fwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_fwd: counters");
   if (rc) return rc;
+  if (gru_wave_ks(a.L, a.B, a.H)) {
+    rc = ks_arm(a.ring, a.L, (size_t)((a.B + 15) / 16) * (a.H / 32) * 1024, s);
+    if (rc) return rc;
+    switch (a.H / 128) {
+      case 1: rc = drop ? ks_launch_fwd<1, true>(a, s) : ks_launch_fwd<1, false>(a, s); break;
+      case 2: rc = drop ? ks_launch_fwd<2, true>(a, s) : ks_launch_fwd<2, false>(a, s); break;
+      case 3: rc = drop ? ks_launch_fwd<3, true>(a, s) : ks_launch_fwd<3, false>(a, s); break;
+      default: rc = drop ? ks_launch_fwd<4, true>(a, s) : ks_launch_fwd<4, false>(a, s); break;
+    }
+    if (rc) return rc;
+    return check_hip(hipGetLastError(), "gru_wave_fwd");
+  }
   const bool rgf = gru_wave_rgf(a.H);
   const int ngrp_ = (a.B + 15) / 16;
   const dim3 grid(loc ? 256 : (rgf ? a.L * ngrp_ * (a.H / 64) : a.L * (a.H / 16)));
@@ -878,6 +919,18 @@ int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   int rc = 0;
   if (!(a_in.flags & 2)) { rc = gru_wave_bwd_clear(a.cnt, a.L, a.T, a.B, s); if (rc) return rc; }   // (bit 1: the caller cleared them, gated consumers are already waiting)
   a.tickets = a.cnt; a.prog = a_in.prog ? a.cnt + 16 : nullptr; a.cnt = a.cnt + 16 + 64;
+  if (gru_wave_ks(a.L, a.B, a.H)) {
+    rc = ks_arm(a.ring, a.L, (size_t)((a.B + 15) / 16) * 4 * (a.H / 32) * 1024, s);
+    if (rc) return rc;
+    switch (a.H / 128) {
+      case 1: rc = drop ? ks_launch_bwd<1, true>(a, s) : ks_launch_bwd<1, false>(a, s); break;
+      case 2: rc = drop ? ks_launch_bwd<2, true>(a, s) : ks_launch_bwd<2, false>(a, s); break;
+      case 3: rc = drop ? ks_launch_bwd<3, true>(a, s) : ks_launch_bwd<3, false>(a, s); break;
+      default: rc = drop ? ks_launch_bwd<4, true>(a, s) : ks_launch_bwd<4, false>(a, s); break;
+    }
+    if (rc) return rc;
+    return check_hip(hipGetLastError(), "gru_wave_bwd");
+  }
   const bool rgf = gru_wave_rgf(a.H);
   const int ngrp_ = (a.B + 15) / 16;
   const dim3 grid(loc ? 256 : (rgf ? a.L * ngrp_ * (a.H / 64) : a.L * (a.H / 16)));

@@ -1,0 +1,563 @@
+// gru_wave_ks.h — the K-SPLIT form of the layer wavefront (included by gru_wave.hip between its device helpers and its host side;
+// same hand-off data, same results' meaning, same launch geometry class as the local form: layer l on XCD l).
+//
+// Why.  In the 16-unit ("fat") form every wave of a workgroup contracts the WHOLE K range for its own row group, so a CU pulls
+// all four row groups' fragments through its vector cache every step: 128 KB forward, 384 KB backward per step and CU at H = 512
+// against ~55 B per clock and CU from the L2 -- 2.3 k / 7 k cycles of a ~10 k / ~21 k cycle step, with the counter hand-off's four
+// dependent L2 round trips (store -> acknowledge -> atomic -> poll -> load) on top (NOTES.md R6.2).  Here
+//   * a workgroup = (layer, TWO row groups, TWO 16-unit slices = one fragment pair) and its four waves split K: wave w contracts
+//     the pairs [NPQ w, NPQ (w + 1)) of both row groups for all of the workgroup's output columns, with a QUARTER of the weight
+//     slices in its registers (96 registers per matrix at H = 512: W_hh AND W_ih both fit, nothing in LDS); the four partial tiles
+//     are summed through LDS (one workgroup barrier per product); then wave w = (row group w >> 1, slice w & 1) runs the gates of
+//     its own 16 x 16 tile exactly as before.  Per CU and step: 64 KB forward, 192 KB backward;
+//   * the own-recurrence hand-off is DATA-POLLED: the ring slot is armed with a sentinel (an all-ones dword -- the producers clamp
+//     their bf16 pairs below it, which only touches a NaN payload), consumers load the fragments they need with L1-bypassing
+//     (sc1) loads straight into the MFMA's operand registers and retry while any dword is still the sentinel.  No acknowledge
+//     wait, no counter, no separate poll: one store -> visible -> load per step.  The ring is KS_D slots deep and lives in the
+//     XCD's L2; a producer re-arms the slot two publishes ahead (the retry loop's vmcnt(0) orders that store before the data of
+//     the next publish; depth >= 4 makes the re-armed slot dead: everything up to two publishes back has been consumed by
+//     every peer that published the previous one);
+//   * the neighbouring layer (another XCD) still reads a second, written-through ring behind agent-scope counters.
+// Serves H % 128 == 0, H <= 512 under the local placement; other shapes keep the 16-unit form.
+#pragma once
+
+constexpr int KS_D = 8;                          // own-ring depth (slots)
+constexpr unsigned KS_MAXDATA = 0xFFFEFFFFu;     // data dwords are clamped to this; anything above is "not yet written"
+
+__device__ __forceinline__ u32x4 ks_clamp(u32x4 v) {
+  return u32x4{v.x < KS_MAXDATA ? v.x : KS_MAXDATA, v.y < KS_MAXDATA ? v.y : KS_MAXDATA, v.z < KS_MAXDATA ? v.z : KS_MAXDATA, v.w < KS_MAXDATA ? v.w : KS_MAXDATA};
+}
+__device__ __forceinline__ unsigned ks_max(unsigned m, u32x4 v) {
+  const unsigned a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+  const unsigned c = a > b ? a : b;
+  return m > c ? m : c;
+}
+__device__ __forceinline__ u32x4 ks_sentinel() { return u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; }
+
+// both row groups' counters of the neighbouring layer's ring slot: even lanes look at the first, odd lanes at the second
+__device__ __forceinline__ void ks_wait2(const unsigned* c0, const unsigned* c1, unsigned target, unsigned* err, int lane) {
+  const unsigned* p = (lane & 1) ? c1 : c0;
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned v = __hip_atomic_load(p, RLX_AGENT);
+    if (__all(v >= target)) break;
+    if ((++spins & 255u) == 0u) {
+      if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+      if (spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// sum of the four waves' partial tiles `tile` (of NT per wave) for this lane: C layout in, C layout out
+template <int NT>
+__device__ __forceinline__ f32x4 ks_reduce(const float4* part, int tile, int lane) {
+  float4 s = part[(0 * NT + tile) * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float4 v = part[(w * NT + tile) * 64 + lane];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  return f32x4{s.x, s.y, s.z, s.w};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NPQ, bool DROP>      // NPQ = H / 128: fragment pairs per K quarter
+__global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wave_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int H = a.H, B = a.B, T = a.T, G = H / 16, P = G / 2, ngrp = (B + 15) / 16, L = a.L, nrh = (ngrp + 1) / 2;
+  int layer, k;
+  if (!wave_role<true>(a.tickets, L, nrh * P, false, layer, k)) return;
+  const int rh = k / P, ub = k % P;                       // row half (row groups 2 rh, 2 rh + 1), unit block (slices 2 ub, 2 ub + 1 = pair ub)
+  const int rgl = wave >> 1, us = wave & 1;               // the tile this wave finishes
+  const int rg = 2 * rh + rgl, slice = 2 * ub + us, u0 = slice * 16, unit = u0 + j, m0 = rg * 16;
+  const bool rg_live = rg < ngrp;
+  const int rgc0 = 2 * rh, rgc1 = (2 * rh + 1 < ngrp) ? 2 * rh + 1 : 2 * rh;     // the row groups whose fragments this workgroup contracts
+  constexpr int NT = 12;                                  // partial tiles per wave: (row group 2) x (slice 2) x (gate 3)
+  float4* part_p = reinterpret_cast<float4*>(wave_lds);
+  float4* part_q = part_p + 4 * NT * 64;
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)2 * 4 * NT * 1024) + wave * (WAVE_TILES * WTILE_F);
+
+  // this wave's quarter of the K range of the workgroup's W_hh and W_ih slices, as B fragments in accumulation registers
+  bf16x8 w[2][3][NPQ], w2[2][3][NPQ];
+  {
+    const float* whh = a.w_hh[layer];
+    const float* wih = layer > 0 ? a.w_ih[layer] : a.w_hh[layer];
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i) {
+      const int k0 = 32 * (NPQ * wave + i) + 8 * q;
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const long long row = (long long)g * H + 16 * (2 * ub + u2) + j;
+          const float* s1 = whh + row * H + k0;
+          const float* s2 = wih + row * H + k0;
+          w[u2][g][i] = cvt8(ld4(s1), ld4(s1 + 4));
+          w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(ld4(s2), ld4(s2 + 4), layer > 0));
+          asm volatile("" : "+a"(w[u2][g][i]));
+          asm volatile("" : "+a"(w2[u2][g][i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_setprio(3);
+
+  unsigned* err = a.err;
+  const size_t cstride = (size_t)(T + 1);
+  unsigned* cnt_x = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + (rg_live ? rg : 0)) * cstride;
+  const bool feeds = layer + 1 < L, dropping = DROP && feeds;
+  const unsigned* cnt_in0 = layer > 0 ? a.cnt + ((size_t)((layer - 1) * 2 + 1) * ngrp + rgc0) * cstride : nullptr;
+  const unsigned* cnt_in1 = layer > 0 ? a.cnt + ((size_t)((layer - 1) * 2 + 1) * ngrp + rgc1) * cstride : nullptr;
+  char* ring = a.ring[layer];
+  char* ringx = a.ringd[layer];
+  const char* ring_in = layer > 0 ? a.ringd[layer - 1] : nullptr;
+  const unsigned slot_bytes = (unsigned)ngrp * (unsigned)P * 1024u, rg_off = (unsigned)rg * (unsigned)P * 1024u;
+  const unsigned my_frag = (unsigned)ub * 1024u + (unsigned)us * 512u + (unsigned)(lane & 31) * 16u;
+  const unsigned in_off0 = (unsigned)rgc0 * (unsigned)P * 1024u + (unsigned)(NPQ * wave) * 1024u + (unsigned)lane * 16u;
+  const unsigned in_off1 = (unsigned)rgc1 * (unsigned)P * 1024u + (unsigned)(NPQ * wave) * 1024u + (unsigned)lane * 16u;
+  const float bhr = a.b_hh[layer][unit], bhz = a.b_hh[layer][H + unit], bhn = a.b_hh[layer][2 * H + unit];
+  float bi[3] = {0.f, 0.f, 0.f};
+  if (layer > 0) { bi[0] = a.b_ih[layer][unit]; bi[1] = a.b_ih[layer][H + unit]; bi[2] = a.b_ih[layer][2 * H + unit]; }
+  bool live[4];
+  f32x4 hp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + 4 * q + i;
+    live[i] = rg_live && row < B;
+    hp[i] = live[i] ? a.h_init[layer][(long long)row * H + unit] : 0.f;
+  }
+  // index 0 of the ring = the initial state (the slots were armed by the host's arm kernel)
+  if (rg_live) {
+    tile_put(tiles, hp, j, q);
+    const u32x4 f = ks_clamp(tile_frag(tiles, lane));
+    if (lane < 32) store_u4<0>(ring, rg_off + my_frag, f);
+  }
+  int pending_x = -1;
+
+#ifdef B2T_WAVE_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+  f32x4 gi[3], gin[3];
+  // the K-split product of one operand stream: A fragments v[2][NPQ] x B fragments wt -> 12 partial tiles -> LDS -> the wave's 3
+  auto contract = [&](const u32x4 (&v)[2][NPQ], const bf16x8 (&wt)[2][3][NPQ], float4* part, f32x4 (&out)[3]) {
+    f32x4 acc[2][2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[r][u2][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, v[r][i]);
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[r][u2][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wt[u2][g][i], acc[r][u2][g], 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const f32x4 c = acc[r][u2][g];
+          part[(wave * NT + (r * 2 + u2) * 3 + g) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
+        }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) out[g] = ks_reduce<NT>(part, (rgl * 2 + us) * 3 + g, lane);
+  };
+  // gi of step t from layer - 1's (dropped) h_t = slot t + 1 of its written-through ring
+  auto project = [&](int t) {
+    ks_wait2(cnt_in0 + (t + 1), cnt_in1 + (t + 1), (unsigned)G, err, lane);
+    WSTAMP(5)
+    u32x4 v[2][NPQ];
+    const unsigned base = (unsigned)(t + 1) * slot_bytes;
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i) {
+      v[0][i] = load_u4<0>(ring_in, base + in_off0 + (unsigned)i * 1024u);
+      v[1][i] = load_u4<0>(ring_in, base + in_off1 + (unsigned)i * 1024u);
+    }
+    f32x4 o[3];
+    contract(v, w2, part_q, o);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gi[g][i] = o[g][i] + bi[g];
+    WSTAMP(6)
+  };
+  auto load_gi0 = [&](int t, f32x4 (&dst)[3]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* g3 = a.gi0 + ((long long)t * B + (live[i] ? m0 + 4 * q + i : 0)) * 3 * H + unit;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) dst[g][i] = live[i] ? __builtin_nontemporal_load(g3 + (long long)g * H) : 0.f;
+    }
+  };
+  if (layer > 0) project(0); else load_gi0(0, gi);
+
+  for (int t = 0; t < T; ++t) {
+    // h_{t-1} of both row groups, this wave's K quarter: load until no dword is the sentinel
+    u32x4 v[2][NPQ];
+    {
+      const unsigned base = (unsigned)(t % KS_D) * slot_bytes;
+      unsigned spins = 0;
+      for (;;) {
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i) {
+          v[0][i] = load_u4<16>(ring, base + in_off0 + (unsigned)i * 1024u);
+          v[1][i] = load_u4<16>(ring, base + in_off1 + (unsigned)i * 1024u);
+        }
+        unsigned m = 0u;
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i) { m = ks_max(m, v[0][i]); m = ks_max(m, v[1][i]); }
+        if (!__any(m > KS_MAXDATA)) break;
+        if ((++spins & 63u) == 0u) {
+          if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+          if (spins > (SPIN_LIMIT >> 2)) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+        }
+      }
+    }
+    wave_drain();      // (already empty: the loads above were waited for -- and with them every earlier store of this wave)
+    if (pending_x >= 0) { wave_bump<false>(cnt_x + pending_x, lane); pending_x = -1; }
+    WSTAMP(0)   // the peers' h_{t-1} is here
+    if (layer == 0 && t + 1 < T) load_gi0(t + 1, gin);     // (lands during the product)
+    f32x4 gh[3];
+    contract(v, w, (layer == 0 && (t & 1)) ? part_q : part_p, gh);
+    WSTAMP(1)   // recurrent product + reduction
+    if (rg_live) {
+      f32x4 sr, sz, sn, sg, h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ghn = gh[2][i] + bhn;
+        const float r = fast_sigmoid(gi[0][i] + gh[0][i] + bhr);
+        const float z = fast_sigmoid(gi[1][i] + gh[1][i] + bhz);
+        const float nn = fast_tanh(gi[2][i] + r * ghn);
+        h[i] = (1.0f - z) * nn + z * hp[i];
+        sr[i] = r; sz[i] = z; sn[i] = nn; sg[i] = ghn;
+      }
+      hp = h;
+      // publish h_t = index t + 1; re-arm the slot of index t + 3
+      tile_put(tiles, h, j, q);
+      const u32x4 f = tile_frag(tiles, lane);
+      if (lane < 32) {
+        store_u4<0>(ring, (unsigned)((t + 1) % KS_D) * slot_bytes + rg_off + my_frag, ks_clamp(f));
+        store_u4<0>(ring, (unsigned)((t + 3) % KS_D) * slot_bytes + rg_off + my_frag, ks_sentinel());
+      }
+      WSTAMP(2)   // gates + publish
+      const int rrow = m0 + (lane & 15), kg = lane >> 4;
+      const float4 hv = ld4(tiles + (lane & 15) * WTP + 4 * kg);
+      if (feeds) {
+        u32x4 fx = f;
+        if (dropping) {
+          const long long e = a.elem0 + ((long long)t * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
+          const float4 u = Philox::uniform4(a.seed[layer], (uint64_t)(e >> 2), 2u);
+          float4 hd;
+          hd.x = u.x >= a.drop_p ? hv.x * a.drop_scale : 0.f; hd.y = u.y >= a.drop_p ? hv.y * a.drop_scale : 0.f;
+          hd.z = u.z >= a.drop_p ? hv.z * a.drop_scale : 0.f; hd.w = u.w >= a.drop_p ? hv.w * a.drop_scale : 0.f;
+          float* td = tiles + WTILE_F;
+          *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = hd;
+          fx = tile_frag(td, lane);
+          if (rrow < B) *reinterpret_cast<float4*>(a.outd[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hd;
+        }
+        if (lane < 32) store_u4<16>(ringx, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, fx);
+        pending_x = t + 1;
+      }
+      if (rrow < B) *reinterpret_cast<float4*>(a.out[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hv;
+      if (a.reserve[layer]) {
+        tile_put(tiles + 0 * WTILE_F, sr, j, q); tile_put(tiles + 1 * WTILE_F, sz, j, q);
+        tile_put(tiles + 2 * WTILE_F, sn, j, q); tile_put(tiles + 3 * WTILE_F, sg, j, q);
+        if (rrow < B) {
+          float* rs = a.reserve[layer] + ((long long)t * B + rrow) * 4 * H + u0 + 4 * kg;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 v4 = ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg);
+            __builtin_nontemporal_store(v4.x, rs + (long long)g * H); __builtin_nontemporal_store(v4.y, rs + (long long)g * H + 1);
+            __builtin_nontemporal_store(v4.z, rs + (long long)g * H + 2); __builtin_nontemporal_store(v4.w, rs + (long long)g * H + 3);
+          }
+        }
+      }
+      WSTAMP(4)   // neighbour's ring, fp32 stores
+    }
+    if (layer > 0) { if (t + 1 < T) project(t + 1); }
+    else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gi[g] = gin[g];
+    }
+  }
+  if (pending_x >= 0) { wave_drain(); wave_bump<false>(cnt_x + pending_x, lane); }
+#ifdef B2T_WAVE_TIMING
+  if (k == 0 && wave == 0 && lane == 0 && a.timing)
+    for (int i = 0; i < 8; ++i) a.timing[layer * 8 + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward.  Ring slot: the gate gradients of one step as fragments, 4 arrays (dr, dz, dn r, dn) x P pairs per row group.
+// Index n of the own ring = step T - 1 - n.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NPQ, bool DROP>
+__global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wave_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int H = a.H, B = a.B, T = a.T, G = H / 16, P = G / 2, ngrp = (B + 15) / 16, L = a.L, nrh = (ngrp + 1) / 2;
+  int layer, k;
+  if (!wave_role<true>(a.tickets, L, nrh * P, true, layer, k)) return;
+  const int rh = k / P, ub = k % P;
+  const int rgl = wave >> 1, us = wave & 1;
+  const int rg = 2 * rh + rgl, slice = 2 * ub + us, u0 = slice * 16, unit = u0 + j, m0 = rg * 16;
+  const bool rg_live = rg < ngrp;
+  const int rgc0 = 2 * rh, rgc1 = (2 * rh + 1 < ngrp) ? 2 * rh + 1 : 2 * rh;
+  constexpr int NT = 4;                                   // partial tiles per wave: (row group 2) x (slice 2)
+  float4* part_p = reinterpret_cast<float4*>(wave_lds);
+  float4* part_q = part_p + 4 * NT * 64;
+  float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)2 * 4 * NT * 1024) + wave * (WAVE_TILES * WTILE_F);
+  const bool has_up = layer + 1 < L;
+
+  // this wave's K quarter (pairs [NPQ w, NPQ (w + 1)) of each of the three arrays) of the W_hh^T and W_ih[layer + 1]^T column slices
+  bf16x8 w[2][3][NPQ], w2[2][3][NPQ];
+  {
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i) {
+      const int k0 = 32 * (NPQ * wave + i) + 8 * q;
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2) {
+        const long long col = 16 * (2 * ub + u2) + j;
+        const float* t1 = a.w_hh_t[layer] + col * 3 * H;
+        const float* t2 = (has_up ? a.w_ih_t[layer + 1] : a.w_hh_t[layer]) + col * 3 * H;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const float* s1 = t1 + (long long)g * H + k0;
+          const float* s2 = t2 + (long long)g * H + k0;
+          w[u2][g][i] = cvt8(ld4(s1), ld4(s1 + 4));
+          w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(ld4(s2), ld4(s2 + 4), has_up));
+          asm volatile("" : "+a"(w[u2][g][i]));
+          asm volatile("" : "+a"(w2[u2][g][i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_setprio(3);
+
+  unsigned* err = a.err;
+  const size_t cstride = (size_t)T;
+  unsigned* cnt_x = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + (rg_live ? rg : 0)) * cstride;
+  const bool feeds = layer > 0;
+  const unsigned* cnt_up0 = has_up ? a.cnt + ((size_t)((layer + 1) * 2 + 1) * ngrp + rgc0) * cstride : nullptr;
+  const unsigned* cnt_up1 = has_up ? a.cnt + ((size_t)((layer + 1) * 2 + 1) * ngrp + rgc1) * cstride : nullptr;
+  char* ring = a.ring[layer];
+  char* ringx = a.ringx[layer];
+  const char* ring_up = has_up ? a.ringx[layer + 1] : nullptr;
+  const unsigned arr_bytes = (unsigned)P * 1024u, rg_bytes = 4u * arr_bytes, slot_bytes = (unsigned)ngrp * rg_bytes, rg_off = (unsigned)rg * rg_bytes;
+  const unsigned my_frag = (unsigned)ub * 1024u + (unsigned)us * 512u + (unsigned)(lane & 31) * 16u;
+  const unsigned in_off0 = (unsigned)rgc0 * rg_bytes + (unsigned)(NPQ * wave) * 1024u + (unsigned)lane * 16u;
+  const unsigned in_off1 = (unsigned)rgc1 * rg_bytes + (unsigned)(NPQ * wave) * 1024u + (unsigned)lane * 16u;
+  bool live[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) live[i] = rg_live && m0 + 4 * q + i < B;
+  const int rrow = m0 + (lane & 15), kg = lane >> 4;
+  int pending_x = -1;
+  unsigned* prog = (a.prog && rg_live) ? a.prog + layer * ngrp + rg : nullptr;
+
+#ifdef B2T_WAVE_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+  auto contract = [&](const u32x4 (&v)[2][3][NPQ], const bf16x8 (&wt)[2][3][NPQ], float4* part) -> f32x4 {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2) acc[r][u2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < NPQ; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, v[r][g][i]);
+#pragma unroll
+          for (int u2 = 0; u2 < 2; ++u2) acc[r][u2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wt[u2][g][i], acc[r][u2], 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2) {
+        const f32x4 c = acc[r][u2];
+        part[(wave * NT + r * 2 + u2) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
+      }
+    __syncthreads();
+    return ks_reduce<NT>(part, rgl * 2 + us, lane);
+  };
+  f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
+  // dY[layer]_t = dGi[layer + 1]_t . W_ih[layer + 1][:, units] (arrays dr, dz, dn of the ring above), then the dropout mask
+  auto project = [&](int t) {
+    ks_wait2(cnt_up0 + t, cnt_up1 + t, (unsigned)G, err, lane);
+    WSTAMP(5)
+    u32x4 v[2][3][NPQ];
+    const unsigned base = (unsigned)t * slot_bytes;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < NPQ; ++i) {
+        const unsigned ao = (unsigned)(g == 2 ? 3 : g) * arr_bytes + (unsigned)i * 1024u;
+        v[0][g][i] = load_u4<0>(ring_up, base + in_off0 + ao);
+        v[1][g][i] = load_u4<0>(ring_up, base + in_off1 + ao);
+      }
+    f32x4 acc = contract(v, w2, part_q);
+    if (DROP) {
+      float* td = tiles;
+      tile_put(td, acc, j, q);
+      float4 v4 = ld4(td + (lane & 15) * WTP + 4 * kg);
+      const long long e = a.elem0 + ((long long)t * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
+      const float4 u = Philox::uniform4(a.seed[layer], (uint64_t)(e >> 2), 2u);
+      v4.x = u.x >= a.drop_p ? v4.x * a.drop_scale : 0.f; v4.y = u.y >= a.drop_p ? v4.y * a.drop_scale : 0.f;
+      v4.z = u.z >= a.drop_p ? v4.z * a.drop_scale : 0.f; v4.w = u.w >= a.drop_p ? v4.w * a.drop_scale : 0.f;
+      *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = v4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = td[(4 * q + i) * WTP + j];
+    }
+    dy = acc;
+    WSTAMP(6)
+  };
+
+  // the step's elementwise operands (saved gates, h_{t-1}, the top layer's dY) come from memory: requested one step ahead, right
+  // after the poll (behind it they would sit in front of the NEXT poll's loads: vector memory returns in order)
+  struct Elem { f32x4 r, z, nv, ghn, hprev, dyt; };
+  auto fetch = [&](int t, Elem& e) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      e.r[i] = e.z[i] = e.nv[i] = e.ghn[i] = e.hprev[i] = e.dyt[i] = 0.f;
+      if (live[i] && t >= 0) {
+        const int row = m0 + 4 * q + i;
+        const float* rs = a.reserve[layer] + ((long long)t * B + row) * 4 * H + unit;
+        e.r[i] = __builtin_nontemporal_load(rs); e.z[i] = __builtin_nontemporal_load(rs + H);
+        e.nv[i] = __builtin_nontemporal_load(rs + 2 * H); e.ghn[i] = __builtin_nontemporal_load(rs + 3 * H);
+        e.hprev[i] = t > 0 ? a.out[layer][((long long)(t - 1) * B + row) * H + unit] : a.h_init[layer][(long long)row * H + unit];
+        if (!has_up) e.dyt[i] = __builtin_nontemporal_load(a.dY_top + ((long long)t * B + row) * H + unit);
+      }
+    }
+  };
+  Elem cur, nxt;
+  fetch(T - 1, cur);
+  if (has_up) project(T - 1);
+  f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int t = T - 1; t >= -1; --t) {
+    f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < T - 1) {
+      // dG_{t+1} = index T - 2 - t: arrays dr, dz, dn r of both row groups, this wave's K quarter
+      u32x4 v[2][3][NPQ];
+      {
+        const unsigned base = (unsigned)((T - 2 - t) % KS_D) * slot_bytes;
+        unsigned spins = 0;
+        for (;;) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < NPQ; ++i) {
+              const unsigned ao = (unsigned)g * arr_bytes + (unsigned)i * 1024u;
+              v[0][g][i] = load_u4<16>(ring, base + in_off0 + ao);
+              v[1][g][i] = load_u4<16>(ring, base + in_off1 + ao);
+            }
+          unsigned m = 0u;
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < NPQ; ++i) { m = ks_max(m, v[0][g][i]); m = ks_max(m, v[1][g][i]); }
+          if (!__any(m > KS_MAXDATA)) break;
+          if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+            if (spins > (SPIN_LIMIT >> 2)) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+          }
+        }
+      }
+      wave_drain();
+      if (pending_x >= 0) { wave_bump<false>(cnt_x + pending_x, lane); pending_x = -1; }
+      // progress for consumers OUTSIDE the launch (the gated weight-gradient GEMMs): every store of the steps > t is acknowledged
+      if (prog) wave_bump<false>(prog, lane);
+      WSTAMP(0)
+      fetch(t - 1, nxt);
+      const f32x4 acc = contract(v, w, part_p);
+      WSTAMP(1)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) carry[i] = acc[i] + dzterm[i];
+    } else {
+      wave_drain();
+      if (prog) wave_bump<false>(prog, lane);
+      fetch(t - 1, nxt);
+      if (a.dh_last) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (live[i]) carry[i] = a.dh_last[((long long)layer * B + (m0 + 4 * q + i)) * H + unit];
+      }
+    }
+    if (t < 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (live[i]) a.dh_init[((long long)layer * B + (m0 + 4 * q + i)) * H + unit] = carry[i];
+      break;
+    }
+    if (rg_live) {
+      f32x4 g0, g1, g2, g3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float d = (has_up ? dy[i] : cur.dyt[i]) + carry[i];
+        const float dn = d * (1.0f - cur.z[i]);
+        const float dz = d * (cur.hprev[i] - cur.nv[i]);
+        const float dn_pre = dn * (1.0f - cur.nv[i] * cur.nv[i]);
+        const float dz_pre = dz * cur.z[i] * (1.0f - cur.z[i]);
+        const float dr_pre = dn_pre * cur.ghn[i] * cur.r[i] * (1.0f - cur.r[i]);
+        g0[i] = dr_pre; g1[i] = dz_pre; g2[i] = dn_pre * cur.r[i]; g3[i] = dn_pre;
+        dzterm[i] = d * cur.z[i];
+      }
+      tile_put(tiles + 0 * WTILE_F, g0, j, q); tile_put(tiles + 1 * WTILE_F, g1, j, q);
+      tile_put(tiles + 2 * WTILE_F, g2, j, q); tile_put(tiles + 3 * WTILE_F, g3, j, q);
+      // lanes 0-31 publish arrays 0 and 2, lanes 32-63 arrays 1 and 3
+      const int a0 = lane >> 5;
+      const u32x4 f0 = tile_frag(tiles + a0 * WTILE_F, lane), f1 = tile_frag(tiles + (a0 + 2) * WTILE_F, lane);
+      const int n = T - 1 - t;
+      const unsigned base = (unsigned)(n % KS_D) * slot_bytes + rg_off + my_frag;
+      const unsigned arm = (unsigned)((n + 2) % KS_D) * slot_bytes + rg_off + my_frag;
+      store_u4<0>(ring, base + (unsigned)a0 * arr_bytes, ks_clamp(f0));
+      store_u4<0>(ring, base + (unsigned)(a0 + 2) * arr_bytes, ks_clamp(f1));
+      store_u4<0>(ring, arm + (unsigned)a0 * arr_bytes, ks_sentinel());
+      store_u4<0>(ring, arm + (unsigned)(a0 + 2) * arr_bytes, ks_sentinel());
+      WSTAMP(2)
+      if (feeds) {
+        const unsigned bx = (unsigned)t * slot_bytes + rg_off + my_frag;
+        store_u4<16>(ringx, bx + (unsigned)a0 * arr_bytes, f0);
+        store_u4<16>(ringx, bx + (unsigned)(a0 + 2) * arr_bytes, f1);
+        pending_x = t;
+      }
+      if (rrow < B) {
+        float* dgl = a.dG[layer] + (long long)t * B * 4 * H;
+        const unsigned off = (unsigned)(((long long)rrow * 4 * H + u0 + 4 * kg) * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store_f4<16>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
+      }
+      WSTAMP(4)
+    }
+    if (has_up && t > 0) project(t - 1);
+    cur = nxt;
+  }
+  wave_drain();
+  if (pending_x >= 0) wave_bump<false>(cnt_x + pending_x, lane);
+#ifdef B2T_WAVE_TIMING
+  if (k == 0 && wave == 0 && lane == 0 && a.timing)
+    for (int i = 0; i < 8; ++i) a.timing[layer * 8 + i] = (unsigned)(tacc[i] / (unsigned long long)T);
+#endif
+}
+
+// arms the own-recurrence rings (KS_D slots each, all ones) and zeroes nothing else: one launch for all layers
+struct KsArmArgs { char* ring[B2T_MAX_LAYERS]; unsigned vec16; };      // vec16: 16-byte words per ring
+__global__ void ks_arm_kernel(const KsArmArgs a) {
+  u32x4* p = reinterpret_cast<u32x4*>(a.ring[blockIdx.y]);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < a.vec16; i += gridDim.x * blockDim.x) p[i] = ks_sentinel();
+}

@@ -136,8 +136,21 @@ def _run(L, T, B, H, p, seed, with_dhl=True, elem0=0):
 
 
 @pytest.mark.parametrize("L,T,B,H,p", [(1, 5, 16, 32, 0.0), (2, 7, 5, 48, 0.0), (3, 9, 17, 80, 0.0), (3, 9, 17, 80, 0.3), (5, 12, 64, 128, 0.4),
-                                       (5, 10, 64, 512, 0.0), (5, 6, 40, 768, 0.4), (2, 40, 33, 256, 0.2)])
+                                       (5, 10, 64, 512, 0.0), (5, 6, 40, 768, 0.4), (2, 40, 33, 256, 0.2),
+                                       # the K-split form (H % 128 == 0, local placement): fewer steps than its ring is deep, one / two / three
+                                       # row groups (a workgroup's second row group missing), every K-quarter length
+                                       (3, 3, 20, 384, 0.3), (4, 30, 16, 512, 0.0), (5, 25, 64, 512, 0.4), (2, 19, 48, 128, 0.0)])
 def test_wavefront_against_the_bf16_operand_recurrences(L, T, B, H, p):
+    _check_wavefront(L, T, B, H, p)
+
+
+@pytest.mark.parametrize("L,T,B,H,p", [(5, 10, 64, 512, 0.4), (2, 40, 33, 256, 0.2)])
+def test_wavefront_16_unit_form_where_the_k_split_form_would_run(monkeypatch, L, T, B, H, p):
+    monkeypatch.setenv("B2T_WAVE_KS", "0")       # (read per call)
+    _check_wavefront(L, T, B, H, p)
+
+
+def _check_wavefront(L, T, B, H, p):
     (outs, outd, res, dG_ref, dh_ref), got = _run(L, T, B, H, p, seed=L * 1000 + H + B)
     for l in range(L):
         o = got["out"][l].cpu().numpy()
