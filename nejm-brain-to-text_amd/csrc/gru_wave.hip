@@ -825,10 +825,11 @@ bool gru_wave_rgf(int H) {
   return !(e && atoi(e) == 0) && H % 64 == 0 && H <= 512;
 }
 // the K-split form (gru_wave_ks.h): local placement, H % 128 == 0, H <= 512, a layer's workgroups fit one XCD; B2T_WAVE_KS=0 (read per call): off
-bool gru_wave_ks(int L, int B, int H) {
+bool gru_wave_ks(int L, int T, int B, int H) {
   const char* e = getenv("B2T_WAVE_KS");
   if (e && atoi(e) == 0) return false;
   const int nrh = ((B + 15) / 16 + 1) / 2;
+  if ((unsigned long long)T * B * 4 * H * sizeof(float) >= (1ull << 31)) return false;      // 32-bit offsets into the saved gates
   return gru_wave_local(L, H) && H % 128 == 0 && H <= 512 && nrh * (H / 32) <= 32;
 }
 static size_t ks_lds_bytes(bool backward) { return (size_t)2 * 4 * (backward ? 4 : 12) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
@@ -868,7 +869,7 @@ int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
   a.tickets = a.cnt; a.cnt = a.cnt + 16;
   int rc = check_hip(hipMemsetAsync(a.tickets, 0, gru_wave_cnt_words_fwd(a.L, a.T, a.B) * sizeof(unsigned), s), "gru_wave_fwd: counters");
   if (rc) return rc;
-  if (gru_wave_ks(a.L, a.B, a.H)) {
+  if (gru_wave_ks(a.L, a.T, a.B, a.H)) {
     rc = ks_arm(a.ring, a.L, (size_t)((a.B + 15) / 16) * (a.H / 32) * 1024, s);
     if (rc) return rc;
     switch (a.H / 128) {
@@ -919,7 +920,7 @@ int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   int rc = 0;
   if (!(a_in.flags & 2)) { rc = gru_wave_bwd_clear(a.cnt, a.L, a.T, a.B, s); if (rc) return rc; }   // (bit 1: the caller cleared them, gated consumers are already waiting)
   a.tickets = a.cnt; a.prog = a_in.prog ? a.cnt + 16 : nullptr; a.cnt = a.cnt + 16 + 64;
-  if (gru_wave_ks(a.L, a.B, a.H)) {
+  if (gru_wave_ks(a.L, a.T, a.B, a.H)) {
     rc = ks_arm(a.ring, a.L, (size_t)((a.B + 15) / 16) * 4 * (a.H / 32) * 1024, s);
     if (rc) return rc;
     switch (a.H / 128) {

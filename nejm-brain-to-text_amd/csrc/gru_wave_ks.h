@@ -32,6 +32,27 @@ __device__ __forceinline__ unsigned ks_max(unsigned m, u32x4 v) {
   const unsigned c = a > b ? a : b;
   return m > c ? m : c;
 }
+// ring accesses with the wave-uniform part of the offset (slot, array) in the instruction's SCALAR offset: the per-lane part is then
+// loop-invariant and the fragment index folds into the immediate -- one address register per stream instead of one per load
+// (added to the per-lane offset, the slot base made every load's address its own VGPR: 56 of them in the backward kernel)
+template <int AUX>
+__device__ __forceinline__ u32x4 ks_load(const char* base_uniform, unsigned voff, unsigned soff) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base_uniform), 0, 0x7fffffff, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void ks_store(char* base_uniform, unsigned voff, unsigned soff, u32x4 v) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, AUX);
+}
+// one float through a buffer descriptor: per-lane byte offset (a lane whose row does not exist passes KS_DEAD: out of range, reads 0 --
+// no branch around the load) + a wave-uniform scalar offset.  Tensors below 2 GB (gru_wave_ks checks).
+constexpr unsigned KS_DEAD = 0x80000000u;
+template <int AUX>
+__device__ __forceinline__ float ks_ldf(const float* base_uniform, unsigned voff, unsigned soff) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base_uniform), 0, 0x7fffffff, 0x00020000);
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, AUX));
+}
 __device__ __forceinline__ u32x4 ks_sentinel() { return u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; }
 
 // both row groups' counters of the neighbouring layer's ring slot: even lanes look at the first, odd lanes at the second
@@ -48,6 +69,11 @@ __device__ __forceinline__ void ks_wait2(const unsigned* c0, const unsigned* c1,
     __builtin_amdgcn_s_sleep(1);
   }
 }
+
+// Workgroup barrier for the partial tiles: LDS writes done (lgkmcnt), NOT the vector memory queue -- __syncthreads() also waits for
+// vmcnt(0), i.e. for every fp32 store (written through: a fabric round trip) and every HBM prefetch in flight: 1-2 k cycles per
+// barrier, two barriers per step (NOTES.md R6.2)
+__device__ __forceinline__ void ks_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // sum of the four waves' partial tiles `tile` (of NT per wave) for this lane: C layout in, C layout out
 template <int NT>
@@ -171,38 +197,63 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
           const f32x4 c = acc[r][u2][g];
           part[(wave * NT + (r * 2 + u2) * 3 + g) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
         }
-    __syncthreads();
+    ks_barrier();
 #pragma unroll
     for (int g = 0; g < 3; ++g) out[g] = ks_reduce<NT>(part, (rgl * 2 + us) * 3 + g, lane);
   };
-  // gi of step t from layer - 1's (dropped) h_t = slot t + 1 of its written-through ring
-  auto project = [&](int t) {
-    ks_wait2(cnt_in0 + (t + 1), cnt_in1 + (t + 1), (unsigned)G, err, lane);
-    WSTAMP(5)
-    u32x4 v[2][NPQ];
-    const unsigned base = (unsigned)(t + 1) * slot_bytes;
+  // gi of step t from layer - 1's (dropped) h_t = slot t + 1 of its written-through ring.  Split-phase: the slot's counters are
+  // REQUESTED two steps ahead and looked at one step ahead (right after the own poll, so that neither request sits in front of a
+  // poll's loads for long: vector memory returns in order); if they were complete, the fragments are requested then and there and
+  // are in registers when the projection starts.  Otherwise (the layer below is less than two steps ahead) the blocking path.
+  unsigned csnap = 0u;
+  auto project = [&](int t, bool loaded, u32x4 (&xq)[2][NPQ]) {
+    if (!loaded) {
+      ks_wait2(cnt_in0 + (t + 1), cnt_in1 + (t + 1), (unsigned)G, err, lane);
+      const unsigned base = (unsigned)(t + 1) * slot_bytes;
 #pragma unroll
-    for (int i = 0; i < NPQ; ++i) {
-      v[0][i] = load_u4<0>(ring_in, base + in_off0 + (unsigned)i * 1024u);
-      v[1][i] = load_u4<0>(ring_in, base + in_off1 + (unsigned)i * 1024u);
+      for (int i = 0; i < NPQ; ++i) {
+        xq[0][i] = ks_load<0>(ring_in, in_off0 + (unsigned)i * 1024u, base);
+        xq[1][i] = ks_load<0>(ring_in, in_off1 + (unsigned)i * 1024u, base);
+      }
     }
+    WSTAMP(5)
     f32x4 o[3];
-    contract(v, w2, part_q, o);
+    contract(xq, w2, part_q, o);
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i) gi[g][i] = o[g][i] + bi[g];
+#ifdef B2T_WAVE_TIMING
+    asm volatile("s_nop 0" :: "v"(gi[0][0]), "v"(gi[1][0]), "v"(gi[2][0]));
+#endif
     WSTAMP(6)
   };
+  // after the own poll of step t: fragments of slot t + 2 if last step's look at its counters found them complete; request the counters of slot t + 3
+  auto prefetch_in = [&](int t, u32x4 (&xq)[2][NPQ]) -> bool {
+    bool loaded = false;
+    if (t + 1 < T && t > 0 && __all(csnap >= (unsigned)G)) {
+      const unsigned base = (unsigned)(t + 2) * slot_bytes;
+#pragma unroll
+      for (int i = 0; i < NPQ; ++i) {
+        xq[0][i] = ks_load<0>(ring_in, in_off0 + (unsigned)i * 1024u, base);
+        xq[1][i] = ks_load<0>(ring_in, in_off1 + (unsigned)i * 1024u, base);
+      }
+      loaded = true;
+    }
+    if (t + 2 < T) csnap = __hip_atomic_load(((lane & 1) ? cnt_in1 : cnt_in0) + (t + 3), RLX_AGENT);
+    return loaded;
+  };
+  unsigned vo_gi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vo_gi[i] = live[i] ? ((unsigned)(m0 + 4 * q + i) * 3u * (unsigned)H + (unsigned)unit) * 4u : KS_DEAD;
+  const unsigned gi_step = (unsigned)B * 3u * (unsigned)H * 4u;
   auto load_gi0 = [&](int t, f32x4 (&dst)[3]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float* g3 = a.gi0 + ((long long)t * B + (live[i] ? m0 + 4 * q + i : 0)) * 3 * H + unit;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int g = 0; g < 3; ++g) dst[g][i] = live[i] ? __builtin_nontemporal_load(g3 + (long long)g * H) : 0.f;
-    }
+      for (int g = 0; g < 3; ++g) dst[g][i] = ks_ldf<2>(a.gi0, vo_gi[i], (unsigned)t * gi_step + (unsigned)g * (unsigned)H * 4u);
   };
-  if (layer > 0) project(0); else load_gi0(0, gi);
+  if (layer > 0) { u32x4 xq[2][NPQ]; project(0, false, xq); } else load_gi0(0, gi);
 
   for (int t = 0; t < T; ++t) {
     // h_{t-1} of both row groups, this wave's K quarter: load until no dword is the sentinel
@@ -213,8 +264,8 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       for (;;) {
 #pragma unroll
         for (int i = 0; i < NPQ; ++i) {
-          v[0][i] = load_u4<16>(ring, base + in_off0 + (unsigned)i * 1024u);
-          v[1][i] = load_u4<16>(ring, base + in_off1 + (unsigned)i * 1024u);
+          v[0][i] = ks_load<16>(ring, in_off0 + (unsigned)i * 1024u, base);
+          v[1][i] = ks_load<16>(ring, in_off1 + (unsigned)i * 1024u, base);
         }
         unsigned m = 0u;
 #pragma unroll
@@ -229,9 +280,15 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
     wave_drain();      // (already empty: the loads above were waited for -- and with them every earlier store of this wave)
     if (pending_x >= 0) { wave_bump<false>(cnt_x + pending_x, lane); pending_x = -1; }
     WSTAMP(0)   // the peers' h_{t-1} is here
-    if (layer == 0 && t + 1 < T) load_gi0(t + 1, gin);     // (lands during the product)
+    u32x4 xq[2][NPQ];
+    bool in_loaded = false;
+    if (layer == 0) { if (t + 1 < T) load_gi0(t + 1, gin); }     // (lands during the product)
+    else in_loaded = prefetch_in(t, xq);
     f32x4 gh[3];
     contract(v, w, (layer == 0 && (t & 1)) ? part_q : part_p, gh);
+#ifdef B2T_WAVE_TIMING
+    asm volatile("s_nop 0" :: "v"(gh[0][0]), "v"(gh[1][0]), "v"(gh[2][0]));
+#endif
     WSTAMP(1)   // recurrent product + reduction
     if (rg_live) {
       f32x4 sr, sz, sn, sg, h;
@@ -249,8 +306,8 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       tile_put(tiles, h, j, q);
       const u32x4 f = tile_frag(tiles, lane);
       if (lane < 32) {
-        store_u4<0>(ring, (unsigned)((t + 1) % KS_D) * slot_bytes + rg_off + my_frag, ks_clamp(f));
-        store_u4<0>(ring, (unsigned)((t + 3) % KS_D) * slot_bytes + rg_off + my_frag, ks_sentinel());
+        ks_store<0>(ring, rg_off + my_frag, (unsigned)((t + 1) % KS_D) * slot_bytes, ks_clamp(f));
+        ks_store<0>(ring, rg_off + my_frag, (unsigned)((t + 3) % KS_D) * slot_bytes, ks_sentinel());
       }
       WSTAMP(2)   // gates + publish
       const int rrow = m0 + (lane & 15), kg = lane >> 4;
@@ -268,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
           fx = tile_frag(td, lane);
           if (rrow < B) *reinterpret_cast<float4*>(a.outd[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hd;
         }
-        if (lane < 32) store_u4<16>(ringx, (unsigned)(t + 1) * slot_bytes + rg_off + my_frag, fx);
+        if (lane < 32) ks_store<16>(ringx, rg_off + my_frag, (unsigned)(t + 1) * slot_bytes, fx);
         pending_x = t + 1;
       }
       if (rrow < B) *reinterpret_cast<float4*>(a.out[layer] + ((long long)t * B + rrow) * H + u0 + 4 * kg) = hv;
@@ -287,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       }
       WSTAMP(4)   // neighbour's ring, fp32 stores
     }
-    if (layer > 0) { if (t + 1 < T) project(t + 1); }
+    if (layer > 0) { if (t + 1 < T) project(t + 1, in_loaded, xq); }
     else {
 #pragma unroll
       for (int g = 0; g < 3; ++g) gi[g] = gin[g];
@@ -394,25 +451,35 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
         const f32x4 c = acc[r][u2];
         part[(wave * NT + r * 2 + u2) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
       }
-    __syncthreads();
+    ks_barrier();
     return ks_reduce<NT>(part, rgl * 2 + us, lane);
   };
   f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
-  // dY[layer]_t = dGi[layer + 1]_t . W_ih[layer + 1][:, units] (arrays dr, dz, dn of the ring above), then the dropout mask
-  auto project = [&](int t) {
-    ks_wait2(cnt_up0 + t, cnt_up1 + t, (unsigned)G, err, lane);
-    WSTAMP(5)
-    u32x4 v[2][3][NPQ];
+  // dY[layer]_t = dGi[layer + 1]_t . W_ih[layer + 1][:, units] (arrays dr, dz, dn of the ring above), then the dropout mask.
+  // Split-phase like the forward pass's: the slot's counters are requested one step ahead and looked at after the own poll; if they
+  // were complete, the fragments are requested as soon as the own product's MFMAs have released the operand registers (they land
+  // during the gates / publish / fp32 stores).  Otherwise the blocking path.
+  // (the fragments are an argument, not a captured variable: declared per step, they are not live across the loop's back edge -- a
+  // captured array was, next to the own product's operands: 32-44 registers spilled)
+  unsigned csnap = 0u;
+  auto load_up = [&](int t, u32x4 (&xv)[2][3][NPQ]) {
     const unsigned base = (unsigned)t * slot_bytes;
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int i = 0; i < NPQ; ++i) {
-        const unsigned ao = (unsigned)(g == 2 ? 3 : g) * arr_bytes + (unsigned)i * 1024u;
-        v[0][g][i] = load_u4<0>(ring_up, base + in_off0 + ao);
-        v[1][g][i] = load_u4<0>(ring_up, base + in_off1 + ao);
+        const unsigned ao = (unsigned)(g == 2 ? 3 : g) * arr_bytes;
+        xv[0][g][i] = ks_load<0>(ring_up, in_off0 + (unsigned)i * 1024u, base + ao);
+        xv[1][g][i] = ks_load<0>(ring_up, in_off1 + (unsigned)i * 1024u, base + ao);
       }
-    f32x4 acc = contract(v, w2, part_q);
+  };
+  auto project = [&](int t, bool loaded, u32x4 (&xv)[2][3][NPQ]) {
+    if (!loaded) {
+      ks_wait2(cnt_up0 + t, cnt_up1 + t, (unsigned)G, err, lane);
+      load_up(t, xv);
+    }
+    WSTAMP(5)
+    f32x4 acc = contract(xv, w2, part_q);
     if (DROP) {
       float* td = tiles;
       tile_put(td, acc, j, q);
@@ -432,45 +499,74 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   // the step's elementwise operands (saved gates, h_{t-1}, the top layer's dY) come from memory: requested one step ahead, right
   // after the poll (behind it they would sit in front of the NEXT poll's loads: vector memory returns in order)
   struct Elem { f32x4 r, z, nv, ghn, hprev, dyt; };
+  unsigned vo_res[4], vo_out[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned row = (unsigned)(m0 + 4 * q + i);
+    vo_res[i] = live[i] ? (row * 4u * (unsigned)H + (unsigned)unit) * 4u : KS_DEAD;
+    vo_out[i] = live[i] ? (row * (unsigned)H + (unsigned)unit) * 4u : KS_DEAD;
+  }
+  const unsigned res_step = (unsigned)B * 4u * (unsigned)H * 4u, out_step = (unsigned)B * (unsigned)H * 4u, hb = (unsigned)H * 4u;
   auto fetch = [&](int t, Elem& e) {
+    if (t < 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e.r[i] = e.z[i] = e.nv[i] = e.ghn[i] = e.hprev[i] = e.dyt[i] = 0.f;
+      return;
+    }
+    const unsigned so = (unsigned)t * res_step;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      e.r[i] = e.z[i] = e.nv[i] = e.ghn[i] = e.hprev[i] = e.dyt[i] = 0.f;
-      if (live[i] && t >= 0) {
-        const int row = m0 + 4 * q + i;
-        const float* rs = a.reserve[layer] + ((long long)t * B + row) * 4 * H + unit;
-        e.r[i] = __builtin_nontemporal_load(rs); e.z[i] = __builtin_nontemporal_load(rs + H);
-        e.nv[i] = __builtin_nontemporal_load(rs + 2 * H); e.ghn[i] = __builtin_nontemporal_load(rs + 3 * H);
-        e.hprev[i] = t > 0 ? a.out[layer][((long long)(t - 1) * B + row) * H + unit] : a.h_init[layer][(long long)row * H + unit];
-        if (!has_up) e.dyt[i] = __builtin_nontemporal_load(a.dY_top + ((long long)t * B + row) * H + unit);
-      }
+      e.r[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so); e.z[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so + hb);
+      e.nv[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so + 2u * hb); e.ghn[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so + 3u * hb);
+      e.hprev[i] = t > 0 ? ks_ldf<0>(a.out[layer], vo_out[i], (unsigned)(t - 1) * out_step) : ks_ldf<0>(a.h_init[layer], vo_out[i], 0u);
+      e.dyt[i] = has_up ? 0.f : ks_ldf<2>(a.dY_top, vo_out[i], (unsigned)t * out_step);
     }
   };
   Elem cur, nxt;
   fetch(T - 1, cur);
-  if (has_up) project(T - 1);
+  if (has_up) { u32x4 xv[2][3][NPQ]; project(T - 1, false, xv); }
   f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int t = T - 1; t >= -1; --t) {
     f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 xv[2][3][NPQ];
+    bool up_loaded = false;
     if (t < T - 1) {
       // dG_{t+1} = index T - 2 - t: arrays dr, dz, dn r of both row groups, this wave's K quarter
       u32x4 v[2][3][NPQ];
       {
+        // first the array a producer stores LAST (dn r: a third of the bytes per look), then the other two -- every dword of all three
+        // is checked (visibility order between a wave's stores is likely, not promised)
         const unsigned base = (unsigned)((T - 2 - t) % KS_D) * slot_bytes;
         unsigned spins = 0;
         for (;;) {
 #pragma unroll
-          for (int g = 0; g < 3; ++g)
+          for (int i = 0; i < NPQ; ++i) {
+            const unsigned ao = 2u * arr_bytes;
+            v[0][2][i] = ks_load<16>(ring, in_off0 + (unsigned)i * 1024u, base + ao);
+            v[1][2][i] = ks_load<16>(ring, in_off1 + (unsigned)i * 1024u, base + ao);
+          }
+          unsigned m = 0u;
+#pragma unroll
+          for (int i = 0; i < NPQ; ++i) { m = ks_max(m, v[0][2][i]); m = ks_max(m, v[1][2][i]); }
+          if (!__any(m > KS_MAXDATA)) break;
+          if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+            if (spins > (SPIN_LIMIT >> 2)) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+          }
+        }
+        for (;;) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int i = 0; i < NPQ; ++i) {
-              const unsigned ao = (unsigned)g * arr_bytes + (unsigned)i * 1024u;
-              v[0][g][i] = load_u4<16>(ring, base + in_off0 + ao);
-              v[1][g][i] = load_u4<16>(ring, base + in_off1 + ao);
+              const unsigned ao = (unsigned)g * arr_bytes;
+              v[0][g][i] = ks_load<16>(ring, in_off0 + (unsigned)i * 1024u, base + ao);
+              v[1][g][i] = ks_load<16>(ring, in_off1 + (unsigned)i * 1024u, base + ao);
             }
           unsigned m = 0u;
 #pragma unroll
-          for (int g = 0; g < 3; ++g)
+          for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int i = 0; i < NPQ; ++i) { m = ks_max(m, v[0][g][i]); m = ks_max(m, v[1][g][i]); }
           if (!__any(m > KS_MAXDATA)) break;
@@ -486,13 +582,22 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       if (prog) wave_bump<false>(prog, lane);
       WSTAMP(0)
       fetch(t - 1, nxt);
-      const f32x4 acc = contract(v, w, part_p);
+      const bool up_ready = has_up && t > 0 && t < T - 2 && __all(csnap >= (unsigned)G);     // (csnap: slot t - 1, requested one step ago)
+      if (has_up && t > 1) csnap = __hip_atomic_load(((lane & 1) ? cnt_up1 : cnt_up0) + (t - 2), RLX_AGENT);
+      // (the top layer has no projection -- no second barrier between two products -- so it alternates the two partial buffers:
+      // a wave may start writing step t - 1's partials while a slower one still reads step t's)
+      const f32x4 acc = contract(v, w, (!has_up && (t & 1)) ? part_q : part_p);
+      if (up_ready) { load_up(t - 1, xv); up_loaded = true; }
+#ifdef B2T_WAVE_TIMING
+      asm volatile("s_nop 0" :: "v"(acc[0]));
+#endif
       WSTAMP(1)
 #pragma unroll
       for (int i = 0; i < 4; ++i) carry[i] = acc[i] + dzterm[i];
     } else {
       wave_drain();
       if (prog) wave_bump<false>(prog, lane);
+      ks_barrier();      // (no product this step: keeps the two projections on either side from meeting in their partial buffer)
       fetch(t - 1, nxt);
       if (a.dh_last) {
 #pragma unroll
@@ -523,17 +628,17 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       const int a0 = lane >> 5;
       const u32x4 f0 = tile_frag(tiles + a0 * WTILE_F, lane), f1 = tile_frag(tiles + (a0 + 2) * WTILE_F, lane);
       const int n = T - 1 - t;
-      const unsigned base = (unsigned)(n % KS_D) * slot_bytes + rg_off + my_frag;
-      const unsigned arm = (unsigned)((n + 2) % KS_D) * slot_bytes + rg_off + my_frag;
-      store_u4<0>(ring, base + (unsigned)a0 * arr_bytes, ks_clamp(f0));
-      store_u4<0>(ring, base + (unsigned)(a0 + 2) * arr_bytes, ks_clamp(f1));
-      store_u4<0>(ring, arm + (unsigned)a0 * arr_bytes, ks_sentinel());
-      store_u4<0>(ring, arm + (unsigned)(a0 + 2) * arr_bytes, ks_sentinel());
+      const unsigned base = (unsigned)(n % KS_D) * slot_bytes, arm = (unsigned)((n + 2) % KS_D) * slot_bytes;
+      const unsigned vo = rg_off + my_frag + (unsigned)a0 * arr_bytes;      // (per lane, loop-invariant)
+      ks_store<0>(ring, vo, base, ks_clamp(f0));
+      ks_store<0>(ring, vo, base + 2u * arr_bytes, ks_clamp(f1));
+      ks_store<0>(ring, vo, arm, ks_sentinel());
+      ks_store<0>(ring, vo, arm + 2u * arr_bytes, ks_sentinel());
       WSTAMP(2)
       if (feeds) {
-        const unsigned bx = (unsigned)t * slot_bytes + rg_off + my_frag;
-        store_u4<16>(ringx, bx + (unsigned)a0 * arr_bytes, f0);
-        store_u4<16>(ringx, bx + (unsigned)(a0 + 2) * arr_bytes, f1);
+        const unsigned bx = (unsigned)t * slot_bytes;
+        ks_store<16>(ringx, vo, bx, f0);
+        ks_store<16>(ringx, vo, bx + 2u * arr_bytes, f1);
         pending_x = t;
       }
       if (rrow < B) {
@@ -544,7 +649,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       }
       WSTAMP(4)
     }
-    if (has_up && t > 0) project(t - 1);
+    if (has_up && t > 0) project(t - 1, up_loaded, xv);
     cur = nxt;
   }
   wave_drain();
