@@ -222,7 +222,7 @@ typedef struct b2t_wave_t {
   const float* w_hh_t[B2T_MAX_LAYERS_]; const float* w_ih_t[B2T_MAX_LAYERS_]; float* dG[B2T_MAX_LAYERS_];
   float drop_p; uint64_t seed[B2T_MAX_LAYERS_]; long long elem0;
 } b2t_wave_t;
-int b2t_gru_wave_supported(int L, int T, int B, int H);
+int b2t_gru_wave_supported(int L, int T, int B, int H);   /* 0: not held; 1: held (16-unit workgroups); 2: held in the K-split form (H % 128 == 0, H <= 512, a layer's workgroups on one XCD): both passes pay there, the forward one only otherwise */
 size_t b2t_gru_wave_ws_bytes(int L, int T, int B, int H, int backward, int dropout);
 int b2t_gru_wave_fwd_f32(const b2t_wave_t* d, void* ws, unsigned* err_word, void* stream);
 int b2t_gru_wave_bwd_f32(const b2t_wave_t* d, void* ws, unsigned* err_word, void* stream);

@@ -294,7 +294,7 @@ WAVE = {"on": os.environ.get("B2T_WAVE", "1") not in ("0", "", "false", "False")
         # time chunks of the wavefront passes (forward, backward): a launch per chunk, one behind the other; what overlaps is the work
         # NEXT to the sweeps on the CUs they leave free -- layer 0's projection of the next chunk, the weight gradients of the chunk
         # before (B2T_WAVE_CHUNKS="f,b", read per pass)
-        "chunks": (1, 1), "dirs": "f"}
+        "chunks": (1, 1), "dirs": "auto"}
 # the exact-fp32 backward sweeps as paired sweeps (B2T_BWD_PAIRED=1; H % 32 == 0, H <= 512, B <= 64 -- other shapes ignore the flag)
 PAIRED_BWD = {"on": os.environ.get("B2T_BWD_PAIRED", "0") not in ("0", "", "false", "False")}
 # which sweeps (exact fp32 or bf16 operands, H <= 512) hand off through one XCD's L2 ("" none, "f", "b", "fb"; B2T_GRU_LOCAL).  Measured at C2: memory-side
@@ -654,8 +654,8 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
     ps.chunks_bwd = time_chunks_bwd(Tp, B, H, AMP["on"], ps.chunks)
     ps.wgrad_chunk_mask = PIPELINE["wgrad_chunk_mask"]
     # (not for streaming-sized calls: a launch loads 192-288 registers of weights per wave before its first step)
-    if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and Tp >= 16 and \
-            lib.b2t_gru_wave_supported(L, Tp, B, H):
+    wave_form = lib.b2t_gru_wave_supported(L, Tp, B, H) if AMP["on"] and mode == 1 else 0     # 0 no, 1 the 16-unit form, 2 the K-split form
+    if AMP["on"] and AMP.get("sweeps", True) and mode == 1 and WAVE["on"] and os.environ.get("B2T_WAVE", "1") != "0" and Tp >= 16 and wave_form:
         wc = os.environ.get("B2T_WAVE_CHUNKS")
         # chunks (forward launches, backward consumer chunks): 1, 1 -- forward launches per chunk measured equal (C2: 8.98 / 9.01 /
         # 8.98 ms with 1 / 2 / 3), gated backward consumers worse with every chunk (NOTES.md R6.2)
@@ -664,7 +664,11 @@ def model_forward(dims: ModelDims, prm: Params, x: torch.Tensor, day_idx: torch.
         # 8.98 ms, shipped shape 5.61 -> 5.11); the backward one (8 us per step at C2, 10.4 at the shipped shape: three times the
         # forward's operand bytes per CU, and its weight gradients then run behind it instead of beside it) does not (9.98 / 5.29) --
         # so the default is "f" (B2T_WAVE_DIRS=fb / b: measurement knob; the backward kernel stays tested)
-        dirs = os.environ.get("B2T_WAVE_DIRS", WAVE.get("dirs", "f"))
+        # -- in the 16-unit form.  In the K-split form (H % 128 == 0, H <= 512: half the operand bytes per CU, data-polled hand-off)
+        # the backward wavefront wins as well (C2: 8.33 forward only, 8.05 both): "auto" = both passes there
+        dirs = os.environ.get("B2T_WAVE_DIRS", WAVE.get("dirs", "auto"))
+        if dirs == "auto":
+            dirs = "fb" if wave_form == 2 else "f"
         if "f" in dirs:
             ps.fwd_mode |= GRU_WAVE
             ps.chunks = max(1, min(cf, Tp // 16))

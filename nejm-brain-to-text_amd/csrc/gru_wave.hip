@@ -819,10 +819,12 @@ template <int NPV, bool DR, bool LC, bool RG = false> static int wave_launch_fwd
   hipLaunchKernelGGL((gru_wave_fwd_kernel<NPV, DR, LC, RG>), grid, dim3(256), lds, s, a);
   return 0;
 }
-// the row-group form serves H % 64 == 0, H <= 512 (both weight slices of a wave in registers); B2T_WAVE_RGF=0 (read per call): the fat form
+// the row-group form serves H % 64 == 0, H <= 256 (both weight slices of a wave in registers); B2T_WAVE_RGF=1 (read per call) selects it
+// (round 6, late: superseded by the K-split form and OFF unless B2T_WAVE_RGF=1; H <= 256 only -- at H = 512 both weight slices of a
+// wave plus the stream buffers do not fit 512 registers and the allocator spilled MFMA operand tuples: see gru_wave_ks.h)
 bool gru_wave_rgf(int H) {
   const char* e = getenv("B2T_WAVE_RGF");
-  return !(e && atoi(e) == 0) && H % 64 == 0 && H <= 512;
+  return e && atoi(e) != 0 && H % 64 == 0 && H <= 256;
 }
 // the K-split form (gru_wave_ks.h): local placement, H % 128 == 0, H <= 512, a layer's workgroups fit one XCD; B2T_WAVE_KS=0 (read per call): off
 bool gru_wave_ks(int L, int T, int B, int H) {
@@ -893,8 +895,10 @@ int gru_wave_fwd(const WaveFwdArgs& a_in, hipStream_t s) {
   } while (0)
   if (a.H <= 128) B2T_WAVE_FWD(4);
   else if (a.H <= 256) B2T_WAVE_FWD(8);
-  else if (a.H <= 512) B2T_WAVE_FWD(16);
-  else rc = drop ? wave_launch_fwd<24, true, false>(a, grid, lds, s) : wave_launch_fwd<24, false, false>(a, grid, lds, s);
+  else if (a.H <= 512) {
+    if (loc) rc = drop ? wave_launch_fwd<16, true, true>(a, grid, lds, s) : wave_launch_fwd<16, false, true>(a, grid, lds, s);
+    else rc = drop ? wave_launch_fwd<16, true, false>(a, grid, lds, s) : wave_launch_fwd<16, false, false>(a, grid, lds, s);
+  } else rc = drop ? wave_launch_fwd<24, true, false>(a, grid, lds, s) : wave_launch_fwd<24, false, false>(a, grid, lds, s);
 #undef B2T_WAVE_FWD
   if (rc) return rc;
   return check_hip(hipGetLastError(), "gru_wave_fwd");
@@ -945,8 +949,10 @@ int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   } while (0)
   if (a.H <= 128) B2T_WAVE_BWD(4);
   else if (a.H <= 256) B2T_WAVE_BWD(8);
-  else if (a.H <= 512) B2T_WAVE_BWD(16);
-  else rc = drop ? wave_launch_bwd<24, true, false>(a, grid, lds, s) : wave_launch_bwd<24, false, false>(a, grid, lds, s);
+  else if (a.H <= 512) {
+    if (loc) rc = drop ? wave_launch_bwd<16, true, true>(a, grid, lds, s) : wave_launch_bwd<16, false, true>(a, grid, lds, s);
+    else rc = drop ? wave_launch_bwd<16, true, false>(a, grid, lds, s) : wave_launch_bwd<16, false, false>(a, grid, lds, s);
+  } else rc = drop ? wave_launch_bwd<24, true, false>(a, grid, lds, s) : wave_launch_bwd<24, false, false>(a, grid, lds, s);
 #undef B2T_WAVE_BWD
   if (rc) return rc;
   return check_hip(hipGetLastError(), "gru_wave_bwd");
@@ -959,7 +965,9 @@ using namespace b2t;
 // ---- C ABI: the stack's sweeps as one launch per direction (include/b2t.h) --------------------------------------------------
 static size_t wave_align(size_t v) { return (v + 255) / 256 * 256; }
 
-extern "C" int b2t_gru_wave_supported(int L, int T, int B, int H) { return gru_wave_ok(L, T, B, H, nullptr) ? 1 : 0; }
+// 0: not held; 1: the 16-unit form; 2: the K-split form (gru_wave_ks.h: this device, this placement, B2T_WAVE_KS) -- callers use the
+// difference to decide whether the BACKWARD pass goes on the wavefront too (it pays in the K-split form only: NOTES.md R6.2)
+extern "C" int b2t_gru_wave_supported(int L, int T, int B, int H) { return !gru_wave_ok(L, T, B, H, nullptr) ? 0 : gru_wave_ks(L, T, B, H) ? 2 : 1; }
 
 extern "C" size_t b2t_gru_wave_ws_bytes(int L, int T, int B, int H, int backward, int dropout) {
   if (L < 1 || L > B2T_MAX_LAYERS || T < 1 || B < 1 || H < 16) return 0;

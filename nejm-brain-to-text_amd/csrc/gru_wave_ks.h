@@ -456,9 +456,11 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   };
   f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
   // dY[layer]_t = dGi[layer + 1]_t . W_ih[layer + 1][:, units] (arrays dr, dz, dn of the ring above), then the dropout mask.
-  // Split-phase like the forward pass's: the slot's counters are requested one step ahead and looked at after the own poll; if they
-  // were complete, the fragments are requested as soon as the own product's MFMAs have released the operand registers (they land
-  // during the gates / publish / fp32 stores).  Otherwise the blocking path.
+  // The slot's counters are requested one step ahead and looked at after the own poll (the request is then never in front of a
+  // poll's loads for long: vector memory returns in order): if they were complete the projection starts without a counter round trip
+  // (~1.9 k cycles, memory side).  The fragments themselves are NOT requested early here (the forward pass does): 96 more live
+  // registers next to the saved gates' double buffer spilled MFMA operand tuples, and the partial reloads of those were wrong
+  // (NOTES.md R6.2: every kernel of this file must compile to ScratchSize 0 -- tests/test_wave_build.py).
   // (the fragments are an argument, not a captured variable: declared per step, they are not live across the loop's back edge -- a
   // captured array was, next to the own product's operands: 32-44 registers spilled)
   unsigned csnap = 0u;
@@ -473,11 +475,10 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
         xv[1][g][i] = ks_load<0>(ring_up, in_off1 + (unsigned)i * 1024u, base + ao);
       }
   };
-  auto project = [&](int t, bool loaded, u32x4 (&xv)[2][3][NPQ]) {
-    if (!loaded) {
-      ks_wait2(cnt_up0 + t, cnt_up1 + t, (unsigned)G, err, lane);
-      load_up(t, xv);
-    }
+  auto project = [&](int t, bool known) {
+    if (!known) ks_wait2(cnt_up0 + t, cnt_up1 + t, (unsigned)G, err, lane);
+    u32x4 xv[2][3][NPQ];
+    load_up(t, xv);
     WSTAMP(5)
     f32x4 acc = contract(xv, w2, part_q);
     if (DROP) {
@@ -524,13 +525,12 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   };
   Elem cur, nxt;
   fetch(T - 1, cur);
-  if (has_up) { u32x4 xv[2][3][NPQ]; project(T - 1, false, xv); }
+  if (has_up) project(T - 1, false);
   f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int t = T - 1; t >= -1; --t) {
     f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 xv[2][3][NPQ];
-    bool up_loaded = false;
+    bool up_known = false;      // the counters of slot t - 1 were seen complete (last step's request)
     if (t < T - 1) {
       // dG_{t+1} = index T - 2 - t: arrays dr, dz, dn r of both row groups, this wave's K quarter
       u32x4 v[2][3][NPQ];
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       // (the top layer has no projection -- no second barrier between two products -- so it alternates the two partial buffers:
       // a wave may start writing step t - 1's partials while a slower one still reads step t's)
       const f32x4 acc = contract(v, w, (!has_up && (t & 1)) ? part_q : part_p);
-      if (up_ready) { load_up(t - 1, xv); up_loaded = true; }
+      up_known = up_ready;
 #ifdef B2T_WAVE_TIMING
       asm volatile("s_nop 0" :: "v"(acc[0]));
 #endif
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       }
       WSTAMP(4)
     }
-    if (has_up && t > 0) project(t - 1, up_loaded, xv);
+    if (has_up && t > 0) project(t - 1, up_known);
     cur = nxt;
   }
   wave_drain();
