@@ -1489,7 +1489,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
               a.reserve[k] = w.res[k]; a.dG[k] = w.dG[k]; a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
             }
             a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
-            a.flags = 2; a.prog = w.wv_cnt_b;     // counters cleared by wbclear; publish progress for the gated consumers
+            a.flags = 2 | (gated ? 4 : 0); a.prog = gated ? w.wv_cnt_b : nullptr;     // counters cleared by wbclear; gated consumers: dG written through + progress words
             a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;
             c.call(gru_wave_bwd(a, ss));
           });

@@ -730,8 +730,13 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     if (rrow < B) {
       float* dgl = a.dG[layer] + (long long)t * B * 4 * H;
       const unsigned off = (unsigned)(((long long)rrow * 4 * H + u0 + 4 * kg) * 4);
+      if (a.flags & 4) {      // (written through only for readers inside the sweep's lifetime: see gru_wave_ks.h)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) store_f4<16>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
+        for (int g = 0; g < 4; ++g) store_f4<16>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store_f4<0>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
+      }
     }
     WSTAMP(4)
     if (has_up && t > 0) project(t - 1);
@@ -916,7 +921,7 @@ int gru_wave_gate(unsigned* cnt, int layer, int t0, int T, int B, int H, unsigne
 
 int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   WaveBwdArgs a = a_in;
-  a.flags = wave_flags();
+  a.flags = wave_flags() | (a_in.flags & 4);     // bit 2: write dG through (consumers inside the sweep's lifetime: gated GEMMs)
   const char* why = nullptr;
   if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_bwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
   const bool drop = a.drop_p > 0.f && a.L > 1, loc = gru_wave_local(a.L, a.H);

@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
   float4* part_q = part_p + 4 * NT * 64;
   float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)2 * 4 * NT * 1024) + wave * (WAVE_TILES * WTILE_F);
 
-  // this wave's quarter of the K range of the workgroup's W_hh and W_ih slices, as B fragments in accumulation registers
+  // this wave's quarter of the K range of the workgroup's W_hh and W_ih slices, as B fragments in accumulation registers.
+  // The PROJECTION walks its fragments in an order rotated by the unit block: the workgroups of a row half all read the SAME
+  // fragments of the neighbouring layer's ring, from another XCD -- in the same order they asked for the same line at the same
+  // moment, every one of them sat out the fabric latency on every line (24 loads took 7-12 k cycles to issue in the backward
+  // pass: the CU's miss queue, ~64 lines, times ~2 us); rotated, a line's first reader fetches it and the others hit the L2.
+  const int rot = ub % NPQ;
   bf16x8 w[2][3][NPQ], w2[2][3][NPQ];
   {
     const float* whh = a.w_hh[layer];
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
         for (int g = 0; g < 3; ++g) {
           const long long row = (long long)g * H + 16 * (2 * ub + u2) + j;
           const float* s1 = whh + row * H + k0;
-          const float* s2 = wih + row * H + k0;
+          const float* s2 = wih + row * H + 32 * (NPQ * wave + (i + rot) % NPQ) + 8 * q;      // (slot i of the projection = pair (i + rot) % NPQ)
           w[u2][g][i] = cvt8(ld4(s1), ld4(s1 + 4));
           w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(ld4(s2), ld4(s2 + 4), layer > 0));
           asm volatile("" : "+a"(w[u2][g][i]));
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       const unsigned base = (unsigned)(t + 1) * slot_bytes;
 #pragma unroll
       for (int i = 0; i < NPQ; ++i) {
-        xq[0][i] = ks_load<0>(ring_in, in_off0 + (unsigned)i * 1024u, base);
-        xq[1][i] = ks_load<0>(ring_in, in_off1 + (unsigned)i * 1024u, base);
+        xq[0][i] = ks_load<0>(ring_in, in_off0, base + (unsigned)((i + rot) % NPQ) * 1024u);
+        xq[1][i] = ks_load<0>(ring_in, in_off1, base + (unsigned)((i + rot) % NPQ) * 1024u);
       }
     }
     WSTAMP(5)
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       const unsigned base = (unsigned)(t + 2) * slot_bytes;
 #pragma unroll
       for (int i = 0; i < NPQ; ++i) {
-        xq[0][i] = ks_load<0>(ring_in, in_off0 + (unsigned)i * 1024u, base);
-        xq[1][i] = ks_load<0>(ring_in, in_off1 + (unsigned)i * 1024u, base);
+        xq[0][i] = ks_load<0>(ring_in, in_off0, base + (unsigned)((i + rot) % NPQ) * 1024u);
+        xq[1][i] = ks_load<0>(ring_in, in_off1, base + (unsigned)((i + rot) % NPQ) * 1024u);
       }
       loaded = true;
     }
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   const bool has_up = layer + 1 < L;
 
   // this wave's K quarter (pairs [NPQ w, NPQ (w + 1)) of each of the three arrays) of the W_hh^T and W_ih[layer + 1]^T column slices
+  const int rot = ub % (3 * NPQ);
   bf16x8 w[2][3][NPQ], w2[2][3][NPQ];
   {
 #pragma unroll
@@ -392,8 +398,9 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
         const float* t2 = (has_up ? a.w_ih_t[layer + 1] : a.w_hh_t[layer]) + col * 3 * H;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
+          const int f = (g * NPQ + i + rot) % (3 * NPQ);      // slot (g, i) of the projection = fragment f of the K quarter (rotation: see the forward kernel)
           const float* s1 = t1 + (long long)g * H + k0;
-          const float* s2 = t2 + (long long)g * H + k0;
+          const float* s2 = t2 + (long long)(f / NPQ) * H + 32 * (NPQ * wave + f % NPQ) + 8 * q;
           w[u2][g][i] = cvt8(ld4(s1), ld4(s1 + 4));
           w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(ld4(s2), ld4(s2 + 4), has_up));
           asm volatile("" : "+a"(w[u2][g][i]));
@@ -464,22 +471,34 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   // (the fragments are an argument, not a captured variable: declared per step, they are not live across the loop's back edge -- a
   // captured array was, next to the own product's operands: 32-44 registers spilled)
   unsigned csnap = 0u;
+  unsigned poff[3][NPQ];      // (wave-uniform: scalar registers)
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i) {
+      const int f = (g * NPQ + i + rot) % (3 * NPQ), gf = f / NPQ;
+      poff[g][i] = (unsigned)(gf == 2 ? 3 : gf) * arr_bytes + (unsigned)(f % NPQ) * 1024u;
+    }
   auto load_up = [&](int t, u32x4 (&xv)[2][3][NPQ]) {
     const unsigned base = (unsigned)t * slot_bytes;
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int i = 0; i < NPQ; ++i) {
-        const unsigned ao = (unsigned)(g == 2 ? 3 : g) * arr_bytes;
-        xv[0][g][i] = ks_load<0>(ring_up, in_off0 + (unsigned)i * 1024u, base + ao);
-        xv[1][g][i] = ks_load<0>(ring_up, in_off1 + (unsigned)i * 1024u, base + ao);
+        xv[0][g][i] = ks_load<0>(ring_up, in_off0, base + poff[g][i]);
+        xv[1][g][i] = ks_load<0>(ring_up, in_off1, base + poff[g][i]);
       }
   };
   auto project = [&](int t, bool known) {
     if (!known) ks_wait2(cnt_up0 + t, cnt_up1 + t, (unsigned)G, err, lane);
+    WSTAMP(3)
     u32x4 xv[2][3][NPQ];
     load_up(t, xv);
     WSTAMP(5)
+#ifdef B2T_WAVE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSTAMP(7)
+#endif
     f32x4 acc = contract(xv, w2, part_q);
     if (DROP) {
       float* td = tiles;
@@ -644,8 +663,16 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       if (rrow < B) {
         float* dgl = a.dG[layer] + (long long)t * B * 4 * H;
         const unsigned off = (unsigned)(((long long)rrow * 4 * H + u0 + 4 * kg) * 4);
+        // written THROUGH only for readers inside the sweep's lifetime (gated GEMMs, flags bit 2): four 4 KB write-through stores per wave
+        // and step kept the wave's memory queue busy for ~13 k cycles -- the next load could not issue (NOTES.md R6.2); otherwise
+        // ordinary stores (the kernel's end makes them visible)
+        if (a.flags & 4) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) store_f4<16>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
+          for (int g = 0; g < 4; ++g) store_f4<16>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) store_f4<0>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
+        }
       }
       WSTAMP(4)
     }

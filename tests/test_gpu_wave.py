@@ -205,7 +205,7 @@ def test_wavefront_refuses_what_it_cannot_hold():
         assert lib.b2t_gru_wave_supported(5, 100, 64, 512) == 2
         assert lib.b2t_gru_wave_supported(5, 100, 64, 384) == 2
     assert lib.b2t_gru_wave_supported(5, 100, 64, 320) == 1          # H % 128
-    assert lib.b2t_gru_wave_supported(5, 3000, 64, 512) == 1         # saved gates >= 2 GB: 32-bit offsets of the K-split form
+    assert lib.b2t_gru_wave_supported(5, 5000, 64, 512) == 1         # saved gates >= 2 GB: 32-bit offsets of the K-split form
 
 
 def _step_args():

@@ -48,7 +48,7 @@ def probe(L, T, B, H, p, reps=5, seed=1, ws=None, timing=True):
         r[name + "_us"] = round(min(ts), 1); r[name + "_us_per_step"] = round(min(ts) / (T + L - 1), 3); r[name + "_all"] = [round(t, 1) for t in ts]
         if "wtiming" in os.environ.get("B2T_LIB", ""):     # cycles per step: wait own, loads + product, gates + tile, drain + counters, stores, wait neighbour, projection
             tm = err[16 + (0 if name == "fwd" else 64):][:8 * L].view(L, 8).cpu().numpy()
-            r[name + "_cycles_per_step_by_layer"] = [[int(v) for v in row[:7]] for row in tm]
+            r[name + "_cycles_per_step_by_layer"] = [[int(v) for v in row[:8]] for row in tm]
     assert all(torch.isfinite(o).all() for o in out + dG)
     print("R6WAVE " + json.dumps(r), flush=True)
 
@@ -62,6 +62,8 @@ for cfg in (() if os.environ.get('R6_PROBE_ONLY_TIMING') else ((5, 500, 64, 512,
         want, _ = probe(*cfg, seed=20 + rep, timing=False)
         ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
     print("R6STALE " + json.dumps(dict(cfg=cfg, sc1_loads=os.environ.get("B2T_WAVE_SC1_LOADS", "0"), local=os.environ.get("B2T_WAVE_LOCAL", "1"), second_pass_on_used_workspace_equals_fresh=ok)), flush=True)
-for cfg in ((5, 500, 64, 512, 0.0), (5, 500, 64, 512, 0.4), (1, 500, 64, 512, 0.0),
-            (5, 122, 64, 768, 0.4), (1, 122, 64, 768, 0.0)):
+CFGS = ((5, 500, 64, 512, 0.0), (5, 500, 64, 512, 0.4), (1, 500, 64, 512, 0.0), (5, 122, 64, 768, 0.4), (1, 122, 64, 768, 0.0))
+if os.environ.get("R6_PROBE_CFGS"):
+    CFGS = tuple(tuple(float(x) if "." in x else int(x) for x in c.split(",")) for c in os.environ["R6_PROBE_CFGS"].split(";"))
+for cfg in CFGS:
     probe(*cfg)
