@@ -1456,12 +1456,41 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // Weight gradients: per chunk (bit l of wgrad_chunk_mask: the first chunk swept overwrites, the others accumulate in sweep
   // order -- a dependency chain, so the sums do not depend on the schedule) or once per layer after its last chunk.
   int t_bs[MAXL][MAXC], t_dx[MAXL][MAXC], t_wg_last[MAXL];
-  int t_wb = -1, t_wclear = -1;   // wavefront: the one backward sweep task and the task that clears its counters
-  // gated consumers of the sweep's dG (wavefront, more than one consumer chunk): they wait on the DEVICE, so they must never sit in
-  // front of the sweep on its own queue (the caller's stream): queues 1..3 only
-  const bool gated = wave && nc > 1 && c.nq > 1;
+  int t_wb = -1, t_wclear = -1;   // wavefront, gated form: the one backward sweep task and the task that clears its counters
+  int t_wbc[MAXC];                // wavefront, launch-per-chunk form: the sweep task of each time chunk
+  for (int ci = 0; ci < MAXC; ++ci) t_wbc[ci] = -1;
+  // Wavefront with more than one time chunk, two forms.  DEFAULT: one sweep launch per chunk, last chunk first, each behind the one
+  // before (the state gradient crosses in w.carry); a chunk's consumers -- layer 0's input gradient, every layer's weight gradients --
+  // are ordinary successors of that launch and run BESIDE the next chunk's sweep on the CUs it leaves free.  B2T_WAVE_GATED=1: ONE
+  // launch for the whole sequence and consumers that wait on the DEVICE for the sweep's progress words (gru_wave_gate; dG written
+  // through): they must never sit in front of the sweep on its own queue (the caller's stream) -- queues 1..3 only.  Measured at C2
+  // with the K-split sweep (NOTES.md R6.2): gated 8.46 / 8.63 / 9.53 ms with 2 / 4 / 8 chunks against 7.63 with one.
+  static const bool gated_env = [] { const char* e = getenv("B2T_WAVE_GATED"); return e && atoi(e) != 0; }();
+  const bool gated = wave && nc > 1 && c.nq > 1 && gated_env;
+  const bool wave_chunked = wave && !gated;      // (nc == 1 included: one launch)
   const unsigned q_gated = gated ? (((1u << c.nq) - 1u) & ~1u) : Q_ANY;
   auto gate = [&](hipStream_t s, int l, int t0) { if (gated && t0 > 0 && !c.rc) c.call(gru_wave_gate(w.wv_cnt_b, l, t0, Tp, B, H, reinterpret_cast<unsigned*>(sync_of(0)), s)); };
+  // one sweep launch of the whole stack over the steps [t0, t0 + n)
+  auto wave_sweep = [&, dhidden](hipStream_t ss, int ci, int t0, int n, bool whole) {
+    if (c.rc) return;
+    Ctx::Scope sc(c, ss, 9, 2.0 * n * B * 3.0 * H * H * (2 * L - 1));
+    WaveBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.L = L; a.T = n; a.B = B; a.H = H; a.dY_top = w.dY[L - 1] + (long long)t0 * B * H;
+    const bool drop = p->rnn_drop > 0.f && L > 1;
+    for (int k = 0; k < L; ++k) {
+      a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k] + (long long)t0 * B * H; a.out[k] = w.out[k] + (long long)(1 + t0) * B * H;
+      a.reserve[k] = w.res[k] + (long long)t0 * B * 4 * H; a.dG[k] = w.dG[k] + (long long)t0 * B * 4 * H;
+      a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
+      a.dh_last[k] = (whole || ci == nc - 1) ? (dhidden ? dhidden + (size_t)k * B * H : nullptr) : w.carry[k] + (size_t)((ci + 1) % 2) * B * H;
+      a.dh_init[k] = (whole || ci == 0) ? w.dh_init + (size_t)k * B * H : w.carry[k] + (size_t)(ci % 2) * B * H;
+    }
+    a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
+    // gated: counters cleared by wbclear (the gates are already polling), dG written through + progress words
+    a.flags = whole && gated ? (2 | 4) : 0; a.prog = whole && gated ? w.wv_cnt_b : nullptr;
+    a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = (long long)t0 * B * H;
+    c.call(gru_wave_bwd(a, ss));
+  };
   for (int l = L - 1; l >= 0; --l) {
     // (wavefront: the weight gradients of a chunk run on the CUs the sweep of the chunk before leaves free -- always per chunk)
     const bool per_chunk = nc > 1 && (wave || ((p->wgrad_chunk_mask >> l) & 1));
@@ -1470,32 +1499,22 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     for (int ci = nc - 1; ci >= 0; --ci) {
       const int t0 = chunks[ci][0], t1 = chunks[ci][1], n = t1 - t0;
       if (wave) {
-        // ONE launch for the whole stack and the whole sequence, created with the top layer (the first iteration of the layer loop).
-        // The time chunks of this pass are the CONSUMERS' chunks: layer 0's input gradient and every layer's weight gradients run chunk
-        // by chunk BESIDE the sweep, on the CUs it leaves free (H = 512: 96 of 256), each behind a one-wave gate kernel that waits for
-        // the sweep's progress word of its layer (gru_wave_gate: dG[t0 .. T') written through and acknowledged).  Launches per chunk
-        // were measured instead and lost 0.15-0.25 ms per chunk to prologues and pipeline fill (NOTES.md R6.2).
+        // created with the top layer (the first iteration of the layer loop)
+        if (wave_chunked) {
+          if (l == L - 1) {
+            t_wbc[ci] = P.add("wbsweep", 60.f + (n + 2 * L) * est_step_us(1) * hs, Q_MAIN, {ci == nc - 1 ? t_top : t_wbc[ci + 1]},
+                              [&, ci, t0, n](hipStream_t ss) { wave_sweep(ss, ci, t0, n, false); });
+            if (ci == nc - 1) for (int k = 0; k < L; ++k) { P.dep(t_wbc[ci], t_wt[k]); P.dep(t_wbc[ci], t_wit[k]); }
+          }
+          t_bs[l][ci] = t_wbc[ci];
+        } else {
         if (l == L - 1 && ci == nc - 1) {
           t_wclear = P.add("wbclear", 5.f, Q_MAIN, {t_start}, [&](hipStream_t ss) { c.call(gru_wave_bwd_clear(w.wv_cnt_b, L, Tp, B, ss)); });
-          t_wb = P.add("wbsweep", 60.f + (Tp + 2 * L) * est_step_us(1) * hs, Q_MAIN, {t_top, t_wclear}, [&](hipStream_t ss) {
-            if (c.rc) return;
-            Ctx::Scope sc(c, ss, 9, 2.0 * Tp * B * 3.0 * H * H * (2 * L - 1));
-            WaveBwdArgs a;
-            memset(&a, 0, sizeof(a));
-            a.L = L; a.T = Tp; a.B = B; a.H = H; a.dY_top = w.dY[L - 1]; a.dh_last = dhidden; a.dh_init = w.dh_init;
-            const bool drop = p->rnn_drop > 0.f && L > 1;
-            for (int k = 0; k < L; ++k) {
-              a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k]; a.out[k] = w.out[k] + (long long)B * H;
-              a.reserve[k] = w.res[k]; a.dG[k] = w.dG[k]; a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
-            }
-            a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
-            a.flags = 2 | (gated ? 4 : 0); a.prog = gated ? w.wv_cnt_b : nullptr;     // counters cleared by wbclear; gated consumers: dG written through + progress words
-            a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = 0;
-            c.call(gru_wave_bwd(a, ss));
-          });
+          t_wb = P.add("wbsweep", 60.f + (Tp + 2 * L) * est_step_us(1) * hs, Q_MAIN, {t_top, t_wclear}, [&](hipStream_t ss) { wave_sweep(ss, 0, 0, Tp, true); });
           for (int k = 0; k < L; ++k) { P.dep(t_wb, t_wt[k]); P.dep(t_wb, t_wit[k]); }
         }
         t_bs[l][ci] = t_wb;
+        }
       } else
       t_bs[l][ci] = P.add("bsweep", 40.f + n * est_step_us(1) * hs, q_sweep,
                           {l < L - 1 ? t_dx[l + 1][ci] : t_top, ci == nc - 1 ? t_wt[l] : t_bs[l][ci + 1]}, [&, l, ci, t0, n](hipStream_t ss) {
@@ -1517,7 +1536,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
       else if (mode & B2T_GRU_LOCAL) P.t[t_bs[l][ci]].cls = l & 1;
       float e_dx = est_gemm((double)n * B, l > 0 ? H : In0, 3 * H);
       if (l == 0 && fast_day) e_dx += est_gemm(F, F, n, B) + 30.f;
-      if (wave && l > 0) t_dx[l][ci] = t_wb;   // made inside the sweep
+      if (wave && l > 0) t_dx[l][ci] = t_bs[l][ci];   // made inside the sweep
       else
       t_dx[l][ci] = P.add("dx", e_dx, (gated && t0 > 0) ? q_gated : Q_ANY, {(gated && t0 > 0) ? t_wclear : t_bs[l][ci], (l == 0 && fast_day && ci < nc - 1) ? t_dx[l][ci + 1] : -1, t_wpk[l]},
                           [&, l, t0, n](hipStream_t s) { gate(s, l, t0); dx_gemm(s, l, t0, n); });

@@ -100,8 +100,8 @@ struct WaveFwdArgs {
 struct WaveBwdArgs {
   int L, T, B, H;
   const float* dY_top;                                     // [T][B][H]: gradient wrt the top layer's outputs
-  const float* dh_last;                                    // [L][B][H] or null
-  float* dh_init;                                          // [L][B][H]
+  const float* dh_last[B2T_MAX_LAYERS];                    // per layer [B][H] or null: gradient wrt the state after the last step (a later chunk's dh_init)
+  float* dh_init[B2T_MAX_LAYERS];                          // per layer [B][H]
   const float* w_hh_t[B2T_MAX_LAYERS];                     // [H][3H] = W_hh^T
   const float* w_ih_t[B2T_MAX_LAYERS];                     // [H][3H] = W_ih^T of layers >= 1
   const float* h_init[B2T_MAX_LAYERS]; const float* out[B2T_MAX_LAYERS]; const float* reserve[B2T_MAX_LAYERS];

@@ -685,13 +685,13 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
       WSTAMP(1)
 #pragma unroll
       for (int i = 0; i < 4; ++i) carry[i] = acc[i] + dzterm[i];
-    } else if (a.dh_last) {
+    } else if (a.dh_last[layer]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (live[i]) carry[i] = a.dh_last[((long long)layer * B + (m0 + 4 * q + i)) * H + unit];
+      for (int i = 0; i < 4; ++i) if (live[i]) carry[i] = a.dh_last[layer][(long long)(m0 + 4 * q + i) * H + unit];
     }
     if (t < 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (live[i]) a.dh_init[((long long)layer * B + (m0 + 4 * q + i)) * H + unit] = carry[i];
+      for (int i = 0; i < 4; ++i) if (live[i]) a.dh_init[layer][(long long)(m0 + 4 * q + i) * H + unit] = carry[i];
       break;
     }
     f32x4 g0, g1, g2, g3;
@@ -1024,7 +1024,8 @@ extern "C" int b2t_gru_wave_bwd_f32(const b2t_wave_t* d, void* ws, unsigned* err
   B2T_REQUIRE(d->dY_top && d->dh_init && d->drop_p >= 0.f && d->drop_p < 1.f, "gru_wave_bwd: dY_top / dh_init / dropout");
   WaveBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.L = L; a.T = T; a.B = B; a.H = H; a.dY_top = d->dY_top; a.dh_last = d->dh_last; a.dh_init = d->dh_init;
+  a.L = L; a.T = T; a.B = B; a.H = H; a.dY_top = d->dY_top;
+  for (int l = 0; l < L; ++l) { a.dh_last[l] = d->dh_last ? d->dh_last + (size_t)l * B * H : nullptr; a.dh_init[l] = d->dh_init + (size_t)l * B * H; }
   const bool drop = d->drop_p > 0.f && L > 1;
   wave_carve(reinterpret_cast<char*>(ws), L, T, B, H, true, a.cnt, a.ring, a.ringx);
   a.err = err_word;

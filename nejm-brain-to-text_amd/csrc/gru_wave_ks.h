@@ -618,14 +618,14 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       if (prog) wave_bump<false>(prog, lane);
       ks_barrier();      // (no product this step: keeps the two projections on either side from meeting in their partial buffer)
       fetch(t - 1, nxt);
-      if (a.dh_last) {
+      if (a.dh_last[layer]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (live[i]) carry[i] = a.dh_last[((long long)layer * B + (m0 + 4 * q + i)) * H + unit];
+        for (int i = 0; i < 4; ++i) if (live[i]) carry[i] = a.dh_last[layer][(long long)(m0 + 4 * q + i) * H + unit];
       }
     }
     if (t < 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (live[i]) a.dh_init[((long long)layer * B + (m0 + 4 * q + i)) * H + unit] = carry[i];
+      for (int i = 0; i < 4; ++i) if (live[i]) a.dh_init[layer][(long long)(m0 + 4 * q + i) * H + unit] = carry[i];
       break;
     }
     if (rg_live) {
