@@ -153,17 +153,21 @@ __device__ __forceinline__ u32x4 load_frag(const char* ring, unsigned base, int 
 // longer streams keep 12 in flight and refill a slot as soon as its MFMAs are issued.  NO run-time branch inside (a `p < P` test per
 // pair made the compiler wait for every refill with vmcnt(0): 430 cycles per pair, R6.2): pairs beyond P re-read the last valid pair
 // and meet zero weights.  BODY sees `av` (the A operand of pair `p`).
+// (slot p of a stream holds pair rotp(p): the workgroups of a layer read the SAME fragments, and in the same order they all asked for
+// the same line at the same moment and all sat out its fetch -- rotated by the workgroup's slice, a line's first reader fetches it
+// and the others hit the L2; the weight fragments are loaded in the same rotated order.  frot_ = 0 unless every pair exists, NP == P.)
+#define B2T_ROTP(p) (((p) + frot_ >= NP) ? (p) + frot_ - NP : (p) + frot_)
 #define B2T_WAVE_STREAM(RING, BASE, BODY) B2T_WAVE_STREAM2(RING, BASE, {}, BODY)
 #define B2T_WAVE_STREAM2(RING, BASE, EXTRA, BODY)                                                                      \
   {                                                                                                                    \
     constexpr int LB_ = NP > 12 ? 12 : NP;                                                                             \
     u32x4 v_[LB_];                                                                                                     \
-    _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, p, P, H, lane, q, plain_);          \
+    _Pragma("unroll") for (int p = 0; p < LB_; ++p) v_[p] = load_frag(RING, BASE, B2T_ROTP(p), P, H, lane, q, plain_);          \
     EXTRA                                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                   \
       const bf16x8 av = __builtin_bit_cast(bf16x8, v_[p % LB_]);                                                       \
-      if (p + LB_ < NP) v_[p % LB_] = load_frag(RING, BASE, p + LB_, P, H, lane, q, plain_);                           \
+      if (p + LB_ < NP) v_[p % LB_] = load_frag(RING, BASE, B2T_ROTP(p + LB_), P, H, lane, q, plain_);                           \
       BODY                                                                                                             \
       if (NP > LB_) __builtin_amdgcn_sched_barrier(0);   /* refills stay where they are: hoisted, they would all be in flight (spills) */ \
     }                                                                                                                  \
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     if (!wave_role<LOC>(a.tickets, L, G, false, layer, slice)) return;
   }
   const int u0 = slice * 16, unit = u0 + j;
+  const int frot_ = (!RGF && P == NP && H == 32 * NP) ? slice % NP : 0;
   // LDS: fat form [3][NP][64] W_ih slice as B fragments; row-group form two stream buffers of NP KB; then the waves' tiles
   u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);
   char* sbuf_c = wave_lds;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
     const float* whh = a.w_hh[layer];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int k0 = 32 * p + 8 * q;
+      const int k0 = 32 * B2T_ROTP(p) + 8 * q;
       const bool ok = k0 < H;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_fwd_kernel(const WaveFwdArgs 
   } else if (layer > 0) {
     const float* wih = a.w_ih[layer];
     for (int idx = wave; idx < 3 * NP; idx += 4) {
-      const int g = idx / NP, p = idx % NP, k0 = 32 * p + 8 * q;
+      const int g = idx / NP, p = idx % NP, k0 = 32 * B2T_ROTP(p) + 8 * q;
       const bool ok = k0 < H;
       const float* src = wih + ((long long)g * H + unit) * H + (ok ? k0 : 0);
       wl[idx * 64 + lane] = masked8(ld4(src), ld4(src + 4), ok);
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     if (!wave_role<LOC>(a.tickets, L, G, true, layer, slice)) return;
   }
   const int u0 = slice * 16, unit = u0 + j;
+  const int frot_ = (!RGF && P == NP && H == 32 * NP) ? slice % NP : 0;
   // LDS: fat form [3][NP][64] W_ih[layer + 1]^T slice; row-group form two stream buffers of 3 NP KB (three arrays each); then the tiles
   u32x4* wl = reinterpret_cast<u32x4*>(wave_lds);
   char* sbuf_c = wave_lds;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
     const float* wt = a.w_hh_t[layer] + (long long)unit * 3 * H;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int k0 = 32 * p + 8 * q;
+      const int k0 = 32 * B2T_ROTP(p) + 8 * q;
       const bool ok = k0 < H;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void gru_wave_bwd_kernel(const WaveBwdArgs 
   } else if (has_up) {
     const float* wt = a.w_ih_t[layer + 1] + (long long)unit * 3 * H;
     for (int idx = wave; idx < 3 * NP; idx += 4) {
-      const int g = idx / NP, p = idx % NP, k0 = 32 * p + 8 * q;
+      const int g = idx / NP, p = idx % NP, k0 = 32 * B2T_ROTP(p) + 8 * q;
       const bool ok = k0 < H;
       const float* src = wt + (long long)g * H + (ok ? k0 : 0);
       wl[idx * 64 + lane] = masked8(ld4(src), ld4(src + 4), ok);

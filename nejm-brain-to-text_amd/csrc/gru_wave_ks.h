@@ -385,7 +385,10 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   const bool has_up = layer + 1 < L;
 
   // this wave's K quarter (pairs [NPQ w, NPQ (w + 1)) of each of the three arrays) of the W_hh^T and W_ih[layer + 1]^T column slices
+  // (unit blocks beyond 3 NPQ walk the same ring of positions BACKWARDS: no two workgroups of a row half share an order)
   const int rot = ub % (3 * NPQ);
+  const bool rdir = ((ub / (3 * NPQ)) & 1) != 0;
+  auto frag_of = [&](int g, int i) { const int s_ = g * NPQ + i; return rdir ? (rot + 3 * NPQ - s_) % (3 * NPQ) : (s_ + rot) % (3 * NPQ); };
   bf16x8 w[2][3][NPQ], w2[2][3][NPQ];
   {
 #pragma unroll
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
         const float* t2 = (has_up ? a.w_ih_t[layer + 1] : a.w_hh_t[layer]) + col * 3 * H;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-          const int f = (g * NPQ + i + rot) % (3 * NPQ);      // slot (g, i) of the projection = fragment f of the K quarter (rotation: see the forward kernel)
+          const int f = frag_of(g, i);      // slot (g, i) of the projection = fragment f of the K quarter (rotation: see the forward kernel)
           const float* s1 = t1 + (long long)g * H + k0;
           const float* s2 = t2 + (long long)(f / NPQ) * H + 32 * (NPQ * wave + f % NPQ) + 8 * q;
           w[u2][g][i] = cvt8(ld4(s1), ld4(s1 + 4));
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   for (int g = 0; g < 3; ++g)
 #pragma unroll
     for (int i = 0; i < NPQ; ++i) {
-      const int f = (g * NPQ + i + rot) % (3 * NPQ), gf = f / NPQ;
+      const int f = frag_of(g, i), gf = f / NPQ;
       poff[g][i] = (unsigned)(gf == 2 ? 3 : gf) * arr_bytes + (unsigned)(f % NPQ) * 1024u;
     }
   auto load_up = [&](int t, u32x4 (&xv)[2][3][NPQ]) {
