@@ -1464,7 +1464,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // are ordinary successors of that launch and run BESIDE the next chunk's sweep on the CUs it leaves free.  B2T_WAVE_GATED=1: ONE
   // launch for the whole sequence and consumers that wait on the DEVICE for the sweep's progress words (gru_wave_gate; dG written
   // through): they must never sit in front of the sweep on its own queue (the caller's stream) -- queues 1..3 only.  Measured at C2
-  // with the K-split sweep (NOTES.md R6.2): gated 8.46 / 8.63 / 9.53 ms with 2 / 4 / 8 chunks against 7.63 with one.
+  // with the K-split sweep (NOTES.md R6.2b): gated 8.46 / 8.63 / 9.53, launch per chunk 8.06 / 8.37 / 9.27 ms with 2 / 4 / 8 chunks against 7.6 with
+  // one -- a kernel launched beside the sweep cannot finish before it (workgroup i is dealt to XCD i % 8 and waits there; the sweep fills XCDs 0-4).
   static const bool gated_env = [] { const char* e = getenv("B2T_WAVE_GATED"); return e && atoi(e) != 0; }();
   const bool gated = wave && nc > 1 && c.nq > 1 && gated_env;
   const bool wave_chunked = wave && !gated;      // (nc == 1 included: one launch)
