@@ -102,7 +102,11 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
   const int rg = 2 * rh + rgl, slice = 2 * ub + us, u0 = slice * 16, unit = u0 + j, m0 = rg * 16;
   const bool rg_live = rg < ngrp;
   const int rgc0 = 2 * rh, rgc1 = (2 * rh + 1 < ngrp) ? 2 * rh + 1 : 2 * rh;     // the row groups whose fragments this workgroup contracts
-  constexpr int NT = 12;                                  // partial tiles per wave: (row group 2) x (slice 2) x (gate 3)
+  // partial tiles per wave: (row group 2) x (slice 2) x (gate 3) of the step's sums + (row group 2) x (slice 2) of gi_n.  ONE reduction
+  // per step: the projection of step t + 1 (made at the end of step t) stays UNREDUCED in registers; its r and z tiles seed the next
+  // product's accumulators (the gates only need gi + gh), its n tile (tanh(gi_n + r gh_n) needs the two apart) rides along as a
+  // fourth tile.  Two buffers by step parity (nothing else separates one step's reads from the next step's writes).
+  constexpr int NT = 16;
   float4* part_p = reinterpret_cast<float4*>(wave_lds);
   float4* part_q = part_p + 4 * NT * 64;
   float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)2 * 4 * NT * 1024) + wave * (WAVE_TILES * WTILE_F);
@@ -173,16 +177,17 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
 #ifdef B2T_WAVE_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-  f32x4 gi[3], gin[3];
-  // the K-split product of one operand stream: A fragments v[2][NPQ] x B fragments wt -> 12 partial tiles -> LDS -> the wave's 3
-  auto contract = [&](const u32x4 (&v)[2][NPQ], const bf16x8 (&wt)[2][3][NPQ], float4* part, f32x4 (&out)[3]) {
-    f32x4 acc[2][2][3];
+  // layers >= 1: pj[r][u2][g] = this wave's K quarter of gi for the NEXT product (unreduced).  Layer 0 (gi comes from memory, own tile
+  // only): pj[0][0][g] = gi of the coming step, pj[0][1][g] = the one after (in flight) -- the same registers, never both uses in one layer
+  f32x4 pj[2][2][3];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int u2 = 0; u2 < 2; ++u2)
+    for (int u2 = 0; u2 < 2; ++u2)
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[r][u2][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 3; ++g) pj[r][u2][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // acc += A fragments v[2][NPQ] x B fragments wt (this wave's K quarter, all 12 tiles of the workgroup)
+  auto mma = [&](const u32x4 (&v)[2][NPQ], const bf16x8 (&wt)[2][3][NPQ], f32x4 (&acc)[2][2][3]) {
 #pragma unroll
     for (int i = 0; i < NPQ; ++i)
 #pragma unroll
@@ -193,23 +198,11 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
 #pragma unroll
           for (int g = 0; g < 3; ++g) acc[r][u2][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wt[u2][g][i], acc[r][u2][g], 0, 0, 0);
       }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int u2 = 0; u2 < 2; ++u2)
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const f32x4 c = acc[r][u2][g];
-          part[(wave * NT + (r * 2 + u2) * 3 + g) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
-        }
-    ks_barrier();
-#pragma unroll
-    for (int g = 0; g < 3; ++g) out[g] = ks_reduce<NT>(part, (rgl * 2 + us) * 3 + g, lane);
   };
-  // gi of step t from layer - 1's (dropped) h_t = slot t + 1 of its written-through ring.  Split-phase: the slot's counters are
-  // REQUESTED two steps ahead and looked at one step ahead (right after the own poll, so that neither request sits in front of a
-  // poll's loads for long: vector memory returns in order); if they were complete, the fragments are requested then and there and
-  // are in registers when the projection starts.  Otherwise (the layer below is less than two steps ahead) the blocking path.
+  // gi of step t from layer - 1's (dropped) h_t = slot t + 1 of its written-through ring -> pj (no LDS, no barrier).  Split-phase: the
+  // slot's counters are REQUESTED two steps ahead and looked at one step ahead (right after the own poll, so that neither request sits
+  // in front of a poll's loads for long: vector memory returns in order); if they were complete, the fragments are requested then and
+  // there and are in registers when the projection starts.  Otherwise (the layer below is less than two steps ahead) the blocking path.
   unsigned csnap = 0u;
   auto project = [&](int t, bool loaded, u32x4 (&xq)[2][NPQ]) {
     if (!loaded) {
@@ -222,14 +215,15 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       }
     }
     WSTAMP(5)
-    f32x4 o[3];
-    contract(xq, w2, part_q, o);
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) gi[g][i] = o[g][i] + bi[g];
+      for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) pj[r][u2][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma(xq, w2, pj);
 #ifdef B2T_WAVE_TIMING
-    asm volatile("s_nop 0" :: "v"(gi[0][0]), "v"(gi[1][0]), "v"(gi[2][0]));
+    asm volatile("s_nop 0" :: "v"(pj[0][0][0][0]), "v"(pj[1][1][2][0]));
 #endif
     WSTAMP(6)
   };
@@ -258,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
 #pragma unroll
       for (int g = 0; g < 3; ++g) dst[g][i] = ks_ldf<2>(a.gi0, vo_gi[i], (unsigned)t * gi_step + (unsigned)g * (unsigned)H * 4u);
   };
-  if (layer > 0) { u32x4 xq[2][NPQ]; project(0, false, xq); } else load_gi0(0, gi);
+  if (layer > 0) { u32x4 xq[2][NPQ]; project(0, false, xq); } else load_gi0(0, pj[0][0]);
 
   for (int t = 0; t < T; ++t) {
     // h_{t-1} of both row groups, this wave's K quarter: load until no dword is the sentinel
@@ -287,22 +281,54 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
     WSTAMP(0)   // the peers' h_{t-1} is here
     u32x4 xq[2][NPQ];
     bool in_loaded = false;
-    if (layer == 0) { if (t + 1 < T) load_gi0(t + 1, gin); }     // (lands during the product)
+    if (layer == 0) { if (t + 1 < T) load_gi0(t + 1, pj[0][1]); }     // (lands during the product)
     else in_loaded = prefetch_in(t, xq);
-    f32x4 gh[3];
-    contract(v, w, (layer == 0 && (t & 1)) ? part_q : part_p, gh);
+    // the step's sums: accumulators seeded with the projection's r and z tiles (layers >= 1), product on top, ONE reduction
+    f32x4 gh[3], gin_;
+    {
+      f32x4 acc[2][2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+          acc[r][u2][0] = layer > 0 ? pj[r][u2][0] : f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[r][u2][1] = layer > 0 ? pj[r][u2][1] : f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[r][u2][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      mma(v, w, acc);
+      float4* part = (t & 1) ? part_q : part_p;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const f32x4 c = acc[r][u2][g];
+            part[(wave * NT + (r * 2 + u2) * 3 + g) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
+          }
+          if (layer > 0) {
+            const f32x4 c = pj[r][u2][2];
+            part[(wave * NT + 12 + r * 2 + u2) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
+          }
+        }
+      ks_barrier();
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gh[g] = ks_reduce<NT>(part, (rgl * 2 + us) * 3 + g, lane);
+      gin_ = layer > 0 ? ks_reduce<NT>(part, 12 + rgl * 2 + us, lane) : pj[0][0][2];
+    }
 #ifdef B2T_WAVE_TIMING
-    asm volatile("s_nop 0" :: "v"(gh[0][0]), "v"(gh[1][0]), "v"(gh[2][0]));
+    asm volatile("s_nop 0" :: "v"(gh[0][0]), "v"(gh[1][0]), "v"(gh[2][0]), "v"(gin_[0]));
 #endif
     WSTAMP(1)   // recurrent product + reduction
     if (rg_live) {
       f32x4 sr, sz, sn, sg, h;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        // (layers >= 1: gh[0], gh[1] already hold gi + gh of the r and z gates; layer 0: gi of memory is added here)
         const float ghn = gh[2][i] + bhn;
-        const float r = fast_sigmoid(gi[0][i] + gh[0][i] + bhr);
-        const float z = fast_sigmoid(gi[1][i] + gh[1][i] + bhz);
-        const float nn = fast_tanh(gi[2][i] + r * ghn);
+        const float r = fast_sigmoid((layer > 0 ? bi[0] : pj[0][0][0][i]) + gh[0][i] + bhr);
+        const float z = fast_sigmoid((layer > 0 ? bi[1] : pj[0][0][1][i]) + gh[1][i] + bhz);
+        const float nn = fast_tanh(gin_[i] + bi[2] + r * ghn);
         h[i] = (1.0f - z) * nn + z * hp[i];
         sr[i] = r; sz[i] = z; sn[i] = nn; sg[i] = ghn;
       }
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
     if (layer > 0) { if (t + 1 < T) project(t + 1, in_loaded, xq); }
     else {
 #pragma unroll
-      for (int g = 0; g < 3; ++g) gi[g] = gin[g];
+      for (int g = 0; g < 3; ++g) pj[0][0][g] = pj[0][1][g];
     }
   }
   if (pending_x >= 0) { wave_drain(); wave_bump<false>(cnt_x + pending_x, lane); }
