@@ -20,6 +20,7 @@
 //   * the neighbouring layer (another XCD) still reads a second, written-through ring behind agent-scope counters.
 // Serves H % 128 == 0, H <= 512 under the local placement; other shapes keep the 16-unit form.
 #pragma once
+#include <type_traits>
 
 constexpr int KS_D = 8;                          // own-ring depth (slots)
 constexpr unsigned KS_MAXDATA = 0xFFFEFFFFu;     // data dwords are clamped to this; anything above is "not yet written"
@@ -177,8 +178,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
 #ifdef B2T_WAVE_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-  // layers >= 1: pj[r][u2][g] = this wave's K quarter of gi for the NEXT product (unreduced).  Layer 0 (gi comes from memory, own tile
-  // only): pj[0][0][g] = gi of the coming step, pj[0][1][g] = the one after (in flight) -- the same registers, never both uses in one layer
+  // layers >= 1: pj[r][u2][g] = this wave's K quarter of gi for the NEXT product (unreduced)
   f32x4 pj[2][2][3];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -227,20 +227,20 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
 #endif
     WSTAMP(6)
   };
-  // after the own poll of step t: fragments of slot t + 2 if last step's look at its counters found them complete; request the counters of slot t + 3
+  // after the own poll of step t: fragments of slot t + 2 if last step's look at its counters found them complete; request the counters
+  // of slot t + 3.  BOTH unconditionally (the fragments from a harmless address when the counters were not complete, the counter index
+  // clamped): behind a branch the compiler merged the loaded registers with the not-loaded path through copies -- and waited for the
+  // loads (fabric: ~2 k cycles) right where they were issued (ISA of the timing build, NOTES.md R6.2b)
   auto prefetch_in = [&](int t, u32x4 (&xq)[2][NPQ]) -> bool {
-    bool loaded = false;
-    if (t + 1 < T && t > 0 && __all(csnap >= (unsigned)G)) {
-      const unsigned base = (unsigned)(t + 2) * slot_bytes;
+    const bool ready = t + 1 < T && t > 0 && __all(csnap >= (unsigned)G);
+    const unsigned base = (unsigned)(ready ? t + 2 : 0) * slot_bytes;      // (slot 0: the initial state, complete since project(0))
 #pragma unroll
-      for (int i = 0; i < NPQ; ++i) {
-        xq[0][i] = ks_load<0>(ring_in, in_off0, base + (unsigned)((i + rot) % NPQ) * 1024u);
-        xq[1][i] = ks_load<0>(ring_in, in_off1, base + (unsigned)((i + rot) % NPQ) * 1024u);
-      }
-      loaded = true;
+    for (int i = 0; i < NPQ; ++i) {
+      xq[0][i] = ks_load<0>(ring_in, in_off0, base + (unsigned)((i + rot) % NPQ) * 1024u);
+      xq[1][i] = ks_load<0>(ring_in, in_off1, base + (unsigned)((i + rot) % NPQ) * 1024u);
     }
-    if (t + 2 < T) csnap = __hip_atomic_load(((lane & 1) ? cnt_in1 : cnt_in0) + (t + 3), RLX_AGENT);
-    return loaded;
+    csnap = __hip_atomic_load(((lane & 1) ? cnt_in1 : cnt_in0) + (t + 3 <= T ? t + 3 : T), RLX_AGENT);
+    return ready;
   };
   unsigned vo_gi[4];
 #pragma unroll
@@ -252,14 +252,32 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
 #pragma unroll
       for (int g = 0; g < 3; ++g) dst[g][i] = ks_ldf<2>(a.gi0, vo_gi[i], (unsigned)t * gi_step + (unsigned)g * (unsigned)H * 4u);
   };
-  if (layer > 0) { u32x4 xq[2][NPQ]; project(0, false, xq); } else load_gi0(0, pj[0][0]);
+  f32x4 giA[3], giB[3];
+  if (layer > 0) { u32x4 xq[2][NPQ]; project(0, false, xq); } else load_gi0(0, giA);
 
-  for (int t = 0; t < T; ++t) {
+  // the step loop, instantiated twice (layer 0: gi from memory, no projection; layers >= 1): in one body the two paths shared
+  // registers through copies the compiler waited on (NOTES.md R6.2b)
+  // (layer 0: gi of a step comes from memory, requested one step ahead into the OTHER of two buffers -- the loop runs two steps per
+  // iteration so that no copy exists: a copy at the end of the step was scheduled right behind the loads and waited for HBM there)
+  auto run = [&](auto l0c) {
+  constexpr bool L0 = decltype(l0c)::value;
+  auto step = [&](int t, f32x4 (&gcur)[3], f32x4 (&gnxt)[3]) {
     // h_{t-1} of both row groups, this wave's K quarter: load until no dword is the sentinel
     u32x4 v[2][NPQ];
     {
       const unsigned base = (unsigned)(t % KS_D) * slot_bytes;
       unsigned spins = 0;
+#ifdef KS_WITNESS
+      // a look at ONE fragment until it is there (an eighth of the bytes per look: 128 waves of an XCD poll at once), then all of them
+      for (;;) {
+        const u32x4 wv = ks_load<16>(ring, in_off1 + (unsigned)(NPQ - 1) * 1024u, base);
+        if (!__any(ks_max(0u, wv) > KS_MAXDATA)) break;
+        if ((++spins & 255u) == 0u) {
+          if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+          if (spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+        }
+      }
+#endif
       for (;;) {
 #pragma unroll
         for (int i = 0; i < NPQ; ++i) {
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
     WSTAMP(0)   // the peers' h_{t-1} is here
     u32x4 xq[2][NPQ];
     bool in_loaded = false;
-    if (layer == 0) { if (t + 1 < T) load_gi0(t + 1, pj[0][1]); }     // (lands during the product)
+    if (L0) { if (t + 1 < T) load_gi0(t + 1, gnxt); }     // (lands during the product)
     else in_loaded = prefetch_in(t, xq);
     // the step's sums: accumulators seeded with the projection's r and z tiles (layers >= 1), product on top, ONE reduction
     f32x4 gh[3], gin_;
@@ -291,11 +309,15 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int u2 = 0; u2 < 2; ++u2) {
-          acc[r][u2][0] = layer > 0 ? pj[r][u2][0] : f32x4{0.f, 0.f, 0.f, 0.f};
-          acc[r][u2][1] = layer > 0 ? pj[r][u2][1] : f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[r][u2][0] = !L0 ? pj[r][u2][0] : f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[r][u2][1] = !L0 ? pj[r][u2][1] : f32x4{0.f, 0.f, 0.f, 0.f};
           acc[r][u2][2] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       mma(v, w, acc);
+#ifdef B2T_WAVE_TIMING
+      asm volatile("s_nop 0" :: "v"(acc[0][0][0][0]), "v"(acc[1][1][2][0]));
+      WSTAMP(3)   // (timing build: the product's MFMAs alone)
+#endif
       float4* part = (t & 1) ? part_q : part_p;
 #pragma unroll
       for (int r = 0; r < 2; ++r)
@@ -306,15 +328,18 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
             const f32x4 c = acc[r][u2][g];
             part[(wave * NT + (r * 2 + u2) * 3 + g) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
           }
-          if (layer > 0) {
+          if (!L0) {
             const f32x4 c = pj[r][u2][2];
             part[(wave * NT + 12 + r * 2 + u2) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
           }
         }
       ks_barrier();
+#ifdef B2T_WAVE_TIMING
+      WSTAMP(7)   // (timing build: partial tiles written + the barrier)
+#endif
 #pragma unroll
       for (int g = 0; g < 3; ++g) gh[g] = ks_reduce<NT>(part, (rgl * 2 + us) * 3 + g, lane);
-      gin_ = layer > 0 ? ks_reduce<NT>(part, 12 + rgl * 2 + us, lane) : pj[0][0][2];
+      gin_ = !L0 ? ks_reduce<NT>(part, 12 + rgl * 2 + us, lane) : gcur[2];
     }
 #ifdef B2T_WAVE_TIMING
     asm volatile("s_nop 0" :: "v"(gh[0][0]), "v"(gh[1][0]), "v"(gh[2][0]), "v"(gin_[0]));
@@ -326,8 +351,8 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       for (int i = 0; i < 4; ++i) {
         // (layers >= 1: gh[0], gh[1] already hold gi + gh of the r and z gates; layer 0: gi of memory is added here)
         const float ghn = gh[2][i] + bhn;
-        const float r = fast_sigmoid((layer > 0 ? bi[0] : pj[0][0][0][i]) + gh[0][i] + bhr);
-        const float z = fast_sigmoid((layer > 0 ? bi[1] : pj[0][0][1][i]) + gh[1][i] + bhz);
+        const float r = fast_sigmoid((!L0 ? bi[0] : gcur[0][i]) + gh[0][i] + bhr);
+        const float z = fast_sigmoid((!L0 ? bi[1] : gcur[1][i]) + gh[1][i] + bhz);
         const float nn = fast_tanh(gin_[i] + bi[2] + r * ghn);
         h[i] = (1.0f - z) * nn + z * hp[i];
         sr[i] = r; sz[i] = z; sn[i] = nn; sg[i] = ghn;
@@ -375,12 +400,14 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
       }
       WSTAMP(4)   // neighbour's ring, fp32 stores
     }
-    if (layer > 0) { if (t + 1 < T) project(t + 1, in_loaded, xq); }
-    else {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) pj[0][0][g] = pj[0][1][g];
-    }
+    if (!L0) { if (t + 1 < T) project(t + 1, in_loaded, xq); }
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, giA, giB);
+    if (t + 1 < T) step(t + 1, giB, giA);
   }
+  };
+  if (layer == 0) run(std::true_type{}); else run(std::false_type{});
   if (pending_x >= 0) { wave_drain(); wave_bump<false>(cnt_x + pending_x, lane); }
 #ifdef B2T_WAVE_TIMING
   if (k == 0 && wave == 0 && lane == 0 && a.timing)

@@ -46,7 +46,7 @@ def probe(L, T, B, H, p, reps=5, seed=1, ws=None, timing=True):
             if i: ts.append(e0.elapsed_time(e1) * 1e3)
         assert int(err[0]) == 0, "hand-off timeout"
         r[name + "_us"] = round(min(ts), 1); r[name + "_us_per_step"] = round(min(ts) / (T + L - 1), 3); r[name + "_all"] = [round(t, 1) for t in ts]
-        if "wtiming" in os.environ.get("B2T_LIB", ""):     # cycles per step: wait own, loads + product, gates + tile, drain + counters, stores, wait neighbour, projection
+        if os.environ.get("B2T_LIB", ""):     # cycles per step: wait own, loads + product, gates + tile, drain + counters, stores, wait neighbour, projection
             tm = err[16 + (0 if name == "fwd" else 64):][:8 * L].view(L, 8).cpu().numpy()
             r[name + "_cycles_per_step_by_layer"] = [[int(v) for v in row[:8]] for row in tm]
     assert all(torch.isfinite(o).all() for o in out + dG)
