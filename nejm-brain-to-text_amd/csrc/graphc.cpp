@@ -1196,6 +1196,8 @@ struct DetRescore {
   // no candidate the beam refused would now pass (alpha + m_drop > limit); otherwise the state is expanded again in its turn.  So
   // the result is the serial one bit for bit.  (The queue holds ~1500 states when a 175 k-arc lattice is half done.)
   bool run(double beam, int n_threads) {
+    failed = false; h_failed.store(false, std::memory_order_relaxed);
+    HelperGuard guard{this};
     const int start = start_r;
     if (beta[(size_t)start] == INFINITY) return false;
     limit = beta[(size_t)start] + beam + 1e-4;
@@ -1239,7 +1241,7 @@ struct DetRescore {
         // run yet (the pool's other lattices keep the cores busy) takes no chunk and is not waited for.
         {
           std::unique_lock<std::mutex> lk(hm);
-          while (h_active.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // a late-comer of the previous batch is still looking at it
+          dcv.wait(lk, [&] { return h_active.load(std::memory_order_acquire) == 0; });   // a late-comer of the previous batch is still looking at it (the wait releases hm)
           h_batch = batch.data(); h_nb = nb;
           h_next.store(0, std::memory_order_relaxed); h_done.store(0, std::memory_order_relaxed);
           ++h_seq;
@@ -1251,7 +1253,8 @@ struct DetRescore {
           }
         hcv.notify_all();
         work_chunks(0);
-        while (h_done.load(std::memory_order_acquire) < nb) std::this_thread::yield();
+        { std::unique_lock<std::mutex> lk(hm); dcv.wait(lk, [&] { return h_done.load(std::memory_order_acquire) >= nb; }); }
+        if (h_failed.load(std::memory_order_acquire)) { stop_helpers(); failed = true; return false; }   // an expand() threw (out of memory): the caller falls back
         outstanding += nb; unprepared -= nb; ++n_batches;
         n_spec += nb;
       }
@@ -1282,6 +1285,10 @@ struct DetRescore {
       }
       if (who == 0 && g0 == keep_grp) { c0.r_grp.resize(keep_grp); c0.r_ent.resize(keep_ent); c0.r_key.resize(keep_ent); }   // groups made in turn are dropped again
     }
+    stop_helpers();
+    return true;
+  }
+  void stop_helpers() {
     if (!helpers.empty()) {
       { std::unique_lock<std::mutex> lk(hm); h_stop = true; }
       hcv.notify_all();
@@ -1289,31 +1296,35 @@ struct DetRescore {
       helpers.clear(); h_stop = false;
     }
     h_refused = false;
-    return true;
   }
+  struct HelperGuard { DetRescore* d; ~HelperGuard() { d->stop_helpers(); } };      // (run(): an exception on the calling thread must not leave joinable threads behind)
+  bool failed = false;
   void release_big() {                                           // (after an outsized lattice: the arrays go back to the allocator)
     std::vector<Ent>().swap(ent); std::vector<Key>().swap(ekey); std::vector<ANode>().swap(ali); std::vector<Ctx>().swap(ctx); std::vector<Raw>().swap(raw);
     std::vector<RArc>().swap(carc); std::vector<RArc>().swap(earc); std::vector<RArc>().swap(warc); std::vector<int>().swap(tr_src); std::vector<int>().swap(tr_ali);
   }
   // helper threads of one run(): chunks of four states of the published batch, results into the thread's own context
-  std::mutex hm; std::condition_variable hcv;
+  std::mutex hm; std::condition_variable hcv, dcv;      // hcv: a batch is published / stop; dcv: a batch is complete / the helpers have left it
   std::vector<std::thread> helpers;
   std::atomic<size_t> h_next{0}, h_done{0};
   std::atomic<int> h_active{0};
+  std::atomic<bool> h_failed{false};
   const std::pair<int, int>* h_batch = nullptr; size_t h_nb = 0; unsigned long long h_seq = 0; bool h_stop = false, h_refused = false;
   void work_chunks(int t) {
     Ctx& c = ctx[(size_t)t];
     const size_t nb = h_nb;
     for (size_t i = h_next.fetch_add(4); i < nb; i = h_next.fetch_add(4)) {
       const size_t i1 = std::min(nb, i + 4);
-      for (size_t q = i; q < i1; ++q) {
-        const int E = h_batch[q].second;
-        const St sd = st[(size_t)E];
-        const size_t g0 = c.r_grp.size();
-        expand(c, sd, sd.alpha);
-        spec[(size_t)E] = Spec{t, g0, (int)(c.r_grp.size() - g0), sd.alpha, c.m_drop};
-      }
-      h_done.fetch_add(i1 - i, std::memory_order_release);
+      try {
+        for (size_t q = i; q < i1; ++q) {
+          const int E = h_batch[q].second;
+          const St sd = st[(size_t)E];
+          const size_t g0 = c.r_grp.size();
+          expand(c, sd, sd.alpha);
+          spec[(size_t)E] = Spec{t, g0, (int)(c.r_grp.size() - g0), sd.alpha, c.m_drop};
+        }
+      } catch (...) { h_failed.store(true, std::memory_order_release); }     // (counted as done all the same: the batch must complete for run() to see the flag)
+      if (h_done.fetch_add(i1 - i, std::memory_order_acq_rel) + (i1 - i) >= nb) { std::lock_guard<std::mutex> lk(hm); dcv.notify_all(); }
     }
   }
   void helper_loop(int t) {
@@ -1327,7 +1338,7 @@ struct DetRescore {
         h_active.fetch_add(1, std::memory_order_acq_rel);
       }
       work_chunks(t);
-      h_active.fetch_sub(1, std::memory_order_acq_rel);
+      if (h_active.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(hm); dcv.notify_all(); }
     }
   }
   size_t n_spec = 0, n_respec = 0, n_batches = 0;
@@ -1361,7 +1372,7 @@ static int rescore_on_determinised(int n_states, int start, int n_arcs, const in
   const char* env_big_s = getenv("B2T_RESCORE_BIG_THREADS");      // threads of a lattice of >= 60 k arcs (default 4; 1 = serial)
   const int big_threads = env_big_s && atoi(env_big_s) > 0 ? std::min(atoi(env_big_s), 16) : 4;
   const int det_threads = env_threads > 0 ? std::min(env_threads, 16) : (n_arcs >= 60000 && std::thread::hardware_concurrency() >= 8 ? big_threads : 1);
-  if (!dr.run((double)beam, det_threads)) { if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0; return 0; }
+  if (!dr.run((double)beam, det_threads)) { if (dr.failed) *fell_back = true; if (stats4) stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0; return 0; }
   const auto t_det = std::chrono::steady_clock::now();
   LmDet Lo(*CFST(g_old), backoff_label), Ln(*CFST(g_new), backoff_label);
   // determinised-lattice adjacency

@@ -598,12 +598,17 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       e.dyt[i] = has_up ? 0.f : ks_ldf<2>(a.dY_top, vo_out[i], (unsigned)t * out_step);
     }
   };
-  Elem cur, nxt;
-  fetch(T - 1, cur);
+  // Two element buffers used alternately -- the loop runs two steps per iteration, there is no copy (a copy at the end of a step was
+  // scheduled right behind the loads and waited for HBM there) -- and the step body instantiated per role (top layer / layers with a
+  // neighbour above): one body made the two paths share registers through copies the compiler waited on (forward kernel, NOTES.md R6.2b)
+  Elem ea, eb;
+  fetch(T - 1, ea);
   if (has_up) project(T - 1, false);
   f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int t = T - 1; t >= -1; --t) {
+  auto run = [&](auto huc) {
+  constexpr bool HU = decltype(huc)::value;      // == has_up
+  auto step = [&](int t, Elem& cur, Elem& nxt) {
     f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
     bool up_known = false;      // the counters of slot t - 1 were seen complete (last step's request)
     if (t < T - 1) {
@@ -657,11 +662,11 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       if (prog) wave_bump<false>(prog, lane);
       WSTAMP(0)
       fetch(t - 1, nxt);
-      const bool up_ready = has_up && t > 0 && t < T - 2 && __all(csnap >= (unsigned)G);     // (csnap: slot t - 1, requested one step ago)
-      if (has_up && t > 1) csnap = __hip_atomic_load(((lane & 1) ? cnt_up1 : cnt_up0) + (t - 2), RLX_AGENT);
+      const bool up_ready = HU && t > 0 && t < T - 2 && __all(csnap >= (unsigned)G);     // (csnap: slot t - 1, requested one step ago)
+      if (HU) csnap = __hip_atomic_load(((lane & 1) ? cnt_up1 : cnt_up0) + (t > 2 ? t - 2 : 0), RLX_AGENT);     // (unconditional: no merge with an old value)
       // (the top layer has no projection -- no second barrier between two products -- so it alternates the two partial buffers:
       // a wave may start writing step t - 1's partials while a slower one still reads step t's)
-      const f32x4 acc = contract(v, w, (!has_up && (t & 1)) ? part_q : part_p);
+      const f32x4 acc = contract(v, w, (!HU && (t & 1)) ? part_q : part_p);
       up_known = up_ready;
 #ifdef B2T_WAVE_TIMING
       asm volatile("s_nop 0" :: "v"(acc[0]));
@@ -682,13 +687,13 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
     if (t < 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) if (live[i]) a.dh_init[layer][(long long)(m0 + 4 * q + i) * H + unit] = carry[i];
-      break;
+      return;
     }
     if (rg_live) {
       f32x4 g0, g1, g2, g3;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float d = (has_up ? dy[i] : cur.dyt[i]) + carry[i];
+        const float d = (HU ? dy[i] : cur.dyt[i]) + carry[i];
         const float dn = d * (1.0f - cur.z[i]);
         const float dz = d * (cur.hprev[i] - cur.nv[i]);
         const float dn_pre = dn * (1.0f - cur.nv[i] * cur.nv[i]);
@@ -732,9 +737,15 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       }
       WSTAMP(4)
     }
-    if (has_up && t > 0) project(t - 1, up_known);
-    cur = nxt;
+    if (HU && t > 0) project(t - 1, up_known);
+  };
+  for (int t = T - 1; t >= -1; t -= 2) {
+    step(t, ea, eb);
+    if (t - 1 >= -1) step(t - 1, eb, ea);
   }
+  };
+  if (has_up) run(std::true_type{}); else run(std::false_type{});
+
   wave_drain();
   if (pending_x >= 0) wave_bump<false>(cnt_x + pending_x, lane);
 #ifdef B2T_WAVE_TIMING
