@@ -845,7 +845,7 @@ bool gru_wave_ks(int L, int T, int B, int H) {
   if ((unsigned long long)T * B * 4 * H * sizeof(float) >= (1ull << 31)) return false;      // 32-bit offsets into the saved gates
   return gru_wave_local(L, H) && H % 128 == 0 && H <= 512 && nrh * (H / 32) <= 32;
 }
-static size_t ks_lds_bytes(bool backward) { return (size_t)2 * 4 * (backward ? 4 : 16) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
+static size_t ks_lds_bytes(bool backward) { return (size_t)2 * 4 * (backward ? 8 : 16) * 1024 + (size_t)4 * WAVE_TILES * WTILE_F * sizeof(float); }
 static int ks_arm(char* const* ring, int L, size_t slot_bytes, hipStream_t s) {
   KsArmArgs k;
   for (int l = 0; l < B2T_MAX_LAYERS; ++l) k.ring[l] = l < L ? ring[l] : nullptr;

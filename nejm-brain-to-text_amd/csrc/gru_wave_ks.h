@@ -418,6 +418,10 @@ __global__ __launch_bounds__(256, 1) void gru_ks_fwd_kernel(const WaveFwdArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 // backward.  Ring slot: the gate gradients of one step as fragments, 4 arrays (dr, dz, dn r, dn) x P pairs per row group.
 // Index n of the own ring = step T - 1 - n.
+// The gradient wrt the layer BELOW's outputs, dY[layer - 1]_t = dGi[layer]_t . W_ih[layer], is made HERE, by the layer that owns dGi
+// (producer side): its fragments are the ones this layer polls for its own recurrence anyway (dr, dz shared; dn instead of dn r: one
+// more array from the own ring, in the XCD's L2), so nothing but a 16 x 16 fp32 tile per wave and step crosses to the layer below --
+// the consumer-side form read 96 KB per CU and step across XCDs at ~27 B per clock: 3.5-4.5 k cycles of a 13 k cycle step (R6.2b).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NPQ, bool DROP>
 __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a) {
@@ -431,17 +435,13 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
   const int rg = 2 * rh + rgl, slice = 2 * ub + us, u0 = slice * 16, unit = u0 + j, m0 = rg * 16;
   const bool rg_live = rg < ngrp;
   const int rgc0 = 2 * rh, rgc1 = (2 * rh + 1 < ngrp) ? 2 * rh + 1 : 2 * rh;
-  constexpr int NT = 4;                                   // partial tiles per wave: (row group 2) x (slice 2)
+  constexpr int NT = 8;                                   // partial tiles per wave: (row group 2) x (slice 2) of the recurrent product, then of the projection
   float4* part_p = reinterpret_cast<float4*>(wave_lds);
   float4* part_q = part_p + 4 * NT * 64;
   float* tiles = reinterpret_cast<float*>(wave_lds + (size_t)2 * 4 * NT * 1024) + wave * (WAVE_TILES * WTILE_F);
-  const bool has_up = layer + 1 < L;
+  const bool has_up = layer + 1 < L, feeds = layer > 0;
 
-  // this wave's K quarter (pairs [NPQ w, NPQ (w + 1)) of each of the three arrays) of the W_hh^T and W_ih[layer + 1]^T column slices
-  // (unit blocks beyond 3 NPQ walk the same ring of positions BACKWARDS: no two workgroups of a row half share an order)
-  const int rot = ub % (3 * NPQ);
-  const bool rdir = ((ub / (3 * NPQ)) & 1) != 0;
-  auto frag_of = [&](int g, int i) { const int s_ = g * NPQ + i; return rdir ? (rot + 3 * NPQ - s_) % (3 * NPQ) : (s_ + rot) % (3 * NPQ); };
+  // this wave's K quarter (pairs [NPQ w, NPQ (w + 1)) of each array) of the W_hh^T and W_ih[layer]^T column slices
   bf16x8 w[2][3][NPQ], w2[2][3][NPQ];
   {
 #pragma unroll
@@ -451,14 +451,13 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       for (int u2 = 0; u2 < 2; ++u2) {
         const long long col = 16 * (2 * ub + u2) + j;
         const float* t1 = a.w_hh_t[layer] + col * 3 * H;
-        const float* t2 = (has_up ? a.w_ih_t[layer + 1] : a.w_hh_t[layer]) + col * 3 * H;
+        const float* t2 = (feeds ? a.w_ih_t[layer] : a.w_hh_t[layer]) + col * 3 * H;      // (layer 0 projects nothing: any valid matrix, masked to zero)
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-          const int f = frag_of(g, i);      // slot (g, i) of the projection = fragment f of the K quarter (rotation: see the forward kernel)
           const float* s1 = t1 + (long long)g * H + k0;
-          const float* s2 = t2 + (long long)(f / NPQ) * H + 32 * (NPQ * wave + f % NPQ) + 8 * q;
+          const float* s2 = t2 + (long long)g * H + k0;
           w[u2][g][i] = cvt8(ld4(s1), ld4(s1 + 4));
-          w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(ld4(s2), ld4(s2 + 4), has_up));
+          w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(ld4(s2), ld4(s2 + 4), feeds));
           asm volatile("" : "+a"(w[u2][g][i]));
           asm volatile("" : "+a"(w2[u2][g][i]));
         }
@@ -470,17 +469,16 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
 
   unsigned* err = a.err;
   const size_t cstride = (size_t)T;
-  unsigned* cnt_x = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + (rg_live ? rg : 0)) * cstride;
-  const bool feeds = layer > 0;
-  const unsigned* cnt_up0 = has_up ? a.cnt + ((size_t)((layer + 1) * 2 + 1) * ngrp + rgc0) * cstride : nullptr;
-  const unsigned* cnt_up1 = has_up ? a.cnt + ((size_t)((layer + 1) * 2 + 1) * ngrp + rgc1) * cstride : nullptr;
+  unsigned* cnt_x = a.cnt + ((size_t)(layer * 2 + 1) * ngrp + (rg_live ? rg : 0)) * cstride;      // dY[layer - 1] tiles of (row group, step) published
+  const unsigned* cnt_up = has_up ? a.cnt + ((size_t)((layer + 1) * 2 + 1) * ngrp + (rg_live ? rg : 0)) * cstride : nullptr;
   char* ring = a.ring[layer];
-  char* ringx = a.ringx[layer];
-  const char* ring_up = has_up ? a.ringx[layer + 1] : nullptr;
+  char* dyr = a.ringx[layer];                                    // dY[layer - 1]: [T][row group][slice][64 lanes x 16 B] (C layout of a 16 x 16 tile), written through
+  const char* dyr_up = has_up ? a.ringx[layer + 1] : nullptr;
   const unsigned arr_bytes = (unsigned)P * 1024u, rg_bytes = 4u * arr_bytes, slot_bytes = (unsigned)ngrp * rg_bytes, rg_off = (unsigned)rg * rg_bytes;
   const unsigned my_frag = (unsigned)ub * 1024u + (unsigned)us * 512u + (unsigned)(lane & 31) * 16u;
   const unsigned in_off0 = (unsigned)rgc0 * rg_bytes + (unsigned)(NPQ * wave) * 1024u + (unsigned)lane * 16u;
   const unsigned in_off1 = (unsigned)rgc1 * rg_bytes + (unsigned)(NPQ * wave) * 1024u + (unsigned)lane * 16u;
+  const unsigned dy_slot = (unsigned)ngrp * (unsigned)G * 1024u, dy_tile = ((unsigned)rg * (unsigned)G + (unsigned)slice) * 1024u + (unsigned)lane * 16u;
   bool live[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) live[i] = rg_live && m0 + 4 * q + i < B;
@@ -491,90 +489,11 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
 #ifdef B2T_WAVE_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-  auto contract = [&](const u32x4 (&v)[2][3][NPQ], const bf16x8 (&wt)[2][3][NPQ], float4* part) -> f32x4 {
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int u2 = 0; u2 < 2; ++u2) acc[r][u2] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int i = 0; i < NPQ; ++i)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const bf16x8 av = __builtin_bit_cast(bf16x8, v[r][g][i]);
-#pragma unroll
-          for (int u2 = 0; u2 < 2; ++u2) acc[r][u2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wt[u2][g][i], acc[r][u2], 0, 0, 0);
-        }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int u2 = 0; u2 < 2; ++u2) {
-        const f32x4 c = acc[r][u2];
-        part[(wave * NT + r * 2 + u2) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
-      }
-    ks_barrier();
-    return ks_reduce<NT>(part, rgl * 2 + us, lane);
-  };
-  f32x4 dy = f32x4{0.f, 0.f, 0.f, 0.f};
-  // dY[layer]_t = dGi[layer + 1]_t . W_ih[layer + 1][:, units] (arrays dr, dz, dn of the ring above), then the dropout mask.
-  // The slot's counters are requested one step ahead and looked at after the own poll (the request is then never in front of a
-  // poll's loads for long: vector memory returns in order): if they were complete the projection starts without a counter round trip
-  // (~1.9 k cycles, memory side).  The fragments themselves are NOT requested early here (the forward pass does): 96 more live
-  // registers next to the saved gates' double buffer spilled MFMA operand tuples, and the partial reloads of those were wrong
-  // (NOTES.md R6.2: every kernel of this file must compile to ScratchSize 0 -- tests/test_wave_build.py).
-  // (the fragments are an argument, not a captured variable: declared per step, they are not live across the loop's back edge -- a
-  // captured array was, next to the own product's operands: 32-44 registers spilled)
-  unsigned csnap = 0u;
-  unsigned poff[3][NPQ];      // (wave-uniform: scalar registers)
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int i = 0; i < NPQ; ++i) {
-      const int f = frag_of(g, i), gf = f / NPQ;
-      poff[g][i] = (unsigned)(gf == 2 ? 3 : gf) * arr_bytes + (unsigned)(f % NPQ) * 1024u;
-    }
-  auto load_up = [&](int t, u32x4 (&xv)[2][3][NPQ]) {
-    const unsigned base = (unsigned)t * slot_bytes;
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int i = 0; i < NPQ; ++i) {
-        xv[0][g][i] = ks_load<0>(ring_up, in_off0, base + poff[g][i]);
-        xv[1][g][i] = ks_load<0>(ring_up, in_off1, base + poff[g][i]);
-      }
-  };
-  auto project = [&](int t, bool known) {
-    if (!known) ks_wait2(cnt_up0 + t, cnt_up1 + t, (unsigned)G, err, lane);
-    WSTAMP(3)
-    u32x4 xv[2][3][NPQ];
-    load_up(t, xv);
-    WSTAMP(5)
-#ifdef B2T_WAVE_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WSTAMP(7)
-#endif
-    f32x4 acc = contract(xv, w2, part_q);
-    if (DROP) {
-      float* td = tiles;
-      tile_put(td, acc, j, q);
-      float4 v4 = ld4(td + (lane & 15) * WTP + 4 * kg);
-      const long long e = a.elem0 + ((long long)t * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
-      const float4 u = Philox::uniform4(a.seed[layer], (uint64_t)(e >> 2), 2u);
-      v4.x = u.x >= a.drop_p ? v4.x * a.drop_scale : 0.f; v4.y = u.y >= a.drop_p ? v4.y * a.drop_scale : 0.f;
-      v4.z = u.z >= a.drop_p ? v4.z * a.drop_scale : 0.f; v4.w = u.w >= a.drop_p ? v4.w * a.drop_scale : 0.f;
-      *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = v4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = td[(4 * q + i) * WTP + j];
-    }
-    dy = acc;
-    WSTAMP(6)
-  };
-
-  // the step's elementwise operands (saved gates, h_{t-1}, the top layer's dY) come from memory: requested one step ahead, right
-  // after the poll (behind it they would sit in front of the NEXT poll's loads: vector memory returns in order)
-  struct Elem { f32x4 r, z, nv, ghn, hprev, dyt; };
+  // the step's elementwise operands (saved gates, h_{t-1}, dY of the step: the top layer's from memory, the others' tile from the ring
+  // of the layer above) come from memory: requested one step ahead, right after the poll (behind it they would sit in front of the
+  // NEXT poll's loads: vector memory returns in order).  dY: only when the counters of its slot were seen complete (requested one
+  // step before that); `ok` says so -- otherwise the step waits for them and loads the tile itself.
+  struct Elem { f32x4 r, z, nv, ghn, hprev, dyt; bool ok; };
   unsigned vo_res[4], vo_out[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -583,7 +502,10 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
     vo_out[i] = live[i] ? (row * (unsigned)H + (unsigned)unit) * 4u : KS_DEAD;
   }
   const unsigned res_step = (unsigned)B * 4u * (unsigned)H * 4u, out_step = (unsigned)B * (unsigned)H * 4u, hb = (unsigned)H * 4u;
-  auto fetch = [&](int t, Elem& e) {
+  unsigned csnap = 0u;
+  auto load_dy = [&](int t) -> f32x4 { return __builtin_bit_cast(f32x4, ks_load<0>(dyr_up, dy_tile, (unsigned)t * dy_slot)); };
+  auto fetch = [&](int t, Elem& e, bool up_ready) {
+    e.ok = up_ready;
     if (t < 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) e.r[i] = e.z[i] = e.nv[i] = e.ghn[i] = e.hprev[i] = e.dyt[i] = 0.f;
@@ -595,30 +517,34 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       e.r[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so); e.z[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so + hb);
       e.nv[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so + 2u * hb); e.ghn[i] = ks_ldf<2>(a.reserve[layer], vo_res[i], so + 3u * hb);
       e.hprev[i] = t > 0 ? ks_ldf<0>(a.out[layer], vo_out[i], (unsigned)(t - 1) * out_step) : ks_ldf<0>(a.h_init[layer], vo_out[i], 0u);
-      e.dyt[i] = has_up ? 0.f : ks_ldf<2>(a.dY_top, vo_out[i], (unsigned)t * out_step);
+      if (!has_up) e.dyt[i] = ks_ldf<2>(a.dY_top, vo_out[i], (unsigned)t * out_step);
     }
+    if (has_up) e.dyt = load_dy(up_ready ? t : T - 1);      // (unconditional -- slot T - 1 is complete since the start: no merge of loaded / not loaded registers)
   };
-  // Two element buffers used alternately -- the loop runs two steps per iteration, there is no copy (a copy at the end of a step was
-  // scheduled right behind the loads and waited for HBM there) -- and the step body instantiated per role (top layer / layers with a
-  // neighbour above): one body made the two paths share registers through copies the compiler waited on (forward kernel, NOTES.md R6.2b)
+  // Two buffers used alternately (two steps per loop iteration, no copy), the next step's operands requested behind this step's MFMAs.
+  // With dropout (16 more live registers around the Philox draws: the allocator spilled) ONE buffer, requested at the END of the step,
+  // when this step's operands are dead -- those HBM loads then sit in front of the next poll's looks (+0.6 us per step alone).
+  constexpr bool DB = !DROP;
   Elem ea, eb;
-  fetch(T - 1, ea);
-  if (has_up) project(T - 1, false);
+  if (has_up) wave_wait<false>(cnt_up + (T - 1), (unsigned)G, err, lane);
+  fetch(T - 1, ea, true);
   f32x4 dzterm = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto run = [&](auto huc) {
-  constexpr bool HU = decltype(huc)::value;      // == has_up
+  // The step body instantiated per role (FD: a layer below to project for; HU: a layer above to take dY from) and two steps per loop
+  // iteration on alternating element buffers: one body / a copy made the paths share registers through copies the compiler waited on.
+  auto run = [&](auto fdc, auto huc) {
+  constexpr bool FD = decltype(fdc)::value, HU = decltype(huc)::value;
   auto step = [&](int t, Elem& cur, Elem& nxt) {
     f32x4 carry = f32x4{0.f, 0.f, 0.f, 0.f};
-    bool up_known = false;      // the counters of slot t - 1 were seen complete (last step's request)
+    bool next_ready = false;
     if (t < T - 1) {
       // dG_{t+1} = index T - 2 - t: arrays dr, dz, dn r of both row groups, this wave's K quarter
       u32x4 v[2][3][NPQ];
+      const unsigned base = (unsigned)((T - 2 - t) % KS_D) * slot_bytes;
+      unsigned spins = 0;
       {
         // first the array a producer stores LAST (dn r: a third of the bytes per look), then the other two -- every dword of all three
         // is checked (visibility order between a wave's stores is likely, not promised)
-        const unsigned base = (unsigned)((T - 2 - t) % KS_D) * slot_bytes;
-        unsigned spins = 0;
         for (;;) {
 #pragma unroll
           for (int i = 0; i < NPQ; ++i) {
@@ -635,50 +561,146 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
             if (spins > (SPIN_LIMIT >> 2)) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
           }
         }
-        for (;;) {
+      }
+      // Order of the rest (vector memory returns in order: nothing slow may sit in front of a look at the own ring):
+      //   request dr, dz -> recurrent MFMAs of dn r (its registers are then free) -> request dn into them (layers that project) ->
+      //   check dr, dz (re-request while something is missing) -> their MFMAs (recurrent + projection) -> check dn -> its MFMAs ->
+      //   only then the drain / counters and the requests that go to HBM and across XCDs (saved gates, dY tile, counter snapshot).
+      f32x4 acc[2][2], accp[2][2];
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+      for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int i = 0; i < NPQ; ++i) {
-              const unsigned ao = (unsigned)g * arr_bytes;
-              v[0][g][i] = ks_load<16>(ring, in_off0 + (unsigned)i * 1024u, base + ao);
-              v[1][g][i] = ks_load<16>(ring, in_off1 + (unsigned)i * 1024u, base + ao);
+        for (int u2 = 0; u2 < 2; ++u2) { acc[r][u2] = f32x4{0.f, 0.f, 0.f, 0.f}; accp[r][u2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      auto load01 = [&]() {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int i = 0; i < NPQ; ++i) {
+            const unsigned ao = (unsigned)g * arr_bytes;
+            v[0][g][i] = ks_load<16>(ring, in_off0 + (unsigned)i * 1024u, base + ao);
+            v[1][g][i] = ks_load<16>(ring, in_off1 + (unsigned)i * 1024u, base + ao);
+          }
+      };
+      load01();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NPQ; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, v[r][2][i]);
+#pragma unroll
+          for (int u2 = 0; u2 < 2; ++u2) acc[r][u2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[u2][2][i], acc[r][u2], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      auto load3 = [&]() {      // (dn into the registers dn r has left)
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i) {
+          v[0][2][i] = ks_load<16>(ring, in_off0 + (unsigned)i * 1024u, base + 3u * arr_bytes);
+          v[1][2][i] = ks_load<16>(ring, in_off1 + (unsigned)i * 1024u, base + 3u * arr_bytes);
+        }
+      };
+      if (FD) load3();
+      __builtin_amdgcn_sched_barrier(0);
+      for (;;) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int i = 0; i < NPQ; ++i) { m = ks_max(m, v[0][g][i]); m = ks_max(m, v[1][g][i]); }
+        if (!__any(m > KS_MAXDATA)) break;
+        if ((++spins & 63u) == 0u) {
+          if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
+          if (spins > (SPIN_LIMIT >> 2)) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
+        }
+        load01();
+      }
+      WSTAMP(0)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, v[r][g][i]);
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+              acc[r][u2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w[u2][g][i], acc[r][u2], 0, 0, 0);
+              if (FD) accp[r][u2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w2[u2][g][i], accp[r][u2], 0, 0, 0);
             }
+          }
+      if (FD) {
+        for (;;) {      // (stored with dn r by the same instruction of each producer: normally there at the first look)
           unsigned m = 0u;
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int i = 0; i < NPQ; ++i) { m = ks_max(m, v[0][g][i]); m = ks_max(m, v[1][g][i]); }
+          for (int i = 0; i < NPQ; ++i) { m = ks_max(m, v[0][2][i]); m = ks_max(m, v[1][2][i]); }
           if (!__any(m > KS_MAXDATA)) break;
           if ((++spins & 63u) == 0u) {
             if (__hip_atomic_load(err, RLX_AGENT) != 0u) break;
             if (spins > (SPIN_LIMIT >> 2)) { __hip_atomic_store(err, 1u, RLX_AGENT); break; }
           }
+          load3();
         }
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, v[r][2][i]);
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) accp[r][u2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w2[u2][2][i], accp[r][u2], 0, 0, 0);
+          }
       }
       wave_drain();
       if (pending_x >= 0) { wave_bump<false>(cnt_x + pending_x, lane); pending_x = -1; }
       // progress for consumers OUTSIDE the launch (the gated weight-gradient GEMMs): every store of the steps > t is acknowledged
       if (prog) wave_bump<false>(prog, lane);
-      WSTAMP(0)
-      fetch(t - 1, nxt);
-      const bool up_ready = HU && t > 0 && t < T - 2 && __all(csnap >= (unsigned)G);     // (csnap: slot t - 1, requested one step ago)
-      if (HU) csnap = __hip_atomic_load(((lane & 1) ? cnt_up1 : cnt_up0) + (t > 2 ? t - 2 : 0), RLX_AGENT);     // (unconditional: no merge with an old value)
-      // (the top layer has no projection -- no second barrier between two products -- so it alternates the two partial buffers:
-      // a wave may start writing step t - 1's partials while a slower one still reads step t's)
-      const f32x4 acc = contract(v, w, (!HU && (t & 1)) ? part_q : part_p);
-      up_known = up_ready;
+      // csnap: the counter of slot t - 1 (this row group's dY tiles of the layer above), requested one step ago
+      const bool up_ready = HU && t > 0 && t < T - 2 && __all(csnap >= (unsigned)G);
+      if (HU) csnap = __hip_atomic_load(cnt_up + (t > 2 ? t - 2 : 0), RLX_AGENT);     // (unconditional: no merge with an old value)
+      next_ready = up_ready;
+      if (DB) fetch(t - 1, nxt, up_ready);
+      WSTAMP(3)
+      // ONE reduction for both: two partial buffers by step parity (nothing else separates one step's reads from the next step's writes)
+      float4* part = (t & 1) ? part_q : part_p;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+          const f32x4 c = acc[r][u2];
+          part[(wave * NT + r * 2 + u2) * 64 + lane] = float4{c[0], c[1], c[2], c[3]};
+          if (FD) { const f32x4 d = accp[r][u2]; part[(wave * NT + 4 + r * 2 + u2) * 64 + lane] = float4{d[0], d[1], d[2], d[3]}; }
+        }
+      ks_barrier();
+      WSTAMP(7)
+      const f32x4 rec = ks_reduce<NT>(part, rgl * 2 + us, lane);
+      if (FD && rg_live) {
+        // dY[layer - 1]_{t+1}, this wave's 16 x 16 tile: nn.GRU's dropout mask of out[layer - 1] (same Philox draws as the forward pass),
+        // then written through for the layer below; its counter moves at the next drain
+        f32x4 py = ks_reduce<NT>(part, 4 + rgl * 2 + us, lane);
+        if (DROP) {
+          float* td = tiles;
+          tile_put(td, py, j, q);
+          float4 v4 = ld4(td + (lane & 15) * WTP + 4 * kg);
+          const long long e = a.elem0 + ((long long)(t + 1) * B + (rrow < B ? rrow : 0)) * H + u0 + 4 * kg;
+          const float4 u = Philox::uniform4(a.seed[layer - 1], (uint64_t)(e >> 2), 2u);
+          v4.x = u.x >= a.drop_p ? v4.x * a.drop_scale : 0.f; v4.y = u.y >= a.drop_p ? v4.y * a.drop_scale : 0.f;
+          v4.z = u.z >= a.drop_p ? v4.z * a.drop_scale : 0.f; v4.w = u.w >= a.drop_p ? v4.w * a.drop_scale : 0.f;
+          *reinterpret_cast<float4*>(td + (lane & 15) * WTP + 4 * kg) = v4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) py[i] = td[(4 * q + i) * WTP + j];
+        }
+        ks_store<16>(dyr, dy_tile, (unsigned)(t + 1) * dy_slot, __builtin_bit_cast(u32x4, py));
+        pending_x = t + 1;
+      }
 #ifdef B2T_WAVE_TIMING
-      asm volatile("s_nop 0" :: "v"(acc[0]));
+      asm volatile("s_nop 0" :: "v"(rec[0]));
 #endif
       WSTAMP(1)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) carry[i] = acc[i] + dzterm[i];
+      for (int i = 0; i < 4; ++i) carry[i] = rec[i] + dzterm[i];
     } else {
       wave_drain();
       if (prog) wave_bump<false>(prog, lane);
-      ks_barrier();      // (no product this step: keeps the two projections on either side from meeting in their partial buffer)
-      fetch(t - 1, nxt);
+      if (DB) fetch(t - 1, nxt, false);
       if (a.dh_last[layer]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (live[i]) carry[i] = a.dh_last[layer][(long long)(m0 + 4 * q + i) * H + unit];
@@ -690,10 +712,16 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       return;
     }
     if (rg_live) {
+      f32x4 dy = cur.dyt;
+      if (HU && !cur.ok) {      // the layer above was less than two steps ahead when this step's dY was asked for: wait, load it now
+        wave_wait<false>(cnt_up + t, (unsigned)G, err, lane);
+        dy = load_dy(t);
+      }
+      WSTAMP(5)
       f32x4 g0, g1, g2, g3;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float d = (HU ? dy[i] : cur.dyt[i]) + carry[i];
+        const float d = dy[i] + carry[i];
         const float dn = d * (1.0f - cur.z[i]);
         const float dz = d * (cur.hprev[i] - cur.nv[i]);
         const float dn_pre = dn * (1.0f - cur.nv[i] * cur.nv[i]);
@@ -715,18 +743,11 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       ks_store<0>(ring, vo, arm, ks_sentinel());
       ks_store<0>(ring, vo, arm + 2u * arr_bytes, ks_sentinel());
       WSTAMP(2)
-      if (feeds) {
-        const unsigned bx = (unsigned)t * slot_bytes;
-        ks_store<16>(ringx, vo, bx, f0);
-        ks_store<16>(ringx, vo, bx + 2u * arr_bytes, f1);
-        pending_x = t;
-      }
       if (rrow < B) {
         float* dgl = a.dG[layer] + (long long)t * B * 4 * H;
         const unsigned off = (unsigned)(((long long)rrow * 4 * H + u0 + 4 * kg) * 4);
-        // written THROUGH only for readers inside the sweep's lifetime (gated GEMMs, flags bit 2): four 4 KB write-through stores per wave
-        // and step kept the wave's memory queue busy for ~13 k cycles -- the next load could not issue (NOTES.md R6.2); otherwise
-        // ordinary stores (the kernel's end makes them visible)
+        // written THROUGH only for readers inside the sweep's lifetime (gated GEMMs, flags bit 2); otherwise ordinary stores (the kernel's
+        // end makes them visible)
         if (a.flags & 4) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) store_f4<16>(dgl, off + (unsigned)g * (unsigned)H * 4u, ld4(tiles + g * WTILE_F + (lane & 15) * WTP + 4 * kg));
@@ -737,14 +758,19 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
       }
       WSTAMP(4)
     }
-    if (HU && t > 0) project(t - 1, up_known);
+    if (!DB) fetch(t - 1, nxt, next_ready);
   };
-  for (int t = T - 1; t >= -1; t -= 2) {
-    step(t, ea, eb);
-    if (t - 1 >= -1) step(t - 1, eb, ea);
+  if (DB) {
+    for (int t = T - 1; t >= -1; t -= 2) {
+      step(t, ea, eb);
+      if (t - 1 >= -1) step(t - 1, eb, ea);
+    }
+  } else {
+    for (int t = T - 1; t >= -1; --t) step(t, ea, ea);
   }
   };
-  if (has_up) run(std::true_type{}); else run(std::false_type{});
+  if (feeds) { if (has_up) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+  else { if (has_up) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
 
   wave_drain();
   if (pending_x >= 0) wave_bump<false>(cnt_x + pending_x, lane);
