@@ -562,6 +562,11 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
           }
         }
       }
+      // (nothing of this wave is in flight here -- the look above was waited for in full: the drain is free)
+      wave_drain();
+      if (pending_x >= 0) { wave_bump<false>(cnt_x + pending_x, lane); pending_x = -1; }
+      // progress for consumers OUTSIDE the launch (the gated weight-gradient GEMMs): every store of the steps > t is acknowledged
+      if (prog) wave_bump<false>(prog, lane);
       // Order of the rest (vector memory returns in order: nothing slow may sit in front of a look at the own ring):
       //   request dr, dz -> recurrent MFMAs of dn r (its registers are then free) -> request dn into them (layers that project) ->
       //   check dr, dz (re-request while something is missing) -> their MFMAs (recurrent + projection) -> check dn -> its MFMAs ->
@@ -649,10 +654,6 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
             for (int u2 = 0; u2 < 2; ++u2) accp[r][u2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w2[u2][2][i], accp[r][u2], 0, 0, 0);
           }
       }
-      wave_drain();
-      if (pending_x >= 0) { wave_bump<false>(cnt_x + pending_x, lane); pending_x = -1; }
-      // progress for consumers OUTSIDE the launch (the gated weight-gradient GEMMs): every store of the steps > t is acknowledged
-      if (prog) wave_bump<false>(prog, lane);
       // csnap: the counter of slot t - 1 (this row group's dY tiles of the layer above), requested one step ago
       const bool up_ready = HU && t > 0 && t < T - 2 && __all(csnap >= (unsigned)G);
       if (HU) csnap = __hip_atomic_load(cnt_up + (t > 2 ? t - 2 : 0), RLX_AGENT);     // (unconditional: no merge with an old value)
