@@ -204,7 +204,9 @@ def test_bf16_mode_phoneme_error_rate_same_weights_0p1_percent_trained_0p3_perce
     (a few fp32-vs-fp32 distances), and (a), which has no trajectory in it, stays the sharp check."""
     import b2t_ops as ops
     from rnn_trainer import BrainToTextDecoder_Trainer
-    N_STEPS = 1600       # to the plateau of this task (PER ~10.7 %: the templates overlap); measured |difference| 0.02 % there, 0.14 % at 1200
+    # to the plateau of this task (PER ~10.7 %: the templates overlap); measured |difference| 0.02 % there, 0.14 % at 1200.  The host-bound
+    # trainer loop makes this the suite's longest test (100-200 s by box): 1200 steps by default, the full 1600 with B2T_TEST_FULL=1
+    N_STEPS = 1600 if os.environ.get("B2T_TEST_FULL") else 1200
     was = ops.AMP["on"]
     try:
         res = {}
