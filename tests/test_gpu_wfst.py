@@ -647,7 +647,10 @@ def test_wfst_search_matches_oracle_on_random_graphs_and_options(seed):
             compare_lists(fin[u], R, tag)
             Rs = W.CtcWfstBeamSearch(g, cfg_of(o, "sequential"))
             Rs.search(lps[u]); Rs.finalize_search()
-            assert _first_diff(fin[u], Rs) != 0, tag + ": best hypothesis differs from the reference-order oracle's"
+            d = _first_diff(fin[u], Rs)
+            assert d != 0, tag + ": best hypothesis differs from the reference-order oracle's"
+            if d > 0:      # (not an error: where the data-parallel and the reference-order cut-off rules part in this list -- printed with -s)
+                print(f"cut-off rules part at rank {d} of {len(fin[u])}: {tag}")
 
 
 
