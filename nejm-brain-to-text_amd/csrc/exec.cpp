@@ -1062,6 +1062,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   }
   const bool gi0_chain = c.bf16_gemm && In0 >= 2048 && nc > 1 && getenv("B2T_GI0_CHAIN") && atoi(getenv("B2T_GI0_CHAIN")) == 1;   // opt-in: measured slower
   int t_gi0_prev = -1;
+  int t_hfin = -1;      // wavefront: the task that copies the final states out
   int t_gi_l0c[MAXC];   // wavefront: layer 0's projection task of every chunk (the only projections left)
   for (int i = 0; i < MAXC; ++i) t_gi_l0c[i] = -1;
   for (int l = 0; l < L; ++l) {
@@ -1159,11 +1160,14 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
           a.cnt = w.wv_cnt_f; a.err = reinterpret_cast<unsigned*>(sync_of(0));
           a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = (long long)t0 * B * H;
           c.call(gru_wave_fwd(a, ss));
-          if (t1 == Tp)
-            for (int k = 0; k < L && !c.rc; ++k)
-              c.call(check_hip(hipMemcpyAsync(hidden + (size_t)k * B * H, w.out[k] + (long long)Tp * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, ss), "model_forward: final state"));
         });
         for (int k = 0; k < L; ++k) { t_sw[k][ci] = t_ws; if (ci == 0) P.dep(t_ws, t_init[k]); }
+        // the final states: a task of its own (the five copies, ~40 us, sat between the sweep and the head on the sweep's queue)
+        if (t1 == Tp)
+          t_hfin = P.add("hfinal", 40.f, Q_ANY, {t_ws}, [&](hipStream_t ss) {
+            for (int k = 0; k < L && !c.rc; ++k)
+              c.call(check_hip(hipMemcpyAsync(hidden + (size_t)k * B * H, w.out[k] + (long long)Tp * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, ss), "model_forward: final state"));
+          });
         continue;
       }
       // 3. recurrent sweep over the chunk, continuing from out[l][t0] = h_{t0-1}
@@ -1213,7 +1217,7 @@ extern "C" int b2t_model_forward(b2t_exec* ex, const b2t_model_t* prm, const b2t
   // the caller's stream leaves ordered after everything: the head transitively depends on every sweep and GEMM except
   // the last chunks of the lower layers' sweeps (their final hidden state)
   {
-    const int t_end = P.add("end", 0.f, Q_MAIN, {t_head}, nullptr);
+    const int t_end = P.add("end", 0.f, Q_MAIN, {t_head, t_hfin}, nullptr);
     for (int l = 0; l + 1 < L; ++l) P.dep(t_end, t_sw[l][nc - 1]);
   }
   run_plan(c, P, c.nq, c.qs);

@@ -6,7 +6,7 @@ cat > /tmp/ab.py <<'PY'
 import os, sys
 sys.path.insert(0, "tools"); sys.path.insert(0, "nejm-brain-to-text_amd"); sys.path.insert(0, ".")
 import bench_secondary as bs
-for shape, ks, dirs in (("c2", "1", "auto"), ("c2", "1", "f"), ("c2", "1", "auto")):
+for shape, ks, dirs in (("c2", "1", "auto"), ("c3", "1", "auto"), ("c2", "1", "auto"), ("c3", "1", "auto")):
     os.environ["B2T_WAVE_KS"] = ks; os.environ["B2T_WAVE_DIRS"] = dirs
     try:
         r = bs.train_ms(shape, True)
