@@ -1340,6 +1340,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   auto cb = [&](int id, hipStream_t s) { if (bucket_cb && !c.rc) bucket_cb(user, id, reinterpret_cast<void*>(s)); };
 
   const bool wave = wave_pass(prm, p, mode) && w.wv_cnt_b;   // round 6: every layer's backward sweep in ONE launch (gru_wave.hip), dX of the layers >= 1 inside it
+  // K-split form of the wavefront: the sweep reads the weight matrices as they are -- no transposes (and no queue hop) in front of it
+  const bool ks_direct = wave && gru_wave_ks(L, Tp, B, H);
   int chunks[MAXC][2];
   const int nc = make_chunks(Tp, p->chunks_bwd > 0 ? p->chunks_bwd : p->chunks, chunks);
   c.exact_k = nc > 1;
@@ -1382,7 +1384,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   // W_hh^T for the backward sweeps depends on the parameters only
   int t_wt[MAXL];
   for (int l = 0; l < L; ++l)
-    t_wt[l] = P.add("whh_t", 8.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
+    t_wt[l] = ks_direct ? -1 : P.add("whh_t", 8.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
       c.call(b2t_transpose_f32(prm->w_hh[l], w.whh_t[l], 3 * H, H, reinterpret_cast<void*>(s)));
     });
 
@@ -1390,7 +1392,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
   int t_wit[MAXL];
   for (int l = 0; l < L; ++l) {
     t_wit[l] = -1;
-    if (wave && l > 0)
+    if (wave && l > 0 && !ks_direct)
       t_wit[l] = P.add("wih_t", 8.f, Q_ANY, {t_start}, [&, l](hipStream_t s) {
         c.call(b2t_transpose_f32(prm->w_ih[l], w.wih_t[l], 3 * H, H, reinterpret_cast<void*>(s)));
       });
@@ -1484,7 +1486,8 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     a.L = L; a.T = n; a.B = B; a.H = H; a.dY_top = w.dY[L - 1] + (long long)t0 * B * H;
     const bool drop = p->rnn_drop > 0.f && L > 1;
     for (int k = 0; k < L; ++k) {
-      a.w_hh_t[k] = w.whh_t[k]; a.w_ih_t[k] = w.wih_t[k]; a.h_init[k] = w.out[k] + (long long)t0 * B * H; a.out[k] = w.out[k] + (long long)(1 + t0) * B * H;
+      a.w_hh_t[k] = ks_direct ? prm->w_hh[k] : w.whh_t[k]; a.w_ih_t[k] = ks_direct ? prm->w_ih[k] : w.wih_t[k];
+      a.h_init[k] = w.out[k] + (long long)t0 * B * H; a.out[k] = w.out[k] + (long long)(1 + t0) * B * H;
       a.reserve[k] = w.res[k] + (long long)t0 * B * 4 * H; a.dG[k] = w.dG[k] + (long long)t0 * B * 4 * H;
       a.ring[k] = w.wv_ring_b[k]; a.ringx[k] = w.wv_ringx_b[k]; a.seed[k] = mix_seed(p->seed, 101 + k);
       a.dh_last[k] = (whole || ci == nc - 1) ? (dhidden ? dhidden + (size_t)k * B * H : nullptr) : w.carry[k] + (size_t)((ci + 1) % 2) * B * H;
@@ -1492,7 +1495,7 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
     }
     a.cnt = w.wv_cnt_b; a.err = reinterpret_cast<unsigned*>(sync_of(0));
     // gated: counters cleared by wbclear (the gates are already polling), dG written through + progress words
-    a.flags = whole && gated ? (2 | 4) : 0; a.prog = whole && gated ? w.wv_cnt_b : nullptr;
+    a.flags = (whole && gated ? (2 | 4) : 0) | (ks_direct ? 8 : 0); a.prog = whole && gated ? w.wv_cnt_b : nullptr;
     a.drop_p = drop ? p->rnn_drop : 0.f; a.drop_scale = drop ? 1.0f / (1.0f - p->rnn_drop) : 1.f; a.elem0 = (long long)t0 * B * H;
     c.call(gru_wave_bwd(a, ss));
   };
@@ -1509,14 +1512,14 @@ extern "C" int b2t_model_backward(b2t_exec* ex, const b2t_model_t* prm, const b2
           if (l == L - 1) {
             t_wbc[ci] = P.add("wbsweep", 60.f + (n + 2 * L) * est_step_us(1) * hs, Q_MAIN, {ci == nc - 1 ? t_top : t_wbc[ci + 1]},
                               [&, ci, t0, n](hipStream_t ss) { wave_sweep(ss, ci, t0, n, false); });
-            if (ci == nc - 1) for (int k = 0; k < L; ++k) { P.dep(t_wbc[ci], t_wt[k]); P.dep(t_wbc[ci], t_wit[k]); }
+            if (ci == nc - 1 && !ks_direct) for (int k = 0; k < L; ++k) { P.dep(t_wbc[ci], t_wt[k]); P.dep(t_wbc[ci], t_wit[k]); }
           }
           t_bs[l][ci] = t_wbc[ci];
         } else {
         if (l == L - 1 && ci == nc - 1) {
           t_wclear = P.add("wbclear", 5.f, Q_MAIN, {t_start}, [&](hipStream_t ss) { c.call(gru_wave_bwd_clear(w.wv_cnt_b, L, Tp, B, ss)); });
           t_wb = P.add("wbsweep", 60.f + (Tp + 2 * L) * est_step_us(1) * hs, Q_MAIN, {t_top, t_wclear}, [&](hipStream_t ss) { wave_sweep(ss, 0, 0, Tp, true); });
-          for (int k = 0; k < L; ++k) { P.dep(t_wb, t_wt[k]); P.dep(t_wb, t_wit[k]); }
+          if (!ks_direct) for (int k = 0; k < L; ++k) { P.dep(t_wb, t_wt[k]); P.dep(t_wb, t_wit[k]); }
         }
         t_bs[l][ci] = t_wb;
         }

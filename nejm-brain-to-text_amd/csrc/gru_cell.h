@@ -118,13 +118,14 @@ struct WaveBwdArgs {
 };
 bool gru_wave_ok(int L, int T, int B, int H, const char** why);
 bool gru_wave_local(int L, int H);
+bool gru_wave_ks(int L, int T, int B, int H);      // the K-split form serves this shape on this device
 bool gru_xcd_dispatch_ok();
 size_t gru_wave_ring_bytes_fwd(int T, int B, int H);
 size_t gru_wave_ring_bytes_bwd(int T, int B, int H);
 size_t gru_wave_cnt_words_fwd(int L, int T, int B);
 size_t gru_wave_cnt_words_bwd(int L, int T, int B);
 int gru_wave_fwd(const WaveFwdArgs& a, hipStream_t s);
-int gru_wave_bwd(const WaveBwdArgs& a, hipStream_t s);   // a.flags bit 1: counters already cleared (gru_wave_bwd_clear); bit 2: dG written through (readers while the sweep runs)
+int gru_wave_bwd(const WaveBwdArgs& a, hipStream_t s);   // a.flags bit 1: counters already cleared (gru_wave_bwd_clear); bit 2: dG written through (readers while the sweep runs); bit 3: K-split form, w_hh_t / w_ih_t are the untransposed [3H][H] matrices
 int gru_wave_bwd_clear(unsigned* cnt, int L, int T, int B, hipStream_t s);
 int gru_wave_gate(unsigned* cnt, int layer, int t0, int T, int B, int H, unsigned* err, hipStream_t s);
 

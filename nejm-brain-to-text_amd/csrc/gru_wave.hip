@@ -928,6 +928,10 @@ int gru_wave_gate(unsigned* cnt, int layer, int t0, int T, int B, int H, unsigne
 int gru_wave_bwd(const WaveBwdArgs& a_in, hipStream_t s) {
   WaveBwdArgs a = a_in;
   a.flags = wave_flags() | (a_in.flags & 4);     // bit 2: write dG through (consumers inside the sweep's lifetime: gated GEMMs)
+  if (a_in.flags & 8) {      // bit 3 (K-split form only): w_hh_t / w_ih_t point at the UNtransposed matrices
+    if (!gru_wave_ks(a.L, a.T, a.B, a.H)) { set_error("gru_wave_bwd: untransposed weights need the K-split form"); return 2; }
+    a.flags |= 8;
+  }
   const char* why = nullptr;
   if (!gru_wave_ok(a.L, a.T, a.B, a.H, &why)) { set_error("gru_wave_bwd: unsupported shape L=%d T=%d B=%d H=%d (%s)", a.L, a.T, a.B, a.H, why); return 2; }
   const bool drop = a.drop_p > 0.f && a.L > 1, loc = gru_wave_local(a.L, a.H);

@@ -454,10 +454,21 @@ __global__ __launch_bounds__(256, 1) void gru_ks_bwd_kernel(const WaveBwdArgs a)
         const float* t2 = (feeds ? a.w_ih_t[layer] : a.w_hh_t[layer]) + col * 3 * H;      // (layer 0 projects nothing: any valid matrix, masked to zero)
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-          const float* s1 = t1 + (long long)g * H + k0;
-          const float* s2 = t2 + (long long)g * H + k0;
-          w[u2][g][i] = cvt8(ld4(s1), ld4(s1 + 4));
-          w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(ld4(s2), ld4(s2 + 4), feeds));
+          float4 h0, h1, i0, i1;
+          if (a.flags & 8) {
+            // the matrices as the model holds them ([3H][H], flags bit 3): element (k, col) at k H + col -- eight strided loads per
+            // fragment, once per launch, instead of a transpose kernel per layer in front of the sweep (and the queue hop behind it)
+            const float* m1 = a.w_hh_t[layer] + ((long long)g * H + k0) * H + col;
+            const float* m2 = (feeds ? a.w_ih_t[layer] : a.w_hh_t[layer]) + ((long long)g * H + k0) * H + col;
+            h0 = float4{m1[0], m1[H], m1[2 * H], m1[3 * H]}; h1 = float4{m1[4 * H], m1[5 * H], m1[6 * H], m1[7 * H]};
+            i0 = float4{m2[0], m2[H], m2[2 * H], m2[3 * H]}; i1 = float4{m2[4 * H], m2[5 * H], m2[6 * H], m2[7 * H]};
+          } else {
+            const float* s1 = t1 + (long long)g * H + k0;
+            const float* s2 = t2 + (long long)g * H + k0;
+            h0 = ld4(s1); h1 = ld4(s1 + 4); i0 = ld4(s2); i1 = ld4(s2 + 4);
+          }
+          w[u2][g][i] = cvt8(h0, h1);
+          w2[u2][g][i] = __builtin_bit_cast(bf16x8, masked8(i0, i1, feeds));
           asm volatile("" : "+a"(w[u2][g][i]));
           asm volatile("" : "+a"(w2[u2][g][i]));
         }
